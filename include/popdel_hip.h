@@ -1,0 +1,158 @@
+/*
+ * popdel_hip.h -- C ABI of the MI355X joint-calling backend (libpopdel_hip.so).
+ *
+ * This is the drop-in boundary for PopDel's `popdel call` hot path. The reference has no
+ * FFI; its seam is the C++ call
+ *     bool genotype_deletion_window(String<Call>&, const ChromosomeProfile&, const TRGs&,
+ *                                   PopDelCallParameters&)
+ * (reference popdel_call/genotype_deletion_popdel_call.h:536-539) invoked once per 30-bp
+ * window from processSegment() (reference workflow_popdel.h:42-47, :73-80). A per-window
+ * call cannot feed a GPU, so the boundary is moved up one loop level: one call per
+ * *segment* (all windows walked by one processSegment() invocation). Everything the window
+ * loop reads from ChromosomeProfile is handed over as plain arrays, everything it appends
+ * to String<Call> comes back as plain arrays.
+ *
+ * Conventions: all functions return 0 on success, non-zero on error (pd_last_error() gives
+ * text); no exceptions cross the boundary; a context is bound to one GPU and calls on one
+ * context must be serialised by the caller. Pointers passed in are caller-owned host
+ * memory unless stated otherwise; pd_calls is callee-owned until pd_calls_free().
+ */
+#ifndef POPDEL_HIP_H_
+#define POPDEL_HIP_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PD_ABI_VERSION 1
+
+/* One read group after start-up conditioning.
+ * Replaces: `Histogram` (reference insert_histogram_popdel.h:19-43) after processHistogram()
+ * (:974-986), plus the per-read-group entries of PopDelCallParameters::maxLoad and
+ * ::minInitDelLengths (reference parameter_parsing_popdel_call.h:153,177). */
+typedef struct pd_readgroup
+{
+    uint32_t      median;               /* Histogram::median                       */
+    uint32_t      read_length;          /* Histogram::readLength                   */
+    double        stddev;               /* Histogram::stddev                       */
+    double        min_prob;             /* Histogram::min_prob                     */
+    int32_t       hist_offset;          /* Histogram::offset                       */
+    uint32_t      hist_len;             /* length(Histogram::values)               */
+    const double *hist_values;          /* conditioned densities, hist_len entries */
+    uint32_t      lower_quantile_dist;  /* Histogram::lowerQuantileDist            */
+    uint32_t      upper_quantile_dist;  /* Histogram::upperQuantileDist            */
+    uint32_t      max_load;             /* PopDelCallParameters::maxLoad[rg]       */
+    uint32_t      min_init_del_len;     /* PopDelCallParameters::minInitDelLengths[rg] */
+} pd_readgroup;
+
+/* Scalar calling parameters read inside the hot path.
+ * Replaces: the members of PopDelCallParameters used by genotype_deletion_window()
+ * (reference genotype_deletion_popdel_call.h:548,583,598,690,692,723). */
+typedef struct pd_config
+{
+    uint32_t iterations;              /* params.iterations (default 15)            */
+    uint32_t min_len;                 /* params.minLen                             */
+    double   min_likelihood_ratio;    /* params.minimumLikelihoodRatio             */
+    double   min_sample_fraction;     /* params.minSampleFraction                  */
+    int32_t  somatic;                 /* params.somatic (-C)                       */
+    int32_t  window_wise_output;      /* params.windowWiseOutput (-n)              */
+} pd_config;
+
+/* One segment = the windows walked by one processSegment() call.
+ * Replaces: the ChromosomeProfile contents read by the window loop (activeReads, startProfiles,
+ * currentPos; reference profile_structure_popdel_call.h:1035-1060). A read pair that is a member
+ * of ChromosomeProfile::activeReads[rg] for the windows with index on <= w < off appears as one
+ * "pair instance" {dev, start, on, off}. The host side derives on/off by running the
+ * reference's window state machine, so the loader's segment-border behaviour stays host-side.
+ * Instances of one read group are stored contiguously, ordered by non-decreasing `on`. */
+typedef struct pd_segment
+{
+    uint32_t        first_window_pos;  /* ChromosomeProfile::currentPos of window 0          */
+    uint32_t        n_windows;         /* number of genotype_deletion_window() calls         */
+    uint32_t        window_shift;      /* params.windowShift (30)                            */
+    uint32_t        n_readgroups;      /* must equal the context's read-group count          */
+    const uint64_t *rg_offsets;        /* n_readgroups + 1 offsets into the pair arrays      */
+    const int32_t  *pair_dev;          /* ChromosomeProfileStartEntry::insertSizeDeviation   */
+    const uint32_t *pair_start;        /* ChromosomeProfileStartEntry::startPos              */
+    const uint32_t *pair_on;           /* first window index in which the pair is active     */
+    const uint32_t *pair_off;          /* first window index in which it is no longer active */
+} pd_segment;
+
+/* Calls of one segment, in the order the reference appends them to String<Call>
+ * (window ascending, initial candidate length ascending within a window).
+ * Replaces: `Call` (reference utils_popdel.h:57-124) as filled at
+ * genotype_deletion_popdel_call.h:692-724. Per-sample arrays are [n_calls][n_samples][k]. */
+typedef struct pd_calls
+{
+    uint32_t  n_calls;
+    uint32_t  n_samples;
+    uint32_t *initial_length;     /* Call::initialLength   */
+    uint32_t *iterations;         /* Call::iterations      */
+    uint32_t *deletion_length;    /* Call::deletionLength  */
+    double   *likelihood_ratio;   /* Call::likelihoodRatio */
+    double   *frequency;          /* Call::frequency       */
+    uint32_t *window_position;    /* Call::windowPosition  */
+    uint32_t *position;           /* Call::position        */
+    uint32_t *end_position;       /* Call::endPosition     */
+    uint8_t  *filter;             /* Call::filter          */
+    uint32_t *pl;                 /* Call::gtLikelihoods, 3 per sample (ref, het, hom)              */
+    uint32_t *lad;                /* Call::lads, 3 per sample                                       */
+    uint32_t *dad;                /* Call::dads, 5 per sample (ref, both, between, alt, right)      */
+    uint32_t *first_last;         /* Call::firstLast, 2 per sample                                  */
+} pd_calls;
+
+/* Per-window stage-1 results of the last collected segment (diagnostics / parity tests).
+ * q3[w * n_samples + s] is the value upperHalfMedian() returned for sample s in window w,
+ * flags bit0 = lowCoverageSamples[s], bit1 = sample contributed a Q3 value.
+ * Replaces nothing in the reference's interface; mirrors the locals of
+ * initialize_deletion_lengths() (reference genotype_deletion_popdel_call.h:33-57). */
+typedef struct pd_stage1_view
+{
+    uint32_t       n_windows;
+    uint32_t       n_samples;
+    const int32_t *q3;
+    const uint8_t *flags;
+} pd_stage1_view;
+
+typedef struct pd_ctx pd_ctx;
+
+/* Create a calling context on GPU `device`.
+ * sample_rg_offsets has n_samples + 1 entries; sample s owns read groups
+ * [sample_rg_offsets[s], sample_rg_offsets[s+1]) (reference TRGs, utils_popdel.h:21-22; read groups
+ * of one profile file are numbered consecutively, insert_histogram_popdel.h:1029-1037).
+ * Replaces: PopDelCallParameters + String<Histogram> after loadAndCalculateParameters()
+ * (reference parameter_calculation_popdel_call.h:160-204). */
+int pd_ctx_create(const pd_config *cfg, const pd_readgroup *rgs, uint32_t n_readgroups,
+                  const uint32_t *sample_rg_offsets, uint32_t n_samples, int device, pd_ctx **out);
+
+void pd_ctx_destroy(pd_ctx *ctx);
+
+/* Stage a segment into HBM and enqueue the whole window loop for it. Returns a ticket.
+ * Replaces: the `while (!profilesAtEnd) genotype_deletion_window(...)` loop of processSegment()
+ * (reference workflow_popdel.h:42-47). */
+int pd_segment_submit(pd_ctx *ctx, const pd_segment *seg, uint64_t *ticket);
+
+/* Wait for a ticket and hand back its calls (callee-owned; release with pd_calls_free).
+ * Replaces: reading `String<Call> calls` after the window loop (reference workflow_popdel.h:48). */
+int pd_segment_collect(pd_ctx *ctx, uint64_t ticket, pd_calls **out);
+
+void pd_calls_free(pd_calls *calls);
+
+/* Stage-1 values of the most recently collected segment; valid until the next submit. */
+int pd_stage1_last(pd_ctx *ctx, pd_stage1_view *out);
+
+/* Text of the last error on this context (or of the last failed pd_ctx_create if ctx == NULL). */
+const char *pd_last_error(const pd_ctx *ctx);
+
+/* Name of the implementation behind the ABI ("hip-gfx950" for the product library). */
+const char *pd_backend_name(void);
+
+int pd_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POPDEL_HIP_H_ */

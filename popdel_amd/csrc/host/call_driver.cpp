@@ -1,0 +1,654 @@
+#include "call_driver.h"
+
+#include <cstring>
+#include <iostream>
+#include <memory>
+
+#include "popdel_hip.h"
+#include "profile_io.h"
+
+namespace pdh {
+namespace {
+
+constexpr unsigned kNoPos = std::numeric_limits<unsigned>::max();
+
+struct Coord
+{
+    std::string contig;
+    unsigned pos = 0;
+};
+
+struct WindowCursor
+{
+    Coord current;
+    Coord next;
+    Coord nextChrom{"", kNoPos};
+};
+
+bool allTrue(const std::vector<char> & v)
+{
+    for (char b : v)
+        if (!b)
+            return false;
+    return true;
+}
+
+bool advanceRoi(CallParams & p)
+{
+    ++p.nextRoi;
+    return p.nextRoi != p.allRois.size();
+}
+
+unsigned contigRank(const std::string & name, const CallParams & p)
+{
+    unsigned i = 0;
+    for (size_t r = p.nextRoi; r < p.allRois.size(); ++r, ++i)
+        if (name == p.allRois[r].seqName)
+            return i;
+    return kNoPos;
+}
+
+// true if `a` does not come after `b` in ROI order.
+bool lowerCoord(const Coord & a, const Coord & b, const CallParams & p)
+{
+    unsigned ra = contigRank(a.contig, p), rb = contigRank(b.contig, p);
+    if (ra != rb)
+        return ra < rb;
+    return a.pos <= b.pos;
+}
+
+// Align the ROI with the next candidate window or vice versa (load_profile_popdel_call.h:220-234).
+bool adaptRegions(Coord & cand, Region & roi, unsigned w)
+{
+    if (cand.contig != roi.seqName)
+        return false;
+    if (static_cast<int>(cand.pos) >= roi.endPos)
+        return false;
+    if (static_cast<int>(cand.pos + w - 1) == roi.beginPos)
+        return true;
+    if (static_cast<int>(cand.pos + w - 1) > roi.beginPos)
+        roi.beginPos = static_cast<int32_t>(cand.pos);
+    else
+        cand.pos += ((roi.beginPos - cand.pos) / w) * w;
+    return true;
+}
+
+class CallRun
+{
+public:
+    CallRun(CallParams & p, SegmentObserver * obs) : p_(p), observer_(obs) {}
+    ~CallRun()
+    {
+        if (ctx_)
+            pd_ctx_destroy(ctx_);
+    }
+    int run();
+
+private:
+    void createBackend();
+    void jumpToRoi(ProfileFile & f, unsigned fileNum);
+    bool goNextRoi(ProfileFile & f, unsigned fileNum);
+    bool goNextRegion();
+    Coord firstWindowCoordinate();
+    bool firstWindowOnNextRoi(Coord & minCoord);
+    bool checkAndSwitch(const std::vector<unsigned> & rg, unsigned beginPos);
+    void addRecords(const std::vector<unsigned> & rg, const ProfileWindow & win);
+    unsigned readTillRoi(ByteSource & src, ProfileWindow & window, const std::vector<std::string> & contigNames,
+                         Coord & coordinate, const std::vector<unsigned> & rg, const Region & roi);
+    unsigned readSegment(ByteSource & src, const std::string & fileName, const std::vector<unsigned> & rg,
+                         const std::vector<std::string> & contigNames, Coord & coordinate, const Region & roi);
+    bool processSegmentCode(unsigned i, unsigned code);
+    void processSegment();
+    void flushPending();
+    bool finalizeRoi();
+    void markRoiComplete(unsigned i);
+
+    CallParams & p_;
+    SegmentObserver * observer_;
+    pd_ctx * ctx_ = nullptr;
+    std::unique_ptr<ChromProfile> profile_;
+    std::unique_ptr<VcfOutput> vcf_;
+    WindowCursor windows_;
+    std::vector<char> finishedFiles_, finishedRois_;
+    std::vector<Coord> nextCandidate_;
+    unsigned nextReadPos_ = kNoPos;
+    // one segment in flight on the device while the next one is loaded
+    bool pending_ = false;
+    uint64_t pendingTicket_ = 0;
+    std::string pendingContig_;
+};
+
+void CallRun::createBackend()
+{
+    std::vector<pd_readgroup> rgs(p_.histograms.size());
+    for (size_t i = 0; i < rgs.size(); ++i)
+    {
+        const InsertHistogram & h = p_.histograms[i];
+        pd_readgroup & r = rgs[i];
+        r.median = h.median;
+        r.read_length = h.readLength;
+        r.stddev = h.stddev;
+        r.min_prob = h.minProb;
+        r.hist_offset = h.offset;
+        r.hist_len = static_cast<uint32_t>(h.values.size());
+        r.hist_values = h.values.data();
+        r.lower_quantile_dist = h.lowerQuantileDist;
+        r.upper_quantile_dist = h.upperQuantileDist;
+        r.max_load = p_.maxLoad[i];
+        r.min_init_del_len = p_.minInitDelLengths[i];
+    }
+    std::vector<uint32_t> offsets(p_.rgs.size() + 1, 0);
+    for (size_t s = 0; s < p_.rgs.size(); ++s)
+    {
+        // read groups of one file are numbered consecutively
+        for (size_t k = 0; k < p_.rgs[s].size(); ++k)
+            if (p_.rgs[s][k] != offsets[s] + k)
+                throw ProfileError("[PopDel] Internal error: read groups of a sample are not contiguous.");
+        offsets[s + 1] = offsets[s] + static_cast<uint32_t>(p_.rgs[s].size());
+    }
+    pd_config cfg;
+    std::memset(&cfg, 0, sizeof(cfg));
+    cfg.iterations = p_.iterations;
+    cfg.min_len = p_.minLen;
+    cfg.min_likelihood_ratio = p_.minimumLikelihoodRatio;
+    cfg.min_sample_fraction = p_.minSampleFraction;
+    cfg.somatic = p_.somatic ? 1 : 0;
+    cfg.window_wise_output = p_.windowWiseOutput ? 1 : 0;
+    int device = 0;
+    if (const char * d = getenv("POPDEL_DEVICE"))
+        device = atoi(d);
+    if (pd_ctx_create(&cfg, rgs.data(), static_cast<uint32_t>(rgs.size()), offsets.data(),
+                      static_cast<uint32_t>(p_.rgs.size()), device, &ctx_) != 0)
+        throw ProfileError(std::string("[PopDel] Could not initialise the genotyping backend: ") + pd_last_error(nullptr));
+}
+
+void CallRun::jumpToRoi(ProfileFile & f, unsigned fileNum)
+{
+    unsigned idx = p_.representativeContigs ? 0 : fileNum;
+    const Region & roi = p_.allRois[p_.nextRoi];
+    f.jumpToRegion(p_.contigNames[idx], p_.contigLengths[idx], p_.indexRegionSizes[idx], roi.seqName, roi.beginPos);
+}
+
+bool CallRun::goNextRoi(ProfileFile & f, unsigned fileNum)
+{
+    if (allTrue(finishedRois_))
+    {
+        if (!advanceRoi(p_))
+            return false;
+        for (char & b : finishedRois_)
+            b = 0;
+    }
+    jumpToRoi(f, fileNum);
+    return true;
+}
+
+bool CallRun::goNextRegion()
+{
+    while (!adaptRegions(windows_.current, p_.allRois[p_.nextRoi], p_.windowSize))
+    {
+        while (advanceRoi(p_))
+        {
+            const Region & r = p_.allRois[p_.nextRoi];
+            if (r.seqName == windows_.current.contig && r.beginPos >= static_cast<int>(windows_.current.pos))
+                break;
+        }
+        if (p_.nextRoi == p_.allRois.size())
+        {
+            printStatus("Output written to '" + p_.outfile + "'.");
+            return false;
+        }
+    }
+    return true;
+}
+
+// Smallest first 30-bp window over all profiles for the current ROI (load_profile_popdel_call.h:291-347).
+Coord CallRun::firstWindowCoordinate()
+{
+    Coord minCoord{"", kNoPos};
+    ProfileWindow window;
+    std::vector<ProfileWindow> converted;
+    while (true)
+    {
+        for (unsigned i = 0; i < p_.fileCount; ++i)
+        {
+            unsigned contigIdx = p_.representativeContigs ? 0 : i;
+            ProfileFile in(p_.inputFiles[i]);
+            goNextRoi(in, i);
+            auto src = in.openSource(p_.uncompressedIn);
+            readWindow(*src, window, static_cast<unsigned>(p_.rgs[i].size()));
+            if (window.empty())
+                continue;
+            if (!splitWindow(window, converted, 256, 30))
+                throw ProfileError("[PopDel] Could not convert window " + p_.contigNames[contigIdx][window.chrom] + ":" +
+                                   std::to_string(window.beginPos) + ". The profile \"" + p_.inputFiles[i] +
+                                   "\" might be corrupted.");
+            Coord cur{p_.contigNames[contigIdx][converted[0].chrom], static_cast<unsigned>(converted[0].beginPos)};
+            if (minCoord.contig.empty() || !lowerCoord(minCoord, cur, p_))
+                minCoord = cur;
+        }
+        if (minCoord.contig == p_.allRois[p_.nextRoi].seqName)
+            break;
+        advanceRoi(p_);
+        if (p_.nextRoi == p_.allRois.size())
+            break;
+    }
+    if (minCoord.contig.empty() || p_.nextRoi == p_.allRois.size())
+        throw ProfileError("[PopDel] Could not find any entries for any of the specified ROIs or reference sequence of the "
+                           "first sample. Terminating.");
+    std::ostringstream msg;
+    msg << "The first window of all profiles starts at '" << minCoord.contig << ":" << minCoord.pos << "'.";
+    printStatus(msg);
+    return minCoord;
+}
+
+bool CallRun::firstWindowOnNextRoi(Coord & minCoord)
+{
+    minCoord = Coord{"", kNoPos};
+    ProfileWindow window;
+    std::vector<ProfileWindow> converted;
+    while (true)
+    {
+        for (unsigned i = 0; i < p_.fileCount; ++i)
+        {
+            unsigned contigIdx = p_.representativeContigs ? 0 : i;
+            ProfileFile in(p_.inputFiles[i]);
+            goNextRoi(in, i);
+            auto src = in.openSource(p_.uncompressedIn);
+            readWindow(*src, window, static_cast<unsigned>(p_.rgs[i].size()));
+            if (window.empty())
+                continue;
+            if (!splitWindow(window, converted, 256, 30))
+                throw ProfileError("[PopDel] Could not convert window at " + p_.contigNames[contigIdx][window.chrom] + ":" +
+                                   std::to_string(window.beginPos) + ". The profile \"" + p_.inputFiles[i] +
+                                   "\" might be corrupted.");
+            Coord cur{p_.contigNames[contigIdx][converted[0].chrom], static_cast<unsigned>(converted[0].beginPos)};
+            if (minCoord.contig.empty() || !lowerCoord(minCoord, cur, p_))
+                minCoord = cur;
+        }
+        if (minCoord.contig == p_.allRois[p_.nextRoi].seqName)
+            break;
+        if (p_.nextRoi + 1 != p_.allRois.size())
+            advanceRoi(p_);
+        else
+            return false;
+    }
+    return true;
+}
+
+bool CallRun::checkAndSwitch(const std::vector<unsigned> & rg, unsigned beginPos)
+{
+    ChromProfile & prof = *profile_;
+    if (prof.starts[rg[0]].tooBigForNext(beginPos) || prof.starts[rg[0]].needsSwitch(beginPos))
+    {
+        prof.performSwitches(rg);
+        return false;
+    }
+    if (prof.ends[rg[0]].readSlot == prof.ends[rg[0]].writeSlot)
+    {
+        for (unsigned r : rg)
+        {
+            prof.ends[r].switchWrite();
+            prof.ends[r].fixConsecutiveSwitch(prof.activeLoad[r]);
+        }
+    }
+    return true;
+}
+
+void CallRun::addRecords(const std::vector<unsigned> & rg, const ProfileWindow & win)
+{
+    for (size_t r = 0; r < win.records.size(); ++r)
+    {
+        const InsertHistogram & h = p_.histograms[rg[r]];
+        for (const PairRecord & rec : win.records[r])
+        {
+            int inner = static_cast<int32_t>(rec.dev) + static_cast<int>(h.median) - 2 * static_cast<int>(h.readLength);
+            unsigned endPos = rec.pos;
+            if (inner > 0)
+                endPos += static_cast<unsigned>(inner);
+            profile_->add(rg[r], rec.pos, endPos, static_cast<int32_t>(rec.dev));
+        }
+    }
+}
+
+unsigned CallRun::readTillRoi(ByteSource & src, ProfileWindow & window, const std::vector<std::string> & contigNames,
+                              Coord & coordinate, const std::vector<unsigned> & rg, const Region & roi)
+{
+    do
+    {
+        if (!readWindow(src, window, static_cast<unsigned>(rg.size())))
+        {
+            profile_->performPartialSwitches(rg);
+            coordinate.contig = "";
+            coordinate.pos = kNoPos;
+            return 3;
+        }
+        if (contigNames[window.chrom] != coordinate.contig)
+        {
+            profile_->performPartialSwitches(rg);
+            coordinate.contig = contigNames[window.chrom];
+            coordinate.pos = static_cast<unsigned>(window.beginPos);
+            return 2;
+        }
+    } while (window.beginPos + 255 < roi.beginPos);
+    return 0;
+}
+
+// 0: slot full, 2: end of contig / ROI, 3: end of file (load_profile_popdel_call.h:526-588).
+unsigned CallRun::readSegment(ByteSource & src, const std::string & fileName, const std::vector<unsigned> & rg,
+                              const std::vector<std::string> & contigNames, Coord & coordinate, const Region & roi)
+{
+    ProfileWindow window;
+    std::vector<ProfileWindow> converted;
+    ChromProfile & prof = *profile_;
+    while (true)
+    {
+        unsigned ret = readTillRoi(src, window, contigNames, coordinate, rg, roi);
+        if (ret > 0)
+            return ret;
+        if (!splitWindow(window, converted, 256, 30))
+            throw ProfileError("[PopDel] Could not convert window at " + contigNames[window.chrom] + ":" +
+                               std::to_string(window.beginPos) + ". The profile \"" + fileName + "\" might be corrupted.");
+        for (const ProfileWindow & w : converted)
+        {
+            if (contigNames[w.chrom] != roi.seqName || w.beginPos >= roi.endPos)
+            {
+                prof.performPartialSwitches(rg);
+                coordinate.contig = contigNames[w.chrom];
+                coordinate.pos = static_cast<unsigned>(w.beginPos);
+                return 2;
+            }
+            if (w.beginPos < roi.beginPos)
+                continue;
+            if (prof.starts[rg[0]].tooBigForNext(static_cast<unsigned>(w.beginPos)))
+            {
+                if (prof.allEmpty())
+                {
+                    prof.resetTo(static_cast<unsigned>(w.beginPos));
+                }
+                else
+                {
+                    prof.performPartialSwitches(rg);
+                    coordinate.contig = contigNames[w.chrom];
+                    coordinate.pos = static_cast<unsigned>(w.beginPos);
+                    return 0;
+                }
+            }
+            else if (prof.starts[rg[0]].needsSwitch(static_cast<unsigned>(w.beginPos)))
+            {
+                prof.performPartialSwitches(rg);
+                coordinate.contig = contigNames[w.chrom];
+                coordinate.pos = static_cast<unsigned>(w.beginPos);
+                return 0;
+            }
+            addRecords(rg, w);
+        }
+    }
+}
+
+bool CallRun::processSegmentCode(unsigned i, unsigned code)
+{
+    if (code == 0u)
+    {
+        if (nextCandidate_[i].pos < nextReadPos_)
+            nextReadPos_ = nextCandidate_[i].pos;
+        return false;
+    }
+    if (code < 3u)
+    {
+        finishedRois_[i] = 1;
+        if (windows_.nextChrom.contig.empty() || lowerCoord(nextCandidate_[i], windows_.nextChrom, p_))
+            windows_.nextChrom = nextCandidate_[i];
+        return true;
+    }
+    finishedRois_[i] = 1;
+    finishedFiles_[i] = 1;
+    --p_.fileCount;
+    return true;
+}
+
+void CallRun::markRoiComplete(unsigned i)
+{
+    finishedRois_[i] = 1;
+    if (!finishedFiles_[i])
+    {
+        finishedFiles_[i] = 1;
+        --p_.fileCount;
+    }
+}
+
+// Collect the calls of the segment that is in flight, merge them and write the records.
+void CallRun::flushPending()
+{
+    if (!pending_)
+        return;
+    pending_ = false;
+    pd_calls * pc = nullptr;
+    if (pd_segment_collect(ctx_, pendingTicket_, &pc) != 0)
+        throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctx_));
+    std::vector<WindowCall> calls(pc->n_calls);
+    const uint32_t S = pc->n_samples;
+    for (uint32_t c = 0; c < pc->n_calls; ++c)
+    {
+        WindowCall & w = calls[c];
+        w.initialLength = pc->initial_length[c];
+        w.iterations = pc->iterations[c];
+        w.deletionLength = pc->deletion_length[c];
+        w.likelihoodRatio = pc->likelihood_ratio[c];
+        w.frequency = pc->frequency[c];
+        w.windowPosition = pc->window_position[c];
+        w.position = pc->position[c];
+        w.endPosition = pc->end_position[c];
+        w.filter = pc->filter[c];
+        w.pl.resize(S);
+        w.lad.resize(S);
+        w.dad.resize(S);
+        w.firstLast.resize(S);
+        const size_t base = static_cast<size_t>(c) * S;
+        for (uint32_t s = 0; s < S; ++s)
+        {
+            for (int k = 0; k < 3; ++k)
+            {
+                w.pl[s][k] = pc->pl[(base + s) * 3 + k];
+                w.lad[s][k] = pc->lad[(base + s) * 3 + k];
+            }
+            for (int k = 0; k < 5; ++k)
+                w.dad[s][k] = pc->dad[(base + s) * 5 + k];
+            w.firstLast[s][0] = pc->first_last[(base + s) * 2];
+            w.firstLast[s][1] = pc->first_last[(base + s) * 2 + 1];
+        }
+    }
+    pd_calls_free(pc);
+    if (observer_ && observer_->onWindowCalls)
+        observer_->onWindowCalls(calls);
+    if (!p_.windowWiseOutput)
+    {
+        if (unifyCalls(calls, p_.meanStddev, p_.minRelWinCover, p_.outputFailed))
+        {
+            vcf_->appendContigName(pendingContig_);
+            vcf_->writeCalls(calls, p_);
+            vcf_->flush();
+        }
+    }
+    else
+    {
+        if (!calls.empty())
+            vcf_->appendContigName(pendingContig_);
+        vcf_->writeCalls(calls, p_);
+        vcf_->flush();
+    }
+}
+
+// Walk the windows of the loaded slot, record which pairs are active in which window, and submit that to the
+// backend. The previous segment is collected and written first so that records stay in order.
+void CallRun::processSegment()
+{
+    ChromProfile & prof = *profile_;
+    prof.beginSegmentLog();
+    if (prof.profilesAtEnd)
+        prof.profilesAtEnd = !prof.nextWindow(p_.windowShift);
+    prof.initializeActive();
+    const unsigned firstPos = prof.currentPos;
+    while (!prof.profilesAtEnd)
+    {
+        prof.windowDone();                      // window (firstPos + k * shift) is genotyped on the device
+        windows_.current.pos += p_.windowShift;
+        prof.profilesAtEnd = !prof.nextWindow(p_.windowShift);
+    }
+    const unsigned nWindows = prof.loggedWindows();
+    std::vector<std::vector<PairInstance>> & log = prof.endSegmentLog();
+    if (observer_ && observer_->onSegment)
+        observer_->onSegment(firstPos, nWindows, log);
+
+    flushPending();
+    if (nWindows == 0)
+        return;
+    // Flatten to the SoA layout of pd_segment.
+    std::vector<uint64_t> offsets(log.size() + 1, 0);
+    for (size_t rg = 0; rg < log.size(); ++rg)
+        offsets[rg + 1] = offsets[rg] + log[rg].size();
+    const size_t total = offsets.back();
+    std::vector<int32_t> dev(total);
+    std::vector<uint32_t> start(total), on(total), off(total);
+    for (size_t rg = 0; rg < log.size(); ++rg)
+    {
+        size_t o = offsets[rg];
+        for (const PairInstance & pi : log[rg])
+        {
+            dev[o] = pi.dev;
+            start[o] = pi.start;
+            on[o] = pi.on;
+            off[o] = pi.off;
+            ++o;
+        }
+    }
+    pd_segment seg;
+    seg.first_window_pos = firstPos;
+    seg.n_windows = nWindows;
+    seg.window_shift = p_.windowShift;
+    seg.n_readgroups = static_cast<uint32_t>(log.size());
+    seg.rg_offsets = offsets.data();
+    seg.pair_dev = dev.data();
+    seg.pair_start = start.data();
+    seg.pair_on = on.data();
+    seg.pair_off = off.data();
+    if (pd_segment_submit(ctx_, &seg, &pendingTicket_) != 0)
+        throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctx_));
+    pending_ = true;
+    pendingContig_ = windows_.current.contig;
+}
+
+bool CallRun::finalizeRoi()
+{
+    if (!advanceRoi(p_))
+    {
+        flushPending();
+        printStatus("Output written to '" + p_.outfile + "'.");
+        return false;
+    }
+    flushPending();                             // records of the finished ROI carry the old contig id
+    profile_->fullReset();
+    nextReadPos_ = kNoPos;
+    windows_.current.contig = p_.allRois[p_.nextRoi].seqName;
+    windows_.current.pos = 0;
+    windows_.nextChrom = Coord{"", kNoPos};
+    vcf_->unlockContigName();
+    for (char & b : finishedRois_)
+        b = 0;
+    return true;
+}
+
+int CallRun::run()
+{
+    loadAndCalculateParameters(p_);
+    printStatus("Finished parameter calculation.\n");
+    {
+        std::ostringstream msg;
+        msg << "Initialized insert size profiles from " << p_.sampleNum << " input files.";
+        printStatus(msg);
+    }
+    finishedFiles_.assign(p_.sampleNum, 0);
+    finishedRois_.assign(p_.sampleNum, 0);
+    windows_.next = windows_.current = firstWindowCoordinate();
+    nextCandidate_.assign(p_.sampleNum, windows_.current);
+
+    vcf_.reset(new VcfOutput(p_.outfile, p_.inputFiles, p_.contigNames[0], p_.contigLengths[0]));
+    vcf_->appendContigName(windows_.current.contig);
+
+    createBackend();
+    profile_.reset(new ChromProfile(static_cast<unsigned>(p_.readGroups.size()), p_.maxLoad, p_.windowBuffer));
+    profile_->currentPos = windows_.current.pos;
+    profile_->resetTo(profile_->currentPos);
+
+    while (p_.fileCount != 0)
+    {
+        if (!goNextRegion())
+        {
+            flushPending();
+            return 0;
+        }
+        for (unsigned i = 0; i < p_.sampleNum; ++i)
+        {
+            if (finishedFiles_[i] || finishedRois_[i])
+                continue;
+            ProfileFile in(p_.inputFiles[i]);
+            if (goNextRoi(in, i))
+            {
+                if (checkAndSwitch(p_.rgs[i], nextCandidate_[i].pos))
+                {
+                    unsigned contigIdx = p_.representativeContigs ? 0 : i;
+                    auto src = in.openSource(p_.uncompressedIn);
+                    unsigned code = readSegment(*src, p_.inputFiles[i], p_.rgs[i], p_.contigNames[contigIdx],
+                                                nextCandidate_[i], p_.allRois[p_.nextRoi]);
+                    if (!processSegmentCode(i, code))
+                        continue;
+                }
+            }
+            else
+            {
+                markRoiComplete(i);
+            }
+        }
+        processSegment();
+        if (allTrue(finishedRois_))
+        {
+            if (!finalizeRoi())
+                return 0;
+            firstWindowOnNextRoi(windows_.current);
+            profile_->currentPos = windows_.current.pos;
+            profile_->resetTo(profile_->currentPos);
+            nextReadPos_ = kNoPos;
+            for (Coord & c : nextCandidate_)
+                c = windows_.current;
+        }
+        else
+        {
+            windows_.current.pos = nextReadPos_;
+            nextReadPos_ = kNoPos;
+        }
+    }
+    flushPending();
+    printStatus("Output written to '" + p_.outfile + "'.");
+    return 0;
+}
+
+}  // namespace
+
+int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer)
+{
+    CallParams params;
+    int res = parseCallCommandLine(params, argc, argv);
+    if (res >= 0)
+        return res;
+    try
+    {
+        CallRun run(params, observer);
+        return run.run();
+    }
+    catch (const std::exception & e)
+    {
+        std::cerr << e.what() << std::endl;
+        return 1;
+    }
+}
+
+}  // namespace pdh

@@ -1,0 +1,458 @@
+#include "chrom_profile.h"
+
+#include <algorithm>
+
+#include "profile_io.h"   // posToWin
+
+namespace pdh {
+
+// ----------------------------------------------------------------------------------------------------------
+// StartSlots
+// ----------------------------------------------------------------------------------------------------------
+StartSlots::StartSlots(unsigned firstWin, unsigned windows) : numWindows(windows)
+{
+    slots[0].reset(0, firstWin + windows);
+    slots[1].reset(0, slots[0].right + windows);
+    slots[2].reset(0, slots[1].right + windows);
+}
+
+void StartSlots::switchWrite()
+{
+    Slot & prev = slots[writeSlot];
+    Slot & next = slots[(writeSlot + 1) % 3];
+    next.reset(insertionCount, prev.right + numWindows);
+    writeSlot = (writeSlot + 1) % 3;
+    prev.readable = true;
+}
+
+bool StartSlots::switchRead()
+{
+    readSlot = (readSlot + 1) % 3;
+    readIdx = 0;
+    return !readAtEnd();
+}
+
+bool StartSlots::switchBoth(unsigned & rightBorderOut)
+{
+    switchWrite();
+    bool res = switchRead();
+    rightBorderOut = slots[readSlot].right;
+    return res;
+}
+
+void StartSlots::add(unsigned startPos, int deviation)
+{
+    slots[writeSlot].entries.push_back(StartEntry{startPos, deviation});
+    ++insertionCount;
+}
+
+// Only the two slots behind the write slot can hold readable ids.
+unsigned StartSlots::slotOfId(unsigned id) const
+{
+    unsigned newer = (writeSlot + 2) % 3;
+    unsigned older = (writeSlot + 1) % 3;
+    return slots[newer].idOffset <= id ? newer : older;
+}
+
+const StartEntry & StartSlots::entryOfId(unsigned id) const
+{
+    const Slot & s = slots[slotOfId(id)];
+    return s.entries[id - s.idOffset];
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// EndSlots
+// ----------------------------------------------------------------------------------------------------------
+EndSlots::EndSlots(unsigned firstWin, unsigned windows) : numWindows(windows)
+{
+    slots[0].reset(firstWin + windows);
+    slots[1].reset(slots[0].right + windows);
+    slots[2].reset(slots[1].right + windows);
+}
+
+// The slot after the next one is recycled; the next one may already hold entries.
+void EndSlots::switchWrite()
+{
+    Slot & cur = slots[writeSlot];
+    Slot & next = slots[(writeSlot + 1) % 3];
+    Slot & afterNext = slots[(writeSlot + 2) % 3];
+    afterNext.reset(next.right + numWindows);
+    writeSlot = (writeSlot + 1) % 3;
+    cur.readable = true;
+}
+
+void EndSlots::fixConsecutiveSwitch(unsigned & activeLoad)
+{
+    if (endPosSlot != (writeSlot + 2) % 3)
+    {
+        endPosSlot = writeSlot;
+        dNext = 0;
+        activeLoad = 0;
+    }
+    else if (slots[endPosSlot].entries.empty())
+    {
+        endPosSlot = writeSlot;
+    }
+}
+
+bool EndSlots::switchRead()
+{
+    readSlot = (readSlot + 1) % 3;
+    slots[readSlot].readable = true;
+    readIdx = 0;
+    return !readAtEnd();
+}
+
+void EndSlots::add(unsigned id, unsigned endPos)
+{
+    const unsigned lastWin = posToWin(endPos, 30);
+    unsigned which = writeSlot;
+    if (needsSwitch(lastWin))
+        which = (which + 1) % 3;
+    std::vector<EndEntry> & v = slots[which].entries;
+    auto at = std::upper_bound(v.begin(), v.end(), lastWin,
+                               [](unsigned l, const EndEntry & e) { return l < e.lastWindow; });
+    v.insert(at, EndEntry{id, lastWin});
+}
+
+// Number of pairs of the current end-position slot (and, by look-ahead, of the following one) whose last
+// window lies before the window of `pos`; advances the dNext cursor. Reference: getEndCount(), :870-924.
+unsigned EndSlots::countEnded(unsigned pos)
+{
+    bool lookAhead = false;
+    unsigned i = dNext;
+    unsigned c = 0;
+    unsigned cSlot = endPosSlot;
+    unsigned n = static_cast<unsigned>(slots[cSlot].entries.size());
+    if (i == n)
+    {
+        if (endPosSlot != writeSlot)
+        {
+            endPosSlot = (endPosSlot + 1) % 3;
+            dNext = dNextOffset;
+            dNextOffset = 0;
+            i = dNext;
+            cSlot = endPosSlot;
+            n = static_cast<unsigned>(slots[cSlot].entries.size());
+        }
+        else
+        {
+            return 0;
+        }
+    }
+    if (n == 0)
+        return 0;
+    const unsigned win = posToWin(pos);
+    while (i < n && slots[cSlot].entries[i].lastWindow < win)
+    {
+        if (lookAhead)
+            ++dNextOffset;
+        ++c;
+        ++i;
+        if (i == n)
+        {
+            if (endPosSlot != writeSlot)
+            {
+                endPosSlot = (endPosSlot + 1) % 3;
+                dNext = dNextOffset;
+                dNextOffset = 0;
+                return c;
+            }
+            cSlot = (cSlot + 1) % 3;
+            n = static_cast<unsigned>(slots[cSlot].entries.size());
+            if (n == 0)
+                break;
+            i = dNextOffset;
+            lookAhead = true;
+        }
+    }
+    dNext += c - dNextOffset;
+    return c;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// ChromProfile
+// ----------------------------------------------------------------------------------------------------------
+ChromProfile::ChromProfile(unsigned numReadGroups, const std::vector<unsigned> & maximumLoad, unsigned bufferSize)
+    : starts(numReadGroups, StartSlots(0, bufferSize)),
+      ends(numReadGroups, EndSlots(0, bufferSize)),
+      active(numReadGroups),
+      activeLoad(numReadGroups, 0),
+      maxLoad(maximumLoad)
+{
+    currentRightBorder = starts[0].slots[2].right;
+    log_.resize(numReadGroups);
+}
+
+void ChromProfile::add(unsigned rg, unsigned startPos, unsigned endPos, int deviation)
+{
+    StartSlots & st = starts[rg];
+    EndSlots & en = ends[rg];
+    const unsigned id = st.insertionCount;
+    if (activeLoad[rg] >= maxLoad[rg])
+    {
+        // Saturated: only look for closing pairs, add the new pair if that freed room.
+        unsigned closing = en.countEnded(startPos);
+        activeLoad[rg] -= closing;
+        if (activeLoad[rg] < maxLoad[rg])
+        {
+            st.add(startPos, deviation);
+            en.add(id, endPos);
+            ++activeLoad[rg];
+        }
+    }
+    else
+    {
+        st.add(startPos, deviation);
+        en.add(id, endPos);
+        ++activeLoad[rg];
+        unsigned closing = en.countEnded(startPos);
+        activeLoad[rg] -= closing;
+    }
+}
+
+void ChromProfile::activate(unsigned rg, unsigned id)
+{
+    auto & set = active[rg];
+    if (set.find(id) != set.end())
+        return;
+    const StartEntry & e = starts[rg].entryOfId(id);
+    ActiveRec rec{e.deviation, e.startPos, kNoLog};
+    if (logging_)
+    {
+        rec.logIdx = static_cast<uint32_t>(log_[rg].size());
+        log_[rg].push_back(PairInstance{e.deviation, e.startPos, logWindow_, kNoLog});
+    }
+    set.emplace(id, rec);
+}
+
+void ChromProfile::deactivate(unsigned rg, unsigned id)
+{
+    auto & set = active[rg];
+    auto it = set.find(id);
+    if (it == set.end())
+        return;
+    if (logging_ && it->second.logIdx != kNoLog)
+        log_[rg][it->second.logIdx].off = logWindow_;
+    set.erase(it);
+}
+
+void ChromProfile::initializeActive()
+{
+    for (unsigned rg = 0; rg < starts.size(); ++rg)
+    {
+        StartSlots & st = starts[rg];
+        st.readIdx = 0;
+        if (st.readAtEnd())
+            continue;
+        unsigned pos = st.current().startPos;
+        if (pos < currentPos)
+            currentPos = pos;
+    }
+    globalMinPos = currentPos;
+    for (unsigned rg = 0; rg < starts.size(); ++rg)
+    {
+        StartSlots & st = starts[rg];
+        if (st.readAtEnd() || !active[rg].empty())
+            continue;
+        const unsigned pos = st.current().startPos;
+        if (pos != currentPos)
+            continue;
+        unsigned id = st.slots[st.readSlot].idOffset;
+        activate(rg, id);
+        ++id;
+        bool endOfSlot = !st.goNext();
+        while (!endOfSlot && st.current().startPos == pos)
+        {
+            activate(rg, id);
+            ++id;
+            endOfSlot = !st.goNext();
+        }
+    }
+}
+
+void ChromProfile::nextStartWindow(unsigned rg)
+{
+    StartSlots & st = starts[rg];
+    const unsigned pos = st.current().startPos;
+    bool more = true;
+    while (more && pos == st.current().startPos)
+    {
+        activate(rg, st.currentId());
+        more = st.goNext();
+    }
+}
+
+bool ChromProfile::nextEndWindow(unsigned rg)
+{
+    EndSlots & en = ends[rg];
+    if (en.readAtEnd())
+        return false;
+    const unsigned win = en.current().lastWindow;
+    while (win == en.current().lastWindow)
+    {
+        deactivate(rg, en.current().id);
+        if (!en.goNext())
+            return false;
+    }
+    return true;
+}
+
+bool ChromProfile::nextWindow(unsigned shift)
+{
+    bool someStillGood = false;
+    currentPos += shift;
+    if (currentPos >= currentRightBorder)
+    {
+        currentPos -= shift;
+        return false;
+    }
+    for (unsigned rg = 0; rg < starts.size(); ++rg)
+    {
+        StartSlots & st = starts[rg];
+        EndSlots & en = ends[rg];
+        if (!(en.readAtEnd() && st.readAtEnd()))
+            someStillGood = true;
+        while (!st.readAtEnd())
+        {
+            if (st.current().startPos <= currentPos)
+                nextStartWindow(rg);
+            else
+                break;
+        }
+        while (!en.readAtEnd())
+        {
+            if (en.current().lastWindow + shift < currentPos)   // the last window itself is still valid
+                nextEndWindow(rg);
+            else
+                break;
+        }
+    }
+    if (!someStillGood)
+        currentPos -= shift;
+    return someStillGood;
+}
+
+void ChromProfile::resetTo(unsigned pos)
+{
+    const unsigned w = starts[0].numWindows;
+    const unsigned r1 = pos + w, r2 = pos + 2 * w, r3 = pos + 3 * w;
+    for (StartSlots & st : starts)
+    {
+        unsigned idO = st.insertionCount;
+        st.slots[0].reset(idO, r1);
+        st.slots[1].reset(idO, r2);
+        st.slots[2].reset(idO, r3);
+        st.writeSlot = 0;
+        st.readSlot = 2;
+        st.readIdx = 0;
+    }
+    for (EndSlots & en : ends)
+    {
+        en.slots[0].reset(r1);
+        en.slots[1].reset(r2);
+        en.slots[2].reset(r3);
+        en.writeSlot = 0;
+        en.readSlot = 2;
+        en.readIdx = 0;
+        en.endPosSlot = 0;
+        en.dNext = 0;
+        en.dNextOffset = 0;
+    }
+    currentRightBorder = starts[0].slots[2].right;
+    for (unsigned & l : activeLoad)
+        l = 0;
+}
+
+void ChromProfile::fullReset()
+{
+    for (StartSlots & st : starts)
+        st.insertionCount = 0;
+    resetTo(0);
+    globalMinPos = std::numeric_limits<unsigned>::max();
+    currentPos = std::numeric_limits<unsigned>::max();
+    profilesAtEnd = false;
+    currentRightBorder = starts[0].slots[2].right;
+}
+
+void ChromProfile::performSwitches(const std::vector<unsigned> & rgs)
+{
+    for (unsigned i : rgs)
+    {
+        while (!ends[i].readAtEnd())
+            nextEndWindow(i);
+        starts[i].switchBoth(currentRightBorder);
+        ends[i].switchWrite();
+        ends[i].fixConsecutiveSwitch(activeLoad[i]);
+        ends[i].switchRead();
+    }
+}
+
+void ChromProfile::performPartialSwitches(const std::vector<unsigned> & rgs)
+{
+    for (unsigned i : rgs)
+    {
+        while (!ends[i].readAtEnd())
+            nextEndWindow(i);
+        starts[i].switchBoth(currentRightBorder);
+        ends[i].switchRead();
+    }
+}
+
+bool ChromProfile::allEmpty() const
+{
+    for (size_t i = 0; i < starts.size(); ++i)
+    {
+        if (!starts[i].slots[starts[i].writeSlot].entries.empty())
+            return false;
+        if (!ends[i].slots[ends[i].writeSlot].entries.empty())
+            return false;
+        if (!active[i].empty())
+            return false;
+    }
+    return true;
+}
+
+void ChromProfile::beginSegmentLog()
+{
+    logging_ = true;
+    logWindow_ = 0;
+    std::vector<std::pair<uint32_t, ActiveRec *>> carried;
+    for (size_t rg = 0; rg < active.size(); ++rg)
+    {
+        log_[rg].clear();
+        carried.clear();
+        for (auto & kv : active[rg])
+            carried.emplace_back(kv.first, &kv.second);
+        std::sort(carried.begin(), carried.end(),
+                  [](const std::pair<uint32_t, ActiveRec *> & a, const std::pair<uint32_t, ActiveRec *> & b) { return a.first < b.first; });
+        for (auto & c : carried)
+        {
+            c.second->logIdx = static_cast<uint32_t>(log_[rg].size());
+            log_[rg].push_back(PairInstance{c.second->dev, c.second->start, 0u, kNoLog});
+        }
+    }
+}
+
+std::vector<std::vector<PairInstance>> & ChromProfile::endSegmentLog()
+{
+    for (size_t rg = 0; rg < active.size(); ++rg)
+    {
+        for (auto & kv : active[rg])
+            kv.second.logIdx = kNoLog;
+        std::vector<PairInstance> & v = log_[rg];
+        size_t keep = 0;
+        for (size_t i = 0; i < v.size(); ++i)
+        {
+            if (v[i].off == kNoLog)
+                v[i].off = logWindow_;
+            if (v[i].on < v[i].off)
+                v[keep++] = v[i];
+        }
+        v.resize(keep);
+    }
+    logging_ = false;
+    return log_;
+}
+
+}  // namespace pdh

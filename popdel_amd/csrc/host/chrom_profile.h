@@ -1,0 +1,169 @@
+// Window state machine of `popdel call`: per read group a three-slot cyclic table of read-pair start entries,
+// a three-slot cyclic table of end entries, and the set of read pairs that are "active" in the current window.
+// This defines WHICH pairs the genotyping kernels see in WHICH window, including the loader's behaviour around
+// the 200 kb slot borders, so it is restated operation for operation.
+// Behavioural reference: popdel_call/profile_structure_popdel_call.h:173-450 (CyclicStartEntryTable),
+// :671-948 (CyclicEndEntryTable), :1035-1785 (ChromosomeProfile), :1878-1927 (switch helpers).
+//
+// Instead of exposing the active set to a per-window callee, this class records for every pair the window
+// index at which it enters and leaves the active set ("pair instances"); that event log is what is shipped to
+// the GPU (include/popdel_hip.h, pd_segment).
+#ifndef PDH_CHROM_PROFILE_H_
+#define PDH_CHROM_PROFILE_H_
+
+#include <cstdint>
+#include <cstddef>
+#include <limits>
+#include <unordered_map>
+#include <vector>
+
+namespace pdh {
+
+struct StartEntry
+{
+    uint32_t startPos;
+    int32_t  deviation;
+};
+
+struct EndEntry
+{
+    uint32_t id;
+    uint32_t lastWindow;
+};
+
+// Three slots used round-robin: one is written while the previous one is read.
+class StartSlots
+{
+public:
+    struct Slot
+    {
+        std::vector<StartEntry> entries;
+        unsigned right = 0;        // exclusive right border
+        unsigned idOffset = 0;     // id of entries[0]
+        bool readable = false;
+        void reset(unsigned idO, unsigned r) { entries.clear(); right = r; idOffset = idO; readable = false; }
+    };
+
+    explicit StartSlots(unsigned firstWin = 0, unsigned windows = 10000);
+
+    bool needsSwitch(unsigned firstWindow) const { return firstWindow >= slots[writeSlot].right; }
+    bool tooBigForNext(unsigned firstWindow) const { return firstWindow >= slots[writeSlot].right + numWindows; }
+    void switchWrite();
+    bool switchRead();
+    bool switchBoth(unsigned & rightBorderOut);
+    void add(unsigned startPos, int deviation);
+
+    bool readAtEnd() const { return readIdx >= slots[readSlot].entries.size(); }
+    bool goNext() { ++readIdx; return !readAtEnd(); }
+    const StartEntry & current() const { return slots[readSlot].entries[readIdx]; }
+    unsigned currentId() const { return static_cast<unsigned>(readIdx) + slots[readSlot].idOffset; }
+    unsigned slotOfId(unsigned id) const;
+    const StartEntry & entryOfId(unsigned id) const;
+
+    Slot     slots[3];
+    size_t   readIdx = 0;          // position of the read cursor inside slots[readSlot]
+    unsigned readSlot = 2;
+    unsigned writeSlot = 0;
+    unsigned insertionCount = 0;
+    unsigned numWindows;
+};
+
+class EndSlots
+{
+public:
+    struct Slot
+    {
+        std::vector<EndEntry> entries;   // ordered by lastWindow (stable)
+        unsigned right = 0;
+        bool readable = false;
+        void reset(unsigned r) { entries.clear(); right = r; readable = false; }
+    };
+
+    explicit EndSlots(unsigned firstWin = 0, unsigned windows = 10000);
+
+    bool needsSwitch(unsigned lastWindow) const { return lastWindow >= slots[writeSlot].right; }
+    void switchWrite();
+    void fixConsecutiveSwitch(unsigned & activeLoad);
+    bool switchRead();
+    void add(unsigned id, unsigned endPos);
+    unsigned countEnded(unsigned pos);      // getEndCount() of the reference
+
+    bool readAtEnd() const { return readIdx >= slots[readSlot].entries.size(); }
+    bool goNext() { ++readIdx; return !readAtEnd(); }
+    const EndEntry & current() const { return slots[readSlot].entries[readIdx]; }
+
+    Slot     slots[3];
+    size_t   readIdx = 0;
+    unsigned dNext = 0;
+    unsigned dNextOffset = 0;
+    unsigned writeSlot = 0;
+    unsigned endPosSlot = 0;
+    unsigned readSlot = 2;
+    unsigned numWindows;
+};
+
+// A pair as seen by the window loop of one segment: active for window indices [on, off).
+struct PairInstance
+{
+    int32_t  dev;
+    uint32_t start;
+    uint32_t on;
+    uint32_t off;
+};
+
+class ChromProfile
+{
+public:
+    ChromProfile(unsigned numReadGroups, const std::vector<unsigned> & maximumLoad, unsigned bufferSize);
+
+    bool isHighCov(unsigned rg) const { return active[rg].size() >= maxLoad[rg]; }
+    void add(unsigned rg, unsigned startPos, unsigned endPos, int deviation);
+    void initializeActive();
+    bool nextWindow(unsigned shift);
+    void resetTo(unsigned pos);
+    void fullReset();
+    void performSwitches(const std::vector<unsigned> & rgs);
+    void performPartialSwitches(const std::vector<unsigned> & rgs);
+    bool allEmpty() const;
+
+    // --- event log (segment builder) -------------------------------------------------------------------
+    // Call before the first genotyped window of a segment: carried-over pairs become instances with on = 0.
+    void beginSegmentLog();
+    // Call after each genotyped window (before nextWindow()).
+    void windowDone() { ++logWindow_; }
+    // Close all open instances at `off = number of windows` and return the per-read-group instance lists.
+    // Still-active pairs stay in the active set for the next segment.
+    std::vector<std::vector<PairInstance>> & endSegmentLog();
+    unsigned loggedWindows() const { return logWindow_; }
+
+    std::vector<StartSlots> starts;
+    std::vector<EndSlots> ends;
+    // Active read pairs of one read group: id -> what the window loop needs to know about the pair.
+    struct ActiveRec
+    {
+        int32_t  dev;
+        uint32_t start;
+        uint32_t logIdx;      // index of the open instance in the segment log (kNoLog if none)
+    };
+    std::vector<std::unordered_map<uint32_t, ActiveRec>> active;
+    unsigned globalMinPos = std::numeric_limits<unsigned>::max();
+    unsigned currentPos = std::numeric_limits<unsigned>::max();
+    bool     profilesAtEnd = false;
+    unsigned currentRightBorder;
+    std::vector<unsigned> activeLoad;
+    std::vector<unsigned> maxLoad;
+
+private:
+    static constexpr uint32_t kNoLog = 0xffffffffu;
+    void activate(unsigned rg, unsigned id);
+    void deactivate(unsigned rg, unsigned id);
+    void nextStartWindow(unsigned rg);
+    bool nextEndWindow(unsigned rg);
+
+    bool logging_ = false;
+    unsigned logWindow_ = 0;
+    std::vector<std::vector<PairInstance>> log_;
+};
+
+}  // namespace pdh
+#endif

@@ -1,0 +1,306 @@
+#include "profile_io.h"
+
+#include <zlib.h>
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace pdh {
+namespace {
+
+constexpr size_t kIndexStart = 7 + 2 * sizeof(uint32_t);
+
+class RawSource : public ByteSource
+{
+public:
+    explicit RawSource(FILE * fp) : fp_(fp) {}
+    size_t read(void * dst, size_t n) override { return fread(dst, 1, n, fp_); }
+private:
+    FILE * fp_;
+};
+
+// Inflates a run of concatenated gzip members starting at the current file offset.
+class GzSource : public ByteSource
+{
+public:
+    explicit GzSource(FILE * fp) : fp_(fp), in_(1 << 16)
+    {
+        std::memset(&zs_, 0, sizeof(zs_));
+        if (inflateInit2(&zs_, 15 + 32) != Z_OK)
+            throw ProfileError("[PopDel] zlib initialisation failed.");
+    }
+    ~GzSource() override { inflateEnd(&zs_); }
+
+    size_t read(void * dst, size_t n) override
+    {
+        zs_.next_out = static_cast<Bytef *>(dst);
+        zs_.avail_out = static_cast<uInt>(n);
+        while (zs_.avail_out != 0 && !finished_)
+        {
+            if (zs_.avail_in == 0)
+            {
+                size_t got = fread(in_.data(), 1, in_.size(), fp_);
+                if (got == 0)
+                {
+                    finished_ = true;
+                    break;
+                }
+                zs_.next_in = in_.data();
+                zs_.avail_in = static_cast<uInt>(got);
+            }
+            int rc = inflate(&zs_, Z_NO_FLUSH);
+            if (rc == Z_STREAM_END)
+            {
+                // Next member (if any) follows immediately.
+                if (inflateReset(&zs_) != Z_OK)
+                    throw ProfileError("[PopDel] zlib reset failed.");
+                continue;
+            }
+            if (rc == Z_BUF_ERROR && zs_.avail_in == 0)
+                continue;
+            if (rc != Z_OK)
+            {
+                // Bytes that are not a gzip member end the stream, like an EOF.
+                finished_ = true;
+                break;
+            }
+        }
+        return n - zs_.avail_out;
+    }
+
+private:
+    FILE * fp_;
+    std::vector<unsigned char> in_;
+    z_stream zs_;
+    bool finished_ = false;
+};
+
+template <typename T>
+bool readPod(FILE * fp, T & v)
+{
+    return fread(&v, sizeof(T), 1, fp) == 1;
+}
+
+[[noreturn]] void corrupted(const std::string & path, const char * what)
+{
+    throw ProfileError("[PopDel] Corrupted profile \"" + path + "\": " + what);
+}
+
+std::string readName(FILE * fp, const std::string & path, const char * lenMsg, const char * nameMsg, const char * termMsg)
+{
+    uint32_t nameLen = 0;
+    if (!readPod(fp, nameLen) || nameLen == 0)
+        corrupted(path, lenMsg);
+    std::string s(nameLen - 1, '\0');
+    char term = 1;
+    if ((nameLen > 1 && fread(&s[0], 1, nameLen - 1, fp) != nameLen - 1) || fread(&term, 1, 1, fp) != 1)
+        corrupted(path, nameMsg);
+    if (term != '\0')
+        corrupted(path, termMsg);
+    return s;
+}
+
+}  // namespace
+
+ProfileFile::ProfileFile(const std::string & path) : path_(path)
+{
+    fp_ = fopen(path.c_str(), "rb");
+    if (!fp_)
+        throw ProfileError("[PopDel] Could not open file '" + path + "' for reading.");
+}
+
+ProfileFile::~ProfileFile()
+{
+    if (fp_)
+        fclose(fp_);
+}
+
+void ProfileFile::readHeader(ProfileHeader & hdr, bool dropContigs)
+{
+    fseeko(fp_, 0, SEEK_SET);
+    char magic[7];
+    if (fread(magic, 1, 7, fp_) != 7)
+        corrupted(path_, "Unable to read magic string.");
+    if (std::memcmp(magic, "POPDEL\1", 7) != 0)
+        corrupted(path_, "Magic string is wrong.");
+    uint32_t regionSize = 0, numRegions = 0;
+    if (!readPod(fp_, regionSize))
+        corrupted(path_, "Unable to read index region size.");
+    if (!readPod(fp_, numRegions))
+        corrupted(path_, "Unable to read index size.");
+    hdr.indexRegionSize = regionSize;
+    hdr.numRegions = numRegions;
+    fseeko(fp_, static_cast<off_t>(numRegions) * sizeof(uint64_t), SEEK_CUR);
+
+    uint32_t numRg = 0;
+    if (!readPod(fp_, numRg))
+        corrupted(path_, "Unable to read number of read groups.");
+    if (numRg == 0)
+        corrupted(path_, "Profile seems to have 0 read groups.");
+    hdr.readGroups.assign(numRg, std::string());
+    hdr.histograms.assign(numRg, InsertHistogram());
+    for (uint32_t i = 0; i < numRg; ++i)
+    {
+        hdr.readGroups[i] = readName(fp_, path_, "Unable to read length of read group name.",
+                                     "Unable to read read group name.",
+                                     "Expecting read group name to be null-terminated.");
+        InsertHistogram & h = hdr.histograms[i];
+        uint32_t median = 0, readLen = 0, histStart = 0, histEnd = 0;
+        double sd = 0;
+        if (!readPod(fp_, median))
+            corrupted(path_, "Unable to read median insert size.");
+        if (!readPod(fp_, sd))
+            corrupted(path_, "Unable to read standard deviation of insert size.");
+        if (!readPod(fp_, readLen))
+            corrupted(path_, "Unable to read read length.");
+        if (!readPod(fp_, histStart))
+            corrupted(path_, "Unable to read offset of insert size histogram.");
+        if (!readPod(fp_, histEnd))
+            corrupted(path_, "Unable to read insert size histogram size.");
+        h.median = median;
+        h.stddev = sd;
+        h.readLength = readLen;
+        h.offset = static_cast<int>(histStart);
+        h.values.assign(histEnd - histStart, 0.0);
+        if (!h.values.empty() && fread(h.values.data(), sizeof(double), h.values.size(), fp_) != h.values.size())
+            corrupted(path_, "Unable to read value from histogram.");
+    }
+    uint32_t numContigs = 0;
+    if (!readPod(fp_, numContigs))
+        corrupted(path_, "Unable to read number of contigs.");
+    if (!dropContigs)
+    {
+        hdr.contigNames.assign(numContigs, std::string());
+        hdr.contigLengths.assign(numContigs, 0);
+    }
+    for (uint32_t i = 0; i < numContigs; ++i)
+    {
+        if (!dropContigs)
+        {
+            hdr.contigNames[i] = readName(fp_, path_, "Unable to read length of contig name.",
+                                          "Unable to read contig name.", "Expecting contig name to be null-terminated.");
+            if (!readPod(fp_, hdr.contigLengths[i]))
+                corrupted(path_, "Unable to read contig length.");
+        }
+        else
+        {
+            uint32_t nameLen = 0;
+            if (!readPod(fp_, nameLen))
+                corrupted(path_, "Unable to read length of contig name.");
+            if (fseeko(fp_, static_cast<off_t>(nameLen) + sizeof(int32_t), SEEK_CUR) != 0)
+                corrupted(path_, "Unable to skip contig name and length.");
+        }
+    }
+}
+
+void ProfileFile::jumpToRegion(const std::vector<std::string> & contigNames, const std::vector<int32_t> & contigLengths,
+                               unsigned indexRegionSize, const std::string & contig, int32_t beginPos)
+{
+    uint64_t slot = 0;
+    for (size_t i = 0; i < contigNames.size(); ++i)
+    {
+        if (contig == contigNames[i])
+            break;
+        slot += static_cast<uint64_t>(contigLengths[i] / static_cast<int32_t>(indexRegionSize)) + 1;
+    }
+    slot += static_cast<uint64_t>(beginPos / static_cast<int32_t>(indexRegionSize));
+    uint64_t offset = 0;
+    fseeko(fp_, static_cast<off_t>(kIndexStart + slot * sizeof(uint64_t)), SEEK_SET);
+    if (!readPod(fp_, offset))
+        offset = 0;
+    fseeko(fp_, static_cast<off_t>(offset), SEEK_SET);
+}
+
+std::unique_ptr<ByteSource> ProfileFile::openSource(bool uncompressed)
+{
+    if (uncompressed)
+        return std::unique_ptr<ByteSource>(new RawSource(fp_));
+    return std::unique_ptr<ByteSource>(new GzSource(fp_));
+}
+
+bool readWindow(ByteSource & src, ProfileWindow & win, unsigned numReadGroups)
+{
+    win.chrom = 0;
+    win.beginPos = 0;
+    for (auto & r : win.records)
+        r.clear();
+    uint32_t chrom = 0, begin = 0;
+    if (src.read(&chrom, 4) != 4)
+        return false;
+    if (src.read(&begin, 4) != 4)
+        throw ProfileError("[PopDel] Unable to read contig position.");
+    win.chrom = static_cast<int32_t>(chrom);
+    win.beginPos = static_cast<int32_t>(begin);
+    win.records.resize(numReadGroups);
+    std::vector<unsigned char> buf;
+    for (unsigned rg = 0; rg < numReadGroups; ++rg)
+    {
+        uint32_t n = 0;
+        if (src.read(&n, 4) != 4)
+            throw ProfileError("[PopDel] Unable to read number of read pairs.");
+        std::vector<PairRecord> & recs = win.records[rg];
+        recs.resize(n);
+        buf.resize(static_cast<size_t>(n) * 5);
+        if (n != 0 && src.read(buf.data(), buf.size()) != buf.size())
+            throw ProfileError("[PopDel] Unable to read insert size deviation.");
+        for (uint32_t i = 0; i < n; ++i)
+        {
+            const unsigned char * p = buf.data() + static_cast<size_t>(i) * 5;
+            uint32_t dev;
+            std::memcpy(&dev, p + 1, 4);
+            recs[i].pos = static_cast<uint32_t>(p[0]) + begin;
+            recs[i].dev = dev;
+        }
+    }
+    return true;
+}
+
+bool splitWindow(const ProfileWindow & in, std::vector<ProfileWindow> & out, unsigned oldSize, unsigned newSize)
+{
+    const size_t rgNum = in.records.size();
+    const size_t slots = static_cast<size_t>(std::ceil(static_cast<double>(oldSize + newSize) / newSize));
+    unsigned base = std::numeric_limits<unsigned>::max();
+    for (size_t rg = 0; rg < rgNum; ++rg)
+        if (!in.records[rg].empty() && in.records[rg][0].pos < base)
+            base = in.records[rg][0].pos;        // records are position-sorted: element 0 is the minimum
+    base = (base / newSize) * newSize;
+
+    std::vector<std::vector<unsigned>> counts(rgNum, std::vector<unsigned>(slots, 0));
+    std::vector<char> hasContent(slots, 0);
+    for (size_t rg = 0; rg < rgNum; ++rg)
+        for (const PairRecord & r : in.records[rg])
+        {
+            size_t idx = (r.pos - base) / newSize;
+            if (idx >= slots)
+                throw ProfileError("[PopDel] Profile window is not position-sorted.");
+            hasContent[idx] = 1;
+            ++counts[rg][idx];
+        }
+    std::vector<int> slotToOut(slots, -1);
+    unsigned total = 0;
+    for (size_t i = 0; i < slots; ++i)
+        if (hasContent[i])
+            slotToOut[i] = static_cast<int>(total++);
+    out.clear();
+    if (total == 0)
+        return false;
+    out.resize(total);
+    for (size_t i = 0; i < slots; ++i)
+    {
+        if (slotToOut[i] < 0)
+            continue;
+        ProfileWindow & w = out[static_cast<size_t>(slotToOut[i])];
+        w.chrom = in.chrom;
+        w.beginPos = static_cast<int32_t>(base + i * newSize);
+        w.records.resize(rgNum);
+        for (size_t rg = 0; rg < rgNum; ++rg)
+            w.records[rg].reserve(counts[rg][i]);
+    }
+    for (size_t rg = 0; rg < rgNum; ++rg)
+        for (const PairRecord & r : in.records[rg])
+            out[static_cast<size_t>(slotToOut[(r.pos - base) / newSize])].records[rg].push_back(r);
+    return true;
+}
+
+}  // namespace pdh

@@ -1,0 +1,93 @@
+// Reader for PopDel's binary profile format ("POPDEL\1"): header, region index, window records, and the
+// 256-bp -> 30-bp window split used by `popdel call`.
+// Behavioural reference: insert_histogram_popdel.h:334-525 (readProfileHeader), :531-562 (jumpToRegion);
+// popdel_profile/window_podel.h:210-251 (readWindow), :314-418 (convertWindow);
+// seqan/stream/iostream_zip_impl.h:336-349 (concatenated gzip members are read through).
+#ifndef PDH_PROFILE_IO_H_
+#define PDH_PROFILE_IO_H_
+
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "histogram.h"
+
+namespace pdh {
+
+struct ProfileError : std::runtime_error
+{
+    using std::runtime_error::runtime_error;
+};
+
+struct ProfileHeader
+{
+    unsigned indexRegionSize = 0;
+    unsigned numRegions = 0;
+    std::vector<std::string> readGroups;
+    std::vector<InsertHistogram> histograms;   // raw counts as stored in the file
+    std::vector<std::string> contigNames;
+    std::vector<int32_t> contigLengths;
+};
+
+// One (position, deviation) record; pos is the absolute end position of the forward read.
+struct PairRecord
+{
+    uint32_t pos;
+    uint32_t dev;     // int32 deviation kept in an unsigned, as the reference does
+};
+
+struct ProfileWindow
+{
+    int32_t chrom = -1;
+    int32_t beginPos = -1;
+    std::vector<std::vector<PairRecord>> records;   // per read group of the file
+    bool empty() const { return records.empty(); }
+};
+
+// Sequential byte source positioned inside a profile: plain file bytes or an inflating view of them.
+class ByteSource
+{
+public:
+    virtual ~ByteSource() {}
+    // Reads exactly n bytes unless the data ends; returns the number of bytes delivered.
+    virtual size_t read(void * dst, size_t n) = 0;
+};
+
+class ProfileFile
+{
+public:
+    explicit ProfileFile(const std::string & path);
+    ~ProfileFile();
+    ProfileFile(const ProfileFile &) = delete;
+    ProfileFile & operator=(const ProfileFile &) = delete;
+
+    const std::string & path() const { return path_; }
+    // Parse the header from the start of the file. With dropContigs the contig table is skipped.
+    void readHeader(ProfileHeader & hdr, bool dropContigs = false);
+    // Seek to the first data block of the index region that contains `beginPos` on `contig`.
+    void jumpToRegion(const std::vector<std::string> & contigNames, const std::vector<int32_t> & contigLengths,
+                      unsigned indexRegionSize, const std::string & contig, int32_t beginPos);
+    // Byte source starting at the current file offset.
+    std::unique_ptr<ByteSource> openSource(bool uncompressed);
+
+    FILE * handle() { return fp_; }
+
+private:
+    std::string path_;
+    FILE * fp_ = nullptr;
+};
+
+// Read the next 256-bp window record. Returns false at end of data (before the contig id).
+bool readWindow(ByteSource & src, ProfileWindow & win, unsigned numReadGroups);
+
+// Split a 256-bp window into 30-bp windows on the global 30-grid; only windows with content are produced.
+// Returns false if the window holds no records at all.
+bool splitWindow(const ProfileWindow & in, std::vector<ProfileWindow> & out, unsigned oldSize = 256, unsigned newSize = 30);
+
+inline unsigned posToWin(unsigned pos, unsigned windowSize = 30u) { return (pos / windowSize) * windowSize; }
+
+}  // namespace pdh
+#endif
