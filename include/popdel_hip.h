@@ -135,6 +135,29 @@ void pd_ctx_destroy(pd_ctx *ctx);
  * (reference workflow_popdel.h:42-47). */
 int pd_segment_submit(pd_ctx *ctx, const pd_segment *seg, uint64_t *ticket);
 
+/* The two halves of pd_segment_submit(), for callers that keep segments resident in HBM or stream them double
+ * buffered: pd_segment_stage() copies a segment into HBM (returns a handle), pd_segment_run() enqueues the window
+ * loop for a staged segment (may be repeated), pd_segment_unstage() releases it.
+ * pd_segment_submit(seg) == stage + run + unstage-after-collect. No reference counterpart (the reference computes
+ * in place on the host). */
+int pd_segment_stage(pd_ctx *ctx, const pd_segment *seg, uint64_t *handle);
+int pd_segment_run(pd_ctx *ctx, uint64_t handle, uint64_t *ticket);
+int pd_segment_unstage(pd_ctx *ctx, uint64_t handle);
+
+/* Device time of the kernels of the last collected ticket, measured with HIP events on the launch stream.
+ * No reference counterpart (instrumentation). */
+typedef struct pd_timing
+{
+    double   stage1_ms;          /* Q3 scan kernel                                            */
+    double   stage2_ms;          /* clustering + EM + final pass kernels                      */
+    uint64_t n_cells;            /* windows x samples handled by the scan                     */
+    uint64_t n_active_pairs;     /* sum over cells of active pairs (algorithmic gather size)  */
+    uint64_t n_pair_chunks;      /* pair chunks resident in HBM for the segment               */
+    uint64_t n_candidate_cells;  /* (window, candidate length) cells entering the EM          */
+    uint32_t max_life;           /* chunk length K in windows                                 */
+} pd_timing;
+int pd_last_timing(pd_ctx *ctx, pd_timing *out);
+
 /* Wait for a ticket and hand back its calls (callee-owned; release with pd_calls_free).
  * Replaces: reading `String<Call> calls` after the window loop (reference workflow_popdel.h:48). */
 int pd_segment_collect(pd_ctx *ctx, uint64_t ticket, pd_calls **out);

@@ -95,6 +95,17 @@ struct pd_ctx
     std::vector<uint8_t> flags;
     uint32_t lastWindows = 0;
     uint64_t ticket = 0;
+    // staged segments (deep copies), see pd_segment_stage()
+    struct Staged
+    {
+        pd_segment seg;
+        std::vector<uint64_t> offsets;
+        std::vector<int32_t> dev;
+        std::vector<uint32_t> start, on, off;
+    };
+    std::map<uint64_t, Staged> staged;
+    uint64_t nextHandle = 1;
+    pd_timing timing;
 
     unsigned nSamples() const { return static_cast<unsigned>(sampleOffsets.size() - 1); }
     bool isHighCov(unsigned rg) const { return active[rg].size() >= rgs[rg].maxLoad; }
@@ -700,7 +711,7 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
 
 void pd_ctx_destroy(pd_ctx * ctx) { delete ctx; }
 
-int pd_segment_submit(pd_ctx * c, const pd_segment * seg, uint64_t * ticket)
+static int runSegment(pd_ctx * c, const pd_segment * seg, uint64_t * ticket)
 {
     if (!c || !seg || seg->n_readgroups != c->rgs.size())
     {
@@ -746,6 +757,49 @@ int pd_segment_submit(pd_ctx * c, const pd_segment * seg, uint64_t * ticket)
         genotypeWindow(*c, &c->q3[static_cast<size_t>(w) * S], &c->flags[static_cast<size_t>(w) * S]);
     }
     *ticket = ++c->ticket;
+    return 0;
+}
+
+
+int pd_segment_submit(pd_ctx * c, const pd_segment * seg, uint64_t * ticket) { return runSegment(c, seg, ticket); }
+
+int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
+{
+    if (!c || !seg || !handle || seg->n_readgroups != c->rgs.size())
+        return 1;
+    pd_ctx::Staged st;
+    const uint64_t total = seg->rg_offsets[seg->n_readgroups];
+    st.offsets.assign(seg->rg_offsets, seg->rg_offsets + seg->n_readgroups + 1);
+    st.dev.assign(seg->pair_dev, seg->pair_dev + total);
+    st.start.assign(seg->pair_start, seg->pair_start + total);
+    st.on.assign(seg->pair_on, seg->pair_on + total);
+    st.off.assign(seg->pair_off, seg->pair_off + total);
+    st.seg = *seg;
+    *handle = c->nextHandle++;
+    pd_ctx::Staged & dst = c->staged[*handle];
+    dst = std::move(st);
+    dst.seg.rg_offsets = dst.offsets.data();
+    dst.seg.pair_dev = dst.dev.data();
+    dst.seg.pair_start = dst.start.data();
+    dst.seg.pair_on = dst.on.data();
+    dst.seg.pair_off = dst.off.data();
+    return 0;
+}
+
+int pd_segment_run(pd_ctx * c, uint64_t handle, uint64_t * ticket)
+{
+    if (!c || !c->staged.count(handle))
+        return 1;
+    return runSegment(c, &c->staged[handle].seg, ticket);
+}
+
+int pd_segment_unstage(pd_ctx * c, uint64_t handle) { return (c && c->staged.erase(handle)) ? 0 : 1; }
+
+int pd_last_timing(pd_ctx * c, pd_timing * out)
+{
+    if (!c || !out)
+        return 1;
+    std::memset(out, 0, sizeof(*out));
     return 0;
 }
 

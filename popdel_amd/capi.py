@@ -1,0 +1,263 @@
+"""ctypes mirror of include/popdel_hip.h.
+
+``load_hip()`` opens the product library (popdel_amd/lib/libpopdel_hip.so) and raises if it is missing: there is no
+CPU fallback in the product path. Tests and the bench's CPU-baseline leg may open the oracle library through
+``load_library(path)`` with an explicit path; both expose the same symbols.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIBRARY = os.path.join(_HERE, "lib", "libpopdel_hip.so")
+
+ABI_SYMBOLS = (
+    "pd_ctx_create", "pd_ctx_destroy", "pd_segment_submit", "pd_segment_stage", "pd_segment_run", "pd_segment_unstage",
+    "pd_segment_collect", "pd_calls_free", "pd_stage1_last", "pd_last_timing", "pd_last_error", "pd_backend_name",
+    "pd_abi_version",
+)
+
+
+class PdReadgroup(C.Structure):
+    _fields_ = [("median", C.c_uint32), ("read_length", C.c_uint32), ("stddev", C.c_double), ("min_prob", C.c_double),
+                ("hist_offset", C.c_int32), ("hist_len", C.c_uint32), ("hist_values", C.POINTER(C.c_double)),
+                ("lower_quantile_dist", C.c_uint32), ("upper_quantile_dist", C.c_uint32), ("max_load", C.c_uint32),
+                ("min_init_del_len", C.c_uint32)]
+
+
+class PdConfig(C.Structure):
+    _fields_ = [("iterations", C.c_uint32), ("min_len", C.c_uint32), ("min_likelihood_ratio", C.c_double),
+                ("min_sample_fraction", C.c_double), ("somatic", C.c_int32), ("window_wise_output", C.c_int32)]
+
+
+class PdSegment(C.Structure):
+    _fields_ = [("first_window_pos", C.c_uint32), ("n_windows", C.c_uint32), ("window_shift", C.c_uint32),
+                ("n_readgroups", C.c_uint32), ("rg_offsets", C.POINTER(C.c_uint64)), ("pair_dev", C.POINTER(C.c_int32)),
+                ("pair_start", C.POINTER(C.c_uint32)), ("pair_on", C.POINTER(C.c_uint32)),
+                ("pair_off", C.POINTER(C.c_uint32))]
+
+
+class PdCalls(C.Structure):
+    _fields_ = [("n_calls", C.c_uint32), ("n_samples", C.c_uint32), ("initial_length", C.POINTER(C.c_uint32)),
+                ("iterations", C.POINTER(C.c_uint32)), ("deletion_length", C.POINTER(C.c_uint32)),
+                ("likelihood_ratio", C.POINTER(C.c_double)), ("frequency", C.POINTER(C.c_double)),
+                ("window_position", C.POINTER(C.c_uint32)), ("position", C.POINTER(C.c_uint32)),
+                ("end_position", C.POINTER(C.c_uint32)), ("filter", C.POINTER(C.c_uint8)), ("pl", C.POINTER(C.c_uint32)),
+                ("lad", C.POINTER(C.c_uint32)), ("dad", C.POINTER(C.c_uint32)), ("first_last", C.POINTER(C.c_uint32))]
+
+
+class PdStage1View(C.Structure):
+    _fields_ = [("n_windows", C.c_uint32), ("n_samples", C.c_uint32), ("q3", C.POINTER(C.c_int32)),
+                ("flags", C.POINTER(C.c_uint8))]
+
+
+class PdTiming(C.Structure):
+    _fields_ = [("stage1_ms", C.c_double), ("stage2_ms", C.c_double), ("n_cells", C.c_uint64),
+                ("n_active_pairs", C.c_uint64), ("n_pair_chunks", C.c_uint64), ("n_candidate_cells", C.c_uint64),
+                ("max_life", C.c_uint32)]
+
+
+def load_library(path):
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    lib = C.CDLL(path)
+    lib.pd_ctx_create.argtypes = [C.POINTER(PdConfig), C.POINTER(PdReadgroup), C.c_uint32, C.POINTER(C.c_uint32),
+                                  C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+    lib.pd_ctx_create.restype = C.c_int
+    lib.pd_ctx_destroy.argtypes = [C.c_void_p]
+    lib.pd_ctx_destroy.restype = None
+    for name in ("pd_segment_submit", "pd_segment_stage"):
+        getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(PdSegment), C.POINTER(C.c_uint64)]
+        getattr(lib, name).restype = C.c_int
+    lib.pd_segment_run.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.pd_segment_run.restype = C.c_int
+    lib.pd_segment_unstage.argtypes = [C.c_void_p, C.c_uint64]
+    lib.pd_segment_unstage.restype = C.c_int
+    lib.pd_segment_collect.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.POINTER(PdCalls))]
+    lib.pd_segment_collect.restype = C.c_int
+    lib.pd_calls_free.argtypes = [C.POINTER(PdCalls)]
+    lib.pd_calls_free.restype = None
+    lib.pd_stage1_last.argtypes = [C.c_void_p, C.POINTER(PdStage1View)]
+    lib.pd_stage1_last.restype = C.c_int
+    lib.pd_last_timing.argtypes = [C.c_void_p, C.POINTER(PdTiming)]
+    lib.pd_last_timing.restype = C.c_int
+    lib.pd_last_error.argtypes = [C.c_void_p]
+    lib.pd_last_error.restype = C.c_char_p
+    lib.pd_backend_name.restype = C.c_char_p
+    lib.pd_abi_version.restype = C.c_int
+    return lib
+
+
+def load_hip():
+    """The product backend. Fails loudly when the HIP library has not been built."""
+    if not os.path.exists(HIP_LIBRARY):
+        raise RuntimeError("libpopdel_hip.so is missing (%s): build it with __graft_entry__.build() or "
+                           "`make -C popdel_amd/csrc`; there is no CPU fallback." % HIP_LIBRARY)
+    lib = load_library(HIP_LIBRARY)
+    if lib.pd_backend_name() != b"hip-gfx950":
+        raise RuntimeError("unexpected backend behind %s: %r" % (HIP_LIBRARY, lib.pd_backend_name()))
+    return lib
+
+
+@dataclass
+class ReadGroup:
+    """One conditioned read group (see pd_readgroup)."""
+    median: int
+    read_length: int
+    stddev: float
+    min_prob: float
+    hist_offset: int
+    hist_values: np.ndarray
+    lower_quantile_dist: int
+    upper_quantile_dist: int
+    max_load: int = 100
+    min_init_del_len: int = 0
+
+
+@dataclass
+class Segment:
+    """Pair instances of one segment (see pd_segment); arrays are read-group major, ordered by ``on``."""
+    first_window_pos: int
+    n_windows: int
+    rg_offsets: np.ndarray
+    dev: np.ndarray
+    start: np.ndarray
+    on: np.ndarray
+    off: np.ndarray
+    window_shift: int = 30
+
+    def as_struct(self):
+        self.rg_offsets = np.ascontiguousarray(self.rg_offsets, dtype=np.uint64)
+        self.dev = np.ascontiguousarray(self.dev, dtype=np.int32)
+        self.start = np.ascontiguousarray(self.start, dtype=np.uint32)
+        self.on = np.ascontiguousarray(self.on, dtype=np.uint32)
+        self.off = np.ascontiguousarray(self.off, dtype=np.uint32)
+        s = PdSegment()
+        s.first_window_pos = self.first_window_pos
+        s.n_windows = self.n_windows
+        s.window_shift = self.window_shift
+        s.n_readgroups = len(self.rg_offsets) - 1
+        s.rg_offsets = self.rg_offsets.ctypes.data_as(C.POINTER(C.c_uint64))
+        s.pair_dev = self.dev.ctypes.data_as(C.POINTER(C.c_int32))
+        s.pair_start = self.start.ctypes.data_as(C.POINTER(C.c_uint32))
+        s.pair_on = self.on.ctypes.data_as(C.POINTER(C.c_uint32))
+        s.pair_off = self.off.ctypes.data_as(C.POINTER(C.c_uint32))
+        return s
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+class Context:
+    """A calling context (pd_ctx) on one device."""
+
+    def __init__(self, lib, readgroups, sample_rg_offsets, iterations=15, min_len=200, min_likelihood_ratio=12.527629,
+                 min_sample_fraction=0.1, somatic=False, window_wise_output=False, device=0):
+        self.lib = lib
+        self._keep = []
+        n = len(readgroups)
+        arr = (PdReadgroup * n)()
+        for i, r in enumerate(readgroups):
+            hv = np.ascontiguousarray(r.hist_values, dtype=np.float64)
+            self._keep.append(hv)
+            arr[i].median = r.median
+            arr[i].read_length = r.read_length
+            arr[i].stddev = r.stddev
+            arr[i].min_prob = r.min_prob
+            arr[i].hist_offset = r.hist_offset
+            arr[i].hist_len = len(hv)
+            arr[i].hist_values = hv.ctypes.data_as(C.POINTER(C.c_double))
+            arr[i].lower_quantile_dist = r.lower_quantile_dist
+            arr[i].upper_quantile_dist = r.upper_quantile_dist
+            arr[i].max_load = r.max_load
+            arr[i].min_init_del_len = r.min_init_del_len
+        cfg = PdConfig(iterations, min_len, min_likelihood_ratio, min_sample_fraction, int(somatic), int(window_wise_output))
+        offs = np.ascontiguousarray(sample_rg_offsets, dtype=np.uint32)
+        self.n_samples = len(offs) - 1
+        self.n_readgroups = n
+        handle = C.c_void_p()
+        rc = lib.pd_ctx_create(C.byref(cfg), arr, n, offs.ctypes.data_as(C.POINTER(C.c_uint32)), self.n_samples, device,
+                               C.byref(handle))
+        if rc != 0:
+            raise BackendError(lib.pd_last_error(None).decode())
+        self.handle = handle
+
+    def close(self):
+        if self.handle:
+            self.lib.pd_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise BackendError(self.lib.pd_last_error(self.handle).decode())
+
+    def submit(self, seg: Segment):
+        t = C.c_uint64()
+        st = seg.as_struct()
+        self._check(self.lib.pd_segment_submit(self.handle, C.byref(st), C.byref(t)))
+        return t.value
+
+    def stage(self, seg: Segment):
+        h = C.c_uint64()
+        st = seg.as_struct()
+        self._check(self.lib.pd_segment_stage(self.handle, C.byref(st), C.byref(h)))
+        return h.value
+
+    def run(self, handle):
+        t = C.c_uint64()
+        self._check(self.lib.pd_segment_run(self.handle, handle, C.byref(t)))
+        return t.value
+
+    def unstage(self, handle):
+        self._check(self.lib.pd_segment_unstage(self.handle, handle))
+
+    def collect(self, ticket):
+        """Returns a dict of numpy arrays (copies)."""
+        p = C.POINTER(PdCalls)()
+        self._check(self.lib.pd_segment_collect(self.handle, ticket, C.byref(p)))
+        c = p.contents
+        n, S = c.n_calls, c.n_samples
+
+        def arr(ptr, shape, dtype):
+            count = int(np.prod(shape)) if len(shape) else 1
+            if count == 0:
+                return np.zeros(shape, dtype=dtype)
+            return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dtype).reshape(shape).copy()
+
+        out = dict(
+            n_calls=n, n_samples=S,
+            initial_length=arr(c.initial_length, (n,), np.uint32), iterations=arr(c.iterations, (n,), np.uint32),
+            deletion_length=arr(c.deletion_length, (n,), np.uint32),
+            likelihood_ratio=arr(c.likelihood_ratio, (n,), np.float64), frequency=arr(c.frequency, (n,), np.float64),
+            window_position=arr(c.window_position, (n,), np.uint32), position=arr(c.position, (n,), np.uint32),
+            end_position=arr(c.end_position, (n,), np.uint32), filter=arr(c.filter, (n,), np.uint8),
+            pl=arr(c.pl, (n, S, 3), np.uint32), lad=arr(c.lad, (n, S, 3), np.uint32), dad=arr(c.dad, (n, S, 5), np.uint32),
+            first_last=arr(c.first_last, (n, S, 2), np.uint32))
+        self.lib.pd_calls_free(p)
+        return out
+
+    def stage1(self):
+        v = PdStage1View()
+        self._check(self.lib.pd_stage1_last(self.handle, C.byref(v)))
+        n = v.n_windows * v.n_samples
+        if n == 0:
+            return np.zeros((0, 0), np.int32), np.zeros((0, 0), np.uint8)
+        q3 = np.ctypeslib.as_array(v.q3, shape=(n,)).reshape(v.n_windows, v.n_samples).copy()
+        fl = np.ctypeslib.as_array(v.flags, shape=(n,)).reshape(v.n_windows, v.n_samples).copy()
+        return q3, fl
+
+    def timing(self):
+        t = PdTiming()
+        self._check(self.lib.pd_last_timing(self.handle, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in PdTiming._fields_}

@@ -1,0 +1,709 @@
+// C ABI of libpopdel_hip.so (include/popdel_hip.h): context, HBM staging of segments, launch orchestration and
+// result packing. No CPU fallback lives here: every entry point either runs the HIP kernels or fails.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "pd_device.h"
+#include "popdel_hip.h"
+
+namespace pd {
+
+void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag, hipStream_t stream);
+void launchCluster(const int32_t * q3, const uint8_t * flags, const int * flaggedWindows, unsigned nFlagged, unsigned W,
+                   const CohortView & co, int * scratch, unsigned rowLen, int * candLen, int * candCount, hipStream_t st);
+void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st);
+void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st);
+void launchGatherOut(const Stage2Buffers & b, const unsigned * emitCells, unsigned nEmit, unsigned nSamples, uint32_t * pl,
+                     uint32_t * lad, uint32_t * dad, uint32_t * fl, hipStream_t st);
+
+}  // namespace pd
+
+namespace {
+
+std::string g_createError;
+
+struct HipError
+{
+    std::string what;
+};
+
+#define PD_HIP(expr)                                                                                          \
+    do                                                                                                        \
+    {                                                                                                         \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            throw HipError{std::string(#expr) + ": " + hipGetErrorString(e_)};                                \
+    } while (0)
+
+// Device allocation that frees itself.
+template <typename T>
+struct DevBuf
+{
+    T *    p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf &) = delete;
+    DevBuf & operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (count)
+            PD_HIP(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+    }
+    void ensure(size_t count)
+    {
+        if (count > n)
+            alloc(count + count / 8);
+    }
+    void upload(const std::vector<T> & v, hipStream_t st)
+    {
+        ensure(v.size());
+        if (!v.empty())
+            PD_HIP(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    }
+};
+
+struct StagedSegment
+{
+    uint32_t firstPos = 0, nWindows = 0, shift = 0, maxLife = 0;
+    uint64_t nChunks = 0, nPairs = 0, nActivePairs = 0;
+    DevBuf<pd::PairDO> pairs;
+    DevBuf<uint32_t> start;
+    DevBuf<uint64_t> rgBase;
+    DevBuf<uint32_t> winStart;
+    bool ownedBySubmit = false;
+};
+
+struct Run
+{
+    uint64_t handle = 0;
+    hipEvent_t s1Begin = nullptr, s1End = nullptr;
+};
+
+}  // namespace
+
+struct pd_ctx
+{
+    pd_config cfg;
+    int device = 0;
+    uint32_t nRg = 0, nSamples = 0;
+    std::vector<uint32_t> sampleRg;
+    std::string error;
+    hipStream_t stream = nullptr;
+    DevBuf<pd::RgConst> dRg;
+    DevBuf<double> dHist;
+    DevBuf<uint32_t> dSampleRg;
+    pd::CohortView cohort;
+
+    std::map<uint64_t, std::unique_ptr<StagedSegment>> staged;
+    uint64_t nextHandle = 1, nextTicket = 1;
+    std::map<uint64_t, Run> runs;
+
+    // stage-1 outputs of the most recent run
+    DevBuf<int32_t> dQ3;
+    DevBuf<uint8_t> dFlags;
+    DevBuf<int> dWinFlag;
+    uint32_t lastWindows = 0;
+    std::vector<int32_t> hQ3View;
+    std::vector<uint8_t> hFlagsView;
+    // stage-2 scratch
+    DevBuf<int> dFlagged, dClusterScratch, dCandLen, dCandCount;
+    DevBuf<pd::CellState> dCells;
+    DevBuf<double> dDl, dPartial;
+    DevBuf<int> dShifts;
+    DevBuf<unsigned> dCounters, dSuppFirst, dSuppLast, dEmit;
+    DevBuf<uint32_t> dPl, dLad, dDad, dFl, dOutPl, dOutLad, dOutDad, dOutFl;
+    pd_timing timing;
+
+    ~pd_ctx()
+    {
+        staged.clear();
+        if (stream)
+            (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+template <typename T>
+T * mallocCopy(const std::vector<T> & v)
+{
+    T * p = static_cast<T *>(std::malloc(std::max<size_t>(1, v.size()) * sizeof(T)));
+    if (!v.empty())
+        std::memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+
+// Split every pair instance into chunks that live at most K windows, order the chunks of each read group by their
+// first window and index them by window (winStart). K is chosen so that nearly all pairs need a single chunk.
+void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, std::vector<pd::PairDO> & pairs,
+                 std::vector<uint32_t> & start, std::vector<uint64_t> & rgBase, std::vector<uint32_t> & winStart)
+{
+    const uint32_t W = seg.n_windows;
+    const uint64_t total = seg.rg_offsets[seg.n_readgroups];
+    // lifetime histogram -> K
+    std::vector<uint64_t> lifeHist(66, 0);
+    uint64_t active = 0;
+    for (uint64_t i = 0; i < total; ++i)
+    {
+        uint32_t on = seg.pair_on[i], off = std::min(seg.pair_off[i], W);
+        if (off <= on)
+            continue;
+        uint32_t life = off - on;
+        active += life;
+        ++lifeHist[std::min<uint32_t>(life, 65)];
+    }
+    uint64_t nInst = 0;
+    for (uint64_t h : lifeHist)
+        nInst += h;
+    uint32_t K = 4;
+    {
+        uint64_t acc = 0;
+        const uint64_t want = nInst - nInst / 64;       // ~98.4 %
+        for (uint32_t l = 0; l <= 65; ++l)
+        {
+            acc += lifeHist[l];
+            if (acc >= want)
+            {
+                K = std::max<uint32_t>(4, l);
+                break;
+            }
+        }
+        K = std::min<uint32_t>(K, 48);
+    }
+    if (const char * e = getenv("POPDEL_HIP_MAXLIFE"))
+        K = std::max(1, atoi(e));
+    out.maxLife = K;
+    out.nPairs = nInst;
+    out.nActivePairs = active;
+
+    rgBase.assign(seg.n_readgroups, 0);
+    winStart.assign(static_cast<size_t>(seg.n_readgroups) * (W + 1), 0);
+    pairs.clear();
+    start.clear();
+    pairs.reserve(total + total / 16);
+    start.reserve(total + total / 16);
+    std::vector<uint32_t> counts(W + 1);
+    for (uint32_t rg = 0; rg < seg.n_readgroups; ++rg)
+    {
+        const uint64_t lo = seg.rg_offsets[rg], hi = seg.rg_offsets[rg + 1];
+        rgBase[rg] = pairs.size();
+        std::fill(counts.begin(), counts.end(), 0u);
+        for (uint64_t i = lo; i < hi; ++i)
+        {
+            uint32_t on = seg.pair_on[i], off = std::min(seg.pair_off[i], W);
+            for (uint32_t a = on; a < off; a += K)
+                ++counts[a];
+        }
+        uint32_t * ws = winStart.data() + static_cast<size_t>(rg) * (W + 1);
+        uint32_t acc = 0;
+        for (uint32_t w = 0; w <= W; ++w)
+        {
+            ws[w] = acc;
+            if (w < W)
+                acc += counts[w];
+        }
+        const size_t base = pairs.size();
+        pairs.resize(base + acc);
+        start.resize(base + acc);
+        std::vector<uint32_t> cursor(ws, ws + W);
+        for (uint64_t i = lo; i < hi; ++i)
+        {
+            uint32_t on = seg.pair_on[i], off = std::min(seg.pair_off[i], W);
+            for (uint32_t a = on; a < off; a += K)
+            {
+                const uint32_t slot = cursor[a]++;
+                pairs[base + slot] = pd::PairDO{seg.pair_dev[i], std::min(off, a + K)};
+                start[base + slot] = seg.pair_start[i];
+            }
+        }
+    }
+    out.nChunks = pairs.size();
+    (void)c;
+}
+
+pd::SegmentView viewOf(const StagedSegment & s)
+{
+    pd::SegmentView v;
+    v.pairs = s.pairs.p;
+    v.start = s.start.p;
+    v.rgBase = s.rgBase.p;
+    v.winStart = s.winStart.p;
+    v.nWindows = s.nWindows;
+    v.maxLife = s.maxLife;
+    v.firstPos = s.firstPos;
+    v.shift = s.shift;
+    return v;
+}
+
+int fail(pd_ctx * c, const std::string & msg)
+{
+    if (c)
+        c->error = msg;
+    else
+        g_createError = msg;
+    return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_readgroups, const uint32_t * sample_rg_offsets,
+                  uint32_t n_samples, int device, pd_ctx ** out)
+{
+    if (!cfg || !rgs || !sample_rg_offsets || !out || n_readgroups == 0 || n_samples == 0)
+        return fail(nullptr, "pd_ctx_create: invalid argument");
+    if (sample_rg_offsets[0] != 0 || sample_rg_offsets[n_samples] != n_readgroups)
+        return fail(nullptr, "pd_ctx_create: sample_rg_offsets do not cover the read groups");
+    if (cfg->iterations > (uint32_t)pd::kMaxIterationsCap)
+        return fail(nullptr, "pd_ctx_create: iterations exceeds the device limit of 64");
+    if (n_samples > 65535u)
+        return fail(nullptr, "pd_ctx_create: more than 65535 samples per context (shard the cohort across contexts)");
+    std::unique_ptr<pd_ctx> c(new pd_ctx());
+    try
+    {
+        int nDev = 0;
+        PD_HIP(hipGetDeviceCount(&nDev));
+        if (nDev <= 0 || device < 0 || device >= nDev)
+            return fail(nullptr, "pd_ctx_create: no such HIP device");
+        PD_HIP(hipSetDevice(device));
+        c->device = device;
+        c->cfg = *cfg;
+        c->nRg = n_readgroups;
+        c->nSamples = n_samples;
+        c->sampleRg.assign(sample_rg_offsets, sample_rg_offsets + n_samples + 1);
+        PD_HIP(hipStreamCreate(&c->stream));
+        std::vector<pd::RgConst> rc(n_readgroups);
+        std::vector<double> pool;
+        int minThreshold = 0x7fffffff;
+        for (uint32_t i = 0; i < n_readgroups; ++i)
+        {
+            rc[i].median = (int)rgs[i].median;
+            rc[i].readLength = (int)rgs[i].read_length;
+            rc[i].histOffset = rgs[i].hist_offset;
+            rc[i].histLen = (int)rgs[i].hist_len;
+            rc[i].lowerQ = (int)rgs[i].lower_quantile_dist;
+            rc[i].upperQ = (int)rgs[i].upper_quantile_dist;
+            rc[i].maxLoad = rgs[i].max_load;
+            rc[i].minInitDelLen = rgs[i].min_init_del_len;
+            rc[i].stddev = rgs[i].stddev;
+            rc[i].minProb = rgs[i].min_prob;
+            rc[i].histBase = pool.size();
+            pool.insert(pool.end(), rgs[i].hist_values, rgs[i].hist_values + rgs[i].hist_len);
+            minThreshold = std::min(minThreshold, (int)rgs[i].min_init_del_len);
+        }
+        c->dRg.upload(rc, c->stream);
+        c->dHist.upload(pool, c->stream);
+        c->dSampleRg.upload(c->sampleRg, c->stream);
+        PD_HIP(hipStreamSynchronize(c->stream));
+        c->cohort.rg = c->dRg.p;
+        c->cohort.hist = c->dHist.p;
+        c->cohort.sampleRg = c->dSampleRg.p;
+        c->cohort.nSamples = n_samples;
+        c->cohort.nRg = n_readgroups;
+        c->cohort.minThreshold = minThreshold;
+        std::memset(&c->timing, 0, sizeof(c->timing));
+    }
+    catch (const HipError & e)
+    {
+        return fail(nullptr, "pd_ctx_create: " + e.what);
+    }
+    *out = c.release();
+    return 0;
+}
+
+void pd_ctx_destroy(pd_ctx * ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    for (auto & r : ctx->runs)
+    {
+        if (r.second.s1Begin)
+            (void)hipEventDestroy(r.second.s1Begin);
+        if (r.second.s1End)
+            (void)hipEventDestroy(r.second.s1End);
+    }
+    delete ctx;
+}
+
+int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
+{
+    if (!c || !seg || !handle)
+        return fail(c, "pd_segment_stage: invalid argument");
+    if (seg->n_readgroups != c->nRg)
+        return fail(c, "pd_segment_stage: read-group count mismatch");
+    if (seg->n_windows == 0)
+        return fail(c, "pd_segment_stage: empty segment");
+    try
+    {
+        PD_HIP(hipSetDevice(c->device));
+        std::unique_ptr<StagedSegment> s(new StagedSegment());
+        s->firstPos = seg->first_window_pos;
+        s->nWindows = seg->n_windows;
+        s->shift = seg->window_shift;
+        std::vector<pd::PairDO> pairs;
+        std::vector<uint32_t> start, winStart;
+        std::vector<uint64_t> rgBase;
+        buildChunks(*c, *seg, *s, pairs, start, rgBase, winStart);
+        s->pairs.upload(pairs, c->stream);
+        s->start.upload(start, c->stream);
+        s->rgBase.upload(rgBase, c->stream);
+        s->winStart.upload(winStart, c->stream);
+        PD_HIP(hipStreamSynchronize(c->stream));       // host vectors go out of scope
+        *handle = c->nextHandle++;
+        c->staged[*handle] = std::move(s);
+    }
+    catch (const HipError & e)
+    {
+        return fail(c, "pd_segment_stage: " + e.what);
+    }
+    return 0;
+}
+
+int pd_segment_run(pd_ctx * c, uint64_t handle, uint64_t * ticket)
+{
+    if (!c || !ticket)
+        return fail(c, "pd_segment_run: invalid argument");
+    auto it = c->staged.find(handle);
+    if (it == c->staged.end())
+        return fail(c, "pd_segment_run: unknown segment handle");
+    try
+    {
+        PD_HIP(hipSetDevice(c->device));
+        StagedSegment & s = *it->second;
+        const size_t cells = static_cast<size_t>(c->nSamples) * s.nWindows;
+        c->dQ3.ensure(cells);
+        c->dFlags.ensure(cells);
+        c->dWinFlag.ensure(s.nWindows);
+        PD_HIP(hipMemsetAsync(c->dWinFlag.p, 0, s.nWindows * sizeof(int), c->stream));
+        Run run;
+        run.handle = handle;
+        PD_HIP(hipEventCreate(&run.s1Begin));
+        PD_HIP(hipEventCreate(&run.s1End));
+        PD_HIP(hipEventRecord(run.s1Begin, c->stream));
+        pd::launchStage1(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->stream);
+        PD_HIP(hipGetLastError());
+        PD_HIP(hipEventRecord(run.s1End, c->stream));
+        c->lastWindows = s.nWindows;
+        *ticket = c->nextTicket++;
+        c->runs[*ticket] = run;
+    }
+    catch (const HipError & e)
+    {
+        return fail(c, "pd_segment_run: " + e.what);
+    }
+    return 0;
+}
+
+int pd_segment_unstage(pd_ctx * c, uint64_t handle)
+{
+    if (!c)
+        return 1;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    return c->staged.erase(handle) ? 0 : fail(c, "pd_segment_unstage: unknown segment handle");
+}
+
+int pd_segment_submit(pd_ctx * c, const pd_segment * seg, uint64_t * ticket)
+{
+    uint64_t h = 0;
+    if (int rc = pd_segment_stage(c, seg, &h))
+        return rc;
+    c->staged[h]->ownedBySubmit = true;
+    if (int rc = pd_segment_run(c, h, ticket))
+    {
+        c->staged.erase(h);
+        return rc;
+    }
+    return 0;
+}
+
+int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
+{
+    if (!c || !out)
+        return fail(c, "pd_segment_collect: invalid argument");
+    *out = nullptr;
+    auto rit = c->runs.find(ticket);
+    if (rit == c->runs.end())
+        return fail(c, "pd_segment_collect: unknown ticket");
+    Run run = rit->second;
+    c->runs.erase(rit);
+    auto sit = c->staged.find(run.handle);
+    if (sit == c->staged.end())
+        return fail(c, "pd_segment_collect: segment was unstaged before collect");
+    StagedSegment & s = *sit->second;
+    hipEvent_t s2Begin = nullptr, s2End = nullptr;
+    int rc = 0;
+    try
+    {
+        PD_HIP(hipSetDevice(c->device));
+        const uint32_t W = s.nWindows, S = c->nSamples;
+        const pd::SegmentView view = viewOf(s);
+        PD_HIP(hipEventCreate(&s2Begin));
+        PD_HIP(hipEventCreate(&s2End));
+
+        // windows with at least one Q3 above the smallest threshold
+        std::vector<int> winFlag(W);
+        PD_HIP(hipMemcpyAsync(winFlag.data(), c->dWinFlag.p, W * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        PD_HIP(hipStreamSynchronize(c->stream));
+        std::vector<int> flagged;
+        for (uint32_t w = 0; w < W; ++w)
+            if (winFlag[w])
+                flagged.push_back((int)w);
+
+        PD_HIP(hipEventRecord(s2Begin, c->stream));
+        std::vector<pd::CellState> cells;
+        if (!flagged.empty())
+        {
+            unsigned rowLen = 1;
+            while (rowLen < S)
+                rowLen <<= 1;
+            c->dFlagged.upload(flagged, c->stream);
+            c->dClusterScratch.ensure(static_cast<size_t>(flagged.size()) * rowLen);
+            c->dCandLen.ensure(flagged.size() * pd::kMaxCandidatesPerWindow);
+            c->dCandCount.ensure(flagged.size());
+            pd::launchCluster(c->dQ3.p, c->dFlags.p, c->dFlagged.p, (unsigned)flagged.size(), W, c->cohort,
+                              c->dClusterScratch.p, rowLen, c->dCandLen.p, c->dCandCount.p, c->stream);
+            PD_HIP(hipGetLastError());
+            std::vector<int> candLen(flagged.size() * pd::kMaxCandidatesPerWindow), candCount(flagged.size());
+            PD_HIP(hipMemcpyAsync(candLen.data(), c->dCandLen.p, candLen.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            PD_HIP(hipMemcpyAsync(candCount.data(), c->dCandCount.p, candCount.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            PD_HIP(hipStreamSynchronize(c->stream));
+            for (size_t f = 0; f < flagged.size(); ++f)
+            {
+                if (candCount[f] > pd::kMaxCandidatesPerWindow)
+                    throw HipError{"more than 8 candidate deletion lengths in one window"};
+                for (int k = 0; k < candCount[f]; ++k)
+                {
+                    pd::CellState cs;
+                    std::memset(&cs, 0, sizeof(cs));
+                    cs.window = flagged[f];
+                    cs.initLen = candLen[f * pd::kMaxCandidatesPerWindow + k];
+                    cs.phase = pd::kCellIterating;
+                    cells.push_back(cs);
+                }
+            }
+        }
+        std::vector<unsigned> emit;
+        const unsigned nCells = (unsigned)cells.size();
+        pd::Stage2Buffers b;
+        std::memset(&b, 0, sizeof(b));
+        if (nCells != 0)
+        {
+            b.nCells = nCells;
+            b.nTiles = (S + pd::kSampleTile - 1) / pd::kSampleTile;
+            c->dCells.upload(cells, c->stream);
+            c->dDl.ensure(static_cast<size_t>(nCells) * S * 3);
+            c->dShifts.ensure(static_cast<size_t>(nCells) * c->nRg);
+            c->dPartial.ensure(static_cast<size_t>(nCells) * b.nTiles * 4);
+            c->dCounters.ensure(static_cast<size_t>(nCells) * 4);
+            c->dPl.ensure(static_cast<size_t>(nCells) * S * 3);
+            c->dLad.ensure(static_cast<size_t>(nCells) * S * 3);
+            c->dDad.ensure(static_cast<size_t>(nCells) * S * 5);
+            c->dFl.ensure(static_cast<size_t>(nCells) * S * 2);
+            PD_HIP(hipMemsetAsync(c->dShifts.p, 0, static_cast<size_t>(nCells) * c->nRg * sizeof(int), c->stream));
+            PD_HIP(hipMemsetAsync(c->dCounters.p, 0, static_cast<size_t>(nCells) * 4 * sizeof(unsigned), c->stream));
+            PD_HIP(hipMemsetAsync(c->dPartial.p, 0, static_cast<size_t>(nCells) * b.nTiles * 4 * sizeof(double), c->stream));
+            b.cells = c->dCells.p;
+            b.dl = c->dDl.p;
+            b.shifts = c->dShifts.p;
+            b.partial = c->dPartial.p;
+            b.counters = c->dCounters.p;
+            b.pl = c->dPl.p;
+            b.lad = c->dLad.p;
+            b.dad = c->dDad.p;
+            b.fl = c->dFl.p;
+            b.minLen = c->cfg.min_len;
+            b.maxIterations = c->cfg.iterations;
+            b.minLR = c->cfg.min_likelihood_ratio;
+            b.minSampleFraction = c->cfg.min_sample_fraction;
+            b.somatic = c->cfg.somatic;
+            b.windowWise = c->cfg.window_wise_output;
+            // Phase A gives, per cell, the number of usable active pairs = capacity of its support pool.
+            pd::runStage2Init(view, c->cohort, b, c->dFlags.p, c->stream);
+            PD_HIP(hipGetLastError());
+            std::vector<unsigned> counters(static_cast<size_t>(nCells) * 4);
+            PD_HIP(hipMemcpyAsync(counters.data(), c->dCounters.p, counters.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            PD_HIP(hipStreamSynchronize(c->stream));
+            uint64_t pool = 0;
+            for (unsigned i = 0; i < nCells; ++i)
+                pool += counters[static_cast<size_t>(i) * 4 + 1];
+            c->dSuppFirst.ensure(pool + 1);
+            c->dSuppLast.ensure(pool + 1);
+            b.suppFirst = c->dSuppFirst.p;
+            b.suppLast = c->dSuppLast.p;
+            pd::runStage2Main(view, c->cohort, b, c->dFlags.p, c->stream);
+            PD_HIP(hipGetLastError());
+            PD_HIP(hipMemcpyAsync(cells.data(), c->dCells.p, cells.size() * sizeof(pd::CellState), hipMemcpyDeviceToHost, c->stream));
+            PD_HIP(hipStreamSynchronize(c->stream));
+            for (unsigned i = 0; i < nCells; ++i)
+                if (cells[i].phase == pd::kCellEmit)
+                    emit.push_back(i);
+        }
+        const uint32_t n = (uint32_t)emit.size();
+        std::vector<uint32_t> pl(static_cast<size_t>(n) * S * 3), lad(static_cast<size_t>(n) * S * 3),
+            dad(static_cast<size_t>(n) * S * 5), fl(static_cast<size_t>(n) * S * 2);
+        if (n != 0)
+        {
+            c->dEmit.upload(emit, c->stream);
+            c->dOutPl.ensure(pl.size());
+            c->dOutLad.ensure(lad.size());
+            c->dOutDad.ensure(dad.size());
+            c->dOutFl.ensure(fl.size());
+            pd::launchGatherOut(b, c->dEmit.p, n, S, c->dOutPl.p, c->dOutLad.p, c->dOutDad.p, c->dOutFl.p, c->stream);
+            PD_HIP(hipGetLastError());
+            PD_HIP(hipMemcpyAsync(pl.data(), c->dOutPl.p, pl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            PD_HIP(hipMemcpyAsync(lad.data(), c->dOutLad.p, lad.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            PD_HIP(hipMemcpyAsync(dad.data(), c->dOutDad.p, dad.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            PD_HIP(hipMemcpyAsync(fl.data(), c->dOutFl.p, fl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        }
+        PD_HIP(hipEventRecord(s2End, c->stream));
+        PD_HIP(hipStreamSynchronize(c->stream));
+
+        float ms1 = 0, ms2 = 0;
+        PD_HIP(hipEventElapsedTime(&ms1, run.s1Begin, run.s1End));
+        PD_HIP(hipEventElapsedTime(&ms2, s2Begin, s2End));
+        c->timing.stage1_ms = ms1;
+        c->timing.stage2_ms = ms2;
+        c->timing.n_cells = static_cast<uint64_t>(S) * W;
+        c->timing.n_active_pairs = s.nActivePairs;
+        c->timing.n_pair_chunks = s.nChunks;
+        c->timing.n_candidate_cells = nCells;
+        c->timing.max_life = s.maxLife;
+
+        pd_calls * pc = static_cast<pd_calls *>(std::calloc(1, sizeof(pd_calls)));
+        pc->n_calls = n;
+        pc->n_samples = S;
+        std::vector<uint32_t> u(n);
+        std::vector<double> d(n);
+        std::vector<uint8_t> f(n);
+        const uint32_t shift = s.shift, firstPos = s.firstPos;
+#define PD_FILL_U(dst, expr) for (uint32_t i = 0; i < n; ++i) { const pd::CellState & cs = cells[emit[i]]; u[i] = (expr); } pc->dst = mallocCopy(u);
+        PD_FILL_U(initial_length, (uint32_t)cs.initLen)
+        PD_FILL_U(iterations, (uint32_t)cs.iterations)
+        PD_FILL_U(deletion_length, cs.len)
+        PD_FILL_U(window_position, firstPos + (uint32_t)cs.window * shift - 1u)
+        PD_FILL_U(position, c->cfg.window_wise_output ? firstPos + (uint32_t)cs.window * shift - 1u : cs.suppStart)
+        PD_FILL_U(end_position, c->cfg.window_wise_output ? 0u : cs.suppEnd)
+#undef PD_FILL_U
+        for (uint32_t i = 0; i < n; ++i) d[i] = cells[emit[i]].logLR;
+        pc->likelihood_ratio = mallocCopy(d);
+        for (uint32_t i = 0; i < n; ++i) d[i] = cells[emit[i]].freq;
+        pc->frequency = mallocCopy(d);
+        for (uint32_t i = 0; i < n; ++i)
+        {
+            // sample-number filter (reference utils_popdel.h:707-718, genotype_deletion_popdel_call.h:723-724)
+            const unsigned dataSamples = S - cells[emit[i]].lowCovSamples;
+            f[i] = (static_cast<double>(dataSamples) / S >= c->cfg.min_sample_fraction) ? 0 : 4;
+        }
+        pc->filter = mallocCopy(f);
+        pc->pl = mallocCopy(pl);
+        pc->lad = mallocCopy(lad);
+        pc->dad = mallocCopy(dad);
+        pc->first_last = mallocCopy(fl);
+        *out = pc;
+    }
+    catch (const HipError & e)
+    {
+        rc = fail(c, "pd_segment_collect: " + e.what);
+    }
+    if (s2Begin)
+        (void)hipEventDestroy(s2Begin);
+    if (s2End)
+        (void)hipEventDestroy(s2End);
+    (void)hipEventDestroy(run.s1Begin);
+    (void)hipEventDestroy(run.s1End);
+    if (s.ownedBySubmit)
+        c->staged.erase(sit);
+    return rc;
+}
+
+void pd_calls_free(pd_calls * pc)
+{
+    if (!pc)
+        return;
+    std::free(pc->initial_length);
+    std::free(pc->iterations);
+    std::free(pc->deletion_length);
+    std::free(pc->likelihood_ratio);
+    std::free(pc->frequency);
+    std::free(pc->window_position);
+    std::free(pc->position);
+    std::free(pc->end_position);
+    std::free(pc->filter);
+    std::free(pc->pl);
+    std::free(pc->lad);
+    std::free(pc->dad);
+    std::free(pc->first_last);
+    std::free(pc);
+}
+
+int pd_stage1_last(pd_ctx * c, pd_stage1_view * out)
+{
+    if (!c || !out)
+        return 1;
+    try
+    {
+        PD_HIP(hipSetDevice(c->device));
+        const uint32_t W = c->lastWindows, S = c->nSamples;
+        const size_t cells = static_cast<size_t>(W) * S;
+        std::vector<int32_t> q(cells);
+        std::vector<uint8_t> f(cells);
+        PD_HIP(hipStreamSynchronize(c->stream));
+        if (cells)
+        {
+            PD_HIP(hipMemcpy(q.data(), c->dQ3.p, cells * sizeof(int32_t), hipMemcpyDeviceToHost));
+            PD_HIP(hipMemcpy(f.data(), c->dFlags.p, cells, hipMemcpyDeviceToHost));
+        }
+        // device layout is [sample][window]; the view is [window][sample]
+        c->hQ3View.resize(cells);
+        c->hFlagsView.resize(cells);
+        for (uint32_t s = 0; s < S; ++s)
+            for (uint32_t w = 0; w < W; ++w)
+            {
+                c->hQ3View[static_cast<size_t>(w) * S + s] = q[static_cast<size_t>(s) * W + w];
+                c->hFlagsView[static_cast<size_t>(w) * S + s] = f[static_cast<size_t>(s) * W + w];
+            }
+        out->n_windows = W;
+        out->n_samples = S;
+        out->q3 = c->hQ3View.data();
+        out->flags = c->hFlagsView.data();
+    }
+    catch (const HipError & e)
+    {
+        return fail(c, "pd_stage1_last: " + e.what);
+    }
+    return 0;
+}
+
+int pd_last_timing(pd_ctx * c, pd_timing * out)
+{
+    if (!c || !out)
+        return 1;
+    *out = c->timing;
+    return 0;
+}
+
+const char * pd_last_error(const pd_ctx * c) { return c ? c->error.c_str() : g_createError.c_str(); }
+
+const char * pd_backend_name(void) { return "hip-gfx950"; }
+
+int pd_abi_version(void) { return PD_ABI_VERSION; }
+
+}  // extern "C"

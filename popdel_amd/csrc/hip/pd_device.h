@@ -1,0 +1,131 @@
+// Device-side data layout and kernel launch interface of the MI355X joint-calling backend.
+// (Private to libpopdel_hip.so; the public boundary is include/popdel_hip.h.)
+#ifndef PD_DEVICE_H_
+#define PD_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pd {
+
+// ---- limits --------------------------------------------------------------------------------------------------
+constexpr int kMaxCandidatesPerWindow = 8;     // candidate deletion lengths kept per window
+constexpr int kMaxIterationsCap = 64;          // visited-table capacity per cell (params.iterations <= this)
+constexpr int kStage1Block = 256;              // windows per workgroup in the stage-1 scan
+constexpr int kStage1LdsPairs = 3072;          // pair chunks staged in LDS per stage-1 workgroup
+constexpr int kSampleTile = 256;               // samples per workgroup in the stage-2 kernels
+
+// x87 `expl` underflows to zero below ln(2^-16446); the reference's "likelihood too small" reset hangs off that.
+#define PD_X87_EXP_UNDERFLOW (-11399.498531488860558)
+#define PD_LOG_PSEUDO (-23.025850929940457)     // ln(1e-10)
+
+// ---- per read group constants (HBM, read-mostly) ----------------------------------------------------------------
+struct RgConst
+{
+    int      median;
+    int      readLength;
+    int      histOffset;
+    int      histLen;
+    int      lowerQ;
+    int      upperQ;
+    unsigned maxLoad;
+    unsigned minInitDelLen;
+    double   stddev;
+    double   minProb;
+    uint64_t histBase;      // offset (in doubles) of this read group's table in the histogram pool
+};
+
+// A read pair chunk: active in window w iff it lies in the chunk range of w and off > w.
+struct PairDO
+{
+    int32_t  dev;
+    uint32_t off;
+};
+
+// ---- everything the kernels need to find the pairs of a (read group, window) --------------------------------------
+struct SegmentView
+{
+    const PairDO *   pairs;        // [nChunks]  dev + off, read-group major, ordered by `on`
+    const uint32_t * start;        // [nChunks]  startPos
+    const uint64_t * rgBase;       // [nRg]      first chunk of the read group
+    const uint32_t * winStart;     // [nRg * (W + 1)] first chunk (relative to rgBase) whose on >= w
+    uint32_t         nWindows;
+    uint32_t         maxLife;      // K: a chunk lives at most K windows
+    uint32_t         firstPos;
+    uint32_t         shift;
+};
+
+struct CohortView
+{
+    const RgConst *  rg;
+    const double *   hist;         // histogram pool
+    const uint32_t * sampleRg;     // [nSamples + 1]
+    uint32_t         nSamples;
+    uint32_t         nRg;
+    int              minThreshold; // min over read groups of minInitDelLen
+};
+
+// ---- stage 2 per-cell state -------------------------------------------------------------------------------------
+enum CellPhase : int
+{
+    kCellDead = 0,
+    kCellIterating = 1,
+    kCellConverged = 2,       // left the EM loop through the visited-table test
+    kCellStopped = 3,         // left the EM loop otherwise (cap, len < minLen, freq == 0)
+    kCellFinal = 4,           // passed the post-loop test, final pass runs
+    kCellEmit = 5             // call is emitted
+};
+
+struct CellState
+{
+    int      window;
+    int      initLen;
+    int      phase;
+    int      iterations;
+    unsigned len, prevLen;
+    double   freq, prevFreq;
+    double   gt[3], prevGt[3];
+    double   logLR, prevLogLR;
+    int      restoreZeroShifts;   // "keep previous estimate": shifts go back to zero
+    int      nVisited;
+    int      visitedLen[kMaxIterationsCap];
+    double   visitedFreq[kMaxIterationsCap];
+    // reductions written by the per-sample kernels (fixed order: tile 0 .. nTiles-1)
+    unsigned suppCapacity;        // upper bound of supporting pairs (a5 "total")
+    unsigned suppCount;
+    uint64_t suppBase;
+    unsigned suppStart, suppEnd;
+    unsigned lowCovSamples;
+    // RG 0's per-read-group triple (log domain); kind: 0 = normal, 1 = high coverage (all zero in the reference)
+    double   rg0[3];
+    int      rg0Kind;
+};
+
+// Device buffers and parameters of the stage-2 kernels.
+struct Stage2Buffers
+{
+    CellState * cells;
+    unsigned    nCells;
+    double *    dl;          // [nCells][S][3]  log-domain data likelihood triples
+    int *       shifts;      // [nCells][nRg]   reference shifts
+    double *    partial;     // [nCells][nTiles][4] per-tile reduction slots
+    unsigned *  counters;    // [nCells][4] integer accumulators (a5 count, a5 total, low coverage samples, unused)
+    unsigned    nTiles;
+    // final-pass outputs, [nCells][S][k]
+    uint32_t *  pl;
+    uint32_t *  lad;
+    uint32_t *  dad;
+    uint32_t *  fl;
+    unsigned *  suppFirst;   // support pools
+    unsigned *  suppLast;
+    // parameters
+    unsigned    minLen;
+    unsigned    maxIterations;
+    double      minLR;
+    double      minSampleFraction;
+    int         somatic;
+    int         windowWise;
+};
+
+}  // namespace pd
+#endif

@@ -1,0 +1,1005 @@
+// Stage 2 of the joint-calling hot path on gfx950: candidate deletion lengths per window (clustering of the per-sample
+// Q3 values), then for every (window, candidate length) cell the EM over deletion length / allele frequency, the final
+// genotyping pass and the likelihood-ratio test.
+//
+// Reference behaviour: genotype_deletion_popdel_call.h:58-87 (clustering), :93-133 (initial allele frequency),
+// :179-253 / :255-337 (data likelihoods), :343-380 (genotype priors), :388-462 (deletion-length update),
+// :467-485 (allele-frequency update), :490-508 (likelihood ratio), :514-529 (support percentiles), :556-728 (driver);
+// utils_popdel.h:1511-1528 (phred-scaled likelihoods), :690-718 (no-data samples, sample-number filter).
+//
+// Numerics: the reference keeps the per-sample genotype triples as x87 `long double` exp(logL - max), which stay
+// non-zero down to e^-11399. FP64 cannot hold that, so the triples live here in the LOG domain (d_k = logL_k - max,
+// FP64) and every consumer is rewritten for that representation; the reference's "triple contains a zero" reset is
+// reproduced by comparing d_k with the x87 underflow threshold.
+//
+// Work split: one lane per (cell, sample); sums over samples are reduced per 256-sample tile inside the workgroup and
+// the per-tile partials are added in tile order by one lane per cell, so results do not depend on scheduling.
+#include "pd_device.h"
+
+namespace pd {
+
+#define PD_LN2 0.69314718055994530942
+#define PD_LOG10_2 0.30102999566398119521
+
+
+__device__ __forceinline__ double lookupI(const RgConst & rc, const double * hist, int deviation)
+{
+    int i = deviation + rc.median - rc.histOffset;
+    if (i <= 0 || i + 1 >= rc.histLen)
+        return rc.minProb;
+    return hist[rc.histBase + (unsigned)i];
+}
+
+__device__ __forceinline__ void priors(double f, int somatic, double * g)
+{
+    const double pseudo = 0.0000000001;
+    if (!somatic)
+    {
+        g[0] = fmax((1 - f) * (1 - f), pseudo);
+        g[1] = fmax(2 * f * (1 - f), pseudo);
+        g[2] = fmax(f * f, pseudo);
+    }
+    else if (f <= 0.4)
+    {
+        g[0] = fmax(1 - 2 * f + pseudo, pseudo);
+        g[1] = fmax(2 * f - 2 * pseudo, pseudo);
+        g[2] = pseudo;
+    }
+    else if (f < 0.75)
+    {
+        g[0] = pseudo;
+        g[1] = 1.;
+        g[2] = pseudo;
+    }
+    else
+    {
+        g[0] = pseudo;
+        g[1] = pseudo;
+        g[2] = 1.;
+    }
+}
+
+// Iteration helper over the active pairs of (read group, window).
+struct PairRange
+{
+    const PairDO *   p;
+    const uint32_t * st;
+    unsigned         begin, end;
+};
+
+__device__ __forceinline__ PairRange pairRange(const SegmentView & seg, unsigned rg, unsigned w)
+{
+    const unsigned K = seg.maxLife;
+    const unsigned wlo = (w + 1 >= K) ? (w + 1 - K) : 0u;
+    const uint32_t * ws = seg.winStart + (size_t)rg * (seg.nWindows + 1);
+    PairRange r;
+    r.p = seg.pairs + seg.rgBase[rg];
+    r.st = seg.start + seg.rgBase[rg];
+    r.begin = ws[wlo];
+    r.end = ws[w + 1];
+    return r;
+}
+
+__device__ __forceinline__ unsigned countActive(const PairRange & r, unsigned w)
+{
+    unsigned c = 0;
+    for (unsigned i = r.begin; i < r.end; ++i)
+        c += (r.p[i].off > w) ? 1u : 0u;
+    return c;
+}
+
+// ---- block reductions (256 threads, deterministic) -----------------------------------------------------------------
+__device__ __forceinline__ double waveSum(double v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double blockSum(double v, double * scratch)
+{
+    v = waveSum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0)
+        scratch[wv] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i)
+            t += scratch[i];
+    return t;     // valid in thread 0
+}
+
+// =====================================================================================================================
+// Candidate lengths: sort the valid Q3 values of a flagged window, chain-cluster them (gap < 50), keep cluster means
+// above the threshold. The threshold table is indexed by POSITION IN THE SORTED ARRAY (reference :65,72,80).
+// One workgroup per flagged window; bitonic sort in a global scratch row (L2 resident).
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void clusterKernel(const int32_t * __restrict__ q3, const uint8_t * __restrict__ flags,
+                                                     const int * __restrict__ flaggedWindows, unsigned W, CohortView co,
+                                                     int * __restrict__ scratch, unsigned rowLen,
+                                                     int * __restrict__ candLen, int * __restrict__ candCount)
+{
+    __shared__ unsigned nValid;
+    const unsigned fw = blockIdx.x;
+    const unsigned w = (unsigned)flaggedWindows[fw];
+    int * row = scratch + (size_t)fw * rowLen;
+    if (threadIdx.x == 0)
+        nValid = 0;
+    __syncthreads();
+    for (unsigned s = threadIdx.x; s < co.nSamples; s += blockDim.x)
+    {
+        const size_t cell = (size_t)s * W + w;
+        if (flags[cell] & 2u)
+        {
+            unsigned slot = atomicAdd(&nValid, 1u);
+            row[slot] = q3[cell];
+        }
+    }
+    __syncthreads();
+    const unsigned m = nValid;
+    unsigned P = 1;
+    while (P < m)
+        P <<= 1;
+    for (unsigned i = m + threadIdx.x; i < P; i += blockDim.x)
+        row[i] = 0x7fffffff;
+    __syncthreads();
+    for (unsigned k = 2; k <= P; k <<= 1)
+    {
+        for (unsigned j = k >> 1; j > 0; j >>= 1)
+        {
+            for (unsigned i = threadIdx.x; i < P; i += blockDim.x)
+            {
+                unsigned ixj = i ^ j;
+                if (ixj > i)
+                {
+                    int a = row[i], b = row[ixj];
+                    bool up = (i & k) == 0;
+                    if ((a > b) == up)
+                    {
+                        row[i] = b;
+                        row[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0)
+    {
+        int nc = 0;
+        if (m > 0)
+        {
+            int sum = row[0];
+            int n = 1;
+            unsigned threshold = co.rg[0].minInitDelLen;
+            for (unsigned i = 1; i < m; ++i)
+            {
+                if (row[i - 1] + 50 > row[i])
+                {
+                    sum += row[i];
+                    ++n;
+                    threshold = min(threshold, co.rg[i].minInitDelLen);
+                }
+                else
+                {
+                    if (sum / n > (int)threshold)
+                    {
+                        int v = sum / n;
+                        bool dup = false;
+                        for (int c = 0; c < nc && c < kMaxCandidatesPerWindow; ++c)
+                            dup |= candLen[fw * kMaxCandidatesPerWindow + c] == v;
+                        if (!dup)
+                        {
+                            if (nc < kMaxCandidatesPerWindow)
+                                candLen[fw * kMaxCandidatesPerWindow + nc] = v;
+                            ++nc;
+                        }
+                    }
+                    sum = row[i];
+                    n = 1;
+                    threshold = co.rg[i].minInitDelLen;
+                }
+            }
+            if (sum / n > (int)threshold)
+            {
+                int v = sum / n;
+                bool dup = false;
+                for (int c = 0; c < nc && c < kMaxCandidatesPerWindow; ++c)
+                    dup |= candLen[fw * kMaxCandidatesPerWindow + c] == v;
+                if (!dup)
+                {
+                    if (nc < kMaxCandidatesPerWindow)
+                        candLen[fw * kMaxCandidatesPerWindow + nc] = v;
+                    ++nc;
+                }
+            }
+        }
+        candCount[fw] = nc;      // cluster means are produced in ascending order already
+    }
+}
+
+// =====================================================================================================================
+// Cell initialisation: first allele-frequency estimate (integer counts), low-coverage sample count.
+// =====================================================================================================================
+__global__ __launch_bounds__(kSampleTile) void cellInitKernel(SegmentView seg, CohortView co, Stage2Buffers b,
+                                                              const uint8_t * __restrict__ flags)
+{
+    __shared__ unsigned acc[3];
+    const unsigned cellIdx = blockIdx.y;
+    const unsigned s = blockIdx.x * kSampleTile + threadIdx.x;
+    if (threadIdx.x < 3)
+        acc[threadIdx.x] = 0;
+    __syncthreads();
+    const CellState & cs = b.cells[cellIdx];
+    const unsigned w = (unsigned)cs.window;
+    const unsigned L = (unsigned)cs.initLen;
+    if (s < co.nSamples)
+    {
+        unsigned count = 0, total = 0;
+        for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
+        {
+            const RgConst rc = co.rg[rg];
+            PairRange r = pairRange(seg, rg, w);
+            unsigned n = countActive(r, w);
+            if (n == 0 || n >= rc.maxLoad)
+                continue;
+            total += n;
+            int windowBegin = max((int)L / 2, (int)floor((L - 2 * rc.stddev) + 0.5));
+            int windowEnd = (int)(L + 2 * rc.stddev);
+            for (unsigned i = r.begin; i < r.end; ++i)
+                if (r.p[i].off > w)
+                {
+                    int dv = r.p[i].dev;
+                    count += (dv > windowBegin && dv < windowEnd) ? 1u : 0u;
+                }
+        }
+        if (count)
+            atomicAdd(&acc[0], count);
+        if (total)
+            atomicAdd(&acc[1], total);
+        if (flags[(size_t)s * seg.nWindows + w] & 1u)
+            atomicAdd(&acc[2], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && acc[threadIdx.x])
+        atomicAdd(&b.counters[cellIdx * 4 + threadIdx.x], acc[threadIdx.x]);
+}
+
+__global__ void cellInitFinishKernel(Stage2Buffers b)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= b.nCells)
+        return;
+    CellState & cs = b.cells[c];
+    const unsigned count = b.counters[c * 4 + 0], total = b.counters[c * 4 + 1];
+    cs.lowCovSamples = b.counters[c * 4 + 2];
+    cs.suppCapacity = total;
+    cs.suppCount = 0;
+    double freq = (total == 0u) ? 0.0 : (double)count / total;
+    cs.freq = freq;
+    cs.len = (unsigned)cs.initLen;
+    cs.iterations = 0;
+    cs.nVisited = 0;
+    cs.restoreZeroShifts = 0;
+    cs.rg0Kind = 0;
+    cs.rg0[0] = cs.rg0[1] = cs.rg0[2] = 0;
+    if (freq == 0)
+    {
+        cs.phase = kCellDead;
+        return;
+    }
+    priors(freq, b.somatic, cs.gt);
+    cs.prevFreq = freq;
+    cs.prevLen = cs.len;
+    cs.prevGt[0] = cs.gt[0];
+    cs.prevGt[1] = cs.gt[1];
+    cs.prevGt[2] = cs.gt[2];
+    cs.phase = kCellIterating;
+}
+
+// Exclusive scan of the support capacities (single lane; the cell list is short).
+__global__ void suppScanKernel(Stage2Buffers b)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0)
+        return;
+    uint64_t off = 0;
+    for (unsigned c = 0; c < b.nCells; ++c)
+    {
+        b.cells[c].suppBase = off;
+        off += b.cells[c].suppCapacity;
+    }
+}
+
+// =====================================================================================================================
+// Data likelihoods of one sample given (len, reference shifts), EM flavour (reference :179-253).
+// mode 0: current estimate (cells in kCellIterating); mode 1: previous estimate with zero shifts (kCellConverged).
+// Also accumulates the per-sample term of the allele-frequency update with the cell's current priors.
+// =====================================================================================================================
+__device__ __forceinline__ void finishTriple(double * d, const double * logL, unsigned nUsed, bool allRefEqDel)
+{
+    const double mx = fmax(fmax(logL[0], logL[1]), logL[2]);
+    d[0] = logL[0] - mx;
+    d[1] = logL[1] - mx;
+    d[2] = logL[2] - mx;
+    bool reset = (d[0] < PD_X87_EXP_UNDERFLOW) || (d[1] < PD_X87_EXP_UNDERFLOW) || (d[2] < PD_X87_EXP_UNDERFLOW);
+    if (allRefEqDel && nUsed > 0)
+    {
+        // ref == del for every pair: in x87 arithmetic the het term sits a hair above the other two
+        // (log(2.0) is a double constant), so the three values are NOT equal there.
+        d[0] = d[1] = d[2] = 0;
+    }
+    else if (d[0] == d[1] && d[0] == d[2])
+    {
+        reset = true;
+    }
+    if (reset)
+    {
+        d[0] = 0;
+        d[1] = PD_LOG_PSEUDO;
+        d[2] = PD_LOG_PSEUDO;
+    }
+}
+
+__global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, CohortView co, Stage2Buffers b, int mode)
+{
+    __shared__ double red[4];
+    const unsigned cellIdx = blockIdx.y;
+    CellState & cs = b.cells[cellIdx];
+    const int wantPhase = mode == 0 ? kCellIterating : kCellConverged;
+    if (cs.phase != wantPhase)
+        return;
+    const unsigned s = blockIdx.x * kSampleTile + threadIdx.x;
+    const unsigned w = (unsigned)cs.window;
+    const int len = (int)(mode == 0 ? cs.len : cs.prevLen);
+    double term = 0;
+    if (s < co.nSamples)
+    {
+        double logL[3] = {0, 0, 0};
+        unsigned nUsed = 0;
+        bool allEq = true;
+        for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
+        {
+            const RgConst rc = co.rg[rg];
+            PairRange r = pairRange(seg, rg, w);
+            const unsigned n = countActive(r, w);
+            if (n >= rc.maxLoad)
+            {
+                if (rg == 0)
+                {
+                    cs.rg0Kind = 1;
+                    cs.rg0[0] = cs.rg0[1] = cs.rg0[2] = 0;
+                }
+                continue;
+            }
+            const int refShift = (mode == 0) ? b.shifts[(size_t)cellIdx * co.nRg + rg] : 0;
+            double rgSum[3] = {0, 0, 0};
+            for (unsigned i = r.begin; i < r.end; ++i)
+            {
+                if (!(r.p[i].off > w))
+                    continue;
+                const int dv = r.p[i].dev;
+                const double ref = lookupI(rc, co.hist, dv - refShift);
+                const double del = lookupI(rc, co.hist, dv - len);
+                const double g0 = log(ref);
+                const double g1 = log(ref + del) - PD_LN2;
+                const double g2 = log(del);
+                rgSum[0] += g0;
+                rgSum[1] += g1;
+                rgSum[2] += g2;
+                allEq = allEq && (ref == del);
+                ++nUsed;
+            }
+            logL[0] += rgSum[0];
+            logL[1] += rgSum[1];
+            logL[2] += rgSum[2];
+            if (rg == 0)
+            {
+                const double m = fmax(fmax(rgSum[0], rgSum[1]), rgSum[2]);
+                cs.rg0Kind = 0;
+                cs.rg0[0] = rgSum[0] - m;
+                cs.rg0[1] = rgSum[1] - m;
+                cs.rg0[2] = rgSum[2] - m;
+            }
+        }
+        double d[3];
+        finishTriple(d, logL, nUsed, allEq);
+        double * out = b.dl + ((size_t)cellIdx * co.nSamples + s) * 3;
+        out[0] = d[0];
+        out[1] = d[1];
+        out[2] = d[2];
+        if (mode == 0)
+        {
+            const double p0 = exp(d[0]) * cs.gt[0];
+            const double p1 = exp(d[1]) * cs.gt[1];
+            const double p2 = exp(d[2]) * cs.gt[2];
+            const double pAll = p0 + p1 + p2;
+            term = (p1 + 2 * p2) / pAll;
+        }
+    }
+    if (mode == 0)
+    {
+        const double t = blockSum(term, red);
+        if (threadIdx.x == 0)
+            b.partial[((size_t)cellIdx * b.nTiles + blockIdx.x) * 4 + 2] = t;
+    }
+}
+
+// =====================================================================================================================
+// EM loop head (reference :598-604): loop condition, bookkeeping of the visited table and the previous estimate.
+// =====================================================================================================================
+__global__ void cellLoopHeadKernel(Stage2Buffers b)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= b.nCells)
+        return;
+    CellState & cs = b.cells[c];
+    if (cs.phase != kCellIterating)
+        return;
+    if (!(cs.len >= b.minLen && (unsigned)cs.iterations < b.maxIterations))
+    {
+        cs.phase = kCellStopped;
+        return;
+    }
+    ++cs.iterations;
+    int slot = -1;
+    for (int i = 0; i < cs.nVisited; ++i)
+        if (cs.visitedLen[i] == (int)cs.len)
+            slot = i;
+    if (slot < 0)
+        slot = cs.nVisited++;
+    cs.visitedLen[slot] = (int)cs.len;
+    cs.visitedFreq[slot] = cs.freq;
+    cs.prevLen = cs.len;
+    cs.prevFreq = cs.freq;
+    cs.prevGt[0] = cs.gt[0];
+    cs.prevGt[1] = cs.gt[1];
+    cs.prevGt[2] = cs.gt[2];
+}
+
+// =====================================================================================================================
+// Deletion-length / reference-shift update (reference :388-462). The per-read-group weights come from RG 0's triple
+// for EVERY read group (the reference never advances that iterator).
+// =====================================================================================================================
+__global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, CohortView co, Stage2Buffers b)
+{
+    __shared__ double red[4];
+    const unsigned cellIdx = blockIdx.y;
+    const CellState & cs = b.cells[cellIdx];
+    if (cs.phase != kCellIterating)
+        return;
+    const unsigned s = blockIdx.x * kSampleTile + threadIdx.x;
+    const unsigned w = (unsigned)cs.window;
+    const int len = (int)cs.len;
+    double sumDel = 0, wSumDel = 0;
+    if (s < co.nSamples)
+    {
+        const double * d = b.dl + ((size_t)cellIdx * co.nSamples + s) * 3;
+        const double g0 = cs.gt[0], g1 = cs.gt[1], g2 = cs.gt[2];
+        const double aSum = exp(d[0]) * g0 + exp(d[1]) * g1 + exp(d[2]) * g2;
+        const double a1 = d[1] + log(g1) - log(aSum);
+        const double a2 = d[2] + log(g2) - log(aSum);
+        const double ea1 = exp(a1), ea2 = exp(a2);
+        // weights of the reference model, shared by all read groups
+        bool rgNan = cs.rg0Kind == 1;
+        double ea0Rg = 0, ea1Rg = 0;
+        if (!rgNan)
+        {
+            const double aSumRg = exp(cs.rg0[0]) * g0 + exp(cs.rg0[1]) * g1 + exp(cs.rg0[2]) * g2;
+            const double l0 = (cs.rg0[0] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : cs.rg0[0];
+            const double l1 = (cs.rg0[1] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : cs.rg0[1];
+            const double a0Rg = l0 + log(g0) - log(aSumRg);
+            const double a1Rg = l1 + log(g1) - log(aSumRg);
+            ea0Rg = exp(a0Rg);
+            ea1Rg = exp(a1Rg);
+            rgNan = isnan(ea0Rg) || isnan(ea1Rg);
+        }
+        for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
+        {
+            const RgConst rc = co.rg[rg];
+            PairRange r = pairRange(seg, rg, w);
+            const unsigned n = countActive(r, w);
+            if (n >= rc.maxLoad)
+                continue;
+            int * shiftSlot = b.shifts + (size_t)cellIdx * co.nRg + rg;
+            const int refShift = *shiftSlot;
+            double sumRef = 0, wSumRef = 0;
+            for (unsigned i = r.begin; i < r.end; ++i)
+            {
+                if (!(r.p[i].off > w))
+                    continue;
+                const int dv = r.p[i].dev;
+                const double del = lookupI(rc, co.hist, dv - len);
+                const double noDel = lookupI(rc, co.hist, dv - refShift);
+                const double probDel = ea1 * del / (del + noDel) + ea2;
+                const double probRef = ea1Rg * noDel / (del + noDel) + ea0Rg;
+                sumDel += probDel;
+                sumRef += probRef;
+                wSumDel += probDel * dv;
+                wSumRef += probRef * dv;
+            }
+            int newShift;
+            const double q = wSumRef / sumRef;
+            if (rgNan || !(q > -2147483649.0 && q < 2147483648.0))
+                newShift = (int)0x80000000;          // what x86 yields for NaN / out-of-range conversions
+            else
+                newShift = (int)q;
+            if (newShift > rc.stddev || newShift < -1 * rc.stddev)
+                newShift = 0;
+            *shiftSlot = newShift;
+        }
+    }
+    const double t0 = blockSum(sumDel, red);
+    const double t1 = blockSum(wSumDel, red);
+    if (threadIdx.x == 0)
+    {
+        double * p = b.partial + ((size_t)cellIdx * b.nTiles + blockIdx.x) * 4;
+        p[0] = t0;
+        p[1] = t1;
+    }
+}
+
+__global__ void cellLenFinishKernel(Stage2Buffers b)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= b.nCells)
+        return;
+    CellState & cs = b.cells[c];
+    if (cs.phase != kCellIterating)
+        return;
+    double sumDel = 0, wSumDel = 0;
+    for (unsigned t = 0; t < b.nTiles; ++t)
+    {
+        const double * p = b.partial + ((size_t)c * b.nTiles + t) * 4;
+        sumDel += p[0];
+        wSumDel += p[1];
+    }
+    unsigned len;
+    if (sumDel == 0)
+        len = 0;
+    else
+    {
+        const double l = wSumDel / sumDel;
+        len = (l < 0) ? 0u : (unsigned)round(l);
+    }
+    cs.len = len;
+}
+
+// Allele-frequency update and convergence test (reference :623-659).
+__global__ void cellFreqFinishKernel(Stage2Buffers b, unsigned nSamples)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= b.nCells)
+        return;
+    CellState & cs = b.cells[c];
+    if (cs.phase != kCellIterating)
+        return;
+    double sum = 0;
+    for (unsigned t = 0; t < b.nTiles; ++t)
+        sum += b.partial[((size_t)c * b.nTiles + t) * 4 + 2];
+    const double freq = sum / 2.0 / nSamples;
+    cs.freq = freq;
+    if (freq == 0)
+    {
+        cs.phase = kCellStopped;
+        return;
+    }
+    priors(freq, b.somatic, cs.gt);
+    for (int i = 0; i < cs.nVisited; ++i)
+        if (cs.visitedLen[i] == (int)cs.len && fabs(cs.visitedFreq[i] - freq) <= 0.0001)
+        {
+            cs.phase = kCellConverged;
+            break;
+        }
+}
+
+// =====================================================================================================================
+// Likelihood-ratio terms (reference :490-508). which: 0 = current priors, 1 = previous priors.
+// =====================================================================================================================
+__global__ __launch_bounds__(kSampleTile) void lrKernel(CohortView co, Stage2Buffers b, int wantPhase, int which)
+{
+    __shared__ double red[4];
+    const unsigned cellIdx = blockIdx.y;
+    const CellState & cs = b.cells[cellIdx];
+    if (cs.phase != wantPhase)
+        return;
+    const unsigned s = blockIdx.x * kSampleTile + threadIdx.x;
+    double del = 0, noDel = 0;
+    if (s < co.nSamples)
+    {
+        const double * d = b.dl + ((size_t)cellIdx * co.nSamples + s) * 3;
+        const double * g = which == 0 ? cs.gt : cs.prevGt;
+        const double t0 = exp(d[0]), t1 = exp(d[1]), t2 = exp(d[2]);
+        const double p0 = t0 * g[0], p1 = t1 * g[1], p2 = t2 * g[2];
+        const double pAll = p0 + p1 + p2;
+        const double a0 = p0 / pAll, a1 = p1 / pAll, a2 = p2 / pAll;
+        del = log(a0 * t0 + a1 * t1 + a2 * t2);
+        noDel = d[0];
+    }
+    const double s0 = blockSum(del, red);
+    const double s1 = blockSum(noDel, red);
+    if (threadIdx.x == 0)
+    {
+        double * p = b.partial + ((size_t)cellIdx * b.nTiles + blockIdx.x) * 4;
+        p[0] = s0;
+        p[1] = s1;
+    }
+}
+
+__device__ __forceinline__ double sumLR(const Stage2Buffers & b, unsigned c)
+{
+    double del = 0, noDel = 0;
+    for (unsigned t = 0; t < b.nTiles; ++t)
+    {
+        const double * p = b.partial + ((size_t)c * b.nTiles + t) * 4;
+        del += p[0];
+        noDel += p[1];
+    }
+    return del - noDel;
+}
+
+// step 0: store LR of the current estimate; step 1: store LR of the previous estimate and keep the better one.
+__global__ void cellConvergedKernel(Stage2Buffers b, int step)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= b.nCells)
+        return;
+    CellState & cs = b.cells[c];
+    if (cs.phase != kCellConverged)
+        return;
+    if (step == 0)
+    {
+        cs.logLR = sumLR(b, c);
+        return;
+    }
+    cs.prevLogLR = sumLR(b, c);
+    if (cs.prevLogLR > cs.logLR)
+    {
+        cs.len = cs.prevLen;
+        cs.freq = cs.prevFreq;
+        cs.restoreZeroShifts = 1;       // prevShifts is the all-zero vector captured before the loop
+    }
+}
+
+// Post-loop test (reference :661-664).
+__global__ void cellPostLoopKernel(Stage2Buffers b)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= b.nCells)
+        return;
+    CellState & cs = b.cells[c];
+    if (cs.phase != kCellConverged && cs.phase != kCellStopped && cs.phase != kCellIterating)
+        return;
+    if (cs.freq < 0.0000000001 || cs.len < b.minLen)
+        cs.phase = kCellDead;
+    else
+        cs.phase = kCellFinal;
+}
+
+// =====================================================================================================================
+// Final pass (reference :255-337): data likelihoods once more, log10 sums -> phred-scaled likelihoods, LAD / DAD
+// counts, first/last, and the pool of supporting pair starts / ends.
+// =====================================================================================================================
+__global__ __launch_bounds__(kSampleTile) void finalKernel(SegmentView seg, CohortView co, Stage2Buffers b,
+                                                           const uint8_t * __restrict__ flags)
+{
+    const unsigned cellIdx = blockIdx.y;
+    CellState & cs = b.cells[cellIdx];
+    if (cs.phase != kCellFinal)
+        return;
+    const unsigned s = blockIdx.x * kSampleTile + threadIdx.x;
+    if (s >= co.nSamples)
+        return;
+    const unsigned w = (unsigned)cs.window;
+    const int len = (int)cs.len;
+    double logL[3] = {0, 0, 0}, gtLogs[3] = {0, 0, 0};
+    unsigned lad[3] = {0, 0, 0}, dad[5] = {0, 0, 0, 0, 0};
+    unsigned nUsed = 0;
+    bool allEq = true;
+    int delLower = 0x7fffffff, delUpper = 0;
+    unsigned mn = 0xffffffffu, mx = 0;
+    for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
+    {
+        const RgConst rc = co.rg[rg];
+        PairRange r = pairRange(seg, rg, w);
+        const unsigned n = countActive(r, w);
+        if (n >= rc.maxLoad)
+            continue;
+        const int refShift = cs.restoreZeroShifts ? 0 : b.shifts[(size_t)cellIdx * co.nRg + rg];
+        delLower = (int)((unsigned)len - (unsigned)rc.lowerQ);
+        delUpper = (int)((unsigned)len + (unsigned)rc.upperQ);
+        for (unsigned i = r.begin; i < r.end; ++i)
+        {
+            if (!(r.p[i].off > w))
+                continue;
+            const int dv = r.p[i].dev;
+            // distribution-derived class
+            if (dv > rc.upperQ)
+            {
+                if (dv < delLower)
+                    ++dad[2];
+                else if (dv <= delUpper)
+                    ++dad[3];
+                else
+                    ++dad[4];
+            }
+            else
+            {
+                if (dv < delUpper)
+                    ++dad[0];
+                else
+                    ++dad[1];
+            }
+            const double ref = lookupI(rc, co.hist, dv - refShift);
+            const double del = lookupI(rc, co.hist, dv - len);
+            if (ref >= 2 * del)
+                ++lad[0];
+            else if (del >= 2 * ref)
+                ++lad[2];
+            else
+                ++lad[1];
+            logL[0] += log(ref);
+            gtLogs[0] += log10(ref);
+            logL[1] += log(ref + del) - PD_LN2;
+            gtLogs[1] += log10(ref + del) - PD_LOG10_2;
+            logL[2] += log(del);
+            gtLogs[2] += log10(del);
+            allEq = allEq && (ref == del);
+            ++nUsed;
+            const unsigned st = r.st[i];
+            const int ins = max(0, dv + rc.median - 2 * rc.readLength);
+            mn = min(mn, st);
+            mx = max(mx, st + (unsigned)ins);
+        }
+    }
+    if (mn == 0xffffffffu)
+        mn = 0;
+    // supporting pairs use the borders of the LAST usable read group for all read groups of the sample
+    for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
+    {
+        const RgConst rc = co.rg[rg];
+        PairRange r = pairRange(seg, rg, w);
+        const unsigned n = countActive(r, w);
+        if (n >= rc.maxLoad)
+            continue;
+        for (unsigned i = r.begin; i < r.end; ++i)
+        {
+            if (!(r.p[i].off > w))
+                continue;
+            const int dv = r.p[i].dev;
+            if (dv >= delLower && dv <= delUpper)
+            {
+                const int ins = max(0, dv + rc.median - 2 * rc.readLength);
+                const unsigned slot = atomicAdd(&cs.suppCount, 1u);
+                b.suppFirst[cs.suppBase + slot] = r.st[i];
+                b.suppLast[cs.suppBase + slot] = r.st[i] + (unsigned)ins;
+            }
+        }
+    }
+    double d[3];
+    double gl[3] = {gtLogs[0], gtLogs[1], gtLogs[2]};
+    if (nUsed == 0)
+    {
+        // sum(gtLogs) == 0: reference-like triple, gtLogs stay untouched (all zero)
+        d[0] = 0;
+        d[1] = PD_LOG_PSEUDO;
+        d[2] = PD_LOG_PSEUDO;
+    }
+    else
+    {
+        const double maxGt = fmax(fmax(gl[0], gl[1]), gl[2]);
+        gl[0] -= maxGt;
+        gl[1] -= maxGt;
+        gl[2] -= maxGt;
+        if (allEq)
+        {
+            gl[0] = gl[1] = gl[2] = 0;      // x87: a hair apart, not equal; all phred values round to 0
+        }
+        else if (gl[0] == gl[1] && gl[0] == gl[2])
+        {
+            gl[0] = 0;
+            gl[1] = -10;
+            gl[2] = -10;
+        }
+        finishTriple(d, logL, nUsed, allEq);
+    }
+    const size_t o = (size_t)cellIdx * co.nSamples + s;
+    b.dl[o * 3 + 0] = d[0];
+    b.dl[o * 3 + 1] = d[1];
+    b.dl[o * 3 + 2] = d[2];
+    // phred-scaled genotype likelihoods; exp() of log10-based values as in the reference
+    uint32_t pl[3];
+    {
+        const double gTot = log10(exp(gl[0]) + exp(gl[1]) + exp(gl[2]));
+        const double p0 = -10 * (gl[0] - gTot);
+        const double p1 = -10 * (gl[1] - gTot);
+        const double p2 = -10 * (gl[2] - gTot);
+        const double mnP = fmin(fmin(p0, p1), p2);
+        pl[0] = (uint32_t)round(p0 - mnP);
+        pl[1] = (uint32_t)round(p1 - mnP);
+        pl[2] = (uint32_t)round(p2 - mnP);
+    }
+    if (flags[(size_t)s * seg.nWindows + w] & 1u)
+        pl[0] = pl[1] = pl[2] = 0;
+    for (int k = 0; k < 3; ++k)
+    {
+        b.pl[o * 3 + k] = pl[k];
+        b.lad[o * 3 + k] = lad[k];
+    }
+    for (int k = 0; k < 5; ++k)
+        b.dad[o * 5 + k] = dad[k];
+    b.fl[o * 2 + 0] = mn;
+    b.fl[o * 2 + 1] = mx;
+}
+
+// k-th smallest of an unsigned pool by 4 x 8-bit radix passes (one workgroup per cell and pool).
+__device__ unsigned radixSelect(const unsigned * v, unsigned n, unsigned k, unsigned * hist /* 256 */, unsigned * sh /* 2 */)
+{
+    unsigned prefix = 0, mask = 0;
+    for (int pass = 3; pass >= 0; --pass)
+    {
+        const int shift = pass * 8;
+        for (unsigned i = threadIdx.x; i < 256; i += blockDim.x)
+            hist[i] = 0;
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < n; i += blockDim.x)
+        {
+            const unsigned x = v[i];
+            if ((x & mask) == prefix)
+                atomicAdd(&hist[(x >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+            unsigned acc = 0, digit = 0;
+            for (digit = 0; digit < 256; ++digit)
+            {
+                if (acc + hist[digit] > k)
+                    break;
+                acc += hist[digit];
+            }
+            sh[0] = digit;
+            sh[1] = k - acc;
+        }
+        __syncthreads();
+        prefix |= sh[0] << shift;
+        mask |= 255u << shift;
+        k = sh[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+__global__ __launch_bounds__(256) void suppSelectKernel(Stage2Buffers b)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh[2];
+    CellState & cs = b.cells[blockIdx.x];
+    if (cs.phase != kCellFinal)
+        return;
+    const unsigned n = cs.suppCount;
+    if (n == 0)
+    {
+        if (threadIdx.x == 0)
+        {
+            cs.suppStart = 0;
+            cs.suppEnd = 0;
+        }
+        return;
+    }
+    const unsigned l = (unsigned)round((double)(n - 1) * 0.8);
+    const unsigned r = (unsigned)round((double)(n - 1) * (1 - 0.8));
+    const unsigned a = radixSelect(b.suppFirst + cs.suppBase, n, l, hist, sh);
+    const unsigned e = radixSelect(b.suppLast + cs.suppBase, n, r, hist, sh);
+    if (threadIdx.x == 0)
+    {
+        cs.suppStart = a;
+        cs.suppEnd = e;
+    }
+}
+
+// Likelihood-ratio test and call emission (reference :685-724).
+__global__ void cellEmitKernel(Stage2Buffers b)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= b.nCells)
+        return;
+    CellState & cs = b.cells[c];
+    if (cs.phase != kCellFinal)
+        return;
+    if (cs.suppCount == 0 || (cs.suppStart == 0 && cs.suppEnd == 0))
+    {
+        cs.phase = kCellDead;
+        return;
+    }
+    cs.logLR = sumLR(b, c);
+    cs.phase = (cs.logLR >= b.minLR) ? kCellEmit : kCellDead;
+}
+
+// Pack the per-sample outputs of the emitted cells.
+__global__ void gatherOutKernel(Stage2Buffers b, const unsigned * __restrict__ emitCells, unsigned nSamples,
+                                uint32_t * __restrict__ pl, uint32_t * __restrict__ lad, uint32_t * __restrict__ dad,
+                                uint32_t * __restrict__ fl)
+{
+    const unsigned e = blockIdx.y;
+    const unsigned c = emitCells[e];
+    const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nSamples)
+        return;
+    const size_t src = (size_t)c * nSamples + s, dst = (size_t)e * nSamples + s;
+    for (int k = 0; k < 3; ++k)
+    {
+        pl[dst * 3 + k] = b.pl[src * 3 + k];
+        lad[dst * 3 + k] = b.lad[src * 3 + k];
+    }
+    for (int k = 0; k < 5; ++k)
+        dad[dst * 5 + k] = b.dad[src * 5 + k];
+    fl[dst * 2] = b.fl[src * 2];
+    fl[dst * 2 + 1] = b.fl[src * 2 + 1];
+}
+
+// ---- host-side launch sequence ---------------------------------------------------------------------------------------
+void launchCluster(const int32_t * q3, const uint8_t * flags, const int * flaggedWindows, unsigned nFlagged, unsigned W,
+                   const CohortView & co, int * scratch, unsigned rowLen, int * candLen, int * candCount, hipStream_t st)
+{
+    if (nFlagged == 0)
+        return;
+    hipLaunchKernelGGL(clusterKernel, dim3(nFlagged), dim3(256), 0, st, q3, flags, flaggedWindows, W, co, scratch, rowLen,
+                       candLen, candCount);
+}
+
+// Phase A: first allele-frequency estimate and support-pool capacities (the host sizes the pools from them).
+void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st)
+{
+    if (b.nCells == 0)
+        return;
+    const dim3 perSample(b.nTiles, b.nCells), tile(kSampleTile);
+    const dim3 perCell((b.nCells + 127) / 128), cellBlock(128);
+    hipLaunchKernelGGL(cellInitKernel, perSample, tile, 0, st, seg, co, b, flags);
+    hipLaunchKernelGGL(cellInitFinishKernel, perCell, cellBlock, 0, st, b);
+    hipLaunchKernelGGL(suppScanKernel, dim3(1), dim3(1), 0, st, b);
+}
+
+// Phase B: EM loop, convergence comparison, final pass, support percentiles, likelihood-ratio test.
+void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st)
+{
+    if (b.nCells == 0)
+        return;
+    const dim3 perSample(b.nTiles, b.nCells), tile(kSampleTile);
+    const dim3 perCell((b.nCells + 127) / 128), cellBlock(128);
+    hipLaunchKernelGGL(dataLikKernel, perSample, tile, 0, st, seg, co, b, 0);
+    for (unsigned it = 0; it <= b.maxIterations; ++it)
+    {
+        hipLaunchKernelGGL(cellLoopHeadKernel, perCell, cellBlock, 0, st, b);
+        if (it == b.maxIterations)
+            break;                      // the last head call only retires cells that hit the iteration cap
+        hipLaunchKernelGGL(updateLenKernel, perSample, tile, 0, st, seg, co, b);
+        hipLaunchKernelGGL(cellLenFinishKernel, perCell, cellBlock, 0, st, b);
+        hipLaunchKernelGGL(dataLikKernel, perSample, tile, 0, st, seg, co, b, 0);
+        hipLaunchKernelGGL(cellFreqFinishKernel, perCell, cellBlock, 0, st, b, co.nSamples);
+    }
+    // cells that left through the visited-table test: compare with the previous estimate
+    hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellConverged, 0);
+    hipLaunchKernelGGL(cellConvergedKernel, perCell, cellBlock, 0, st, b, 0);
+    hipLaunchKernelGGL(dataLikKernel, perSample, tile, 0, st, seg, co, b, 1);
+    hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellConverged, 1);
+    hipLaunchKernelGGL(cellConvergedKernel, perCell, cellBlock, 0, st, b, 1);
+    hipLaunchKernelGGL(cellPostLoopKernel, perCell, cellBlock, 0, st, b);
+    hipLaunchKernelGGL(finalKernel, perSample, tile, 0, st, seg, co, b, flags);
+    hipLaunchKernelGGL(suppSelectKernel, dim3(b.nCells), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellFinal, 0);
+    hipLaunchKernelGGL(cellEmitKernel, perCell, cellBlock, 0, st, b);
+}
+
+void launchGatherOut(const Stage2Buffers & b, const unsigned * emitCells, unsigned nEmit, unsigned nSamples, uint32_t * pl,
+                     uint32_t * lad, uint32_t * dad, uint32_t * fl, hipStream_t st)
+{
+    if (nEmit == 0)
+        return;
+    hipLaunchKernelGGL(gatherOutKernel, dim3((nSamples + 255) / 256, nEmit), dim3(256), 0, st, b, emitCells, nSamples, pl, lad,
+                       dad, fl);
+}
+
+}  // namespace pd

@@ -1,0 +1,68 @@
+"""CPU: the C-ABI libraries export what include/popdel_hip.h declares; host-side units."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+
+from conftest import HIP_LIB, ORACLE_LIB, POPDEL_BIN, ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "popdel_hip.h")).read()
+    return sorted(set(re.findall(r"\b(pd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_by_both_libraries(built):
+    names = declared_symbols()
+    assert "pd_segment_submit" in names and "pd_ctx_create" in names
+    for path in (HIP_LIB, ORACLE_LIB):
+        lib = ctypes.CDLL(path)          # loading needs no GPU
+        for n in names:
+            assert hasattr(lib, n), (path, n)
+    from popdel_amd import capi
+    assert sorted(capi.ABI_SYMBOLS) == names
+    hip = capi.load_hip()
+    assert hip.pd_backend_name() == b"hip-gfx950" and hip.pd_abi_version() == 1
+
+
+def test_product_binary_links_only_the_hip_library(built):
+    out = subprocess.check_output(["ldd", POPDEL_BIN]).decode()
+    assert "libpopdel_hip.so" in out and "oracle" not in out
+    needed = subprocess.check_output(["readelf", "-d", HIP_LIB]).decode()
+    assert "oracle" not in needed
+
+
+def test_product_sources_do_not_reference_the_oracle():
+    for base, _, files in os.walk(os.path.join(ROOT, "popdel_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")) or f == "Makefile":
+                text = open(os.path.join(base, f)).read()
+                assert "genotype_oracle" not in text and "libpopdel_oracle" not in text and "oracle/_build" not in text, f
+
+
+def test_histogram_conditioning_matches_start_up_log(built):
+    """min_prob / quantile distances of the survey cohort's library; 4 sigma threshold = 200."""
+    from popdel_amd import synth
+    rg = synth.conditioned_readgroup(synth.Library())
+    assert rg.min_init_del_len == 200
+    assert len(rg.hist_values) == 301 and rg.hist_offset == 350
+    assert rg.lower_quantile_dist == 114 and rg.upper_quantile_dist == 112
+    assert abs(rg.min_prob - max(rg.hist_values) / 500) < 1e-18
+    assert rg.hist_values.min() >= rg.min_prob
+
+
+def test_interval_rule_matches_state_machine_inside_a_segment(built):
+    """instances_by_interval_rule() is what bench/parity inputs use; away from segment borders it must agree with the
+    host driver's event log (checked through the oracle: same calls from both descriptions)."""
+    from popdel_amd import synth
+    lib = synth.Library()
+    pos, dev = synth.sample_pairs(1000, (1000000, 1050000), lib)
+    d, s, on, off = synth.instances_by_interval_rule(pos, dev, lib, 1000020, 1000)
+    assert (off > on).all() and (np.diff(on.astype(np.int64)) >= 0).all()
+    # a pair starting exactly on a grid position is active from that window on
+    k = int(np.flatnonzero((s - 1000020) % 30 == 0)[0])
+    assert on[k] == (int(s[k]) - 1000020) // 30
+    life = (off - on).astype(int)
+    assert 6 <= life.mean() <= 10

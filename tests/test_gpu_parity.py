@@ -1,0 +1,136 @@
+"""GPU: the HIP library against the oracle through the C ABI, and the product binary against the golden fixtures."""
+import gzip
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ORACLE_LIB, POPDEL_BIN, run_call
+
+pytestmark = pytest.mark.gpu
+
+INT_KEYS = ("initial_length", "iterations", "deletion_length", "window_position", "position", "end_position", "filter", "pl",
+            "lad", "dad", "first_last")
+
+
+def both(seg, rgs, offsets, **kw):
+    from popdel_amd import capi
+    out = []
+    for lib in (capi.load_hip(), capi.load_library(ORACLE_LIB)):
+        ctx = capi.Context(lib, rgs, offsets, **kw)
+        calls = ctx.collect(ctx.submit(seg))
+        q3, fl = ctx.stage1()
+        out.append((calls, q3, fl))
+        ctx.close()
+    return out
+
+
+def assert_same(gpu, cpu):
+    (gc, gq, gf), (oc, oq, of) = gpu, cpu
+    assert np.array_equal(gf, of)
+    assert np.array_equal(gq, oq)
+    assert gc["n_calls"] == oc["n_calls"]
+    for k in INT_KEYS:
+        assert np.array_equal(gc[k], oc[k]), k
+    # north_star tolerance on the likelihood-ratio score: 1e-6
+    assert np.allclose(gc["likelihood_ratio"], oc["likelihood_ratio"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(gc["frequency"], oc["frequency"], rtol=0, atol=1e-9)
+
+
+def test_stage1_and_calls_single_deletion(built):
+    from popdel_amd import synth
+    lib = synth.Library()
+    rg = synth.conditioned_readgroup(lib)
+    n = 48
+    seg = synth.cohort_segment(n, (1000000, 1150000), 1000020, 4900, lib,
+                               deletions=lambda k, r: [synth.Deletion(1070000, 1000, [1, 2, 0][k % 3])])
+    gpu, cpu = both(seg, [rg] * n, list(range(n + 1)))
+    assert cpu[0]["n_calls"] > 20
+    assert_same(gpu, cpu)
+
+
+def test_dense_deletions_window_wise_and_somatic(built):
+    from popdel_amd import synth
+    lib = synth.Library()
+    rg = synth.conditioned_readgroup(lib)
+    n = 40
+    seg = synth.cohort_segment(n, (1000000, 1200000), 1000020, 6600, lib, deletions=synth.dense_deletions)
+    for kw in (dict(), dict(window_wise_output=True), dict(somatic=True), dict(iterations=3), dict(min_sample_fraction=1.0)):
+        gpu, cpu = both(seg, [rg] * n, list(range(n + 1)), **kw)
+        assert cpu[0]["n_calls"] > 100
+        assert_same(gpu, cpu)
+
+
+def test_ragged_inputs(built):
+    """Empty samples, low coverage, a sample above max_load, multi-read-group samples, long-lived pairs."""
+    from popdel_amd import capi, synth
+    lib = synth.Library()
+    lowcov = synth.Library(coverage=1.0)
+    rg = synth.conditioned_readgroup(lib)
+    rg_tight = synth.conditioned_readgroup(lib, max_load=20)
+    region, first, W = (1000000, 1090000), 1000020, 2900
+    dels = lambda k, r: [synth.Deletion(1040000, 2500, [2, 1, 0][k % 3]), synth.Deletion(1060000, 400, [1, 2, 2][k % 3])]
+    parts, offsets, rgs, sample_offsets = [], [0], [], [0]
+    specs = [("normal", lib, rg)] * 5 + [("empty", None, rg), ("low", lowcov, rg), ("tight", lib, rg_tight),
+                                          ("multi", lib, rg), ("multi", lib, rg)]
+    seed = 4000
+    for kind, l, r in specs:
+        n_rg = 3 if kind == "multi" else 1
+        for j in range(n_rg):
+            seed += 1
+            if l is None:
+                d = s = a = b = np.zeros(0, dtype=np.int64)
+            else:
+                sub = synth.Library(coverage=l.coverage / n_rg)
+                pos, dev = synth.sample_pairs(seed, region, sub, dels(seed, region))
+                d, s, a, b = synth.instances_by_interval_rule(pos, dev, lib, first, W)
+            parts.append((d, s, a, b))
+            offsets.append(offsets[-1] + len(d))
+            rgs.append(r)
+        sample_offsets.append(len(rgs))
+    seg = capi.Segment(first, W, np.array(offsets, np.uint64), np.concatenate([p[0] for p in parts]).astype(np.int32),
+                       np.concatenate([p[1] for p in parts]).astype(np.uint32),
+                       np.concatenate([p[2] for p in parts]).astype(np.uint32),
+                       np.concatenate([p[3] for p in parts]).astype(np.uint32))
+    gpu, cpu = both(seg, rgs, sample_offsets)
+    assert cpu[0]["n_calls"] > 10
+    assert (cpu[2] & 1).any()            # some low-coverage cells exist
+    assert_same(gpu, cpu)
+
+
+def test_no_pairs_at_all(built):
+    from popdel_amd import capi, synth
+    rg = synth.conditioned_readgroup(synth.Library())
+    z = np.zeros(0, dtype=np.uint32)
+    seg = capi.Segment(1000020, 50, np.zeros(4, np.uint64), z.astype(np.int32), z, z, z)
+    gpu, cpu = both(seg, [rg] * 3, [0, 1, 2, 3])
+    assert gpu[0]["n_calls"] == 0
+    assert_same(gpu, cpu)
+
+
+def golden_text(name):
+    path = os.path.join(GOLDEN, name)
+    return gzip.open(path, "rt").read() if name.endswith(".gz") else open(path).read()
+
+
+def test_product_binary_two_samples_golden(built, cohort_dir, tmp_path):
+    from popdel_amd import synth
+    d = cohort_dir("s2", 2, synth.single_deletion)
+    assert run_call(POPDEL_BIN, d, str(tmp_path / "a.vcf")) == golden_text("s2_default.vcf")
+    assert run_call(POPDEL_BIN, d, str(tmp_path / "b.vcf"), "-n") == golden_text("s2_windowwise.vcf")
+
+
+def test_product_binary_dense_200_golden(built, cohort_dir, tmp_path):
+    from popdel_amd import synth
+    d = cohort_dir("dd200", 200, synth.dense_deletions)
+    assert run_call(POPDEL_BIN, d, str(tmp_path / "t.vcf")) == golden_text("dd200_default.vcf.gz")
+    text = run_call(POPDEL_BIN, d, str(tmp_path / "tn.vcf"), "-n")
+    out = []
+    for l in text.splitlines(True):
+        if l.startswith("#"):
+            out.append(l)
+            continue
+        cols = l.rstrip("\n").split("\t")
+        out.append("\t".join(cols[:8]) + "\t" + hashlib.sha1("\t".join(cols[8:]).encode()).hexdigest() + "\n")
+    assert "".join(out) == golden_text("dd200_windowwise.digest.tsv.gz")

@@ -1,0 +1,96 @@
+"""CPU: the oracle-backed host driver against the reference's captured outputs (tests/golden)."""
+import gzip
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ORACLE_CALL, run_call, strip_date
+
+
+def golden_text(name):
+    path = os.path.join(GOLDEN, name)
+    if name.endswith(".gz"):
+        return gzip.open(path, "rt").read()
+    return open(path).read()
+
+
+def vcf_digest(text):
+    out = []
+    for l in text.splitlines(True):
+        if l.startswith("#"):
+            out.append(l)
+            continue
+        cols = l.rstrip("\n").split("\t")
+        out.append("\t".join(cols[:8]) + "\t" + hashlib.sha1("\t".join(cols[8:]).encode()).hexdigest() + "\n")
+    return "".join(out)
+
+
+def test_two_samples_default_and_windowwise(built, cohort_dir, tmp_path):
+    from popdel_amd import synth
+    d = cohort_dir("s2", 2, synth.single_deletion)
+    assert run_call(ORACLE_CALL, d, str(tmp_path / "a.vcf")) == golden_text("s2_default.vcf")
+    assert run_call(ORACLE_CALL, d, str(tmp_path / "b.vcf"), "-n") == golden_text("s2_windowwise.vcf")
+    # -F changes nothing here: no window call fails a filter
+    assert run_call(ORACLE_CALL, d, str(tmp_path / "c.vcf"), "-n", "-F") == golden_text("s2_windowwise.vcf")
+
+
+def test_uncompressed_profiles_give_the_same_vcf(built, cohort_dir, tmp_path):
+    from popdel_amd import synth
+    d = cohort_dir("s2raw", 2, synth.single_deletion, compressed=False)
+    assert run_call(ORACLE_CALL, d, str(tmp_path / "a.vcf"), "-x") == golden_text("s2_default.vcf")
+
+
+def test_active_sets_across_segment_borders(built, cohort_dir, tmp_path):
+    """Loader + window state machine: per-window count and sum(startPos) per read group, 4 segment borders."""
+    from popdel_amd import synth
+    d = cohort_dir("s2", 2, synth.single_deletion)
+    dump = tmp_path / "active.tsv"
+    env = dict(os.environ, POPDEL_ORACLE_ACTIVE_DUMP=str(dump))
+    subprocess.check_call([ORACLE_CALL, os.path.join(d, "profiles.txt"), "-o", str(tmp_path / "o.vcf"), "-r",
+                           "chr20:1003001-2000000", "-n"], stdout=subprocess.DEVNULL, env=env)
+    assert dump.read_text() == golden_text("s2_active_r1003001.tsv.gz")
+
+
+def test_200_samples_default(built, cohort_dir, tmp_path):
+    from popdel_amd import synth
+    d = cohort_dir("s200", 200, synth.single_deletion)
+    assert run_call(ORACLE_CALL, d, str(tmp_path / "a.vcf")) == golden_text("s200_default.vcf")
+
+
+def test_dense_200_samples(built, cohort_dir, tmp_path):
+    """49 planted deletions: merged VCF, all 5,163 window calls, LR/AF at full precision."""
+    from popdel_amd import synth
+    d = cohort_dir("dd200", 200, synth.dense_deletions)
+    assert run_call(ORACLE_CALL, d, str(tmp_path / "t.vcf")) == golden_text("dd200_default.vcf.gz")
+    dump = tmp_path / "calls.txt"
+    env = dict(os.environ, POPDEL_ORACLE_CALL_DUMP=str(dump))
+    out = tmp_path / "tn.vcf"
+    subprocess.check_call([ORACLE_CALL, os.path.join(d, "profiles.txt"), "-o", str(out), "-r", "chr20:1000000-2000000", "-n"],
+                          stdout=subprocess.DEVNULL, env=env)
+    assert vcf_digest(strip_date(out.read_text())) == golden_text("dd200_windowwise.digest.tsv.gz")
+    want = golden_text("dd200_calls.digest.tsv.gz").splitlines()
+    got = dump.read_text().splitlines()
+    assert len(got) == len(want) == 5163
+    worst = 0.0
+    for g, w in zip(got, want):
+        parts = g.split(" | ")
+        head = dict(kv.split("=") for kv in parts[0].split()[1:])
+        wf = w.split("\t")
+        for key, ref in zip(("win", "pos", "end", "init", "it", "len"), wf[:6]):
+            assert head[key] == ref
+        assert head["filt"] == wf[8]
+        assert hashlib.sha1(" | ".join(parts[1:]).encode()).hexdigest() == wf[9]
+        lr, lr_ref = float(head["lr"]), float(wf[6])
+        worst = max(worst, abs(lr - lr_ref) / abs(lr_ref))
+        assert abs(float(head["af"]) - float(wf[7])) < 1e-12
+    assert worst < 1e-12      # summation order differs from the reference's hash-set order, nothing else
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(os.environ.get("POPDEL_SLOW") != "1", reason="set POPDEL_SLOW=1 (about 3 minutes)")
+def test_1000_samples_default(built, cohort_dir, tmp_path):
+    from popdel_amd import synth
+    d = cohort_dir("s1000", 1000, synth.single_deletion)
+    assert run_call(ORACLE_CALL, d, str(tmp_path / "a.vcf")) == golden_text("s1000_default.vcf")
