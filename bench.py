@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Throughput of the joint-calling hot path (window x sample likelihood evaluations per second) on MI355X.
+
+Workload (BASELINE.json configs[2]): 10,000 synthetic profiles x chr20 (2,148,139 calling windows of 30 bp).
+The pair stream of 10,000 samples x chr20 is ~770 GB, so the chromosome is processed the way the host driver does it:
+one 200-kb segment (6,667 windows) of all samples at a time. The bench keeps ONE such segment of all 10,000 samples
+resident in HBM (generated on the device, staged through the C ABI before the clock starts) and a "step" runs the
+complete hot path -- stage-1 Q3 scan, candidate clustering, EM + final genotyping for every candidate cell, result
+packing -- over it 323 times, i.e. over as many windows as chr20 has. Nothing is cached between passes.
+
+With --gpus N the 323 segment passes of a step are dealt round-robin to the ranks (segments are independent given the
+host-side carry-over of active pairs, so no data-path collective is needed); value = all cells / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CHR20_WINDOWS = 2148139
+SEG_WINDOWS = 6667            # windows walked per 200-kb segment (windowBuffer 200000 / 30)
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def device_tile(n_samples, seed, device):
+    """Pair instances of one 200-kb segment for n_samples single-read-group samples, generated with torch on the GPU:
+    30x coverage, 2x150 bp, insert ~ round(N(500, 50)), one planted deletion (length log-uniform 300..5000,
+    population AF ~ Beta(0.5, 2), genotype ~ Binomial(2, AF)); activity by the interval rule."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    first, shift, W = 1000020, 30, SEG_WINDOWS
+    lo, hi = first - 600, first + W * shift
+    n = int((hi - lo) * 30.0 / 300.0)
+    median, read_len = 500, 150
+    pos = torch.randint(lo, hi, (n_samples, n), generator=g, device=device, dtype=torch.int64)
+    pos, _ = torch.sort(pos, dim=1)
+    ins = torch.round(torch.randn((n_samples, n), generator=g, device=device) * 50.0 + median).to(torch.int64)
+    hap = torch.randint(0, 2, (n_samples, n), generator=g, device=device, dtype=torch.int64)
+    rs = np.random.default_rng(seed)
+    del_len = int(np.exp(rs.uniform(np.log(300), np.log(5000))))
+    del_start = first + (W // 2) * shift
+    af = rs.beta(0.5, 2.0)
+    gt = torch.from_numpy(rs.binomial(2, af, size=n_samples)).to(device).view(-1, 1)
+    carrier = (gt == 2) | ((gt == 1) & (hap == 0))
+    inner = torch.clamp(ins - 2 * read_len, min=1)
+    inside = carrier & (pos >= del_start) & (pos < del_start + del_len)
+    span = carrier & (pos < del_start) & (pos + inner > del_start)
+    ins = torch.where(span, ins + del_len, ins)
+    dev = ins - median
+    end = pos + torch.clamp(dev + median - 2 * read_len, min=0)
+    last = torch.div(end, shift, rounding_mode="floor") * shift + shift
+    on = torch.clamp(-torch.div(first - pos, shift, rounding_mode="floor"), min=0)
+    off = torch.clamp(torch.div(last - first, shift, rounding_mode="floor") + 1, max=W)
+    keep = (~inside) & (off > on) & (on < W)
+    counts = keep.sum(dim=1).cpu().numpy().astype(np.uint64)
+    offsets = np.zeros(n_samples + 1, dtype=np.uint64)
+    np.cumsum(counts, out=offsets[1:])
+    flat = keep.view(-1)
+    out = dict(dev=dev.view(-1)[flat].to(torch.int32).cpu().numpy(), start=pos.view(-1)[flat].to(torch.int32).cpu().numpy().astype(np.uint32),
+               on=on.view(-1)[flat].to(torch.int32).cpu().numpy().astype(np.uint32),
+               off=off.view(-1)[flat].to(torch.int32).cpu().numpy().astype(np.uint32))
+    del pos, ins, hap, dev, end, last, on, off, keep, flat
+    torch.cuda.empty_cache()
+    return first, W, offsets, out, dict(del_len=del_len, af=float(af))
+
+
+def take_samples(offsets, arrays, n):
+    e = int(offsets[n])
+    return offsets[: n + 1].copy(), {k: v[:e] for k, v in arrays.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--samples", type=int, default=10000)
+    ap.add_argument("--passes", type=int, default=0, help="segment passes per step (default: chr20 = 323)")
+    ap.add_argument("--cpu-samples", type=int, default=600, help="samples of the same segment timed on one host core")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from popdel_amd import capi, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+
+    hip = capi.load_hip()                     # no fallback: raises if the HIP library is missing
+    lib = synth.Library()
+    rg = synth.conditioned_readgroup(lib)
+    S = args.samples
+    first, W, offsets, arrays, planted = device_tile(S, 20260 + rank, device)
+    seg = capi.Segment(first, W, offsets, arrays["dev"], arrays["start"], arrays["on"], arrays["off"])
+    ctx = capi.Context(hip, [rg] * S, list(range(S + 1)), device=local_rank)
+    handle = ctx.stage(seg)                   # host -> HBM, outside the timed region
+
+    total_passes = args.passes or -(-CHR20_WINDOWS // W)
+    my_passes = len(range(rank, total_passes, world))
+
+    def one_step():
+        s1 = s2 = 0.0
+        calls = 0
+        cand = 0
+        for _ in range(my_passes):
+            res = ctx.collect(ctx.run(handle))
+            t = ctx.timing()
+            s1 += t["stage1_ms"]
+            s2 += t["stage2_ms"]
+            calls += res["n_calls"]
+            cand += t["n_candidate_cells"]
+        return s1, s2, calls, cand, t
+
+    def sync():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+    t0 = time.perf_counter()
+    s1_ms = s2_ms = 0.0
+    n_calls = n_cand = 0
+    for _ in range(args.steps):
+        a, b, c, d, tinfo = one_step()
+        s1_ms += a
+        s2_ms += b
+        n_calls += c
+        n_cand += d
+    sync()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    cells_per_step = total_passes * W * S
+    value = cells_per_step * args.steps / elapsed
+
+    # roofline of the dominant kernel (stage-1 scan): algorithmic bytes per launch / mean launch duration
+    launches = my_passes * args.steps
+    s1_mean_s = s1_ms / launches / 1e3
+    cells = tinfo["n_cells"]
+    alg_bytes = 4 * tinfo["n_active_pairs"] + 4 * cells + 4 * cells          # gather + cell index + Q3 out
+    compact_bytes = 8 * tinfo["n_pair_chunks"] + 4 * (W + 1) * S + 5 * cells   # what this layout actually has to move
+    achieved = alg_bytes / s1_mean_s / 1e9
+    roofline = dict(bound="hbm", kernel="stage1Kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=achieved / HBM_PEAK_GBS, traffic=None, algorithmic_bytes_per_launch=alg_bytes,
+                    compact_bytes_per_launch=compact_bytes, compact_GBs=compact_bytes / s1_mean_s / 1e9,
+                    mean_launch_ms=s1_mean_s * 1e3, mean_active_pairs_per_cell=tinfo["n_active_pairs"] / cells)
+
+    cpu_baseline = None
+    if rank == 0 and not args.no_cpu:
+        oracle_path = os.path.join(ROOT, "oracle", "_build", "libpopdel_oracle.so")
+        if os.path.exists(oracle_path):
+            n_cpu = min(args.cpu_samples, S)
+            o_off, o_arr = take_samples(offsets, arrays, n_cpu)
+            oseg = capi.Segment(first, W, o_off, o_arr["dev"], o_arr["start"], o_arr["on"], o_arr["off"])
+            octx = capi.Context(capi.load_library(oracle_path), [rg] * n_cpu, list(range(n_cpu + 1)))
+            c0 = time.perf_counter()
+            octx.collect(octx.submit(oseg))
+            cpu_s = time.perf_counter() - c0
+            octx.close()
+            cpu_baseline = dict(value=n_cpu * W / cpu_s, unit="window*sample/s", cores=1, kind="port",
+                                sample="%d of the %d samples x the same %d-window segment, oracle/ (x87 long double), %.1f s"
+                                       % (n_cpu, S, W, cpu_s))
+
+    if rank == 0:
+        print(json.dumps({
+            "metric": "window x sample likelihood evals/sec", "value": value, "unit": "window*sample/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32 scan + f64 likelihoods",
+            "data": "synthetic",
+            "config": {"workload": "10,000 synthetic profiles x chr20 windows on MI355X (configs[2])" if S == 10000 and not args.passes
+                       else "%d synthetic profiles x %d windows" % (S, total_passes * W),
+                       "samples": S, "windows_per_step": total_passes * W, "segment_windows": W,
+                       "segment_passes_per_step": total_passes, "resident_segment": "one 200-kb segment of all samples, re-scanned",
+                       "planted_deletion": planted, "parallelism": "segments round-robin over %d rank(s)" % world},
+            "stage1_ms_per_step": s1_ms / args.steps, "stage2_ms_per_step": s2_ms / args.steps,
+            "calls_per_step": n_calls / args.steps, "candidate_cells_per_step": n_cand / args.steps,
+            "max_life": tinfo["max_life"], "roofline": roofline, "cpu_baseline": cpu_baseline}))
+    ctx.unstage(handle)
+    ctx.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
