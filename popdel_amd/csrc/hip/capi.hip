@@ -13,9 +13,13 @@
 
 namespace pd {
 
-void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag, hipStream_t stream);
+void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag, uint8_t * tileTodo,
+                  hipStream_t stream);
+void launchStage1Fallback(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
+                          const uint8_t * tileTodo, hipStream_t stream);
 void launchCluster(const int32_t * q3, const uint8_t * flags, const int * flaggedWindows, unsigned nFlagged, unsigned W,
-                   const CohortView & co, int * scratch, unsigned rowLen, int * candLen, int * candCount, hipStream_t st);
+                   const CohortView & co, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,
+                   hipStream_t st);
 void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st);
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st);
 void launchGatherOut(const Stage2Buffers & b, const unsigned * emitCells, unsigned nEmit, unsigned nSamples, uint32_t * pl,
@@ -108,6 +112,7 @@ struct pd_ctx
     DevBuf<double> dHist;
     DevBuf<uint32_t> dSampleRg;
     pd::CohortView cohort;
+    int uniformThreshold = -1;      // minInitDelLen if it is the same for all read groups, else -1
 
     std::map<uint64_t, std::unique_ptr<StagedSegment>> staged;
     uint64_t nextHandle = 1, nextTicket = 1;
@@ -117,6 +122,7 @@ struct pd_ctx
     DevBuf<int32_t> dQ3;
     DevBuf<uint8_t> dFlags;
     DevBuf<int> dWinFlag;
+    DevBuf<uint8_t> dTileTodo;
     uint32_t lastWindows = 0;
     std::vector<int32_t> hQ3View;
     std::vector<uint8_t> hFlagsView;
@@ -126,7 +132,7 @@ struct pd_ctx
     DevBuf<double> dDl, dPartial;
     DevBuf<int> dShifts;
     DevBuf<unsigned> dCounters, dSuppFirst, dSuppLast, dEmit;
-    DevBuf<uint32_t> dPl, dLad, dDad, dFl, dOutPl, dOutLad, dOutDad, dOutFl;
+    DevBuf<uint32_t> dPl, dLad, dDad, dFl, dOutPl;
     pd_timing timing;
 
     ~pd_ctx()
@@ -138,6 +144,52 @@ struct pd_ctx
 };
 
 namespace {
+
+// Page-locked host blocks for the per-sample result arrays (D2H at PCIe rate, no staging copy). Blocks are recycled:
+// pd_calls_free() hands them back.
+struct PinnedBlock
+{
+    void * p = nullptr;
+    size_t bytes = 0;
+};
+std::vector<PinnedBlock> g_pinnedPool;
+
+PinnedBlock takePinned(size_t bytes)
+{
+    size_t best = g_pinnedPool.size();
+    for (size_t i = 0; i < g_pinnedPool.size(); ++i)
+        if (g_pinnedPool[i].bytes >= bytes && (best == g_pinnedPool.size() || g_pinnedPool[i].bytes < g_pinnedPool[best].bytes))
+            best = i;
+    if (best != g_pinnedPool.size())
+    {
+        PinnedBlock b = g_pinnedPool[best];
+        g_pinnedPool.erase(g_pinnedPool.begin() + best);
+        return b;
+    }
+    PinnedBlock b;
+    b.bytes = bytes + bytes / 4 + 4096;
+    PD_HIP(hipHostMalloc(&b.p, b.bytes, hipHostMallocDefault));
+    return b;
+}
+
+void givePinned(PinnedBlock b)
+{
+    if (!b.p)
+        return;
+    if (g_pinnedPool.size() >= 4)
+    {
+        (void)hipHostFree(b.p);
+        return;
+    }
+    g_pinnedPool.push_back(b);
+}
+
+// pd_calls plus what pd_calls_free() needs to know.
+struct CallsBox
+{
+    pd_calls pub;
+    PinnedBlock pinned;
+};
 
 template <typename T>
 T * mallocCopy(const std::vector<T> & v)
@@ -317,6 +369,10 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
         c->cohort.nSamples = n_samples;
         c->cohort.nRg = n_readgroups;
         c->cohort.minThreshold = minThreshold;
+        c->uniformThreshold = (int)rgs[0].min_init_del_len;
+        for (uint32_t i = 1; i < n_readgroups; ++i)
+            if (rgs[i].min_init_del_len != rgs[0].min_init_del_len)
+                c->uniformThreshold = -1;
         std::memset(&c->timing, 0, sizeof(c->timing));
     }
     catch (const HipError & e)
@@ -397,9 +453,13 @@ int pd_segment_run(pd_ctx * c, uint64_t handle, uint64_t * ticket)
         PD_HIP(hipEventCreate(&run.s1Begin));
         PD_HIP(hipEventCreate(&run.s1End));
         PD_HIP(hipEventRecord(run.s1Begin, c->stream));
-        pd::launchStage1(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->stream);
+        const size_t tiles = static_cast<size_t>((s.nWindows + pd::kStage1Block - 1) / pd::kStage1Block) * c->nSamples;
+        c->dTileTodo.ensure(tiles);
+        pd::launchStage1(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTileTodo.p, c->stream);
         PD_HIP(hipGetLastError());
         PD_HIP(hipEventRecord(run.s1End, c->stream));
+        pd::launchStage1Fallback(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTileTodo.p, c->stream);
+        PD_HIP(hipGetLastError());
         c->lastWindows = s.nWindows;
         *ticket = c->nextTicket++;
         c->runs[*ticket] = run;
@@ -479,7 +539,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             c->dCandLen.ensure(flagged.size() * pd::kMaxCandidatesPerWindow);
             c->dCandCount.ensure(flagged.size());
             pd::launchCluster(c->dQ3.p, c->dFlags.p, c->dFlagged.p, (unsigned)flagged.size(), W, c->cohort,
-                              c->dClusterScratch.p, rowLen, c->dCandLen.p, c->dCandCount.p, c->stream);
+                              c->uniformThreshold, c->dClusterScratch.p, rowLen, c->dCandLen.p, c->dCandCount.p, c->stream);
             PD_HIP(hipGetLastError());
             std::vector<int> candLen(flagged.size() * pd::kMaxCandidatesPerWindow), candCount(flagged.size());
             PD_HIP(hipMemcpyAsync(candLen.data(), c->dCandLen.p, candLen.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -557,21 +617,22 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
                     emit.push_back(i);
         }
         const uint32_t n = (uint32_t)emit.size();
-        std::vector<uint32_t> pl(static_cast<size_t>(n) * S * 3), lad(static_cast<size_t>(n) * S * 3),
-            dad(static_cast<size_t>(n) * S * 5), fl(static_cast<size_t>(n) * S * 2);
+        const size_t perSample = static_cast<size_t>(n) * S;
+        PinnedBlock pinned;
+        uint32_t *hPl = nullptr, *hLad = nullptr, *hDad = nullptr, *hFl = nullptr;
         if (n != 0)
         {
+            pinned = takePinned(perSample * 13 * sizeof(uint32_t));
+            hPl = static_cast<uint32_t *>(pinned.p);
+            hLad = hPl + perSample * 3;
+            hDad = hLad + perSample * 3;
+            hFl = hDad + perSample * 5;
             c->dEmit.upload(emit, c->stream);
-            c->dOutPl.ensure(pl.size());
-            c->dOutLad.ensure(lad.size());
-            c->dOutDad.ensure(dad.size());
-            c->dOutFl.ensure(fl.size());
-            pd::launchGatherOut(b, c->dEmit.p, n, S, c->dOutPl.p, c->dOutLad.p, c->dOutDad.p, c->dOutFl.p, c->stream);
+            c->dOutPl.ensure(perSample * 13);
+            uint32_t *dPl = c->dOutPl.p, *dLad = dPl + perSample * 3, *dDad = dLad + perSample * 3, *dFl = dDad + perSample * 5;
+            pd::launchGatherOut(b, c->dEmit.p, n, S, dPl, dLad, dDad, dFl, c->stream);
             PD_HIP(hipGetLastError());
-            PD_HIP(hipMemcpyAsync(pl.data(), c->dOutPl.p, pl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            PD_HIP(hipMemcpyAsync(lad.data(), c->dOutLad.p, lad.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            PD_HIP(hipMemcpyAsync(dad.data(), c->dOutDad.p, dad.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            PD_HIP(hipMemcpyAsync(fl.data(), c->dOutFl.p, fl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            PD_HIP(hipMemcpyAsync(hPl, dPl, perSample * 13 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         }
         PD_HIP(hipEventRecord(s2End, c->stream));
         PD_HIP(hipStreamSynchronize(c->stream));
@@ -587,7 +648,10 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         c->timing.n_candidate_cells = nCells;
         c->timing.max_life = s.maxLife;
 
-        pd_calls * pc = static_cast<pd_calls *>(std::calloc(1, sizeof(pd_calls)));
+        CallsBox * box = new CallsBox();
+        std::memset(&box->pub, 0, sizeof(pd_calls));
+        box->pinned = pinned;
+        pd_calls * pc = &box->pub;
         pc->n_calls = n;
         pc->n_samples = S;
         std::vector<uint32_t> u(n);
@@ -613,10 +677,10 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             f[i] = (static_cast<double>(dataSamples) / S >= c->cfg.min_sample_fraction) ? 0 : 4;
         }
         pc->filter = mallocCopy(f);
-        pc->pl = mallocCopy(pl);
-        pc->lad = mallocCopy(lad);
-        pc->dad = mallocCopy(dad);
-        pc->first_last = mallocCopy(fl);
+        pc->pl = hPl;
+        pc->lad = hLad;
+        pc->dad = hDad;
+        pc->first_last = hFl;
         *out = pc;
     }
     catch (const HipError & e)
@@ -647,11 +711,9 @@ void pd_calls_free(pd_calls * pc)
     std::free(pc->position);
     std::free(pc->end_position);
     std::free(pc->filter);
-    std::free(pc->pl);
-    std::free(pc->lad);
-    std::free(pc->dad);
-    std::free(pc->first_last);
-    std::free(pc);
+    CallsBox * box = reinterpret_cast<CallsBox *>(pc);       // pub is the first member
+    givePinned(box->pinned);
+    delete box;
 }
 
 int pd_stage1_last(pd_ctx * c, pd_stage1_view * out)

@@ -182,12 +182,236 @@ __device__ __forceinline__ unsigned waveMaxU32(unsigned v)
     return v;
 }
 
+// ---- packed 16-bit variant: two cells per lane ----------------------------------------------------------------------
+// Deviations that fit int16 are sorted two at a time with v_pk_min_i16 / v_pk_max_i16: the low half of every register
+// belongs to window w, the high half to window w + 256. The number of active pairs n(w) is known before the values
+// are loaded (pairs started minus pairs ended, both per window prefix counts), so the inactive slots can be filled
+// with p(w) copies of -INF and +INF otherwise such that the wanted order statistics land at the STATIC positions
+// T and T+1 of the sorted array; the compiler then prunes every comparator outside the cone of those two outputs.
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+#define PD_CE16(i, j)                                          \
+    {                                                          \
+        const v2s lo_ = __builtin_elementwise_min(r[i], r[j]); \
+        const v2s hi_ = __builtin_elementwise_max(r[i], r[j]); \
+        r[i] = lo_;                                            \
+        r[j] = hi_;                                            \
+    }
+
+template <int C>
+__device__ __forceinline__ void sortRegs16(v2s (&r)[C]);
+template <>
+__device__ __forceinline__ void sortRegs16<32>(v2s (&r)[32]) { PD_SORTNET_32(PD_CE16) }
+template <>
+__device__ __forceinline__ void sortRegs16<64>(v2s (&r)[64]) { PD_SORTNET_64(PD_CE16) }
+
+__device__ __forceinline__ unsigned rankL0(unsigned n)
+{
+    return (n < 4u) ? (n - 1u) : ((3u * n + 2u + (n & 1u) - 4u) >> 2);
+}
+
+constexpr int kPackedWindows = 2 * kStage1Block;          // windows per workgroup
+constexpr int kPackedLdsPairs = 4096;
+constexpr int kPackedWsLen = kPackedWindows + 64 + 2;
+
+template <int C>
+__device__ __forceinline__ void stage1PairFast(const PairDO * lds, unsigned aA, unsigned cntA, unsigned nA, unsigned wA,
+                                               unsigned aB, unsigned cntB, unsigned nB, unsigned wB, int & vaA, int & vbA,
+                                               int & vaB, int & vbB)
+{
+    constexpr unsigned T = (3u * C + 2u - 4u) >> 2;        // l0(C): 23 for 32 slots, 47 for 64
+    // number of -INF fillers that moves rank l0(n) to position T
+    const unsigned pA = (nA >= 2u) ? (T - rankL0(nA)) : 0u;
+    const unsigned pB = (nB >= 2u) ? (T - rankL0(nB)) : 0u;
+    v2s r[C];
+    unsigned jA = 0, jB = 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+    {
+        const PairDO pa = lds[aA + c];
+        const PairDO pb = lds[aB + c];
+        const bool actA = ((unsigned)c < cntA) && (pa.off > wA);
+        const bool actB = ((unsigned)c < cntB) && (pb.off > wB);
+        const int fillA = (jA < pA) ? -32768 : 32767;
+        const int fillB = (jB < pB) ? -32768 : 32767;
+        const int xA = actA ? pa.dev : fillA;
+        const int xB = actB ? pb.dev : fillB;
+        jA += actA ? 0u : 1u;
+        jB += actB ? 0u : 1u;
+        v2s v;
+        v.x = (short)xA;
+        v.y = (short)xB;
+        r[c] = v;
+    }
+    sortRegs16<C>(r);
+    vaA = r[T].x;
+    vbA = r[T + 1].x;
+    vaB = r[T].y;
+    vbB = r[T + 1].y;
+}
+
+__device__ __forceinline__ void storeCell(unsigned n, unsigned maxLoad, int va, int vb, size_t cell, unsigned w, int minThreshold,
+                                          int32_t * q3, uint8_t * flags, int * winFlag)
+{
+    int q = 0;
+    unsigned fl = 0;
+    if (n < 2u)
+        fl = 1u;
+    else if (n < maxLoad)
+    {
+        q = (n < 4u) ? va : q3FromRankPair(n, va, vb);
+        fl = 2u;
+    }
+    q3[cell] = q;
+    flags[cell] = (uint8_t)fl;
+    if ((fl & 2u) && q > minThreshold)
+        winFlag[w] = 1;                 // benign race: every writer stores the same value
+}
+
+// Main scan kernel (single-read-group samples, int16 deviations, at most 64 candidates per cell). Everything else is
+// marked in tileTodo (one entry per 256 windows) and handled by stage1FallbackKernel.
 __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, CohortView co, int32_t * __restrict__ q3,
-                                                             uint8_t * __restrict__ flags, int * __restrict__ winFlag)
+                                                             uint8_t * __restrict__ flags, int * __restrict__ winFlag,
+                                                             uint8_t * __restrict__ tileTodo, unsigned tilesPerSample)
+{
+    __shared__ PairDO ldsPairs[kPackedLdsPairs + 64];
+    __shared__ uint32_t ldsWs[kPackedWsLen];
+    __shared__ int ldsEnd[kPackedWsLen + 6];
+    __shared__ int waveTotals[kStage1Block / 64];
+
+    const unsigned s = blockIdx.y;
+    const unsigned w0 = blockIdx.x * kPackedWindows;
+    const unsigned W = seg.nWindows;
+    const unsigned K = seg.maxLife;
+    const unsigned tid = threadIdx.x;
+    const unsigned rg0 = co.sampleRg[s];
+    const bool singleRg = (co.sampleRg[s + 1] - rg0) == 1u;
+    uint8_t * todo = tileTodo + (size_t)s * tilesPerSample + 2u * blockIdx.x;      // two 256-window tiles
+    const bool secondTile = (w0 + kStage1Block) < W;
+
+    if (!(singleRg && K <= 64u))
+    {
+        if (tid == 0)
+        {
+            todo[0] = 1;
+            if (secondTile)
+                todo[1] = 1;
+        }
+        return;
+    }
+    const uint32_t * ws = seg.winStart + (size_t)rg0 * (W + 1);
+    const unsigned wlo0 = (w0 + 1 >= K) ? (w0 + 1 - K) : 0u;        // first window whose chunks matter
+    const unsigned whi = min(W, w0 + kPackedWindows);                // ws index of the range end
+    const unsigned nWs = whi - wlo0 + 1;
+    for (unsigned i = tid; i < nWs; i += kStage1Block)
+    {
+        ldsWs[i] = ws[wlo0 + i];
+        ldsEnd[i] = 0;
+    }
+    __syncthreads();
+    const unsigned A = ldsWs[0];
+    const unsigned nPairs = ldsWs[nWs - 1] - A;
+    bool bad = nPairs > (unsigned)kPackedLdsPairs;
+    if (!bad)
+    {
+        const PairDO * src = seg.pairs + seg.rgBase[rg0] + A;
+        for (unsigned i = tid; i < nPairs; i += kStage1Block)
+        {
+            const PairDO p = src[i];
+            ldsPairs[i] = p;
+            bad |= (p.dev < -32767) || (p.dev > 32766);
+            const unsigned rel = p.off - wlo0;                      // off > on >= wlo0
+            if (rel < nWs)
+                atomicAdd(&ldsEnd[rel], 1);
+        }
+    }
+    unsigned aA = 0, cntA = 0, aB = 0, cntB = 0;
+    const unsigned wA = w0 + tid, wB = w0 + kStage1Block + tid;
+    if (wA < W)
+    {
+        const unsigned wlo = (wA + 1 >= K) ? (wA + 1 - K) : 0u;
+        aA = ldsWs[wlo - wlo0] - A;
+        cntA = ldsWs[wA + 1 - wlo0] - A - aA;
+    }
+    if (wB < W)
+    {
+        const unsigned wlo = (wB + 1 >= K) ? (wB + 1 - K) : 0u;
+        aB = ldsWs[wlo - wlo0] - A;
+        cntB = ldsWs[wB + 1 - wlo0] - A - aB;
+    }
+    bad |= (cntA > 64u) || (cntB > 64u);
+    if (__syncthreads_or(bad))                                     // also orders the LDS writes above
+    {
+        if (tid == 0)
+        {
+            todo[0] = 1;
+            if (secondTile)
+                todo[1] = 1;
+        }
+        return;
+    }
+    if (tid == 0)
+    {
+        todo[0] = 0;
+        if (secondTile)
+            todo[1] = 0;
+    }
+    // inclusive prefix sum of ldsEnd over nWs (<= 3 * 256) entries: E(w) = pairs that ended at or before w
+    {
+        const unsigned base = 3u * tid;
+        int e0 = (base < nWs) ? ldsEnd[base] : 0;
+        int e1 = (base + 1 < nWs) ? ldsEnd[base + 1] : 0;
+        int e2 = (base + 2 < nWs) ? ldsEnd[base + 2] : 0;
+        e1 += e0;
+        e2 += e1;
+        int incl = e2;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1)
+        {
+            const int t = __shfl_up(incl, o, 64);
+            if ((int)(tid & 63u) >= o)
+                incl += t;
+        }
+        if ((tid & 63u) == 63u)
+            waveTotals[tid >> 6] = incl;
+        __syncthreads();
+        int offset = incl - e2;
+        for (unsigned wv = 0; wv < (tid >> 6); ++wv)
+            offset += waveTotals[wv];
+        if (base < nWs)
+            ldsEnd[base] = e0 + offset;
+        if (base + 1 < nWs)
+            ldsEnd[base + 1] = e1 + offset;
+        if (base + 2 < nWs)
+            ldsEnd[base + 2] = e2 + offset;
+        __syncthreads();
+    }
+    if (wA >= W)
+        return;
+    const unsigned nA = (ldsWs[wA + 1 - wlo0] - A) - (unsigned)ldsEnd[wA - wlo0];
+    const unsigned nB = (wB < W) ? (ldsWs[wB + 1 - wlo0] - A) - (unsigned)ldsEnd[wB - wlo0] : 0u;
+    const unsigned cmax = waveMaxU32(max(cntA, cntB));               // wave-uniform network size
+    int vaA, vbA, vaB, vbB;
+    if (cmax <= 32u)
+        stage1PairFast<32>(ldsPairs, aA, cntA, nA, wA, aB, cntB, nB, wB, vaA, vbA, vaB, vbB);
+    else
+        stage1PairFast<64>(ldsPairs, aA, cntA, nA, wA, aB, cntB, nB, wB, vaA, vbA, vaB, vbB);
+    const unsigned maxLoad = co.rg[rg0].maxLoad;
+    storeCell(nA, maxLoad, vaA, vbA, (size_t)s * W + wA, wA, co.minThreshold, q3, flags, winFlag);
+    if (wB < W)
+        storeCell(nB, maxLoad, vaB, vbB, (size_t)s * W + wB, wB, co.minThreshold, q3, flags, winFlag);
+}
+
+// Tiles the main kernel skipped: 128-input network where the LDS stage still fits, otherwise rank counting from HBM.
+__global__ __launch_bounds__(kStage1Block) void stage1FallbackKernel(SegmentView seg, CohortView co, int32_t * __restrict__ q3,
+                                                                     uint8_t * __restrict__ flags, int * __restrict__ winFlag,
+                                                                     const uint8_t * __restrict__ tileTodo)
 {
     __shared__ PairDO ldsPairs[kStage1LdsPairs + 128];
     __shared__ uint32_t ldsWs[kStage1Block + 64 + 2];
-
+    const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;      // gridDim.x == tiles per sample
+    if (!tileTodo[tile])
+        return;
     const unsigned s = blockIdx.y;
     const unsigned w0 = blockIdx.x * kStage1Block;
     const unsigned W = seg.nWindows;
@@ -196,23 +420,21 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     const unsigned w = w0 + tid;
     const unsigned rg0 = co.sampleRg[s];
     const bool singleRg = (co.sampleRg[s + 1] - rg0) == 1u;
-
     int q = 0;
     unsigned fl = 0;
     bool done = false;
-
     if (singleRg && K <= 64u)
     {
         const uint32_t * ws = seg.winStart + (size_t)rg0 * (W + 1);
-        const unsigned wlo0 = (w0 + 1 >= K) ? (w0 + 1 - K) : 0u;        // first window whose chunks matter
-        const unsigned whi = min(W, w0 + kStage1Block);                  // ws index of the range end
+        const unsigned wlo0 = (w0 + 1 >= K) ? (w0 + 1 - K) : 0u;
+        const unsigned whi = min(W, w0 + kStage1Block);
         const unsigned nWs = whi - wlo0 + 1;
         for (unsigned i = tid; i < nWs; i += kStage1Block)
             ldsWs[i] = ws[wlo0 + i];
         __syncthreads();
         const unsigned A = ldsWs[0];
         const unsigned nPairs = ldsWs[nWs - 1] - A;
-        if (nPairs <= (unsigned)kStage1LdsPairs)                          // block-uniform
+        if (nPairs <= (unsigned)kStage1LdsPairs)
         {
             const PairDO * src = seg.pairs + seg.rgBase[rg0] + A;
             for (unsigned i = tid; i < nPairs; i += kStage1Block)
@@ -225,21 +447,16 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
                 a = ldsWs[wlo - wlo0] - A;
                 cnt = ldsWs[w + 1 - wlo0] - A - a;
             }
-            const unsigned cmax = waveMaxU32(cnt);                        // wave-uniform network size
-            const unsigned maxLoad = co.rg[rg0].maxLoad;
+            const unsigned cmax = waveMaxU32(cnt);
             if (cmax <= 128u)
             {
                 done = true;
                 if (w < W)
                 {
-                    if (cmax <= 16u)
-                        stage1CellFast<16>(ldsPairs, a, cnt, w, maxLoad, q, fl);
-                    else if (cmax <= 32u)
-                        stage1CellFast<32>(ldsPairs, a, cnt, w, maxLoad, q, fl);
-                    else if (cmax <= 64u)
-                        stage1CellFast<64>(ldsPairs, a, cnt, w, maxLoad, q, fl);
+                    if (cmax <= 64u)
+                        stage1CellFast<64>(ldsPairs, a, cnt, w, co.rg[rg0].maxLoad, q, fl);
                     else
-                        stage1CellFast<128>(ldsPairs, a, cnt, w, maxLoad, q, fl);
+                        stage1CellFast<128>(ldsPairs, a, cnt, w, co.rg[rg0].maxLoad, q, fl);
                 }
             }
         }
@@ -252,14 +469,22 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     q3[cell] = q;
     flags[cell] = (uint8_t)fl;
     if ((fl & 2u) && q > co.minThreshold)
-        winFlag[w] = 1;                 // benign race: every writer stores the same value
+        winFlag[w] = 1;
 }
 
 void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
-                  hipStream_t stream)
+                  uint8_t * tileTodo, hipStream_t stream)
+{
+    const unsigned tilesPerSample = (seg.nWindows + kStage1Block - 1) / kStage1Block;
+    dim3 grid((seg.nWindows + kPackedWindows - 1) / kPackedWindows, co.nSamples);
+    hipLaunchKernelGGL(stage1Kernel, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo, tilesPerSample);
+}
+
+void launchStage1Fallback(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
+                          const uint8_t * tileTodo, hipStream_t stream)
 {
     dim3 grid((seg.nWindows + kStage1Block - 1) / kStage1Block, co.nSamples);
-    hipLaunchKernelGGL(stage1Kernel, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag);
+    hipLaunchKernelGGL(stage1FallbackKernel, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo);
 }
 
 }  // namespace pd

@@ -117,14 +117,123 @@ __device__ __forceinline__ double blockSum(double v, double * scratch)
 // above the threshold. The threshold table is indexed by POSITION IN THE SORTED ARRAY (reference :65,72,80).
 // One workgroup per flagged window; bitonic sort in a global scratch row (L2 resident).
 // =====================================================================================================================
+// Emits one cluster (mean above threshold) into the candidate list of flagged window `fw`.
+__device__ __forceinline__ void emitCluster(int sum, int n, unsigned threshold, int * candLen, unsigned fw, int & nc)
+{
+    if (!(sum / n > (int)threshold))
+        return;
+    const int v = sum / n;
+    for (int c = 0; c < nc && c < kMaxCandidatesPerWindow; ++c)
+        if (candLen[fw * kMaxCandidatesPerWindow + c] == v)
+            return;                                   // std::set semantics
+    if (nc < kMaxCandidatesPerWindow)
+        candLen[fw * kMaxCandidatesPerWindow + nc] = v;
+    ++nc;
+}
+
+__device__ __forceinline__ unsigned thresholdOfRanks(const CohortView & co, int uniformThreshold, unsigned i0, unsigned i1)
+{
+    if (uniformThreshold >= 0)
+        return (unsigned)uniformThreshold;
+    unsigned t = co.rg[i0].minInitDelLen;
+    for (unsigned i = i0 + 1; i <= i1; ++i)
+        t = min(t, co.rg[i].minInitDelLen);
+    return t;
+}
+
+constexpr int kClusterBins = 8192;
+
+// Fast path: the Q3 values of a window span fewer than kClusterBins integers -> counting sort in LDS, clusters are read
+// off the occupied bins in ascending order. Otherwise: bitonic sort of the values in a global scratch row.
 __global__ __launch_bounds__(256) void clusterKernel(const int32_t * __restrict__ q3, const uint8_t * __restrict__ flags,
                                                      const int * __restrict__ flaggedWindows, unsigned W, CohortView co,
-                                                     int * __restrict__ scratch, unsigned rowLen,
+                                                     int uniformThreshold, int * __restrict__ scratch, unsigned rowLen,
                                                      int * __restrict__ candLen, int * __restrict__ candCount)
 {
+    __shared__ int hist[kClusterBins];
     __shared__ unsigned nValid;
+    __shared__ int vMin, vMax;
     const unsigned fw = blockIdx.x;
     const unsigned w = (unsigned)flaggedWindows[fw];
+    if (threadIdx.x == 0)
+    {
+        nValid = 0;
+        vMin = 0x7fffffff;
+        vMax = (int)0x80000000;
+    }
+    __syncthreads();
+    {
+        int lmin = 0x7fffffff, lmax = (int)0x80000000;
+        unsigned cnt = 0;
+        for (unsigned s = threadIdx.x; s < co.nSamples; s += blockDim.x)
+        {
+            const size_t cell = (size_t)s * W + w;
+            if (flags[cell] & 2u)
+            {
+                const int v = q3[cell];
+                lmin = min(lmin, v);
+                lmax = max(lmax, v);
+                ++cnt;
+            }
+        }
+        if (cnt)
+        {
+            atomicMin(&vMin, lmin);
+            atomicMax(&vMax, lmax);
+            atomicAdd(&nValid, cnt);
+        }
+    }
+    __syncthreads();
+    const unsigned m = nValid;
+    if (m == 0)
+    {
+        if (threadIdx.x == 0)
+            candCount[fw] = 0;
+        return;
+    }
+    const long long range = (long long)vMax - (long long)vMin + 1;
+    if (range <= kClusterBins)
+    {
+        const int base = vMin;
+        for (int i = threadIdx.x; i < (int)range; i += blockDim.x)
+            hist[i] = 0;
+        __syncthreads();
+        for (unsigned s = threadIdx.x; s < co.nSamples; s += blockDim.x)
+        {
+            const size_t cell = (size_t)s * W + w;
+            if (flags[cell] & 2u)
+                atomicAdd(&hist[q3[cell] - base], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+            int nc = 0;
+            int sum = 0, n = 0, prev = 0;
+            unsigned rank = 0, i0 = 0;
+            for (int bin = 0; bin < (int)range; ++bin)
+            {
+                const int c = hist[bin];
+                if (c == 0)
+                    continue;
+                const int v = base + bin;
+                if (n != 0 && !(prev + 50 > v))
+                {
+                    emitCluster(sum, n, thresholdOfRanks(co, uniformThreshold, i0, rank - 1), candLen, fw, nc);
+                    sum = 0;
+                    n = 0;
+                    i0 = rank;
+                }
+                sum += v * c;
+                n += c;
+                rank += (unsigned)c;
+                prev = v;
+            }
+            emitCluster(sum, n, thresholdOfRanks(co, uniformThreshold, i0, rank - 1), candLen, fw, nc);
+            candCount[fw] = nc;
+        }
+        return;
+    }
+    // ---- wide value range: full sort ----------------------------------------------------------------------------
     int * row = scratch + (size_t)fw * rowLen;
     if (threadIdx.x == 0)
         nValid = 0;
@@ -139,7 +248,6 @@ __global__ __launch_bounds__(256) void clusterKernel(const int32_t * __restrict_
         }
     }
     __syncthreads();
-    const unsigned m = nValid;
     unsigned P = 1;
     while (P < m)
         P <<= 1;
@@ -170,54 +278,26 @@ __global__ __launch_bounds__(256) void clusterKernel(const int32_t * __restrict_
     if (threadIdx.x == 0)
     {
         int nc = 0;
-        if (m > 0)
+        int sum = row[0];
+        int n = 1;
+        unsigned i0 = 0;
+        for (unsigned i = 1; i < m; ++i)
         {
-            int sum = row[0];
-            int n = 1;
-            unsigned threshold = co.rg[0].minInitDelLen;
-            for (unsigned i = 1; i < m; ++i)
+            if (row[i - 1] + 50 > row[i])
             {
-                if (row[i - 1] + 50 > row[i])
-                {
-                    sum += row[i];
-                    ++n;
-                    threshold = min(threshold, co.rg[i].minInitDelLen);
-                }
-                else
-                {
-                    if (sum / n > (int)threshold)
-                    {
-                        int v = sum / n;
-                        bool dup = false;
-                        for (int c = 0; c < nc && c < kMaxCandidatesPerWindow; ++c)
-                            dup |= candLen[fw * kMaxCandidatesPerWindow + c] == v;
-                        if (!dup)
-                        {
-                            if (nc < kMaxCandidatesPerWindow)
-                                candLen[fw * kMaxCandidatesPerWindow + nc] = v;
-                            ++nc;
-                        }
-                    }
-                    sum = row[i];
-                    n = 1;
-                    threshold = co.rg[i].minInitDelLen;
-                }
+                sum += row[i];
+                ++n;
             }
-            if (sum / n > (int)threshold)
+            else
             {
-                int v = sum / n;
-                bool dup = false;
-                for (int c = 0; c < nc && c < kMaxCandidatesPerWindow; ++c)
-                    dup |= candLen[fw * kMaxCandidatesPerWindow + c] == v;
-                if (!dup)
-                {
-                    if (nc < kMaxCandidatesPerWindow)
-                        candLen[fw * kMaxCandidatesPerWindow + nc] = v;
-                    ++nc;
-                }
+                emitCluster(sum, n, thresholdOfRanks(co, uniformThreshold, i0, i - 1), candLen, fw, nc);
+                sum = row[i];
+                n = 1;
+                i0 = i;
             }
         }
-        candCount[fw] = nc;      // cluster means are produced in ascending order already
+        emitCluster(sum, n, thresholdOfRanks(co, uniformThreshold, i0, m - 1), candLen, fw, nc);
+        candCount[fw] = nc;
     }
 }
 
@@ -942,12 +1022,13 @@ __global__ void gatherOutKernel(Stage2Buffers b, const unsigned * __restrict__ e
 
 // ---- host-side launch sequence ---------------------------------------------------------------------------------------
 void launchCluster(const int32_t * q3, const uint8_t * flags, const int * flaggedWindows, unsigned nFlagged, unsigned W,
-                   const CohortView & co, int * scratch, unsigned rowLen, int * candLen, int * candCount, hipStream_t st)
+                   const CohortView & co, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,
+                   hipStream_t st)
 {
     if (nFlagged == 0)
         return;
-    hipLaunchKernelGGL(clusterKernel, dim3(nFlagged), dim3(256), 0, st, q3, flags, flaggedWindows, W, co, scratch, rowLen,
-                       candLen, candCount);
+    hipLaunchKernelGGL(clusterKernel, dim3(nFlagged), dim3(256), 0, st, q3, flags, flaggedWindows, W, co, uniformThreshold,
+                       scratch, rowLen, candLen, candCount);
 }
 
 // Phase A: first allele-frequency estimate and support-pool capacities (the host sizes the pools from them).
