@@ -1,6 +1,7 @@
 // C ABI of libpopdel_hip.so (include/popdel_hip.h): context, HBM staging of segments, launch orchestration and
 // result packing. No CPU fallback lives here: every entry point either runs the HIP kernels or fails.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -22,6 +23,7 @@ void launchCluster(const int32_t * q3, const uint8_t * flags, const int * flagge
                    hipStream_t st);
 void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st);
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st);
+void buildLogTables(const double * hist, double * logHist, double * log10Hist, size_t n, RgConst * rg, unsigned nRg, hipStream_t st);
 void launchGatherOut(const Stage2Buffers & b, const unsigned * emitCells, unsigned nEmit, unsigned nSamples, uint32_t * pl,
                      uint32_t * lad, uint32_t * dad, uint32_t * fl, hipStream_t st);
 
@@ -109,7 +111,8 @@ struct pd_ctx
     std::string error;
     hipStream_t stream = nullptr;
     DevBuf<pd::RgConst> dRg;
-    DevBuf<double> dHist;
+    DevBuf<double> dHist, dLogHist, dLog10Hist;
+    DevBuf<unsigned> dIterFlags;
     DevBuf<uint32_t> dSampleRg;
     pd::CohortView cohort;
     int uniformThreshold = -1;      // minInitDelLen if it is the same for all read groups, else -1
@@ -362,9 +365,16 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
         c->dRg.upload(rc, c->stream);
         c->dHist.upload(pool, c->stream);
         c->dSampleRg.upload(c->sampleRg, c->stream);
+        c->dLogHist.alloc(pool.size());
+        c->dLog10Hist.alloc(pool.size());
+        c->dIterFlags.alloc(pd::kMaxIterationsCap + 1);
+        pd::buildLogTables(c->dHist.p, c->dLogHist.p, c->dLog10Hist.p, pool.size(), c->dRg.p, n_readgroups, c->stream);
+        PD_HIP(hipGetLastError());
         PD_HIP(hipStreamSynchronize(c->stream));
         c->cohort.rg = c->dRg.p;
         c->cohort.hist = c->dHist.p;
+        c->cohort.logHist = c->dLogHist.p;
+        c->cohort.log10Hist = c->dLog10Hist.p;
         c->cohort.sampleRg = c->dSampleRg.p;
         c->cohort.nSamples = n_samples;
         c->cohort.nRg = n_readgroups;
@@ -460,6 +470,16 @@ int pd_segment_run(pd_ctx * c, uint64_t handle, uint64_t * ticket)
         PD_HIP(hipEventRecord(run.s1End, c->stream));
         pd::launchStage1Fallback(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTileTodo.p, c->stream);
         PD_HIP(hipGetLastError());
+        if (getenv("POPDEL_HIP_DEBUG"))
+        {
+            std::vector<uint8_t> todo(tiles);
+            PD_HIP(hipMemcpyAsync(todo.data(), c->dTileTodo.p, tiles, hipMemcpyDeviceToHost, c->stream));
+            PD_HIP(hipStreamSynchronize(c->stream));
+            size_t nTodo = 0;
+            for (uint8_t t : todo)
+                nTodo += t != 0;
+            fprintf(stderr, "[popdel_hip] stage 1: %zu of %zu tiles went to the fallback kernel (K=%u)\n", nTodo, tiles, s.maxLife);
+        }
         c->lastWindows = s.nWindows;
         *ticket = c->nextTicket++;
         c->runs[*ticket] = run;
@@ -585,6 +605,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             b.shifts = c->dShifts.p;
             b.partial = c->dPartial.p;
             b.counters = c->dCounters.p;
+            b.iterFlags = c->dIterFlags.p;
             b.pl = c->dPl.p;
             b.lad = c->dLad.p;
             b.dad = c->dDad.p;

@@ -32,6 +32,8 @@ struct RgConst
     unsigned minInitDelLen;
     double   stddev;
     double   minProb;
+    double   logMinProb;    // log(minProb), log10(minProb): filled on the device (buildLogTables)
+    double   log10MinProb;
     uint64_t histBase;      // offset (in doubles) of this read group's table in the histogram pool
 };
 
@@ -59,6 +61,8 @@ struct CohortView
 {
     const RgConst *  rg;
     const double *   hist;         // histogram pool
+    const double *   logHist;      // log() of every pool entry, computed once on the device
+    const double *   log10Hist;    // log10() of every pool entry
     const uint32_t * sampleRg;     // [nSamples + 1]
     uint32_t         nSamples;
     uint32_t         nRg;
@@ -119,6 +123,7 @@ struct Stage2Buffers
     unsigned *  suppFirst;   // support pools
     unsigned *  suppLast;
     // parameters
+    unsigned *  iterFlags;   // [maxIterations + 1]: 1 if any cell was still iterating after EM iteration i
     unsigned    minLen;
     unsigned    maxIterations;
     double      minLR;

@@ -402,74 +402,80 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
         storeCell(nB, maxLoad, vaB, vbB, (size_t)s * W + wB, wB, co.minThreshold, q3, flags, winFlag);
 }
 
-// Tiles the main kernel skipped: 128-input network where the LDS stage still fits, otherwise rank counting from HBM.
+// Tiles the main kernel skipped: 32-bit 64- or 128-input network where the LDS stage still fits, otherwise rank counting
+// straight from HBM. Persistent workgroups stride over the tile list so that an (almost) empty list costs nothing.
 __global__ __launch_bounds__(kStage1Block) void stage1FallbackKernel(SegmentView seg, CohortView co, int32_t * __restrict__ q3,
                                                                      uint8_t * __restrict__ flags, int * __restrict__ winFlag,
-                                                                     const uint8_t * __restrict__ tileTodo)
+                                                                     const uint8_t * __restrict__ tileTodo,
+                                                                     unsigned tilesPerSample, unsigned nTiles)
 {
     __shared__ PairDO ldsPairs[kStage1LdsPairs + 128];
     __shared__ uint32_t ldsWs[kStage1Block + 64 + 2];
-    const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;      // gridDim.x == tiles per sample
-    if (!tileTodo[tile])
-        return;
-    const unsigned s = blockIdx.y;
-    const unsigned w0 = blockIdx.x * kStage1Block;
-    const unsigned W = seg.nWindows;
-    const unsigned K = seg.maxLife;
-    const unsigned tid = threadIdx.x;
-    const unsigned w = w0 + tid;
-    const unsigned rg0 = co.sampleRg[s];
-    const bool singleRg = (co.sampleRg[s + 1] - rg0) == 1u;
-    int q = 0;
-    unsigned fl = 0;
-    bool done = false;
-    if (singleRg && K <= 64u)
+    for (unsigned tile = blockIdx.x; tile < nTiles; tile += gridDim.x)
     {
-        const uint32_t * ws = seg.winStart + (size_t)rg0 * (W + 1);
-        const unsigned wlo0 = (w0 + 1 >= K) ? (w0 + 1 - K) : 0u;
-        const unsigned whi = min(W, w0 + kStage1Block);
-        const unsigned nWs = whi - wlo0 + 1;
-        for (unsigned i = tid; i < nWs; i += kStage1Block)
-            ldsWs[i] = ws[wlo0 + i];
-        __syncthreads();
-        const unsigned A = ldsWs[0];
-        const unsigned nPairs = ldsWs[nWs - 1] - A;
-        if (nPairs <= (unsigned)kStage1LdsPairs)
+        if (!tileTodo[tile])
+            continue;                                              // block-uniform
+        const unsigned s = tile / tilesPerSample;
+        const unsigned w0 = (tile % tilesPerSample) * kStage1Block;
+        const unsigned W = seg.nWindows;
+        const unsigned K = seg.maxLife;
+        const unsigned tid = threadIdx.x;
+        const unsigned w = w0 + tid;
+        const unsigned rg0 = co.sampleRg[s];
+        const bool singleRg = (co.sampleRg[s + 1] - rg0) == 1u;
+        int q = 0;
+        unsigned fl = 0;
+        bool done = false;
+        __syncthreads();                                           // LDS reuse across tiles
+        if (singleRg && K <= 64u)
         {
-            const PairDO * src = seg.pairs + seg.rgBase[rg0] + A;
-            for (unsigned i = tid; i < nPairs; i += kStage1Block)
-                ldsPairs[i] = src[i];
+            const uint32_t * ws = seg.winStart + (size_t)rg0 * (W + 1);
+            const unsigned wlo0 = (w0 + 1 >= K) ? (w0 + 1 - K) : 0u;
+            const unsigned whi = min(W, w0 + kStage1Block);
+            const unsigned nWs = whi - wlo0 + 1;
+            for (unsigned i = tid; i < nWs; i += kStage1Block)
+                ldsWs[i] = ws[wlo0 + i];
             __syncthreads();
-            unsigned a = 0, cnt = 0;
-            if (w < W)
+            const unsigned A = ldsWs[0];
+            const unsigned nPairs = ldsWs[nWs - 1] - A;
+            if (nPairs <= (unsigned)kStage1LdsPairs)
             {
-                const unsigned wlo = (w + 1 >= K) ? (w + 1 - K) : 0u;
-                a = ldsWs[wlo - wlo0] - A;
-                cnt = ldsWs[w + 1 - wlo0] - A - a;
-            }
-            const unsigned cmax = waveMaxU32(cnt);
-            if (cmax <= 128u)
-            {
-                done = true;
+                const PairDO * src = seg.pairs + seg.rgBase[rg0] + A;
+                for (unsigned i = tid; i < nPairs; i += kStage1Block)
+                    ldsPairs[i] = src[i];
+                __syncthreads();
+                unsigned a = 0, cnt = 0;
                 if (w < W)
                 {
-                    if (cmax <= 64u)
-                        stage1CellFast<64>(ldsPairs, a, cnt, w, co.rg[rg0].maxLoad, q, fl);
-                    else
-                        stage1CellFast<128>(ldsPairs, a, cnt, w, co.rg[rg0].maxLoad, q, fl);
+                    const unsigned wlo = (w + 1 >= K) ? (w + 1 - K) : 0u;
+                    a = ldsWs[wlo - wlo0] - A;
+                    cnt = ldsWs[w + 1 - wlo0] - A - a;
+                }
+                const unsigned cmax = waveMaxU32(cnt);
+                if (cmax <= 128u)
+                {
+                    done = true;
+                    if (w < W)
+                    {
+                        if (cmax <= 64u)
+                            stage1CellFast<64>(ldsPairs, a, cnt, w, co.rg[rg0].maxLoad, q, fl);
+                        else
+                            stage1CellFast<128>(ldsPairs, a, cnt, w, co.rg[rg0].maxLoad, q, fl);
+                    }
                 }
             }
         }
+        if (w < W)
+        {
+            if (!done)
+                stage1CellGeneric(seg, co, s, w, q, fl);
+            const size_t cell = (size_t)s * W + w;
+            q3[cell] = q;
+            flags[cell] = (uint8_t)fl;
+            if ((fl & 2u) && q > co.minThreshold)
+                winFlag[w] = 1;
+        }
     }
-    if (w >= W)
-        return;
-    if (!done)
-        stage1CellGeneric(seg, co, s, w, q, fl);
-    const size_t cell = (size_t)s * W + w;
-    q3[cell] = q;
-    flags[cell] = (uint8_t)fl;
-    if ((fl & 2u) && q > co.minThreshold)
-        winFlag[w] = 1;
 }
 
 void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
@@ -483,8 +489,11 @@ void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, 
 void launchStage1Fallback(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
                           const uint8_t * tileTodo, hipStream_t stream)
 {
-    dim3 grid((seg.nWindows + kStage1Block - 1) / kStage1Block, co.nSamples);
-    hipLaunchKernelGGL(stage1FallbackKernel, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo);
+    const unsigned tilesPerSample = (seg.nWindows + kStage1Block - 1) / kStage1Block;
+    const unsigned nTiles = tilesPerSample * co.nSamples;
+    const unsigned blocks = nTiles < 2048u ? nTiles : 2048u;
+    hipLaunchKernelGGL(stage1FallbackKernel, dim3(blocks), dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo,
+                       tilesPerSample, nTiles);
 }
 
 }  // namespace pd

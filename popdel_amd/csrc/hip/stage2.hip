@@ -30,6 +30,38 @@ __device__ __forceinline__ double lookupI(const RgConst & rc, const double * his
     return hist[rc.histBase + (unsigned)i];
 }
 
+// Table position of a deviation, -1 for "outside the table" (min_prob).
+__device__ __forceinline__ long long lookupPos(const RgConst & rc, int deviation)
+{
+    int i = deviation + rc.median - rc.histOffset;
+    if (i <= 0 || i + 1 >= rc.histLen)
+        return -1;
+    return (long long)(rc.histBase + (unsigned)i);
+}
+
+// log / log10 of every histogram value, computed with the same device functions the kernels use on the fly.
+__global__ void logTableKernel(const double * __restrict__ hist, double * __restrict__ logHist, double * __restrict__ log10Hist,
+                               size_t n, RgConst * __restrict__ rg, unsigned nRg)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+    {
+        logHist[i] = log(hist[i]);
+        log10Hist[i] = log10(hist[i]);
+    }
+    if (i < nRg)
+    {
+        rg[i].logMinProb = log(rg[i].minProb);
+        rg[i].log10MinProb = log10(rg[i].minProb);
+    }
+}
+
+void buildLogTables(const double * hist, double * logHist, double * log10Hist, size_t n, RgConst * rg, unsigned nRg, hipStream_t st)
+{
+    const size_t m = n > nRg ? n : nRg;
+    hipLaunchKernelGGL(logTableKernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, hist, logHist, log10Hist, n, rg, nRg);
+}
+
 __device__ __forceinline__ void priors(double f, int somatic, double * g)
 {
     const double pseudo = 0.0000000001;
@@ -461,11 +493,12 @@ __global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, Co
                 if (!(r.p[i].off > w))
                     continue;
                 const int dv = r.p[i].dev;
-                const double ref = lookupI(rc, co.hist, dv - refShift);
-                const double del = lookupI(rc, co.hist, dv - len);
-                const double g0 = log(ref);
+                const long long pr = lookupPos(rc, dv - refShift), pdl = lookupPos(rc, dv - len);
+                const double ref = pr < 0 ? rc.minProb : co.hist[pr];
+                const double del = pdl < 0 ? rc.minProb : co.hist[pdl];
+                const double g0 = pr < 0 ? rc.logMinProb : co.logHist[pr];
                 const double g1 = log(ref + del) - PD_LN2;
-                const double g2 = log(del);
+                const double g2 = pdl < 0 ? rc.logMinProb : co.logHist[pdl];
                 rgSum[0] += g0;
                 rgSum[1] += g1;
                 rgSum[2] += g2;
@@ -648,7 +681,7 @@ __global__ void cellLenFinishKernel(Stage2Buffers b)
 }
 
 // Allele-frequency update and convergence test (reference :623-659).
-__global__ void cellFreqFinishKernel(Stage2Buffers b, unsigned nSamples)
+__global__ void cellFreqFinishKernel(Stage2Buffers b, unsigned nSamples, unsigned iteration)
 {
     const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= b.nCells)
@@ -656,6 +689,16 @@ __global__ void cellFreqFinishKernel(Stage2Buffers b, unsigned nSamples)
     CellState & cs = b.cells[c];
     if (cs.phase != kCellIterating)
         return;
+    struct Mark
+    {
+        CellState & cs;
+        unsigned *  flag;
+        __device__ ~Mark()
+        {
+            if (cs.phase == kCellIterating)
+                *flag = 1u;               // every writer stores the same value
+        }
+    } mark{cs, b.iterFlags + iteration};
     double sum = 0;
     for (unsigned t = 0; t < b.nTiles; ++t)
         sum += b.partial[((size_t)c * b.nTiles + t) * 4 + 2];
@@ -812,20 +855,21 @@ __global__ __launch_bounds__(kSampleTile) void finalKernel(SegmentView seg, Coho
                 else
                     ++dad[1];
             }
-            const double ref = lookupI(rc, co.hist, dv - refShift);
-            const double del = lookupI(rc, co.hist, dv - len);
+            const long long pr = lookupPos(rc, dv - refShift), pdl = lookupPos(rc, dv - len);
+            const double ref = pr < 0 ? rc.minProb : co.hist[pr];
+            const double del = pdl < 0 ? rc.minProb : co.hist[pdl];
             if (ref >= 2 * del)
                 ++lad[0];
             else if (del >= 2 * ref)
                 ++lad[2];
             else
                 ++lad[1];
-            logL[0] += log(ref);
-            gtLogs[0] += log10(ref);
+            logL[0] += pr < 0 ? rc.logMinProb : co.logHist[pr];
+            gtLogs[0] += pr < 0 ? rc.log10MinProb : co.log10Hist[pr];
             logL[1] += log(ref + del) - PD_LN2;
             gtLogs[1] += log10(ref + del) - PD_LOG10_2;
-            logL[2] += log(del);
-            gtLogs[2] += log10(del);
+            logL[2] += pdl < 0 ? rc.logMinProb : co.logHist[pdl];
+            gtLogs[2] += pdl < 0 ? rc.log10MinProb : co.log10Hist[pdl];
             allEq = allEq && (ref == del);
             ++nUsed;
             const unsigned st = r.st[i];
@@ -1051,6 +1095,7 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     const dim3 perSample(b.nTiles, b.nCells), tile(kSampleTile);
     const dim3 perCell((b.nCells + 127) / 128), cellBlock(128);
     hipLaunchKernelGGL(dataLikKernel, perSample, tile, 0, st, seg, co, b, 0);
+    (void)hipMemsetAsync(b.iterFlags, 0, (b.maxIterations + 1) * sizeof(unsigned), st);
     for (unsigned it = 0; it <= b.maxIterations; ++it)
     {
         hipLaunchKernelGGL(cellLoopHeadKernel, perCell, cellBlock, 0, st, b);
@@ -1059,7 +1104,17 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
         hipLaunchKernelGGL(updateLenKernel, perSample, tile, 0, st, seg, co, b);
         hipLaunchKernelGGL(cellLenFinishKernel, perCell, cellBlock, 0, st, b);
         hipLaunchKernelGGL(dataLikKernel, perSample, tile, 0, st, seg, co, b, 0);
-        hipLaunchKernelGGL(cellFreqFinishKernel, perCell, cellBlock, 0, st, b, co.nSamples);
+        hipLaunchKernelGGL(cellFreqFinishKernel, perCell, cellBlock, 0, st, b, co.nSamples, it);
+        // Most cells leave the loop after 2-4 iterations: look at the "someone is still iterating" flag now and then
+        // instead of launching the remaining (empty) iterations.
+        if (it == 2 || it == 4 || it == 7 || it == 10)
+        {
+            unsigned still = 1;
+            (void)hipMemcpyAsync(&still, b.iterFlags + it, sizeof(unsigned), hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            if (!still)
+                break;
+        }
     }
     // cells that left through the visited-table test: compare with the previous estimate
     hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellConverged, 0);
