@@ -144,6 +144,116 @@ __device__ __forceinline__ double blockSum(double v, double * scratch)
     return t;     // valid in thread 0
 }
 
+
+// ---- half-wave helpers: 32 lanes work on the pairs of ONE (cell, sample); the two halves of a wave are independent --
+__device__ __forceinline__ unsigned long long halfMask() { return 0xffffffffull << (threadIdx.x & 32u); }
+__device__ __forceinline__ unsigned halfCount(bool pred) { return (unsigned)__popcll(__ballot(pred) & halfMask()); }
+__device__ __forceinline__ double halfSum(double v)
+{
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1)
+        v += __shfl_xor(v, o, 32);
+    return v;
+}
+__device__ __forceinline__ unsigned halfMinU(unsigned v)
+{
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1)
+        v = min(v, (unsigned)__shfl_xor((int)v, o, 32));
+    return v;
+}
+__device__ __forceinline__ unsigned halfMaxU(unsigned v)
+{
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1)
+        v = max(v, (unsigned)__shfl_xor((int)v, o, 32));
+    return v;
+}
+// Number of active pairs of a read group in window w, counted by the half-wave (coalesced 8-byte loads).
+__device__ __forceinline__ unsigned halfCountActive(const PairRange & r, unsigned w, unsigned hl)
+{
+    unsigned n = 0;
+    for (unsigned base = r.begin; base < r.end; base += 32u)
+    {
+        const unsigned i = base + hl;
+        n += halfCount(i < r.end && r.p[i].off > w);
+    }
+    return n;
+}
+constexpr int kHalvesPerBlock = kSampleTile / 32;
+constexpr unsigned kHalfBufCap = 128;         // compacted active pairs kept in LDS per half-wave
+
+// Compacts the active pairs of (read group, window) into the half-wave's LDS buffer (ballot + rank), returns their
+// number n. If n < maxLoad, calls f(dev, start) once per active pair with the pairs spread densely over the 32 lanes,
+// so the FP64 work in f runs with ~n/32 lane utilisation instead of (#active / #candidates).
+template <bool NeedStart, class F>
+__device__ __forceinline__ unsigned halfForEachActive(const PairRange & r, unsigned w, unsigned hl, unsigned maxLoad, int * devBuf,
+                                                      unsigned * stBuf, F f)
+{
+    const unsigned long long hm = halfMask();
+    const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
+    unsigned n = 0;
+    for (unsigned base = r.begin; base < r.end; base += 32u)
+    {
+        const unsigned i = base + hl;
+        bool act = false;
+        PairDO p;
+        p.dev = 0;
+        p.off = 0;
+        if (i < r.end)
+        {
+            p = r.p[i];
+            act = p.off > w;
+        }
+        const unsigned long long bal = __ballot(act) & hm;
+        if (act)
+        {
+            const unsigned slot = n + (unsigned)__popcll(bal & below);
+            if (slot < kHalfBufCap)
+            {
+                devBuf[slot] = p.dev;
+                if (NeedStart)
+                    stBuf[slot] = r.st[i];
+            }
+        }
+        n += (unsigned)__popcll(bal);
+    }
+    if (n >= maxLoad)
+        return n;
+    if (n <= kHalfBufCap)
+    {
+        for (unsigned j = hl; j < n; j += 32u)
+            f(devBuf[j], NeedStart ? stBuf[j] : 0u);
+    }
+    else
+    {
+        for (unsigned base = r.begin; base < r.end; base += 32u)
+        {
+            const unsigned i = base + hl;
+            if (i < r.end)
+            {
+                const PairDO p = r.p[i];
+                if (p.off > w)
+                    f(p.dev, NeedStart ? r.st[i] : 0u);
+            }
+        }
+    }
+    return n;
+}
+// Sum of one value per half-wave over the block, in half-wave order (valid in thread 0).
+__device__ __forceinline__ double blockSumHalves(double v, double * scratch /* kHalvesPerBlock */)
+{
+    __syncthreads();
+    if ((threadIdx.x & 31u) == 0)
+        scratch[threadIdx.x >> 5] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < kHalvesPerBlock; ++i)
+            t += scratch[i];
+    return t;
+}
+
 // =====================================================================================================================
 // Candidate lengths: sort the valid Q3 values of a flagged window, chain-cluster them (gap < 50), keep cluster means
 // above the threshold. The threshold table is indexed by POSITION IN THE SORTED ARRAY (reference :65,72,80).
@@ -341,39 +451,51 @@ __global__ __launch_bounds__(kSampleTile) void cellInitKernel(SegmentView seg, C
 {
     __shared__ unsigned acc[3];
     const unsigned cellIdx = blockIdx.y;
-    const unsigned s = blockIdx.x * kSampleTile + threadIdx.x;
     if (threadIdx.x < 3)
         acc[threadIdx.x] = 0;
     __syncthreads();
     const CellState & cs = b.cells[cellIdx];
     const unsigned w = (unsigned)cs.window;
     const unsigned L = (unsigned)cs.initLen;
-    if (s < co.nSamples)
+    const unsigned hl = threadIdx.x & 31u, half = threadIdx.x >> 5;
+    unsigned count = 0, total = 0, low = 0;
+    for (unsigned k = 0; k < 32u; ++k)
     {
-        unsigned count = 0, total = 0;
+        const unsigned s = blockIdx.x * kSampleTile + half + k * kHalvesPerBlock;
+        if (s >= co.nSamples)
+            break;                                         // uniform per half-wave
         for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
         {
             const RgConst rc = co.rg[rg];
             PairRange r = pairRange(seg, rg, w);
-            unsigned n = countActive(r, w);
+            const unsigned n = halfCountActive(r, w, hl);
             if (n == 0 || n >= rc.maxLoad)
                 continue;
             total += n;
-            int windowBegin = max((int)L / 2, (int)floor((L - 2 * rc.stddev) + 0.5));
-            int windowEnd = (int)(L + 2 * rc.stddev);
-            for (unsigned i = r.begin; i < r.end; ++i)
-                if (r.p[i].off > w)
+            const int windowBegin = max((int)L / 2, (int)floor((L - 2 * rc.stddev) + 0.5));
+            const int windowEnd = (int)(L + 2 * rc.stddev);
+            for (unsigned base = r.begin; base < r.end; base += 32u)
+            {
+                const unsigned i = base + hl;
+                bool hit = false;
+                if (i < r.end)
                 {
-                    int dv = r.p[i].dev;
-                    count += (dv > windowBegin && dv < windowEnd) ? 1u : 0u;
+                    const PairDO p = r.p[i];
+                    hit = p.off > w && p.dev > windowBegin && p.dev < windowEnd;
                 }
+                count += halfCount(hit);
+            }
         }
+        low += (flags[(size_t)s * seg.nWindows + w] & 1u) ? 1u : 0u;
+    }
+    if (hl == 0)
+    {
         if (count)
             atomicAdd(&acc[0], count);
         if (total)
             atomicAdd(&acc[1], total);
-        if (flags[(size_t)s * seg.nWindows + w] & 1u)
-            atomicAdd(&acc[2], 1u);
+        if (low)
+            atomicAdd(&acc[2], low);
     }
     __syncthreads();
     if (threadIdx.x < 3 && acc[threadIdx.x])
@@ -458,17 +580,24 @@ __device__ __forceinline__ void finishTriple(double * d, const double * logL, un
 __global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, CohortView co, Stage2Buffers b, int mode)
 {
     __shared__ double red[4];
+    __shared__ double shLogL[kSampleTile][3];
+    __shared__ unsigned shUsed[kSampleTile];          // bit 31: every pair had ref == del
+    __shared__ int shDev[kHalvesPerBlock][kHalfBufCap];
     const unsigned cellIdx = blockIdx.y;
     CellState & cs = b.cells[cellIdx];
     const int wantPhase = mode == 0 ? kCellIterating : kCellConverged;
     if (cs.phase != wantPhase)
         return;
-    const unsigned s = blockIdx.x * kSampleTile + threadIdx.x;
     const unsigned w = (unsigned)cs.window;
     const int len = (int)(mode == 0 ? cs.len : cs.prevLen);
-    double term = 0;
-    if (s < co.nSamples)
+    const unsigned hl = threadIdx.x & 31u, half = threadIdx.x >> 5;
+    // phase 1: half-waves walk the pairs, lane = pair
+    for (unsigned k = 0; k < 32u; ++k)
     {
+        const unsigned slot = half + k * kHalvesPerBlock;
+        const unsigned s = blockIdx.x * kSampleTile + slot;
+        if (s >= co.nSamples)
+            break;                                         // uniform per half-wave
         double logL[3] = {0, 0, 0};
         unsigned nUsed = 0;
         bool allEq = true;
@@ -476,49 +605,59 @@ __global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, Co
         {
             const RgConst rc = co.rg[rg];
             PairRange r = pairRange(seg, rg, w);
-            const unsigned n = countActive(r, w);
+            const int refShift = (mode == 0) ? b.shifts[(size_t)cellIdx * co.nRg + rg] : 0;
+            double g0 = 0, g1 = 0, g2 = 0;
+            bool eq = true;
+            const unsigned n = halfForEachActive<false>(r, w, hl, rc.maxLoad, shDev[half], nullptr, [&](int dv, unsigned) {
+                const long long pr = lookupPos(rc, dv - refShift), pdl = lookupPos(rc, dv - len);
+                const double ref = pr < 0 ? rc.minProb : co.hist[pr];
+                const double del = pdl < 0 ? rc.minProb : co.hist[pdl];
+                g0 += pr < 0 ? rc.logMinProb : co.logHist[pr];
+                g1 += log(ref + del) - PD_LN2;
+                g2 += pdl < 0 ? rc.logMinProb : co.logHist[pdl];
+                eq = eq && (ref == del);
+            });
             if (n >= rc.maxLoad)
             {
-                if (rg == 0)
+                if (rg == 0 && hl == 0)
                 {
                     cs.rg0Kind = 1;
                     cs.rg0[0] = cs.rg0[1] = cs.rg0[2] = 0;
                 }
                 continue;
             }
-            const int refShift = (mode == 0) ? b.shifts[(size_t)cellIdx * co.nRg + rg] : 0;
-            double rgSum[3] = {0, 0, 0};
-            for (unsigned i = r.begin; i < r.end; ++i)
+            const double rs0 = halfSum(g0), rs1 = halfSum(g1), rs2 = halfSum(g2);
+            allEq = allEq && (halfCount(!eq) == 0u);
+            nUsed += n;
+            logL[0] += rs0;
+            logL[1] += rs1;
+            logL[2] += rs2;
+            if (rg == 0 && hl == 0)
             {
-                if (!(r.p[i].off > w))
-                    continue;
-                const int dv = r.p[i].dev;
-                const long long pr = lookupPos(rc, dv - refShift), pdl = lookupPos(rc, dv - len);
-                const double ref = pr < 0 ? rc.minProb : co.hist[pr];
-                const double del = pdl < 0 ? rc.minProb : co.hist[pdl];
-                const double g0 = pr < 0 ? rc.logMinProb : co.logHist[pr];
-                const double g1 = log(ref + del) - PD_LN2;
-                const double g2 = pdl < 0 ? rc.logMinProb : co.logHist[pdl];
-                rgSum[0] += g0;
-                rgSum[1] += g1;
-                rgSum[2] += g2;
-                allEq = allEq && (ref == del);
-                ++nUsed;
-            }
-            logL[0] += rgSum[0];
-            logL[1] += rgSum[1];
-            logL[2] += rgSum[2];
-            if (rg == 0)
-            {
-                const double m = fmax(fmax(rgSum[0], rgSum[1]), rgSum[2]);
+                const double m = fmax(fmax(rs0, rs1), rs2);
                 cs.rg0Kind = 0;
-                cs.rg0[0] = rgSum[0] - m;
-                cs.rg0[1] = rgSum[1] - m;
-                cs.rg0[2] = rgSum[2] - m;
+                cs.rg0[0] = rs0 - m;
+                cs.rg0[1] = rs1 - m;
+                cs.rg0[2] = rs2 - m;
             }
         }
+        if (hl == 0)
+        {
+            shLogL[slot][0] = logL[0];
+            shLogL[slot][1] = logL[1];
+            shLogL[slot][2] = logL[2];
+            shUsed[slot] = nUsed | (allEq ? 0x80000000u : 0u);
+        }
+    }
+    __syncthreads();
+    // phase 2: one lane per sample finishes the triple and the allele-frequency term
+    double term = 0;
+    const unsigned s = blockIdx.x * kSampleTile + threadIdx.x;
+    if (s < co.nSamples)
+    {
         double d[3];
-        finishTriple(d, logL, nUsed, allEq);
+        const double logL[3] = {shLogL[threadIdx.x][0], shLogL[threadIdx.x][1], shLogL[threadIdx.x][2]};
+        finishTriple(d, logL, shUsed[threadIdx.x] & 0x7fffffffu, (shUsed[threadIdx.x] >> 31) != 0u);
         double * out = b.dl + ((size_t)cellIdx * co.nSamples + s) * 3;
         out[0] = d[0];
         out[1] = d[1];
@@ -578,52 +717,58 @@ __global__ void cellLoopHeadKernel(Stage2Buffers b)
 // =====================================================================================================================
 __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, CohortView co, Stage2Buffers b)
 {
-    __shared__ double red[4];
+    __shared__ double red[kHalvesPerBlock];
     const unsigned cellIdx = blockIdx.y;
     const CellState & cs = b.cells[cellIdx];
     if (cs.phase != kCellIterating)
         return;
-    const unsigned s = blockIdx.x * kSampleTile + threadIdx.x;
     const unsigned w = (unsigned)cs.window;
     const int len = (int)cs.len;
-    double sumDel = 0, wSumDel = 0;
-    if (s < co.nSamples)
+    const unsigned hl = threadIdx.x & 31u, half = threadIdx.x >> 5;
+    const double g0 = cs.gt[0], g1 = cs.gt[1], g2 = cs.gt[2];
+    // weights of the reference model, shared by all read groups (always RG 0's triple)
+    bool rgNan = cs.rg0Kind == 1;
+    double ea0Rg = 0, ea1Rg = 0;
+    if (!rgNan)
     {
-        const double * d = b.dl + ((size_t)cellIdx * co.nSamples + s) * 3;
-        const double g0 = cs.gt[0], g1 = cs.gt[1], g2 = cs.gt[2];
-        const double aSum = exp(d[0]) * g0 + exp(d[1]) * g1 + exp(d[2]) * g2;
-        const double a1 = d[1] + log(g1) - log(aSum);
-        const double a2 = d[2] + log(g2) - log(aSum);
-        const double ea1 = exp(a1), ea2 = exp(a2);
-        // weights of the reference model, shared by all read groups
-        bool rgNan = cs.rg0Kind == 1;
-        double ea0Rg = 0, ea1Rg = 0;
-        if (!rgNan)
+        const double aSumRg = exp(cs.rg0[0]) * g0 + exp(cs.rg0[1]) * g1 + exp(cs.rg0[2]) * g2;
+        const double l0 = (cs.rg0[0] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : cs.rg0[0];
+        const double l1 = (cs.rg0[1] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : cs.rg0[1];
+        ea0Rg = exp(l0 + log(g0) - log(aSumRg));
+        ea1Rg = exp(l1 + log(g1) - log(aSumRg));
+        rgNan = isnan(ea0Rg) || isnan(ea1Rg);
+    }
+    // per-sample weights exp(a1), exp(a2): one lane per sample, shared through LDS
+    __shared__ double shEa[kSampleTile][2];
+    __shared__ int shDev[kHalvesPerBlock][kHalfBufCap];
+    {
+        const unsigned s = blockIdx.x * kSampleTile + threadIdx.x;
+        if (s < co.nSamples)
         {
-            const double aSumRg = exp(cs.rg0[0]) * g0 + exp(cs.rg0[1]) * g1 + exp(cs.rg0[2]) * g2;
-            const double l0 = (cs.rg0[0] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : cs.rg0[0];
-            const double l1 = (cs.rg0[1] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : cs.rg0[1];
-            const double a0Rg = l0 + log(g0) - log(aSumRg);
-            const double a1Rg = l1 + log(g1) - log(aSumRg);
-            ea0Rg = exp(a0Rg);
-            ea1Rg = exp(a1Rg);
-            rgNan = isnan(ea0Rg) || isnan(ea1Rg);
+            const double * d = b.dl + ((size_t)cellIdx * co.nSamples + s) * 3;
+            const double aSum = exp(d[0]) * g0 + exp(d[1]) * g1 + exp(d[2]) * g2;
+            shEa[threadIdx.x][0] = exp(d[1] + log(g1) - log(aSum));
+            shEa[threadIdx.x][1] = exp(d[2] + log(g2) - log(aSum));
         }
+    }
+    __syncthreads();
+    double sumDelAcc = 0, wSumDelAcc = 0;
+    for (unsigned k = 0; k < 32u; ++k)
+    {
+        const unsigned slot = half + k * kHalvesPerBlock;
+        const unsigned s = blockIdx.x * kSampleTile + slot;
+        if (s >= co.nSamples)
+            break;
+        const double ea1 = shEa[slot][0];
+        const double ea2 = shEa[slot][1];
         for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
         {
             const RgConst rc = co.rg[rg];
             PairRange r = pairRange(seg, rg, w);
-            const unsigned n = countActive(r, w);
-            if (n >= rc.maxLoad)
-                continue;
             int * shiftSlot = b.shifts + (size_t)cellIdx * co.nRg + rg;
             const int refShift = *shiftSlot;
-            double sumRef = 0, wSumRef = 0;
-            for (unsigned i = r.begin; i < r.end; ++i)
-            {
-                if (!(r.p[i].off > w))
-                    continue;
-                const int dv = r.p[i].dev;
+            double sumDel = 0, wSumDel = 0, sumRef = 0, wSumRef = 0;
+            const unsigned n = halfForEachActive<false>(r, w, hl, rc.maxLoad, shDev[half], nullptr, [&](int dv, unsigned) {
                 const double del = lookupI(rc, co.hist, dv - len);
                 const double noDel = lookupI(rc, co.hist, dv - refShift);
                 const double probDel = ea1 * del / (del + noDel) + ea2;
@@ -632,7 +777,15 @@ __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, 
                 sumRef += probRef;
                 wSumDel += probDel * dv;
                 wSumRef += probRef * dv;
-            }
+            });
+            if (n >= rc.maxLoad)
+                continue;
+            sumDel = halfSum(sumDel);
+            wSumDel = halfSum(wSumDel);
+            sumRef = halfSum(sumRef);
+            wSumRef = halfSum(wSumRef);
+            sumDelAcc += sumDel;
+            wSumDelAcc += wSumDel;
             int newShift;
             const double q = wSumRef / sumRef;
             if (rgNan || !(q > -2147483649.0 && q < 2147483648.0))
@@ -641,11 +794,12 @@ __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, 
                 newShift = (int)q;
             if (newShift > rc.stddev || newShift < -1 * rc.stddev)
                 newShift = 0;
-            *shiftSlot = newShift;
+            if (hl == 0)
+                *shiftSlot = newShift;
         }
     }
-    const double t0 = blockSum(sumDel, red);
-    const double t1 = blockSum(wSumDel, red);
+    const double t0 = blockSumHalves(sumDelAcc, red);
+    const double t1 = blockSumHalves(wSumDelAcc, red);
     if (threadIdx.x == 0)
     {
         double * p = b.partial + ((size_t)cellIdx * b.nTiles + blockIdx.x) * 4;
@@ -808,154 +962,171 @@ __global__ void cellPostLoopKernel(Stage2Buffers b)
 __global__ __launch_bounds__(kSampleTile) void finalKernel(SegmentView seg, CohortView co, Stage2Buffers b,
                                                            const uint8_t * __restrict__ flags)
 {
+    __shared__ int shDev[kHalvesPerBlock][kHalfBufCap];
+    __shared__ unsigned shSt[kHalvesPerBlock][kHalfBufCap];
     const unsigned cellIdx = blockIdx.y;
     CellState & cs = b.cells[cellIdx];
     if (cs.phase != kCellFinal)
         return;
-    const unsigned s = blockIdx.x * kSampleTile + threadIdx.x;
-    if (s >= co.nSamples)
-        return;
     const unsigned w = (unsigned)cs.window;
     const int len = (int)cs.len;
-    double logL[3] = {0, 0, 0}, gtLogs[3] = {0, 0, 0};
-    unsigned lad[3] = {0, 0, 0}, dad[5] = {0, 0, 0, 0, 0};
-    unsigned nUsed = 0;
-    bool allEq = true;
-    int delLower = 0x7fffffff, delUpper = 0;
-    unsigned mn = 0xffffffffu, mx = 0;
-    for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
+    const unsigned hl = threadIdx.x & 31u, half = threadIdx.x >> 5;
+    for (unsigned k = 0; k < 32u; ++k)
     {
-        const RgConst rc = co.rg[rg];
-        PairRange r = pairRange(seg, rg, w);
-        const unsigned n = countActive(r, w);
-        if (n >= rc.maxLoad)
-            continue;
-        const int refShift = cs.restoreZeroShifts ? 0 : b.shifts[(size_t)cellIdx * co.nRg + rg];
-        delLower = (int)((unsigned)len - (unsigned)rc.lowerQ);
-        delUpper = (int)((unsigned)len + (unsigned)rc.upperQ);
-        for (unsigned i = r.begin; i < r.end; ++i)
+        const unsigned s = blockIdx.x * kSampleTile + half + k * kHalvesPerBlock;
+        if (s >= co.nSamples)
+            break;
+        double logL[3] = {0, 0, 0}, gtLogs[3] = {0, 0, 0};
+        unsigned lad[3] = {0, 0, 0}, dad[5] = {0, 0, 0, 0, 0};
+        unsigned nUsed = 0;
+        bool allEq = true;
+        int delLower = 0x7fffffff, delUpper = 0;
+        unsigned mn = 0xffffffffu, mx = 0;
+        for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
         {
-            if (!(r.p[i].off > w))
-                continue;
-            const int dv = r.p[i].dev;
-            // distribution-derived class
-            if (dv > rc.upperQ)
-            {
-                if (dv < delLower)
-                    ++dad[2];
-                else if (dv <= delUpper)
-                    ++dad[3];
+            const RgConst rc = co.rg[rg];
+            PairRange r = pairRange(seg, rg, w);
+            const int refShift = cs.restoreZeroShifts ? 0 : b.shifts[(size_t)cellIdx * co.nRg + rg];
+            const int rgLower = (int)((unsigned)len - (unsigned)rc.lowerQ);
+            const int rgUpper = (int)((unsigned)len + (unsigned)rc.upperQ);
+            double l0 = 0, l1 = 0, l2 = 0, t0 = 0, t1 = 0, t2 = 0;
+            bool eq = true;
+            unsigned rgMn = 0xffffffffu, rgMx = 0;
+            unsigned rgLad[3] = {0, 0, 0}, rgDad[5] = {0, 0, 0, 0, 0};
+            const unsigned n = halfForEachActive<true>(r, w, hl, rc.maxLoad, shDev[half], shSt[half], [&](int dv, unsigned st) {
+                int cls;
+                if (dv > rc.upperQ)
+                    cls = (dv < rgLower) ? 2 : ((dv <= rgUpper) ? 3 : 4);
                 else
-                    ++dad[4];
-            }
-            else
-            {
-                if (dv < delUpper)
-                    ++dad[0];
-                else
-                    ++dad[1];
-            }
-            const long long pr = lookupPos(rc, dv - refShift), pdl = lookupPos(rc, dv - len);
-            const double ref = pr < 0 ? rc.minProb : co.hist[pr];
-            const double del = pdl < 0 ? rc.minProb : co.hist[pdl];
-            if (ref >= 2 * del)
-                ++lad[0];
-            else if (del >= 2 * ref)
-                ++lad[2];
-            else
-                ++lad[1];
-            logL[0] += pr < 0 ? rc.logMinProb : co.logHist[pr];
-            gtLogs[0] += pr < 0 ? rc.log10MinProb : co.log10Hist[pr];
-            logL[1] += log(ref + del) - PD_LN2;
-            gtLogs[1] += log10(ref + del) - PD_LOG10_2;
-            logL[2] += pdl < 0 ? rc.logMinProb : co.logHist[pdl];
-            gtLogs[2] += pdl < 0 ? rc.log10MinProb : co.log10Hist[pdl];
-            allEq = allEq && (ref == del);
-            ++nUsed;
-            const unsigned st = r.st[i];
-            const int ins = max(0, dv + rc.median - 2 * rc.readLength);
-            mn = min(mn, st);
-            mx = max(mx, st + (unsigned)ins);
-        }
-    }
-    if (mn == 0xffffffffu)
-        mn = 0;
-    // supporting pairs use the borders of the LAST usable read group for all read groups of the sample
-    for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
-    {
-        const RgConst rc = co.rg[rg];
-        PairRange r = pairRange(seg, rg, w);
-        const unsigned n = countActive(r, w);
-        if (n >= rc.maxLoad)
-            continue;
-        for (unsigned i = r.begin; i < r.end; ++i)
-        {
-            if (!(r.p[i].off > w))
-                continue;
-            const int dv = r.p[i].dev;
-            if (dv >= delLower && dv <= delUpper)
-            {
+                    cls = (dv < rgUpper) ? 0 : 1;
+                const long long pr = lookupPos(rc, dv - refShift), pdl = lookupPos(rc, dv - len);
+                const double ref = pr < 0 ? rc.minProb : co.hist[pr];
+                const double del = pdl < 0 ? rc.minProb : co.hist[pdl];
+                const int lcls = (ref >= 2 * del) ? 0 : ((del >= 2 * ref) ? 2 : 1);
+                l0 += pr < 0 ? rc.logMinProb : co.logHist[pr];
+                t0 += pr < 0 ? rc.log10MinProb : co.log10Hist[pr];
+                l1 += log(ref + del) - PD_LN2;
+                t1 += log10(ref + del) - PD_LOG10_2;
+                l2 += pdl < 0 ? rc.logMinProb : co.logHist[pdl];
+                t2 += pdl < 0 ? rc.log10MinProb : co.log10Hist[pdl];
+                eq = eq && (ref == del);
                 const int ins = max(0, dv + rc.median - 2 * rc.readLength);
-                const unsigned slot = atomicAdd(&cs.suppCount, 1u);
-                b.suppFirst[cs.suppBase + slot] = r.st[i];
-                b.suppLast[cs.suppBase + slot] = r.st[i] + (unsigned)ins;
+                rgMn = min(rgMn, st);
+                rgMx = max(rgMx, st + (unsigned)ins);
+                // class counts: lane 0 takes part in every iteration that has any lane, so its totals are complete
+#pragma unroll
+                for (int c = 0; c < 5; ++c)
+                    rgDad[c] += halfCount(cls == c);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    rgLad[c] += halfCount(lcls == c);
+            });
+            if (n >= rc.maxLoad)
+                continue;
+            delLower = rgLower;
+            delUpper = rgUpper;
+            logL[0] += halfSum(l0);
+            logL[1] += halfSum(l1);
+            logL[2] += halfSum(l2);
+            gtLogs[0] += halfSum(t0);
+            gtLogs[1] += halfSum(t1);
+            gtLogs[2] += halfSum(t2);
+            allEq = allEq && (halfCount(!eq) == 0u);
+            nUsed += n;
+            mn = min(mn, rgMn);
+            mx = max(mx, rgMx);
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+                dad[c] += rgDad[c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                lad[c] += rgLad[c];
+        }
+        mn = halfMinU(mn);
+        mx = halfMaxU(mx);
+        if (mn == 0xffffffffu)
+            mn = 0;
+        // supporting pairs use the borders of the LAST usable read group for all read groups of the sample
+        for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
+        {
+            const RgConst rc = co.rg[rg];
+            PairRange r = pairRange(seg, rg, w);
+            halfForEachActive<true>(r, w, hl, rc.maxLoad, shDev[half], shSt[half], [&](int dv, unsigned st) {
+                const bool supp = dv >= delLower && dv <= delUpper;
+                const unsigned long long bal = __ballot(supp) & halfMask();
+                const unsigned cnt = (unsigned)__popcll(bal);
+                if (cnt)                                              // same for all lanes in here
+                {
+                    unsigned slot0 = 0;
+                    if (hl == 0)
+                        slot0 = atomicAdd(&cs.suppCount, cnt);
+                    slot0 = (unsigned)__shfl((int)slot0, 0, 32);
+                    if (supp)
+                    {
+                        const unsigned rank = (unsigned)__popcll(bal & ((1ull << (threadIdx.x & 63u)) - 1ull));
+                        b.suppFirst[cs.suppBase + slot0 + rank] = st;
+                        b.suppLast[cs.suppBase + slot0 + rank] = st + (unsigned)max(0, dv + rc.median - 2 * rc.readLength);
+                    }
+                }
+            });
+        }
+        if (hl != 0)
+            continue;
+        double d[3];
+        double gl[3] = {gtLogs[0], gtLogs[1], gtLogs[2]};
+        if (nUsed == 0)
+        {
+            // sum(gtLogs) == 0: reference-like triple, gtLogs stay untouched (all zero)
+            d[0] = 0;
+            d[1] = PD_LOG_PSEUDO;
+            d[2] = PD_LOG_PSEUDO;
+        }
+        else
+        {
+            const double maxGt = fmax(fmax(gl[0], gl[1]), gl[2]);
+            gl[0] -= maxGt;
+            gl[1] -= maxGt;
+            gl[2] -= maxGt;
+            if (allEq)
+            {
+                gl[0] = gl[1] = gl[2] = 0;      // x87: a hair apart, not equal; all phred values round to 0
             }
+            else if (gl[0] == gl[1] && gl[0] == gl[2])
+            {
+                gl[0] = 0;
+                gl[1] = -10;
+                gl[2] = -10;
+            }
+            finishTriple(d, logL, nUsed, allEq);
         }
-    }
-    double d[3];
-    double gl[3] = {gtLogs[0], gtLogs[1], gtLogs[2]};
-    if (nUsed == 0)
-    {
-        // sum(gtLogs) == 0: reference-like triple, gtLogs stay untouched (all zero)
-        d[0] = 0;
-        d[1] = PD_LOG_PSEUDO;
-        d[2] = PD_LOG_PSEUDO;
-    }
-    else
-    {
-        const double maxGt = fmax(fmax(gl[0], gl[1]), gl[2]);
-        gl[0] -= maxGt;
-        gl[1] -= maxGt;
-        gl[2] -= maxGt;
-        if (allEq)
+        const size_t o = (size_t)cellIdx * co.nSamples + s;
+        b.dl[o * 3 + 0] = d[0];
+        b.dl[o * 3 + 1] = d[1];
+        b.dl[o * 3 + 2] = d[2];
+        // phred-scaled genotype likelihoods; exp() of log10-based values as in the reference
+        uint32_t pl[3];
         {
-            gl[0] = gl[1] = gl[2] = 0;      // x87: a hair apart, not equal; all phred values round to 0
+            const double gTot = log10(exp(gl[0]) + exp(gl[1]) + exp(gl[2]));
+            const double p0 = -10 * (gl[0] - gTot);
+            const double p1 = -10 * (gl[1] - gTot);
+            const double p2 = -10 * (gl[2] - gTot);
+            const double mnP = fmin(fmin(p0, p1), p2);
+            pl[0] = (uint32_t)round(p0 - mnP);
+            pl[1] = (uint32_t)round(p1 - mnP);
+            pl[2] = (uint32_t)round(p2 - mnP);
         }
-        else if (gl[0] == gl[1] && gl[0] == gl[2])
+        if (flags[(size_t)s * seg.nWindows + w] & 1u)
+            pl[0] = pl[1] = pl[2] = 0;
+        for (int c = 0; c < 3; ++c)
         {
-            gl[0] = 0;
-            gl[1] = -10;
-            gl[2] = -10;
+            b.pl[o * 3 + c] = pl[c];
+            b.lad[o * 3 + c] = lad[c];
         }
-        finishTriple(d, logL, nUsed, allEq);
+        for (int c = 0; c < 5; ++c)
+            b.dad[o * 5 + c] = dad[c];
+        b.fl[o * 2 + 0] = mn;
+        b.fl[o * 2 + 1] = mx;
     }
-    const size_t o = (size_t)cellIdx * co.nSamples + s;
-    b.dl[o * 3 + 0] = d[0];
-    b.dl[o * 3 + 1] = d[1];
-    b.dl[o * 3 + 2] = d[2];
-    // phred-scaled genotype likelihoods; exp() of log10-based values as in the reference
-    uint32_t pl[3];
-    {
-        const double gTot = log10(exp(gl[0]) + exp(gl[1]) + exp(gl[2]));
-        const double p0 = -10 * (gl[0] - gTot);
-        const double p1 = -10 * (gl[1] - gTot);
-        const double p2 = -10 * (gl[2] - gTot);
-        const double mnP = fmin(fmin(p0, p1), p2);
-        pl[0] = (uint32_t)round(p0 - mnP);
-        pl[1] = (uint32_t)round(p1 - mnP);
-        pl[2] = (uint32_t)round(p2 - mnP);
-    }
-    if (flags[(size_t)s * seg.nWindows + w] & 1u)
-        pl[0] = pl[1] = pl[2] = 0;
-    for (int k = 0; k < 3; ++k)
-    {
-        b.pl[o * 3 + k] = pl[k];
-        b.lad[o * 3 + k] = lad[k];
-    }
-    for (int k = 0; k < 5; ++k)
-        b.dad[o * 5 + k] = dad[k];
-    b.fl[o * 2 + 0] = mn;
-    b.fl[o * 2 + 1] = mx;
 }
 
 // k-th smallest of an unsigned pool by 4 x 8-bit radix passes (one workgroup per cell and pool).
