@@ -180,6 +180,47 @@ __device__ __forceinline__ unsigned halfCountActive(const PairRange & r, unsigne
     }
     return n;
 }
+
+// Per-sample metadata of one 256-sample tile, fetched by 256 lanes in parallel (one dependent-load chain for the whole
+// tile instead of one per sample) and kept in LDS while the half-waves walk the samples.
+struct SampleMeta
+{
+    RgConst   rc;        // constants of the sample's first read group
+    PairRange r;         // its pair range in the cell's window
+    unsigned  rg0, rg1;  // read groups of the sample: [rg0, rg1)
+};
+
+__device__ __forceinline__ void loadTileMeta(const SegmentView & seg, const CohortView & co, unsigned w, SampleMeta * meta)
+{
+    const unsigned s = blockIdx.x * kSampleTile + threadIdx.x;
+    if (s < co.nSamples)
+    {
+        SampleMeta m;
+        m.rg0 = co.sampleRg[s];
+        m.rg1 = co.sampleRg[s + 1];
+        m.rc = co.rg[m.rg0];
+        m.r = pairRange(seg, m.rg0, w);
+        meta[threadIdx.x] = m;
+    }
+    __syncthreads();
+}
+
+// Constants and pair range of read group `rg` of the sample described by `m` (cached for the first read group).
+__device__ __forceinline__ void rgOfSample(const SampleMeta & m, const SegmentView & seg, const CohortView & co, unsigned w,
+                                           unsigned rg, RgConst & rc, PairRange & r)
+{
+    if (rg == m.rg0)
+    {
+        rc = m.rc;
+        r = m.r;
+    }
+    else
+    {
+        rc = co.rg[rg];
+        r = pairRange(seg, rg, w);
+    }
+}
+
 constexpr int kHalvesPerBlock = kSampleTile / 32;
 constexpr unsigned kHalfBufCap = 128;         // compacted active pairs kept in LDS per half-wave
 
@@ -458,16 +499,21 @@ __global__ __launch_bounds__(kSampleTile) void cellInitKernel(SegmentView seg, C
     const unsigned w = (unsigned)cs.window;
     const unsigned L = (unsigned)cs.initLen;
     const unsigned hl = threadIdx.x & 31u, half = threadIdx.x >> 5;
+    __shared__ SampleMeta shMeta[kSampleTile];
+    loadTileMeta(seg, co, w, shMeta);
     unsigned count = 0, total = 0, low = 0;
     for (unsigned k = 0; k < 32u; ++k)
     {
-        const unsigned s = blockIdx.x * kSampleTile + half + k * kHalvesPerBlock;
+        const unsigned slot = half + k * kHalvesPerBlock;
+        const unsigned s = blockIdx.x * kSampleTile + slot;
         if (s >= co.nSamples)
             break;                                         // uniform per half-wave
-        for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
+        const SampleMeta & meta = shMeta[slot];
+        for (unsigned rg = meta.rg0; rg < meta.rg1; ++rg)
         {
-            const RgConst rc = co.rg[rg];
-            PairRange r = pairRange(seg, rg, w);
+            RgConst rc;
+            PairRange r;
+            rgOfSample(meta, seg, co, w, rg, rc, r);
             const unsigned n = halfCountActive(r, w, hl);
             if (n == 0 || n >= rc.maxLoad)
                 continue;
@@ -591,6 +637,8 @@ __global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, Co
     const unsigned w = (unsigned)cs.window;
     const int len = (int)(mode == 0 ? cs.len : cs.prevLen);
     const unsigned hl = threadIdx.x & 31u, half = threadIdx.x >> 5;
+    __shared__ SampleMeta shMeta[kSampleTile];
+    loadTileMeta(seg, co, w, shMeta);
     // phase 1: half-waves walk the pairs, lane = pair
     for (unsigned k = 0; k < 32u; ++k)
     {
@@ -598,13 +646,15 @@ __global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, Co
         const unsigned s = blockIdx.x * kSampleTile + slot;
         if (s >= co.nSamples)
             break;                                         // uniform per half-wave
+        const SampleMeta & meta = shMeta[slot];
         double logL[3] = {0, 0, 0};
         unsigned nUsed = 0;
         bool allEq = true;
-        for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
+        for (unsigned rg = meta.rg0; rg < meta.rg1; ++rg)
         {
-            const RgConst rc = co.rg[rg];
-            PairRange r = pairRange(seg, rg, w);
+            RgConst rc;
+            PairRange r;
+            rgOfSample(meta, seg, co, w, rg, rc, r);
             const int refShift = (mode == 0) ? b.shifts[(size_t)cellIdx * co.nRg + rg] : 0;
             double g0 = 0, g1 = 0, g2 = 0;
             bool eq = true;
@@ -738,6 +788,8 @@ __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, 
         ea1Rg = exp(l1 + log(g1) - log(aSumRg));
         rgNan = isnan(ea0Rg) || isnan(ea1Rg);
     }
+    __shared__ SampleMeta shMeta[kSampleTile];
+    loadTileMeta(seg, co, w, shMeta);
     // per-sample weights exp(a1), exp(a2): one lane per sample, shared through LDS
     __shared__ double shEa[kSampleTile][2];
     __shared__ int shDev[kHalvesPerBlock][kHalfBufCap];
@@ -761,10 +813,12 @@ __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, 
             break;
         const double ea1 = shEa[slot][0];
         const double ea2 = shEa[slot][1];
-        for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
+        const SampleMeta & meta = shMeta[slot];
+        for (unsigned rg = meta.rg0; rg < meta.rg1; ++rg)
         {
-            const RgConst rc = co.rg[rg];
-            PairRange r = pairRange(seg, rg, w);
+            RgConst rc;
+            PairRange r;
+            rgOfSample(meta, seg, co, w, rg, rc, r);
             int * shiftSlot = b.shifts + (size_t)cellIdx * co.nRg + rg;
             const int refShift = *shiftSlot;
             double sumDel = 0, wSumDel = 0, sumRef = 0, wSumRef = 0;
@@ -971,6 +1025,8 @@ __global__ __launch_bounds__(kSampleTile) void finalKernel(SegmentView seg, Coho
     const unsigned w = (unsigned)cs.window;
     const int len = (int)cs.len;
     const unsigned hl = threadIdx.x & 31u, half = threadIdx.x >> 5;
+    __shared__ SampleMeta shMeta[kSampleTile];
+    loadTileMeta(seg, co, w, shMeta);
     for (unsigned k = 0; k < 32u; ++k)
     {
         const unsigned s = blockIdx.x * kSampleTile + half + k * kHalvesPerBlock;
@@ -982,10 +1038,12 @@ __global__ __launch_bounds__(kSampleTile) void finalKernel(SegmentView seg, Coho
         bool allEq = true;
         int delLower = 0x7fffffff, delUpper = 0;
         unsigned mn = 0xffffffffu, mx = 0;
-        for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
+        const SampleMeta & meta = shMeta[half + k * kHalvesPerBlock];
+        for (unsigned rg = meta.rg0; rg < meta.rg1; ++rg)
         {
-            const RgConst rc = co.rg[rg];
-            PairRange r = pairRange(seg, rg, w);
+            RgConst rc;
+            PairRange r;
+            rgOfSample(meta, seg, co, w, rg, rc, r);
             const int refShift = cs.restoreZeroShifts ? 0 : b.shifts[(size_t)cellIdx * co.nRg + rg];
             const int rgLower = (int)((unsigned)len - (unsigned)rc.lowerQ);
             const int rgUpper = (int)((unsigned)len + (unsigned)rc.upperQ);
@@ -1047,10 +1105,11 @@ __global__ __launch_bounds__(kSampleTile) void finalKernel(SegmentView seg, Coho
         if (mn == 0xffffffffu)
             mn = 0;
         // supporting pairs use the borders of the LAST usable read group for all read groups of the sample
-        for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
+        for (unsigned rg = meta.rg0; rg < meta.rg1; ++rg)
         {
-            const RgConst rc = co.rg[rg];
-            PairRange r = pairRange(seg, rg, w);
+            RgConst rc;
+            PairRange r;
+            rgOfSample(meta, seg, co, w, rg, rc, r);
             halfForEachActive<true>(r, w, hl, rc.maxLoad, shDev[half], shSt[half], [&](int dv, unsigned st) {
                 const bool supp = dv >= delLower && dv <= delUpper;
                 const unsigned long long bal = __ballot(supp) & halfMask();
