@@ -203,6 +203,8 @@ __device__ __forceinline__ void sortRegs16(v2s (&r)[C]);
 template <>
 __device__ __forceinline__ void sortRegs16<32>(v2s (&r)[32]) { PD_SORTNET_32(PD_CE16) }
 template <>
+__device__ __forceinline__ void sortRegs16<48>(v2s (&r)[48]) { PD_SORTNET_48(PD_CE16) }
+template <>
 __device__ __forceinline__ void sortRegs16<64>(v2s (&r)[64]) { PD_SORTNET_64(PD_CE16) }
 
 __device__ __forceinline__ unsigned rankL0(unsigned n)
@@ -211,37 +213,60 @@ __device__ __forceinline__ unsigned rankL0(unsigned n)
 }
 
 constexpr int kPackedWindows = 2 * kStage1Block;          // windows per workgroup
-constexpr int kPackedLdsPairs = 4096;
+constexpr int kPackedLdsPairs = 2304;                      // 9 x 256: staged chunks per workgroup (512 windows x ~3.1 + K x 3)
 constexpr int kPackedWsLen = kPackedWindows + 64 + 2;
 
+// Two ADJACENT windows per lane (w in the low halves, w + 1 in the high halves). Their candidate ranges overlap almost
+// completely, so every LDS entry is read once and feeds both cells: slot c of the lane is entry (aA + c) for both.
+// Slots are processed in groups of 8; groups past the wave's longest range skip the LDS reads (fill values only).
 template <int C>
 __device__ __forceinline__ void stage1PairFast(const PairDO * lds, unsigned aA, unsigned cntA, unsigned nA, unsigned wA,
-                                               unsigned aB, unsigned cntB, unsigned nB, unsigned wB, int & vaA, int & vbA,
+                                               unsigned dB, unsigned endB, unsigned nB, unsigned cmax, int & vaA, int & vbA,
                                                int & vaB, int & vbB)
 {
-    constexpr unsigned T = (3u * C + 2u - 4u) >> 2;        // l0(C): 23 for 32 slots, 47 for 64
+    constexpr unsigned T = (3u * C + 2u - 4u) >> 2;        // l0(C): 23 for 32 slots, 35 for 48, 47 for 64
     // number of -INF fillers that moves rank l0(n) to position T
     const unsigned pA = (nA >= 2u) ? (T - rankL0(nA)) : 0u;
     const unsigned pB = (nB >= 2u) ? (T - rankL0(nB)) : 0u;
+    const unsigned wB = wA + 1u;
     v2s r[C];
     unsigned jA = 0, jB = 0;
 #pragma unroll
-    for (int c = 0; c < C; ++c)
+    for (int g = 0; g < C; g += 8)
     {
-        const PairDO pa = lds[aA + c];
-        const PairDO pb = lds[aB + c];
-        const bool actA = ((unsigned)c < cntA) && (pa.off > wA);
-        const bool actB = ((unsigned)c < cntB) && (pb.off > wB);
-        const int fillA = (jA < pA) ? -32768 : 32767;
-        const int fillB = (jB < pB) ? -32768 : 32767;
-        const int xA = actA ? pa.dev : fillA;
-        const int xB = actB ? pb.dev : fillB;
-        jA += actA ? 0u : 1u;
-        jB += actB ? 0u : 1u;
-        v2s v;
-        v.x = (short)xA;
-        v.y = (short)xB;
-        r[c] = v;
+        if (true || (unsigned)g < cmax)                      // (group skipping disabled: the branches serialise the LDS reads)
+        {
+#pragma unroll
+            for (int c = g; c < g + 8; ++c)
+            {
+                const PairDO e = lds[aA + c];
+                const bool actA = ((unsigned)c < cntA) && (e.off > wA);
+                const bool actB = ((unsigned)c >= dB) && ((unsigned)c < endB) && (e.off > wB);
+                const int fillA = (jA < pA) ? -32768 : 32767;
+                const int fillB = (jB < pB) ? -32768 : 32767;
+                const int xA = actA ? e.dev : fillA;
+                const int xB = actB ? e.dev : fillB;
+                jA += actA ? 0u : 1u;
+                jB += actB ? 0u : 1u;
+                v2s v;
+                v.x = (short)xA;
+                v.y = (short)xB;
+                r[c] = v;
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int c = g; c < g + 8; ++c)
+            {
+                v2s v;
+                v.x = (short)((jA < pA) ? -32768 : 32767);
+                v.y = (short)((jB < pB) ? -32768 : 32767);
+                ++jA;
+                ++jB;
+                r[c] = v;
+            }
+        }
     }
     sortRegs16<C>(r);
     vaA = r[T].x;
@@ -315,18 +340,34 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     if (!bad)
     {
         const PairDO * src = seg.pairs + seg.rgBase[rg0] + A;
-        for (unsigned i = tid; i < nPairs; i += kStage1Block)
+        // all global loads of the stage are issued before the first LDS write (one HBM latency, not nine)
+        constexpr int kIters = kPackedLdsPairs / kStage1Block;
+        PairDO tmp[kIters];
+#pragma unroll
+        for (int it = 0; it < kIters; ++it)
         {
-            const PairDO p = src[i];
-            ldsPairs[i] = p;
-            bad |= (p.dev < -32767) || (p.dev > 32766);
-            const unsigned rel = p.off - wlo0;                      // off > on >= wlo0
-            if (rel < nWs)
-                atomicAdd(&ldsEnd[rel], 1);
+            const unsigned i = tid + (unsigned)it * kStage1Block;
+            if (i < nPairs)
+                tmp[it] = src[i];
+        }
+#pragma unroll
+        for (int it = 0; it < kIters; ++it)
+        {
+            const unsigned i = tid + (unsigned)it * kStage1Block;
+            if (i < nPairs)
+            {
+                const PairDO p = tmp[it];
+                ldsPairs[i] = p;
+                bad |= (p.dev < -32767) || (p.dev > 32766);
+                const unsigned rel = p.off - wlo0;                  // off > on >= wlo0
+                if (rel < nWs)
+                    atomicAdd(&ldsEnd[rel], 1);
+            }
         }
     }
-    unsigned aA = 0, cntA = 0, aB = 0, cntB = 0;
-    const unsigned wA = w0 + tid, wB = w0 + kStage1Block + tid;
+    // lane t owns the adjacent windows w0 + 2t and w0 + 2t + 1; B's range is expressed in A's slot coordinates
+    unsigned aA = 0, cntA = 0, dB = 0, endB = 0;
+    const unsigned wA = w0 + 2u * tid, wB = wA + 1u;
     if (wA < W)
     {
         const unsigned wlo = (wA + 1 >= K) ? (wA + 1 - K) : 0u;
@@ -336,10 +377,12 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     if (wB < W)
     {
         const unsigned wlo = (wB + 1 >= K) ? (wB + 1 - K) : 0u;
-        aB = ldsWs[wlo - wlo0] - A;
-        cntB = ldsWs[wB + 1 - wlo0] - A - aB;
+        const unsigned aB = ldsWs[wlo - wlo0] - A;
+        dB = aB - aA;
+        endB = ldsWs[wB + 1 - wlo0] - A - aA;
     }
-    bad |= (cntA > 64u) || (cntB > 64u);
+    const unsigned cntU = max(cntA, endB);
+    bad |= cntU > 64u;
     if (__syncthreads_or(bad))                                     // also orders the LDS writes above
     {
         if (tid == 0)
@@ -390,12 +433,14 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
         return;
     const unsigned nA = (ldsWs[wA + 1 - wlo0] - A) - (unsigned)ldsEnd[wA - wlo0];
     const unsigned nB = (wB < W) ? (ldsWs[wB + 1 - wlo0] - A) - (unsigned)ldsEnd[wB - wlo0] : 0u;
-    const unsigned cmax = waveMaxU32(max(cntA, cntB));               // wave-uniform network size
+    const unsigned cmax = waveMaxU32(cntU);                          // wave-uniform network size
     int vaA, vbA, vaB, vbB;
     if (cmax <= 32u)
-        stage1PairFast<32>(ldsPairs, aA, cntA, nA, wA, aB, cntB, nB, wB, vaA, vbA, vaB, vbB);
+        stage1PairFast<32>(ldsPairs, aA, cntA, nA, wA, dB, endB, nB, cmax, vaA, vbA, vaB, vbB);
+    else if (cmax <= 48u)
+        stage1PairFast<48>(ldsPairs, aA, cntA, nA, wA, dB, endB, nB, cmax, vaA, vbA, vaB, vbB);
     else
-        stage1PairFast<64>(ldsPairs, aA, cntA, nA, wA, aB, cntB, nB, wB, vaA, vbA, vaB, vbB);
+        stage1PairFast<64>(ldsPairs, aA, cntA, nA, wA, dB, endB, nB, cmax, vaA, vbA, vaB, vbB);
     const unsigned maxLoad = co.rg[rg0].maxLoad;
     storeCell(nA, maxLoad, vaA, vbA, (size_t)s * W + wA, wA, co.minThreshold, q3, flags, winFlag);
     if (wB < W)
