@@ -89,7 +89,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from popdel_amd import capi, synth
+    from popdel_amd import capi, distributed, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -111,7 +111,7 @@ def main():
     handle = ctx.stage(seg)                   # host -> HBM, outside the timed region
 
     total_passes = args.passes or -(-CHR20_WINDOWS // W)
-    my_passes = len(range(rank, total_passes, world))
+    my_passes = len(distributed.shard_segments(total_passes, rank, world))
 
     def one_step():
         s1 = s2 = 0.0
@@ -161,8 +161,17 @@ def main():
     alg_bytes = 4 * tinfo["n_active_pairs"] + 4 * cells + 4 * cells          # gather + cell index + Q3 out
     compact_bytes = 8 * tinfo["n_pair_chunks"] + 4 * (W + 1) * S + 5 * cells   # what this layout actually has to move
     achieved = alg_bytes / s1_mean_s / 1e9
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), measured with rocprofv3 on
+    # exactly this launch shape; summary committed under profiles/. Only quoted when the shape matches.
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_stage1.json")
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+        if pmc["config"] == {"samples": S, "windows": W}:
+            traffic = pmc["hbm_bytes_per_launch"]
     roofline = dict(bound="hbm", kernel="stage1Kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=None, algorithmic_bytes_per_launch=alg_bytes,
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source="profiles/r01_pmc_stage1.json" if traffic else None,
+                    algorithmic_bytes_per_launch=alg_bytes,
                     compact_bytes_per_launch=compact_bytes, compact_GBs=compact_bytes / s1_mean_s / 1e9,
                     mean_launch_ms=s1_mean_s * 1e3, mean_active_pairs_per_cell=tinfo["n_active_pairs"] / cells)
 

@@ -13,8 +13,9 @@
  * to String<Call> comes back as plain arrays.
  *
  * Conventions: all functions return 0 on success, non-zero on error (pd_last_error() gives
- * text); no exceptions cross the boundary; a context is bound to one GPU and calls on one
- * context must be serialised by the caller. Pointers passed in are caller-owned host
+ * text); no exceptions cross the boundary; a context is bound to one GPU, calls on one
+ * context must be serialised by the caller, and a context has ONE ticket in flight at a time
+ * (collect it before the next submit/run; use one context per stream of segments). Pointers passed in are caller-owned host
  * memory unless stated otherwise; pd_calls is callee-owned until pd_calls_free().
  */
 #ifndef POPDEL_HIP_H_

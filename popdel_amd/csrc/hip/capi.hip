@@ -449,6 +449,8 @@ int pd_segment_run(pd_ctx * c, uint64_t handle, uint64_t * ticket)
     auto it = c->staged.find(handle);
     if (it == c->staged.end())
         return fail(c, "pd_segment_run: unknown segment handle");
+    if (!c->runs.empty())
+        return fail(c, "pd_segment_run: the previous ticket has not been collected (one ticket in flight per context)");
     try
     {
         PD_HIP(hipSetDevice(c->device));

@@ -33,6 +33,7 @@ class Library:
         """Counts trimmed to [max(1, floor(median - 3 sd)), ceil(median + 3 sd) + 1)."""
         rng = np.random.default_rng(self.hist_seed)
         samp = np.rint(rng.normal(self.median, self.stddev, self.hist_draws)).astype(int)
+        samp = np.clip(samp, 1, None)          # wide libraries: no negative insert sizes
         full = np.bincount(samp, minlength=2000).astype(float)
         start = max(1, int(np.floor(self.median - 3 * self.stddev)))
         end = int(np.ceil(self.median + 3 * self.stddev)) + 1
@@ -121,6 +122,75 @@ def write_profile(path, rg_name, pos, dev, lib: Library, contigs=(("chr20", CHR2
             cur_region = r
         blk += struct.pack("<III", chrom, bp, b - a)
         blk += raw[a * 5:b * 5]
+    flush()
+    prev = base + len(body)
+    for j in range(num_regions - 1, -1, -1):
+        if offsets[j] == 0:
+            offsets[j] = prev
+        else:
+            prev = offsets[j]
+    hdr[idx_off:idx_off + 8 * num_regions] = struct.pack("<%dQ" % num_regions, *offsets)
+    with open(path, "wb") as fh:
+        fh.write(hdr)
+        fh.write(body)
+
+
+def write_profile_multi(path, read_groups, contigs=(("chr20", CHR20_LEN),), chrom=0, region_size=10000, compressed=True):
+    """Write a profile with several read groups. ``read_groups`` = [(name, pos, dev, Library), ...] (each sorted)."""
+    num_regions = sum(l // region_size + 1 for _, l in contigs)
+    hdr = bytearray(b"POPDEL\x01")
+    hdr += struct.pack("<II", region_size, num_regions)
+    idx_off = len(hdr)
+    hdr += b"\0" * (8 * num_regions)
+    hdr += struct.pack("<I", len(read_groups))
+    for name, _, _, lib in read_groups:
+        hist_start, hist = lib.histogram()
+        hdr += struct.pack("<I", len(name) + 1) + name.encode() + b"\0"
+        hdr += struct.pack("<IdIII", lib.median, lib.stddev, lib.read_len, hist_start, hist_start + len(hist))
+        hdr += np.asarray(hist, dtype="<f8").tobytes()
+    hdr += struct.pack("<I", len(contigs))
+    for name, length in contigs:
+        hdr += struct.pack("<I", len(name) + 1) + name.encode() + b"\0" + struct.pack("<I", length)
+    first_slot = sum(l // region_size + 1 for _, l in contigs[:chrom])
+    offsets = [0] * num_regions
+    base = len(hdr)
+    body = bytearray()
+    # per read group: window id -> slice
+    per_rg = []
+    all_windows = set()
+    for _, pos, dev, _ in read_groups:
+        win = pos // 256
+        rec = np.empty(len(pos), dtype=_REC)
+        rec["off"] = (pos - win * 256).astype(np.uint8)
+        rec["dev"] = dev
+        raw = rec.tobytes()
+        cuts = np.flatnonzero(np.diff(win)) + 1
+        starts = np.concatenate(([0], cuts)) if len(pos) else np.array([], dtype=np.int64)
+        ends = np.concatenate((cuts, [len(pos)])) if len(pos) else np.array([], dtype=np.int64)
+        table = {int(win[a]): (a, b) for a, b in zip(starts.tolist(), ends.tolist())}
+        per_rg.append((table, raw))
+        all_windows.update(table)
+    cur_region, blk = None, bytearray()
+
+    def flush():
+        nonlocal blk
+        if cur_region is None:
+            return
+        offsets[first_slot + cur_region] = base + len(body)
+        body.extend(gzip.compress(bytes(blk), 6, mtime=0) if compressed else blk)
+        blk = bytearray()
+
+    for wdx in sorted(all_windows):
+        bp = wdx * 256
+        r = bp // region_size
+        if r != cur_region:
+            flush()
+            cur_region = r
+        blk += struct.pack("<II", chrom, bp)
+        for table, raw in per_rg:
+            a, b = table.get(wdx, (0, 0))
+            blk += struct.pack("<I", b - a)
+            blk += raw[a * 5:b * 5]
     flush()
     prev = base + len(body)
     for j in range(num_regions - 1, -1, -1):

@@ -1,0 +1,80 @@
+"""GPU: the product binary (HIP backend) against the oracle-backed driver for command-line variants that have no
+reference capture; both read the same profiles, outputs must be byte-identical."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ORACLE_CALL, POPDEL_BIN, strip_date
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mixed_cohort(tmp_path_factory):
+    """12 samples: heterogeneous libraries (median 350..550, sd 40..100), two 3-read-group samples, one low coverage."""
+    from popdel_amd import synth
+    d = tmp_path_factory.mktemp("mixed")
+    region = (1000000, 1400000)
+    rs = np.random.default_rng(7)
+    dels = lambda k: [synth.Deletion(1100000, 800, [1, 2, 0][k % 3]), synth.Deletion(1250000, 2500, [2, 0, 1][k % 3]),
+                      synth.Deletion(1330000, 350, [1, 1, 2][k % 3])]
+    paths = []
+    for k in range(12):
+        lib = synth.Library(median=int(rs.integers(350, 551)), stddev=float(rs.integers(40, 101)), hist_seed=100 + k,
+                            coverage=2.0 if k == 5 else 30.0)
+        p = os.path.join(str(d), "m%02d.profile" % k)
+        if k in (3, 8):
+            rgs = []
+            for j in range(3):
+                sub = synth.Library(median=lib.median + 10 * j, stddev=lib.stddev, hist_seed=200 + 3 * k + j, coverage=10.0)
+                pos, dev = synth.sample_pairs(5000 + 10 * k + j, region, sub, dels(k))
+                rgs.append(("M%02d_RG%d" % (k, j), pos, dev, sub))
+            synth.write_profile_multi(p, rgs)
+        else:
+            pos, dev = synth.sample_pairs(5000 + 10 * k, region, lib, dels(k))
+            synth.write_profile(p, "M%02d" % k, pos, dev, lib)
+        paths.append(p)
+    lst = os.path.join(str(d), "profiles.txt")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    cov = os.path.join(str(d), "maxcov.txt")
+    open(cov, "w").write("M00 12\nM01 0\nM03_RG1 8\n")
+    rois = os.path.join(str(d), "rois.txt")
+    open(rois, "w").write("chr20:1050001-1150000\nchr20:1240001-1290000\n")
+    return str(d)
+
+
+def run(binary, cohort, out, args):
+    cmd = [binary] + (["call"] if os.path.basename(binary) == "popdel" else []) + [os.path.join(cohort, "profiles.txt"), "-o", out] + args
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return strip_date(open(out).read())
+
+
+OPTION_SETS = [
+    ["-r", "chr20:1000000-1400000"],
+    ["-r", "chr20:1000000-1400000", "-n", "-F"],
+    ["-r", "chr20:1000000-1400000", "-a", "15", "-n"],
+    ["-r", "chr20:1000000-1400000", "-u", "-n"],
+    ["-r", "chr20:1000000-1400000", "-C", "-n"],
+    ["-r", "chr20:1000000-1400000", "-l", "250", "-m", "220", "-t", "4", "-n"],
+    ["-r", "chr20:1000000-1400000", "-s", "1.0", "-F"],
+    ["-r", "chr20:1000000-1400000", "-f", "100", "-p", "0.01", "-c", "0.2"],
+    ["-r", "chr20:1050001-1150000", "-r", "chr20:1240001-1290000", "-n"],
+    ["-b", "100000", "-r", "chr20:1000000-1400000", "-n"],
+]
+
+
+@pytest.mark.parametrize("opts", OPTION_SETS, ids=lambda o: "_".join(x.replace(":", "").replace("-", "") for x in o)[:60])
+def test_product_matches_oracle_driver(built, mixed_cohort, tmp_path, opts):
+    a = run(POPDEL_BIN, mixed_cohort, str(tmp_path / "gpu.vcf"), list(opts))
+    b = run(ORACLE_CALL, mixed_cohort, str(tmp_path / "cpu.vcf"), list(opts))
+    assert a.count("\n") > 25            # header + at least one record
+    assert a == b
+
+
+def test_files_for_coverage_and_rois(built, mixed_cohort, tmp_path):
+    opts = ["-A", os.path.join(mixed_cohort, "maxcov.txt"), "-R", os.path.join(mixed_cohort, "rois.txt"), "-n"]
+    a = run(POPDEL_BIN, mixed_cohort, str(tmp_path / "gpu.vcf"), opts)
+    b = run(ORACLE_CALL, mixed_cohort, str(tmp_path / "cpu.vcf"), opts)
+    assert a == b and a.count("\n") > 25
