@@ -94,8 +94,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
-    if distributed:
+    is_dist = world > 1
+    if is_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -128,7 +128,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if distributed:
+        if is_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -146,7 +146,7 @@ def main():
         n_cand += d
     sync()
     elapsed = time.perf_counter() - t0
-    if distributed:
+    if is_dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -207,7 +207,7 @@ def main():
             "max_life": tinfo["max_life"], "roofline": roofline, "cpu_baseline": cpu_baseline}))
     ctx.unstage(handle)
     ctx.close()
-    if distributed:
+    if is_dist:
         dist.destroy_process_group()
 
 

@@ -429,22 +429,62 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
             ldsEnd[base + 2] = e2 + offset;
         __syncthreads();
     }
-    if (wA >= W)
+    // Re-deal the 256 window pairs to the lanes ordered by candidate count (largest first): every wave then runs the
+    // smallest network that fits ITS lanes instead of the one that fits the worst lane of an arbitrary 64.
+    __shared__ unsigned short unitOrder[kStage1Block];
+    __shared__ unsigned classCount[4][kStage1Block / 64];
+    {
+        const unsigned cls = (wA >= W) ? 3u : (cntU > 48u ? 0u : (cntU > 32u ? 1u : 2u));
+        const unsigned long long below = (1ull << (tid & 63u)) - 1ull;
+        unsigned rank = 0;
+#pragma unroll
+        for (unsigned k = 0; k < 4u; ++k)
+        {
+            const unsigned long long bal = __ballot(cls == k);
+            if (cls == k)
+                rank = (unsigned)__popcll(bal & below);
+            if ((tid & 63u) == 0u)
+                classCount[k][tid >> 6] = (unsigned)__popcll(bal);
+        }
+        __syncthreads();
+        unsigned offset = 0;
+        for (unsigned k = 0; k < 4u; ++k)
+            for (unsigned v = 0; v < kStage1Block / 64; ++v)
+                if (k < cls || (k == cls && v < (tid >> 6)))
+                    offset += classCount[k][v];
+        unitOrder[offset + rank] = (unsigned short)tid;
+        __syncthreads();
+    }
+    const unsigned u = unitOrder[tid];
+    const unsigned uA = w0 + 2u * u, uB = uA + 1u;
+    if (uA >= W)
         return;
-    const unsigned nA = (ldsWs[wA + 1 - wlo0] - A) - (unsigned)ldsEnd[wA - wlo0];
-    const unsigned nB = (wB < W) ? (ldsWs[wB + 1 - wlo0] - A) - (unsigned)ldsEnd[wB - wlo0] : 0u;
-    const unsigned cmax = waveMaxU32(cntU);                          // wave-uniform network size
+    unsigned xA, xCntA, xDB = 0, xEndB = 0;
+    {
+        const unsigned wlo = (uA + 1 >= K) ? (uA + 1 - K) : 0u;
+        xA = ldsWs[wlo - wlo0] - A;
+        xCntA = ldsWs[uA + 1 - wlo0] - A - xA;
+    }
+    if (uB < W)
+    {
+        const unsigned wlo = (uB + 1 >= K) ? (uB + 1 - K) : 0u;
+        xDB = ldsWs[wlo - wlo0] - A - xA;
+        xEndB = ldsWs[uB + 1 - wlo0] - A - xA;
+    }
+    const unsigned nA = (ldsWs[uA + 1 - wlo0] - A) - (unsigned)ldsEnd[uA - wlo0];
+    const unsigned nB = (uB < W) ? (ldsWs[uB + 1 - wlo0] - A) - (unsigned)ldsEnd[uB - wlo0] : 0u;
+    const unsigned cmax = waveMaxU32(max(xCntA, xEndB));             // wave-uniform network size
     int vaA, vbA, vaB, vbB;
     if (cmax <= 32u)
-        stage1PairFast<32>(ldsPairs, aA, cntA, nA, wA, dB, endB, nB, cmax, vaA, vbA, vaB, vbB);
+        stage1PairFast<32>(ldsPairs, xA, xCntA, nA, uA, xDB, xEndB, nB, cmax, vaA, vbA, vaB, vbB);
     else if (cmax <= 48u)
-        stage1PairFast<48>(ldsPairs, aA, cntA, nA, wA, dB, endB, nB, cmax, vaA, vbA, vaB, vbB);
+        stage1PairFast<48>(ldsPairs, xA, xCntA, nA, uA, xDB, xEndB, nB, cmax, vaA, vbA, vaB, vbB);
     else
-        stage1PairFast<64>(ldsPairs, aA, cntA, nA, wA, dB, endB, nB, cmax, vaA, vbA, vaB, vbB);
+        stage1PairFast<64>(ldsPairs, xA, xCntA, nA, uA, xDB, xEndB, nB, cmax, vaA, vbA, vaB, vbB);
     const unsigned maxLoad = co.rg[rg0].maxLoad;
-    storeCell(nA, maxLoad, vaA, vbA, (size_t)s * W + wA, wA, co.minThreshold, q3, flags, winFlag);
-    if (wB < W)
-        storeCell(nB, maxLoad, vaB, vbB, (size_t)s * W + wB, wB, co.minThreshold, q3, flags, winFlag);
+    storeCell(nA, maxLoad, vaA, vbA, (size_t)s * W + uA, uA, co.minThreshold, q3, flags, winFlag);
+    if (uB < W)
+        storeCell(nB, maxLoad, vaB, vbB, (size_t)s * W + uB, uB, co.minThreshold, q3, flags, winFlag);
 }
 
 // Tiles the main kernel skipped: 32-bit 64- or 128-input network where the LDS stage still fits, otherwise rank counting
