@@ -108,7 +108,9 @@ def main():
     first, W, offsets, arrays, planted = device_tile(S, 20260 + rank, device)
     seg = capi.Segment(first, W, offsets, arrays["dev"], arrays["start"], arrays["on"], arrays["off"])
     ctx = capi.Context(hip, [rg] * S, list(range(S + 1)), device=local_rank)
+    t_stage = time.perf_counter()
     handle = ctx.stage(seg)                   # host -> HBM, outside the timed region
+    stage_seconds = time.perf_counter() - t_stage
 
     total_passes = args.passes or -(-CHR20_WINDOWS // W)
     my_passes = len(distributed.shard_segments(total_passes, rank, world))
@@ -204,7 +206,12 @@ def main():
                        "planted_deletion": planted, "parallelism": "segments round-robin over %d rank(s)" % world},
             "stage1_ms_per_step": s1_ms / args.steps, "stage2_ms_per_step": s2_ms / args.steps,
             "calls_per_step": n_calls / args.steps, "candidate_cells_per_step": n_cand / args.steps,
-            "max_life": tinfo["max_life"], "roofline": roofline, "cpu_baseline": cpu_baseline}))
+            "max_life": tinfo["max_life"],
+            # host arrays -> chunked layout -> HBM for one segment of all samples (single host thread + PCIe); with it
+            # inside every pass the rate would be cells_per_pass / (stage_seconds + pass time): reported, never `value`
+            "staging_seconds_per_segment": stage_seconds,
+            "pcie_inclusive_value": (W * S) / (stage_seconds + elapsed / args.steps / max(1, my_passes)),
+            "roofline": roofline, "cpu_baseline": cpu_baseline}))
     ctx.unstage(handle)
     ctx.close()
     if is_dist:

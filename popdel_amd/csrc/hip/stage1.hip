@@ -216,57 +216,54 @@ constexpr int kPackedWindows = 2 * kStage1Block;          // windows per workgro
 constexpr int kPackedLdsPairs = 2304;                      // 9 x 256: staged chunks per workgroup (512 windows x ~3.1 + K x 3)
 constexpr int kPackedWsLen = kPackedWindows + 64 + 2;
 
+// Packed-16-bit helpers on 32-bit registers (low half = window w, high half = window w + 1).
+__device__ __forceinline__ unsigned pkSub(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, (v2s)(__builtin_bit_cast(v2s, a) - __builtin_bit_cast(v2s, b)));
+}
+__device__ __forceinline__ unsigned pkAdd(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, (v2s)(__builtin_bit_cast(v2s, a) + __builtin_bit_cast(v2s, b)));
+}
+__device__ __forceinline__ unsigned pkSignMask(unsigned a)          // 0xFFFF in every half that is negative
+{
+    return __builtin_bit_cast(unsigned, (v2s)(__builtin_bit_cast(v2s, a) >> 15));
+}
+
+// LDS image of a staged chunk: deviation and (segment-relative) end window, each duplicated into both halves.
+struct PairPk
+{
+    unsigned devdev;
+    unsigned offoff;
+};
+
 // Two ADJACENT windows per lane (w in the low halves, w + 1 in the high halves). Their candidate ranges overlap almost
 // completely, so every LDS entry is read once and feeds both cells: slot c of the lane is entry (aA + c) for both.
-// Slots are processed in groups of 8; groups past the wave's longest range skip the LDS reads (fill values only).
+// All per-slot logic (active test, range test, filler choice, filler count) is packed 16-bit arithmetic on both cells
+// at once: a slot costs ~10 VALU for the two cells.
 template <int C>
-__device__ __forceinline__ void stage1PairFast(const PairDO * lds, unsigned aA, unsigned cntA, unsigned nA, unsigned wA,
-                                               unsigned dB, unsigned endB, unsigned nB, unsigned cmax, int & vaA, int & vbA,
-                                               int & vaB, int & vbB)
+__device__ __forceinline__ void stage1PairFast(const PairPk * lds, unsigned aA, unsigned wPk, unsigned cntPk, unsigned nA,
+                                               unsigned nB, int & vaA, int & vbA, int & vaB, int & vbB)
 {
     constexpr unsigned T = (3u * C + 2u - 4u) >> 2;        // l0(C): 23 for 32 slots, 35 for 48, 47 for 64
     // number of -INF fillers that moves rank l0(n) to position T
     const unsigned pA = (nA >= 2u) ? (T - rankL0(nA)) : 0u;
     const unsigned pB = (nB >= 2u) ? (T - rankL0(nB)) : 0u;
-    const unsigned wB = wA + 1u;
+    unsigned bPk = pA | (pB << 16);                        // p + number of active slots seen so far
     v2s r[C];
-    unsigned jA = 0, jB = 0;
 #pragma unroll
-    for (int g = 0; g < C; g += 8)
+    for (int c = 0; c < C; ++c)
     {
-        if (true || (unsigned)g < cmax)                      // (group skipping disabled: the branches serialise the LDS reads)
-        {
-#pragma unroll
-            for (int c = g; c < g + 8; ++c)
-            {
-                const PairDO e = lds[aA + c];
-                const bool actA = ((unsigned)c < cntA) && (e.off > wA);
-                const bool actB = ((unsigned)c >= dB) && ((unsigned)c < endB) && (e.off > wB);
-                const int fillA = (jA < pA) ? -32768 : 32767;
-                const int fillB = (jB < pB) ? -32768 : 32767;
-                const int xA = actA ? e.dev : fillA;
-                const int xB = actB ? e.dev : fillB;
-                jA += actA ? 0u : 1u;
-                jB += actB ? 0u : 1u;
-                v2s v;
-                v.x = (short)xA;
-                v.y = (short)xB;
-                r[c] = v;
-            }
-        }
-        else
-        {
-#pragma unroll
-            for (int c = g; c < g + 8; ++c)
-            {
-                v2s v;
-                v.x = (short)((jA < pA) ? -32768 : 32767);
-                v.y = (short)((jB < pB) ? -32768 : 32767);
-                ++jA;
-                ++jB;
-                r[c] = v;
-            }
-        }
+        const PairPk e = lds[aA + c];
+        const unsigned cPk = (unsigned)c | ((unsigned)c << 16);
+        // active <=> off > w  and  c < cnt   (both differences negative)
+        const unsigned m = pkSignMask(pkSub(wPk, e.offoff) & pkSub(cPk, cntPk));
+        // filler: -INF (0x8000) while fewer than p fillers were handed out, +INF (0x7FFF) afterwards;
+        // (#inactive slots before c) < p  <=>  c < p + (#active slots before c)
+        const unsigned fill = pkSignMask(pkSub(cPk, bPk)) ^ 0x7FFF7FFFu;
+        const unsigned x = (e.devdev & m) | (fill & ~m);
+        bPk = pkSub(bPk, m);                                  // +1 per active slot
+        r[c] = __builtin_bit_cast(v2s, x);
     }
     sortRegs16<C>(r);
     vaA = r[T].x;
@@ -299,7 +296,7 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
                                                              uint8_t * __restrict__ flags, int * __restrict__ winFlag,
                                                              uint8_t * __restrict__ tileTodo, unsigned tilesPerSample)
 {
-    __shared__ PairDO ldsPairs[kPackedLdsPairs + 64];
+    __shared__ PairPk ldsPairs[kPackedLdsPairs + 64];
     __shared__ uint32_t ldsWs[kPackedWsLen];
     __shared__ int ldsEnd[kPackedWsLen + 6];
     __shared__ int waveTotals[kStage1Block / 64];
@@ -357,16 +354,20 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
             if (i < nPairs)
             {
                 const PairDO p = tmp[it];
-                ldsPairs[i] = p;
+                const unsigned rel = p.off - wlo0;                  // off > on >= wlo0, and off <= on + K: fits 16 bits
+                const unsigned d16 = (unsigned)p.dev & 0xffffu;
+                PairPk e;
+                e.devdev = d16 | (d16 << 16);
+                e.offoff = rel | (rel << 16);
+                ldsPairs[i] = e;
                 bad |= (p.dev < -32767) || (p.dev > 32766);
-                const unsigned rel = p.off - wlo0;                  // off > on >= wlo0
                 if (rel < nWs)
                     atomicAdd(&ldsEnd[rel], 1);
             }
         }
     }
     // lane t owns the adjacent windows w0 + 2t and w0 + 2t + 1; B's range is expressed in A's slot coordinates
-    unsigned aA = 0, cntA = 0, dB = 0, endB = 0;
+    unsigned aA = 0, cntA = 0, endB = 0;
     const unsigned wA = w0 + 2u * tid, wB = wA + 1u;
     if (wA < W)
     {
@@ -376,9 +377,6 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     }
     if (wB < W)
     {
-        const unsigned wlo = (wB + 1 >= K) ? (wB + 1 - K) : 0u;
-        const unsigned aB = ldsWs[wlo - wlo0] - A;
-        dB = aB - aA;
         endB = ldsWs[wB + 1 - wlo0] - A - aA;
     }
     const unsigned cntU = max(cntA, endB);
@@ -459,7 +457,7 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     const unsigned uA = w0 + 2u * u, uB = uA + 1u;
     if (uA >= W)
         return;
-    unsigned xA, xCntA, xDB = 0, xEndB = 0;
+    unsigned xA, xCntA, xEndB = 0;
     {
         const unsigned wlo = (uA + 1 >= K) ? (uA + 1 - K) : 0u;
         xA = ldsWs[wlo - wlo0] - A;
@@ -467,20 +465,22 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     }
     if (uB < W)
     {
-        const unsigned wlo = (uB + 1 >= K) ? (uB + 1 - K) : 0u;
-        xDB = ldsWs[wlo - wlo0] - A - xA;
         xEndB = ldsWs[uB + 1 - wlo0] - A - xA;
     }
     const unsigned nA = (ldsWs[uA + 1 - wlo0] - A) - (unsigned)ldsEnd[uA - wlo0];
     const unsigned nB = (uB < W) ? (ldsWs[uB + 1 - wlo0] - A) - (unsigned)ldsEnd[uB - wlo0] : 0u;
     const unsigned cmax = waveMaxU32(max(xCntA, xEndB));             // wave-uniform network size
+    // window numbers relative to the staged range; entries ahead of B's range ended before w + 1 (chunk life <= K),
+    // so B needs no lower range test
+    const unsigned wPk = (uA - wlo0) | ((uB - wlo0) << 16);
+    const unsigned cntPk = xCntA | (xEndB << 16);
     int vaA, vbA, vaB, vbB;
     if (cmax <= 32u)
-        stage1PairFast<32>(ldsPairs, xA, xCntA, nA, uA, xDB, xEndB, nB, cmax, vaA, vbA, vaB, vbB);
+        stage1PairFast<32>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
     else if (cmax <= 48u)
-        stage1PairFast<48>(ldsPairs, xA, xCntA, nA, uA, xDB, xEndB, nB, cmax, vaA, vbA, vaB, vbB);
+        stage1PairFast<48>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
     else
-        stage1PairFast<64>(ldsPairs, xA, xCntA, nA, uA, xDB, xEndB, nB, cmax, vaA, vbA, vaB, vbB);
+        stage1PairFast<64>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
     const unsigned maxLoad = co.rg[rg0].maxLoad;
     storeCell(nA, maxLoad, vaA, vbA, (size_t)s * W + uA, uA, co.minThreshold, q3, flags, winFlag);
     if (uB < W)
