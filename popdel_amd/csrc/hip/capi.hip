@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include "parallel.h"
 #include "pd_device.h"
 #include "popdel_hip.h"
 
@@ -246,36 +247,41 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
     out.nPairs = nInst;
     out.nActivePairs = active;
 
+    // pass 1 (parallel over read groups): chunks per window -> winStart, chunk totals -> rgBase
     rgBase.assign(seg.n_readgroups, 0);
     winStart.assign(static_cast<size_t>(seg.n_readgroups) * (W + 1), 0);
-    pairs.clear();
-    start.clear();
-    pairs.reserve(total + total / 16);
-    start.reserve(total + total / 16);
-    std::vector<uint32_t> counts(W + 1);
-    for (uint32_t rg = 0; rg < seg.n_readgroups; ++rg)
-    {
+    std::vector<uint64_t> rgChunks(seg.n_readgroups, 0);
+    pdh::parallelFor(seg.n_readgroups, [&](size_t rg) {
         const uint64_t lo = seg.rg_offsets[rg], hi = seg.rg_offsets[rg + 1];
-        rgBase[rg] = pairs.size();
-        std::fill(counts.begin(), counts.end(), 0u);
+        uint32_t * ws = winStart.data() + rg * (W + 1);
         for (uint64_t i = lo; i < hi; ++i)
         {
             uint32_t on = seg.pair_on[i], off = std::min(seg.pair_off[i], W);
             for (uint32_t a = on; a < off; a += K)
-                ++counts[a];
+                ++ws[a + 1];                                  // counts, shifted by one for the prefix sum
         }
-        uint32_t * ws = winStart.data() + static_cast<size_t>(rg) * (W + 1);
         uint32_t acc = 0;
         for (uint32_t w = 0; w <= W; ++w)
         {
+            acc += ws[w];
             ws[w] = acc;
-            if (w < W)
-                acc += counts[w];
         }
-        const size_t base = pairs.size();
-        pairs.resize(base + acc);
-        start.resize(base + acc);
+        rgChunks[rg] = acc;
+    }, 8);
+    uint64_t totalChunks = 0;
+    for (uint32_t rg = 0; rg < seg.n_readgroups; ++rg)
+    {
+        rgBase[rg] = totalChunks;
+        totalChunks += rgChunks[rg];
+    }
+    pairs.resize(totalChunks);
+    start.resize(totalChunks);
+    // pass 2 (parallel): scatter the chunks to their slots, stable within a window
+    pdh::parallelFor(seg.n_readgroups, [&](size_t rg) {
+        const uint64_t lo = seg.rg_offsets[rg], hi = seg.rg_offsets[rg + 1];
+        const uint32_t * ws = winStart.data() + rg * (W + 1);
         std::vector<uint32_t> cursor(ws, ws + W);
+        const size_t base = rgBase[rg];
         for (uint64_t i = lo; i < hi; ++i)
         {
             uint32_t on = seg.pair_on[i], off = std::min(seg.pair_off[i], W);
@@ -286,7 +292,7 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
                 start[base + slot] = seg.pair_start[i];
             }
         }
-    }
+    }, 8);
     out.nChunks = pairs.size();
     (void)c;
 }

@@ -1,9 +1,11 @@
 #include "call_driver.h"
 
+#include <chrono>
 #include <cstring>
 #include <iostream>
 #include <memory>
 
+#include "parallel.h"
 #include "popdel_hip.h"
 #include "profile_io.h"
 
@@ -11,6 +13,13 @@ namespace pdh {
 namespace {
 
 constexpr unsigned kNoPos = std::numeric_limits<unsigned>::max();
+
+// Wall-clock split of the host phases, printed at exit when POPDEL_TIMING is set.
+struct PhaseClock
+{
+    double switches = 0, decode = 0, replay = 0, walk = 0, flatten = 0, submit = 0, collect = 0, merge = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
 
 struct Coord
 {
@@ -73,6 +82,27 @@ bool adaptRegions(Coord & cand, Region & roi, unsigned w)
     return true;
 }
 
+// What a decoder thread produced for one sample and one round: the 256-bp windows from the index jump up to (and
+// including) the window at which the loader will stop, each already split into 30-bp windows. Decoding (inflate, parse,
+// split) touches no shared state; inserting the records into the window state machine is replayed sequentially.
+struct DecodedRaw
+{
+    int32_t  chrom = 0;
+    int32_t  beginPos = 0;
+    bool     splitFailed = false;
+    uint32_t firstWin = 0, nWin = 0;       // its 30-bp windows in DecodedStream::wins
+};
+
+struct DecodedStream
+{
+    std::vector<DecodedRaw> raws;
+    std::vector<FlatWindow> wins;          // all 30-bp windows, flat
+    std::vector<uint32_t> counts;          // per window: records per read group of the file
+    std::vector<PairRecord> recs;
+    bool eof = false;
+    bool sawFarWindow = false;     // a window beyond the next slot: the replay may consult ALL tables (allEmpty/resetTo)
+};
+
 class CallRun
 {
 public:
@@ -81,6 +111,10 @@ public:
     {
         if (ctx_)
             pd_ctx_destroy(ctx_);
+        if (getenv("POPDEL_TIMING"))
+            std::cerr << "[popdel timing] threads " << hostThreads() << "; switches " << clock_.switches << " s; decode " << clock_.decode << " s; replay " << clock_.replay
+                      << " s; window walk " << clock_.walk << " s; flatten " << clock_.flatten << " s; stage+submit " << clock_.submit
+                      << " s; collect+merge+write " << clock_.collect << " s" << std::endl;
     }
     int run();
 
@@ -91,12 +125,10 @@ private:
     bool goNextRegion();
     Coord firstWindowCoordinate();
     bool firstWindowOnNextRoi(Coord & minCoord);
-    bool checkAndSwitch(const std::vector<unsigned> & rg, unsigned beginPos);
-    void addRecords(const std::vector<unsigned> & rg, const ProfileWindow & win);
-    unsigned readTillRoi(ByteSource & src, ProfileWindow & window, const std::vector<std::string> & contigNames,
-                         Coord & coordinate, const std::vector<unsigned> & rg, const Region & roi);
-    unsigned readSegment(ByteSource & src, const std::string & fileName, const std::vector<unsigned> & rg,
-                         const std::vector<std::string> & contigNames, Coord & coordinate, const Region & roi);
+    bool checkAndSwitch(const std::vector<unsigned> & rg, unsigned beginPos, unsigned * border);
+    void decodeSample(unsigned i, const std::string & coordContig, unsigned border, unsigned numWindows, DecodedStream & out) const;
+    unsigned replaySegment(const DecodedStream & in, const std::string & fileName, const std::vector<unsigned> & rg,
+                           const std::vector<std::string> & contigNames, Coord & coordinate, const Region & roi, unsigned * border);
     bool processSegmentCode(unsigned i, unsigned code);
     void processSegment();
     void flushPending();
@@ -113,6 +145,7 @@ private:
     std::vector<Coord> nextCandidate_;
     unsigned nextReadPos_ = kNoPos;
     // one segment in flight on the device while the next one is loaded
+    PhaseClock clock_;
     bool pending_ = false;
     uint64_t pendingTicket_ = 0;
     std::string pendingContig_;
@@ -275,12 +308,12 @@ bool CallRun::firstWindowOnNextRoi(Coord & minCoord)
     return true;
 }
 
-bool CallRun::checkAndSwitch(const std::vector<unsigned> & rg, unsigned beginPos)
+bool CallRun::checkAndSwitch(const std::vector<unsigned> & rg, unsigned beginPos, unsigned * border)
 {
     ChromProfile & prof = *profile_;
     if (prof.starts[rg[0]].tooBigForNext(beginPos) || prof.starts[rg[0]].needsSwitch(beginPos))
     {
-        prof.performSwitches(rg);
+        prof.performSwitches(rg, border);
         return false;
     }
     if (prof.ends[rg[0]].readSlot == prof.ends[rg[0]].writeSlot)
@@ -294,65 +327,97 @@ bool CallRun::checkAndSwitch(const std::vector<unsigned> & rg, unsigned beginPos
     return true;
 }
 
-void CallRun::addRecords(const std::vector<unsigned> & rg, const ProfileWindow & win)
+// Decoder thread body: everything readSegment() does that needs no profile state. The slot border is tracked
+// optimistically (a window far beyond the next slot is assumed to trigger the "tables are empty -> reset" branch); the
+// sequential replay takes the real decision and simply stops earlier if it differs.
+void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned border, unsigned numWindows,
+                           DecodedStream & out) const
 {
-    for (size_t r = 0; r < win.records.size(); ++r)
+    const unsigned contigIdx = p_.representativeContigs ? 0 : i;
+    const std::vector<std::string> & contigNames = p_.contigNames[contigIdx];
+    const Region & roi = p_.allRois[p_.nextRoi];
+    ProfileFile in(p_.inputFiles[i]);
+    in.jumpToRegion(contigNames, p_.contigLengths[contigIdx], p_.indexRegionSizes[contigIdx], roi.seqName, roi.beginPos);
+    auto src = in.openSource(p_.uncompressedIn);
+    const unsigned nRg = static_cast<unsigned>(p_.rgs[i].size());
+    ProfileWindow window;
+    for (;;)
     {
-        const InsertHistogram & h = p_.histograms[rg[r]];
-        for (const PairRecord & rec : win.records[r])
+        if (!readWindow(*src, window, nRg))
         {
-            int inner = static_cast<int32_t>(rec.dev) + static_cast<int>(h.median) - 2 * static_cast<int>(h.readLength);
-            unsigned endPos = rec.pos;
-            if (inner > 0)
-                endPos += static_cast<unsigned>(inner);
-            profile_->add(rg[r], rec.pos, endPos, static_cast<int32_t>(rec.dev));
+            out.eof = true;
+            return;
         }
+        DecodedRaw raw;
+        raw.chrom = window.chrom;
+        raw.beginPos = window.beginPos;
+        if (contigNames[window.chrom] != coordContig)
+        {
+            out.raws.push_back(std::move(raw));
+            return;
+        }
+        if (window.beginPos + 255 < roi.beginPos)
+            continue;
+        raw.firstWin = static_cast<uint32_t>(out.wins.size());
+        if (!splitWindowFlat(window, out.wins, out.counts, out.recs, 256, 30))
+        {
+            raw.splitFailed = true;
+            out.raws.push_back(std::move(raw));
+            return;
+        }
+        raw.nWin = static_cast<uint32_t>(out.wins.size()) - raw.firstWin;
+        bool stop = false;
+        for (uint32_t wi = raw.firstWin; wi < raw.firstWin + raw.nWin; ++wi)
+        {
+            const FlatWindow & w = out.wins[wi];
+            if (contigNames[w.chrom] != roi.seqName || w.beginPos >= roi.endPos)
+            {
+                stop = true;
+                break;
+            }
+            if (w.beginPos < roi.beginPos)
+                continue;
+            const unsigned pos = static_cast<unsigned>(w.beginPos);
+            if (pos >= border + numWindows)
+            {
+                border = pos + numWindows;
+                out.sawFarWindow = true;
+            }
+            else if (pos >= border)
+            {
+                stop = true;
+                break;
+            }
+        }
+        out.raws.push_back(std::move(raw));
+        if (stop)
+            return;
     }
 }
 
-unsigned CallRun::readTillRoi(ByteSource & src, ProfileWindow & window, const std::vector<std::string> & contigNames,
-                              Coord & coordinate, const std::vector<unsigned> & rg, const Region & roi)
+// Sequential half of readSegment(): same decisions, same order, fed from a decoded stream.
+unsigned CallRun::replaySegment(const DecodedStream & in, const std::string & fileName, const std::vector<unsigned> & rg,
+                                const std::vector<std::string> & contigNames, Coord & coordinate, const Region & roi, unsigned * border)
 {
-    do
+    ChromProfile & prof = *profile_;
+    for (const DecodedRaw & raw : in.raws)
     {
-        if (!readWindow(src, window, static_cast<unsigned>(rg.size())))
+        if (contigNames[raw.chrom] != coordinate.contig)
         {
-            profile_->performPartialSwitches(rg);
-            coordinate.contig = "";
-            coordinate.pos = kNoPos;
-            return 3;
-        }
-        if (contigNames[window.chrom] != coordinate.contig)
-        {
-            profile_->performPartialSwitches(rg);
-            coordinate.contig = contigNames[window.chrom];
-            coordinate.pos = static_cast<unsigned>(window.beginPos);
+            prof.performPartialSwitches(rg, border);
+            coordinate.contig = contigNames[raw.chrom];
+            coordinate.pos = static_cast<unsigned>(raw.beginPos);
             return 2;
         }
-    } while (window.beginPos + 255 < roi.beginPos);
-    return 0;
-}
-
-// 0: slot full, 2: end of contig / ROI, 3: end of file (load_profile_popdel_call.h:526-588).
-unsigned CallRun::readSegment(ByteSource & src, const std::string & fileName, const std::vector<unsigned> & rg,
-                              const std::vector<std::string> & contigNames, Coord & coordinate, const Region & roi)
-{
-    ProfileWindow window;
-    std::vector<ProfileWindow> converted;
-    ChromProfile & prof = *profile_;
-    while (true)
-    {
-        unsigned ret = readTillRoi(src, window, contigNames, coordinate, rg, roi);
-        if (ret > 0)
-            return ret;
-        if (!splitWindow(window, converted, 256, 30))
-            throw ProfileError("[PopDel] Could not convert window at " + contigNames[window.chrom] + ":" +
-                               std::to_string(window.beginPos) + ". The profile \"" + fileName + "\" might be corrupted.");
-        for (const ProfileWindow & w : converted)
+        if (raw.splitFailed)
+            throw ProfileError("[PopDel] Could not convert window at " + contigNames[raw.chrom] + ":" +
+                               std::to_string(raw.beginPos) + ". The profile \"" + fileName + "\" might be corrupted.");
+        for (uint32_t wi = raw.firstWin; wi < raw.firstWin + raw.nWin; ++wi)
         {
+            const FlatWindow & w = in.wins[wi];
             if (contigNames[w.chrom] != roi.seqName || w.beginPos >= roi.endPos)
             {
-                prof.performPartialSwitches(rg);
+                prof.performPartialSwitches(rg, border);
                 coordinate.contig = contigNames[w.chrom];
                 coordinate.pos = static_cast<unsigned>(w.beginPos);
                 return 2;
@@ -367,7 +432,7 @@ unsigned CallRun::readSegment(ByteSource & src, const std::string & fileName, co
                 }
                 else
                 {
-                    prof.performPartialSwitches(rg);
+                    prof.performPartialSwitches(rg, border);
                     coordinate.contig = contigNames[w.chrom];
                     coordinate.pos = static_cast<unsigned>(w.beginPos);
                     return 0;
@@ -375,14 +440,38 @@ unsigned CallRun::readSegment(ByteSource & src, const std::string & fileName, co
             }
             else if (prof.starts[rg[0]].needsSwitch(static_cast<unsigned>(w.beginPos)))
             {
-                prof.performPartialSwitches(rg);
+                prof.performPartialSwitches(rg, border);
                 coordinate.contig = contigNames[w.chrom];
                 coordinate.pos = static_cast<unsigned>(w.beginPos);
                 return 0;
             }
-            addRecords(rg, w);
+            // add all records of the window, read group by read group (load_profile_popdel_call.h:463-480)
+            {
+                uint32_t r0 = w.firstRec;
+                for (size_t r = 0; r < rg.size(); ++r)
+                {
+                    const uint32_t n = in.counts[static_cast<size_t>(wi) * rg.size() + r];
+                    const InsertHistogram & h = p_.histograms[rg[r]];
+                    for (uint32_t q = r0; q < r0 + n; ++q)
+                    {
+                        const PairRecord & rec = in.recs[q];
+                        int inner = static_cast<int32_t>(rec.dev) + static_cast<int>(h.median) - 2 * static_cast<int>(h.readLength);
+                        unsigned endPos = rec.pos;
+                        if (inner > 0)
+                            endPos += static_cast<unsigned>(inner);
+                        prof.add(rg[r], rec.pos, endPos, static_cast<int32_t>(rec.dev));
+                    }
+                    r0 += n;
+                }
+            }
         }
     }
+    if (!in.eof)
+        throw ProfileError("[PopDel] Internal error: decoded stream of \"" + fileName + "\" ended before the loader stopped.");
+    prof.performPartialSwitches(rg, border);
+    coordinate.contig = "";
+    coordinate.pos = kNoPos;
+    return 3;
 }
 
 bool CallRun::processSegmentCode(unsigned i, unsigned code)
@@ -488,20 +577,21 @@ void CallRun::processSegment()
         prof.profilesAtEnd = !prof.nextWindow(p_.windowShift);
     prof.initializeActive();
     const unsigned firstPos = prof.currentPos;
-    while (!prof.profilesAtEnd)
-    {
-        prof.windowDone();                      // window (firstPos + k * shift) is genotyped on the device
-        windows_.current.pos += p_.windowShift;
-        prof.profilesAtEnd = !prof.nextWindow(p_.windowShift);
-    }
-    const unsigned nWindows = prof.loggedWindows();
+    // the window loop: window (firstPos + k * shift) is genotyped on the device, read groups are walked in parallel
+    double t0 = PhaseClock::now();
+    const unsigned nWindows = prof.walkSegment(p_.windowShift);
+    windows_.current.pos += nWindows * p_.windowShift;
+    clock_.walk += PhaseClock::now() - t0;
     std::vector<std::vector<PairInstance>> & log = prof.endSegmentLog();
     if (observer_ && observer_->onSegment)
         observer_->onSegment(firstPos, nWindows, log);
 
+    t0 = PhaseClock::now();
     flushPending();
+    clock_.collect += PhaseClock::now() - t0;
     if (nWindows == 0)
         return;
+    t0 = PhaseClock::now();
     // Flatten to the SoA layout of pd_segment.
     std::vector<uint64_t> offsets(log.size() + 1, 0);
     for (size_t rg = 0; rg < log.size(); ++rg)
@@ -509,8 +599,7 @@ void CallRun::processSegment()
     const size_t total = offsets.back();
     std::vector<int32_t> dev(total);
     std::vector<uint32_t> start(total), on(total), off(total);
-    for (size_t rg = 0; rg < log.size(); ++rg)
-    {
+    parallelFor(log.size(), [&](size_t rg) {
         size_t o = offsets[rg];
         for (const PairInstance & pi : log[rg])
         {
@@ -520,7 +609,9 @@ void CallRun::processSegment()
             off[o] = pi.off;
             ++o;
         }
-    }
+    }, 16);
+    clock_.flatten += PhaseClock::now() - t0;
+    t0 = PhaseClock::now();
     pd_segment seg;
     seg.first_window_pos = firstPos;
     seg.n_windows = nWindows;
@@ -535,6 +626,7 @@ void CallRun::processSegment()
         throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctx_));
     pending_ = true;
     pendingContig_ = windows_.current.contig;
+    clock_.submit += PhaseClock::now() - t0;
 }
 
 bool CallRun::finalizeRoi()
@@ -586,27 +678,87 @@ int CallRun::run()
             flushPending();
             return 0;
         }
-        for (unsigned i = 0; i < p_.sampleNum; ++i)
+        const unsigned batch = std::max(64u, 8u * hostThreads());
+        for (unsigned b0 = 0; b0 < p_.sampleNum; b0 += batch)
         {
-            if (finishedFiles_[i] || finishedRois_[i])
-                continue;
-            ProfileFile in(p_.inputFiles[i]);
-            if (goNextRoi(in, i))
+            const unsigned b1 = std::min(p_.sampleNum, b0 + batch);
+            // (1) who takes part in this round (sequential bookkeeping), then their slot switches in parallel: a switch
+            //     touches only the sample's own tables plus the shared right border, which is published afterwards in
+            //     sample order
+            double t0 = PhaseClock::now();
+            std::vector<unsigned> members;
+            for (unsigned i = b0; i < b1; ++i)
             {
-                if (checkAndSwitch(p_.rgs[i], nextCandidate_[i].pos))
+                if (finishedFiles_[i] || finishedRois_[i])
+                    continue;
+                if (allTrue(finishedRois_))                     // cannot happen while sample i itself is unfinished
                 {
-                    unsigned contigIdx = p_.representativeContigs ? 0 : i;
-                    auto src = in.openSource(p_.uncompressedIn);
-                    unsigned code = readSegment(*src, p_.inputFiles[i], p_.rgs[i], p_.contigNames[contigIdx],
-                                                nextCandidate_[i], p_.allRois[p_.nextRoi]);
-                    if (!processSegmentCode(i, code))
+                    if (!advanceRoi(p_))
+                    {
+                        markRoiComplete(i);
                         continue;
+                    }
+                    for (char & f : finishedRois_)
+                        f = 0;
                 }
+                members.push_back(i);
+            }
+            constexpr unsigned kNoBorder = 0xffffffffu;
+            std::vector<unsigned> border(members.size(), kNoBorder);
+            std::vector<char> reads(members.size(), 0);
+            parallelFor(members.size(), [&](size_t k) {
+                const unsigned i = members[k];
+                reads[k] = checkAndSwitch(p_.rgs[i], nextCandidate_[i].pos, &border[k]) ? 1 : 0;
+            }, 4);
+            std::vector<unsigned> readers;
+            for (size_t k = 0; k < members.size(); ++k)
+            {
+                if (border[k] != kNoBorder)
+                    profile_->currentRightBorder = border[k];
+                if (reads[k])
+                    readers.push_back(members[k]);
+            }
+            clock_.switches += PhaseClock::now() - t0;
+            // (2) parallel: inflate, parse and split the profile windows of this round
+            t0 = PhaseClock::now();
+            std::vector<DecodedStream> decoded(readers.size());
+            parallelFor(readers.size(), [&](size_t k) {
+                const unsigned i = readers[k];
+                const StartSlots & st = profile_->starts[p_.rgs[i][0]];
+                decodeSample(i, nextCandidate_[i].contig, st.slots[st.writeSlot].right, st.numWindows, decoded[k]);
+            });
+            clock_.decode += PhaseClock::now() - t0;
+            t0 = PhaseClock::now();
+            // (3) insert the records and switch slots: per sample independent unless a stream contains a window beyond the
+            //     next slot (then the loader looks at ALL tables and order matters -> this batch is replayed in order)
+            bool ordered = false;
+            for (const DecodedStream & d : decoded)
+                ordered |= d.sawFarWindow;
+            std::vector<unsigned> codes(readers.size(), 0);
+            std::fill(border.begin(), border.end(), kNoBorder);
+            border.resize(readers.size(), kNoBorder);
+            auto replayOne = [&](size_t k, unsigned * borderOut) {
+                const unsigned i = readers[k];
+                const unsigned contigIdx = p_.representativeContigs ? 0 : i;
+                codes[k] = replaySegment(decoded[k], p_.inputFiles[i], p_.rgs[i], p_.contigNames[contigIdx], nextCandidate_[i],
+                                         p_.allRois[p_.nextRoi], borderOut);
+                decoded[k] = DecodedStream();                   // free early
+            };
+            if (ordered)
+            {
+                for (size_t k = 0; k < readers.size(); ++k)
+                    replayOne(k, nullptr);
             }
             else
             {
-                markRoiComplete(i);
+                parallelFor(readers.size(), [&](size_t k) { replayOne(k, &border[k]); }, 8);   // blocks of neighbours: the per-read-group tables of adjacent samples share cache lines
+                for (size_t k = 0; k < readers.size(); ++k)
+                    if (border[k] != kNoBorder)
+                        profile_->currentRightBorder = border[k];
             }
+            for (size_t k = 0; k < readers.size(); ++k)
+                processSegmentCode(readers[k], codes[k]);
+            clock_.replay += PhaseClock::now() - t0;
         }
         processSegment();
         if (allTrue(finishedRois_))
@@ -636,11 +788,11 @@ int CallRun::run()
 int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer)
 {
     CallParams params;
-    int res = parseCallCommandLine(params, argc, argv);
-    if (res >= 0)
-        return res;
     try
     {
+        int res = parseCallCommandLine(params, argc, argv);
+        if (res >= 0)
+            return res;
         CallRun run(params, observer);
         return run.run();
     }

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 
+#include "parallel.h"
 #include "profile_io.h"   // posToWin
 
 namespace pdh {
@@ -211,7 +212,7 @@ void ChromProfile::add(unsigned rg, unsigned startPos, unsigned endPos, int devi
     }
 }
 
-void ChromProfile::activate(unsigned rg, unsigned id)
+void ChromProfile::activate(unsigned rg, unsigned id, unsigned logWindow)
 {
     auto & set = active[rg];
     if (set.find(id) != set.end())
@@ -221,19 +222,19 @@ void ChromProfile::activate(unsigned rg, unsigned id)
     if (logging_)
     {
         rec.logIdx = static_cast<uint32_t>(log_[rg].size());
-        log_[rg].push_back(PairInstance{e.deviation, e.startPos, logWindow_, kNoLog});
+        log_[rg].push_back(PairInstance{e.deviation, e.startPos, logWindow, kNoLog});
     }
     set.emplace(id, rec);
 }
 
-void ChromProfile::deactivate(unsigned rg, unsigned id)
+void ChromProfile::deactivate(unsigned rg, unsigned id, unsigned logWindow)
 {
     auto & set = active[rg];
     auto it = set.find(id);
     if (it == set.end())
         return;
     if (logging_ && it->second.logIdx != kNoLog)
-        log_[rg][it->second.logIdx].off = logWindow_;
+        log_[rg][it->second.logIdx].off = logWindow;
     set.erase(it);
 }
 
@@ -259,31 +260,31 @@ void ChromProfile::initializeActive()
         if (pos != currentPos)
             continue;
         unsigned id = st.slots[st.readSlot].idOffset;
-        activate(rg, id);
+        activate(rg, id, logWindow_);
         ++id;
         bool endOfSlot = !st.goNext();
         while (!endOfSlot && st.current().startPos == pos)
         {
-            activate(rg, id);
+            activate(rg, id, logWindow_);
             ++id;
             endOfSlot = !st.goNext();
         }
     }
 }
 
-void ChromProfile::nextStartWindow(unsigned rg)
+void ChromProfile::nextStartWindow(unsigned rg, unsigned logWindow)
 {
     StartSlots & st = starts[rg];
     const unsigned pos = st.current().startPos;
     bool more = true;
     while (more && pos == st.current().startPos)
     {
-        activate(rg, st.currentId());
+        activate(rg, st.currentId(), logWindow);
         more = st.goNext();
     }
 }
 
-bool ChromProfile::nextEndWindow(unsigned rg)
+bool ChromProfile::nextEndWindow(unsigned rg, unsigned logWindow)
 {
     EndSlots & en = ends[rg];
     if (en.readAtEnd())
@@ -291,7 +292,7 @@ bool ChromProfile::nextEndWindow(unsigned rg)
     const unsigned win = en.current().lastWindow;
     while (win == en.current().lastWindow)
     {
-        deactivate(rg, en.current().id);
+        deactivate(rg, en.current().id, logWindow);
         if (!en.goNext())
             return false;
     }
@@ -316,14 +317,14 @@ bool ChromProfile::nextWindow(unsigned shift)
         while (!st.readAtEnd())
         {
             if (st.current().startPos <= currentPos)
-                nextStartWindow(rg);
+                nextStartWindow(rg, logWindow_);
             else
                 break;
         }
         while (!en.readAtEnd())
         {
             if (en.current().lastWindow + shift < currentPos)   // the last window itself is still valid
-                nextEndWindow(rg);
+                nextEndWindow(rg, logWindow_);
             else
                 break;
         }
@@ -331,6 +332,55 @@ bool ChromProfile::nextWindow(unsigned shift)
     if (!someStillGood)
         currentPos -= shift;
     return someStillGood;
+}
+
+// One read group's share of the window loop: steps 1..maxSteps at positions pos0 + j * shift, until both of its
+// cursors are at the end. Returns the number of steps at whose start the read group still had entries.
+unsigned ChromProfile::walkReadGroup(unsigned rg, unsigned pos0, unsigned shift, unsigned maxSteps)
+{
+    StartSlots & st = starts[rg];
+    EndSlots & en = ends[rg];
+    unsigned j = 0;
+    while (j < maxSteps && !(en.readAtEnd() && st.readAtEnd()))
+    {
+        ++j;
+        const unsigned pos = pos0 + j * shift;
+        while (!st.readAtEnd())
+        {
+            if (st.current().startPos <= pos)
+                nextStartWindow(rg, j);
+            else
+                break;
+        }
+        while (!en.readAtEnd())
+        {
+            if (en.current().lastWindow + shift < pos)
+                nextEndWindow(rg, j);
+            else
+                break;
+        }
+    }
+    return j;
+}
+
+unsigned ChromProfile::walkSegment(unsigned shift)
+{
+    if (profilesAtEnd)
+        return logWindow_;
+    const unsigned pos0 = currentPos;
+    // steps the slot border allows: positions pos0 + j * shift must stay below currentRightBorder
+    unsigned maxSteps = 0;
+    if (pos0 + shift < currentRightBorder)
+        maxSteps = (currentRightBorder - pos0 - 1) / shift;
+    std::vector<unsigned> good(starts.size(), 0);
+    parallelFor(starts.size(), [&](size_t rg) { good[rg] = walkReadGroup(static_cast<unsigned>(rg), pos0, shift, maxSteps); }, 16);
+    unsigned steps = 0;
+    for (unsigned g : good)
+        steps = std::max(steps, g);
+    currentPos = pos0 + steps * shift;
+    profilesAtEnd = true;
+    logWindow_ += steps + 1;
+    return logWindow_;
 }
 
 void ChromProfile::resetTo(unsigned pos)
@@ -375,26 +425,28 @@ void ChromProfile::fullReset()
     currentRightBorder = starts[0].slots[2].right;
 }
 
-void ChromProfile::performSwitches(const std::vector<unsigned> & rgs)
+void ChromProfile::performSwitches(const std::vector<unsigned> & rgs, unsigned * border)
 {
+    unsigned & rightBorder = border ? *border : currentRightBorder;
     for (unsigned i : rgs)
     {
         while (!ends[i].readAtEnd())
-            nextEndWindow(i);
-        starts[i].switchBoth(currentRightBorder);
+            nextEndWindow(i, logWindow_);
+        starts[i].switchBoth(rightBorder);
         ends[i].switchWrite();
         ends[i].fixConsecutiveSwitch(activeLoad[i]);
         ends[i].switchRead();
     }
 }
 
-void ChromProfile::performPartialSwitches(const std::vector<unsigned> & rgs)
+void ChromProfile::performPartialSwitches(const std::vector<unsigned> & rgs, unsigned * border)
 {
+    unsigned & rightBorder = border ? *border : currentRightBorder;
     for (unsigned i : rgs)
     {
         while (!ends[i].readAtEnd())
-            nextEndWindow(i);
-        starts[i].switchBoth(currentRightBorder);
+            nextEndWindow(i, logWindow_);
+        starts[i].switchBoth(rightBorder);
         ends[i].switchRead();
     }
 }

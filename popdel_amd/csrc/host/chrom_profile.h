@@ -122,8 +122,10 @@ public:
     bool nextWindow(unsigned shift);
     void resetTo(unsigned pos);
     void fullReset();
-    void performSwitches(const std::vector<unsigned> & rgs);
-    void performPartialSwitches(const std::vector<unsigned> & rgs);
+    // The switch helpers write the right border of the new read slot to *border (default: currentRightBorder); parallel
+    // callers pass a private variable and publish it afterwards in sample order.
+    void performSwitches(const std::vector<unsigned> & rgs, unsigned * border = nullptr);
+    void performPartialSwitches(const std::vector<unsigned> & rgs, unsigned * border = nullptr);
     bool allEmpty() const;
 
     // --- event log (segment builder) -------------------------------------------------------------------
@@ -131,6 +133,12 @@ public:
     void beginSegmentLog();
     // Call after each genotyped window (before nextWindow()).
     void windowDone() { ++logWindow_; }
+    // The whole window loop of one segment in one call: equivalent to
+    //     while (!profilesAtEnd) { windowDone(); profilesAtEnd = !nextWindow(shift); }
+    // but read groups are walked independently (and in parallel): within a step they only share the position, and the
+    // loop ends after min(steps to the slot border, steps until the last read group runs dry). Returns the number of
+    // genotyped windows.
+    unsigned walkSegment(unsigned shift);
     // Close all open instances at `off = number of windows` and return the per-read-group instance lists.
     // Still-active pairs stay in the active set for the next segment.
     std::vector<std::vector<PairInstance>> & endSegmentLog();
@@ -155,10 +163,11 @@ public:
 
 private:
     static constexpr uint32_t kNoLog = 0xffffffffu;
-    void activate(unsigned rg, unsigned id);
-    void deactivate(unsigned rg, unsigned id);
-    void nextStartWindow(unsigned rg);
-    bool nextEndWindow(unsigned rg);
+    void activate(unsigned rg, unsigned id, unsigned logWindow);
+    void deactivate(unsigned rg, unsigned id, unsigned logWindow);
+    void nextStartWindow(unsigned rg, unsigned logWindow);
+    bool nextEndWindow(unsigned rg, unsigned logWindow);
+    unsigned walkReadGroup(unsigned rg, unsigned pos0, unsigned shift, unsigned maxSteps);
 
     bool logging_ = false;
     unsigned logWindow_ = 0;

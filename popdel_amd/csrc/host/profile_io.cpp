@@ -303,4 +303,56 @@ bool splitWindow(const ProfileWindow & in, std::vector<ProfileWindow> & out, uns
     return true;
 }
 
+bool splitWindowFlat(const ProfileWindow & in, std::vector<FlatWindow> & wins, std::vector<uint32_t> & counts,
+                     std::vector<PairRecord> & recs, unsigned oldSize, unsigned newSize)
+{
+    const size_t rgNum = in.records.size();
+    const size_t slots = static_cast<size_t>(std::ceil(static_cast<double>(oldSize + newSize) / newSize));
+    unsigned base = std::numeric_limits<unsigned>::max();
+    for (size_t rg = 0; rg < rgNum; ++rg)
+        if (!in.records[rg].empty() && in.records[rg][0].pos < base)
+            base = in.records[rg][0].pos;
+    base = (base / newSize) * newSize;
+    // per slot and read group: number of records
+    std::vector<uint32_t> perSlot(slots * rgNum, 0);
+    std::vector<char> hasContent(slots, 0);
+    for (size_t rg = 0; rg < rgNum; ++rg)
+        for (const PairRecord & r : in.records[rg])
+        {
+            size_t idx = (r.pos - base) / newSize;
+            if (idx >= slots)
+                throw ProfileError("[PopDel] Profile window is not position-sorted.");
+            hasContent[idx] = 1;
+            ++perSlot[idx * rgNum + rg];
+        }
+    size_t total = 0;
+    for (size_t i = 0; i < slots; ++i)
+        total += hasContent[i] ? 1 : 0;
+    if (total == 0)
+        return false;
+    // layout: windows in slot order; within a window read groups in order
+    std::vector<uint32_t> cursor(slots * rgNum, 0);
+    uint32_t next = static_cast<uint32_t>(recs.size());
+    for (size_t i = 0; i < slots; ++i)
+    {
+        if (!hasContent[i])
+            continue;
+        wins.push_back(FlatWindow{in.chrom, static_cast<int32_t>(base + i * newSize), next});
+        for (size_t rg = 0; rg < rgNum; ++rg)
+        {
+            counts.push_back(perSlot[i * rgNum + rg]);
+            cursor[i * rgNum + rg] = next;
+            next += perSlot[i * rgNum + rg];
+        }
+    }
+    recs.resize(next);
+    for (size_t rg = 0; rg < rgNum; ++rg)
+        for (const PairRecord & r : in.records[rg])
+        {
+            size_t idx = (r.pos - base) / newSize;
+            recs[cursor[idx * rgNum + rg]++] = r;
+        }
+    return true;
+}
+
 }  // namespace pdh

@@ -87,6 +87,18 @@ bool readWindow(ByteSource & src, ProfileWindow & win, unsigned numReadGroups);
 // Returns false if the window holds no records at all.
 bool splitWindow(const ProfileWindow & in, std::vector<ProfileWindow> & out, unsigned oldSize = 256, unsigned newSize = 30);
 
+// Flat variant for bulk decoding: appends the 30-bp windows of `in` to `wins` (begin positions), their per-read-group
+// record counts to `counts` (numReadGroups entries per window) and the records to `recs` (window by window, read group by
+// read group, file order within). Same windows and order as splitWindow(). Returns false if `in` holds no records.
+struct FlatWindow
+{
+    int32_t  chrom;
+    int32_t  beginPos;
+    uint32_t firstRec;     // index into the record array
+};
+bool splitWindowFlat(const ProfileWindow & in, std::vector<FlatWindow> & wins, std::vector<uint32_t> & counts,
+                     std::vector<PairRecord> & recs, unsigned oldSize = 256, unsigned newSize = 30);
+
 inline unsigned posToWin(unsigned pos, unsigned windowSize = 30u) { return (pos / windowSize) * windowSize; }
 
 }  // namespace pdh
