@@ -92,6 +92,9 @@ struct StagedSegment
     DevBuf<uint32_t> start;
     DevBuf<uint64_t> rgBase;
     DevBuf<uint32_t> winStart;
+    DevBuf<uint2> pairsPk;
+    DevBuf<uint32_t> endCount;
+    DevBuf<uint8_t> rgPacked;
     bool ownedBySubmit = false;
 };
 
@@ -207,7 +210,8 @@ T * mallocCopy(const std::vector<T> & v)
 // Split every pair instance into chunks that live at most K windows, order the chunks of each read group by their
 // first window and index them by window (winStart). K is chosen so that nearly all pairs need a single chunk.
 void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, std::vector<pd::PairDO> & pairs,
-                 std::vector<uint32_t> & start, std::vector<uint64_t> & rgBase, std::vector<uint32_t> & winStart)
+                 std::vector<uint32_t> & start, std::vector<uint64_t> & rgBase, std::vector<uint32_t> & winStart,
+                 std::vector<uint2> & pairsPk, std::vector<uint32_t> & endCount, std::vector<uint8_t> & rgPacked)
 {
     const uint32_t W = seg.n_windows;
     const uint64_t total = seg.rg_offsets[seg.n_readgroups];
@@ -276,22 +280,40 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
     }
     pairs.resize(totalChunks);
     start.resize(totalChunks);
+    pairsPk.resize(totalChunks);
+    endCount.assign(static_cast<size_t>(seg.n_readgroups) * (W + 1), 0);
+    rgPacked.assign(seg.n_readgroups, 0);
     // pass 2 (parallel): scatter the chunks to their slots, stable within a window
     pdh::parallelFor(seg.n_readgroups, [&](size_t rg) {
         const uint64_t lo = seg.rg_offsets[rg], hi = seg.rg_offsets[rg + 1];
         const uint32_t * ws = winStart.data() + rg * (W + 1);
         std::vector<uint32_t> cursor(ws, ws + W);
         const size_t base = rgBase[rg];
+        uint32_t * ec = endCount.data() + rg * (W + 1);
+        bool fits = W <= 0xffffu;
         for (uint64_t i = lo; i < hi; ++i)
         {
             uint32_t on = seg.pair_on[i], off = std::min(seg.pair_off[i], W);
+            const int32_t dv = seg.pair_dev[i];
+            fits = fits && dv >= -32767 && dv <= 32766;
+            const uint32_t d16 = static_cast<uint32_t>(dv) & 0xffffu;
             for (uint32_t a = on; a < off; a += K)
             {
                 const uint32_t slot = cursor[a]++;
-                pairs[base + slot] = pd::PairDO{seg.pair_dev[i], std::min(off, a + K)};
+                const uint32_t chunkOff = std::min(off, a + K);
+                pairs[base + slot] = pd::PairDO{dv, chunkOff};
                 start[base + slot] = seg.pair_start[i];
+                pairsPk[base + slot] = make_uint2(d16 | (d16 << 16), (chunkOff & 0xffffu) | (chunkOff << 16));
+                ++ec[chunkOff];
             }
         }
+        uint32_t acc = 0;
+        for (uint32_t w = 0; w <= W; ++w)
+        {
+            acc += ec[w];
+            ec[w] = acc;
+        }
+        rgPacked[rg] = fits ? 1 : 0;
     }, 8);
     out.nChunks = pairs.size();
     (void)c;
@@ -304,6 +326,9 @@ pd::SegmentView viewOf(const StagedSegment & s)
     v.start = s.start.p;
     v.rgBase = s.rgBase.p;
     v.winStart = s.winStart.p;
+    v.pairsPk = s.pairsPk.p;
+    v.endCount = s.endCount.p;
+    v.rgPacked = s.rgPacked.p;
     v.nWindows = s.nWindows;
     v.maxLife = s.maxLife;
     v.firstPos = s.firstPos;
@@ -430,13 +455,18 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
         s->nWindows = seg->n_windows;
         s->shift = seg->window_shift;
         std::vector<pd::PairDO> pairs;
-        std::vector<uint32_t> start, winStart;
+        std::vector<uint32_t> start, winStart, endCount;
         std::vector<uint64_t> rgBase;
-        buildChunks(*c, *seg, *s, pairs, start, rgBase, winStart);
+        std::vector<uint2> pairsPk;
+        std::vector<uint8_t> rgPacked;
+        buildChunks(*c, *seg, *s, pairs, start, rgBase, winStart, pairsPk, endCount, rgPacked);
         s->pairs.upload(pairs, c->stream);
         s->start.upload(start, c->stream);
         s->rgBase.upload(rgBase, c->stream);
         s->winStart.upload(winStart, c->stream);
+        s->pairsPk.upload(pairsPk, c->stream);
+        s->endCount.upload(endCount, c->stream);
+        s->rgPacked.upload(rgPacked, c->stream);
         PD_HIP(hipStreamSynchronize(c->stream));       // host vectors go out of scope
         *handle = c->nextHandle++;
         c->staged[*handle] = std::move(s);

@@ -51,6 +51,11 @@ struct SegmentView
     const uint32_t * start;        // [nChunks]  startPos
     const uint64_t * rgBase;       // [nRg]      first chunk of the read group
     const uint32_t * winStart;     // [nRg * (W + 1)] first chunk (relative to rgBase) whose on >= w
+    // stage-1 image of the chunks: deviation and end window as int16, each duplicated into both halves of a dword
+    // (ready for packed 16-bit arithmetic on two windows at once); only valid for read groups with rgPacked != 0
+    const uint2 *    pairsPk;      // [nChunks]
+    const uint32_t * endCount;     // [nRg * (W + 1)] number of chunks of the read group that ended at or before w
+    const uint8_t *  rgPacked;     // [nRg] 1 if all deviations fit int16 and W fits 16 bits
     uint32_t         nWindows;
     uint32_t         maxLife;      // K: a chunk lives at most K windows
     uint32_t         firstPos;

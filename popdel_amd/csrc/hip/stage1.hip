@@ -272,6 +272,13 @@ __device__ __forceinline__ void stage1PairFast(const PairPk * lds, unsigned aA, 
     vbB = r[T + 1].y;
 }
 
+// Same interpolation for int16 inputs: everything fits 32 bits.
+__device__ __forceinline__ int q3FromRankPair16(unsigned n, int a, int b)
+{
+    const int k = (int)((3u * n + 2u + (n & 1u)) & 3u);       // (pos4 - 4) & 3 == pos4 & 3
+    return ((4 - k) * a + k * b + 2) >> 2;
+}
+
 __device__ __forceinline__ void storeCell(unsigned n, unsigned maxLoad, int va, int vb, size_t cell, unsigned w, int minThreshold,
                                           int32_t * q3, uint8_t * flags, int * winFlag)
 {
@@ -281,7 +288,7 @@ __device__ __forceinline__ void storeCell(unsigned n, unsigned maxLoad, int va, 
         fl = 1u;
     else if (n < maxLoad)
     {
-        q = (n < 4u) ? va : q3FromRankPair(n, va, vb);
+        q = (n < 4u) ? va : q3FromRankPair16(n, va, vb);
         fl = 2u;
     }
     q3[cell] = q;
@@ -298,8 +305,6 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
 {
     __shared__ PairPk ldsPairs[kPackedLdsPairs + 64];
     __shared__ uint32_t ldsWs[kPackedWsLen];
-    __shared__ int ldsEnd[kPackedWsLen + 6];
-    __shared__ int waveTotals[kStage1Block / 64];
 
     const unsigned s = blockIdx.y;
     const unsigned w0 = blockIdx.x * kPackedWindows;
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     uint8_t * todo = tileTodo + (size_t)s * tilesPerSample + 2u * blockIdx.x;      // two 256-window tiles
     const bool secondTile = (w0 + kStage1Block) < W;
 
-    if (!(singleRg && K <= 64u))
+    if (!(singleRg && K <= 64u && seg.rgPacked[rg0]))
     {
         if (tid == 0)
         {
@@ -326,20 +331,22 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     const unsigned whi = min(W, w0 + kPackedWindows);                // ws index of the range end
     const unsigned nWs = whi - wlo0 + 1;
     for (unsigned i = tid; i < nWs; i += kStage1Block)
-    {
         ldsWs[i] = ws[wlo0 + i];
-        ldsEnd[i] = 0;
-    }
+    // pairs that ended at or before the lane's windows (host-built prefix counts): n(w) = started - ended
+    const unsigned wA = w0 + 2u * tid, wB = wA + 1u;
+    const uint32_t * ec = seg.endCount + (size_t)rg0 * (W + 1);
+    const unsigned endedA = (wA < W) ? ec[wA] : 0u;
+    const unsigned endedB = (wB < W) ? ec[wB] : 0u;
     __syncthreads();
     const unsigned A = ldsWs[0];
     const unsigned nPairs = ldsWs[nWs - 1] - A;
     bool bad = nPairs > (unsigned)kPackedLdsPairs;
     if (!bad)
     {
-        const PairDO * src = seg.pairs + seg.rgBase[rg0] + A;
-        // all global loads of the stage are issued before the first LDS write (one HBM latency, not nine)
+        // the LDS image is the HBM image: plain copy, all loads in flight before the first LDS write
+        const uint2 * src = seg.pairsPk + seg.rgBase[rg0] + A;
         constexpr int kIters = kPackedLdsPairs / kStage1Block;
-        PairDO tmp[kIters];
+        uint2 tmp[kIters];
 #pragma unroll
         for (int it = 0; it < kIters; ++it)
         {
@@ -353,22 +360,15 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
             const unsigned i = tid + (unsigned)it * kStage1Block;
             if (i < nPairs)
             {
-                const PairDO p = tmp[it];
-                const unsigned rel = p.off - wlo0;                  // off > on >= wlo0, and off <= on + K: fits 16 bits
-                const unsigned d16 = (unsigned)p.dev & 0xffffu;
                 PairPk e;
-                e.devdev = d16 | (d16 << 16);
-                e.offoff = rel | (rel << 16);
+                e.devdev = tmp[it].x;
+                e.offoff = tmp[it].y;
                 ldsPairs[i] = e;
-                bad |= (p.dev < -32767) || (p.dev > 32766);
-                if (rel < nWs)
-                    atomicAdd(&ldsEnd[rel], 1);
             }
         }
     }
     // lane t owns the adjacent windows w0 + 2t and w0 + 2t + 1; B's range is expressed in A's slot coordinates
     unsigned aA = 0, cntA = 0, endB = 0;
-    const unsigned wA = w0 + 2u * tid, wB = wA + 1u;
     if (wA < W)
     {
         const unsigned wlo = (wA + 1 >= K) ? (wA + 1 - K) : 0u;
@@ -376,9 +376,7 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
         cntA = ldsWs[wA + 1 - wlo0] - A - aA;
     }
     if (wB < W)
-    {
         endB = ldsWs[wB + 1 - wlo0] - A - aA;
-    }
     const unsigned cntU = max(cntA, endB);
     bad |= cntU > 64u;
     if (__syncthreads_or(bad))                                     // also orders the LDS writes above
@@ -397,36 +395,10 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
         if (secondTile)
             todo[1] = 0;
     }
-    // inclusive prefix sum of ldsEnd over nWs (<= 3 * 256) entries: E(w) = pairs that ended at or before w
-    {
-        const unsigned base = 3u * tid;
-        int e0 = (base < nWs) ? ldsEnd[base] : 0;
-        int e1 = (base + 1 < nWs) ? ldsEnd[base + 1] : 0;
-        int e2 = (base + 2 < nWs) ? ldsEnd[base + 2] : 0;
-        e1 += e0;
-        e2 += e1;
-        int incl = e2;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1)
-        {
-            const int t = __shfl_up(incl, o, 64);
-            if ((int)(tid & 63u) >= o)
-                incl += t;
-        }
-        if ((tid & 63u) == 63u)
-            waveTotals[tid >> 6] = incl;
-        __syncthreads();
-        int offset = incl - e2;
-        for (unsigned wv = 0; wv < (tid >> 6); ++wv)
-            offset += waveTotals[wv];
-        if (base < nWs)
-            ldsEnd[base] = e0 + offset;
-        if (base + 1 < nWs)
-            ldsEnd[base + 1] = e1 + offset;
-        if (base + 2 < nWs)
-            ldsEnd[base + 2] = e2 + offset;
-        __syncthreads();
-    }
+    // active pairs per window; parked in LDS because the lanes are re-dealt below
+    __shared__ unsigned short ldsN[kPackedWindows];
+    ldsN[2u * tid] = (unsigned short)((wA < W) ? (ldsWs[wA + 1 - wlo0] - endedA) : 0u);
+    ldsN[2u * tid + 1u] = (unsigned short)((wB < W) ? (ldsWs[wB + 1 - wlo0] - endedB) : 0u);
     // Re-deal the 256 window pairs to the lanes ordered by candidate count (largest first): every wave then runs the
     // smallest network that fits ITS lanes instead of the one that fits the worst lane of an arbitrary 64.
     __shared__ unsigned short unitOrder[kStage1Block];
@@ -467,12 +439,11 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     {
         xEndB = ldsWs[uB + 1 - wlo0] - A - xA;
     }
-    const unsigned nA = (ldsWs[uA + 1 - wlo0] - A) - (unsigned)ldsEnd[uA - wlo0];
-    const unsigned nB = (uB < W) ? (ldsWs[uB + 1 - wlo0] - A) - (unsigned)ldsEnd[uB - wlo0] : 0u;
+    const unsigned nA = ldsN[2u * u];
+    const unsigned nB = ldsN[2u * u + 1u];
     const unsigned cmax = waveMaxU32(max(xCntA, xEndB));             // wave-uniform network size
-    // window numbers relative to the staged range; entries ahead of B's range ended before w + 1 (chunk life <= K),
-    // so B needs no lower range test
-    const unsigned wPk = (uA - wlo0) | ((uB - wlo0) << 16);
+    // entries ahead of B's range ended before w + 1 (chunk life <= K), so B needs no lower range test
+    const unsigned wPk = uA | (uB << 16);                            // absolute window numbers (W fits 16 bits here)
     const unsigned cntPk = xCntA | (xEndB << 16);
     int vaA, vbA, vaB, vbB;
     if (cmax <= 32u)
