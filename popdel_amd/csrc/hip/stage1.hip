@@ -203,7 +203,11 @@ __device__ __forceinline__ void sortRegs16(v2s (&r)[C]);
 template <>
 __device__ __forceinline__ void sortRegs16<32>(v2s (&r)[32]) { PD_SORTNET_32(PD_CE16) }
 template <>
+__device__ __forceinline__ void sortRegs16<40>(v2s (&r)[40]) { PD_SORTNET_40(PD_CE16) }
+template <>
 __device__ __forceinline__ void sortRegs16<48>(v2s (&r)[48]) { PD_SORTNET_48(PD_CE16) }
+template <>
+__device__ __forceinline__ void sortRegs16<56>(v2s (&r)[56]) { PD_SORTNET_56(PD_CE16) }
 template <>
 __device__ __forceinline__ void sortRegs16<64>(v2s (&r)[64]) { PD_SORTNET_64(PD_CE16) }
 
@@ -241,28 +245,57 @@ struct PairPk
 // completely, so every LDS entry is read once and feeds both cells: slot c of the lane is entry (aA + c) for both.
 // All per-slot logic (active test, range test, filler choice, filler count) is packed 16-bit arithmetic on both cells
 // at once: a slot costs ~10 VALU for the two cells.
+// The per-slot logic below is written with the packed instructions spelled out: left to itself hipcc canonicalises
+// "(a - b) >> 15" on <2 x i16> into a compare + select per half (v_cmp_*_sdwa, v_cndmask, v_perm: ~16 VALU per slot
+// instead of 9). These are pure register-to-register VALU ops, so the asm statements need no waits or clobbers.
+__device__ __forceinline__ unsigned asmPkSub(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned asmPkAdd(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned asmPkAddS(unsigned a, unsigned sconst)      // second operand from an SGPR
+{
+    unsigned r;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(sconst));
+    return r;
+}
+__device__ __forceinline__ unsigned asmPkSign(unsigned a)                       // 0xFFFF in every negative half
+{
+    unsigned r;
+    asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+
 template <int C>
 __device__ __forceinline__ void stage1PairFast(const PairPk * lds, unsigned aA, unsigned wPk, unsigned cntPk, unsigned nA,
                                                unsigned nB, int & vaA, int & vbA, int & vaB, int & vbB)
 {
-    constexpr unsigned T = (3u * C + 2u - 4u) >> 2;        // l0(C): 23 for 32 slots, 35 for 48, 47 for 64
+    constexpr unsigned T = (3u * C + 2u - 4u) >> 2;        // l0(C): 23 / 29 / 35 / 41 / 47 for 32 / 40 / 48 / 56 / 64 slots
     // number of -INF fillers that moves rank l0(n) to position T
     const unsigned pA = (nA >= 2u) ? (T - rankL0(nA)) : 0u;
     const unsigned pB = (nB >= 2u) ? (T - rankL0(nB)) : 0u;
-    unsigned bPk = pA | (pB << 16);                        // p + number of active slots seen so far
+    const unsigned one = 0x00010001u;
+    unsigned qPk = asmPkSub(0u, cntPk);                    // c - cnt        (negative while the slot is in range)
+    unsigned dPk = asmPkSub(0u, pA | (pB << 16));          // c - (p + #active slots before c): negative -> filler is -INF
     v2s r[C];
 #pragma unroll
     for (int c = 0; c < C; ++c)
     {
         const PairPk e = lds[aA + c];
-        const unsigned cPk = (unsigned)c | ((unsigned)c << 16);
-        // active <=> off > w  and  c < cnt   (both differences negative)
-        const unsigned m = pkSignMask(pkSub(wPk, e.offoff) & pkSub(cPk, cntPk));
-        // filler: -INF (0x8000) while fewer than p fillers were handed out, +INF (0x7FFF) afterwards;
-        // (#inactive slots before c) < p  <=>  c < p + (#active slots before c)
-        const unsigned fill = pkSignMask(pkSub(cPk, bPk)) ^ 0x7FFF7FFFu;
+        // active <=> off > w and c < cnt: both differences negative
+        const unsigned m = asmPkSign(asmPkSub(wPk, e.offoff) & qPk);
+        // filler: -INF (0x8000) for the first p inactive slots, +INF (0x7FFF) afterwards
+        const unsigned fill = asmPkSign(dPk) ^ 0x7FFF7FFFu;
         const unsigned x = (e.devdev & m) | (fill & ~m);
-        bPk = pkSub(bPk, m);                                  // +1 per active slot
+        qPk = asmPkAddS(qPk, one);
+        dPk = asmPkAdd(asmPkAddS(dPk, one), m);               // +1, and -1 again if the slot was active
         r[c] = __builtin_bit_cast(v2s, x);
     }
     sortRegs16<C>(r);
@@ -402,13 +435,14 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     // Re-deal the 256 window pairs to the lanes ordered by candidate count (largest first): every wave then runs the
     // smallest network that fits ITS lanes instead of the one that fits the worst lane of an arbitrary 64.
     __shared__ unsigned short unitOrder[kStage1Block];
-    __shared__ unsigned classCount[4][kStage1Block / 64];
+    constexpr unsigned kClasses = 6;
+    __shared__ unsigned classCount[kClasses][kStage1Block / 64];
     {
-        const unsigned cls = (wA >= W) ? 3u : (cntU > 48u ? 0u : (cntU > 32u ? 1u : 2u));
+        const unsigned cls = (wA >= W) ? 5u : (cntU > 56u ? 0u : (cntU > 48u ? 1u : (cntU > 40u ? 2u : (cntU > 32u ? 3u : 4u))));
         const unsigned long long below = (1ull << (tid & 63u)) - 1ull;
         unsigned rank = 0;
 #pragma unroll
-        for (unsigned k = 0; k < 4u; ++k)
+        for (unsigned k = 0; k < kClasses; ++k)
         {
             const unsigned long long bal = __ballot(cls == k);
             if (cls == k)
@@ -418,7 +452,7 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
         }
         __syncthreads();
         unsigned offset = 0;
-        for (unsigned k = 0; k < 4u; ++k)
+        for (unsigned k = 0; k < kClasses; ++k)
             for (unsigned v = 0; v < kStage1Block / 64; ++v)
                 if (k < cls || (k == cls && v < (tid >> 6)))
                     offset += classCount[k][v];
@@ -448,8 +482,12 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     int vaA, vbA, vaB, vbB;
     if (cmax <= 32u)
         stage1PairFast<32>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
+    else if (cmax <= 40u)
+        stage1PairFast<40>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
     else if (cmax <= 48u)
         stage1PairFast<48>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
+    else if (cmax <= 56u)
+        stage1PairFast<56>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
     else
         stage1PairFast<64>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
     const unsigned maxLoad = co.rg[rg0].maxLoad;
