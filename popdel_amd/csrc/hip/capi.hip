@@ -24,7 +24,7 @@ void launchCluster(const int32_t * q3, const uint8_t * flags, const int * flagge
                    hipStream_t st);
 void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st);
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st);
-void buildLogTables(const double * hist, double * logHist, double * log10Hist, size_t n, RgConst * rg, unsigned nRg, hipStream_t st);
+void buildLogTables(const double * hist, double4 * tab, size_t n, RgConst * rg, unsigned nRg, hipStream_t st);
 void launchGatherOut(const Stage2Buffers & b, const unsigned * emitCells, unsigned nEmit, unsigned nSamples, uint32_t * pl,
                      uint32_t * lad, uint32_t * dad, uint32_t * fl, hipStream_t st);
 
@@ -115,7 +115,8 @@ struct pd_ctx
     std::string error;
     hipStream_t stream = nullptr;
     DevBuf<pd::RgConst> dRg;
-    DevBuf<double> dHist, dLogHist, dLog10Hist;
+    DevBuf<double> dHist;
+    DevBuf<double4> dTab;
     DevBuf<unsigned> dIterFlags;
     DevBuf<uint32_t> dSampleRg;
     pd::CohortView cohort;
@@ -396,16 +397,14 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
         c->dRg.upload(rc, c->stream);
         c->dHist.upload(pool, c->stream);
         c->dSampleRg.upload(c->sampleRg, c->stream);
-        c->dLogHist.alloc(pool.size());
-        c->dLog10Hist.alloc(pool.size());
+        c->dTab.alloc(pool.size());
         c->dIterFlags.alloc(pd::kMaxIterationsCap + 1);
-        pd::buildLogTables(c->dHist.p, c->dLogHist.p, c->dLog10Hist.p, pool.size(), c->dRg.p, n_readgroups, c->stream);
+        pd::buildLogTables(c->dHist.p, c->dTab.p, pool.size(), c->dRg.p, n_readgroups, c->stream);
         PD_HIP(hipGetLastError());
         PD_HIP(hipStreamSynchronize(c->stream));
         c->cohort.rg = c->dRg.p;
         c->cohort.hist = c->dHist.p;
-        c->cohort.logHist = c->dLogHist.p;
-        c->cohort.log10Hist = c->dLog10Hist.p;
+        c->cohort.tab = c->dTab.p;
         c->cohort.sampleRg = c->dSampleRg.p;
         c->cohort.nSamples = n_samples;
         c->cohort.nRg = n_readgroups;
@@ -625,7 +624,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         if (nCells != 0)
         {
             b.nCells = nCells;
-            b.nTiles = (S + pd::kSampleTile - 1) / pd::kSampleTile;
+            b.nTiles = (S + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock;
             c->dCells.upload(cells, c->stream);
             c->dDl.ensure(static_cast<size_t>(nCells) * S * 3);
             c->dShifts.ensure(static_cast<size_t>(nCells) * c->nRg);

@@ -13,7 +13,8 @@ constexpr int kMaxCandidatesPerWindow = 8;     // candidate deletion lengths kep
 constexpr int kMaxIterationsCap = 64;          // visited-table capacity per cell (params.iterations <= this)
 constexpr int kStage1Block = 256;              // windows per workgroup in the stage-1 scan
 constexpr int kStage1LdsPairs = 3072;          // pair chunks staged in LDS per stage-1 workgroup
-constexpr int kSampleTile = 256;               // samples per workgroup in the stage-2 kernels
+constexpr int kSampleTile = 256;               // threads per workgroup in the stage-2 per-sample kernels
+constexpr int kSamplesPerBlock = 256;           // samples one such workgroup walks (8 half-waves x 32 samples; 64 and 128 were measured slower)
 
 // x87 `expl` underflows to zero below ln(2^-16446); the reference's "likelihood too small" reset hangs off that.
 #define PD_X87_EXP_UNDERFLOW (-11399.498531488860558)
@@ -66,8 +67,8 @@ struct CohortView
 {
     const RgConst *  rg;
     const double *   hist;         // histogram pool
-    const double *   logHist;      // log() of every pool entry, computed once on the device
-    const double *   log10Hist;    // log10() of every pool entry
+    const double4 *  tab;          // per pool entry {value, log(value), log10(value), -}: one 32-byte line per lookup
+                                   // (logs computed once on the device with the functions the kernels would call)
     const uint32_t * sampleRg;     // [nSamples + 1]
     uint32_t         nSamples;
     uint32_t         nRg;
