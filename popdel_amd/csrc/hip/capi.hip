@@ -254,22 +254,24 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
 
     // pass 1 (parallel over read groups): chunks per window -> winStart, chunk totals -> rgBase
     rgBase.assign(seg.n_readgroups, 0);
-    winStart.assign(static_cast<size_t>(seg.n_readgroups) * (W + 1), 0);
+    const size_t wsRow = static_cast<size_t>(W) + K;           // slots 0 .. W + K - 2, plus the end entry
+    auto slotOf = [K](uint32_t a, uint32_t chunkOff) { return a == 0 ? std::min(chunkOff, K) - 1 : a + K - 1; };
+    winStart.assign(static_cast<size_t>(seg.n_readgroups) * wsRow, 0);
     std::vector<uint64_t> rgChunks(seg.n_readgroups, 0);
     pdh::parallelFor(seg.n_readgroups, [&](size_t rg) {
         const uint64_t lo = seg.rg_offsets[rg], hi = seg.rg_offsets[rg + 1];
-        uint32_t * ws = winStart.data() + rg * (W + 1);
+        uint32_t * ws = winStart.data() + rg * wsRow;
         for (uint64_t i = lo; i < hi; ++i)
         {
             uint32_t on = seg.pair_on[i], off = std::min(seg.pair_off[i], W);
             for (uint32_t a = on; a < off; a += K)
-                ++ws[a + 1];                                  // counts, shifted by one for the prefix sum
+                ++ws[slotOf(a, std::min(off, a + K)) + 1];   // counts, shifted by one for the prefix sum
         }
         uint32_t acc = 0;
-        for (uint32_t w = 0; w <= W; ++w)
+        for (size_t x = 0; x < wsRow; ++x)
         {
-            acc += ws[w];
-            ws[w] = acc;
+            acc += ws[x];
+            ws[x] = acc;
         }
         rgChunks[rg] = acc;
     }, 8);
@@ -287,8 +289,8 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
     // pass 2 (parallel): scatter the chunks to their slots, stable within a window
     pdh::parallelFor(seg.n_readgroups, [&](size_t rg) {
         const uint64_t lo = seg.rg_offsets[rg], hi = seg.rg_offsets[rg + 1];
-        const uint32_t * ws = winStart.data() + rg * (W + 1);
-        std::vector<uint32_t> cursor(ws, ws + W);
+        const uint32_t * ws = winStart.data() + rg * wsRow;
+        std::vector<uint32_t> cursor(ws, ws + wsRow - 1);
         const size_t base = rgBase[rg];
         uint32_t * ec = endCount.data() + rg * (W + 1);
         bool fits = W <= 0xffffu;
@@ -300,8 +302,8 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
             const uint32_t d16 = static_cast<uint32_t>(dv) & 0xffffu;
             for (uint32_t a = on; a < off; a += K)
             {
-                const uint32_t slot = cursor[a]++;
                 const uint32_t chunkOff = std::min(off, a + K);
+                const uint32_t slot = cursor[slotOf(a, chunkOff)]++;
                 pairs[base + slot] = pd::PairDO{dv, chunkOff};
                 start[base + slot] = seg.pair_start[i];
                 pairsPk[base + slot] = make_uint2(d16 | (d16 << 16), (chunkOff & 0xffffu) | (chunkOff << 16));

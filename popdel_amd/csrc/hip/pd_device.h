@@ -51,7 +51,10 @@ struct SegmentView
     const PairDO *   pairs;        // [nChunks]  dev + off, read-group major, ordered by `on`
     const uint32_t * start;        // [nChunks]  startPos
     const uint64_t * rgBase;       // [nRg]      first chunk of the read group
-    const uint32_t * winStart;     // [nRg * (W + 1)] first chunk (relative to rgBase) whose on >= w
+    // Chunk index by SLOT: a chunk starting in window a >= 1 has slot a + K - 1; a chunk present from window 0 on
+    // (carried over or new) has slot (its end window - 1), so carried-over pairs leave the candidate range exactly when
+    // they end. Window w sees the slots [w, w + K): chunks [winStart[w], winStart[w + K]). Row length W + K.
+    const uint32_t * winStart;     // [nRg * (W + K)] first chunk (relative to rgBase) whose slot >= x
     // stage-1 image of the chunks: deviation and end window as int16, each duplicated into both halves of a dword
     // (ready for packed 16-bit arithmetic on two windows at once); only valid for read groups with rgPacked != 0
     const uint2 *    pairsPk;      // [nChunks]

@@ -46,14 +46,13 @@ __device__ void stage1CellGeneric(const SegmentView & seg, const CohortView & co
                                   unsigned & flagsOut)
 {
     const unsigned K = seg.maxLife;
-    const unsigned wlo = (w + 1 >= K) ? (w + 1 - K) : 0u;
     unsigned total = 0, usable = 0;
     for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
     {
-        const uint32_t * ws = seg.winStart + (size_t)rg * (seg.nWindows + 1);
+        const uint32_t * ws = seg.winStart + (size_t)rg * (seg.nWindows + K);
         const PairDO * p = seg.pairs + seg.rgBase[rg];
         unsigned c = 0;
-        for (unsigned i = ws[wlo]; i < ws[w + 1]; ++i)
+        for (unsigned i = ws[w]; i < ws[w + K]; ++i)
             c += (p[i].off > w) ? 1u : 0u;
         total += c;
         if (c < co.rg[rg].maxLoad)
@@ -75,14 +74,14 @@ __device__ void stage1CellGeneric(const SegmentView & seg, const CohortView & co
     unsigned outerIdx = 0;
     for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
     {
-        const uint32_t * ws = seg.winStart + (size_t)rg * (seg.nWindows + 1);
+        const uint32_t * ws = seg.winStart + (size_t)rg * (seg.nWindows + K);
         const PairDO * p = seg.pairs + seg.rgBase[rg];
         unsigned c = 0;
-        for (unsigned i = ws[wlo]; i < ws[w + 1]; ++i)
+        for (unsigned i = ws[w]; i < ws[w + K]; ++i)
             c += (p[i].off > w) ? 1u : 0u;
         if (c >= co.rg[rg].maxLoad)
             continue;
-        for (unsigned i = ws[wlo]; i < ws[w + 1]; ++i)
+        for (unsigned i = ws[w]; i < ws[w + K]; ++i)
         {
             if (!(p[i].off > w))
                 continue;
@@ -90,14 +89,14 @@ __device__ void stage1CellGeneric(const SegmentView & seg, const CohortView & co
             unsigned rank = 0, innerIdx = 0;
             for (unsigned rg2 = co.sampleRg[s]; rg2 < co.sampleRg[s + 1]; ++rg2)
             {
-                const uint32_t * ws2 = seg.winStart + (size_t)rg2 * (seg.nWindows + 1);
+                const uint32_t * ws2 = seg.winStart + (size_t)rg2 * (seg.nWindows + K);
                 const PairDO * p2 = seg.pairs + seg.rgBase[rg2];
                 unsigned c2 = 0;
-                for (unsigned j = ws2[wlo]; j < ws2[w + 1]; ++j)
+                for (unsigned j = ws2[w]; j < ws2[w + K]; ++j)
                     c2 += (p2[j].off > w) ? 1u : 0u;
                 if (c2 >= co.rg[rg2].maxLoad)
                     continue;
-                for (unsigned j = ws2[wlo]; j < ws2[w + 1]; ++j)
+                for (unsigned j = ws2[w]; j < ws2[w + K]; ++j)
                 {
                     if (!(p2[j].off > w))
                         continue;
@@ -359,10 +358,10 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
         }
         return;
     }
-    const uint32_t * ws = seg.winStart + (size_t)rg0 * (W + 1);
-    const unsigned wlo0 = (w0 + 1 >= K) ? (w0 + 1 - K) : 0u;        // first window whose chunks matter
-    const unsigned whi = min(W, w0 + kPackedWindows);                // ws index of the range end
-    const unsigned nWs = whi - wlo0 + 1;
+    const uint32_t * ws = seg.winStart + (size_t)rg0 * (W + K);
+    const unsigned wlo0 = w0;                                        // first slot the block's windows see
+    const unsigned whi = min(W, w0 + kPackedWindows);                // one past the block's last window
+    const unsigned nWs = whi - w0 + K;                               // slots w0 .. whi + K - 1 (the last one is the end entry)
     for (unsigned i = tid; i < nWs; i += kStage1Block)
         ldsWs[i] = ws[wlo0 + i];
     // pairs that ended at or before the lane's windows (host-built prefix counts): n(w) = started - ended
@@ -404,12 +403,11 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     unsigned aA = 0, cntA = 0, endB = 0;
     if (wA < W)
     {
-        const unsigned wlo = (wA + 1 >= K) ? (wA + 1 - K) : 0u;
-        aA = ldsWs[wlo - wlo0] - A;
-        cntA = ldsWs[wA + 1 - wlo0] - A - aA;
+        aA = ldsWs[wA - wlo0] - A;
+        cntA = ldsWs[wA + K - wlo0] - A - aA;
     }
     if (wB < W)
-        endB = ldsWs[wB + 1 - wlo0] - A - aA;
+        endB = ldsWs[wB + K - wlo0] - A - aA;
     const unsigned cntU = max(cntA, endB);
     bad |= cntU > 64u;
     if (__syncthreads_or(bad))                                     // also orders the LDS writes above
@@ -430,8 +428,8 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     }
     // active pairs per window; parked in LDS because the lanes are re-dealt below
     __shared__ unsigned short ldsN[kPackedWindows];
-    ldsN[2u * tid] = (unsigned short)((wA < W) ? (ldsWs[wA + 1 - wlo0] - endedA) : 0u);
-    ldsN[2u * tid + 1u] = (unsigned short)((wB < W) ? (ldsWs[wB + 1 - wlo0] - endedB) : 0u);
+    ldsN[2u * tid] = (unsigned short)((wA < W) ? (ldsWs[wA + K - wlo0] - endedA) : 0u);
+    ldsN[2u * tid + 1u] = (unsigned short)((wB < W) ? (ldsWs[wB + K - wlo0] - endedB) : 0u);
     // Re-deal the 256 window pairs to the lanes ordered by candidate count (largest first): every wave then runs the
     // smallest network that fits ITS lanes instead of the one that fits the worst lane of an arbitrary 64.
     __shared__ unsigned short unitOrder[kStage1Block];
@@ -465,13 +463,12 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
         return;
     unsigned xA, xCntA, xEndB = 0;
     {
-        const unsigned wlo = (uA + 1 >= K) ? (uA + 1 - K) : 0u;
-        xA = ldsWs[wlo - wlo0] - A;
-        xCntA = ldsWs[uA + 1 - wlo0] - A - xA;
+        xA = ldsWs[uA - wlo0] - A;
+        xCntA = ldsWs[uA + K - wlo0] - A - xA;
     }
     if (uB < W)
     {
-        xEndB = ldsWs[uB + 1 - wlo0] - A - xA;
+        xEndB = ldsWs[uB + K - wlo0] - A - xA;
     }
     const unsigned nA = ldsN[2u * u];
     const unsigned nB = ldsN[2u * u + 1u];
@@ -523,10 +520,10 @@ __global__ __launch_bounds__(kStage1Block) void stage1FallbackKernel(SegmentView
         __syncthreads();                                           // LDS reuse across tiles
         if (singleRg && K <= 64u)
         {
-            const uint32_t * ws = seg.winStart + (size_t)rg0 * (W + 1);
-            const unsigned wlo0 = (w0 + 1 >= K) ? (w0 + 1 - K) : 0u;
+            const uint32_t * ws = seg.winStart + (size_t)rg0 * (W + K);
+            const unsigned wlo0 = w0;
             const unsigned whi = min(W, w0 + kStage1Block);
-            const unsigned nWs = whi - wlo0 + 1;
+            const unsigned nWs = whi - w0 + K;
             for (unsigned i = tid; i < nWs; i += kStage1Block)
                 ldsWs[i] = ws[wlo0 + i];
             __syncthreads();
@@ -541,9 +538,8 @@ __global__ __launch_bounds__(kStage1Block) void stage1FallbackKernel(SegmentView
                 unsigned a = 0, cnt = 0;
                 if (w < W)
                 {
-                    const unsigned wlo = (w + 1 >= K) ? (w + 1 - K) : 0u;
-                    a = ldsWs[wlo - wlo0] - A;
-                    cnt = ldsWs[w + 1 - wlo0] - A - a;
+                    a = ldsWs[w - wlo0] - A;
+                    cnt = ldsWs[w + K - wlo0] - A - a;
                 }
                 const unsigned cmax = waveMaxU32(cnt);
                 if (cmax <= 128u)

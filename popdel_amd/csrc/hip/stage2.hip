@@ -104,13 +104,12 @@ struct PairRange
 __device__ __forceinline__ PairRange pairRange(const SegmentView & seg, unsigned rg, unsigned w)
 {
     const unsigned K = seg.maxLife;
-    const unsigned wlo = (w + 1 >= K) ? (w + 1 - K) : 0u;
-    const uint32_t * ws = seg.winStart + (size_t)rg * (seg.nWindows + 1);
+    const uint32_t * ws = seg.winStart + (size_t)rg * (seg.nWindows + K);
     PairRange r;
     r.p = seg.pairs + seg.rgBase[rg];
     r.st = seg.start + seg.rgBase[rg];
-    r.begin = ws[wlo];
-    r.end = ws[w + 1];
+    r.begin = ws[w];
+    r.end = ws[w + K];
     return r;
 }
 
