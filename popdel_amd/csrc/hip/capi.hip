@@ -82,6 +82,51 @@ struct DevBuf
         if (!v.empty())
             PD_HIP(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
     }
+    template <typename P>
+    void uploadPinned(const P & v, hipStream_t st)
+    {
+        ensure(v.size());
+        if (v.size())
+            PD_HIP(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    }
+};
+
+// Page-locked host array (grow-only), so that segment staging copies run at PCIe rate.
+template <typename T>
+struct PinnedBuf
+{
+    T *    p = nullptr;
+    size_t cap = 0, n = 0;
+    PinnedBuf() {}
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf & operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf()
+    {
+        if (p)
+            (void)hipHostFree(p);
+    }
+    void resize(size_t count)
+    {
+        if (count > cap)
+        {
+            if (p)
+                (void)hipHostFree(p);
+            p = nullptr;
+            cap = count + count / 8 + 1024;
+            PD_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), cap * sizeof(T), hipHostMallocDefault));
+        }
+        n = count;
+    }
+    void assignZero(size_t count)
+    {
+        resize(count);
+        std::memset(p, 0, count * sizeof(T));
+    }
+    T * data() { return p; }
+    const T * data() const { return p; }
+    size_t size() const { return n; }
+    T & operator[](size_t i) { return p[i]; }
+    const T & operator[](size_t i) const { return p[i]; }
 };
 
 struct StagedSegment
@@ -123,6 +168,13 @@ struct pd_ctx
     int uniformThreshold = -1;      // minInitDelLen if it is the same for all read groups, else -1
 
     std::map<uint64_t, std::unique_ptr<StagedSegment>> staged;
+    std::vector<std::unique_ptr<StagedSegment>> spare;      // released segments: their HBM buffers are reused (no hipMalloc per segment)
+    // host-side scratch of pd_segment_stage(), kept between calls
+    PinnedBuf<pd::PairDO> hPairs;
+    PinnedBuf<uint32_t> hStart, hWinStart, hEndCount;
+    std::vector<uint64_t> hRgBase;
+    PinnedBuf<uint2> hPairsPk;
+    std::vector<uint8_t> hRgPacked;
     uint64_t nextHandle = 1, nextTicket = 1;
     std::map<uint64_t, Run> runs;
 
@@ -146,6 +198,7 @@ struct pd_ctx
     ~pd_ctx()
     {
         staged.clear();
+        spare.clear();
         if (stream)
             (void)hipStreamDestroy(stream);
     }
@@ -210,23 +263,35 @@ T * mallocCopy(const std::vector<T> & v)
 
 // Split every pair instance into chunks that live at most K windows, order the chunks of each read group by their
 // first window and index them by window (winStart). K is chosen so that nearly all pairs need a single chunk.
-void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, std::vector<pd::PairDO> & pairs,
-                 std::vector<uint32_t> & start, std::vector<uint64_t> & rgBase, std::vector<uint32_t> & winStart,
-                 std::vector<uint2> & pairsPk, std::vector<uint32_t> & endCount, std::vector<uint8_t> & rgPacked)
+void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, PinnedBuf<pd::PairDO> & pairs,
+                 PinnedBuf<uint32_t> & start, std::vector<uint64_t> & rgBase, PinnedBuf<uint32_t> & winStart,
+                 PinnedBuf<uint2> & pairsPk, PinnedBuf<uint32_t> & endCount, std::vector<uint8_t> & rgPacked)
 {
     const uint32_t W = seg.n_windows;
-    const uint64_t total = seg.rg_offsets[seg.n_readgroups];
     // lifetime histogram -> K
     std::vector<uint64_t> lifeHist(66, 0);
     uint64_t active = 0;
-    for (uint64_t i = 0; i < total; ++i)
     {
-        uint32_t on = seg.pair_on[i], off = std::min(seg.pair_off[i], W);
-        if (off <= on)
-            continue;
-        uint32_t life = off - on;
-        active += life;
-        ++lifeHist[std::min<uint32_t>(life, 65)];
+        // per read group in parallel, merged afterwards
+        std::vector<uint64_t> part(static_cast<size_t>(seg.n_readgroups) * 67, 0);
+        pdh::parallelFor(seg.n_readgroups, [&](size_t rg) {
+            uint64_t * h = part.data() + rg * 67;
+            for (uint64_t i = seg.rg_offsets[rg]; i < seg.rg_offsets[rg + 1]; ++i)
+            {
+                uint32_t on = seg.pair_on[i], off = std::min(seg.pair_off[i], W);
+                if (off <= on)
+                    continue;
+                uint32_t life = off - on;
+                h[66] += life;
+                ++h[std::min<uint32_t>(life, 65)];
+            }
+        }, 16);
+        for (uint32_t rg = 0; rg < seg.n_readgroups; ++rg)
+        {
+            for (int k = 0; k < 66; ++k)
+                lifeHist[k] += part[static_cast<size_t>(rg) * 67 + k];
+            active += part[static_cast<size_t>(rg) * 67 + 66];
+        }
     }
     uint64_t nInst = 0;
     for (uint64_t h : lifeHist)
@@ -256,7 +321,7 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
     rgBase.assign(seg.n_readgroups, 0);
     const size_t wsRow = static_cast<size_t>(W) + K;           // slots 0 .. W + K - 2, plus the end entry
     auto slotOf = [K](uint32_t a, uint32_t chunkOff) { return a == 0 ? std::min(chunkOff, K) - 1 : a + K - 1; };
-    winStart.assign(static_cast<size_t>(seg.n_readgroups) * wsRow, 0);
+    winStart.assignZero(static_cast<size_t>(seg.n_readgroups) * wsRow);
     std::vector<uint64_t> rgChunks(seg.n_readgroups, 0);
     pdh::parallelFor(seg.n_readgroups, [&](size_t rg) {
         const uint64_t lo = seg.rg_offsets[rg], hi = seg.rg_offsets[rg + 1];
@@ -284,7 +349,7 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
     pairs.resize(totalChunks);
     start.resize(totalChunks);
     pairsPk.resize(totalChunks);
-    endCount.assign(static_cast<size_t>(seg.n_readgroups) * (W + 1), 0);
+    endCount.assignZero(static_cast<size_t>(seg.n_readgroups) * (W + 1));
     rgPacked.assign(seg.n_readgroups, 0);
     // pass 2 (parallel): scatter the chunks to their slots, stable within a window
     pdh::parallelFor(seg.n_readgroups, [&](size_t rg) {
@@ -451,22 +516,32 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
     try
     {
         PD_HIP(hipSetDevice(c->device));
-        std::unique_ptr<StagedSegment> s(new StagedSegment());
+        std::unique_ptr<StagedSegment> s;
+        if (!c->spare.empty())
+        {
+            s = std::move(c->spare.back());
+            c->spare.pop_back();
+        }
+        else
+        {
+            s.reset(new StagedSegment());
+        }
+        s->ownedBySubmit = false;
         s->firstPos = seg->first_window_pos;
         s->nWindows = seg->n_windows;
         s->shift = seg->window_shift;
-        std::vector<pd::PairDO> pairs;
-        std::vector<uint32_t> start, winStart, endCount;
-        std::vector<uint64_t> rgBase;
-        std::vector<uint2> pairsPk;
-        std::vector<uint8_t> rgPacked;
+        PinnedBuf<pd::PairDO> & pairs = c->hPairs;
+        PinnedBuf<uint32_t> &start = c->hStart, &winStart = c->hWinStart, &endCount = c->hEndCount;
+        std::vector<uint64_t> & rgBase = c->hRgBase;
+        PinnedBuf<uint2> & pairsPk = c->hPairsPk;
+        std::vector<uint8_t> & rgPacked = c->hRgPacked;
         buildChunks(*c, *seg, *s, pairs, start, rgBase, winStart, pairsPk, endCount, rgPacked);
-        s->pairs.upload(pairs, c->stream);
-        s->start.upload(start, c->stream);
+        s->pairs.uploadPinned(pairs, c->stream);
+        s->start.uploadPinned(start, c->stream);
         s->rgBase.upload(rgBase, c->stream);
-        s->winStart.upload(winStart, c->stream);
-        s->pairsPk.upload(pairsPk, c->stream);
-        s->endCount.upload(endCount, c->stream);
+        s->winStart.uploadPinned(winStart, c->stream);
+        s->pairsPk.uploadPinned(pairsPk, c->stream);
+        s->endCount.uploadPinned(endCount, c->stream);
         s->rgPacked.upload(rgPacked, c->stream);
         PD_HIP(hipStreamSynchronize(c->stream));       // host vectors go out of scope
         *handle = c->nextHandle++;
@@ -536,7 +611,13 @@ int pd_segment_unstage(pd_ctx * c, uint64_t handle)
         return 1;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    return c->staged.erase(handle) ? 0 : fail(c, "pd_segment_unstage: unknown segment handle");
+    auto it = c->staged.find(handle);
+    if (it == c->staged.end())
+        return fail(c, "pd_segment_unstage: unknown segment handle");
+    if (c->spare.size() < 2)
+        c->spare.push_back(std::move(it->second));
+    c->staged.erase(it);
+    return 0;
 }
 
 int pd_segment_submit(pd_ctx * c, const pd_segment * seg, uint64_t * ticket)
@@ -754,7 +835,11 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
     (void)hipEventDestroy(run.s1Begin);
     (void)hipEventDestroy(run.s1End);
     if (s.ownedBySubmit)
+    {
+        if (c->spare.size() < 2)
+            c->spare.push_back(std::move(sit->second));
         c->staged.erase(sit);
+    }
     return rc;
 }
 

@@ -136,3 +136,10 @@ def test_product_binary_dense_200_golden(built, cohort_dir, tmp_path):
         cols = l.rstrip("\n").split("\t")
         out.append("\t".join(cols[:8]) + "\t" + hashlib.sha1("\t".join(cols[8:]).encode()).hexdigest() + "\n")
     assert "".join(out) == golden_text("dd200_windowwise.digest.tsv.gz")
+
+
+def test_product_binary_1000_samples_golden(built, cohort_dir, tmp_path):
+    """BASELINE.md's largest survey run of the reference (1000 samples x 1 Mb, default mode): byte-identical VCF."""
+    from popdel_amd import synth
+    d = cohort_dir("s1000", 1000, synth.single_deletion)
+    assert run_call(POPDEL_BIN, d, str(tmp_path / "a.vcf")) == golden_text("s1000_default.vcf")
