@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--passes", type=int, default=0, help="segment passes per step (default: chr20 = 323)")
     ap.add_argument("--cpu-samples", type=int, default=600, help="samples of the same segment timed on one host core")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--contexts", type=int, default=1,
+                    help="segments in flight per GPU (one context and host thread each); 1 keeps the kernel timings clean")
     args = ap.parse_args()
 
     import torch
@@ -112,23 +114,41 @@ def main():
     t_stage = time.perf_counter()
     handle = ctx.stage(seg)                   # host -> HBM, outside the timed region
     stage_seconds = time.perf_counter() - t_stage
+    # optional extra contexts: independent segments in flight on the same GPU (segments do not depend on each other)
+    extra = []
+    for _ in range(max(0, args.contexts - 1)):
+        c2 = capi.Context(hip, [rg] * S, list(range(S + 1)), device=local_rank)
+        extra.append((c2, c2.stage(seg)))
 
     total_passes = args.passes or -(-CHR20_WINDOWS // W)
     # weak scaling: the global job is world x total_passes segments, dealt round-robin -> total_passes per rank
     my_passes = len(distributed.shard_segments(total_passes * world, rank, world))
 
+    def passes_on(c, h, n, acc):
+        for _ in range(n):
+            res = c.collect(c.run(h), copy=False)
+            t = c.timing()
+            acc[0] += t["stage1_ms"]
+            acc[1] += t["stage2_ms"]
+            acc[2] += res["n_calls"]
+            acc[3] += t["n_candidate_cells"]
+            acc[4] = t
+
     def one_step():
-        s1 = s2 = 0.0
-        calls = 0
-        cand = 0
-        for _ in range(my_passes):
-            res = ctx.collect(ctx.run(handle), copy=False)
-            t = ctx.timing()
-            s1 += t["stage1_ms"]
-            s2 += t["stage2_ms"]
-            calls += res["n_calls"]
-            cand += t["n_candidate_cells"]
-        return s1, s2, calls, cand, t
+        if not extra:
+            acc = [0.0, 0.0, 0, 0, None]
+            passes_on(ctx, handle, my_passes, acc)
+            return tuple(acc)
+        import threading
+        lanes = [(ctx, handle)] + extra
+        share = [len(range(k, my_passes, len(lanes))) for k in range(len(lanes))]
+        accs = [[0.0, 0.0, 0, 0, None] for _ in lanes]
+        threads = [threading.Thread(target=passes_on, args=(c, h, n, a)) for (c, h), n, a in zip(lanes, share, accs)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        return (sum(a[0] for a in accs), sum(a[1] for a in accs), sum(a[2] for a in accs), sum(a[3] for a in accs), accs[0][4])
 
     def sync():
         torch.cuda.synchronize()
@@ -209,7 +229,7 @@ def main():
                        "planted_deletion": planted, "parallelism": "%d rank(s), each a chr20-sized set of segments (no collective in the data path)" % world},
             "stage1_ms_per_step": s1_ms / args.steps, "stage2_ms_per_step": s2_ms / args.steps,
             "calls_per_step": n_calls / args.steps, "candidate_cells_per_step": n_cand / args.steps,
-            "max_life": tinfo["max_life"],
+            "max_life": tinfo["max_life"], "contexts_per_gpu": args.contexts,
             # host arrays -> chunked layout -> HBM for one segment of all samples (single host thread + PCIe); with it
             # inside every pass the rate would be cells_per_pass / (stage_seconds + pass time): reported, never `value`
             "staging_seconds_per_segment": stage_seconds,
@@ -217,6 +237,9 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline}))
     ctx.unstage(handle)
     ctx.close()
+    for c2, h2 in extra:
+        c2.unstage(h2)
+        c2.close()
     if is_dist:
         dist.destroy_process_group()
 
