@@ -78,3 +78,16 @@ def test_files_for_coverage_and_rois(built, mixed_cohort, tmp_path):
     a = run(POPDEL_BIN, mixed_cohort, str(tmp_path / "gpu.vcf"), opts)
     b = run(ORACLE_CALL, mixed_cohort, str(tmp_path / "cpu.vcf"), opts)
     assert a == b and a.count("\n") > 25
+
+
+def test_more_than_65535_windows_per_segment(built, tmp_path):
+    """-b 3000000 makes one segment of ~73,000 windows: window numbers no longer fit the packed 16-bit image, every tile
+    takes the 32-bit fallback kernel; output must not change."""
+    from popdel_amd import synth
+    d = str(tmp_path / "long")
+    synth.write_cohort(d, 6, region=(1000000, 3200000),
+                       deletions=lambda k, r: [synth.Deletion(1500000, 900, [1, 2, 0][k % 3]), synth.Deletion(2900000, 1500, [2, 0, 1][k % 3])])
+    opts = ["-r", "chr20:1000000-3200000", "-b", "3000000", "-n"]
+    a = run(POPDEL_BIN, d, str(tmp_path / "gpu.vcf"), opts)
+    b = run(ORACLE_CALL, d, str(tmp_path / "cpu.vcf"), opts)
+    assert a == b and a.count("\n") > 60

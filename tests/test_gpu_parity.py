@@ -143,3 +143,17 @@ def test_product_binary_1000_samples_golden(built, cohort_dir, tmp_path):
     from popdel_amd import synth
     d = cohort_dir("s1000", 1000, synth.single_deletion)
     assert run_call(POPDEL_BIN, d, str(tmp_path / "a.vcf")) == golden_text("s1000_default.vcf")
+
+
+def test_wide_q3_range_takes_the_sorting_path(built):
+    """A 12-kb deletion spreads the per-sample Q3 values over more than 8192 integers: clustering by bitonic sort."""
+    from popdel_amd import synth
+    lib = synth.Library()
+    rg = synth.conditioned_readgroup(lib)
+    n = 30
+    seg = synth.cohort_segment(n, (1000000, 1100000), 1000020, 3200, lib,
+                               deletions=lambda k, r: [synth.Deletion(1040000, 12000, [1, 2, 0][k % 3])])
+    gpu, cpu = both(seg, [rg] * n, list(range(n + 1)))
+    assert cpu[1].max() - cpu[1].min() > 8192
+    assert cpu[0]["n_calls"] > 20
+    assert_same(gpu, cpu)
