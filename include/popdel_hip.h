@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 1
+#define PD_ABI_VERSION 2
 
 /* One read group after start-up conditioning.
  * Replaces: `Histogram` (reference insert_histogram_popdel.h:19-43) after processHistogram()
@@ -158,6 +158,41 @@ typedef struct pd_timing
     uint32_t max_life;           /* chunk length K in windows                                 */
 } pd_timing;
 int pd_last_timing(pd_ctx *ctx, pd_timing *out);
+
+/* ---- cohort sharded by samples over several contexts (one per GPU) -------------------------------------------------
+ * The reference has no counterpart (single process); this is how `genotype_deletion_window()` is split over GPUs:
+ * context r of `world` owns the samples [first_sample, first_sample + n_samples) of the cohort, where the partition is
+ * the one pd_shard_samples() returns (whole 256-sample tiles per context). Every context is created with ITS OWN
+ * samples/read groups only (pd_ctx_create), receives ITS OWN pairs in pd_segment, and returns the call list of the
+ * whole cohort with the per-sample columns of its own samples. What crosses samples -- the sorted Q3 values per
+ * flagged window (reference :58-87), the integer counts of :93-133, per EM iteration the sums of :388-462 / :467-485 and
+ * read group 0's triple (quirk: :411), the likelihood-ratio sums of :490-508 and the support percentiles of :514-529 --
+ * is all-gathered between kernels through `all_gather` and reduced in a fixed order, so the results are bit-identical to
+ * the unsharded run. All contexts of a cohort must call pd_segment_run / pd_segment_collect for the same segments in
+ * the same order (the calls are collective).
+ *
+ * reserve():    returns a device buffer of at least `bytes` (contents undefined; the previous buffer is dead). The host
+ *               owns it (e.g. a torch tensor), so that it can address the regions in its collective library.
+ * all_gather(): the region [offset, offset + world * bytes_per_rank) of the current buffer holds `world` chunks; chunk
+ *               `rank` is filled. On return (or stream-ordered on `hip_stream`) all chunks must be filled on every
+ *               context. Return non-zero on failure. */
+typedef struct pd_shard
+{
+    uint32_t rank, world;
+    uint32_t first_sample;                  /* cohort-wide index of this context's first sample                      */
+    uint32_t n_samples_global;
+    uint32_t n_readgroups_global;
+    const uint32_t *min_init_del_len_global; /* [n_readgroups_global], cohort order (rank-indexed lookup, quirk Q1)    */
+    void *(*reserve)(void *user, uint64_t bytes);
+    int (*all_gather)(void *user, uint64_t offset, uint64_t bytes_per_rank, void *hip_stream);
+    void *user;
+} pd_shard;
+
+/* Partition rule: samples per context (a multiple of 256; the last contexts may own fewer or none). */
+uint32_t pd_shard_samples(uint32_t n_samples_global, uint32_t world);
+
+/* Must be called before the first segment is run. */
+int pd_ctx_set_shard(pd_ctx *ctx, const pd_shard *shard);
 
 /* Wait for a ticket and hand back its calls (callee-owned; release with pd_calls_free).
  * Replaces: reading `String<Call> calls` after the window loop (reference workflow_popdel.h:48). */

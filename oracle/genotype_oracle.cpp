@@ -880,6 +880,28 @@ int pd_stage1_last(pd_ctx * c, pd_stage1_view * out)
 
 const char * pd_last_error(const pd_ctx * c) { return c ? c->error.c_str() : g_createError.c_str(); }
 
+// Same partition rule as the product library; the oracle itself always sees the whole cohort (tests compare the
+// sharded product run with it).
+uint32_t pd_shard_samples(uint32_t n_samples_global, uint32_t world)
+{
+    if (world == 0)
+        return 0;
+    const uint32_t tiles = (n_samples_global + 255u) / 256u;
+    return (tiles + world - 1) / world * 256u;
+}
+
+int pd_ctx_set_shard(pd_ctx * c, const pd_shard * sh)
+{
+    if (!c || !sh)
+        return 1;
+    if (sh->world != 1 || sh->rank != 0)
+    {
+        c->error = "pd_ctx_set_shard: the oracle runs the whole cohort in one context";
+        return 1;
+    }
+    return 0;
+}
+
 const char * pd_backend_name(void) { return "oracle-cpu-longdouble"; }
 
 int pd_abi_version(void) { return PD_ABI_VERSION; }

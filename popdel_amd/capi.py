@@ -18,7 +18,7 @@ HIP_LIBRARY = os.path.join(_HERE, "lib", "libpopdel_hip.so")
 ABI_SYMBOLS = (
     "pd_ctx_create", "pd_ctx_destroy", "pd_segment_submit", "pd_segment_stage", "pd_segment_run", "pd_segment_unstage",
     "pd_segment_collect", "pd_calls_free", "pd_stage1_last", "pd_last_timing", "pd_last_error", "pd_backend_name",
-    "pd_abi_version",
+    "pd_abi_version", "pd_shard_samples", "pd_ctx_set_shard",
 )
 
 
@@ -61,6 +61,17 @@ class PdTiming(C.Structure):
                 ("max_life", C.c_uint32)]
 
 
+RESERVE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p)
+
+
+class PdShard(C.Structure):
+    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("first_sample", C.c_uint32),
+                ("n_samples_global", C.c_uint32), ("n_readgroups_global", C.c_uint32),
+                ("min_init_del_len_global", C.POINTER(C.c_uint32)), ("reserve", RESERVE_FN),
+                ("all_gather", ALL_GATHER_FN), ("user", C.c_void_p)]
+
+
 def load_library(path):
     if not os.path.exists(path):
         raise FileNotFoundError(path)
@@ -89,6 +100,10 @@ def load_library(path):
     lib.pd_last_error.restype = C.c_char_p
     lib.pd_backend_name.restype = C.c_char_p
     lib.pd_abi_version.restype = C.c_int
+    lib.pd_shard_samples.argtypes = [C.c_uint32, C.c_uint32]
+    lib.pd_shard_samples.restype = C.c_uint32
+    lib.pd_ctx_set_shard.argtypes = [C.c_void_p, C.POINTER(PdShard)]
+    lib.pd_ctx_set_shard.restype = C.c_int
     return lib
 
 
@@ -201,6 +216,21 @@ class Context:
     def _check(self, rc):
         if rc != 0:
             raise BackendError(self.lib.pd_last_error(self.handle).decode())
+
+    def set_shard(self, rank, world, first_sample, n_samples_global, min_init_del_len_global, reserve, all_gather):
+        """Declare this context one shard of a cohort split by samples (pd_ctx_set_shard). ``reserve(bytes) -> device
+        pointer`` and ``all_gather(offset, bytes_per_rank, hip_stream) -> 0`` are Python callables (see
+        popdel_amd.distributed.SampleShardExchange)."""
+        table = np.ascontiguousarray(min_init_del_len_global, dtype=np.uint32)
+        sh = PdShard()
+        sh.rank, sh.world, sh.first_sample = rank, world, first_sample
+        sh.n_samples_global, sh.n_readgroups_global = n_samples_global, len(table)
+        sh.min_init_del_len_global = table.ctypes.data_as(C.POINTER(C.c_uint32))
+        self._shard_fns = (RESERVE_FN(lambda user, nbytes: reserve(nbytes)),
+                           ALL_GATHER_FN(lambda user, off, per, stream: all_gather(off, per, stream)))
+        sh.reserve, sh.all_gather = self._shard_fns
+        sh.user = None
+        self._check(self.lib.pd_ctx_set_shard(self.handle, C.byref(sh)))
 
     def submit(self, seg: Segment):
         t = C.c_uint64()

@@ -19,11 +19,14 @@ void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, 
                   hipStream_t stream);
 void launchStage1Fallback(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
                           const uint8_t * tileTodo, hipStream_t stream);
-void launchCluster(const int32_t * q3, const uint8_t * flags, const int * flaggedWindows, unsigned nFlagged, unsigned W,
-                   const CohortView & co, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,
+void launchPackFlagged(const int32_t * q3, const uint8_t * flags, const int * flaggedWindows, unsigned W, unsigned nLocal,
+                       const ClusterInput & in, unsigned rank, hipStream_t st);
+void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,
                    hipStream_t st);
-void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st);
-void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st);
+void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
+                   hipStream_t st);
+void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
+                   hipStream_t st);
 void buildLogTables(const double * hist, double4 * tab, size_t n, RgConst * rg, unsigned nRg, hipStream_t st);
 void launchGatherOut(const Stage2Buffers & b, const unsigned * emitCells, unsigned nEmit, unsigned nSamples, uint32_t * pl,
                      uint32_t * lad, uint32_t * dad, uint32_t * fl, hipStream_t st);
@@ -165,7 +168,13 @@ struct pd_ctx
     DevBuf<unsigned> dIterFlags;
     DevBuf<uint32_t> dSampleRg;
     pd::CohortView cohort;
-    int uniformThreshold = -1;      // minInitDelLen if it is the same for all read groups, else -1
+    int uniformThreshold = -1;      // minInitDelLen if it is the same for all read groups of the cohort, else -1
+    // The cohort may be sharded by samples over several contexts (pd_ctx_set_shard); defaults describe "all samples here".
+    uint32_t rank = 0, world = 1, nSamplesGlobal = 0, samplesPerRank = 0;
+    pd_shard shard;
+    DevBuf<unsigned> dMinInitGlobal;
+    DevBuf<uint8_t> ownArena;       // exchange areas when world == 1 (otherwise the host owns the buffer)
+    uint8_t * arena = nullptr;
 
     std::map<uint64_t, std::unique_ptr<StagedSegment>> staged;
     std::vector<std::unique_ptr<StagedSegment>> spare;      // released segments: their HBM buffers are reused (no hipMalloc per segment)
@@ -189,9 +198,9 @@ struct pd_ctx
     // stage-2 scratch
     DevBuf<int> dFlagged, dClusterScratch, dCandLen, dCandCount;
     DevBuf<pd::CellState> dCells;
-    DevBuf<double> dDl, dPartial;
+    DevBuf<double> dDl;
     DevBuf<int> dShifts;
-    DevBuf<unsigned> dCounters, dSuppFirst, dSuppLast, dEmit;
+    DevBuf<unsigned> dSuppFirst, dSuppLast, dEmit;
     DevBuf<uint32_t> dPl, dLad, dDad, dFl, dOutPl;
     pd_timing timing;
 
@@ -251,6 +260,40 @@ struct CallsBox
     pd_calls pub;
     PinnedBlock pinned;
 };
+
+// The exchange buffer: owned by the library for an unsharded cohort, by the host otherwise.
+uint8_t * reserveArena(pd_ctx & c, size_t bytes)
+{
+    if (c.world == 1)
+    {
+        c.ownArena.ensure(bytes);
+        c.arena = c.ownArena.p;
+    }
+    else
+    {
+        PD_HIP(hipStreamSynchronize(c.stream));            // nothing in flight may still use the previous buffer
+        c.arena = static_cast<uint8_t *>(c.shard.reserve(c.shard.user, bytes));
+        if (!c.arena)
+            throw HipError{"the host's reserve() callback returned no buffer"};
+    }
+    return c.arena;
+}
+
+struct CtxExchange : pd::Exchange
+{
+    pd_ctx & c;
+    explicit CtxExchange(pd_ctx & ctx) : c(ctx) {}
+    void allGather(void * area, size_t bytesPerRank) override
+    {
+        if (c.world == 1)
+            return;
+        const uint64_t off = static_cast<uint64_t>(static_cast<uint8_t *>(area) - c.arena);
+        if (c.shard.all_gather(c.shard.user, off, bytesPerRank, c.stream) != 0)
+            throw HipError{"the host's all_gather() callback failed"};
+    }
+};
+
+inline size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 template <typename T>
 T * mallocCopy(const std::vector<T> & v)
@@ -481,12 +524,77 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
             if (rgs[i].min_init_del_len != rgs[0].min_init_del_len)
                 c->uniformThreshold = -1;
         std::memset(&c->timing, 0, sizeof(c->timing));
+        std::memset(&c->shard, 0, sizeof(c->shard));
+        c->nSamplesGlobal = n_samples;
+        c->samplesPerRank = pd_shard_samples(n_samples, 1);
+        std::vector<unsigned> minInit(n_readgroups);
+        for (uint32_t i = 0; i < n_readgroups; ++i)
+            minInit[i] = rgs[i].min_init_del_len;
+        c->dMinInitGlobal.upload(minInit, c->stream);
+        PD_HIP(hipStreamSynchronize(c->stream));
     }
     catch (const HipError & e)
     {
         return fail(nullptr, "pd_ctx_create: " + e.what);
     }
     *out = c.release();
+    return 0;
+}
+
+uint32_t pd_shard_samples(uint32_t n_samples_global, uint32_t world)
+{
+    if (world == 0)
+        return 0;
+    const uint32_t tiles = (n_samples_global + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock;
+    return (tiles + world - 1) / world * pd::kSamplesPerBlock;
+}
+
+int pd_ctx_set_shard(pd_ctx * c, const pd_shard * sh)
+{
+    if (!c || !sh)
+        return fail(c, "pd_ctx_set_shard: invalid argument");
+    if (!c->runs.empty() || !c->staged.empty())
+        return fail(c, "pd_ctx_set_shard: must be called before segments are staged");
+    if (sh->world == 0 || sh->rank >= sh->world || !sh->min_init_del_len_global)
+        return fail(c, "pd_ctx_set_shard: invalid rank/world or missing threshold table");
+    if (sh->world > 1 && (!sh->reserve || !sh->all_gather))
+        return fail(c, "pd_ctx_set_shard: a sharded cohort needs the reserve() and all_gather() callbacks");
+    const uint32_t per = pd_shard_samples(sh->n_samples_global, sh->world);
+    const uint64_t first = static_cast<uint64_t>(sh->rank) * per;
+    if (first >= sh->n_samples_global)
+        return fail(c, "pd_ctx_set_shard: this rank owns no samples (cohort too small for that many contexts)");
+    const uint32_t own = static_cast<uint32_t>(std::min<uint64_t>(per, sh->n_samples_global - first));
+    if (sh->first_sample != first || c->nSamples != own)
+        return fail(c, "pd_ctx_set_shard: the context's samples are not this rank's part of the pd_shard_samples() partition");
+    if (sh->n_readgroups_global < sh->n_samples_global)
+        return fail(c, "pd_ctx_set_shard: fewer read groups than samples");
+    try
+    {
+        PD_HIP(hipSetDevice(c->device));
+        c->shard = *sh;
+        c->rank = sh->rank;
+        c->world = sh->world;
+        c->nSamplesGlobal = sh->n_samples_global;
+        c->samplesPerRank = per;
+        std::vector<unsigned> minInit(sh->min_init_del_len_global, sh->min_init_del_len_global + sh->n_readgroups_global);
+        c->dMinInitGlobal.upload(minInit, c->stream);
+        PD_HIP(hipStreamSynchronize(c->stream));
+        c->shard.min_init_del_len_global = nullptr;        // copied; the caller's table need not outlive this call
+        // thresholds are looked up across the whole cohort
+        unsigned mn = minInit[0];
+        c->uniformThreshold = static_cast<int>(minInit[0]);
+        for (unsigned v : minInit)
+        {
+            mn = std::min(mn, v);
+            if (v != minInit[0])
+                c->uniformThreshold = -1;
+        }
+        c->cohort.minThreshold = static_cast<int>(mn);
+    }
+    catch (const HipError & e)
+    {
+        return fail(c, "pd_ctx_set_shard: " + e.what);
+    }
     return 0;
 }
 
@@ -658,28 +766,55 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         PD_HIP(hipEventCreate(&s2Begin));
         PD_HIP(hipEventCreate(&s2End));
 
-        // windows with at least one Q3 above the smallest threshold
-        std::vector<int> winFlag(W);
-        PD_HIP(hipMemcpyAsync(winFlag.data(), c->dWinFlag.p, W * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        CtxExchange xch(*c);
+        const uint32_t world = c->world, sper = c->samplesPerRank, SG = c->nSamplesGlobal;
+        // windows in which some sample of the cohort has a Q3 above the smallest threshold
+        std::vector<int> winFlag(static_cast<size_t>(W) * world);
+        if (world == 1)
+        {
+            PD_HIP(hipMemcpyAsync(winFlag.data(), c->dWinFlag.p, W * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        }
+        else
+        {
+            uint8_t * area = reserveArena(*c, static_cast<size_t>(W) * world * sizeof(int));
+            PD_HIP(hipMemcpyAsync(area + static_cast<size_t>(c->rank) * W * sizeof(int), c->dWinFlag.p, W * sizeof(int),
+                                  hipMemcpyDeviceToDevice, c->stream));
+            xch.allGather(area, W * sizeof(int));
+            PD_HIP(hipMemcpyAsync(winFlag.data(), area, winFlag.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        }
         PD_HIP(hipStreamSynchronize(c->stream));
         std::vector<int> flagged;
         for (uint32_t w = 0; w < W; ++w)
-            if (winFlag[w])
+        {
+            int any = 0;
+            for (uint32_t r = 0; r < world; ++r)
+                any |= winFlag[static_cast<size_t>(r) * W + w];
+            if (any)
                 flagged.push_back((int)w);
+        }
 
         PD_HIP(hipEventRecord(s2Begin, c->stream));
         std::vector<pd::CellState> cells;
         if (!flagged.empty())
         {
             unsigned rowLen = 1;
-            while (rowLen < S)
+            while (rowLen < SG)
                 rowLen <<= 1;
             c->dFlagged.upload(flagged, c->stream);
             c->dClusterScratch.ensure(static_cast<size_t>(flagged.size()) * rowLen);
             c->dCandLen.ensure(flagged.size() * pd::kMaxCandidatesPerWindow);
             c->dCandCount.ensure(flagged.size());
-            pd::launchCluster(c->dQ3.p, c->dFlags.p, c->dFlagged.p, (unsigned)flagged.size(), W, c->cohort,
-                              c->uniformThreshold, c->dClusterScratch.p, rowLen, c->dCandLen.p, c->dCandCount.p, c->stream);
+            pd::ClusterInput in;
+            in.chunkBytes = alignUp(flagged.size() * static_cast<size_t>(sper) * 5, 256);
+            in.base = reserveArena(*c, in.chunkBytes * world);
+            in.sper = sper;
+            in.world = world;
+            in.nFlagged = (unsigned)flagged.size();
+            in.minInit = c->dMinInitGlobal.p;
+            pd::launchPackFlagged(c->dQ3.p, c->dFlags.p, c->dFlagged.p, W, S, in, c->rank, c->stream);
+            PD_HIP(hipGetLastError());
+            xch.allGather(c->arena, in.chunkBytes);
+            pd::launchCluster(in, c->uniformThreshold, c->dClusterScratch.p, rowLen, c->dCandLen.p, c->dCandCount.p, c->stream);
             PD_HIP(hipGetLastError());
             std::vector<int> candLen(flagged.size() * pd::kMaxCandidatesPerWindow), candCount(flagged.size());
             PD_HIP(hipMemcpyAsync(candLen.data(), c->dCandLen.p, candLen.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -707,24 +842,32 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         if (nCells != 0)
         {
             b.nCells = nCells;
-            b.nTiles = (S + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock;
+            b.nTiles = (SG + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock;
+            b.tilesPerRank = sper / pd::kSamplesPerBlock;
+            b.rank = c->rank;
+            b.world = world;
+            b.nSamplesGlobal = SG;
+            // exchange areas: integer counts | per-tile sums + RG-0 record | digit histograms
+            b.xchChunk = (static_cast<size_t>(b.tilesPerRank) + 1) * nCells * 4;
+            const size_t countersBytes = alignUp(static_cast<size_t>(world) * nCells * 4 * sizeof(unsigned), 256);
+            const size_t xchBytes = alignUp(static_cast<size_t>(world) * b.xchChunk * sizeof(double), 256);
+            const size_t histBytes = static_cast<size_t>(world) * nCells * 2 * 256 * sizeof(unsigned);
+            uint8_t * area = reserveArena(*c, countersBytes + xchBytes + histBytes);
+            PD_HIP(hipMemsetAsync(area, 0, countersBytes + xchBytes, c->stream));
+            b.counters = reinterpret_cast<unsigned *>(area);
+            b.xch = reinterpret_cast<double *>(area + countersBytes);
+            b.selHist = reinterpret_cast<unsigned *>(area + countersBytes + xchBytes);
             c->dCells.upload(cells, c->stream);
             c->dDl.ensure(static_cast<size_t>(nCells) * S * 3);
             c->dShifts.ensure(static_cast<size_t>(nCells) * c->nRg);
-            c->dPartial.ensure(static_cast<size_t>(nCells) * b.nTiles * 4);
-            c->dCounters.ensure(static_cast<size_t>(nCells) * 4);
             c->dPl.ensure(static_cast<size_t>(nCells) * S * 3);
             c->dLad.ensure(static_cast<size_t>(nCells) * S * 3);
             c->dDad.ensure(static_cast<size_t>(nCells) * S * 5);
             c->dFl.ensure(static_cast<size_t>(nCells) * S * 2);
             PD_HIP(hipMemsetAsync(c->dShifts.p, 0, static_cast<size_t>(nCells) * c->nRg * sizeof(int), c->stream));
-            PD_HIP(hipMemsetAsync(c->dCounters.p, 0, static_cast<size_t>(nCells) * 4 * sizeof(unsigned), c->stream));
-            PD_HIP(hipMemsetAsync(c->dPartial.p, 0, static_cast<size_t>(nCells) * b.nTiles * 4 * sizeof(double), c->stream));
             b.cells = c->dCells.p;
             b.dl = c->dDl.p;
             b.shifts = c->dShifts.p;
-            b.partial = c->dPartial.p;
-            b.counters = c->dCounters.p;
             b.iterFlags = c->dIterFlags.p;
             b.pl = c->dPl.p;
             b.lad = c->dLad.p;
@@ -737,10 +880,11 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             b.somatic = c->cfg.somatic;
             b.windowWise = c->cfg.window_wise_output;
             // Phase A gives, per cell, the number of usable active pairs = capacity of its support pool.
-            pd::runStage2Init(view, c->cohort, b, c->dFlags.p, c->stream);
+            pd::runStage2Init(view, c->cohort, b, c->dFlags.p, xch, c->stream);
             PD_HIP(hipGetLastError());
-            std::vector<unsigned> counters(static_cast<size_t>(nCells) * 4);
-            PD_HIP(hipMemcpyAsync(counters.data(), c->dCounters.p, counters.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            std::vector<unsigned> counters(static_cast<size_t>(nCells) * 4);       // of this context's own samples
+            PD_HIP(hipMemcpyAsync(counters.data(), b.counters + static_cast<size_t>(c->rank) * nCells * 4,
+                                  counters.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
             PD_HIP(hipStreamSynchronize(c->stream));
             uint64_t pool = 0;
             for (unsigned i = 0; i < nCells; ++i)
@@ -749,7 +893,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             c->dSuppLast.ensure(pool + 1);
             b.suppFirst = c->dSuppFirst.p;
             b.suppLast = c->dSuppLast.p;
-            pd::runStage2Main(view, c->cohort, b, c->dFlags.p, c->stream);
+            pd::runStage2Main(view, c->cohort, b, c->dFlags.p, xch, c->stream);
             PD_HIP(hipGetLastError());
             PD_HIP(hipMemcpyAsync(cells.data(), c->dCells.p, cells.size() * sizeof(pd::CellState), hipMemcpyDeviceToHost, c->stream));
             PD_HIP(hipStreamSynchronize(c->stream));
@@ -814,8 +958,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         for (uint32_t i = 0; i < n; ++i)
         {
             // sample-number filter (reference utils_popdel.h:707-718, genotype_deletion_popdel_call.h:723-724)
-            const unsigned dataSamples = S - cells[emit[i]].lowCovSamples;
-            f[i] = (static_cast<double>(dataSamples) / S >= c->cfg.min_sample_fraction) ? 0 : 4;
+            const unsigned dataSamples = SG - cells[emit[i]].lowCovSamples;
+            f[i] = (static_cast<double>(dataSamples) / SG >= c->cfg.min_sample_fraction) ? 0 : 4;
         }
         pc->filter = mallocCopy(f);
         pc->pl = hPl;

@@ -78,6 +78,32 @@ struct CohortView
     int              minThreshold; // min over read groups of minInitDelLen
 };
 
+// Input of the clustering kernel: Q3 values and flags of the flagged windows of ALL samples of the cohort, one chunk
+// per context (all-gathered when the cohort is sharded): int32 q3[nFlagged][sper], then uint8 flags[nFlagged][sper].
+struct ClusterInput
+{
+    const uint8_t *  base;
+    size_t           chunkBytes;
+    unsigned         sper;         // samples per context, padded to whole tiles (padding carries "no value")
+    unsigned         world;
+    unsigned         nFlagged;
+    const unsigned * minInit;      // [read groups of the cohort] minInitDelLen, looked up BY SORTED RANK (quirk Q1)
+};
+
+// Called by the launch sequences wherever samples of other contexts are needed: all-gathers `bytesPerRank` bytes per
+// context inside the area starting at `area` (layout [world][bytesPerRank]); stream-ordered. No-op for world == 1.
+struct Exchange
+{
+    virtual void allGather(void * area, size_t bytesPerRank) = 0;
+    virtual ~Exchange() {}
+};
+
+// Where the per-tile sums of (cell c, cohort-wide tile t) live, and the record of read group 0's triple
+// ({d0, d1, d2, kind}; kind 1 = high coverage) that rank `r` published for cell c.
+struct Stage2Buffers;
+__device__ __forceinline__ double * tileSlot(const Stage2Buffers & b, unsigned c, unsigned t);
+__device__ __forceinline__ double * rg0Slot(const Stage2Buffers & b, unsigned c, unsigned r);
+
 // ---- stage 2 per-cell state -------------------------------------------------------------------------------------
 enum CellPhase : int
 {
@@ -109,9 +135,9 @@ struct CellState
     uint64_t suppBase;
     unsigned suppStart, suppEnd;
     unsigned lowCovSamples;
-    // RG 0's per-read-group triple (log domain); kind: 0 = normal, 1 = high coverage (all zero in the reference)
-    double   rg0[3];
-    int      rg0Kind;
+    // distributed percentile selection over the support pools (0: starts, 1: ends): radix prefix and remaining rank
+    unsigned selPrefix[2];
+    unsigned selK[2];
 };
 
 // Device buffers and parameters of the stage-2 kernels.
@@ -121,9 +147,18 @@ struct Stage2Buffers
     unsigned    nCells;
     double *    dl;          // [nCells][S][3]  log-domain data likelihood triples
     int *       shifts;      // [nCells][nRg]   reference shifts
-    double *    partial;     // [nCells][nTiles][4] per-tile reduction slots
-    unsigned *  counters;    // [nCells][4] integer accumulators (a5 count, a5 total, low coverage samples, unused)
-    unsigned    nTiles;
+    // Exchange areas. The cohort may be sharded by samples over `world` contexts (one per GPU); every context owns
+    // `tilesPerRank` consecutive 256-sample tiles. Whatever crosses samples is written into the context's own chunk of
+    // an area laid out [world][chunk] and all-gathered by the host between kernels; per-cell kernels then add the
+    // chunks in rank/tile order, so results do not depend on the number of shards (world == 1: no exchange at all).
+    double *    xch;         // [world][xchChunk]: [tilesPerRank][nCells][4] per-tile sums, then [nCells][4] RG-0 record
+    size_t      xchChunk;    // doubles per chunk
+    unsigned *  counters;    // [world][nCells][4] integer accumulators (a5 count, a5 total, low coverage samples, unused)
+    unsigned *  selHist;     // [world][nCells][2][256] digit histograms of the support pools
+    unsigned    nTiles;      // tiles of the whole cohort
+    unsigned    tilesPerRank;
+    unsigned    rank, world;
+    unsigned    nSamplesGlobal;
     // final-pass outputs, [nCells][S][k]
     uint32_t *  pl;
     uint32_t *  lad;
@@ -140,6 +175,16 @@ struct Stage2Buffers
     int         somatic;
     int         windowWise;
 };
+
+__device__ __forceinline__ double * tileSlot(const Stage2Buffers & b, unsigned c, unsigned t)
+{
+    const unsigned r = t / b.tilesPerRank, lt = t - r * b.tilesPerRank;
+    return b.xch + (size_t)r * b.xchChunk + ((size_t)lt * b.nCells + c) * 4;
+}
+__device__ __forceinline__ double * rg0Slot(const Stage2Buffers & b, unsigned c, unsigned r)
+{
+    return b.xch + (size_t)r * b.xchChunk + ((size_t)b.tilesPerRank * b.nCells + c) * 4;
+}
 
 }  // namespace pd
 #endif

@@ -23,6 +23,9 @@ namespace pd {
 #define PD_CELL_IDX blockIdx.y
 #define PD_TILE_IDX blockIdx.x
 
+// per-tile sums of this context's own tile PD_TILE_IDX
+#define PD_OWN_TILE_SLOT(b, c) tileSlot(b, c, (b).rank * (b).tilesPerRank + PD_TILE_IDX)
+
 #define PD_LN2 0.69314718055994530942
 #define PD_LOG10_2 0.30102999566398119521
 
@@ -315,30 +318,64 @@ __device__ __forceinline__ void emitCluster(int sum, int n, unsigned threshold, 
     ++nc;
 }
 
-__device__ __forceinline__ unsigned thresholdOfRanks(const CohortView & co, int uniformThreshold, unsigned i0, unsigned i1)
+__device__ __forceinline__ unsigned thresholdOfRanks(const ClusterInput & in, int uniformThreshold, unsigned i0, unsigned i1)
 {
     if (uniformThreshold >= 0)
         return (unsigned)uniformThreshold;
-    unsigned t = co.rg[i0].minInitDelLen;
+    unsigned t = in.minInit[i0];
     for (unsigned i = i0 + 1; i <= i1; ++i)
-        t = min(t, co.rg[i].minInitDelLen);
+        t = min(t, in.minInit[i]);
     return t;
 }
 
 constexpr int kClusterBins = 8192;
 
+// Copies the Q3 values and flags of the flagged windows out of the [sample][window] stage-1 arrays into this context's
+// chunk of the clustering input (window-major, samples padded to `sper` with "no value").
+__global__ __launch_bounds__(256) void packFlaggedKernel(const int32_t * __restrict__ q3, const uint8_t * __restrict__ flags,
+                                                         const int * __restrict__ flaggedWindows, unsigned W, unsigned nLocal,
+                                                         ClusterInput in, unsigned rank)
+{
+    const unsigned l = blockIdx.x * blockDim.x + threadIdx.x, fw = blockIdx.y;
+    if (l >= in.sper)
+        return;
+    int v = 0;
+    uint8_t f = 0;
+    if (l < nLocal)
+    {
+        const size_t cell = (size_t)l * W + (unsigned)flaggedWindows[fw];
+        v = q3[cell];
+        f = flags[cell];
+    }
+    uint8_t * chunk = const_cast<uint8_t *>(in.base) + (size_t)rank * in.chunkBytes;
+    reinterpret_cast<int32_t *>(chunk)[(size_t)fw * in.sper + l] = v;
+    chunk[(size_t)in.nFlagged * in.sper * 4 + (size_t)fw * in.sper + l] = f;
+}
+
+// Calls f(q3) for every sample of the cohort with a valid Q3 in flagged window fw (block-strided).
+template <class F>
+__device__ __forceinline__ void forEachValidQ3(const ClusterInput & in, unsigned fw, F f)
+{
+    for (unsigned r = 0; r < in.world; ++r)
+    {
+        const uint8_t * chunk = in.base + (size_t)r * in.chunkBytes;
+        const int32_t * q = reinterpret_cast<const int32_t *>(chunk) + (size_t)fw * in.sper;
+        const uint8_t * fl = chunk + (size_t)in.nFlagged * in.sper * 4 + (size_t)fw * in.sper;
+        for (unsigned l = threadIdx.x; l < in.sper; l += blockDim.x)
+            if (fl[l] & 2u)
+                f(q[l]);
+    }
+}
+
 // Fast path: the Q3 values of a window span fewer than kClusterBins integers -> counting sort in LDS, clusters are read
 // off the occupied bins in ascending order. Otherwise: bitonic sort of the values in a global scratch row.
-__global__ __launch_bounds__(256) void clusterKernel(const int32_t * __restrict__ q3, const uint8_t * __restrict__ flags,
-                                                     const int * __restrict__ flaggedWindows, unsigned W, CohortView co,
-                                                     int uniformThreshold, int * __restrict__ scratch, unsigned rowLen,
-                                                     int * __restrict__ candLen, int * __restrict__ candCount)
+__global__ __launch_bounds__(256) void clusterKernel(ClusterInput in, int uniformThreshold, int * __restrict__ scratch,
+                                                     unsigned rowLen, int * __restrict__ candLen, int * __restrict__ candCount)
 {
     __shared__ int hist[kClusterBins];
     __shared__ unsigned nValid;
     __shared__ int vMin, vMax;
     const unsigned fw = blockIdx.x;
-    const unsigned w = (unsigned)flaggedWindows[fw];
     if (threadIdx.x == 0)
     {
         nValid = 0;
@@ -349,17 +386,11 @@ __global__ __launch_bounds__(256) void clusterKernel(const int32_t * __restrict_
     {
         int lmin = 0x7fffffff, lmax = (int)0x80000000;
         unsigned cnt = 0;
-        for (unsigned s = threadIdx.x; s < co.nSamples; s += blockDim.x)
-        {
-            const size_t cell = (size_t)s * W + w;
-            if (flags[cell] & 2u)
-            {
-                const int v = q3[cell];
-                lmin = min(lmin, v);
-                lmax = max(lmax, v);
-                ++cnt;
-            }
-        }
+        forEachValidQ3(in, fw, [&](int v) {
+            lmin = min(lmin, v);
+            lmax = max(lmax, v);
+            ++cnt;
+        });
         if (cnt)
         {
             atomicMin(&vMin, lmin);
@@ -382,12 +413,7 @@ __global__ __launch_bounds__(256) void clusterKernel(const int32_t * __restrict_
         for (int i = threadIdx.x; i < (int)range; i += blockDim.x)
             hist[i] = 0;
         __syncthreads();
-        for (unsigned s = threadIdx.x; s < co.nSamples; s += blockDim.x)
-        {
-            const size_t cell = (size_t)s * W + w;
-            if (flags[cell] & 2u)
-                atomicAdd(&hist[q3[cell] - base], 1);
-        }
+        forEachValidQ3(in, fw, [&](int v) { atomicAdd(&hist[v - base], 1); });
         __syncthreads();
         if (threadIdx.x == 0)
         {
@@ -402,7 +428,7 @@ __global__ __launch_bounds__(256) void clusterKernel(const int32_t * __restrict_
                 const int v = base + bin;
                 if (n != 0 && !(prev + 50 > v))
                 {
-                    emitCluster(sum, n, thresholdOfRanks(co, uniformThreshold, i0, rank - 1), candLen, fw, nc);
+                    emitCluster(sum, n, thresholdOfRanks(in, uniformThreshold, i0, rank - 1), candLen, fw, nc);
                     sum = 0;
                     n = 0;
                     i0 = rank;
@@ -412,7 +438,7 @@ __global__ __launch_bounds__(256) void clusterKernel(const int32_t * __restrict_
                 rank += (unsigned)c;
                 prev = v;
             }
-            emitCluster(sum, n, thresholdOfRanks(co, uniformThreshold, i0, rank - 1), candLen, fw, nc);
+            emitCluster(sum, n, thresholdOfRanks(in, uniformThreshold, i0, rank - 1), candLen, fw, nc);
             candCount[fw] = nc;
         }
         return;
@@ -422,15 +448,7 @@ __global__ __launch_bounds__(256) void clusterKernel(const int32_t * __restrict_
     if (threadIdx.x == 0)
         nValid = 0;
     __syncthreads();
-    for (unsigned s = threadIdx.x; s < co.nSamples; s += blockDim.x)
-    {
-        const size_t cell = (size_t)s * W + w;
-        if (flags[cell] & 2u)
-        {
-            unsigned slot = atomicAdd(&nValid, 1u);
-            row[slot] = q3[cell];
-        }
-    }
+    forEachValidQ3(in, fw, [&](int v) { row[atomicAdd(&nValid, 1u)] = v; });
     __syncthreads();
     unsigned P = 1;
     while (P < m)
@@ -474,13 +492,13 @@ __global__ __launch_bounds__(256) void clusterKernel(const int32_t * __restrict_
             }
             else
             {
-                emitCluster(sum, n, thresholdOfRanks(co, uniformThreshold, i0, i - 1), candLen, fw, nc);
+                emitCluster(sum, n, thresholdOfRanks(in, uniformThreshold, i0, i - 1), candLen, fw, nc);
                 sum = row[i];
                 n = 1;
                 i0 = i;
             }
         }
-        emitCluster(sum, n, thresholdOfRanks(co, uniformThreshold, i0, m - 1), candLen, fw, nc);
+        emitCluster(sum, n, thresholdOfRanks(in, uniformThreshold, i0, m - 1), candLen, fw, nc);
         candCount[fw] = nc;
     }
 }
@@ -546,7 +564,7 @@ __global__ __launch_bounds__(kSampleTile) void cellInitKernel(SegmentView seg, C
     }
     __syncthreads();
     if (threadIdx.x < 3 && acc[threadIdx.x])
-        atomicAdd(&b.counters[cellIdx * 4 + threadIdx.x], acc[threadIdx.x]);
+        atomicAdd(&b.counters[((size_t)b.rank * b.nCells + cellIdx) * 4 + threadIdx.x], acc[threadIdx.x]);
 }
 
 __global__ void cellInitFinishKernel(Stage2Buffers b)
@@ -555,9 +573,16 @@ __global__ void cellInitFinishKernel(Stage2Buffers b)
     if (c >= b.nCells)
         return;
     CellState & cs = b.cells[c];
-    const unsigned count = b.counters[c * 4 + 0], total = b.counters[c * 4 + 1];
-    cs.lowCovSamples = b.counters[c * 4 + 2];
-    cs.suppCapacity = total;
+    unsigned count = 0, total = 0, low = 0;
+    for (unsigned r = 0; r < b.world; ++r)
+    {
+        const unsigned * k = b.counters + ((size_t)r * b.nCells + c) * 4;
+        count += k[0];
+        total += k[1];
+        low += k[2];
+    }
+    cs.lowCovSamples = low;
+    cs.suppCapacity = b.counters[((size_t)b.rank * b.nCells + c) * 4 + 1];     // pool of this context's own samples
     cs.suppCount = 0;
     double freq = (total == 0u) ? 0.0 : (double)count / total;
     cs.freq = freq;
@@ -565,8 +590,6 @@ __global__ void cellInitFinishKernel(Stage2Buffers b)
     cs.iterations = 0;
     cs.nVisited = 0;
     cs.restoreZeroShifts = 0;
-    cs.rg0Kind = 0;
-    cs.rg0[0] = cs.rg0[1] = cs.rg0[2] = 0;
     if (freq == 0)
     {
         cs.phase = kCellDead;
@@ -681,10 +704,11 @@ __global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, Co
             });
             if (n >= rc.maxLoad)
             {
-                if (rg == 0 && hl == 0)
+                if (rg == 0 && b.rank == 0 && hl == 0)
                 {
-                    cs.rg0Kind = 1;
-                    cs.rg0[0] = cs.rg0[1] = cs.rg0[2] = 0;
+                    double * r0 = rg0Slot(b, cellIdx, 0);
+                    r0[0] = r0[1] = r0[2] = 0;
+                    r0[3] = 1;
                 }
                 continue;
             }
@@ -694,13 +718,14 @@ __global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, Co
             logL[0] += rs0;
             logL[1] += rs1;
             logL[2] += rs2;
-            if (rg == 0 && hl == 0)
+            if (rg == 0 && b.rank == 0 && hl == 0)
             {
                 const double m = fmax(fmax(rs0, rs1), rs2);
-                cs.rg0Kind = 0;
-                cs.rg0[0] = rs0 - m;
-                cs.rg0[1] = rs1 - m;
-                cs.rg0[2] = rs2 - m;
+                double * r0 = rg0Slot(b, cellIdx, 0);
+                r0[0] = rs0 - m;
+                r0[1] = rs1 - m;
+                r0[2] = rs2 - m;
+                r0[3] = 0;
             }
         }
         if (hl == 0)
@@ -737,7 +762,7 @@ __global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, Co
     {
         const double t = blockSum(term, red);
         if (threadIdx.x == 0)
-            b.partial[((size_t)cellIdx * b.nTiles + PD_TILE_IDX) * 4 + 2] = t;
+            PD_OWN_TILE_SLOT(b, cellIdx)[2] = t;
     }
 }
 
@@ -789,13 +814,14 @@ __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, 
     const unsigned hl = threadIdx.x & 31u, half = threadIdx.x >> 5;
     const double g0 = cs.gt[0], g1 = cs.gt[1], g2 = cs.gt[2];
     // weights of the reference model, shared by all read groups (always RG 0's triple)
-    bool rgNan = cs.rg0Kind == 1;
+    const double * rg0 = rg0Slot(b, cellIdx, 0);           // published by the context that owns read group 0
+    bool rgNan = rg0[3] != 0;
     double ea0Rg = 0, ea1Rg = 0;
     if (!rgNan)
     {
-        const double aSumRg = exp(cs.rg0[0]) * g0 + exp(cs.rg0[1]) * g1 + exp(cs.rg0[2]) * g2;
-        const double l0 = (cs.rg0[0] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : cs.rg0[0];
-        const double l1 = (cs.rg0[1] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : cs.rg0[1];
+        const double aSumRg = exp(rg0[0]) * g0 + exp(rg0[1]) * g1 + exp(rg0[2]) * g2;
+        const double l0 = (rg0[0] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[0];
+        const double l1 = (rg0[1] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[1];
         ea0Rg = exp(l0 + log(g0) - log(aSumRg));
         ea1Rg = exp(l1 + log(g1) - log(aSumRg));
         rgNan = isnan(ea0Rg) || isnan(ea1Rg);
@@ -868,7 +894,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, 
     const double t1 = blockSumHalves(wSumDelAcc, red);
     if (threadIdx.x == 0)
     {
-        double * p = b.partial + ((size_t)cellIdx * b.nTiles + PD_TILE_IDX) * 4;
+        double * p = PD_OWN_TILE_SLOT(b, cellIdx);
         p[0] = t0;
         p[1] = t1;
     }
@@ -885,7 +911,7 @@ __global__ void cellLenFinishKernel(Stage2Buffers b)
     double sumDel = 0, wSumDel = 0;
     for (unsigned t = 0; t < b.nTiles; ++t)
     {
-        const double * p = b.partial + ((size_t)c * b.nTiles + t) * 4;
+        const double * p = tileSlot(b, c, t);
         sumDel += p[0];
         wSumDel += p[1];
     }
@@ -901,7 +927,7 @@ __global__ void cellLenFinishKernel(Stage2Buffers b)
 }
 
 // Allele-frequency update and convergence test (reference :623-659).
-__global__ void cellFreqFinishKernel(Stage2Buffers b, unsigned nSamples, unsigned iteration)
+__global__ void cellFreqFinishKernel(Stage2Buffers b, unsigned iteration)
 {
     const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= b.nCells)
@@ -921,8 +947,8 @@ __global__ void cellFreqFinishKernel(Stage2Buffers b, unsigned nSamples, unsigne
     } mark{cs, b.iterFlags + iteration};
     double sum = 0;
     for (unsigned t = 0; t < b.nTiles; ++t)
-        sum += b.partial[((size_t)c * b.nTiles + t) * 4 + 2];
-    const double freq = sum / 2.0 / nSamples;
+        sum += tileSlot(b, c, t)[2];
+    const double freq = sum / 2.0 / b.nSamplesGlobal;
     cs.freq = freq;
     if (freq == 0)
     {
@@ -965,7 +991,7 @@ __global__ __launch_bounds__(kSampleTile) void lrKernel(CohortView co, Stage2Buf
     const double s1 = blockSum(noDel, red);
     if (threadIdx.x == 0)
     {
-        double * p = b.partial + ((size_t)cellIdx * b.nTiles + PD_TILE_IDX) * 4;
+        double * p = PD_OWN_TILE_SLOT(b, cellIdx);
         p[0] = s0;
         p[1] = s1;
     }
@@ -976,7 +1002,7 @@ __device__ __forceinline__ double sumLR(const Stage2Buffers & b, unsigned c)
     double del = 0, noDel = 0;
     for (unsigned t = 0; t < b.nTiles; ++t)
     {
-        const double * p = b.partial + ((size_t)c * b.nTiles + t) * 4;
+        const double * p = tileSlot(b, c, t);
         del += p[0];
         noDel += p[1];
     }
@@ -1204,70 +1230,89 @@ __global__ __launch_bounds__(kSampleTile) void finalKernel(SegmentView seg, Coho
     }
 }
 
-// k-th smallest of an unsigned pool by 4 x 8-bit radix passes (one workgroup per cell and pool).
-__device__ unsigned radixSelect(const unsigned * v, unsigned n, unsigned k, unsigned * hist /* 256 */, unsigned * sh /* 2 */)
-{
-    unsigned prefix = 0, mask = 0;
-    for (int pass = 3; pass >= 0; --pass)
-    {
-        const int shift = pass * 8;
-        for (unsigned i = threadIdx.x; i < 256; i += blockDim.x)
-            hist[i] = 0;
-        __syncthreads();
-        for (unsigned i = threadIdx.x; i < n; i += blockDim.x)
-        {
-            const unsigned x = v[i];
-            if ((x & mask) == prefix)
-                atomicAdd(&hist[(x >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0)
-        {
-            unsigned acc = 0, digit = 0;
-            for (digit = 0; digit < 256; ++digit)
-            {
-                if (acc + hist[digit] > k)
-                    break;
-                acc += hist[digit];
-            }
-            sh[0] = digit;
-            sh[1] = k - acc;
-        }
-        __syncthreads();
-        prefix |= sh[0] << shift;
-        mask |= 255u << shift;
-        k = sh[1];
-        __syncthreads();
-    }
-    return prefix;
-}
-
-__global__ __launch_bounds__(256) void suppSelectKernel(Stage2Buffers b)
+// Percentiles of the support pools (reference :514-529) by 4 x 8-bit radix selection. The pool of a cell is spread over
+// the contexts of a sharded cohort, so every pass is: digit histogram of the own pool (suppHistKernel) -> exchange ->
+// sum of the histograms, pick the digit (suppPickKernel). Pool 0: pair starts (80th percentile), pool 1: pair ends (20th).
+__global__ __launch_bounds__(256) void suppHistKernel(Stage2Buffers b, int pass)
 {
     __shared__ unsigned hist[256];
-    __shared__ unsigned sh[2];
-    CellState & cs = b.cells[blockIdx.x];
+    const unsigned c = blockIdx.x, pool = blockIdx.y;
+    const CellState & cs = b.cells[c];
     if (cs.phase != kCellFinal)
         return;
-    const unsigned n = cs.suppCount;
-    if (n == 0)
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned * v = (pool == 0 ? b.suppFirst : b.suppLast) + cs.suppBase;
+    const unsigned n = cs.suppCount;                       // own pool; replaced by the cohort-wide count after pass 0
+    const int shift = pass * 8;
+    const unsigned mask = pass == 3 ? 0u : (0xffffffffu << (shift + 8)), prefix = cs.selPrefix[pool];
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x)
     {
-        if (threadIdx.x == 0)
+        const unsigned x = v[i];
+        if ((x & mask) == prefix)
+            atomicAdd(&hist[(x >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    b.selHist[(((size_t)b.rank * b.nCells + c) * 2 + pool) * 256 + threadIdx.x] = hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void suppPickKernel(Stage2Buffers b, int pass)
+{
+    __shared__ unsigned hist[256];
+    const unsigned c = blockIdx.x, pool = blockIdx.y;
+    CellState & cs = b.cells[c];
+    if (cs.phase != kCellFinal)
+        return;
+    unsigned h = 0;
+    for (unsigned r = 0; r < b.world; ++r)
+        h += b.selHist[(((size_t)r * b.nCells + c) * 2 + pool) * 256 + threadIdx.x];
+    hist[threadIdx.x] = h;
+    __syncthreads();
+    if (threadIdx.x != 0)
+        return;
+    unsigned k = cs.selK[pool];
+    if (pass == 3)
+    {
+        unsigned n = 0;
+        for (int d = 0; d < 256; ++d)
+            n += hist[d];
+        if (pool == 0)
+            cs.suppCapacity = n;                           // cohort-wide number of supporting pairs (parked here)
+        if (n == 0)
         {
-            cs.suppStart = 0;
-            cs.suppEnd = 0;
+            cs.selPrefix[pool] = 0;
+            cs.selK[pool] = 0;
+            return;
         }
+        k = (unsigned)round((double)(n - 1) * (pool == 0 ? 0.8 : (1 - 0.8)));
+    }
+    else if (cs.suppCapacity == 0)
+    {
         return;
     }
-    const unsigned l = (unsigned)round((double)(n - 1) * 0.8);
-    const unsigned r = (unsigned)round((double)(n - 1) * (1 - 0.8));
-    const unsigned a = radixSelect(b.suppFirst + cs.suppBase, n, l, hist, sh);
-    const unsigned e = radixSelect(b.suppLast + cs.suppBase, n, r, hist, sh);
-    if (threadIdx.x == 0)
+    unsigned acc = 0, digit = 0;
+    for (digit = 0; digit < 256; ++digit)
     {
-        cs.suppStart = a;
-        cs.suppEnd = e;
+        if (acc + hist[digit] > k)
+            break;
+        acc += hist[digit];
     }
+    cs.selPrefix[pool] |= digit << (pass * 8);
+    cs.selK[pool] = k - acc;
+}
+
+// After the last pass: publish the percentiles and the cohort-wide support count.
+__global__ void suppFinishKernel(Stage2Buffers b)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= b.nCells)
+        return;
+    CellState & cs = b.cells[c];
+    if (cs.phase != kCellFinal)
+        return;
+    cs.suppCount = cs.suppCapacity;
+    cs.suppStart = cs.suppCount ? cs.selPrefix[0] : 0u;
+    cs.suppEnd = cs.suppCount ? cs.selPrefix[1] : 0u;
 }
 
 // Likelihood-ratio test and call emission (reference :685-724).
@@ -1311,36 +1356,49 @@ __global__ void gatherOutKernel(Stage2Buffers b, const unsigned * __restrict__ e
 }
 
 // ---- host-side launch sequence ---------------------------------------------------------------------------------------
-void launchCluster(const int32_t * q3, const uint8_t * flags, const int * flaggedWindows, unsigned nFlagged, unsigned W,
-                   const CohortView & co, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,
+void launchPackFlagged(const int32_t * q3, const uint8_t * flags, const int * flaggedWindows, unsigned W, unsigned nLocal,
+                       const ClusterInput & in, unsigned rank, hipStream_t st)
+{
+    hipLaunchKernelGGL(packFlaggedKernel, dim3((in.sper + 255) / 256, in.nFlagged), dim3(256), 0, st, q3, flags, flaggedWindows, W,
+                       nLocal, in, rank);
+}
+
+void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,
                    hipStream_t st)
 {
-    if (nFlagged == 0)
-        return;
-    hipLaunchKernelGGL(clusterKernel, dim3(nFlagged), dim3(256), 0, st, q3, flags, flaggedWindows, W, co, uniformThreshold,
-                       scratch, rowLen, candLen, candCount);
+    hipLaunchKernelGGL(clusterKernel, dim3(in.nFlagged), dim3(256), 0, st, in, uniformThreshold, scratch, rowLen, candLen,
+                       candCount);
 }
 
 // Phase A: first allele-frequency estimate and support-pool capacities (the host sizes the pools from them).
-void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st)
+void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
+                   hipStream_t st)
 {
     if (b.nCells == 0)
         return;
-    const dim3 perSample(b.nTiles, b.nCells), tile(kSampleTile);
+    const unsigned ownTiles = (co.nSamples + kSamplesPerBlock - 1) / kSamplesPerBlock;
+    const dim3 perSample(ownTiles, b.nCells), tile(kSampleTile);
     const dim3 perCell((b.nCells + 127) / 128), cellBlock(128);
     hipLaunchKernelGGL(cellInitKernel, perSample, tile, 0, st, seg, co, b, flags);
+    x.allGather(b.counters, (size_t)b.nCells * 4 * sizeof(unsigned));
     hipLaunchKernelGGL(cellInitFinishKernel, perCell, cellBlock, 0, st, b);
     hipLaunchKernelGGL(suppScanKernel, dim3(1), dim3(1), 0, st, b);
 }
 
 // Phase B: EM loop, convergence comparison, final pass, support percentiles, likelihood-ratio test.
-void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st)
+// Every context of a sharded cohort runs the same sequence; the per-cell kernels see identical inputs everywhere
+// (all-gathered per-tile sums), so all contexts take the same decisions, including the early exit below.
+void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
+                   hipStream_t st)
 {
     if (b.nCells == 0)
         return;
-    const dim3 perSample(b.nTiles, b.nCells), tile(kSampleTile);
+    const unsigned ownTiles = (co.nSamples + kSamplesPerBlock - 1) / kSamplesPerBlock;
+    const dim3 perSample(ownTiles, b.nCells), tile(kSampleTile);
     const dim3 perCell((b.nCells + 127) / 128), cellBlock(128);
+    const size_t xchBytes = b.xchChunk * sizeof(double);
     hipLaunchKernelGGL(dataLikKernel, perSample, tile, 0, st, seg, co, b, 0);
+    x.allGather(b.xch, xchBytes);
     (void)hipMemsetAsync(b.iterFlags, 0, (b.maxIterations + 1) * sizeof(unsigned), st);
     for (unsigned it = 0; it <= b.maxIterations; ++it)
     {
@@ -1348,9 +1406,11 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
         if (it == b.maxIterations)
             break;                      // the last head call only retires cells that hit the iteration cap
         hipLaunchKernelGGL(updateLenKernel, perSample, tile, 0, st, seg, co, b);
+        x.allGather(b.xch, xchBytes);
         hipLaunchKernelGGL(cellLenFinishKernel, perCell, cellBlock, 0, st, b);
         hipLaunchKernelGGL(dataLikKernel, perSample, tile, 0, st, seg, co, b, 0);
-        hipLaunchKernelGGL(cellFreqFinishKernel, perCell, cellBlock, 0, st, b, co.nSamples, it);
+        x.allGather(b.xch, xchBytes);
+        hipLaunchKernelGGL(cellFreqFinishKernel, perCell, cellBlock, 0, st, b, it);
         // Most cells leave the loop after 2-4 iterations: look at the "someone is still iterating" flag now and then
         // instead of launching the remaining (empty) iterations.
         if (it == 2 || it == 4 || it == 7 || it == 10)
@@ -1364,14 +1424,23 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     }
     // cells that left through the visited-table test: compare with the previous estimate
     hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellConverged, 0);
+    x.allGather(b.xch, xchBytes);
     hipLaunchKernelGGL(cellConvergedKernel, perCell, cellBlock, 0, st, b, 0);
     hipLaunchKernelGGL(dataLikKernel, perSample, tile, 0, st, seg, co, b, 1);
     hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellConverged, 1);
+    x.allGather(b.xch, xchBytes);
     hipLaunchKernelGGL(cellConvergedKernel, perCell, cellBlock, 0, st, b, 1);
     hipLaunchKernelGGL(cellPostLoopKernel, perCell, cellBlock, 0, st, b);
     hipLaunchKernelGGL(finalKernel, perSample, tile, 0, st, seg, co, b, flags);
-    hipLaunchKernelGGL(suppSelectKernel, dim3(b.nCells), dim3(256), 0, st, b);
+    for (int pass = 3; pass >= 0; --pass)
+    {
+        hipLaunchKernelGGL(suppHistKernel, dim3(b.nCells, 2), dim3(256), 0, st, b, pass);
+        x.allGather(b.selHist, (size_t)b.nCells * 2 * 256 * sizeof(unsigned));
+        hipLaunchKernelGGL(suppPickKernel, dim3(b.nCells, 2), dim3(256), 0, st, b, pass);
+    }
+    hipLaunchKernelGGL(suppFinishKernel, perCell, cellBlock, 0, st, b);
     hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellFinal, 0);
+    x.allGather(b.xch, xchBytes);
     hipLaunchKernelGGL(cellEmitKernel, perCell, cellBlock, 0, st, b);
 }
 

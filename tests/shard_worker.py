@@ -1,0 +1,58 @@
+"""Worker of the sample-shard tests: rank RANK of WORLD_SIZE processes (gloo rendezvous on 127.0.0.1) runs its block of
+samples of the cohort described by `make_case()` through the HIP library; rank 0 pickles the joined result.
+usage: shard_worker.py <repo root> <case> <out.pkl> [device]"""
+import os
+import pickle
+import sys
+
+import numpy as np
+
+
+def make_case(name):
+    """(segment of the whole cohort, read groups, sample offsets, context options)"""
+    from popdel_amd import synth
+    lib = synth.Library()
+    base = synth.conditioned_readgroup(lib)
+    if name == "deletions600":
+        n = 600
+        seg = synth.cohort_segment(n, (1000000, 1036000), 1000020, 1100, lib,
+                                   deletions=lambda k, r: [synth.Deletion(1010000, 900, [1, 2, 0, 0][k % 4]),
+                                                           synth.Deletion(1024000, 2500, [0, 0, 1, 2, 0][k % 5])])
+        rgs = [base] * n
+        opts = {}
+    elif name == "thresholds300":
+        # per-sample thresholds differ: the rank-indexed threshold lookup (quirk Q1) must see the cohort-wide table
+        import dataclasses
+        n = 300
+        seg = synth.cohort_segment(n, (1000000, 1030000), 1000020, 900, lib,
+                                   deletions=lambda k, r: [synth.Deletion(1012000, 700 + 40 * (k % 3), [1, 2, 0][k % 3])])
+        rgs = [dataclasses.replace(base, min_init_del_len=[0, 350, 900, 120][(k // 7) % 4]) for k in range(n)]
+        opts = dict(window_wise_output=True, min_sample_fraction=0.5)
+    else:
+        raise ValueError(name)
+    return seg, rgs, list(range(n + 1)), opts
+
+
+def main():
+    root, case, out = sys.argv[1:4]
+    device = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+    from popdel_amd import capi, distributed
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(os.environ.get("POPDEL_TEST_BACKEND", "gloo"), rank=rank, world_size=world)
+    seg, rgs, offs, opts = make_case(case)
+    shard = distributed.SampleShard(capi.load_hip(), rgs, offs, rank, world, device=device, **opts)
+    res = shard.run(shard.local_segment(seg))
+    assert res["n_samples"] == shard.last - shard.first
+    full = shard.gather_columns(res)
+    q3, fl = shard.ctx.stage1()
+    if rank == 0:
+        pickle.dump(dict(calls=full, exchanges=shard.exchange.calls, q3_shape=q3.shape), open(out, "wb"))
+    dist.barrier()
+    shard.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
