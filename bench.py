@@ -12,6 +12,11 @@ With --gpus N every rank runs such a chromosome-sized step on its own GPU (segme
 carry-over of active pairs, so whole-genome work is dealt out by segment/chromosome with no data-path collective):
 per-GPU work is fixed (weak scaling), value = N x cells / max-over-ranks time.
 
+With N > 1 the same JSON line also carries "sample_sharded": the other exact split (north_star) -- ONE cohort
+of N x 9,984 samples, every rank owning the pairs of its own 9,984 samples, the library all-gathering over RCCL what
+crosses samples (popdel_amd/distributed.py: SampleShard) -- timed on a few passes of the same segment. It is a secondary
+figure: per-pass collectives cost latency that whole-segment sharding does not pay, so the headline stays on segments.
+
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -87,6 +92,11 @@ def main():
     ap.add_argument("--passes", type=int, default=0, help="segment passes per step (default: chr20 = 323)")
     ap.add_argument("--cpu-samples", type=int, default=600, help="samples of the same segment timed on one host core")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sharded-passes", type=int, default=40,
+                    help="passes of the secondary sample-sharded leg (N > 1 only; 0 switches it off)")
+    ap.add_argument("--sharded-timeout", type=float, default=240.0, help="give up on the secondary leg after this many seconds")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
+    ap.add_argument("--share-gpu", action="store_true", help="dry run: all ranks use GPU 0 (needs --backend gloo)")
     ap.add_argument("--contexts", type=int, default=1,
                     help="segments in flight per GPU (one context and host thread each); 1 keeps the kernel timings clean")
     args = ap.parse_args()
@@ -100,9 +110,15 @@ def main():
     is_dist = world > 1
     if is_dist:
         import torch.distributed as dist
+        if args.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     device = torch.device("cuda", local_rank)
+    red_device = device if args.backend == "nccl" else torch.device("cpu")       # where timing reductions live
 
     hip = capi.load_hip()                     # no fallback: raises if the HIP library is missing
     lib = synth.Library()
@@ -171,7 +187,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if is_dist:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=red_device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -216,8 +232,47 @@ def main():
                                 sample="%d of the %d samples x the same %d-window segment, oracle/ (x87 long double), %.1f s"
                                        % (n_cpu, S, W, cpu_s))
 
+    # ---- secondary leg: the cohort sharded by SAMPLES over the ranks (collectives in the data path) --------------------
+    result = {}
+
+    def emit_and_finish(sample_sharded):
+        if rank == 0:
+            line = dict(result)
+            line["sample_sharded"] = sample_sharded
+            print(json.dumps(line), flush=True)
+
+    def sample_sharded_leg():
+        n = S // 256 * 256                                     # whole tiles per rank (partition rule of pd_shard_samples)
+        o, a = take_samples(offsets, arrays, n)
+        lseg = capi.Segment(first, W, o, a["dev"], a["start"], a["on"], a["off"])
+        shard = distributed.SampleShard(hip, [rg] * (n * world), list(range(n * world + 1)), rank, world, device=local_rank)
+        h = shard.ctx.stage(lseg)
+        calls = 0
+        for _ in range(2):
+            shard.ctx.collect(shard.ctx.run(h), copy=False)
+        x0 = shard.exchange.calls, shard.exchange.bytes
+        sync()
+        q0 = time.perf_counter()
+        for _ in range(args.sharded_passes):
+            calls += shard.ctx.collect(shard.ctx.run(h), copy=False)["n_calls"]
+        sync()
+        dt = time.perf_counter() - q0
+        tt = torch.tensor([dt], device=red_device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        tm = shard.ctx.timing()
+        out = dict(value=args.sharded_passes * W * n * world / dt, unit="window*sample/s", samples_per_gpu=n,
+                   cohort_samples=n * world, passes=args.sharded_passes, ms_per_pass=dt / args.sharded_passes * 1e3,
+                   all_gathers_per_pass=(shard.exchange.calls - x0[0]) / args.sharded_passes,
+                   all_gather_bytes_per_pass=(shard.exchange.bytes - x0[1]) / args.sharded_passes,
+                   calls_per_pass=calls / args.sharded_passes, candidate_cells_per_pass=tm["n_candidate_cells"],
+                   backend=dist.get_backend(), scaling="weak")
+        shard.ctx.unstage(h)
+        shard.close()
+        return out
+
     if rank == 0:
-        print(json.dumps({
+        result = ({
             "metric": "window x sample likelihood evals/sec", "value": value, "unit": "window*sample/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 scan + f64 likelihoods",
@@ -234,12 +289,32 @@ def main():
             # inside every pass the rate would be cells_per_pass / (stage_seconds + pass time): reported, never `value`
             "staging_seconds_per_segment": stage_seconds,
             "pcie_inclusive_value": (W * S) / (stage_seconds + elapsed / args.steps / max(1, my_passes)),
-            "roofline": roofline, "cpu_baseline": cpu_baseline}))
+            "roofline": roofline, "cpu_baseline": cpu_baseline})
     ctx.unstage(handle)
     ctx.close()
     for c2, h2 in extra:
         c2.unstage(h2)
         c2.close()
+    if not is_dist or args.sharded_passes <= 0:
+        emit_and_finish(None)
+    else:
+        # A collective that never completes must not take the headline with it: a watchdog prints the line and ends the
+        # process if the secondary leg overruns.
+        import threading
+
+        def give_up():
+            emit_and_finish({"error": "sample-sharded leg did not finish within %.0f s" % args.sharded_timeout})
+            os._exit(0)
+
+        dog = threading.Timer(args.sharded_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            leg = sample_sharded_leg()
+        except Exception as e:          # reported, never fatal for the headline
+            leg = {"error": "%s: %s" % (type(e).__name__, e)}
+        dog.cancel()
+        emit_and_finish(leg)
     if is_dist:
         dist.destroy_process_group()
 
