@@ -26,7 +26,7 @@ void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch,
 void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
                    hipStream_t st);
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
-                   hipStream_t st);
+                   bool anyGenericTile, hipStream_t st);
 void buildLogTables(const double * hist, double4 * tab, size_t n, RgConst * rg, unsigned nRg, hipStream_t st);
 void launchGatherOut(const Stage2Buffers & b, const unsigned * emitCells, unsigned nEmit, unsigned nSamples, uint32_t * pl,
                      uint32_t * lad, uint32_t * dad, uint32_t * fl, hipStream_t st);
@@ -200,6 +200,10 @@ struct pd_ctx
     DevBuf<pd::CellState> dCells;
     DevBuf<double> dDl;
     DevBuf<int> dShifts;
+    DevBuf<int32_t> dCellDev;
+    DevBuf<uint32_t> dCellStart;
+    DevBuf<uint16_t> dCellN;
+    DevBuf<uint8_t> dWaveRows, dTileMode;
     DevBuf<unsigned> dSuppFirst, dSuppLast, dEmit;
     DevBuf<uint32_t> dPl, dLad, dDad, dFl, dOutPl;
     pd_timing timing;
@@ -860,6 +864,18 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             c->dCells.upload(cells, c->stream);
             c->dDl.ensure(static_cast<size_t>(nCells) * S * 3);
             c->dShifts.ensure(static_cast<size_t>(nCells) * c->nRg);
+            b.ownTiles = (S + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock;
+            const size_t waveTiles = static_cast<size_t>(nCells) * b.ownTiles * 4;
+            c->dCellDev.ensure(waveTiles * pd::kDenseCap * 64);
+            c->dCellStart.ensure(waveTiles * pd::kDenseCap * 64);
+            c->dCellN.ensure(static_cast<size_t>(nCells) * S);
+            c->dWaveRows.ensure(waveTiles);
+            c->dTileMode.ensure(static_cast<size_t>(nCells) * b.ownTiles);
+            b.cellDev = c->dCellDev.p;
+            b.cellStart = c->dCellStart.p;
+            b.cellN = c->dCellN.p;
+            b.waveRows = c->dWaveRows.p;
+            b.tileMode = c->dTileMode.p;
             c->dPl.ensure(static_cast<size_t>(nCells) * S * 3);
             c->dLad.ensure(static_cast<size_t>(nCells) * S * 3);
             c->dDad.ensure(static_cast<size_t>(nCells) * S * 5);
@@ -886,14 +902,20 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             PD_HIP(hipMemcpyAsync(counters.data(), b.counters + static_cast<size_t>(c->rank) * nCells * 4,
                                   counters.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
             PD_HIP(hipStreamSynchronize(c->stream));
-            uint64_t pool = 0;
+            uint64_t pool = 0, genericTiles = 0;
             for (unsigned i = 0; i < nCells; ++i)
+            {
                 pool += counters[static_cast<size_t>(i) * 4 + 1];
+                genericTiles += counters[static_cast<size_t>(i) * 4 + 3];
+            }
+            if (getenv("POPDEL_HIP_DEBUG"))
+                fprintf(stderr, "[popdel_hip] stage 2: %u cells, %llu of %llu (cell, tile) units on the generic kernels\n", nCells,
+                        (unsigned long long)genericTiles, (unsigned long long)nCells * b.ownTiles);
             c->dSuppFirst.ensure(pool + 1);
             c->dSuppLast.ensure(pool + 1);
             b.suppFirst = c->dSuppFirst.p;
             b.suppLast = c->dSuppLast.p;
-            pd::runStage2Main(view, c->cohort, b, c->dFlags.p, xch, c->stream);
+            pd::runStage2Main(view, c->cohort, b, c->dFlags.p, xch, genericTiles != 0, c->stream);
             PD_HIP(hipGetLastError());
             PD_HIP(hipMemcpyAsync(cells.data(), c->dCells.p, cells.size() * sizeof(pd::CellState), hipMemcpyDeviceToHost, c->stream));
             PD_HIP(hipStreamSynchronize(c->stream));

@@ -14,6 +14,8 @@ constexpr int kMaxIterationsCap = 64;          // visited-table capacity per cel
 constexpr int kStage1Block = 256;              // windows per workgroup in the stage-1 scan
 constexpr int kStage1LdsPairs = 3072;          // pair chunks staged in LDS per stage-1 workgroup
 constexpr int kSampleTile = 256;               // threads per workgroup in the stage-2 per-sample kernels
+constexpr int kDenseCap = 64;                  // active pairs per (cell, sample) the dense stage-2 image holds
+constexpr unsigned kDenseHighCov = 0xffffu;    // cellN marker: read group at or above maxLoad (skipped by the reference)
 constexpr int kSamplesPerBlock = 256;           // samples one such workgroup walks (8 half-waves x 32 samples; 64 and 128 were measured slower)
 
 // x87 `expl` underflows to zero below ln(2^-16446); the reference's "likelihood too small" reset hangs off that.
@@ -159,6 +161,16 @@ struct Stage2Buffers
     unsigned    tilesPerRank;
     unsigned    rank, world;
     unsigned    nSamplesGlobal;
+    // Dense image of the cells' active pairs, built once per cell by cellGatherKernel: for every 64-sample wave tile
+    // the deviations (and start positions) transposed to [row j][lane = sample], so that the EM kernels run ONE LANE PER
+    // SAMPLE with coalesced loads and no cross-lane work. Tiles the image cannot hold (a multi-read-group sample, more
+    // than kDenseCap active pairs below maxLoad) are flagged in tileMode and go through the generic half-wave kernels.
+    int32_t *   cellDev;     // [nCells][ownTiles*4][kDenseCap][64]
+    uint32_t *  cellStart;   // same shape
+    uint16_t *  cellN;       // [nCells][S] active pairs of the sample's read group, or kDenseHighCov
+    uint8_t *   waveRows;    // [nCells][ownTiles*4] max cellN over the wave tile (rows in use)
+    uint8_t *   tileMode;    // [nCells][ownTiles] 0: dense kernels, 1: generic kernels
+    unsigned    ownTiles;    // 256-sample tiles of this context
     // final-pass outputs, [nCells][S][k]
     uint32_t *  pl;
     uint32_t *  lad;

@@ -504,54 +504,122 @@ __global__ __launch_bounds__(256) void clusterKernel(ClusterInput in, int unifor
 }
 
 // =====================================================================================================================
-// Cell initialisation: first allele-frequency estimate (integer counts), low-coverage sample count.
+// Cell set-up: first allele-frequency estimate (integer counts, reference :93-133), low-coverage sample count, and
+// the dense image of the cell's active pairs (see Stage2Buffers::cellDev).
+// A workgroup takes one (cell, 256-sample tile); per 64-sample wave tile the half-waves compact the active pairs of
+// their samples into LDS rows, then the whole workgroup writes the rows out transposed (coalesced).
 // =====================================================================================================================
-__global__ __launch_bounds__(kSampleTile) void cellInitKernel(SegmentView seg, CohortView co, Stage2Buffers b,
-                                                              const uint8_t * __restrict__ flags)
+__global__ __launch_bounds__(kSampleTile) void cellGatherKernel(SegmentView seg, CohortView co, Stage2Buffers b,
+                                                                const uint8_t * __restrict__ flags)
 {
     __shared__ unsigned acc[3];
+    __shared__ SampleMeta shMeta[kSamplesPerBlock];
+    __shared__ int shDev[64][kDenseCap + 1];
+    __shared__ unsigned shSt[64][kDenseCap + 1];
+    __shared__ unsigned shN[64];
+    __shared__ unsigned shRows, shGeneric;
     const unsigned cellIdx = PD_CELL_IDX;
     if (threadIdx.x < 3)
         acc[threadIdx.x] = 0;
-    __syncthreads();
+    if (threadIdx.x == 0)
+        shGeneric = 0;
     const CellState & cs = b.cells[cellIdx];
     const unsigned w = (unsigned)cs.window;
     const unsigned L = (unsigned)cs.initLen;
     const unsigned hl = threadIdx.x & 31u, half = threadIdx.x >> 5;
-    __shared__ SampleMeta shMeta[kSamplesPerBlock];
+    const unsigned long long hm = halfMask();
+    const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
     loadTileMeta(seg, co, w, shMeta);
+    const unsigned waveTiles = b.ownTiles * 4;
     unsigned count = 0, total = 0, low = 0;
-    for (unsigned k = 0; k < (unsigned)(kSamplesPerBlock / kHalvesPerBlock); ++k)
+    for (unsigned wt = 0; wt < 4; ++wt)
     {
-        const unsigned slot = half + k * kHalvesPerBlock;
-        const unsigned s = PD_TILE_IDX * kSamplesPerBlock + slot;
-        if (s >= co.nSamples)
-            break;                                         // uniform per half-wave
-        const SampleMeta & meta = shMeta[slot];
-        for (unsigned rg = meta.rg0; rg < meta.rg1; ++rg)
+        if (threadIdx.x == 0)
+            shRows = 0;
+        __syncthreads();
+        for (unsigned k = 0; k < 8; ++k)
         {
-            RgConst rc;
-            PairRange r;
-            rgOfSample(meta, seg, co, w, rg, rc, r);
-            const unsigned n = halfCountActive(r, w, hl);
-            if (n == 0 || n >= rc.maxLoad)
-                continue;
-            total += n;
-            const int windowBegin = max((int)L / 2, (int)floor((L - 2 * rc.stddev) + 0.5));
-            const int windowEnd = (int)(L + 2 * rc.stddev);
-            for (unsigned base = r.begin; base < r.end; base += 32u)
+            const unsigned inWt = half + k * 8;
+            const unsigned slot = wt * 64 + inWt;
+            const unsigned s = PD_TILE_IDX * kSamplesPerBlock + slot;
+            if (s >= co.nSamples)                              // uniform per half-wave
             {
-                const unsigned i = base + hl;
-                bool hit = false;
-                if (i < r.end)
+                if (hl == 0)
+                    shN[inWt] = 0;
+                continue;
+            }
+            const SampleMeta & meta = shMeta[slot];
+            bool generic = (meta.rg1 - meta.rg0) != 1u;
+            unsigned nDense = 0;
+            for (unsigned rg = meta.rg0; rg < meta.rg1; ++rg)
+            {
+                RgConst rc;
+                PairRange r;
+                rgOfSample(meta, seg, co, w, rg, rc, r);
+                const int windowBegin = max((int)L / 2, (int)floor((L - 2 * rc.stddev) + 0.5));
+                const int windowEnd = (int)(L + 2 * rc.stddev);
+                unsigned n = 0, hits = 0;
+                for (unsigned base = r.begin; base < r.end; base += 32u)
                 {
-                    const PairDO p = r.p[i];
-                    hit = p.off > w && p.dev > windowBegin && p.dev < windowEnd;
+                    const unsigned i = base + hl;
+                    bool act = false;
+                    PairDO p;
+                    p.dev = 0;
+                    p.off = 0;
+                    if (i < r.end)
+                    {
+                        p = r.p[i];
+                        act = p.off > w;
+                    }
+                    const unsigned long long bal = __ballot(act) & hm;
+                    if (act)
+                    {
+                        const unsigned pos = n + (unsigned)__popcll(bal & below);
+                        if (pos < (unsigned)kDenseCap)
+                        {
+                            shDev[inWt][pos] = p.dev;
+                            shSt[inWt][pos] = r.st[i];
+                        }
+                    }
+                    n += (unsigned)__popcll(bal);
+                    hits += halfCount(act && p.dev > windowBegin && p.dev < windowEnd);
                 }
-                count += halfCount(hit);
+                if (n >= rc.maxLoad)
+                    nDense = kDenseHighCov;
+                if (n == 0 || n >= rc.maxLoad)
+                    continue;
+                total += n;
+                count += hits;
+                nDense = n;
+                if (n > (unsigned)kDenseCap)
+                    generic = true;
+            }
+            low += (flags[(size_t)s * seg.nWindows + w] & 1u) ? 1u : 0u;
+            if (hl == 0)
+            {
+                shN[inWt] = generic ? 0u : nDense;
+                b.cellN[(size_t)cellIdx * co.nSamples + s] = (uint16_t)(generic ? 0u : nDense);
+                if (generic)
+                    shGeneric = 1u;
+                else if (nDense != kDenseHighCov)
+                    atomicMax(&shRows, nDense);
             }
         }
-        low += (flags[(size_t)s * seg.nWindows + w] & 1u) ? 1u : 0u;
+        __syncthreads();
+        const unsigned rows = shRows;
+        const size_t wtGlobal = (size_t)cellIdx * waveTiles + PD_TILE_IDX * 4 + wt;
+        int32_t * outD = b.cellDev + wtGlobal * (kDenseCap * 64);
+        uint32_t * outS = b.cellStart + wtGlobal * (kDenseCap * 64);
+        for (unsigned idx = threadIdx.x; idx < rows * 64u; idx += blockDim.x)
+        {
+            const unsigned j = idx >> 6, lane = idx & 63u, nl = shN[lane];
+            const bool has = nl != kDenseHighCov && j < nl;
+            outD[idx] = has ? shDev[lane][j] : 0;
+            outS[idx] = has ? shSt[lane][j] : 0u;
+        }
+        if (threadIdx.x == 0)
+            b.waveRows[wtGlobal] = (uint8_t)rows;
+        __syncthreads();
     }
     if (hl == 0)
     {
@@ -563,8 +631,15 @@ __global__ __launch_bounds__(kSampleTile) void cellInitKernel(SegmentView seg, C
             atomicAdd(&acc[2], low);
     }
     __syncthreads();
+    unsigned * mine = b.counters + ((size_t)b.rank * b.nCells + cellIdx) * 4;
     if (threadIdx.x < 3 && acc[threadIdx.x])
-        atomicAdd(&b.counters[((size_t)b.rank * b.nCells + cellIdx) * 4 + threadIdx.x], acc[threadIdx.x]);
+        atomicAdd(&mine[threadIdx.x], acc[threadIdx.x]);
+    if (threadIdx.x == 0)
+    {
+        b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] = (uint8_t)shGeneric;
+        if (shGeneric)
+            atomicAdd(&mine[3], 1u);                       // tells the host that the generic kernels are needed at all
+    }
 }
 
 __global__ void cellInitFinishKernel(Stage2Buffers b)
@@ -656,7 +731,7 @@ __global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, Co
     const unsigned cellIdx = PD_CELL_IDX;
     CellState & cs = b.cells[cellIdx];
     const int wantPhase = mode == 0 ? kCellIterating : kCellConverged;
-    if (cs.phase != wantPhase)
+    if (cs.phase != wantPhase || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] == 0)
         return;
     const unsigned w = (unsigned)cs.window;
     const int len = (int)(mode == 0 ? cs.len : cs.prevLen);
@@ -766,6 +841,138 @@ __global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, Co
     }
 }
 
+// The same on the dense image: ONE LANE PER SAMPLE walks the rows of its wave tile (coalesced 4-byte loads, no
+// cross-lane work). sum_j log(ref_j + del_j) is taken as log(prod_j mantissa_j) + ln2 * sum_j exponent_j: one log per
+// sample instead of one per pair (mantissas lie in [0.5, 1), 64 of them cannot underflow).
+struct LaneRg
+{
+    int      base;       // median - histOffset
+    int      histLen;
+    uint64_t histBase;
+    unsigned maxLoad;
+    double   minProb, logMinProb, stddev;
+};
+__device__ __forceinline__ LaneRg laneRg(const RgConst & rc)
+{
+    LaneRg l;
+    l.base = rc.median - rc.histOffset;
+    l.histLen = rc.histLen;
+    l.histBase = rc.histBase;
+    l.maxLoad = rc.maxLoad;
+    l.minProb = rc.minProb;
+    l.logMinProb = rc.logMinProb;
+    l.stddev = rc.stddev;
+    return l;
+}
+__device__ __forceinline__ long long lanePos(const LaneRg & l, int deviation)
+{
+    const int i = deviation + l.base;
+    if (i <= 0 || i + 1 >= l.histLen)
+        return -1;
+    return (long long)(l.histBase + (unsigned)i);
+}
+
+__global__ __launch_bounds__(kSampleTile) void dataLikDenseKernel(CohortView co, Stage2Buffers b, int mode)
+{
+    __shared__ double red[4];
+    const unsigned cellIdx = PD_CELL_IDX;
+    const CellState & cs = b.cells[cellIdx];
+    const int wantPhase = mode == 0 ? kCellIterating : kCellConverged;
+    if (cs.phase != wantPhase || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] != 0)
+        return;
+    const int len = (int)(mode == 0 ? cs.len : cs.prevLen);
+    const unsigned s = PD_TILE_IDX * kSamplesPerBlock + threadIdx.x;
+    const bool valid = s < co.nSamples;
+    const size_t wtGlobal = (size_t)cellIdx * (b.ownTiles * 4) + PD_TILE_IDX * 4 + (threadIdx.x >> 6);
+    const unsigned rows = b.waveRows[wtGlobal];
+    const int32_t * col = b.cellDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+    double term = 0;
+    unsigned rg = 0, n = 0;
+    LaneRg l = {};
+    int refShift = 0;
+    if (valid)
+    {
+        rg = co.sampleRg[s];
+        l = laneRg(co.rg[rg]);
+        n = b.cellN[(size_t)cellIdx * co.nSamples + s];
+        refShift = (mode == 0) ? b.shifts[(size_t)cellIdx * co.nRg + rg] : 0;
+    }
+    const bool highCov = n == kDenseHighCov;
+    const unsigned nn = highCov ? 0u : n;
+    double g0 = 0, g2 = 0, prod = 1.0;
+    int esum = 0;
+    bool eq = true;
+    for (unsigned j = 0; j < rows; ++j)
+    {
+        if (j < nn)
+        {
+            const int dv = col[j * 64];
+            const long long pr = lanePos(l, dv - refShift), pdl = lanePos(l, dv - len);
+            double ref = l.minProb, lref = l.logMinProb, del = l.minProb, ldel = l.logMinProb;
+            if (pr >= 0)
+            {
+                const double2 t = *reinterpret_cast<const double2 *>(&co.tab[pr]);
+                ref = t.x;
+                lref = t.y;
+            }
+            if (pdl >= 0)
+            {
+                const double2 t = *reinterpret_cast<const double2 *>(&co.tab[pdl]);
+                del = t.x;
+                ldel = t.y;
+            }
+            g0 += lref;
+            g2 += ldel;
+            int e;
+            prod *= frexp(ref + del, &e);
+            esum += e;
+            eq = eq && (ref == del);
+        }
+    }
+    if (valid)
+    {
+        const double g1 = log(prod) + (double)(esum - (int)nn) * PD_LN2;
+        if (rg == 0 && b.rank == 0)
+        {
+            double * r0 = rg0Slot(b, cellIdx, 0);
+            if (highCov)
+            {
+                r0[0] = r0[1] = r0[2] = 0;
+                r0[3] = 1;
+            }
+            else
+            {
+                const double m = fmax(fmax(g0, g1), g2);
+                r0[0] = g0 - m;
+                r0[1] = g1 - m;
+                r0[2] = g2 - m;
+                r0[3] = 0;
+            }
+        }
+        double d[3];
+        const double logL[3] = {g0, nn ? g1 : 0.0, g2};
+        finishTriple(d, logL, nn, eq);
+        double * out = b.dl + ((size_t)cellIdx * co.nSamples + s) * 3;
+        out[0] = d[0];
+        out[1] = d[1];
+        out[2] = d[2];
+        if (mode == 0)
+        {
+            const double p0 = exp(d[0]) * cs.gt[0];
+            const double p1 = exp(d[1]) * cs.gt[1];
+            const double p2 = exp(d[2]) * cs.gt[2];
+            const double pAll = p0 + p1 + p2;
+            term = (p1 + 2 * p2) / pAll;
+        }
+    }
+    if (mode == 0)
+    {
+        const double t = blockSum(term, red);
+        if (threadIdx.x == 0)
+            PD_OWN_TILE_SLOT(b, cellIdx)[2] = t;
+    }
+}
+
 // =====================================================================================================================
 // EM loop head (reference :598-604): loop condition, bookkeeping of the visited table and the previous estimate.
 // =====================================================================================================================
@@ -807,7 +1014,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, 
     __shared__ double red[kHalvesPerBlock];
     const unsigned cellIdx = PD_CELL_IDX;
     const CellState & cs = b.cells[cellIdx];
-    if (cs.phase != kCellIterating)
+    if (cs.phase != kCellIterating || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] == 0)
         return;
     const unsigned w = (unsigned)cs.window;
     const int len = (int)cs.len;
@@ -892,6 +1099,91 @@ __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, 
     }
     const double t0 = blockSumHalves(sumDelAcc, red);
     const double t1 = blockSumHalves(wSumDelAcc, red);
+    if (threadIdx.x == 0)
+    {
+        double * p = PD_OWN_TILE_SLOT(b, cellIdx);
+        p[0] = t0;
+        p[1] = t1;
+    }
+}
+
+// The same on the dense image, one lane per sample.
+__global__ __launch_bounds__(kSampleTile) void updateLenDenseKernel(CohortView co, Stage2Buffers b)
+{
+    __shared__ double red[4];
+    const unsigned cellIdx = PD_CELL_IDX;
+    const CellState & cs = b.cells[cellIdx];
+    if (cs.phase != kCellIterating || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] != 0)
+        return;
+    const int len = (int)cs.len;
+    const double g0 = cs.gt[0], g1 = cs.gt[1], g2 = cs.gt[2];
+    const double * rg0 = rg0Slot(b, cellIdx, 0);
+    bool rgNan = rg0[3] != 0;
+    double ea0Rg = 0, ea1Rg = 0;
+    if (!rgNan)
+    {
+        const double aSumRg = exp(rg0[0]) * g0 + exp(rg0[1]) * g1 + exp(rg0[2]) * g2;
+        const double l0 = (rg0[0] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[0];
+        const double l1 = (rg0[1] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[1];
+        ea0Rg = exp(l0 + log(g0) - log(aSumRg));
+        ea1Rg = exp(l1 + log(g1) - log(aSumRg));
+        rgNan = isnan(ea0Rg) || isnan(ea1Rg);
+    }
+    const unsigned s = PD_TILE_IDX * kSamplesPerBlock + threadIdx.x;
+    const bool valid = s < co.nSamples;
+    const size_t wtGlobal = (size_t)cellIdx * (b.ownTiles * 4) + PD_TILE_IDX * 4 + (threadIdx.x >> 6);
+    const unsigned rows = b.waveRows[wtGlobal];
+    const int32_t * col = b.cellDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+    unsigned rg = 0, n = 0;
+    LaneRg l = {};
+    int refShift = 0;
+    double ea1 = 0, ea2 = 0;
+    int * shiftSlot = nullptr;
+    if (valid)
+    {
+        rg = co.sampleRg[s];
+        l = laneRg(co.rg[rg]);
+        n = b.cellN[(size_t)cellIdx * co.nSamples + s];
+        shiftSlot = b.shifts + (size_t)cellIdx * co.nRg + rg;
+        refShift = *shiftSlot;
+        const double * d = b.dl + ((size_t)cellIdx * co.nSamples + s) * 3;
+        const double aSum = exp(d[0]) * g0 + exp(d[1]) * g1 + exp(d[2]) * g2;
+        ea1 = exp(d[1] + log(g1) - log(aSum));
+        ea2 = exp(d[2] + log(g2) - log(aSum));
+    }
+    const bool highCov = n == kDenseHighCov;
+    const unsigned nn = highCov ? 0u : n;
+    double sumDel = 0, wSumDel = 0, sumRef = 0, wSumRef = 0;
+    for (unsigned j = 0; j < rows; ++j)
+    {
+        if (j < nn)
+        {
+            const int dv = col[j * 64];
+            const long long pd_ = lanePos(l, dv - len), pn = lanePos(l, dv - refShift);
+            const double del = pd_ >= 0 ? co.hist[pd_] : l.minProb;
+            const double noDel = pn >= 0 ? co.hist[pn] : l.minProb;
+            const double probDel = ea1 * del / (del + noDel) + ea2;
+            const double probRef = ea1Rg * noDel / (del + noDel) + ea0Rg;
+            sumDel += probDel;
+            sumRef += probRef;
+            wSumDel += probDel * dv;
+            wSumRef += probRef * dv;
+        }
+    }
+    if (valid && !highCov)
+    {
+        int newShift;
+        const double q = wSumRef / sumRef;
+        if (rgNan || !(q > -2147483649.0 && q < 2147483648.0))
+            newShift = (int)0x80000000;          // what x86 yields for NaN / out-of-range conversions
+        else
+            newShift = (int)q;
+        if (newShift > l.stddev || newShift < -1 * l.stddev)
+            newShift = 0;
+        *shiftSlot = newShift;
+    }
+    const double t0 = blockSum(sumDel, red);
+    const double t1 = blockSum(wSumDel, red);
     if (threadIdx.x == 0)
     {
         double * p = PD_OWN_TILE_SLOT(b, cellIdx);
@@ -1379,7 +1671,7 @@ void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers
     const unsigned ownTiles = (co.nSamples + kSamplesPerBlock - 1) / kSamplesPerBlock;
     const dim3 perSample(ownTiles, b.nCells), tile(kSampleTile);
     const dim3 perCell((b.nCells + 127) / 128), cellBlock(128);
-    hipLaunchKernelGGL(cellInitKernel, perSample, tile, 0, st, seg, co, b, flags);
+    hipLaunchKernelGGL(cellGatherKernel, perSample, tile, 0, st, seg, co, b, flags);
     x.allGather(b.counters, (size_t)b.nCells * 4 * sizeof(unsigned));
     hipLaunchKernelGGL(cellInitFinishKernel, perCell, cellBlock, 0, st, b);
     hipLaunchKernelGGL(suppScanKernel, dim3(1), dim3(1), 0, st, b);
@@ -1389,7 +1681,7 @@ void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers
 // Every context of a sharded cohort runs the same sequence; the per-cell kernels see identical inputs everywhere
 // (all-gathered per-tile sums), so all contexts take the same decisions, including the early exit below.
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
-                   hipStream_t st)
+                   bool anyGenericTile, hipStream_t st)
 {
     if (b.nCells == 0)
         return;
@@ -1397,7 +1689,13 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     const dim3 perSample(ownTiles, b.nCells), tile(kSampleTile);
     const dim3 perCell((b.nCells + 127) / 128), cellBlock(128);
     const size_t xchBytes = b.xchChunk * sizeof(double);
-    hipLaunchKernelGGL(dataLikKernel, perSample, tile, 0, st, seg, co, b, 0);
+    // every (cell, tile) is served by exactly one of the two kernels of a pair (tileMode)
+    auto dataLik = [&](int mode) {
+        hipLaunchKernelGGL(dataLikDenseKernel, perSample, tile, 0, st, co, b, mode);
+        if (anyGenericTile)
+            hipLaunchKernelGGL(dataLikKernel, perSample, tile, 0, st, seg, co, b, mode);
+    };
+    dataLik(0);
     x.allGather(b.xch, xchBytes);
     (void)hipMemsetAsync(b.iterFlags, 0, (b.maxIterations + 1) * sizeof(unsigned), st);
     for (unsigned it = 0; it <= b.maxIterations; ++it)
@@ -1405,10 +1703,12 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
         hipLaunchKernelGGL(cellLoopHeadKernel, perCell, cellBlock, 0, st, b);
         if (it == b.maxIterations)
             break;                      // the last head call only retires cells that hit the iteration cap
-        hipLaunchKernelGGL(updateLenKernel, perSample, tile, 0, st, seg, co, b);
+        hipLaunchKernelGGL(updateLenDenseKernel, perSample, tile, 0, st, co, b);
+        if (anyGenericTile)
+            hipLaunchKernelGGL(updateLenKernel, perSample, tile, 0, st, seg, co, b);
         x.allGather(b.xch, xchBytes);
         hipLaunchKernelGGL(cellLenFinishKernel, perCell, cellBlock, 0, st, b);
-        hipLaunchKernelGGL(dataLikKernel, perSample, tile, 0, st, seg, co, b, 0);
+        dataLik(0);
         x.allGather(b.xch, xchBytes);
         hipLaunchKernelGGL(cellFreqFinishKernel, perCell, cellBlock, 0, st, b, it);
         // Most cells leave the loop after 2-4 iterations: look at the "someone is still iterating" flag now and then
@@ -1426,7 +1726,7 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellConverged, 0);
     x.allGather(b.xch, xchBytes);
     hipLaunchKernelGGL(cellConvergedKernel, perCell, cellBlock, 0, st, b, 0);
-    hipLaunchKernelGGL(dataLikKernel, perSample, tile, 0, st, seg, co, b, 1);
+    dataLik(1);
     hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellConverged, 1);
     x.allGather(b.xch, xchBytes);
     hipLaunchKernelGGL(cellConvergedKernel, perCell, cellBlock, 0, st, b, 1);
