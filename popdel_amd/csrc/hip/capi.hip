@@ -203,7 +203,8 @@ struct pd_ctx
     DevBuf<int32_t> dCellDev;
     DevBuf<uint32_t> dCellStart;
     DevBuf<uint16_t> dCellN;
-    DevBuf<uint8_t> dWaveRows, dTileMode;
+    DevBuf<uint8_t> dWaveRows;
+    DevBuf<unsigned> dTileMode;
     DevBuf<unsigned> dSuppFirst, dSuppLast, dEmit;
     DevBuf<uint32_t> dPl, dLad, dDad, dFl, dOutPl;
     pd_timing timing;

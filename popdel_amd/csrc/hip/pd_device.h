@@ -169,7 +169,7 @@ struct Stage2Buffers
     uint32_t *  cellStart;   // same shape
     uint16_t *  cellN;       // [nCells][S] active pairs of the sample's read group, or kDenseHighCov
     uint8_t *   waveRows;    // [nCells][ownTiles*4] max cellN over the wave tile (rows in use)
-    uint8_t *   tileMode;    // [nCells][ownTiles] 0: dense kernels, 1: generic kernels
+    unsigned *  tileMode;    // [nCells][ownTiles] 0: dense kernels, 1: generic kernels
     unsigned    ownTiles;    // 256-sample tiles of this context
     // final-pass outputs, [nCells][S][k]
     uint32_t *  pl;

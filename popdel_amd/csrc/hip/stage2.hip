@@ -513,113 +513,102 @@ __global__ __launch_bounds__(kSampleTile) void cellGatherKernel(SegmentView seg,
                                                                 const uint8_t * __restrict__ flags)
 {
     __shared__ unsigned acc[3];
-    __shared__ SampleMeta shMeta[kSamplesPerBlock];
+    __shared__ SampleMeta shMeta[64];
     __shared__ int shDev[64][kDenseCap + 1];
     __shared__ unsigned shSt[64][kDenseCap + 1];
     __shared__ unsigned shN[64];
     __shared__ unsigned shRows, shGeneric;
-    const unsigned cellIdx = PD_CELL_IDX;
+    const unsigned cellIdx = blockIdx.y, wt = blockIdx.x;          // one workgroup per (cell, 64-sample wave tile)
     if (threadIdx.x < 3)
         acc[threadIdx.x] = 0;
     if (threadIdx.x == 0)
+    {
         shGeneric = 0;
+        shRows = 0;
+    }
     const CellState & cs = b.cells[cellIdx];
     const unsigned w = (unsigned)cs.window;
     const unsigned L = (unsigned)cs.initLen;
     const unsigned hl = threadIdx.x & 31u, half = threadIdx.x >> 5;
     const unsigned long long hm = halfMask();
     const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
-    loadTileMeta(seg, co, w, shMeta);
-    const unsigned waveTiles = b.ownTiles * 4;
-    unsigned count = 0, total = 0, low = 0;
-    for (unsigned wt = 0; wt < 4; ++wt)
+    if (threadIdx.x < 64u && wt * 64u + threadIdx.x < co.nSamples)
     {
-        if (threadIdx.x == 0)
-            shRows = 0;
-        __syncthreads();
-        for (unsigned k = 0; k < 8; ++k)
+        SampleMeta m;
+        m.rg0 = co.sampleRg[wt * 64u + threadIdx.x];
+        m.rg1 = co.sampleRg[wt * 64u + threadIdx.x + 1];
+        m.rc = co.rg[m.rg0];
+        m.r = pairRange(seg, m.rg0, w);
+        shMeta[threadIdx.x] = m;
+    }
+    __syncthreads();
+    unsigned count = 0, total = 0, low = 0;
+    for (unsigned k = 0; k < 8; ++k)
+    {
+        const unsigned inWt = half + k * 8;
+        const unsigned s = wt * 64u + inWt;
+        if (s >= co.nSamples)                              // uniform per half-wave
         {
-            const unsigned inWt = half + k * 8;
-            const unsigned slot = wt * 64 + inWt;
-            const unsigned s = PD_TILE_IDX * kSamplesPerBlock + slot;
-            if (s >= co.nSamples)                              // uniform per half-wave
-            {
-                if (hl == 0)
-                    shN[inWt] = 0;
-                continue;
-            }
-            const SampleMeta & meta = shMeta[slot];
-            bool generic = (meta.rg1 - meta.rg0) != 1u;
-            unsigned nDense = 0;
-            for (unsigned rg = meta.rg0; rg < meta.rg1; ++rg)
-            {
-                RgConst rc;
-                PairRange r;
-                rgOfSample(meta, seg, co, w, rg, rc, r);
-                const int windowBegin = max((int)L / 2, (int)floor((L - 2 * rc.stddev) + 0.5));
-                const int windowEnd = (int)(L + 2 * rc.stddev);
-                unsigned n = 0, hits = 0;
-                for (unsigned base = r.begin; base < r.end; base += 32u)
-                {
-                    const unsigned i = base + hl;
-                    bool act = false;
-                    PairDO p;
-                    p.dev = 0;
-                    p.off = 0;
-                    if (i < r.end)
-                    {
-                        p = r.p[i];
-                        act = p.off > w;
-                    }
-                    const unsigned long long bal = __ballot(act) & hm;
-                    if (act)
-                    {
-                        const unsigned pos = n + (unsigned)__popcll(bal & below);
-                        if (pos < (unsigned)kDenseCap)
-                        {
-                            shDev[inWt][pos] = p.dev;
-                            shSt[inWt][pos] = r.st[i];
-                        }
-                    }
-                    n += (unsigned)__popcll(bal);
-                    hits += halfCount(act && p.dev > windowBegin && p.dev < windowEnd);
-                }
-                if (n >= rc.maxLoad)
-                    nDense = kDenseHighCov;
-                if (n == 0 || n >= rc.maxLoad)
-                    continue;
-                total += n;
-                count += hits;
-                nDense = n;
-                if (n > (unsigned)kDenseCap)
-                    generic = true;
-            }
-            low += (flags[(size_t)s * seg.nWindows + w] & 1u) ? 1u : 0u;
             if (hl == 0)
-            {
-                shN[inWt] = generic ? 0u : nDense;
-                b.cellN[(size_t)cellIdx * co.nSamples + s] = (uint16_t)(generic ? 0u : nDense);
-                if (generic)
-                    shGeneric = 1u;
-                else if (nDense != kDenseHighCov)
-                    atomicMax(&shRows, nDense);
-            }
+                shN[inWt] = 0;
+            continue;
         }
-        __syncthreads();
-        const unsigned rows = shRows;
-        const size_t wtGlobal = (size_t)cellIdx * waveTiles + PD_TILE_IDX * 4 + wt;
-        int32_t * outD = b.cellDev + wtGlobal * (kDenseCap * 64);
-        uint32_t * outS = b.cellStart + wtGlobal * (kDenseCap * 64);
-        for (unsigned idx = threadIdx.x; idx < rows * 64u; idx += blockDim.x)
+        const SampleMeta & meta = shMeta[inWt];
+        bool generic = (meta.rg1 - meta.rg0) != 1u;
+        unsigned nDense = 0;
+        for (unsigned rg = meta.rg0; rg < meta.rg1; ++rg)
         {
-            const unsigned j = idx >> 6, lane = idx & 63u, nl = shN[lane];
-            const bool has = nl != kDenseHighCov && j < nl;
-            outD[idx] = has ? shDev[lane][j] : 0;
-            outS[idx] = has ? shSt[lane][j] : 0u;
+            RgConst rc;
+            PairRange r;
+            rgOfSample(meta, seg, co, w, rg, rc, r);
+            const int windowBegin = max((int)L / 2, (int)floor((L - 2 * rc.stddev) + 0.5));
+            const int windowEnd = (int)(L + 2 * rc.stddev);
+            unsigned n = 0, hits = 0;
+            for (unsigned base = r.begin; base < r.end; base += 32u)
+            {
+                const unsigned i = base + hl;
+                bool act = false;
+                PairDO p;
+                p.dev = 0;
+                p.off = 0;
+                if (i < r.end)
+                {
+                    p = r.p[i];
+                    act = p.off > w;
+                }
+                const unsigned long long bal = __ballot(act) & hm;
+                if (act)
+                {
+                    const unsigned pos = n + (unsigned)__popcll(bal & below);
+                    if (pos < (unsigned)kDenseCap)
+                    {
+                        shDev[inWt][pos] = p.dev;
+                        shSt[inWt][pos] = r.st[i];
+                    }
+                }
+                n += (unsigned)__popcll(bal);
+                hits += halfCount(act && p.dev > windowBegin && p.dev < windowEnd);
+            }
+            if (n >= rc.maxLoad)
+                nDense = kDenseHighCov;
+            if (n == 0 || n >= rc.maxLoad)
+                continue;
+            total += n;
+            count += hits;
+            nDense = n;
+            if (n > (unsigned)kDenseCap)
+                generic = true;
         }
-        if (threadIdx.x == 0)
-            b.waveRows[wtGlobal] = (uint8_t)rows;
-        __syncthreads();
+        low += (flags[(size_t)s * seg.nWindows + w] & 1u) ? 1u : 0u;
+        if (hl == 0)
+        {
+            shN[inWt] = generic ? 0u : nDense;
+            b.cellN[(size_t)cellIdx * co.nSamples + s] = (uint16_t)(generic ? 0u : nDense);
+            if (generic)
+                shGeneric = 1u;
+            else if (nDense != kDenseHighCov)
+                atomicMax(&shRows, nDense);
+        }
     }
     if (hl == 0)
     {
@@ -631,14 +620,29 @@ __global__ __launch_bounds__(kSampleTile) void cellGatherKernel(SegmentView seg,
             atomicAdd(&acc[2], low);
     }
     __syncthreads();
+    // transposed write-out: row j holds the j-th active pair of each of the 64 samples
+    const unsigned rows = shRows;
+    const size_t wtGlobal = (size_t)cellIdx * (b.ownTiles * 4) + wt;
+    int32_t * outD = b.cellDev + wtGlobal * (kDenseCap * 64);
+    uint32_t * outS = b.cellStart + wtGlobal * (kDenseCap * 64);
+    for (unsigned idx = threadIdx.x; idx < rows * 64u; idx += blockDim.x)
+    {
+        const unsigned j = idx >> 6, lane = idx & 63u, nl = shN[lane];
+        const bool has = nl != kDenseHighCov && j < nl;
+        outD[idx] = has ? shDev[lane][j] : 0;
+        outS[idx] = has ? shSt[lane][j] : 0u;
+    }
     unsigned * mine = b.counters + ((size_t)b.rank * b.nCells + cellIdx) * 4;
     if (threadIdx.x < 3 && acc[threadIdx.x])
         atomicAdd(&mine[threadIdx.x], acc[threadIdx.x]);
     if (threadIdx.x == 0)
     {
-        b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] = (uint8_t)shGeneric;
+        b.waveRows[wtGlobal] = (uint8_t)rows;
         if (shGeneric)
+        {
+            atomicMax(&b.tileMode[(size_t)cellIdx * b.ownTiles + wt / 4], 1u);     // the whole 256-sample tile goes generic
             atomicAdd(&mine[3], 1u);                       // tells the host that the generic kernels are needed at all
+        }
     }
 }
 
@@ -1350,7 +1354,7 @@ __global__ __launch_bounds__(kSampleTile) void finalKernel(SegmentView seg, Coho
     __shared__ unsigned shSt[kHalvesPerBlock][kHalfBufCap];
     const unsigned cellIdx = PD_CELL_IDX;
     CellState & cs = b.cells[cellIdx];
-    if (cs.phase != kCellFinal)
+    if (cs.phase != kCellFinal || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] == 0)
         return;
     const unsigned w = (unsigned)cs.window;
     const int len = (int)cs.len;
@@ -1522,6 +1526,177 @@ __global__ __launch_bounds__(kSampleTile) void finalKernel(SegmentView seg, Coho
     }
 }
 
+// The final pass on the dense image, one lane per sample. log / log10 of the heterozygous term again come from one
+// mantissa product per sample; the supporting pairs are appended to the pool with one atomic per wave.
+__global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, Stage2Buffers b, const uint8_t * __restrict__ flags,
+                                                                unsigned nWindows)
+{
+    const unsigned cellIdx = PD_CELL_IDX;
+    CellState & cs = b.cells[cellIdx];
+    if (cs.phase != kCellFinal || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] != 0)
+        return;
+    const unsigned w = (unsigned)cs.window;
+    const int len = (int)cs.len;
+    const unsigned s = PD_TILE_IDX * kSamplesPerBlock + threadIdx.x;
+    const bool valid = s < co.nSamples;
+    const size_t wtGlobal = (size_t)cellIdx * (b.ownTiles * 4) + PD_TILE_IDX * 4 + (threadIdx.x >> 6);
+    const unsigned rows = b.waveRows[wtGlobal];
+    const int32_t * col = b.cellDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+    const uint32_t * colSt = b.cellStart + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+    unsigned rg = 0, n = 0;
+    RgConst rc = {};
+    int refShift = 0;
+    if (valid)
+    {
+        rg = co.sampleRg[s];
+        rc = co.rg[rg];
+        n = b.cellN[(size_t)cellIdx * co.nSamples + s];
+        refShift = cs.restoreZeroShifts ? 0 : b.shifts[(size_t)cellIdx * co.nRg + rg];
+    }
+    const bool highCov = n == kDenseHighCov;
+    const unsigned nn = highCov ? 0u : n;
+    const int rgLower = (int)((unsigned)len - (unsigned)rc.lowerQ);
+    const int rgUpper = (int)((unsigned)len + (unsigned)rc.upperQ);
+    double l0 = 0, l2 = 0, t0 = 0, t2 = 0, prod = 1.0;
+    int esum = 0;
+    bool eq = true;
+    unsigned mn = 0xffffffffu, mx = 0, nSupp = 0;
+    unsigned lad[3] = {0, 0, 0}, dad[5] = {0, 0, 0, 0, 0};
+    for (unsigned j = 0; j < rows; ++j)
+    {
+        if (j < nn)
+        {
+            const int dv = col[j * 64];
+            const unsigned st = colSt[j * 64];
+            int cls;
+            if (dv > rc.upperQ)
+                cls = (dv < rgLower) ? 2 : ((dv <= rgUpper) ? 3 : 4);
+            else
+                cls = (dv < rgUpper) ? 0 : 1;
+            const long long pr = lookupPos(rc, dv - refShift), pdl = lookupPos(rc, dv - len);
+            double4 tr = make_double4(rc.minProb, rc.logMinProb, rc.log10MinProb, 0.0), td = tr;
+            if (pr >= 0)
+                tr = co.tab[pr];
+            if (pdl >= 0)
+                td = co.tab[pdl];
+            const double ref = tr.x, del = td.x;
+            const int lcls = (ref >= 2 * del) ? 0 : ((del >= 2 * ref) ? 2 : 1);
+            l0 += tr.y;
+            t0 += tr.z;
+            l2 += td.y;
+            t2 += td.z;
+            int e;
+            prod *= frexp(ref + del, &e);
+            esum += e;
+            eq = eq && (ref == del);
+            const unsigned last = st + (unsigned)max(0, dv + rc.median - 2 * rc.readLength);
+            mn = min(mn, st);
+            mx = max(mx, last);
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+                dad[c] += (cls == c) ? 1u : 0u;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                lad[c] += (lcls == c) ? 1u : 0u;
+            nSupp += (dv >= rgLower && dv <= rgUpper) ? 1u : 0u;
+        }
+    }
+    // supporting pairs: one pool allocation per wave, lanes fill their own stretch
+    {
+        unsigned incl = nSupp;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1)
+        {
+            const unsigned t = (unsigned)__shfl_up((int)incl, o, 64);
+            if ((int)(threadIdx.x & 63u) >= o)
+                incl += t;
+        }
+        const unsigned waveTotal = (unsigned)__shfl((int)incl, 63, 64);
+        if (waveTotal)                                        // wave-uniform
+        {
+            unsigned base0 = 0;
+            if ((threadIdx.x & 63u) == 0)
+                base0 = atomicAdd(&cs.suppCount, waveTotal);
+            base0 = (unsigned)__shfl((int)base0, 0, 64);
+            unsigned at = base0 + incl - nSupp;
+            if (nSupp)
+                for (unsigned j = 0; j < nn; ++j)
+                {
+                    const int dv = col[j * 64];
+                    if (dv >= rgLower && dv <= rgUpper)
+                    {
+                        const unsigned st = colSt[j * 64];
+                        b.suppFirst[cs.suppBase + at] = st;
+                        b.suppLast[cs.suppBase + at] = st + (unsigned)max(0, dv + rc.median - 2 * rc.readLength);
+                        ++at;
+                    }
+                }
+        }
+    }
+    if (!valid)
+        return;
+    if (mn == 0xffffffffu)
+        mn = 0;
+    double d[3];
+    double gl[3] = {0, 0, 0};
+    if (nn == 0)
+    {
+        // sum(gtLogs) == 0: reference-like triple, gtLogs stay untouched (all zero)
+        d[0] = 0;
+        d[1] = PD_LOG_PSEUDO;
+        d[2] = PD_LOG_PSEUDO;
+    }
+    else
+    {
+        const double l1 = log(prod) + (double)(esum - (int)nn) * PD_LN2;
+        gl[0] = t0;
+        gl[1] = log10(prod) + (double)(esum - (int)nn) * PD_LOG10_2;
+        gl[2] = t2;
+        const double maxGt = fmax(fmax(gl[0], gl[1]), gl[2]);
+        gl[0] -= maxGt;
+        gl[1] -= maxGt;
+        gl[2] -= maxGt;
+        if (eq)
+        {
+            gl[0] = gl[1] = gl[2] = 0;      // x87: a hair apart, not equal; all phred values round to 0
+        }
+        else if (gl[0] == gl[1] && gl[0] == gl[2])
+        {
+            gl[0] = 0;
+            gl[1] = -10;
+            gl[2] = -10;
+        }
+        const double logL[3] = {l0, l1, l2};
+        finishTriple(d, logL, nn, eq);
+    }
+    const size_t o = (size_t)cellIdx * co.nSamples + s;
+    b.dl[o * 3 + 0] = d[0];
+    b.dl[o * 3 + 1] = d[1];
+    b.dl[o * 3 + 2] = d[2];
+    uint32_t pl[3];
+    {
+        const double gTot = log10(exp(gl[0]) + exp(gl[1]) + exp(gl[2]));
+        const double p0 = -10 * (gl[0] - gTot);
+        const double p1 = -10 * (gl[1] - gTot);
+        const double p2 = -10 * (gl[2] - gTot);
+        const double mnP = fmin(fmin(p0, p1), p2);
+        pl[0] = (uint32_t)round(p0 - mnP);
+        pl[1] = (uint32_t)round(p1 - mnP);
+        pl[2] = (uint32_t)round(p2 - mnP);
+    }
+    if (flags[(size_t)s * nWindows + w] & 1u)
+        pl[0] = pl[1] = pl[2] = 0;
+    for (int c = 0; c < 3; ++c)
+    {
+        b.pl[o * 3 + c] = pl[c];
+        b.lad[o * 3 + c] = lad[c];
+    }
+    for (int c = 0; c < 5; ++c)
+        b.dad[o * 5 + c] = dad[c];
+    b.fl[o * 2 + 0] = mn;
+    b.fl[o * 2 + 1] = mx;
+}
+
 // Percentiles of the support pools (reference :514-529) by 4 x 8-bit radix selection. The pool of a cell is spread over
 // the contexts of a sharded cohort, so every pass is: digit histogram of the own pool (suppHistKernel) -> exchange ->
 // sum of the histograms, pick the digit (suppPickKernel). Pool 0: pair starts (80th percentile), pool 1: pair ends (20th).
@@ -1671,7 +1846,8 @@ void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers
     const unsigned ownTiles = (co.nSamples + kSamplesPerBlock - 1) / kSamplesPerBlock;
     const dim3 perSample(ownTiles, b.nCells), tile(kSampleTile);
     const dim3 perCell((b.nCells + 127) / 128), cellBlock(128);
-    hipLaunchKernelGGL(cellGatherKernel, perSample, tile, 0, st, seg, co, b, flags);
+    (void)hipMemsetAsync(b.tileMode, 0, (size_t)b.nCells * b.ownTiles * sizeof(unsigned), st);
+    hipLaunchKernelGGL(cellGatherKernel, dim3(b.ownTiles * 4, b.nCells), tile, 0, st, seg, co, b, flags);
     x.allGather(b.counters, (size_t)b.nCells * 4 * sizeof(unsigned));
     hipLaunchKernelGGL(cellInitFinishKernel, perCell, cellBlock, 0, st, b);
     hipLaunchKernelGGL(suppScanKernel, dim3(1), dim3(1), 0, st, b);
@@ -1731,7 +1907,9 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     x.allGather(b.xch, xchBytes);
     hipLaunchKernelGGL(cellConvergedKernel, perCell, cellBlock, 0, st, b, 1);
     hipLaunchKernelGGL(cellPostLoopKernel, perCell, cellBlock, 0, st, b);
-    hipLaunchKernelGGL(finalKernel, perSample, tile, 0, st, seg, co, b, flags);
+    hipLaunchKernelGGL(finalDenseKernel, perSample, tile, 0, st, co, b, flags, seg.nWindows);
+    if (anyGenericTile)
+        hipLaunchKernelGGL(finalKernel, perSample, tile, 0, st, seg, co, b, flags);
     for (int pass = 3; pass >= 0; --pass)
     {
         hipLaunchKernelGGL(suppHistKernel, dim3(b.nCells, 2), dim3(256), 0, st, b, pass);
