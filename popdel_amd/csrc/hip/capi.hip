@@ -16,9 +16,9 @@
 namespace pd {
 
 void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag, uint8_t * tileTodo,
-                  hipStream_t stream);
+                  unsigned * todoList, hipStream_t stream);
 void launchStage1Fallback(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
-                          const uint8_t * tileTodo, hipStream_t stream);
+                          const unsigned * todoList, hipStream_t stream);
 void launchPackFlagged(const int32_t * q3, const uint8_t * flags, const int * flaggedWindows, unsigned W, unsigned nLocal,
                        const ClusterInput & in, unsigned rank, hipStream_t st);
 void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,
@@ -192,6 +192,7 @@ struct pd_ctx
     DevBuf<uint8_t> dFlags;
     DevBuf<int> dWinFlag;
     DevBuf<uint8_t> dTileTodo;
+    DevBuf<unsigned> dTodoList;     // [0] = number of entries, then the 256-window tiles left to the fallback kernel
     uint32_t lastWindows = 0;
     std::vector<int32_t> hQ3View;
     std::vector<uint8_t> hFlagsView;
@@ -685,17 +686,19 @@ int pd_segment_run(pd_ctx * c, uint64_t handle, uint64_t * ticket)
         c->dFlags.ensure(cells);
         c->dWinFlag.ensure(s.nWindows);
         PD_HIP(hipMemsetAsync(c->dWinFlag.p, 0, s.nWindows * sizeof(int), c->stream));
+        const size_t tiles = static_cast<size_t>((s.nWindows + pd::kStage1Block - 1) / pd::kStage1Block) * c->nSamples;
+        c->dTileTodo.ensure(tiles);
+        c->dTodoList.ensure(tiles + 2);
+        PD_HIP(hipMemsetAsync(c->dTodoList.p, 0, sizeof(unsigned), c->stream));
         Run run;
         run.handle = handle;
         PD_HIP(hipEventCreate(&run.s1Begin));
         PD_HIP(hipEventCreate(&run.s1End));
         PD_HIP(hipEventRecord(run.s1Begin, c->stream));
-        const size_t tiles = static_cast<size_t>((s.nWindows + pd::kStage1Block - 1) / pd::kStage1Block) * c->nSamples;
-        c->dTileTodo.ensure(tiles);
-        pd::launchStage1(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTileTodo.p, c->stream);
+        pd::launchStage1(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTileTodo.p, c->dTodoList.p, c->stream);
         PD_HIP(hipGetLastError());
         PD_HIP(hipEventRecord(run.s1End, c->stream));
-        pd::launchStage1Fallback(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTileTodo.p, c->stream);
+        pd::launchStage1Fallback(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTodoList.p, c->stream);
         PD_HIP(hipGetLastError());
         if (getenv("POPDEL_HIP_DEBUG"))
         {

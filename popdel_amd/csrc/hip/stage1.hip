@@ -333,7 +333,8 @@ __device__ __forceinline__ void storeCell(unsigned n, unsigned maxLoad, int va, 
 // marked in tileTodo (one entry per 256 windows) and handled by stage1FallbackKernel.
 __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, CohortView co, int32_t * __restrict__ q3,
                                                              uint8_t * __restrict__ flags, int * __restrict__ winFlag,
-                                                             uint8_t * __restrict__ tileTodo, unsigned tilesPerSample)
+                                                             uint8_t * __restrict__ tileTodo, unsigned * __restrict__ todoList,
+                                                             unsigned tilesPerSample)
 {
     __shared__ PairPk ldsPairs[kPackedLdsPairs + 64];
     __shared__ uint32_t ldsWs[kPackedWsLen];
@@ -352,9 +353,16 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     {
         if (tid == 0)
         {
+            // todoList[0] counts the entries; the order of the list does not matter
+            const unsigned tile = s * tilesPerSample + 2u * blockIdx.x;
+            const unsigned at = atomicAdd(&todoList[0], secondTile ? 2u : 1u);
             todo[0] = 1;
+            todoList[1 + at] = tile;
             if (secondTile)
+            {
                 todo[1] = 1;
+                todoList[2 + at] = tile + 1;
+            }
         }
         return;
     }
@@ -414,9 +422,16 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     {
         if (tid == 0)
         {
+            // todoList[0] counts the entries; the order of the list does not matter
+            const unsigned tile = s * tilesPerSample + 2u * blockIdx.x;
+            const unsigned at = atomicAdd(&todoList[0], secondTile ? 2u : 1u);
             todo[0] = 1;
+            todoList[1 + at] = tile;
             if (secondTile)
+            {
                 todo[1] = 1;
+                todoList[2 + at] = tile + 1;
+            }
         }
         return;
     }
@@ -494,18 +509,18 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
 }
 
 // Tiles the main kernel skipped: 32-bit 64- or 128-input network where the LDS stage still fits, otherwise rank counting
-// straight from HBM. Persistent workgroups stride over the tile list so that an (almost) empty list costs nothing.
+// straight from HBM. Workgroups stride over the compact list the main kernel appended to (an empty list costs a launch).
 __global__ __launch_bounds__(kStage1Block) void stage1FallbackKernel(SegmentView seg, CohortView co, int32_t * __restrict__ q3,
                                                                      uint8_t * __restrict__ flags, int * __restrict__ winFlag,
-                                                                     const uint8_t * __restrict__ tileTodo,
-                                                                     unsigned tilesPerSample, unsigned nTiles)
+                                                                     const unsigned * __restrict__ todoList,
+                                                                     unsigned tilesPerSample)
 {
     __shared__ PairDO ldsPairs[kStage1LdsPairs + 128];
     __shared__ uint32_t ldsWs[kStage1Block + 64 + 2];
-    for (unsigned tile = blockIdx.x; tile < nTiles; tile += gridDim.x)
+    const unsigned nTodo = todoList[0];
+    for (unsigned k = blockIdx.x; k < nTodo; k += gridDim.x)
     {
-        if (!tileTodo[tile])
-            continue;                                              // block-uniform
+        const unsigned tile = todoList[1 + k];
         const unsigned s = tile / tilesPerSample;
         const unsigned w0 = (tile % tilesPerSample) * kStage1Block;
         const unsigned W = seg.nWindows;
@@ -569,21 +584,22 @@ __global__ __launch_bounds__(kStage1Block) void stage1FallbackKernel(SegmentView
 }
 
 void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
-                  uint8_t * tileTodo, hipStream_t stream)
+                  uint8_t * tileTodo, unsigned * todoList, hipStream_t stream)
 {
     const unsigned tilesPerSample = (seg.nWindows + kStage1Block - 1) / kStage1Block;
     dim3 grid((seg.nWindows + kPackedWindows - 1) / kPackedWindows, co.nSamples);
-    hipLaunchKernelGGL(stage1Kernel, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo, tilesPerSample);
+    hipLaunchKernelGGL(stage1Kernel, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo, todoList,
+                       tilesPerSample);
 }
 
 void launchStage1Fallback(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
-                          const uint8_t * tileTodo, hipStream_t stream)
+                          const unsigned * todoList, hipStream_t stream)
 {
     const unsigned tilesPerSample = (seg.nWindows + kStage1Block - 1) / kStage1Block;
     const unsigned nTiles = tilesPerSample * co.nSamples;
     const unsigned blocks = nTiles < 2048u ? nTiles : 2048u;
-    hipLaunchKernelGGL(stage1FallbackKernel, dim3(blocks), dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo,
-                       tilesPerSample, nTiles);
+    hipLaunchKernelGGL(stage1FallbackKernel, dim3(blocks), dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, todoList,
+                       tilesPerSample);
 }
 
 }  // namespace pd

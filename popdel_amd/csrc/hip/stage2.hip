@@ -683,16 +683,28 @@ __global__ void cellInitFinishKernel(Stage2Buffers b)
     cs.phase = kCellIterating;
 }
 
-// Exclusive scan of the support capacities (single lane; the cell list is short).
-__global__ void suppScanKernel(Stage2Buffers b)
+// Exclusive scan of the support capacities (one workgroup, 256 cells per round).
+__global__ __launch_bounds__(256) void suppScanKernel(Stage2Buffers b)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0)
-        return;
-    uint64_t off = 0;
-    for (unsigned c = 0; c < b.nCells; ++c)
+    __shared__ uint64_t sh[256];
+    uint64_t carry = 0;
+    for (unsigned base = 0; base < b.nCells; base += 256u)
     {
-        b.cells[c].suppBase = off;
-        off += b.cells[c].suppCapacity;
+        const unsigned c = base + threadIdx.x;
+        const uint64_t v = c < b.nCells ? b.cells[c].suppCapacity : 0u;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (unsigned o = 1; o < 256u; o <<= 1)
+        {
+            const uint64_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (c < b.nCells)
+            b.cells[c].suppBase = carry + sh[threadIdx.x] - v;
+        carry += sh[255];
+        __syncthreads();
     }
 }
 
@@ -1196,21 +1208,43 @@ __global__ __launch_bounds__(kSampleTile) void updateLenDenseKernel(CohortView c
     }
 }
 
-__global__ void cellLenFinishKernel(Stage2Buffers b)
+// Per-cell kernels that add up per-tile sums run ONE WAVE PER CELL: the lanes fetch the tiles in parallel, the additions
+// stay sequential in cohort tile order (bit-identical to a single-lane loop, without its chain of dependent loads).
+// Result valid in every lane.
+__device__ __forceinline__ void waveTileSums(const Stage2Buffers & b, unsigned c, double & s0, double & s1, double & s2)
 {
-    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= b.nCells)
-        return;
+    s0 = s1 = s2 = 0;
+    const unsigned lane = threadIdx.x & 63u;
+    for (unsigned base = 0; base < b.nTiles; base += 64u)
+    {
+        double v0 = 0, v1 = 0, v2 = 0;
+        if (base + lane < b.nTiles)
+        {
+            const double * p = tileSlot(b, c, base + lane);
+            v0 = p[0];
+            v1 = p[1];
+            v2 = p[2];
+        }
+        const unsigned cnt = min(64u, b.nTiles - base);
+        for (unsigned i = 0; i < cnt; ++i)
+        {
+            s0 += __shfl(v0, (int)i, 64);
+            s1 += __shfl(v1, (int)i, 64);
+            s2 += __shfl(v2, (int)i, 64);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void cellLenFinishKernel(Stage2Buffers b)
+{
+    const unsigned c = blockIdx.x;
     CellState & cs = b.cells[c];
     if (cs.phase != kCellIterating)
         return;
-    double sumDel = 0, wSumDel = 0;
-    for (unsigned t = 0; t < b.nTiles; ++t)
-    {
-        const double * p = tileSlot(b, c, t);
-        sumDel += p[0];
-        wSumDel += p[1];
-    }
+    double sumDel, wSumDel, unused;
+    waveTileSums(b, c, sumDel, wSumDel, unused);
+    if (threadIdx.x != 0)
+        return;
     unsigned len;
     if (sumDel == 0)
         len = 0;
@@ -1223,13 +1257,15 @@ __global__ void cellLenFinishKernel(Stage2Buffers b)
 }
 
 // Allele-frequency update and convergence test (reference :623-659).
-__global__ void cellFreqFinishKernel(Stage2Buffers b, unsigned iteration)
+__global__ __launch_bounds__(64) void cellFreqFinishKernel(Stage2Buffers b, unsigned iteration)
 {
-    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= b.nCells)
-        return;
+    const unsigned c = blockIdx.x;
     CellState & cs = b.cells[c];
     if (cs.phase != kCellIterating)
+        return;
+    double unused0, unused1, sum;
+    waveTileSums(b, c, unused0, unused1, sum);
+    if (threadIdx.x != 0)
         return;
     struct Mark
     {
@@ -1241,9 +1277,6 @@ __global__ void cellFreqFinishKernel(Stage2Buffers b, unsigned iteration)
                 *flag = 1u;               // every writer stores the same value
         }
     } mark{cs, b.iterFlags + iteration};
-    double sum = 0;
-    for (unsigned t = 0; t < b.nTiles; ++t)
-        sum += tileSlot(b, c, t)[2];
     const double freq = sum / 2.0 / b.nSamplesGlobal;
     cs.freq = freq;
     if (freq == 0)
@@ -1293,33 +1326,29 @@ __global__ __launch_bounds__(kSampleTile) void lrKernel(CohortView co, Stage2Buf
     }
 }
 
-__device__ __forceinline__ double sumLR(const Stage2Buffers & b, unsigned c)
+__device__ __forceinline__ double sumLR(const Stage2Buffers & b, unsigned c)       // by one wave, see waveTileSums
 {
-    double del = 0, noDel = 0;
-    for (unsigned t = 0; t < b.nTiles; ++t)
-    {
-        const double * p = tileSlot(b, c, t);
-        del += p[0];
-        noDel += p[1];
-    }
+    double del, noDel, unused;
+    waveTileSums(b, c, del, noDel, unused);
     return del - noDel;
 }
 
 // step 0: store LR of the current estimate; step 1: store LR of the previous estimate and keep the better one.
-__global__ void cellConvergedKernel(Stage2Buffers b, int step)
+__global__ __launch_bounds__(64) void cellConvergedKernel(Stage2Buffers b, int step)
 {
-    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= b.nCells)
-        return;
+    const unsigned c = blockIdx.x;
     CellState & cs = b.cells[c];
     if (cs.phase != kCellConverged)
         return;
+    const double lr = sumLR(b, c);
+    if (threadIdx.x != 0)
+        return;
     if (step == 0)
     {
-        cs.logLR = sumLR(b, c);
+        cs.logLR = lr;
         return;
     }
-    cs.prevLogLR = sumLR(b, c);
+    cs.prevLogLR = lr;
     if (cs.prevLogLR > cs.logLR)
     {
         cs.len = cs.prevLen;
@@ -1783,20 +1812,22 @@ __global__ void suppFinishKernel(Stage2Buffers b)
 }
 
 // Likelihood-ratio test and call emission (reference :685-724).
-__global__ void cellEmitKernel(Stage2Buffers b)
+__global__ __launch_bounds__(64) void cellEmitKernel(Stage2Buffers b)
 {
-    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= b.nCells)
-        return;
+    const unsigned c = blockIdx.x;
     CellState & cs = b.cells[c];
     if (cs.phase != kCellFinal)
         return;
-    if (cs.suppCount == 0 || (cs.suppStart == 0 && cs.suppEnd == 0))
+    const bool noSupport = cs.suppCount == 0 || (cs.suppStart == 0 && cs.suppEnd == 0);      // wave-uniform
+    const double lr = noSupport ? 0.0 : sumLR(b, c);
+    if (threadIdx.x != 0)
+        return;
+    if (noSupport)
     {
         cs.phase = kCellDead;
         return;
     }
-    cs.logLR = sumLR(b, c);
+    cs.logLR = lr;
     cs.phase = (cs.logLR >= b.minLR) ? kCellEmit : kCellDead;
 }
 
@@ -1850,7 +1881,7 @@ void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers
     hipLaunchKernelGGL(cellGatherKernel, dim3(b.ownTiles * 4, b.nCells), tile, 0, st, seg, co, b, flags);
     x.allGather(b.counters, (size_t)b.nCells * 4 * sizeof(unsigned));
     hipLaunchKernelGGL(cellInitFinishKernel, perCell, cellBlock, 0, st, b);
-    hipLaunchKernelGGL(suppScanKernel, dim3(1), dim3(1), 0, st, b);
+    hipLaunchKernelGGL(suppScanKernel, dim3(1), dim3(256), 0, st, b);
 }
 
 // Phase B: EM loop, convergence comparison, final pass, support percentiles, likelihood-ratio test.
@@ -1863,7 +1894,7 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
         return;
     const unsigned ownTiles = (co.nSamples + kSamplesPerBlock - 1) / kSamplesPerBlock;
     const dim3 perSample(ownTiles, b.nCells), tile(kSampleTile);
-    const dim3 perCell((b.nCells + 127) / 128), cellBlock(128);
+    const dim3 perCell((b.nCells + 127) / 128), cellBlock(128), wavePerCell(b.nCells);
     const size_t xchBytes = b.xchChunk * sizeof(double);
     // every (cell, tile) is served by exactly one of the two kernels of a pair (tileMode)
     auto dataLik = [&](int mode) {
@@ -1883,10 +1914,10 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
         if (anyGenericTile)
             hipLaunchKernelGGL(updateLenKernel, perSample, tile, 0, st, seg, co, b);
         x.allGather(b.xch, xchBytes);
-        hipLaunchKernelGGL(cellLenFinishKernel, perCell, cellBlock, 0, st, b);
+        hipLaunchKernelGGL(cellLenFinishKernel, wavePerCell, dim3(64), 0, st, b);
         dataLik(0);
         x.allGather(b.xch, xchBytes);
-        hipLaunchKernelGGL(cellFreqFinishKernel, perCell, cellBlock, 0, st, b, it);
+        hipLaunchKernelGGL(cellFreqFinishKernel, wavePerCell, dim3(64), 0, st, b, it);
         // Most cells leave the loop after 2-4 iterations: look at the "someone is still iterating" flag now and then
         // instead of launching the remaining (empty) iterations.
         if (it == 2 || it == 4 || it == 7 || it == 10)
@@ -1901,11 +1932,11 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     // cells that left through the visited-table test: compare with the previous estimate
     hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellConverged, 0);
     x.allGather(b.xch, xchBytes);
-    hipLaunchKernelGGL(cellConvergedKernel, perCell, cellBlock, 0, st, b, 0);
+    hipLaunchKernelGGL(cellConvergedKernel, wavePerCell, dim3(64), 0, st, b, 0);
     dataLik(1);
     hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellConverged, 1);
     x.allGather(b.xch, xchBytes);
-    hipLaunchKernelGGL(cellConvergedKernel, perCell, cellBlock, 0, st, b, 1);
+    hipLaunchKernelGGL(cellConvergedKernel, wavePerCell, dim3(64), 0, st, b, 1);
     hipLaunchKernelGGL(cellPostLoopKernel, perCell, cellBlock, 0, st, b);
     hipLaunchKernelGGL(finalDenseKernel, perSample, tile, 0, st, co, b, flags, seg.nWindows);
     if (anyGenericTile)
@@ -1919,7 +1950,7 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     hipLaunchKernelGGL(suppFinishKernel, perCell, cellBlock, 0, st, b);
     hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellFinal, 0);
     x.allGather(b.xch, xchBytes);
-    hipLaunchKernelGGL(cellEmitKernel, perCell, cellBlock, 0, st, b);
+    hipLaunchKernelGGL(cellEmitKernel, wavePerCell, dim3(64), 0, st, b);
 }
 
 void launchGatherOut(const Stage2Buffers & b, const unsigned * emitCells, unsigned nEmit, unsigned nSamples, uint32_t * pl,
