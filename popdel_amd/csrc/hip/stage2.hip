@@ -373,6 +373,7 @@ __global__ __launch_bounds__(256) void clusterKernel(ClusterInput in, int unifor
                                                      unsigned rowLen, int * __restrict__ candLen, int * __restrict__ candCount)
 {
     __shared__ int hist[kClusterBins];
+    __shared__ unsigned occ[kClusterBins / 32];
     __shared__ unsigned nValid;
     __shared__ int vMin, vMax;
     const unsigned fw = blockIdx.x;
@@ -415,28 +416,41 @@ __global__ __launch_bounds__(256) void clusterKernel(ClusterInput in, int unifor
         __syncthreads();
         forEachValidQ3(in, fw, [&](int v) { atomicAdd(&hist[v - base], 1); });
         __syncthreads();
+        // occupancy bitmap, built by all lanes, so that the single lane below only visits occupied bins
+        const int nWords = ((int)range + 31) / 32;
+        for (int wd = threadIdx.x; wd < nWords; wd += blockDim.x)
+        {
+            unsigned bits = 0;
+            for (int k = 0; k < 32; ++k)
+                if (wd * 32 + k < (int)range && hist[wd * 32 + k] != 0)
+                    bits |= 1u << k;
+            occ[wd] = bits;
+        }
+        __syncthreads();
         if (threadIdx.x == 0)
         {
             int nc = 0;
             int sum = 0, n = 0, prev = 0;
             unsigned rank = 0, i0 = 0;
-            for (int bin = 0; bin < (int)range; ++bin)
+            for (int wd = 0; wd < nWords; ++wd)
             {
-                const int c = hist[bin];
-                if (c == 0)
-                    continue;
-                const int v = base + bin;
-                if (n != 0 && !(prev + 50 > v))
+                for (unsigned bits = occ[wd]; bits != 0; bits &= bits - 1u)
                 {
-                    emitCluster(sum, n, thresholdOfRanks(in, uniformThreshold, i0, rank - 1), candLen, fw, nc);
-                    sum = 0;
-                    n = 0;
-                    i0 = rank;
+                    const int bin = wd * 32 + (__ffs((int)bits) - 1);
+                    const int c = hist[bin];
+                    const int v = base + bin;
+                    if (n != 0 && !(prev + 50 > v))
+                    {
+                        emitCluster(sum, n, thresholdOfRanks(in, uniformThreshold, i0, rank - 1), candLen, fw, nc);
+                        sum = 0;
+                        n = 0;
+                        i0 = rank;
+                    }
+                    sum += v * c;
+                    n += c;
+                    rank += (unsigned)c;
+                    prev = v;
                 }
-                sum += v * c;
-                n += c;
-                rank += (unsigned)c;
-                prev = v;
             }
             emitCluster(sum, n, thresholdOfRanks(in, uniformThreshold, i0, rank - 1), candLen, fw, nc);
             candCount[fw] = nc;
@@ -888,6 +902,16 @@ __device__ __forceinline__ long long lanePos(const LaneRg & l, int deviation)
     return (long long)(l.histBase + (unsigned)i);
 }
 
+// Table position for the dense loops (clamped to the table's first entry when outside). Rows beyond a lane's own count
+// hold zeros or stale values and are masked by `use`. (Loading unconditionally and selecting afterwards was measured
+// 1.7x slower: every lane reads its own sample's table, so each lookup costs the L1 a whole cache line.)
+__device__ __forceinline__ uint64_t lanePosClamped(const LaneRg & l, int deviation, bool & inside)
+{
+    const int i = deviation + l.base;
+    inside = !(i <= 0 || i + 1 >= l.histLen);
+    return l.histBase + (inside ? (unsigned)i : 0u);
+}
+
 __global__ __launch_bounds__(kSampleTile) void dataLikDenseKernel(CohortView co, Stage2Buffers b, int mode)
 {
     __shared__ double red[4];
@@ -918,32 +942,27 @@ __global__ __launch_bounds__(kSampleTile) void dataLikDenseKernel(CohortView co,
     double g0 = 0, g2 = 0, prod = 1.0;
     int esum = 0;
     bool eq = true;
+#pragma unroll 4
     for (unsigned j = 0; j < rows; ++j)
     {
-        if (j < nn)
-        {
-            const int dv = col[j * 64];
-            const long long pr = lanePos(l, dv - refShift), pdl = lanePos(l, dv - len);
-            double ref = l.minProb, lref = l.logMinProb, del = l.minProb, ldel = l.logMinProb;
-            if (pr >= 0)
-            {
-                const double2 t = *reinterpret_cast<const double2 *>(&co.tab[pr]);
-                ref = t.x;
-                lref = t.y;
-            }
-            if (pdl >= 0)
-            {
-                const double2 t = *reinterpret_cast<const double2 *>(&co.tab[pdl]);
-                del = t.x;
-                ldel = t.y;
-            }
-            g0 += lref;
-            g2 += ldel;
-            int e;
-            prod *= frexp(ref + del, &e);
-            esum += e;
-            eq = eq && (ref == del);
-        }
+        const bool use = j < nn;
+        const int dv = col[j * 64];
+        bool inR, inD;
+        const uint64_t pr = lanePosClamped(l, dv - refShift, inR), pdl = lanePosClamped(l, dv - len, inD);
+        // only in-range lookups touch memory: every lane reads its own sample's table, so each one costs a cache line
+        double2 tr = make_double2(l.minProb, l.logMinProb), td = tr;
+        if (use && inR)
+            tr = *reinterpret_cast<const double2 *>(&co.tab[pr]);
+        if (use && inD)
+            td = *reinterpret_cast<const double2 *>(&co.tab[pdl]);
+        const double ref = tr.x, lref = tr.y, del = td.x, ldel = td.y;
+        int e;
+        const double m = frexp(ref + del, &e);
+        g0 += use ? lref : 0.0;
+        g2 += use ? ldel : 0.0;
+        prod *= use ? m : 1.0;
+        esum += use ? e : 0;
+        eq = eq && (!use || ref == del);
     }
     if (valid)
     {
@@ -1170,21 +1189,24 @@ __global__ __launch_bounds__(kSampleTile) void updateLenDenseKernel(CohortView c
     const bool highCov = n == kDenseHighCov;
     const unsigned nn = highCov ? 0u : n;
     double sumDel = 0, wSumDel = 0, sumRef = 0, wSumRef = 0;
+#pragma unroll 4
     for (unsigned j = 0; j < rows; ++j)
     {
-        if (j < nn)
-        {
-            const int dv = col[j * 64];
-            const long long pd_ = lanePos(l, dv - len), pn = lanePos(l, dv - refShift);
-            const double del = pd_ >= 0 ? co.hist[pd_] : l.minProb;
-            const double noDel = pn >= 0 ? co.hist[pn] : l.minProb;
-            const double probDel = ea1 * del / (del + noDel) + ea2;
-            const double probRef = ea1Rg * noDel / (del + noDel) + ea0Rg;
-            sumDel += probDel;
-            sumRef += probRef;
-            wSumDel += probDel * dv;
-            wSumRef += probRef * dv;
-        }
+        const bool use = j < nn;
+        const int dv = col[j * 64];
+        bool inD, inN;
+        const uint64_t pd_ = lanePosClamped(l, dv - len, inD), pn = lanePosClamped(l, dv - refShift, inN);
+        double del = l.minProb, noDel = l.minProb;
+        if (use && inD)
+            del = co.hist[pd_];
+        if (use && inN)
+            noDel = co.hist[pn];
+        const double probDel = ea1 * del / (del + noDel) + ea2;
+        const double probRef = ea1Rg * noDel / (del + noDel) + ea0Rg;
+        sumDel += use ? probDel : 0.0;
+        sumRef += use ? probRef : 0.0;
+        wSumDel += use ? probDel * dv : 0.0;
+        wSumRef += use ? probRef * dv : 0.0;
     }
     if (valid && !highCov)
     {
