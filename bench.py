@@ -141,8 +141,13 @@ def main():
     my_passes = len(distributed.shard_segments(total_passes * world, rank, world))
 
     def passes_on(c, h, n, acc):
-        for _ in range(n):
-            res = c.collect(c.run(h), copy=False)
+        # software-pipelined the way a streaming host drives the library: the next segment's ticket is issued before
+        # the open one is collected, so its scan starts behind the open segment's last kernel, under the result D2H
+        ticket = c.run(h) if n else None
+        for i in range(n):
+            nxt = c.run(h) if i + 1 < n else None
+            res = c.collect(ticket, copy=False)
+            ticket = nxt
             t = c.timing()
             acc[0] += t["stage1_ms"]
             acc[1] += t["stage2_ms"]
@@ -253,8 +258,11 @@ def main():
         x0 = shard.exchange.calls, shard.exchange.bytes
         sync()
         q0 = time.perf_counter()
-        for _ in range(args.sharded_passes):
-            calls += shard.ctx.collect(shard.ctx.run(h), copy=False)["n_calls"]
+        ticket = shard.ctx.run(h)
+        for i in range(args.sharded_passes):
+            nxt = shard.ctx.run(h) if i + 1 < args.sharded_passes else None
+            calls += shard.ctx.collect(ticket, copy=False)["n_calls"]
+            ticket = nxt
         sync()
         dt = time.perf_counter() - q0
         tt = torch.tensor([dt], device=red_device, dtype=torch.float64)

@@ -140,7 +140,10 @@ int pd_segment_submit(pd_ctx *ctx, const pd_segment *seg, uint64_t *ticket);
  * buffered: pd_segment_stage() copies a segment into HBM (returns a handle), pd_segment_run() enqueues the window
  * loop for a staged segment (may be repeated), pd_segment_unstage() releases it.
  * pd_segment_submit(seg) == stage + run + unstage-after-collect. No reference counterpart (the reference computes
- * in place on the host). */
+ * in place on the host).
+ * Tickets: at most two may be outstanding per context, collected in the order issued. Issuing the next ticket BEFORE
+ * collecting the open one lets the library start the next segment's scan right behind the open segment's last kernel,
+ * underneath the device-to-host copy of its results (software pipelining across segments). */
 int pd_segment_stage(pd_ctx *ctx, const pd_segment *seg, uint64_t *handle);
 int pd_segment_run(pd_ctx *ctx, uint64_t handle, uint64_t *ticket);
 int pd_segment_unstage(pd_ctx *ctx, uint64_t handle);
@@ -200,7 +203,8 @@ int pd_segment_collect(pd_ctx *ctx, uint64_t ticket, pd_calls **out);
 
 void pd_calls_free(pd_calls *calls);
 
-/* Stage-1 values of the most recently collected segment; valid until the next submit. */
+/* Stage-1 values of the most recently collected segment; valid until the next submit/run (also one issued before
+ * that collect). */
 int pd_stage1_last(pd_ctx *ctx, pd_stage1_view *out);
 
 /* Text of the last error on this context (or of the last failed pd_ctx_create if ctx == NULL). */

@@ -150,6 +150,7 @@ struct Run
 {
     uint64_t handle = 0;
     hipEvent_t s1Begin = nullptr, s1End = nullptr;
+    bool launched = false;          // false: accepted while the previous ticket was still open, scan not enqueued yet
 };
 
 }  // namespace
@@ -162,6 +163,8 @@ struct pd_ctx
     std::vector<uint32_t> sampleRg;
     std::string error;
     hipStream_t stream = nullptr;
+    hipStream_t copyStream = nullptr;   // result D2H, so that the next segment's scan can run underneath it
+    hipEvent_t resultsPacked = nullptr;
     DevBuf<pd::RgConst> dRg;
     DevBuf<double> dHist;
     DevBuf<double4> dTab;
@@ -214,6 +217,10 @@ struct pd_ctx
     {
         staged.clear();
         spare.clear();
+        if (resultsPacked)
+            (void)hipEventDestroy(resultsPacked);
+        if (copyStream)
+            (void)hipStreamDestroy(copyStream);
         if (stream)
             (void)hipStreamDestroy(stream);
     }
@@ -491,6 +498,8 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
         c->nSamples = n_samples;
         c->sampleRg.assign(sample_rg_offsets, sample_rg_offsets + n_samples + 1);
         PD_HIP(hipStreamCreate(&c->stream));
+        PD_HIP(hipStreamCreate(&c->copyStream));
+        PD_HIP(hipEventCreateWithFlags(&c->resultsPacked, hipEventDisableTiming));
         std::vector<pd::RgConst> rc(n_readgroups);
         std::vector<double> pool;
         int minThreshold = 0x7fffffff;
@@ -668,6 +677,42 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
     return 0;
 }
 
+// Enqueues the stage-1 scan of a run on the context's stream.
+static void launchScan(pd_ctx * c, Run & run)
+{
+    auto sit = c->staged.find(run.handle);
+    if (sit == c->staged.end())
+        throw HipError{"the segment of a waiting ticket was unstaged"};
+    StagedSegment & s = *sit->second;
+    const size_t cells = static_cast<size_t>(c->nSamples) * s.nWindows;
+    c->dQ3.ensure(cells);
+    c->dFlags.ensure(cells);
+    c->dWinFlag.ensure(s.nWindows);
+    PD_HIP(hipMemsetAsync(c->dWinFlag.p, 0, s.nWindows * sizeof(int), c->stream));
+    const size_t tiles = static_cast<size_t>((s.nWindows + pd::kStage1Block - 1) / pd::kStage1Block) * c->nSamples;
+    c->dTileTodo.ensure(tiles);
+    c->dTodoList.ensure(tiles + 2);
+    PD_HIP(hipMemsetAsync(c->dTodoList.p, 0, sizeof(unsigned), c->stream));
+    PD_HIP(hipEventRecord(run.s1Begin, c->stream));
+    pd::launchStage1(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTileTodo.p, c->dTodoList.p, c->stream);
+    PD_HIP(hipGetLastError());
+    PD_HIP(hipEventRecord(run.s1End, c->stream));
+    pd::launchStage1Fallback(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTodoList.p, c->stream);
+    PD_HIP(hipGetLastError());
+    if (getenv("POPDEL_HIP_DEBUG"))
+    {
+        std::vector<uint8_t> todo(tiles);
+        PD_HIP(hipMemcpyAsync(todo.data(), c->dTileTodo.p, tiles, hipMemcpyDeviceToHost, c->stream));
+        PD_HIP(hipStreamSynchronize(c->stream));
+        size_t nTodo = 0;
+        for (uint8_t t : todo)
+            nTodo += t != 0;
+        fprintf(stderr, "[popdel_hip] stage 1: %zu of %zu tiles went to the fallback kernel (K=%u)\n", nTodo, tiles, s.maxLife);
+    }
+    c->lastWindows = s.nWindows;
+    run.launched = true;
+}
+
 int pd_segment_run(pd_ctx * c, uint64_t handle, uint64_t * ticket)
 {
     if (!c || !ticket)
@@ -675,44 +720,22 @@ int pd_segment_run(pd_ctx * c, uint64_t handle, uint64_t * ticket)
     auto it = c->staged.find(handle);
     if (it == c->staged.end())
         return fail(c, "pd_segment_run: unknown segment handle");
-    if (!c->runs.empty())
-        return fail(c, "pd_segment_run: the previous ticket has not been collected (one ticket in flight per context)");
+    // One ticket may be open plus one waiting: the waiting one's scan is enqueued by pd_segment_collect() of the open one,
+    // right behind its last kernel, so that it runs while the open ticket's results travel to the host.
+    if (c->runs.size() >= 2 || (c->runs.size() == 1 && !c->runs.begin()->second.launched))
+        return fail(c, "pd_segment_run: two tickets are already outstanding (collect the older one first)");
     try
     {
         PD_HIP(hipSetDevice(c->device));
-        StagedSegment & s = *it->second;
-        const size_t cells = static_cast<size_t>(c->nSamples) * s.nWindows;
-        c->dQ3.ensure(cells);
-        c->dFlags.ensure(cells);
-        c->dWinFlag.ensure(s.nWindows);
-        PD_HIP(hipMemsetAsync(c->dWinFlag.p, 0, s.nWindows * sizeof(int), c->stream));
-        const size_t tiles = static_cast<size_t>((s.nWindows + pd::kStage1Block - 1) / pd::kStage1Block) * c->nSamples;
-        c->dTileTodo.ensure(tiles);
-        c->dTodoList.ensure(tiles + 2);
-        PD_HIP(hipMemsetAsync(c->dTodoList.p, 0, sizeof(unsigned), c->stream));
         Run run;
         run.handle = handle;
         PD_HIP(hipEventCreate(&run.s1Begin));
         PD_HIP(hipEventCreate(&run.s1End));
-        PD_HIP(hipEventRecord(run.s1Begin, c->stream));
-        pd::launchStage1(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTileTodo.p, c->dTodoList.p, c->stream);
-        PD_HIP(hipGetLastError());
-        PD_HIP(hipEventRecord(run.s1End, c->stream));
-        pd::launchStage1Fallback(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTodoList.p, c->stream);
-        PD_HIP(hipGetLastError());
-        if (getenv("POPDEL_HIP_DEBUG"))
-        {
-            std::vector<uint8_t> todo(tiles);
-            PD_HIP(hipMemcpyAsync(todo.data(), c->dTileTodo.p, tiles, hipMemcpyDeviceToHost, c->stream));
-            PD_HIP(hipStreamSynchronize(c->stream));
-            size_t nTodo = 0;
-            for (uint8_t t : todo)
-                nTodo += t != 0;
-            fprintf(stderr, "[popdel_hip] stage 1: %zu of %zu tiles went to the fallback kernel (K=%u)\n", nTodo, tiles, s.maxLife);
-        }
-        c->lastWindows = s.nWindows;
         *ticket = c->nextTicket++;
-        c->runs[*ticket] = run;
+        auto & slot = c->runs[*ticket];
+        slot = run;
+        if (c->runs.size() == 1)
+            launchScan(c, slot);
     }
     catch (const HipError & e)
     {
@@ -758,6 +781,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
     auto rit = c->runs.find(ticket);
     if (rit == c->runs.end())
         return fail(c, "pd_segment_collect: unknown ticket");
+    if (rit != c->runs.begin())
+        return fail(c, "pd_segment_collect: tickets are collected in the order they were issued");
     Run run = rit->second;
     c->runs.erase(rit);
     auto sit = c->staged.find(run.handle);
@@ -769,6 +794,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
     try
     {
         PD_HIP(hipSetDevice(c->device));
+        if (!run.launched)              // the collect that should have started it failed
+            launchScan(c, run);
         const uint32_t W = s.nWindows, S = c->nSamples;
         const pd::SegmentView view = viewOf(s);
         PD_HIP(hipEventCreate(&s2Begin));
@@ -943,10 +970,20 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             uint32_t *dPl = c->dOutPl.p, *dLad = dPl + perSample * 3, *dDad = dLad + perSample * 3, *dFl = dDad + perSample * 5;
             pd::launchGatherOut(b, c->dEmit.p, n, S, dPl, dLad, dDad, dFl, c->stream);
             PD_HIP(hipGetLastError());
-            PD_HIP(hipMemcpyAsync(hPl, dPl, perSample * 13 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         }
         PD_HIP(hipEventRecord(s2End, c->stream));
-        PD_HIP(hipStreamSynchronize(c->stream));
+        if (n != 0)
+        {
+            // results travel on the copy stream ...
+            PD_HIP(hipEventRecord(c->resultsPacked, c->stream));
+            PD_HIP(hipStreamWaitEvent(c->copyStream, c->resultsPacked, 0));
+            PD_HIP(hipMemcpyAsync(hPl, c->dOutPl.p, perSample * 13 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->copyStream));
+        }
+        // ... while the scan of a waiting ticket starts right behind this segment's last kernel
+        if (!c->runs.empty() && !c->runs.begin()->second.launched)
+            launchScan(c, c->runs.begin()->second);
+        PD_HIP(hipEventSynchronize(s2End));
+        PD_HIP(hipStreamSynchronize(c->copyStream));
 
         float ms1 = 0, ms2 = 0;
         PD_HIP(hipEventElapsedTime(&ms1, run.s1Begin, run.s1End));

@@ -157,3 +157,36 @@ def test_wide_q3_range_takes_the_sorting_path(built):
     assert cpu[1].max() - cpu[1].min() > 8192
     assert cpu[0]["n_calls"] > 20
     assert_same(gpu, cpu)
+
+
+def test_two_tickets_pipelined_equal_sequential(built):
+    """A second ticket may be issued before the open one is collected (its scan then starts underneath the result copy
+    of the open one); results must equal the one-at-a-time order, a third ticket and out-of-order collects are refused."""
+    from popdel_amd import capi, synth
+    lib = synth.Library()
+    rg = synth.conditioned_readgroup(lib)
+    n = 20
+    segs = [synth.cohort_segment(n, (1000000 + k * 60000, 1000000 + (k + 1) * 60000), 1000020 + k * 60000, 1900, lib,
+                                 deletions=lambda j, r, k=k: [synth.Deletion(r[0] + 20000, 600 + 300 * k, [1, 2, 0][(j + k) % 3])])
+            for k in range(3)]
+    ctx = capi.Context(capi.load_hip(), [rg] * n, list(range(n + 1)))
+    handles = [ctx.stage(s) for s in segs]
+    sequential = [ctx.collect(ctx.run(h)) for h in handles]
+    assert all(r["n_calls"] > 5 for r in sequential)
+    piped = []
+    ticket = ctx.run(handles[0])
+    for i in range(3):
+        nxt = ctx.run(handles[i + 1]) if i + 1 < 3 else None
+        if nxt is not None:
+            with pytest.raises(capi.BackendError):
+                ctx.run(handles[0])                      # a third outstanding ticket
+            with pytest.raises(capi.BackendError):
+                ctx.collect(nxt)                         # out of order
+        piped.append(ctx.collect(ticket))
+        ticket = nxt
+    for a, b in zip(piped, sequential):
+        for k, v in b.items():
+            assert np.array_equal(np.asarray(a[k]), np.asarray(v)), k
+    for h in handles:
+        ctx.unstage(h)
+    ctx.close()
