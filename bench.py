@@ -95,6 +95,10 @@ def main():
     ap.add_argument("--sharded-passes", type=int, default=40,
                     help="passes of the secondary sample-sharded leg (N > 1 only; 0 switches it off)")
     ap.add_argument("--sharded-timeout", type=float, default=240.0, help="give up on the secondary leg after this many seconds")
+    ap.add_argument("--serial", action="store_true",
+                    help="one ticket at a time (no pipelining across segments). Used for the rocprofv3 kernel trace: under "
+                         "the profiler the result copy runs as a blit KERNEL that competes with the next scan, which "
+                         "inflates the scan's traced duration; un-profiled runs copy over SDMA")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: all ranks use GPU 0 (needs --backend gloo)")
     ap.add_argument("--contexts", type=int, default=1,
@@ -145,9 +149,9 @@ def main():
         # the open one is collected, so its scan starts behind the open segment's last kernel, under the result D2H
         ticket = c.run(h) if n else None
         for i in range(n):
-            nxt = c.run(h) if i + 1 < n else None
+            nxt = c.run(h) if (i + 1 < n and not args.serial) else None
             res = c.collect(ticket, copy=False)
-            ticket = nxt
+            ticket = nxt if not args.serial else (c.run(h) if i + 1 < n else None)
             t = c.timing()
             acc[0] += t["stage1_ms"]
             acc[1] += t["stage2_ms"]
@@ -292,7 +296,7 @@ def main():
                        "planted_deletion": planted, "parallelism": "%d rank(s), each a chr20-sized set of segments (no collective in the data path)" % world},
             "stage1_ms_per_step": s1_ms / args.steps, "stage2_ms_per_step": s2_ms / args.steps,
             "calls_per_step": n_calls / args.steps, "candidate_cells_per_step": n_cand / args.steps,
-            "max_life": tinfo["max_life"], "contexts_per_gpu": args.contexts,
+            "max_life": tinfo["max_life"], "contexts_per_gpu": args.contexts, "pipelined_tickets": not args.serial,
             # host arrays -> chunked layout -> HBM for one segment of all samples (single host thread + PCIe); with it
             # inside every pass the rate would be cells_per_pass / (stage_seconds + pass time): reported, never `value`
             "staging_seconds_per_segment": stage_seconds,

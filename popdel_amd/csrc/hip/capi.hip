@@ -973,15 +973,18 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         }
         PD_HIP(hipEventRecord(s2End, c->stream));
         if (n != 0)
-        {
-            // results travel on the copy stream ...
             PD_HIP(hipEventRecord(c->resultsPacked, c->stream));
+        // the scan of a waiting ticket starts right behind this segment's last kernel ...
+        // (enqueued BEFORE the copy: the other order was measured to hold the scan's first packets back until the copy,
+        // a blit kernel on this platform, had finished)
+        if (!c->runs.empty() && !c->runs.begin()->second.launched)
+            launchScan(c, c->runs.begin()->second);
+        if (n != 0)
+        {
+            // ... while the results travel on the copy stream
             PD_HIP(hipStreamWaitEvent(c->copyStream, c->resultsPacked, 0));
             PD_HIP(hipMemcpyAsync(hPl, c->dOutPl.p, perSample * 13 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->copyStream));
         }
-        // ... while the scan of a waiting ticket starts right behind this segment's last kernel
-        if (!c->runs.empty() && !c->runs.begin()->second.launched)
-            launchScan(c, c->runs.begin()->second);
         PD_HIP(hipEventSynchronize(s2End));
         PD_HIP(hipStreamSynchronize(c->copyStream));
 

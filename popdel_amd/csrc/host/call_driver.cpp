@@ -17,7 +17,7 @@ constexpr unsigned kNoPos = std::numeric_limits<unsigned>::max();
 // Wall-clock split of the host phases, printed at exit when POPDEL_TIMING is set.
 struct PhaseClock
 {
-    double switches = 0, decode = 0, replay = 0, walk = 0, flatten = 0, submit = 0, collect = 0, merge = 0;
+    double params = 0, backend = 0, switches = 0, decode = 0, replay = 0, walk = 0, flatten = 0, submit = 0, collect = 0, merge = 0;
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 };
 
@@ -112,7 +112,7 @@ public:
         if (ctx_)
             pd_ctx_destroy(ctx_);
         if (getenv("POPDEL_TIMING"))
-            std::cerr << "[popdel timing] threads " << hostThreads() << "; switches " << clock_.switches << " s; decode " << clock_.decode << " s; replay " << clock_.replay
+            std::cerr << "[popdel timing] threads " << hostThreads() << "; parameters " << clock_.params << " s; backend start " << clock_.backend << " s; switches " << clock_.switches << " s; decode " << clock_.decode << " s; replay " << clock_.replay
                       << " s; window walk " << clock_.walk << " s; flatten " << clock_.flatten << " s; stage+submit " << clock_.submit
                       << " s; collect+merge+write " << clock_.collect << " s" << std::endl;
     }
@@ -651,7 +651,9 @@ bool CallRun::finalizeRoi()
 
 int CallRun::run()
 {
+    double tStart = PhaseClock::now();
     loadAndCalculateParameters(p_);
+    clock_.params = PhaseClock::now() - tStart;
     printStatus("Finished parameter calculation.\n");
     {
         std::ostringstream msg;
@@ -666,7 +668,9 @@ int CallRun::run()
     vcf_.reset(new VcfOutput(p_.outfile, p_.inputFiles, p_.contigNames[0], p_.contigLengths[0]));
     vcf_->appendContigName(windows_.current.contig);
 
+    tStart = PhaseClock::now();
     createBackend();
+    clock_.backend = PhaseClock::now() - tStart;
     profile_.reset(new ChromProfile(static_cast<unsigned>(p_.readGroups.size()), p_.maxLoad, p_.windowBuffer));
     profile_->currentPos = windows_.current.pos;
     profile_->resetTo(profile_->currentPos);
