@@ -940,7 +940,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
                 genericTiles += counters[static_cast<size_t>(i) * 4 + 3];
             }
             if (getenv("POPDEL_HIP_DEBUG"))
-                fprintf(stderr, "[popdel_hip] stage 2: %u cells, %llu of %llu (cell, tile) units on the generic kernels\n", nCells,
+                fprintf(stderr, "[popdel_hip] stage 2: %u cells, %llu of %llu (cell, 64-sample wave tile) units need the generic kernels\n", nCells,
                         (unsigned long long)genericTiles, (unsigned long long)nCells * b.ownTiles);
             c->dSuppFirst.ensure(pool + 1);
             c->dSuppLast.ensure(pool + 1);

@@ -190,3 +190,34 @@ def test_two_tickets_pipelined_equal_sequential(built):
     for h in handles:
         ctx.unstage(h)
     ctx.close()
+
+
+def test_dense_and_generic_tiles_mixed(built):
+    """520 samples = 3 tiles of 256: the first is served by the dense lane-per-sample kernels and holds a read group above
+    max_load as sample 0 (its triple drives quirk Q2), the second holds an 85x sample (more active pairs than the dense
+    image keeps -> generic kernels for that tile), the third a 3-read-group sample (generic as well)."""
+    from popdel_amd import capi, synth
+    lib = synth.Library()
+    rg = synth.conditioned_readgroup(lib)
+    rg_tight = synth.conditioned_readgroup(lib, max_load=20)
+    region, first, W = (1000000, 1046000), 1000020, 1450
+    dels = lambda k, r: [synth.Deletion(1015000, 1200, [2, 1, 0, 0][k % 4]), synth.Deletion(1031000, 500, [0, 1, 2][k % 3])]
+    parts, offsets, rgs, sample_offsets = [], [0], [], [0]
+    for k in range(520):
+        kind = "tight" if k == 0 else ("deep" if k == 300 else ("multi" if k == 515 else "normal"))
+        n_rg = 3 if kind == "multi" else 1
+        for j in range(n_rg):
+            cov = 85.0 if kind == "deep" else 30.0 / n_rg
+            pos, dev = synth.sample_pairs(7000 + 3 * k + j, region, synth.Library(coverage=cov), dels(k, region))
+            d, s, a, b = synth.instances_by_interval_rule(pos, dev, lib, first, W)
+            parts.append((d, s, a, b))
+            offsets.append(offsets[-1] + len(d))
+            rgs.append(rg_tight if kind == "tight" else rg)
+        sample_offsets.append(len(rgs))
+    seg = capi.Segment(first, W, np.array(offsets, np.uint64), np.concatenate([p[0] for p in parts]).astype(np.int32),
+                       np.concatenate([p[1] for p in parts]).astype(np.uint32),
+                       np.concatenate([p[2] for p in parts]).astype(np.uint32),
+                       np.concatenate([p[3] for p in parts]).astype(np.uint32))
+    gpu, cpu = both(seg, rgs, sample_offsets)
+    assert cpu[0]["n_calls"] > 30
+    assert_same(gpu, cpu)
