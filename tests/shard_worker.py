@@ -28,6 +28,30 @@ def make_case(name):
                                    deletions=lambda k, r: [synth.Deletion(1012000, 700 + 40 * (k % 3), [1, 2, 0][k % 3])])
         rgs = [dataclasses.replace(base, min_init_del_len=[0, 350, 900, 120][(k // 7) % 4]) for k in range(n)]
         opts = dict(window_wise_output=True, min_sample_fraction=0.5)
+    elif name == "mixed520":
+        # dense and generic stage-2 tiles, a read group above max_load as cohort sample 0, a 3-read-group sample on the
+        # second rank (same cohort as tests/test_gpu_parity.py::test_dense_and_generic_tiles_mixed)
+        from popdel_amd import capi
+        rg_tight = synth.conditioned_readgroup(lib, max_load=20)
+        region, first, W = (1000000, 1046000), 1000020, 1450
+        dels = lambda k, r: [synth.Deletion(1015000, 1200, [2, 1, 0, 0][k % 4]), synth.Deletion(1031000, 500, [0, 1, 2][k % 3])]
+        parts, offsets, rgs, sample_offsets = [], [0], [], [0]
+        for k in range(520):
+            kind = "tight" if k == 0 else ("deep" if k == 300 else ("multi" if k == 515 else "normal"))
+            n_rg = 3 if kind == "multi" else 1
+            for j in range(n_rg):
+                cov = 85.0 if kind == "deep" else 30.0 / n_rg
+                pos, dev = synth.sample_pairs(7000 + 3 * k + j, region, synth.Library(coverage=cov), dels(k, region))
+                d, s, a, b = synth.instances_by_interval_rule(pos, dev, lib, first, W)
+                parts.append((d, s, a, b))
+                offsets.append(offsets[-1] + len(d))
+                rgs.append(rg_tight if kind == "tight" else base)
+            sample_offsets.append(len(rgs))
+        seg = capi.Segment(first, W, np.array(offsets, np.uint64), np.concatenate([p[0] for p in parts]).astype(np.int32),
+                           np.concatenate([p[1] for p in parts]).astype(np.uint32),
+                           np.concatenate([p[2] for p in parts]).astype(np.uint32),
+                           np.concatenate([p[3] for p in parts]).astype(np.uint32))
+        return seg, rgs, sample_offsets, {}
     else:
         raise ValueError(name)
     return seg, rgs, list(range(n + 1)), opts

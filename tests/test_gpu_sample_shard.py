@@ -36,7 +36,7 @@ def run_world(case, world, out):
     return pickle.load(open(out, "rb"))
 
 
-@pytest.mark.parametrize("case,world", [("deletions600", 2), ("thresholds300", 2), ("deletions600", 3)])
+@pytest.mark.parametrize("case,world", [("deletions600", 2), ("thresholds300", 2), ("deletions600", 3), ("mixed520", 2)])
 def test_sample_shards_equal_one_context(built, tmp_path, case, world):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from shard_worker import make_case
