@@ -523,8 +523,10 @@ __global__ __launch_bounds__(256) void clusterKernel(ClusterInput in, int unifor
 // A workgroup takes one (cell, 256-sample tile); per 64-sample wave tile the half-waves compact the active pairs of
 // their samples into LDS rows, then the whole workgroup writes the rows out transposed (coalesced).
 // =====================================================================================================================
-__global__ __launch_bounds__(kSampleTile) void cellGatherKernel(SegmentView seg, CohortView co, Stage2Buffers b,
-                                                                const uint8_t * __restrict__ flags)
+constexpr int kGatherThreads = 512;            // 16 half-waves x 4 samples: the per-sample work is a chain of dependent loads,
+                                               // so more half-waves in flight per LDS footprint beat longer loops
+__global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView seg, CohortView co, Stage2Buffers b,
+                                                                   const uint8_t * __restrict__ flags)
 {
     __shared__ unsigned acc[3];
     __shared__ SampleMeta shMeta[64];
@@ -557,9 +559,10 @@ __global__ __launch_bounds__(kSampleTile) void cellGatherKernel(SegmentView seg,
     }
     __syncthreads();
     unsigned count = 0, total = 0, low = 0;
-    for (unsigned k = 0; k < 8; ++k)
+    constexpr unsigned kHalves = kGatherThreads / 32;
+    for (unsigned k = 0; k < 64u / kHalves; ++k)
     {
-        const unsigned inWt = half + k * 8;
+        const unsigned inWt = half + k * kHalves;
         const unsigned s = wt * 64u + inWt;
         if (s >= co.nSamples)                              // uniform per half-wave
         {
@@ -578,30 +581,42 @@ __global__ __launch_bounds__(kSampleTile) void cellGatherKernel(SegmentView seg,
             const int windowBegin = max((int)L / 2, (int)floor((L - 2 * rc.stddev) + 0.5));
             const int windowEnd = (int)(L + 2 * rc.stddev);
             unsigned n = 0, hits = 0;
-            for (unsigned base = r.begin; base < r.end; base += 32u)
+            // two 32-chunk groups per round, deviation AND start loaded up front: one memory round trip per ~64 candidates
+            // instead of a chain of four (the kernel is bound by exactly that latency)
+            for (unsigned base = r.begin; base < r.end; base += 64u)
             {
-                const unsigned i = base + hl;
-                bool act = false;
-                PairDO p;
-                p.dev = 0;
-                p.off = 0;
-                if (i < r.end)
+                PairDO p[2];
+                unsigned st[2];
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
                 {
-                    p = r.p[i];
-                    act = p.off > w;
-                }
-                const unsigned long long bal = __ballot(act) & hm;
-                if (act)
-                {
-                    const unsigned pos = n + (unsigned)__popcll(bal & below);
-                    if (pos < (unsigned)kDenseCap)
+                    const unsigned i = base + 32u * g + hl;
+                    p[g].dev = 0;
+                    p[g].off = 0;
+                    st[g] = 0;
+                    if (i < r.end)
                     {
-                        shDev[inWt][pos] = p.dev;
-                        shSt[inWt][pos] = r.st[i];
+                        p[g] = r.p[i];
+                        st[g] = r.st[i];
                     }
                 }
-                n += (unsigned)__popcll(bal);
-                hits += halfCount(act && p.dev > windowBegin && p.dev < windowEnd);
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                {
+                    const bool act = p[g].off > w;                 // off == 0 for lanes past the end
+                    const unsigned long long bal = __ballot(act) & hm;
+                    if (act)
+                    {
+                        const unsigned pos = n + (unsigned)__popcll(bal & below);
+                        if (pos < (unsigned)kDenseCap)
+                        {
+                            shDev[inWt][pos] = p[g].dev;
+                            shSt[inWt][pos] = st[g];
+                        }
+                    }
+                    n += (unsigned)__popcll(bal);
+                    hits += halfCount(act && p[g].dev > windowBegin && p[g].dev < windowEnd);
+                }
             }
             if (n >= rc.maxLoad)
                 nDense = kDenseHighCov;
@@ -1896,11 +1911,9 @@ void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers
 {
     if (b.nCells == 0)
         return;
-    const unsigned ownTiles = (co.nSamples + kSamplesPerBlock - 1) / kSamplesPerBlock;
-    const dim3 perSample(ownTiles, b.nCells), tile(kSampleTile);
     const dim3 perCell((b.nCells + 127) / 128), cellBlock(128);
     (void)hipMemsetAsync(b.tileMode, 0, (size_t)b.nCells * b.ownTiles * sizeof(unsigned), st);
-    hipLaunchKernelGGL(cellGatherKernel, dim3(b.ownTiles * 4, b.nCells), tile, 0, st, seg, co, b, flags);
+    hipLaunchKernelGGL(cellGatherKernel, dim3(b.ownTiles * 4, b.nCells), dim3(kGatherThreads), 0, st, seg, co, b, flags);
     x.allGather(b.counters, (size_t)b.nCells * 4 * sizeof(unsigned));
     hipLaunchKernelGGL(cellInitFinishKernel, perCell, cellBlock, 0, st, b);
     hipLaunchKernelGGL(suppScanKernel, dim3(1), dim3(256), 0, st, b);
