@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--sharded-passes", type=int, default=40,
                     help="passes of the secondary sample-sharded leg (N > 1 only; 0 switches it off)")
     ap.add_argument("--sharded-timeout", type=float, default=240.0, help="give up on the secondary leg after this many seconds")
+    ap.add_argument("--stream-segments", type=int, default=4,
+                    help="segments of the streaming leg (host memory -> HBM -> calls, double buffered); 0 switches it off")
     ap.add_argument("--serial", action="store_true",
                     help="one ticket at a time (no pipelining across segments). Used for the rocprofv3 kernel trace: under "
                          "the profiler the result copy runs as a blit KERNEL that competes with the next scan, which "
@@ -200,6 +202,30 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # streaming leg (reported, never `value`): every segment comes from host memory -- chunk layout built by the host
+    # threads, uploaded over the copy stream while the previous segment computes, results collected -- i.e. what a host
+    # that has the pair instances in RAM can sustain through one GPU
+    streaming = None
+    if args.stream_segments > 0:
+        sync()
+        q0 = time.perf_counter()
+        h_cur = ctx.stage(seg)
+        t_cur = ctx.run(h_cur)
+        for i in range(args.stream_segments):
+            last = i + 1 == args.stream_segments
+            if not last:
+                h_nxt = ctx.stage(seg)
+                t_nxt = ctx.run(h_nxt)
+            ctx.collect(t_cur, copy=False)
+            ctx.unstage(h_cur)
+            if not last:
+                h_cur, t_cur = h_nxt, t_nxt
+        sync()
+        dt = time.perf_counter() - q0
+        streaming = dict(value=args.stream_segments * W * S / dt, unit="window*sample/s", segments=args.stream_segments,
+                         seconds_per_segment=dt / args.stream_segments,
+                         host_bytes_per_segment=int(16 * len(arrays["dev"]) + 8 * (S + 1)))
+
     cells_per_step = total_passes * W * S * world
     value = cells_per_step * args.steps / elapsed
 
@@ -301,6 +327,7 @@ def main():
             # inside every pass the rate would be cells_per_pass / (stage_seconds + pass time): reported, never `value`
             "staging_seconds_per_segment": stage_seconds,
             "pcie_inclusive_value": (W * S) / (stage_seconds + elapsed / args.steps / max(1, my_passes)),
+            "streaming": streaming,
             "roofline": roofline, "cpu_baseline": cpu_baseline})
     ctx.unstage(handle)
     ctx.close()

@@ -319,9 +319,13 @@ T * mallocCopy(const std::vector<T> & v)
 
 // Split every pair instance into chunks that live at most K windows, order the chunks of each read group by their
 // first window and index them by window (winStart). K is chosen so that nearly all pairs need a single chunk.
+// `sized()` is called once the chunk totals are known (winStart is final then), `slabDone(lo, hi)` whenever the chunks
+// of the read groups [lo, hi) are in place: the caller uploads slab by slab while the next slab is being built.
+template <typename Sized, typename SlabDone>
 void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, PinnedBuf<pd::PairDO> & pairs,
                  PinnedBuf<uint32_t> & start, std::vector<uint64_t> & rgBase, PinnedBuf<uint32_t> & winStart,
-                 PinnedBuf<uint2> & pairsPk, PinnedBuf<uint32_t> & endCount, std::vector<uint8_t> & rgPacked)
+                 PinnedBuf<uint2> & pairsPk, PinnedBuf<uint32_t> & endCount, std::vector<uint8_t> & rgPacked, Sized sized,
+                 SlabDone slabDone)
 {
     const uint32_t W = seg.n_windows;
     // lifetime histogram -> K
@@ -407,8 +411,15 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
     pairsPk.resize(totalChunks);
     endCount.assignZero(static_cast<size_t>(seg.n_readgroups) * (W + 1));
     rgPacked.assign(seg.n_readgroups, 0);
-    // pass 2 (parallel): scatter the chunks to their slots, stable within a window
-    pdh::parallelFor(seg.n_readgroups, [&](size_t rg) {
+    out.nChunks = pairs.size();
+    sized();
+    // pass 2 (parallel): scatter the chunks to their slots, stable within a window; in slabs of read groups
+    const size_t nSlabs = std::min<size_t>(8, std::max<size_t>(1, seg.n_readgroups / 64));
+    for (size_t slab = 0; slab < nSlabs; ++slab)
+    {
+    const size_t slabLo = seg.n_readgroups * slab / nSlabs, slabHi = seg.n_readgroups * (slab + 1) / nSlabs;
+    pdh::parallelFor(slabHi - slabLo, [&](size_t rgInSlab) {
+        const size_t rg = slabLo + rgInSlab;
         const uint64_t lo = seg.rg_offsets[rg], hi = seg.rg_offsets[rg + 1];
         const uint32_t * ws = winStart.data() + rg * wsRow;
         std::vector<uint32_t> cursor(ws, ws + wsRow - 1);
@@ -439,7 +450,8 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
         }
         rgPacked[rg] = fits ? 1 : 0;
     }, 8);
-    out.nChunks = pairs.size();
+    slabDone(slabLo, slabHi);
+    }
     (void)c;
 }
 
@@ -658,15 +670,33 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
         std::vector<uint64_t> & rgBase = c->hRgBase;
         PinnedBuf<uint2> & pairsPk = c->hPairsPk;
         std::vector<uint8_t> & rgPacked = c->hRgPacked;
-        buildChunks(*c, *seg, *s, pairs, start, rgBase, winStart, pairsPk, endCount, rgPacked);
-        s->pairs.uploadPinned(pairs, c->stream);
-        s->start.uploadPinned(start, c->stream);
-        s->rgBase.upload(rgBase, c->stream);
-        s->winStart.uploadPinned(winStart, c->stream);
-        s->pairsPk.uploadPinned(pairsPk, c->stream);
-        s->endCount.uploadPinned(endCount, c->stream);
-        s->rgPacked.upload(rgPacked, c->stream);
-        PD_HIP(hipStreamSynchronize(c->stream));       // host vectors go out of scope
+        // Uploads go over the copy stream: a ticket that is running on the compute stream is not held up by the staging
+        // of the next segment (double-buffered streaming: run(N), stage(N+1), collect(N), run(N+1), ...), and they go
+        // slab by slab, so that PCIe works while the host threads still build the next slab.
+        const uint32_t W = seg->n_windows;
+        hipStream_t cs = c->copyStream;
+        auto sized = [&]() {
+            s->pairs.ensure(pairs.size());
+            s->start.ensure(start.size());
+            s->pairsPk.ensure(pairsPk.size());
+            s->endCount.ensure(endCount.size());
+            s->rgBase.upload(rgBase, cs);
+            s->winStart.uploadPinned(winStart, cs);
+        };
+        auto slabDone = [&](size_t lo, size_t hi) {
+            const uint64_t a = rgBase[lo], b = hi < rgBase.size() ? rgBase[hi] : pairs.size();
+            if (b > a)
+            {
+                PD_HIP(hipMemcpyAsync(s->pairs.p + a, pairs.data() + a, (b - a) * sizeof(pd::PairDO), hipMemcpyHostToDevice, cs));
+                PD_HIP(hipMemcpyAsync(s->start.p + a, start.data() + a, (b - a) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+                PD_HIP(hipMemcpyAsync(s->pairsPk.p + a, pairsPk.data() + a, (b - a) * sizeof(uint2), hipMemcpyHostToDevice, cs));
+            }
+            const size_t e0 = lo * (static_cast<size_t>(W) + 1), e1 = hi * (static_cast<size_t>(W) + 1);
+            PD_HIP(hipMemcpyAsync(s->endCount.p + e0, endCount.data() + e0, (e1 - e0) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+        };
+        buildChunks(*c, *seg, *s, pairs, start, rgBase, winStart, pairsPk, endCount, rgPacked, sized, slabDone);
+        s->rgPacked.upload(rgPacked, cs);
+        PD_HIP(hipStreamSynchronize(cs));              // the host scratch is reused by the next call
         *handle = c->nextHandle++;
         c->staged[*handle] = std::move(s);
     }

@@ -1628,44 +1628,44 @@ __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, S
     bool eq = true;
     unsigned mn = 0xffffffffu, mx = 0, nSupp = 0;
     unsigned lad[3] = {0, 0, 0}, dad[5] = {0, 0, 0, 0, 0};
+#pragma unroll 2
     for (unsigned j = 0; j < rows; ++j)
     {
-        if (j < nn)
-        {
-            const int dv = col[j * 64];
-            const unsigned st = colSt[j * 64];
-            int cls;
-            if (dv > rc.upperQ)
-                cls = (dv < rgLower) ? 2 : ((dv <= rgUpper) ? 3 : 4);
-            else
-                cls = (dv < rgUpper) ? 0 : 1;
-            const long long pr = lookupPos(rc, dv - refShift), pdl = lookupPos(rc, dv - len);
-            double4 tr = make_double4(rc.minProb, rc.logMinProb, rc.log10MinProb, 0.0), td = tr;
-            if (pr >= 0)
-                tr = co.tab[pr];
-            if (pdl >= 0)
-                td = co.tab[pdl];
-            const double ref = tr.x, del = td.x;
-            const int lcls = (ref >= 2 * del) ? 0 : ((del >= 2 * ref) ? 2 : 1);
-            l0 += tr.y;
-            t0 += tr.z;
-            l2 += td.y;
-            t2 += td.z;
-            int e;
-            prod *= frexp(ref + del, &e);
-            esum += e;
-            eq = eq && (ref == del);
-            const unsigned last = st + (unsigned)max(0, dv + rc.median - 2 * rc.readLength);
-            mn = min(mn, st);
-            mx = max(mx, last);
+        const bool use = j < nn;
+        const int dv = col[j * 64];
+        const unsigned st = colSt[j * 64];
+        int cls;
+        if (dv > rc.upperQ)
+            cls = (dv < rgLower) ? 2 : ((dv <= rgUpper) ? 3 : 4);
+        else
+            cls = (dv < rgUpper) ? 0 : 1;
+        const long long pr = lookupPos(rc, dv - refShift), pdl = lookupPos(rc, dv - len);
+        double4 tr = make_double4(rc.minProb, rc.logMinProb, rc.log10MinProb, 0.0), td = tr;
+        if (use && pr >= 0)
+            tr = co.tab[pr];
+        if (use && pdl >= 0)
+            td = co.tab[pdl];
+        const double ref = tr.x, del = td.x;
+        const int lcls = (ref >= 2 * del) ? 0 : ((del >= 2 * ref) ? 2 : 1);
+        int e;
+        const double m = frexp(ref + del, &e);
+        l0 += use ? tr.y : 0.0;
+        t0 += use ? tr.z : 0.0;
+        l2 += use ? td.y : 0.0;
+        t2 += use ? td.z : 0.0;
+        prod *= use ? m : 1.0;
+        esum += use ? e : 0;
+        eq = eq && (!use || ref == del);
+        const unsigned last = st + (unsigned)max(0, dv + rc.median - 2 * rc.readLength);
+        mn = use ? min(mn, st) : mn;
+        mx = use ? max(mx, last) : mx;
 #pragma unroll
-            for (int c = 0; c < 5; ++c)
-                dad[c] += (cls == c) ? 1u : 0u;
+        for (int c = 0; c < 5; ++c)
+            dad[c] += (use && cls == c) ? 1u : 0u;
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                lad[c] += (lcls == c) ? 1u : 0u;
-            nSupp += (dv >= rgLower && dv <= rgUpper) ? 1u : 0u;
-        }
+        for (int c = 0; c < 3; ++c)
+            lad[c] += (use && lcls == c) ? 1u : 0u;
+        nSupp += (use && dv >= rgLower && dv <= rgUpper) ? 1u : 0u;
     }
     // supporting pairs: one pool allocation per wave, lanes fill their own stretch
     {
