@@ -146,6 +146,9 @@ private:
     unsigned nextReadPos_ = kNoPos;
     // one segment in flight on the device while the next one is loaded
     PhaseClock clock_;
+    std::vector<uint64_t> flatOffsets_;
+    std::vector<int32_t> flatDev_;
+    std::vector<uint32_t> flatStart_, flatOn_, flatOff_;
     bool pending_ = false;
     uint64_t pendingTicket_ = 0;
     std::string pendingContig_;
@@ -593,12 +596,21 @@ void CallRun::processSegment()
         return;
     t0 = PhaseClock::now();
     // Flatten to the SoA layout of pd_segment.
-    std::vector<uint64_t> offsets(log.size() + 1, 0);
+    // (buffers are members: their pages stay mapped from segment to segment)
+    std::vector<uint64_t> & offsets = flatOffsets_;
+    offsets.assign(log.size() + 1, 0);
     for (size_t rg = 0; rg < log.size(); ++rg)
         offsets[rg + 1] = offsets[rg] + log[rg].size();
     const size_t total = offsets.back();
-    std::vector<int32_t> dev(total);
-    std::vector<uint32_t> start(total), on(total), off(total);
+    std::vector<int32_t> & dev = flatDev_;
+    std::vector<uint32_t> &start = flatStart_, &on = flatOn_, &off = flatOff_;
+    if (dev.size() < total)
+    {
+        dev.resize(total);
+        start.resize(total);
+        on.resize(total);
+        off.resize(total);
+    }
     parallelFor(log.size(), [&](size_t rg) {
         size_t o = offsets[rg];
         for (const PairInstance & pi : log[rg])
@@ -797,8 +809,17 @@ int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer)
         int res = parseCallCommandLine(params, argc, argv);
         if (res >= 0)
             return res;
-        CallRun run(params, observer);
-        return run.run();
+        const double t0 = PhaseClock::now();
+        int rc;
+        double tRun;
+        {
+            CallRun run(params, observer);
+            rc = run.run();
+            tRun = PhaseClock::now();
+        }
+        if (getenv("POPDEL_TIMING"))
+            std::cerr << "[popdel timing] run " << tRun - t0 << " s; teardown " << PhaseClock::now() - tRun << " s" << std::endl;
+        return rc;
     }
     catch (const std::exception & e)
     {
