@@ -926,6 +926,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             c->dDl.ensure(static_cast<size_t>(nCells) * S * 3);
             c->dShifts.ensure(static_cast<size_t>(nCells) * c->nRg);
             b.ownTiles = (S + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock;
+            b.forceGeneric = getenv("POPDEL_HIP_FORCE_GENERIC") ? 1 : 0;
             const size_t waveTiles = static_cast<size_t>(nCells) * b.ownTiles * 4;
             c->dCellDev.ensure(waveTiles * pd::kDenseCap * 64);
             c->dCellStart.ensure(waveTiles * pd::kDenseCap * 64);

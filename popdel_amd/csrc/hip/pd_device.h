@@ -171,6 +171,7 @@ struct Stage2Buffers
     uint8_t *   waveRows;    // [nCells][ownTiles*4] max cellN over the wave tile (rows in use)
     unsigned *  tileMode;    // [nCells][ownTiles] 0: dense kernels, 1: generic kernels
     unsigned    ownTiles;    // 256-sample tiles of this context
+    int         forceGeneric; // debugging (POPDEL_HIP_FORCE_GENERIC): every tile through the generic kernels
     // final-pass outputs, [nCells][S][k]
     uint32_t *  pl;
     uint32_t *  lad;

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
             continue;
         }
         const SampleMeta & meta = shMeta[inWt];
-        bool generic = (meta.rg1 - meta.rg0) != 1u;
+        bool generic = (meta.rg1 - meta.rg0) != 1u || b.forceGeneric != 0;
         unsigned nDense = 0;
         for (unsigned rg = meta.rg0; rg < meta.rg1; ++rg)
         {
