@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--passes", type=int, default=0, help="segment passes per step (default: chr20 = 323)")
     ap.add_argument("--cpu-samples", type=int, default=600, help="samples of the same segment timed on one host core")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the all-cores CPU figure (0/1: skip)")
     ap.add_argument("--sharded-passes", type=int, default=40,
                     help="passes of the secondary sample-sharded leg (N > 1 only; 0 switches it off)")
     ap.add_argument("--sharded-timeout", type=float, default=240.0, help="give up on the secondary leg after this many seconds")
@@ -266,6 +267,30 @@ def main():
             cpu_baseline = dict(value=n_cpu * W / cpu_s, unit="window*sample/s", cores=1, kind="port",
                                 sample="%d of the %d samples x the same %d-window segment, oracle/ (x87 long double), %.1f s"
                                        % (n_cpu, S, W, cpu_s))
+            # the same on all host cores the way a CPU run would use them: independent cohorts of n_cpu samples each (the
+            # oracle is single-threaded; ctypes releases the GIL), reported next to the one-core figure
+            import threading
+            n_thr = max(1, min(args.cpu_threads, os.cpu_count() or 1, S // n_cpu))
+            if n_thr > 1:
+                olib = capi.load_library(oracle_path)
+                parts = []
+                for t in range(n_thr):
+                    lo, hi = int(offsets[t * n_cpu]), int(offsets[(t + 1) * n_cpu])
+                    parts.append(capi.Segment(first, W, offsets[t * n_cpu:(t + 1) * n_cpu + 1] - offsets[t * n_cpu],
+                                              arrays["dev"][lo:hi], arrays["start"][lo:hi], arrays["on"][lo:hi], arrays["off"][lo:hi]))
+                ctxs = [capi.Context(olib, [rg] * n_cpu, list(range(n_cpu + 1))) for _ in range(n_thr)]
+                work = [threading.Thread(target=lambda c=c, p=p: c.collect(c.submit(p), copy=False)) for c, p in zip(ctxs, parts)]
+                c0 = time.perf_counter()
+                for th in work:
+                    th.start()
+                for th in work:
+                    th.join()
+                cpu_all_s = time.perf_counter() - c0
+                for c in ctxs:
+                    c.close()
+                cpu_baseline["all_cores"] = dict(value=n_thr * n_cpu * W / cpu_all_s, unit="window*sample/s", cores=n_thr,
+                                                 sample="%d independent cohorts of %d samples, one oracle context per thread, %.1f s"
+                                                        % (n_thr, n_cpu, cpu_all_s))
 
     # ---- secondary leg: the cohort sharded by SAMPLES over the ranks (collectives in the data path) --------------------
     result = {}
