@@ -900,49 +900,67 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
                 }
             }
         }
+        // Stage 2 runs over the cells in batches that keep its per-(cell, sample) buffers (dense pair image 512 B,
+        // triples 24 B, outputs 52 B, ...) within a byte budget: a candidate-rich segment of a large cohort would not
+        // fit otherwise (13,000 cells x 50,000 samples = 390 GB). One batch is the normal case.
         std::vector<unsigned> emit;
         const unsigned nCells = (unsigned)cells.size();
+        size_t budget = static_cast<size_t>(24) << 30;
+        if (const char * e = getenv("POPDEL_HIP_STAGE2_BYTES"))
+            budget = static_cast<size_t>(std::max(1.0, atof(e)));
+        // (from the samples per context of the partition, not from this context's own count: all contexts of a sharded
+        // cohort must cut the cell list at the same places, the exchanges run per batch)
+        const size_t bytesPerCell = static_cast<size_t>(sper) * (2 * pd::kDenseCap * 4 + 24 + 52 + 2 + 24) + 4096;
+        const unsigned batchCells = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(nCells ? nCells : 1, budget / bytesPerCell)));
+        const unsigned nBatches = nCells ? (nCells + batchCells - 1) / batchCells : 0;
         pd::Stage2Buffers b;
         std::memset(&b, 0, sizeof(b));
-        if (nCells != 0)
+        // per-sample results of the emitted cells: device buffer of the current batch, host block of the whole segment
+        PinnedBlock pinned;
+        uint32_t *hPl = nullptr, *hLad = nullptr, *hDad = nullptr, *hFl = nullptr;
+        std::vector<uint32_t> accPl, accLad, accDad, accFl;       // only used when there is more than one batch
+        uint32_t nLastBatch = 0;                                  // emitted cells of the last batch (still on the device)
+        for (unsigned batch = 0; batch < nBatches; ++batch)
         {
-            b.nCells = nCells;
+            const unsigned lo = batch * batchCells, hi = std::min(nCells, lo + batchCells), nb = hi - lo;
+            b.nCells = nb;
             b.nTiles = (SG + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock;
             b.tilesPerRank = sper / pd::kSamplesPerBlock;
             b.rank = c->rank;
             b.world = world;
             b.nSamplesGlobal = SG;
             // exchange areas: integer counts | per-tile sums + RG-0 record | digit histograms
-            b.xchChunk = (static_cast<size_t>(b.tilesPerRank) + 1) * nCells * 4;
-            const size_t countersBytes = alignUp(static_cast<size_t>(world) * nCells * 4 * sizeof(unsigned), 256);
+            b.xchChunk = (static_cast<size_t>(b.tilesPerRank) + 1) * nb * 4;
+            const size_t countersBytes = alignUp(static_cast<size_t>(world) * nb * 4 * sizeof(unsigned), 256);
             const size_t xchBytes = alignUp(static_cast<size_t>(world) * b.xchChunk * sizeof(double), 256);
-            const size_t histBytes = static_cast<size_t>(world) * nCells * 2 * 256 * sizeof(unsigned);
+            const size_t histBytes = static_cast<size_t>(world) * nb * 2 * 256 * sizeof(unsigned);
             uint8_t * area = reserveArena(*c, countersBytes + xchBytes + histBytes);
             PD_HIP(hipMemsetAsync(area, 0, countersBytes + xchBytes, c->stream));
             b.counters = reinterpret_cast<unsigned *>(area);
             b.xch = reinterpret_cast<double *>(area + countersBytes);
             b.selHist = reinterpret_cast<unsigned *>(area + countersBytes + xchBytes);
-            c->dCells.upload(cells, c->stream);
-            c->dDl.ensure(static_cast<size_t>(nCells) * S * 3);
-            c->dShifts.ensure(static_cast<size_t>(nCells) * c->nRg);
+            c->dCells.ensure(nb);
+            PD_HIP(hipMemcpyAsync(c->dCells.p, cells.data() + lo, nb * sizeof(pd::CellState), hipMemcpyHostToDevice, c->stream));
+            c->dDl.ensure(static_cast<size_t>(nb) * S * 3);
+            c->dShifts.ensure(static_cast<size_t>(nb) * c->nRg);
             b.ownTiles = (S + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock;
             b.forceGeneric = getenv("POPDEL_HIP_FORCE_GENERIC") ? 1 : 0;
-            const size_t waveTiles = static_cast<size_t>(nCells) * b.ownTiles * 4;
+            const size_t waveTiles = static_cast<size_t>(nb) * b.ownTiles * 4;
             c->dCellDev.ensure(waveTiles * pd::kDenseCap * 64);
             c->dCellStart.ensure(waveTiles * pd::kDenseCap * 64);
-            c->dCellN.ensure(static_cast<size_t>(nCells) * S);
+            c->dCellN.ensure(static_cast<size_t>(nb) * S);
             c->dWaveRows.ensure(waveTiles);
-            c->dTileMode.ensure(static_cast<size_t>(nCells) * b.ownTiles);
+            c->dTileMode.ensure(static_cast<size_t>(nb) * b.ownTiles);
             b.cellDev = c->dCellDev.p;
             b.cellStart = c->dCellStart.p;
             b.cellN = c->dCellN.p;
             b.waveRows = c->dWaveRows.p;
             b.tileMode = c->dTileMode.p;
-            c->dPl.ensure(static_cast<size_t>(nCells) * S * 3);
-            c->dLad.ensure(static_cast<size_t>(nCells) * S * 3);
-            c->dDad.ensure(static_cast<size_t>(nCells) * S * 5);
-            c->dFl.ensure(static_cast<size_t>(nCells) * S * 2);
-            PD_HIP(hipMemsetAsync(c->dShifts.p, 0, static_cast<size_t>(nCells) * c->nRg * sizeof(int), c->stream));
+            c->dPl.ensure(static_cast<size_t>(nb) * S * 3);
+            c->dLad.ensure(static_cast<size_t>(nb) * S * 3);
+            c->dDad.ensure(static_cast<size_t>(nb) * S * 5);
+            c->dFl.ensure(static_cast<size_t>(nb) * S * 2);
+            PD_HIP(hipMemsetAsync(c->dShifts.p, 0, static_cast<size_t>(nb) * c->nRg * sizeof(int), c->stream));
             b.cells = c->dCells.p;
             b.dl = c->dDl.p;
             b.shifts = c->dShifts.p;
@@ -960,35 +978,61 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             // Phase A gives, per cell, the number of usable active pairs = capacity of its support pool.
             pd::runStage2Init(view, c->cohort, b, c->dFlags.p, xch, c->stream);
             PD_HIP(hipGetLastError());
-            std::vector<unsigned> counters(static_cast<size_t>(nCells) * 4);       // of this context's own samples
-            PD_HIP(hipMemcpyAsync(counters.data(), b.counters + static_cast<size_t>(c->rank) * nCells * 4,
+            std::vector<unsigned> counters(static_cast<size_t>(nb) * 4);       // of this context's own samples
+            PD_HIP(hipMemcpyAsync(counters.data(), b.counters + static_cast<size_t>(c->rank) * nb * 4,
                                   counters.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
             PD_HIP(hipStreamSynchronize(c->stream));
             uint64_t pool = 0, genericTiles = 0;
-            for (unsigned i = 0; i < nCells; ++i)
+            for (unsigned i = 0; i < nb; ++i)
             {
                 pool += counters[static_cast<size_t>(i) * 4 + 1];
                 genericTiles += counters[static_cast<size_t>(i) * 4 + 3];
             }
             if (getenv("POPDEL_HIP_DEBUG"))
-                fprintf(stderr, "[popdel_hip] stage 2: %u cells, %llu of %llu (cell, 64-sample wave tile) units need the generic kernels\n", nCells,
-                        (unsigned long long)genericTiles, (unsigned long long)nCells * b.ownTiles);
+                fprintf(stderr, "[popdel_hip] stage 2 batch %u/%u: %u cells, %llu of %llu (cell, 64-sample wave tile) units need the generic kernels\n",
+                        batch + 1, nBatches, nb, (unsigned long long)genericTiles, (unsigned long long)nb * b.ownTiles * 4);
             c->dSuppFirst.ensure(pool + 1);
             c->dSuppLast.ensure(pool + 1);
             b.suppFirst = c->dSuppFirst.p;
             b.suppLast = c->dSuppLast.p;
             pd::runStage2Main(view, c->cohort, b, c->dFlags.p, xch, genericTiles != 0, c->stream);
             PD_HIP(hipGetLastError());
-            PD_HIP(hipMemcpyAsync(cells.data(), c->dCells.p, cells.size() * sizeof(pd::CellState), hipMemcpyDeviceToHost, c->stream));
+            PD_HIP(hipMemcpyAsync(cells.data() + lo, c->dCells.p, nb * sizeof(pd::CellState), hipMemcpyDeviceToHost, c->stream));
             PD_HIP(hipStreamSynchronize(c->stream));
-            for (unsigned i = 0; i < nCells; ++i)
-                if (cells[i].phase == pd::kCellEmit)
-                    emit.push_back(i);
+            std::vector<unsigned> emitLocal;
+            for (unsigned i = 0; i < nb; ++i)
+                if (cells[lo + i].phase == pd::kCellEmit)
+                {
+                    emit.push_back(lo + i);
+                    emitLocal.push_back(i);
+                }
+            const uint32_t nbEmit = (uint32_t)emitLocal.size();
+            const size_t per = static_cast<size_t>(nbEmit) * S;
+            if (nbEmit != 0)
+            {
+                c->dEmit.upload(emitLocal, c->stream);
+                c->dOutPl.ensure(per * 13);
+                uint32_t *dPl = c->dOutPl.p, *dLad = dPl + per * 3, *dDad = dLad + per * 3, *dFl = dDad + per * 5;
+                pd::launchGatherOut(b, c->dEmit.p, nbEmit, S, dPl, dLad, dDad, dFl, c->stream);
+                PD_HIP(hipGetLastError());
+            }
+            nLastBatch = nbEmit;
+            if (nBatches > 1 && nbEmit != 0)
+            {
+                // not the streamlined path: fetch this batch's columns now, the device buffers are reused by the next one
+                PinnedBlock tmp = takePinned(per * 13 * sizeof(uint32_t));
+                PD_HIP(hipMemcpyAsync(tmp.p, c->dOutPl.p, per * 13 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+                PD_HIP(hipStreamSynchronize(c->stream));
+                const uint32_t * t = static_cast<const uint32_t *>(tmp.p);
+                accPl.insert(accPl.end(), t, t + per * 3);
+                accLad.insert(accLad.end(), t + per * 3, t + per * 6);
+                accDad.insert(accDad.end(), t + per * 6, t + per * 11);
+                accFl.insert(accFl.end(), t + per * 11, t + per * 13);
+                givePinned(tmp);
+            }
         }
         const uint32_t n = (uint32_t)emit.size();
         const size_t perSample = static_cast<size_t>(n) * S;
-        PinnedBlock pinned;
-        uint32_t *hPl = nullptr, *hLad = nullptr, *hDad = nullptr, *hFl = nullptr;
         if (n != 0)
         {
             pinned = takePinned(perSample * 13 * sizeof(uint32_t));
@@ -996,25 +1040,28 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             hLad = hPl + perSample * 3;
             hDad = hLad + perSample * 3;
             hFl = hDad + perSample * 5;
-            c->dEmit.upload(emit, c->stream);
-            c->dOutPl.ensure(perSample * 13);
-            uint32_t *dPl = c->dOutPl.p, *dLad = dPl + perSample * 3, *dDad = dLad + perSample * 3, *dFl = dDad + perSample * 5;
-            pd::launchGatherOut(b, c->dEmit.p, n, S, dPl, dLad, dDad, dFl, c->stream);
-            PD_HIP(hipGetLastError());
         }
         PD_HIP(hipEventRecord(s2End, c->stream));
-        if (n != 0)
+        const bool direct = nBatches == 1 && nLastBatch != 0;      // results of the only batch still sit in dOutPl
+        if (direct)
             PD_HIP(hipEventRecord(c->resultsPacked, c->stream));
         // the scan of a waiting ticket starts right behind this segment's last kernel ...
         // (enqueued BEFORE the copy: the other order was measured to hold the scan's first packets back until the copy,
         // a blit kernel on this platform, had finished)
         if (!c->runs.empty() && !c->runs.begin()->second.launched)
             launchScan(c, c->runs.begin()->second);
-        if (n != 0)
+        if (direct)
         {
             // ... while the results travel on the copy stream
             PD_HIP(hipStreamWaitEvent(c->copyStream, c->resultsPacked, 0));
             PD_HIP(hipMemcpyAsync(hPl, c->dOutPl.p, perSample * 13 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->copyStream));
+        }
+        else if (n != 0)
+        {
+            std::memcpy(hPl, accPl.data(), accPl.size() * sizeof(uint32_t));
+            std::memcpy(hLad, accLad.data(), accLad.size() * sizeof(uint32_t));
+            std::memcpy(hDad, accDad.data(), accDad.size() * sizeof(uint32_t));
+            std::memcpy(hFl, accFl.data(), accFl.size() * sizeof(uint32_t));
         }
         PD_HIP(hipEventSynchronize(s2End));
         PD_HIP(hipStreamSynchronize(c->copyStream));

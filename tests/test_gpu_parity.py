@@ -221,3 +221,27 @@ def test_dense_and_generic_tiles_mixed(built):
     gpu, cpu = both(seg, rgs, sample_offsets)
     assert cpu[0]["n_calls"] > 30
     assert_same(gpu, cpu)
+
+
+def test_stage2_in_batches_equals_one_batch(built):
+    """A small byte budget cuts the cell list of a candidate-dense segment into several stage-2 batches (what a large
+    cohort needs when a segment is rich in candidates); the calls must not change."""
+    from popdel_amd import capi, synth
+    lib = synth.Library()
+    rg = synth.conditioned_readgroup(lib)
+    n = 40
+    seg = synth.cohort_segment(n, (1000000, 1200000), 1000020, 6600, lib, deletions=synth.dense_deletions)
+    ctx = capi.Context(capi.load_hip(), [rg] * n, list(range(n + 1)), window_wise_output=True)
+    one = ctx.collect(ctx.submit(seg))
+    ctx.close()
+    assert one["n_calls"] > 200
+    # the budget is read from the environment at collect time
+    os.environ["POPDEL_HIP_STAGE2_BYTES"] = "6500000"                   # room for about 40 cells per batch -> 13 batches
+    try:
+        ctx = capi.Context(capi.load_hip(), [rg] * n, list(range(n + 1)), window_wise_output=True)
+        many = ctx.collect(ctx.submit(seg))
+        ctx.close()
+    finally:
+        del os.environ["POPDEL_HIP_STAGE2_BYTES"]
+    for k, v in one.items():
+        assert np.array_equal(np.asarray(many[k]), np.asarray(v)), k
