@@ -25,11 +25,12 @@ def free_port():
     return p
 
 
-def run_world(case, world, out):
+def run_world(case, world, out, extra_env=None):
     port = str(free_port())
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, WORKER, ROOT, case, str(out)], env=env))
     for p in procs:
         assert p.wait(timeout=900) == 0
@@ -58,3 +59,19 @@ def test_sample_shards_equal_one_context(built, tmp_path, case, world):
     for k in ("deletion_length", "position", "end_position", "pl", "lad", "dad", "first_last", "filter"):
         assert np.array_equal(got[k], ref[k]), k
     assert np.allclose(got["likelihood_ratio"], ref["likelihood_ratio"], rtol=1e-6, atol=1e-6)
+
+
+def test_sample_shards_with_stage2_batches(built, tmp_path):
+    """Sharded AND batched: the exchanges run per stage-2 batch, all contexts cut the cell list at the same places."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from shard_worker import make_case
+    from popdel_amd import capi
+    budget = {"POPDEL_HIP_STAGE2_BYTES": "4000000"}
+    sharded = run_world("deletions600", 2, tmp_path / "sharded.pkl", budget)
+    seg, rgs, offs, opts = make_case("deletions600")
+    ctx = capi.Context(capi.load_hip(), rgs, offs, **opts)
+    single = ctx.collect(ctx.submit(seg))
+    ctx.close()
+    assert sharded["exchanges"] > 60          # several batches, each with its own round of exchanges
+    for k, v in single.items():
+        assert np.array_equal(np.asarray(sharded["calls"][k]), np.asarray(v)), k
