@@ -888,7 +888,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             for (size_t f = 0; f < flagged.size(); ++f)
             {
                 if (candCount[f] > pd::kMaxCandidatesPerWindow)
-                    throw HipError{"more than 8 candidate deletion lengths in one window"};
+                    throw HipError{"more than 32 candidate deletion lengths in one window"};
                 for (int k = 0; k < candCount[f]; ++k)
                 {
                     pd::CellState cs;

@@ -9,7 +9,7 @@
 namespace pd {
 
 // ---- limits --------------------------------------------------------------------------------------------------
-constexpr int kMaxCandidatesPerWindow = 8;     // candidate deletion lengths kept per window
+constexpr int kMaxCandidatesPerWindow = 32;    // candidate deletion lengths kept per window
 constexpr int kMaxIterationsCap = 64;          // visited-table capacity per cell (params.iterations <= this)
 constexpr int kStage1Block = 256;              // windows per workgroup in the stage-1 scan
 constexpr int kStage1LdsPairs = 3072;          // pair chunks staged in LDS per stage-1 workgroup

@@ -245,3 +245,18 @@ def test_stage2_in_batches_equals_one_batch(built):
         del os.environ["POPDEL_HIP_STAGE2_BYTES"]
     for k, v in one.items():
         assert np.array_equal(np.asarray(many[k]), np.asarray(v)), k
+
+
+def test_many_candidate_lengths_in_one_window(built):
+    """Twelve deletions of different lengths over the same windows, each carried by a few samples: a dozen Q3 clusters,
+    hence a dozen (window, candidate length) cells per window."""
+    from popdel_amd import synth
+    lib = synth.Library()
+    rg = synth.conditioned_readgroup(lib)
+    n = 48
+    seg = synth.cohort_segment(n, (1000000, 1060000), 1000020, 1900, lib,
+                               deletions=lambda k, r: [synth.Deletion(1020000, 400 + 330 * (k % 12), 2 if k % 24 < 12 else 1)])
+    gpu, cpu = both(seg, [rg] * n, list(range(n + 1)), window_wise_output=True)
+    per_window = np.unique(cpu[0]["window_position"], return_counts=True)[1]
+    assert per_window.max() > 8
+    assert_same(gpu, cpu)
