@@ -23,7 +23,8 @@ struct SegmentObserver
 };
 
 // Runs the whole `popdel call` command. Returns the process exit code.
-int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer = nullptr);
+// quickExit: end the process right after the output is complete (command-line use), skipping the teardown.
+int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer = nullptr, bool quickExit = false);
 
 }  // namespace pdh
 #endif

@@ -1,5 +1,6 @@
 // `popdel` command-line entry point of the MI355X build. Only the `call` sub-command exists here; `profile` and
 // `view` are out of scope for this implementation (reference popdel.cpp:15-54 dispatches all three).
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 
@@ -15,7 +16,7 @@ int main(int argc, const char ** argv)
         return argc < 2 ? 1 : 0;
     }
     if (std::strcmp(argv[1], "call") == 0)
-        return pdh::runPopdelCall(argc - 1, argv + 1);
+        return pdh::runPopdelCall(argc - 1, argv + 1, nullptr, getenv("POPDEL_KEEP_TEARDOWN") == nullptr);
     std::cerr << "popdel: unknown or unsupported command '" << argv[1] << "' (this build provides `call` only)." << std::endl;
     return 1;
 }
