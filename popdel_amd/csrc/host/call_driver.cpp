@@ -19,6 +19,7 @@ constexpr unsigned kNoPos = std::numeric_limits<unsigned>::max();
 // Wall-clock split of the host phases, printed at exit when POPDEL_TIMING is set.
 struct PhaseClock
 {
+    unsigned orderedBatches = 0, parallelBatches = 0;
     double params = 0, backend = 0, switches = 0, decode = 0, replay = 0, walk = 0, flatten = 0, submit = 0, collect = 0, merge = 0;
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 };
@@ -118,8 +119,8 @@ public:
     void printTiming()
     {
         if (getenv("POPDEL_TIMING") && !timingPrinted_)
-            std::cerr << "[popdel timing] threads " << hostThreads() << "; parameters " << clock_.params << " s; backend start " << clock_.backend << " s; switches " << clock_.switches << " s; decode " << clock_.decode << " s; replay " << clock_.replay
-                      << " s; window walk " << clock_.walk << " s; flatten " << clock_.flatten << " s; stage+submit " << clock_.submit
+            std::cerr << "[popdel timing] threads " << hostThreads() << "; parameters " << clock_.params << " s; backend start " << clock_.backend << " s; switches " << clock_.switches << " s; decode " << clock_.decode << " s; replay " << clock_.replay << " s (" << clock_.parallelBatches << " batches in parallel, " << clock_.orderedBatches << " in order)"
+                      << "; window walk " << clock_.walk << " s; flatten " << clock_.flatten << " s; stage+submit " << clock_.submit
                       << " s; collect+merge+write " << clock_.collect << " s" << std::endl;
         timingPrinted_ = true;
     }
@@ -769,6 +770,7 @@ int CallRun::run()
                                          p_.allRois[p_.nextRoi], borderOut);
                 decoded[k] = DecodedStream();                   // free early
             };
+            ++(ordered ? clock_.orderedBatches : clock_.parallelBatches);
             if (ordered)
             {
                 for (size_t k = 0; k < readers.size(); ++k)
