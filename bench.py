@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--sharded-timeout", type=float, default=240.0, help="give up on the secondary leg after this many seconds")
     ap.add_argument("--stream-segments", type=int, default=4,
                     help="segments of the streaming leg (host memory -> HBM -> calls, double buffered); 0 switches it off")
+    ap.add_argument("--rgs-per-sample", type=int, default=1,
+                    help="split every sample's pairs over this many read groups (same library): measures the generic "
+                         "kernels that multi-read-group samples take; the headline workload has 1")
     ap.add_argument("--serial", action="store_true",
                     help="one ticket at a time (no pipelining across segments). Used for the rocprofv3 kernel trace: under "
                          "the profiler the result copy runs as a blit KERNEL that competes with the next scan, which "
@@ -132,15 +135,28 @@ def main():
     rg = synth.conditioned_readgroup(lib)
     S = args.samples
     first, W, offsets, arrays, planted = device_tile(S, 20260 + rank, device)
+    R = max(1, args.rgs_per_sample)
+    sample_offsets = list(range(0, R * S + 1, R))
+    if R > 1:
+        # deal the pairs of every sample to R read groups (stable, so each read group stays ordered by start window)
+        rs = np.random.default_rng(7 + rank)
+        which = rs.integers(0, R, size=len(arrays["dev"]))
+        sample_of = np.repeat(np.arange(S), np.diff(offsets).astype(np.int64))
+        key = sample_of * R + which
+        order = np.argsort(key, kind="stable")
+        arrays = {k: v[order] for k, v in arrays.items()}
+        counts = np.bincount(key, minlength=R * S).astype(np.uint64)
+        offsets = np.zeros(R * S + 1, dtype=np.uint64)
+        np.cumsum(counts, out=offsets[1:])
     seg = capi.Segment(first, W, offsets, arrays["dev"], arrays["start"], arrays["on"], arrays["off"])
-    ctx = capi.Context(hip, [rg] * S, list(range(S + 1)), device=local_rank)
+    ctx = capi.Context(hip, [rg] * (R * S), sample_offsets, device=local_rank)
     t_stage = time.perf_counter()
     handle = ctx.stage(seg)                   # host -> HBM, outside the timed region
     stage_seconds = time.perf_counter() - t_stage
     # optional extra contexts: independent segments in flight on the same GPU (segments do not depend on each other)
     extra = []
     for _ in range(max(0, args.contexts - 1)):
-        c2 = capi.Context(hip, [rg] * S, list(range(S + 1)), device=local_rank)
+        c2 = capi.Context(hip, [rg] * (R * S), sample_offsets, device=local_rank)
         extra.append((c2, c2.stage(seg)))
 
     total_passes = args.passes or -(-CHR20_WINDOWS // W)

@@ -143,6 +143,10 @@ struct StagedSegment
     DevBuf<uint2> pairsPk;
     DevBuf<uint32_t> endCount;
     DevBuf<uint8_t> rgPacked;
+    DevBuf<uint8_t> scanGeneric;
+    const uint32_t * scanRg = nullptr;      // the context's table (see SegmentView::scanRg)
+    uint32_t nRealRg = 0;
+    bool hasScanGeneric = false;
     bool ownedBySubmit = false;
 };
 
@@ -170,6 +174,9 @@ struct pd_ctx
     DevBuf<double4> dTab;
     DevBuf<unsigned> dIterFlags;
     DevBuf<uint32_t> dSampleRg;
+    DevBuf<uint32_t> dScanRg;
+    std::vector<uint32_t> scanSample;       // appended scan read group j -> its sample (samples with several read groups)
+    std::vector<uint32_t> maxLoad;          // per real read group
     pd::CohortView cohort;
     int uniformThreshold = -1;      // minInitDelLen if it is the same for all read groups of the cohort, else -1
     // The cohort may be sharded by samples over several contexts (pd_ctx_set_shard); defaults describe "all samples here".
@@ -186,7 +193,7 @@ struct pd_ctx
     PinnedBuf<uint32_t> hStart, hWinStart, hEndCount;
     std::vector<uint64_t> hRgBase;
     PinnedBuf<uint2> hPairsPk;
-    std::vector<uint8_t> hRgPacked;
+    std::vector<uint8_t> hRgPacked, hScanGeneric;
     uint64_t nextHandle = 1, nextTicket = 1;
     std::map<uint64_t, Run> runs;
 
@@ -324,8 +331,8 @@ T * mallocCopy(const std::vector<T> & v)
 template <typename Sized, typename SlabDone>
 void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, PinnedBuf<pd::PairDO> & pairs,
                  PinnedBuf<uint32_t> & start, std::vector<uint64_t> & rgBase, PinnedBuf<uint32_t> & winStart,
-                 PinnedBuf<uint2> & pairsPk, PinnedBuf<uint32_t> & endCount, std::vector<uint8_t> & rgPacked, Sized sized,
-                 SlabDone slabDone)
+                 PinnedBuf<uint2> & pairsPk, PinnedBuf<uint32_t> & endCount, std::vector<uint8_t> & rgPacked,
+                 std::vector<uint8_t> & scanGeneric, Sized sized, SlabDone slabDone)
 {
     const uint32_t W = seg.n_windows;
     // lifetime histogram -> K
@@ -377,15 +384,21 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
     out.nPairs = nInst;
     out.nActivePairs = active;
 
-    // pass 1 (parallel over read groups): chunks per window -> winStart, chunk totals -> rgBase
-    rgBase.assign(seg.n_readgroups, 0);
+    // "Entities" below are the real read groups followed by the scan read groups of the samples that have several read
+    // groups (SegmentView::scanRg): such an entity covers the instances of ALL read groups of its sample -- they are
+    // contiguous in the caller's arrays -- and only gets the stage-1 image plus its winStart / endCount rows.
+    const uint32_t nRg = seg.n_readgroups, nV = static_cast<uint32_t>(c.scanSample.size()), nEnt = nRg + nV;
+    auto entLo = [&](size_t e) { return e < nRg ? seg.rg_offsets[e] : seg.rg_offsets[c.sampleRg[c.scanSample[e - nRg]]]; };
+    auto entHi = [&](size_t e) { return e < nRg ? seg.rg_offsets[e + 1] : seg.rg_offsets[c.sampleRg[c.scanSample[e - nRg] + 1]]; };
+    // pass 1 (parallel over entities): chunks per window -> winStart, chunk totals -> rgBase
+    rgBase.assign(nEnt, 0);
     const size_t wsRow = static_cast<size_t>(W) + K;           // slots 0 .. W + K - 2, plus the end entry
     auto slotOf = [K](uint32_t a, uint32_t chunkOff) { return a == 0 ? std::min(chunkOff, K) - 1 : a + K - 1; };
-    winStart.assignZero(static_cast<size_t>(seg.n_readgroups) * wsRow);
-    std::vector<uint64_t> rgChunks(seg.n_readgroups, 0);
-    pdh::parallelFor(seg.n_readgroups, [&](size_t rg) {
-        const uint64_t lo = seg.rg_offsets[rg], hi = seg.rg_offsets[rg + 1];
-        uint32_t * ws = winStart.data() + rg * wsRow;
+    winStart.assignZero(static_cast<size_t>(nEnt) * wsRow);
+    std::vector<uint64_t> rgChunks(nEnt, 0);
+    pdh::parallelFor(nEnt, [&](size_t e) {
+        const uint64_t lo = entLo(e), hi = entHi(e);
+        uint32_t * ws = winStart.data() + e * wsRow;
         for (uint64_t i = lo; i < hi; ++i)
         {
             uint32_t on = seg.pair_on[i], off = std::min(seg.pair_off[i], W);
@@ -398,61 +411,86 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
             acc += ws[x];
             ws[x] = acc;
         }
-        rgChunks[rg] = acc;
+        rgChunks[e] = acc;
     }, 8);
     uint64_t totalChunks = 0;
-    for (uint32_t rg = 0; rg < seg.n_readgroups; ++rg)
+    for (uint32_t e = 0; e < nEnt; ++e)
     {
-        rgBase[rg] = totalChunks;
-        totalChunks += rgChunks[rg];
+        if (e == nRg)
+            out.nChunks = totalChunks;                         // real chunks: pairs[] / start[] end here
+        rgBase[e] = totalChunks;
+        totalChunks += rgChunks[e];
     }
-    pairs.resize(totalChunks);
-    start.resize(totalChunks);
+    if (nV == 0)
+        out.nChunks = totalChunks;
+    pairs.resize(out.nChunks);
+    start.resize(out.nChunks);
     pairsPk.resize(totalChunks);
-    endCount.assignZero(static_cast<size_t>(seg.n_readgroups) * (W + 1));
-    rgPacked.assign(seg.n_readgroups, 0);
-    out.nChunks = pairs.size();
+    endCount.assignZero(static_cast<size_t>(nEnt) * (W + 1));
+    rgPacked.assign(nEnt, 0);
     sized();
-    // pass 2 (parallel): scatter the chunks to their slots, stable within a window; in slabs of read groups
-    const size_t nSlabs = std::min<size_t>(8, std::max<size_t>(1, seg.n_readgroups / 64));
-    for (size_t slab = 0; slab < nSlabs; ++slab)
+    // pass 2 (parallel): scatter the chunks to their slots, stable within a window; in slabs of entities
+    const size_t nSlabs = std::min<size_t>(8, std::max<size_t>(1, nRg / 64));
+    for (size_t slab = 0; slab <= nSlabs; ++slab)
     {
-    const size_t slabLo = seg.n_readgroups * slab / nSlabs, slabHi = seg.n_readgroups * (slab + 1) / nSlabs;
-    pdh::parallelFor(slabHi - slabLo, [&](size_t rgInSlab) {
-        const size_t rg = slabLo + rgInSlab;
-        const uint64_t lo = seg.rg_offsets[rg], hi = seg.rg_offsets[rg + 1];
-        const uint32_t * ws = winStart.data() + rg * wsRow;
-        std::vector<uint32_t> cursor(ws, ws + wsRow - 1);
-        const size_t base = rgBase[rg];
-        uint32_t * ec = endCount.data() + rg * (W + 1);
-        bool fits = W <= 0xffffu;
-        for (uint64_t i = lo; i < hi; ++i)
-        {
-            uint32_t on = seg.pair_on[i], off = std::min(seg.pair_off[i], W);
-            const int32_t dv = seg.pair_dev[i];
-            fits = fits && dv >= -32767 && dv <= 32766;
-            const uint32_t d16 = static_cast<uint32_t>(dv) & 0xffffu;
-            for (uint32_t a = on; a < off; a += K)
+        // slabs 0 .. nSlabs-1: the real read groups; the last one: the scan read groups
+        const size_t slabLo = slab < nSlabs ? nRg * slab / nSlabs : nRg;
+        const size_t slabHi = slab < nSlabs ? nRg * (slab + 1) / nSlabs : nEnt;
+        if (slabHi == slabLo)
+            continue;
+        pdh::parallelFor(slabHi - slabLo, [&](size_t inSlab) {
+            const size_t e = slabLo + inSlab;
+            const bool real = e < nRg;
+            const uint64_t lo = entLo(e), hi = entHi(e);
+            const uint32_t * ws = winStart.data() + e * wsRow;
+            std::vector<uint32_t> cursor(ws, ws + wsRow - 1);
+            const size_t base = rgBase[e];
+            uint32_t * ec = endCount.data() + e * (W + 1);
+            bool fits = W <= 0xffffu;
+            for (uint64_t i = lo; i < hi; ++i)
             {
-                const uint32_t chunkOff = std::min(off, a + K);
-                const uint32_t slot = cursor[slotOf(a, chunkOff)]++;
-                pairs[base + slot] = pd::PairDO{dv, chunkOff};
-                start[base + slot] = seg.pair_start[i];
-                pairsPk[base + slot] = make_uint2(d16 | (d16 << 16), (chunkOff & 0xffffu) | (chunkOff << 16));
-                ++ec[chunkOff];
+                uint32_t on = seg.pair_on[i], off = std::min(seg.pair_off[i], W);
+                const int32_t dv = seg.pair_dev[i];
+                fits = fits && dv >= -32767 && dv <= 32766;
+                const uint32_t d16 = static_cast<uint32_t>(dv) & 0xffffu;
+                for (uint32_t a = on; a < off; a += K)
+                {
+                    const uint32_t chunkOff = std::min(off, a + K);
+                    const uint32_t slot = cursor[slotOf(a, chunkOff)]++;
+                    if (real)
+                    {
+                        pairs[base + slot] = pd::PairDO{dv, chunkOff};
+                        start[base + slot] = seg.pair_start[i];
+                    }
+                    pairsPk[base + slot] = make_uint2(d16 | (d16 << 16), (chunkOff & 0xffffu) | (chunkOff << 16));
+                    ++ec[chunkOff];
+                }
             }
-        }
-        uint32_t acc = 0;
-        for (uint32_t w = 0; w <= W; ++w)
-        {
-            acc += ec[w];
-            ec[w] = acc;
-        }
-        rgPacked[rg] = fits ? 1 : 0;
-    }, 8);
-    slabDone(slabLo, slabHi);
+            uint32_t acc = 0;
+            for (uint32_t w = 0; w <= W; ++w)
+            {
+                acc += ec[w];
+                ec[w] = acc;
+            }
+            rgPacked[e] = fits ? 1 : 0;
+        }, 8);
+        slabDone(slabLo, slabHi);
     }
-    (void)c;
+    // where a real read group of a multi-read-group sample reaches its maxLoad, the reference drops that read group's
+    // pairs: those 512-window blocks of the sample go to the fallback kernel (it knows the read groups)
+    const size_t blocksPerSample = (static_cast<size_t>(W) + 2 * pd::kStage1Block - 1) / (2 * pd::kStage1Block);
+    scanGeneric.assign(static_cast<size_t>(nV) * blocksPerSample, 0);
+    pdh::parallelFor(nV, [&](size_t j) {
+        const uint32_t sIdx = c.scanSample[j];
+        for (uint32_t rg = c.sampleRg[sIdx]; rg < c.sampleRg[sIdx + 1]; ++rg)
+        {
+            const uint32_t * ws = winStart.data() + static_cast<size_t>(rg) * wsRow;
+            const uint32_t * ec = endCount.data() + static_cast<size_t>(rg) * (W + 1);
+            for (uint32_t w = 0; w < W; ++w)
+                if (ws[w + K] - ec[w] >= c.maxLoad[rg])
+                    scanGeneric[j * blocksPerSample + w / (2 * pd::kStage1Block)] = 1;
+        }
+    }, 4);
 }
 
 pd::SegmentView viewOf(const StagedSegment & s)
@@ -465,6 +503,9 @@ pd::SegmentView viewOf(const StagedSegment & s)
     v.pairsPk = s.pairsPk.p;
     v.endCount = s.endCount.p;
     v.rgPacked = s.rgPacked.p;
+    v.scanRg = s.scanRg;
+    v.scanGeneric = s.hasScanGeneric ? s.scanGeneric.p : nullptr;
+    v.nRealRg = s.nRealRg;
     v.nWindows = s.nWindows;
     v.maxLife = s.maxLife;
     v.firstPos = s.firstPos;
@@ -492,6 +533,9 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
         return fail(nullptr, "pd_ctx_create: invalid argument");
     if (sample_rg_offsets[0] != 0 || sample_rg_offsets[n_samples] != n_readgroups)
         return fail(nullptr, "pd_ctx_create: sample_rg_offsets do not cover the read groups");
+    for (uint32_t i = 0; i < n_samples; ++i)
+        if (sample_rg_offsets[i + 1] <= sample_rg_offsets[i])
+            return fail(nullptr, "pd_ctx_create: every sample needs at least one read group");
     if (cfg->iterations > (uint32_t)pd::kMaxIterationsCap)
         return fail(nullptr, "pd_ctx_create: iterations exceeds the device limit of 64");
     if (n_samples > 65535u)
@@ -531,6 +575,25 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
             pool.insert(pool.end(), rgs[i].hist_values, rgs[i].hist_values + rgs[i].hist_len);
             minThreshold = std::min(minThreshold, (int)rgs[i].min_init_del_len);
         }
+        // scan read groups of the samples that have several read groups (see SegmentView::scanRg)
+        std::vector<uint32_t> scanRg(n_samples);
+        c->maxLoad.resize(n_readgroups);
+        for (uint32_t i = 0; i < n_readgroups; ++i)
+            c->maxLoad[i] = rgs[i].max_load;
+        for (uint32_t sIdx = 0; sIdx < n_samples; ++sIdx)
+        {
+            if (sample_rg_offsets[sIdx + 1] - sample_rg_offsets[sIdx] == 1u)
+            {
+                scanRg[sIdx] = sample_rg_offsets[sIdx];
+                continue;
+            }
+            scanRg[sIdx] = n_readgroups + static_cast<uint32_t>(c->scanSample.size());
+            c->scanSample.push_back(sIdx);
+            pd::RgConst v = rc[sample_rg_offsets[sIdx]];
+            v.maxLoad = 0xffffffffu;            // the per-read-group limit is enforced through scanGeneric
+            rc.push_back(v);
+        }
+        c->dScanRg.upload(scanRg, c->stream);
         c->dRg.upload(rc, c->stream);
         c->dHist.upload(pool, c->stream);
         c->dSampleRg.upload(c->sampleRg, c->stream);
@@ -684,18 +747,26 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
             s->winStart.uploadPinned(winStart, cs);
         };
         auto slabDone = [&](size_t lo, size_t hi) {
-            const uint64_t a = rgBase[lo], b = hi < rgBase.size() ? rgBase[hi] : pairs.size();
+            const uint64_t a = rgBase[lo], b = hi < rgBase.size() ? rgBase[hi] : pairsPk.size();
             if (b > a)
             {
-                PD_HIP(hipMemcpyAsync(s->pairs.p + a, pairs.data() + a, (b - a) * sizeof(pd::PairDO), hipMemcpyHostToDevice, cs));
-                PD_HIP(hipMemcpyAsync(s->start.p + a, start.data() + a, (b - a) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+                if (lo < c->nRg)            // real read groups: all three chunk arrays; scan read groups: the stage-1 image only
+                {
+                    PD_HIP(hipMemcpyAsync(s->pairs.p + a, pairs.data() + a, (b - a) * sizeof(pd::PairDO), hipMemcpyHostToDevice, cs));
+                    PD_HIP(hipMemcpyAsync(s->start.p + a, start.data() + a, (b - a) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+                }
                 PD_HIP(hipMemcpyAsync(s->pairsPk.p + a, pairsPk.data() + a, (b - a) * sizeof(uint2), hipMemcpyHostToDevice, cs));
             }
             const size_t e0 = lo * (static_cast<size_t>(W) + 1), e1 = hi * (static_cast<size_t>(W) + 1);
             PD_HIP(hipMemcpyAsync(s->endCount.p + e0, endCount.data() + e0, (e1 - e0) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
         };
-        buildChunks(*c, *seg, *s, pairs, start, rgBase, winStart, pairsPk, endCount, rgPacked, sized, slabDone);
+        buildChunks(*c, *seg, *s, pairs, start, rgBase, winStart, pairsPk, endCount, rgPacked, c->hScanGeneric, sized, slabDone);
         s->rgPacked.upload(rgPacked, cs);
+        s->hasScanGeneric = !c->hScanGeneric.empty();
+        if (s->hasScanGeneric)
+            s->scanGeneric.upload(c->hScanGeneric, cs);
+        s->scanRg = c->dScanRg.p;
+        s->nRealRg = c->nRg;
         PD_HIP(hipStreamSynchronize(cs));              // the host scratch is reused by the next call
         *handle = c->nextHandle++;
         c->staged[*handle] = std::move(s);

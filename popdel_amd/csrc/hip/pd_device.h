@@ -61,7 +61,15 @@ struct SegmentView
     // (ready for packed 16-bit arithmetic on two windows at once); only valid for read groups with rgPacked != 0
     const uint2 *    pairsPk;      // [nChunks]
     const uint32_t * endCount;     // [nRg * (W + 1)] number of chunks of the read group that ended at or before w
-    const uint8_t *  rgPacked;     // [nRg] 1 if all deviations fit int16 and W fits 16 bits
+    const uint8_t *  rgPacked;     // [nRg + nScanRg] 1 if all deviations fit int16 and W fits 16 bits
+    // Samples with several read groups get a "scan read group" appended behind the real ones: the chunks of all their
+    // read groups as ONE stream (stage-1 image, winStart and endCount rows only), so that the scan kernel treats them
+    // like single-read-group samples. scanRg[s] is the sample's own read group or that appended one. Where one of the
+    // real read groups reaches its maxLoad (the reference then drops that read group's pairs) the 512-window block
+    // is flagged in scanGeneric and goes to the fallback kernel.
+    const uint32_t * scanRg;       // [nSamples]
+    const uint8_t *  scanGeneric;  // [nScanRg][ceil(W / 512)], or null if there are no such samples
+    uint32_t         nRealRg;
     uint32_t         nWindows;
     uint32_t         maxLife;      // K: a chunk lives at most K windows
     uint32_t         firstPos;

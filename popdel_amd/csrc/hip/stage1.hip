@@ -344,12 +344,12 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     const unsigned W = seg.nWindows;
     const unsigned K = seg.maxLife;
     const unsigned tid = threadIdx.x;
-    const unsigned rg0 = co.sampleRg[s];
-    const bool singleRg = (co.sampleRg[s + 1] - rg0) == 1u;
+    const unsigned rg0 = seg.scanRg[s];          // the (possibly appended) read group whose stream holds all pairs of s
     uint8_t * todo = tileTodo + (size_t)s * tilesPerSample + 2u * blockIdx.x;      // two 256-window tiles
     const bool secondTile = (w0 + kStage1Block) < W;
+    const bool rgOverloaded = rg0 >= seg.nRealRg && seg.scanGeneric[(size_t)(rg0 - seg.nRealRg) * gridDim.x + blockIdx.x] != 0;
 
-    if (!(singleRg && K <= 64u && seg.rgPacked[rg0]))
+    if (!(K <= 64u && seg.rgPacked[rg0]) || rgOverloaded)
     {
         if (tid == 0)
         {
