@@ -527,13 +527,16 @@ __global__ __launch_bounds__(kStage1Block) void stage1FallbackKernel(SegmentView
         const unsigned K = seg.maxLife;
         const unsigned tid = threadIdx.x;
         const unsigned w = w0 + tid;
-        const unsigned rg0 = co.sampleRg[s];
-        const bool singleRg = (co.sampleRg[s + 1] - rg0) == 1u;
+        // the sample's own read group or its scan read group (all pairs of the sample as one stream, packed image only)
+        const unsigned rg0 = seg.scanRg[s];
+        const bool merged = rg0 >= seg.nRealRg;
+        const bool rgOverloaded = merged && seg.scanGeneric[(size_t)(rg0 - seg.nRealRg) * ((W + 2u * kStage1Block - 1u) / (2u * kStage1Block)) +
+                                                            w0 / (2u * kStage1Block)] != 0;
         int q = 0;
         unsigned fl = 0;
         bool done = false;
         __syncthreads();                                           // LDS reuse across tiles
-        if (singleRg && K <= 64u)
+        if (K <= 64u && !rgOverloaded && (!merged || seg.rgPacked[rg0]))
         {
             const uint32_t * ws = seg.winStart + (size_t)rg0 * (W + K);
             const unsigned wlo0 = w0;
@@ -546,9 +549,24 @@ __global__ __launch_bounds__(kStage1Block) void stage1FallbackKernel(SegmentView
             const unsigned nPairs = ldsWs[nWs - 1] - A;
             if (nPairs <= (unsigned)kStage1LdsPairs)
             {
-                const PairDO * src = seg.pairs + seg.rgBase[rg0] + A;
-                for (unsigned i = tid; i < nPairs; i += kStage1Block)
-                    ldsPairs[i] = src[i];
+                if (!merged)
+                {
+                    const PairDO * src = seg.pairs + seg.rgBase[rg0] + A;
+                    for (unsigned i = tid; i < nPairs; i += kStage1Block)
+                        ldsPairs[i] = src[i];
+                }
+                else
+                {
+                    const uint2 * src = seg.pairsPk + seg.rgBase[rg0] + A;
+                    for (unsigned i = tid; i < nPairs; i += kStage1Block)
+                    {
+                        const uint2 e = src[i];
+                        PairDO p;
+                        p.dev = (int)(short)(e.x & 0xffffu);
+                        p.off = e.y & 0xffffu;
+                        ldsPairs[i] = p;
+                    }
+                }
                 __syncthreads();
                 unsigned a = 0, cnt = 0;
                 if (w < W)
