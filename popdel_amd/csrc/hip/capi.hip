@@ -452,7 +452,7 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
                 uint32_t on = seg.pair_on[i], off = std::min(seg.pair_off[i], W);
                 const int32_t dv = seg.pair_dev[i];
                 fits = fits && dv >= -32767 && dv <= 32766;
-                const uint32_t d16 = static_cast<uint32_t>(dv) & 0xffffu;
+                const uint32_t d16 = (static_cast<uint32_t>(dv) & 0xffffu) ^ 0x8000u;     // biased: see stage1.hip
                 for (uint32_t a = on; a < off; a += K)
                 {
                     const uint32_t chunkOff = std::min(off, a + K);

@@ -182,12 +182,14 @@ __device__ __forceinline__ unsigned waveMaxU32(unsigned v)
 }
 
 // ---- packed 16-bit variant: two cells per lane ----------------------------------------------------------------------
-// Deviations that fit int16 are sorted two at a time with v_pk_min_i16 / v_pk_max_i16: the low half of every register
-// belongs to window w, the high half to window w + 256. The number of active pairs n(w) is known before the values
-// are loaded (pairs started minus pairs ended, both per window prefix counts), so the inactive slots can be filled
-// with p(w) copies of -INF and +INF otherwise such that the wanted order statistics land at the STATIC positions
-// T and T+1 of the sorted array; the compiler then prunes every comparator outside the cone of those two outputs.
-typedef short v2s __attribute__((ext_vector_type(2)));
+// Deviations that fit int16 are sorted two at a time with v_pk_min_u16 / v_pk_max_u16: the low half of every register
+// belongs to window w, the high half to window w + 1. The staged image holds the deviations BIASED by 0x8000 (order
+// preserving map of int16 onto uint16), so that the two fillers are the all-zeros / all-ones patterns: -INF = 0x0000,
+// +INF = 0xFFFF -- a filler is then simply a sign mask, no constant to mix in. The number of active pairs n(w) is known
+// before the values are loaded (pairs started minus pairs ended, both per window prefix counts), so the inactive slots
+// can be filled with p(w) copies of -INF and +INF otherwise such that the wanted order statistics land at the STATIC
+// positions T and T+1 of the sorted array; the compiler then prunes every comparator outside the cone of those two.
+typedef unsigned short v2s __attribute__((ext_vector_type(2)));
 
 #define PD_CE16(i, j)                                          \
     {                                                          \
@@ -243,10 +245,10 @@ struct PairPk
 // Two ADJACENT windows per lane (w in the low halves, w + 1 in the high halves). Their candidate ranges overlap almost
 // completely, so every LDS entry is read once and feeds both cells: slot c of the lane is entry (aA + c) for both.
 // All per-slot logic (active test, range test, filler choice, filler count) is packed 16-bit arithmetic on both cells
-// at once: a slot costs ~10 VALU for the two cells.
+// at once: a slot costs 7 VALU for the two cells.
 // The per-slot logic below is written with the packed instructions spelled out: left to itself hipcc canonicalises
 // "(a - b) >> 15" on <2 x i16> into a compare + select per half (v_cmp_*_sdwa, v_cndmask, v_perm: ~16 VALU per slot
-// instead of 9). These are pure register-to-register VALU ops, so the asm statements need no waits or clobbers.
+// instead of 7). These are pure register-to-register VALU ops, so the asm statements need no waits or clobbers.
 __device__ __forceinline__ unsigned asmPkSub(unsigned a, unsigned b)
 {
     unsigned r;
@@ -280,28 +282,30 @@ __device__ __forceinline__ void stage1PairFast(const PairPk * lds, unsigned aA, 
     // number of -INF fillers that moves rank l0(n) to position T
     const unsigned pA = (nA >= 2u) ? (T - rankL0(nA)) : 0u;
     const unsigned pB = (nB >= 2u) ? (T - rankL0(nB)) : 0u;
-    const unsigned one = 0x00010001u;
-    unsigned qPk = asmPkSub(0u, cntPk);                    // c - cnt        (negative while the slot is in range)
-    unsigned dPk = asmPkSub(0u, pA | (pB << 16));          // c - (p + #active slots before c): negative -> filler is -INF
+    const unsigned one = 0x00010001u, minusOne = 0xFFFFFFFFu;
+    const unsigned w1Pk = asmPkAddS(wPk, one);             // w + 1
+    unsigned rPk = asmPkAddS(cntPk, minusOne);             // cnt - 1 - c: negative once the slot is out of range
+    unsigned vPk = pA | (pB << 16);                        // p - #inactive slots so far: >= 0 -> this filler is -INF
     v2s r[C];
 #pragma unroll
     for (int c = 0; c < C; ++c)
     {
         const PairPk e = lds[aA + c];
-        // active <=> off > w and c < cnt: both differences negative
-        const unsigned m = asmPkSign(asmPkSub(wPk, e.offoff) & qPk);
-        // filler: -INF (0x8000) for the first p inactive slots, +INF (0x7FFF) afterwards
-        const unsigned fill = asmPkSign(dPk) ^ 0x7FFF7FFFu;
-        const unsigned x = (e.devdev & m) | (fill & ~m);
-        qPk = asmPkAddS(qPk, one);
-        dPk = asmPkAdd(asmPkAddS(dPk, one), m);               // +1, and -1 again if the slot was active
+        // INACTIVE <=> off <= w (off - (w + 1) negative) or c >= cnt: 7 VALU per slot for the two cells
+        // (a native formulation -- vector types, shift amount hidden from the optimiser -- compiled to 8 and ran 7 % slower)
+        const unsigned mI = asmPkSign(asmPkSub(e.offoff, w1Pk) | rPk);
+        vPk = asmPkAdd(vPk, mI);                           // one filler more
+        const unsigned fill = asmPkSign(vPk);              // 0x0000 = -INF while within the first p, 0xFFFF = +INF after
+        const unsigned x = (fill & mI) | (e.devdev & ~mI);
+        rPk = asmPkAddS(rPk, minusOne);
         r[c] = __builtin_bit_cast(v2s, x);
     }
     sortRegs16<C>(r);
-    vaA = r[T].x;
-    vbA = r[T + 1].x;
-    vaB = r[T].y;
-    vbB = r[T + 1].y;
+    // back from the biased representation
+    vaA = (int)(short)(r[T].x ^ 0x8000u);
+    vbA = (int)(short)(r[T + 1].x ^ 0x8000u);
+    vaB = (int)(short)(r[T].y ^ 0x8000u);
+    vbB = (int)(short)(r[T + 1].y ^ 0x8000u);
 }
 
 // Same interpolation for int16 inputs: everything fits 32 bits.
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(kStage1Block) void stage1FallbackKernel(SegmentView
                     {
                         const uint2 e = src[i];
                         PairDO p;
-                        p.dev = (int)(short)(e.x & 0xffffu);
+                        p.dev = (int)(short)((e.x & 0xffffu) ^ 0x8000u);      // the packed image is biased
                         p.off = e.y & 0xffffu;
                         ldsPairs[i] = p;
                     }
