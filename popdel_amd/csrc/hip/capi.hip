@@ -6,6 +6,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -243,9 +244,11 @@ struct PinnedBlock
     size_t bytes = 0;
 };
 std::vector<PinnedBlock> g_pinnedPool;
+std::mutex g_pinnedLock;            // contexts may live on different host threads
 
 PinnedBlock takePinned(size_t bytes)
 {
+    std::unique_lock<std::mutex> guard(g_pinnedLock);
     size_t best = g_pinnedPool.size();
     for (size_t i = 0; i < g_pinnedPool.size(); ++i)
         if (g_pinnedPool[i].bytes >= bytes && (best == g_pinnedPool.size() || g_pinnedPool[i].bytes < g_pinnedPool[best].bytes))
@@ -256,6 +259,7 @@ PinnedBlock takePinned(size_t bytes)
         g_pinnedPool.erase(g_pinnedPool.begin() + best);
         return b;
     }
+    guard.unlock();
     PinnedBlock b;
     b.bytes = bytes + bytes / 4 + 4096;
     PD_HIP(hipHostMalloc(&b.p, b.bytes, hipHostMallocDefault));
@@ -266,12 +270,15 @@ void givePinned(PinnedBlock b)
 {
     if (!b.p)
         return;
-    if (g_pinnedPool.size() >= 4)
     {
-        (void)hipHostFree(b.p);
-        return;
+        std::lock_guard<std::mutex> guard(g_pinnedLock);
+        if (g_pinnedPool.size() < 4)
+        {
+            g_pinnedPool.push_back(b);
+            return;
+        }
     }
-    g_pinnedPool.push_back(b);
+    (void)hipHostFree(b.p);
 }
 
 // pd_calls plus what pd_calls_free() needs to know.
