@@ -176,6 +176,9 @@ struct pd_ctx
     DevBuf<unsigned> dIterFlags;
     DevBuf<uint32_t> dSampleRg;
     DevBuf<uint32_t> dScanRg;
+    // tiles with multi-read-group samples (pd::MultiTiles): static tables
+    DevBuf<uint32_t> dMtTile, dMtRgLo, dMtRgHi, dMtWaveBase, dMtWaveTile, dRgSample;
+    pd::MultiTiles multiTiles;
     std::vector<uint32_t> scanSample;       // appended scan read group j -> its sample (samples with several read groups)
     std::vector<uint32_t> maxLoad;          // per real read group
     pd::CohortView cohort;
@@ -217,6 +220,12 @@ struct pd_ctx
     DevBuf<uint16_t> dCellN;
     DevBuf<uint8_t> dWaveRows;
     DevBuf<unsigned> dTileMode;
+    DevBuf<int32_t> dMDev;
+    DevBuf<uint32_t> dMStart;
+    DevBuf<uint16_t> dMN;
+    DevBuf<uint8_t> dMWaveRows;
+    DevBuf<double> dRgOutD;
+    DevBuf<unsigned> dRgOutU;
     DevBuf<unsigned> dSuppFirst, dSuppLast, dEmit;
     DevBuf<uint32_t> dPl, dLad, dDad, dFl, dOutPl;
     pd_timing timing;
@@ -601,6 +610,47 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
             rc.push_back(v);
         }
         c->dScanRg.upload(scanRg, c->stream);
+        {
+            // multi tiles: 256-sample tiles with at least one multi-read-group sample
+            std::vector<uint32_t> mtTile, mtRgLo, mtRgHi, mtWaveBase, mtWaveTile, rgSample(n_readgroups);
+            for (uint32_t sIdx = 0; sIdx < n_samples; ++sIdx)
+                for (uint32_t rg = sample_rg_offsets[sIdx]; rg < sample_rg_offsets[sIdx + 1]; ++rg)
+                    rgSample[rg] = sIdx;
+            const uint32_t tiles = (n_samples + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock;
+            uint32_t waves = 0;
+            for (uint32_t t = 0; t < tiles; ++t)
+            {
+                const uint32_t s0 = t * pd::kSamplesPerBlock, s1 = std::min<uint32_t>(n_samples, s0 + pd::kSamplesPerBlock);
+                const uint32_t lo = sample_rg_offsets[s0], hi = sample_rg_offsets[s1];
+                if (hi - lo == s1 - s0)
+                    continue;                                  // one read group per sample
+                mtTile.push_back(t);
+                mtRgLo.push_back(lo);
+                mtRgHi.push_back(hi);
+                mtWaveBase.push_back(waves);
+                for (uint32_t k = 0; k < (hi - lo + 63) / 64; ++k)
+                    mtWaveTile.push_back(static_cast<uint32_t>(mtTile.size() - 1));
+                waves += (hi - lo + 63) / 64;
+            }
+            c->dRgSample.upload(rgSample, c->stream);
+            std::memset(&c->multiTiles, 0, sizeof(c->multiTiles));
+            c->multiTiles.n = static_cast<uint32_t>(mtTile.size());
+            c->multiTiles.nWaves = waves;
+            if (!mtTile.empty())
+            {
+                c->dMtTile.upload(mtTile, c->stream);
+                c->dMtRgLo.upload(mtRgLo, c->stream);
+                c->dMtRgHi.upload(mtRgHi, c->stream);
+                c->dMtWaveBase.upload(mtWaveBase, c->stream);
+                c->dMtWaveTile.upload(mtWaveTile, c->stream);
+                c->multiTiles.tile = c->dMtTile.p;
+                c->multiTiles.rgLo = c->dMtRgLo.p;
+                c->multiTiles.rgHi = c->dMtRgHi.p;
+                c->multiTiles.waveBase = c->dMtWaveBase.p;
+                c->multiTiles.waveTile = c->dMtWaveTile.p;
+            }
+            c->multiTiles.rgSample = c->dRgSample.p;
+        }
         c->dRg.upload(rc, c->stream);
         c->dHist.upload(pool, c->stream);
         c->dSampleRg.upload(c->sampleRg, c->stream);
@@ -1034,6 +1084,24 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             b.cellN = c->dCellN.p;
             b.waveRows = c->dWaveRows.p;
             b.tileMode = c->dTileMode.p;
+            b.mt = c->multiTiles;
+            b.nRg = c->nRg;
+            if (b.mt.n != 0)
+            {
+                const size_t mWaves = static_cast<size_t>(nb) * b.mt.nWaves;
+                c->dMDev.ensure(mWaves * pd::kDenseCap * 64);
+                c->dMStart.ensure(mWaves * pd::kDenseCap * 64);
+                c->dMN.ensure(static_cast<size_t>(nb) * c->nRg);
+                c->dMWaveRows.ensure(mWaves);
+                c->dRgOutD.ensure(static_cast<size_t>(nb) * c->nRg * 8);
+                c->dRgOutU.ensure(static_cast<size_t>(nb) * c->nRg * 12);
+                b.mDev = c->dMDev.p;
+                b.mStart = c->dMStart.p;
+                b.mN = c->dMN.p;
+                b.mWaveRows = c->dMWaveRows.p;
+                b.rgOutD = c->dRgOutD.p;
+                b.rgOutU = c->dRgOutU.p;
+            }
             c->dPl.ensure(static_cast<size_t>(nb) * S * 3);
             c->dLad.ensure(static_cast<size_t>(nb) * S * 3);
             c->dDad.ensure(static_cast<size_t>(nb) * S * 5);

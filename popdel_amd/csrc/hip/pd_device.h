@@ -114,6 +114,25 @@ struct Stage2Buffers;
 __device__ __forceinline__ double * tileSlot(const Stage2Buffers & b, unsigned c, unsigned t);
 __device__ __forceinline__ double * rg0Slot(const Stage2Buffers & b, unsigned c, unsigned r);
 
+enum TileMode : unsigned
+{
+    kTileDense = 0,          // one lane per sample (every sample of the tile has one read group)
+    kTileMulti = 1,          // one lane per read group + per-sample combine
+    kTileGeneric = 2         // half-wave per sample with on-the-fly compaction (more than kDenseCap pairs somewhere)
+};
+
+// Static description of the tiles that contain multi-read-group samples.
+struct MultiTiles
+{
+    const uint32_t * tile;       // [n] sample tile
+    const uint32_t * rgLo;       // [n] first read group of the tile's samples
+    const uint32_t * rgHi;       // [n] one past the last
+    const uint32_t * waveBase;   // [n] first 64-read-group wave tile of the tile in the multi image
+    const uint32_t * waveTile;   // [nWaves] multi tile of a wave tile
+    const uint32_t * rgSample;   // [nRg] sample (local index) of a read group
+    uint32_t         n, nWaves;
+};
+
 // ---- stage 2 per-cell state -------------------------------------------------------------------------------------
 enum CellPhase : int
 {
@@ -177,7 +196,18 @@ struct Stage2Buffers
     uint32_t *  cellStart;   // same shape
     uint16_t *  cellN;       // [nCells][S] active pairs of the sample's read group, or kDenseHighCov
     uint8_t *   waveRows;    // [nCells][ownTiles*4] max cellN over the wave tile (rows in use)
-    unsigned *  tileMode;    // [nCells][ownTiles] 0: dense kernels, 1: generic kernels
+    unsigned *  tileMode;    // [nCells][ownTiles] kTileDense / kTileMulti / kTileGeneric (raised with atomicMax)
+    // Tiles that contain samples with several read groups ("multi tiles", a static property of the cohort) have a second
+    // dense image with ONE LANE PER READ GROUP: rows of 64 read groups instead of 64 samples. Their kernels run the
+    // per-pair loops per read group, park the per-read-group results in rgOut and then add them up per sample.
+    MultiTiles  mt;
+    int32_t *   mDev;        // [nCells][mt.nWaves][kDenseCap][64]
+    uint32_t *  mStart;      // same shape
+    uint16_t *  mN;          // [nCells][nRg] active pairs of the read group, or kDenseHighCov (multi tiles only)
+    uint8_t *   mWaveRows;   // [nCells][mt.nWaves]
+    double *    rgOutD;      // [nCells][nRg][8]  per-read-group sums (log-likelihoods, log10-likelihoods)
+    unsigned *  rgOutU;      // [nCells][nRg][12] per-read-group counts (LAD, DAD, first/last, pairs, flags)
+    unsigned    nRg;
     unsigned    ownTiles;    // 256-sample tiles of this context
     int         forceGeneric; // debugging (POPDEL_HIP_FORCE_GENERIC): every tile through the generic kernels
     // final-pass outputs, [nCells][S][k]

@@ -571,7 +571,8 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
             continue;
         }
         const SampleMeta & meta = shMeta[inWt];
-        bool generic = (meta.rg1 - meta.rg0) != 1u || b.forceGeneric != 0;
+        const bool multi = (meta.rg1 - meta.rg0) != 1u;        // its pairs go into the per-read-group image instead
+        bool generic = b.forceGeneric != 0;
         unsigned nDense = 0;
         for (unsigned rg = meta.rg0; rg < meta.rg1; ++rg)
         {
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
                 {
                     const bool act = p[g].off > w;                 // off == 0 for lanes past the end
                     const unsigned long long bal = __ballot(act) & hm;
-                    if (act)
+                    if (act && !multi)
                     {
                         const unsigned pos = n + (unsigned)__popcll(bal & below);
                         if (pos < (unsigned)kDenseCap)
@@ -631,10 +632,13 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
         low += (flags[(size_t)s * seg.nWindows + w] & 1u) ? 1u : 0u;
         if (hl == 0)
         {
-            shN[inWt] = generic ? 0u : nDense;
-            b.cellN[(size_t)cellIdx * co.nSamples + s] = (uint16_t)(generic ? 0u : nDense);
+            const bool noRows = generic || multi;
+            shN[inWt] = noRows ? 0u : nDense;
+            b.cellN[(size_t)cellIdx * co.nSamples + s] = (uint16_t)(noRows ? 0u : nDense);
             if (generic)
-                shGeneric = 1u;
+                atomicMax(&shGeneric, 2u);
+            else if (multi)
+                atomicMax(&shGeneric, 1u);
             else if (nDense != kDenseHighCov)
                 atomicMax(&shRows, nDense);
         }
@@ -669,8 +673,10 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
         b.waveRows[wtGlobal] = (uint8_t)rows;
         if (shGeneric)
         {
-            atomicMax(&b.tileMode[(size_t)cellIdx * b.ownTiles + wt / 4], 1u);     // the whole 256-sample tile goes generic
-            atomicAdd(&mine[3], 1u);                       // tells the host that the generic kernels are needed at all
+            // the whole 256-sample tile leaves the lane-per-sample kernels: kTileMulti (1) or kTileGeneric (2)
+            atomicMax(&b.tileMode[(size_t)cellIdx * b.ownTiles + wt / 4], shGeneric);
+            if (shGeneric == 2u)
+                atomicAdd(&mine[3], 1u);                   // tells the host that the generic kernels are needed at all
         }
     }
 }
@@ -776,7 +782,7 @@ __global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, Co
     const unsigned cellIdx = PD_CELL_IDX;
     CellState & cs = b.cells[cellIdx];
     const int wantPhase = mode == 0 ? kCellIterating : kCellConverged;
-    if (cs.phase != wantPhase || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] == 0)
+    if (cs.phase != wantPhase || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] != kTileGeneric)
         return;
     const unsigned w = (unsigned)cs.window;
     const int len = (int)(mode == 0 ? cs.len : cs.prevLen);
@@ -1064,7 +1070,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, 
     __shared__ double red[kHalvesPerBlock];
     const unsigned cellIdx = PD_CELL_IDX;
     const CellState & cs = b.cells[cellIdx];
-    if (cs.phase != kCellIterating || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] == 0)
+    if (cs.phase != kCellIterating || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] != kTileGeneric)
         return;
     const unsigned w = (unsigned)cs.window;
     const int len = (int)cs.len;
@@ -1420,7 +1426,7 @@ __global__ __launch_bounds__(kSampleTile) void finalKernel(SegmentView seg, Coho
     __shared__ unsigned shSt[kHalvesPerBlock][kHalfBufCap];
     const unsigned cellIdx = PD_CELL_IDX;
     CellState & cs = b.cells[cellIdx];
-    if (cs.phase != kCellFinal || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] == 0)
+    if (cs.phase != kCellFinal || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] != kTileGeneric)
         return;
     const unsigned w = (unsigned)cs.window;
     const int len = (int)cs.len;
@@ -1763,6 +1769,552 @@ __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, S
     b.fl[o * 2 + 1] = mx;
 }
 
+// =====================================================================================================================
+// Multi tiles (samples with several read groups): the same three passes with ONE LANE PER READ GROUP over a second
+// dense image, then one lane per sample adds up the results of its read groups in read-group order.
+// =====================================================================================================================
+// Dense image of the multi tiles: one workgroup per (cell, 64-read-group wave tile).
+__global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView seg, CohortView co, Stage2Buffers b)
+{
+    __shared__ int shDev[64][kDenseCap + 1];
+    __shared__ unsigned shSt[64][kDenseCap + 1];
+    __shared__ unsigned shN[64];
+    __shared__ unsigned shRows;
+    const unsigned cellIdx = blockIdx.y, mw = blockIdx.x;
+    const unsigned mtI = b.mt.waveTile[mw];
+    if (b.tileMode[(size_t)cellIdx * b.ownTiles + b.mt.tile[mtI]] != kTileMulti)
+        return;
+    const unsigned rgBase = b.mt.rgLo[mtI] + (mw - b.mt.waveBase[mtI]) * 64u, rgHi = b.mt.rgHi[mtI];
+    const unsigned w = (unsigned)b.cells[cellIdx].window;
+    const unsigned hl = threadIdx.x & 31u, half = threadIdx.x >> 5;
+    const unsigned long long hm = halfMask();
+    const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
+    if (threadIdx.x == 0)
+        shRows = 0;
+    __syncthreads();
+    constexpr unsigned kHalves = kGatherThreads / 32;
+    for (unsigned k = 0; k < 64u / kHalves; ++k)
+    {
+        const unsigned inWt = half + k * kHalves;
+        const unsigned rg = rgBase + inWt;
+        if (rg >= rgHi)                                    // uniform per half-wave
+        {
+            if (hl == 0)
+                shN[inWt] = 0;
+            continue;
+        }
+        const PairRange r = pairRange(seg, rg, w);
+        unsigned n = 0;
+        for (unsigned base = r.begin; base < r.end; base += 64u)
+        {
+            PairDO p[2];
+            unsigned st[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+            {
+                const unsigned i = base + 32u * g + hl;
+                p[g].dev = 0;
+                p[g].off = 0;
+                st[g] = 0;
+                if (i < r.end)
+                {
+                    p[g] = r.p[i];
+                    st[g] = r.st[i];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+            {
+                const bool act = p[g].off > w;
+                const unsigned long long bal = __ballot(act) & hm;
+                if (act)
+                {
+                    const unsigned pos = n + (unsigned)__popcll(bal & below);
+                    if (pos < (unsigned)kDenseCap)
+                    {
+                        shDev[inWt][pos] = p[g].dev;
+                        shSt[inWt][pos] = st[g];
+                    }
+                }
+                n += (unsigned)__popcll(bal);
+            }
+        }
+        const unsigned nDense = (n >= co.rg[rg].maxLoad) ? kDenseHighCov : n;   // n <= kDenseCap otherwise (else: kTileGeneric)
+        if (hl == 0)
+        {
+            shN[inWt] = nDense;
+            b.mN[(size_t)cellIdx * b.nRg + rg] = (uint16_t)nDense;
+            if (nDense != kDenseHighCov)
+                atomicMax(&shRows, nDense);
+        }
+    }
+    __syncthreads();
+    const unsigned rows = shRows;
+    const size_t wtGlobal = (size_t)cellIdx * b.mt.nWaves + mw;
+    int32_t * outD = b.mDev + wtGlobal * (kDenseCap * 64);
+    uint32_t * outS = b.mStart + wtGlobal * (kDenseCap * 64);
+    for (unsigned idx = threadIdx.x; idx < rows * 64u; idx += blockDim.x)
+    {
+        const unsigned j = idx >> 6, lane = idx & 63u, nl = shN[lane];
+        const bool has = nl != kDenseHighCov && j < nl;
+        outD[idx] = has ? shDev[lane][j] : 0;
+        outS[idx] = has ? shSt[lane][j] : 0u;
+    }
+    if (threadIdx.x == 0)
+        b.mWaveRows[wtGlobal] = (uint8_t)rows;
+}
+
+// flag word of a read group's parked result
+#define PD_RGF_HIGHCOV 0x80000000u
+#define PD_RGF_EQ 0x40000000u
+
+__global__ __launch_bounds__(kSampleTile) void dataLikMultiKernel(CohortView co, Stage2Buffers b, int mode)
+{
+    __shared__ double red[4];
+    const unsigned cellIdx = blockIdx.y, mtI = blockIdx.x, tileIdx = b.mt.tile[mtI];
+    const CellState & cs = b.cells[cellIdx];
+    const int wantPhase = mode == 0 ? kCellIterating : kCellConverged;
+    if (cs.phase != wantPhase || b.tileMode[(size_t)cellIdx * b.ownTiles + tileIdx] != kTileMulti)
+        return;
+    const int len = (int)(mode == 0 ? cs.len : cs.prevLen);
+    const unsigned rgLo = b.mt.rgLo[mtI], rgHi = b.mt.rgHi[mtI];
+    // phase 1: one lane per read group
+    for (unsigned base = rgLo; base < rgHi; base += kSampleTile)
+    {
+        const unsigned rg = base + threadIdx.x;
+        const bool valid = rg < rgHi;
+        const size_t wtGlobal = (size_t)cellIdx * b.mt.nWaves + b.mt.waveBase[mtI] + ((base - rgLo) >> 6) + (threadIdx.x >> 6);
+        const unsigned rows = (base - rgLo) + (threadIdx.x & ~63u) < rgHi - rgLo ? b.mWaveRows[wtGlobal] : 0u;
+        const int32_t * col = b.mDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+        unsigned n = 0;
+        LaneRg l = {};
+        int refShift = 0;
+        if (valid)
+        {
+            l = laneRg(co.rg[rg]);
+            n = b.mN[(size_t)cellIdx * b.nRg + rg];
+            refShift = (mode == 0) ? b.shifts[(size_t)cellIdx * co.nRg + rg] : 0;
+        }
+        const bool highCov = n == kDenseHighCov;
+        const unsigned nn = highCov ? 0u : n;
+        double g0 = 0, g2 = 0, prod = 1.0;
+        int esum = 0;
+        bool eq = true;
+#pragma unroll 4
+        for (unsigned j = 0; j < rows; ++j)
+        {
+            const bool use = j < nn;
+            const int dv = col[j * 64];
+            bool inR, inD;
+            const uint64_t pr = lanePosClamped(l, dv - refShift, inR), pdl = lanePosClamped(l, dv - len, inD);
+            double2 tr = make_double2(l.minProb, l.logMinProb), td = tr;
+            if (use && inR)
+                tr = *reinterpret_cast<const double2 *>(&co.tab[pr]);
+            if (use && inD)
+                td = *reinterpret_cast<const double2 *>(&co.tab[pdl]);
+            int e;
+            const double m = frexp(tr.x + td.x, &e);
+            g0 += use ? tr.y : 0.0;
+            g2 += use ? td.y : 0.0;
+            prod *= use ? m : 1.0;
+            esum += use ? e : 0;
+            eq = eq && (!use || tr.x == td.x);
+        }
+        if (valid)
+        {
+            const double g1 = nn ? log(prod) + (double)(esum - (int)nn) * PD_LN2 : 0.0;
+            double * od = b.rgOutD + ((size_t)cellIdx * b.nRg + rg) * 8;
+            od[0] = g0;
+            od[1] = g1;
+            od[2] = g2;
+            b.rgOutU[((size_t)cellIdx * b.nRg + rg) * 12] = nn | (highCov ? PD_RGF_HIGHCOV : 0u) | (eq ? PD_RGF_EQ : 0u);
+            if (rg == 0 && b.rank == 0)
+            {
+                double * r0 = rg0Slot(b, cellIdx, 0);
+                if (highCov)
+                {
+                    r0[0] = r0[1] = r0[2] = 0;
+                    r0[3] = 1;
+                }
+                else
+                {
+                    const double m = fmax(fmax(g0, g1), g2);
+                    r0[0] = g0 - m;
+                    r0[1] = g1 - m;
+                    r0[2] = g2 - m;
+                    r0[3] = 0;
+                }
+            }
+        }
+    }
+    __syncthreads();                                       // the parked results are read by other lanes of this workgroup
+    // phase 2: one lane per sample
+    double term = 0;
+    const unsigned s = tileIdx * kSamplesPerBlock + threadIdx.x;
+    if (s < co.nSamples)
+    {
+        double logL[3] = {0, 0, 0};
+        unsigned nUsed = 0;
+        bool allEq = true;
+        for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
+        {
+            const unsigned f = b.rgOutU[((size_t)cellIdx * b.nRg + rg) * 12];
+            if (f & PD_RGF_HIGHCOV)
+                continue;
+            const double * od = b.rgOutD + ((size_t)cellIdx * b.nRg + rg) * 8;
+            logL[0] += od[0];
+            logL[1] += od[1];
+            logL[2] += od[2];
+            nUsed += f & 0xffffu;
+            allEq = allEq && (f & PD_RGF_EQ) != 0u;
+        }
+        double d[3];
+        finishTriple(d, logL, nUsed, allEq);
+        double * out = b.dl + ((size_t)cellIdx * co.nSamples + s) * 3;
+        out[0] = d[0];
+        out[1] = d[1];
+        out[2] = d[2];
+        if (mode == 0)
+        {
+            const double p0 = exp(d[0]) * cs.gt[0];
+            const double p1 = exp(d[1]) * cs.gt[1];
+            const double p2 = exp(d[2]) * cs.gt[2];
+            const double pAll = p0 + p1 + p2;
+            term = (p1 + 2 * p2) / pAll;
+        }
+    }
+    if (mode == 0)
+    {
+        const double t = blockSum(term, red);
+        if (threadIdx.x == 0)
+            tileSlot(b, cellIdx, b.rank * b.tilesPerRank + tileIdx)[2] = t;
+    }
+}
+
+__global__ __launch_bounds__(kSampleTile) void updateLenMultiKernel(CohortView co, Stage2Buffers b)
+{
+    __shared__ double red[4];
+    const unsigned cellIdx = blockIdx.y, mtI = blockIdx.x, tileIdx = b.mt.tile[mtI];
+    const CellState & cs = b.cells[cellIdx];
+    if (cs.phase != kCellIterating || b.tileMode[(size_t)cellIdx * b.ownTiles + tileIdx] != kTileMulti)
+        return;
+    const int len = (int)cs.len;
+    const double g0 = cs.gt[0], g1 = cs.gt[1], g2 = cs.gt[2];
+    const double * rg0 = rg0Slot(b, cellIdx, 0);
+    bool rgNan = rg0[3] != 0;
+    double ea0Rg = 0, ea1Rg = 0;
+    if (!rgNan)
+    {
+        const double aSumRg = exp(rg0[0]) * g0 + exp(rg0[1]) * g1 + exp(rg0[2]) * g2;
+        const double l0 = (rg0[0] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[0];
+        const double l1 = (rg0[1] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[1];
+        ea0Rg = exp(l0 + log(g0) - log(aSumRg));
+        ea1Rg = exp(l1 + log(g1) - log(aSumRg));
+        rgNan = isnan(ea0Rg) || isnan(ea1Rg);
+    }
+    const unsigned rgLo = b.mt.rgLo[mtI], rgHi = b.mt.rgHi[mtI];
+    double sumDelAcc = 0, wSumDelAcc = 0;                  // over the read groups this lane handles, in read-group order
+    for (unsigned base = rgLo; base < rgHi; base += kSampleTile)
+    {
+        const unsigned rg = base + threadIdx.x;
+        const bool valid = rg < rgHi;
+        const size_t wtGlobal = (size_t)cellIdx * b.mt.nWaves + b.mt.waveBase[mtI] + ((base - rgLo) >> 6) + (threadIdx.x >> 6);
+        const unsigned rows = (base - rgLo) + (threadIdx.x & ~63u) < rgHi - rgLo ? b.mWaveRows[wtGlobal] : 0u;
+        const int32_t * col = b.mDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+        unsigned n = 0;
+        LaneRg l = {};
+        int refShift = 0;
+        double ea1 = 0, ea2 = 0;
+        int * shiftSlot = nullptr;
+        if (valid)
+        {
+            l = laneRg(co.rg[rg]);
+            n = b.mN[(size_t)cellIdx * b.nRg + rg];
+            shiftSlot = b.shifts + (size_t)cellIdx * co.nRg + rg;
+            refShift = *shiftSlot;
+            const double * d = b.dl + ((size_t)cellIdx * co.nSamples + b.mt.rgSample[rg]) * 3;
+            const double aSum = exp(d[0]) * g0 + exp(d[1]) * g1 + exp(d[2]) * g2;
+            ea1 = exp(d[1] + log(g1) - log(aSum));
+            ea2 = exp(d[2] + log(g2) - log(aSum));
+        }
+        const bool highCov = n == kDenseHighCov;
+        const unsigned nn = highCov ? 0u : n;
+        double sumDel = 0, wSumDel = 0, sumRef = 0, wSumRef = 0;
+#pragma unroll 4
+        for (unsigned j = 0; j < rows; ++j)
+        {
+            const bool use = j < nn;
+            const int dv = col[j * 64];
+            bool inD, inN;
+            const uint64_t pd_ = lanePosClamped(l, dv - len, inD), pn = lanePosClamped(l, dv - refShift, inN);
+            double del = l.minProb, noDel = l.minProb;
+            if (use && inD)
+                del = co.hist[pd_];
+            if (use && inN)
+                noDel = co.hist[pn];
+            const double probDel = ea1 * del / (del + noDel) + ea2;
+            const double probRef = ea1Rg * noDel / (del + noDel) + ea0Rg;
+            sumDel += use ? probDel : 0.0;
+            sumRef += use ? probRef : 0.0;
+            wSumDel += use ? probDel * dv : 0.0;
+            wSumRef += use ? probRef * dv : 0.0;
+        }
+        if (valid && !highCov)
+        {
+            int newShift;
+            const double q = wSumRef / sumRef;
+            if (rgNan || !(q > -2147483649.0 && q < 2147483648.0))
+                newShift = (int)0x80000000;          // what x86 yields for NaN / out-of-range conversions
+            else
+                newShift = (int)q;
+            if (newShift > l.stddev || newShift < -1 * l.stddev)
+                newShift = 0;
+            *shiftSlot = newShift;
+            sumDelAcc += sumDel;
+            wSumDelAcc += wSumDel;
+        }
+    }
+    const double t0 = blockSum(sumDelAcc, red);
+    const double t1 = blockSum(wSumDelAcc, red);
+    if (threadIdx.x == 0)
+    {
+        double * p = tileSlot(b, cellIdx, b.rank * b.tilesPerRank + tileIdx);
+        p[0] = t0;
+        p[1] = t1;
+    }
+}
+
+__global__ __launch_bounds__(kSampleTile) void finalMultiKernel(CohortView co, Stage2Buffers b, const uint8_t * __restrict__ flags,
+                                                                unsigned nWindows)
+{
+    __shared__ unsigned shBorder[kSamplesPerBlock];        // per sample: its last read group below maxLoad, or ~0
+    const unsigned cellIdx = blockIdx.y, mtI = blockIdx.x, tileIdx = b.mt.tile[mtI];
+    CellState & cs = b.cells[cellIdx];
+    if (cs.phase != kCellFinal || b.tileMode[(size_t)cellIdx * b.ownTiles + tileIdx] != kTileMulti)
+        return;
+    const unsigned w = (unsigned)cs.window;
+    const int len = (int)cs.len;
+    const unsigned s = tileIdx * kSamplesPerBlock + threadIdx.x;
+    // phase 0: the supporting-pair borders of a sample come from its LAST usable read group (quirk Q7)
+    {
+        unsigned border = 0xffffffffu;
+        if (s < co.nSamples)
+            for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
+                if (b.mN[(size_t)cellIdx * b.nRg + rg] != kDenseHighCov)
+                    border = rg;
+        shBorder[threadIdx.x] = border;
+    }
+    __syncthreads();
+    const unsigned rgLo = b.mt.rgLo[mtI], rgHi = b.mt.rgHi[mtI];
+    // phase 1: one lane per read group
+    for (unsigned base = rgLo; base < rgHi; base += kSampleTile)
+    {
+        const unsigned rg = base + threadIdx.x;
+        const bool valid = rg < rgHi;
+        const size_t wtGlobal = (size_t)cellIdx * b.mt.nWaves + b.mt.waveBase[mtI] + ((base - rgLo) >> 6) + (threadIdx.x >> 6);
+        const unsigned rows = (base - rgLo) + (threadIdx.x & ~63u) < rgHi - rgLo ? b.mWaveRows[wtGlobal] : 0u;
+        const int32_t * col = b.mDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+        const uint32_t * colSt = b.mStart + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+        unsigned n = 0;
+        RgConst rc = {};
+        int refShift = 0;
+        int delLower = 0x7fffffff, delUpper = 0;
+        if (valid)
+        {
+            rc = co.rg[rg];
+            n = b.mN[(size_t)cellIdx * b.nRg + rg];
+            refShift = cs.restoreZeroShifts ? 0 : b.shifts[(size_t)cellIdx * co.nRg + rg];
+            const unsigned border = shBorder[b.mt.rgSample[rg] - tileIdx * kSamplesPerBlock];
+            if (border != 0xffffffffu)
+            {
+                const RgConst & rb = co.rg[border];
+                delLower = (int)((unsigned)len - (unsigned)rb.lowerQ);
+                delUpper = (int)((unsigned)len + (unsigned)rb.upperQ);
+            }
+        }
+        const bool highCov = n == kDenseHighCov;
+        const unsigned nn = highCov ? 0u : n;
+        const int rgLower = (int)((unsigned)len - (unsigned)rc.lowerQ);
+        const int rgUpper = (int)((unsigned)len + (unsigned)rc.upperQ);
+        double l0 = 0, l2 = 0, t0 = 0, t2 = 0, prod = 1.0;
+        int esum = 0;
+        bool eq = true;
+        unsigned mn = 0xffffffffu, mx = 0, nSupp = 0;
+        unsigned lad[3] = {0, 0, 0}, dad[5] = {0, 0, 0, 0, 0};
+#pragma unroll 2
+        for (unsigned j = 0; j < rows; ++j)
+        {
+            const bool use = j < nn;
+            const int dv = col[j * 64];
+            const unsigned st = colSt[j * 64];
+            int cls;
+            if (dv > rc.upperQ)
+                cls = (dv < rgLower) ? 2 : ((dv <= rgUpper) ? 3 : 4);
+            else
+                cls = (dv < rgUpper) ? 0 : 1;
+            const long long pr = lookupPos(rc, dv - refShift), pdl = lookupPos(rc, dv - len);
+            double4 tr = make_double4(rc.minProb, rc.logMinProb, rc.log10MinProb, 0.0), td = tr;
+            if (use && pr >= 0)
+                tr = co.tab[pr];
+            if (use && pdl >= 0)
+                td = co.tab[pdl];
+            const double ref = tr.x, del = td.x;
+            const int lcls = (ref >= 2 * del) ? 0 : ((del >= 2 * ref) ? 2 : 1);
+            int e;
+            const double m = frexp(ref + del, &e);
+            l0 += use ? tr.y : 0.0;
+            t0 += use ? tr.z : 0.0;
+            l2 += use ? td.y : 0.0;
+            t2 += use ? td.z : 0.0;
+            prod *= use ? m : 1.0;
+            esum += use ? e : 0;
+            eq = eq && (!use || ref == del);
+            const unsigned last = st + (unsigned)max(0, dv + rc.median - 2 * rc.readLength);
+            mn = use ? min(mn, st) : mn;
+            mx = use ? max(mx, last) : mx;
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+                dad[c] += (use && cls == c) ? 1u : 0u;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                lad[c] += (use && lcls == c) ? 1u : 0u;
+            nSupp += (use && dv >= delLower && dv <= delUpper) ? 1u : 0u;
+        }
+        // supporting pairs: one pool allocation per wave, lanes fill their own stretch
+        {
+            unsigned incl = nSupp;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                const unsigned t = (unsigned)__shfl_up((int)incl, o, 64);
+                if ((int)(threadIdx.x & 63u) >= o)
+                    incl += t;
+            }
+            const unsigned waveTotal = (unsigned)__shfl((int)incl, 63, 64);
+            if (waveTotal)                                        // wave-uniform
+            {
+                unsigned base0 = 0;
+                if ((threadIdx.x & 63u) == 0)
+                    base0 = atomicAdd(&cs.suppCount, waveTotal);
+                base0 = (unsigned)__shfl((int)base0, 0, 64);
+                unsigned at = base0 + incl - nSupp;
+                if (nSupp)
+                    for (unsigned j = 0; j < nn; ++j)
+                    {
+                        const int dv = col[j * 64];
+                        if (dv >= delLower && dv <= delUpper)
+                        {
+                            const unsigned st = colSt[j * 64];
+                            b.suppFirst[cs.suppBase + at] = st;
+                            b.suppLast[cs.suppBase + at] = st + (unsigned)max(0, dv + rc.median - 2 * rc.readLength);
+                            ++at;
+                        }
+                    }
+            }
+        }
+        if (valid)
+        {
+            double * od = b.rgOutD + ((size_t)cellIdx * b.nRg + rg) * 8;
+            unsigned * ou = b.rgOutU + ((size_t)cellIdx * b.nRg + rg) * 12;
+            od[0] = l0;
+            od[1] = nn ? log(prod) + (double)(esum - (int)nn) * PD_LN2 : 0.0;
+            od[2] = l2;
+            od[3] = t0;
+            od[4] = nn ? log10(prod) + (double)(esum - (int)nn) * PD_LOG10_2 : 0.0;
+            od[5] = t2;
+            ou[0] = nn | (highCov ? PD_RGF_HIGHCOV : 0u) | (eq ? PD_RGF_EQ : 0u);
+            for (int c = 0; c < 3; ++c)
+                ou[1 + c] = lad[c];
+            for (int c = 0; c < 5; ++c)
+                ou[4 + c] = dad[c];
+            ou[9] = mn;
+            ou[10] = mx;
+        }
+    }
+    __syncthreads();
+    // phase 2: one lane per sample
+    if (s >= co.nSamples)
+        return;
+    double logL[3] = {0, 0, 0}, gl[3] = {0, 0, 0};
+    unsigned lad[3] = {0, 0, 0}, dad[5] = {0, 0, 0, 0, 0};
+    unsigned nUsed = 0, mn = 0xffffffffu, mx = 0;
+    bool allEq = true;
+    for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
+    {
+        const unsigned * ou = b.rgOutU + ((size_t)cellIdx * b.nRg + rg) * 12;
+        if (ou[0] & PD_RGF_HIGHCOV)
+            continue;
+        const double * od = b.rgOutD + ((size_t)cellIdx * b.nRg + rg) * 8;
+        for (int k = 0; k < 3; ++k)
+        {
+            logL[k] += od[k];
+            gl[k] += od[3 + k];
+            lad[k] += ou[1 + k];
+        }
+        for (int k = 0; k < 5; ++k)
+            dad[k] += ou[4 + k];
+        nUsed += ou[0] & 0xffffu;
+        allEq = allEq && (ou[0] & PD_RGF_EQ) != 0u;
+        mn = min(mn, ou[9]);
+        mx = max(mx, ou[10]);
+    }
+    if (mn == 0xffffffffu)
+        mn = 0;
+    double d[3];
+    if (nUsed == 0)
+    {
+        // sum(gtLogs) == 0: reference-like triple, gtLogs stay untouched (all zero)
+        d[0] = 0;
+        d[1] = PD_LOG_PSEUDO;
+        d[2] = PD_LOG_PSEUDO;
+        gl[0] = gl[1] = gl[2] = 0;
+    }
+    else
+    {
+        const double maxGt = fmax(fmax(gl[0], gl[1]), gl[2]);
+        gl[0] -= maxGt;
+        gl[1] -= maxGt;
+        gl[2] -= maxGt;
+        if (allEq)
+        {
+            gl[0] = gl[1] = gl[2] = 0;      // x87: a hair apart, not equal; all phred values round to 0
+        }
+        else if (gl[0] == gl[1] && gl[0] == gl[2])
+        {
+            gl[0] = 0;
+            gl[1] = -10;
+            gl[2] = -10;
+        }
+        finishTriple(d, logL, nUsed, allEq);
+    }
+    const size_t o = (size_t)cellIdx * co.nSamples + s;
+    b.dl[o * 3 + 0] = d[0];
+    b.dl[o * 3 + 1] = d[1];
+    b.dl[o * 3 + 2] = d[2];
+    uint32_t pl[3];
+    {
+        const double gTot = log10(exp(gl[0]) + exp(gl[1]) + exp(gl[2]));
+        const double p0 = -10 * (gl[0] - gTot);
+        const double p1 = -10 * (gl[1] - gTot);
+        const double p2 = -10 * (gl[2] - gTot);
+        const double mnP = fmin(fmin(p0, p1), p2);
+        pl[0] = (uint32_t)round(p0 - mnP);
+        pl[1] = (uint32_t)round(p1 - mnP);
+        pl[2] = (uint32_t)round(p2 - mnP);
+    }
+    if (flags[(size_t)s * nWindows + w] & 1u)
+        pl[0] = pl[1] = pl[2] = 0;
+    for (int c = 0; c < 3; ++c)
+    {
+        b.pl[o * 3 + c] = pl[c];
+        b.lad[o * 3 + c] = lad[c];
+    }
+    for (int c = 0; c < 5; ++c)
+        b.dad[o * 5 + c] = dad[c];
+    b.fl[o * 2 + 0] = mn;
+    b.fl[o * 2 + 1] = mx;
+}
+
 // Percentiles of the support pools (reference :514-529) by 4 x 8-bit radix selection. The pool of a cell is spread over
 // the contexts of a sharded cohort, so every pass is: digit histogram of the own pool (suppHistKernel) -> exchange ->
 // sum of the histograms, pick the digit (suppPickKernel). Pool 0: pair starts (80th percentile), pool 1: pair ends (20th).
@@ -1914,6 +2466,8 @@ void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers
     const dim3 perCell((b.nCells + 127) / 128), cellBlock(128);
     (void)hipMemsetAsync(b.tileMode, 0, (size_t)b.nCells * b.ownTiles * sizeof(unsigned), st);
     hipLaunchKernelGGL(cellGatherKernel, dim3(b.ownTiles * 4, b.nCells), dim3(kGatherThreads), 0, st, seg, co, b, flags);
+    if (b.mt.n != 0)
+        hipLaunchKernelGGL(multiGatherKernel, dim3(b.mt.nWaves, b.nCells), dim3(kGatherThreads), 0, st, seg, co, b);
     x.allGather(b.counters, (size_t)b.nCells * 4 * sizeof(unsigned));
     hipLaunchKernelGGL(cellInitFinishKernel, perCell, cellBlock, 0, st, b);
     hipLaunchKernelGGL(suppScanKernel, dim3(1), dim3(256), 0, st, b);
@@ -1932,8 +2486,11 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     const dim3 perCell((b.nCells + 127) / 128), cellBlock(128), wavePerCell(b.nCells);
     const size_t xchBytes = b.xchChunk * sizeof(double);
     // every (cell, tile) is served by exactly one of the two kernels of a pair (tileMode)
+    const dim3 perMulti(b.mt.n, b.nCells);
     auto dataLik = [&](int mode) {
         hipLaunchKernelGGL(dataLikDenseKernel, perSample, tile, 0, st, co, b, mode);
+        if (b.mt.n != 0)
+            hipLaunchKernelGGL(dataLikMultiKernel, perMulti, tile, 0, st, co, b, mode);
         if (anyGenericTile)
             hipLaunchKernelGGL(dataLikKernel, perSample, tile, 0, st, seg, co, b, mode);
     };
@@ -1946,6 +2503,8 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
         if (it == b.maxIterations)
             break;                      // the last head call only retires cells that hit the iteration cap
         hipLaunchKernelGGL(updateLenDenseKernel, perSample, tile, 0, st, co, b);
+        if (b.mt.n != 0)
+            hipLaunchKernelGGL(updateLenMultiKernel, perMulti, tile, 0, st, co, b);
         if (anyGenericTile)
             hipLaunchKernelGGL(updateLenKernel, perSample, tile, 0, st, seg, co, b);
         x.allGather(b.xch, xchBytes);
@@ -1974,6 +2533,8 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     hipLaunchKernelGGL(cellConvergedKernel, wavePerCell, dim3(64), 0, st, b, 1);
     hipLaunchKernelGGL(cellPostLoopKernel, perCell, cellBlock, 0, st, b);
     hipLaunchKernelGGL(finalDenseKernel, perSample, tile, 0, st, co, b, flags, seg.nWindows);
+    if (b.mt.n != 0)
+        hipLaunchKernelGGL(finalMultiKernel, perMulti, tile, 0, st, co, b, flags, seg.nWindows);
     if (anyGenericTile)
         hipLaunchKernelGGL(finalKernel, perSample, tile, 0, st, seg, co, b, flags);
     for (int pass = 3; pass >= 0; --pass)
