@@ -38,6 +38,21 @@ def random_case(seed):
         parts.append((d, s, a, b))
         offsets.append(offsets[-1] + len(d))
         rgs.append(base)
+    sample_offsets = list(range(n + 1))
+    if seed % 3 == 2:
+        # same pairs, but every sample's pairs dealt to 1-3 read groups of the same library (stable: each read group stays
+        # ordered by start window): exercises the scan read groups and the lane-per-read-group stage-2 kernels
+        split, sample_offsets, offsets, rgs = [], [0], [0], []
+        for d, s_, a, b in parts:
+            R = int(rng.integers(1, 4))
+            which = rng.integers(0, R, size=len(d))
+            for r in range(R):
+                sel = which == r
+                split.append((d[sel], s_[sel], a[sel], b[sel]))
+                offsets.append(offsets[-1] + int(sel.sum()))
+                rgs.append(base)
+            sample_offsets.append(len(rgs))
+        parts = split
     seg = capi.Segment(first, W, np.array(offsets, np.uint64), np.concatenate([p[0] for p in parts]).astype(np.int32),
                        np.concatenate([p[1] for p in parts]).astype(np.uint32),
                        np.concatenate([p[2] for p in parts]).astype(np.uint32),
@@ -45,7 +60,7 @@ def random_case(seed):
     opts = dict(iterations=int(rng.choice([15, 15, 3, 7])), window_wise_output=bool(rng.integers(0, 2)),
                 somatic=bool(rng.integers(0, 4) == 0), min_sample_fraction=float(rng.choice([0.1, 0.6])),
                 min_len=int(rng.choice([200, 120, 400])))
-    return seg, rgs, list(range(n + 1)), opts
+    return seg, rgs, sample_offsets, opts
 
 
 def assert_same_up_to_knife_edges(gpu, cpu):
