@@ -35,7 +35,7 @@ SEG_WINDOWS = 6667            # windows walked per 200-kb segment (windowBuffer 
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def device_tile(n_samples, seed, device):
+def device_tile(n_samples, seed, device, coverage=30.0):
     """Pair instances of one 200-kb segment for n_samples single-read-group samples, generated with torch on the GPU:
     30x coverage, 2x150 bp, insert ~ round(N(500, 50)), one planted deletion (length log-uniform 300..5000,
     population AF ~ Beta(0.5, 2), genotype ~ Binomial(2, AF)); activity by the interval rule."""
@@ -44,7 +44,7 @@ def device_tile(n_samples, seed, device):
     g.manual_seed(seed)
     first, shift, W = 1000020, 30, SEG_WINDOWS
     lo, hi = first - 600, first + W * shift
-    n = int((hi - lo) * 30.0 / 300.0)
+    n = int((hi - lo) * coverage / 300.0)
     median, read_len = 500, 150
     pos = torch.randint(lo, hi, (n_samples, n), generator=g, device=device, dtype=torch.int64)
     pos, _ = torch.sort(pos, dim=1)
@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--sharded-timeout", type=float, default=240.0, help="give up on the secondary leg after this many seconds")
     ap.add_argument("--stream-segments", type=int, default=4,
                     help="segments of the streaming leg (host memory -> HBM -> calls, double buffered); 0 switches it off")
+    ap.add_argument("--coverage", type=float, default=30.0, help="sequencing depth of the synthetic samples (headline: 30)")
     ap.add_argument("--rgs-per-sample", type=int, default=1,
                     help="split every sample's pairs over this many read groups (same library): measures the generic "
                          "kernels that multi-read-group samples take; the headline workload has 1")
@@ -134,7 +135,7 @@ def main():
     lib = synth.Library()
     rg = synth.conditioned_readgroup(lib)
     S = args.samples
-    first, W, offsets, arrays, planted = device_tile(S, 20260 + rank, device)
+    first, W, offsets, arrays, planted = device_tile(S, 20260 + rank, device, args.coverage)
     R = max(1, args.rgs_per_sample)
     sample_offsets = list(range(0, R * S + 1, R))
     if R > 1:

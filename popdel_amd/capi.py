@@ -107,11 +107,28 @@ def load_library(path):
     return lib
 
 
+def _let_torch_initialise_first():
+    """PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so) next to the system one this library
+    links (/opt/rocm/lib/libamdhip64.so.7). Both can live in one process, but only if torch's initialises FIRST: the
+    other way round torch later reports "No HIP GPUs are available". Processes that never touch torch.cuda are not
+    affected; since bench.py, the multi-GPU drivers and some tests do, the binding makes the order right up front
+    whenever torch is installed (POPDEL_NO_TORCH_INIT=1 skips this)."""
+    if os.environ.get("POPDEL_NO_TORCH_INIT"):
+        return
+    import importlib.util
+    if importlib.util.find_spec("torch") is None:
+        return
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+
+
 def load_hip():
     """The product backend. Fails loudly when the HIP library has not been built."""
     if not os.path.exists(HIP_LIBRARY):
         raise RuntimeError("libpopdel_hip.so is missing (%s): build it with __graft_entry__.build() or "
                            "`make -C popdel_amd/csrc`; there is no CPU fallback." % HIP_LIBRARY)
+    _let_torch_initialise_first()
     lib = load_library(HIP_LIBRARY)
     if lib.pd_backend_name() != b"hip-gfx950":
         raise RuntimeError("unexpected backend behind %s: %r" % (HIP_LIBRARY, lib.pd_backend_name()))

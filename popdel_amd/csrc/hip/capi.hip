@@ -16,10 +16,10 @@
 
 namespace pd {
 
-void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag, uint8_t * tileTodo,
-                  unsigned * todoList, hipStream_t stream);
+void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
+                  uint8_t * tileTodo, unsigned * todoList, unsigned * bigList, unsigned maxBlockChunks, hipStream_t stream);
 void launchStage1Fallback(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
-                          const unsigned * todoList, hipStream_t stream);
+                          uint8_t * tileTodo, unsigned * todoList, const unsigned * bigList, hipStream_t stream);
 void launchPackFlagged(const int32_t * q3, const uint8_t * flags, const int * flaggedWindows, unsigned W, unsigned nLocal,
                        const ClusterInput & in, unsigned rank, hipStream_t st);
 void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,
@@ -136,6 +136,7 @@ struct PinnedBuf
 struct StagedSegment
 {
     uint32_t firstPos = 0, nWindows = 0, shift = 0, maxLife = 0;
+    uint32_t maxBlockChunks = 0;    // chunks of the densest 512-window block any scan stream has (picks the kernel's LDS size)
     uint64_t nChunks = 0, nPairs = 0, nActivePairs = 0;
     DevBuf<pd::PairDO> pairs;
     DevBuf<uint32_t> start;
@@ -207,6 +208,7 @@ struct pd_ctx
     DevBuf<int> dWinFlag;
     DevBuf<uint8_t> dTileTodo;
     DevBuf<unsigned> dTodoList;     // [0] = number of entries, then the 256-window tiles left to the fallback kernel
+    DevBuf<unsigned> dBigList;      // [0] = number of entries, then the 512-window blocks left to the 128-candidate kernel
     uint32_t lastWindows = 0;
     std::vector<int32_t> hQ3View;
     std::vector<uint8_t> hFlagsView;
@@ -439,6 +441,24 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
     }
     if (nV == 0)
         out.nChunks = totalChunks;
+    {
+        // densest 512-window block over all streams the scan kernel reads (it stages ws[w0] .. ws[min(W, w0 + 512) + K - 1])
+        std::vector<uint32_t> entMax(nEnt, 0);
+        pdh::parallelFor(nEnt, [&](size_t e) {
+            const uint32_t * ws = winStart.data() + e * wsRow;
+            uint32_t m = 0;
+            for (uint32_t w0 = 0; w0 < W; w0 += 2 * pd::kStage1Block)
+            {
+                const uint32_t whi = std::min<uint32_t>(W, w0 + 2 * pd::kStage1Block);
+                m = std::max(m, ws[whi + K - 1] - ws[w0]);
+            }
+            entMax[e] = m;
+        }, 64);
+        // ... of 99 % of the streams: a few unusually deep samples should not cost everybody else occupancy (their
+        // blocks go to the fallback kernel instead)
+        std::sort(entMax.begin(), entMax.end());
+        out.maxBlockChunks = entMax.empty() ? 0 : entMax[std::min(entMax.size() - 1, entMax.size() * 99 / 100)];
+    }
     pairs.resize(out.nChunks);
     start.resize(out.nChunks);
     pairsPk.resize(totalChunks);
@@ -850,12 +870,16 @@ static void launchScan(pd_ctx * c, Run & run)
     const size_t tiles = static_cast<size_t>((s.nWindows + pd::kStage1Block - 1) / pd::kStage1Block) * c->nSamples;
     c->dTileTodo.ensure(tiles);
     c->dTodoList.ensure(tiles + 2);
+    c->dBigList.ensure(tiles / 2 + c->nSamples + 2);
     PD_HIP(hipMemsetAsync(c->dTodoList.p, 0, sizeof(unsigned), c->stream));
+    PD_HIP(hipMemsetAsync(c->dBigList.p, 0, sizeof(unsigned), c->stream));
     PD_HIP(hipEventRecord(run.s1Begin, c->stream));
-    pd::launchStage1(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTileTodo.p, c->dTodoList.p, c->stream);
+    pd::launchStage1(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTileTodo.p, c->dTodoList.p, c->dBigList.p,
+                     s.maxBlockChunks, c->stream);
     PD_HIP(hipGetLastError());
     PD_HIP(hipEventRecord(run.s1End, c->stream));
-    pd::launchStage1Fallback(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTodoList.p, c->stream);
+    pd::launchStage1Fallback(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTileTodo.p, c->dTodoList.p,
+                             c->dBigList.p, c->stream);
     PD_HIP(hipGetLastError());
     if (getenv("POPDEL_HIP_DEBUG"))
     {
@@ -865,7 +889,10 @@ static void launchScan(pd_ctx * c, Run & run)
         size_t nTodo = 0;
         for (uint8_t t : todo)
             nTodo += t != 0;
-        fprintf(stderr, "[popdel_hip] stage 1: %zu of %zu tiles went to the fallback kernel (K=%u)\n", nTodo, tiles, s.maxLife);
+        unsigned nBig = 0;
+        PD_HIP(hipMemcpy(&nBig, c->dBigList.p, sizeof(unsigned), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[popdel_hip] stage 1: %u 512-window blocks through the 128-candidate kernel, %zu of %zu 256-window tiles through the "
+                        "32-bit fallback kernel (K=%u, densest block %u chunks)\n", nBig, nTodo, tiles, s.maxLife, s.maxBlockChunks);
     }
     c->lastWindows = s.nWindows;
     run.launched = true;

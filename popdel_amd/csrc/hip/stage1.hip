@@ -211,6 +211,14 @@ template <>
 __device__ __forceinline__ void sortRegs16<56>(v2s (&r)[56]) { PD_SORTNET_56(PD_CE16) }
 template <>
 __device__ __forceinline__ void sortRegs16<64>(v2s (&r)[64]) { PD_SORTNET_64(PD_CE16) }
+template <>
+__device__ __forceinline__ void sortRegs16<80>(v2s (&r)[80]) { PD_SORTNET_80(PD_CE16) }
+template <>
+__device__ __forceinline__ void sortRegs16<96>(v2s (&r)[96]) { PD_SORTNET_96(PD_CE16) }
+template <>
+__device__ __forceinline__ void sortRegs16<112>(v2s (&r)[112]) { PD_SORTNET_112(PD_CE16) }
+template <>
+__device__ __forceinline__ void sortRegs16<128>(v2s (&r)[128]) { PD_SORTNET_128(PD_CE16) }
 
 __device__ __forceinline__ unsigned rankL0(unsigned n)
 {
@@ -218,7 +226,10 @@ __device__ __forceinline__ unsigned rankL0(unsigned n)
 }
 
 constexpr int kPackedWindows = 2 * kStage1Block;          // windows per workgroup
-constexpr int kPackedLdsPairs = 2304;                      // 9 x 256: staged chunks per workgroup (512 windows x ~3.1 + K x 3)
+constexpr int kPackedLdsRound = 2304;                      // 9 x 256 chunks are copied per round (512 windows x ~3.1 + K x 3 at 30x)
+// LDS capacities (chunks per workgroup) the scan kernel is instantiated for; the launch picks the smallest that holds the
+// densest 512-window block of the segment (deeper coverage = more chunks per block), blocks beyond the largest fall back.
+constexpr int kPackedLdsSmall = 2304, kPackedLdsMedium = 3328, kPackedLdsLarge = 4864, kPackedLdsHuge = 6912;
 constexpr int kPackedWsLen = kPackedWindows + 64 + 2;
 
 // Packed-16-bit helpers on 32-bit registers (low half = window w, high half = window w + 1).
@@ -333,43 +344,26 @@ __device__ __forceinline__ void storeCell(unsigned n, unsigned maxLoad, int va, 
         winFlag[w] = 1;                 // benign race: every writer stores the same value
 }
 
-// Main scan kernel (single-read-group samples, int16 deviations, at most 64 candidates per cell). Everything else is
-// marked in tileTodo (one entry per 256 windows) and handled by stage1FallbackKernel.
-__global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, CohortView co, int32_t * __restrict__ q3,
-                                                             uint8_t * __restrict__ flags, int * __restrict__ winFlag,
-                                                             uint8_t * __restrict__ tileTodo, unsigned * __restrict__ todoList,
-                                                             unsigned tilesPerSample)
+// ---- the scan of one 512-window block of one sample -------------------------------------------------------------------
+// kBig = false: candidate counts up to 64 (networks of 32..64 inputs); kBig = true: up to 128 (64..128 inputs; deeper
+// coverage), run by a second kernel over the blocks the first one could not take. Returns 0 if the block was done,
+// 1 if it must go to the 32-bit fallback kernel, 2 (kBig = false only) if it should be retried with kBig = true.
+// All return paths are workgroup-uniform.
+template <int kLdsPairs, bool kBig>
+__device__ __forceinline__ int scanBlock(const SegmentView & seg, const CohortView & co, int32_t * __restrict__ q3,
+                                         uint8_t * __restrict__ flags, int * __restrict__ winFlag, unsigned s, unsigned bx,
+                                         unsigned blocksPerSample, PairPk * ldsPairs, uint32_t * ldsWs, unsigned short * ldsN,
+                                         unsigned short * unitOrder, unsigned (*classCount)[kStage1Block / 64])
 {
-    __shared__ PairPk ldsPairs[kPackedLdsPairs + 64];
-    __shared__ uint32_t ldsWs[kPackedWsLen];
-
-    const unsigned s = blockIdx.y;
-    const unsigned w0 = blockIdx.x * kPackedWindows;
+    constexpr unsigned kMaxCand = kBig ? 128u : 64u;
+    const unsigned w0 = bx * kPackedWindows;
     const unsigned W = seg.nWindows;
     const unsigned K = seg.maxLife;
     const unsigned tid = threadIdx.x;
     const unsigned rg0 = seg.scanRg[s];          // the (possibly appended) read group whose stream holds all pairs of s
-    uint8_t * todo = tileTodo + (size_t)s * tilesPerSample + 2u * blockIdx.x;      // two 256-window tiles
-    const bool secondTile = (w0 + kStage1Block) < W;
-    const bool rgOverloaded = rg0 >= seg.nRealRg && seg.scanGeneric[(size_t)(rg0 - seg.nRealRg) * gridDim.x + blockIdx.x] != 0;
-
+    const bool rgOverloaded = rg0 >= seg.nRealRg && seg.scanGeneric[(size_t)(rg0 - seg.nRealRg) * blocksPerSample + bx] != 0;
     if (!(K <= 64u && seg.rgPacked[rg0]) || rgOverloaded)
-    {
-        if (tid == 0)
-        {
-            // todoList[0] counts the entries; the order of the list does not matter
-            const unsigned tile = s * tilesPerSample + 2u * blockIdx.x;
-            const unsigned at = atomicAdd(&todoList[0], secondTile ? 2u : 1u);
-            todo[0] = 1;
-            todoList[1 + at] = tile;
-            if (secondTile)
-            {
-                todo[1] = 1;
-                todoList[2 + at] = tile + 1;
-            }
-        }
-        return;
-    }
+        return 1;
     const uint32_t * ws = seg.winStart + (size_t)rg0 * (W + K);
     const unsigned wlo0 = w0;                                        // first slot the block's windows see
     const unsigned whi = min(W, w0 + kPackedWindows);                // one past the block's last window
@@ -384,30 +378,34 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     __syncthreads();
     const unsigned A = ldsWs[0];
     const unsigned nPairs = ldsWs[nWs - 1] - A;
-    bool bad = nPairs > (unsigned)kPackedLdsPairs;
-    if (!bad)
+    const bool tooMany = nPairs > (unsigned)kLdsPairs;               // workgroup-uniform
+    if (!tooMany)
     {
-        // the LDS image is the HBM image: plain copy, all loads in flight before the first LDS write
+        // the LDS image is the HBM image: plain copy in rounds of 9 loads per lane, all loads of a round in flight before
+        // its first LDS write (one round at 30x coverage)
         const uint2 * src = seg.pairsPk + seg.rgBase[rg0] + A;
-        constexpr int kIters = kPackedLdsPairs / kStage1Block;
-        uint2 tmp[kIters];
-#pragma unroll
-        for (int it = 0; it < kIters; ++it)
+        constexpr int kIters = kPackedLdsRound / kStage1Block;
+        for (unsigned round = 0; round < nPairs; round += (unsigned)kPackedLdsRound)
         {
-            const unsigned i = tid + (unsigned)it * kStage1Block;
-            if (i < nPairs)
-                tmp[it] = src[i];
-        }
+            uint2 tmp[kIters];
 #pragma unroll
-        for (int it = 0; it < kIters; ++it)
-        {
-            const unsigned i = tid + (unsigned)it * kStage1Block;
-            if (i < nPairs)
+            for (int it = 0; it < kIters; ++it)
             {
-                PairPk e;
-                e.devdev = tmp[it].x;
-                e.offoff = tmp[it].y;
-                ldsPairs[i] = e;
+                const unsigned i = round + tid + (unsigned)it * kStage1Block;
+                if (i < nPairs)
+                    tmp[it] = src[i];
+            }
+#pragma unroll
+            for (int it = 0; it < kIters; ++it)
+            {
+                const unsigned i = round + tid + (unsigned)it * kStage1Block;
+                if (i < nPairs)
+                {
+                    PairPk e;
+                    e.devdev = tmp[it].x;
+                    e.offoff = tmp[it].y;
+                    ldsPairs[i] = e;
+                }
             }
         }
     }
@@ -421,41 +419,25 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     if (wB < W)
         endB = ldsWs[wB + K - wlo0] - A - aA;
     const unsigned cntU = max(cntA, endB);
-    bad |= cntU > 64u;
-    if (__syncthreads_or(bad))                                     // also orders the LDS writes above
+    const int over = __syncthreads_or(cntU > kMaxCand);            // also orders the LDS writes above
+    if (tooMany || over)
     {
-        if (tid == 0)
-        {
-            // todoList[0] counts the entries; the order of the list does not matter
-            const unsigned tile = s * tilesPerSample + 2u * blockIdx.x;
-            const unsigned at = atomicAdd(&todoList[0], secondTile ? 2u : 1u);
-            todo[0] = 1;
-            todoList[1 + at] = tile;
-            if (secondTile)
-            {
-                todo[1] = 1;
-                todoList[2 + at] = tile + 1;
-            }
-        }
-        return;
-    }
-    if (tid == 0)
-    {
-        todo[0] = 0;
-        if (secondTile)
-            todo[1] = 0;
+        // the first kernel hands the block to the second one if that has a chance (128 candidates, the largest LDS stage)
+        if (!kBig && nPairs <= (unsigned)kPackedLdsHuge && !__syncthreads_or(cntU > 128u))
+            return 2;
+        return 1;
     }
     // active pairs per window; parked in LDS because the lanes are re-dealt below
-    __shared__ unsigned short ldsN[kPackedWindows];
     ldsN[2u * tid] = (unsigned short)((wA < W) ? (ldsWs[wA + K - wlo0] - endedA) : 0u);
     ldsN[2u * tid + 1u] = (unsigned short)((wB < W) ? (ldsWs[wB + K - wlo0] - endedB) : 0u);
     // Re-deal the 256 window pairs to the lanes ordered by candidate count (largest first): every wave then runs the
     // smallest network that fits ITS lanes instead of the one that fits the worst lane of an arbitrary 64.
-    __shared__ unsigned short unitOrder[kStage1Block];
     constexpr unsigned kClasses = 6;
-    __shared__ unsigned classCount[kClasses][kStage1Block / 64];
+    constexpr unsigned kStep = kBig ? 16u : 8u, kTop = kBig ? 128u : 64u;        // class bounds: top, top - step, ...
     {
-        const unsigned cls = (wA >= W) ? 5u : (cntU > 56u ? 0u : (cntU > 48u ? 1u : (cntU > 40u ? 2u : (cntU > 32u ? 3u : 4u))));
+        const unsigned cls = (wA >= W) ? 5u
+                                       : (cntU > kTop - kStep ? 0u
+                                                              : (cntU > kTop - 2 * kStep ? 1u : (cntU > kTop - 3 * kStep ? 2u : (cntU > kTop - 4 * kStep ? 3u : 4u))));
         const unsigned long long below = (1ull << (tid & 63u)) - 1ull;
         unsigned rank = 0;
 #pragma unroll
@@ -478,38 +460,127 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
     }
     const unsigned u = unitOrder[tid];
     const unsigned uA = w0 + 2u * u, uB = uA + 1u;
-    if (uA >= W)
-        return;
-    unsigned xA, xCntA, xEndB = 0;
+    if (uA < W)
     {
+        unsigned xA, xCntA, xEndB = 0;
         xA = ldsWs[uA - wlo0] - A;
         xCntA = ldsWs[uA + K - wlo0] - A - xA;
+        if (uB < W)
+            xEndB = ldsWs[uB + K - wlo0] - A - xA;
+        const unsigned nA = ldsN[2u * u];
+        const unsigned nB = ldsN[2u * u + 1u];
+        const unsigned cmax = waveMaxU32(max(xCntA, xEndB));         // wave-uniform network size
+        // entries ahead of B's range ended before w + 1 (chunk life <= K), so B needs no lower range test
+        const unsigned wPk = uA | (uB << 16);                        // absolute window numbers (W fits 16 bits here)
+        const unsigned cntPk = xCntA | (xEndB << 16);
+        int vaA, vbA, vaB, vbB;
+        if (kBig)
+        {
+            if (cmax <= 64u)
+                stage1PairFast<64>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
+            else if (cmax <= 80u)
+                stage1PairFast<80>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
+            else if (cmax <= 96u)
+                stage1PairFast<96>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
+            else if (cmax <= 112u)
+                stage1PairFast<112>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
+            else
+                stage1PairFast<128>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
+        }
+        else
+        {
+            if (cmax <= 32u)
+                stage1PairFast<32>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
+            else if (cmax <= 40u)
+                stage1PairFast<40>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
+            else if (cmax <= 48u)
+                stage1PairFast<48>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
+            else if (cmax <= 56u)
+                stage1PairFast<56>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
+            else
+                stage1PairFast<64>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
+        }
+        const unsigned maxLoad = co.rg[rg0].maxLoad;
+        storeCell(nA, maxLoad, vaA, vbA, (size_t)s * W + uA, uA, co.minThreshold, q3, flags, winFlag);
+        if (uB < W)
+            storeCell(nB, maxLoad, vaB, vbB, (size_t)s * W + uB, uB, co.minThreshold, q3, flags, winFlag);
     }
-    if (uB < W)
+    return 0;
+}
+
+// Appends the two 256-window tiles of block (s, bx) to the list of the 32-bit fallback kernel (lane 0).
+__device__ __forceinline__ void deferToFallback(unsigned s, unsigned bx, unsigned W, unsigned tilesPerSample, uint8_t * tileTodo,
+                                                unsigned * todoList, bool defer)
+{
+    if (threadIdx.x != 0)
+        return;
+    uint8_t * todo = tileTodo + (size_t)s * tilesPerSample + 2u * bx;
+    const bool secondTile = (bx * kPackedWindows + kStage1Block) < W;
+    todo[0] = defer ? 1 : 0;
+    if (secondTile)
+        todo[1] = defer ? 1 : 0;
+    if (!defer)
+        return;
+    // todoList[0] counts the entries; the order of the list does not matter
+    const unsigned tile = s * tilesPerSample + 2u * bx;
+    const unsigned at = atomicAdd(&todoList[0], secondTile ? 2u : 1u);
+    todoList[1 + at] = tile;
+    if (secondTile)
+        todoList[2 + at] = tile + 1;
+}
+
+// Main scan kernel: one workgroup per (512-window block, sample); int16 deviations, at most 64 candidates per cell.
+// Blocks with up to 128 candidates are appended to bigList for stage1BigKernel, everything else it cannot take to
+// todoList (256-window tiles) for stage1FallbackKernel.
+template <int kLdsPairs>
+__global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, CohortView co, int32_t * __restrict__ q3,
+                                                             uint8_t * __restrict__ flags, int * __restrict__ winFlag,
+                                                             uint8_t * __restrict__ tileTodo, unsigned * __restrict__ todoList,
+                                                             unsigned * __restrict__ bigList, unsigned tilesPerSample)
+{
+    __shared__ PairPk ldsPairs[kLdsPairs + 64];
+    __shared__ uint32_t ldsWs[kPackedWsLen];
+    __shared__ unsigned short ldsN[kPackedWindows];
+    __shared__ unsigned short unitOrder[kStage1Block];
+    __shared__ unsigned classCount[6][kStage1Block / 64];
+    const int st = scanBlock<kLdsPairs, false>(seg, co, q3, flags, winFlag, blockIdx.y, blockIdx.x, gridDim.x, ldsPairs, ldsWs, ldsN,
+                                               unitOrder, classCount);
+    if (st == 2)
     {
-        xEndB = ldsWs[uB + K - wlo0] - A - xA;
+        if (threadIdx.x == 0)
+        {
+            deferToFallback(blockIdx.y, blockIdx.x, seg.nWindows, tilesPerSample, tileTodo, todoList, false);
+            bigList[1 + atomicAdd(&bigList[0], 1u)] = blockIdx.y * gridDim.x + blockIdx.x;
+        }
+        return;
     }
-    const unsigned nA = ldsN[2u * u];
-    const unsigned nB = ldsN[2u * u + 1u];
-    const unsigned cmax = waveMaxU32(max(xCntA, xEndB));             // wave-uniform network size
-    // entries ahead of B's range ended before w + 1 (chunk life <= K), so B needs no lower range test
-    const unsigned wPk = uA | (uB << 16);                            // absolute window numbers (W fits 16 bits here)
-    const unsigned cntPk = xCntA | (xEndB << 16);
-    int vaA, vbA, vaB, vbB;
-    if (cmax <= 32u)
-        stage1PairFast<32>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
-    else if (cmax <= 40u)
-        stage1PairFast<40>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
-    else if (cmax <= 48u)
-        stage1PairFast<48>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
-    else if (cmax <= 56u)
-        stage1PairFast<56>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
-    else
-        stage1PairFast<64>(ldsPairs, xA, wPk, cntPk, nA, nB, vaA, vbA, vaB, vbB);
-    const unsigned maxLoad = co.rg[rg0].maxLoad;
-    storeCell(nA, maxLoad, vaA, vbA, (size_t)s * W + uA, uA, co.minThreshold, q3, flags, winFlag);
-    if (uB < W)
-        storeCell(nB, maxLoad, vaB, vbB, (size_t)s * W + uB, uB, co.minThreshold, q3, flags, winFlag);
+    deferToFallback(blockIdx.y, blockIdx.x, seg.nWindows, tilesPerSample, tileTodo, todoList, st == 1);
+}
+
+// Second pass over the blocks with 65..128 candidates somewhere (deeper coverage): same scan with networks of up to
+// 128 inputs and the largest LDS stage; 128 value registers per lane, hence its own kernel (the register budget of a
+// kernel is that of its largest path). Workgroups stride over the list.
+__global__ __launch_bounds__(kStage1Block) void stage1BigKernel(SegmentView seg, CohortView co, int32_t * __restrict__ q3,
+                                                                uint8_t * __restrict__ flags, int * __restrict__ winFlag,
+                                                                uint8_t * __restrict__ tileTodo, unsigned * __restrict__ todoList,
+                                                                const unsigned * __restrict__ bigList, unsigned tilesPerSample,
+                                                                unsigned blocksPerSample)
+{
+    __shared__ PairPk ldsPairs[kPackedLdsHuge + 64];
+    __shared__ uint32_t ldsWs[kPackedWsLen];
+    __shared__ unsigned short ldsN[kPackedWindows];
+    __shared__ unsigned short unitOrder[kStage1Block];
+    __shared__ unsigned classCount[6][kStage1Block / 64];
+    const unsigned nBig = bigList[0];
+    for (unsigned k = blockIdx.x; k < nBig; k += gridDim.x)
+    {
+        const unsigned id = bigList[1 + k], s = id / blocksPerSample, bx = id % blocksPerSample;
+        __syncthreads();                                           // LDS reuse across blocks
+        const int st = scanBlock<kPackedLdsHuge, true>(seg, co, q3, flags, winFlag, s, bx, blocksPerSample, ldsPairs, ldsWs, ldsN,
+                                                       unitOrder, classCount);
+        if (st != 0)
+            deferToFallback(s, bx, seg.nWindows, tilesPerSample, tileTodo, todoList, true);
+    }
 }
 
 // Tiles the main kernel skipped: 32-bit 64- or 128-input network where the LDS stage still fits, otherwise rank counting
@@ -606,18 +677,34 @@ __global__ __launch_bounds__(kStage1Block) void stage1FallbackKernel(SegmentView
 }
 
 void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
-                  uint8_t * tileTodo, unsigned * todoList, hipStream_t stream)
+                  uint8_t * tileTodo, unsigned * todoList, unsigned * bigList, unsigned maxBlockChunks, hipStream_t stream)
 {
     const unsigned tilesPerSample = (seg.nWindows + kStage1Block - 1) / kStage1Block;
     dim3 grid((seg.nWindows + kPackedWindows - 1) / kPackedWindows, co.nSamples);
-    hipLaunchKernelGGL(stage1Kernel, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo, todoList,
-                       tilesPerSample);
+    // maxBlockChunks: chunks of the densest 512-window block of (99 % of) the streams, host-computed at staging time
+    if (maxBlockChunks <= (unsigned)kPackedLdsSmall)
+        hipLaunchKernelGGL(stage1Kernel<kPackedLdsSmall>, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo,
+                           todoList, bigList, tilesPerSample);
+    else if (maxBlockChunks <= (unsigned)kPackedLdsMedium)
+        hipLaunchKernelGGL(stage1Kernel<kPackedLdsMedium>, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo,
+                           todoList, bigList, tilesPerSample);
+    else if (maxBlockChunks <= (unsigned)kPackedLdsLarge)
+        hipLaunchKernelGGL(stage1Kernel<kPackedLdsLarge>, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo,
+                           todoList, bigList, tilesPerSample);
+    else
+        hipLaunchKernelGGL(stage1Kernel<kPackedLdsHuge>, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo,
+                           todoList, bigList, tilesPerSample);
 }
 
+// The blocks the main kernel left for the 128-candidate networks, then the tiles left for the 32-bit paths.
 void launchStage1Fallback(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
-                          const unsigned * todoList, hipStream_t stream)
+                          uint8_t * tileTodo, unsigned * todoList, const unsigned * bigList, hipStream_t stream)
 {
     const unsigned tilesPerSample = (seg.nWindows + kStage1Block - 1) / kStage1Block;
+    const unsigned blocksPerSample = (seg.nWindows + kPackedWindows - 1) / kPackedWindows;
+    const unsigned nBlocks = blocksPerSample * co.nSamples;
+    hipLaunchKernelGGL(stage1BigKernel, dim3(nBlocks < 1024u ? nBlocks : 1024u), dim3(kStage1Block), 0, stream, seg, co, q3, flags,
+                       winFlag, tileTodo, todoList, bigList, tilesPerSample, blocksPerSample);
     const unsigned nTiles = tilesPerSample * co.nSamples;
     const unsigned blocks = nTiles < 2048u ? nTiles : 2048u;
     hipLaunchKernelGGL(stage1FallbackKernel, dim3(blocks), dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, todoList,

@@ -260,3 +260,29 @@ def test_many_candidate_lengths_in_one_window(built):
     per_window = np.unique(cpu[0]["window_position"], return_counts=True)[1]
     assert per_window.max() > 8
     assert_same(gpu, cpu)
+
+
+def test_deep_coverage_takes_the_128_candidate_scan(built):
+    """45x to 85x samples next to 30x ones: more than 64 candidate chunks per cell -> the second scan kernel with networks
+    of up to 128 inputs (and, past 64 ACTIVE pairs, the generic stage-2 kernels); above ~100 active pairs the read group
+    is over its max_load in places, which the reference skips."""
+    from popdel_amd import capi, synth
+    lib = synth.Library()
+    rg = synth.conditioned_readgroup(lib)
+    region, first, W = (1000000, 1050000), 1000020, 1600
+    dels = lambda k, r: [synth.Deletion(1020000, 1500, [1, 2, 0][k % 3])]
+    covs = [30.0, 45.0, 60.0, 75.0, 85.0, 30.0, 52.0, 68.0]
+    parts, offsets = [], [0]
+    for k, cov in enumerate(covs * 3):
+        pos, dev = synth.sample_pairs(9100 + k, region, synth.Library(coverage=cov), dels(k, region))
+        d, s, a, b = synth.instances_by_interval_rule(pos, dev, lib, first, W)
+        parts.append((d, s, a, b))
+        offsets.append(offsets[-1] + len(d))
+    n = len(parts)
+    seg = capi.Segment(first, W, np.array(offsets, np.uint64), np.concatenate([p[0] for p in parts]).astype(np.int32),
+                       np.concatenate([p[1] for p in parts]).astype(np.uint32),
+                       np.concatenate([p[2] for p in parts]).astype(np.uint32),
+                       np.concatenate([p[3] for p in parts]).astype(np.uint32))
+    gpu, cpu = both(seg, [rg] * n, list(range(n + 1)))
+    assert cpu[0]["n_calls"] > 20
+    assert_same(gpu, cpu)
