@@ -14,7 +14,7 @@ constexpr int kMaxIterationsCap = 64;          // visited-table capacity per cel
 constexpr int kStage1Block = 256;              // windows per workgroup in the stage-1 scan
 constexpr int kStage1LdsPairs = 3072;          // pair chunks staged in LDS per stage-1 workgroup
 constexpr int kSampleTile = 256;               // threads per workgroup in the stage-2 per-sample kernels
-constexpr int kDenseCap = 64;                  // active pairs per (cell, sample) the dense stage-2 image holds
+constexpr int kDenseCap = 96;                  // active pairs per (cell, sample) the dense stage-2 image holds
 constexpr unsigned kDenseHighCov = 0xffffu;    // cellN marker: read group at or above maxLoad (skipped by the reference)
 constexpr int kSamplesPerBlock = 256;           // samples one such workgroup walks (8 half-waves x 32 samples; 64 and 128 were measured slower)
 
