@@ -1,4 +1,4 @@
-"""Debug helper (GPU box): python tests/debug_fuzz.py <seed> -- prints where HIP and oracle differ for a fuzz case."""
+"""Debug helper (GPU box): python tools/debug_fuzz.py <seed> -- prints where HIP and oracle differ for a fuzz case."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,4 @@
-"""One-off wider sweep (GPU box): python tests/debug_fuzz_sweep.py <first seed> <last seed>"""
+"""One-off wider sweep (GPU box): python tools/debug_fuzz_sweep.py <first seed> <last seed>"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
