@@ -31,6 +31,8 @@ inline unsigned hostThreads()
 }
 
 // Calls fn(i) for i in [0, n) on up to hostThreads() threads (dynamic chunks). Exceptions are re-thrown on the caller.
+// Threads are spawned per call on purpose: a persistent pool (condition-variable hand-off to parked workers) was
+// measured 10-20 % SLOWER on the 256-core GPU host for the memory-bound staging passes.
 template <typename F>
 void parallelFor(size_t n, F fn, size_t grain = 1)
 {
