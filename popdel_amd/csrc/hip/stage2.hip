@@ -531,7 +531,7 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
     __shared__ unsigned acc[3];
     __shared__ SampleMeta shMeta[64];
     __shared__ int shDev[64][kDenseCap + 1];
-    __shared__ unsigned shSt[64][kDenseCap + 1];
+    __shared__ short shSt[64][kDenseCap + 1];              // start positions relative to the cell's window (see stBase)
     __shared__ unsigned shN[64];
     __shared__ unsigned shRows, shGeneric;
     const unsigned cellIdx = blockIdx.y, wt = blockIdx.x;          // one workgroup per (cell, 64-sample wave tile)
@@ -545,6 +545,7 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
     const CellState & cs = b.cells[cellIdx];
     const unsigned w = (unsigned)cs.window;
     const unsigned L = (unsigned)cs.initLen;
+    const unsigned stBase = seg.firstPos + w * seg.shift;  // LDS keeps the pair starts as 16-bit offsets from here
     const unsigned hl = threadIdx.x & 31u, half = threadIdx.x >> 5;
     const unsigned long long hm = halfMask();
     const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
@@ -573,6 +574,7 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
         const SampleMeta & meta = shMeta[inWt];
         const bool multi = (meta.rg1 - meta.rg0) != 1u;        // its pairs go into the per-read-group image instead
         bool generic = b.forceGeneric != 0;
+        bool farStart = false;                                 // a start further than 32 kb from the window: not in 16 bits
         unsigned nDense = 0;
         for (unsigned rg = meta.rg0; rg < meta.rg1; ++rg)
         {
@@ -611,8 +613,10 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
                         const unsigned pos = n + (unsigned)__popcll(bal & below);
                         if (pos < (unsigned)kDenseCap)
                         {
+                            const int rel = (int)(st[g] - stBase);
                             shDev[inWt][pos] = p[g].dev;
-                            shSt[inWt][pos] = st[g];
+                            shSt[inWt][pos] = (short)rel;
+                            farStart = farStart || rel < -32768 || rel > 32767;
                         }
                     }
                     n += (unsigned)__popcll(bal);
@@ -630,6 +634,7 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
                 generic = true;
         }
         low += (flags[(size_t)s * seg.nWindows + w] & 1u) ? 1u : 0u;
+        generic = generic || halfCount(farStart) != 0u;
         if (hl == 0)
         {
             const bool noRows = generic || multi;
@@ -663,7 +668,7 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
         const unsigned j = idx >> 6, lane = idx & 63u, nl = shN[lane];
         const bool has = nl != kDenseHighCov && j < nl;
         outD[idx] = has ? shDev[lane][j] : 0;
-        outS[idx] = has ? shSt[lane][j] : 0u;
+        outS[idx] = has ? stBase + (unsigned)(int)shSt[lane][j] : 0u;
     }
     unsigned * mine = b.counters + ((size_t)b.rank * b.nCells + cellIdx) * 4;
     if (threadIdx.x < 3 && acc[threadIdx.x])
@@ -1777,7 +1782,7 @@ __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, S
 __global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView seg, CohortView co, Stage2Buffers b)
 {
     __shared__ int shDev[64][kDenseCap + 1];
-    __shared__ unsigned shSt[64][kDenseCap + 1];
+    __shared__ short shSt[64][kDenseCap + 1];              // start positions relative to the cell's window (see stBase)
     __shared__ unsigned shN[64];
     __shared__ unsigned shRows;
     const unsigned cellIdx = blockIdx.y, mw = blockIdx.x;
@@ -1786,6 +1791,7 @@ __global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView 
         return;
     const unsigned rgBase = b.mt.rgLo[mtI] + (mw - b.mt.waveBase[mtI]) * 64u, rgHi = b.mt.rgHi[mtI];
     const unsigned w = (unsigned)b.cells[cellIdx].window;
+    const unsigned stBase = seg.firstPos + w * seg.shift;
     const unsigned hl = threadIdx.x & 31u, half = threadIdx.x >> 5;
     const unsigned long long hm = halfMask();
     const unsigned long long below = (1ull << (threadIdx.x & 63u)) - 1ull;
@@ -1805,6 +1811,7 @@ __global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView 
         }
         const PairRange r = pairRange(seg, rg, w);
         unsigned n = 0;
+        bool farStart = false;
         for (unsigned base = r.begin; base < r.end; base += 64u)
         {
             PairDO p[2];
@@ -1832,12 +1839,19 @@ __global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView 
                     const unsigned pos = n + (unsigned)__popcll(bal & below);
                     if (pos < (unsigned)kDenseCap)
                     {
+                        const int rel = (int)(st[g] - stBase);
                         shDev[inWt][pos] = p[g].dev;
-                        shSt[inWt][pos] = st[g];
+                        shSt[inWt][pos] = (short)rel;
+                        farStart = farStart || rel < -32768 || rel > 32767;
                     }
                 }
                 n += (unsigned)__popcll(bal);
             }
+        }
+        if (halfCount(farStart) != 0u && hl == 0)          // cannot be represented here: the tile goes to the generic kernels
+        {
+            atomicMax(&b.tileMode[(size_t)cellIdx * b.ownTiles + b.mt.tile[mtI]], (unsigned)kTileGeneric);
+            atomicAdd(&b.counters[((size_t)b.rank * b.nCells + cellIdx) * 4 + 3], 1u);
         }
         const unsigned nDense = (n >= co.rg[rg].maxLoad) ? kDenseHighCov : n;   // n <= kDenseCap otherwise (else: kTileGeneric)
         if (hl == 0)
@@ -1858,7 +1872,7 @@ __global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView 
         const unsigned j = idx >> 6, lane = idx & 63u, nl = shN[lane];
         const bool has = nl != kDenseHighCov && j < nl;
         outD[idx] = has ? shDev[lane][j] : 0;
-        outS[idx] = has ? shSt[lane][j] : 0u;
+        outS[idx] = has ? stBase + (unsigned)(int)shSt[lane][j] : 0u;
     }
     if (threadIdx.x == 0)
         b.mWaveRows[wtGlobal] = (uint8_t)rows;
