@@ -28,7 +28,7 @@ void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers
                    hipStream_t st);
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
                    bool anyGenericTile, hipStream_t st);
-void buildLogTables(const double * hist, double4 * tab, size_t n, RgConst * rg, unsigned nRg, hipStream_t st);
+void buildLogTables(const double * hist, double4 * tab, double2 * tab2, size_t n, RgConst * rg, unsigned nRg, hipStream_t st);
 void launchGatherOut(const Stage2Buffers & b, const unsigned * emitCells, unsigned nEmit, unsigned nSamples, uint32_t * pl,
                      uint32_t * lad, uint32_t * dad, uint32_t * fl, hipStream_t st);
 
@@ -174,6 +174,7 @@ struct pd_ctx
     DevBuf<pd::RgConst> dRg;
     DevBuf<double> dHist;
     DevBuf<double4> dTab;
+    DevBuf<double2> dTab2;
     DevBuf<unsigned> dIterFlags;
     DevBuf<uint32_t> dSampleRg;
     DevBuf<uint32_t> dScanRg;
@@ -675,13 +676,15 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
         c->dHist.upload(pool, c->stream);
         c->dSampleRg.upload(c->sampleRg, c->stream);
         c->dTab.alloc(pool.size());
+        c->dTab2.alloc(pool.size());
         c->dIterFlags.alloc(pd::kMaxIterationsCap + 1);
-        pd::buildLogTables(c->dHist.p, c->dTab.p, pool.size(), c->dRg.p, n_readgroups, c->stream);
+        pd::buildLogTables(c->dHist.p, c->dTab.p, c->dTab2.p, pool.size(), c->dRg.p, n_readgroups, c->stream);
         PD_HIP(hipGetLastError());
         PD_HIP(hipStreamSynchronize(c->stream));
         c->cohort.rg = c->dRg.p;
         c->cohort.hist = c->dHist.p;
         c->cohort.tab = c->dTab.p;
+        c->cohort.tab2 = c->dTab2.p;
         c->cohort.sampleRg = c->dSampleRg.p;
         c->cohort.nSamples = n_samples;
         c->cohort.nRg = n_readgroups;

@@ -82,6 +82,8 @@ struct CohortView
     const double *   hist;         // histogram pool
     const double4 *  tab;          // per pool entry {value, log(value), log10(value), -}: one 32-byte line per lookup
                                    // (logs computed once on the device with the functions the kernels would call)
+    const double2 *  tab2;         // {value, log(value)} only: what the EM kernels look up, four entries per 64-byte
+                                   // line (the 32-byte entries cost the data-likelihood kernel 4x the HBM traffic)
     const uint32_t * sampleRg;     // [nSamples + 1]
     uint32_t         nSamples;
     uint32_t         nRg;

@@ -48,12 +48,16 @@ __device__ __forceinline__ long long lookupPos(const RgConst & rc, int deviation
 }
 
 // log / log10 of every histogram value, computed with the same device functions the kernels use on the fly.
-__global__ void logTableKernel(const double * __restrict__ hist, double4 * __restrict__ tab, size_t n, RgConst * __restrict__ rg,
-                               unsigned nRg)
+__global__ void logTableKernel(const double * __restrict__ hist, double4 * __restrict__ tab, double2 * __restrict__ tab2, size_t n,
+                               RgConst * __restrict__ rg, unsigned nRg)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n)
-        tab[i] = make_double4(hist[i], log(hist[i]), log10(hist[i]), 0.0);
+    {
+        const double lg = log(hist[i]);
+        tab[i] = make_double4(hist[i], lg, log10(hist[i]), 0.0);
+        tab2[i] = make_double2(hist[i], lg);
+    }
     if (i < nRg)
     {
         rg[i].logMinProb = log(rg[i].minProb);
@@ -61,10 +65,10 @@ __global__ void logTableKernel(const double * __restrict__ hist, double4 * __res
     }
 }
 
-void buildLogTables(const double * hist, double4 * tab, size_t n, RgConst * rg, unsigned nRg, hipStream_t st)
+void buildLogTables(const double * hist, double4 * tab, double2 * tab2, size_t n, RgConst * rg, unsigned nRg, hipStream_t st)
 {
     const size_t m = n > nRg ? n : nRg;
-    hipLaunchKernelGGL(logTableKernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, hist, tab, n, rg, nRg);
+    hipLaunchKernelGGL(logTableKernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, hist, tab, tab2, n, rg, nRg);
 }
 
 __device__ __forceinline__ void priors(double f, int somatic, double * g)
@@ -818,13 +822,13 @@ __global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, Co
                 double ref = rc.minProb, lref = rc.logMinProb, del = rc.minProb, ldel = rc.logMinProb;
                 if (pr >= 0)
                 {
-                    const double2 t = *reinterpret_cast<const double2 *>(&co.tab[pr]);
+                    const double2 t = co.tab2[pr];
                     ref = t.x;
                     lref = t.y;
                 }
                 if (pdl >= 0)
                 {
-                    const double2 t = *reinterpret_cast<const double2 *>(&co.tab[pdl]);
+                    const double2 t = co.tab2[pdl];
                     del = t.x;
                     ldel = t.y;
                 }
@@ -978,9 +982,9 @@ __global__ __launch_bounds__(kSampleTile) void dataLikDenseKernel(CohortView co,
         // only in-range lookups touch memory: every lane reads its own sample's table, so each one costs a cache line
         double2 tr = make_double2(l.minProb, l.logMinProb), td = tr;
         if (use && inR)
-            tr = *reinterpret_cast<const double2 *>(&co.tab[pr]);
+            tr = co.tab2[pr];
         if (use && inD)
-            td = *reinterpret_cast<const double2 *>(&co.tab[pdl]);
+            td = co.tab2[pdl];
         const double ref = tr.x, lref = tr.y, del = td.x, ldel = td.y;
         int e;
         const double m = frexp(ref + del, &e);
@@ -1923,9 +1927,9 @@ __global__ __launch_bounds__(kSampleTile) void dataLikMultiKernel(CohortView co,
             const uint64_t pr = lanePosClamped(l, dv - refShift, inR), pdl = lanePosClamped(l, dv - len, inD);
             double2 tr = make_double2(l.minProb, l.logMinProb), td = tr;
             if (use && inR)
-                tr = *reinterpret_cast<const double2 *>(&co.tab[pr]);
+                tr = co.tab2[pr];
             if (use && inD)
-                td = *reinterpret_cast<const double2 *>(&co.tab[pdl]);
+                td = co.tab2[pdl];
             int e;
             const double m = frexp(tr.x + td.x, &e);
             g0 += use ? tr.y : 0.0;
