@@ -218,13 +218,11 @@ struct pd_ctx
     DevBuf<pd::CellState> dCells;
     DevBuf<double> dDl;
     DevBuf<int> dShifts;
-    DevBuf<int32_t> dCellDev;
-    DevBuf<uint32_t> dCellStart;
+    DevBuf<int16_t> dCellDev, dCellStart;
     DevBuf<uint16_t> dCellN;
     DevBuf<uint8_t> dWaveRows;
     DevBuf<unsigned> dTileMode;
-    DevBuf<int32_t> dMDev;
-    DevBuf<uint32_t> dMStart;
+    DevBuf<int16_t> dMDev, dMStart;
     DevBuf<uint16_t> dMN;
     DevBuf<uint8_t> dMWaveRows;
     DevBuf<double> dRgOutD;
@@ -1068,7 +1066,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             budget = static_cast<size_t>(std::max(1.0, atof(e)));
         // (from the samples per context of the partition, not from this context's own count: all contexts of a sharded
         // cohort must cut the cell list at the same places, the exchanges run per batch)
-        const size_t bytesPerCell = static_cast<size_t>(sper) * (2 * pd::kDenseCap * 4 + 24 + 52 + 2 + 24) + 4096;
+        const size_t bytesPerCell = static_cast<size_t>(sper) * (2 * pd::kDenseCap * 2 + 24 + 52 + 2 + 24) + 4096;
         const unsigned batchCells = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(nCells ? nCells : 1, budget / bytesPerCell)));
         const unsigned nBatches = nCells ? (nCells + batchCells - 1) / batchCells : 0;
         pd::Stage2Buffers b;

@@ -194,8 +194,9 @@ struct Stage2Buffers
     // the deviations (and start positions) transposed to [row j][lane = sample], so that the EM kernels run ONE LANE PER
     // SAMPLE with coalesced loads and no cross-lane work. Tiles the image cannot hold (a multi-read-group sample, more
     // than kDenseCap active pairs below maxLoad) are flagged in tileMode and go through the generic half-wave kernels.
-    int32_t *   cellDev;     // [nCells][ownTiles*4][kDenseCap][64]
-    uint32_t *  cellStart;   // same shape
+    int16_t *   cellDev;     // [nCells][ownTiles*4][kDenseCap][64]; 16 bits: a pair outside that range sends its tile to
+                             // the generic kernels (profiles written with the default size limits stay far inside)
+    int16_t *   cellStart;   // same shape; pair starts as offsets from the cell's window position
     uint16_t *  cellN;       // [nCells][S] active pairs of the sample's read group, or kDenseHighCov
     uint8_t *   waveRows;    // [nCells][ownTiles*4] max cellN over the wave tile (rows in use)
     unsigned *  tileMode;    // [nCells][ownTiles] kTileDense / kTileMulti / kTileGeneric (raised with atomicMax)
@@ -203,8 +204,8 @@ struct Stage2Buffers
     // dense image with ONE LANE PER READ GROUP: rows of 64 read groups instead of 64 samples. Their kernels run the
     // per-pair loops per read group, park the per-read-group results in rgOut and then add them up per sample.
     MultiTiles  mt;
-    int32_t *   mDev;        // [nCells][mt.nWaves][kDenseCap][64]
-    uint32_t *  mStart;      // same shape
+    int16_t *   mDev;        // [nCells][mt.nWaves][kDenseCap][64]
+    int16_t *   mStart;      // same shape
     uint16_t *  mN;          // [nCells][nRg] active pairs of the read group, or kDenseHighCov (multi tiles only)
     uint8_t *   mWaveRows;   // [nCells][mt.nWaves]
     double *    rgOutD;      // [nCells][nRg][8]  per-read-group sums (log-likelihoods, log10-likelihoods)

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
 {
     __shared__ unsigned acc[3];
     __shared__ SampleMeta shMeta[64];
-    __shared__ int shDev[64][kDenseCap + 1];
+    __shared__ short shDev[64][kDenseCap + 1];             // deviations: 16 bits in the dense image (else: generic kernels)
     __shared__ short shSt[64][kDenseCap + 1];              // start positions relative to the cell's window (see stBase)
     __shared__ unsigned shN[64];
     __shared__ unsigned shRows, shGeneric;
@@ -618,9 +618,9 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
                         if (pos < (unsigned)kDenseCap)
                         {
                             const int rel = (int)(st[g] - stBase);
-                            shDev[inWt][pos] = p[g].dev;
+                            shDev[inWt][pos] = (short)p[g].dev;
                             shSt[inWt][pos] = (short)rel;
-                            farStart = farStart || rel < -32768 || rel > 32767;
+                            farStart = farStart || rel < -32768 || rel > 32767 || p[g].dev < -32768 || p[g].dev > 32767;
                         }
                     }
                     n += (unsigned)__popcll(bal);
@@ -665,14 +665,14 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
     // transposed write-out: row j holds the j-th active pair of each of the 64 samples
     const unsigned rows = shRows;
     const size_t wtGlobal = (size_t)cellIdx * (b.ownTiles * 4) + wt;
-    int32_t * outD = b.cellDev + wtGlobal * (kDenseCap * 64);
-    uint32_t * outS = b.cellStart + wtGlobal * (kDenseCap * 64);
+    int16_t * outD = b.cellDev + wtGlobal * (kDenseCap * 64);
+    int16_t * outS = b.cellStart + wtGlobal * (kDenseCap * 64);
     for (unsigned idx = threadIdx.x; idx < rows * 64u; idx += blockDim.x)
     {
         const unsigned j = idx >> 6, lane = idx & 63u, nl = shN[lane];
         const bool has = nl != kDenseHighCov && j < nl;
-        outD[idx] = has ? shDev[lane][j] : 0;
-        outS[idx] = has ? stBase + (unsigned)(int)shSt[lane][j] : 0u;
+        outD[idx] = has ? shDev[lane][j] : (short)0;
+        outS[idx] = has ? shSt[lane][j] : (short)0;
     }
     unsigned * mine = b.counters + ((size_t)b.rank * b.nCells + cellIdx) * 4;
     if (threadIdx.x < 3 && acc[threadIdx.x])
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(kSampleTile) void dataLikDenseKernel(CohortView co,
     const bool valid = s < co.nSamples;
     const size_t wtGlobal = (size_t)cellIdx * (b.ownTiles * 4) + PD_TILE_IDX * 4 + (threadIdx.x >> 6);
     const unsigned rows = b.waveRows[wtGlobal];
-    const int32_t * col = b.cellDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+    const int16_t * col = b.cellDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
     double term = 0;
     unsigned rg = 0, n = 0;
     LaneRg l = {};
@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenDenseKernel(CohortView c
     const bool valid = s < co.nSamples;
     const size_t wtGlobal = (size_t)cellIdx * (b.ownTiles * 4) + PD_TILE_IDX * 4 + (threadIdx.x >> 6);
     const unsigned rows = b.waveRows[wtGlobal];
-    const int32_t * col = b.cellDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+    const int16_t * col = b.cellDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
     unsigned rg = 0, n = 0;
     LaneRg l = {};
     int refShift = 0;
@@ -1610,20 +1610,21 @@ __global__ __launch_bounds__(kSampleTile) void finalKernel(SegmentView seg, Coho
 // The final pass on the dense image, one lane per sample. log / log10 of the heterozygous term again come from one
 // mantissa product per sample; the supporting pairs are appended to the pool with one atomic per wave.
 __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, Stage2Buffers b, const uint8_t * __restrict__ flags,
-                                                                unsigned nWindows)
+                                                                unsigned nWindows, unsigned firstPos, unsigned shift)
 {
     const unsigned cellIdx = PD_CELL_IDX;
     CellState & cs = b.cells[cellIdx];
     if (cs.phase != kCellFinal || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] != 0)
         return;
     const unsigned w = (unsigned)cs.window;
+    const unsigned stBase = firstPos + w * shift;          // the image keeps pair starts as 16-bit offsets from the window
     const int len = (int)cs.len;
     const unsigned s = PD_TILE_IDX * kSamplesPerBlock + threadIdx.x;
     const bool valid = s < co.nSamples;
     const size_t wtGlobal = (size_t)cellIdx * (b.ownTiles * 4) + PD_TILE_IDX * 4 + (threadIdx.x >> 6);
     const unsigned rows = b.waveRows[wtGlobal];
-    const int32_t * col = b.cellDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
-    const uint32_t * colSt = b.cellStart + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+    const int16_t * col = b.cellDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+    const int16_t * colSt = b.cellStart + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
     unsigned rg = 0, n = 0;
     RgConst rc = {};
     int refShift = 0;
@@ -1648,7 +1649,7 @@ __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, S
     {
         const bool use = j < nn;
         const int dv = col[j * 64];
-        const unsigned st = colSt[j * 64];
+        const unsigned st = stBase + (unsigned)(int)colSt[j * 64];
         int cls;
         if (dv > rc.upperQ)
             cls = (dv < rgLower) ? 2 : ((dv <= rgUpper) ? 3 : 4);
@@ -1706,7 +1707,7 @@ __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, S
                     const int dv = col[j * 64];
                     if (dv >= rgLower && dv <= rgUpper)
                     {
-                        const unsigned st = colSt[j * 64];
+                        const unsigned st = stBase + (unsigned)(int)colSt[j * 64];
                         b.suppFirst[cs.suppBase + at] = st;
                         b.suppLast[cs.suppBase + at] = st + (unsigned)max(0, dv + rc.median - 2 * rc.readLength);
                         ++at;
@@ -1785,7 +1786,7 @@ __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, S
 // Dense image of the multi tiles: one workgroup per (cell, 64-read-group wave tile).
 __global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView seg, CohortView co, Stage2Buffers b)
 {
-    __shared__ int shDev[64][kDenseCap + 1];
+    __shared__ short shDev[64][kDenseCap + 1];             // deviations: 16 bits in the dense image (else: generic kernels)
     __shared__ short shSt[64][kDenseCap + 1];              // start positions relative to the cell's window (see stBase)
     __shared__ unsigned shN[64];
     __shared__ unsigned shRows;
@@ -1844,9 +1845,9 @@ __global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView 
                     if (pos < (unsigned)kDenseCap)
                     {
                         const int rel = (int)(st[g] - stBase);
-                        shDev[inWt][pos] = p[g].dev;
+                        shDev[inWt][pos] = (short)p[g].dev;
                         shSt[inWt][pos] = (short)rel;
-                        farStart = farStart || rel < -32768 || rel > 32767;
+                        farStart = farStart || rel < -32768 || rel > 32767 || p[g].dev < -32768 || p[g].dev > 32767;
                     }
                 }
                 n += (unsigned)__popcll(bal);
@@ -1869,14 +1870,14 @@ __global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView 
     __syncthreads();
     const unsigned rows = shRows;
     const size_t wtGlobal = (size_t)cellIdx * b.mt.nWaves + mw;
-    int32_t * outD = b.mDev + wtGlobal * (kDenseCap * 64);
-    uint32_t * outS = b.mStart + wtGlobal * (kDenseCap * 64);
+    int16_t * outD = b.mDev + wtGlobal * (kDenseCap * 64);
+    int16_t * outS = b.mStart + wtGlobal * (kDenseCap * 64);
     for (unsigned idx = threadIdx.x; idx < rows * 64u; idx += blockDim.x)
     {
         const unsigned j = idx >> 6, lane = idx & 63u, nl = shN[lane];
         const bool has = nl != kDenseHighCov && j < nl;
-        outD[idx] = has ? shDev[lane][j] : 0;
-        outS[idx] = has ? stBase + (unsigned)(int)shSt[lane][j] : 0u;
+        outD[idx] = has ? shDev[lane][j] : (short)0;
+        outS[idx] = has ? shSt[lane][j] : (short)0;
     }
     if (threadIdx.x == 0)
         b.mWaveRows[wtGlobal] = (uint8_t)rows;
@@ -1903,7 +1904,7 @@ __global__ __launch_bounds__(kSampleTile) void dataLikMultiKernel(CohortView co,
         const bool valid = rg < rgHi;
         const size_t wtGlobal = (size_t)cellIdx * b.mt.nWaves + b.mt.waveBase[mtI] + ((base - rgLo) >> 6) + (threadIdx.x >> 6);
         const unsigned rows = (base - rgLo) + (threadIdx.x & ~63u) < rgHi - rgLo ? b.mWaveRows[wtGlobal] : 0u;
-        const int32_t * col = b.mDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+        const int16_t * col = b.mDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
         unsigned n = 0;
         LaneRg l = {};
         int refShift = 0;
@@ -2038,7 +2039,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenMultiKernel(CohortView c
         const bool valid = rg < rgHi;
         const size_t wtGlobal = (size_t)cellIdx * b.mt.nWaves + b.mt.waveBase[mtI] + ((base - rgLo) >> 6) + (threadIdx.x >> 6);
         const unsigned rows = (base - rgLo) + (threadIdx.x & ~63u) < rgHi - rgLo ? b.mWaveRows[wtGlobal] : 0u;
-        const int32_t * col = b.mDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+        const int16_t * col = b.mDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
         unsigned n = 0;
         LaneRg l = {};
         int refShift = 0;
@@ -2103,7 +2104,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenMultiKernel(CohortView c
 }
 
 __global__ __launch_bounds__(kSampleTile) void finalMultiKernel(CohortView co, Stage2Buffers b, const uint8_t * __restrict__ flags,
-                                                                unsigned nWindows)
+                                                                unsigned nWindows, unsigned firstPos, unsigned shift)
 {
     __shared__ unsigned shBorder[kSamplesPerBlock];        // per sample: its last read group below maxLoad, or ~0
     const unsigned cellIdx = blockIdx.y, mtI = blockIdx.x, tileIdx = b.mt.tile[mtI];
@@ -2111,6 +2112,7 @@ __global__ __launch_bounds__(kSampleTile) void finalMultiKernel(CohortView co, S
     if (cs.phase != kCellFinal || b.tileMode[(size_t)cellIdx * b.ownTiles + tileIdx] != kTileMulti)
         return;
     const unsigned w = (unsigned)cs.window;
+    const unsigned stBase = firstPos + w * shift;
     const int len = (int)cs.len;
     const unsigned s = tileIdx * kSamplesPerBlock + threadIdx.x;
     // phase 0: the supporting-pair borders of a sample come from its LAST usable read group (quirk Q7)
@@ -2131,8 +2133,8 @@ __global__ __launch_bounds__(kSampleTile) void finalMultiKernel(CohortView co, S
         const bool valid = rg < rgHi;
         const size_t wtGlobal = (size_t)cellIdx * b.mt.nWaves + b.mt.waveBase[mtI] + ((base - rgLo) >> 6) + (threadIdx.x >> 6);
         const unsigned rows = (base - rgLo) + (threadIdx.x & ~63u) < rgHi - rgLo ? b.mWaveRows[wtGlobal] : 0u;
-        const int32_t * col = b.mDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
-        const uint32_t * colSt = b.mStart + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+        const int16_t * col = b.mDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+        const int16_t * colSt = b.mStart + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
         unsigned n = 0;
         RgConst rc = {};
         int refShift = 0;
@@ -2164,7 +2166,7 @@ __global__ __launch_bounds__(kSampleTile) void finalMultiKernel(CohortView co, S
         {
             const bool use = j < nn;
             const int dv = col[j * 64];
-            const unsigned st = colSt[j * 64];
+            const unsigned st = stBase + (unsigned)(int)colSt[j * 64];
             int cls;
             if (dv > rc.upperQ)
                 cls = (dv < rgLower) ? 2 : ((dv <= rgUpper) ? 3 : 4);
@@ -2222,7 +2224,7 @@ __global__ __launch_bounds__(kSampleTile) void finalMultiKernel(CohortView co, S
                         const int dv = col[j * 64];
                         if (dv >= delLower && dv <= delUpper)
                         {
-                            const unsigned st = colSt[j * 64];
+                            const unsigned st = stBase + (unsigned)(int)colSt[j * 64];
                             b.suppFirst[cs.suppBase + at] = st;
                             b.suppLast[cs.suppBase + at] = st + (unsigned)max(0, dv + rc.median - 2 * rc.readLength);
                             ++at;
@@ -2550,9 +2552,9 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     x.allGather(b.xch, xchBytes);
     hipLaunchKernelGGL(cellConvergedKernel, wavePerCell, dim3(64), 0, st, b, 1);
     hipLaunchKernelGGL(cellPostLoopKernel, perCell, cellBlock, 0, st, b);
-    hipLaunchKernelGGL(finalDenseKernel, perSample, tile, 0, st, co, b, flags, seg.nWindows);
+    hipLaunchKernelGGL(finalDenseKernel, perSample, tile, 0, st, co, b, flags, seg.nWindows, seg.firstPos, seg.shift);
     if (b.mt.n != 0)
-        hipLaunchKernelGGL(finalMultiKernel, perMulti, tile, 0, st, co, b, flags, seg.nWindows);
+        hipLaunchKernelGGL(finalMultiKernel, perMulti, tile, 0, st, co, b, flags, seg.nWindows, seg.firstPos, seg.shift);
     if (anyGenericTile)
         hipLaunchKernelGGL(finalKernel, perSample, tile, 0, st, seg, co, b, flags);
     for (int pass = 3; pass >= 0; --pass)
