@@ -24,6 +24,7 @@ void launchPackFlagged(const int32_t * q3, const uint8_t * flags, const int * fl
                        const ClusterInput & in, unsigned rank, hipStream_t st);
 void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,
                    hipStream_t st);
+void launchCopyBytes(const void * src, void * dst, size_t n, hipStream_t st);
 void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
                    hipStream_t st);
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
@@ -998,8 +999,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         else
         {
             uint8_t * area = reserveArena(*c, static_cast<size_t>(W) * world * sizeof(int));
-            PD_HIP(hipMemcpyAsync(area + static_cast<size_t>(c->rank) * W * sizeof(int), c->dWinFlag.p, W * sizeof(int),
-                                  hipMemcpyDeviceToDevice, c->stream));
+            pd::launchCopyBytes(c->dWinFlag.p, area + static_cast<size_t>(c->rank) * W * sizeof(int), W * sizeof(int), c->stream);
             xch.allGather(area, W * sizeof(int));
             PD_HIP(hipMemcpyAsync(winFlag.data(), area, winFlag.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         }

@@ -2470,6 +2470,20 @@ void launchPackFlagged(const int32_t * q3, const uint8_t * flags, const int * fl
                        nLocal, in, rank);
 }
 
+__global__ void copyBytesKernel(const uint8_t * __restrict__ src, uint8_t * __restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+// A plain copy kernel: hipMemcpyAsync(DeviceToDevice) in the middle of a kernel sequence was measured to cost ~0.1 ms.
+void launchCopyBytes(const void * src, void * dst, size_t n, hipStream_t st)
+{
+    if (n)
+        hipLaunchKernelGGL(copyBytesKernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, st,
+                           static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), n);
+}
+
 void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,
                    hipStream_t st)
 {
