@@ -28,7 +28,7 @@ void launchCopyBytes(const void * src, void * dst, size_t n, hipStream_t st);
 void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
                    hipStream_t st);
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
-                   bool anyGenericTile, hipStream_t st);
+                   bool anyGenericTile, unsigned * pinnedWord, hipStream_t st);
 void buildLogTables(const double * hist, double4 * tab, double2 * tab2, size_t n, RgConst * rg, unsigned nRg, hipStream_t st);
 void launchGatherOut(const Stage2Buffers & b, const unsigned * emitCells, unsigned nEmit, unsigned nSamples, uint32_t * pl,
                      uint32_t * lad, uint32_t * dad, uint32_t * fl, hipStream_t st);
@@ -201,6 +201,11 @@ struct pd_ctx
     std::vector<uint64_t> hRgBase;
     PinnedBuf<uint2> hPairsPk;
     std::vector<uint8_t> hRgPacked, hScanGeneric;
+    // page-locked staging for the small control transfers of a collect (window flags, candidate lists, cell records,
+    // counters): pageable memory costs every one of these round trips an extra bounce copy
+    PinnedBuf<int> hWinFlag, hFlagged, hCandLen, hCandCount;
+    PinnedBuf<pd::CellState> hCells;
+    PinnedBuf<unsigned> hCounters, hEmit, hIterFlag;
     uint64_t nextHandle = 1, nextTicket = 1;
     std::map<uint64_t, Run> runs;
 
@@ -991,7 +996,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         CtxExchange xch(*c);
         const uint32_t world = c->world, sper = c->samplesPerRank, SG = c->nSamplesGlobal;
         // windows in which some sample of the cohort has a Q3 above the smallest threshold
-        std::vector<int> winFlag(static_cast<size_t>(W) * world);
+        PinnedBuf<int> & winFlag = c->hWinFlag;
+        winFlag.resize(static_cast<size_t>(W) * world);
         if (world == 1)
         {
             PD_HIP(hipMemcpyAsync(winFlag.data(), c->dWinFlag.p, W * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1021,7 +1027,9 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             unsigned rowLen = 1;
             while (rowLen < SG)
                 rowLen <<= 1;
-            c->dFlagged.upload(flagged, c->stream);
+            c->hFlagged.resize(flagged.size());
+            std::memcpy(c->hFlagged.data(), flagged.data(), flagged.size() * sizeof(int));
+            c->dFlagged.uploadPinned(c->hFlagged, c->stream);
             c->dClusterScratch.ensure(static_cast<size_t>(flagged.size()) * rowLen);
             c->dCandLen.ensure(flagged.size() * pd::kMaxCandidatesPerWindow);
             c->dCandCount.ensure(flagged.size());
@@ -1037,7 +1045,9 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             xch.allGather(c->arena, in.chunkBytes);
             pd::launchCluster(in, c->uniformThreshold, c->dClusterScratch.p, rowLen, c->dCandLen.p, c->dCandCount.p, c->stream);
             PD_HIP(hipGetLastError());
-            std::vector<int> candLen(flagged.size() * pd::kMaxCandidatesPerWindow), candCount(flagged.size());
+            PinnedBuf<int> &candLen = c->hCandLen, &candCount = c->hCandCount;
+            candLen.resize(flagged.size() * pd::kMaxCandidatesPerWindow);
+            candCount.resize(flagged.size());
             PD_HIP(hipMemcpyAsync(candLen.data(), c->dCandLen.p, candLen.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
             PD_HIP(hipMemcpyAsync(candCount.data(), c->dCandCount.p, candCount.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
             PD_HIP(hipStreamSynchronize(c->stream));
@@ -1071,6 +1081,10 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         const unsigned nBatches = nCells ? (nCells + batchCells - 1) / batchCells : 0;
         pd::Stage2Buffers b;
         std::memset(&b, 0, sizeof(b));
+        c->hCells.resize(std::max<size_t>(1, cells.size()));
+        if (!cells.empty())
+            std::memcpy(c->hCells.data(), cells.data(), cells.size() * sizeof(pd::CellState));
+        c->hIterFlag.resize(4);
         // per-sample results of the emitted cells: device buffer of the current batch, host block of the whole segment
         PinnedBlock pinned;
         uint32_t *hPl = nullptr, *hLad = nullptr, *hDad = nullptr, *hFl = nullptr;
@@ -1096,7 +1110,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             b.xch = reinterpret_cast<double *>(area + countersBytes);
             b.selHist = reinterpret_cast<unsigned *>(area + countersBytes + xchBytes);
             c->dCells.ensure(nb);
-            PD_HIP(hipMemcpyAsync(c->dCells.p, cells.data() + lo, nb * sizeof(pd::CellState), hipMemcpyHostToDevice, c->stream));
+            PD_HIP(hipMemcpyAsync(c->dCells.p, c->hCells.data() + lo, nb * sizeof(pd::CellState), hipMemcpyHostToDevice, c->stream));
             c->dDl.ensure(static_cast<size_t>(nb) * S * 3);
             c->dShifts.ensure(static_cast<size_t>(nb) * c->nRg);
             b.ownTiles = (S + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock;
@@ -1152,7 +1166,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             // Phase A gives, per cell, the number of usable active pairs = capacity of its support pool.
             pd::runStage2Init(view, c->cohort, b, c->dFlags.p, xch, c->stream);
             PD_HIP(hipGetLastError());
-            std::vector<unsigned> counters(static_cast<size_t>(nb) * 4);       // of this context's own samples
+            PinnedBuf<unsigned> & counters = c->hCounters;                    // of this context's own samples
+            counters.resize(static_cast<size_t>(nb) * 4);
             PD_HIP(hipMemcpyAsync(counters.data(), b.counters + static_cast<size_t>(c->rank) * nb * 4,
                                   counters.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
             PD_HIP(hipStreamSynchronize(c->stream));
@@ -1169,10 +1184,11 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             c->dSuppLast.ensure(pool + 1);
             b.suppFirst = c->dSuppFirst.p;
             b.suppLast = c->dSuppLast.p;
-            pd::runStage2Main(view, c->cohort, b, c->dFlags.p, xch, genericTiles != 0, c->stream);
+            pd::runStage2Main(view, c->cohort, b, c->dFlags.p, xch, genericTiles != 0, c->hIterFlag.data(), c->stream);
             PD_HIP(hipGetLastError());
-            PD_HIP(hipMemcpyAsync(cells.data() + lo, c->dCells.p, nb * sizeof(pd::CellState), hipMemcpyDeviceToHost, c->stream));
+            PD_HIP(hipMemcpyAsync(c->hCells.data() + lo, c->dCells.p, nb * sizeof(pd::CellState), hipMemcpyDeviceToHost, c->stream));
             PD_HIP(hipStreamSynchronize(c->stream));
+            std::memcpy(cells.data() + lo, c->hCells.data() + lo, nb * sizeof(pd::CellState));
             std::vector<unsigned> emitLocal;
             for (unsigned i = 0; i < nb; ++i)
                 if (cells[lo + i].phase == pd::kCellEmit)
@@ -1184,7 +1200,9 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             const size_t per = static_cast<size_t>(nbEmit) * S;
             if (nbEmit != 0)
             {
-                c->dEmit.upload(emitLocal, c->stream);
+                c->hEmit.resize(emitLocal.size());
+                std::memcpy(c->hEmit.data(), emitLocal.data(), emitLocal.size() * sizeof(unsigned));
+                c->dEmit.uploadPinned(c->hEmit, c->stream);
                 c->dOutPl.ensure(per * 13);
                 uint32_t *dPl = c->dOutPl.p, *dLad = dPl + per * 3, *dDad = dLad + per * 3, *dFl = dDad + per * 5;
                 pd::launchGatherOut(b, c->dEmit.p, nbEmit, S, dPl, dLad, dDad, dFl, c->stream);

@@ -2511,7 +2511,7 @@ void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers
 // Every context of a sharded cohort runs the same sequence; the per-cell kernels see identical inputs everywhere
 // (all-gathered per-tile sums), so all contexts take the same decisions, including the early exit below.
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
-                   bool anyGenericTile, hipStream_t st)
+                   bool anyGenericTile, unsigned * pinnedWord, hipStream_t st)
 {
     if (b.nCells == 0)
         return;
@@ -2550,10 +2550,10 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
         // instead of launching the remaining (empty) iterations.
         if (it == 2 || it == 4 || it == 7 || it == 10)
         {
-            unsigned still = 1;
-            (void)hipMemcpyAsync(&still, b.iterFlags + it, sizeof(unsigned), hipMemcpyDeviceToHost, st);
+            *pinnedWord = 1;                               // page-locked: no bounce copy for four bytes
+            (void)hipMemcpyAsync(pinnedWord, b.iterFlags + it, sizeof(unsigned), hipMemcpyDeviceToHost, st);
             (void)hipStreamSynchronize(st);
-            if (!still)
+            if (!*pinnedWord)
                 break;
         }
     }
