@@ -1041,12 +1041,8 @@ __global__ __launch_bounds__(kSampleTile) void dataLikDenseKernel(CohortView co,
 // =====================================================================================================================
 // EM loop head (reference :598-604): loop condition, bookkeeping of the visited table and the previous estimate.
 // =====================================================================================================================
-__global__ void cellLoopHeadKernel(Stage2Buffers b)
+__device__ __forceinline__ void loopHead(CellState & cs, const Stage2Buffers & b)
 {
-    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= b.nCells)
-        return;
-    CellState & cs = b.cells[c];
     if (cs.phase != kCellIterating)
         return;
     if (!(cs.len >= b.minLen && (unsigned)cs.iterations < b.maxIterations))
@@ -1068,6 +1064,14 @@ __global__ void cellLoopHeadKernel(Stage2Buffers b)
     cs.prevGt[0] = cs.gt[0];
     cs.prevGt[1] = cs.gt[1];
     cs.prevGt[2] = cs.gt[2];
+}
+
+// The head of the first iteration; the heads of the following ones run at the end of cellFreqFinishKernel.
+__global__ void cellLoopHeadKernel(Stage2Buffers b)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < b.nCells)
+        loopHead(b.cells[c], b);
 }
 
 // =====================================================================================================================
@@ -1343,6 +1347,7 @@ __global__ __launch_bounds__(64) void cellFreqFinishKernel(Stage2Buffers b, unsi
             cs.phase = kCellConverged;
             break;
         }
+    loopHead(cs, b);                        // head of the next iteration (also retires cells that hit the iteration cap)
 }
 
 // =====================================================================================================================
@@ -2531,11 +2536,9 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     dataLik(0);
     x.allGather(b.xch, xchBytes);
     (void)hipMemsetAsync(b.iterFlags, 0, (b.maxIterations + 1) * sizeof(unsigned), st);
-    for (unsigned it = 0; it <= b.maxIterations; ++it)
+    hipLaunchKernelGGL(cellLoopHeadKernel, perCell, cellBlock, 0, st, b);
+    for (unsigned it = 0; it < b.maxIterations; ++it)
     {
-        hipLaunchKernelGGL(cellLoopHeadKernel, perCell, cellBlock, 0, st, b);
-        if (it == b.maxIterations)
-            break;                      // the last head call only retires cells that hit the iteration cap
         hipLaunchKernelGGL(updateLenDenseKernel, perSample, tile, 0, st, co, b);
         if (b.mt.n != 0)
             hipLaunchKernelGGL(updateLenMultiKernel, perMulti, tile, 0, st, co, b);
