@@ -972,7 +972,7 @@ __global__ __launch_bounds__(kSampleTile) void dataLikDenseKernel(CohortView co,
     double g0 = 0, g2 = 0, prod = 1.0;
     int esum = 0;
     bool eq = true;
-#pragma unroll 4
+#pragma unroll 8
     for (unsigned j = 0; j < rows; ++j)
     {
         const bool use = j < nn;
@@ -1186,18 +1186,31 @@ __global__ __launch_bounds__(kSampleTile) void updateLenDenseKernel(CohortView c
         return;
     const int len = (int)cs.len;
     const double g0 = cs.gt[0], g1 = cs.gt[1], g2 = cs.gt[2];
-    const double * rg0 = rg0Slot(b, cellIdx, 0);
-    bool rgNan = rg0[3] != 0;
-    double ea0Rg = 0, ea1Rg = 0;
-    if (!rgNan)
+    // what depends on the cell only (seven exp/log calls) is worked out by one lane and shared
+    __shared__ double shCell[5];
+    if (threadIdx.x == 0)
     {
-        const double aSumRg = exp(rg0[0]) * g0 + exp(rg0[1]) * g1 + exp(rg0[2]) * g2;
-        const double l0 = (rg0[0] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[0];
-        const double l1 = (rg0[1] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[1];
-        ea0Rg = exp(l0 + log(g0) - log(aSumRg));
-        ea1Rg = exp(l1 + log(g1) - log(aSumRg));
-        rgNan = isnan(ea0Rg) || isnan(ea1Rg);
+        const double * rg0 = rg0Slot(b, cellIdx, 0);
+        bool nan_ = rg0[3] != 0;
+        double e0 = 0, e1 = 0;
+        if (!nan_)
+        {
+            const double aSumRg = exp(rg0[0]) * g0 + exp(rg0[1]) * g1 + exp(rg0[2]) * g2;
+            const double l0 = (rg0[0] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[0];
+            const double l1 = (rg0[1] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[1];
+            e0 = exp(l0 + log(g0) - log(aSumRg));
+            e1 = exp(l1 + log(g1) - log(aSumRg));
+            nan_ = isnan(e0) || isnan(e1);
+        }
+        shCell[0] = e0;
+        shCell[1] = e1;
+        shCell[2] = nan_ ? 1.0 : 0.0;
+        shCell[3] = log(g1);
+        shCell[4] = log(g2);
     }
+    __syncthreads();
+    const double ea0Rg = shCell[0], ea1Rg = shCell[1], logG1 = shCell[3], logG2 = shCell[4];
+    const bool rgNan = shCell[2] != 0.0;
     const unsigned s = PD_TILE_IDX * kSamplesPerBlock + threadIdx.x;
     const bool valid = s < co.nSamples;
     const size_t wtGlobal = (size_t)cellIdx * (b.ownTiles * 4) + PD_TILE_IDX * 4 + (threadIdx.x >> 6);
@@ -1217,13 +1230,13 @@ __global__ __launch_bounds__(kSampleTile) void updateLenDenseKernel(CohortView c
         refShift = *shiftSlot;
         const double * d = b.dl + ((size_t)cellIdx * co.nSamples + s) * 3;
         const double aSum = exp(d[0]) * g0 + exp(d[1]) * g1 + exp(d[2]) * g2;
-        ea1 = exp(d[1] + log(g1) - log(aSum));
-        ea2 = exp(d[2] + log(g2) - log(aSum));
+        ea1 = exp(d[1] + logG1 - log(aSum));
+        ea2 = exp(d[2] + logG2 - log(aSum));
     }
     const bool highCov = n == kDenseHighCov;
     const unsigned nn = highCov ? 0u : n;
     double sumDel = 0, wSumDel = 0, sumRef = 0, wSumRef = 0;
-#pragma unroll 4
+#pragma unroll 8
     for (unsigned j = 0; j < rows; ++j)
     {
         const bool use = j < nn;
@@ -1924,7 +1937,7 @@ __global__ __launch_bounds__(kSampleTile) void dataLikMultiKernel(CohortView co,
         double g0 = 0, g2 = 0, prod = 1.0;
         int esum = 0;
         bool eq = true;
-#pragma unroll 4
+#pragma unroll 8
         for (unsigned j = 0; j < rows; ++j)
         {
             const bool use = j < nn;
@@ -2024,18 +2037,31 @@ __global__ __launch_bounds__(kSampleTile) void updateLenMultiKernel(CohortView c
         return;
     const int len = (int)cs.len;
     const double g0 = cs.gt[0], g1 = cs.gt[1], g2 = cs.gt[2];
-    const double * rg0 = rg0Slot(b, cellIdx, 0);
-    bool rgNan = rg0[3] != 0;
-    double ea0Rg = 0, ea1Rg = 0;
-    if (!rgNan)
+    // what depends on the cell only (seven exp/log calls) is worked out by one lane and shared
+    __shared__ double shCell[5];
+    if (threadIdx.x == 0)
     {
-        const double aSumRg = exp(rg0[0]) * g0 + exp(rg0[1]) * g1 + exp(rg0[2]) * g2;
-        const double l0 = (rg0[0] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[0];
-        const double l1 = (rg0[1] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[1];
-        ea0Rg = exp(l0 + log(g0) - log(aSumRg));
-        ea1Rg = exp(l1 + log(g1) - log(aSumRg));
-        rgNan = isnan(ea0Rg) || isnan(ea1Rg);
+        const double * rg0 = rg0Slot(b, cellIdx, 0);
+        bool nan_ = rg0[3] != 0;
+        double e0 = 0, e1 = 0;
+        if (!nan_)
+        {
+            const double aSumRg = exp(rg0[0]) * g0 + exp(rg0[1]) * g1 + exp(rg0[2]) * g2;
+            const double l0 = (rg0[0] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[0];
+            const double l1 = (rg0[1] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[1];
+            e0 = exp(l0 + log(g0) - log(aSumRg));
+            e1 = exp(l1 + log(g1) - log(aSumRg));
+            nan_ = isnan(e0) || isnan(e1);
+        }
+        shCell[0] = e0;
+        shCell[1] = e1;
+        shCell[2] = nan_ ? 1.0 : 0.0;
+        shCell[3] = log(g1);
+        shCell[4] = log(g2);
     }
+    __syncthreads();
+    const double ea0Rg = shCell[0], ea1Rg = shCell[1], logG1 = shCell[3], logG2 = shCell[4];
+    const bool rgNan = shCell[2] != 0.0;
     const unsigned rgLo = b.mt.rgLo[mtI], rgHi = b.mt.rgHi[mtI];
     double sumDelAcc = 0, wSumDelAcc = 0;                  // over the read groups this lane handles, in read-group order
     for (unsigned base = rgLo; base < rgHi; base += kSampleTile)
@@ -2058,13 +2084,13 @@ __global__ __launch_bounds__(kSampleTile) void updateLenMultiKernel(CohortView c
             refShift = *shiftSlot;
             const double * d = b.dl + ((size_t)cellIdx * co.nSamples + b.mt.rgSample[rg]) * 3;
             const double aSum = exp(d[0]) * g0 + exp(d[1]) * g1 + exp(d[2]) * g2;
-            ea1 = exp(d[1] + log(g1) - log(aSum));
-            ea2 = exp(d[2] + log(g2) - log(aSum));
+            ea1 = exp(d[1] + logG1 - log(aSum));
+            ea2 = exp(d[2] + logG2 - log(aSum));
         }
         const bool highCov = n == kDenseHighCov;
         const unsigned nn = highCov ? 0u : n;
         double sumDel = 0, wSumDel = 0, sumRef = 0, wSumRef = 0;
-#pragma unroll 4
+#pragma unroll 8
         for (unsigned j = 0; j < rows; ++j)
         {
             const bool use = j < nn;
