@@ -52,6 +52,14 @@ def make_case(name):
                            np.concatenate([p[2] for p in parts]).astype(np.uint32),
                            np.concatenate([p[3] for p in parts]).astype(np.uint32))
         return seg, rgs, sample_offsets, {}
+    elif name.startswith("stress"):
+        # random cohort of tools/stress_consistency.py (several hundred samples, 1-3 read groups each)
+        import importlib.util
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("stress_consistency_cases", os.path.join(root, "tools", "stress_cases.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod.case(int(name[6:]))
     else:
         raise ValueError(name)
     return seg, rgs, list(range(n + 1)), opts
