@@ -13,7 +13,9 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIBRARY = os.path.join(_HERE, "lib", "libpopdel_hip.so")
+# POPDEL_HIP_LIBRARY points the binding at another build of the product library (A/B measurements); never at the oracle:
+# load_hip() checks the backend name.
+HIP_LIBRARY = os.environ.get("POPDEL_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libpopdel_hip.so")
 
 ABI_SYMBOLS = (
     "pd_ctx_create", "pd_ctx_destroy", "pd_segment_submit", "pd_segment_stage", "pd_segment_run", "pd_segment_unstage",

@@ -229,7 +229,7 @@ constexpr int kPackedWindows = 2 * kStage1Block;          // windows per workgro
 constexpr int kPackedLdsRound = 2304;                      // 9 x 256 chunks are copied per round (512 windows x ~3.1 + K x 3 at 30x)
 // LDS capacities (chunks per workgroup) the scan kernel is instantiated for; the launch picks the smallest that holds the
 // densest 512-window block of the segment (deeper coverage = more chunks per block), blocks beyond the largest fall back.
-constexpr int kPackedLdsSmall = 2304, kPackedLdsMedium = 3328, kPackedLdsLarge = 4864, kPackedLdsHuge = 6912;
+constexpr int kPackedLdsSmall = 2176, kPackedLdsMedium = 3328, kPackedLdsLarge = 4864, kPackedLdsHuge = 6912;
 constexpr int kPackedWsLen = kPackedWindows + 64 + 2;
 
 // Packed-16-bit helpers on 32-bit registers (low half = window w, high half = window w + 1).
@@ -533,10 +533,9 @@ __device__ __forceinline__ void deferToFallback(unsigned s, unsigned bx, unsigne
 // Blocks with up to 128 candidates are appended to bigList for stage1BigKernel, everything else it cannot take to
 // todoList (256-window tiles) for stage1FallbackKernel.
 template <int kLdsPairs>
-__global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, CohortView co, int32_t * __restrict__ q3,
-                                                             uint8_t * __restrict__ flags, int * __restrict__ winFlag,
-                                                             uint8_t * __restrict__ tileTodo, unsigned * __restrict__ todoList,
-                                                             unsigned * __restrict__ bigList, unsigned tilesPerSample)
+__device__ __forceinline__ void scanKernelBody(const SegmentView & seg, const CohortView & co, int32_t * __restrict__ q3,
+                                               uint8_t * __restrict__ flags, int * __restrict__ winFlag, uint8_t * __restrict__ tileTodo,
+                                               unsigned * __restrict__ todoList, unsigned * __restrict__ bigList, unsigned tilesPerSample)
 {
     __shared__ PairPk ldsPairs[kLdsPairs + 64];
     __shared__ uint32_t ldsWs[kPackedWsLen];
@@ -555,6 +554,27 @@ __global__ __launch_bounds__(kStage1Block) void stage1Kernel(SegmentView seg, Co
         return;
     }
     deferToFallback(blockIdx.y, blockIdx.x, seg.nWindows, tilesPerSample, tileTodo, todoList, st == 1);
+}
+
+// The instantiation for ordinary coverage (smallest LDS stage: 7 workgroups fit a CU) is compiled for 7 waves per SIMD:
+// 72 VGPRs, with the 64-input network spilling a few values to scratch. A/B on one box: 6 waves (75 VGPRs, what the
+// compiler picks by itself) 1.380 ms, 8 waves (64 VGPRs, 88 B scratch) 1.311 ms, 7 waves 1.29 ms -- the scan alternates
+// load, barrier and compute phases, more resident waves keep the VALU fed across them.
+__global__ __launch_bounds__(kStage1Block) __attribute__((amdgpu_waves_per_eu(7, 7))) void stage1Kernel(
+    SegmentView seg, CohortView co, int32_t * __restrict__ q3, uint8_t * __restrict__ flags, int * __restrict__ winFlag,
+    uint8_t * __restrict__ tileTodo, unsigned * __restrict__ todoList, unsigned * __restrict__ bigList, unsigned tilesPerSample)
+{
+    scanKernelBody<kPackedLdsSmall>(seg, co, q3, flags, winFlag, tileTodo, todoList, bigList, tilesPerSample);
+}
+
+// The same with larger LDS stages (deeper coverage): occupancy is bounded by LDS there, registers are left alone.
+template <int kLdsPairs>
+__global__ __launch_bounds__(kStage1Block) void stage1KernelDeep(SegmentView seg, CohortView co, int32_t * __restrict__ q3,
+                                                                 uint8_t * __restrict__ flags, int * __restrict__ winFlag,
+                                                                 uint8_t * __restrict__ tileTodo, unsigned * __restrict__ todoList,
+                                                                 unsigned * __restrict__ bigList, unsigned tilesPerSample)
+{
+    scanKernelBody<kLdsPairs>(seg, co, q3, flags, winFlag, tileTodo, todoList, bigList, tilesPerSample);
 }
 
 // Second pass over the blocks with 65..128 candidates somewhere (deeper coverage): same scan with networks of up to
@@ -683,16 +703,16 @@ void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, 
     dim3 grid((seg.nWindows + kPackedWindows - 1) / kPackedWindows, co.nSamples);
     // maxBlockChunks: chunks of the densest 512-window block of (99 % of) the streams, host-computed at staging time
     if (maxBlockChunks <= (unsigned)kPackedLdsSmall)
-        hipLaunchKernelGGL(stage1Kernel<kPackedLdsSmall>, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo,
+        hipLaunchKernelGGL(stage1Kernel, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo,
                            todoList, bigList, tilesPerSample);
     else if (maxBlockChunks <= (unsigned)kPackedLdsMedium)
-        hipLaunchKernelGGL(stage1Kernel<kPackedLdsMedium>, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo,
+        hipLaunchKernelGGL(stage1KernelDeep<kPackedLdsMedium>, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo,
                            todoList, bigList, tilesPerSample);
     else if (maxBlockChunks <= (unsigned)kPackedLdsLarge)
-        hipLaunchKernelGGL(stage1Kernel<kPackedLdsLarge>, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo,
+        hipLaunchKernelGGL(stage1KernelDeep<kPackedLdsLarge>, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo,
                            todoList, bigList, tilesPerSample);
     else
-        hipLaunchKernelGGL(stage1Kernel<kPackedLdsHuge>, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo,
+        hipLaunchKernelGGL(stage1KernelDeep<kPackedLdsHuge>, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo,
                            todoList, bigList, tilesPerSample);
 }
 
