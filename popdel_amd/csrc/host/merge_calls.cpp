@@ -1,6 +1,7 @@
 #include <algorithm>
 #include <cmath>
 
+#include "parallel.h"
 #include "window_call.h"
 
 namespace pdh {
@@ -87,77 +88,69 @@ struct MergeState
 };
 
 // Average the PLs and take per-component medians of LAD/DAD over the windows of [start, end) that lie inside the
-// deletion. Returns false if no window qualifies.
+// deletion. Returns false if no window qualifies. The per-sample part is independent from sample to sample and runs on
+// the host threads (the accumulators of MergeState are only used inside this function and left empty by it, so they
+// play no part in the state that leaks from group to group).
 bool regenotype(std::vector<WindowCall> & calls, size_t start, size_t end, MergeState & st)
 {
     WindowCall & head = calls[start];
     const size_t S = st.genotypes.size();
-    unsigned count = 0;
+    std::vector<size_t> members;
     for (size_t g = start; g < end; ++g)
     {
         const WindowCall & c = calls[g];
         if (c.windowPosition > head.position && c.windowPosition - 30 < head.position + head.deletionLength)
-        {
-            for (size_t s = 0; s < S; ++s)
-            {
-                for (int k = 0; k < 3; ++k)
-                {
-                    st.genotypes[s][k] += c.pl[s][k];
-                    st.lads[s][k].push_back(c.lad[s][k]);
-                }
-                for (int k = 0; k < 5; ++k)
-                    st.dads[s][k].push_back(c.dad[s][k]);
-            }
-            ++count;
-        }
+            members.push_back(g);
     }
+    const unsigned count = static_cast<unsigned>(members.size());
     if (count == 0)
         return false;
-    for (size_t s = 0; s < S; ++s)
-    {
-        std::array<unsigned, 3> & g = st.genotypes[s];
+    const size_t m = count / 2;                                    // upper median
+    parallelFor(S, [&](size_t s) {
+        std::array<unsigned, 3> g = {0, 0, 0};
+        static thread_local std::vector<unsigned> col;
+        col.resize(count);
+        auto medianOf = [&](auto pick) {
+            for (unsigned i = 0; i < count; ++i)
+                col[i] = pick(calls[members[i]]);
+            std::nth_element(col.begin(), col.begin() + m, col.end());
+            return col[m];
+        };
+        for (size_t idx : members)
+            for (int k = 0; k < 3; ++k)
+                g[k] += calls[idx].pl[s][k];
         double minGt = std::min(std::min(g[0], g[1]), g[2]);
         double ref = static_cast<double>(g[0] - minGt) / count;
         double het = static_cast<double>(g[1] - minGt) / count;
         double hom = static_cast<double>(g[2] - minGt) / count;
-        g = {0, 0, 0};
-        head.pl[s][0] = static_cast<uint32_t>(std::round(ref));
-        head.pl[s][1] = static_cast<uint32_t>(std::round(het));
-        head.pl[s][2] = static_cast<uint32_t>(std::round(hom));
-        {
-            size_t m = st.lads[s][0].size() / 2;
-            for (int k = 0; k < 3; ++k)
-            {
-                std::sort(st.lads[s][k].begin(), st.lads[s][k].end());
-                head.lad[s][k] = st.lads[s][k][m];
-                st.lads[s][k].clear();
-            }
-        }
-        {
-            size_t m = st.dads[s][0].size() / 2;
-            for (int k = 0; k < 5; ++k)
-            {
-                std::sort(st.dads[s][k].begin(), st.dads[s][k].end());
-                head.dad[s][k] = st.dads[s][k][m];
-                st.dads[s][k].clear();
-            }
-        }
+        std::array<uint32_t, 3> pl = {static_cast<uint32_t>(std::round(ref)), static_cast<uint32_t>(std::round(het)),
+                                      static_cast<uint32_t>(std::round(hom))};
+        std::array<uint32_t, 3> lad;
+        std::array<uint32_t, 5> dad;
+        for (int k = 0; k < 3; ++k)
+            lad[k] = medianOf([&](const WindowCall & c) { return c.lad[s][k]; });
+        for (int k = 0; k < 5; ++k)
+            dad[k] = medianOf([&](const WindowCall & c) { return c.dad[s][k]; });
         // Break ties between neighbouring genotypes.
-        if (head.pl[s][1] == head.pl[s][2])
+        if (pl[1] == pl[2])
         {
             if (het > hom)
-                ++head.pl[s][1];
+                ++pl[1];
             else
-                ++head.pl[s][2];
+                ++pl[2];
         }
-        else if (head.pl[s][0] == head.pl[s][1])
+        else if (pl[0] == pl[1])
         {
             if (ref > het)
-                ++head.pl[s][0];
+                ++pl[0];
             else
-                ++head.pl[s][1];
+                ++pl[1];
         }
-    }
+        // the head is a member of its own group in general: write only after all members have been read for this sample
+        head.pl[s] = pl;
+        head.lad[s] = lad;
+        head.dad[s] = dad;
+    }, 256);
     return true;
 }
 

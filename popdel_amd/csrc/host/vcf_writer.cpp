@@ -2,7 +2,10 @@
 #include <cstdio>
 #include <ctime>
 #include <sstream>
+#include <string>
+#include <vector>
 
+#include "parallel.h"
 #include "profile_io.h"
 #include "window_call.h"
 
@@ -24,28 +27,65 @@ unsigned genotypeQuality(const std::array<uint32_t, 3> & pl)
     return std::min(pl[0], pl[1]);
 }
 
+// Decimal digits of an unsigned value, appended without going through printf (a record has 13 numbers per sample
+// column; at 10,000+ samples the formatter is the next host cost after the loader).
+inline void appendUInt(std::string & out, unsigned v)
+{
+    char buf[10];
+    int n = 0;
+    do
+    {
+        buf[n++] = static_cast<char>('0' + v % 10u);
+        v /= 10u;
+    } while (v != 0u);
+    while (n > 0)
+        out.push_back(buf[--n]);
+}
+
 void appendSampleColumn(std::string & out, const WindowCall & c, size_t s)
 {
     const auto & pl = c.pl[s];
-    unsigned gq = std::min(genotypeQuality(pl), 255u);
-    char buf[192];
-    int n;
+    const unsigned gq = std::min(genotypeQuality(pl), 255u);
     if (gq == 0u)
     {
-        n = snprintf(buf, sizeof(buf), "./.:0,0,0");
+        out += "./.:0,0,0";
     }
     else
     {
-        n = snprintf(buf, sizeof(buf), "%c/%c:%u,%u,%u", pl[2] == 0 ? '1' : '0', pl[0] != 0 ? '1' : '0',
-                     std::min(pl[0], 255u), std::min(pl[1], 255u), std::min(pl[2], 255u));
+        out.push_back(pl[2] == 0 ? '1' : '0');
+        out.push_back('/');
+        out.push_back(pl[0] != 0 ? '1' : '0');
+        out.push_back(':');
+        appendUInt(out, std::min(pl[0], 255u));
+        out.push_back(',');
+        appendUInt(out, std::min(pl[1], 255u));
+        out.push_back(',');
+        appendUInt(out, std::min(pl[2], 255u));
     }
-    out.append(buf, static_cast<size_t>(n));
     const auto & lad = c.lad[s];
     const auto & dad = c.dad[s];
     const auto & fl = c.firstLast[s];
-    n = snprintf(buf, sizeof(buf), ":%u:%u,%u,%u:%u,%u,%u,%u,%u:%u,%u:%u", gq, lad[0], lad[1], lad[2], dad[0], dad[1],
-                 dad[2], dad[3], dad[4], fl[0], fl[1], fl[1] - fl[0]);
-    out.append(buf, static_cast<size_t>(n));
+    out.push_back(':');
+    appendUInt(out, gq);
+    out.push_back(':');
+    appendUInt(out, lad[0]);
+    out.push_back(',');
+    appendUInt(out, lad[1]);
+    out.push_back(',');
+    appendUInt(out, lad[2]);
+    out.push_back(':');
+    for (int k = 0; k < 5; ++k)
+    {
+        if (k)
+            out.push_back(',');
+        appendUInt(out, dad[k]);
+    }
+    out.push_back(':');
+    appendUInt(out, fl[0]);
+    out.push_back(',');
+    appendUInt(out, fl[1]);
+    out.push_back(':');
+    appendUInt(out, fl[1] - fl[0]);
 }
 
 std::string filterText(const WindowCall & c)
@@ -108,11 +148,29 @@ std::string formatRecord(const QuantileTable & q, const WindowCall & call, const
          << "SWIN=" << call.significantWindows;
     line += info.str();
     line += "\tGT:PL:GQ:LAD:DAD:FL:FLD";
-    for (size_t s = 0; s < call.pl.size(); ++s)
+    // the sample columns: in blocks on the host threads for large cohorts, joined in order
+    const size_t S = call.pl.size(), kBlock = 2048;
+    if (S < 4 * kBlock)
     {
-        line.push_back('\t');
-        appendSampleColumn(line, call, s);
+        for (size_t s = 0; s < S; ++s)
+        {
+            line.push_back('\t');
+            appendSampleColumn(line, call, s);
+        }
+        return line;
     }
+    std::vector<std::string> parts((S + kBlock - 1) / kBlock);
+    parallelFor(parts.size(), [&](size_t b) {
+        std::string & out = parts[b];
+        out.reserve(kBlock * 48);
+        for (size_t s = b * kBlock; s < std::min(S, (b + 1) * kBlock); ++s)
+        {
+            out.push_back('\t');
+            appendSampleColumn(out, call, s);
+        }
+    });
+    for (const std::string & part : parts)
+        line += part;
     return line;
 }
 
@@ -178,13 +236,20 @@ void VcfOutput::unlockContigName()
 
 void VcfOutput::writeCalls(const std::vector<WindowCall> & calls, const CallParams & params)
 {
+    std::vector<const WindowCall *> wanted;
     for (const WindowCall & c : calls)
-    {
-        if (c.iterations == 0)
-            continue;
-        if (params.outputFailed || passesAll(c))
-            out_ << formatRecord(params.quantileTable, c, contigNames_[rID_]) << '\n';
-    }
+        if (c.iterations != 0 && (params.outputFailed || passesAll(c)))
+            wanted.push_back(&c);
+    // records are formatted on the host threads (large records split their sample columns themselves), written in order
+    std::vector<std::string> lines(wanted.size());
+    const bool perRecord = !wanted.empty() && wanted[0]->pl.size() < 8192;
+    if (perRecord)
+        parallelFor(wanted.size(), [&](size_t i) { lines[i] = formatRecord(params.quantileTable, *wanted[i], contigNames_[rID_]); });
+    else
+        for (size_t i = 0; i < wanted.size(); ++i)
+            lines[i] = formatRecord(params.quantileTable, *wanted[i], contigNames_[rID_]);
+    for (const std::string & l : lines)
+        out_ << l << '\n';
 }
 
 }  // namespace pdh
