@@ -1,5 +1,6 @@
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <ctime>
 #include <sstream>
 #include <string>
@@ -27,65 +28,70 @@ unsigned genotypeQuality(const std::array<uint32_t, 3> & pl)
     return std::min(pl[0], pl[1]);
 }
 
-// Decimal digits of an unsigned value, appended without going through printf (a record has 13 numbers per sample
-// column; at 10,000+ samples the formatter is the next host cost after the loader).
-inline void appendUInt(std::string & out, unsigned v)
+// Decimal digits of an unsigned value written straight into a buffer (a record has 13 numbers per sample column; at
+// 10,000+ samples the formatter is the next host cost after the loader). Returns the position behind the last digit.
+inline char * putUInt(char * p, unsigned v)
 {
-    char buf[10];
+    char tmp[10];
     int n = 0;
     do
     {
-        buf[n++] = static_cast<char>('0' + v % 10u);
+        tmp[n++] = static_cast<char>('0' + v % 10u);
         v /= 10u;
     } while (v != 0u);
     while (n > 0)
-        out.push_back(buf[--n]);
+        *p++ = tmp[--n];
+    return p;
 }
 
 void appendSampleColumn(std::string & out, const WindowCall & c, size_t s)
 {
+    char buf[176];                                   // 13 numbers of at most 10 digits + separators
+    char * p = buf;
     const auto & pl = c.pl[s];
     const unsigned gq = std::min(genotypeQuality(pl), 255u);
     if (gq == 0u)
     {
-        out += "./.:0,0,0";
+        std::memcpy(p, "./.:0,0,0", 9);
+        p += 9;
     }
     else
     {
-        out.push_back(pl[2] == 0 ? '1' : '0');
-        out.push_back('/');
-        out.push_back(pl[0] != 0 ? '1' : '0');
-        out.push_back(':');
-        appendUInt(out, std::min(pl[0], 255u));
-        out.push_back(',');
-        appendUInt(out, std::min(pl[1], 255u));
-        out.push_back(',');
-        appendUInt(out, std::min(pl[2], 255u));
+        *p++ = pl[2] == 0 ? '1' : '0';
+        *p++ = '/';
+        *p++ = pl[0] != 0 ? '1' : '0';
+        *p++ = ':';
+        p = putUInt(p, std::min(pl[0], 255u));
+        *p++ = ',';
+        p = putUInt(p, std::min(pl[1], 255u));
+        *p++ = ',';
+        p = putUInt(p, std::min(pl[2], 255u));
     }
     const auto & lad = c.lad[s];
     const auto & dad = c.dad[s];
     const auto & fl = c.firstLast[s];
-    out.push_back(':');
-    appendUInt(out, gq);
-    out.push_back(':');
-    appendUInt(out, lad[0]);
-    out.push_back(',');
-    appendUInt(out, lad[1]);
-    out.push_back(',');
-    appendUInt(out, lad[2]);
-    out.push_back(':');
+    *p++ = ':';
+    p = putUInt(p, gq);
+    *p++ = ':';
+    p = putUInt(p, lad[0]);
+    *p++ = ',';
+    p = putUInt(p, lad[1]);
+    *p++ = ',';
+    p = putUInt(p, lad[2]);
+    *p++ = ':';
     for (int k = 0; k < 5; ++k)
     {
         if (k)
-            out.push_back(',');
-        appendUInt(out, dad[k]);
+            *p++ = ',';
+        p = putUInt(p, dad[k]);
     }
-    out.push_back(':');
-    appendUInt(out, fl[0]);
-    out.push_back(',');
-    appendUInt(out, fl[1]);
-    out.push_back(':');
-    appendUInt(out, fl[1] - fl[0]);
+    *p++ = ':';
+    p = putUInt(p, fl[0]);
+    *p++ = ',';
+    p = putUInt(p, fl[1]);
+    *p++ = ':';
+    p = putUInt(p, fl[1] - fl[0]);
+    out.append(buf, static_cast<size_t>(p - buf));
 }
 
 std::string filterText(const WindowCall & c)
