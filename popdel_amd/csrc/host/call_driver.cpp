@@ -529,8 +529,7 @@ void CallRun::flushPending()
         throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctx_));
     std::vector<WindowCall> calls(pc->n_calls);
     const uint32_t S = pc->n_samples;
-    for (uint32_t c = 0; c < pc->n_calls; ++c)
-    {
+    parallelFor(pc->n_calls, [&](size_t c) {
         WindowCall & w = calls[c];
         w.initialLength = pc->initial_length[c];
         w.iterations = pc->iterations[c];
@@ -558,7 +557,7 @@ void CallRun::flushPending()
             w.firstLast[s][0] = pc->first_last[(base + s) * 2];
             w.firstLast[s][1] = pc->first_last[(base + s) * 2 + 1];
         }
-    }
+    });
     pd_calls_free(pc);
     if (observer_ && observer_->onWindowCalls)
         observer_->onWindowCalls(calls);
