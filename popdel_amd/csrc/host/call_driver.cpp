@@ -104,6 +104,17 @@ struct DecodedStream
     std::vector<PairRecord> recs;
     bool eof = false;
     bool sawFarWindow = false;     // a window beyond the next slot: the replay may consult ALL tables (allEmpty/resetTo)
+    // Streams are pooled per batch position and reused round after round: their vectors keep their capacity, so the
+    // steady state allocates nothing (hundreds of kilobytes per sample and round otherwise -- mmap/munmap from 64 threads).
+    void reuse()
+    {
+        raws.clear();
+        wins.clear();
+        counts.clear();
+        recs.clear();
+        eof = false;
+        sawFarWindow = false;
+    }
 };
 
 class CallRun
@@ -158,6 +169,7 @@ private:
     std::vector<uint64_t> flatOffsets_;
     std::vector<int32_t> flatDev_;
     std::vector<uint32_t> flatStart_, flatOn_, flatOff_;
+    std::vector<DecodedStream> decodedPool_;
     bool timingPrinted_ = false;
     bool pending_ = false;
     uint64_t pendingTicket_ = 0;
@@ -746,7 +758,11 @@ int CallRun::run()
             clock_.switches += PhaseClock::now() - t0;
             // (2) parallel: inflate, parse and split the profile windows of this round
             t0 = PhaseClock::now();
-            std::vector<DecodedStream> decoded(readers.size());
+            if (decodedPool_.size() < readers.size())
+                decodedPool_.resize(readers.size());
+            std::vector<DecodedStream> & decoded = decodedPool_;
+            for (size_t k = 0; k < readers.size(); ++k)
+                decoded[k].reuse();
             parallelFor(readers.size(), [&](size_t k) {
                 const unsigned i = readers[k];
                 const StartSlots & st = profile_->starts[p_.rgs[i][0]];
@@ -757,8 +773,8 @@ int CallRun::run()
             // (3) insert the records and switch slots: per sample independent unless a stream contains a window beyond the
             //     next slot (then the loader looks at ALL tables and order matters -> this batch is replayed in order)
             bool ordered = false;
-            for (const DecodedStream & d : decoded)
-                ordered |= d.sawFarWindow;
+            for (size_t k = 0; k < readers.size(); ++k)
+                ordered |= decoded[k].sawFarWindow;
             std::vector<unsigned> codes(readers.size(), 0);
             std::fill(border.begin(), border.end(), kNoBorder);
             border.resize(readers.size(), kNoBorder);
@@ -767,7 +783,6 @@ int CallRun::run()
                 const unsigned contigIdx = p_.representativeContigs ? 0 : i;
                 codes[k] = replaySegment(decoded[k], p_.inputFiles[i], p_.rgs[i], p_.contigNames[contigIdx], nextCandidate_[i],
                                          p_.allRois[p_.nextRoi], borderOut);
-                decoded[k] = DecodedStream();                   // free early
             };
             ++(ordered ? clock_.orderedBatches : clock_.parallelBatches);
             if (ordered)

@@ -215,7 +215,7 @@ void ChromProfile::add(unsigned rg, unsigned startPos, unsigned endPos, int devi
 void ChromProfile::activate(unsigned rg, unsigned id, unsigned logWindow)
 {
     auto & set = active[rg];
-    if (set.find(id) != set.end())
+    if (set.find(id) != nullptr)
         return;
     const StartEntry & e = starts[rg].entryOfId(id);
     ActiveRec rec{e.deviation, e.startPos, kNoLog};
@@ -230,12 +230,12 @@ void ChromProfile::activate(unsigned rg, unsigned id, unsigned logWindow)
 void ChromProfile::deactivate(unsigned rg, unsigned id, unsigned logWindow)
 {
     auto & set = active[rg];
-    auto it = set.find(id);
-    if (it == set.end())
+    const ActiveRec * rec = set.find(id);
+    if (rec == nullptr)
         return;
-    if (logging_ && it->second.logIdx != kNoLog)
-        log_[rg][it->second.logIdx].off = logWindow;
-    set.erase(it);
+    if (logging_ && rec->logIdx != kNoLog)
+        log_[rg][rec->logIdx].off = logWindow;
+    set.erase(id);
 }
 
 void ChromProfile::initializeActive()
@@ -474,8 +474,7 @@ void ChromProfile::beginSegmentLog()
     {
         log_[rg].clear();
         carried.clear();
-        for (auto & kv : active[rg])
-            carried.emplace_back(kv.first, &kv.second);
+        active[rg].forEach([&](uint32_t id, ActiveRec & rec) { carried.emplace_back(id, &rec); });
         std::sort(carried.begin(), carried.end(),
                   [](const std::pair<uint32_t, ActiveRec *> & a, const std::pair<uint32_t, ActiveRec *> & b) { return a.first < b.first; });
         for (auto & c : carried)
@@ -490,8 +489,7 @@ std::vector<std::vector<PairInstance>> & ChromProfile::endSegmentLog()
 {
     for (size_t rg = 0; rg < active.size(); ++rg)
     {
-        for (auto & kv : active[rg])
-            kv.second.logIdx = kNoLog;
+        active[rg].forEach([](uint32_t, ActiveRec & rec) { rec.logIdx = kNoLog; });
         std::vector<PairInstance> & v = log_[rg];
         size_t keep = 0;
         for (size_t i = 0; i < v.size(); ++i)

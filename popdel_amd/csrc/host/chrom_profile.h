@@ -153,7 +153,98 @@ public:
         uint32_t start;
         uint32_t logIdx;      // index of the open instance in the segment log (kNoLog if none)
     };
-    std::vector<std::unordered_map<uint32_t, ActiveRec>> active;
+    // id -> ActiveRec in one flat array (open addressing, linear probing, deletion by backward shift): the reference's
+    // std::unordered_set costs one heap node per activation, which on 64 host threads means allocator traffic for every
+    // read pair. Only membership matters; whoever needs an order sorts by id.
+    class ActiveSet
+    {
+    public:
+        ActiveSet() : slots_(64), mask_(63) {}
+        size_t size() const { return size_; }
+        bool empty() const { return size_ == 0; }
+        ActiveRec * find(uint32_t id)
+        {
+            for (size_t i = hash(id) & mask_;; i = (i + 1) & mask_)
+            {
+                Slot & s = slots_[i];
+                if (!s.used)
+                    return nullptr;
+                if (s.id == id)
+                    return &s.rec;
+            }
+        }
+        void emplace(uint32_t id, const ActiveRec & rec)          // id must not be present
+        {
+            if ((size_ + 1) * 2 > slots_.size())
+                grow();
+            insert(id, rec);
+            ++size_;
+        }
+        void erase(uint32_t id)
+        {
+            size_t i = hash(id) & mask_;
+            for (;; i = (i + 1) & mask_)
+            {
+                if (!slots_[i].used)
+                    return;
+                if (slots_[i].id == id)
+                    break;
+            }
+            // backward shift: close the gap so that probing sequences stay intact
+            size_t hole = i;
+            for (size_t j = (i + 1) & mask_; slots_[j].used; j = (j + 1) & mask_)
+            {
+                const size_t home = hash(slots_[j].id) & mask_;
+                const bool movable = ((j - home) & mask_) >= ((j - hole) & mask_);
+                if (movable)
+                {
+                    slots_[hole] = slots_[j];
+                    hole = j;
+                }
+            }
+            slots_[hole].used = false;
+            --size_;
+        }
+        template <typename F>
+        void forEach(F f)
+        {
+            for (Slot & s : slots_)
+                if (s.used)
+                    f(s.id, s.rec);
+        }
+
+    private:
+        struct Slot
+        {
+            uint32_t  id = 0;
+            bool      used = false;
+            ActiveRec rec{};
+        };
+        static size_t hash(uint32_t id) { return static_cast<size_t>(id) * 0x9E3779B1u; }
+        void insert(uint32_t id, const ActiveRec & rec)
+        {
+            size_t i = hash(id) & mask_;
+            while (slots_[i].used)
+                i = (i + 1) & mask_;
+            slots_[i].id = id;
+            slots_[i].used = true;
+            slots_[i].rec = rec;
+        }
+        void grow()
+        {
+            std::vector<Slot> old;
+            old.swap(slots_);
+            slots_.assign(old.size() * 2, Slot());
+            mask_ = slots_.size() - 1;
+            for (const Slot & s : old)
+                if (s.used)
+                    insert(s.id, s.rec);
+        }
+        std::vector<Slot> slots_;
+        size_t mask_;
+        size_t size_ = 0;
+    };
+    std::vector<ActiveSet> active;
     unsigned globalMinPos = std::numeric_limits<unsigned>::max();
     unsigned currentPos = std::numeric_limits<unsigned>::max();
     bool     profilesAtEnd = false;
