@@ -5,12 +5,14 @@
 // ChromosomeProfile::getActiveReadsDeviations() (profile_structure_popdel_call.h:1443-1478) and upperHalfMedian()
 // (genotype_deletion_popdel_call.h:15-27).
 //
-// Mapping: one lane per cell, the 64 lanes of a wave are 64 CONSECUTIVE windows of ONE sample, a 256-thread
-// workgroup covers 256 consecutive windows. Consecutive windows share most of their pairs, so the workgroup stages the
-// union of their pair chunks ONCE from HBM into LDS (coalesced 8-byte loads); HBM traffic is the compact pair
-// stream (8 B per pair chunk) instead of the expanded [sample x window x pair] tensor. Each lane then pulls its
-// candidates from LDS into a register array and sorts it with a straight-line Batcher network (VALU min/max, no
-// cross-lane traffic, no divergence); inactive slots hold +INF.
+// Mapping (main kernel): one lane per PAIR of adjacent windows of one sample, both cells packed into the 16-bit halves of
+// the lane's registers; a 256-thread workgroup covers 512 consecutive windows. Consecutive windows share most of their
+// pairs, so the workgroup stages the union of their pair chunks ONCE from HBM into LDS (coalesced 8-byte loads); HBM
+// traffic is the compact chunk stream instead of the expanded [sample x window x pair] tensor. Each lane then pulls its
+// candidates from LDS into a register array -- inactive slots become -INF / +INF fillers such that the wanted order
+// statistics land at static positions -- and sorts it with a straight-line Batcher network (packed VALU min/max, no
+// cross-lane traffic, no divergence) pruned to those positions. Kernels: stage1Kernel (up to 64 candidates, four LDS
+// capacities), stage1BigKernel (up to 128), stage1FallbackKernel (32-bit, one window per lane, or rank counting).
 #include "pd_device.h"
 #include "sortnet_gen.h"
 

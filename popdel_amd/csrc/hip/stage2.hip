@@ -12,8 +12,12 @@
 // FP64) and every consumer is rewritten for that representation; the reference's "triple contains a zero" reset is
 // reproduced by comparing d_k with the x87 underflow threshold.
 //
-// Work split: one lane per (cell, sample); sums over samples are reduced per 256-sample tile inside the workgroup and
-// the per-tile partials are added in tile order by one lane per cell, so results do not depend on scheduling.
+// Work split: a gather pass compacts the active pairs of every (cell, sample) once into a dense, transposed 16-bit
+// image; the EM and final passes then run one lane per sample (one lane per read group in tiles with multi-read-group
+// samples) over the rows of that image. A half-wave-per-sample variant with on-the-fly compaction remains for tiles the
+// image cannot hold. Sums over samples are reduced per 256-sample tile inside the workgroup and the per-tile partials
+// are added in cohort tile order by one wave per cell (lanes fetch, the additions stay sequential), so results depend
+// neither on scheduling nor on how the cohort is sharded over GPUs.
 #include "pd_device.h"
 
 namespace pd {
