@@ -8,6 +8,11 @@ import sys
 import numpy as np
 
 
+def capi_segment(first, W, offsets, arrays):
+    from popdel_amd import capi
+    return capi.Segment(first, W, offsets, arrays["dev"], arrays["start"], arrays["on"], arrays["off"])
+
+
 def make_case(name):
     """(segment of the whole cohort, read groups, sample offsets, context options)"""
     from popdel_amd import synth
@@ -52,6 +57,18 @@ def make_case(name):
                            np.concatenate([p[2] for p in parts]).astype(np.uint32),
                            np.concatenate([p[3] for p in parts]).astype(np.uint32))
         return seg, rgs, sample_offsets, {}
+    elif name == "tile3000":
+        # a BASELINE-shaped segment (6,667 windows, 3,000 samples) generated on the GPU exactly like bench.py does
+        import importlib.util
+        import torch
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("popdel_bench", os.path.join(root, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        n = 3000
+        first, W, offsets, arrays, _ = bench.device_tile(n, 777, torch.device("cuda", 0))
+        seg = capi_segment(first, W, offsets, arrays)
+        return seg, [base] * n, list(range(n + 1)), {}
     elif name.startswith("stress"):
         # random cohort of tools/stress_consistency.py (several hundred samples, 1-3 read groups each)
         import importlib.util
