@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -448,6 +449,9 @@ DTriple genotypePriors(double f, bool somatic)
     return g;
 }
 
+static bool g_snapShifts = false;    // POPDEL_SNAP_SHIFTS, read per segment
+static bool g_traceKnife = false;   // set while the window named by POPDEL_TRACE_POS is processed
+
 // genotype_deletion_popdel_call.h:388-462. The per-read-group weights are always taken from rgWise[0].
 unsigned updateDeletionLength(const pd_ctx & c, const std::vector<LTriple> & dataL, const std::vector<LTriple> & rgWise,
                               const DTriple & gt, int deletionLength, std::vector<int> & referenceShifts)
@@ -483,7 +487,24 @@ unsigned updateDeletionLength(const pd_ctx & c, const std::vector<LTriple> & dat
                 weightedSumDel += probDel * p.dev;
                 weightedSumRef += probRef * p.dev;
             }
-            referenceShifts[rg] = toIntX86(weightedSumRef / sumRef);
+            double quotient = weightedSumRef / sumRef;
+            if (g_snapShifts)
+            {
+                // Test knob POPDEL_SNAP_SHIFTS (honoured by the HIP library too): a quotient within 1e-9 of an integer is
+                // moved onto it, which takes the last-bit dependence out of the truncation below.
+                const double r = std::rint(quotient);
+                if (std::fabs(quotient - r) <= 1e-9 * std::max(1.0, std::fabs(r)))
+                    quotient = r;
+            }
+            referenceShifts[rg] = toIntX86(quotient);
+            if (g_traceKnife)
+            {
+                // debugging aid: quotients within a few ulp of an integer are the order-/x87-sensitive truncations
+                const double q = weightedSumRef / sumRef, r = std::nearbyint(q);
+                if (r != 0 && std::fabs(q - r) <= 64 * 2.220446049250313e-16 * std::fabs(r))
+                    fprintf(stderr, "[oracle trace]    knife edge: rg %u pairs %zu quotient %.17g (sigma %.3f)\n", rg,
+                            c.active[rg].size(), q, hist.stddev);
+            }
             if (referenceShifts[rg] > hist.stddev || referenceShifts[rg] < -1 * hist.stddev)
                 referenceShifts[rg] = 0;
         }
@@ -553,6 +574,8 @@ void genotypeWindow(pd_ctx & c, int32_t * q3Out, uint8_t * flagOut)
     if (lengths.empty())
         return;
     std::vector<int> referenceShifts(c.rgs.size());
+    static const char * tracePos = getenv("POPDEL_TRACE_POS");   // debugging aid: per-iteration trace of one window
+    g_traceKnife = tracePos && *tracePos && static_cast<uint32_t>(atol(tracePos)) == c.currentPos;
     for (int initLen : lengths)
     {
         std::fill(referenceShifts.begin(), referenceShifts.end(), 0);
@@ -585,6 +608,17 @@ void genotypeWindow(pd_ctx & c, int32_t * q3Out, uint8_t * flagOut)
             if (freq == 0)
                 break;
             gt = genotypePriors(freq, c.cfg.somatic != 0);
+            if (tracePos && *tracePos && static_cast<uint32_t>(atol(tracePos)) == c.currentPos)
+            {
+                long shiftSum = 0, shiftNonZero = 0;
+                for (int sft : referenceShifts)
+                {
+                    shiftSum += sft;
+                    shiftNonZero += sft != 0;
+                }
+                fprintf(stderr, "[oracle trace] pos %u init %d it %u len %u freq %.17g shifts sum %ld nonzero %ld\n", c.currentPos,
+                        initLen, iterations, len, freq, shiftSum, shiftNonZero);
+            }
             auto v = visited.find(static_cast<int>(len));
             if (v != visited.end() && std::fabs(v->second - freq) <= 0.0001)
             {
@@ -731,6 +765,7 @@ static int runSegment(pd_ctx * c, const pd_segment * seg, uint64_t * ticket)
         c->active[rg].clear();
     }
     // Active lists are kept as instance indices so that pairs can be retired by their `off` window.
+    g_snapShifts = getenv("POPDEL_SNAP_SHIFTS") != nullptr;
     std::vector<std::vector<uint64_t>> activeIdx(c->rgs.size());
     for (uint32_t w = 0; w < seg->n_windows; ++w)
     {

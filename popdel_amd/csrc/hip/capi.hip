@@ -1115,6 +1115,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             c->dShifts.ensure(static_cast<size_t>(nb) * c->nRg);
             b.ownTiles = (S + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock;
             b.forceGeneric = getenv("POPDEL_HIP_FORCE_GENERIC") ? 1 : 0;
+            b.snapShifts = getenv("POPDEL_SNAP_SHIFTS") ? 1 : 0;
             const size_t waveTiles = static_cast<size_t>(nb) * b.ownTiles * 4;
             c->dCellDev.ensure(waveTiles * pd::kDenseCap * 64);
             c->dCellStart.ensure(waveTiles * pd::kDenseCap * 64);
@@ -1189,6 +1190,18 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             PD_HIP(hipMemcpyAsync(c->hCells.data() + lo, c->dCells.p, nb * sizeof(pd::CellState), hipMemcpyDeviceToHost, c->stream));
             PD_HIP(hipStreamSynchronize(c->stream));
             std::memcpy(cells.data() + lo, c->hCells.data() + lo, nb * sizeof(pd::CellState));
+            if (const char * tp = getenv("POPDEL_TRACE_POS"))                 // debugging aid: EM trace of one window
+                for (unsigned i = 0; i < nb; ++i)
+                {
+                    const pd::CellState & cs = cells[lo + i];
+                    if (s.firstPos + (uint32_t)cs.window * s.shift != (uint32_t)atol(tp))
+                        continue;
+                    for (int v = 0; v < cs.nVisited; ++v)
+                        fprintf(stderr, "[hip trace] pos %s init %d visited %d len %d freq %.17g\n", tp, cs.initLen, v,
+                                cs.visitedLen[v], cs.visitedFreq[v]);
+                    fprintf(stderr, "[hip trace] pos %s init %d end: it %d len %u freq %.17g phase %d\n", tp, cs.initLen,
+                            cs.iterations, cs.len, cs.freq, cs.phase);
+                }
             std::vector<unsigned> emitLocal;
             for (unsigned i = 0; i < nb; ++i)
                 if (cells[lo + i].phase == pd::kCellEmit)

@@ -213,6 +213,7 @@ struct Stage2Buffers
     unsigned    nRg;
     unsigned    ownTiles;    // 256-sample tiles of this context
     int         forceGeneric; // debugging (POPDEL_HIP_FORCE_GENERIC): every tile through the generic kernels
+    int         snapShifts;   // test knob (POPDEL_SNAP_SHIFTS): near-integer reference-shift quotients snap to the integer
     // final-pass outputs, [nCells][S][k]
     uint32_t *  pl;
     uint32_t *  lad;

@@ -1081,6 +1081,30 @@ __global__ void cellLoopHeadKernel(Stage2Buffers b)
         loopHead(b.cells[c], b);
 }
 
+// New reference shift of one read group (genotype_deletion_popdel_call.h:447-451): the weighted mean deviation of its
+// pairs, truncated the way x86 converts, zeroed beyond one standard deviation. `snap` (POPDEL_SNAP_SHIFTS, a test knob that
+// the oracle honours too) first moves a quotient that is within 1e-9 of an integer onto it: single-pair and equal-weight
+// read groups put the exact quotient on an integer, and which side of it the rounded one lands on is decided by the last
+// bit of the weights (Numerics); with the knob both sides must agree everywhere.
+__device__ __forceinline__ int referenceShiftOf(double wSumRef, double sumRef, bool rgNan, double stddev, int snap)
+{
+    double q = wSumRef / sumRef;
+    if (snap)
+    {
+        const double r = rint(q);
+        if (fabs(q - r) <= 1e-9 * fmax(1.0, fabs(r)))
+            q = r;
+    }
+    int newShift;
+    if (rgNan || !(q > -2147483649.0 && q < 2147483648.0))
+        newShift = (int)0x80000000;          // what x86 yields for NaN / out-of-range conversions
+    else
+        newShift = (int)q;
+    if (newShift > stddev || newShift < -1 * stddev)
+        newShift = 0;
+    return newShift;
+}
+
 // =====================================================================================================================
 // Deletion-length / reference-shift update (reference :388-462). The per-read-group weights come from RG 0's triple
 // for EVERY read group (the reference never advances that iterator).
@@ -1161,14 +1185,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, 
             wSumRef = halfSum(wSumRef);
             sumDelAcc += sumDel;
             wSumDelAcc += wSumDel;
-            int newShift;
-            const double q = wSumRef / sumRef;
-            if (rgNan || !(q > -2147483649.0 && q < 2147483648.0))
-                newShift = (int)0x80000000;          // what x86 yields for NaN / out-of-range conversions
-            else
-                newShift = (int)q;
-            if (newShift > rc.stddev || newShift < -1 * rc.stddev)
-                newShift = 0;
+            const int newShift = referenceShiftOf(wSumRef, sumRef, rgNan, rc.stddev, b.snapShifts);
             if (hl == 0)
                 *shiftSlot = newShift;
         }
@@ -1264,14 +1281,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenDenseKernel(CohortView c
     }
     if (valid && !highCov)
     {
-        int newShift;
-        const double q = wSumRef / sumRef;
-        if (rgNan || !(q > -2147483649.0 && q < 2147483648.0))
-            newShift = (int)0x80000000;          // what x86 yields for NaN / out-of-range conversions
-        else
-            newShift = (int)q;
-        if (newShift > l.stddev || newShift < -1 * l.stddev)
-            newShift = 0;
+        const int newShift = referenceShiftOf(wSumRef, sumRef, rgNan, l.stddev, b.snapShifts);
         *shiftSlot = newShift;
     }
     const double t0 = blockSum(sumDel, red);
@@ -2118,14 +2128,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenMultiKernel(CohortView c
         }
         if (valid && !highCov)
         {
-            int newShift;
-            const double q = wSumRef / sumRef;
-            if (rgNan || !(q > -2147483649.0 && q < 2147483648.0))
-                newShift = (int)0x80000000;          // what x86 yields for NaN / out-of-range conversions
-            else
-                newShift = (int)q;
-            if (newShift > l.stddev || newShift < -1 * l.stddev)
-                newShift = 0;
+            const int newShift = referenceShiftOf(wSumRef, sumRef, rgNan, l.stddev, b.snapShifts);
             *shiftSlot = newShift;
             sumDelAcc += sumDel;
             wSumDelAcc += wSumDel;
