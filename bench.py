@@ -108,6 +108,8 @@ def main():
                          "inflates the scan's traced duration; un-profiled runs copy over SDMA")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: all ranks use GPU 0 (needs --backend gloo)")
+    ap.add_argument("--concurrent", type=int, default=3,
+                    help="contexts of the secondary concurrent-segments leg (0/1: skip it)")
     ap.add_argument("--contexts", type=int, default=1,
                     help="segments in flight per GPU (one context and host thread each); 1 keeps the kernel timings clean")
     args = ap.parse_args()
@@ -179,13 +181,13 @@ def main():
             acc[3] += t["n_candidate_cells"]
             acc[4] = t
 
-    def one_step():
-        if not extra:
+    def one_step(lanes=None):
+        lanes = lanes or ([(ctx, handle)] + extra)
+        if len(lanes) == 1:
             acc = [0.0, 0.0, 0, 0, None]
             passes_on(ctx, handle, my_passes, acc)
             return tuple(acc)
         import threading
-        lanes = [(ctx, handle)] + extra
         share = [len(range(k, my_passes, len(lanes))) for k in range(len(lanes))]
         accs = [[0.0, 0.0, 0, 0, None] for _ in lanes]
         threads = [threading.Thread(target=passes_on, args=(c, h, n, a)) for (c, h), n, a in zip(lanes, share, accs)]
@@ -246,6 +248,36 @@ def main():
 
     cells_per_step = total_passes * W * S * world
     value = cells_per_step * args.steps / elapsed
+
+    # concurrent-segments leg (reported, never `value`): the same step with several independent segments in flight on the
+    # GPU, one context and host thread each. Stage 2 is a chain of short gather-bound kernels that leaves most of the
+    # chip idle; another segment's scan fills it. Kept out of the headline because concurrent kernels stretch each
+    # other's durations, which would make the scan's roofline figure meaningless.
+    concurrent = None
+    if args.concurrent > 1 and args.contexts == 1:
+        more = []
+        for _ in range(args.concurrent - 1):
+            c2 = capi.Context(hip, [rg] * (R * S), sample_offsets, device=local_rank)
+            more.append((c2, c2.stage(seg)))
+        lanes = [(ctx, handle)] + more
+        saved = my_passes
+        my_passes = max(len(lanes), saved // 8)
+        one_step(lanes)                                        # warm-up of the new contexts
+        my_passes = saved
+        sync()
+        q0 = time.perf_counter()
+        one_step(lanes)
+        sync()
+        dt = time.perf_counter() - q0
+        if is_dist:
+            tt = torch.tensor([dt], device=red_device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        concurrent = dict(value=cells_per_step / dt, unit="window*sample/s", contexts_per_gpu=len(lanes),
+                          ms_per_pass=dt / my_passes * 1e3, steps=1)
+        for c2, h2 in more:
+            c2.unstage(h2)
+            c2.close()
 
     # roofline of the dominant kernel (stage-1 scan): algorithmic bytes per launch / mean launch duration
     launches = my_passes * args.steps
@@ -369,7 +401,7 @@ def main():
             # inside every pass the rate would be cells_per_pass / (stage_seconds + pass time): reported, never `value`
             "staging_seconds_per_segment": stage_seconds,
             "pcie_inclusive_value": (W * S) / (stage_seconds + elapsed / args.steps / max(1, my_passes)),
-            "streaming": streaming,
+            "streaming": streaming, "concurrent_segments": concurrent,
             "roofline": roofline, "cpu_baseline": cpu_baseline})
     ctx.unstage(handle)
     ctx.close()
