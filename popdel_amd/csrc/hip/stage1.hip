@@ -189,8 +189,8 @@ __device__ __forceinline__ unsigned waveMaxU32(unsigned v)
 // preserving map of int16 onto uint16), so that the two fillers are the all-zeros / all-ones patterns: -INF = 0x0000,
 // +INF = 0xFFFF -- a filler is then simply a sign mask, no constant to mix in. The number of active pairs n(w) is known
 // before the values are loaded (pairs started minus pairs ended, both per window prefix counts), so the inactive slots
-// can be filled with p(w) copies of -INF and +INF otherwise such that the wanted order statistics land at the STATIC
-// positions T and T+1 of the sorted array; the compiler then prunes every comparator outside the cone of those two.
+// can be filled with p(w) copies of -INF and +INF otherwise such that the wanted order statistics are those of the STATIC
+// ranks T and T+1: a selection network for exactly these two ranks replaces the sorter.
 typedef unsigned short v2s __attribute__((ext_vector_type(2)));
 
 #define PD_CE16(i, j)                                          \
@@ -201,26 +201,27 @@ typedef unsigned short v2s __attribute__((ext_vector_type(2)));
         r[j] = hi_;                                            \
     }
 
+// Selection instead of sorting: sortnet_gen.h's PD_SELNET_<C> leaves the order statistics of ranks T and T + 1 on the
+// wires PD_SELNET_<C>_LO / _HI (group sorts + truncated odd-even merges, only comparators in the cone of the two).
 template <int C>
-__device__ __forceinline__ void sortRegs16(v2s (&r)[C]);
-template <>
-__device__ __forceinline__ void sortRegs16<32>(v2s (&r)[32]) { PD_SORTNET_32(PD_CE16) }
-template <>
-__device__ __forceinline__ void sortRegs16<40>(v2s (&r)[40]) { PD_SORTNET_40(PD_CE16) }
-template <>
-__device__ __forceinline__ void sortRegs16<48>(v2s (&r)[48]) { PD_SORTNET_48(PD_CE16) }
-template <>
-__device__ __forceinline__ void sortRegs16<56>(v2s (&r)[56]) { PD_SORTNET_56(PD_CE16) }
-template <>
-__device__ __forceinline__ void sortRegs16<64>(v2s (&r)[64]) { PD_SORTNET_64(PD_CE16) }
-template <>
-__device__ __forceinline__ void sortRegs16<80>(v2s (&r)[80]) { PD_SORTNET_80(PD_CE16) }
-template <>
-__device__ __forceinline__ void sortRegs16<96>(v2s (&r)[96]) { PD_SORTNET_96(PD_CE16) }
-template <>
-__device__ __forceinline__ void sortRegs16<112>(v2s (&r)[112]) { PD_SORTNET_112(PD_CE16) }
-template <>
-__device__ __forceinline__ void sortRegs16<128>(v2s (&r)[128]) { PD_SORTNET_128(PD_CE16) }
+struct SelNet16;
+#define PD_SELNET16(C)                                                                      \
+    template <>                                                                             \
+    struct SelNet16<C>                                                                      \
+    {                                                                                       \
+        static constexpr int kLo = PD_SELNET_##C##_LO, kHi = PD_SELNET_##C##_HI;            \
+        static __device__ __forceinline__ void run(v2s (&r)[C]) { PD_SELNET_##C(PD_CE16) } \
+    };
+PD_SELNET16(32)
+PD_SELNET16(40)
+PD_SELNET16(48)
+PD_SELNET16(56)
+PD_SELNET16(64)
+PD_SELNET16(80)
+PD_SELNET16(96)
+PD_SELNET16(112)
+PD_SELNET16(128)
+#undef PD_SELNET16
 
 __device__ __forceinline__ unsigned rankL0(unsigned n)
 {
@@ -313,12 +314,12 @@ __device__ __forceinline__ void stage1PairFast(const PairPk * lds, unsigned aA, 
         rPk = asmPkAddS(rPk, minusOne);
         r[c] = __builtin_bit_cast(v2s, x);
     }
-    sortRegs16<C>(r);
+    SelNet16<C>::run(r);
     // back from the biased representation
-    vaA = (int)(short)(r[T].x ^ 0x8000u);
-    vbA = (int)(short)(r[T + 1].x ^ 0x8000u);
-    vaB = (int)(short)(r[T].y ^ 0x8000u);
-    vbB = (int)(short)(r[T + 1].y ^ 0x8000u);
+    vaA = (int)(short)(r[SelNet16<C>::kLo].x ^ 0x8000u);
+    vbA = (int)(short)(r[SelNet16<C>::kHi].x ^ 0x8000u);
+    vaB = (int)(short)(r[SelNet16<C>::kLo].y ^ 0x8000u);
+    vbB = (int)(short)(r[SelNet16<C>::kHi].y ^ 0x8000u);
 }
 
 // Same interpolation for int16 inputs: everything fits 32 bits.
