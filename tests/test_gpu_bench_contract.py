@@ -36,3 +36,7 @@ def test_bench_line_has_the_contract_fields(built):
     # value is cells per second of the timed region
     cells = d["config"]["windows_per_step"] * d["config"]["samples"]
     assert abs(d["value"] - cells * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-6
+    # secondary legs are reported beside the headline, never instead of it
+    assert d["contexts_per_gpu"] == 1
+    cs = d["concurrent_segments"]
+    assert cs["contexts_per_gpu"] == 3 and cs["value"] > 0 and cs["unit"] == d["unit"]

@@ -192,6 +192,44 @@ def test_two_tickets_pipelined_equal_sequential(built):
     ctx.close()
 
 
+def test_three_contexts_on_one_gpu_concurrently(built):
+    """Several segments in flight on one GPU, one context and host thread each (what bench.py's concurrent_segments leg
+    and INTEGRATION.md 3 recommend for throughput): every context must return exactly what a context alone returns."""
+    import threading
+    from popdel_amd import capi, synth
+    lib = synth.Library()
+    rg = synth.conditioned_readgroup(lib)
+    n = 300
+    segs = [synth.cohort_segment(n, (1000000, 1100000), 1000020, 3300, lib, seed_base=1000 + 500 * k,
+                                 deletions=lambda i, r, k=k: [synth.Deletion(1030000 + 7000 * k, 700 + 300 * k, [1, 2, 0][(i + k) % 3])])
+            for k in range(3)]
+    hip = capi.load_hip()
+    alone = []
+    for seg in segs:
+        ctx = capi.Context(hip, [rg] * n, list(range(n + 1)))
+        alone.append(ctx.collect(ctx.submit(seg)))
+        ctx.close()
+    assert all(a["n_calls"] > 10 for a in alone)
+    ctxs = [capi.Context(hip, [rg] * n, list(range(n + 1))) for _ in segs]
+    got = [[] for _ in segs]
+
+    def work(k):
+        for _ in range(6):
+            got[k].append(ctxs[k].collect(ctxs[k].submit(segs[k])))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for c in ctxs:
+        c.close()
+    for k in range(3):
+        for res in got[k]:
+            for key, v in alone[k].items():
+                assert np.array_equal(np.asarray(res[key]), np.asarray(v)), (k, key)
+
+
 def test_dense_and_generic_tiles_mixed(built):
     """520 samples = 3 tiles of 256: the first is served by the dense lane-per-sample kernels and holds a read group above
     max_load as sample 0 (its triple drives quirk Q2), the second holds an 85x sample (more active pairs than the dense
