@@ -255,29 +255,31 @@ def main():
     # other's durations, which would make the scan's roofline figure meaningless.
     concurrent = None
     if args.concurrent > 1 and args.contexts == 1:
-        more = []
-        for _ in range(args.concurrent - 1):
-            c2 = capi.Context(hip, [rg] * (R * S), sample_offsets, device=local_rank)
-            more.append((c2, c2.stage(seg)))
-        lanes = [(ctx, handle)] + more
-        saved = my_passes
-        my_passes = max(len(lanes), saved // 8)
-        one_step(lanes)                                        # warm-up of the new contexts
-        my_passes = saved
-        sync()
-        q0 = time.perf_counter()
-        one_step(lanes)
-        sync()
-        dt = time.perf_counter() - q0
-        if is_dist:
-            tt = torch.tensor([dt], device=red_device, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        concurrent = dict(value=cells_per_step / dt, unit="window*sample/s", contexts_per_gpu=len(lanes),
-                          ms_per_pass=dt / my_passes * 1e3, steps=1)
-        for c2, h2 in more:
-            c2.unstage(h2)
-            c2.close()
+        try:
+            more = []
+            for _ in range(args.concurrent - 1):
+                c2 = capi.Context(hip, [rg] * (R * S), sample_offsets, device=local_rank)
+                more.append((c2, c2.stage(seg)))
+            lanes = [(ctx, handle)] + more
+            saved = my_passes
+            my_passes = max(len(lanes), saved // 8)
+            one_step(lanes)                                        # warm-up of the new contexts
+            my_passes = saved
+            torch.cuda.synchronize()
+            q0 = time.perf_counter()
+            one_step(lanes)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - q0
+            # no collective in here (a rank that fails must not hang the others): with more than one rank this is rank
+            # 0's own clock, the ranks doing identical work side by side
+            concurrent = dict(value=cells_per_step / dt, unit="window*sample/s", contexts_per_gpu=len(lanes),
+                              ms_per_pass=dt / my_passes * 1e3, steps=1)
+            for c2, h2 in more:
+                c2.unstage(h2)
+                c2.close()
+        except Exception as e:          # a secondary leg must never take the headline with it
+            my_passes = len(distributed.shard_segments(total_passes * world, rank, world))
+            concurrent = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # roofline of the dominant kernel (stage-1 scan): algorithmic bytes per launch / mean launch duration
     launches = my_passes * args.steps
