@@ -2447,6 +2447,70 @@ __global__ __launch_bounds__(256) void suppPickKernel(Stage2Buffers b, int pass)
     cs.selK[pool] = k - acc;
 }
 
+// The same selection in ONE launch when the cohort is not sharded (the whole pool is local): the four passes run inside
+// the workgroup, histograms in LDS, and the percentiles are published directly (what suppFinishKernel does after the
+// exchanged passes). Saves seven launches per pass over the segment.
+__global__ __launch_bounds__(256) void suppSelectLocalKernel(Stage2Buffers b)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned shPrefix, shK, waveTot[4];
+    const unsigned c = blockIdx.x, pool = blockIdx.y;
+    CellState & cs = b.cells[c];
+    if (cs.phase != kCellFinal)
+        return;
+    const unsigned * v = (pool == 0 ? b.suppFirst : b.suppLast) + cs.suppBase;
+    const unsigned n = cs.suppCount;
+    if (threadIdx.x == 0)
+    {
+        shPrefix = 0;
+        shK = n ? (unsigned)round((double)(n - 1) * (pool == 0 ? 0.8 : (1 - 0.8))) : 0u;
+    }
+    for (int pass = 3; pass >= 0 && n != 0; --pass)
+    {
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+        const int shift = pass * 8;
+        const unsigned mask = pass == 3 ? 0u : (0xffffffffu << (shift + 8)), prefix = shPrefix;
+        for (unsigned i = threadIdx.x; i < n; i += blockDim.x)
+        {
+            const unsigned x = v[i];
+            if ((x & mask) == prefix)
+                atomicAdd(&hist[(x >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        // first digit whose inclusive prefix count exceeds k: block-wide inclusive scan, one lane per digit
+        const unsigned h = hist[threadIdx.x], k = shK;
+        unsigned incl = h;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1)
+        {
+            const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
+            if ((threadIdx.x & 63u) >= (unsigned)o)
+                incl += up;
+        }
+        if ((threadIdx.x & 63u) == 63u)
+            waveTot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        for (unsigned wv = 0; wv < (threadIdx.x >> 6); ++wv)
+            incl += waveTot[wv];
+        const unsigned digit = (unsigned)__syncthreads_count(incl <= k);       // < 256: the total exceeds k
+        if (threadIdx.x == digit)
+        {
+            shPrefix = prefix | (digit << shift);
+            shK = k - (incl - h);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        // both pools of a cell see the same count; each publishes its own percentile (suppCount itself is left alone)
+        if (pool == 0)
+            cs.suppStart = n ? shPrefix : 0u;
+        else
+            cs.suppEnd = n ? shPrefix : 0u;
+    }
+}
+
 // After the last pass: publish the percentiles and the cohort-wide support count.
 __global__ void suppFinishKernel(Stage2Buffers b)
 {
@@ -2610,13 +2674,20 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
         hipLaunchKernelGGL(finalMultiKernel, perMulti, tile, 0, st, co, b, flags, seg.nWindows, seg.firstPos, seg.shift);
     if (anyGenericTile)
         hipLaunchKernelGGL(finalKernel, perSample, tile, 0, st, seg, co, b, flags);
-    for (int pass = 3; pass >= 0; --pass)
+    if (b.world == 1)
     {
-        hipLaunchKernelGGL(suppHistKernel, dim3(b.nCells, 2), dim3(256), 0, st, b, pass);
-        x.allGather(b.selHist, (size_t)b.nCells * 2 * 256 * sizeof(unsigned));
-        hipLaunchKernelGGL(suppPickKernel, dim3(b.nCells, 2), dim3(256), 0, st, b, pass);
+        hipLaunchKernelGGL(suppSelectLocalKernel, dim3(b.nCells, 2), dim3(256), 0, st, b);
     }
-    hipLaunchKernelGGL(suppFinishKernel, perCell, cellBlock, 0, st, b);
+    else
+    {
+        for (int pass = 3; pass >= 0; --pass)
+        {
+            hipLaunchKernelGGL(suppHistKernel, dim3(b.nCells, 2), dim3(256), 0, st, b, pass);
+            x.allGather(b.selHist, (size_t)b.nCells * 2 * 256 * sizeof(unsigned));
+            hipLaunchKernelGGL(suppPickKernel, dim3(b.nCells, 2), dim3(256), 0, st, b, pass);
+        }
+        hipLaunchKernelGGL(suppFinishKernel, perCell, cellBlock, 0, st, b);
+    }
     hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellFinal, 0);
     x.allGather(b.xch, xchBytes);
     hipLaunchKernelGGL(cellEmitKernel, wavePerCell, dim3(64), 0, st, b);
