@@ -2447,52 +2447,99 @@ __global__ __launch_bounds__(256) void suppPickKernel(Stage2Buffers b, int pass)
     cs.selK[pool] = k - acc;
 }
 
-// The same selection in ONE launch when the cohort is not sharded (the whole pool is local): the four passes run inside
-// the workgroup, histograms in LDS, and the percentiles are published directly (what suppFinishKernel does after the
-// exchanged passes). Saves seven launches per pass over the segment.
+// The same selection in ONE launch when the cohort is not sharded (the whole pool is local): the passes run inside the
+// workgroup and the percentiles are published directly (what suppFinishKernel does after the exchanged passes). The pool
+// holds positions of one deletion's supporting pairs -- a few thousand bases wide, every upper byte identical -- so the
+// selection works on x - min(pool) and only on the bytes the range max - min needs (two, normally): the passes over the
+// constant upper bytes were the expensive ones (all 256 lanes adding to ONE LDS counter). One histogram per wave.
 __global__ __launch_bounds__(256) void suppSelectLocalKernel(Stage2Buffers b)
 {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned shPrefix, shK, waveTot[4];
+    __shared__ unsigned hist[4][256];
+    __shared__ unsigned shPrefix, shK, waveTot[4], shLo[4], shHi[4];
     const unsigned c = blockIdx.x, pool = blockIdx.y;
     CellState & cs = b.cells[c];
     if (cs.phase != kCellFinal)
         return;
     const unsigned * v = (pool == 0 ? b.suppFirst : b.suppLast) + cs.suppBase;
     const unsigned n = cs.suppCount;
+    const unsigned wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (n == 0)
+    {
+        if (threadIdx.x == 0)
+            (pool == 0 ? cs.suppStart : cs.suppEnd) = 0u;
+        return;
+    }
+    unsigned lo = 0xffffffffu, hi = 0;
+    // (eight loads in flight per lane: with one, the walks over the pool are a chain of L2 latencies)
+    for (unsigned i0 = threadIdx.x; i0 < n; i0 += 8u * blockDim.x)
+    {
+        unsigned x[8];
+#pragma unroll
+        for (unsigned u = 0; u < 8; ++u)
+            x[u] = (i0 + u * blockDim.x < n) ? v[i0 + u * blockDim.x] : v[i0];
+#pragma unroll
+        for (unsigned u = 0; u < 8; ++u)
+        {
+            lo = min(lo, x[u]);
+            hi = max(hi, x[u]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+    {
+        lo = min(lo, (unsigned)__shfl_xor((int)lo, o, 64));
+        hi = max(hi, (unsigned)__shfl_xor((int)hi, o, 64));
+    }
+    if (lane == 0)
+    {
+        shLo[wv] = lo;
+        shHi[wv] = hi;
+    }
     if (threadIdx.x == 0)
     {
         shPrefix = 0;
-        shK = n ? (unsigned)round((double)(n - 1) * (pool == 0 ? 0.8 : (1 - 0.8))) : 0u;
+        shK = (unsigned)round((double)(n - 1) * (pool == 0 ? 0.8 : (1 - 0.8)));
     }
-    for (int pass = 3; pass >= 0 && n != 0; --pass)
+    __syncthreads();
+    lo = min(min(shLo[0], shLo[1]), min(shLo[2], shLo[3]));
+    hi = max(max(shHi[0], shHi[1]), max(shHi[2], shHi[3]));
+    const unsigned range = hi - lo;
+    const int topPass = range >= (1u << 24) ? 3 : (range >= (1u << 16) ? 2 : (range >= (1u << 8) ? 1 : 0));
+    for (int pass = topPass; pass >= 0; --pass)
     {
-        hist[threadIdx.x] = 0;
+        for (int q = 0; q < 4; ++q)
+            hist[q][threadIdx.x] = 0;
         __syncthreads();
         const int shift = pass * 8;
         const unsigned mask = pass == 3 ? 0u : (0xffffffffu << (shift + 8)), prefix = shPrefix;
-        for (unsigned i = threadIdx.x; i < n; i += blockDim.x)
+        for (unsigned i0 = threadIdx.x; i0 < n; i0 += 8u * blockDim.x)
         {
-            const unsigned x = v[i];
-            if ((x & mask) == prefix)
-                atomicAdd(&hist[(x >> shift) & 255u], 1u);
+            unsigned y[8];
+#pragma unroll
+            for (unsigned u = 0; u < 8; ++u)
+                y[u] = (i0 + u * blockDim.x < n) ? v[i0 + u * blockDim.x] - lo : 0xffffffffu;
+#pragma unroll
+            for (unsigned u = 0; u < 8; ++u)
+                if (i0 + u * blockDim.x < n && (y[u] & mask) == prefix)
+                    atomicAdd(&hist[wv][(y[u] >> shift) & 255u], 1u);
         }
         __syncthreads();
         // first digit whose inclusive prefix count exceeds k: block-wide inclusive scan, one lane per digit
-        const unsigned h = hist[threadIdx.x], k = shK;
+        const unsigned h = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
+        const unsigned k = shK;
         unsigned incl = h;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1)
         {
             const unsigned up = (unsigned)__shfl_up((int)incl, o, 64);
-            if ((threadIdx.x & 63u) >= (unsigned)o)
+            if (lane >= (unsigned)o)
                 incl += up;
         }
-        if ((threadIdx.x & 63u) == 63u)
-            waveTot[threadIdx.x >> 6] = incl;
+        if (lane == 63u)
+            waveTot[wv] = incl;
         __syncthreads();
-        for (unsigned wv = 0; wv < (threadIdx.x >> 6); ++wv)
-            incl += waveTot[wv];
+        for (unsigned q = 0; q < wv; ++q)
+            incl += waveTot[q];
         const unsigned digit = (unsigned)__syncthreads_count(incl <= k);       // < 256: the total exceeds k
         if (threadIdx.x == digit)
         {
@@ -2502,13 +2549,7 @@ __global__ __launch_bounds__(256) void suppSelectLocalKernel(Stage2Buffers b)
         __syncthreads();
     }
     if (threadIdx.x == 0)
-    {
-        // both pools of a cell see the same count; each publishes its own percentile (suppCount itself is left alone)
-        if (pool == 0)
-            cs.suppStart = n ? shPrefix : 0u;
-        else
-            cs.suppEnd = n ? shPrefix : 0u;
-    }
+        (pool == 0 ? cs.suppStart : cs.suppEnd) = lo + shPrefix;
 }
 
 // After the last pass: publish the percentiles and the cohort-wide support count.
@@ -2650,8 +2691,8 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
         x.allGather(b.xch, xchBytes);
         hipLaunchKernelGGL(cellFreqFinishKernel, wavePerCell, dim3(64), 0, st, b, it);
         // Most cells leave the loop after 2-4 iterations: look at the "someone is still iterating" flag now and then
-        // instead of launching the remaining (empty) iterations.
-        if (it == 2 || it == 4 || it == 7 || it == 10)
+        // instead of launching the remaining (empty) iterations (a look costs a round trip of ~50 us, an empty iteration ~20).
+        if (it == 3 || it == 5 || it == 8 || it == 11)
         {
             *pinnedWord = 1;                               // page-locked: no bounce copy for four bytes
             (void)hipMemcpyAsync(pinnedWord, b.iterFlags + it, sizeof(unsigned), hipMemcpyDeviceToHost, st);
