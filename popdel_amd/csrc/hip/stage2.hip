@@ -372,9 +372,24 @@ __device__ __forceinline__ void forEachValidQ3(const ClusterInput & in, unsigned
         const uint8_t * chunk = in.base + (size_t)r * in.chunkBytes;
         const int32_t * q = reinterpret_cast<const int32_t *>(chunk) + (size_t)fw * in.sper;
         const uint8_t * fl = chunk + (size_t)in.nFlagged * in.sper * 4 + (size_t)fw * in.sper;
-        for (unsigned l = threadIdx.x; l < in.sper; l += blockDim.x)
-            if (fl[l] & 2u)
-                f(q[l]);
+        // eight independent (flag, value) loads in flight per lane: one at a time, the walk is a chain of L2 latencies
+        // (measured: 75 us for the two walks over 10,000 samples)
+        for (unsigned l0 = threadIdx.x; l0 < in.sper; l0 += 8u * blockDim.x)
+        {
+            uint8_t fv[8];
+            int qv[8];
+#pragma unroll
+            for (unsigned u = 0; u < 8; ++u)
+            {
+                const unsigned l = l0 + u * blockDim.x;
+                fv[u] = l < in.sper ? fl[l] : (uint8_t)0;
+                qv[u] = l < in.sper ? q[l] : 0;
+            }
+#pragma unroll
+            for (unsigned u = 0; u < 8; ++u)
+                if (fv[u] & 2u)
+                    f(qv[u]);
+        }
     }
 }
 
