@@ -395,7 +395,7 @@ __device__ __forceinline__ void forEachValidQ3(const ClusterInput & in, unsigned
 
 // Fast path: the Q3 values of a window span fewer than kClusterBins integers -> counting sort in LDS, clusters are read
 // off the occupied bins in ascending order. Otherwise: bitonic sort of the values in a global scratch row.
-__global__ __launch_bounds__(256) void clusterKernel(ClusterInput in, int uniformThreshold, int * __restrict__ scratch,
+__global__ __launch_bounds__(1024) void clusterKernel(ClusterInput in, int uniformThreshold, int * __restrict__ scratch,
                                                      unsigned rowLen, int * __restrict__ candLen, int * __restrict__ candCount)
 {
     __shared__ int hist[kClusterBins];
@@ -2648,7 +2648,7 @@ void launchCopyBytes(const void * src, void * dst, size_t n, hipStream_t st)
 void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,
                    hipStream_t st)
 {
-    hipLaunchKernelGGL(clusterKernel, dim3(in.nFlagged), dim3(256), 0, st, in, uniformThreshold, scratch, rowLen, candLen,
+    hipLaunchKernelGGL(clusterKernel, dim3(in.nFlagged), dim3(1024), 0, st, in, uniformThreshold, scratch, rowLen, candLen,
                        candCount);
 }
 
