@@ -373,7 +373,9 @@ unsigned ChromProfile::walkSegment(unsigned shift)
     if (pos0 + shift < currentRightBorder)
         maxSteps = (currentRightBorder - pos0 - 1) / shift;
     std::vector<unsigned> good(starts.size(), 0);
-    parallelFor(starts.size(), [&](size_t rg) { good[rg] = walkReadGroup(static_cast<unsigned>(rg), pos0, shift, maxSteps); }, 16);
+    // (pointer chasing through the slot tables and the active sets of one read group at a time: on the 256-core GPU host
+    // 16 / 32 / 64 threads measured 0.12 / 0.13 / 0.30 s for 1000 samples x 1 Mb)
+    parallelFor(starts.size(), [&](size_t rg) { good[rg] = walkReadGroup(static_cast<unsigned>(rg), pos0, shift, maxSteps); }, 8, 24);
     unsigned steps = 0;
     for (unsigned g : good)
         steps = std::max(steps, g);

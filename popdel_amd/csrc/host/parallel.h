@@ -33,10 +33,13 @@ inline unsigned hostThreads()
 // Calls fn(i) for i in [0, n) on up to hostThreads() threads (dynamic chunks). Exceptions are re-thrown on the caller.
 // Threads are spawned per call on purpose: a persistent pool (condition-variable hand-off to parked workers) was
 // measured 10-20 % SLOWER on the 256-core GPU host for the memory-bound staging passes.
+// `maxThreads` (0: no extra limit) caps the threads of passes that were measured to get SLOWER with more of them.
 template <typename F>
-void parallelFor(size_t n, F fn, size_t grain = 1)
+void parallelFor(size_t n, F fn, size_t grain = 1, unsigned maxThreads = 0)
 {
-    const unsigned threads = static_cast<unsigned>(std::min<size_t>(hostThreads(), (n + grain - 1) / grain));
+    unsigned threads = static_cast<unsigned>(std::min<size_t>(hostThreads(), (n + grain - 1) / grain));
+    if (maxThreads != 0)
+        threads = std::min(threads, maxThreads);
     if (threads <= 1)
     {
         for (size_t i = 0; i < n; ++i)
