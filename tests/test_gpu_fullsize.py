@@ -1,4 +1,4 @@
-"""GPU: size-independent properties at a BASELINE-sized launch (thousands of samples x a full 200-kb segment), where the
+"""GPU: size-independent properties at the BASELINE-sized launch (10,000 samples x a full 200-kb segment), where the
 oracle would take minutes: (1) stage-1 Q3 of randomly drawn cells against numpy; (2) cutting the segment in two and
 carrying the active pairs over gives exactly the calls of the uncut segment; (3) every pass over resident data gives
 the same answer (no state leaks between runs)."""
@@ -7,7 +7,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-S, W, FIRST = 3000, 6667, 1000020
+S, W, FIRST = 10000, 6667, 1000020        # configs[2]: the bench workload itself
 
 
 @pytest.fixture(scope="module")
