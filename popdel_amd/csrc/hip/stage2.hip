@@ -1398,6 +1398,8 @@ __global__ __launch_bounds__(64) void cellFreqFinishKernel(Stage2Buffers b, unsi
 // =====================================================================================================================
 // Likelihood-ratio terms (reference :490-508). which: 0 = current priors, 1 = previous priors.
 // =====================================================================================================================
+// `which`: 0 = the current priors, 1 = those of the previous estimate; the two sums go to entries 2*which, 2*which+1 of the
+// tile slot, so both evaluations of a converged cell travel in ONE exchange.
 __global__ __launch_bounds__(kSampleTile) void lrKernel(CohortView co, Stage2Buffers b, int wantPhase, int which)
 {
     __shared__ double red[4];
@@ -1422,7 +1424,7 @@ __global__ __launch_bounds__(kSampleTile) void lrKernel(CohortView co, Stage2Buf
     const double s1 = blockSum(noDel, red);
     if (threadIdx.x == 0)
     {
-        double * p = PD_OWN_TILE_SLOT(b, cellIdx);
+        double * p = PD_OWN_TILE_SLOT(b, cellIdx) + 2 * which;
         p[0] = s0;
         p[1] = s1;
     }
@@ -1435,22 +1437,37 @@ __device__ __forceinline__ double sumLR(const Stage2Buffers & b, unsigned c)    
     return del - noDel;
 }
 
-// step 0: store LR of the current estimate; step 1: store LR of the previous estimate and keep the better one.
-__global__ __launch_bounds__(64) void cellConvergedKernel(Stage2Buffers b, int step)
+// LR of the current estimate (tile-slot entries 0, 1) and of the previous estimate (entries 2, 3, evaluated on the
+// likelihoods recomputed at the previous length): keep the better one (reference :640-657).
+__global__ __launch_bounds__(64) void cellConvergedKernel(Stage2Buffers b)
 {
     const unsigned c = blockIdx.x;
     CellState & cs = b.cells[c];
     if (cs.phase != kCellConverged)
         return;
-    const double lr = sumLR(b, c);
+    // one wave: lanes fetch the tiles in parallel, the additions stay sequential in cohort tile order (see waveTileSums)
+    double s[4] = {0, 0, 0, 0};
+    const unsigned lane = threadIdx.x & 63u;
+    for (unsigned base = 0; base < b.nTiles; base += 64u)
+    {
+        double v[4] = {0, 0, 0, 0};
+        if (base + lane < b.nTiles)
+        {
+            const double * p = tileSlot(b, c, base + lane);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                v[k] = p[k];
+        }
+        const unsigned cnt = min(64u, b.nTiles - base);
+        for (unsigned i = 0; i < cnt; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                s[k] += __shfl(v[k], (int)i, 64);
+    }
     if (threadIdx.x != 0)
         return;
-    if (step == 0)
-    {
-        cs.logLR = lr;
-        return;
-    }
-    cs.prevLogLR = lr;
+    cs.logLR = s[0] - s[1];
+    cs.prevLogLR = s[2] - s[3];
     if (cs.prevLogLR > cs.logLR)
     {
         cs.len = cs.prevLen;
@@ -2718,12 +2735,10 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     }
     // cells that left through the visited-table test: compare with the previous estimate
     hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellConverged, 0);
-    x.allGather(b.xch, xchBytes);
-    hipLaunchKernelGGL(cellConvergedKernel, wavePerCell, dim3(64), 0, st, b, 0);
     dataLik(1);
     hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellConverged, 1);
     x.allGather(b.xch, xchBytes);
-    hipLaunchKernelGGL(cellConvergedKernel, wavePerCell, dim3(64), 0, st, b, 1);
+    hipLaunchKernelGGL(cellConvergedKernel, wavePerCell, dim3(64), 0, st, b);
     hipLaunchKernelGGL(cellPostLoopKernel, perCell, cellBlock, 0, st, b);
     hipLaunchKernelGGL(finalDenseKernel, perSample, tile, 0, st, co, b, flags, seg.nWindows, seg.firstPos, seg.shift);
     if (b.mt.n != 0)
