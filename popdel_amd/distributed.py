@@ -65,6 +65,7 @@ class SampleShardExchange:
         self.calls = 0
         self.bytes = 0
         self.last_error = None
+        self._streams = {}
 
     def reserve(self, nbytes):
         try:
@@ -83,7 +84,10 @@ class SampleShardExchange:
             mine = region[self.rank * per:(self.rank + 1) * per]
             if self.direct:
                 # RCCL, ordered on the library's stream: kernels before -> collective -> kernels after, no host wait
-                with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
+                ext = self._streams.get(stream)
+                if ext is None:                  # one wrapper per library stream, not one per exchange (20 per segment)
+                    ext = self._streams[stream] = torch.cuda.ExternalStream(stream, device=self.device)
+                with torch.cuda.stream(ext):
                     dist.all_gather_into_tensor(region, mine.clone(), group=self.group)
             elif self.on_gpu:
                 # a backend without device support (gloo): stage through host memory
