@@ -3,29 +3,29 @@
 
 Workload (BASELINE.json configs[2]): 10,000 synthetic profiles x chr20 (2,148,139 calling windows of 30 bp).
 The pair stream of 10,000 samples x chr20 is ~770 GB, so the chromosome is processed the way the host driver does it:
-one 200-kb segment (6,667 windows) of all samples at a time. The bench keeps ONE such segment of all 10,000 samples
-resident in HBM (generated on the device, staged through the C ABI before the clock starts) and a "step" runs the
-complete hot path -- stage-1 Q3 scan, candidate clustering, EM + final genotyping for every candidate cell, result
-packing -- over it 323 times, i.e. over as many windows as chr20 has. Nothing is cached between passes.
+one 200-kb segment (6,667 windows) of all samples at a time. The bench keeps ONE such segment of all samples resident in
+HBM (generated on the device, staged through the C ABI before the clock starts) and a "step" runs the complete hot path
+-- stage-1 Q3 scan, candidate clustering, EM + final genotyping for every candidate cell, result packing -- over it 323
+times, i.e. over as many windows as chr20 has. Nothing is cached between passes.
 
-With --gpus N every rank runs such a chromosome-sized step on its own GPU (segments are independent given the host-side
-carry-over of active pairs, so whole-genome work is dealt out by segment/chromosome with no data-path collective):
-per-GPU work is fixed (weak scaling), value = N x cells / max-over-ranks time.
-
-With N > 1 the same JSON line also carries "sample_sharded": the other exact split (north_star) -- ONE cohort
-of N x 9,984 samples, every rank owning the pairs of its own 9,984 samples, the library all-gathering over RCCL what
-crosses samples (popdel_amd/distributed.py: SampleShard) -- timed on a few passes of the same segment. It is a secondary
-figure: per-pass collectives cost latency that whole-segment sharding does not pay, so the headline stays on segments.
+`--gpus N` (N > 1): when no launcher has set WORLD_SIZE, this process -- before torch is imported or a GPU touched --
+starts N ranks of itself through `python -m torch.distributed.run` (one per GPU, RCCL) and exits with their status.
+The N-rank headline is the split north_star names: ONE cohort of N x 9,984 samples sharded BY SAMPLES, every
+rank staging and scanning only its own samples, the library all-gathering what crosses samples between its kernels
+(popdel_amd/distributed.py: SampleShard); per-GPU work is fixed (weak scaling), value = cohort cells / max-over-ranks
+time. The same line carries `segment_sharded`: the other exact split (whole segments of a 9,984-sample cohort per rank,
+no collective in the data path), measured before the headline so that an RCCL failure in the exchanges still leaves a
+line: it is then printed with `headline_fallback` set and the process exits non-zero.
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -33,12 +33,69 @@ sys.path.insert(0, ROOT)
 CHR20_WINDOWS = 2148139
 SEG_WINDOWS = 6667            # windows walked per 200-kb segment (windowBuffer 200000 / 30)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+SCAN_SOURCES = ("popdel_amd/csrc/hip/stage1.hip", "popdel_amd/csrc/hip/sortnet_gen.h", "popdel_amd/csrc/hip/pd_device.h")
 
 
-def device_tile(n_samples, seed, device, coverage=30.0):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--samples", type=int, default=10000)
+    ap.add_argument("--passes", type=int, default=0, help="segment passes per step (default: chr20 = 323)")
+    ap.add_argument("--cpu-samples", type=int, default=600, help="samples of the same segment timed on one host core")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=-1,
+                    help="threads of the all-cores CPU figure (-1: every host core; 0/1: skip)")
+    ap.add_argument("--sharded-timeout", type=float, default=420.0,
+                    help="N > 1: give up on the sample-sharded headline after this many seconds (the line is then printed "
+                         "with the segment split as value and the process exits 3)")
+    ap.add_argument("--stream-segments", type=int, default=4,
+                    help="segments of the streaming leg (host memory -> HBM -> calls, double buffered); 0 switches it off")
+    ap.add_argument("--coverage", type=float, default=30.0, help="sequencing depth of the synthetic samples (headline: 30)")
+    ap.add_argument("--rgs-per-sample", type=int, default=1,
+                    help="split every sample's pairs over this many read groups (same library): measures the kernels "
+                         "that multi-read-group samples take; the headline workload has 1")
+    ap.add_argument("--serial", action="store_true",
+                    help="one ticket at a time (no pipelining across segments). Used for the rocprofv3 kernel trace: under "
+                         "the profiler the result copy runs as a blit KERNEL that competes with the next scan, which "
+                         "inflates the scan's traced duration; un-profiled runs copy over SDMA")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
+    ap.add_argument("--share-gpu", action="store_true", help="dry run: all ranks use GPU 0 (needs --backend gloo)")
+    ap.add_argument("--concurrent", type=int, default=3,
+                    help="contexts of the secondary concurrent-segments leg (0/1: skip it)")
+    ap.add_argument("--contexts", type=int, default=1,
+                    help="segments in flight per GPU (one context and host thread each); 1 keeps the kernel timings clean")
+    ap.add_argument("--dense-deletions", type=int, default=10,
+                    help="planted deletions of the candidate-dense leg's segment (SURVEY 6: 49 per Mb ~ 10 per 200 kb); 0: skip")
+    ap.add_argument("--small-cohort", type=int, default=1000,
+                    help="samples of the configs[1] leg (1,000 profiles x chr20 windows); 0: skip")
+    ap.add_argument("--no-legs", action="store_true", help="headline only (profiling runs)")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start N ranks of this script (one per GPU). Runs in a process that has not imported
+    torch; the ranks are fresh child processes of the launcher module, nothing is re-executed in place."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def device_tile(n_samples, seed, device, coverage=30.0, n_deletions=1, deletion_seed=None):
     """Pair instances of one 200-kb segment for n_samples single-read-group samples, generated with torch on the GPU:
-    30x coverage, 2x150 bp, insert ~ round(N(500, 50)), one planted deletion (length log-uniform 300..5000,
-    population AF ~ Beta(0.5, 2), genotype ~ Binomial(2, AF)); activity by the interval rule."""
+    30x coverage, 2x150 bp, insert ~ round(N(500, 50)), planted deletions (length log-uniform 300..5000, population
+    AF ~ Beta(0.5, 2), genotype ~ Binomial(2, AF); one in the middle of the segment, or n_deletions evenly spaced);
+    activity by the interval rule."""
+    import numpy as np
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -50,16 +107,22 @@ def device_tile(n_samples, seed, device, coverage=30.0):
     pos, _ = torch.sort(pos, dim=1)
     ins = torch.round(torch.randn((n_samples, n), generator=g, device=device) * 50.0 + median).to(torch.int64)
     hap = torch.randint(0, 2, (n_samples, n), generator=g, device=device, dtype=torch.int64)
-    rs = np.random.default_rng(seed)
-    del_len = int(np.exp(rs.uniform(np.log(300), np.log(5000))))
-    del_start = first + (W // 2) * shift
-    af = rs.beta(0.5, 2.0)
-    gt = torch.from_numpy(rs.binomial(2, af, size=n_samples)).to(device).view(-1, 1)
-    carrier = (gt == 2) | ((gt == 1) & (hap == 0))
+    # the deletions (length, population frequency) belong to the cohort, the genotypes to this rank's samples
+    rs = np.random.default_rng(seed if deletion_seed is None else deletion_seed)
+    rs_gt = rs if deletion_seed in (None, seed) else np.random.default_rng(seed)
     inner = torch.clamp(ins - 2 * read_len, min=1)
-    inside = carrier & (pos >= del_start) & (pos < del_start + del_len)
-    span = carrier & (pos < del_start) & (pos + inner > del_start)
-    ins = torch.where(span, ins + del_len, ins)
+    inside = torch.zeros_like(pos, dtype=torch.bool)
+    planted = []
+    for k in range(n_deletions):
+        del_len = int(np.exp(rs.uniform(np.log(300), np.log(5000))))
+        del_start = first + int((k + 0.5) * W / n_deletions) * shift
+        af = rs.beta(0.5, 2.0)
+        gt = torch.from_numpy(rs_gt.binomial(2, af, size=n_samples)).to(device).view(-1, 1)
+        carrier = (gt == 2) | ((gt == 1) & (hap == 0))
+        inside |= carrier & (pos >= del_start) & (pos < del_start + del_len)
+        span = carrier & (pos < del_start) & (pos + inner > del_start)
+        ins = torch.where(span, ins + del_len, ins)
+        planted.append(dict(del_len=del_len, af=float(af)))
     dev = ins - median
     end = pos + torch.clamp(dev + median - 2 * read_len, min=0)
     last = torch.div(end, shift, rounding_mode="floor") * shift + shift
@@ -73,9 +136,9 @@ def device_tile(n_samples, seed, device, coverage=30.0):
     out = dict(dev=dev.view(-1)[flat].to(torch.int32).cpu().numpy(), start=pos.view(-1)[flat].to(torch.int32).cpu().numpy().astype(np.uint32),
                on=on.view(-1)[flat].to(torch.int32).cpu().numpy().astype(np.uint32),
                off=off.view(-1)[flat].to(torch.int32).cpu().numpy().astype(np.uint32))
-    del pos, ins, hap, dev, end, last, on, off, keep, flat
+    del pos, ins, hap, dev, end, last, on, off, keep, flat, inside
     torch.cuda.empty_cache()
-    return first, W, offsets, out, dict(del_len=del_len, af=float(af))
+    return first, W, offsets, out, (planted[0] if n_deletions == 1 else planted)
 
 
 def take_samples(offsets, arrays, n):
@@ -83,44 +146,80 @@ def take_samples(offsets, arrays, n):
     return offsets[: n + 1].copy(), {k: v[:e] for k, v in arrays.items()}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--samples", type=int, default=10000)
-    ap.add_argument("--passes", type=int, default=0, help="segment passes per step (default: chr20 = 323)")
-    ap.add_argument("--cpu-samples", type=int, default=600, help="samples of the same segment timed on one host core")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the all-cores CPU figure (0/1: skip)")
-    ap.add_argument("--sharded-passes", type=int, default=40,
-                    help="passes of the secondary sample-sharded leg (N > 1 only; 0 switches it off)")
-    ap.add_argument("--sharded-timeout", type=float, default=240.0, help="give up on the secondary leg after this many seconds")
-    ap.add_argument("--stream-segments", type=int, default=4,
-                    help="segments of the streaming leg (host memory -> HBM -> calls, double buffered); 0 switches it off")
-    ap.add_argument("--coverage", type=float, default=30.0, help="sequencing depth of the synthetic samples (headline: 30)")
-    ap.add_argument("--rgs-per-sample", type=int, default=1,
-                    help="split every sample's pairs over this many read groups (same library): measures the generic "
-                         "kernels that multi-read-group samples take; the headline workload has 1")
-    ap.add_argument("--serial", action="store_true",
-                    help="one ticket at a time (no pipelining across segments). Used for the rocprofv3 kernel trace: under "
-                         "the profiler the result copy runs as a blit KERNEL that competes with the next scan, which "
-                         "inflates the scan's traced duration; un-profiled runs copy over SDMA")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
-    ap.add_argument("--share-gpu", action="store_true", help="dry run: all ranks use GPU 0 (needs --backend gloo)")
-    ap.add_argument("--concurrent", type=int, default=3,
-                    help="contexts of the secondary concurrent-segments leg (0/1: skip it)")
-    ap.add_argument("--contexts", type=int, default=1,
-                    help="segments in flight per GPU (one context and host thread each); 1 keeps the kernel timings clean")
-    args = ap.parse_args()
+def scan_source_stamp():
+    """Identifies the build of the scan kernel a PMC summary under profiles/ was taken on."""
+    h = hashlib.sha256()
+    for rel in SCAN_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+class Lane:
+    """One context with one resident segment; runs passes the way a streaming host drives the library: the next
+    segment's ticket is issued before the open one is collected."""
+
+    def __init__(self, ctx, handle, serial=False):
+        self.ctx, self.handle, self.serial = ctx, handle, serial
+
+    def passes(self, n, acc):
+        c, h = self.ctx, self.handle
+        ticket = c.run(h) if n else None
+        for i in range(n):
+            nxt = c.run(h) if (i + 1 < n and not self.serial) else None
+            res = c.collect(ticket, copy=False)
+            ticket = nxt if not self.serial else (c.run(h) if i + 1 < n else None)
+            t = c.timing()
+            acc[0] += t["stage1_ms"]
+            acc[1] += t["stage2_ms"]
+            acc[2] += res["n_calls"]
+            acc[3] += t["n_candidate_cells"]
+            acc[4] = t
+
+
+def run_lanes(lanes, n_passes):
+    if len(lanes) == 1:
+        acc = [0.0, 0.0, 0, 0, None]
+        lanes[0].passes(n_passes, acc)
+        return tuple(acc)
+    share = [len(range(k, n_passes, len(lanes))) for k in range(len(lanes))]
+    accs = [[0.0, 0.0, 0, 0, None] for _ in lanes]
+    threads = [threading.Thread(target=l.passes, args=(n, a)) for l, n, a in zip(lanes, share, accs)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    return (sum(a[0] for a in accs), sum(a[1] for a in accs), sum(a[2] for a in accs), sum(a[3] for a in accs), accs[0][4])
+
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to print a line whose "
+                 "n_gpus would not be what was asked for" % (args.gpus, world))
+
+    import numpy as np
     import torch
     from popdel_amd import capi, distributed, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     is_dist = world > 1
+    dist = None
     if is_dist:
         import torch.distributed as dist
         if args.share_gpu:
@@ -133,11 +232,24 @@ def main():
     device = torch.device("cuda", local_rank)
     red_device = device if args.backend == "nccl" else torch.device("cpu")       # where timing reductions live
 
+    def sync():
+        torch.cuda.synchronize()
+        if is_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(seconds):
+        if not is_dist:
+            return seconds
+        tt = torch.tensor([seconds], device=red_device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     hip = capi.load_hip()                     # no fallback: raises if the HIP library is missing
     lib = synth.Library()
     rg = synth.conditioned_readgroup(lib)
-    S = args.samples
-    first, W, offsets, arrays, planted = device_tile(S, 20260 + rank, device, args.coverage)
+    S = args.samples if not is_dist else args.samples // 256 * 256     # whole 256-sample tiles per rank (pd_shard_samples)
+    first, W, offsets, arrays, planted = device_tile(S, 20260 + rank, device, args.coverage, deletion_seed=20260)
     R = max(1, args.rgs_per_sample)
     sample_offsets = list(range(0, R * S + 1, R))
     if R > 1:
@@ -156,78 +268,192 @@ def main():
     t_stage = time.perf_counter()
     handle = ctx.stage(seg)                   # host -> HBM, outside the timed region
     stage_seconds = time.perf_counter() - t_stage
-    # optional extra contexts: independent segments in flight on the same GPU (segments do not depend on each other)
-    extra = []
-    for _ in range(max(0, args.contexts - 1)):
+    lanes = [Lane(ctx, handle, args.serial)]
+    for _ in range(max(0, args.contexts - 1)):   # optional: independent segments in flight on the same GPU
         c2 = capi.Context(hip, [rg] * (R * S), sample_offsets, device=local_rank)
-        extra.append((c2, c2.stage(seg)))
+        lanes.append(Lane(c2, c2.stage(seg), args.serial))
 
     total_passes = args.passes or -(-CHR20_WINDOWS // W)
-    # weak scaling: the global job is world x total_passes segments, dealt round-robin -> total_passes per rank
-    my_passes = len(distributed.shard_segments(total_passes * world, rank, world))
 
-    def passes_on(c, h, n, acc):
-        # software-pipelined the way a streaming host drives the library: the next segment's ticket is issued before
-        # the open one is collected, so its scan starts behind the open segment's last kernel, under the result D2H
-        ticket = c.run(h) if n else None
-        for i in range(n):
-            nxt = c.run(h) if (i + 1 < n and not args.serial) else None
-            res = c.collect(ticket, copy=False)
-            ticket = nxt if not args.serial else (c.run(h) if i + 1 < n else None)
-            t = c.timing()
-            acc[0] += t["stage1_ms"]
-            acc[1] += t["stage2_ms"]
-            acc[2] += res["n_calls"]
-            acc[3] += t["n_candidate_cells"]
-            acc[4] = t
-
-    def one_step(lanes=None):
-        lanes = lanes or ([(ctx, handle)] + extra)
-        if len(lanes) == 1:
-            acc = [0.0, 0.0, 0, 0, None]
-            passes_on(ctx, handle, my_passes, acc)
-            return tuple(acc)
-        import threading
-        share = [len(range(k, my_passes, len(lanes))) for k in range(len(lanes))]
-        accs = [[0.0, 0.0, 0, 0, None] for _ in lanes]
-        threads = [threading.Thread(target=passes_on, args=(c, h, n, a)) for (c, h), n, a in zip(lanes, share, accs)]
-        for th in threads:
-            th.start()
-        for th in threads:
-            th.join()
-        return (sum(a[0] for a in accs), sum(a[1] for a in accs), sum(a[2] for a in accs), sum(a[3] for a in accs), accs[0][4])
-
-    def sync():
-        torch.cuda.synchronize()
-        if is_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one_step()
-    sync()
-    t0 = time.perf_counter()
-    s1_ms = s2_ms = 0.0
-    n_calls = n_cand = 0
-    for _ in range(args.steps):
-        a, b, c, d, tinfo = one_step()
-        s1_ms += a
-        s2_ms += b
-        n_calls += c
-        n_cand += d
-    sync()
-    elapsed = time.perf_counter() - t0
-    if is_dist:
-        tt = torch.tensor([elapsed], device=red_device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # streaming leg (reported, never `value`): every segment comes from host memory -- chunk layout built by the host
-    # threads, uploaded over the copy stream while the previous segment computes, results collected -- i.e. what a host
-    # that has the pair instances in RAM can sustain through one GPU
-    streaming = None
-    if args.stream_segments > 0:
+    def timed_steps(step_fn, warmup, steps):
+        for _ in range(warmup):
+            step_fn()
         sync()
+        t0 = time.perf_counter()
+        tot = [0.0, 0.0, 0, 0, None]
+        for _ in range(steps):
+            a, b, c, d, tinfo = step_fn()
+            tot[0] += a
+            tot[1] += b
+            tot[2] += c
+            tot[3] += d
+            tot[4] = tinfo
+        sync()
+        return max_over_ranks(time.perf_counter() - t0), tot
+
+    # ---- one context per rank over a chr20-sized set of segments: the N = 1 headline, the segment split for N > 1 -----
+    # weak scaling: the global job is world x total_passes segments dealt round-robin -> total_passes per rank
+    my_passes = len(distributed.shard_segments(total_passes * world, rank, world))
+    if not is_dist:
+        elapsed, tot = timed_steps(lambda: run_lanes(lanes, my_passes), args.warmup, args.steps)
+        steps_done = args.steps
+    else:
+        elapsed, tot = timed_steps(lambda: run_lanes(lanes, my_passes), 1, 1)
+        steps_done = 1
+    seg_value = total_passes * W * S * world * steps_done / elapsed
+    seg_split = dict(value=seg_value, unit="window*sample/s", ms_per_step=elapsed / steps_done * 1e3, steps=steps_done,
+                     samples_per_gpu=S, all_gathers_per_pass=0,
+                     parallelism="%d rank(s), each a chr20-sized set of segments of its own %d-sample cohort "
+                                 "(no collective in the data path)" % (world, S))
+    s1_ms, s2_ms, n_calls, n_cand, tinfo = tot
+    headline = dict(value=seg_value, elapsed=elapsed, steps=steps_done, s1_ms=s1_ms, s2_ms=s2_ms, n_calls=n_calls, n_cand=n_cand,
+                    tinfo=tinfo, launches=my_passes * steps_done, exchange=dict(all_gathers_per_pass=0, all_gather_bytes_per_pass=0),
+                    parallelism=seg_split["parallelism"], cohort=S, fallback=None)
+
+    result_lock = threading.Lock()
+    emitted = []
+
+    def emit(line):
+        with result_lock:                      # exactly one line, whoever gets here first (watchdog or main thread)
+            if emitted:
+                return False
+            emitted.append(True)
+            if rank == 0:
+                print(json.dumps(line), flush=True)
+            return True
+
+    def assemble(legs):
+        h = headline
+        tinfo = h["tinfo"]
+        s1_mean_s = h["s1_ms"] / h["launches"] / 1e3
+        cells = tinfo["n_cells"]
+        # gather of the [samples x windows x pairs] SoA + cell index + Q3 out
+        alg_bytes = 4 * tinfo["n_active_pairs"] + 4 * cells + 4 * cells
+        # what this layout actually has to move: 8 B per chunk + chunk index + end counts (4 B each per window) + 5 B out
+        compact_bytes = 8 * tinfo["n_pair_chunks"] + 4 * (W + tinfo["max_life"]) * h["cohort_local"] + 4 * (W + 1) * h["cohort_local"] + 5 * cells
+        achieved = alg_bytes / s1_mean_s / 1e9
+        # HBM bytes per launch and SQ counters from rocprofv3 --pmc passes on exactly this launch shape and THIS build of
+        # the scan kernel (the summary carries a hash of the kernel's sources); dropped when either does not match.
+        traffic = traffic_src = valu = None
+        stamp = scan_source_stamp()
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if not (name.endswith("_pmc_stage1.json")):
+                continue
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if pmc.get("config") == {"samples": h["cohort_local"], "windows": W} and pmc.get("scan_source_stamp") == stamp:
+                traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/" + name
+                valu = pmc.get("valu_issue_utilisation")
+                break
+        roofline = dict(bound="hbm", kernel="stage1Kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                        accounting="achieved = ALGORITHMIC bytes of SURVEY 8(d) (4 B per active pair of the expanded "
+                                   "[samples x windows x pairs] gather + 8 B per cell) / mean launch time; the chunk "
+                                   "layout moves far fewer bytes (traffic, traffic_GBs) and the kernel is bound by packed "
+                                   "16-bit VALU issue, not by HBM (limiter)",
+                        limiter="valu", valu_issue_utilisation=valu,
+                        traffic_GBs=(traffic / s1_mean_s / 1e9) if traffic else None,
+                        traffic_frac=(traffic / s1_mean_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                        scan_source_stamp=stamp,
+                        algorithmic_bytes_per_launch=alg_bytes,
+                        compact_bytes_per_launch=compact_bytes, compact_GBs=compact_bytes / s1_mean_s / 1e9,
+                        mean_launch_ms=s1_mean_s * 1e3, mean_active_pairs_per_cell=tinfo["n_active_pairs"] / cells)
+        steps = h["steps"]
+        line = {
+            "metric": "window x sample likelihood evals/sec", "value": h["value"], "unit": "window*sample/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": h["elapsed"] / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 scan + f64 likelihoods",
+            "data": "synthetic",
+            "config": {"workload": ("10,000 synthetic profiles x chr20 windows on MI355X (configs[2])" if h["cohort"] == 10000 and not args.passes
+                                    else "%d synthetic profiles x %d windows" % (h["cohort"], total_passes * W)),
+                       "samples": h["cohort"], "samples_per_gpu": h["cohort_local"], "windows_per_step": h["windows_per_step"],
+                       "segment_windows": W, "segment_passes_per_step": total_passes,
+                       "resident_segment": "one 200-kb segment of all samples, re-scanned",
+                       "planted_deletion": planted, "parallelism": h["parallelism"],
+                       "layout": "pair chunks [slot][chunk] of {dev16|dev16, off16|off16} + per-window slot index; "
+                                 "Q3/flags [sample][window]; stage 2 dense image [cell][64-sample wave tile][row][lane]"},
+            "exchange": h["exchange"],
+            "stage1_ms_per_step": h["s1_ms"] / steps, "stage2_ms_per_step": h["s2_ms"] / steps,
+            "calls_per_step": h["n_calls"] / steps, "candidate_cells_per_step": h["n_cand"] / steps,
+            "max_life": tinfo["max_life"], "contexts_per_gpu": args.contexts, "pipelined_tickets": not args.serial,
+            # host arrays -> chunked layout -> HBM for one segment of all samples; with it inside every pass the rate
+            # would be cells_per_pass / (stage_seconds + pass time): reported, never `value`
+            "staging_seconds_per_segment": stage_seconds,
+            "pcie_inclusive_value": (W * S) / (stage_seconds + seg_split["ms_per_step"] / 1e3 / max(1, my_passes)),
+            "roofline": roofline}
+        if h["fallback"]:
+            line["headline_fallback"] = h["fallback"]
+        line.update(legs)
+        return line
+
+    headline["cohort_local"] = S
+    headline["windows_per_step"] = total_passes * W * world
+    legs = {}
+
+    # ---- N > 1 headline: ONE cohort of world x S samples sharded by samples (collectives in the data path) ------------
+    if is_dist:
+        legs["segment_sharded"] = seg_split
+
+        def give_up():
+            headline["fallback"] = ("value is the SEGMENT split: the sample-sharded headline did not finish within %.0f s"
+                                    % args.sharded_timeout)
+            if emit(assemble(legs)):
+                sys.stdout.flush()
+                os._exit(3)
+
+        dog = threading.Timer(args.sharded_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            shard = distributed.SampleShard(hip, [rg] * (R * S * world), list(range(0, R * S * world + 1, R)), rank, world,
+                                            device=local_rank)
+            h_sh = shard.ctx.stage(seg)
+            lane = Lane(shard.ctx, h_sh, args.serial)
+            acc0 = [0.0, 0.0, 0, 0, None]
+            lane.passes(2, acc0)                                   # first exchanges (communicator set-up) outside the warm-up
+
+            def step():
+                acc = [0.0, 0.0, 0, 0, None]
+                lane.passes(total_passes, acc)
+                return tuple(acc)
+
+            for _ in range(args.warmup):
+                step()
+            x0 = (shard.exchange.calls, shard.exchange.bytes)
+            el, tot = timed_steps(step, 0, args.steps)
+            passes_timed = total_passes * args.steps
+            headline.update(value=total_passes * W * S * world * args.steps / el, elapsed=el, steps=args.steps, s1_ms=tot[0],
+                            s2_ms=tot[1], n_calls=tot[2], n_cand=tot[3], tinfo=tot[4], launches=passes_timed, cohort=S * world,
+                            windows_per_step=total_passes * W,
+                            exchange=dict(all_gathers_per_pass=(shard.exchange.calls - x0[0]) / passes_timed,
+                                          all_gather_bytes_per_pass=(shard.exchange.bytes - x0[1]) / passes_timed,
+                                          backend=dist.get_backend(),
+                                          what="window flags, Q3 of flagged windows, a5 counts, per-iteration tile sums + read "
+                                               "group 0's record, LR sums, support-percentile digit histograms"),
+                            parallelism="ONE cohort of %d samples sharded by samples over %d ranks (%d each); every rank scans "
+                                        "its own samples, stage 2 all-gathers per-tile sums (bit-identical to one context)"
+                                        % (S * world, world, S))
+            shard.ctx.unstage(h_sh)
+            shard.close()
+        except Exception as e:
+            headline["fallback"] = "value is the SEGMENT split: the sample-sharded headline failed: %s: %s" % (type(e).__name__, e)
+        dog.cancel()
+        if headline["fallback"]:
+            if emit(assemble(legs)):
+                sys.stdout.flush()
+                os._exit(3)
+            return
+
+    # ---- secondary legs (rank 0's own clock, no collectives; a failing leg is reported, never fatal) -------------------
+    def leg(name, fn):
+        try:
+            legs[name] = fn()
+        except Exception as e:
+            legs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    def streaming_leg():
+        # every segment comes from host memory -- layout built, uploaded over the copy stream while the previous segment
+        # computes, results collected -- i.e. what a host that has the pair instances in RAM sustains through one GPU
+        torch.cuda.synchronize()
         q0 = time.perf_counter()
         h_cur = ctx.stage(seg)
         t_cur = ctx.run(h_cur)
@@ -240,197 +466,131 @@ def main():
             ctx.unstage(h_cur)
             if not last:
                 h_cur, t_cur = h_nxt, t_nxt
-        sync()
+        torch.cuda.synchronize()
         dt = time.perf_counter() - q0
-        streaming = dict(value=args.stream_segments * W * S / dt, unit="window*sample/s", segments=args.stream_segments,
-                         seconds_per_segment=dt / args.stream_segments,
-                         host_bytes_per_segment=int(16 * len(arrays["dev"]) + 8 * (S + 1)))
+        return dict(value=args.stream_segments * W * S / dt, unit="window*sample/s", segments=args.stream_segments,
+                    seconds_per_segment=dt / args.stream_segments,
+                    host_bytes_per_segment=int(16 * len(arrays["dev"]) + 8 * (S + 1)))
 
-    cells_per_step = total_passes * W * S * world
-    value = cells_per_step * args.steps / elapsed
-
-    # concurrent-segments leg (reported, never `value`): the same step with several independent segments in flight on the
-    # GPU, one context and host thread each. Stage 2 is a chain of short gather-bound kernels that leaves most of the
-    # chip idle; another segment's scan fills it. Kept out of the headline because concurrent kernels stretch each
-    # other's durations, which would make the scan's roofline figure meaningless.
-    concurrent = None
-    if args.concurrent > 1 and args.contexts == 1:
-        try:
-            more = []
-            for _ in range(args.concurrent - 1):
-                c2 = capi.Context(hip, [rg] * (R * S), sample_offsets, device=local_rank)
-                more.append((c2, c2.stage(seg)))
-            lanes = [(ctx, handle)] + more
-            saved = my_passes
-            my_passes = max(len(lanes), saved // 8)
-            one_step(lanes)                                        # warm-up of the new contexts
-            my_passes = saved
-            torch.cuda.synchronize()
-            q0 = time.perf_counter()
-            one_step(lanes)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - q0
-            # no collective in here (a rank that fails must not hang the others): with more than one rank this is rank
-            # 0's own clock, the ranks doing identical work side by side
-            concurrent = dict(value=cells_per_step / dt, unit="window*sample/s", contexts_per_gpu=len(lanes),
-                              ms_per_pass=dt / my_passes * 1e3, steps=1)
-            for c2, h2 in more:
-                c2.unstage(h2)
-                c2.close()
-        except Exception as e:          # a secondary leg must never take the headline with it
-            my_passes = len(distributed.shard_segments(total_passes * world, rank, world))
-            concurrent = {"error": "%s: %s" % (type(e).__name__, e)}
-
-    # roofline of the dominant kernel (stage-1 scan): algorithmic bytes per launch / mean launch duration
-    launches = my_passes * args.steps
-    s1_mean_s = s1_ms / launches / 1e3
-    cells = tinfo["n_cells"]
-    alg_bytes = 4 * tinfo["n_active_pairs"] + 4 * cells + 4 * cells          # gather + cell index + Q3 out
-    # what this layout actually has to move: 8 B per chunk + chunk index + end counts (4 B each per window) + 5 B out
-    compact_bytes = 8 * tinfo["n_pair_chunks"] + 4 * (W + tinfo["max_life"]) * S + 4 * (W + 1) * S + 5 * cells
-    achieved = alg_bytes / s1_mean_s / 1e9
-    # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), measured with rocprofv3 on
-    # exactly this launch shape; summary committed under profiles/. Only quoted when the shape matches.
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_stage1.json")
-    if os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path))
-        if pmc["config"] == {"samples": S, "windows": W}:
-            traffic = pmc["hbm_bytes_per_launch"]
-    roofline = dict(bound="hbm", kernel="stage1Kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source="profiles/r01_pmc_stage1.json" if traffic else None,
-                    algorithmic_bytes_per_launch=alg_bytes,
-                    compact_bytes_per_launch=compact_bytes, compact_GBs=compact_bytes / s1_mean_s / 1e9,
-                    mean_launch_ms=s1_mean_s * 1e3, mean_active_pairs_per_cell=tinfo["n_active_pairs"] / cells)
-
-    cpu_baseline = None
-    if rank == 0 and not args.no_cpu:
-        oracle_path = os.path.join(ROOT, "oracle", "_build", "libpopdel_oracle.so")
-        if os.path.exists(oracle_path):
-            n_cpu = min(args.cpu_samples, S)
-            o_off, o_arr = take_samples(offsets, arrays, n_cpu)
-            oseg = capi.Segment(first, W, o_off, o_arr["dev"], o_arr["start"], o_arr["on"], o_arr["off"])
-            octx = capi.Context(capi.load_library(oracle_path), [rg] * n_cpu, list(range(n_cpu + 1)))
-            c0 = time.perf_counter()
-            octx.collect(octx.submit(oseg))
-            cpu_s = time.perf_counter() - c0
-            octx.close()
-            cpu_baseline = dict(value=n_cpu * W / cpu_s, unit="window*sample/s", cores=1, kind="port",
-                                sample="%d of the %d samples x the same %d-window segment, oracle/ (x87 long double), %.1f s"
-                                       % (n_cpu, S, W, cpu_s))
-            # the same on all host cores the way a CPU run would use them: independent cohorts of n_cpu samples each (the
-            # oracle is single-threaded; ctypes releases the GIL), reported next to the one-core figure
-            import threading
-            n_thr = max(1, min(args.cpu_threads, os.cpu_count() or 1, S // n_cpu))
-            if n_thr > 1:
-                olib = capi.load_library(oracle_path)
-                parts = []
-                for t in range(n_thr):
-                    lo, hi = int(offsets[t * n_cpu]), int(offsets[(t + 1) * n_cpu])
-                    parts.append(capi.Segment(first, W, offsets[t * n_cpu:(t + 1) * n_cpu + 1] - offsets[t * n_cpu],
-                                              arrays["dev"][lo:hi], arrays["start"][lo:hi], arrays["on"][lo:hi], arrays["off"][lo:hi]))
-                ctxs = [capi.Context(olib, [rg] * n_cpu, list(range(n_cpu + 1))) for _ in range(n_thr)]
-                work = [threading.Thread(target=lambda c=c, p=p: c.collect(c.submit(p), copy=False)) for c, p in zip(ctxs, parts)]
-                c0 = time.perf_counter()
-                for th in work:
-                    th.start()
-                for th in work:
-                    th.join()
-                cpu_all_s = time.perf_counter() - c0
-                for c in ctxs:
-                    c.close()
-                cpu_baseline["all_cores"] = dict(value=n_thr * n_cpu * W / cpu_all_s, unit="window*sample/s", cores=n_thr,
-                                                 sample="%d independent cohorts of %d samples, one oracle context per thread, %.1f s"
-                                                        % (n_thr, n_cpu, cpu_all_s))
-
-    # ---- secondary leg: the cohort sharded by SAMPLES over the ranks (collectives in the data path) --------------------
-    result = {}
-
-    def emit_and_finish(sample_sharded):
-        if rank == 0:
-            line = dict(result)
-            line["sample_sharded"] = sample_sharded
-            print(json.dumps(line), flush=True)
-
-    def sample_sharded_leg():
-        n = S // 256 * 256                                     # whole tiles per rank (partition rule of pd_shard_samples)
-        o, a = take_samples(offsets, arrays, n)
-        lseg = capi.Segment(first, W, o, a["dev"], a["start"], a["on"], a["off"])
-        shard = distributed.SampleShard(hip, [rg] * (n * world), list(range(n * world + 1)), rank, world, device=local_rank)
-        h = shard.ctx.stage(lseg)
-        calls = 0
-        for _ in range(2):
-            shard.ctx.collect(shard.ctx.run(h), copy=False)
-        x0 = shard.exchange.calls, shard.exchange.bytes
-        sync()
+    def concurrent_leg():
+        # the same step with several independent segments in flight on the GPU, one context and host thread each
+        more = []
+        for _ in range(args.concurrent - 1):
+            c2 = capi.Context(hip, [rg] * (R * S), sample_offsets, device=local_rank)
+            more.append(Lane(c2, c2.stage(seg), args.serial))
+        all_lanes = lanes[:1] + more
+        run_lanes(all_lanes, max(len(all_lanes), my_passes // 8))          # warm-up of the new contexts
+        torch.cuda.synchronize()
         q0 = time.perf_counter()
-        ticket = shard.ctx.run(h)
-        for i in range(args.sharded_passes):
-            nxt = shard.ctx.run(h) if i + 1 < args.sharded_passes else None
-            calls += shard.ctx.collect(ticket, copy=False)["n_calls"]
-            ticket = nxt
-        sync()
+        run_lanes(all_lanes, my_passes)
+        torch.cuda.synchronize()
         dt = time.perf_counter() - q0
-        tt = torch.tensor([dt], device=red_device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        tm = shard.ctx.timing()
-        out = dict(value=args.sharded_passes * W * n * world / dt, unit="window*sample/s", samples_per_gpu=n,
-                   cohort_samples=n * world, passes=args.sharded_passes, ms_per_pass=dt / args.sharded_passes * 1e3,
-                   all_gathers_per_pass=(shard.exchange.calls - x0[0]) / args.sharded_passes,
-                   all_gather_bytes_per_pass=(shard.exchange.bytes - x0[1]) / args.sharded_passes,
-                   calls_per_pass=calls / args.sharded_passes, candidate_cells_per_pass=tm["n_candidate_cells"],
-                   backend=dist.get_backend(), scaling="weak")
-        shard.ctx.unstage(h)
-        shard.close()
+        for l in more:
+            l.ctx.unstage(l.handle)
+            l.ctx.close()
+        return dict(value=total_passes * W * S / dt, unit="window*sample/s", contexts_per_gpu=len(all_lanes),
+                    ms_per_pass=dt / my_passes * 1e3, steps=1)
+
+    def small_cohort_leg():
+        # BASELINE configs[1]: 1,000 synthetic profiles x chr20 windows on one GPU
+        n = min(args.small_cohort, S)
+        o, a = take_samples(offsets, arrays, n * R)
+        c2 = capi.Context(hip, [rg] * (R * n), sample_offsets[: n + 1], device=local_rank)
+        l2 = Lane(c2, c2.stage(capi.Segment(first, W, o, a["dev"], a["start"], a["on"], a["off"])), args.serial)
+        run_lanes([l2], max(2, total_passes // 8))
+        torch.cuda.synchronize()
+        q0 = time.perf_counter()
+        acc = run_lanes([l2], total_passes)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - q0
+        c2.unstage(l2.handle)
+        c2.close()
+        return dict(workload="%d synthetic profiles x chr20 windows (configs[1])" % n, value=total_passes * W * n / dt,
+                    unit="window*sample/s", ms_per_pass=dt / total_passes * 1e3, stage1_ms_per_pass=acc[0] / total_passes,
+                    stage2_ms_per_pass=acc[1] / total_passes, calls_per_pass=acc[2] / total_passes)
+
+    def dense_leg():
+        # candidate-dense segment (one deletion per 20 kb): stage 2 dominates on the CPU (7x stage 1)
+        f2, W2, o2, a2, pl2 = device_tile(S, 777 + rank, device, args.coverage, n_deletions=args.dense_deletions)
+        c2 = capi.Context(hip, [rg] * S, list(range(S + 1)), device=local_rank)
+        l2 = Lane(c2, c2.stage(capi.Segment(f2, W2, o2, a2["dev"], a2["start"], a2["on"], a2["off"])), args.serial)
+        n_pass = 12
+        run_lanes([l2], 2)
+        torch.cuda.synchronize()
+        q0 = time.perf_counter()
+        acc = run_lanes([l2], n_pass)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - q0
+        c2.unstage(l2.handle)
+        c2.close()
+        return dict(workload="%d samples x %d windows, %d planted deletions in the segment" % (S, W2, args.dense_deletions),
+                    value=n_pass * W2 * S / dt, unit="window*sample/s", ms_per_pass=dt / n_pass * 1e3,
+                    stage1_ms_per_pass=acc[0] / n_pass, stage2_ms_per_pass=acc[1] / n_pass,
+                    candidate_cells_per_pass=acc[3] / n_pass, calls_per_pass=acc[2] / n_pass,
+                    planted=[dict(del_len=p["del_len"], af=round(p["af"], 4)) for p in pl2])
+
+    def cpu_leg():
+        oracle_path = os.path.join(ROOT, "oracle", "_build", "libpopdel_oracle.so")
+        if not os.path.exists(oracle_path):
+            return None
+        n_cpu = min(args.cpu_samples, S)
+        o_off, o_arr = take_samples(offsets, arrays, n_cpu * R)
+        oseg = capi.Segment(first, W, o_off, o_arr["dev"], o_arr["start"], o_arr["on"], o_arr["off"])
+        olib = capi.load_library(oracle_path)
+        octx = capi.Context(olib, [rg] * (n_cpu * R), sample_offsets[: n_cpu + 1])
+        c0 = time.perf_counter()
+        octx.collect(octx.submit(oseg))
+        cpu_s = time.perf_counter() - c0
+        octx.close()
+        out = dict(value=n_cpu * W / cpu_s, unit="window*sample/s", cores=1, kind="port", cpu_model=cpu_model(),
+                   host_cores=os.cpu_count(),
+                   sample="%d of the %d samples x the same %d-window segment, oracle/ (x87 long double), %.1f s"
+                          % (n_cpu, S, W, cpu_s))
+        # the same on all host cores the way a CPU run would use them: independent cohorts of n_cpu samples each (the
+        # oracle is single-threaded; ctypes releases the GIL)
+        n_thr = (os.cpu_count() or 1) if args.cpu_threads < 0 else min(args.cpu_threads, os.cpu_count() or 1)
+        if n_thr > 1 and R == 1:
+            distinct = max(1, S // n_cpu)
+            parts = []
+            for t in range(min(distinct, n_thr)):
+                lo, hi = int(offsets[t * n_cpu]), int(offsets[(t + 1) * n_cpu])
+                parts.append(capi.Segment(first, W, offsets[t * n_cpu:(t + 1) * n_cpu + 1] - offsets[t * n_cpu],
+                                          arrays["dev"][lo:hi], arrays["start"][lo:hi], arrays["on"][lo:hi], arrays["off"][lo:hi]))
+            ctxs = [capi.Context(olib, [rg] * n_cpu, list(range(n_cpu + 1))) for _ in range(n_thr)]
+            work = [threading.Thread(target=lambda c=c, p=parts[i % len(parts)]: c.collect(c.submit(p), copy=False))
+                    for i, c in enumerate(ctxs)]
+            c0 = time.perf_counter()
+            for th in work:
+                th.start()
+            for th in work:
+                th.join()
+            cpu_all_s = time.perf_counter() - c0
+            for c in ctxs:
+                c.close()
+            out["all_cores"] = dict(value=n_thr * n_cpu * W / cpu_all_s, unit="window*sample/s", cores=n_thr,
+                                    sample="%d independent cohorts of %d samples (%d distinct), one oracle context per thread, %.1f s"
+                                           % (n_thr, n_cpu, len(parts), cpu_all_s))
         return out
 
+    if rank == 0 and not args.no_legs and not is_dist:      # N > 1 runs carry the two splits only
+        if args.stream_segments > 0:
+            leg("streaming", streaming_leg)
+        if args.concurrent > 1 and args.contexts == 1:
+            leg("concurrent_segments", concurrent_leg)
+        if args.small_cohort > 0:
+            leg("small_cohort", small_cohort_leg)
+        if args.dense_deletions > 0 and R == 1:
+            leg("candidate_dense", dense_leg)
     if rank == 0:
-        result = ({
-            "metric": "window x sample likelihood evals/sec", "value": value, "unit": "window*sample/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 scan + f64 likelihoods",
-            "data": "synthetic",
-            "config": {"workload": "10,000 synthetic profiles x chr20 windows on MI355X (configs[2])" if S == 10000 and not args.passes
-                       else "%d synthetic profiles x %d windows" % (S, total_passes * W),
-                       "samples": S, "windows_per_step": total_passes * W * world, "segment_windows": W,
-                       "segment_passes_per_step": total_passes, "resident_segment": "one 200-kb segment of all samples, re-scanned",
-                       "planted_deletion": planted, "parallelism": "%d rank(s), each a chr20-sized set of segments (no collective in the data path)" % world},
-            "stage1_ms_per_step": s1_ms / args.steps, "stage2_ms_per_step": s2_ms / args.steps,
-            "calls_per_step": n_calls / args.steps, "candidate_cells_per_step": n_cand / args.steps,
-            "max_life": tinfo["max_life"], "contexts_per_gpu": args.contexts, "pipelined_tickets": not args.serial,
-            # host arrays -> chunked layout -> HBM for one segment of all samples (single host thread + PCIe); with it
-            # inside every pass the rate would be cells_per_pass / (stage_seconds + pass time): reported, never `value`
-            "staging_seconds_per_segment": stage_seconds,
-            "pcie_inclusive_value": (W * S) / (stage_seconds + elapsed / args.steps / max(1, my_passes)),
-            "streaming": streaming, "concurrent_segments": concurrent,
-            "roofline": roofline, "cpu_baseline": cpu_baseline})
-    ctx.unstage(handle)
-    ctx.close()
-    for c2, h2 in extra:
-        c2.unstage(h2)
-        c2.close()
-    if not is_dist or args.sharded_passes <= 0:
-        emit_and_finish(None)
-    else:
-        # A collective that never completes must not take the headline with it: a watchdog prints the line and ends the
-        # process if the secondary leg overruns.
-        import threading
-
-        def give_up():
-            emit_and_finish({"error": "sample-sharded leg did not finish within %.0f s" % args.sharded_timeout})
-            os._exit(0)
-
-        dog = threading.Timer(args.sharded_timeout, give_up)
-        dog.daemon = True
-        dog.start()
-        try:
-            leg = sample_sharded_leg()
-        except Exception as e:          # reported, never fatal for the headline
-            leg = {"error": "%s: %s" % (type(e).__name__, e)}
-        dog.cancel()
-        emit_and_finish(leg)
+        legs["cpu_baseline"] = None
+        if not args.no_cpu and not is_dist:                 # timed on rank 0 at N = 1 only
+            leg("cpu_baseline", cpu_leg)
+    for l in lanes:
+        l.ctx.unstage(l.handle)
+        l.ctx.close()
+    emit(assemble(legs))
     if is_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

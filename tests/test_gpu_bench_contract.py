@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_line_has_the_contract_fields(built):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--samples", "512", "--passes", "3", "--steps", "2",
-                          "--warmup", "1", "--cpu-samples", "40", "--cpu-threads", "2", "--stream-segments", "2"],
+                          "--warmup", "1", "--cpu-samples", "40", "--cpu-threads", "2", "--stream-segments", "2", "--small-cohort", "128",
+                          "--dense-deletions", "3"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -40,3 +41,36 @@ def test_bench_line_has_the_contract_fields(built):
     assert d["contexts_per_gpu"] == 1
     cs = d["concurrent_segments"]
     assert cs["contexts_per_gpu"] == 3 and cs["value"] > 0 and cs["unit"] == d["unit"]
+    assert d["exchange"]["all_gathers_per_pass"] == 0
+    assert d["small_cohort"]["value"] > 0 and d["candidate_dense"]["candidate_cells_per_pass"] > 0
+    assert c["all_cores"]["cores"] == 2 and c["cpu_model"]
+    assert r["limiter"] == "valu" and r["scan_source_stamp"]
+
+
+def test_gpus_2_spawns_two_ranks_and_reports_the_sample_split(built):
+    """`bench.py --gpus 2` with no launcher around it starts two ranks itself; here both share the box's one GPU and
+    exchange over gloo (RCCL refuses two ranks on one device). The headline is the cohort sharded by samples."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
+                          "--samples", "512", "--passes", "3", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and "headline_fallback" not in d
+    assert d["config"]["samples"] == 1024 and d["config"]["samples_per_gpu"] == 512
+    assert d["exchange"]["all_gathers_per_pass"] >= 10 and d["exchange"]["backend"] == "gloo"
+    cells = d["config"]["windows_per_step"] * d["config"]["samples"]
+    assert abs(d["value"] - cells / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
+    assert d["segment_sharded"]["value"] > 0 and d["segment_sharded"]["all_gathers_per_pass"] == 0
+    assert d["calls_per_step"] > 0
+
+
+def test_gpus_mismatch_fails_loudly(built):
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode != 0 and "refusing" in out.stderr
