@@ -13,10 +13,24 @@
  * to String<Call> comes back as plain arrays.
  *
  * Conventions: all functions return 0 on success, non-zero on error (pd_last_error() gives
- * text); no exceptions cross the boundary; a context is bound to one GPU, calls on one
- * context must be serialised by the caller, and a context has ONE ticket in flight at a time
- * (collect it before the next submit/run; use one context per stream of segments). Pointers passed in are caller-owned host
- * memory unless stated otherwise; pd_calls is callee-owned until pd_calls_free().
+ * text); no exceptions cross the boundary; a context is bound to one GPU and calls on one
+ * context must be serialised by the caller. Tickets: at most TWO may be outstanding per context
+ * (one running, one waiting), collected in the order issued; see pd_segment_run(). Pointers
+ * passed in are caller-owned host memory unless stated otherwise; pd_calls is callee-owned
+ * until pd_calls_free().
+ *
+ * Limits (violations are reported as errors, never truncated silently):
+ *   - at most 65,535 samples per context (pd_ctx_create fails beyond; larger cohorts are sharded
+ *     by samples over several contexts, pd_ctx_set_shard);
+ *   - at most 64 EM iterations (pd_config::iterations);
+ *   - at most 32 candidate deletion lengths per window (pd_segment_collect fails beyond; the
+ *     reference's clustering yields one per ~50 bp of Q3 spread, a handful at most in practice);
+ *   - segments of at most 2^31 windows and 2^32 - 1 pair chunks per read group.
+ *
+ * Where floating point decides an integer: the reference evaluates the per-read-group weights of
+ * its reference-shift update in x87 `long double` (genotype_deletion_popdel_call.h:421-445).
+ * Those two numbers per (window, candidate) and EM iteration are computed on the HOST FPU of the
+ * calling process (x86-64 `long double`, glibc logl/expl), everything else on the GPU.
  */
 #ifndef POPDEL_HIP_H_
 #define POPDEL_HIP_H_
@@ -28,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 2
+#define PD_ABI_VERSION 3
 
 /* One read group after start-up conditioning.
  * Replaces: `Histogram` (reference insert_histogram_popdel.h:19-43) after processHistogram()
@@ -68,7 +82,9 @@ typedef struct pd_config
  * of ChromosomeProfile::activeReads[rg] for the windows with index on <= w < off appears as one
  * "pair instance" {dev, start, on, off}. The host side derives on/off by running the
  * reference's window state machine, so the loader's segment-border behaviour stays host-side.
- * Instances of one read group are stored contiguously, ordered by non-decreasing `on`. */
+ * Instances of one read group are stored contiguously, ordered by non-decreasing `on`. Their order
+ * is also the order in which floating-point sums over the pairs of a (window, sample) are formed
+ * (the reference walks its active set there): results are bit-reproducible for a given order. */
 typedef struct pd_segment
 {
     uint32_t        first_window_pos;  /* ChromosomeProfile::currentPos of window 0          */

@@ -449,7 +449,6 @@ DTriple genotypePriors(double f, bool somatic)
     return g;
 }
 
-static bool g_snapShifts = false;    // POPDEL_SNAP_SHIFTS, read per segment
 static bool g_traceKnife = false;   // set while the window named by POPDEL_TRACE_POS is processed
 
 // genotype_deletion_popdel_call.h:388-462. The per-read-group weights are always taken from rgWise[0].
@@ -475,6 +474,9 @@ unsigned updateDeletionLength(const pd_ctx & c, const std::vector<LTriple> & dat
             long double a = std::log(aSumRg);
             long double a0Rg = l + g - a;
             long double a1Rg = logl(rgDl.i2) + std::log(gt.i2) - std::log(aSumRg);
+            if (g_traceKnife && rg == 0)
+                fprintf(stderr, "[oracle trace]   update: len %d shift0 %d gt %.17g %.17g %.17g expA0 %.17g expA1 %.17g\n", deletionLength,
+                        referenceShifts[0], gt.i1, gt.i2, gt.i3, (double)expl(a0Rg), (double)expl(a1Rg));
             const ReadGroup & hist = c.rgs[rg];
             for (const ActivePair & p : c.active[rg])
             {
@@ -487,15 +489,7 @@ unsigned updateDeletionLength(const pd_ctx & c, const std::vector<LTriple> & dat
                 weightedSumDel += probDel * p.dev;
                 weightedSumRef += probRef * p.dev;
             }
-            double quotient = weightedSumRef / sumRef;
-            if (g_snapShifts)
-            {
-                // Test knob POPDEL_SNAP_SHIFTS (honoured by the HIP library too): a quotient within 1e-9 of an integer is
-                // moved onto it, which takes the last-bit dependence out of the truncation below.
-                const double r = std::rint(quotient);
-                if (std::fabs(quotient - r) <= 1e-9 * std::max(1.0, std::fabs(r)))
-                    quotient = r;
-            }
+            const double quotient = weightedSumRef / sumRef;
             referenceShifts[rg] = toIntX86(quotient);
             if (g_traceKnife)
             {
@@ -611,13 +605,22 @@ void genotypeWindow(pd_ctx & c, int32_t * q3Out, uint8_t * flagOut)
             if (tracePos && *tracePos && static_cast<uint32_t>(atol(tracePos)) == c.currentPos)
             {
                 long shiftSum = 0, shiftNonZero = 0;
+                unsigned long hash = 1469598103934665603ul;
                 for (int sft : referenceShifts)
                 {
                     shiftSum += sft;
                     shiftNonZero += sft != 0;
+                    hash = (hash ^ (unsigned)sft) * 1099511628211ul;
                 }
-                fprintf(stderr, "[oracle trace] pos %u init %d it %u len %u freq %.17g shifts sum %ld nonzero %ld\n", c.currentPos,
-                        initLen, iterations, len, freq, shiftSum, shiftNonZero);
+                fprintf(stderr, "[oracle trace] pos %u init %d it %u len %u freq %.17g shifts sum %ld nonzero %ld hash %016lx\n", c.currentPos,
+                        initLen, iterations, len, freq, shiftSum, shiftNonZero, hash);
+                if (getenv("POPDEL_TRACE_SHIFTS"))
+                {
+                    fprintf(stderr, "[oracle trace]   shifts:");
+                    for (int sft : referenceShifts)
+                        fprintf(stderr, " %d", sft);
+                    fprintf(stderr, "\n");
+                }
             }
             auto v = visited.find(static_cast<int>(len));
             if (v != visited.end() && std::fabs(v->second - freq) <= 0.0001)
@@ -765,7 +768,6 @@ static int runSegment(pd_ctx * c, const pd_segment * seg, uint64_t * ticket)
         c->active[rg].clear();
     }
     // Active lists are kept as instance indices so that pairs can be retired by their `off` window.
-    g_snapShifts = getenv("POPDEL_SNAP_SHIFTS") != nullptr;
     std::vector<std::vector<uint64_t>> activeIdx(c->rgs.size());
     for (uint32_t w = 0; w < seg->n_windows; ++w)
     {

@@ -13,6 +13,7 @@
 #include "parallel.h"
 #include "pd_device.h"
 #include "popdel_hip.h"
+#include "rg0_x87.h"
 
 namespace pd {
 
@@ -28,7 +29,7 @@ void launchCopyBytes(const void * src, void * dst, size_t n, hipStream_t st);
 void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
                    hipStream_t st);
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
-                   bool anyGenericTile, unsigned * pinnedWord, hipStream_t st);
+                   Rg0Provider & rg0, bool anyGenericTile, hipStream_t st);
 void buildLogTables(const double * hist, double4 * tab, double2 * tab2, size_t n, RgConst * rg, unsigned nRg, hipStream_t st);
 void launchGatherOut(const Stage2Buffers & b, const unsigned * emitCells, unsigned nEmit, unsigned nSamples, uint32_t * pl,
                      uint32_t * lad, uint32_t * dad, uint32_t * fl, hipStream_t st);
@@ -141,6 +142,7 @@ struct StagedSegment
     uint64_t nChunks = 0, nPairs = 0, nActivePairs = 0;
     DevBuf<pd::PairDO> pairs;
     DevBuf<uint32_t> start;
+    DevBuf<uint32_t> inst;
     DevBuf<uint64_t> rgBase;
     DevBuf<uint32_t> winStart;
     DevBuf<uint2> pairsPk;
@@ -151,6 +153,7 @@ struct StagedSegment
     uint32_t nRealRg = 0;
     bool hasScanGeneric = false;
     bool ownedBySubmit = false;
+    pdh::Rg0Service::Segment rg0;           // host copy of read group 0's pair instances (context that owns read group 0)
 };
 
 struct Run
@@ -176,7 +179,6 @@ struct pd_ctx
     DevBuf<double> dHist;
     DevBuf<double4> dTab;
     DevBuf<double2> dTab2;
-    DevBuf<unsigned> dIterFlags;
     DevBuf<uint32_t> dSampleRg;
     DevBuf<uint32_t> dScanRg;
     // tiles with multi-read-group samples (pd::MultiTiles): static tables
@@ -197,7 +199,7 @@ struct pd_ctx
     std::vector<std::unique_ptr<StagedSegment>> spare;      // released segments: their HBM buffers are reused (no hipMalloc per segment)
     // host-side scratch of pd_segment_stage(), kept between calls
     PinnedBuf<pd::PairDO> hPairs;
-    PinnedBuf<uint32_t> hStart, hWinStart, hEndCount;
+    PinnedBuf<uint32_t> hStart, hInst, hWinStart, hEndCount;
     std::vector<uint64_t> hRgBase;
     PinnedBuf<uint2> hPairsPk;
     std::vector<uint8_t> hRgPacked, hScanGeneric;
@@ -205,7 +207,12 @@ struct pd_ctx
     // counters): pageable memory costs every one of these round trips an extra bounce copy
     PinnedBuf<int> hWinFlag, hFlagged, hCandLen, hCandCount;
     PinnedBuf<pd::CellState> hCells;
-    PinnedBuf<unsigned> hCounters, hEmit, hIterFlag;
+    PinnedBuf<unsigned> hCounters, hEmit;
+    // read group 0's weights of the reference-shift update: evaluated on the host FPU per cell and EM iteration
+    pdh::Rg0Service rg0svc;
+    PinnedBuf<pd::Rg0Query> hRg0Q;
+    PinnedBuf<pd::Rg0Weights> hRg0W;
+    DevBuf<pd::Rg0Query> dRg0Q;
     uint64_t nextHandle = 1, nextTicket = 1;
     std::map<uint64_t, Run> runs;
 
@@ -336,6 +343,66 @@ struct CtxExchange : pd::Exchange
     }
 };
 
+// Read group 0's weights for the next reference-shift update of every cell (x87soft.h, host/rg0_x87.h). The context that
+// owns read group 0 evaluates them on its host FPU; a sharded cohort all-gathers them (the record of rank 0 is the one
+// the kernels read). Also the loop control of the EM: false when no cell iterates any more (all contexts of a sharded
+// cohort hold identical cell states, so they agree).
+struct CtxRg0 : pd::Rg0Provider
+{
+    pd_ctx & c;
+    const StagedSegment & s;
+    CtxExchange & x;
+    CtxRg0(pd_ctx & ctx, const StagedSegment & seg, CtxExchange & xch) : c(ctx), s(seg), x(xch) {}
+    bool provide(const pd::Stage2Buffers & b, hipStream_t st) override
+    {
+        const unsigned nb = b.nCells;
+        c.hRg0Q.resize(nb);
+        PD_HIP(hipMemcpyAsync(c.hRg0Q.data(), b.rg0q, nb * sizeof(pd::Rg0Query), hipMemcpyDeviceToHost, st));
+        PD_HIP(hipStreamSynchronize(st));
+        bool any = false;
+        for (unsigned i = 0; i < nb && !any; ++i)
+            any = c.hRg0Q[i].active != 0;
+        if (!any)
+            return false;
+        if (c.rank == 0)
+        {
+            c.hRg0W.resize(nb);
+            c.rg0svc.weights(s.rg0, c.hRg0Q.data(), nb, c.hRg0W.data());
+            if (const char * tp = getenv("POPDEL_TRACE_POS"))        // debugging aid (results unchanged): EM trace of one window
+                for (unsigned i = 0; i < nb; ++i)
+                {
+                    const pd::Rg0Query & q = c.hRg0Q[i];
+                    if (!q.active || s.firstPos + (uint32_t)q.window * s.shift != (uint32_t)atol(tp))
+                        continue;
+                    std::vector<int> sh(c.nRg);
+                    PD_HIP(hipMemcpy(sh.data(), b.shifts + static_cast<size_t>(i) * c.nRg, c.nRg * sizeof(int), hipMemcpyDeviceToHost));
+                    long sum = 0, nz = 0;
+                    unsigned long hash = 1469598103934665603ul;
+                    for (int v : sh)
+                    {
+                        sum += v;
+                        nz += v != 0;
+                        hash = (hash ^ (unsigned)v) * 1099511628211ul;
+                    }
+                    fprintf(stderr, "[hip trace] cell %u before update: shifts sum %ld nonzero %ld hash %016lx\n", i, sum, nz, hash);
+                    fprintf(stderr, "[hip trace]   update: len %u shift0 %d gt %.17g %.17g %.17g expA0 %.17g expA1 %.17g%s\n", q.len, q.shift0,
+                            q.gt[0], q.gt[1], q.gt[2], c.hRg0W[i].expA0d, c.hRg0W[i].expA1d, c.hRg0W[i].invalid ? " INVALID" : "");
+                    if (getenv("POPDEL_TRACE_SHIFTS"))
+                    {
+                        fprintf(stderr, "[hip trace]   shifts:");
+                        for (int v : sh)
+                            fprintf(stderr, " %d", v);
+                        fprintf(stderr, "\n");
+                    }
+                }
+            PD_HIP(hipMemcpyAsync(const_cast<pd::Rg0Weights *>(b.rg0w), c.hRg0W.data(), nb * sizeof(pd::Rg0Weights),
+                                  hipMemcpyHostToDevice, st));
+        }
+        x.allGather(const_cast<pd::Rg0Weights *>(b.rg0w), nb * sizeof(pd::Rg0Weights));
+        return true;
+    }
+};
+
 inline size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 template <typename T>
@@ -353,7 +420,7 @@ T * mallocCopy(const std::vector<T> & v)
 // of the read groups [lo, hi) are in place: the caller uploads slab by slab while the next slab is being built.
 template <typename Sized, typename SlabDone>
 void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, PinnedBuf<pd::PairDO> & pairs,
-                 PinnedBuf<uint32_t> & start, std::vector<uint64_t> & rgBase, PinnedBuf<uint32_t> & winStart,
+                 PinnedBuf<uint32_t> & start, PinnedBuf<uint32_t> & inst, std::vector<uint64_t> & rgBase, PinnedBuf<uint32_t> & winStart,
                  PinnedBuf<uint2> & pairsPk, PinnedBuf<uint32_t> & endCount, std::vector<uint8_t> & rgPacked,
                  std::vector<uint8_t> & scanGeneric, Sized sized, SlabDone slabDone)
 {
@@ -466,6 +533,7 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
     }
     pairs.resize(out.nChunks);
     start.resize(out.nChunks);
+    inst.resize(out.nChunks);
     pairsPk.resize(totalChunks);
     endCount.assignZero(static_cast<size_t>(nEnt) * (W + 1));
     rgPacked.assign(nEnt, 0);
@@ -502,6 +570,7 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
                     {
                         pairs[base + slot] = pd::PairDO{dv, chunkOff};
                         start[base + slot] = seg.pair_start[i];
+                        inst[base + slot] = static_cast<uint32_t>(i - lo);
                     }
                     pairsPk[base + slot] = make_uint2(d16 | (d16 << 16), (chunkOff & 0xffffu) | (chunkOff << 16));
                     ++ec[chunkOff];
@@ -539,6 +608,7 @@ pd::SegmentView viewOf(const StagedSegment & s)
     pd::SegmentView v;
     v.pairs = s.pairs.p;
     v.start = s.start.p;
+    v.inst = s.inst.p;
     v.rgBase = s.rgBase.p;
     v.winStart = s.winStart.p;
     v.pairsPk = s.pairsPk.p;
@@ -594,6 +664,7 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
         c->nRg = n_readgroups;
         c->nSamples = n_samples;
         c->sampleRg.assign(sample_rg_offsets, sample_rg_offsets + n_samples + 1);
+        c->rg0svc.setReadGroup(rgs[0]);         // used by the context that owns read group 0 of the cohort (rank 0)
         PD_HIP(hipStreamCreate(&c->stream));
         PD_HIP(hipStreamCreate(&c->copyStream));
         PD_HIP(hipEventCreateWithFlags(&c->resultsPacked, hipEventDisableTiming));
@@ -681,7 +752,6 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
         c->dSampleRg.upload(c->sampleRg, c->stream);
         c->dTab.alloc(pool.size());
         c->dTab2.alloc(pool.size());
-        c->dIterFlags.alloc(pd::kMaxIterationsCap + 1);
         pd::buildLogTables(c->dHist.p, c->dTab.p, c->dTab2.p, pool.size(), c->dRg.p, n_readgroups, c->stream);
         PD_HIP(hipGetLastError());
         PD_HIP(hipStreamSynchronize(c->stream));
@@ -710,6 +780,14 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
     catch (const HipError & e)
     {
         return fail(nullptr, "pd_ctx_create: " + e.what);
+    }
+    catch (const std::exception & e)
+    {
+        return fail(nullptr, std::string("pd_ctx_create: ") + e.what());
+    }
+    catch (...)
+    {
+        return fail(nullptr, "pd_ctx_create: unknown exception");
     }
     *out = c.release();
     return 0;
@@ -769,6 +847,14 @@ int pd_ctx_set_shard(pd_ctx * c, const pd_shard * sh)
     {
         return fail(c, "pd_ctx_set_shard: " + e.what);
     }
+    catch (const std::exception & e)
+    {
+        return fail(c, std::string("pd_ctx_set_shard: ") + e.what());
+    }
+    catch (...)
+    {
+        return fail(c, "pd_ctx_set_shard: unknown exception");
+    }
     return 0;
 }
 
@@ -813,7 +899,7 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
         s->nWindows = seg->n_windows;
         s->shift = seg->window_shift;
         PinnedBuf<pd::PairDO> & pairs = c->hPairs;
-        PinnedBuf<uint32_t> &start = c->hStart, &winStart = c->hWinStart, &endCount = c->hEndCount;
+        PinnedBuf<uint32_t> &start = c->hStart, &inst = c->hInst, &winStart = c->hWinStart, &endCount = c->hEndCount;
         std::vector<uint64_t> & rgBase = c->hRgBase;
         PinnedBuf<uint2> & pairsPk = c->hPairsPk;
         std::vector<uint8_t> & rgPacked = c->hRgPacked;
@@ -825,6 +911,7 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
         auto sized = [&]() {
             s->pairs.ensure(pairs.size());
             s->start.ensure(start.size());
+            s->inst.ensure(inst.size());
             s->pairsPk.ensure(pairsPk.size());
             s->endCount.ensure(endCount.size());
             s->rgBase.upload(rgBase, cs);
@@ -838,13 +925,16 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
                 {
                     PD_HIP(hipMemcpyAsync(s->pairs.p + a, pairs.data() + a, (b - a) * sizeof(pd::PairDO), hipMemcpyHostToDevice, cs));
                     PD_HIP(hipMemcpyAsync(s->start.p + a, start.data() + a, (b - a) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+                    PD_HIP(hipMemcpyAsync(s->inst.p + a, inst.data() + a, (b - a) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
                 }
                 PD_HIP(hipMemcpyAsync(s->pairsPk.p + a, pairsPk.data() + a, (b - a) * sizeof(uint2), hipMemcpyHostToDevice, cs));
             }
             const size_t e0 = lo * (static_cast<size_t>(W) + 1), e1 = hi * (static_cast<size_t>(W) + 1);
             PD_HIP(hipMemcpyAsync(s->endCount.p + e0, endCount.data() + e0, (e1 - e0) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
         };
-        buildChunks(*c, *seg, *s, pairs, start, rgBase, winStart, pairsPk, endCount, rgPacked, c->hScanGeneric, sized, slabDone);
+        buildChunks(*c, *seg, *s, pairs, start, inst, rgBase, winStart, pairsPk, endCount, rgPacked, c->hScanGeneric, sized, slabDone);
+        if (c->rank == 0)
+            pdh::Rg0Service::copySegment(s->rg0, *seg);
         s->rgPacked.upload(rgPacked, cs);
         s->hasScanGeneric = !c->hScanGeneric.empty();
         if (s->hasScanGeneric)
@@ -858,6 +948,14 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
     catch (const HipError & e)
     {
         return fail(c, "pd_segment_stage: " + e.what);
+    }
+    catch (const std::exception & e)
+    {
+        return fail(c, std::string("pd_segment_stage: ") + e.what());
+    }
+    catch (...)
+    {
+        return fail(c, "pd_segment_stage: unknown exception");
     }
     return 0;
 }
@@ -933,6 +1031,14 @@ int pd_segment_run(pd_ctx * c, uint64_t handle, uint64_t * ticket)
     {
         return fail(c, "pd_segment_run: " + e.what);
     }
+    catch (const std::exception & e)
+    {
+        return fail(c, std::string("pd_segment_run: ") + e.what());
+    }
+    catch (...)
+    {
+        return fail(c, "pd_segment_run: unknown exception");
+    }
     return 0;
 }
 
@@ -979,9 +1085,14 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
     c->runs.erase(rit);
     auto sit = c->staged.find(run.handle);
     if (sit == c->staged.end())
+    {
+        (void)hipEventDestroy(run.s1Begin);
+        (void)hipEventDestroy(run.s1End);
         return fail(c, "pd_segment_collect: segment was unstaged before collect");
+    }
     StagedSegment & s = *sit->second;
     hipEvent_t s2Begin = nullptr, s2End = nullptr;
+    PinnedBlock pinned;
     int rc = 0;
     try
     {
@@ -1077,16 +1188,16 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         // (from the samples per context of the partition, not from this context's own count: all contexts of a sharded
         // cohort must cut the cell list at the same places, the exchanges run per batch)
         const size_t bytesPerCell = static_cast<size_t>(sper) * (2 * pd::kDenseCap * 2 + 24 + 52 + 2 + 24) + 4096;
-        const unsigned batchCells = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(nCells ? nCells : 1, budget / bytesPerCell)));
+        // (the cell index is a grid's y dimension: at most 65,535 cells per batch)
+        const unsigned batchCells = static_cast<unsigned>(
+            std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nCells ? nCells : 1, 65535), budget / bytesPerCell)));
         const unsigned nBatches = nCells ? (nCells + batchCells - 1) / batchCells : 0;
         pd::Stage2Buffers b;
         std::memset(&b, 0, sizeof(b));
         c->hCells.resize(std::max<size_t>(1, cells.size()));
         if (!cells.empty())
             std::memcpy(c->hCells.data(), cells.data(), cells.size() * sizeof(pd::CellState));
-        c->hIterFlag.resize(4);
         // per-sample results of the emitted cells: device buffer of the current batch, host block of the whole segment
-        PinnedBlock pinned;
         uint32_t *hPl = nullptr, *hLad = nullptr, *hDad = nullptr, *hFl = nullptr;
         std::vector<uint32_t> accPl, accLad, accDad, accFl;       // only used when there is more than one batch
         uint32_t nLastBatch = 0;                                  // emitted cells of the last batch (still on the device)
@@ -1099,23 +1210,26 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             b.rank = c->rank;
             b.world = world;
             b.nSamplesGlobal = SG;
-            // exchange areas: integer counts | per-tile sums + RG-0 record | digit histograms
-            b.xchChunk = (static_cast<size_t>(b.tilesPerRank) + 1) * nb * 4;
+            // exchange areas: integer counts | per-tile sums | read group 0's weights | digit histograms
+            b.xchChunk = static_cast<size_t>(b.tilesPerRank) * nb * 4;
             const size_t countersBytes = alignUp(static_cast<size_t>(world) * nb * 4 * sizeof(unsigned), 256);
             const size_t xchBytes = alignUp(static_cast<size_t>(world) * b.xchChunk * sizeof(double), 256);
+            const size_t rg0Bytes = alignUp(static_cast<size_t>(world) * nb * sizeof(pd::Rg0Weights), 256);
             const size_t histBytes = static_cast<size_t>(world) * nb * 2 * 256 * sizeof(unsigned);
-            uint8_t * area = reserveArena(*c, countersBytes + xchBytes + histBytes);
-            PD_HIP(hipMemsetAsync(area, 0, countersBytes + xchBytes, c->stream));
+            uint8_t * area = reserveArena(*c, countersBytes + xchBytes + rg0Bytes + histBytes);
+            PD_HIP(hipMemsetAsync(area, 0, countersBytes + xchBytes + rg0Bytes, c->stream));
             b.counters = reinterpret_cast<unsigned *>(area);
             b.xch = reinterpret_cast<double *>(area + countersBytes);
-            b.selHist = reinterpret_cast<unsigned *>(area + countersBytes + xchBytes);
+            b.rg0w = reinterpret_cast<const pd::Rg0Weights *>(area + countersBytes + xchBytes);
+            b.selHist = reinterpret_cast<unsigned *>(area + countersBytes + xchBytes + rg0Bytes);
+            c->dRg0Q.ensure(nb);
+            b.rg0q = c->dRg0Q.p;
+            c->rg0svc.beginBatch(nb);
             c->dCells.ensure(nb);
             PD_HIP(hipMemcpyAsync(c->dCells.p, c->hCells.data() + lo, nb * sizeof(pd::CellState), hipMemcpyHostToDevice, c->stream));
             c->dDl.ensure(static_cast<size_t>(nb) * S * 3);
             c->dShifts.ensure(static_cast<size_t>(nb) * c->nRg);
             b.ownTiles = (S + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock;
-            b.forceGeneric = getenv("POPDEL_HIP_FORCE_GENERIC") ? 1 : 0;
-            b.snapShifts = getenv("POPDEL_SNAP_SHIFTS") ? 1 : 0;
             const size_t waveTiles = static_cast<size_t>(nb) * b.ownTiles * 4;
             c->dCellDev.ensure(waveTiles * pd::kDenseCap * 64);
             c->dCellStart.ensure(waveTiles * pd::kDenseCap * 64);
@@ -1153,7 +1267,6 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             b.cells = c->dCells.p;
             b.dl = c->dDl.p;
             b.shifts = c->dShifts.p;
-            b.iterFlags = c->dIterFlags.p;
             b.pl = c->dPl.p;
             b.lad = c->dLad.p;
             b.dad = c->dDad.p;
@@ -1185,23 +1298,12 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             c->dSuppLast.ensure(pool + 1);
             b.suppFirst = c->dSuppFirst.p;
             b.suppLast = c->dSuppLast.p;
-            pd::runStage2Main(view, c->cohort, b, c->dFlags.p, xch, genericTiles != 0, c->hIterFlag.data(), c->stream);
+            CtxRg0 rg0(*c, s, xch);
+            pd::runStage2Main(view, c->cohort, b, c->dFlags.p, xch, rg0, genericTiles != 0, c->stream);
             PD_HIP(hipGetLastError());
             PD_HIP(hipMemcpyAsync(c->hCells.data() + lo, c->dCells.p, nb * sizeof(pd::CellState), hipMemcpyDeviceToHost, c->stream));
             PD_HIP(hipStreamSynchronize(c->stream));
             std::memcpy(cells.data() + lo, c->hCells.data() + lo, nb * sizeof(pd::CellState));
-            if (const char * tp = getenv("POPDEL_TRACE_POS"))                 // debugging aid: EM trace of one window
-                for (unsigned i = 0; i < nb; ++i)
-                {
-                    const pd::CellState & cs = cells[lo + i];
-                    if (s.firstPos + (uint32_t)cs.window * s.shift != (uint32_t)atol(tp))
-                        continue;
-                    for (int v = 0; v < cs.nVisited; ++v)
-                        fprintf(stderr, "[hip trace] pos %s init %d visited %d len %d freq %.17g\n", tp, cs.initLen, v,
-                                cs.visitedLen[v], cs.visitedFreq[v]);
-                    fprintf(stderr, "[hip trace] pos %s init %d end: it %d len %u freq %.17g phase %d\n", tp, cs.initLen,
-                            cs.iterations, cs.len, cs.freq, cs.phase);
-                }
             std::vector<unsigned> emitLocal;
             for (unsigned i = 0; i < nb; ++i)
                 if (cells[lo + i].phase == pd::kCellEmit)
@@ -1321,6 +1423,19 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
     {
         rc = fail(c, "pd_segment_collect: " + e.what);
     }
+    catch (const std::exception & e)
+    {
+        rc = fail(c, std::string("pd_segment_collect: ") + e.what());
+    }
+    catch (...)
+    {
+        rc = fail(c, "pd_segment_collect: unknown exception");
+    }
+    if (rc != 0)
+    {
+        givePinned(pinned);                 // nobody owns the result block of a failed collect
+        *out = nullptr;
+    }
     if (s2Begin)
         (void)hipEventDestroy(s2Begin);
     if (s2End)
@@ -1388,6 +1503,14 @@ int pd_stage1_last(pd_ctx * c, pd_stage1_view * out)
     catch (const HipError & e)
     {
         return fail(c, "pd_stage1_last: " + e.what);
+    }
+    catch (const std::exception & e)
+    {
+        return fail(c, std::string("pd_stage1_last: ") + e.what());
+    }
+    catch (...)
+    {
+        return fail(c, "pd_stage1_last: unknown exception");
     }
     return 0;
 }
