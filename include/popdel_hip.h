@@ -26,11 +26,6 @@
  *   - at most 32 candidate deletion lengths per window (pd_segment_collect fails beyond; the
  *     reference's clustering yields one per ~50 bp of Q3 spread, a handful at most in practice);
  *   - segments of at most 2^31 windows and 2^32 - 1 pair chunks per read group.
- *
- * Where floating point decides an integer: the reference evaluates the per-read-group weights of
- * its reference-shift update in x87 `long double` (genotype_deletion_popdel_call.h:421-445).
- * Those two numbers per (window, candidate) and EM iteration are computed on the HOST FPU of the
- * calling process (x86-64 `long double`, glibc logl/expl), everything else on the GPU.
  */
 #ifndef POPDEL_HIP_H_
 #define POPDEL_HIP_H_
@@ -82,9 +77,7 @@ typedef struct pd_config
  * of ChromosomeProfile::activeReads[rg] for the windows with index on <= w < off appears as one
  * "pair instance" {dev, start, on, off}. The host side derives on/off by running the
  * reference's window state machine, so the loader's segment-border behaviour stays host-side.
- * Instances of one read group are stored contiguously, ordered by non-decreasing `on`. Their order
- * is also the order in which floating-point sums over the pairs of a (window, sample) are formed
- * (the reference walks its active set there): results are bit-reproducible for a given order. */
+ * Instances of one read group are stored contiguously, ordered by non-decreasing `on`. */
 typedef struct pd_segment
 {
     uint32_t        first_window_pos;  /* ChromosomeProfile::currentPos of window 0          */
@@ -219,8 +212,7 @@ int pd_segment_collect(pd_ctx *ctx, uint64_t ticket, pd_calls **out);
 
 void pd_calls_free(pd_calls *calls);
 
-/* Stage-1 values of the most recently collected segment; valid until the next submit/run (also one issued before
- * that collect). */
+/* Stage-1 values of the most recently collected segment; valid until the next submit/run issued AFTER that collect. */
 int pd_stage1_last(pd_ctx *ctx, pd_stage1_view *out);
 
 /* Text of the last error on this context (or of the last failed pd_ctx_create if ctx == NULL). */

@@ -449,6 +449,8 @@ DTriple genotypePriors(double f, bool somatic)
     return g;
 }
 
+static bool g_snapShifts = false;    // POPDEL_SNAP_SHIFTS, read per segment
+static int g_perturbFreq = 0;        // POPDEL_ORACLE_PERTURB_FREQ, read per segment
 static bool g_traceKnife = false;   // set while the window named by POPDEL_TRACE_POS is processed
 
 // genotype_deletion_popdel_call.h:388-462. The per-read-group weights are always taken from rgWise[0].
@@ -474,9 +476,6 @@ unsigned updateDeletionLength(const pd_ctx & c, const std::vector<LTriple> & dat
             long double a = std::log(aSumRg);
             long double a0Rg = l + g - a;
             long double a1Rg = logl(rgDl.i2) + std::log(gt.i2) - std::log(aSumRg);
-            if (g_traceKnife && rg == 0)
-                fprintf(stderr, "[oracle trace]   update: len %d shift0 %d gt %.17g %.17g %.17g expA0 %.17g expA1 %.17g\n", deletionLength,
-                        referenceShifts[0], gt.i1, gt.i2, gt.i3, (double)expl(a0Rg), (double)expl(a1Rg));
             const ReadGroup & hist = c.rgs[rg];
             for (const ActivePair & p : c.active[rg])
             {
@@ -489,7 +488,15 @@ unsigned updateDeletionLength(const pd_ctx & c, const std::vector<LTriple> & dat
                 weightedSumDel += probDel * p.dev;
                 weightedSumRef += probRef * p.dev;
             }
-            const double quotient = weightedSumRef / sumRef;
+            double quotient = weightedSumRef / sumRef;
+            if (g_snapShifts)
+            {
+                // Test knob POPDEL_SNAP_SHIFTS (the test build libpopdel_hip_snap.so does the same): a quotient within 1e-9 of an integer is
+                // moved onto it, which takes the last-bit dependence out of the truncation below.
+                const double r = std::rint(quotient);
+                if (std::fabs(quotient - r) <= 1e-9 * std::max(1.0, std::fabs(r)))
+                    quotient = r;
+            }
             referenceShifts[rg] = toIntX86(quotient);
             if (g_traceKnife)
             {
@@ -599,28 +606,29 @@ void genotypeWindow(pd_ctx & c, int32_t * q3Out, uint8_t * flagOut)
             for (unsigned i = 0; i < S; ++i)
                 dataL[i] = dataLikelihoods(c, rgWise, i, len, referenceShifts);
             freq = updateAlleleFrequency(dataL, gt);
+            if (g_perturbFreq != 0)
+            {
+                // Test knob POPDEL_ORACLE_PERTURB_FREQ (tests/test_oracle_golden.py): the allele frequency -- a sum over all samples
+                // of terms derived from x87 exp/log results -- moved by ONE unit in the last place (1: up, 2: down, 3:
+                // pseudo-random direction). Shows which outputs of the reference's algorithm hang off the last bit of that sum.
+                static unsigned lcg = 12345u;
+                lcg = lcg * 1664525u + 1013904223u;
+                const bool up = g_perturbFreq == 1 || (g_perturbFreq == 3 && ((lcg >> 8) & 1u));
+                freq = std::nextafter(freq, up ? 1.0 : 0.0);
+            }
             if (freq == 0)
                 break;
             gt = genotypePriors(freq, c.cfg.somatic != 0);
             if (tracePos && *tracePos && static_cast<uint32_t>(atol(tracePos)) == c.currentPos)
             {
                 long shiftSum = 0, shiftNonZero = 0;
-                unsigned long hash = 1469598103934665603ul;
                 for (int sft : referenceShifts)
                 {
                     shiftSum += sft;
                     shiftNonZero += sft != 0;
-                    hash = (hash ^ (unsigned)sft) * 1099511628211ul;
                 }
-                fprintf(stderr, "[oracle trace] pos %u init %d it %u len %u freq %.17g shifts sum %ld nonzero %ld hash %016lx\n", c.currentPos,
-                        initLen, iterations, len, freq, shiftSum, shiftNonZero, hash);
-                if (getenv("POPDEL_TRACE_SHIFTS"))
-                {
-                    fprintf(stderr, "[oracle trace]   shifts:");
-                    for (int sft : referenceShifts)
-                        fprintf(stderr, " %d", sft);
-                    fprintf(stderr, "\n");
-                }
+                fprintf(stderr, "[oracle trace] pos %u init %d it %u len %u freq %.17g shifts sum %ld nonzero %ld\n", c.currentPos,
+                        initLen, iterations, len, freq, shiftSum, shiftNonZero);
             }
             auto v = visited.find(static_cast<int>(len));
             if (v != visited.end() && std::fabs(v->second - freq) <= 0.0001)
@@ -768,6 +776,8 @@ static int runSegment(pd_ctx * c, const pd_segment * seg, uint64_t * ticket)
         c->active[rg].clear();
     }
     // Active lists are kept as instance indices so that pairs can be retired by their `off` window.
+    g_snapShifts = getenv("POPDEL_SNAP_SHIFTS") != nullptr;
+    g_perturbFreq = getenv("POPDEL_ORACLE_PERTURB_FREQ") ? atoi(getenv("POPDEL_ORACLE_PERTURB_FREQ")) : 0;
     std::vector<std::vector<uint64_t>> activeIdx(c->rgs.size());
     for (uint32_t w = 0; w < seg->n_windows; ++w)
     {

@@ -13,7 +13,6 @@
 #include "parallel.h"
 #include "pd_device.h"
 #include "popdel_hip.h"
-#include "rg0_x87.h"
 
 namespace pd {
 
@@ -29,7 +28,7 @@ void launchCopyBytes(const void * src, void * dst, size_t n, hipStream_t st);
 void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
                    hipStream_t st);
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
-                   Rg0Provider & rg0, bool anyGenericTile, hipStream_t st);
+                   bool anyGenericTile, unsigned * pinnedWord, hipStream_t st);
 void buildLogTables(const double * hist, double4 * tab, double2 * tab2, size_t n, RgConst * rg, unsigned nRg, hipStream_t st);
 void launchGatherOut(const Stage2Buffers & b, const unsigned * emitCells, unsigned nEmit, unsigned nSamples, uint32_t * pl,
                      uint32_t * lad, uint32_t * dad, uint32_t * fl, hipStream_t st);
@@ -142,7 +141,6 @@ struct StagedSegment
     uint64_t nChunks = 0, nPairs = 0, nActivePairs = 0;
     DevBuf<pd::PairDO> pairs;
     DevBuf<uint32_t> start;
-    DevBuf<uint32_t> inst;
     DevBuf<uint64_t> rgBase;
     DevBuf<uint32_t> winStart;
     DevBuf<uint2> pairsPk;
@@ -153,14 +151,30 @@ struct StagedSegment
     uint32_t nRealRg = 0;
     bool hasScanGeneric = false;
     bool ownedBySubmit = false;
-    pdh::Rg0Service::Segment rg0;           // host copy of read group 0's pair instances (context that owns read group 0)
 };
 
 struct Run
 {
     uint64_t handle = 0;
-    hipEvent_t s1Begin = nullptr, s1End = nullptr;
+    hipEvent_t s1Begin = nullptr, s1End = nullptr;      // around the scan kernel (timing)
+    int set = 0;                                        // which of the two stage-1 output sets the scan writes
     bool launched = false;          // false: accepted while the previous ticket was still open, scan not enqueued yet
+};
+
+// Stage-1 outputs of one run. Two sets, so that the scan of the waiting ticket can be enqueued while the open one's
+// values are still wanted (pd_stage1_last). (Round 2 measured the scan on its OWN stream, started when the ticket is
+// issued, concurrently with the open segment's stage 2: the scan's one big launch fills every CU for its 1.2 ms and the
+// ~60 short stage-2 kernels crawl until it is through -- 2.94 ms per pass against 2.59 for the order used here, with or
+// without stream priorities.)
+struct Stage1Out
+{
+    DevBuf<int32_t> q3;
+    DevBuf<uint8_t> flags;
+    DevBuf<int> winFlag;
+    DevBuf<uint8_t> tileTodo;
+    DevBuf<unsigned> todoList;      // [0] = number of entries, then the 256-window tiles left to the fallback kernel
+    DevBuf<unsigned> bigList;       // [0] = number of entries, then the 512-window blocks left to the 128-candidate kernel
+    uint32_t windows = 0;
 };
 
 }  // namespace
@@ -172,13 +186,14 @@ struct pd_ctx
     uint32_t nRg = 0, nSamples = 0;
     std::vector<uint32_t> sampleRg;
     std::string error;
-    hipStream_t stream = nullptr;
-    hipStream_t copyStream = nullptr;   // result D2H, so that the next segment's scan can run underneath it
+    hipStream_t stream = nullptr;       // all kernels
+    hipStream_t copyStream = nullptr;   // segment uploads and the result D2H, so that the next segment's scan can run underneath it
     hipEvent_t resultsPacked = nullptr;
     DevBuf<pd::RgConst> dRg;
     DevBuf<double> dHist;
     DevBuf<double4> dTab;
     DevBuf<double2> dTab2;
+    DevBuf<unsigned> dIterFlags;
     DevBuf<uint32_t> dSampleRg;
     DevBuf<uint32_t> dScanRg;
     // tiles with multi-read-group samples (pd::MultiTiles): static tables
@@ -199,7 +214,7 @@ struct pd_ctx
     std::vector<std::unique_ptr<StagedSegment>> spare;      // released segments: their HBM buffers are reused (no hipMalloc per segment)
     // host-side scratch of pd_segment_stage(), kept between calls
     PinnedBuf<pd::PairDO> hPairs;
-    PinnedBuf<uint32_t> hStart, hInst, hWinStart, hEndCount;
+    PinnedBuf<uint32_t> hStart, hWinStart, hEndCount;
     std::vector<uint64_t> hRgBase;
     PinnedBuf<uint2> hPairsPk;
     std::vector<uint8_t> hRgPacked, hScanGeneric;
@@ -207,23 +222,12 @@ struct pd_ctx
     // counters): pageable memory costs every one of these round trips an extra bounce copy
     PinnedBuf<int> hWinFlag, hFlagged, hCandLen, hCandCount;
     PinnedBuf<pd::CellState> hCells;
-    PinnedBuf<unsigned> hCounters, hEmit;
-    // read group 0's weights of the reference-shift update: evaluated on the host FPU per cell and EM iteration
-    pdh::Rg0Service rg0svc;
-    PinnedBuf<pd::Rg0Query> hRg0Q;
-    PinnedBuf<pd::Rg0Weights> hRg0W;
-    DevBuf<pd::Rg0Query> dRg0Q;
+    PinnedBuf<unsigned> hCounters, hEmit, hIterFlag;
     uint64_t nextHandle = 1, nextTicket = 1;
     std::map<uint64_t, Run> runs;
 
-    // stage-1 outputs of the most recent run
-    DevBuf<int32_t> dQ3;
-    DevBuf<uint8_t> dFlags;
-    DevBuf<int> dWinFlag;
-    DevBuf<uint8_t> dTileTodo;
-    DevBuf<unsigned> dTodoList;     // [0] = number of entries, then the 256-window tiles left to the fallback kernel
-    DevBuf<unsigned> dBigList;      // [0] = number of entries, then the 512-window blocks left to the 128-candidate kernel
-    uint32_t lastWindows = 0;
+    Stage1Out s1[2];
+    int lastSet = 0;                // set of the most recently collected run (pd_stage1_last)
     std::vector<int32_t> hQ3View;
     std::vector<uint8_t> hFlagsView;
     // stage-2 scratch
@@ -343,66 +347,6 @@ struct CtxExchange : pd::Exchange
     }
 };
 
-// Read group 0's weights for the next reference-shift update of every cell (x87soft.h, host/rg0_x87.h). The context that
-// owns read group 0 evaluates them on its host FPU; a sharded cohort all-gathers them (the record of rank 0 is the one
-// the kernels read). Also the loop control of the EM: false when no cell iterates any more (all contexts of a sharded
-// cohort hold identical cell states, so they agree).
-struct CtxRg0 : pd::Rg0Provider
-{
-    pd_ctx & c;
-    const StagedSegment & s;
-    CtxExchange & x;
-    CtxRg0(pd_ctx & ctx, const StagedSegment & seg, CtxExchange & xch) : c(ctx), s(seg), x(xch) {}
-    bool provide(const pd::Stage2Buffers & b, hipStream_t st) override
-    {
-        const unsigned nb = b.nCells;
-        c.hRg0Q.resize(nb);
-        PD_HIP(hipMemcpyAsync(c.hRg0Q.data(), b.rg0q, nb * sizeof(pd::Rg0Query), hipMemcpyDeviceToHost, st));
-        PD_HIP(hipStreamSynchronize(st));
-        bool any = false;
-        for (unsigned i = 0; i < nb && !any; ++i)
-            any = c.hRg0Q[i].active != 0;
-        if (!any)
-            return false;
-        if (c.rank == 0)
-        {
-            c.hRg0W.resize(nb);
-            c.rg0svc.weights(s.rg0, c.hRg0Q.data(), nb, c.hRg0W.data());
-            if (const char * tp = getenv("POPDEL_TRACE_POS"))        // debugging aid (results unchanged): EM trace of one window
-                for (unsigned i = 0; i < nb; ++i)
-                {
-                    const pd::Rg0Query & q = c.hRg0Q[i];
-                    if (!q.active || s.firstPos + (uint32_t)q.window * s.shift != (uint32_t)atol(tp))
-                        continue;
-                    std::vector<int> sh(c.nRg);
-                    PD_HIP(hipMemcpy(sh.data(), b.shifts + static_cast<size_t>(i) * c.nRg, c.nRg * sizeof(int), hipMemcpyDeviceToHost));
-                    long sum = 0, nz = 0;
-                    unsigned long hash = 1469598103934665603ul;
-                    for (int v : sh)
-                    {
-                        sum += v;
-                        nz += v != 0;
-                        hash = (hash ^ (unsigned)v) * 1099511628211ul;
-                    }
-                    fprintf(stderr, "[hip trace] cell %u before update: shifts sum %ld nonzero %ld hash %016lx\n", i, sum, nz, hash);
-                    fprintf(stderr, "[hip trace]   update: len %u shift0 %d gt %.17g %.17g %.17g expA0 %.17g expA1 %.17g%s\n", q.len, q.shift0,
-                            q.gt[0], q.gt[1], q.gt[2], c.hRg0W[i].expA0d, c.hRg0W[i].expA1d, c.hRg0W[i].invalid ? " INVALID" : "");
-                    if (getenv("POPDEL_TRACE_SHIFTS"))
-                    {
-                        fprintf(stderr, "[hip trace]   shifts:");
-                        for (int v : sh)
-                            fprintf(stderr, " %d", v);
-                        fprintf(stderr, "\n");
-                    }
-                }
-            PD_HIP(hipMemcpyAsync(const_cast<pd::Rg0Weights *>(b.rg0w), c.hRg0W.data(), nb * sizeof(pd::Rg0Weights),
-                                  hipMemcpyHostToDevice, st));
-        }
-        x.allGather(const_cast<pd::Rg0Weights *>(b.rg0w), nb * sizeof(pd::Rg0Weights));
-        return true;
-    }
-};
-
 inline size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 template <typename T>
@@ -420,7 +364,7 @@ T * mallocCopy(const std::vector<T> & v)
 // of the read groups [lo, hi) are in place: the caller uploads slab by slab while the next slab is being built.
 template <typename Sized, typename SlabDone>
 void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, PinnedBuf<pd::PairDO> & pairs,
-                 PinnedBuf<uint32_t> & start, PinnedBuf<uint32_t> & inst, std::vector<uint64_t> & rgBase, PinnedBuf<uint32_t> & winStart,
+                 PinnedBuf<uint32_t> & start, std::vector<uint64_t> & rgBase, PinnedBuf<uint32_t> & winStart,
                  PinnedBuf<uint2> & pairsPk, PinnedBuf<uint32_t> & endCount, std::vector<uint8_t> & rgPacked,
                  std::vector<uint8_t> & scanGeneric, Sized sized, SlabDone slabDone)
 {
@@ -533,7 +477,6 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
     }
     pairs.resize(out.nChunks);
     start.resize(out.nChunks);
-    inst.resize(out.nChunks);
     pairsPk.resize(totalChunks);
     endCount.assignZero(static_cast<size_t>(nEnt) * (W + 1));
     rgPacked.assign(nEnt, 0);
@@ -570,7 +513,6 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
                     {
                         pairs[base + slot] = pd::PairDO{dv, chunkOff};
                         start[base + slot] = seg.pair_start[i];
-                        inst[base + slot] = static_cast<uint32_t>(i - lo);
                     }
                     pairsPk[base + slot] = make_uint2(d16 | (d16 << 16), (chunkOff & 0xffffu) | (chunkOff << 16));
                     ++ec[chunkOff];
@@ -608,7 +550,6 @@ pd::SegmentView viewOf(const StagedSegment & s)
     pd::SegmentView v;
     v.pairs = s.pairs.p;
     v.start = s.start.p;
-    v.inst = s.inst.p;
     v.rgBase = s.rgBase.p;
     v.winStart = s.winStart.p;
     v.pairsPk = s.pairsPk.p;
@@ -664,7 +605,6 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
         c->nRg = n_readgroups;
         c->nSamples = n_samples;
         c->sampleRg.assign(sample_rg_offsets, sample_rg_offsets + n_samples + 1);
-        c->rg0svc.setReadGroup(rgs[0]);         // used by the context that owns read group 0 of the cohort (rank 0)
         PD_HIP(hipStreamCreate(&c->stream));
         PD_HIP(hipStreamCreate(&c->copyStream));
         PD_HIP(hipEventCreateWithFlags(&c->resultsPacked, hipEventDisableTiming));
@@ -752,6 +692,7 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
         c->dSampleRg.upload(c->sampleRg, c->stream);
         c->dTab.alloc(pool.size());
         c->dTab2.alloc(pool.size());
+        c->dIterFlags.alloc(pd::kMaxIterationsCap + 1);
         pd::buildLogTables(c->dHist.p, c->dTab.p, c->dTab2.p, pool.size(), c->dRg.p, n_readgroups, c->stream);
         PD_HIP(hipGetLastError());
         PD_HIP(hipStreamSynchronize(c->stream));
@@ -899,7 +840,7 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
         s->nWindows = seg->n_windows;
         s->shift = seg->window_shift;
         PinnedBuf<pd::PairDO> & pairs = c->hPairs;
-        PinnedBuf<uint32_t> &start = c->hStart, &inst = c->hInst, &winStart = c->hWinStart, &endCount = c->hEndCount;
+        PinnedBuf<uint32_t> &start = c->hStart, &winStart = c->hWinStart, &endCount = c->hEndCount;
         std::vector<uint64_t> & rgBase = c->hRgBase;
         PinnedBuf<uint2> & pairsPk = c->hPairsPk;
         std::vector<uint8_t> & rgPacked = c->hRgPacked;
@@ -911,7 +852,6 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
         auto sized = [&]() {
             s->pairs.ensure(pairs.size());
             s->start.ensure(start.size());
-            s->inst.ensure(inst.size());
             s->pairsPk.ensure(pairsPk.size());
             s->endCount.ensure(endCount.size());
             s->rgBase.upload(rgBase, cs);
@@ -925,16 +865,13 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
                 {
                     PD_HIP(hipMemcpyAsync(s->pairs.p + a, pairs.data() + a, (b - a) * sizeof(pd::PairDO), hipMemcpyHostToDevice, cs));
                     PD_HIP(hipMemcpyAsync(s->start.p + a, start.data() + a, (b - a) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
-                    PD_HIP(hipMemcpyAsync(s->inst.p + a, inst.data() + a, (b - a) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
                 }
                 PD_HIP(hipMemcpyAsync(s->pairsPk.p + a, pairsPk.data() + a, (b - a) * sizeof(uint2), hipMemcpyHostToDevice, cs));
             }
             const size_t e0 = lo * (static_cast<size_t>(W) + 1), e1 = hi * (static_cast<size_t>(W) + 1);
             PD_HIP(hipMemcpyAsync(s->endCount.p + e0, endCount.data() + e0, (e1 - e0) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
         };
-        buildChunks(*c, *seg, *s, pairs, start, inst, rgBase, winStart, pairsPk, endCount, rgPacked, c->hScanGeneric, sized, slabDone);
-        if (c->rank == 0)
-            pdh::Rg0Service::copySegment(s->rg0, *seg);
+        buildChunks(*c, *seg, *s, pairs, start, rgBase, winStart, pairsPk, endCount, rgPacked, c->hScanGeneric, sized, slabDone);
         s->rgPacked.upload(rgPacked, cs);
         s->hasScanGeneric = !c->hScanGeneric.empty();
         if (s->hasScanGeneric)
@@ -965,41 +902,41 @@ static void launchScan(pd_ctx * c, Run & run)
 {
     auto sit = c->staged.find(run.handle);
     if (sit == c->staged.end())
-        throw HipError{"the segment of a waiting ticket was unstaged"};
+        throw HipError{"the segment of a ticket was unstaged"};
     StagedSegment & s = *sit->second;
+    Stage1Out & o = c->s1[run.set];
+    hipStream_t st = c->stream;
     const size_t cells = static_cast<size_t>(c->nSamples) * s.nWindows;
-    c->dQ3.ensure(cells);
-    c->dFlags.ensure(cells);
-    c->dWinFlag.ensure(s.nWindows);
-    PD_HIP(hipMemsetAsync(c->dWinFlag.p, 0, s.nWindows * sizeof(int), c->stream));
+    o.q3.ensure(cells);
+    o.flags.ensure(cells);
+    o.winFlag.ensure(s.nWindows);
+    PD_HIP(hipMemsetAsync(o.winFlag.p, 0, s.nWindows * sizeof(int), st));
     const size_t tiles = static_cast<size_t>((s.nWindows + pd::kStage1Block - 1) / pd::kStage1Block) * c->nSamples;
-    c->dTileTodo.ensure(tiles);
-    c->dTodoList.ensure(tiles + 2);
-    c->dBigList.ensure(tiles / 2 + c->nSamples + 2);
-    PD_HIP(hipMemsetAsync(c->dTodoList.p, 0, sizeof(unsigned), c->stream));
-    PD_HIP(hipMemsetAsync(c->dBigList.p, 0, sizeof(unsigned), c->stream));
-    PD_HIP(hipEventRecord(run.s1Begin, c->stream));
-    pd::launchStage1(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTileTodo.p, c->dTodoList.p, c->dBigList.p,
-                     s.maxBlockChunks, c->stream);
+    o.tileTodo.ensure(tiles);
+    o.todoList.ensure(tiles + 2);
+    o.bigList.ensure(tiles / 2 + c->nSamples + 2);
+    PD_HIP(hipMemsetAsync(o.todoList.p, 0, sizeof(unsigned), st));
+    PD_HIP(hipMemsetAsync(o.bigList.p, 0, sizeof(unsigned), st));
+    PD_HIP(hipEventRecord(run.s1Begin, st));
+    pd::launchStage1(viewOf(s), c->cohort, o.q3.p, o.flags.p, o.winFlag.p, o.tileTodo.p, o.todoList.p, o.bigList.p, s.maxBlockChunks, st);
     PD_HIP(hipGetLastError());
-    PD_HIP(hipEventRecord(run.s1End, c->stream));
-    pd::launchStage1Fallback(viewOf(s), c->cohort, c->dQ3.p, c->dFlags.p, c->dWinFlag.p, c->dTileTodo.p, c->dTodoList.p,
-                             c->dBigList.p, c->stream);
+    PD_HIP(hipEventRecord(run.s1End, st));
+    pd::launchStage1Fallback(viewOf(s), c->cohort, o.q3.p, o.flags.p, o.winFlag.p, o.tileTodo.p, o.todoList.p, o.bigList.p, st);
     PD_HIP(hipGetLastError());
     if (getenv("POPDEL_HIP_DEBUG"))
     {
         std::vector<uint8_t> todo(tiles);
-        PD_HIP(hipMemcpyAsync(todo.data(), c->dTileTodo.p, tiles, hipMemcpyDeviceToHost, c->stream));
-        PD_HIP(hipStreamSynchronize(c->stream));
+        PD_HIP(hipMemcpyAsync(todo.data(), o.tileTodo.p, tiles, hipMemcpyDeviceToHost, st));
+        PD_HIP(hipStreamSynchronize(st));
         size_t nTodo = 0;
         for (uint8_t t : todo)
             nTodo += t != 0;
         unsigned nBig = 0;
-        PD_HIP(hipMemcpy(&nBig, c->dBigList.p, sizeof(unsigned), hipMemcpyDeviceToHost));
+        PD_HIP(hipMemcpy(&nBig, o.bigList.p, sizeof(unsigned), hipMemcpyDeviceToHost));
         fprintf(stderr, "[popdel_hip] stage 1: %u 512-window blocks through the 128-candidate kernel, %zu of %zu 256-window tiles through the "
                         "32-bit fallback kernel (K=%u, densest block %u chunks)\n", nBig, nTodo, tiles, s.maxLife, s.maxBlockChunks);
     }
-    c->lastWindows = s.nWindows;
+    o.windows = s.nWindows;
     run.launched = true;
 }
 
@@ -1012,7 +949,7 @@ int pd_segment_run(pd_ctx * c, uint64_t handle, uint64_t * ticket)
         return fail(c, "pd_segment_run: unknown segment handle");
     // One ticket may be open plus one waiting: the waiting one's scan is enqueued by pd_segment_collect() of the open one,
     // right behind its last kernel, so that it runs while the open ticket's results travel to the host.
-    if (c->runs.size() >= 2 || (c->runs.size() == 1 && !c->runs.begin()->second.launched))
+    if (c->runs.size() >= 2)
         return fail(c, "pd_segment_run: two tickets are already outstanding (collect the older one first)");
     try
     {
@@ -1022,6 +959,7 @@ int pd_segment_run(pd_ctx * c, uint64_t handle, uint64_t * ticket)
         PD_HIP(hipEventCreate(&run.s1Begin));
         PD_HIP(hipEventCreate(&run.s1End));
         *ticket = c->nextTicket++;
+        run.set = static_cast<int>(*ticket & 1u);          // tickets alternate between the two output sets
         auto & slot = c->runs[*ticket];
         slot = run;
         if (c->runs.size() == 1)
@@ -1099,6 +1037,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         PD_HIP(hipSetDevice(c->device));
         if (!run.launched)              // the collect that should have started it failed
             launchScan(c, run);
+        Stage1Out & o = c->s1[run.set];
         const uint32_t W = s.nWindows, S = c->nSamples;
         const pd::SegmentView view = viewOf(s);
         PD_HIP(hipEventCreate(&s2Begin));
@@ -1111,12 +1050,12 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         winFlag.resize(static_cast<size_t>(W) * world);
         if (world == 1)
         {
-            PD_HIP(hipMemcpyAsync(winFlag.data(), c->dWinFlag.p, W * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            PD_HIP(hipMemcpyAsync(winFlag.data(), o.winFlag.p, W * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         }
         else
         {
             uint8_t * area = reserveArena(*c, static_cast<size_t>(W) * world * sizeof(int));
-            pd::launchCopyBytes(c->dWinFlag.p, area + static_cast<size_t>(c->rank) * W * sizeof(int), W * sizeof(int), c->stream);
+            pd::launchCopyBytes(o.winFlag.p, area + static_cast<size_t>(c->rank) * W * sizeof(int), W * sizeof(int), c->stream);
             xch.allGather(area, W * sizeof(int));
             PD_HIP(hipMemcpyAsync(winFlag.data(), area, winFlag.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         }
@@ -1151,7 +1090,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             in.world = world;
             in.nFlagged = (unsigned)flagged.size();
             in.minInit = c->dMinInitGlobal.p;
-            pd::launchPackFlagged(c->dQ3.p, c->dFlags.p, c->dFlagged.p, W, S, in, c->rank, c->stream);
+            pd::launchPackFlagged(o.q3.p, o.flags.p, c->dFlagged.p, W, S, in, c->rank, c->stream);
             PD_HIP(hipGetLastError());
             xch.allGather(c->arena, in.chunkBytes);
             pd::launchCluster(in, c->uniformThreshold, c->dClusterScratch.p, rowLen, c->dCandLen.p, c->dCandCount.p, c->stream);
@@ -1197,6 +1136,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         c->hCells.resize(std::max<size_t>(1, cells.size()));
         if (!cells.empty())
             std::memcpy(c->hCells.data(), cells.data(), cells.size() * sizeof(pd::CellState));
+        c->hIterFlag.resize(4);
         // per-sample results of the emitted cells: device buffer of the current batch, host block of the whole segment
         uint32_t *hPl = nullptr, *hLad = nullptr, *hDad = nullptr, *hFl = nullptr;
         std::vector<uint32_t> accPl, accLad, accDad, accFl;       // only used when there is more than one batch
@@ -1210,21 +1150,16 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             b.rank = c->rank;
             b.world = world;
             b.nSamplesGlobal = SG;
-            // exchange areas: integer counts | per-tile sums | read group 0's weights | digit histograms
-            b.xchChunk = static_cast<size_t>(b.tilesPerRank) * nb * 4;
+            // exchange areas: integer counts | per-tile sums + RG-0 record | digit histograms
+            b.xchChunk = (static_cast<size_t>(b.tilesPerRank) + 1) * nb * 4;
             const size_t countersBytes = alignUp(static_cast<size_t>(world) * nb * 4 * sizeof(unsigned), 256);
             const size_t xchBytes = alignUp(static_cast<size_t>(world) * b.xchChunk * sizeof(double), 256);
-            const size_t rg0Bytes = alignUp(static_cast<size_t>(world) * nb * sizeof(pd::Rg0Weights), 256);
             const size_t histBytes = static_cast<size_t>(world) * nb * 2 * 256 * sizeof(unsigned);
-            uint8_t * area = reserveArena(*c, countersBytes + xchBytes + rg0Bytes + histBytes);
-            PD_HIP(hipMemsetAsync(area, 0, countersBytes + xchBytes + rg0Bytes, c->stream));
+            uint8_t * area = reserveArena(*c, countersBytes + xchBytes + histBytes);
+            PD_HIP(hipMemsetAsync(area, 0, countersBytes + xchBytes, c->stream));
             b.counters = reinterpret_cast<unsigned *>(area);
             b.xch = reinterpret_cast<double *>(area + countersBytes);
-            b.rg0w = reinterpret_cast<const pd::Rg0Weights *>(area + countersBytes + xchBytes);
-            b.selHist = reinterpret_cast<unsigned *>(area + countersBytes + xchBytes + rg0Bytes);
-            c->dRg0Q.ensure(nb);
-            b.rg0q = c->dRg0Q.p;
-            c->rg0svc.beginBatch(nb);
+            b.selHist = reinterpret_cast<unsigned *>(area + countersBytes + xchBytes);
             c->dCells.ensure(nb);
             PD_HIP(hipMemcpyAsync(c->dCells.p, c->hCells.data() + lo, nb * sizeof(pd::CellState), hipMemcpyHostToDevice, c->stream));
             c->dDl.ensure(static_cast<size_t>(nb) * S * 3);
@@ -1267,6 +1202,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             b.cells = c->dCells.p;
             b.dl = c->dDl.p;
             b.shifts = c->dShifts.p;
+            b.iterFlags = c->dIterFlags.p;
             b.pl = c->dPl.p;
             b.lad = c->dLad.p;
             b.dad = c->dDad.p;
@@ -1278,7 +1214,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             b.somatic = c->cfg.somatic;
             b.windowWise = c->cfg.window_wise_output;
             // Phase A gives, per cell, the number of usable active pairs = capacity of its support pool.
-            pd::runStage2Init(view, c->cohort, b, c->dFlags.p, xch, c->stream);
+            pd::runStage2Init(view, c->cohort, b, o.flags.p, xch, c->stream);
             PD_HIP(hipGetLastError());
             PinnedBuf<unsigned> & counters = c->hCounters;                    // of this context's own samples
             counters.resize(static_cast<size_t>(nb) * 4);
@@ -1298,8 +1234,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             c->dSuppLast.ensure(pool + 1);
             b.suppFirst = c->dSuppFirst.p;
             b.suppLast = c->dSuppLast.p;
-            CtxRg0 rg0(*c, s, xch);
-            pd::runStage2Main(view, c->cohort, b, c->dFlags.p, xch, rg0, genericTiles != 0, c->stream);
+            pd::runStage2Main(view, c->cohort, b, o.flags.p, xch, genericTiles != 0, c->hIterFlag.data(), c->stream);
             PD_HIP(hipGetLastError());
             PD_HIP(hipMemcpyAsync(c->hCells.data() + lo, c->dCells.p, nb * sizeof(pd::CellState), hipMemcpyDeviceToHost, c->stream));
             PD_HIP(hipStreamSynchronize(c->stream));
@@ -1442,6 +1377,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         (void)hipEventDestroy(s2End);
     (void)hipEventDestroy(run.s1Begin);
     (void)hipEventDestroy(run.s1End);
+    c->lastSet = run.set;
     if (s.ownedBySubmit)
     {
         if (c->spare.size() < 2)
@@ -1476,15 +1412,16 @@ int pd_stage1_last(pd_ctx * c, pd_stage1_view * out)
     try
     {
         PD_HIP(hipSetDevice(c->device));
-        const uint32_t W = c->lastWindows, S = c->nSamples;
+        Stage1Out & o = c->s1[c->lastSet];
+        const uint32_t W = o.windows, S = c->nSamples;
         const size_t cells = static_cast<size_t>(W) * S;
         std::vector<int32_t> q(cells);
         std::vector<uint8_t> f(cells);
         PD_HIP(hipStreamSynchronize(c->stream));
         if (cells)
         {
-            PD_HIP(hipMemcpy(q.data(), c->dQ3.p, cells * sizeof(int32_t), hipMemcpyDeviceToHost));
-            PD_HIP(hipMemcpy(f.data(), c->dFlags.p, cells, hipMemcpyDeviceToHost));
+            PD_HIP(hipMemcpy(q.data(), o.q3.p, cells * sizeof(int32_t), hipMemcpyDeviceToHost));
+            PD_HIP(hipMemcpy(f.data(), o.flags.p, cells, hipMemcpyDeviceToHost));
         }
         // device layout is [sample][window]; the view is [window][sample]
         c->hQ3View.resize(cells);

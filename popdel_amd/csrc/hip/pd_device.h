@@ -6,8 +6,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "x87soft.h"
-
 namespace pd {
 
 // ---- limits --------------------------------------------------------------------------------------------------
@@ -54,8 +52,6 @@ struct SegmentView
 {
     const PairDO *   pairs;        // [nChunks]  dev + off, read-group major, ordered by `on`
     const uint32_t * start;        // [nChunks]  startPos
-    const uint32_t * inst;         // [nChunks]  index of the pair instance within its read group (pd_segment order): the
-                                   // order in which stage 2 adds up the pairs of a cell
     const uint64_t * rgBase;       // [nRg]      first chunk of the read group
     // Chunk index by SLOT: a chunk starting in window a >= 1 has slot a + K - 1; a chunk present from window 0 on
     // (carried over or new) has slot (its end window - 1), so carried-over pairs leave the candidate range exactly when
@@ -114,19 +110,11 @@ struct Exchange
     virtual ~Exchange() {}
 };
 
-// Called once per EM iteration, after rg0QueryKernel has filled b.rg0q (stream-ordered): makes b.rg0w valid on every
-// context (stream-ordered) for the reference-shift update that follows and tells whether any cell still iterates.
-struct Stage2Buffers;
-struct Rg0Provider
-{
-    virtual bool provide(const Stage2Buffers & b, hipStream_t st) = 0;
-    virtual ~Rg0Provider() {}
-};
-
 // Where the per-tile sums of (cell c, cohort-wide tile t) live, and the record of read group 0's triple
 // ({d0, d1, d2, kind}; kind 1 = high coverage) that rank `r` published for cell c.
 struct Stage2Buffers;
 __device__ __forceinline__ double * tileSlot(const Stage2Buffers & b, unsigned c, unsigned t);
+__device__ __forceinline__ double * rg0Slot(const Stage2Buffers & b, unsigned c, unsigned r);
 
 enum TileMode : unsigned
 {
@@ -194,7 +182,7 @@ struct Stage2Buffers
     // `tilesPerRank` consecutive 256-sample tiles. Whatever crosses samples is written into the context's own chunk of
     // an area laid out [world][chunk] and all-gathered by the host between kernels; per-cell kernels then add the
     // chunks in rank/tile order, so results do not depend on the number of shards (world == 1: no exchange at all).
-    double *    xch;         // [world][xchChunk]: [tilesPerRank][nCells][4] per-tile sums
+    double *    xch;         // [world][xchChunk]: [tilesPerRank][nCells][4] per-tile sums, then [nCells][4] RG-0 record
     size_t      xchChunk;    // doubles per chunk
     unsigned *  counters;    // [world][nCells][4] integer accumulators (a5 count, a5 total, low coverage samples, unused)
     unsigned *  selHist;     // [world][nCells][2][256] digit histograms of the support pools
@@ -224,10 +212,6 @@ struct Stage2Buffers
     unsigned *  rgOutU;      // [nCells][nRg][12] per-read-group counts (LAD, DAD, first/last, pairs, flags)
     unsigned    nRg;
     unsigned    ownTiles;    // 256-sample tiles of this context
-    // Read group 0's weights of the reference-shift update (the reference uses them for every read group): evaluated on
-    // the host FPU per cell and iteration (host/rg0_x87.cpp), see x87soft.h. rg0q is what the host reads for that.
-    const Rg0Weights * rg0w;  // [nCells]
-    Rg0Query *  rg0q;         // [nCells]
     // final-pass outputs, [nCells][S][k]
     uint32_t *  pl;
     uint32_t *  lad;
@@ -236,6 +220,7 @@ struct Stage2Buffers
     unsigned *  suppFirst;   // support pools
     unsigned *  suppLast;
     // parameters
+    unsigned *  iterFlags;   // [maxIterations + 1]: 1 if any cell was still iterating after EM iteration i
     unsigned    minLen;
     unsigned    maxIterations;
     double      minLR;
@@ -248,6 +233,10 @@ __device__ __forceinline__ double * tileSlot(const Stage2Buffers & b, unsigned c
 {
     const unsigned r = t / b.tilesPerRank, lt = t - r * b.tilesPerRank;
     return b.xch + (size_t)r * b.xchChunk + ((size_t)lt * b.nCells + c) * 4;
+}
+__device__ __forceinline__ double * rg0Slot(const Stage2Buffers & b, unsigned c, unsigned r)
+{
+    return b.xch + (size_t)r * b.xchChunk + ((size_t)b.tilesPerRank * b.nCells + c) * 4;
 }
 
 }  // namespace pd

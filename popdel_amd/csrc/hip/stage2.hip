@@ -112,7 +112,6 @@ struct PairRange
 {
     const PairDO *   p;
     const uint32_t * st;
-    const uint32_t * inst;
     unsigned         begin, end;
 };
 
@@ -123,7 +122,6 @@ __device__ __forceinline__ PairRange pairRange(const SegmentView & seg, unsigned
     PairRange r;
     r.p = seg.pairs + seg.rgBase[rg];
     r.st = seg.start + seg.rgBase[rg];
-    r.inst = seg.inst + seg.rgBase[rg];
     r.begin = ws[w];
     r.end = ws[w + K];
     return r;
@@ -545,53 +543,6 @@ __global__ __launch_bounds__(1024) void clusterKernel(ClusterInput in, int unifo
     }
 }
 
-// Puts the compacted row of one sample / read group (n <= kDenseCap entries, written by its half-wave) into the order of
-// the pair instances in pd_segment -- the order in which the oracle, like the reference's active set, is walked when sums
-// over the pairs of a cell are formed. Chunk order differs from it for the continuation chunks of long-lived pairs and
-// for pairs carried over from the previous segment. Rank by counting; the keys are distinct.
-__device__ __forceinline__ void halfSortRow(short * dev, short * st, const unsigned * key, unsigned n, unsigned hl)
-{
-    if (n < 2u)
-        return;
-    bool sorted = true;
-    for (unsigned e = hl + 1u; e < n; e += 32u)
-        sorted = sorted && key[e - 1u] < key[e];
-    if (halfCount(!sorted) == 0u)
-        return;
-    short d[3], s[3];
-    unsigned k[3], rank[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-    {
-        const unsigned e = hl + 32u * t;
-        d[t] = 0;
-        s[t] = 0;
-        k[t] = 0;
-        rank[t] = 0;
-        if (e < n)
-        {
-            d[t] = dev[e];
-            s[t] = st[e];
-            k[t] = key[e];
-        }
-    }
-    for (unsigned j = 0; j < n; ++j)
-    {
-        const unsigned kj = key[j];
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-            rank[t] += kj < k[t] ? 1u : 0u;
-    }
-    // every lane of the half-wave has read its entries (one instruction stream per wave) before any is overwritten
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-        if (hl + 32u * t < n)
-        {
-            dev[rank[t]] = d[t];
-            st[rank[t]] = s[t];
-        }
-}
-
 // =====================================================================================================================
 // Cell set-up: first allele-frequency estimate (integer counts, reference :93-133), low-coverage sample count, and
 // the dense image of the cell's active pairs (see Stage2Buffers::cellDev).
@@ -607,7 +558,6 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
     __shared__ SampleMeta shMeta[64];
     __shared__ short shDev[64][kDenseCap + 1];             // deviations: 16 bits in the dense image (else: generic kernels)
     __shared__ short shSt[64][kDenseCap + 1];              // start positions relative to the cell's window (see stBase)
-    __shared__ unsigned shKey[64][kDenseCap + 1];          // instance index of the pair: rows end up in that order
     __shared__ unsigned shN[64];
     __shared__ unsigned shRows, shGeneric;
     const unsigned cellIdx = blockIdx.y, wt = blockIdx.x;          // one workgroup per (cell, 64-sample wave tile)
@@ -665,7 +615,7 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
             for (unsigned base = r.begin; base < r.end; base += 64u)
             {
                 PairDO p[2];
-                unsigned st[2], key[2];
+                unsigned st[2];
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
                 {
@@ -673,12 +623,10 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
                     p[g].dev = 0;
                     p[g].off = 0;
                     st[g] = 0;
-                    key[g] = 0;
                     if (i < r.end)
                     {
                         p[g] = r.p[i];
                         st[g] = r.st[i];
-                        key[g] = r.inst[i];
                     }
                 }
 #pragma unroll
@@ -694,7 +642,6 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
                             const int rel = (int)(st[g] - stBase);
                             shDev[inWt][pos] = (short)p[g].dev;
                             shSt[inWt][pos] = (short)rel;
-                            shKey[inWt][pos] = key[g];
                             farStart = farStart || rel < -32768 || rel > 32767 || p[g].dev < -32768 || p[g].dev > 32767;
                         }
                     }
@@ -714,8 +661,6 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
         }
         low += (flags[(size_t)s * seg.nWindows + w] & 1u) ? 1u : 0u;
         generic = generic || halfCount(farStart) != 0u;
-        if (!multi && !generic && nDense != kDenseHighCov)
-            halfSortRow(shDev[inWt], shSt[inWt], shKey[inWt], nDense, hl);
         if (hl == 0)
         {
             const bool noRows = generic || multi;
@@ -915,13 +860,30 @@ __global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, Co
                 eq = eq && (ref == del);
             });
             if (n >= rc.maxLoad)
+            {
+                if (rg == 0 && b.rank == 0 && hl == 0)
+                {
+                    double * r0 = rg0Slot(b, cellIdx, 0);
+                    r0[0] = r0[1] = r0[2] = 0;
+                    r0[3] = 1;
+                }
                 continue;
+            }
             const double rs0 = halfSum(g0), rs1 = halfSum(g1), rs2 = halfSum(g2);
             allEq = allEq && (halfCount(!eq) == 0u);
             nUsed += n;
             logL[0] += rs0;
             logL[1] += rs1;
             logL[2] += rs2;
+            if (rg == 0 && b.rank == 0 && hl == 0)
+            {
+                const double m = fmax(fmax(rs0, rs1), rs2);
+                double * r0 = rg0Slot(b, cellIdx, 0);
+                r0[0] = rs0 - m;
+                r0[1] = rs1 - m;
+                r0[2] = rs2 - m;
+                r0[3] = 0;
+            }
         }
         if (hl == 0)
         {
@@ -1057,6 +1019,23 @@ __global__ __launch_bounds__(kSampleTile) void dataLikDenseKernel(CohortView co,
     if (valid)
     {
         const double g1 = log(prod) + (double)(esum - (int)nn) * PD_LN2;
+        if (rg == 0 && b.rank == 0)
+        {
+            double * r0 = rg0Slot(b, cellIdx, 0);
+            if (highCov)
+            {
+                r0[0] = r0[1] = r0[2] = 0;
+                r0[3] = 1;
+            }
+            else
+            {
+                const double m = fmax(fmax(g0, g1), g2);
+                r0[0] = g0 - m;
+                r0[1] = g1 - m;
+                r0[2] = g2 - m;
+                r0[3] = 0;
+            }
+        }
         double d[3];
         const double logL[3] = {g0, nn ? g1 : 0.0, g2};
         finishTriple(d, logL, nn, eq);
@@ -1117,28 +1096,22 @@ __global__ void cellLoopHeadKernel(Stage2Buffers b)
         loopHead(b.cells[c], b);
 }
 
-// What the host needs to evaluate read group 0's weights for the next reference-shift update of every cell (x87soft.h).
-__global__ void rg0QueryKernel(Stage2Buffers b)
-{
-    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= b.nCells)
-        return;
-    const CellState & cs = b.cells[c];
-    Rg0Query q;
-    q.active = cs.phase == kCellIterating ? 1 : 0;
-    q.window = cs.window;
-    q.len = cs.len;
-    q.shift0 = b.shifts[(size_t)c * b.nRg];
-    q.gt[0] = cs.gt[0];
-    q.gt[1] = cs.gt[1];
-    q.gt[2] = cs.gt[2];
-    b.rg0q[c] = q;
-}
-
 // New reference shift of one read group (genotype_deletion_popdel_call.h:447-451): the weighted mean deviation of its
 // pairs, truncated the way x86 converts, zeroed beyond one standard deviation.
-__device__ __forceinline__ int referenceShiftOf(double q, bool rgNan, double stddev)
+// PD_TEST_SNAP_SHIFTS is a compile-time switch of a TEST build of this file (never of the shipped library; the oracle has
+// the matching knob): a quotient within 1e-9 of an integer is first moved onto it. Single-pair and equal-weight read
+// groups put the exact quotient on an integer, and which side of it the rounded one lands on is decided by the last bit
+// of the weights (Numerics); with the switch on both sides HIP and oracle must agree everywhere.
+__device__ __forceinline__ int referenceShiftOf(double wSumRef, double sumRef, bool rgNan, double stddev)
 {
+    double q = wSumRef / sumRef;
+#ifdef PD_TEST_SNAP_SHIFTS
+    {
+        const double r = rint(q);
+        if (fabs(q - r) <= 1e-9 * fmax(1.0, fabs(r)))
+            q = r;
+    }
+#endif
     int newShift;
     if (rgNan || !(q > -2147483649.0 && q < 2147483648.0))
         newShift = (int)0x80000000;          // what x86 yields for NaN / out-of-range conversions
@@ -1148,25 +1121,6 @@ __device__ __forceinline__ int referenceShiftOf(double q, bool rgNan, double std
         newShift = 0;
     return newShift;
 }
-
-// A quotient this close to an integer is decided by the last bits of the weights: single-pair read groups and equally
-// weighted pairs put the EXACT quotient on an integer, and whether the rounded one lands on it or one ulp below -- i.e.
-// what the truncation gives -- follows from how the reference rounds (x87 weights, double sums in pair order). Those
-// read groups are re-evaluated by exactQuotient(); all others cannot change sides through rounding.
-__device__ __forceinline__ bool quotientOnKnifeEdge(double q)
-{
-    const double r = rint(q);
-    return fabs(q - r) <= 1e-9 * fmax(1.0, fabs(r));
-}
-
-struct LaneRg;
-__device__ __forceinline__ uint64_t lanePosClamped(const LaneRg & l, int deviation, bool & inside);
-
-// The reference's arithmetic for one read group, operation for operation (genotype_deletion_popdel_call.h:435-447):
-// weights through the x87 model (x87soft.h) from the host-evaluated exp(a0Rg), exp(a1Rg), sums in double in the order of
-// the dense image's rows (= pair instance order), no contraction into fused multiply-adds.
-__device__ __noinline__ double exactQuotient(const int16_t * col, unsigned n, const LaneRg & l, const double * __restrict__ hist,
-                                             int len, int refShift, X87 expA0, X87 expA1);
 
 // =====================================================================================================================
 // Deletion-length / reference-shift update (reference :388-462). The per-read-group weights come from RG 0's triple
@@ -1183,12 +1137,19 @@ __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, 
     const int len = (int)cs.len;
     const unsigned hl = threadIdx.x & 31u, half = threadIdx.x >> 5;
     const double g0 = cs.gt[0], g1 = cs.gt[1], g2 = cs.gt[2];
-    // weights of the reference model, shared by all read groups (always RG 0's triple; evaluated on the host FPU).
-    // This kernel serves the few tiles the dense image cannot hold and adds the pairs up in a tree: quotients on a
-    // knife edge are not re-evaluated here.
-    const Rg0Weights & rw = b.rg0w[cellIdx];
-    const bool rgNan = rw.invalid != 0;
-    const double ea0Rg = rw.expA0d, ea1Rg = rw.expA1d;
+    // weights of the reference model, shared by all read groups (always RG 0's triple)
+    const double * rg0 = rg0Slot(b, cellIdx, 0);           // published by the context that owns read group 0
+    bool rgNan = rg0[3] != 0;
+    double ea0Rg = 0, ea1Rg = 0;
+    if (!rgNan)
+    {
+        const double aSumRg = exp(rg0[0]) * g0 + exp(rg0[1]) * g1 + exp(rg0[2]) * g2;
+        const double l0 = (rg0[0] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[0];
+        const double l1 = (rg0[1] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[1];
+        ea0Rg = exp(l0 + log(g0) - log(aSumRg));
+        ea1Rg = exp(l1 + log(g1) - log(aSumRg));
+        rgNan = isnan(ea0Rg) || isnan(ea1Rg);
+    }
     __shared__ SampleMeta shMeta[kSamplesPerBlock];
     loadTileMeta(seg, co, w, shMeta);
     // per-sample weights exp(a1), exp(a2): one lane per sample, shared through LDS
@@ -1241,7 +1202,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, 
             wSumRef = halfSum(wSumRef);
             sumDelAcc += sumDel;
             wSumDelAcc += wSumDel;
-            const int newShift = referenceShiftOf(wSumRef / sumRef, rgNan, rc.stddev);
+            const int newShift = referenceShiftOf(wSumRef, sumRef, rgNan, rc.stddev);
             if (hl == 0)
                 *shiftSlot = newShift;
         }
@@ -1256,26 +1217,6 @@ __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, 
     }
 }
 
-__device__ __noinline__ double exactQuotient(const int16_t * col, unsigned n, const LaneRg & l, const double * __restrict__ hist,
-                                             int len, int refShift, X87 expA0, X87 expA1)
-{
-#pragma clang fp contract(off)
-    double sumRef = 0, wSumRef = 0;
-    for (unsigned j = 0; j < n; ++j)
-    {
-        const int dv = col[j * 64];
-        bool inD, inN;
-        const uint64_t pd_ = lanePosClamped(l, dv - len, inD), pn = lanePosClamped(l, dv - refShift, inN);
-        const double del = inD ? hist[pd_] : l.minProb;
-        const double noDel = inN ? hist[pn] : l.minProb;
-        const double probRef = x87ProbRef(expA1, expA0, noDel, del + noDel);
-        sumRef = sumRef + probRef;
-        const double term = probRef * (double)dv;
-        wSumRef = wSumRef + term;
-    }
-    return wSumRef / sumRef;
-}
-
 // The same on the dense image, one lane per sample.
 __global__ __launch_bounds__(kSampleTile) void updateLenDenseKernel(CohortView co, Stage2Buffers b)
 {
@@ -1286,18 +1227,31 @@ __global__ __launch_bounds__(kSampleTile) void updateLenDenseKernel(CohortView c
         return;
     const int len = (int)cs.len;
     const double g0 = cs.gt[0], g1 = cs.gt[1], g2 = cs.gt[2];
-    // what depends on the cell only is worked out by one lane and shared; the weights of the reference model come from
-    // the host FPU (always read group 0's, for every read group)
-    __shared__ double shCell[2];
+    // what depends on the cell only (seven exp/log calls) is worked out by one lane and shared
+    __shared__ double shCell[5];
     if (threadIdx.x == 0)
     {
-        shCell[0] = log(g1);
-        shCell[1] = log(g2);
+        const double * rg0 = rg0Slot(b, cellIdx, 0);
+        bool nan_ = rg0[3] != 0;
+        double e0 = 0, e1 = 0;
+        if (!nan_)
+        {
+            const double aSumRg = exp(rg0[0]) * g0 + exp(rg0[1]) * g1 + exp(rg0[2]) * g2;
+            const double l0 = (rg0[0] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[0];
+            const double l1 = (rg0[1] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[1];
+            e0 = exp(l0 + log(g0) - log(aSumRg));
+            e1 = exp(l1 + log(g1) - log(aSumRg));
+            nan_ = isnan(e0) || isnan(e1);
+        }
+        shCell[0] = e0;
+        shCell[1] = e1;
+        shCell[2] = nan_ ? 1.0 : 0.0;
+        shCell[3] = log(g1);
+        shCell[4] = log(g2);
     }
     __syncthreads();
-    const Rg0Weights & rw = b.rg0w[cellIdx];
-    const double ea0Rg = rw.expA0d, ea1Rg = rw.expA1d, logG1 = shCell[0], logG2 = shCell[1];
-    const bool rgNan = rw.invalid != 0;
+    const double ea0Rg = shCell[0], ea1Rg = shCell[1], logG1 = shCell[3], logG2 = shCell[4];
+    const bool rgNan = shCell[2] != 0.0;
     const unsigned s = PD_TILE_IDX * kSamplesPerBlock + threadIdx.x;
     const bool valid = s < co.nSamples;
     const size_t wtGlobal = (size_t)cellIdx * (b.ownTiles * 4) + PD_TILE_IDX * 4 + (threadIdx.x >> 6);
@@ -1344,10 +1298,8 @@ __global__ __launch_bounds__(kSampleTile) void updateLenDenseKernel(CohortView c
     }
     if (valid && !highCov)
     {
-        double q = wSumRef / sumRef;
-        if (!rgNan && quotientOnKnifeEdge(q))
-            q = exactQuotient(col, nn, l, co.hist, len, refShift, rw.expA0, rw.expA1);
-        *shiftSlot = referenceShiftOf(q, rgNan, l.stddev);
+        const int newShift = referenceShiftOf(wSumRef, sumRef, rgNan, l.stddev);
+        *shiftSlot = newShift;
     }
     const double t0 = blockSum(sumDel, red);
     const double t1 = blockSum(wSumDel, red);
@@ -1408,7 +1360,7 @@ __global__ __launch_bounds__(64) void cellLenFinishKernel(Stage2Buffers b)
 }
 
 // Allele-frequency update and convergence test (reference :623-659).
-__global__ __launch_bounds__(64) void cellFreqFinishKernel(Stage2Buffers b)
+__global__ __launch_bounds__(64) void cellFreqFinishKernel(Stage2Buffers b, unsigned iteration)
 {
     const unsigned c = blockIdx.x;
     CellState & cs = b.cells[c];
@@ -1418,6 +1370,16 @@ __global__ __launch_bounds__(64) void cellFreqFinishKernel(Stage2Buffers b)
     waveTileSums(b, c, unused0, unused1, sum);
     if (threadIdx.x != 0)
         return;
+    struct Mark
+    {
+        CellState & cs;
+        unsigned *  flag;
+        __device__ ~Mark()
+        {
+            if (cs.phase == kCellIterating)
+                *flag = 1u;               // every writer stores the same value
+        }
+    } mark{cs, b.iterFlags + iteration};
     const double freq = sum / 2.0 / b.nSamplesGlobal;
     cs.freq = freq;
     if (freq == 0)
@@ -1895,7 +1857,6 @@ __global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView 
 {
     __shared__ short shDev[64][kDenseCap + 1];             // deviations: 16 bits in the dense image (else: generic kernels)
     __shared__ short shSt[64][kDenseCap + 1];              // start positions relative to the cell's window (see stBase)
-    __shared__ unsigned shKey[64][kDenseCap + 1];          // instance index of the pair: rows end up in that order
     __shared__ unsigned shN[64];
     __shared__ unsigned shRows;
     const unsigned cellIdx = blockIdx.y, mw = blockIdx.x;
@@ -1928,7 +1889,7 @@ __global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView 
         for (unsigned base = r.begin; base < r.end; base += 64u)
         {
             PairDO p[2];
-            unsigned st[2], key[2];
+            unsigned st[2];
 #pragma unroll
             for (int g = 0; g < 2; ++g)
             {
@@ -1936,12 +1897,10 @@ __global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView 
                 p[g].dev = 0;
                 p[g].off = 0;
                 st[g] = 0;
-                key[g] = 0;
                 if (i < r.end)
                 {
                     p[g] = r.p[i];
                     st[g] = r.st[i];
-                    key[g] = r.inst[i];
                 }
             }
 #pragma unroll
@@ -1957,7 +1916,6 @@ __global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView 
                         const int rel = (int)(st[g] - stBase);
                         shDev[inWt][pos] = (short)p[g].dev;
                         shSt[inWt][pos] = (short)rel;
-                        shKey[inWt][pos] = key[g];
                         farStart = farStart || rel < -32768 || rel > 32767 || p[g].dev < -32768 || p[g].dev > 32767;
                     }
                 }
@@ -1970,8 +1928,6 @@ __global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView 
             atomicAdd(&b.counters[((size_t)b.rank * b.nCells + cellIdx) * 4 + 3], 1u);
         }
         const unsigned nDense = (n >= co.rg[rg].maxLoad) ? kDenseHighCov : n;   // n <= kDenseCap otherwise (else: kTileGeneric)
-        if (nDense <= (unsigned)kDenseCap)
-            halfSortRow(shDev[inWt], shSt[inWt], shKey[inWt], nDense, hl);
         if (hl == 0)
         {
             shN[inWt] = nDense;
@@ -2060,6 +2016,23 @@ __global__ __launch_bounds__(kSampleTile) void dataLikMultiKernel(CohortView co,
             od[1] = g1;
             od[2] = g2;
             b.rgOutU[((size_t)cellIdx * b.nRg + rg) * 12] = nn | (highCov ? PD_RGF_HIGHCOV : 0u) | (eq ? PD_RGF_EQ : 0u);
+            if (rg == 0 && b.rank == 0)
+            {
+                double * r0 = rg0Slot(b, cellIdx, 0);
+                if (highCov)
+                {
+                    r0[0] = r0[1] = r0[2] = 0;
+                    r0[3] = 1;
+                }
+                else
+                {
+                    const double m = fmax(fmax(g0, g1), g2);
+                    r0[0] = g0 - m;
+                    r0[1] = g1 - m;
+                    r0[2] = g2 - m;
+                    r0[3] = 0;
+                }
+            }
         }
     }
     __syncthreads();                                       // the parked results are read by other lanes of this workgroup
@@ -2115,18 +2088,31 @@ __global__ __launch_bounds__(kSampleTile) void updateLenMultiKernel(CohortView c
         return;
     const int len = (int)cs.len;
     const double g0 = cs.gt[0], g1 = cs.gt[1], g2 = cs.gt[2];
-    // what depends on the cell only is worked out by one lane and shared; the weights of the reference model come from
-    // the host FPU (always read group 0's, for every read group)
-    __shared__ double shCell[2];
+    // what depends on the cell only (seven exp/log calls) is worked out by one lane and shared
+    __shared__ double shCell[5];
     if (threadIdx.x == 0)
     {
-        shCell[0] = log(g1);
-        shCell[1] = log(g2);
+        const double * rg0 = rg0Slot(b, cellIdx, 0);
+        bool nan_ = rg0[3] != 0;
+        double e0 = 0, e1 = 0;
+        if (!nan_)
+        {
+            const double aSumRg = exp(rg0[0]) * g0 + exp(rg0[1]) * g1 + exp(rg0[2]) * g2;
+            const double l0 = (rg0[0] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[0];
+            const double l1 = (rg0[1] < PD_X87_EXP_UNDERFLOW) ? -INFINITY : rg0[1];
+            e0 = exp(l0 + log(g0) - log(aSumRg));
+            e1 = exp(l1 + log(g1) - log(aSumRg));
+            nan_ = isnan(e0) || isnan(e1);
+        }
+        shCell[0] = e0;
+        shCell[1] = e1;
+        shCell[2] = nan_ ? 1.0 : 0.0;
+        shCell[3] = log(g1);
+        shCell[4] = log(g2);
     }
     __syncthreads();
-    const Rg0Weights & rw = b.rg0w[cellIdx];
-    const double ea0Rg = rw.expA0d, ea1Rg = rw.expA1d, logG1 = shCell[0], logG2 = shCell[1];
-    const bool rgNan = rw.invalid != 0;
+    const double ea0Rg = shCell[0], ea1Rg = shCell[1], logG1 = shCell[3], logG2 = shCell[4];
+    const bool rgNan = shCell[2] != 0.0;
     const unsigned rgLo = b.mt.rgLo[mtI], rgHi = b.mt.rgHi[mtI];
     double sumDelAcc = 0, wSumDelAcc = 0;                  // over the read groups this lane handles, in read-group order
     for (unsigned base = rgLo; base < rgHi; base += kSampleTile)
@@ -2176,10 +2162,8 @@ __global__ __launch_bounds__(kSampleTile) void updateLenMultiKernel(CohortView c
         }
         if (valid && !highCov)
         {
-            double q = wSumRef / sumRef;
-            if (!rgNan && quotientOnKnifeEdge(q))
-                q = exactQuotient(col, nn, l, co.hist, len, refShift, rw.expA0, rw.expA1);
-            *shiftSlot = referenceShiftOf(q, rgNan, l.stddev);
+            const int newShift = referenceShiftOf(wSumRef, sumRef, rgNan, l.stddev);
+            *shiftSlot = newShift;
             sumDelAcc += sumDel;
             wSumDelAcc += wSumDel;
         }
@@ -2707,7 +2691,7 @@ void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers
 // Every context of a sharded cohort runs the same sequence; the per-cell kernels see identical inputs everywhere
 // (all-gathered per-tile sums), so all contexts take the same decisions, including the early exit below.
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
-                   Rg0Provider & rg0, bool anyGenericTile, hipStream_t st)
+                   bool anyGenericTile, unsigned * pinnedWord, hipStream_t st)
 {
     if (b.nCells == 0)
         return;
@@ -2726,14 +2710,10 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     };
     dataLik(0);
     x.allGather(b.xch, xchBytes);
+    (void)hipMemsetAsync(b.iterFlags, 0, (b.maxIterations + 1) * sizeof(unsigned), st);
     hipLaunchKernelGGL(cellLoopHeadKernel, perCell, cellBlock, 0, st, b);
     for (unsigned it = 0; it < b.maxIterations; ++it)
     {
-        // Read group 0's weights for this update come from the host FPU (x87soft.h); the same round trip ends the loop
-        // as soon as no cell iterates any more (most cells need 2-4 iterations).
-        hipLaunchKernelGGL(rg0QueryKernel, perCell, cellBlock, 0, st, b);
-        if (!rg0.provide(b, st))
-            break;
         hipLaunchKernelGGL(updateLenDenseKernel, perSample, tile, 0, st, co, b);
         if (b.mt.n != 0)
             hipLaunchKernelGGL(updateLenMultiKernel, perMulti, tile, 0, st, co, b);
@@ -2743,7 +2723,17 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
         hipLaunchKernelGGL(cellLenFinishKernel, wavePerCell, dim3(64), 0, st, b);
         dataLik(0);
         x.allGather(b.xch, xchBytes);
-        hipLaunchKernelGGL(cellFreqFinishKernel, wavePerCell, dim3(64), 0, st, b);
+        hipLaunchKernelGGL(cellFreqFinishKernel, wavePerCell, dim3(64), 0, st, b, it);
+        // Most cells leave the loop after 2-4 iterations: look at the "someone is still iterating" flag now and then
+        // instead of launching the remaining (empty) iterations (a look costs a round trip of ~50 us, an empty iteration ~20).
+        if (it == 3 || it == 5 || it == 8 || it == 11)
+        {
+            *pinnedWord = 1;                               // page-locked: no bounce copy for four bytes
+            (void)hipMemcpyAsync(pinnedWord, b.iterFlags + it, sizeof(unsigned), hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            if (!*pinnedWord)
+                break;
+        }
     }
     // cells that left through the visited-table test: compare with the previous estimate
     hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellConverged, 0);

@@ -10,6 +10,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "libpopdel_oracle.so")
 ORACLE_CALL = os.path.join(ROOT, "oracle", "_build", "popdel_oracle_call")
 HIP_LIB = os.path.join(ROOT, "popdel_amd", "lib", "libpopdel_hip.so")
+# test build of the HIP library (stage 2 compiled with PD_TEST_SNAP_SHIFTS), lives beside the oracle
+HIP_SNAP_LIB = os.path.join(ROOT, "oracle", "_build", "libpopdel_hip_snap.so")
 POPDEL_BIN = os.path.join(ROOT, "popdel_amd", "lib", "popdel")
 
 
@@ -22,7 +24,7 @@ def pytest_configure(config):
 def built():
     """Builds the oracle (always) and the product libraries (cross-compiled; needs hipcc) once per session."""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-j4"], stdout=subprocess.DEVNULL)
-    if not (os.path.exists(HIP_LIB) and os.path.exists(POPDEL_BIN)):
+    if not (os.path.exists(HIP_LIB) and os.path.exists(POPDEL_BIN) and os.path.exists(HIP_SNAP_LIB)):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "popdel_amd", "csrc"), "-j4"], stdout=subprocess.DEVNULL)
     return True
 

@@ -14,10 +14,11 @@ INT_KEYS = ("initial_length", "iterations", "deletion_length", "window_position"
             "lad", "dad", "first_last")
 
 
-def both(seg, rgs, offsets, **kw):
+def both(seg, rgs, offsets, hip_library=None, **kw):
+    """hip_library: path of a TEST build of the HIP library (tests/test_gpu_fuzz.py); default: the product library."""
     from popdel_amd import capi
     out = []
-    for lib in (capi.load_hip(), capi.load_library(ORACLE_LIB)):
+    for lib in (capi.load_library(hip_library) if hip_library else capi.load_hip(), capi.load_library(ORACLE_LIB)):
         ctx = capi.Context(lib, rgs, offsets, **kw)
         calls = ctx.collect(ctx.submit(seg))
         q3, fl = ctx.stage1()

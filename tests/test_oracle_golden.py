@@ -130,3 +130,37 @@ def test_reference_algorithm_is_order_sensitive(built):
         assert np.array_equal(np.argmin(a["pl"], axis=2), np.argmin(b["pl"], axis=2))
         changed += int((a["pl"] != b["pl"]).any(axis=2).sum())
     assert 1 <= changed <= 20
+
+
+def test_reference_algorithm_hangs_off_the_last_bit_of_the_allele_frequency(built, monkeypatch):
+    """The second reason (found in round 2 while trying to close the gap): the weights of the reference-shift update come
+    from exp(a0Rg), exp(a1Rg) with a = log(triple of read group 0) + log(prior) - log(sum) (genotype_deletion_popdel_call.h:
+    421-431), and the priors from the allele frequency, a double sum over all samples of terms that are quotients of x87
+    exp() results (:467-485). Moving that frequency by ONE unit in the last place after every EM iteration -- far less than
+    any implementation without the x87's logl/expl can promise for a sum of thousands of such terms -- flips knife-edge
+    truncations and with them a few phred values, in the oracle itself. (A build that took read group 0's weights from
+    the host FPU, modelled the x87 multiply/divide/add bit for bit on the GPU and added the pairs in the oracle's order
+    made the FIRST iteration of every cell bit-identical; from the second on the frequency's last bits differed and the
+    same columns flipped as here, at 2.5x the stage-2 time: DESIGN.md 4.) Nothing but phred values, supporting-pair
+    counts and the last digits of LR / AF may move."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from popdel_amd import capi
+    from test_gpu_fuzz import random_case
+    lib = capi.load_library(ORACLE_LIB)
+    changed = 0
+    for seed in (105, 113):
+        seg, rgs, offs, opts = random_case(seed)
+        out = []
+        for mode in ("0", "3"):
+            monkeypatch.setenv("POPDEL_ORACLE_PERTURB_FREQ", mode)
+            ctx = capi.Context(lib, rgs, offs, **opts)
+            out.append(ctx.collect(ctx.submit(seg)))
+            ctx.close()
+        a, b = out
+        for k in ("deletion_length", "position", "end_position", "iterations", "first_last"):
+            assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(np.argmin(a["pl"], axis=2), np.argmin(b["pl"], axis=2))
+        assert np.allclose(a["likelihood_ratio"], b["likelihood_ratio"], rtol=1e-6, atol=1e-4)
+        changed += int((a["pl"] != b["pl"]).any(axis=2).sum())
+    assert 1 <= changed <= 10

@@ -1,41 +1,45 @@
-"""GPU box: python tools/debug_fuzz.py <seed> -- HIP against the oracle on one fuzz cohort; lists what differs and, for the first
-differing call, the EM traces of both sides (POPDEL_TRACE_POS: a debugging aid of library and oracle, results unchanged)."""
-import os, subprocess, sys
+"""Debug helper (GPU box): python tools/debug_fuzz.py <seed> -- prints where HIP and oracle differ for a fuzz case."""
+import os, sys
+import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np
-
-def run(seed):
-    from test_gpu_fuzz import random_case
-    from test_gpu_parity import both
-    seg, rgs, offs, opts = random_case(seed)
-    return both(seg, rgs, offs, **opts), opts
-
-if len(sys.argv) > 2 and sys.argv[2] == "trace":
-    run(int(sys.argv[1]))
-    sys.exit(0)
+from conftest import ORACLE_LIB
+from test_gpu_fuzz import random_case
+from popdel_amd import capi
 seed = int(sys.argv[1])
-((gc, gq, gf), (oc, oq, of)), opts = run(seed)
-print("seed", seed, "options", opts, "calls", gc["n_calls"], oc["n_calls"], "stage 1 equal", np.array_equal(gq, oq) and np.array_equal(gf, of))
-if gc["n_calls"] != oc["n_calls"]:
-    sys.exit("call counts differ")
-first = None
-for i in range(gc["n_calls"]):
-    what = [k for k in ("initial_length", "iterations", "deletion_length", "window_position", "position", "end_position", "filter")
-            if gc[k][i] != oc[k][i]]
-    cols = [s for s in range(gc["n_samples"]) if any((gc[k][i, s] != oc[k][i, s]).any() for k in ("pl", "lad", "dad", "first_last"))]
-    dlr = abs(gc["likelihood_ratio"][i] - oc["likelihood_ratio"][i])
-    daf = abs(gc["frequency"][i] - oc["frequency"][i])
-    if what or cols or dlr > 1e-6 * max(1, abs(oc["likelihood_ratio"][i])) or daf > 1e-6:
-        print("call %d window_position %d init %d: fields %s, %d columns %s, |dLR| %.3g |dAF| %.3g, iterations %d/%d len %d/%d"
-              % (i, oc["window_position"][i], oc["initial_length"][i], what, len(cols), cols[:8], dlr, daf, gc["iterations"][i],
-                 oc["iterations"][i], gc["deletion_length"][i], oc["deletion_length"][i]))
-        for s in cols[:3]:
-            print("    sample %d: pl %s / %s lad %s / %s" % (s, gc["pl"][i, s], oc["pl"][i, s], gc["lad"][i, s], oc["lad"][i, s]))
-        if first is None:
-            first = int(oc["window_position"][i]) + 1
-if first is not None:
-    env = dict(os.environ, POPDEL_TRACE_POS=str(first))
-    out = subprocess.run([sys.executable, os.path.abspath(__file__), str(seed), "trace"], env=env, capture_output=True, text=True)
-    print("---- traces of the window at", first)
-    print("\n".join(l for l in out.stderr.splitlines() if "trace]" in l))
+seg, rgs, offs, opts = random_case(seed)
+print("opts", opts, "n", len(offs) - 1, "W", seg.n_windows, "rg0 median/sd/readlen", rgs[0].median, rgs[0].stddev, rgs[0].read_length, "maxload", rgs[0].max_load)
+res = []
+st = []
+for lib in (capi.load_hip(), capi.load_library(ORACLE_LIB)):
+    ctx = capi.Context(lib, rgs, offs, **opts)
+    res.append(ctx.collect(ctx.submit(seg)))
+    st.append(ctx.stage1())
+g, o = res
+(gq, gf), (oq, of) = st
+print("q3 differs at", int((gq != oq).sum()), "flags differ at", int((gf != of).sum()))
+if (gq != oq).any():
+    idx = np.argwhere(gq != oq)
+    for t in idx[:8]:
+        print("   window", t[0], "sample", t[1], "gpu", gq[t[0], t[1]], "cpu", oq[t[0], t[1]], "flags", gf[t[0], t[1]], of[t[0], t[1]])
+print("calls", g["n_calls"], o["n_calls"])
+for k in g:
+    if k in ("n_calls", "n_samples"): continue
+    a, b = np.asarray(g[k]), np.asarray(o[k])
+    if a.shape != b.shape:
+        print(k, "shape", a.shape, b.shape)
+        if k == "window_position":
+            print("   gpu only", sorted(set(zip(g["window_position"].tolist(), g["initial_length"].tolist())) - set(zip(o["window_position"].tolist(), o["initial_length"].tolist())))[:10])
+            print("   cpu only", sorted(set(zip(o["window_position"].tolist(), o["initial_length"].tolist())) - set(zip(g["window_position"].tolist(), g["initial_length"].tolist())))[:10])
+        continue
+    if a.dtype.kind == "f":
+        d = np.abs(a - b)
+        print(k, "max abs diff", d.max() if d.size else 0)
+    else:
+        idx = np.argwhere(a != b)
+        print(k, "differs at", len(idx))
+        for t in idx[:12]:
+            c, s = int(t[0]), (int(t[1]) if len(t) > 1 else -1)
+            print("   call", c, "sample", s, "gpu", a[c, s] if s >= 0 else a[c], "cpu", b[c, s] if s >= 0 else b[c],
+                  "| win", g["window_position"][c], "len", g["deletion_length"][c], "it", g["iterations"][c],
+                  "lad", g["lad"][c, s] if s >= 0 else "", "dad", g["dad"][c, s] if s >= 0 else "")

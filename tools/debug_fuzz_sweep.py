@@ -1,30 +1,32 @@
-"""Wider sweep (GPU box): python tools/debug_fuzz_sweep.py <first seed> <last seed>
-Demands what tests/test_gpu_fuzz.py demands (every integer field bit-exact, LR/AF within 1e-6) on more seeds."""
+"""Wider sweep (GPU box): python tools/debug_fuzz_sweep.py <first seed> <last seed> [snap]
+"snap" takes the knife edge out on both sides (oracle knob + test build of the library) and demands exact equality (tests/test_gpu_fuzz.py explains the knob)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np
-from test_gpu_fuzz import random_case
+from test_gpu_fuzz import random_case, assert_same_up_to_knife_edges
 from test_gpu_parity import assert_same, both
-fails = calls = cols = diff_cols = 0
+from conftest import HIP_SNAP_LIB
+snap = len(sys.argv) > 3 and sys.argv[3] == "snap"
+if snap:
+    os.environ["POPDEL_SNAP_SHIFTS"] = "1"
+tot_bad = tot_cols = fails = tot_div = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     seg, rgs, offs, opts = random_case(seed)
-    gpu, cpu = both(seg, rgs, offs, **opts)
-    (gc, _, _), (oc, _, _) = gpu, cpu
-    n = gc["n_calls"]
-    calls += n
-    cols += n * gc["n_samples"]
+    gpu, cpu = both(seg, rgs, offs, hip_library=HIP_SNAP_LIB if snap else None, **opts)
     try:
-        assert_same(gpu, cpu)
-        print("seed", seed, "calls", n, "exact", flush=True)
+        if snap:
+            assert_same(gpu, cpu)
+            _calls, nb = 0, 0
+        else:
+            _calls, nb, dv = assert_same_up_to_knife_edges(gpu, cpu, allowed_diverged=1)
+            tot_div += dv
+            if dv:
+                print("seed", seed, "has a diverged call")
     except AssertionError as e:
         fails += 1
-        d = 0
-        if n == oc["n_calls"] and n:
-            c = np.zeros(gc["pl"].shape[:2], bool)
-            for k in ("pl", "lad", "dad"):
-                c |= (gc[k] != oc[k]).any(axis=2)
-            d = int(c.sum())
-        diff_cols += d
-        print("seed", seed, "calls", n, "FAILED: %d sample columns differ;" % d, str(e)[:200].replace("\n", " "), flush=True)
-print("total: %d seeds failed, %d calls, %d sample columns, %d differing columns" % (fails, calls, cols, diff_cols))
+        print("seed", seed, "FAILED", str(e)[:300])
+        continue
+    cols = gpu[0]["pl"].shape[0] * gpu[0]["pl"].shape[1] if gpu[0]["n_calls"] else 0
+    tot_bad += nb; tot_cols += cols
+    print("seed", seed, "calls", gpu[0]["n_calls"], "columns", cols, "knife-edge", nb, flush=True)
+print("total knife-edge", tot_bad, "of", tot_cols, "columns; diverged calls", tot_div, "; failures", fails)
