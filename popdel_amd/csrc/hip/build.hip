@@ -14,25 +14,9 @@
 //   baseScanKernel    exclusive scan of the entities' chunk totals -> rgBase
 //   scatterKernel     per entity, ONE WAVE walking the instances in order: deterministic stable placement of every chunk
 //   scanGenericKernel 512-window blocks of multi-read-group samples in which a read group reaches maxLoad
-#include "pd_device.h"
+#include "pd_build.h"
 
 namespace pd {
-
-// Pair instances in device memory as uploaded: narrow (16-bit fields; start as distance back from the position of the
-// instance's first window) or wide (the caller's arrays as they are).
-struct InstanceArrays
-{
-    const int16_t *  dev16;
-    const uint16_t * on16;
-    const uint16_t * off16;
-    const uint16_t * back16;      // firstPos + on * shift - start
-    const int32_t *  dev32;
-    const uint32_t * on32;
-    const uint32_t * off32;
-    const uint32_t * start32;
-    int              wide;
-    uint32_t         firstPos, shift;
-};
 
 struct Instance
 {
@@ -59,16 +43,6 @@ __device__ __forceinline__ Instance loadInstance(const InstanceArrays & a, uint6
     }
     return r;
 }
-
-// Entities: the real read groups, then the scan read groups of the samples that have several read groups (they cover the
-// instances of all read groups of their sample, read group after read group).
-struct BuildEntities
-{
-    const uint64_t * rgOffsets;    // [nRg + 1] instance offsets of the real read groups
-    const uint32_t * sampleRg;     // [nSamples + 1]
-    const uint32_t * scanSample;   // [nScan] sample of a scan read group
-    uint32_t         nRg, nScan;
-};
 
 __device__ __forceinline__ void entityRange(const BuildEntities & en, unsigned e, unsigned & rgLo, unsigned & rgHi)
 {
@@ -120,16 +94,6 @@ __global__ __launch_bounds__(256) void lifeStatsKernel(InstanceArrays in, uint64
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-struct CountOut
-{
-    uint32_t * winStart;     // [nEnt][W + K]
-    uint32_t * endCount;     // [nEnt][W + 1]
-    uint32_t * entChunks;    // [nEnt]
-    uint32_t * entMax;       // [nEnt] chunks of the entity's densest 512-window block
-    uint8_t *  rgPacked;     // [nEnt]
-    unsigned * problems;     // [0]: instances out of `on` order
-};
-
 // Block-wide inclusive prefix sum of the LDS array v[0 .. n) in place (256 threads).
 __device__ __forceinline__ void blockPrefixInPlace(unsigned * v, unsigned n, unsigned * scratch /* [256] */)
 {
@@ -273,15 +237,6 @@ __global__ __launch_bounds__(256) void baseScanKernel(const uint32_t * __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-struct ScatterOut
-{
-    PairDO *         pairs;       // [real chunks]
-    uint32_t *       start;       // [real chunks]
-    uint2 *          pairsPk;     // [all chunks]
-    const uint64_t * rgBase;
-    const uint32_t * winStart;
-};
-
 // One wave per entity walks its instances in order, 64 at a time. The host builder files the chunks of a slot in instance
 // order (a cursor per slot, instances visited one after the other). Here: instances are ordered by `on`, so within a
 // block of 64 the instances with equal `on` are neighbours, and the m-th chunk of an instance (first window on + m K) has

@@ -1,6 +1,7 @@
 // C ABI of libpopdel_hip.so (include/popdel_hip.h): context, HBM staging of segments, launch orchestration and
 // result packing. No CPU fallback lives here: every entry point either runs the HIP kernels or fails.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -11,6 +12,7 @@
 #include <vector>
 
 #include "parallel.h"
+#include "pd_build.h"
 #include "pd_device.h"
 #include "popdel_hip.h"
 
@@ -223,6 +225,19 @@ struct pd_ctx
     PinnedBuf<int> hWinFlag, hFlagged, hCandLen, hCandCount;
     PinnedBuf<pd::CellState> hCells;
     PinnedBuf<unsigned> hCounters, hEmit, hIterFlag;
+    // device-side layout build (build.hip): the uploaded instances and the small tables around them
+    PinnedBuf<uint16_t> hIn16[4];           // dev, on, off, start distance (narrow upload)
+    PinnedBuf<uint32_t> hIn32[4];           // dev, on, off, start (wide upload)
+    PinnedBuf<uint64_t> hRgOffsets;
+    DevBuf<uint16_t> dIn16[4];
+    DevBuf<uint32_t> dIn32[4];
+    DevBuf<uint64_t> dRgOffsets, dTotals;
+    DevBuf<uint32_t> dScanSample, dEntChunks, dEntMax;
+    DevBuf<unsigned long long> dLifeHist;
+    DevBuf<unsigned> dProblems;
+    PinnedBuf<unsigned long long> hLifeHist;
+    PinnedBuf<uint64_t> hTotals;
+    PinnedBuf<uint32_t> hEntMax;
     uint64_t nextHandle = 1, nextTicket = 1;
     std::map<uint64_t, Run> runs;
 
@@ -545,6 +560,201 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
     }, 4);
 }
 
+// The same layout built on the device (build.hip) from instances that cross PCIe once: 8 bytes per instance when every
+// field fits 16 bits (deviation, window indices, distance of the pair start behind its first window), else 16.
+// Returns false if this segment has to take the host builder (window count beyond what the build kernels keep in LDS).
+bool buildChunksOnDevice(pd_ctx & c, const pd_segment & seg, StagedSegment & out)
+{
+    const uint32_t W = seg.n_windows, nRg = seg.n_readgroups, nV = static_cast<uint32_t>(c.scanSample.size()), nEnt = nRg + nV;
+    const uint64_t nInst = seg.rg_offsets[nRg];
+    if (pd::buildLdsBytes(W, 48) > 160u * 1024u || nInst == 0)
+        return false;
+    hipStream_t cs = c.copyStream;
+    // ---- narrow or wide? decided while packing; a segment that does not fit is packed again, wide
+    const bool narrowPossible = W <= 0xffffu;
+    std::atomic<bool> narrow(narrowPossible);
+    const size_t nSlabs = std::min<size_t>(8, std::max<size_t>(1, nRg / 64));
+    c.hRgOffsets.resize(nRg + 1);
+    std::memcpy(c.hRgOffsets.data(), seg.rg_offsets, (nRg + 1) * sizeof(uint64_t));
+    c.dRgOffsets.uploadPinned(c.hRgOffsets, cs);
+    if (narrowPossible)
+    {
+        for (int k = 0; k < 4; ++k)
+        {
+            c.hIn16[k].resize(nInst);
+            c.dIn16[k].ensure(nInst);
+        }
+        for (size_t slab = 0; slab < nSlabs && narrow.load(); ++slab)
+        {
+            const size_t rgLo = nRg * slab / nSlabs, rgHi = nRg * (slab + 1) / nSlabs;
+            pdh::parallelFor(rgHi - rgLo, [&](size_t k) {
+                const size_t rg = rgLo + k;
+                bool ok = true;
+                int16_t * dv = reinterpret_cast<int16_t *>(c.hIn16[0].data());
+                uint16_t *on = c.hIn16[1].data(), *off = c.hIn16[2].data(), *back = c.hIn16[3].data();
+                for (uint64_t i = seg.rg_offsets[rg]; i < seg.rg_offsets[rg + 1]; ++i)
+                {
+                    const int32_t d = seg.pair_dev[i];
+                    const uint32_t a = seg.pair_on[i], b = std::min(seg.pair_off[i], W);
+                    const int64_t dist = static_cast<int64_t>(seg.first_window_pos) + static_cast<int64_t>(a) * seg.window_shift -
+                                         static_cast<int64_t>(seg.pair_start[i]);
+                    ok = ok && d >= -32768 && d <= 32767 && a <= 0xffffu && dist >= 0 && dist <= 0xffff;
+                    dv[i] = static_cast<int16_t>(d);
+                    on[i] = static_cast<uint16_t>(a);
+                    off[i] = static_cast<uint16_t>(b);
+                    back[i] = static_cast<uint16_t>(dist);
+                }
+                if (!ok)
+                    narrow.store(false);
+            }, 8);
+            if (!narrow.load())
+                break;
+            const uint64_t a = seg.rg_offsets[rgLo], b = seg.rg_offsets[rgHi];
+            for (int k = 0; k < 4 && b > a; ++k)
+                PD_HIP(hipMemcpyAsync(c.dIn16[k].p + a, c.hIn16[k].data() + a, (b - a) * sizeof(uint16_t), hipMemcpyHostToDevice, cs));
+        }
+    }
+    if (!narrow.load())
+    {
+        const void * src[4] = {seg.pair_dev, seg.pair_on, seg.pair_off, seg.pair_start};
+        for (int k = 0; k < 4; ++k)
+        {
+            c.hIn32[k].resize(nInst);
+            c.dIn32[k].ensure(nInst);
+        }
+        for (size_t slab = 0; slab < nSlabs; ++slab)
+        {
+            const size_t rgLo = nRg * slab / nSlabs, rgHi = nRg * (slab + 1) / nSlabs;
+            const uint64_t a = seg.rg_offsets[rgLo], b = seg.rg_offsets[rgHi];
+            if (b == a)
+                continue;
+            // page-locked staging copy, split over the host threads
+            const size_t pieces = 64;
+            pdh::parallelFor(pieces * 4, [&](size_t j) {
+                const int k = static_cast<int>(j / pieces);
+                const uint64_t lo = a + (b - a) * (j % pieces) / pieces, hi = a + (b - a) * (j % pieces + 1) / pieces;
+                std::memcpy(c.hIn32[k].data() + lo, static_cast<const uint32_t *>(src[k]) + lo, (hi - lo) * sizeof(uint32_t));
+            });
+            for (int k = 0; k < 4; ++k)
+                PD_HIP(hipMemcpyAsync(c.dIn32[k].p + a, c.hIn32[k].data() + a, (b - a) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
+        }
+    }
+    pd::InstanceArrays in;
+    std::memset(&in, 0, sizeof(in));
+    in.wide = narrow.load() ? 0 : 1;
+    in.dev16 = reinterpret_cast<const int16_t *>(c.dIn16[0].p);
+    in.on16 = c.dIn16[1].p;
+    in.off16 = c.dIn16[2].p;
+    in.back16 = c.dIn16[3].p;
+    in.dev32 = reinterpret_cast<const int32_t *>(c.dIn32[0].p);
+    in.on32 = c.dIn32[1].p;
+    in.off32 = c.dIn32[2].p;
+    in.start32 = c.dIn32[3].p;
+    in.firstPos = seg.first_window_pos;
+    in.shift = seg.window_shift;
+    pd::BuildEntities en;
+    en.rgOffsets = c.dRgOffsets.p;
+    en.sampleRg = c.dSampleRg.p;
+    en.scanSample = c.dScanSample.p;
+    en.nRg = nRg;
+    en.nScan = nV;
+    // ---- K from the lifetime histogram (the rule of the host builder)
+    c.dLifeHist.ensure(67);
+    c.hLifeHist.resize(67);
+    PD_HIP(hipMemsetAsync(c.dLifeHist.p, 0, 67 * sizeof(unsigned long long), cs));
+    pd::launchLifeStats(in, nInst, W, c.dLifeHist.p, cs);
+    PD_HIP(hipGetLastError());
+    PD_HIP(hipMemcpyAsync(c.hLifeHist.data(), c.dLifeHist.p, 67 * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+    PD_HIP(hipStreamSynchronize(cs));
+    uint64_t living = 0;
+    for (int l = 0; l <= 65; ++l)
+        living += c.hLifeHist[l];
+    uint32_t K = 4;
+    {
+        uint64_t acc = 0;
+        const uint64_t want = living - living / 64;       // ~98.4 %
+        for (uint32_t l = 0; l <= 65; ++l)
+        {
+            acc += c.hLifeHist[l];
+            if (acc >= want)
+            {
+                K = std::max<uint32_t>(4, l);
+                break;
+            }
+        }
+        K = std::min<uint32_t>(K, 48);
+    }
+    if (const char * e = getenv("POPDEL_HIP_MAXLIFE"))
+        K = std::max(1, atoi(e));
+    if (pd::buildLdsBytes(W, K) > 160u * 1024u)
+        return false;
+    out.maxLife = K;
+    out.nPairs = living;
+    out.nActivePairs = c.hLifeHist[66];
+    // ---- counts -> index rows, chunk totals -> bases
+    const size_t wsRow = static_cast<size_t>(W) + K;
+    out.winStart.ensure(static_cast<size_t>(nEnt) * wsRow);
+    out.endCount.ensure(static_cast<size_t>(nEnt) * (W + 1));
+    out.rgBase.ensure(nEnt);
+    out.rgPacked.ensure(nEnt);
+    c.dEntChunks.ensure(nEnt);
+    c.dEntMax.ensure(nEnt);
+    c.dTotals.ensure(2);
+    c.dProblems.ensure(1);
+    c.hTotals.resize(3);
+    PD_HIP(hipMemsetAsync(c.dProblems.p, 0, sizeof(unsigned), cs));
+    pd::CountOut co;
+    co.winStart = out.winStart.p;
+    co.endCount = out.endCount.p;
+    co.entChunks = c.dEntChunks.p;
+    co.entMax = c.dEntMax.p;
+    co.rgPacked = out.rgPacked.p;
+    co.problems = c.dProblems.p;
+    if (!pd::launchCount(in, en, W, K, co, cs))
+        throw HipError{"the layout build kernel cannot get its LDS"};
+    PD_HIP(hipGetLastError());
+    pd::launchBaseScan(c.dEntChunks.p, nEnt, nRg, out.rgBase.p, c.dTotals.p, cs);
+    PD_HIP(hipGetLastError());
+    c.hEntMax.resize(nEnt);
+    PD_HIP(hipMemcpyAsync(c.hTotals.data(), c.dTotals.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
+    PD_HIP(hipMemcpyAsync(c.hTotals.data() + 2, c.dProblems.p, sizeof(unsigned), hipMemcpyDeviceToHost, cs));
+    PD_HIP(hipMemcpyAsync(c.hEntMax.data(), c.dEntMax.p, nEnt * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+    PD_HIP(hipStreamSynchronize(cs));
+    if (static_cast<unsigned>(c.hTotals[2] & 0xffffffffu) != 0)
+        throw HipError{"pair instances of a read group are not ordered by their first window (pd_segment: non-decreasing `on`)"};
+    const uint64_t totalReal = c.hTotals[0], totalAll = c.hTotals[1];
+    out.nChunks = totalReal;
+    {
+        // ... of 99 % of the streams: a few unusually deep samples should not cost everybody else occupancy
+        std::vector<uint32_t> entMax(c.hEntMax.data(), c.hEntMax.data() + nEnt);
+        std::sort(entMax.begin(), entMax.end());
+        out.maxBlockChunks = entMax.empty() ? 0 : entMax[std::min(entMax.size() - 1, entMax.size() * 99 / 100)];
+    }
+    // ---- chunks to their places
+    out.pairs.ensure(totalReal);
+    out.start.ensure(totalReal);
+    out.pairsPk.ensure(totalAll);
+    pd::ScatterOut so;
+    so.pairs = out.pairs.p;
+    so.start = out.start.p;
+    so.pairsPk = out.pairsPk.p;
+    so.rgBase = out.rgBase.p;
+    so.winStart = out.winStart.p;
+    if (!pd::launchScatter(in, en, W, K, so, cs))
+        throw HipError{"the layout scatter kernel cannot get its LDS"};
+    PD_HIP(hipGetLastError());
+    const size_t blocksPerSample = (static_cast<size_t>(W) + 2 * pd::kStage1Block - 1) / (2 * pd::kStage1Block);
+    out.hasScanGeneric = nV != 0;
+    if (nV != 0)
+    {
+        out.scanGeneric.ensure(static_cast<size_t>(nV) * blocksPerSample);
+        PD_HIP(hipMemsetAsync(out.scanGeneric.p, 0, static_cast<size_t>(nV) * blocksPerSample, cs));
+        pd::launchScanGeneric(en, c.dRg.p, out.winStart.p, out.endCount.p, W, K, out.scanGeneric.p, static_cast<unsigned>(blocksPerSample), cs);
+        PD_HIP(hipGetLastError());
+    }
+    return true;
+}
+
 pd::SegmentView viewOf(const StagedSegment & s)
 {
     pd::SegmentView v;
@@ -646,6 +856,7 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
             rc.push_back(v);
         }
         c->dScanRg.upload(scanRg, c->stream);
+        c->dScanSample.upload(c->scanSample, c->stream);
         {
             // multi tiles: 256-sample tiles with at least one multi-read-group sample
             std::vector<uint32_t> mtTile, mtRgLo, mtRgHi, mtWaveBase, mtWaveTile, rgSample(n_readgroups);
@@ -839,6 +1050,18 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
         s->firstPos = seg->first_window_pos;
         s->nWindows = seg->n_windows;
         s->shift = seg->window_shift;
+        // the layout is built on the device from instances that cross PCIe once; POPDEL_HIP_HOST_BUILD=1 (A/B runs; the
+        // results are identical) or a window count beyond the build kernels' LDS selects the host builder below
+        const bool onDevice = !getenv("POPDEL_HIP_HOST_BUILD") && buildChunksOnDevice(*c, *seg, *s);
+        if (onDevice)
+        {
+            s->scanRg = c->dScanRg.p;
+            s->nRealRg = c->nRg;
+            PD_HIP(hipStreamSynchronize(c->copyStream));   // the host scratch is reused by the next call
+            *handle = c->nextHandle++;
+            c->staged[*handle] = std::move(s);
+            return 0;
+        }
         PinnedBuf<pd::PairDO> & pairs = c->hPairs;
         PinnedBuf<uint32_t> &start = c->hStart, &winStart = c->hWinStart, &endCount = c->hEndCount;
         std::vector<uint64_t> & rgBase = c->hRgBase;

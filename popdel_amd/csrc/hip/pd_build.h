@@ -1,0 +1,63 @@
+// Device-side construction of the staged segment layout: interface between build.hip (kernels) and capi.hip (staging).
+#ifndef PD_BUILD_H_
+#define PD_BUILD_H_
+
+#include "pd_device.h"
+
+namespace pd {
+
+// Pair instances in device memory as uploaded: narrow (16-bit fields; start as distance back from the position of the
+// instance's first window) or wide (the caller's arrays as they are).
+struct InstanceArrays
+{
+    const int16_t *  dev16;
+    const uint16_t * on16;
+    const uint16_t * off16;
+    const uint16_t * back16;      // firstPos + on * shift - start
+    const int32_t *  dev32;
+    const uint32_t * on32;
+    const uint32_t * off32;
+    const uint32_t * start32;
+    int              wide;
+    uint32_t         firstPos, shift;
+};
+
+// Entities: the real read groups, then the scan read groups of the samples that have several read groups (they cover the
+// instances of all read groups of their sample, read group after read group).
+struct BuildEntities
+{
+    const uint64_t * rgOffsets;    // [nRg + 1] instance offsets of the real read groups
+    const uint32_t * sampleRg;     // [nSamples + 1]
+    const uint32_t * scanSample;   // [nScan] sample of a scan read group
+    uint32_t         nRg, nScan;
+};
+
+struct CountOut
+{
+    uint32_t * winStart;     // [nEnt][W + K]
+    uint32_t * endCount;     // [nEnt][W + 1]
+    uint32_t * entChunks;    // [nEnt]
+    uint32_t * entMax;       // [nEnt] chunks of the entity's densest 512-window block
+    uint8_t *  rgPacked;     // [nEnt]
+    unsigned * problems;     // [0]: instances out of `on` order
+};
+
+struct ScatterOut
+{
+    PairDO *         pairs;       // [real chunks]
+    uint32_t *       start;       // [real chunks]
+    uint2 *          pairsPk;     // [all chunks]
+    const uint64_t * rgBase;
+    const uint32_t * winStart;
+};
+
+void launchLifeStats(const InstanceArrays & in, uint64_t n, unsigned W, unsigned long long * hist, hipStream_t st);
+size_t buildLdsBytes(unsigned W, unsigned K);
+bool launchCount(const InstanceArrays & in, const BuildEntities & en, unsigned W, unsigned K, const CountOut & out, hipStream_t st);
+void launchBaseScan(const uint32_t * entChunks, unsigned nEnt, unsigned nRg, uint64_t * rgBase, uint64_t * totals, hipStream_t st);
+bool launchScatter(const InstanceArrays & in, const BuildEntities & en, unsigned W, unsigned K, const ScatterOut & out, hipStream_t st);
+void launchScanGeneric(const BuildEntities & en, const RgConst * rgConst, const uint32_t * winStart, const uint32_t * endCount, unsigned W,
+                       unsigned K, uint8_t * scanGeneric, unsigned blocksPerSample, hipStream_t st);
+
+}  // namespace pd
+#endif
