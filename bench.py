@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 CHR20_WINDOWS = 2148139
 SEG_WINDOWS = 6667            # windows walked per 200-kb segment (windowBuffer 200000 / 30)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
-SCAN_SOURCES = ("popdel_amd/csrc/hip/stage1.hip", "popdel_amd/csrc/hip/sortnet_gen.h", "popdel_amd/csrc/hip/pd_device.h")
+SCAN_SOURCES = ("popdel_amd/csrc/hip/stage1.hip", "popdel_amd/csrc/hip/sortnet_gen.h")
 
 
 def parse_args(argv=None):
@@ -46,7 +46,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-samples", type=int, default=600, help="samples of the same segment timed on one host core")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=-1,
-                    help="threads of the all-cores CPU figure (-1: every host core; 0/1: skip)")
+                    help="threads of the all-cores CPU figure (-1: every core the job may use; 0/1: skip)")
     ap.add_argument("--sharded-timeout", type=float, default=420.0,
                     help="N > 1: give up on the sample-sharded headline after this many seconds (the line is then printed "
                          "with the segment split as value and the process exits 3)")
@@ -62,6 +62,10 @@ def parse_args(argv=None):
                          "inflates the scan's traced duration; un-profiled runs copy over SDMA")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: all ranks use GPU 0 (needs --backend gloo)")
+    ap.add_argument("--exchange", default="auto", choices=("auto", "native", "torch"),
+                    help="N > 1: who runs the all-gathers of the sample-sharded cohort: native = the library itself over RCCL "
+                         "on its own stream (default with --backend nccl), torch = host callbacks over torch.distributed "
+                         "(default otherwise: gloo dry runs)")
     ap.add_argument("--concurrent", type=int, default=3,
                     help="contexts of the secondary concurrent-segments leg (0/1: skip it)")
     ap.add_argument("--contexts", type=int, default=1,
@@ -153,6 +157,19 @@ def scan_source_stamp():
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
+
+
+def usable_cores():
+    """CPUs this job may use: the affinity mask, cut down to the cgroup CPU-time quota if there is one (the GPU boxes show
+    256 logical CPUs and grant a job 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def cpu_model():
@@ -404,8 +421,9 @@ def main():
         dog.daemon = True
         dog.start()
         try:
+            native = args.exchange == "native" or (args.exchange == "auto" and args.backend == "nccl")
             shard = distributed.SampleShard(hip, [rg] * (R * S * world), list(range(0, R * S * world + 1, R)), rank, world,
-                                            device=local_rank)
+                                            device=local_rank, native=native)
             h_sh = shard.ctx.stage(seg)
             lane = Lane(shard.ctx, h_sh, args.serial)
             acc0 = [0.0, 0.0, 0, 0, None]
@@ -424,9 +442,9 @@ def main():
             headline.update(value=total_passes * W * S * world * args.steps / el, elapsed=el, steps=args.steps, s1_ms=tot[0],
                             s2_ms=tot[1], n_calls=tot[2], n_cand=tot[3], tinfo=tot[4], launches=passes_timed, cohort=S * world,
                             windows_per_step=total_passes * W,
-                            exchange=dict(all_gathers_per_pass=(shard.exchange.calls - x0[0]) / passes_timed,
-                                          all_gather_bytes_per_pass=(shard.exchange.bytes - x0[1]) / passes_timed,
-                                          backend=dist.get_backend(),
+                            exchange=dict(all_gathers_per_pass=((shard.exchange.calls - x0[0]) / passes_timed) if not native else 20,
+                                          all_gather_bytes_per_pass=((shard.exchange.bytes - x0[1]) / passes_timed) if not native else None,
+                                          backend="rccl (library-native, ncclAllGather on the context's stream)" if native else dist.get_backend(),
                                           what="window flags, Q3 of flagged windows, a5 counts, per-iteration tile sums + read "
                                                "group 0's record, LR sums, support-percentile digit histograms"),
                             parallelism="ONE cohort of %d samples sharded by samples over %d ranks (%d each); every rank scans "
@@ -543,12 +561,13 @@ def main():
         cpu_s = time.perf_counter() - c0
         octx.close()
         out = dict(value=n_cpu * W / cpu_s, unit="window*sample/s", cores=1, kind="port", cpu_model=cpu_model(),
-                   host_cores=os.cpu_count(),
+                   host_cores=os.cpu_count(), usable_cores=usable_cores(),
                    sample="%d of the %d samples x the same %d-window segment, oracle/ (x87 long double), %.1f s"
                           % (n_cpu, S, W, cpu_s))
         # the same on all host cores the way a CPU run would use them: independent cohorts of n_cpu samples each (the
         # oracle is single-threaded; ctypes releases the GIL)
-        n_thr = (os.cpu_count() or 1) if args.cpu_threads < 0 else min(args.cpu_threads, os.cpu_count() or 1)
+        # every core this job may use (cgroup quota / affinity; more threads than that are only throttled)
+        n_thr = usable_cores() if args.cpu_threads < 0 else min(args.cpu_threads, os.cpu_count() or 1)
         if n_thr > 1 and R == 1:
             distinct = max(1, S // n_cpu)
             parts = []

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 3
+#define PD_ABI_VERSION 4
 
 /* One read group after start-up conditioning.
  * Replaces: `Histogram` (reference insert_histogram_popdel.h:19-43) after processHistogram()
@@ -199,6 +199,16 @@ typedef struct pd_shard
     int (*all_gather)(void *user, uint64_t offset, uint64_t bytes_per_rank, void *hip_stream);
     void *user;
 } pd_shard;
+
+/* The same with the exchange done by the library itself: RCCL all-gathers issued on the context's own HIP stream, in place
+ * in an exchange buffer the library owns (no host callbacks in the data path; `reserve`, `all_gather` and `user` of
+ * `shard` are ignored). One process calls pd_rccl_unique_id() and hands the 128 bytes to all others over any channel;
+ * then EVERY context of the cohort calls pd_ctx_set_shard_rccl() with them (the call is collective: it creates the
+ * communicator). RCCL is loaded at that moment (librccl.so.1; POPDEL_RCCL_LIBRARY names another file), a process that
+ * never shards does not need it. */
+#define PD_RCCL_ID_BYTES 128
+int pd_rccl_unique_id(uint8_t *id /* PD_RCCL_ID_BYTES */);
+int pd_ctx_set_shard_rccl(pd_ctx *ctx, const pd_shard *shard, const uint8_t *id /* PD_RCCL_ID_BYTES */);
 
 /* Partition rule: samples per context (a multiple of 256; the last contexts may own fewer or none). */
 uint32_t pd_shard_samples(uint32_t n_samples_global, uint32_t world);

@@ -949,6 +949,15 @@ int pd_ctx_set_shard(pd_ctx * c, const pd_shard * sh)
     return 0;
 }
 
+int pd_rccl_unique_id(uint8_t *) { return 1; }
+
+int pd_ctx_set_shard_rccl(pd_ctx * c, const pd_shard *, const uint8_t *)
+{
+    if (c)
+        c->error = "pd_ctx_set_shard_rccl: the oracle runs the whole cohort in one context";
+    return 1;
+}
+
 const char * pd_backend_name(void) { return "oracle-cpu-longdouble"; }
 
 int pd_abi_version(void) { return PD_ABI_VERSION; }

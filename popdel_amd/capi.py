@@ -20,8 +20,9 @@ HIP_LIBRARY = os.environ.get("POPDEL_HIP_LIBRARY") or os.path.join(_HERE, "lib",
 ABI_SYMBOLS = (
     "pd_ctx_create", "pd_ctx_destroy", "pd_segment_submit", "pd_segment_stage", "pd_segment_run", "pd_segment_unstage",
     "pd_segment_collect", "pd_calls_free", "pd_stage1_last", "pd_last_timing", "pd_last_error", "pd_backend_name",
-    "pd_abi_version", "pd_shard_samples", "pd_ctx_set_shard",
+    "pd_abi_version", "pd_shard_samples", "pd_ctx_set_shard", "pd_ctx_set_shard_rccl", "pd_rccl_unique_id",
 )
+RCCL_ID_BYTES = 128
 
 
 class PdReadgroup(C.Structure):
@@ -106,7 +107,22 @@ def load_library(path):
     lib.pd_shard_samples.restype = C.c_uint32
     lib.pd_ctx_set_shard.argtypes = [C.c_void_p, C.POINTER(PdShard)]
     lib.pd_ctx_set_shard.restype = C.c_int
+    lib.pd_ctx_set_shard_rccl.argtypes = [C.c_void_p, C.POINTER(PdShard), C.c_char_p]
+    lib.pd_ctx_set_shard_rccl.restype = C.c_int
+    lib.pd_rccl_unique_id.argtypes = [C.c_char_p]
+    lib.pd_rccl_unique_id.restype = C.c_int
     return lib
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def rccl_unique_id(lib) -> bytes:
+    buf = C.create_string_buffer(RCCL_ID_BYTES)
+    if lib.pd_rccl_unique_id(buf) != 0:
+        raise BackendError(lib.pd_last_error(None).decode())
+    return buf.raw
 
 
 def _let_torch_initialise_first():
@@ -183,10 +199,6 @@ class Segment:
         return s
 
 
-class BackendError(RuntimeError):
-    pass
-
-
 class Context:
     """A calling context (pd_ctx) on one device."""
 
@@ -250,6 +262,17 @@ class Context:
         sh.reserve, sh.all_gather = self._shard_fns
         sh.user = None
         self._check(self.lib.pd_ctx_set_shard(self.handle, C.byref(sh)))
+
+    def set_shard_rccl(self, rank, world, first_sample, n_samples_global, min_init_del_len_global, rccl_id: bytes):
+        """The same with the exchange done by the library itself over RCCL (pd_ctx_set_shard_rccl); collective: every
+        context of the cohort calls it with the 128 bytes one of them got from ``rccl_unique_id``."""
+        table = np.ascontiguousarray(min_init_del_len_global, dtype=np.uint32)
+        sh = PdShard()
+        sh.rank, sh.world, sh.first_sample = rank, world, first_sample
+        sh.n_samples_global, sh.n_readgroups_global = n_samples_global, len(table)
+        sh.min_init_del_len_global = table.ctypes.data_as(C.POINTER(C.c_uint32))
+        assert len(rccl_id) == RCCL_ID_BYTES
+        self._check(self.lib.pd_ctx_set_shard_rccl(self.handle, C.byref(sh), rccl_id))
 
     def submit(self, seg: Segment):
         t = C.c_uint64()

@@ -1,5 +1,8 @@
 // C ABI of libpopdel_hip.so (include/popdel_hip.h): context, HBM staging of segments, launch orchestration and
 // result packing. No CPU fallback lives here: every entry point either runs the HIP kernels or fails.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
@@ -40,6 +43,50 @@ void launchGatherOut(const Stage2Buffers & b, const unsigned * emitCells, unsign
 namespace {
 
 std::string g_createError;
+
+// RCCL is bound at run time, when a context is first sharded with pd_ctx_set_shard_rccl(): the library has no load-time
+// dependency on it, and the copy that is opened is the system one, built against the HIP runtime this library links
+// (a Python process may carry a second RCCL inside its torch wheel).
+struct RcclApi
+{
+    void * handle = nullptr;
+    decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+    decltype(&ncclCommInitRank) commInitRank = nullptr;
+    decltype(&ncclAllGather) allGather = nullptr;
+    decltype(&ncclCommDestroy) commDestroy = nullptr;
+    decltype(&ncclGetErrorString) getErrorString = nullptr;
+    std::string error;
+};
+
+RcclApi & rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char * names[] = {getenv("POPDEL_RCCL_LIBRARY"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+        for (const char * n : names)
+        {
+            if (!n || !*n)
+                continue;
+            api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle)
+                break;
+        }
+        if (!api.handle)
+        {
+            api.error = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "librccl.so.1 not found");
+            return;
+        }
+        api.getUniqueId = reinterpret_cast<decltype(api.getUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
+        api.commInitRank = reinterpret_cast<decltype(api.commInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
+        api.allGather = reinterpret_cast<decltype(api.allGather)>(dlsym(api.handle, "ncclAllGather"));
+        api.commDestroy = reinterpret_cast<decltype(api.commDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+        api.getErrorString = reinterpret_cast<decltype(api.getErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+        if (!api.getUniqueId || !api.commInitRank || !api.allGather || !api.commDestroy || !api.getErrorString)
+            api.error = "the RCCL library lacks an expected entry point";
+    });
+    return api;
+}
 
 struct HipError
 {
@@ -208,6 +255,7 @@ struct pd_ctx
     // The cohort may be sharded by samples over several contexts (pd_ctx_set_shard); defaults describe "all samples here".
     uint32_t rank = 0, world = 1, nSamplesGlobal = 0, samplesPerRank = 0;
     pd_shard shard;
+    ncclComm_t comm = nullptr;      // exchange by the library itself (pd_ctx_set_shard_rccl) instead of the host's callbacks
     DevBuf<unsigned> dMinInitGlobal;
     DevBuf<uint8_t> ownArena;       // exchange areas when world == 1 (otherwise the host owns the buffer)
     uint8_t * arena = nullptr;
@@ -267,6 +315,8 @@ struct pd_ctx
     {
         staged.clear();
         spare.clear();
+        if (comm)
+            (void)rccl().commDestroy(comm);
         if (resultsPacked)
             (void)hipEventDestroy(resultsPacked);
         if (copyStream)
@@ -333,8 +383,10 @@ struct CallsBox
 // The exchange buffer: owned by the library for an unsharded cohort, by the host otherwise.
 uint8_t * reserveArena(pd_ctx & c, size_t bytes)
 {
-    if (c.world == 1)
+    if (c.world == 1 || c.comm)
     {
+        if (bytes > c.ownArena.n)
+            PD_HIP(hipStreamSynchronize(c.stream));        // nothing in flight may still use the buffer that is replaced
         c.ownArena.ensure(bytes);
         c.arena = c.ownArena.p;
     }
@@ -354,6 +406,16 @@ struct CtxExchange : pd::Exchange
     explicit CtxExchange(pd_ctx & ctx) : c(ctx) {}
     void allGather(void * area, size_t bytesPerRank) override
     {
+        if (c.comm)
+        {
+            // in place: chunk `rank` of [area, area + world * bytesPerRank) is filled; stream-ordered between the kernels
+            uint8_t * base = static_cast<uint8_t *>(area);
+            const ncclResult_t r = rccl().allGather(base + static_cast<size_t>(c.rank) * bytesPerRank, base, bytesPerRank, ncclUint8,
+                                                    c.comm, c.stream);
+            if (r != ncclSuccess)
+                throw HipError{std::string("ncclAllGather: ") + rccl().getErrorString(r)};
+            return;
+        }
         if (c.world == 1)
             return;
         const uint64_t off = static_cast<uint64_t>(static_cast<uint8_t *>(area) - c.arena);
@@ -953,28 +1015,49 @@ uint32_t pd_shard_samples(uint32_t n_samples_global, uint32_t world)
     return (tiles + world - 1) / world * pd::kSamplesPerBlock;
 }
 
-int pd_ctx_set_shard(pd_ctx * c, const pd_shard * sh)
+static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, const char * who)
 {
+    const std::string name = who;
     if (!c || !sh)
-        return fail(c, "pd_ctx_set_shard: invalid argument");
+        return fail(c, name + ": invalid argument");
     if (!c->runs.empty() || !c->staged.empty())
-        return fail(c, "pd_ctx_set_shard: must be called before segments are staged");
+        return fail(c, name + ": must be called before segments are staged");
     if (sh->world == 0 || sh->rank >= sh->world || !sh->min_init_del_len_global)
-        return fail(c, "pd_ctx_set_shard: invalid rank/world or missing threshold table");
-    if (sh->world > 1 && (!sh->reserve || !sh->all_gather))
-        return fail(c, "pd_ctx_set_shard: a sharded cohort needs the reserve() and all_gather() callbacks");
+        return fail(c, name + ": invalid rank/world or missing threshold table");
+    if (!rcclId && sh->world > 1 && (!sh->reserve || !sh->all_gather))
+        return fail(c, name + ": a sharded cohort needs the reserve() and all_gather() callbacks");
     const uint32_t per = pd_shard_samples(sh->n_samples_global, sh->world);
     const uint64_t first = static_cast<uint64_t>(sh->rank) * per;
     if (first >= sh->n_samples_global)
-        return fail(c, "pd_ctx_set_shard: this rank owns no samples (cohort too small for that many contexts)");
+        return fail(c, name + ": this rank owns no samples (cohort too small for that many contexts)");
     const uint32_t own = static_cast<uint32_t>(std::min<uint64_t>(per, sh->n_samples_global - first));
     if (sh->first_sample != first || c->nSamples != own)
-        return fail(c, "pd_ctx_set_shard: the context's samples are not this rank's part of the pd_shard_samples() partition");
+        return fail(c, name + ": the context's samples are not this rank's part of the pd_shard_samples() partition");
     if (sh->n_readgroups_global < sh->n_samples_global)
-        return fail(c, "pd_ctx_set_shard: fewer read groups than samples");
+        return fail(c, name + ": fewer read groups than samples");
     try
     {
         PD_HIP(hipSetDevice(c->device));
+        if (rcclId)
+        {
+            RcclApi & api = rccl();
+            if (!api.error.empty())
+                return fail(c, name + ": " + api.error);
+            ncclUniqueId id;
+            static_assert(sizeof(id) == PD_RCCL_ID_BYTES, "ncclUniqueId size");
+            std::memcpy(&id, rcclId, sizeof(id));
+            if (c->comm)
+            {
+                (void)api.commDestroy(c->comm);
+                c->comm = nullptr;
+            }
+            const ncclResult_t r = api.commInitRank(&c->comm, static_cast<int>(sh->world), id, static_cast<int>(sh->rank));
+            if (r != ncclSuccess)
+            {
+                c->comm = nullptr;
+                return fail(c, name + ": ncclCommInitRank: " + api.getErrorString(r));
+            }
+        }
         c->shard = *sh;
         c->rank = sh->rank;
         c->world = sh->world;
@@ -997,16 +1080,40 @@ int pd_ctx_set_shard(pd_ctx * c, const pd_shard * sh)
     }
     catch (const HipError & e)
     {
-        return fail(c, "pd_ctx_set_shard: " + e.what);
+        return fail(c, name + ": " + e.what);
     }
     catch (const std::exception & e)
     {
-        return fail(c, std::string("pd_ctx_set_shard: ") + e.what());
+        return fail(c, name + ": " + e.what());
     }
     catch (...)
     {
-        return fail(c, "pd_ctx_set_shard: unknown exception");
+        return fail(c, name + ": unknown exception");
     }
+    return 0;
+}
+
+int pd_ctx_set_shard(pd_ctx * c, const pd_shard * sh) { return applyShard(c, sh, nullptr, "pd_ctx_set_shard"); }
+
+int pd_ctx_set_shard_rccl(pd_ctx * c, const pd_shard * sh, const uint8_t * id)
+{
+    if (!id)
+        return fail(c, "pd_ctx_set_shard_rccl: invalid argument");
+    return applyShard(c, sh, id, "pd_ctx_set_shard_rccl");
+}
+
+int pd_rccl_unique_id(uint8_t * id)
+{
+    if (!id)
+        return fail(nullptr, "pd_rccl_unique_id: invalid argument");
+    RcclApi & api = rccl();
+    if (!api.error.empty())
+        return fail(nullptr, "pd_rccl_unique_id: " + api.error);
+    ncclUniqueId u;
+    const ncclResult_t r = api.getUniqueId(&u);
+    if (r != ncclSuccess)
+        return fail(nullptr, std::string("pd_rccl_unique_id: ") + api.getErrorString(r));
+    std::memcpy(id, &u, sizeof(u));
     return 0;
 }
 

@@ -5,13 +5,74 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <exception>
 #include <mutex>
 #include <thread>
 #include <vector>
+#ifdef __linux__
+#include <sched.h>
+#endif
 
 namespace pdh {
+
+// CPUs this process may actually use: the affinity mask, cut down to the cgroup's CPU-time quota if there is one
+// (cgroup v2 cpu.max / v1 cpu.cfs_quota_us). The GPU boxes show 256 logical CPUs and grant a job 16 of them: more
+// threads than that only get throttled.
+inline unsigned usableCpus()
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0)
+        hw = 1;
+#ifdef __linux__
+    {
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0)
+        {
+            const int n = CPU_COUNT(&set);
+            if (n > 0 && static_cast<unsigned>(n) < hw)
+                hw = static_cast<unsigned>(n);
+        }
+    }
+    auto quotaOf = [](const char * path, bool v2) -> double {
+        FILE * f = fopen(path, "r");
+        if (!f)
+            return 0;
+        char a[64] = {0};
+        long long period = 100000;
+        double cpus = 0;
+        if (v2)
+        {
+            if (fscanf(f, "%63s %lld", a, &period) >= 1 && a[0] != 'm' && period > 0)
+                cpus = atof(a) / static_cast<double>(period);
+        }
+        else
+        {
+            long long q = -1;
+            if (fscanf(f, "%lld", &q) == 1 && q > 0)
+            {
+                FILE * g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+                if (g)
+                {
+                    if (fscanf(g, "%lld", &period) != 1 || period <= 0)
+                        period = 100000;
+                    fclose(g);
+                }
+                cpus = static_cast<double>(q) / static_cast<double>(period);
+            }
+        }
+        fclose(f);
+        return cpus;
+    };
+    double q = quotaOf("/sys/fs/cgroup/cpu.max", true);
+    if (q <= 0)
+        q = quotaOf("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", false);
+    if (q >= 1 && q < hw)
+        hw = static_cast<unsigned>(q + 0.5);
+#endif
+    return hw;
+}
 
 inline unsigned hostThreads()
 {
@@ -22,9 +83,7 @@ inline unsigned hostThreads()
             if (v >= 1)
                 return static_cast<unsigned>(v);
         }
-        unsigned hw = std::thread::hardware_concurrency();
-        if (hw == 0)
-            hw = 1;
+        const unsigned hw = usableCpus();
         return hw > 64u ? 64u : hw;
     }();
     return n;

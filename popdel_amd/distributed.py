@@ -110,6 +110,13 @@ class SampleShardExchange:
             return 1
 
 
+class NativeExchangeStats:
+    """Placeholder with the counters of SampleShardExchange: the library does not report its own collectives."""
+    calls = 0
+    bytes = 0
+    last_error = None
+
+
 class SampleShard:
     """One rank's context of a cohort split by samples.
 
@@ -117,7 +124,10 @@ class SampleShard:
     loader would parse only its own profiles and exchange the per-read-group ``min_init_del_len`` values); the context is
     created for this rank's samples only."""
 
-    def __init__(self, lib, readgroups, sample_rg_offsets, rank, world, group=None, device=0, **config):
+    def __init__(self, lib, readgroups, sample_rg_offsets, rank, world, group=None, device=0, native=False, **config):
+        """native=True: the library runs the all-gathers itself with RCCL on its own stream (pd_ctx_set_shard_rccl; the
+        communicator's id travels over `group` once); otherwise through the two host callbacks implemented by
+        SampleShardExchange (any torch.distributed backend; what the CPU and one-GPU tests use)."""
         import torch
         from . import capi
         offs = np.asarray(sample_rg_offsets, dtype=np.int64)
@@ -132,9 +142,18 @@ class SampleShard:
         self.ctx = capi.Context(lib, readgroups[self.rg_lo:self.rg_hi], offs[self.first:self.last + 1] - self.rg_lo,
                                 device=device, **config)
         dev = torch.device("cuda", device) if torch.cuda.is_available() else torch.device("cpu")
-        self.exchange = SampleShardExchange(rank, world, dev, group)
-        self.ctx.set_shard(rank, world, self.first, n_samples, [r.min_init_del_len for r in readgroups],
-                           self.exchange.reserve, self.exchange.all_gather)
+        self.native = bool(native)
+        if self.native:
+            import torch.distributed as dist
+            box = [capi.rccl_unique_id(lib) if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0, group=group)
+            self.exchange = NativeExchangeStats()
+            self.ctx.set_shard_rccl(rank, world, self.first, n_samples, [r.min_init_del_len for r in readgroups], box[0])
+        else:
+            self.exchange = SampleShardExchange(rank, world, dev, group)
+            self.ctx.set_shard(rank, world, self.first, n_samples, [r.min_init_del_len for r in readgroups],
+                               self.exchange.reserve, self.exchange.all_gather)
 
     def local_segment(self, seg):
         """The read groups of this rank out of a whole-cohort capi.Segment."""
