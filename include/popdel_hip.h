@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 4
+#define PD_ABI_VERSION 5
 
 /* One read group after start-up conditioning.
  * Replaces: `Histogram` (reference insert_histogram_popdel.h:19-43) after processHistogram()
@@ -209,6 +209,17 @@ typedef struct pd_shard
 #define PD_RCCL_ID_BYTES 128
 int pd_rccl_unique_id(uint8_t *id /* PD_RCCL_ID_BYTES */);
 int pd_ctx_set_shard_rccl(pd_ctx *ctx, const pd_shard *shard, const uint8_t *id /* PD_RCCL_ID_BYTES */);
+
+/* Contexts of ONE process (one host thread each; several GPUs, or several contexts on one GPU): the library exchanges
+ * between them itself -- peer copies between the contexts' exchange buffers, bracketed by barriers of the host threads.
+ * Create the group, then pd_ctx_set_shard_local() on every context (`reserve`, `all_gather`, `user` of `shard` are
+ * ignored); the contexts' collective calls (pd_segment_run / _collect / _submit) must be issued from `world` threads
+ * concurrently. An error in one context fails the pending and later collective calls of all. Destroy the group after
+ * its contexts. This is how `popdel call` drives several GPUs (POPDEL_DEVICES). */
+typedef struct pd_local_group pd_local_group;
+int pd_local_group_create(uint32_t world, pd_local_group **out);
+void pd_local_group_destroy(pd_local_group *group);
+int pd_ctx_set_shard_local(pd_ctx *ctx, const pd_shard *shard, pd_local_group *group);
 
 /* Partition rule: samples per context (a multiple of 256; the last contexts may own fewer or none). */
 uint32_t pd_shard_samples(uint32_t n_samples_global, uint32_t world);

@@ -949,6 +949,22 @@ int pd_ctx_set_shard(pd_ctx * c, const pd_shard * sh)
     return 0;
 }
 
+int pd_local_group_create(uint32_t, pd_local_group ** out)
+{
+    if (out)
+        *out = nullptr;
+    return 1;                                     // the oracle runs the whole cohort in one context
+}
+
+void pd_local_group_destroy(pd_local_group *) {}
+
+int pd_ctx_set_shard_local(pd_ctx * c, const pd_shard *, pd_local_group *)
+{
+    if (c)
+        c->error = "pd_ctx_set_shard_local: the oracle runs the whole cohort in one context";
+    return 1;
+}
+
 int pd_rccl_unique_id(uint8_t *) { return 1; }
 
 int pd_ctx_set_shard_rccl(pd_ctx * c, const pd_shard *, const uint8_t *)

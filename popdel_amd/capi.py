@@ -21,6 +21,7 @@ ABI_SYMBOLS = (
     "pd_ctx_create", "pd_ctx_destroy", "pd_segment_submit", "pd_segment_stage", "pd_segment_run", "pd_segment_unstage",
     "pd_segment_collect", "pd_calls_free", "pd_stage1_last", "pd_last_timing", "pd_last_error", "pd_backend_name",
     "pd_abi_version", "pd_shard_samples", "pd_ctx_set_shard", "pd_ctx_set_shard_rccl", "pd_rccl_unique_id",
+    "pd_local_group_create", "pd_local_group_destroy", "pd_ctx_set_shard_local",
 )
 RCCL_ID_BYTES = 128
 

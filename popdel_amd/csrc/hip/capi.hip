@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -228,6 +229,18 @@ struct Stage1Out
 
 }  // namespace
 
+// Contexts of one process that exchange among themselves (pd_ctx_set_shard_local).
+struct pd_local_group
+{
+    uint32_t world = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    uint32_t arrived = 0;
+    uint64_t generation = 0;
+    bool failed = false;
+    std::vector<pd_ctx *> members;
+};
+
 struct pd_ctx
 {
     pd_config cfg;
@@ -256,6 +269,7 @@ struct pd_ctx
     uint32_t rank = 0, world = 1, nSamplesGlobal = 0, samplesPerRank = 0;
     pd_shard shard;
     ncclComm_t comm = nullptr;      // exchange by the library itself (pd_ctx_set_shard_rccl) instead of the host's callbacks
+    pd_local_group * group = nullptr;   // ... or among the contexts of this process (pd_ctx_set_shard_local)
     DevBuf<unsigned> dMinInitGlobal;
     DevBuf<uint8_t> ownArena;       // exchange areas when world == 1 (otherwise the host owns the buffer)
     uint8_t * arena = nullptr;
@@ -383,7 +397,7 @@ struct CallsBox
 // The exchange buffer: owned by the library for an unsharded cohort, by the host otherwise.
 uint8_t * reserveArena(pd_ctx & c, size_t bytes)
 {
-    if (c.world == 1 || c.comm)
+    if (c.world == 1 || c.comm || c.group)
     {
         if (bytes > c.ownArena.n)
             PD_HIP(hipStreamSynchronize(c.stream));        // nothing in flight may still use the buffer that is replaced
@@ -400,12 +414,59 @@ uint8_t * reserveArena(pd_ctx & c, size_t bytes)
     return c.arena;
 }
 
+// Barrier of the host threads of a local group; throws once any member has failed.
+void groupBarrier(pd_ctx & c)
+{
+    pd_local_group & g = *c.group;
+    std::unique_lock<std::mutex> lock(g.m);
+    if (g.failed)
+        throw HipError{"another context of the local group failed"};
+    const uint64_t gen = g.generation;
+    if (++g.arrived == g.world)
+    {
+        g.arrived = 0;
+        ++g.generation;
+        g.cv.notify_all();
+        return;
+    }
+    g.cv.wait(lock, [&] { return g.generation != gen || g.failed; });
+    if (g.generation == gen)
+        throw HipError{"another context of the local group failed"};
+}
+
+void groupFail(pd_ctx * c)
+{
+    if (!c || !c->group)
+        return;
+    std::lock_guard<std::mutex> lock(c->group->m);
+    c->group->failed = true;
+    c->group->cv.notify_all();
+}
+
 struct CtxExchange : pd::Exchange
 {
     pd_ctx & c;
     explicit CtxExchange(pd_ctx & ctx) : c(ctx) {}
     void allGather(void * area, size_t bytesPerRank) override
     {
+        if (c.group)
+        {
+            // every context pulls the other contexts' chunks out of their exchange buffers (same layout everywhere)
+            const size_t off = static_cast<size_t>(static_cast<uint8_t *>(area) - c.arena);
+            PD_HIP(hipStreamSynchronize(c.stream));            // my chunk is written
+            groupBarrier(c);
+            for (uint32_t p = 0; p < c.world; ++p)
+            {
+                if (p == c.rank)
+                    continue;
+                const pd_ctx * peer = c.group->members[p];
+                PD_HIP(hipMemcpyPeerAsync(c.arena + off + static_cast<size_t>(p) * bytesPerRank, c.device,
+                                          peer->arena + off + static_cast<size_t>(p) * bytesPerRank, peer->device, bytesPerRank, c.stream));
+            }
+            PD_HIP(hipStreamSynchronize(c.stream));
+            groupBarrier(c);                                   // nobody rewrites its chunk before everybody has copied it
+            return;
+        }
         if (c.comm)
         {
             // in place: chunk `rank` of [area, area + world * bytesPerRank) is filled; stream-ordered between the kernels
@@ -1015,7 +1076,7 @@ uint32_t pd_shard_samples(uint32_t n_samples_global, uint32_t world)
     return (tiles + world - 1) / world * pd::kSamplesPerBlock;
 }
 
-static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, const char * who)
+static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, pd_local_group * group, const char * who)
 {
     const std::string name = who;
     if (!c || !sh)
@@ -1024,7 +1085,9 @@ static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, c
         return fail(c, name + ": must be called before segments are staged");
     if (sh->world == 0 || sh->rank >= sh->world || !sh->min_init_del_len_global)
         return fail(c, name + ": invalid rank/world or missing threshold table");
-    if (!rcclId && sh->world > 1 && (!sh->reserve || !sh->all_gather))
+    if (group && (group->world != sh->world || group->members.size() != sh->world))
+        return fail(c, name + ": the group was created for another number of contexts");
+    if (!rcclId && !group && sh->world > 1 && (!sh->reserve || !sh->all_gather))
         return fail(c, name + ": a sharded cohort needs the reserve() and all_gather() callbacks");
     const uint32_t per = pd_shard_samples(sh->n_samples_global, sh->world);
     const uint64_t first = static_cast<uint64_t>(sh->rank) * per;
@@ -1057,6 +1120,12 @@ static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, c
                 c->comm = nullptr;
                 return fail(c, name + ": ncclCommInitRank: " + api.getErrorString(r));
             }
+        }
+        if (group)
+        {
+            std::lock_guard<std::mutex> lock(group->m);
+            group->members[sh->rank] = c;
+            c->group = group;
         }
         c->shard = *sh;
         c->rank = sh->rank;
@@ -1093,13 +1162,35 @@ static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, c
     return 0;
 }
 
-int pd_ctx_set_shard(pd_ctx * c, const pd_shard * sh) { return applyShard(c, sh, nullptr, "pd_ctx_set_shard"); }
+int pd_ctx_set_shard(pd_ctx * c, const pd_shard * sh) { return applyShard(c, sh, nullptr, nullptr, "pd_ctx_set_shard"); }
+
+int pd_local_group_create(uint32_t world, pd_local_group ** out)
+{
+    if (!out || world == 0)
+        return fail(nullptr, "pd_local_group_create: invalid argument");
+    pd_local_group * g = new (std::nothrow) pd_local_group();
+    if (!g)
+        return fail(nullptr, "pd_local_group_create: out of memory");
+    g->world = world;
+    g->members.assign(world, nullptr);
+    *out = g;
+    return 0;
+}
+
+void pd_local_group_destroy(pd_local_group * group) { delete group; }
+
+int pd_ctx_set_shard_local(pd_ctx * c, const pd_shard * sh, pd_local_group * group)
+{
+    if (!group)
+        return fail(c, "pd_ctx_set_shard_local: invalid argument");
+    return applyShard(c, sh, nullptr, group, "pd_ctx_set_shard_local");
+}
 
 int pd_ctx_set_shard_rccl(pd_ctx * c, const pd_shard * sh, const uint8_t * id)
 {
     if (!id)
         return fail(c, "pd_ctx_set_shard_rccl: invalid argument");
-    return applyShard(c, sh, id, "pd_ctx_set_shard_rccl");
+    return applyShard(c, sh, id, nullptr, "pd_ctx_set_shard_rccl");
 }
 
 int pd_rccl_unique_id(uint8_t * id)
@@ -1700,6 +1791,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
     {
         givePinned(pinned);                 // nobody owns the result block of a failed collect
         *out = nullptr;
+        groupFail(c);                       // the other contexts of a local group must not wait for this one
     }
     if (s2Begin)
         (void)hipEventDestroy(s2Begin);

@@ -5,7 +5,9 @@
 #include <chrono>
 #include <cstring>
 #include <iostream>
+#include <exception>
 #include <memory>
+#include <thread>
 
 #include "parallel.h"
 #include "popdel_hip.h"
@@ -123,8 +125,10 @@ public:
     CallRun(CallParams & p, SegmentObserver * obs) : p_(p), observer_(obs) {}
     ~CallRun()
     {
-        if (ctx_)
-            pd_ctx_destroy(ctx_);
+        for (pd_ctx * c : ctxs_)
+            pd_ctx_destroy(c);
+        if (group_)
+            pd_local_group_destroy(group_);
         printTiming();
     }
     void printTiming()
@@ -157,7 +161,16 @@ private:
 
     CallParams & p_;
     SegmentObserver * observer_;
-    pd_ctx * ctx_ = nullptr;
+    // One context, or (POPDEL_DEVICES=0,1,...) one per listed GPU with the cohort sharded by samples over them: the
+    // library exchanges between the contexts of this process itself (pd_ctx_set_shard_local); collective calls are issued
+    // from one thread per context.
+    std::vector<pd_ctx *> ctxs_;
+    pd_local_group * group_ = nullptr;
+    std::vector<uint32_t> shardRg_;         // first read group of every context's samples, plus the end
+    std::vector<uint32_t> shardSample_;     // first sample of every context, plus the end
+    std::vector<uint64_t> tickets_;
+    template <typename F>
+    void onEveryContext(F fn);
     std::unique_ptr<ChromProfile> profile_;
     std::unique_ptr<VcfOutput> vcf_;
     WindowCursor windows_;
@@ -172,7 +185,6 @@ private:
     std::vector<DecodedStream> decodedPool_;
     bool timingPrinted_ = false;
     bool pending_ = false;
-    uint64_t pendingTicket_ = 0;
     std::string pendingContig_;
 };
 
@@ -212,12 +224,97 @@ void CallRun::createBackend()
     cfg.min_sample_fraction = p_.minSampleFraction;
     cfg.somatic = p_.somatic ? 1 : 0;
     cfg.window_wise_output = p_.windowWiseOutput ? 1 : 0;
-    int device = 0;
-    if (const char * d = getenv("POPDEL_DEVICE"))
-        device = atoi(d);
-    if (pd_ctx_create(&cfg, rgs.data(), static_cast<uint32_t>(rgs.size()), offsets.data(),
-                      static_cast<uint32_t>(p_.rgs.size()), device, &ctx_) != 0)
+    std::vector<int> devices;
+    if (const char * d = getenv("POPDEL_DEVICES"))
+    {
+        for (const char * q = d; *q;)
+        {
+            devices.push_back(atoi(q));
+            while (*q && *q != ',')
+                ++q;
+            if (*q == ',')
+                ++q;
+        }
+    }
+    if (devices.empty())
+    {
+        const char * d = getenv("POPDEL_DEVICE");
+        devices.push_back(d ? atoi(d) : 0);
+    }
+    const uint32_t S = static_cast<uint32_t>(p_.rgs.size()), world = static_cast<uint32_t>(devices.size());
+    ctxs_.assign(world, nullptr);
+    tickets_.assign(world, 0);
+    if (world == 1)
+    {
+        shardSample_ = {0u, S};
+        shardRg_ = {0u, static_cast<uint32_t>(rgs.size())};
+        if (pd_ctx_create(&cfg, rgs.data(), static_cast<uint32_t>(rgs.size()), offsets.data(), S, devices[0], &ctxs_[0]) != 0)
+            throw ProfileError(std::string("[PopDel] Could not initialise the genotyping backend: ") + pd_last_error(nullptr));
+        return;
+    }
+    // the cohort sharded by samples: whole 256-sample tiles per context (pd_shard_samples)
+    const uint32_t per = pd_shard_samples(S, world);
+    if (static_cast<uint64_t>(per) * (world - 1) >= S)
+        throw ProfileError("[PopDel] POPDEL_DEVICES lists " + std::to_string(world) + " contexts, but " + std::to_string(S) +
+                           " samples fill only " + std::to_string((S + per - 1) / per) + " (every context takes whole tiles of 256 samples).");
+    if (pd_local_group_create(world, &group_) != 0)
         throw ProfileError(std::string("[PopDel] Could not initialise the genotyping backend: ") + pd_last_error(nullptr));
+    std::vector<uint32_t> minInit(rgs.size());
+    for (size_t i = 0; i < rgs.size(); ++i)
+        minInit[i] = rgs[i].min_init_del_len;
+    for (uint32_t r = 0; r <= world; ++r)
+    {
+        shardSample_.push_back(std::min<uint64_t>(S, static_cast<uint64_t>(r) * per));
+        shardRg_.push_back(offsets[shardSample_.back()]);
+    }
+    for (uint32_t r = 0; r < world; ++r)
+    {
+        const uint32_t s0 = shardSample_[r], s1 = shardSample_[r + 1], g0 = shardRg_[r];
+        std::vector<uint32_t> local(offsets.begin() + s0, offsets.begin() + s1 + 1);
+        for (uint32_t & o : local)
+            o -= g0;
+        if (pd_ctx_create(&cfg, rgs.data() + g0, shardRg_[r + 1] - g0, local.data(), s1 - s0, devices[r], &ctxs_[r]) != 0)
+            throw ProfileError(std::string("[PopDel] Could not initialise the genotyping backend: ") + pd_last_error(nullptr));
+        pd_shard sh;
+        std::memset(&sh, 0, sizeof(sh));
+        sh.rank = r;
+        sh.world = world;
+        sh.first_sample = s0;
+        sh.n_samples_global = S;
+        sh.n_readgroups_global = static_cast<uint32_t>(rgs.size());
+        sh.min_init_del_len_global = minInit.data();
+        if (pd_ctx_set_shard_local(ctxs_[r], &sh, group_) != 0)
+            throw ProfileError(std::string("[PopDel] Could not initialise the genotyping backend: ") + pd_last_error(ctxs_[r]));
+    }
+}
+
+// fn(r) for every context; from one thread per context when there are several (their calls are collective)
+template <typename F>
+void CallRun::onEveryContext(F fn)
+{
+    if (ctxs_.size() == 1)
+    {
+        fn(0u);
+        return;
+    }
+    std::vector<std::thread> threads;
+    std::vector<std::exception_ptr> errors(ctxs_.size());
+    for (unsigned r = 0; r < ctxs_.size(); ++r)
+        threads.emplace_back([&, r] {
+            try
+            {
+                fn(r);
+            }
+            catch (...)
+            {
+                errors[r] = std::current_exception();
+            }
+        });
+    for (std::thread & t : threads)
+        t.join();
+    for (std::exception_ptr & e : errors)
+        if (e)
+            std::rethrow_exception(e);
 }
 
 void CallRun::jumpToRoi(ProfileFile & f, unsigned fileNum)
@@ -536,11 +633,18 @@ void CallRun::flushPending()
     if (!pending_)
         return;
     pending_ = false;
-    pd_calls * pc = nullptr;
-    if (pd_segment_collect(ctx_, pendingTicket_, &pc) != 0)
-        throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctx_));
+    std::vector<pd_calls *> parts(ctxs_.size(), nullptr);
+    onEveryContext([&](unsigned r) {
+        if (pd_segment_collect(ctxs_[r], tickets_[r], &parts[r]) != 0)
+            throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
+    });
+    // every context returns the calls of the whole cohort with the columns of its own samples
+    pd_calls * pc = parts[0];
+    for (pd_calls * q : parts)
+        if (q->n_calls != pc->n_calls)
+            throw ProfileError("[PopDel] Internal error: the contexts disagree on the calls of a segment.");
     std::vector<WindowCall> calls(pc->n_calls);
-    const uint32_t S = pc->n_samples;
+    const uint32_t S = shardSample_.back();
     parallelFor(pc->n_calls, [&](size_t c) {
         WindowCall & w = calls[c];
         w.initialLength = pc->initial_length[c];
@@ -556,21 +660,28 @@ void CallRun::flushPending()
         w.lad.resize(S);
         w.dad.resize(S);
         w.firstLast.resize(S);
-        const size_t base = static_cast<size_t>(c) * S;
-        for (uint32_t s = 0; s < S; ++s)
+        for (size_t r = 0; r < parts.size(); ++r)
         {
-            for (int k = 0; k < 3; ++k)
+            const pd_calls * q = parts[r];
+            const uint32_t s0 = shardSample_[r], n = q->n_samples;
+            const size_t base = static_cast<size_t>(c) * n;
+            for (uint32_t j = 0; j < n; ++j)
             {
-                w.pl[s][k] = pc->pl[(base + s) * 3 + k];
-                w.lad[s][k] = pc->lad[(base + s) * 3 + k];
+                const uint32_t s = s0 + j;
+                for (int k = 0; k < 3; ++k)
+                {
+                    w.pl[s][k] = q->pl[(base + j) * 3 + k];
+                    w.lad[s][k] = q->lad[(base + j) * 3 + k];
+                }
+                for (int k = 0; k < 5; ++k)
+                    w.dad[s][k] = q->dad[(base + j) * 5 + k];
+                w.firstLast[s][0] = q->first_last[(base + j) * 2];
+                w.firstLast[s][1] = q->first_last[(base + j) * 2 + 1];
             }
-            for (int k = 0; k < 5; ++k)
-                w.dad[s][k] = pc->dad[(base + s) * 5 + k];
-            w.firstLast[s][0] = pc->first_last[(base + s) * 2];
-            w.firstLast[s][1] = pc->first_last[(base + s) * 2 + 1];
         }
     });
-    pd_calls_free(pc);
+    for (pd_calls * q : parts)
+        pd_calls_free(q);
     if (observer_ && observer_->onWindowCalls)
         observer_->onWindowCalls(calls);
     if (!p_.windowWiseOutput)
@@ -645,18 +756,26 @@ void CallRun::processSegment()
     }, 16);
     clock_.flatten += PhaseClock::now() - t0;
     t0 = PhaseClock::now();
-    pd_segment seg;
-    seg.first_window_pos = firstPos;
-    seg.n_windows = nWindows;
-    seg.window_shift = p_.windowShift;
-    seg.n_readgroups = static_cast<uint32_t>(log.size());
-    seg.rg_offsets = offsets.data();
-    seg.pair_dev = dev.data();
-    seg.pair_start = start.data();
-    seg.pair_on = on.data();
-    seg.pair_off = off.data();
-    if (pd_segment_submit(ctx_, &seg, &pendingTicket_) != 0)
-        throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctx_));
+    onEveryContext([&](unsigned r) {
+        // the read groups of this context's samples: a slice of the arrays (they are read-group major)
+        const uint32_t g0 = shardRg_[r], g1 = shardRg_[r + 1];
+        std::vector<uint64_t> local(offsets.begin() + g0, offsets.begin() + g1 + 1);
+        const uint64_t base = local.front();
+        for (uint64_t & o : local)
+            o -= base;
+        pd_segment seg;
+        seg.first_window_pos = firstPos;
+        seg.n_windows = nWindows;
+        seg.window_shift = p_.windowShift;
+        seg.n_readgroups = g1 - g0;
+        seg.rg_offsets = local.data();
+        seg.pair_dev = dev.data() + base;
+        seg.pair_start = start.data() + base;
+        seg.pair_on = on.data() + base;
+        seg.pair_off = off.data() + base;
+        if (pd_segment_submit(ctxs_[r], &seg, &tickets_[r]) != 0)
+            throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
+    });
     pending_ = true;
     pendingContig_ = windows_.current.contig;
     clock_.submit += PhaseClock::now() - t0;
