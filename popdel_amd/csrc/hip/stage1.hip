@@ -453,11 +453,25 @@ __device__ __forceinline__ int scanBlock(const SegmentView & seg, const CohortVi
                 classCount[k][tid >> 6] = (unsigned)__popcll(bal);
         }
         __syncthreads();
-        unsigned offset = 0;
+        // units ahead of this lane's (class, wave): the 24 counts are the same for every lane, so they are pulled into
+        // scalar registers and added up by the scalar unit; what is left per lane is the choice by its class
+        // (each lane adding up the 24 counts itself cost 110 VALU per wave)
+        const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+        unsigned offset = 0, run = 0;
+#pragma unroll
         for (unsigned k = 0; k < kClasses; ++k)
+        {
+            unsigned within = 0, total = 0;
+#pragma unroll
             for (unsigned v = 0; v < kStage1Block / 64; ++v)
-                if (k < cls || (k == cls && v < (tid >> 6)))
-                    offset += classCount[k][v];
+            {
+                const unsigned c = (unsigned)__builtin_amdgcn_readfirstlane((int)classCount[k][v]);
+                within += v < wv ? c : 0u;
+                total += c;
+            }
+            offset = cls == k ? run + within : offset;
+            run += total;
+        }
         unitOrder[offset + rank] = (unsigned short)tid;
         __syncthreads();
     }

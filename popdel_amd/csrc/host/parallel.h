@@ -83,7 +83,9 @@ inline unsigned hostThreads()
             if (v >= 1)
                 return static_cast<unsigned>(v);
         }
-        const unsigned hw = usableCpus();
+        // twice the usable CPUs: the passes are memory-bound and fault pages in, a second thread per CPU fills the stalls
+        // (GPU box, 16 usable CPUs, popdel call on 1000 samples: 16 threads 1.84 s, 32 and 64 threads 1.62 s)
+        const unsigned hw = 2u * usableCpus();
         return hw > 64u ? 64u : hw;
     }();
     return n;
