@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 5
+#define PD_ABI_VERSION 6
 
 /* One read group after start-up conditioning.
  * Replaces: `Histogram` (reference insert_histogram_popdel.h:19-43) after processHistogram()
@@ -235,6 +235,13 @@ void pd_calls_free(pd_calls *calls);
 
 /* Stage-1 values of the most recently collected segment; valid until the next submit/run issued AFTER that collect. */
 int pd_stage1_last(pd_ctx *ctx, pd_stage1_view *out);
+
+/* The device-resident lookup tables of read group `rg` (diagnostics / parity tests): the conditioned densities as uploaded
+ * and their natural and decadic logarithms as the kernels read them (computed once on the device at pd_ctx_create).
+ * Each output array takes hist_len entries; returns the number of entries through *n.
+ * Replaces nothing in the reference's interface; the reference evaluates logl()/log10l() of Histogram::values per read
+ * pair (genotype_deletion_popdel_call.h:205-215, 290-300). */
+int pd_log_table_view(pd_ctx *ctx, uint32_t rg, double *value, double *log_value, double *log10_value, uint32_t *n);
 
 /* Text of the last error on this context (or of the last failed pd_ctx_create if ctx == NULL). */
 const char *pd_last_error(const pd_ctx *ctx);

@@ -18,9 +18,12 @@
 #include <map>
 #include <set>
 #include <string>
+#include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "popdel_hip.h"
+#include "oracle_side_channel.h"
 
 namespace {
 
@@ -106,6 +109,10 @@ struct pd_ctx
     };
     std::map<uint64_t, Staged> staged;
     uint64_t nextHandle = 1;
+    // The reference's active sets themselves (only when the driver feeds the mutation log, oracle_side_channel.h): real
+    // std::unordered_set<uint32_t> per read group, alive across segments like the reference's, iterated for the order
+    // in which the pairs of a window are visited.
+    std::vector<std::unordered_set<uint32_t>> refActive;
     pd_timing timing;
 
     unsigned nSamples() const { return static_cast<unsigned>(sampleOffsets.size() - 1); }
@@ -756,6 +763,25 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
 
 void pd_ctx_destroy(pd_ctx * ctx) { delete ctx; }
 
+// Mutation log and pair ids of the next segment (oracle_side_channel.h); consumed by the next runSegment().
+struct PendingOrder
+{
+    bool present = false;
+    std::vector<uint64_t> opOffsets;
+    std::vector<pd_oracle_op> ops;
+    std::vector<uint32_t> ids;
+};
+static PendingOrder g_order;
+
+extern "C" void pd_oracle_next_segment_order(uint32_t n_readgroups, const uint64_t * rg_op_offsets, const pd_oracle_op * ops,
+                                             const uint32_t * instance_ids, uint64_t n_instances)
+{
+    g_order.present = true;
+    g_order.opOffsets.assign(rg_op_offsets, rg_op_offsets + n_readgroups + 1);
+    g_order.ops.assign(ops, ops + rg_op_offsets[n_readgroups]);
+    g_order.ids.assign(instance_ids, instance_ids + n_instances);
+}
+
 static int runSegment(pd_ctx * c, const pd_segment * seg, uint64_t * ticket)
 {
     if (!c || !seg || seg->n_readgroups != c->rgs.size())
@@ -779,10 +805,64 @@ static int runSegment(pd_ctx * c, const pd_segment * seg, uint64_t * ticket)
     g_snapShifts = getenv("POPDEL_SNAP_SHIFTS") != nullptr;
     g_perturbFreq = getenv("POPDEL_ORACLE_PERTURB_FREQ") ? atoi(getenv("POPDEL_ORACLE_PERTURB_FREQ")) : 0;
     std::vector<std::vector<uint64_t>> activeIdx(c->rgs.size());
+    // the reference's visiting order, if the driver supplied the mutation log of this segment
+    const bool refOrder = g_order.present;
+    PendingOrder order;
+    std::vector<std::unordered_map<uint32_t, uint64_t>> instanceOfId;
+    std::vector<uint64_t> nextOp;
+    if (refOrder)
+    {
+        std::swap(order, g_order);
+        g_order = PendingOrder();
+        if (order.opOffsets.size() != c->rgs.size() + 1 || order.ids.size() != seg->rg_offsets[seg->n_readgroups])
+        {
+            c->error = "pd_segment_submit: the mutation log does not belong to this segment";
+            return 1;
+        }
+        c->refActive.resize(c->rgs.size());
+        instanceOfId.resize(c->rgs.size());
+        nextOp.assign(order.opOffsets.begin(), order.opOffsets.end() - 1);
+        for (size_t rg = 0; rg < c->rgs.size(); ++rg)
+            for (uint64_t i = seg->rg_offsets[rg]; i < seg->rg_offsets[rg + 1]; ++i)
+                instanceOfId[rg][order.ids[i]] = i;       // a pair has one instance per segment
+    }
     for (uint32_t w = 0; w < seg->n_windows; ++w)
     {
         for (size_t rg = 0; rg < c->rgs.size(); ++rg)
         {
+            if (refOrder)
+            {
+                std::unordered_set<uint32_t> & set = c->refActive[rg];
+                while (nextOp[rg] < order.opOffsets[rg + 1] && order.ops[nextOp[rg]].window <= w)
+                {
+                    const pd_oracle_op & op = order.ops[nextOp[rg]++];
+                    if (op.add)
+                        set.emplace(op.id);
+                    else
+                        set.erase(op.id);
+                }
+                std::vector<ActivePair> & act = c->active[rg];
+                act.clear();
+                for (uint32_t id : set)
+                {
+                    auto it = instanceOfId[rg].find(id);
+                    if (it == instanceOfId[rg].end() || !(seg->pair_on[it->second] <= w && seg->pair_off[it->second] > w))
+                    {
+                        c->error = "pd_segment_submit: the replayed active set disagrees with the segment's instances";
+                        return 1;
+                    }
+                    act.push_back(ActivePair{seg->pair_dev[it->second], seg->pair_start[it->second]});
+                }
+                size_t expect = 0;
+                for (uint64_t i = seg->rg_offsets[rg]; i < seg->rg_offsets[rg + 1] && seg->pair_on[i] <= w; ++i)
+                    expect += seg->pair_off[i] > w;
+                if (expect != act.size())
+                {
+                    c->error = "pd_segment_submit: the replayed active set misses pairs of the segment";
+                    return 1;
+                }
+                continue;
+            }
             std::vector<uint64_t> & idx = activeIdx[rg];
             size_t keep = 0;
             for (size_t k = 0; k < idx.size(); ++k)
@@ -963,6 +1043,21 @@ int pd_ctx_set_shard_local(pd_ctx * c, const pd_shard *, pd_local_group *)
     if (c)
         c->error = "pd_ctx_set_shard_local: the oracle runs the whole cohort in one context";
     return 1;
+}
+
+int pd_log_table_view(pd_ctx * c, uint32_t rg, double * value, double * logValue, double * log10Value, uint32_t * n)
+{
+    if (!c || rg >= c->rgs.size() || !value || !logValue || !log10Value || !n)
+        return 1;
+    const ReadGroup & h = c->rgs[rg];
+    for (size_t i = 0; i < h.values.size(); ++i)
+    {
+        value[i] = h.values[i];
+        logValue[i] = static_cast<double>(logl(h.values[i]));          // what the reference computes per pair, rounded to double
+        log10Value[i] = static_cast<double>(log10l(h.values[i]));
+    }
+    *n = static_cast<uint32_t>(h.values.size());
+    return 0;
 }
 
 int pd_rccl_unique_id(uint8_t *) { return 1; }

@@ -4,11 +4,13 @@
 // survey-stage captures under tests/golden/, so that the restatement can be compared with the reference's outputs.
 //   POPDEL_ORACLE_ACTIVE_DUMP=<file>  per window: pos \t count:sum(startPos) per read group
 //   POPDEL_ORACLE_CALL_DUMP=<file>    per window call: scalars at 17 significant digits + per-sample integers
+//   POPDEL_ORACLE_SET_ORDER=1         visit the pairs of a window in the reference's std::unordered_set order
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
 #include "call_driver.h"
+#include "oracle_side_channel.h"
 
 int main(int argc, const char ** argv)
 {
@@ -62,7 +64,26 @@ int main(int argc, const char ** argv)
             }
         };
     }
-    int rc = pdh::runPopdelCall(argc, argv, (act || cd) ? &obs : nullptr);
+    const bool setOrder = getenv("POPDEL_ORACLE_SET_ORDER") != nullptr;
+    if (setOrder)
+    {
+        obs.onActiveOps = [](const std::vector<std::vector<pdh::ActiveOp>> & ops, const std::vector<std::vector<pdh::PairInstance>> & log) {
+            std::vector<uint64_t> offsets(ops.size() + 1, 0);
+            std::vector<pd_oracle_op> flat;
+            for (size_t rg = 0; rg < ops.size(); ++rg)
+            {
+                for (const pdh::ActiveOp & o : ops[rg])
+                    flat.push_back(pd_oracle_op{o.window, o.id, o.add});
+                offsets[rg + 1] = flat.size();
+            }
+            std::vector<uint32_t> ids;
+            for (const auto & v : log)
+                for (const pdh::PairInstance & p : v)
+                    ids.push_back(p.id);
+            pd_oracle_next_segment_order(static_cast<uint32_t>(ops.size()), offsets.data(), flat.data(), ids.data(), ids.size());
+        };
+    }
+    int rc = pdh::runPopdelCall(argc, argv, (act || cd || setOrder) ? &obs : nullptr);
     if (act)
         fclose(act);
     if (cd)

@@ -21,7 +21,7 @@ ABI_SYMBOLS = (
     "pd_ctx_create", "pd_ctx_destroy", "pd_segment_submit", "pd_segment_stage", "pd_segment_run", "pd_segment_unstage",
     "pd_segment_collect", "pd_calls_free", "pd_stage1_last", "pd_last_timing", "pd_last_error", "pd_backend_name",
     "pd_abi_version", "pd_shard_samples", "pd_ctx_set_shard", "pd_ctx_set_shard_rccl", "pd_rccl_unique_id",
-    "pd_local_group_create", "pd_local_group_destroy", "pd_ctx_set_shard_local",
+    "pd_local_group_create", "pd_local_group_destroy", "pd_ctx_set_shard_local", "pd_log_table_view",
 )
 RCCL_ID_BYTES = 128
 
@@ -110,6 +110,9 @@ def load_library(path):
     lib.pd_ctx_set_shard.restype = C.c_int
     lib.pd_ctx_set_shard_rccl.argtypes = [C.c_void_p, C.POINTER(PdShard), C.c_char_p]
     lib.pd_ctx_set_shard_rccl.restype = C.c_int
+    lib.pd_log_table_view.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_uint32)]
+    lib.pd_log_table_view.restype = C.c_int
     lib.pd_rccl_unique_id.argtypes = [C.c_char_p]
     lib.pd_rccl_unique_id.restype = C.c_int
     return lib
@@ -333,6 +336,14 @@ class Context:
         q3 = np.ctypeslib.as_array(v.q3, shape=(n,)).reshape(v.n_windows, v.n_samples).copy()
         fl = np.ctypeslib.as_array(v.flags, shape=(n,)).reshape(v.n_windows, v.n_samples).copy()
         return q3, fl
+
+    def log_tables(self, rg, hist_len):
+        """(values, ln, log10) of read group `rg` as the backend holds them (pd_log_table_view)."""
+        v, l, l10 = (np.zeros(hist_len, np.float64) for _ in range(3))
+        n = C.c_uint32()
+        p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        self._check(self.lib.pd_log_table_view(self.handle, rg, p(v), p(l), p(l10), C.byref(n)))
+        return v[:n.value], l[:n.value], l10[:n.value]
 
     def timing(self):
         t = PdTiming()

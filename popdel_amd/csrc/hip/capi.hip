@@ -1874,6 +1874,41 @@ int pd_stage1_last(pd_ctx * c, pd_stage1_view * out)
     return 0;
 }
 
+int pd_log_table_view(pd_ctx * c, uint32_t rg, double * value, double * logValue, double * log10Value, uint32_t * n)
+{
+    if (!c || rg >= c->nRg || !value || !logValue || !log10Value || !n)
+        return fail(c, "pd_log_table_view: invalid argument");
+    try
+    {
+        PD_HIP(hipSetDevice(c->device));
+        pd::RgConst rc;
+        PD_HIP(hipMemcpy(&rc, c->dRg.p + rg, sizeof(rc), hipMemcpyDeviceToHost));
+        std::vector<double4> tab(static_cast<size_t>(rc.histLen));
+        if (!tab.empty())
+            PD_HIP(hipMemcpy(tab.data(), c->dTab.p + rc.histBase, tab.size() * sizeof(double4), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tab.size(); ++i)
+        {
+            value[i] = tab[i].x;
+            logValue[i] = tab[i].y;
+            log10Value[i] = tab[i].z;
+        }
+        *n = static_cast<uint32_t>(tab.size());
+    }
+    catch (const HipError & e)
+    {
+        return fail(c, "pd_log_table_view: " + e.what);
+    }
+    catch (const std::exception & e)
+    {
+        return fail(c, std::string("pd_log_table_view: ") + e.what());
+    }
+    catch (...)
+    {
+        return fail(c, "pd_log_table_view: unknown exception");
+    }
+    return 0;
+}
+
 int pd_last_timing(pd_ctx * c, pd_timing * out)
 {
     if (!c || !out)

@@ -720,6 +720,12 @@ void CallRun::processSegment()
     std::vector<std::vector<PairInstance>> & log = prof.endSegmentLog();
     if (observer_ && observer_->onSegment)
         observer_->onSegment(firstPos, nWindows, log);
+    if (observer_ && observer_->onActiveOps && nWindows != 0)
+    {
+        // (the mutations of a segment without windows stay in the log: they precede window 0 of the next one)
+        observer_->onActiveOps(prof.activeOps(), log);
+        prof.clearActiveOps();
+    }
 
     t0 = PhaseClock::now();
     flushPending();
@@ -824,6 +830,8 @@ int CallRun::run()
     createBackend();
     clock_.backend = PhaseClock::now() - tStart;
     profile_.reset(new ChromProfile(static_cast<unsigned>(p_.readGroups.size()), p_.maxLoad, p_.windowBuffer));
+    if (observer_ && observer_->onActiveOps)
+        profile_->enableActiveOpLog();
     profile_->currentPos = windows_.current.pos;
     profile_->resetTo(profile_->currentPos);
 

@@ -20,6 +20,9 @@ struct SegmentObserver
     std::function<void(unsigned firstWindowPos, unsigned nWindows, const std::vector<std::vector<PairInstance>> &)> onSegment;
     // called with the raw window calls of a segment, before merging
     std::function<void(const std::vector<WindowCall> &)> onWindowCalls;
+    // if set: called once per segment, before it is submitted, with the mutations of the active sets since the previous
+    // segment in the reference's order (ActiveOp) and the instance log (whose entries carry the reference's pair ids)
+    std::function<void(const std::vector<std::vector<ActiveOp>> &, const std::vector<std::vector<PairInstance>> &)> onActiveOps;
 };
 
 // Runs the whole `popdel call` command. Returns the process exit code.

@@ -222,8 +222,10 @@ void ChromProfile::activate(unsigned rg, unsigned id, unsigned logWindow)
     if (logging_)
     {
         rec.logIdx = static_cast<uint32_t>(log_[rg].size());
-        log_[rg].push_back(PairInstance{e.deviation, e.startPos, logWindow, kNoLog});
+        log_[rg].push_back(PairInstance{e.deviation, e.startPos, logWindow, kNoLog, id});
     }
+    if (opLogging_)
+        ops_[rg].push_back(ActiveOp{logging_ ? logWindow : 0u, id, 1u});
     set.emplace(id, rec);
 }
 
@@ -235,6 +237,8 @@ void ChromProfile::deactivate(unsigned rg, unsigned id, unsigned logWindow)
         return;
     if (logging_ && rec->logIdx != kNoLog)
         log_[rg][rec->logIdx].off = logWindow;
+    if (opLogging_)
+        ops_[rg].push_back(ActiveOp{logging_ ? logWindow : 0u, id, 0u});
     set.erase(id);
 }
 
@@ -482,7 +486,7 @@ void ChromProfile::beginSegmentLog()
         for (auto & c : carried)
         {
             c.second->logIdx = static_cast<uint32_t>(log_[rg].size());
-            log_[rg].push_back(PairInstance{c.second->dev, c.second->start, 0u, kNoLog});
+            log_[rg].push_back(PairInstance{c.second->dev, c.second->start, 0u, kNoLog, c.first});
         }
     }
 }

@@ -109,6 +109,18 @@ struct PairInstance
     uint32_t start;
     uint32_t on;
     uint32_t off;
+    uint32_t id;           // the reference's id of the pair (entry of the cyclic start table); not part of pd_segment
+};
+
+// One mutation of a read group's active set, in the order the reference performs them (emplace / erase on its
+// std::unordered_set, profile_structure_popdel_call.h:1143-1207). Recorded on request only (tests: the oracle replays them
+// on a real std::unordered_set to visit the pairs in the reference's order). `window`: index of the first window of the
+// segment that is genotyped after the mutation (0 for mutations the loader makes between segments).
+struct ActiveOp
+{
+    uint32_t window;
+    uint32_t id;
+    uint32_t add;
 };
 
 class ChromProfile
@@ -143,6 +155,10 @@ public:
     // Still-active pairs stay in the active set for the next segment.
     std::vector<std::vector<PairInstance>> & endSegmentLog();
     unsigned loggedWindows() const { return logWindow_; }
+    // mutation log (see ActiveOp): everything since the last takeActiveOps()
+    void enableActiveOpLog() { opLogging_ = true; ops_.resize(active.size()); }
+    std::vector<std::vector<ActiveOp>> & activeOps() { return ops_; }
+    void clearActiveOps() { for (auto & v : ops_) v.clear(); }
 
     std::vector<StartSlots> starts;
     std::vector<EndSlots> ends;
@@ -261,6 +277,8 @@ private:
     unsigned walkReadGroup(unsigned rg, unsigned pos0, unsigned shift, unsigned maxSteps);
 
     bool logging_ = false;
+    bool opLogging_ = false;
+    std::vector<std::vector<ActiveOp>> ops_;
     unsigned logWindow_ = 0;
     std::vector<std::vector<PairInstance>> log_;
 };

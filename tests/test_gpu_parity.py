@@ -325,3 +325,22 @@ def test_deep_coverage_takes_the_128_candidate_scan(built):
     gpu, cpu = both(seg, [rg] * n, list(range(n + 1)))
     assert cpu[0]["n_calls"] > 20
     assert_same(gpu, cpu)
+
+
+def test_device_log_tables_against_the_x87_logarithms(built):
+    """Row f4: the lookup tables the kernels read -- conditioned densities with their natural and decadic logarithms,
+    computed once on the device -- against what the reference evaluates per pair (logl / log10l of the same densities,
+    here through the oracle): the densities bit for bit, the logarithms within one unit in the last place of a double."""
+    from popdel_amd import capi, synth
+    libs = [synth.Library(), synth.Library(median=380, stddev=31.0, read_len=100, hist_seed=5),
+            synth.Library(median=610, stddev=74.0, read_len=125, hist_seed=9)]
+    rgs = [synth.conditioned_readgroup(l) for l in libs]
+    out = []
+    for lib in (capi.load_hip(), capi.load_library(ORACLE_LIB)):
+        ctx = capi.Context(lib, rgs, list(range(len(rgs) + 1)))
+        out.append([ctx.log_tables(i, len(r.hist_values)) for i, r in enumerate(rgs)])
+        ctx.close()
+    for (gv, gl, g10), (ov, ol, o10), r in zip(out[0], out[1], rgs):
+        assert len(gv) == len(r.hist_values) and np.array_equal(gv, ov) and np.array_equal(gv, np.asarray(r.hist_values))
+        assert np.all(np.abs(gl - ol) <= np.spacing(np.abs(ol))) and np.all(np.abs(g10 - o10) <= np.spacing(np.abs(o10)))
+        assert (gl == ol).mean() > 0.5

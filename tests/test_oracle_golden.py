@@ -90,6 +90,33 @@ def test_dense_200_samples(built, cohort_dir, tmp_path):
     assert worst < 1e-12      # summation order differs from the reference's hash-set order, nothing else
 
 
+def test_dense_200_samples_in_the_reference_visiting_order(built, cohort_dir, tmp_path):
+    """The same 5,163 window calls with the pairs of every window visited in the REFERENCE's order: the host driver logs
+    every emplace / erase on the active sets in the order the reference performs them (pdh::ActiveOp) and the oracle
+    replays them on real std::unordered_set<uint32_t>s that live across segments like the reference's
+    (oracle/oracle_side_channel.h). Then the likelihood ratio and the allele frequency of every call equal the reference's
+    capture in all 17 digits -- the 2e-16 of the test above was summation order and nothing else."""
+    from popdel_amd import synth
+    d = cohort_dir("dd200", 200, synth.dense_deletions)
+    dump = tmp_path / "calls.txt"
+    env = dict(os.environ, POPDEL_ORACLE_CALL_DUMP=str(dump), POPDEL_ORACLE_SET_ORDER="1")
+    out = tmp_path / "tn.vcf"
+    subprocess.check_call([ORACLE_CALL, os.path.join(d, "profiles.txt"), "-o", str(out), "-r", "chr20:1000000-2000000", "-n"],
+                          stdout=subprocess.DEVNULL, env=env)
+    assert vcf_digest(strip_date(out.read_text())) == golden_text("dd200_windowwise.digest.tsv.gz")
+    want = golden_text("dd200_calls.digest.tsv.gz").splitlines()
+    got = dump.read_text().splitlines()
+    assert len(got) == len(want) == 5163
+    for g, w in zip(got, want):
+        parts = g.split(" | ")
+        head = dict(kv.split("=") for kv in parts[0].split()[1:])
+        wf = w.split("\t")
+        for key, ref in zip(("win", "pos", "end", "init", "it", "len", "lr", "af"), wf[:8]):
+            assert head[key] == ref, (key, head[key], ref)
+        assert head["filt"] == wf[8]
+        assert hashlib.sha1(" | ".join(parts[1:]).encode()).hexdigest() == wf[9]
+
+
 @pytest.mark.slow
 @pytest.mark.skipif(os.environ.get("POPDEL_SLOW") != "1", reason="set POPDEL_SLOW=1 (about 3 minutes)")
 def test_1000_samples_default(built, cohort_dir, tmp_path):
