@@ -856,7 +856,7 @@ bool buildChunksOnDevice(pd_ctx & c, const pd_segment & seg, StagedSegment & out
     // ---- chunks to their places
     out.pairs.ensure(totalReal);
     out.start.ensure(totalReal);
-    out.pairsPk.ensure(totalAll);
+    out.pairsPk.ensure(totalAll + 128);            // the scan's LDS-DMA copies whole 128-chunk pieces (stage1.hip)
     pd::ScatterOut so;
     so.pairs = out.pairs.p;
     so.start = out.start.p;
@@ -1273,7 +1273,7 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
         auto sized = [&]() {
             s->pairs.ensure(pairs.size());
             s->start.ensure(start.size());
-            s->pairsPk.ensure(pairsPk.size());
+            s->pairsPk.ensure(pairsPk.size() + 128);     // the scan's LDS-DMA copies whole 128-chunk pieces (stage1.hip)
             s->endCount.ensure(endCount.size());
             s->rgBase.upload(rgBase, cs);
             s->winStart.uploadPinned(winStart, cs);

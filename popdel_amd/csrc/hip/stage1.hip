@@ -379,38 +379,25 @@ __device__ __forceinline__ int scanBlock(const SegmentView & seg, const CohortVi
     const unsigned endedA = (wA < W) ? ec[wA] : 0u;
     const unsigned endedB = (wB < W) ? ec[wB] : 0u;
     __syncthreads();
-    const unsigned A = ldsWs[0];
-    const unsigned nPairs = ldsWs[nWs - 1] - A;
+    const unsigned A0 = ldsWs[0];
+    const unsigned nPairs = ldsWs[nWs - 1] - A0;
     const bool tooMany = nPairs > (unsigned)kLdsPairs;               // workgroup-uniform
+    // The LDS image is the HBM image: the chunks of the block are copied by LDS-DMA (global_load_lds_dwordx4: 64 lanes x
+    // 16 B = 128 chunks per wave instruction, no VGPR round trip, no ds_write, no per-element address arithmetic; the
+    // register-staged copy cost ~100 VALU per wave). The source is aligned down to 16 bytes: LDS entry i is stream entry
+    // A + i with A = A0 - mis; the last instruction may copy up to 127 chunks beyond the block's (both arrays are padded).
+    const size_t g0 = seg.rgBase[rg0] + A0;
+    const unsigned mis = (unsigned)(g0 & 1u);
+    const unsigned A = A0 - mis;
     if (!tooMany)
     {
-        // the LDS image is the HBM image: plain copy in rounds of 9 loads per lane, all loads of a round in flight before
-        // its first LDS write (one round at 30x coverage)
-        const uint2 * src = seg.pairsPk + seg.rgBase[rg0] + A;
-        constexpr int kIters = kPackedLdsRound / kStage1Block;
-        for (unsigned round = 0; round < nPairs; round += (unsigned)kPackedLdsRound)
-        {
-            uint2 tmp[kIters];
-#pragma unroll
-            for (int it = 0; it < kIters; ++it)
-            {
-                const unsigned i = round + tid + (unsigned)it * kStage1Block;
-                if (i < nPairs)
-                    tmp[it] = src[i];
-            }
-#pragma unroll
-            for (int it = 0; it < kIters; ++it)
-            {
-                const unsigned i = round + tid + (unsigned)it * kStage1Block;
-                if (i < nPairs)
-                {
-                    PairPk e;
-                    e.devdev = tmp[it].x;
-                    e.offoff = tmp[it].y;
-                    ldsPairs[i] = e;
-                }
-            }
-        }
+        const uint2 * src = seg.pairsPk + (g0 - mis);
+        const unsigned nCopy = nPairs + mis;
+        const unsigned lane = tid & 63u;
+        for (unsigned base = (tid >> 6) * 128u; base < nCopy; base += (unsigned)(kStage1Block / 64) * 128u)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + base + 2u * lane),
+                                             (__attribute__((address_space(3))) void *)(ldsPairs + base), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // lane t owns the adjacent windows w0 + 2t and w0 + 2t + 1; B's range is expressed in A's slot coordinates
     unsigned aA = 0, cntA = 0, endB = 0;
@@ -554,7 +541,7 @@ __device__ __forceinline__ void scanKernelBody(const SegmentView & seg, const Co
                                                uint8_t * __restrict__ flags, int * __restrict__ winFlag, uint8_t * __restrict__ tileTodo,
                                                unsigned * __restrict__ todoList, unsigned * __restrict__ bigList, unsigned tilesPerSample)
 {
-    __shared__ PairPk ldsPairs[kLdsPairs + 64];
+    __shared__ __attribute__((aligned(16))) PairPk ldsPairs[kLdsPairs + 128];
     __shared__ uint32_t ldsWs[kPackedWsLen];
     __shared__ unsigned short ldsN[kPackedWindows];
     __shared__ unsigned short unitOrder[kStage1Block];
@@ -603,7 +590,7 @@ __global__ __launch_bounds__(kStage1Block) void stage1BigKernel(SegmentView seg,
                                                                 const unsigned * __restrict__ bigList, unsigned tilesPerSample,
                                                                 unsigned blocksPerSample)
 {
-    __shared__ PairPk ldsPairs[kPackedLdsHuge + 64];
+    __shared__ __attribute__((aligned(16))) PairPk ldsPairs[kPackedLdsHuge + 128];
     __shared__ uint32_t ldsWs[kPackedWsLen];
     __shared__ unsigned short ldsN[kPackedWindows];
     __shared__ unsigned short unitOrder[kStage1Block];
