@@ -436,14 +436,12 @@ def main():
 
             for _ in range(args.warmup):
                 step()
-            x0 = (shard.exchange.calls, shard.exchange.bytes)
             el, tot = timed_steps(step, 0, args.steps)
             passes_timed = total_passes * args.steps
             headline.update(value=total_passes * W * S * world * args.steps / el, elapsed=el, steps=args.steps, s1_ms=tot[0],
                             s2_ms=tot[1], n_calls=tot[2], n_cand=tot[3], tinfo=tot[4], launches=passes_timed, cohort=S * world,
                             windows_per_step=total_passes * W,
-                            exchange=dict(all_gathers_per_pass=((shard.exchange.calls - x0[0]) / passes_timed) if not native else 20,
-                                          all_gather_bytes_per_pass=((shard.exchange.bytes - x0[1]) / passes_timed) if not native else None,
+                            exchange=dict(all_gathers_per_pass=tot[4]["n_all_gathers"], all_gather_bytes_per_pass=tot[4]["all_gather_bytes"],
                                           backend="rccl (library-native, ncclAllGather on the context's stream)" if native else dist.get_backend(),
                                           what="window flags, Q3 of flagged windows, a5 counts, per-iteration tile sums + read "
                                                "group 0's record, LR sums, support-percentile digit histograms"),

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 6
+#define PD_ABI_VERSION 7
 
 /* One read group after start-up conditioning.
  * Replaces: `Histogram` (reference insert_histogram_popdel.h:19-43) after processHistogram()
@@ -168,6 +168,8 @@ typedef struct pd_timing
     uint64_t n_pair_chunks;      /* pair chunks resident in HBM for the segment               */
     uint64_t n_candidate_cells;  /* (window, candidate length) cells entering the EM          */
     uint32_t max_life;           /* chunk length K in windows                                 */
+    uint32_t n_all_gathers;      /* exchanges of the ticket (cohort sharded by samples; else 0) */
+    uint64_t all_gather_bytes;   /* bytes gathered per context by them                        */
 } pd_timing;
 int pd_last_timing(pd_ctx *ctx, pd_timing *out);
 

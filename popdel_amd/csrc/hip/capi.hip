@@ -324,6 +324,8 @@ struct pd_ctx
     DevBuf<unsigned> dSuppFirst, dSuppLast, dEmit;
     DevBuf<uint32_t> dPl, dLad, dDad, dFl, dOutPl;
     pd_timing timing;
+    uint32_t nAllGathers = 0;       // of the collect in progress
+    uint64_t allGatherBytes = 0;
 
     ~pd_ctx()
     {
@@ -449,6 +451,11 @@ struct CtxExchange : pd::Exchange
     explicit CtxExchange(pd_ctx & ctx) : c(ctx) {}
     void allGather(void * area, size_t bytesPerRank) override
     {
+        if (c.world > 1 || c.comm || c.group)
+        {
+            ++c.nAllGathers;
+            c.allGatherBytes += static_cast<uint64_t>(bytesPerRank) * c.world;
+        }
         if (c.group)
         {
             // every context pulls the other contexts' chunks out of their exchange buffers (same layout everywhere)
@@ -538,7 +545,11 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
     uint32_t K = 4;
     {
         uint64_t acc = 0;
-        const uint64_t want = nInst - nInst / 64;       // ~98.4 %
+        // ~98.4 % of the pairs in one chunk. (A smaller share shortens the scan -- bench segment, K = 9 / 10 / 11 / 12: 1.127 /
+        // 1.120 / 1.161 / 1.225 ms per pass; 95.1 % of the lives are <= 10 windows, 98.8 % <= 11 -- but where the
+        // distribution is steep the contexts of a sharded cohort pick different K from their own samples, the chunk order
+        // of stage 2 differs and with it the last bits of LR: tests/test_gpu_local_group.py caught exactly that with 15/16.)
+        const uint64_t want = nInst - nInst / 64;
         for (uint32_t l = 0; l <= 65; ++l)
         {
             acc += lifeHist[l];
@@ -795,7 +806,7 @@ bool buildChunksOnDevice(pd_ctx & c, const pd_segment & seg, StagedSegment & out
     uint32_t K = 4;
     {
         uint64_t acc = 0;
-        const uint64_t want = living - living / 64;       // ~98.4 %
+        const uint64_t want = living - living / 64;       // ~98.4 % (see buildChunks)
         for (uint32_t l = 0; l <= 65; ++l)
         {
             acc += c.hLifeHist[l];
@@ -1465,6 +1476,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         PD_HIP(hipEventCreate(&s2End));
 
         CtxExchange xch(*c);
+        c->nAllGathers = 0;
+        c->allGatherBytes = 0;
         const uint32_t world = c->world, sper = c->samplesPerRank, SG = c->nSamplesGlobal;
         // windows in which some sample of the cohort has a Q3 above the smallest threshold
         PinnedBuf<int> & winFlag = c->hWinFlag;
@@ -1739,6 +1752,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         c->timing.n_pair_chunks = s.nChunks;
         c->timing.n_candidate_cells = nCells;
         c->timing.max_life = s.maxLife;
+        c->timing.n_all_gathers = c->nAllGathers;
+        c->timing.all_gather_bytes = c->allGatherBytes;
 
         CallsBox * box = new CallsBox();
         std::memset(&box->pub, 0, sizeof(pd_calls));
