@@ -94,29 +94,32 @@ __global__ __launch_bounds__(256) void lifeStatsKernel(InstanceArrays in, uint64
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Block-wide inclusive prefix sum of the LDS array v[0 .. n) in place (256 threads).
+// Block-wide inclusive prefix sum of the LDS array v[0 .. n) in place (256 threads): every thread adds up its own
+// contiguous stretch, the 256 stretch totals are scanned once, then every thread rewrites its stretch -- three barriers
+// and one 8-step scan, whatever n is (scanning 256 elements at a time cost ~18 barriers per 256 elements).
 __device__ __forceinline__ void blockPrefixInPlace(unsigned * v, unsigned n, unsigned * scratch /* [256] */)
 {
-    unsigned carry = 0;
-    for (unsigned base = 0; base < n; base += 256u)
+    const unsigned per = (n + 255u) / 256u;
+    const unsigned lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    unsigned sum = 0;
+    for (unsigned i = lo; i < hi; ++i)
+        sum += v[i];
+    scratch[threadIdx.x] = sum;
+    __syncthreads();
+    for (unsigned o = 1; o < 256u; o <<= 1)
     {
-        const unsigned i = base + threadIdx.x;
-        unsigned x = i < n ? v[i] : 0u;
-        scratch[threadIdx.x] = x;
+        const unsigned t = threadIdx.x >= o ? scratch[threadIdx.x - o] : 0u;
         __syncthreads();
-        for (unsigned o = 1; o < 256u; o <<= 1)
-        {
-            const unsigned t = threadIdx.x >= o ? scratch[threadIdx.x - o] : 0u;
-            __syncthreads();
-            scratch[threadIdx.x] += t;
-            __syncthreads();
-        }
-        x = scratch[threadIdx.x] + carry;
-        if (i < n)
-            v[i] = x;
-        carry += scratch[255];
+        scratch[threadIdx.x] += t;
         __syncthreads();
     }
+    unsigned run = scratch[threadIdx.x] - sum;            // total of the stretches before this one
+    for (unsigned i = lo; i < hi; ++i)
+    {
+        run += v[i];
+        v[i] = run;
+    }
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void countKernel(InstanceArrays in, BuildEntities en, unsigned W, unsigned K, CountOut out)
@@ -252,7 +255,8 @@ __global__ __launch_bounds__(64) void scatterKernel(InstanceArrays in, BuildEnti
     for (unsigned i = lane; i < W + K - 1u; i += 64u)
         cursor[i] = ws[i];
     __syncthreads();
-    const bool real = e < en.nRg;
+    const bool real = e < en.nRg && out.pairs != nullptr;       // stage-2 arrays wanted (and this is a real read group)
+    const bool packed = out.pairsPk != nullptr;                 // stage-1 image wanted
     const uint64_t base = out.rgBase[e];
     const unsigned long long below = (1ull << lane) - 1ull;
     unsigned rgLo, rgHi;
@@ -260,17 +264,26 @@ __global__ __launch_bounds__(64) void scatterKernel(InstanceArrays in, BuildEnti
     for (unsigned rg = rgLo; rg < rgHi; ++rg)
     {
         const uint64_t lo = en.rgOffsets[rg], hi = en.rgOffsets[rg + 1];
+        // (the instances of the next block are fetched while this one is placed: the walk is a chain of dependent LDS
+        // steps, the loads must not be part of it)
+        Instance nextP;
+        nextP.dev = 0;
+        nextP.start = 0;
+        nextP.on = 0xffffffffu;
+        nextP.off = 0;
+        if (lo + lane < hi)
+            nextP = loadInstance(in, lo + lane);
         for (uint64_t blk = lo; blk < hi; blk += 64u)
         {
             const uint64_t i = blk + lane;
             const bool have = i < hi;
-            Instance p;
-            p.dev = 0;
-            p.start = 0;
-            p.on = 0xffffffffu;
-            p.off = 0;
-            if (have)
-                p = loadInstance(in, i);
+            const Instance p = nextP;
+            nextP.dev = 0;
+            nextP.start = 0;
+            nextP.on = 0xffffffffu;
+            nextP.off = 0;
+            if (i + 64u < hi)
+                nextP = loadInstance(in, i + 64u);
             const unsigned off = have ? min(p.off, W) : 0u;
             const unsigned nCh = (have && off > p.on) ? (off - p.on + K - 1u) / K : 0u;
             // runs of equal `on` among neighbouring lanes
@@ -333,7 +346,8 @@ __global__ __launch_bounds__(64) void scatterKernel(InstanceArrays in, BuildEnti
                         out.pairs[base + place] = q;
                         out.start[base + place] = p.start;
                     }
-                    out.pairsPk[base + place] = make_uint2(d16 | (d16 << 16), (chunkOff & 0xffffu) | (chunkOff << 16));
+                    if (packed)
+                        out.pairsPk[base + place] = make_uint2(d16 | (d16 << 16), (chunkOff & 0xffffu) | (chunkOff << 16));
                 }
             }
         }

@@ -196,6 +196,11 @@ struct StagedSegment
     DevBuf<uint2> pairsPk;
     DevBuf<uint32_t> endCount;
     DevBuf<uint8_t> rgPacked;
+    // index of the stage-1 image when it is cut with its own chunk life (SegmentView::maxLifePk); else the arrays above
+    DevBuf<uint64_t> rgBasePk;
+    DevBuf<uint32_t> winStartPk, endCountPk;
+    uint32_t maxLifePk = 0;
+    bool ownPkIndex = false;
     DevBuf<uint8_t> scanGeneric;
     const uint32_t * scanRg = nullptr;      // the context's table (see SegmentView::scanRg)
     uint32_t nRealRg = 0;
@@ -803,60 +808,91 @@ bool buildChunksOnDevice(pd_ctx & c, const pd_segment & seg, StagedSegment & out
     uint64_t living = 0;
     for (int l = 0; l <= 65; ++l)
         living += c.hLifeHist[l];
-    uint32_t K = 4;
-    {
+    // Chunk lives. Stage 2 (K): ~98.4 % of the pairs in one chunk, the rule of the host builder -- its chunk order is the
+    // order stage 2 adds pairs up in. Stage-1 image (K1 <= K): 15/16 in one chunk -- fewer slots per cell of the scan
+    // (bench segment, scan per pass with 9 / 10 / 11 / 12: 1.127 / 1.120 / 1.161 / 1.225 ms; 95.1 % of the lives are
+    // <= 10 windows, 98.8 % <= 11); Q3 does not depend on how the pairs are cut, so every context may pick its own.
+    auto lifeAt = [&](uint64_t tail) {
         uint64_t acc = 0;
-        const uint64_t want = living - living / 64;       // ~98.4 % (see buildChunks)
+        const uint64_t want = living - living / tail;
         for (uint32_t l = 0; l <= 65; ++l)
         {
             acc += c.hLifeHist[l];
             if (acc >= want)
-            {
-                K = std::max<uint32_t>(4, l);
-                break;
-            }
+                return std::min<uint32_t>(std::max<uint32_t>(4, l), 48);
         }
-        K = std::min<uint32_t>(K, 48);
-    }
+        return 48u;
+    };
+    uint32_t K = lifeAt(64), K1 = std::min(lifeAt(16), K);
     if (const char * e = getenv("POPDEL_HIP_MAXLIFE"))
-        K = std::max(1, atoi(e));
+        K1 = K = std::max(1, atoi(e));
+    if (const char * e = getenv("POPDEL_HIP_MAXLIFE_SCAN"))
+        K1 = std::min<uint32_t>(K, std::max(1, atoi(e)));
     if (pd::buildLdsBytes(W, K) > 160u * 1024u)
         return false;
+    const bool twoLives = K1 != K;
     out.maxLife = K;
+    out.maxLifePk = K1;
+    out.ownPkIndex = twoLives;
     out.nPairs = living;
     out.nActivePairs = c.hLifeHist[66];
-    // ---- counts -> index rows, chunk totals -> bases
-    const size_t wsRow = static_cast<size_t>(W) + K;
-    out.winStart.ensure(static_cast<size_t>(nEnt) * wsRow);
-    out.endCount.ensure(static_cast<size_t>(nEnt) * (W + 1));
+    // ---- counts -> index rows, chunk totals -> bases (per image if the lives differ)
+    out.winStart.ensure(static_cast<size_t>(twoLives ? nRg : nEnt) * (static_cast<size_t>(W) + K));
+    out.endCount.ensure(static_cast<size_t>(twoLives ? nRg : nEnt) * (W + 1));
     out.rgBase.ensure(nEnt);
     out.rgPacked.ensure(nEnt);
-    c.dEntChunks.ensure(nEnt);
-    c.dEntMax.ensure(nEnt);
-    c.dTotals.ensure(2);
+    c.dEntChunks.ensure(2 * static_cast<size_t>(nEnt));
+    c.dEntMax.ensure(2 * static_cast<size_t>(nEnt));
+    c.dTotals.ensure(4);
     c.dProblems.ensure(1);
-    c.hTotals.resize(3);
+    c.hTotals.resize(5);
     PD_HIP(hipMemsetAsync(c.dProblems.p, 0, sizeof(unsigned), cs));
-    pd::CountOut co;
-    co.winStart = out.winStart.p;
-    co.endCount = out.endCount.p;
-    co.entChunks = c.dEntChunks.p;
-    co.entMax = c.dEntMax.p;
-    co.rgPacked = out.rgPacked.p;
-    co.problems = c.dProblems.p;
-    if (!pd::launchCount(in, en, W, K, co, cs))
-        throw HipError{"the layout build kernel cannot get its LDS"};
-    PD_HIP(hipGetLastError());
-    pd::launchBaseScan(c.dEntChunks.p, nEnt, nRg, out.rgBase.p, c.dTotals.p, cs);
-    PD_HIP(hipGetLastError());
+    pd::BuildEntities enReal = en;
+    enReal.nScan = 0;
+    if (twoLives)
+    {
+        out.winStartPk.ensure(static_cast<size_t>(nEnt) * (static_cast<size_t>(W) + K1));
+        out.endCountPk.ensure(static_cast<size_t>(nEnt) * (W + 1));
+        out.rgBasePk.ensure(nEnt);
+    }
+    {
+        // stage-2 arrays (real read groups; all entities if there is one life only)
+        pd::CountOut co;
+        co.winStart = out.winStart.p;
+        co.endCount = out.endCount.p;
+        co.entChunks = c.dEntChunks.p;
+        co.entMax = c.dEntMax.p;
+        co.rgPacked = out.rgPacked.p;
+        co.problems = c.dProblems.p;
+        if (!pd::launchCount(in, twoLives ? enReal : en, W, K, co, cs))
+            throw HipError{"the layout build kernel cannot get its LDS"};
+        PD_HIP(hipGetLastError());
+        pd::launchBaseScan(c.dEntChunks.p, twoLives ? nRg : nEnt, nRg, out.rgBase.p, c.dTotals.p, cs);
+        PD_HIP(hipGetLastError());
+    }
+    if (twoLives)
+    {
+        pd::CountOut co;
+        co.winStart = out.winStartPk.p;
+        co.endCount = out.endCountPk.p;
+        co.entChunks = c.dEntChunks.p + nEnt;
+        co.entMax = c.dEntMax.p + nEnt;
+        co.rgPacked = out.rgPacked.p;
+        co.problems = c.dProblems.p;
+        if (!pd::launchCount(in, en, W, K1, co, cs))
+            throw HipError{"the layout build kernel cannot get its LDS"};
+        PD_HIP(hipGetLastError());
+        pd::launchBaseScan(c.dEntChunks.p + nEnt, nEnt, nRg, out.rgBasePk.p, c.dTotals.p + 2, cs);
+        PD_HIP(hipGetLastError());
+    }
     c.hEntMax.resize(nEnt);
-    PD_HIP(hipMemcpyAsync(c.hTotals.data(), c.dTotals.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
-    PD_HIP(hipMemcpyAsync(c.hTotals.data() + 2, c.dProblems.p, sizeof(unsigned), hipMemcpyDeviceToHost, cs));
-    PD_HIP(hipMemcpyAsync(c.hEntMax.data(), c.dEntMax.p, nEnt * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+    PD_HIP(hipMemcpyAsync(c.hTotals.data(), c.dTotals.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
+    PD_HIP(hipMemcpyAsync(c.hTotals.data() + 4, c.dProblems.p, sizeof(unsigned), hipMemcpyDeviceToHost, cs));
+    PD_HIP(hipMemcpyAsync(c.hEntMax.data(), c.dEntMax.p + (twoLives ? nEnt : 0), nEnt * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
     PD_HIP(hipStreamSynchronize(cs));
-    if (static_cast<unsigned>(c.hTotals[2] & 0xffffffffu) != 0)
+    if (static_cast<unsigned>(c.hTotals[4] & 0xffffffffu) != 0)
         throw HipError{"pair instances of a read group are not ordered by their first window (pd_segment: non-decreasing `on`)"};
-    const uint64_t totalReal = c.hTotals[0], totalAll = c.hTotals[1];
+    const uint64_t totalReal = c.hTotals[0], totalPk = twoLives ? c.hTotals[3] : c.hTotals[1];
     out.nChunks = totalReal;
     {
         // ... of 99 % of the streams: a few unusually deep samples should not cost everybody else occupancy
@@ -867,16 +903,30 @@ bool buildChunksOnDevice(pd_ctx & c, const pd_segment & seg, StagedSegment & out
     // ---- chunks to their places
     out.pairs.ensure(totalReal);
     out.start.ensure(totalReal);
-    out.pairsPk.ensure(totalAll + 128);            // the scan's LDS-DMA copies whole 128-chunk pieces (stage1.hip)
-    pd::ScatterOut so;
-    so.pairs = out.pairs.p;
-    so.start = out.start.p;
-    so.pairsPk = out.pairsPk.p;
-    so.rgBase = out.rgBase.p;
-    so.winStart = out.winStart.p;
-    if (!pd::launchScatter(in, en, W, K, so, cs))
-        throw HipError{"the layout scatter kernel cannot get its LDS"};
-    PD_HIP(hipGetLastError());
+    out.pairsPk.ensure(totalPk + 128);             // the scan's LDS-DMA copies whole 128-chunk pieces (stage1.hip)
+    {
+        pd::ScatterOut so;
+        so.pairs = out.pairs.p;
+        so.start = out.start.p;
+        so.pairsPk = twoLives ? nullptr : out.pairsPk.p;
+        so.rgBase = out.rgBase.p;
+        so.winStart = out.winStart.p;
+        if (!pd::launchScatter(in, twoLives ? enReal : en, W, K, so, cs))
+            throw HipError{"the layout scatter kernel cannot get its LDS"};
+        PD_HIP(hipGetLastError());
+    }
+    if (twoLives)
+    {
+        pd::ScatterOut so;
+        so.pairs = nullptr;
+        so.start = nullptr;
+        so.pairsPk = out.pairsPk.p;
+        so.rgBase = out.rgBasePk.p;
+        so.winStart = out.winStartPk.p;
+        if (!pd::launchScatter(in, en, W, K1, so, cs))
+            throw HipError{"the layout scatter kernel cannot get its LDS"};
+        PD_HIP(hipGetLastError());
+    }
     const size_t blocksPerSample = (static_cast<size_t>(W) + 2 * pd::kStage1Block - 1) / (2 * pd::kStage1Block);
     out.hasScanGeneric = nV != 0;
     if (nV != 0)
@@ -898,6 +948,10 @@ pd::SegmentView viewOf(const StagedSegment & s)
     v.winStart = s.winStart.p;
     v.pairsPk = s.pairsPk.p;
     v.endCount = s.endCount.p;
+    v.rgBasePk = s.ownPkIndex ? s.rgBasePk.p : s.rgBase.p;
+    v.winStartPk = s.ownPkIndex ? s.winStartPk.p : s.winStart.p;
+    v.endCountPk = s.ownPkIndex ? s.endCountPk.p : s.endCount.p;
+    v.maxLifePk = s.ownPkIndex ? s.maxLifePk : s.maxLife;
     v.rgPacked = s.rgPacked.p;
     v.scanRg = s.scanRg;
     v.scanGeneric = s.hasScanGeneric ? s.scanGeneric.p : nullptr;
@@ -1303,6 +1357,7 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
             const size_t e0 = lo * (static_cast<size_t>(W) + 1), e1 = hi * (static_cast<size_t>(W) + 1);
             PD_HIP(hipMemcpyAsync(s->endCount.p + e0, endCount.data() + e0, (e1 - e0) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
         };
+        s->ownPkIndex = false;                      // the host builder cuts both images with one chunk life
         buildChunks(*c, *seg, *s, pairs, start, rgBase, winStart, pairsPk, endCount, rgPacked, c->hScanGeneric, sized, slabDone);
         s->rgPacked.upload(rgPacked, cs);
         s->hasScanGeneric = !c->hScanGeneric.empty();

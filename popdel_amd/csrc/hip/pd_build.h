@@ -44,9 +44,9 @@ struct CountOut
 
 struct ScatterOut
 {
-    PairDO *         pairs;       // [real chunks]
+    PairDO *         pairs;       // [real chunks]   stage-2 arrays, or null
     uint32_t *       start;       // [real chunks]
-    uint2 *          pairsPk;     // [all chunks]
+    uint2 *          pairsPk;     // [all chunks]    stage-1 image, or null
     const uint64_t * rgBase;
     const uint32_t * winStart;
 };

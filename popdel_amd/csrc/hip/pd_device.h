@@ -59,8 +59,16 @@ struct SegmentView
     const uint32_t * winStart;     // [nRg * (W + K)] first chunk (relative to rgBase) whose slot >= x
     // stage-1 image of the chunks: deviation and end window as int16, each duplicated into both halves of a dword
     // (ready for packed 16-bit arithmetic on two windows at once); only valid for read groups with rgPacked != 0
-    const uint2 *    pairsPk;      // [nChunks]
+    const uint2 *    pairsPk;      // [chunks of the stage-1 image]
     const uint32_t * endCount;     // [nRg * (W + 1)] number of chunks of the read group that ended at or before w
+    // The stage-1 image is cut with ITS OWN chunk life (maxLifePk <= maxLife) and has its own index: Q3 is an order
+    // statistic of integers and does not depend on how the pairs are cut, so the scan takes the life that makes it
+    // fastest (fewer slots per cell), while stage 2 keeps the chunk order its sums are formed in. Rows for the real
+    // read groups and the scan read groups behind them.
+    const uint64_t * rgBasePk;     // [nRg + nScanRg] first chunk of the stream in pairsPk
+    const uint32_t * winStartPk;   // [(nRg + nScanRg) * (W + maxLifePk)]
+    const uint32_t * endCountPk;   // [(nRg + nScanRg) * (W + 1)]
+    uint32_t         maxLifePk;
     const uint8_t *  rgPacked;     // [nRg + nScanRg] 1 if all deviations fit int16 and W fits 16 bits
     // Samples with several read groups get a "scan read group" appended behind the real ones: the chunks of all their
     // read groups as ONE stream (stage-1 image, winStart and endCount rows only), so that the scan kernel treats them

@@ -361,13 +361,13 @@ __device__ __forceinline__ int scanBlock(const SegmentView & seg, const CohortVi
     constexpr unsigned kMaxCand = kBig ? 128u : 64u;
     const unsigned w0 = bx * kPackedWindows;
     const unsigned W = seg.nWindows;
-    const unsigned K = seg.maxLife;
+    const unsigned K = seg.maxLifePk;            // chunk life of the stage-1 image (its own, see SegmentView)
     const unsigned tid = threadIdx.x;
     const unsigned rg0 = seg.scanRg[s];          // the (possibly appended) read group whose stream holds all pairs of s
     const bool rgOverloaded = rg0 >= seg.nRealRg && seg.scanGeneric[(size_t)(rg0 - seg.nRealRg) * blocksPerSample + bx] != 0;
     if (!(K <= 64u && seg.rgPacked[rg0]) || rgOverloaded)
         return 1;
-    const uint32_t * ws = seg.winStart + (size_t)rg0 * (W + K);
+    const uint32_t * ws = seg.winStartPk + (size_t)rg0 * (W + K);
     const unsigned wlo0 = w0;                                        // first slot the block's windows see
     const unsigned whi = min(W, w0 + kPackedWindows);                // one past the block's last window
     const unsigned nWs = whi - w0 + K;                               // slots w0 .. whi + K - 1 (the last one is the end entry)
@@ -375,7 +375,7 @@ __device__ __forceinline__ int scanBlock(const SegmentView & seg, const CohortVi
         ldsWs[i] = ws[wlo0 + i];
     // pairs that ended at or before the lane's windows (host-built prefix counts): n(w) = started - ended
     const unsigned wA = w0 + 2u * tid, wB = wA + 1u;
-    const uint32_t * ec = seg.endCount + (size_t)rg0 * (W + 1);
+    const uint32_t * ec = seg.endCountPk + (size_t)rg0 * (W + 1);
     const unsigned endedA = (wA < W) ? ec[wA] : 0u;
     const unsigned endedB = (wB < W) ? ec[wB] : 0u;
     __syncthreads();
@@ -386,7 +386,7 @@ __device__ __forceinline__ int scanBlock(const SegmentView & seg, const CohortVi
     // 16 B = 128 chunks per wave instruction, no VGPR round trip, no ds_write, no per-element address arithmetic; the
     // register-staged copy cost ~100 VALU per wave). The source is aligned down to 16 bytes: LDS entry i is stream entry
     // A + i with A = A0 - mis; the last instruction may copy up to 127 chunks beyond the block's (both arrays are padded).
-    const size_t g0 = seg.rgBase[rg0] + A0;
+    const size_t g0 = seg.rgBasePk[rg0] + A0;
     const unsigned mis = (unsigned)(g0 & 1u);
     const unsigned A = A0 - mis;
     if (!tooMany)
@@ -623,12 +623,12 @@ __global__ __launch_bounds__(kStage1Block) void stage1FallbackKernel(SegmentView
         const unsigned s = tile / tilesPerSample;
         const unsigned w0 = (tile % tilesPerSample) * kStage1Block;
         const unsigned W = seg.nWindows;
-        const unsigned K = seg.maxLife;
         const unsigned tid = threadIdx.x;
         const unsigned w = w0 + tid;
         // the sample's own read group or its scan read group (all pairs of the sample as one stream, packed image only)
         const unsigned rg0 = seg.scanRg[s];
         const bool merged = rg0 >= seg.nRealRg;
+        const unsigned K = merged ? seg.maxLifePk : seg.maxLife;     // each image with its own chunk life and index
         const bool rgOverloaded = merged && seg.scanGeneric[(size_t)(rg0 - seg.nRealRg) * ((W + 2u * kStage1Block - 1u) / (2u * kStage1Block)) +
                                                             w0 / (2u * kStage1Block)] != 0;
         int q = 0;
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(kStage1Block) void stage1FallbackKernel(SegmentView
         __syncthreads();                                           // LDS reuse across tiles
         if (K <= 64u && !rgOverloaded && (!merged || seg.rgPacked[rg0]))
         {
-            const uint32_t * ws = seg.winStart + (size_t)rg0 * (W + K);
+            const uint32_t * ws = (merged ? seg.winStartPk : seg.winStart) + (size_t)rg0 * (W + K);
             const unsigned wlo0 = w0;
             const unsigned whi = min(W, w0 + kStage1Block);
             const unsigned nWs = whi - w0 + K;
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(kStage1Block) void stage1FallbackKernel(SegmentView
                 }
                 else
                 {
-                    const uint2 * src = seg.pairsPk + seg.rgBase[rg0] + A;
+                    const uint2 * src = seg.pairsPk + seg.rgBasePk[rg0] + A;
                     for (unsigned i = tid; i < nPairs; i += kStage1Block)
                     {
                         const uint2 e = src[i];
