@@ -201,6 +201,13 @@ struct StagedSegment
     DevBuf<uint32_t> winStartPk, endCountPk;
     uint32_t maxLifePk = 0;
     bool ownPkIndex = false;
+    hipEvent_t built = nullptr;             // device-side build: recorded behind its last kernel (copy stream); runs wait for it
+    bool waitBuilt = false;
+    ~StagedSegment()
+    {
+        if (built)
+            (void)hipEventDestroy(built);
+    }
     DevBuf<uint8_t> scanGeneric;
     const uint32_t * scanRg = nullptr;      // the context's table (see SegmentView::scanRg)
     uint32_t nRealRg = 0;
@@ -1310,6 +1317,7 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
             s.reset(new StagedSegment());
         }
         s->ownedBySubmit = false;
+        s->waitBuilt = false;
         s->firstPos = seg->first_window_pos;
         s->nWindows = seg->n_windows;
         s->shift = seg->window_shift;
@@ -1320,7 +1328,13 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
         {
             s->scanRg = c->dScanRg.p;
             s->nRealRg = c->nRg;
-            PD_HIP(hipStreamSynchronize(c->copyStream));   // the host scratch is reused by the next call
+            // No wait for the last build kernels: the uploads have completed (the build's own syncs come after them), so
+            // the host scratch is free; the kernels keep running on the copy stream while the caller prepares the next
+            // segment, and the first run of this segment waits for the event on the device.
+            if (!s->built)
+                PD_HIP(hipEventCreateWithFlags(&s->built, hipEventDisableTiming));
+            PD_HIP(hipEventRecord(s->built, c->copyStream));
+            s->waitBuilt = true;
             *handle = c->nextHandle++;
             c->staged[*handle] = std::move(s);
             return 0;
@@ -1393,6 +1407,11 @@ static void launchScan(pd_ctx * c, Run & run)
     StagedSegment & s = *sit->second;
     Stage1Out & o = c->s1[run.set];
     hipStream_t st = c->stream;
+    if (s.waitBuilt)
+    {
+        PD_HIP(hipStreamWaitEvent(st, s.built, 0));
+        s.waitBuilt = false;
+    }
     const size_t cells = static_cast<size_t>(c->nSamples) * s.nWindows;
     o.q3.ensure(cells);
     o.flags.ensure(cells);
