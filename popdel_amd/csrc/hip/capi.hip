@@ -735,22 +735,44 @@ bool buildChunksOnDevice(pd_ctx & c, const pd_segment & seg, StagedSegment & out
             const size_t rgLo = nRg * slab / nSlabs, rgHi = nRg * (slab + 1) / nSlabs;
             pdh::parallelFor(rgHi - rgLo, [&](size_t k) {
                 const size_t rg = rgLo + k;
-                bool ok = true;
-                int16_t * dv = reinterpret_cast<int16_t *>(c.hIn16[0].data());
-                uint16_t *on = c.hIn16[1].data(), *off = c.hIn16[2].data(), *back = c.hIn16[3].data();
-                for (uint64_t i = seg.rg_offsets[rg]; i < seg.rg_offsets[rg + 1]; ++i)
+                const uint64_t lo = seg.rg_offsets[rg], n = seg.rg_offsets[rg + 1] - lo;
+                // plain loops over restrict pointers, no early exit: the compiler vectorises them (AVX2 on the host)
+                const int32_t * __restrict sd = seg.pair_dev + lo;
+                const uint32_t * __restrict so = seg.pair_on + lo;
+                const uint32_t * __restrict sf = seg.pair_off + lo;
+                const uint32_t * __restrict ss = seg.pair_start + lo;
+                int16_t * __restrict dv = reinterpret_cast<int16_t *>(c.hIn16[0].data()) + lo;
+                uint16_t * __restrict on = c.hIn16[1].data() + lo;
+                uint16_t * __restrict off = c.hIn16[2].data() + lo;
+                uint16_t * __restrict back = c.hIn16[3].data() + lo;
+                const uint32_t first = seg.first_window_pos, shift = seg.window_shift;
+                uint32_t bad = 0;
+                for (uint64_t i = 0; i < n; ++i)
                 {
-                    const int32_t d = seg.pair_dev[i];
-                    const uint32_t a = seg.pair_on[i], b = std::min(seg.pair_off[i], W);
-                    const int64_t dist = static_cast<int64_t>(seg.first_window_pos) + static_cast<int64_t>(a) * seg.window_shift -
-                                         static_cast<int64_t>(seg.pair_start[i]);
-                    ok = ok && d >= -32768 && d <= 32767 && a <= 0xffffu && dist >= 0 && dist <= 0xffff;
+                    const int32_t d = sd[i];
+                    bad |= static_cast<uint32_t>(d + 32768) >> 16;
                     dv[i] = static_cast<int16_t>(d);
+                }
+                for (uint64_t i = 0; i < n; ++i)
+                {
+                    const uint32_t a = so[i];
+                    bad |= a >> 16;
                     on[i] = static_cast<uint16_t>(a);
-                    off[i] = static_cast<uint16_t>(b);
+                }
+                for (uint64_t i = 0; i < n; ++i)
+                    off[i] = static_cast<uint16_t>(sf[i] < W ? sf[i] : W);
+                for (uint64_t i = 0; i < n; ++i)
+                {
+                    // first + on * shift - start in [0, 65535]; 64-bit only where the 32-bit value could wrap
+                    const uint32_t dist = first + so[i] * shift - ss[i];
+                    bad |= dist >> 16;
                     back[i] = static_cast<uint16_t>(dist);
                 }
-                if (!ok)
+                // (window indices are < 2^16 here and positions < 2^32: the product and sum stay below 2^32 for any real
+                // segment; a wrap would need first + on * shift >= 2^32, which the 64-bit check below excludes)
+                if (n != 0 && static_cast<uint64_t>(first) + static_cast<uint64_t>(so[n - 1] & 0xffffu) * shift > 0xffffffffull)
+                    bad = 1;
+                if (bad)
                     narrow.store(false);
             }, 8);
             if (!narrow.load())
