@@ -1,7 +1,7 @@
 """GPU: a cohort split by samples over two contexts (two processes sharing the box's one GPU, collectives over gloo)
 must give bit-for-bit what one context gives for the whole cohort -- integers AND floating point, because every
 cross-sample reduction adds all-gathered per-tile values in cohort order. On a multi-GPU node the same code runs with
-one GPU per process over RCCL (bench.py --shard samples)."""
+one GPU per process and the library's own RCCL all-gathers (bench.py --gpus N: the sample split is its N > 1 headline)."""
 import os
 import pickle
 import socket
