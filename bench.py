@@ -422,12 +422,35 @@ def main():
         dog.start()
         try:
             native = args.exchange == "native" or (args.exchange == "auto" and args.backend == "nccl")
-            shard = distributed.SampleShard(hip, [rg] * (R * S * world), list(range(0, R * S * world + 1, R)), rank, world,
-                                            device=local_rank, native=native)
-            h_sh = shard.ctx.stage(seg)
-            lane = Lane(shard.ctx, h_sh, args.serial)
-            acc0 = [0.0, 0.0, 0, 0, None]
-            lane.passes(2, acc0)                                   # first exchanges (communicator set-up) outside the warm-up
+
+            def open_shard(use_native):
+                sh = distributed.SampleShard(hip, [rg] * (R * S * world), list(range(0, R * S * world + 1, R)), rank, world,
+                                             device=local_rank, native=use_native)
+                h = sh.ctx.stage(seg)
+                ln = Lane(sh.ctx, h, args.serial)
+                ln.passes(2, [0.0, 0.0, 0, 0, None])                # first exchanges (communicator set-up) outside the warm-up
+                return sh, h, ln
+
+            # With --exchange auto a failure of the library's own RCCL exchange (set-up or first passes) on ANY rank sends
+            # all ranks to the host-callback exchange over torch.distributed; the ranks agree on that with one all-reduce.
+            opened, exchange_note = None, None
+            try:
+                opened = open_shard(native)
+                failed = 0
+            except Exception as e:
+                failed, exchange_note = 1, "%s: %s" % (type(e).__name__, e)
+            if native and args.exchange == "auto":
+                flag = torch.tensor([failed], device=red_device, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if int(flag.item()):
+                    if opened is not None:
+                        opened[0].close()
+                    native = False
+                    opened = open_shard(False)
+                    exchange_note = "library-native RCCL exchange failed on a rank (%s); host callbacks used" % exchange_note
+            elif failed:
+                raise RuntimeError(exchange_note)
+            shard, h_sh, lane = opened
 
             def step():
                 acc = [0.0, 0.0, 0, 0, None]
@@ -443,6 +466,7 @@ def main():
                             windows_per_step=total_passes * W,
                             exchange=dict(all_gathers_per_pass=tot[4]["n_all_gathers"], all_gather_bytes_per_pass=tot[4]["all_gather_bytes"],
                                           backend="rccl (library-native, ncclAllGather on the context's stream)" if native else dist.get_backend(),
+                                          note=exchange_note,
                                           what="window flags, Q3 of flagged windows, a5 counts, per-iteration tile sums + read "
                                                "group 0's record, LR sums, support-percentile digit histograms"),
                             parallelism="ONE cohort of %d samples sharded by samples over %d ranks (%d each); every rank scans "
