@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 7
+#define PD_ABI_VERSION 8
 
 /* One read group after start-up conditioning.
  * Replaces: `Histogram` (reference insert_histogram_popdel.h:19-43) after processHistogram()
@@ -234,6 +234,35 @@ int pd_ctx_set_shard(pd_ctx *ctx, const pd_shard *shard);
 int pd_segment_collect(pd_ctx *ctx, uint64_t ticket, pd_calls **out);
 
 void pd_calls_free(pd_calls *calls);
+
+/* ---- per-sample part of call merging on the device -------------------------------------------------------------------
+ * The reference merges the window calls of a segment into variants (unifyCalls, utils_popdel.h:567-654): a scalar pass
+ * over call-level fields decides which calls form a variant, then setGenotypes() (:446-501) averages the members'
+ * phred-scaled likelihoods and takes per-component upper medians of LAD / DAD per sample, and setFreqFromGTs() (:339-359)
+ * counts alleles. With pd_ctx_keep_results_on_device(ctx, 1), pd_segment_collect() returns the call-level fields only
+ * (pl, lad, dad, first_last are NULL) and keeps the per-sample arrays in HBM until the next pd_segment_collect() on the
+ * context; the host runs the scalar pass and hands the groups to pd_calls_merge(): group g consists of the calls
+ * member_index[member_offsets[g] .. member_offsets[g + 1]) (indices into `calls`), head_index[g] is the call whose
+ * first_last columns the variant keeps. Returned (callee-owned, pd_merged_free): per group and sample the merged PL /
+ * LAD / DAD / first_last, per group the allele count over this context's samples. Return code 2: a LAD / DAD value
+ * beyond 127 (the kernel's median bins) -- nothing is returned; fetch the columns and merge on the host.
+ * pd_calls_fetch_columns() fills pl / lad / dad / first_last of such a pd_calls after the fact (same lifetime rule).
+ * A segment whose stage 2 ran in several batches is returned with its columns regardless of the mode. */
+typedef struct pd_merged
+{
+    uint32_t  n_groups;
+    uint32_t  n_samples;
+    uint32_t *pl;           /* [n_groups][n_samples][3] */
+    uint32_t *lad;          /* [n_groups][n_samples][3] */
+    uint32_t *dad;          /* [n_groups][n_samples][5] */
+    uint32_t *first_last;   /* [n_groups][n_samples][2] */
+    uint32_t *alleles;      /* [n_groups] */
+} pd_merged;
+int pd_ctx_keep_results_on_device(pd_ctx *ctx, int on);
+int pd_calls_merge(pd_ctx *ctx, const pd_calls *calls, uint32_t n_groups, const uint32_t *member_offsets,
+                   const uint32_t *member_index, const uint32_t *head_index, pd_merged **out);
+int pd_calls_fetch_columns(pd_ctx *ctx, pd_calls *calls);
+void pd_merged_free(pd_merged *merged);
 
 /* Stage-1 values of the most recently collected segment; valid until the next submit/run issued AFTER that collect. */
 int pd_stage1_last(pd_ctx *ctx, pd_stage1_view *out);

@@ -1060,6 +1060,17 @@ int pd_log_table_view(pd_ctx * c, uint32_t rg, double * value, double * logValue
     return 0;
 }
 
+// per-sample merging on the device: not offered by the oracle (the host driver then merges on the host)
+int pd_ctx_keep_results_on_device(pd_ctx *, int) { return 1; }
+int pd_calls_merge(pd_ctx *, const pd_calls *, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, pd_merged ** out)
+{
+    if (out)
+        *out = nullptr;
+    return 1;
+}
+int pd_calls_fetch_columns(pd_ctx *, pd_calls *) { return 1; }
+void pd_merged_free(pd_merged *) {}
+
 int pd_rccl_unique_id(uint8_t *) { return 1; }
 
 int pd_ctx_set_shard_rccl(pd_ctx * c, const pd_shard *, const uint8_t *)

@@ -336,6 +336,11 @@ struct pd_ctx
     DevBuf<unsigned> dSuppFirst, dSuppLast, dEmit;
     DevBuf<uint32_t> dPl, dLad, dDad, dFl, dOutPl;
     pd_timing timing;
+    // per-sample result arrays kept in HBM for pd_calls_merge (pd_ctx_keep_results_on_device)
+    bool keepOnDevice = false;
+    const pd_calls * keptCalls = nullptr;   // the collect whose columns sit in dOutPl
+    DevBuf<uint32_t> dMergeIdx, dMergeOut;
+    DevBuf<unsigned> dMergeCounters;
     uint32_t nAllGathers = 0;       // of the collect in progress
     uint64_t allGatherBytes = 0;
 
@@ -1805,7 +1810,10 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         }
         const uint32_t n = (uint32_t)emit.size();
         const size_t perSample = static_cast<size_t>(n) * S;
-        if (n != 0)
+        // columns stay in HBM (pd_ctx_keep_results_on_device) if they are all there: one batch
+        const bool keep = c->keepOnDevice && nBatches == 1 && nLastBatch != 0;
+        c->keptCalls = nullptr;
+        if (n != 0 && !keep)
         {
             pinned = takePinned(perSample * 13 * sizeof(uint32_t));
             hPl = static_cast<uint32_t *>(pinned.p);
@@ -1814,7 +1822,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             hFl = hDad + perSample * 5;
         }
         PD_HIP(hipEventRecord(s2End, c->stream));
-        const bool direct = nBatches == 1 && nLastBatch != 0;      // results of the only batch still sit in dOutPl
+        const bool direct = nBatches == 1 && nLastBatch != 0 && !keep;      // results of the only batch still sit in dOutPl
         if (direct)
             PD_HIP(hipEventRecord(c->resultsPacked, c->stream));
         // the scan of a waiting ticket starts right behind this segment's last kernel ...
@@ -1828,7 +1836,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             PD_HIP(hipStreamWaitEvent(c->copyStream, c->resultsPacked, 0));
             PD_HIP(hipMemcpyAsync(hPl, c->dOutPl.p, perSample * 13 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->copyStream));
         }
-        else if (n != 0)
+        else if (n != 0 && !keep)
         {
             std::memcpy(hPl, accPl.data(), accPl.size() * sizeof(uint32_t));
             std::memcpy(hLad, accLad.data(), accLad.size() * sizeof(uint32_t));
@@ -1884,6 +1892,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         pc->lad = hLad;
         pc->dad = hDad;
         pc->first_last = hFl;
+        if (keep)
+            c->keptCalls = pc;
         *out = pc;
     }
     catch (const HipError & e)
@@ -2016,6 +2026,163 @@ int pd_log_table_view(pd_ctx * c, uint32_t rg, double * value, double * logValue
     catch (...)
     {
         return fail(c, "pd_log_table_view: unknown exception");
+    }
+    return 0;
+}
+
+int pd_ctx_keep_results_on_device(pd_ctx * c, int on)
+{
+    if (!c)
+        return 1;
+    c->keepOnDevice = on != 0;
+    return 0;
+}
+
+namespace {
+struct MergedBox
+{
+    pd_merged pub;
+    PinnedBlock pinned;
+};
+}  // namespace
+
+int pd_calls_merge(pd_ctx * c, const pd_calls * calls, uint32_t n_groups, const uint32_t * member_offsets, const uint32_t * member_index,
+                   const uint32_t * head_index, pd_merged ** out)
+{
+    if (!c || !calls || !out || (n_groups != 0 && (!member_offsets || !member_index || !head_index)))
+        return fail(c, "pd_calls_merge: invalid argument");
+    *out = nullptr;
+    if (calls != c->keptCalls)
+        return fail(c, "pd_calls_merge: the per-sample arrays of these calls are not (or no longer) on the device");
+    PinnedBlock pinned;
+    int rc = 0;
+    try
+    {
+        PD_HIP(hipSetDevice(c->device));
+        const uint32_t S = calls->n_samples, n = calls->n_calls;
+        const uint32_t nMembers = n_groups ? member_offsets[n_groups] : 0;
+        for (uint32_t m = 0; m < nMembers; ++m)
+            if (member_index[m] >= n)
+                return fail(c, "pd_calls_merge: member index out of range");
+        for (uint32_t g = 0; g < n_groups; ++g)
+            if (head_index[g] >= n || member_offsets[g + 1] < member_offsets[g])
+                return fail(c, "pd_calls_merge: malformed group");
+        const size_t perOut = static_cast<size_t>(n_groups) * S;
+        MergedBox * box = new MergedBox();
+        std::memset(&box->pub, 0, sizeof(pd_merged));
+        box->pub.n_groups = n_groups;
+        box->pub.n_samples = S;
+        if (n_groups != 0)
+        {
+            // indices up, kernel, merged columns down
+            std::vector<uint32_t> idx;
+            idx.insert(idx.end(), member_offsets, member_offsets + n_groups + 1);
+            idx.insert(idx.end(), head_index, head_index + n_groups);
+            idx.insert(idx.end(), member_index, member_index + nMembers);
+            c->dMergeIdx.upload(idx, c->stream);
+            c->dMergeOut.ensure(perOut * 13);
+            c->dMergeCounters.ensure(n_groups + 1);
+            PD_HIP(hipMemsetAsync(c->dMergeCounters.p, 0, (n_groups + 1) * sizeof(unsigned), c->stream));
+            const size_t per = static_cast<size_t>(n) * S;
+            pd::MergeIn in;
+            in.pl = c->dOutPl.p;
+            in.lad = in.pl + per * 3;
+            in.dad = in.lad + per * 3;
+            in.fl = in.dad + per * 5;
+            in.memberOffsets = c->dMergeIdx.p;
+            in.headIndex = c->dMergeIdx.p + n_groups + 1;
+            in.memberIndex = in.headIndex + n_groups;
+            in.nSamples = S;
+            pd::MergeOut mo;
+            mo.pl = c->dMergeOut.p;
+            mo.lad = mo.pl + perOut * 3;
+            mo.dad = mo.lad + perOut * 3;
+            mo.fl = mo.dad + perOut * 5;
+            mo.alleles = c->dMergeCounters.p;
+            mo.overflow = c->dMergeCounters.p + n_groups;
+            if (!pd::launchMergeGroups(in, mo, n_groups, c->stream))
+                throw HipError{"the merge kernel cannot get its LDS"};
+            PD_HIP(hipGetLastError());
+            pinned = takePinned((perOut * 13 + n_groups + 1) * sizeof(uint32_t));
+            uint32_t * h = static_cast<uint32_t *>(pinned.p);
+            PD_HIP(hipMemcpyAsync(h, c->dMergeOut.p, perOut * 13 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            PD_HIP(hipMemcpyAsync(h + perOut * 13, c->dMergeCounters.p, (n_groups + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            PD_HIP(hipStreamSynchronize(c->stream));
+            if (h[perOut * 13 + n_groups] != 0)
+            {
+                givePinned(pinned);
+                delete box;
+                c->error = "pd_calls_merge: a LAD/DAD value beyond the median bins; merge this segment on the host";
+                return 2;
+            }
+            box->pub.pl = h;
+            box->pub.lad = h + perOut * 3;
+            box->pub.dad = h + perOut * 6;
+            box->pub.first_last = h + perOut * 11;
+            box->pub.alleles = h + perOut * 13;
+        }
+        box->pinned = pinned;
+        *out = &box->pub;
+    }
+    catch (const HipError & e)
+    {
+        rc = fail(c, "pd_calls_merge: " + e.what);
+    }
+    catch (const std::exception & e)
+    {
+        rc = fail(c, std::string("pd_calls_merge: ") + e.what());
+    }
+    catch (...)
+    {
+        rc = fail(c, "pd_calls_merge: unknown exception");
+    }
+    if (rc != 0)
+        givePinned(pinned);
+    return rc;
+}
+
+void pd_merged_free(pd_merged * m)
+{
+    if (!m)
+        return;
+    MergedBox * box = reinterpret_cast<MergedBox *>(m);           // pub is the first member
+    givePinned(box->pinned);
+    delete box;
+}
+
+int pd_calls_fetch_columns(pd_ctx * c, pd_calls * calls)
+{
+    if (!c || !calls)
+        return fail(c, "pd_calls_fetch_columns: invalid argument");
+    if (calls->pl)
+        return 0;                                   // they are there already
+    if (calls != c->keptCalls)
+        return fail(c, "pd_calls_fetch_columns: the per-sample arrays of these calls are not (or no longer) on the device");
+    try
+    {
+        PD_HIP(hipSetDevice(c->device));
+        const size_t per = static_cast<size_t>(calls->n_calls) * calls->n_samples;
+        CallsBox * box = reinterpret_cast<CallsBox *>(calls);     // pub is the first member
+        box->pinned = takePinned(per * 13 * sizeof(uint32_t));
+        uint32_t * h = static_cast<uint32_t *>(box->pinned.p);
+        PD_HIP(hipMemcpyAsync(h, c->dOutPl.p, per * 13 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        PD_HIP(hipStreamSynchronize(c->stream));
+        calls->pl = h;
+        calls->lad = h + per * 3;
+        calls->dad = h + per * 6;
+        calls->first_last = h + per * 11;
+    }
+    catch (const HipError & e)
+    {
+        return fail(c, "pd_calls_fetch_columns: " + e.what);
+    }
+    catch (const std::exception & e)
+    {
+        return fail(c, std::string("pd_calls_fetch_columns: ") + e.what());
+    }
+    catch (...)
+    {
+        return fail(c, "pd_calls_fetch_columns: unknown exception");
     }
     return 0;
 }

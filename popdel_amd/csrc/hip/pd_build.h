@@ -59,5 +59,28 @@ bool launchScatter(const InstanceArrays & in, const BuildEntities & en, unsigned
 void launchScanGeneric(const BuildEntities & en, const RgConst * rgConst, const uint32_t * winStart, const uint32_t * endCount, unsigned W,
                        unsigned K, uint8_t * scanGeneric, unsigned blocksPerSample, hipStream_t st);
 
+// merge.hip: per-sample part of call merging on the device
+struct MergeIn
+{
+    const uint32_t * pl;
+    const uint32_t * lad;
+    const uint32_t * dad;
+    const uint32_t * fl;
+    const uint32_t * memberOffsets;
+    const uint32_t * memberIndex;
+    const uint32_t * headIndex;
+    unsigned         nSamples;
+};
+struct MergeOut
+{
+    uint32_t * pl;
+    uint32_t * lad;
+    uint32_t * dad;
+    uint32_t * fl;
+    unsigned * alleles;
+    unsigned * overflow;
+};
+bool launchMergeGroups(const MergeIn & in, const MergeOut & out, unsigned nGroups, hipStream_t st);
+
 }  // namespace pd
 #endif

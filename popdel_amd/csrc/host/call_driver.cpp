@@ -171,6 +171,9 @@ private:
     std::vector<uint64_t> tickets_;
     template <typename F>
     void onEveryContext(F fn);
+    void chooseMergeSite();
+    bool mergeOnDevice_ = false;
+    bool mergeCallsOnDevice(std::vector<WindowCall> & calls, const std::vector<pd_calls *> & parts);
     std::unique_ptr<ChromProfile> profile_;
     std::unique_ptr<VcfOutput> vcf_;
     WindowCursor windows_;
@@ -286,6 +289,23 @@ void CallRun::createBackend()
         if (pd_ctx_set_shard_local(ctxs_[r], &sh, group_) != 0)
             throw ProfileError(std::string("[PopDel] Could not initialise the genotyping backend: ") + pd_last_error(ctxs_[r]));
     }
+}
+
+// Merged output (no -n) and no observer of the raw window calls: the per-sample columns of the window calls stay on the
+// device, the backend merges them there (pd_calls_merge) and only the merged columns come back. A backend that does not
+// offer this (the oracle) says so and everything is merged on the host as before.
+void CallRun::chooseMergeSite()
+{
+    mergeOnDevice_ = false;
+    if (p_.windowWiseOutput || (observer_ && observer_->onWindowCalls) || getenv("POPDEL_HOST_MERGE"))
+        return;
+    bool all = true;
+    for (pd_ctx * c : ctxs_)
+        all = all && pd_ctx_keep_results_on_device(c, 1) == 0;
+    if (!all)
+        for (pd_ctx * c : ctxs_)
+            (void)pd_ctx_keep_results_on_device(c, 0);
+    mergeOnDevice_ = all;
 }
 
 // fn(r) for every context; from one thread per context when there are several (their calls are collective)
@@ -627,6 +647,119 @@ void CallRun::markRoiComplete(unsigned i)
     }
 }
 
+// unifyCalls() with its per-sample half on the device: the scalar grouping runs here on call-level fields, every context
+// merges the columns of its own samples (pd_calls_merge) and the merged columns are joined. Falls back to the host merge
+// for a segment the device declines (a LAD / DAD value beyond its median bins). Returns what unifyCalls() returns.
+bool CallRun::mergeCallsOnDevice(std::vector<WindowCall> & calls, const std::vector<pd_calls *> & parts)
+{
+    const uint32_t S = shardSample_.back();
+    std::vector<WindowCall> backup;
+    std::vector<MergeGroup> groups;
+    size_t firstKept = 0;
+    backup = calls;                                             // call-level fields only: cheap; needed if the device declines
+    if (!unifyCallsScalar(calls, p_.meanStddev, p_.minRelWinCover, p_.outputFailed, groups, firstKept))
+        return false;
+    std::vector<uint32_t> offsets(1, 0), members, heads;
+    for (const MergeGroup & g : groups)
+    {
+        heads.push_back(calls[g.head].sourceIndex);
+        for (size_t m : g.members)
+            members.push_back(calls[m].sourceIndex);
+        offsets.push_back(static_cast<uint32_t>(members.size()));
+    }
+    // A call can survive the grouping without having been merged (the head of a group whose position list ran empty,
+    // utils_popdel.h:621-640): it keeps its own window's columns, which are not here -- such a segment goes to the host.
+    bool declined = false;
+    {
+        std::vector<char> isHead(calls.size(), 0);
+        for (const MergeGroup & g : groups)
+            isHead[g.head] = 1;
+        for (size_t i = firstKept; i < calls.size(); ++i)
+            declined = declined || (calls[i].filter != kFilterInvalid && !isHead[i]);
+    }
+    std::vector<pd_merged *> out(ctxs_.size(), nullptr);
+    std::vector<int> codes(ctxs_.size(), 0);
+    // (not collective: every context works on its own columns; one after the other is as good as threads here)
+    for (size_t r = 0; r < ctxs_.size() && !declined; ++r)
+        codes[r] = pd_calls_merge(ctxs_[r], parts[r], static_cast<uint32_t>(groups.size()), offsets.data(), members.data(), heads.data(), &out[r]);
+    for (size_t r = 0; r < ctxs_.size(); ++r)
+    {
+        if (codes[r] == 2)
+            declined = true;
+        else if (codes[r] != 0)
+            throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
+    }
+    if (declined)
+    {
+        for (pd_merged * m : out)
+            pd_merged_free(m);
+        // the whole segment on the host: fetch the columns, then the ordinary merge
+        calls = backup;
+        for (size_t r = 0; r < parts.size(); ++r)
+            if (pd_calls_fetch_columns(ctxs_[r], parts[r]) != 0)
+                throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
+        parallelFor(calls.size(), [&](size_t c) {
+            WindowCall & w = calls[c];
+            w.pl.resize(S);
+            w.lad.resize(S);
+            w.dad.resize(S);
+            w.firstLast.resize(S);
+            for (size_t r = 0; r < parts.size(); ++r)
+            {
+                const pd_calls * q = parts[r];
+                const uint32_t s0 = shardSample_[r], n = q->n_samples;
+                const size_t base = static_cast<size_t>(c) * n;
+                for (uint32_t j = 0; j < n; ++j)
+                {
+                    for (int k = 0; k < 3; ++k)
+                    {
+                        w.pl[s0 + j][k] = q->pl[(base + j) * 3 + k];
+                        w.lad[s0 + j][k] = q->lad[(base + j) * 3 + k];
+                    }
+                    for (int k = 0; k < 5; ++k)
+                        w.dad[s0 + j][k] = q->dad[(base + j) * 5 + k];
+                    w.firstLast[s0 + j][0] = q->first_last[(base + j) * 2];
+                    w.firstLast[s0 + j][1] = q->first_last[(base + j) * 2 + 1];
+                }
+            }
+        });
+        return unifyCalls(calls, p_.meanStddev, p_.minRelWinCover, p_.outputFailed);
+    }
+    // join the merged columns of the contexts; allele frequency from the allele counts (reference utils_popdel.h:339-359)
+    parallelFor(groups.size(), [&](size_t g) {
+        WindowCall & head = calls[groups[g].head];
+        head.pl.resize(S);
+        head.lad.resize(S);
+        head.dad.resize(S);
+        head.firstLast.resize(S);
+        unsigned alleles = 0;
+        for (size_t r = 0; r < out.size(); ++r)
+        {
+            const pd_merged * m = out[r];
+            const uint32_t s0 = shardSample_[r], n = m->n_samples;
+            const size_t base = g * static_cast<size_t>(n);
+            for (uint32_t j = 0; j < n; ++j)
+            {
+                for (int k = 0; k < 3; ++k)
+                {
+                    head.pl[s0 + j][k] = m->pl[(base + j) * 3 + k];
+                    head.lad[s0 + j][k] = m->lad[(base + j) * 3 + k];
+                }
+                for (int k = 0; k < 5; ++k)
+                    head.dad[s0 + j][k] = m->dad[(base + j) * 5 + k];
+                head.firstLast[s0 + j][0] = m->first_last[(base + j) * 2];
+                head.firstLast[s0 + j][1] = m->first_last[(base + j) * 2 + 1];
+            }
+            alleles += m->alleles[g];
+        }
+        head.frequency = static_cast<double>(alleles) / (static_cast<size_t>(S) * 2);
+    });
+    for (pd_merged * m : out)
+        pd_merged_free(m);
+    keepValidCalls(calls, firstKept);
+    return true;
+}
+
 // Collect the calls of the segment that is in flight, merge them and write the records.
 void CallRun::flushPending()
 {
@@ -645,8 +778,17 @@ void CallRun::flushPending()
             throw ProfileError("[PopDel] Internal error: the contexts disagree on the calls of a segment.");
     std::vector<WindowCall> calls(pc->n_calls);
     const uint32_t S = shardSample_.back();
+    // columns left on the device (every context decides the same way: the rule is the number of stage-2 batches)
+    bool columnsOnDevice = mergeOnDevice_ && pc->n_calls != 0;
+    for (pd_calls * q : parts)
+        columnsOnDevice = columnsOnDevice && q->pl == nullptr;
+    if (!columnsOnDevice)
+        for (size_t r = 0; r < parts.size(); ++r)
+            if (parts[r]->n_calls != 0 && parts[r]->pl == nullptr && pd_calls_fetch_columns(ctxs_[r], parts[r]) != 0)
+                throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
     parallelFor(pc->n_calls, [&](size_t c) {
         WindowCall & w = calls[c];
+        w.sourceIndex = static_cast<uint32_t>(c);
         w.initialLength = pc->initial_length[c];
         w.iterations = pc->iterations[c];
         w.deletionLength = pc->deletion_length[c];
@@ -656,6 +798,8 @@ void CallRun::flushPending()
         w.position = pc->position[c];
         w.endPosition = pc->end_position[c];
         w.filter = pc->filter[c];
+        if (columnsOnDevice)
+            return;
         w.pl.resize(S);
         w.lad.resize(S);
         w.dad.resize(S);
@@ -680,13 +824,19 @@ void CallRun::flushPending()
             }
         }
     });
+    bool merged = false, mergedAny = false;
+    if (columnsOnDevice)
+    {
+        merged = true;
+        mergedAny = mergeCallsOnDevice(calls, parts);
+    }
     for (pd_calls * q : parts)
         pd_calls_free(q);
     if (observer_ && observer_->onWindowCalls)
         observer_->onWindowCalls(calls);
     if (!p_.windowWiseOutput)
     {
-        if (unifyCalls(calls, p_.meanStddev, p_.minRelWinCover, p_.outputFailed))
+        if (merged ? mergedAny : unifyCalls(calls, p_.meanStddev, p_.minRelWinCover, p_.outputFailed))
         {
             vcf_->appendContigName(pendingContig_);
             vcf_->writeCalls(calls, p_);
@@ -828,6 +978,7 @@ int CallRun::run()
 
     tStart = PhaseClock::now();
     createBackend();
+    chooseMergeSite();
     clock_.backend = PhaseClock::now() - tStart;
     profile_.reset(new ChromProfile(static_cast<unsigned>(p_.readGroups.size()), p_.maxLoad, p_.windowBuffer));
     if (observer_ && observer_->onActiveOps)

@@ -76,25 +76,19 @@ unsigned upperMedianAndClear(std::vector<unsigned> & v)
 // Working state of unifyCalls() that survives from one merge group to the next.
 struct MergeState
 {
-    std::vector<std::array<unsigned, 3>> genotypes;
     std::vector<unsigned> startPositions;
     std::vector<unsigned> sizeEstimates;
-    std::vector<std::array<std::vector<unsigned>, 3>> lads;
-    std::vector<std::array<std::vector<unsigned>, 5>> dads;
     long double lr = 0;
     unsigned callCount = 1;
     unsigned winCount = 1;
     unsigned significantWindows = 1;
 };
 
-// Average the PLs and take per-component medians of LAD/DAD over the windows of [start, end) that lie inside the
-// deletion. Returns false if no window qualifies. The per-sample part is independent from sample to sample and runs on
-// the host threads (the accumulators of MergeState are only used inside this function and left empty by it, so they
-// play no part in the state that leaks from group to group).
-bool regenotype(std::vector<WindowCall> & calls, size_t start, size_t end, MergeState & st)
+// The windows of [start, end) that lie inside the head's deletion: the members whose per-sample columns are merged
+// (reference utils_popdel.h:454-470).
+std::vector<size_t> groupMembers(const std::vector<WindowCall> & calls, size_t start, size_t end)
 {
-    WindowCall & head = calls[start];
-    const size_t S = st.genotypes.size();
+    const WindowCall & head = calls[start];
     std::vector<size_t> members;
     for (size_t g = start; g < end; ++g)
     {
@@ -102,9 +96,17 @@ bool regenotype(std::vector<WindowCall> & calls, size_t start, size_t end, Merge
         if (c.windowPosition > head.position && c.windowPosition - 30 < head.position + head.deletionLength)
             members.push_back(g);
     }
+    return members;
+}
+
+// Average the PLs and take per-component medians of LAD/DAD over the member windows. The per-sample part is independent
+// from sample to sample and runs on the host threads.
+void regenotype(std::vector<WindowCall> & calls, const MergeGroup & grp)
+{
+    WindowCall & head = calls[grp.head];
+    const std::vector<size_t> & members = grp.members;
+    const size_t S = head.pl.size();
     const unsigned count = static_cast<unsigned>(members.size());
-    if (count == 0)
-        return false;
     const size_t m = count / 2;                                    // upper median
     parallelFor(S, [&](size_t s) {
         std::array<unsigned, 3> g = {0, 0, 0};
@@ -151,7 +153,6 @@ bool regenotype(std::vector<WindowCall> & calls, size_t start, size_t end, Merge
         head.lad[s] = lad;
         head.dad[s] = dad;
     }, 256);
-    return true;
 }
 
 void frequencyFromGenotypes(WindowCall & c)
@@ -166,15 +167,18 @@ void frequencyFromGenotypes(WindowCall & c)
     c.frequency = static_cast<double>(alleles) / (c.pl.size() * 2);
 }
 
-void mergeRange(std::vector<WindowCall> & calls, size_t start, size_t last, MergeState & st, double r)
+void mergeRange(std::vector<WindowCall> & calls, size_t start, size_t last, MergeState & st, double r, std::vector<MergeGroup> & groups)
 {
     WindowCall & head = calls[start];
     head.position = upperMedianAndClear(st.startPositions);
     head.deletionLength = upperMedianAndClear(st.sizeEstimates);
     head.likelihoodRatio = static_cast<double>(st.lr / st.winCount);
-    if (regenotype(calls, start, last, st))
+    // the per-sample columns of the head and its allele frequency are filled in afterwards (regenotype on the host, or
+    // the backend's merge on the device): nothing below or in the grouping that follows reads them
+    std::vector<size_t> members = groupMembers(calls, start, last);
+    if (!members.empty())
     {
-        frequencyFromGenotypes(head);
+        groups.push_back(MergeGroup{start, std::move(members)});
         head.significantWindows = st.significantWindows;
         if (30.0 * st.significantWindows / head.deletionLength < r)
             head.filter |= kFilterRelWinCov;
@@ -191,8 +195,11 @@ void mergeRange(std::vector<WindowCall> & calls, size_t start, size_t last, Merg
 
 }  // namespace
 
-bool unifyCalls(std::vector<WindowCall> & calls, double stddev, double r, bool outputFailed)
+bool unifyCallsScalar(std::vector<WindowCall> & calls, double stddev, double r, bool outputFailed, std::vector<MergeGroup> & groups,
+                      size_t & firstKept)
 {
+    groups.clear();
+    firstKept = 0;
     if (calls.size() <= 1u)
         return false;
     std::sort(calls.begin(), calls.end(), callOrder);
@@ -211,9 +218,6 @@ bool unifyCalls(std::vector<WindowCall> & calls, double stddev, double r, bool o
     }
     const size_t firstGood = cur;
     MergeState st;
-    st.genotypes.assign(calls[cur].pl.size(), {0, 0, 0});
-    st.lads.resize(calls[cur].lad.size());
-    st.dads.resize(calls[cur].dad.size());
     st.startPositions.push_back(calls[cur].position);
     st.sizeEstimates.push_back(calls[cur].deletionLength);
     st.lr = calls[cur].likelihoodRatio;
@@ -235,14 +239,14 @@ bool unifyCalls(std::vector<WindowCall> & calls, double stddev, double r, bool o
             if (it == last)
             {
                 if (!st.startPositions.empty())
-                    mergeRange(calls, cur, it, st, r);
+                    mergeRange(calls, cur, it, st, r, groups);
                 break;
             }
         }
         else
         {
             if (st.winCount != 1 && !st.startPositions.empty())
-                mergeRange(calls, cur, it, st, r);
+                mergeRange(calls, cur, it, st, r, groups);
             else
                 calls[cur].filter = kFilterInvalid;
             cur = it;
@@ -261,11 +265,36 @@ bool unifyCalls(std::vector<WindowCall> & calls, double stddev, double r, bool o
             break;
         }
     }
+    firstKept = firstGood;
+    return true;
+}
+
+void regenotypeOnHost(std::vector<WindowCall> & calls, const std::vector<MergeGroup> & groups)
+{
+    for (const MergeGroup & g : groups)
+    {
+        regenotype(calls, g);
+        frequencyFromGenotypes(calls[g.head]);
+    }
+}
+
+void keepValidCalls(std::vector<WindowCall> & calls, size_t firstKept)
+{
     std::vector<WindowCall> kept;
-    for (size_t i = firstGood; i <= last; ++i)
+    for (size_t i = firstKept; i < calls.size(); ++i)
         if (calls[i].filter != kFilterInvalid)
             kept.push_back(std::move(calls[i]));
     calls.swap(kept);
+}
+
+bool unifyCalls(std::vector<WindowCall> & calls, double stddev, double r, bool outputFailed)
+{
+    std::vector<MergeGroup> groups;
+    size_t firstKept = 0;
+    if (!unifyCallsScalar(calls, stddev, r, outputFailed, groups, firstKept))
+        return false;
+    regenotypeOnHost(calls, groups);
+    keepValidCalls(calls, firstKept);
     return true;
 }
 

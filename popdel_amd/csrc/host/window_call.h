@@ -31,6 +31,7 @@ struct WindowCall
     std::vector<std::array<uint32_t, 3>> lad;        // likelihood-derived allelic depth
     std::vector<std::array<uint32_t, 5>> dad;        // distribution-derived allelic depth
     std::vector<std::array<uint32_t, 2>> firstLast;
+    uint32_t sourceIndex = 0;                        // position in the backend's call list (pd_calls) of the segment
 };
 
 enum CallFilter : uint8_t
@@ -47,6 +48,22 @@ inline bool passesAll(const WindowCall & c) { return (c.filter & (kFilterLR | kF
 
 // Merge the window calls of one segment into variant calls (in place). Returns false if nothing is to be written.
 bool unifyCalls(std::vector<WindowCall> & calls, double stddev, double minRelWinCover, bool outputFailed);
+
+// The same in its two halves (reference utils_popdel.h:567-654 / :446-501, :339-359). unifyCallsScalar() sorts the calls
+// and runs the grouping pass over call-level fields (positions, lengths, LR, filters -- accumulator quirks included); it
+// leaves, per merged variant, the head and the member windows whose per-sample columns are to be merged (positions in the
+// sorted vector). The per-sample half fills the heads' PL / LAD / DAD columns and allele frequency: regenotypeOnHost(),
+// or the genotyping backend on the device (pd_calls_merge) when the calls carry no per-sample columns. keepValidCalls()
+// then drops everything that was merged away.
+struct MergeGroup
+{
+    size_t head;
+    std::vector<size_t> members;
+};
+bool unifyCallsScalar(std::vector<WindowCall> & calls, double stddev, double minRelWinCover, bool outputFailed,
+                      std::vector<MergeGroup> & groups, size_t & firstKept);
+void regenotypeOnHost(std::vector<WindowCall> & calls, const std::vector<MergeGroup> & groups);
+void keepValidCalls(std::vector<WindowCall> & calls, size_t firstKept);
 
 class VcfOutput
 {

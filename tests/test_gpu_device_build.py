@@ -86,3 +86,18 @@ def test_unordered_instances_are_refused(built, monkeypatch):
     with pytest.raises(capi.BackendError, match="not ordered"):
         ctx.submit(seg)
     ctx.close()
+
+
+@pytest.mark.parametrize("scan_life", ["5", "8", "13"])
+def test_results_do_not_depend_on_the_chunk_life_of_the_stage1_image(built, scan_life, monkeypatch):
+    """The stage-1 image is cut with its own chunk life (Q3 is an order statistic of integers): whatever that life, every
+    field of the result is the same, floating point included."""
+    from popdel_amd import capi
+    from test_gpu_fuzz import random_case
+    seg, rgs, offs, opts = random_case(8)
+    hip = capi.load_hip()
+    monkeypatch.delenv("POPDEL_HIP_MAXLIFE_SCAN", raising=False)
+    want = run(hip, seg, rgs, offs, opts)
+    monkeypatch.setenv("POPDEL_HIP_MAXLIFE_SCAN", scan_life)
+    got = run(hip, seg, rgs, offs, opts)
+    identical(got, want)

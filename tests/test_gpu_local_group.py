@@ -94,3 +94,19 @@ def test_popdel_call_refuses_more_contexts_than_tiles(built, cohort_dir, tmp_pat
     out = subprocess.run([POPDEL_BIN, "call", os.path.join(d, "profiles.txt"), "-o", str(tmp_path / "x.vcf"), "-r", "chr20:1000000-2000000"],
                          capture_output=True, text=True, env=env)
     assert out.returncode != 0 and "whole tiles of 256 samples" in (out.stderr + out.stdout)
+
+
+def test_merging_on_the_device_equals_merging_on_the_host(built, cohort_dir, tmp_path, monkeypatch):
+    """Default (merged) output: the per-sample half of unifyCalls runs on the device (pd_calls_merge) and only merged
+    columns cross PCIe; POPDEL_HOST_MERGE=1 fetches every window call's columns and merges on the host threads as in
+    round 1. Same bytes, on one context and on two; and both equal the reference's VCF (golden)."""
+    from popdel_amd import synth
+    d = cohort_dir("s1000", 1000, synth.single_deletion)
+    golden = strip_date(open(os.path.join(GOLDEN, "s1000_default.vcf")).read())
+    for devices in ("0", "0,0"):
+        monkeypatch.setenv("POPDEL_DEVICES", devices)
+        monkeypatch.delenv("POPDEL_HOST_MERGE", raising=False)
+        on_device = run_call(POPDEL_BIN, d, str(tmp_path / "dev.vcf"))
+        monkeypatch.setenv("POPDEL_HOST_MERGE", "1")
+        on_host = run_call(POPDEL_BIN, d, str(tmp_path / "host.vcf"))
+        assert on_device == on_host == golden
