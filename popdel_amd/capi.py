@@ -55,6 +55,11 @@ class PdCalls(C.Structure):
                 ("lad", C.POINTER(C.c_uint32)), ("dad", C.POINTER(C.c_uint32)), ("first_last", C.POINTER(C.c_uint32))]
 
 
+class PdMerged(C.Structure):
+    _fields_ = [("n_groups", C.c_uint32), ("n_samples", C.c_uint32), ("pl", C.POINTER(C.c_uint32)), ("lad", C.POINTER(C.c_uint32)),
+                ("dad", C.POINTER(C.c_uint32)), ("first_last", C.POINTER(C.c_uint32)), ("alleles", C.POINTER(C.c_uint32))]
+
+
 class PdStage1View(C.Structure):
     _fields_ = [("n_windows", C.c_uint32), ("n_samples", C.c_uint32), ("q3", C.POINTER(C.c_int32)),
                 ("flags", C.POINTER(C.c_uint8))]
@@ -114,6 +119,15 @@ def load_library(path):
     lib.pd_log_table_view.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_uint32)]
     lib.pd_log_table_view.restype = C.c_int
+    lib.pd_ctx_keep_results_on_device.argtypes = [C.c_void_p, C.c_int]
+    lib.pd_ctx_keep_results_on_device.restype = C.c_int
+    lib.pd_calls_merge.argtypes = [C.c_void_p, C.POINTER(PdCalls), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                   C.POINTER(C.c_uint32), C.POINTER(C.POINTER(PdMerged))]
+    lib.pd_calls_merge.restype = C.c_int
+    lib.pd_calls_fetch_columns.argtypes = [C.c_void_p, C.POINTER(PdCalls)]
+    lib.pd_calls_fetch_columns.restype = C.c_int
+    lib.pd_merged_free.argtypes = [C.POINTER(PdMerged)]
+    lib.pd_merged_free.restype = None
     lib.pd_rccl_unique_id.argtypes = [C.c_char_p]
     lib.pd_rccl_unique_id.restype = C.c_int
     return lib
@@ -327,6 +341,48 @@ class Context:
             first_last=arr(c.first_last, (n, S, 2), np.uint32))
         self.lib.pd_calls_free(p)
         return out
+
+    # ---- merging on the device (pd_ctx_keep_results_on_device / pd_calls_merge) -------------------------------------------
+    def keep_results_on_device(self, on=True):
+        self._check(self.lib.pd_ctx_keep_results_on_device(self.handle, int(on)))
+
+    def collect_raw(self, ticket):
+        """The pd_calls pointer itself (release with ``free_raw``): what pd_calls_merge / pd_calls_fetch_columns take."""
+        p = C.POINTER(PdCalls)()
+        self._check(self.lib.pd_segment_collect(self.handle, ticket, C.byref(p)))
+        return p
+
+    def free_raw(self, p):
+        self.lib.pd_calls_free(p)
+
+    def fetch_columns(self, p):
+        self._check(self.lib.pd_calls_fetch_columns(self.handle, p))
+
+    def merge(self, p, groups, heads):
+        """groups: list of lists of call indices; heads: one call index per group. Returns a dict of numpy arrays, or None
+        if the device declined (return code 2)."""
+        offsets = np.zeros(len(groups) + 1, dtype=np.uint32)
+        np.cumsum([len(g) for g in groups], out=offsets[1:])
+        members = np.ascontiguousarray(np.concatenate([np.asarray(g, dtype=np.uint32) for g in groups]) if groups else np.zeros(0, np.uint32))
+        heads = np.ascontiguousarray(heads, dtype=np.uint32)
+        out = C.POINTER(PdMerged)()
+        u32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+        rc = self.lib.pd_calls_merge(self.handle, p, len(groups), u32(offsets), u32(members), u32(heads), C.byref(out))
+        if rc == 2:
+            return None
+        self._check(rc)
+        m = out.contents
+        G, S = m.n_groups, m.n_samples
+
+        def arr(ptr, k):
+            if G * S == 0:
+                return np.zeros((G, S, k), np.uint32)
+            return np.ctypeslib.as_array(ptr, shape=(G * S * k,)).reshape(G, S, k).copy()
+
+        res = dict(pl=arr(m.pl, 3), lad=arr(m.lad, 3), dad=arr(m.dad, 5), first_last=arr(m.first_last, 2),
+                   alleles=np.ctypeslib.as_array(m.alleles, shape=(G,)).copy() if G else np.zeros(0, np.uint32))
+        self.lib.pd_merged_free(out)
+        return res
 
     def stage1(self):
         v = PdStage1View()
