@@ -561,12 +561,39 @@ def main():
         acc = run_lanes([l2], n_pass)
         torch.cuda.synchronize()
         dt = time.perf_counter() - q0
+        # the same passes with the window calls' columns left in HBM and merged there (pd_calls_merge: what `popdel call`
+        # does for merged output): the groups are runs of calls at most 60 windows apart, as the host's grouping would form
+        # them around the planted deletions; only the merged columns cross PCIe
+        merged = None
+        try:
+            c2.keep_results_on_device(True)
+            torch.cuda.synchronize()
+            q1 = time.perf_counter()
+            n_groups = 0
+            ticket = c2.run(l2.handle)
+            for i in range(n_pass):
+                nxt = c2.run(l2.handle) if i + 1 < n_pass else None
+                p = c2.collect_raw(ticket)
+                k = p.contents.n_calls
+                wp = np.ctypeslib.as_array(p.contents.window_position, shape=(k,)) if k else np.zeros(0, np.uint32)
+                cuts = np.flatnonzero(np.diff(wp.astype(np.int64)) > 60 * 30) + 1
+                groups = [g.tolist() for g in np.split(np.arange(k), cuts)] if k else []
+                m = c2.merge(p, groups, [g[0] for g in groups])
+                n_groups = len(groups)
+                c2.free_raw(p)
+                ticket = nxt
+            torch.cuda.synchronize()
+            dm = time.perf_counter() - q1
+            merged = dict(ms_per_pass=dm / n_pass * 1e3, groups_per_pass=n_groups, declined=m is None,
+                          result_bytes_per_pass=int(n_groups * S * 52), full_result_bytes_per_pass=int(acc[2] / n_pass * S * 52))
+        except Exception as e:
+            merged = {"error": "%s: %s" % (type(e).__name__, e)}
         c2.unstage(l2.handle)
         c2.close()
         return dict(workload="%d samples x %d windows, %d planted deletions in the segment" % (S, W2, args.dense_deletions),
                     value=n_pass * W2 * S / dt, unit="window*sample/s", ms_per_pass=dt / n_pass * 1e3,
                     stage1_ms_per_pass=acc[0] / n_pass, stage2_ms_per_pass=acc[1] / n_pass,
-                    candidate_cells_per_pass=acc[3] / n_pass, calls_per_pass=acc[2] / n_pass,
+                    candidate_cells_per_pass=acc[3] / n_pass, calls_per_pass=acc[2] / n_pass, merged_on_device=merged,
                     planted=[dict(del_len=p["del_len"], af=round(p["af"], 4)) for p in pl2])
 
     def cpu_leg():
