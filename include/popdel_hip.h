@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 8
+#define PD_ABI_VERSION 9
 
 /* One read group after start-up conditioning.
  * Replaces: `Histogram` (reference insert_histogram_popdel.h:19-43) after processHistogram()
@@ -170,6 +170,8 @@ typedef struct pd_timing
     uint32_t max_life;           /* chunk length K in windows                                 */
     uint32_t n_all_gathers;      /* exchanges of the ticket (cohort sharded by samples; else 0) */
     uint64_t all_gather_bytes;   /* bytes gathered per context by them                        */
+    uint64_t n_repeated_batches; /* stage-2 batches of this context (cumulative) that were launched before the host had
+                                    seen their support-pool sizes and had to be run again the exact way */
 } pd_timing;
 int pd_last_timing(pd_ctx *ctx, pd_timing *out);
 

@@ -28,6 +28,9 @@ void launchStage1Fallback(const SegmentView & seg, const CohortView & co, int32_
                           uint8_t * tileTodo, unsigned * todoList, const unsigned * bigList, hipStream_t stream);
 void launchPackFlagged(const int32_t * q3, const uint8_t * flags, const int * flaggedWindows, unsigned W, unsigned nLocal,
                        const ClusterInput & in, unsigned rank, hipStream_t st);
+void launchCompactFlagged(const int * winFlag, unsigned W, unsigned cap, int * flagged, unsigned * hdr, hipStream_t st);
+void launchListCells(const int * flagged, const int * candLen, const int * candCount, unsigned cap, unsigned listCap,
+                     unsigned * hdr, hipStream_t st);
 void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,
                    hipStream_t st);
 void launchCopyBytes(const void * src, void * dst, size_t n, hipStream_t st);
@@ -36,8 +39,7 @@ void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
                    bool anyGenericTile, unsigned * pinnedWord, hipStream_t st);
 void buildLogTables(const double * hist, double4 * tab, double2 * tab2, size_t n, RgConst * rg, unsigned nRg, hipStream_t st);
-void launchGatherOut(const Stage2Buffers & b, const unsigned * emitCells, unsigned nEmit, unsigned nSamples, uint32_t * pl,
-                     uint32_t * lad, uint32_t * dad, uint32_t * fl, hipStream_t st);
+void launchGatherOut(const Stage2Buffers & b, unsigned * emitCells, unsigned nSamples, uint32_t * out, hipStream_t st);
 
 }  // namespace pd
 
@@ -298,7 +300,13 @@ struct pd_ctx
     // counters): pageable memory costs every one of these round trips an extra bounce copy
     PinnedBuf<int> hWinFlag, hFlagged, hCandLen, hCandCount;
     PinnedBuf<pd::CellState> hCells;
-    PinnedBuf<unsigned> hCounters, hEmit, hIterFlag;
+    PinnedBuf<unsigned> hCounters, hIterFlag, hCandHdr;
+    DevBuf<unsigned> dCandHdr;            // flagged-window count, cell count, cell list (listCellsKernel)
+    bool deviceLists = true;              // POPDEL_HIP_HOST_LISTS=1: the host forms the flagged-window and cell lists
+    // stage 2 launched without waiting for the pool sizes (see pd_segment_collect); POPDEL_HIP_EXACT_POOLS=1 turns it off
+    bool optimisticPools = true;
+    bool genericSeen = false;             // some segment needed the generic stage-2 kernels
+    uint64_t nRepeatedBatches = 0;
     // device-side layout build (build.hip): the uploaded instances and the small tables around them
     PinnedBuf<uint16_t> hIn16[4];           // dev, on, off, start distance (narrow upload)
     PinnedBuf<uint32_t> hIn32[4];           // dev, on, off, start (wide upload)
@@ -1125,7 +1133,11 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
         c->dSampleRg.upload(c->sampleRg, c->stream);
         c->dTab.alloc(pool.size());
         c->dTab2.alloc(pool.size());
-        c->dIterFlags.alloc(pd::kMaxIterationsCap + 1);
+        c->dIterFlags.alloc(pd::kMaxIterationsCap + 2);          // the last word is the guard of an optimistic launch
+        if (const char * e = getenv("POPDEL_HIP_EXACT_POOLS"))
+            c->optimisticPools = atoi(e) == 0;
+        if (const char * e = getenv("POPDEL_HIP_HOST_LISTS"))
+            c->deviceLists = atoi(e) == 0;
         pd::buildLogTables(c->dHist.p, c->dTab.p, c->dTab2.p, pool.size(), c->dRg.p, n_readgroups, c->stream);
         PD_HIP(hipGetLastError());
         PD_HIP(hipStreamSynchronize(c->stream));
@@ -1580,74 +1592,127 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         c->nAllGathers = 0;
         c->allGatherBytes = 0;
         const uint32_t world = c->world, sper = c->samplesPerRank, SG = c->nSamplesGlobal;
-        // windows in which some sample of the cohort has a Q3 above the smallest threshold
-        PinnedBuf<int> & winFlag = c->hWinFlag;
-        winFlag.resize(static_cast<size_t>(W) * world);
-        if (world == 1)
-        {
-            PD_HIP(hipMemcpyAsync(winFlag.data(), o.winFlag.p, W * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        }
-        else
-        {
-            uint8_t * area = reserveArena(*c, static_cast<size_t>(W) * world * sizeof(int));
-            pd::launchCopyBytes(o.winFlag.p, area + static_cast<size_t>(c->rank) * W * sizeof(int), W * sizeof(int), c->stream);
-            xch.allGather(area, W * sizeof(int));
-            PD_HIP(hipMemcpyAsync(winFlag.data(), area, winFlag.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        }
-        PD_HIP(hipStreamSynchronize(c->stream));
-        std::vector<int> flagged;
-        for (uint32_t w = 0; w < W; ++w)
-        {
-            int any = 0;
-            for (uint32_t r = 0; r < world; ++r)
-                any |= winFlag[static_cast<size_t>(r) * W + w];
-            if (any)
-                flagged.push_back((int)w);
-        }
-
-        PD_HIP(hipEventRecord(s2Begin, c->stream));
+        unsigned rowLen = 1;
+        while (rowLen < SG)
+            rowLen <<= 1;
         std::vector<pd::CellState> cells;
-        if (!flagged.empty())
+        auto addCell = [&](int window, int initLen) {
+            pd::CellState cs;
+            std::memset(&cs, 0, sizeof(cs));
+            cs.window = window;
+            cs.initLen = initLen;
+            cs.phase = pd::kCellIterating;
+            cells.push_back(cs);
+        };
+        // Flagged windows (some sample of the cohort has a Q3 above the smallest threshold) -> candidate lengths per
+        // window -> (window, length) cells. An unsharded context forms both lists on the device and the host reads the
+        // cells in ONE round trip; the kernels are launched for a capacity of flagged windows and find the number on the
+        // device. (A sharded cohort exchanges per flagged window: the host has to know their number in between.)
+        bool listed = false;
+        if (world == 1 && W != 0 && c->deviceLists)
         {
-            unsigned rowLen = 1;
-            while (rowLen < SG)
-                rowLen <<= 1;
-            c->hFlagged.resize(flagged.size());
-            std::memcpy(c->hFlagged.data(), flagged.data(), flagged.size() * sizeof(int));
-            c->dFlagged.uploadPinned(c->hFlagged, c->stream);
-            c->dClusterScratch.ensure(static_cast<size_t>(flagged.size()) * rowLen);
-            c->dCandLen.ensure(flagged.size() * pd::kMaxCandidatesPerWindow);
-            c->dCandCount.ensure(flagged.size());
+            PD_HIP(hipEventRecord(s2Begin, c->stream));
+            const unsigned capF = std::min<unsigned>(W, std::max<unsigned>(256u, std::min<unsigned>(4096u, (1u << 28) / rowLen)));
+            constexpr unsigned kListCap = 1022;                                 // cells the first copy brings along
+            const size_t listRoom = static_cast<size_t>(capF) * pd::kMaxCandidatesPerWindow;
+            c->dFlagged.ensure(capF);
+            c->dCandHdr.ensure(4 + 2 * listRoom);
+            c->dClusterScratch.ensure(static_cast<size_t>(capF) * rowLen);
+            c->dCandLen.ensure(listRoom);
+            c->dCandCount.ensure(capF);
             pd::ClusterInput in;
-            in.chunkBytes = alignUp(flagged.size() * static_cast<size_t>(sper) * 5, 256);
-            in.base = reserveArena(*c, in.chunkBytes * world);
+            in.chunkBytes = alignUp(capF * static_cast<size_t>(sper) * 5, 256);
+            in.base = reserveArena(*c, in.chunkBytes);
             in.sper = sper;
-            in.world = world;
-            in.nFlagged = (unsigned)flagged.size();
+            in.world = 1;
+            in.nFlagged = capF;
+            in.nFlaggedDev = c->dCandHdr.p;
             in.minInit = c->dMinInitGlobal.p;
-            pd::launchPackFlagged(o.q3.p, o.flags.p, c->dFlagged.p, W, S, in, c->rank, c->stream);
-            PD_HIP(hipGetLastError());
-            xch.allGather(c->arena, in.chunkBytes);
+            pd::launchCompactFlagged(o.winFlag.p, W, capF, c->dFlagged.p, c->dCandHdr.p, c->stream);
+            pd::launchPackFlagged(o.q3.p, o.flags.p, c->dFlagged.p, W, S, in, 0, c->stream);
             pd::launchCluster(in, c->uniformThreshold, c->dClusterScratch.p, rowLen, c->dCandLen.p, c->dCandCount.p, c->stream);
+            pd::launchListCells(c->dFlagged.p, c->dCandLen.p, c->dCandCount.p, capF, (unsigned)listRoom, c->dCandHdr.p, c->stream);
             PD_HIP(hipGetLastError());
-            PinnedBuf<int> &candLen = c->hCandLen, &candCount = c->hCandCount;
-            candLen.resize(flagged.size() * pd::kMaxCandidatesPerWindow);
-            candCount.resize(flagged.size());
-            PD_HIP(hipMemcpyAsync(candLen.data(), c->dCandLen.p, candLen.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            PD_HIP(hipMemcpyAsync(candCount.data(), c->dCandCount.p, candCount.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            PinnedBuf<unsigned> & hdr = c->hCandHdr;
+            hdr.resize(4 + 2 * kListCap);
+            PD_HIP(hipMemcpyAsync(hdr.data(), c->dCandHdr.p, hdr.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
             PD_HIP(hipStreamSynchronize(c->stream));
-            for (size_t f = 0; f < flagged.size(); ++f)
+            const unsigned nFlagged = hdr[0], nListed = hdr[1];
+            if (nFlagged <= capF)
             {
-                if (candCount[f] > pd::kMaxCandidatesPerWindow)
+                if (hdr[2] != 0)
                     throw HipError{"more than 32 candidate deletion lengths in one window"};
-                for (int k = 0; k < candCount[f]; ++k)
+                if (nListed > kListCap)                         // a candidate-rich segment: fetch the rest of the list
                 {
-                    pd::CellState cs;
-                    std::memset(&cs, 0, sizeof(cs));
-                    cs.window = flagged[f];
-                    cs.initLen = candLen[f * pd::kMaxCandidatesPerWindow + k];
-                    cs.phase = pd::kCellIterating;
-                    cells.push_back(cs);
+                    hdr.resize(4 + 2 * static_cast<size_t>(nListed));
+                    PD_HIP(hipMemcpyAsync(hdr.data(), c->dCandHdr.p, hdr.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+                    PD_HIP(hipStreamSynchronize(c->stream));
+                }
+                for (unsigned i = 0; i < nListed; ++i)
+                    addCell((int)hdr[4 + 2 * i], (int)hdr[5 + 2 * i]);
+                listed = true;
+            }
+            // (more flagged windows than the capacity: the host-side lists below take over)
+        }
+        if (!listed)
+        {
+            PinnedBuf<int> & winFlag = c->hWinFlag;
+            winFlag.resize(static_cast<size_t>(W) * world);
+            if (world == 1)
+            {
+                PD_HIP(hipMemcpyAsync(winFlag.data(), o.winFlag.p, W * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            }
+            else
+            {
+                uint8_t * area = reserveArena(*c, static_cast<size_t>(W) * world * sizeof(int));
+                pd::launchCopyBytes(o.winFlag.p, area + static_cast<size_t>(c->rank) * W * sizeof(int), W * sizeof(int), c->stream);
+                xch.allGather(area, W * sizeof(int));
+                PD_HIP(hipMemcpyAsync(winFlag.data(), area, winFlag.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            }
+            PD_HIP(hipStreamSynchronize(c->stream));
+            std::vector<int> flagged;
+            for (uint32_t w = 0; w < W; ++w)
+            {
+                int any = 0;
+                for (uint32_t r = 0; r < world; ++r)
+                    any |= winFlag[static_cast<size_t>(r) * W + w];
+                if (any)
+                    flagged.push_back((int)w);
+            }
+            PD_HIP(hipEventRecord(s2Begin, c->stream));
+            if (!flagged.empty())
+            {
+                c->hFlagged.resize(flagged.size());
+                std::memcpy(c->hFlagged.data(), flagged.data(), flagged.size() * sizeof(int));
+                c->dFlagged.uploadPinned(c->hFlagged, c->stream);
+                c->dClusterScratch.ensure(static_cast<size_t>(flagged.size()) * rowLen);
+                c->dCandLen.ensure(flagged.size() * pd::kMaxCandidatesPerWindow);
+                c->dCandCount.ensure(flagged.size());
+                pd::ClusterInput in;
+                in.chunkBytes = alignUp(flagged.size() * static_cast<size_t>(sper) * 5, 256);
+                in.base = reserveArena(*c, in.chunkBytes * world);
+                in.sper = sper;
+                in.world = world;
+                in.nFlagged = (unsigned)flagged.size();
+                in.nFlaggedDev = nullptr;
+                in.minInit = c->dMinInitGlobal.p;
+                pd::launchPackFlagged(o.q3.p, o.flags.p, c->dFlagged.p, W, S, in, c->rank, c->stream);
+                PD_HIP(hipGetLastError());
+                xch.allGather(c->arena, in.chunkBytes);
+                pd::launchCluster(in, c->uniformThreshold, c->dClusterScratch.p, rowLen, c->dCandLen.p, c->dCandCount.p, c->stream);
+                PD_HIP(hipGetLastError());
+                PinnedBuf<int> &candLen = c->hCandLen, &candCount = c->hCandCount;
+                candLen.resize(flagged.size() * pd::kMaxCandidatesPerWindow);
+                candCount.resize(flagged.size());
+                PD_HIP(hipMemcpyAsync(candLen.data(), c->dCandLen.p, candLen.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                PD_HIP(hipMemcpyAsync(candCount.data(), c->dCandCount.p, candCount.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                PD_HIP(hipStreamSynchronize(c->stream));
+                for (size_t f = 0; f < flagged.size(); ++f)
+                {
+                    if (candCount[f] > pd::kMaxCandidatesPerWindow)
+                        throw HipError{"more than 32 candidate deletion lengths in one window"};
+                    for (int k = 0; k < candCount[f]; ++k)
+                        addCell(flagged[f], candLen[f * pd::kMaxCandidatesPerWindow + k]);
                 }
             }
         }
@@ -1691,12 +1756,10 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             const size_t xchBytes = alignUp(static_cast<size_t>(world) * b.xchChunk * sizeof(double), 256);
             const size_t histBytes = static_cast<size_t>(world) * nb * 2 * 256 * sizeof(unsigned);
             uint8_t * area = reserveArena(*c, countersBytes + xchBytes + histBytes);
-            PD_HIP(hipMemsetAsync(area, 0, countersBytes + xchBytes, c->stream));
             b.counters = reinterpret_cast<unsigned *>(area);
             b.xch = reinterpret_cast<double *>(area + countersBytes);
             b.selHist = reinterpret_cast<unsigned *>(area + countersBytes + xchBytes);
             c->dCells.ensure(nb);
-            PD_HIP(hipMemcpyAsync(c->dCells.p, c->hCells.data() + lo, nb * sizeof(pd::CellState), hipMemcpyHostToDevice, c->stream));
             c->dDl.ensure(static_cast<size_t>(nb) * S * 3);
             c->dShifts.ensure(static_cast<size_t>(nb) * c->nRg);
             b.ownTiles = (S + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock;
@@ -1729,11 +1792,12 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
                 b.rgOutD = c->dRgOutD.p;
                 b.rgOutU = c->dRgOutU.p;
             }
+            c->dEmit.ensure(static_cast<size_t>(nb) + 1);
+            c->dOutPl.ensure(static_cast<size_t>(nb) * S * 13);
             c->dPl.ensure(static_cast<size_t>(nb) * S * 3);
             c->dLad.ensure(static_cast<size_t>(nb) * S * 3);
             c->dDad.ensure(static_cast<size_t>(nb) * S * 5);
             c->dFl.ensure(static_cast<size_t>(nb) * S * 2);
-            PD_HIP(hipMemsetAsync(c->dShifts.p, 0, static_cast<size_t>(nb) * c->nRg * sizeof(int), c->stream));
             b.cells = c->dCells.p;
             b.dl = c->dDl.p;
             b.shifts = c->dShifts.p;
@@ -1748,51 +1812,89 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             b.minSampleFraction = c->cfg.min_sample_fraction;
             b.somatic = c->cfg.somatic;
             b.windowWise = c->cfg.window_wise_output;
-            // Phase A gives, per cell, the number of usable active pairs = capacity of its support pool.
-            pd::runStage2Init(view, c->cohort, b, o.flags.p, xch, c->stream);
-            PD_HIP(hipGetLastError());
-            PinnedBuf<unsigned> & counters = c->hCounters;                    // of this context's own samples
-            counters.resize(static_cast<size_t>(nb) * 4);
-            PD_HIP(hipMemcpyAsync(counters.data(), b.counters + static_cast<size_t>(c->rank) * nb * 4,
-                                  counters.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-            PD_HIP(hipStreamSynchronize(c->stream));
-            uint64_t pool = 0, genericTiles = 0;
-            for (unsigned i = 0; i < nb; ++i)
+            // Phase A gives, per cell, the number of usable active pairs = capacity of its support pool, and tells whether
+            // any tile needs the generic kernels. The first attempt does not wait for either (one host round trip less):
+            // pools sized from the segment's average with headroom, generic kernels as earlier segments needed them, both
+            // checked on the device (Stage2Buffers::guard); the second attempt, if the check failed, reads the counts.
+            // A cohort sharded over several contexts always reads them: every context must take the same path.
+            for (int attempt = 0; attempt < 2; ++attempt)
             {
-                pool += counters[static_cast<size_t>(i) * 4 + 1];
-                genericTiles += counters[static_cast<size_t>(i) * 4 + 3];
+                const bool optimistic = attempt == 0 && world == 1 && c->optimisticPools;
+                unsigned * guard = c->dIterFlags.p + pd::kMaxIterationsCap + 1;
+                PD_HIP(hipMemsetAsync(area, 0, countersBytes + xchBytes, c->stream));
+                PD_HIP(hipMemsetAsync(c->dShifts.p, 0, static_cast<size_t>(nb) * c->nRg * sizeof(int), c->stream));
+                PD_HIP(hipMemcpyAsync(c->dCells.p, c->hCells.data() + lo, nb * sizeof(pd::CellState), hipMemcpyHostToDevice, c->stream));
+                bool generic = c->genericSeen;
+                b.guard = nullptr;
+                if (optimistic)
+                {
+                    const uint64_t perCell = s.nActivePairs * 3 / (2 * static_cast<uint64_t>(W)) + 1024;
+                    c->dSuppFirst.ensure(static_cast<size_t>(nb) * perCell + 1);
+                    c->dSuppLast.ensure(static_cast<size_t>(nb) * perCell + 1);
+                    b.suppCap = std::min(c->dSuppFirst.n, c->dSuppLast.n) - 1;
+                    b.genericLaunched = generic ? 1u : 0u;
+                    b.guard = guard;
+                    b.suppFirst = c->dSuppFirst.p;
+                    b.suppLast = c->dSuppLast.p;
+                    PD_HIP(hipMemsetAsync(guard, 0, sizeof(unsigned), c->stream));
+                    pd::runStage2Init(view, c->cohort, b, o.flags.p, xch, c->stream);
+                    PD_HIP(hipGetLastError());
+                }
+                else
+                {
+                    pd::runStage2Init(view, c->cohort, b, o.flags.p, xch, c->stream);
+                    PD_HIP(hipGetLastError());
+                    PinnedBuf<unsigned> & counters = c->hCounters;                    // of this context's own samples
+                    counters.resize(static_cast<size_t>(nb) * 4);
+                    PD_HIP(hipMemcpyAsync(counters.data(), b.counters + static_cast<size_t>(c->rank) * nb * 4,
+                                          counters.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+                    PD_HIP(hipStreamSynchronize(c->stream));
+                    uint64_t pool = 0, genericTiles = 0;
+                    for (unsigned i = 0; i < nb; ++i)
+                    {
+                        pool += counters[static_cast<size_t>(i) * 4 + 1];
+                        genericTiles += counters[static_cast<size_t>(i) * 4 + 3];
+                    }
+                    if (getenv("POPDEL_HIP_DEBUG"))
+                        fprintf(stderr, "[popdel_hip] stage 2 batch %u/%u%s: %u cells, %llu of %llu (cell, 64-sample wave tile) units need the generic kernels\n",
+                                batch + 1, nBatches, attempt ? " (repeated)" : "", nb, (unsigned long long)genericTiles,
+                                (unsigned long long)nb * b.ownTiles * 4);
+                    c->dSuppFirst.ensure(pool + 1);
+                    c->dSuppLast.ensure(pool + 1);
+                    b.suppFirst = c->dSuppFirst.p;
+                    b.suppLast = c->dSuppLast.p;
+                    generic = genericTiles != 0;
+                    if (generic && world == 1)
+                        c->genericSeen = true;      // from now on the generic kernels ride along (they exit early where not needed)
+                }
+                pd::runStage2Main(view, c->cohort, b, o.flags.p, xch, generic, c->hIterFlag.data(), c->stream);
+                PD_HIP(hipGetLastError());
+                // the columns of the emitted cells are packed before the host has seen which cells those are
+                // (the list is formed on the device; room for all cells of the batch)
+                pd::launchGatherOut(b, c->dEmit.p, S, c->dOutPl.p, c->stream);
+                PD_HIP(hipGetLastError());
+                PD_HIP(hipMemcpyAsync(c->hCells.data() + lo, c->dCells.p, nb * sizeof(pd::CellState), hipMemcpyDeviceToHost, c->stream));
+                PD_HIP(hipMemcpyAsync(c->hIterFlag.data() + 2, c->dEmit.p, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+                c->hIterFlag[1] = 0;
+                if (optimistic)
+                    PD_HIP(hipMemcpyAsync(c->hIterFlag.data() + 1, guard, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+                PD_HIP(hipStreamSynchronize(c->stream));
+                if (!optimistic || c->hIterFlag[1] == 0)
+                    break;
+                ++c->nRepeatedBatches;
             }
-            if (getenv("POPDEL_HIP_DEBUG"))
-                fprintf(stderr, "[popdel_hip] stage 2 batch %u/%u: %u cells, %llu of %llu (cell, 64-sample wave tile) units need the generic kernels\n",
-                        batch + 1, nBatches, nb, (unsigned long long)genericTiles, (unsigned long long)nb * b.ownTiles * 4);
-            c->dSuppFirst.ensure(pool + 1);
-            c->dSuppLast.ensure(pool + 1);
-            b.suppFirst = c->dSuppFirst.p;
-            b.suppLast = c->dSuppLast.p;
-            pd::runStage2Main(view, c->cohort, b, o.flags.p, xch, genericTiles != 0, c->hIterFlag.data(), c->stream);
-            PD_HIP(hipGetLastError());
-            PD_HIP(hipMemcpyAsync(c->hCells.data() + lo, c->dCells.p, nb * sizeof(pd::CellState), hipMemcpyDeviceToHost, c->stream));
-            PD_HIP(hipStreamSynchronize(c->stream));
             std::memcpy(cells.data() + lo, c->hCells.data() + lo, nb * sizeof(pd::CellState));
-            std::vector<unsigned> emitLocal;
+            uint32_t nbEmit = 0;
             for (unsigned i = 0; i < nb; ++i)
                 if (cells[lo + i].phase == pd::kCellEmit)
                 {
                     emit.push_back(lo + i);
-                    emitLocal.push_back(i);
+                    ++nbEmit;
                 }
-            const uint32_t nbEmit = (uint32_t)emitLocal.size();
             const size_t per = static_cast<size_t>(nbEmit) * S;
-            if (nbEmit != 0)
-            {
-                c->hEmit.resize(emitLocal.size());
-                std::memcpy(c->hEmit.data(), emitLocal.data(), emitLocal.size() * sizeof(unsigned));
-                c->dEmit.uploadPinned(c->hEmit, c->stream);
-                c->dOutPl.ensure(per * 13);
-                uint32_t *dPl = c->dOutPl.p, *dLad = dPl + per * 3, *dDad = dLad + per * 3, *dFl = dDad + per * 5;
-                pd::launchGatherOut(b, c->dEmit.p, nbEmit, S, dPl, dLad, dDad, dFl, c->stream);
-                PD_HIP(hipGetLastError());
-            }
+            if (nbEmit != c->hIterFlag[2])
+                throw HipError{"the device packed the columns of " + std::to_string(c->hIterFlag[2]) + " calls, the host counts " +
+                               std::to_string(nbEmit)};
             nLastBatch = nbEmit;
             if (nBatches > 1 && nbEmit != 0)
             {
@@ -1858,6 +1960,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         c->timing.max_life = s.maxLife;
         c->timing.n_all_gathers = c->nAllGathers;
         c->timing.all_gather_bytes = c->allGatherBytes;
+        c->timing.n_repeated_batches = c->nRepeatedBatches;
 
         CallsBox * box = new CallsBox();
         std::memset(&box->pub, 0, sizeof(pd_calls));

@@ -106,7 +106,8 @@ struct ClusterInput
     size_t           chunkBytes;
     unsigned         sper;         // samples per context, padded to whole tiles (padding carries "no value")
     unsigned         world;
-    unsigned         nFlagged;
+    unsigned         nFlagged;     // flagged windows; with nFlaggedDev set: the capacity the layout is made for
+    const unsigned * nFlaggedDev;  // null, or where the device finds their number (the host has not seen it yet)
     const unsigned * minInit;      // [read groups of the cohort] minInitDelLen, looked up BY SORTED RANK (quirk Q1)
 };
 
@@ -227,6 +228,13 @@ struct Stage2Buffers
     uint32_t *  fl;
     unsigned *  suppFirst;   // support pools
     unsigned *  suppLast;
+    // Launch without the host looking at the pool sizes first (one round trip less per segment): if `guard` is set, the
+    // pools hold suppCap entries sized from the segment's average, and the generic kernels are launched or not
+    // (genericLaunched) by what earlier segments needed; suppScanKernel checks both against the real counts, and if either
+    // does not hold it kills every cell and raises *guard -- the host then repeats the batch the exact way.
+    uint64_t    suppCap;
+    unsigned    genericLaunched;
+    unsigned *  guard;
     // parameters
     unsigned *  iterFlags;   // [maxIterations + 1]: 1 if any cell was still iterating after EM iteration i
     unsigned    minLen;

@@ -347,20 +347,24 @@ __global__ __launch_bounds__(256) void packFlaggedKernel(const int32_t * __restr
                                                          const int * __restrict__ flaggedWindows, unsigned W, unsigned nLocal,
                                                          ClusterInput in, unsigned rank)
 {
-    const unsigned l = blockIdx.x * blockDim.x + threadIdx.x, fw = blockIdx.y;
+    const unsigned l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= in.sper)
         return;
-    int v = 0;
-    uint8_t f = 0;
-    if (l < nLocal)
-    {
-        const size_t cell = (size_t)l * W + (unsigned)flaggedWindows[fw];
-        v = q3[cell];
-        f = flags[cell];
-    }
+    const unsigned n = in.nFlaggedDev ? min(*in.nFlaggedDev, in.nFlagged) : in.nFlagged;
     uint8_t * chunk = const_cast<uint8_t *>(in.base) + (size_t)rank * in.chunkBytes;
-    reinterpret_cast<int32_t *>(chunk)[(size_t)fw * in.sper + l] = v;
-    chunk[(size_t)in.nFlagged * in.sper * 4 + (size_t)fw * in.sper + l] = f;
+    for (unsigned fw = blockIdx.y; fw < n; fw += gridDim.y)
+    {
+        int v = 0;
+        uint8_t f = 0;
+        if (l < nLocal)
+        {
+            const size_t cell = (size_t)l * W + (unsigned)flaggedWindows[fw];
+            v = q3[cell];
+            f = flags[cell];
+        }
+        reinterpret_cast<int32_t *>(chunk)[(size_t)fw * in.sper + l] = v;
+        chunk[(size_t)in.nFlagged * in.sper * 4 + (size_t)fw * in.sper + l] = f;
+    }
 }
 
 // Calls f(q3) for every sample of the cohort with a valid Q3 in flagged window fw (block-strided).
@@ -395,14 +399,23 @@ __device__ __forceinline__ void forEachValidQ3(const ClusterInput & in, unsigned
 
 // Fast path: the Q3 values of a window span fewer than kClusterBins integers -> counting sort in LDS, clusters are read
 // off the occupied bins in ascending order. Otherwise: bitonic sort of the values in a global scratch row.
-__global__ __launch_bounds__(1024) void clusterKernel(ClusterInput in, int uniformThreshold, int * __restrict__ scratch,
-                                                     unsigned rowLen, int * __restrict__ candLen, int * __restrict__ candCount)
+struct ClusterShared
 {
-    __shared__ int hist[kClusterBins];
-    __shared__ unsigned occ[kClusterBins / 32];
-    __shared__ unsigned nValid;
-    __shared__ int vMin, vMax;
-    const unsigned fw = blockIdx.x;
+    int      hist[kClusterBins];
+    unsigned occ[kClusterBins / 32];
+    unsigned nValid;
+    int      vMin, vMax;
+};
+
+// One flagged window by one workgroup; every return is workgroup-uniform.
+__device__ __forceinline__ void clusterWindow(const ClusterInput & in, int uniformThreshold, int * __restrict__ scratch,
+                                              unsigned rowLen, int * __restrict__ candLen, int * __restrict__ candCount,
+                                              unsigned fw, ClusterShared & sh)
+{
+    int (&hist)[kClusterBins] = sh.hist;
+    unsigned (&occ)[kClusterBins / 32] = sh.occ;
+    unsigned & nValid = sh.nValid;
+    int &vMin = sh.vMin, &vMax = sh.vMax;
     if (threadIdx.x == 0)
     {
         nValid = 0;
@@ -540,6 +553,97 @@ __global__ __launch_bounds__(1024) void clusterKernel(ClusterInput in, int unifo
         }
         emitCluster(sum, n, thresholdOfRanks(in, uniformThreshold, i0, m - 1), candLen, fw, nc);
         candCount[fw] = nc;
+    }
+}
+
+// The workgroups take the flagged windows in turn (their number may only be known on the device: ClusterInput).
+__global__ __launch_bounds__(1024) void clusterKernel(ClusterInput in, int uniformThreshold, int * __restrict__ scratch,
+                                                     unsigned rowLen, int * __restrict__ candLen, int * __restrict__ candCount)
+{
+    __shared__ ClusterShared sh;
+    const unsigned n = in.nFlaggedDev ? min(*in.nFlaggedDev, in.nFlagged) : in.nFlagged;
+    for (unsigned fw = blockIdx.x; fw < n; fw += gridDim.x)
+    {
+        clusterWindow(in, uniformThreshold, scratch, rowLen, candLen, candCount, fw, sh);
+        __syncthreads();
+    }
+}
+
+// The flagged windows of a segment in ascending order (one workgroup): hdr[0] = their number (also if the list, which
+// holds `cap`, is too short for them).
+__global__ __launch_bounds__(1024) void compactFlaggedKernel(const int * __restrict__ winFlag, unsigned W, unsigned cap,
+                                                            int * __restrict__ flagged, unsigned * __restrict__ hdr)
+{
+    __shared__ unsigned perWave[16];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned carry = 0;
+    for (unsigned base = 0; base < W; base += 1024u)
+    {
+        const unsigned w = base + threadIdx.x;
+        const bool v = w < W && winFlag[w] != 0;
+        const unsigned long long bal = __ballot(v);
+        if (lane == 0)
+            perWave[wave] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before = 0, all = 0;
+        for (unsigned k = 0; k < 16u; ++k)
+        {
+            before += k < wave ? perWave[k] : 0u;
+            all += perWave[k];
+        }
+        const unsigned at = carry + before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        if (v && at < cap)
+            flagged[at] = (int)w;
+        carry += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        hdr[0] = carry;
+}
+
+// The (window, candidate length) cells in the order the host would list them (flagged window, then candidate):
+// hdr[1] = their number, hdr[2] = 1 if a window has more candidates than its list holds, hdr[4 + 2 i] / hdr[5 + 2 i] =
+// window and length of cell i < listCap.
+__global__ __launch_bounds__(256) void listCellsKernel(const int * __restrict__ flagged, const int * __restrict__ candLen,
+                                                       const int * __restrict__ candCount, unsigned cap, unsigned listCap,
+                                                       unsigned * __restrict__ hdr)
+{
+    __shared__ unsigned sh[256];
+    __shared__ unsigned tooMany;
+    const unsigned n = min(hdr[0], cap);
+    if (threadIdx.x == 0)
+        tooMany = 0;
+    unsigned carry = 0;
+    for (unsigned base = 0; base < n; base += 256u)
+    {
+        const unsigned f = base + threadIdx.x;
+        const int cnt = f < n ? candCount[f] : 0;
+        const unsigned v = (unsigned)min(cnt, kMaxCandidatesPerWindow);
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        if (cnt > kMaxCandidatesPerWindow)
+            tooMany = 1u;
+        for (unsigned o = 1; o < 256u; o <<= 1)
+        {
+            const unsigned t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const unsigned first = carry + sh[threadIdx.x] - v;
+        for (unsigned k = 0; k < v; ++k)
+            if (first + k < listCap)
+            {
+                hdr[4 + 2 * (first + k)] = (unsigned)flagged[f];
+                hdr[5 + 2 * (first + k)] = (unsigned)candLen[f * kMaxCandidatesPerWindow + k];
+            }
+        carry += sh[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        hdr[1] = carry;
+        hdr[2] = tooMany;
     }
 }
 
@@ -771,6 +875,25 @@ __global__ __launch_bounds__(256) void suppScanKernel(Stage2Buffers b)
             b.cells[c].suppBase = carry + sh[threadIdx.x] - v;
         carry += sh[255];
         __syncthreads();
+    }
+    if (b.guard == nullptr)
+        return;
+    // launched ahead of the host's look at the counts: do the pools hold, are the generic kernels there if needed?
+    __shared__ unsigned bad;
+    if (threadIdx.x == 0)
+        bad = carry > b.suppCap ? 1u : 0u;
+    __syncthreads();
+    if (!b.genericLaunched)
+        for (unsigned c = threadIdx.x; c < b.nCells; c += 256u)
+            if (b.counters[((size_t)b.rank * b.nCells + c) * 4 + 3] != 0u)
+                atomicOr(&bad, 1u);
+    __syncthreads();
+    if (bad)
+    {
+        for (unsigned c = threadIdx.x; c < b.nCells; c += 256u)
+            b.cells[c].phase = kCellDead;
+        if (threadIdx.x == 0)
+            *b.guard = 1u;
     }
 }
 
@@ -2620,16 +2743,51 @@ __global__ __launch_bounds__(64) void cellEmitKernel(Stage2Buffers b)
     cs.phase = (cs.logLR >= b.minLR) ? kCellEmit : kCellDead;
 }
 
-// Pack the per-sample outputs of the emitted cells.
+// The emitted cells of a batch in cell order (one workgroup): emitCells[0] = their number, emitCells[1..] = their indices.
+__global__ __launch_bounds__(256) void emitCompactKernel(Stage2Buffers b, unsigned * __restrict__ emitCells)
+{
+    __shared__ unsigned sh[256];
+    unsigned carry = 0;
+    for (unsigned base = 0; base < b.nCells; base += 256u)
+    {
+        const unsigned c = base + threadIdx.x;
+        const unsigned v = (c < b.nCells && b.cells[c].phase == kCellEmit) ? 1u : 0u;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (unsigned o = 1; o < 256u; o <<= 1)
+        {
+            const unsigned t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (v)
+            emitCells[carry + sh[threadIdx.x]] = c;            // (inclusive count: slot 0 is the total)
+        carry += sh[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        emitCells[0] = carry;
+}
+
+// Pack the per-sample outputs of the emitted cells: [n][S][3] PL | [n][S][3] LAD | [n][S][5] DAD | [n][S][2] first/last,
+// n = emitCells[0]. Launched for every cell of the batch before the host knows n; the surplus workgroups leave at once.
 __global__ void gatherOutKernel(Stage2Buffers b, const unsigned * __restrict__ emitCells, unsigned nSamples,
-                                uint32_t * __restrict__ pl, uint32_t * __restrict__ lad, uint32_t * __restrict__ dad,
-                                uint32_t * __restrict__ fl)
+                                uint32_t * __restrict__ out)
 {
     const unsigned e = blockIdx.y;
-    const unsigned c = emitCells[e];
+    const unsigned n = emitCells[0];
+    if (e >= n)
+        return;
+    const unsigned c = emitCells[1 + e];
     const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nSamples)
         return;
+    const size_t per = (size_t)n * nSamples;
+    uint32_t * pl = out;
+    uint32_t * lad = pl + per * 3;
+    uint32_t * dad = lad + per * 3;
+    uint32_t * fl = dad + per * 5;
     const size_t src = (size_t)c * nSamples + s, dst = (size_t)e * nSamples + s;
     for (int k = 0; k < 3; ++k)
     {
@@ -2646,8 +2804,20 @@ __global__ void gatherOutKernel(Stage2Buffers b, const unsigned * __restrict__ e
 void launchPackFlagged(const int32_t * q3, const uint8_t * flags, const int * flaggedWindows, unsigned W, unsigned nLocal,
                        const ClusterInput & in, unsigned rank, hipStream_t st)
 {
-    hipLaunchKernelGGL(packFlaggedKernel, dim3((in.sper + 255) / 256, in.nFlagged), dim3(256), 0, st, q3, flags, flaggedWindows, W,
+    const unsigned rows = in.nFlaggedDev ? (in.nFlagged < 64u ? in.nFlagged : 64u) : in.nFlagged;
+    hipLaunchKernelGGL(packFlaggedKernel, dim3((in.sper + 255) / 256, rows), dim3(256), 0, st, q3, flags, flaggedWindows, W,
                        nLocal, in, rank);
+}
+
+void launchCompactFlagged(const int * winFlag, unsigned W, unsigned cap, int * flagged, unsigned * hdr, hipStream_t st)
+{
+    hipLaunchKernelGGL(compactFlaggedKernel, dim3(1), dim3(1024), 0, st, winFlag, W, cap, flagged, hdr);
+}
+
+void launchListCells(const int * flagged, const int * candLen, const int * candCount, unsigned cap, unsigned listCap,
+                     unsigned * hdr, hipStream_t st)
+{
+    hipLaunchKernelGGL(listCellsKernel, dim3(1), dim3(256), 0, st, flagged, candLen, candCount, cap, listCap, hdr);
 }
 
 __global__ void copyBytesKernel(const uint8_t * __restrict__ src, uint8_t * __restrict__ dst, size_t n)
@@ -2667,7 +2837,8 @@ void launchCopyBytes(const void * src, void * dst, size_t n, hipStream_t st)
 void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,
                    hipStream_t st)
 {
-    hipLaunchKernelGGL(clusterKernel, dim3(in.nFlagged), dim3(1024), 0, st, in, uniformThreshold, scratch, rowLen, candLen,
+    const unsigned groups = in.nFlaggedDev ? (in.nFlagged < 256u ? in.nFlagged : 256u) : in.nFlagged;
+    hipLaunchKernelGGL(clusterKernel, dim3(groups), dim3(1024), 0, st, in, uniformThreshold, scratch, rowLen, candLen,
                        candCount);
 }
 
@@ -2766,13 +2937,13 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     hipLaunchKernelGGL(cellEmitKernel, wavePerCell, dim3(64), 0, st, b);
 }
 
-void launchGatherOut(const Stage2Buffers & b, const unsigned * emitCells, unsigned nEmit, unsigned nSamples, uint32_t * pl,
-                     uint32_t * lad, uint32_t * dad, uint32_t * fl, hipStream_t st)
+// emitCells: [1 + nCells] (count, then indices); out: room for nCells x nSamples x 13 words
+void launchGatherOut(const Stage2Buffers & b, unsigned * emitCells, unsigned nSamples, uint32_t * out, hipStream_t st)
 {
-    if (nEmit == 0)
+    if (b.nCells == 0)
         return;
-    hipLaunchKernelGGL(gatherOutKernel, dim3((nSamples + 255) / 256, nEmit), dim3(256), 0, st, b, emitCells, nSamples, pl, lad,
-                       dad, fl);
+    hipLaunchKernelGGL(emitCompactKernel, dim3(1), dim3(256), 0, st, b, emitCells);
+    hipLaunchKernelGGL(gatherOutKernel, dim3((nSamples + 255) / 256, b.nCells), dim3(256), 0, st, b, emitCells, nSamples, out);
 }
 
 }  // namespace pd

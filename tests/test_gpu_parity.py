@@ -344,3 +344,68 @@ def test_device_log_tables_against_the_x87_logarithms(built):
         assert len(gv) == len(r.hist_values) and np.array_equal(gv, ov) and np.array_equal(gv, np.asarray(r.hist_values))
         assert np.all(np.abs(gl - ol) <= np.spacing(np.abs(ol))) and np.all(np.abs(g10 - o10) <= np.spacing(np.abs(o10)))
         assert (gl == ol).mean() > 0.5
+
+
+def test_stage2_launched_ahead_of_the_pool_sizes(built):
+    """Stage 2 does not wait for the host to size the support pools: they are sized from the segment's average with
+    headroom and checked on the device; a batch whose pools do not hold (here: all pairs of the segment sit around the
+    deletion, the rest of the windows is empty), or that needs the generic kernels for the first time, is run again the
+    exact way. Either way the calls are the oracle's."""
+    from popdel_amd import capi, synth
+    lib = synth.Library()
+    rg = synth.conditioned_readgroup(lib)
+    n, region, first, W = 128, (1000000, 1060000), 1000020, 1900
+    ordinary = synth.cohort_segment(n, region, first, W, lib)
+
+    def around_the_deletion(k):
+        pos, dev = synth.sample_pairs(1000 + k, region, lib, synth.single_deletion(k, region))
+        d = synth.single_deletion(k, region)[0]
+        near = (pos > d.start - 1500) & (pos < d.start + d.length + 1500)
+        return synth.instances_by_interval_rule(pos[near], dev[near], lib, first, W)
+    parts = [around_the_deletion(k) for k in range(n)]
+    offsets = np.concatenate([[0], np.cumsum([len(p[0]) for p in parts])]).astype(np.uint64)
+    concentrated = capi.Segment(first, W, offsets, *[np.concatenate([p[i] for p in parts]) for i in range(4)])
+
+    oracle = capi.Context(capi.load_library(ORACLE_LIB), [rg] * n, list(range(n + 1)))
+    for order, expect in (((ordinary, ordinary), [0, 0]), ((concentrated, ordinary), [1, 1])):
+        ctx = capi.Context(capi.load_hip(), [rg] * n, list(range(n + 1)))     # (the pools of a context only grow)
+        repeated = []
+        for seg in order:
+            got = ctx.collect(ctx.submit(seg))
+            repeated.append(ctx.timing()["n_repeated_batches"])
+            want = oracle.collect(oracle.submit(seg))
+            assert want["n_calls"] > 0
+            assert got["n_calls"] == want["n_calls"]
+            for k in INT_KEYS:
+                assert np.array_equal(got[k], want[k]), k
+            assert np.allclose(got["likelihood_ratio"], want["likelihood_ratio"], rtol=1e-6, atol=1e-6)
+        ctx.close()
+        assert repeated == expect, repeated
+    oracle.close()
+
+
+@pytest.mark.parametrize("n_windows", [1900, 6600])
+def test_flagged_windows_and_cells_listed_on_the_device(built, n_windows):
+    """An unsharded context forms the lists of flagged windows and of (window, length) cells on the device and reads them
+    in one round trip. With a threshold of 1 nearly every window is flagged: 1900 windows -> more cells than the first copy
+    brings along (second fetch); 6600 windows -> more flagged windows than the device lists are made for (4096: the
+    host-side lists take over). Both against the host-side lists and the oracle."""
+    import dataclasses
+    from popdel_amd import capi, synth
+    lib = synth.Library()
+    rg = dataclasses.replace(synth.conditioned_readgroup(lib), min_init_del_len=1)
+    n = 5
+    seg = synth.cohort_segment(n, (1000000, 1000000 + 30 * n_windows + 2000), 1000020, n_windows, lib)
+    gpu, cpu = both(seg, [rg] * n, list(range(n + 1)), window_wise_output=True)
+    assert cpu[0]["n_calls"] > 0
+    assert_same(gpu, cpu)
+    os.environ["POPDEL_HIP_HOST_LISTS"] = "1"
+    try:
+        ctx = capi.Context(capi.load_hip(), [rg] * n, list(range(n + 1)), window_wise_output=True)
+        host_lists = ctx.collect(ctx.submit(seg))
+        assert ctx.timing()["n_candidate_cells"] > (4096 if n_windows > 4096 else 1022)      # (at least one per flagged window)
+        ctx.close()
+    finally:
+        del os.environ["POPDEL_HIP_HOST_LISTS"]
+    for k, v in host_lists.items():
+        assert np.array_equal(np.asarray(gpu[0][k]), np.asarray(v)), k
