@@ -28,6 +28,7 @@ void launchStage1Fallback(const SegmentView & seg, const CohortView & co, int32_
                           uint8_t * tileTodo, unsigned * todoList, const unsigned * bigList, hipStream_t stream);
 void launchPackFlagged(const int32_t * q3, const uint8_t * flags, const int * flaggedWindows, unsigned W, unsigned nLocal,
                        const ClusterInput & in, unsigned rank, hipStream_t st);
+void launchZero(const ZeroRanges & r, hipStream_t st);
 void launchCompactFlagged(const int * winFlag, unsigned W, unsigned cap, int * flagged, unsigned * hdr, hipStream_t st);
 void launchListCells(const int * flagged, const int * candLen, const int * candCount, unsigned cap, unsigned listCap,
                      unsigned * hdr, hipStream_t st);
@@ -265,6 +266,7 @@ struct pd_ctx
     hipStream_t stream = nullptr;       // all kernels
     hipStream_t copyStream = nullptr;   // segment uploads and the result D2H, so that the next segment's scan can run underneath it
     hipEvent_t resultsPacked = nullptr;
+    hipEvent_t cellsFetched = nullptr;
     DevBuf<pd::RgConst> dRg;
     DevBuf<double> dHist;
     DevBuf<double4> dTab;
@@ -360,6 +362,8 @@ struct pd_ctx
             (void)rccl().commDestroy(comm);
         if (resultsPacked)
             (void)hipEventDestroy(resultsPacked);
+        if (cellsFetched)
+            (void)hipEventDestroy(cellsFetched);
         if (copyStream)
             (void)hipStreamDestroy(copyStream);
         if (stream)
@@ -1048,6 +1052,7 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
         PD_HIP(hipStreamCreate(&c->stream));
         PD_HIP(hipStreamCreate(&c->copyStream));
         PD_HIP(hipEventCreateWithFlags(&c->resultsPacked, hipEventDisableTiming));
+        PD_HIP(hipEventCreateWithFlags(&c->cellsFetched, hipEventDisableTiming));
         std::vector<pd::RgConst> rc(n_readgroups);
         std::vector<double> pool;
         int minThreshold = 0x7fffffff;
@@ -1455,13 +1460,15 @@ static void launchScan(pd_ctx * c, Run & run)
     o.q3.ensure(cells);
     o.flags.ensure(cells);
     o.winFlag.ensure(s.nWindows);
-    PD_HIP(hipMemsetAsync(o.winFlag.p, 0, s.nWindows * sizeof(int), st));
     const size_t tiles = static_cast<size_t>((s.nWindows + pd::kStage1Block - 1) / pd::kStage1Block) * c->nSamples;
     o.tileTodo.ensure(tiles);
     o.todoList.ensure(tiles + 2);
     o.bigList.ensure(tiles / 2 + c->nSamples + 2);
-    PD_HIP(hipMemsetAsync(o.todoList.p, 0, sizeof(unsigned), st));
-    PD_HIP(hipMemsetAsync(o.bigList.p, 0, sizeof(unsigned), st));
+    pd::ZeroRanges zero{};
+    zero.add(o.winFlag.p, s.nWindows * sizeof(int));
+    zero.add(o.todoList.p, sizeof(unsigned));
+    zero.add(o.bigList.p, sizeof(unsigned));
+    pd::launchZero(zero, st);
     PD_HIP(hipEventRecord(run.s1Begin, st));
     pd::launchStage1(viewOf(s), c->cohort, o.q3.p, o.flags.p, o.winFlag.p, o.tileTodo.p, o.todoList.p, o.bigList.p, s.maxBlockChunks, st);
     PD_HIP(hipGetLastError());
@@ -1741,6 +1748,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         uint32_t *hPl = nullptr, *hLad = nullptr, *hDad = nullptr, *hFl = nullptr;
         std::vector<uint32_t> accPl, accLad, accDad, accFl;       // only used when there is more than one batch
         uint32_t nLastBatch = 0;                                  // emitted cells of the last batch (still on the device)
+        bool tailRecorded = false;                                // s2End / resultsPacked are on the stream
         for (unsigned batch = 0; batch < nBatches; ++batch)
         {
             const unsigned lo = batch * batchCells, hi = std::min(nCells, lo + batchCells), nb = hi - lo;
@@ -1821,8 +1829,12 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             {
                 const bool optimistic = attempt == 0 && world == 1 && c->optimisticPools;
                 unsigned * guard = c->dIterFlags.p + pd::kMaxIterationsCap + 1;
-                PD_HIP(hipMemsetAsync(area, 0, countersBytes + xchBytes, c->stream));
-                PD_HIP(hipMemsetAsync(c->dShifts.p, 0, static_cast<size_t>(nb) * c->nRg * sizeof(int), c->stream));
+                pd::ZeroRanges zero{};
+                zero.add(area, countersBytes + xchBytes);
+                zero.add(c->dShifts.p, static_cast<size_t>(nb) * c->nRg * sizeof(int));
+                zero.add(c->dTileMode.p, static_cast<size_t>(nb) * b.ownTiles * sizeof(unsigned));
+                zero.add(c->dIterFlags.p, (pd::kMaxIterationsCap + 2) * sizeof(unsigned));     // EM flags and the guard word
+                pd::launchZero(zero, c->stream);
                 PD_HIP(hipMemcpyAsync(c->dCells.p, c->hCells.data() + lo, nb * sizeof(pd::CellState), hipMemcpyHostToDevice, c->stream));
                 bool generic = c->genericSeen;
                 b.guard = nullptr;
@@ -1836,7 +1848,6 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
                     b.guard = guard;
                     b.suppFirst = c->dSuppFirst.p;
                     b.suppLast = c->dSuppLast.p;
-                    PD_HIP(hipMemsetAsync(guard, 0, sizeof(unsigned), c->stream));
                     pd::runStage2Init(view, c->cohort, b, o.flags.p, xch, c->stream);
                     PD_HIP(hipGetLastError());
                 }
@@ -1873,12 +1884,25 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
                 // (the list is formed on the device; room for all cells of the batch)
                 pd::launchGatherOut(b, c->dEmit.p, S, c->dOutPl.p, c->stream);
                 PD_HIP(hipGetLastError());
+                const bool lastBatch = batch + 1 == nBatches;
+                if (lastBatch)
+                {
+                    PD_HIP(hipEventRecord(s2End, c->stream));
+                    PD_HIP(hipEventRecord(c->resultsPacked, c->stream));
+                    tailRecorded = true;
+                }
                 PD_HIP(hipMemcpyAsync(c->hCells.data() + lo, c->dCells.p, nb * sizeof(pd::CellState), hipMemcpyDeviceToHost, c->stream));
                 PD_HIP(hipMemcpyAsync(c->hIterFlag.data() + 2, c->dEmit.p, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
                 c->hIterFlag[1] = 0;
                 if (optimistic)
                     PD_HIP(hipMemcpyAsync(c->hIterFlag.data() + 1, guard, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-                PD_HIP(hipStreamSynchronize(c->stream));
+                PD_HIP(hipEventRecord(c->cellsFetched, c->stream));
+                // the scan of a waiting ticket goes onto the stream now, right behind this segment's last kernel: the host
+                // reads the cells (and, on the copy stream, the columns travel) while it runs. Not earlier: the looks of the
+                // EM loop wait for everything enqueued before them.
+                if (lastBatch && nBatches == 1 && !c->runs.empty() && !c->runs.begin()->second.launched)
+                    launchScan(c, c->runs.begin()->second);
+                PD_HIP(hipEventSynchronize(c->cellsFetched));
                 if (!optimistic || c->hIterFlag[1] == 0)
                     break;
                 ++c->nRepeatedBatches;
@@ -1923,11 +1947,10 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             hDad = hLad + perSample * 3;
             hFl = hDad + perSample * 5;
         }
-        PD_HIP(hipEventRecord(s2End, c->stream));
+        if (!tailRecorded)                                                   // (no cells at all)
+            PD_HIP(hipEventRecord(s2End, c->stream));
         const bool direct = nBatches == 1 && nLastBatch != 0 && !keep;      // results of the only batch still sit in dOutPl
-        if (direct)
-            PD_HIP(hipEventRecord(c->resultsPacked, c->stream));
-        // the scan of a waiting ticket starts right behind this segment's last kernel ...
+        // the scan of a waiting ticket is on the stream by now (see the batch loop); with no cells it starts here
         // (enqueued BEFORE the copy: the other order was measured to hold the scan's first packets back until the copy,
         // a blit kernel on this platform, had finished)
         if (!c->runs.empty() && !c->runs.begin()->second.launched)

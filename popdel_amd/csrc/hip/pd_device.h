@@ -111,6 +111,21 @@ struct ClusterInput
     const unsigned * minInit;      // [read groups of the cohort] minInitDelLen, looked up BY SORTED RANK (quirk Q1)
 };
 
+// Up to six word-aligned ranges cleared by ONE kernel launch (every hipMemsetAsync is a launch of its own, ~6-10 us apart
+// on the stream; a segment needs nine).
+struct ZeroRanges
+{
+    uint32_t * p[6];
+    size_t     words[6];
+    unsigned   n;
+    void add(void * ptr, size_t bytes)
+    {
+        p[n] = static_cast<uint32_t *>(ptr);
+        words[n] = (bytes + 3) / 4;
+        ++n;
+    }
+};
+
 // Called by the launch sequences wherever samples of other contexts are needed: all-gathers `bytesPerRank` bytes per
 // context inside the area starting at `area` (layout [world][bytesPerRank]); stream-ordered. No-op for world == 1.
 struct Exchange

@@ -2820,6 +2820,25 @@ void launchListCells(const int * flagged, const int * candLen, const int * candC
     hipLaunchKernelGGL(listCellsKernel, dim3(1), dim3(256), 0, st, flagged, candLen, candCount, cap, listCap, hdr);
 }
 
+__global__ __launch_bounds__(256) void zeroRangesKernel(ZeroRanges r)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (unsigned k = 0; k < r.n; ++k)
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < r.words[k]; i += stride)
+            r.p[k][i] = 0u;
+}
+
+void launchZero(const ZeroRanges & r, hipStream_t st)
+{
+    size_t most = 0;
+    for (unsigned k = 0; k < r.n; ++k)
+        most = most > r.words[k] ? most : r.words[k];
+    if (most == 0)
+        return;
+    const unsigned groups = (unsigned)((most + 1023) / 1024 < 1024 ? (most + 1023) / 1024 : 1024);
+    hipLaunchKernelGGL(zeroRangesKernel, dim3(groups), dim3(256), 0, st, r);
+}
+
 __global__ void copyBytesKernel(const uint8_t * __restrict__ src, uint8_t * __restrict__ dst, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -2843,13 +2862,13 @@ void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch,
 }
 
 // Phase A: first allele-frequency estimate and support-pool capacities (the host sizes the pools from them).
+// The caller has cleared counters, xch, shifts, tileMode and iterFlags[0 .. maxIterations] (one launchZero).
 void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
                    hipStream_t st)
 {
     if (b.nCells == 0)
         return;
     const dim3 perCell((b.nCells + 127) / 128), cellBlock(128);
-    (void)hipMemsetAsync(b.tileMode, 0, (size_t)b.nCells * b.ownTiles * sizeof(unsigned), st);
     hipLaunchKernelGGL(cellGatherKernel, dim3(b.ownTiles * 4, b.nCells), dim3(kGatherThreads), 0, st, seg, co, b, flags);
     if (b.mt.n != 0)
         hipLaunchKernelGGL(multiGatherKernel, dim3(b.mt.nWaves, b.nCells), dim3(kGatherThreads), 0, st, seg, co, b);
@@ -2881,7 +2900,6 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     };
     dataLik(0);
     x.allGather(b.xch, xchBytes);
-    (void)hipMemsetAsync(b.iterFlags, 0, (b.maxIterations + 1) * sizeof(unsigned), st);
     hipLaunchKernelGGL(cellLoopHeadKernel, perCell, cellBlock, 0, st, b);
     for (unsigned it = 0; it < b.maxIterations; ++it)
     {
