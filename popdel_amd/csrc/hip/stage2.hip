@@ -26,7 +26,8 @@ namespace pd {
 // dispatched back to back -- was measured 23 % slower on MI355X: all XCDs then pull the same lines at the same time. An
 // XCD-aware 1-D order -- XCD x takes the tiles t = x mod 8 and walks all cells of a tile back to back, so that the
 // tile's lookup tables stay in that XCD's L2 -- was 13 % slower as well: concurrent workgroups then hammer the same few
-// table lines; spreading the samples over the channels matters more here than L2 reuse.)
+// table lines; spreading the samples over the channels matters more here than L2 reuse. What does matter: grid.x a
+// multiple of 8, so that tile t always lands on XCD t mod 8 -- see runStage2Main.)
 #define PD_CELL_IDX blockIdx.y
 #define PD_TILE_IDX blockIdx.x
 
