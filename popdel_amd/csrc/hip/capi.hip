@@ -1734,9 +1734,10 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         // (from the samples per context of the partition, not from this context's own count: all contexts of a sharded
         // cohort must cut the cell list at the same places, the exchanges run per batch)
         const size_t bytesPerCell = static_cast<size_t>(sper) * (2 * pd::kDenseCap * 2 + 24 + 52 + 2 + 24) + 4096;
-        // (the cell index is a grid's y dimension: at most 65,535 cells per batch)
+        // ((sweep, cell) is a grid's y dimension: at most 65,535 / sweeps cells per batch; pd::kTilesPerSweep)
+        const size_t sweeps = ((static_cast<size_t>(S) + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock + 7) / 8 * 8 / pd::kTilesPerSweep + 1;
         const unsigned batchCells = static_cast<unsigned>(
-            std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nCells ? nCells : 1, 65535), budget / bytesPerCell)));
+            std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nCells ? nCells : 1, 65535 / sweeps), budget / bytesPerCell)));
         const unsigned nBatches = nCells ? (nCells + batchCells - 1) / batchCells : 0;
         pd::Stage2Buffers b;
         std::memset(&b, 0, sizeof(b));

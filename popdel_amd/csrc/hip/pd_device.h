@@ -16,6 +16,7 @@ constexpr int kStage1LdsPairs = 3072;          // pair chunks staged in LDS per 
 constexpr int kSampleTile = 256;               // threads per workgroup in the stage-2 per-sample kernels
 constexpr int kDenseCap = 96;                  // active pairs per (cell, sample) the dense stage-2 image holds
 constexpr unsigned kDenseHighCov = 0xffffu;    // cellN marker: read group at or above maxLoad (skipped by the reference)
+constexpr unsigned kTilesPerSweep = 40;         // sample tiles a per-sample kernel walks for ALL cells before it moves on (see stage2.hip)
 constexpr int kSamplesPerBlock = 256;           // samples one such workgroup walks (8 half-waves x 32 samples; 64 and 128 were measured slower)
 
 // x87 `expl` underflows to zero below ln(2^-16446); the reference's "likelihood too small" reset hangs off that.
