@@ -495,21 +495,29 @@ def main():
         # computes, results collected -- i.e. what a host that has the pair instances in RAM sustains through one GPU
         torch.cuda.synchronize()
         q0 = time.perf_counter()
+        t_stage = t_collect = 0.0
         h_cur = ctx.stage(seg)
+        t_first = time.perf_counter() - q0
         t_cur = ctx.run(h_cur)
         for i in range(args.stream_segments):
             last = i + 1 == args.stream_segments
             if not last:
+                a = time.perf_counter()
                 h_nxt = ctx.stage(seg)
                 t_nxt = ctx.run(h_nxt)
+                t_stage += time.perf_counter() - a
+            a = time.perf_counter()
             ctx.collect(t_cur, copy=False)
             ctx.unstage(h_cur)
+            t_collect += time.perf_counter() - a
             if not last:
                 h_cur, t_cur = h_nxt, t_nxt
         torch.cuda.synchronize()
         dt = time.perf_counter() - q0
         return dict(value=args.stream_segments * W * S / dt, unit="window*sample/s", segments=args.stream_segments,
                     seconds_per_segment=dt / args.stream_segments,
+                    stage_seconds_per_segment=t_stage / max(1, args.stream_segments - 1),
+                    collect_seconds_per_segment=t_collect / args.stream_segments, first_stage_seconds=t_first,
                     host_bytes_per_segment=int(16 * len(arrays["dev"]) + 8 * (S + 1)))
 
     def concurrent_leg():

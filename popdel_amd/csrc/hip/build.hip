@@ -65,6 +65,80 @@ __device__ __forceinline__ unsigned slotOf(unsigned a, unsigned chunkOff, unsign
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// One workgroup per read group: running sum of the `on` differences, 256 instances per round.
+__global__ __launch_bounds__(256) void expandKernel(CompactInstances in, const uint64_t * __restrict__ rgOffsets, unsigned W,
+                                                    uint16_t * __restrict__ on16, uint16_t * __restrict__ off16,
+                                                    uint16_t * __restrict__ back16)
+{
+    __shared__ unsigned perWave[4];
+    const unsigned rg = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t lo = rgOffsets[rg], hi = rgOffsets[rg + 1];
+    const unsigned excLo = in.excRgStart[rg], excHi = in.excRgStart[rg + 1];
+    unsigned carry = 0;
+    for (uint64_t blk = lo; blk < hi; blk += 256u)
+    {
+        const uint64_t i = blk + threadIdx.x;
+        unsigned d = 0, l = 0, bk = 0;
+        if (i < hi)
+        {
+            d = in.onDelta[i];
+            l = in.life[i];
+            bk = in.back[i];
+            if (d == 255u || l == 255u || bk == 255u)
+            {
+                // (exceptions: a pair that was active before the segment began, a long-lived pair, 255 windows or more
+                // without a new pair -- a per cent of the instances; the read group's part of the list is short)
+                unsigned a = excLo, b = excHi;
+                while (a < b)
+                {
+                    const unsigned m = (a + b) >> 1;
+                    if (in.excIndex[m] < (uint32_t)i)
+                        a = m + 1u;
+                    else
+                        b = m;
+                }
+                d = in.excOnDelta[a];
+                l = in.excLife[a];
+                bk = in.excBack[a];
+            }
+        }
+        unsigned incl = d;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1)
+        {
+            const unsigned t = (unsigned)__shfl_up((int)incl, o, 64);
+            if (lane >= (unsigned)o)
+                incl += t;
+        }
+        if (lane == 63u)
+            perWave[wave] = incl;
+        __syncthreads();
+        unsigned before = 0, all = 0;
+        for (unsigned k = 0; k < 4u; ++k)
+        {
+            before += k < wave ? perWave[k] : 0u;
+            all += perWave[k];
+        }
+        const unsigned on = carry + before + incl;
+        if (i < hi)
+        {
+            on16[i] = (uint16_t)min(on, 0xffffu);
+            off16[i] = (uint16_t)min(on + l, W);
+            back16[i] = (uint16_t)bk;
+        }
+        carry += all;
+        __syncthreads();
+    }
+}
+
+void launchExpand(const CompactInstances & in, const uint64_t * rgOffsets, unsigned nRg, unsigned W, uint16_t * on16, uint16_t * off16,
+                  uint16_t * back16, hipStream_t st)
+{
+    if (nRg)
+        hipLaunchKernelGGL(expandKernel, dim3(nRg), dim3(256), 0, st, in, rgOffsets, W, on16, off16, back16);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lifeStatsKernel(InstanceArrays in, uint64_t n, unsigned W, unsigned long long * hist /* [67] */)
 {
     __shared__ unsigned shHist[66];

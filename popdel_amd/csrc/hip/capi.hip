@@ -4,7 +4,9 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -311,6 +313,11 @@ struct pd_ctx
     uint64_t nRepeatedBatches = 0;
     // device-side layout build (build.hip): the uploaded instances and the small tables around them
     PinnedBuf<uint16_t> hIn16[4];           // dev, on, off, start distance (narrow upload)
+    PinnedBuf<uint8_t> hIn8[3];             // on difference, life, start distance (compact upload)
+    DevBuf<uint8_t> dIn8[3];
+    PinnedBuf<uint32_t> hExc[5];            // its exceptions: instance, on difference, life, start distance; first one per read group
+    DevBuf<uint32_t> dExc[5];
+    bool compactUpload = true;              // POPDEL_HIP_PLAIN_UPLOAD=1: 8 bytes per instance (A/B runs)
     PinnedBuf<uint32_t> hIn32[4];           // dev, on, off, start (wide upload)
     PinnedBuf<uint64_t> hRgOffsets;
     DevBuf<uint16_t> dIn16[4];
@@ -740,16 +747,36 @@ bool buildChunksOnDevice(pd_ctx & c, const pd_segment & seg, StagedSegment & out
     c.hRgOffsets.resize(nRg + 1);
     std::memcpy(c.hRgOffsets.data(), seg.rg_offsets, (nRg + 1) * sizeof(uint64_t));
     c.dRgOffsets.uploadPinned(c.hRgOffsets, cs);
-    if (narrowPossible)
-    {
+    // Narrow upload, two flavours. Compact (5 bytes per instance): the deviation in 16 bits; `on` as the difference to the
+    // read group's previous instance, the life off - on and the start distance in one byte each (255: see the exception
+    // list) -- expanded to the narrow arrays on the device (pd::launchExpand). Plain (8 bytes): four 16-bit fields.
+    // The compact flavour needs the instances of a read group in `on` order and few exceptions; else the plain one is
+    // packed (which reports instances out of order through the build kernels), else the wide one.
+    bool compact = narrowPossible && nInst < 0xffffffffull && c.compactUpload;
+    const bool debug = getenv("POPDEL_HIP_DEBUG") != nullptr;
+    const auto tBuild0 = std::chrono::steady_clock::now();
+    double packSeconds = 0;
+    std::vector<std::array<uint32_t, 4>> exceptions;             // (instance, on difference, life, start distance)
+    auto packNarrow = [&](bool asCompact) -> bool {
+        std::atomic<bool> ok(true);
+        std::mutex excLock;
+        exceptions.clear();
         for (int k = 0; k < 4; ++k)
         {
-            c.hIn16[k].resize(nInst);
+            if (!asCompact || k == 0)
+                c.hIn16[k].resize(nInst);
             c.dIn16[k].ensure(nInst);
         }
-        for (size_t slab = 0; slab < nSlabs && narrow.load(); ++slab)
+        if (asCompact)
+            for (int k = 0; k < 3; ++k)
+            {
+                c.hIn8[k].resize(nInst);
+                c.dIn8[k].ensure(nInst);
+            }
+        for (size_t slab = 0; slab < nSlabs && ok.load(); ++slab)
         {
             const size_t rgLo = nRg * slab / nSlabs, rgHi = nRg * (slab + 1) / nSlabs;
+            const auto tPack0 = std::chrono::steady_clock::now();
             pdh::parallelFor(rgHi - rgLo, [&](size_t k) {
                 const size_t rg = rgLo + k;
                 const uint64_t lo = seg.rg_offsets[rg], n = seg.rg_offsets[rg + 1] - lo;
@@ -759,9 +786,6 @@ bool buildChunksOnDevice(pd_ctx & c, const pd_segment & seg, StagedSegment & out
                 const uint32_t * __restrict sf = seg.pair_off + lo;
                 const uint32_t * __restrict ss = seg.pair_start + lo;
                 int16_t * __restrict dv = reinterpret_cast<int16_t *>(c.hIn16[0].data()) + lo;
-                uint16_t * __restrict on = c.hIn16[1].data() + lo;
-                uint16_t * __restrict off = c.hIn16[2].data() + lo;
-                uint16_t * __restrict back = c.hIn16[3].data() + lo;
                 const uint32_t first = seg.first_window_pos, shift = seg.window_shift;
                 uint32_t bad = 0;
                 for (uint64_t i = 0; i < n; ++i)
@@ -770,35 +794,154 @@ bool buildChunksOnDevice(pd_ctx & c, const pd_segment & seg, StagedSegment & out
                     bad |= static_cast<uint32_t>(d + 32768) >> 16;
                     dv[i] = static_cast<int16_t>(d);
                 }
-                for (uint64_t i = 0; i < n; ++i)
+                if (asCompact)
                 {
-                    const uint32_t a = so[i];
-                    bad |= a >> 16;
-                    on[i] = static_cast<uint16_t>(a);
+                    uint8_t * __restrict dOn = c.hIn8[0].data() + lo;
+                    uint8_t * __restrict life = c.hIn8[1].data() + lo;
+                    uint8_t * __restrict back8 = c.hIn8[2].data() + lo;
+                    uint32_t special = 0;
+                    for (uint64_t i = 0; i < n; ++i)
+                    {
+                        // first + on * shift - start in [0, 65535]; 64-bit only where the 32-bit value could wrap
+                        const uint32_t dist = first + so[i] * shift - ss[i];
+                        bad |= dist >> 16;
+                        special |= dist >= 255u;
+                        back8[i] = static_cast<uint8_t>(dist < 255u ? dist : 255u);
+                    }
+                    if (n != 0)
+                    {
+                        bad |= so[0] >> 16;
+                        special |= so[0] >= 255u;
+                        dOn[0] = static_cast<uint8_t>(so[0] < 255u ? so[0] : 255u);
+                    }
+                    for (uint64_t i = 1; i < n; ++i)
+                    {
+                        const uint32_t a = so[i], d = a - so[i - 1];             // wraps if out of order: caught as "bad"
+                        bad |= (a >> 16) | (d >> 16);
+                        special |= d >= 255u;
+                        dOn[i] = static_cast<uint8_t>(d < 255u ? d : 255u);
+                    }
+                    for (uint64_t i = 0; i < n; ++i)
+                    {
+                        const uint32_t e = sf[i] < W ? sf[i] : W, l = e > so[i] ? e - so[i] : 0u;
+                        special |= l >= 255u;
+                        life[i] = static_cast<uint8_t>(l < 255u ? l : 255u);
+                    }
+                    if (special && !bad)
+                    {
+                        std::vector<std::array<uint32_t, 4>> mine;
+                        auto look = [&](uint64_t i) {
+                            if (dOn[i] == 255u || life[i] == 255u || back8[i] == 255u)
+                            {
+                                const uint32_t e = sf[i] < W ? sf[i] : W;
+                                mine.push_back({static_cast<uint32_t>(lo + i), i ? so[i] - so[i - 1] : so[0], e > so[i] ? e - so[i] : 0u,
+                                                first + so[i] * shift - ss[i]});
+                            }
+                        };
+                        // eight instances per step: does any of the 24 bytes equal 255? (most read groups have a handful)
+                        auto anyFF = [](const uint8_t * p) {
+                            uint64_t v;
+                            std::memcpy(&v, p, 8);
+                            v = ~v;
+                            return ((v - 0x0101010101010101ull) & ~v & 0x8080808080808080ull) != 0;
+                        };
+                        uint64_t i = 0;
+                        for (; i + 8 <= n; i += 8)
+                            if (anyFF(dOn + i) || anyFF(life + i) || anyFF(back8 + i))
+                                for (uint64_t j = i; j < i + 8; ++j)
+                                    look(j);
+                        for (; i < n; ++i)
+                            look(i);
+                        std::lock_guard<std::mutex> hold(excLock);
+                        exceptions.insert(exceptions.end(), mine.begin(), mine.end());
+                    }
                 }
-                for (uint64_t i = 0; i < n; ++i)
-                    off[i] = static_cast<uint16_t>(sf[i] < W ? sf[i] : W);
-                for (uint64_t i = 0; i < n; ++i)
+                else
                 {
-                    // first + on * shift - start in [0, 65535]; 64-bit only where the 32-bit value could wrap
-                    const uint32_t dist = first + so[i] * shift - ss[i];
-                    bad |= dist >> 16;
-                    back[i] = static_cast<uint16_t>(dist);
+                    uint16_t * __restrict on = c.hIn16[1].data() + lo;
+                    uint16_t * __restrict off = c.hIn16[2].data() + lo;
+                    uint16_t * __restrict back = c.hIn16[3].data() + lo;
+                    for (uint64_t i = 0; i < n; ++i)
+                    {
+                        const uint32_t dist = first + so[i] * shift - ss[i];
+                        bad |= dist >> 16;
+                        back[i] = static_cast<uint16_t>(dist);
+                    }
+                    for (uint64_t i = 0; i < n; ++i)
+                    {
+                        const uint32_t a = so[i];
+                        bad |= a >> 16;
+                        on[i] = static_cast<uint16_t>(a);
+                    }
+                    for (uint64_t i = 0; i < n; ++i)
+                        off[i] = static_cast<uint16_t>(sf[i] < W ? sf[i] : W);
                 }
                 // (window indices are < 2^16 here and positions < 2^32: the product and sum stay below 2^32 for any real
                 // segment; a wrap would need first + on * shift >= 2^32, which the 64-bit check below excludes)
                 if (n != 0 && static_cast<uint64_t>(first) + static_cast<uint64_t>(so[n - 1] & 0xffffu) * shift > 0xffffffffull)
                     bad = 1;
                 if (bad)
-                    narrow.store(false);
+                    ok.store(false);
             }, 8);
-            if (!narrow.load())
-                break;
+            packSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tPack0).count();
+            if (!ok.load() || (asCompact && exceptions.size() > nInst / 32 + 1024))
+                return false;
             const uint64_t a = seg.rg_offsets[rgLo], b = seg.rg_offsets[rgHi];
-            for (int k = 0; k < 4 && b > a; ++k)
-                PD_HIP(hipMemcpyAsync(c.dIn16[k].p + a, c.hIn16[k].data() + a, (b - a) * sizeof(uint16_t), hipMemcpyHostToDevice, cs));
+            if (b > a)
+            {
+                PD_HIP(hipMemcpyAsync(c.dIn16[0].p + a, c.hIn16[0].data() + a, (b - a) * sizeof(uint16_t), hipMemcpyHostToDevice, cs));
+                if (asCompact)
+                    for (int k = 0; k < 3; ++k)
+                        PD_HIP(hipMemcpyAsync(c.dIn8[k].p + a, c.hIn8[k].data() + a, b - a, hipMemcpyHostToDevice, cs));
+                else
+                    for (int k = 1; k < 4; ++k)
+                        PD_HIP(hipMemcpyAsync(c.dIn16[k].p + a, c.hIn16[k].data() + a, (b - a) * sizeof(uint16_t), hipMemcpyHostToDevice, cs));
+            }
+        }
+        return true;
+    };
+    if (narrowPossible)
+    {
+        if (compact && !packNarrow(true))
+            compact = false;
+        if (!compact && !packNarrow(false))
+            narrow.store(false);
+        if (compact)
+        {
+            // the exception list (ascending instance index), then the expansion into the narrow arrays
+            std::sort(exceptions.begin(), exceptions.end());
+            const size_t nExc = exceptions.size();
+            for (int k = 0; k < 4; ++k)
+            {
+                c.hExc[k].resize(nExc + 1);
+                for (size_t i = 0; i < nExc; ++i)
+                    c.hExc[k][i] = exceptions[i][k];
+                c.hExc[k][nExc] = 0;
+                c.dExc[k].uploadPinned(c.hExc[k], cs);
+            }
+            c.hExc[4].resize(nRg + 1);                          // first exception of every read group
+            for (size_t rg = 0, e = 0; rg <= nRg; ++rg)
+            {
+                while (e < nExc && exceptions[e][0] < seg.rg_offsets[rg])
+                    ++e;
+                c.hExc[4][rg] = static_cast<uint32_t>(e);
+            }
+            c.dExc[4].uploadPinned(c.hExc[4], cs);
+            pd::CompactInstances ci;
+            ci.onDelta = c.dIn8[0].p;
+            ci.life = c.dIn8[1].p;
+            ci.back = c.dIn8[2].p;
+            ci.excRgStart = c.dExc[4].p;
+            ci.excIndex = c.dExc[0].p;
+            ci.excOnDelta = c.dExc[1].p;
+            ci.excLife = c.dExc[2].p;
+            ci.excBack = c.dExc[3].p;
+            pd::launchExpand(ci, c.dRgOffsets.p, nRg, W, c.dIn16[1].p, c.dIn16[2].p, c.dIn16[3].p, cs);
+            PD_HIP(hipGetLastError());
         }
     }
+    else
+        narrow.store(false);
     if (!narrow.load())
     {
         const void * src[4] = {seg.pair_dev, seg.pair_on, seg.pair_off, seg.pair_start};
@@ -851,6 +994,11 @@ bool buildChunksOnDevice(pd_ctx & c, const pd_segment & seg, StagedSegment & out
     PD_HIP(hipGetLastError());
     PD_HIP(hipMemcpyAsync(c.hLifeHist.data(), c.dLifeHist.p, 67 * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
     PD_HIP(hipStreamSynchronize(cs));
+    if (debug)
+        fprintf(stderr, "[popdel_hip] device build: %llu instances uploaded %s, %zu exceptions; packing %.1f ms on the host threads, "
+                        "%.1f ms until the last byte was on the device\n", (unsigned long long)nInst,
+                narrow.load() ? (compact ? "compact (5 B)" : "narrow (8 B)") : "wide (16 B)", exceptions.size(), packSeconds * 1e3,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild0).count() * 1e3);
     uint64_t living = 0;
     for (int l = 0; l <= 65; ++l)
         living += c.hLifeHist[l];
@@ -1143,6 +1291,8 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
             c->optimisticPools = atoi(e) == 0;
         if (const char * e = getenv("POPDEL_HIP_HOST_LISTS"))
             c->deviceLists = atoi(e) == 0;
+        if (const char * e = getenv("POPDEL_HIP_PLAIN_UPLOAD"))
+            c->compactUpload = atoi(e) == 0;
         pd::buildLogTables(c->dHist.p, c->dTab.p, c->dTab2.p, pool.size(), c->dRg.p, n_readgroups, c->stream);
         PD_HIP(hipGetLastError());
         PD_HIP(hipStreamSynchronize(c->stream));

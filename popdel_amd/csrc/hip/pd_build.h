@@ -51,6 +51,23 @@ struct ScatterOut
     const uint32_t * winStart;
 };
 
+// Compact upload (5 bytes per instance): the deviation in 16 bits; `on` as the difference to the previous instance of the
+// read group, the life off - on and the distance of the pair start behind its first window in one byte each, 255 = look
+// the instance up in the exception list (ascending instance index; excRgStart[rg] = first exception of read group rg).
+// expandKernel turns them into the on16 / off16 / back16 arrays of the narrow format in device memory.
+struct CompactInstances
+{
+    const uint8_t *  onDelta;      // [nInst]
+    const uint8_t *  life;         // [nInst]
+    const uint8_t *  back;         // [nInst]
+    const uint32_t * excRgStart;   // [nRg + 1]
+    const uint32_t * excIndex;     // [nExc] instance index, ascending
+    const uint32_t * excOnDelta;   // [nExc]
+    const uint32_t * excLife;      // [nExc]
+    const uint32_t * excBack;      // [nExc]
+};
+void launchExpand(const CompactInstances & in, const uint64_t * rgOffsets, unsigned nRg, unsigned W, uint16_t * on16, uint16_t * off16,
+                  uint16_t * back16, hipStream_t st);
 void launchLifeStats(const InstanceArrays & in, uint64_t n, unsigned W, unsigned long long * hist, hipStream_t st);
 size_t buildLdsBytes(unsigned W, unsigned K);
 bool launchCount(const InstanceArrays & in, const BuildEntities & en, unsigned W, unsigned K, const CountOut & out, hipStream_t st);

@@ -1,4 +1,4 @@
-"""GPU: the staged segment layout built on the device (build.hip; instances cross PCIe once, 8 or 16 bytes each) against the
+"""GPU: the staged segment layout built on the device (build.hip; instances cross PCIe once, 5, 8 or 16 bytes each) against the
 host-side builder (POPDEL_HIP_HOST_BUILD=1, kept for segments the device builder does not take): every result field
 identical, floating point included -- chunks keep the order of the pair instances either way -- and both equal to the
 oracle."""
@@ -101,3 +101,47 @@ def test_results_do_not_depend_on_the_chunk_life_of_the_stage1_image(built, scan
     monkeypatch.setenv("POPDEL_HIP_MAXLIFE_SCAN", scan_life)
     got = run(hip, seg, rgs, offs, opts)
     identical(got, want)
+
+
+def test_compact_upload_and_its_exceptions(built, monkeypatch):
+    """The narrow upload is compact by default (5 bytes per instance): `on` as a one-byte difference to the previous instance
+    of the read group, the life and the distance of the pair start behind its first window in one byte each, exceptions in
+    a list (every pair that was active before the segment began is one: its start lies far behind window 0). A pair that
+    lives 600 windows, a read group whose pairs pause for 300 windows, one that starts 400 windows into the segment: same
+    result as the plain 8-byte upload and as the host builder."""
+    from popdel_amd import capi
+    from test_gpu_fuzz import random_case
+    seg, rgs, offs, opts = random_case(6)
+    W, shift = seg.n_windows, 30
+    o = np.asarray(seg.rg_offsets, dtype=np.int64)
+    for name in ("dev", "start", "on", "off"):
+        setattr(seg, name, getattr(seg, name).copy())
+    # read group 0: one long-lived pair
+    i = int(o[0]) + 40
+    seg.off[i] = min(W, int(seg.on[i]) + 600)
+    # read group 1: nothing new for 300 windows from its 50th instance on
+    a, b = int(o[1]) + 50, int(o[2])
+    seg.on[a:b] += 300
+    seg.off[a:b] += 300
+    seg.start[a:b] += 300 * shift
+    # read group 2: starts 400 windows into the segment
+    a, b = int(o[2]), int(o[3])
+    seg.on[a:b] += 400
+    seg.off[a:b] += 400
+    seg.start[a:b] += 400 * shift
+    keep = seg.on < W                                   # (instances pushed beyond the segment are dropped, read group by read group)
+    counts = [int(keep[int(o[r]):int(o[r + 1])].sum()) for r in range(len(o) - 1)]
+    for name in ("dev", "start", "on", "off"):
+        setattr(seg, name, getattr(seg, name)[keep])
+    seg.off = np.minimum(seg.off, W).astype(seg.off.dtype)
+    seg.rg_offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    hip = capi.load_hip()
+    monkeypatch.delenv("POPDEL_HIP_PLAIN_UPLOAD", raising=False)
+    compact = run(hip, seg, rgs, offs, opts, monkeypatch, host_build=False)
+    monkeypatch.setenv("POPDEL_HIP_PLAIN_UPLOAD", "1")
+    plain = run(hip, seg, rgs, offs, opts, monkeypatch, host_build=False)
+    monkeypatch.delenv("POPDEL_HIP_PLAIN_UPLOAD", raising=False)
+    host = run(hip, seg, rgs, offs, opts, monkeypatch, host_build=True)
+    identical(compact, plain)
+    identical(compact, host)
+    assert compact[3]["max_life"] >= 4 and compact[0]["n_calls"] > 0
