@@ -91,3 +91,27 @@ def test_cut_segment_with_carry_over_gives_the_same_calls(built, big):
         assert np.array_equal(joined, full[key]), key
     assert np.allclose(np.concatenate([parts[0]["likelihood_ratio"], parts[1]["likelihood_ratio"]]), full["likelihood_ratio"],
                        rtol=1e-9, atol=1e-9)
+
+
+def test_more_than_one_sweep_of_sample_tiles_against_the_oracle(built):
+    """10,500 samples = 42 tiles of 256: the per-sample kernels of stage 2 pad their grid to 48 tiles (an XCD then always
+    serves the same tiles) and walk them in two sweeps (40 + 8 tiles, all cells per sweep; pd::kTilesPerSweep). Calls and
+    per-sample columns against the oracle."""
+    from conftest import ORACLE_LIB
+    from popdel_amd import capi, synth
+    from test_gpu_parity import INT_KEYS
+    lib = synth.Library()
+    rg = synth.conditioned_readgroup(lib)
+    n, region, first, W = 10500, (1000000, 1017000), 1000020, 520
+    seg = synth.cohort_segment(n, region, first, W, lib, deletions=lambda k, r: [synth.Deletion(1007000, 900, [1, 0, 2, 0, 0][k % 5])])
+    out = []
+    for library in (capi.load_hip(), capi.load_library(ORACLE_LIB)):
+        ctx = capi.Context(library, [rg] * n, list(range(n + 1)))
+        out.append(ctx.collect(ctx.submit(seg)))
+        ctx.close()
+    got, want = out
+    assert want["n_calls"] > 10 and got["n_calls"] == want["n_calls"]
+    for k in INT_KEYS:
+        assert np.array_equal(got[k], want[k]), k
+    assert np.allclose(got["likelihood_ratio"], want["likelihood_ratio"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(got["frequency"], want["frequency"], rtol=0, atol=1e-6)
