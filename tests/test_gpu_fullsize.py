@@ -115,3 +115,36 @@ def test_more_than_one_sweep_of_sample_tiles_against_the_oracle(built):
         assert np.array_equal(got[k], want[k]), k
     assert np.allclose(got["likelihood_ratio"], want["likelihood_ratio"], rtol=1e-6, atol=1e-6)
     assert np.allclose(got["frequency"], want["frequency"], rtol=0, atol=1e-6)
+
+
+def test_multi_read_group_tiles_with_a_padded_grid_against_the_oracle(built):
+    """3,400 samples with two read groups each = 14 multi-read-group tiles: the lane-per-read-group kernels run on a grid
+    padded to 16 tiles. Against the oracle."""
+    from conftest import ORACLE_LIB
+    from popdel_amd import capi, synth
+    from test_gpu_parity import INT_KEYS
+    lib = synth.Library()
+    rg = synth.conditioned_readgroup(lib)
+    n, region, first, W = 3400, (1000000, 1017000), 1000020, 520
+    rng = np.random.default_rng(77)
+    parts, offsets = [], [0]
+    for k in range(n):
+        pos, dev = synth.sample_pairs(3000 + k, region, lib, [synth.Deletion(1007000, 900, [1, 0, 2, 0][k % 4])])
+        d, s, a, b = synth.instances_by_interval_rule(pos, dev, lib, first, W)
+        which = rng.integers(0, 2, size=len(d))
+        for r in range(2):                                  # (stable: each read group stays ordered by its first window)
+            sel = which == r
+            parts.append((d[sel], s[sel], a[sel], b[sel]))
+            offsets.append(offsets[-1] + int(sel.sum()))
+    seg = capi.Segment(first, W, np.array(offsets, np.uint64), *[np.concatenate([p[i] for p in parts]) for i in range(4)])
+    out = []
+    for library in (capi.load_hip(), capi.load_library(ORACLE_LIB)):
+        ctx = capi.Context(library, [rg] * (2 * n), list(range(0, 2 * n + 1, 2)))
+        out.append(ctx.collect(ctx.submit(seg)))
+        ctx.close()
+    got, want = out
+    assert want["n_calls"] > 10 and got["n_calls"] == want["n_calls"]
+    for k in INT_KEYS:
+        assert np.array_equal(got[k], want[k]), k
+    assert np.allclose(got["likelihood_ratio"], want["likelihood_ratio"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(got["frequency"], want["frequency"], rtol=0, atol=1e-6)
