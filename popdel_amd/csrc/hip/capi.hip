@@ -1795,6 +1795,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             PD_HIP(hipMemcpyAsync(hdr.data(), c->dCandHdr.p, hdr.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
             PD_HIP(hipStreamSynchronize(c->stream));
             const unsigned nFlagged = hdr[0], nListed = hdr[1];
+            if (getenv("POPDEL_HIP_DEBUG"))
+                fprintf(stderr, "[popdel_hip] %u flagged windows, %u candidate cells\n", nFlagged, nListed);
             if (nFlagged <= capF)
             {
                 if (hdr[2] != 0)
@@ -1922,12 +1924,27 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             c->dDl.ensure(static_cast<size_t>(nb) * S * 3);
             c->dShifts.ensure(static_cast<size_t>(nb) * c->nRg);
             b.ownTiles = (S + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock;
-            const size_t waveTiles = static_cast<size_t>(nb) * b.ownTiles * 4;
+            // dense images: one per distinct window of the batch (the cells are ordered by window)
+            unsigned nImg = 0;
+            for (unsigned i = 0; i < nb; ++i)
+            {
+                pd::CellState & cs = c->hCells[lo + i];
+                if (i == 0 || cs.window != c->hCells[lo + i - 1].window)
+                {
+                    if (nImg)
+                        c->hCells[lo + nImg - 1].imageEnd = i;
+                    c->hCells[lo + nImg++].imageFirst = i;          // (image numbers never run ahead of cell numbers)
+                }
+                cs.image = nImg - 1;
+            }
+            c->hCells[lo + nImg - 1].imageEnd = nb;
+            b.nImages = nImg;
+            const size_t waveTiles = static_cast<size_t>(nImg) * b.ownTiles * 4;
             c->dCellDev.ensure(waveTiles * pd::kDenseCap * 64);
             c->dCellStart.ensure(waveTiles * pd::kDenseCap * 64);
-            c->dCellN.ensure(static_cast<size_t>(nb) * S);
+            c->dCellN.ensure(static_cast<size_t>(nImg) * S);
             c->dWaveRows.ensure(waveTiles);
-            c->dTileMode.ensure(static_cast<size_t>(nb) * b.ownTiles);
+            c->dTileMode.ensure(static_cast<size_t>(nImg) * b.ownTiles);
             b.cellDev = c->dCellDev.p;
             b.cellStart = c->dCellStart.p;
             b.cellN = c->dCellN.p;
@@ -1937,10 +1954,10 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             b.nRg = c->nRg;
             if (b.mt.n != 0)
             {
-                const size_t mWaves = static_cast<size_t>(nb) * b.mt.nWaves;
+                const size_t mWaves = static_cast<size_t>(nImg) * b.mt.nWaves;
                 c->dMDev.ensure(mWaves * pd::kDenseCap * 64);
                 c->dMStart.ensure(mWaves * pd::kDenseCap * 64);
-                c->dMN.ensure(static_cast<size_t>(nb) * c->nRg);
+                c->dMN.ensure(static_cast<size_t>(nImg) * c->nRg);
                 c->dMWaveRows.ensure(mWaves);
                 c->dRgOutD.ensure(static_cast<size_t>(nb) * c->nRg * 8);
                 c->dRgOutU.ensure(static_cast<size_t>(nb) * c->nRg * 12);
@@ -1983,7 +2000,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
                 pd::ZeroRanges zero{};
                 zero.add(area, countersBytes + xchBytes);
                 zero.add(c->dShifts.p, static_cast<size_t>(nb) * c->nRg * sizeof(int));
-                zero.add(c->dTileMode.p, static_cast<size_t>(nb) * b.ownTiles * sizeof(unsigned));
+                zero.add(c->dTileMode.p, static_cast<size_t>(nImg) * b.ownTiles * sizeof(unsigned));
                 zero.add(c->dIterFlags.p, (pd::kMaxIterationsCap + 2) * sizeof(unsigned));     // EM flags and the guard word
                 pd::launchZero(zero, c->stream);
                 PD_HIP(hipMemcpyAsync(c->dCells.p, c->hCells.data() + lo, nb * sizeof(pd::CellState), hipMemcpyHostToDevice, c->stream));

@@ -177,6 +177,9 @@ struct CellState
     int      initLen;
     int      phase;
     int      iterations;
+    unsigned image;               // dense image of the cell's window, index within the batch
+    unsigned imageFirst;          // cells[i].imageFirst / imageEnd: the cells of IMAGE i (rides along with the cells' upload)
+    unsigned imageEnd;
     unsigned len, prevLen;
     double   freq, prevFreq;
     double   gt[3], prevGt[3];
@@ -219,20 +222,23 @@ struct Stage2Buffers
     // the deviations (and start positions) transposed to [row j][lane = sample], so that the EM kernels run ONE LANE PER
     // SAMPLE with coalesced loads and no cross-lane work. Tiles the image cannot hold (a multi-read-group sample, more
     // than kDenseCap active pairs below maxLoad) are flagged in tileMode and go through the generic half-wave kernels.
-    int16_t *   cellDev;     // [nCells][ownTiles*4][kDenseCap][64]; 16 bits: a pair outside that range sends its tile to
+    // The image depends on the window only: it is kept per IMAGE = distinct window of the batch (cells are ordered by
+    // window; CellState::image, imageFirst, imageEnd), and the arrays below that say [nImages] are indexed by it.
+    unsigned         nImages;
+    int16_t *   cellDev;     // [nImages][ownTiles*4][kDenseCap][64]; 16 bits: a pair outside that range sends its tile to
                              // the generic kernels (profiles written with the default size limits stay far inside)
     int16_t *   cellStart;   // same shape; pair starts as offsets from the cell's window position
-    uint16_t *  cellN;       // [nCells][S] active pairs of the sample's read group, or kDenseHighCov
-    uint8_t *   waveRows;    // [nCells][ownTiles*4] max cellN over the wave tile (rows in use)
-    unsigned *  tileMode;    // [nCells][ownTiles] kTileDense / kTileMulti / kTileGeneric (raised with atomicMax)
+    uint16_t *  cellN;       // [nImages][S] active pairs of the sample's read group, or kDenseHighCov
+    uint8_t *   waveRows;    // [nImages][ownTiles*4] max cellN over the wave tile (rows in use)
+    unsigned *  tileMode;    // [nImages][ownTiles] kTileDense / kTileMulti / kTileGeneric (raised with atomicMax)
     // Tiles that contain samples with several read groups ("multi tiles", a static property of the cohort) have a second
     // dense image with ONE LANE PER READ GROUP: rows of 64 read groups instead of 64 samples. Their kernels run the
     // per-pair loops per read group, park the per-read-group results in rgOut and then add them up per sample.
     MultiTiles  mt;
-    int16_t *   mDev;        // [nCells][mt.nWaves][kDenseCap][64]
+    int16_t *   mDev;        // [nImages][mt.nWaves][kDenseCap][64]
     int16_t *   mStart;      // same shape
-    uint16_t *  mN;          // [nCells][nRg] active pairs of the read group, or kDenseHighCov (multi tiles only)
-    uint8_t *   mWaveRows;   // [nCells][mt.nWaves]
+    uint16_t *  mN;          // [nImages][nRg] active pairs of the read group, or kDenseHighCov (multi tiles only)
+    uint8_t *   mWaveRows;   // [nImages][mt.nWaves]
     double *    rgOutD;      // [nCells][nRg][8]  per-read-group sums (log-likelihoods, log10-likelihoods)
     unsigned *  rgOutU;      // [nCells][nRg][12] per-read-group counts (LAD, DAD, first/last, pairs, flags)
     unsigned    nRg;

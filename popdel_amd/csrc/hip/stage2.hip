@@ -656,32 +656,34 @@ __global__ __launch_bounds__(256) void listCellsKernel(const int * __restrict__ 
 
 // =====================================================================================================================
 // Cell set-up: first allele-frequency estimate (integer counts, reference :93-133), low-coverage sample count, and
-// the dense image of the cell's active pairs (see Stage2Buffers::cellDev).
-// A workgroup takes one (cell, 256-sample tile); per 64-sample wave tile the half-waves compact the active pairs of
+// the dense image of the active pairs (see Stage2Buffers::cellDev).
+// The image depends on the window only, and a window usually carries several cells (candidate lengths): it is built once
+// per IMAGE = distinct window of the batch (CellState::imageFirst / imageEnd), and only the counts that depend on the candidate
+// length are taken per cell. A workgroup takes one (image, 64-sample wave tile): the half-waves compact the active pairs of
 // their samples into LDS rows, then the whole workgroup writes the rows out transposed (coalesced).
 // =====================================================================================================================
 constexpr int kGatherThreads = 512;            // 16 half-waves x 4 samples: the per-sample work is a chain of dependent loads,
                                                // so more half-waves in flight per LDS footprint beat longer loops
+constexpr unsigned kGatherCells = 2;           // cells of an image whose counts one walk over the pairs takes (2 is the rule)
 __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView seg, CohortView co, Stage2Buffers b,
                                                                    const uint8_t * __restrict__ flags)
 {
-    __shared__ unsigned acc[3];
+    __shared__ unsigned acc[2 + kMaxCandidatesPerWindow];  // usable pairs, low-coverage samples, hits per cell of the image
     __shared__ SampleMeta shMeta[64];
     __shared__ short shDev[64][kDenseCap + 1];             // deviations: 16 bits in the dense image (else: generic kernels)
     __shared__ short shSt[64][kDenseCap + 1];              // start positions relative to the cell's window (see stBase)
     __shared__ unsigned shN[64];
     __shared__ unsigned shRows, shGeneric;
-    const unsigned cellIdx = blockIdx.y, wt = blockIdx.x;          // one workgroup per (cell, 64-sample wave tile)
-    if (threadIdx.x < 3)
+    const unsigned img = blockIdx.y, wt = blockIdx.x;              // one workgroup per (image, 64-sample wave tile)
+    const unsigned cell0 = b.cells[img].imageFirst, nc = min(b.cells[img].imageEnd - cell0, (unsigned)kMaxCandidatesPerWindow);
+    if (threadIdx.x < 2u + (unsigned)kMaxCandidatesPerWindow)
         acc[threadIdx.x] = 0;
     if (threadIdx.x == 0)
     {
         shGeneric = 0;
         shRows = 0;
     }
-    const CellState & cs = b.cells[cellIdx];
-    const unsigned w = (unsigned)cs.window;
-    const unsigned L = (unsigned)cs.initLen;
+    const unsigned w = (unsigned)b.cells[cell0].window;
     const unsigned stBase = seg.firstPos + w * seg.shift;  // LDS keeps the pair starts as 16-bit offsets from here
     const unsigned hl = threadIdx.x & 31u, half = threadIdx.x >> 5;
     const unsigned long long hm = halfMask();
@@ -696,108 +698,139 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
         shMeta[threadIdx.x] = m;
     }
     __syncthreads();
-    unsigned count = 0, total = 0, low = 0;
+    unsigned total = 0, low = 0;
     constexpr unsigned kHalves = kGatherThreads / 32;
-    for (unsigned k = 0; k < 64u / kHalves; ++k)
+    // the cells of the image, kGatherCells per walk over the pairs (the first walk also fills the image)
+    for (unsigned c0 = 0; c0 < nc; c0 += kGatherCells)
     {
-        const unsigned inWt = half + k * kHalves;
-        const unsigned s = wt * 64u + inWt;
-        if (s >= co.nSamples)                              // uniform per half-wave
+        const bool fill = c0 == 0u;
+        unsigned L[kGatherCells], count[kGatherCells];
+#pragma unroll
+        for (unsigned q = 0; q < kGatherCells; ++q)
         {
-            if (hl == 0)
-                shN[inWt] = 0;
-            continue;
+            L[q] = (unsigned)b.cells[cell0 + min(c0 + q, nc - 1u)].initLen;
+            count[q] = 0;
         }
-        const SampleMeta & meta = shMeta[inWt];
-        const bool multi = (meta.rg1 - meta.rg0) != 1u;        // its pairs go into the per-read-group image instead
-        bool generic = false;
-        bool farStart = false;                                 // a start further than 32 kb from the window: not in 16 bits
-        unsigned nDense = 0;
-        for (unsigned rg = meta.rg0; rg < meta.rg1; ++rg)
+        for (unsigned k = 0; k < 64u / kHalves; ++k)
         {
-            RgConst rc;
-            PairRange r;
-            rgOfSample(meta, seg, co, w, rg, rc, r);
-            const int windowBegin = max((int)L / 2, (int)floor((L - 2 * rc.stddev) + 0.5));
-            const int windowEnd = (int)(L + 2 * rc.stddev);
-            unsigned n = 0, hits = 0;
-            // two 32-chunk groups per round, deviation AND start loaded up front: one memory round trip per ~64 candidates
-            // instead of a chain of four (the kernel is bound by exactly that latency)
-            for (unsigned base = r.begin; base < r.end; base += 64u)
+            const unsigned inWt = half + k * kHalves;
+            const unsigned s = wt * 64u + inWt;
+            if (s >= co.nSamples)                              // uniform per half-wave
             {
-                PairDO p[2];
-                unsigned st[2];
+                if (hl == 0 && fill)
+                    shN[inWt] = 0;
+                continue;
+            }
+            const SampleMeta & meta = shMeta[inWt];
+            const bool multi = (meta.rg1 - meta.rg0) != 1u;        // its pairs go into the per-read-group image instead
+            bool generic = false;
+            bool farStart = false;                                 // a start further than 32 kb from the window: not in 16 bits
+            unsigned nDense = 0;
+            for (unsigned rg = meta.rg0; rg < meta.rg1; ++rg)
+            {
+                RgConst rc;
+                PairRange r;
+                rgOfSample(meta, seg, co, w, rg, rc, r);
+                int windowBegin[kGatherCells], windowEnd[kGatherCells];
+                unsigned hits[kGatherCells];
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
+                for (unsigned q = 0; q < kGatherCells; ++q)
                 {
-                    const unsigned i = base + 32u * g + hl;
-                    p[g].dev = 0;
-                    p[g].off = 0;
-                    st[g] = 0;
-                    if (i < r.end)
-                    {
-                        p[g] = r.p[i];
-                        st[g] = r.st[i];
-                    }
+                    windowBegin[q] = max((int)L[q] / 2, (int)floor((L[q] - 2 * rc.stddev) + 0.5));
+                    windowEnd[q] = (int)(L[q] + 2 * rc.stddev);
+                    hits[q] = 0;
                 }
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
+                unsigned n = 0;
+                // two 32-chunk groups per round, deviation AND start loaded up front: one memory round trip per ~64 candidates
+                // instead of a chain of four (the kernel is bound by exactly that latency)
+                for (unsigned base = r.begin; base < r.end; base += 64u)
                 {
-                    const bool act = p[g].off > w;                 // off == 0 for lanes past the end
-                    const unsigned long long bal = __ballot(act) & hm;
-                    if (act && !multi)
+                    PairDO p[2];
+                    unsigned st[2];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
                     {
-                        const unsigned pos = n + (unsigned)__popcll(bal & below);
-                        if (pos < (unsigned)kDenseCap)
+                        const unsigned i = base + 32u * g + hl;
+                        p[g].dev = 0;
+                        p[g].off = 0;
+                        st[g] = 0;
+                        if (i < r.end)
                         {
-                            const int rel = (int)(st[g] - stBase);
-                            shDev[inWt][pos] = (short)p[g].dev;
-                            shSt[inWt][pos] = (short)rel;
-                            farStart = farStart || rel < -32768 || rel > 32767 || p[g].dev < -32768 || p[g].dev > 32767;
+                            p[g] = r.p[i];
+                            st[g] = r.st[i];
                         }
                     }
-                    n += (unsigned)__popcll(bal);
-                    hits += halfCount(act && p[g].dev > windowBegin && p[g].dev < windowEnd);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+                    {
+                        const bool act = p[g].off > w;                 // off == 0 for lanes past the end
+                        const unsigned long long bal = __ballot(act) & hm;
+                        if (act && !multi && fill)
+                        {
+                            const unsigned pos = n + (unsigned)__popcll(bal & below);
+                            if (pos < (unsigned)kDenseCap)
+                            {
+                                const int rel = (int)(st[g] - stBase);
+                                shDev[inWt][pos] = (short)p[g].dev;
+                                shSt[inWt][pos] = (short)rel;
+                                farStart = farStart || rel < -32768 || rel > 32767 || p[g].dev < -32768 || p[g].dev > 32767;
+                            }
+                        }
+                        n += (unsigned)__popcll(bal);
+#pragma unroll
+                        for (unsigned q = 0; q < kGatherCells; ++q)
+                            hits[q] += halfCount(act && p[g].dev > windowBegin[q] && p[g].dev < windowEnd[q]);
+                    }
                 }
+                if (n >= rc.maxLoad)
+                    nDense = kDenseHighCov;
+                if (n == 0 || n >= rc.maxLoad)
+                    continue;
+                if (fill)
+                    total += n;
+#pragma unroll
+                for (unsigned q = 0; q < kGatherCells; ++q)
+                    count[q] += hits[q];
+                nDense = n;
+                if (n > (unsigned)kDenseCap)
+                    generic = true;
             }
-            if (n >= rc.maxLoad)
-                nDense = kDenseHighCov;
-            if (n == 0 || n >= rc.maxLoad)
+            if (!fill)
                 continue;
-            total += n;
-            count += hits;
-            nDense = n;
-            if (n > (unsigned)kDenseCap)
-                generic = true;
+            low += (flags[(size_t)s * seg.nWindows + w] & 1u) ? 1u : 0u;
+            generic = generic || halfCount(farStart) != 0u;
+            if (hl == 0)
+            {
+                const bool noRows = generic || multi;
+                shN[inWt] = noRows ? 0u : nDense;
+                b.cellN[(size_t)img * co.nSamples + s] = (uint16_t)(noRows ? 0u : nDense);
+                if (generic)
+                    atomicMax(&shGeneric, 2u);
+                else if (multi)
+                    atomicMax(&shGeneric, 1u);
+                else if (nDense != kDenseHighCov)
+                    atomicMax(&shRows, nDense);
+            }
         }
-        low += (flags[(size_t)s * seg.nWindows + w] & 1u) ? 1u : 0u;
-        generic = generic || halfCount(farStart) != 0u;
         if (hl == 0)
         {
-            const bool noRows = generic || multi;
-            shN[inWt] = noRows ? 0u : nDense;
-            b.cellN[(size_t)cellIdx * co.nSamples + s] = (uint16_t)(noRows ? 0u : nDense);
-            if (generic)
-                atomicMax(&shGeneric, 2u);
-            else if (multi)
-                atomicMax(&shGeneric, 1u);
-            else if (nDense != kDenseHighCov)
-                atomicMax(&shRows, nDense);
+#pragma unroll
+            for (unsigned q = 0; q < kGatherCells; ++q)
+                if (c0 + q < nc && count[q])
+                    atomicAdd(&acc[2u + c0 + q], count[q]);
         }
     }
     if (hl == 0)
     {
-        if (count)
-            atomicAdd(&acc[0], count);
         if (total)
-            atomicAdd(&acc[1], total);
+            atomicAdd(&acc[0], total);
         if (low)
-            atomicAdd(&acc[2], low);
+            atomicAdd(&acc[1], low);
     }
     __syncthreads();
     // transposed write-out: row j holds the j-th active pair of each of the 64 samples
     const unsigned rows = shRows;
-    const size_t wtGlobal = (size_t)cellIdx * (b.ownTiles * 4) + wt;
+    const size_t wtGlobal = (size_t)img * (b.ownTiles * 4) + wt;
     int16_t * outD = b.cellDev + wtGlobal * (kDenseCap * 64);
     int16_t * outS = b.cellStart + wtGlobal * (kDenseCap * 64);
     for (unsigned idx = threadIdx.x; idx < rows * 64u; idx += blockDim.x)
@@ -807,18 +840,26 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
         outD[idx] = has ? shDev[lane][j] : (short)0;
         outS[idx] = has ? shSt[lane][j] : (short)0;
     }
-    unsigned * mine = b.counters + ((size_t)b.rank * b.nCells + cellIdx) * 4;
-    if (threadIdx.x < 3 && acc[threadIdx.x])
-        atomicAdd(&mine[threadIdx.x], acc[threadIdx.x]);
+    // every cell of the image: its own hits, the image's usable pairs and low-coverage samples
+    for (unsigned q = threadIdx.x; q < nc; q += blockDim.x)
+    {
+        unsigned * mine = b.counters + ((size_t)b.rank * b.nCells + cell0 + q) * 4;
+        if (acc[2u + q])
+            atomicAdd(&mine[0], acc[2u + q]);
+        if (acc[0])
+            atomicAdd(&mine[1], acc[0]);
+        if (acc[1])
+            atomicAdd(&mine[2], acc[1]);
+        if (shGeneric == 2u)
+            atomicAdd(&mine[3], 1u);                       // tells the host that the generic kernels are needed at all
+    }
     if (threadIdx.x == 0)
     {
         b.waveRows[wtGlobal] = (uint8_t)rows;
         if (shGeneric)
         {
             // the whole 256-sample tile leaves the lane-per-sample kernels: kTileMulti (1) or kTileGeneric (2)
-            atomicMax(&b.tileMode[(size_t)cellIdx * b.ownTiles + wt / 4], shGeneric);
-            if (shGeneric == 2u)
-                atomicAdd(&mine[3], 1u);                   // tells the host that the generic kernels are needed at all
+            atomicMax(&b.tileMode[(size_t)img * b.ownTiles + wt / 4], shGeneric);
         }
     }
 }
@@ -943,9 +984,10 @@ __global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, Co
     __shared__ unsigned shUsed[kSamplesPerBlock];          // bit 31: every pair had ref == del
     __shared__ int shDev[kHalvesPerBlock][kHalfBufCap];
     const unsigned cellIdx = PD_CELL_IDX;
+    [[maybe_unused]] const unsigned imgIdx = b.cells[cellIdx].image;          // dense image of the cell's window
     CellState & cs = b.cells[cellIdx];
     const int wantPhase = mode == 0 ? kCellIterating : kCellConverged;
-    if (cs.phase != wantPhase || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] != kTileGeneric)
+    if (cs.phase != wantPhase || b.tileMode[(size_t)imgIdx * b.ownTiles + PD_TILE_IDX] != kTileGeneric)
         return;
     const unsigned w = (unsigned)cs.window;
     const int len = (int)(mode == 0 ? cs.len : cs.prevLen);
@@ -1102,14 +1144,15 @@ __global__ __launch_bounds__(kSampleTile) void dataLikDenseKernel(CohortView co,
         return;
     __shared__ double red[4];
     const unsigned cellIdx = PD_CELL_IDX;
+    [[maybe_unused]] const unsigned imgIdx = b.cells[cellIdx].image;          // dense image of the cell's window
     const CellState & cs = b.cells[cellIdx];
     const int wantPhase = mode == 0 ? kCellIterating : kCellConverged;
-    if (cs.phase != wantPhase || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] != 0)
+    if (cs.phase != wantPhase || b.tileMode[(size_t)imgIdx * b.ownTiles + PD_TILE_IDX] != 0)
         return;
     const int len = (int)(mode == 0 ? cs.len : cs.prevLen);
     const unsigned s = PD_TILE_IDX * kSamplesPerBlock + threadIdx.x;
     const bool valid = s < co.nSamples;
-    const size_t wtGlobal = (size_t)cellIdx * (b.ownTiles * 4) + PD_TILE_IDX * 4 + (threadIdx.x >> 6);
+    const size_t wtGlobal = (size_t)imgIdx * (b.ownTiles * 4) + PD_TILE_IDX * 4 + (threadIdx.x >> 6);
     const unsigned rows = b.waveRows[wtGlobal];
     const int16_t * col = b.cellDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
     double term = 0;
@@ -1120,7 +1163,7 @@ __global__ __launch_bounds__(kSampleTile) void dataLikDenseKernel(CohortView co,
     {
         rg = co.sampleRg[s];
         l = laneRg(co.rg[rg]);
-        n = b.cellN[(size_t)cellIdx * co.nSamples + s];
+        n = b.cellN[(size_t)imgIdx * co.nSamples + s];
         refShift = (mode == 0) ? b.shifts[(size_t)cellIdx * co.nRg + rg] : 0;
     }
     const bool highCov = n == kDenseHighCov;
@@ -1266,8 +1309,9 @@ __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, 
         return;
     __shared__ double red[kHalvesPerBlock];
     const unsigned cellIdx = PD_CELL_IDX;
+    [[maybe_unused]] const unsigned imgIdx = b.cells[cellIdx].image;          // dense image of the cell's window
     const CellState & cs = b.cells[cellIdx];
-    if (cs.phase != kCellIterating || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] != kTileGeneric)
+    if (cs.phase != kCellIterating || b.tileMode[(size_t)imgIdx * b.ownTiles + PD_TILE_IDX] != kTileGeneric)
         return;
     const unsigned w = (unsigned)cs.window;
     const int len = (int)cs.len;
@@ -1360,8 +1404,9 @@ __global__ __launch_bounds__(kSampleTile) void updateLenDenseKernel(CohortView c
         return;
     __shared__ double red[4];
     const unsigned cellIdx = PD_CELL_IDX;
+    [[maybe_unused]] const unsigned imgIdx = b.cells[cellIdx].image;          // dense image of the cell's window
     const CellState & cs = b.cells[cellIdx];
-    if (cs.phase != kCellIterating || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] != 0)
+    if (cs.phase != kCellIterating || b.tileMode[(size_t)imgIdx * b.ownTiles + PD_TILE_IDX] != 0)
         return;
     const int len = (int)cs.len;
     const double g0 = cs.gt[0], g1 = cs.gt[1], g2 = cs.gt[2];
@@ -1392,7 +1437,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenDenseKernel(CohortView c
     const bool rgNan = shCell[2] != 0.0;
     const unsigned s = PD_TILE_IDX * kSamplesPerBlock + threadIdx.x;
     const bool valid = s < co.nSamples;
-    const size_t wtGlobal = (size_t)cellIdx * (b.ownTiles * 4) + PD_TILE_IDX * 4 + (threadIdx.x >> 6);
+    const size_t wtGlobal = (size_t)imgIdx * (b.ownTiles * 4) + PD_TILE_IDX * 4 + (threadIdx.x >> 6);
     const unsigned rows = b.waveRows[wtGlobal];
     const int16_t * col = b.cellDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
     unsigned rg = 0, n = 0;
@@ -1404,7 +1449,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenDenseKernel(CohortView c
     {
         rg = co.sampleRg[s];
         l = laneRg(co.rg[rg]);
-        n = b.cellN[(size_t)cellIdx * co.nSamples + s];
+        n = b.cellN[(size_t)imgIdx * co.nSamples + s];
         shiftSlot = b.shifts + (size_t)cellIdx * co.nRg + rg;
         refShift = *shiftSlot;
         const double * d = b.dl + ((size_t)cellIdx * co.nSamples + s) * 3;
@@ -1546,6 +1591,7 @@ __global__ __launch_bounds__(kSampleTile) void lrKernel(CohortView co, Stage2Buf
         return;
     __shared__ double red[4];
     const unsigned cellIdx = PD_CELL_IDX;
+    [[maybe_unused]] const unsigned imgIdx = b.cells[cellIdx].image;          // dense image of the cell's window
     const CellState & cs = b.cells[cellIdx];
     if (cs.phase != wantPhase)
         return;
@@ -1645,8 +1691,9 @@ __global__ __launch_bounds__(kSampleTile) void finalKernel(SegmentView seg, Coho
     __shared__ int shDev[kHalvesPerBlock][kHalfBufCap];
     __shared__ unsigned shSt[kHalvesPerBlock][kHalfBufCap];
     const unsigned cellIdx = PD_CELL_IDX;
+    [[maybe_unused]] const unsigned imgIdx = b.cells[cellIdx].image;          // dense image of the cell's window
     CellState & cs = b.cells[cellIdx];
-    if (cs.phase != kCellFinal || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] != kTileGeneric)
+    if (cs.phase != kCellFinal || b.tileMode[(size_t)imgIdx * b.ownTiles + PD_TILE_IDX] != kTileGeneric)
         return;
     const unsigned w = (unsigned)cs.window;
     const int len = (int)cs.len;
@@ -1826,15 +1873,16 @@ __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, S
     if (PD_TILE_IDX >= b.ownTiles)      // grid.x is padded to a multiple of 8 (runStage2Main)
         return;
     const unsigned cellIdx = PD_CELL_IDX;
+    [[maybe_unused]] const unsigned imgIdx = b.cells[cellIdx].image;          // dense image of the cell's window
     CellState & cs = b.cells[cellIdx];
-    if (cs.phase != kCellFinal || b.tileMode[(size_t)cellIdx * b.ownTiles + PD_TILE_IDX] != 0)
+    if (cs.phase != kCellFinal || b.tileMode[(size_t)imgIdx * b.ownTiles + PD_TILE_IDX] != 0)
         return;
     const unsigned w = (unsigned)cs.window;
     const unsigned stBase = firstPos + w * shift;          // the image keeps pair starts as 16-bit offsets from the window
     const int len = (int)cs.len;
     const unsigned s = PD_TILE_IDX * kSamplesPerBlock + threadIdx.x;
     const bool valid = s < co.nSamples;
-    const size_t wtGlobal = (size_t)cellIdx * (b.ownTiles * 4) + PD_TILE_IDX * 4 + (threadIdx.x >> 6);
+    const size_t wtGlobal = (size_t)imgIdx * (b.ownTiles * 4) + PD_TILE_IDX * 4 + (threadIdx.x >> 6);
     const unsigned rows = b.waveRows[wtGlobal];
     const int16_t * col = b.cellDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
     const int16_t * colSt = b.cellStart + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
@@ -1845,7 +1893,7 @@ __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, S
     {
         rg = co.sampleRg[s];
         rc = co.rg[rg];
-        n = b.cellN[(size_t)cellIdx * co.nSamples + s];
+        n = b.cellN[(size_t)imgIdx * co.nSamples + s];
         refShift = cs.restoreZeroShifts ? 0 : b.shifts[(size_t)cellIdx * co.nRg + rg];
     }
     const bool highCov = n == kDenseHighCov;
@@ -2003,9 +2051,10 @@ __global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView 
     __shared__ short shSt[64][kDenseCap + 1];              // start positions relative to the cell's window (see stBase)
     __shared__ unsigned shN[64];
     __shared__ unsigned shRows;
-    const unsigned cellIdx = blockIdx.y, mw = blockIdx.x;
+    const unsigned imgIdx = blockIdx.y, mw = blockIdx.x;           // one workgroup per (image, 64-read-group wave tile)
+    const unsigned cellIdx = b.cells[imgIdx].imageFirst;           // (the image's first cell: window, and where "generic" is counted)
     const unsigned mtI = b.mt.waveTile[mw];
-    if (b.tileMode[(size_t)cellIdx * b.ownTiles + b.mt.tile[mtI]] != kTileMulti)
+    if (b.tileMode[(size_t)imgIdx * b.ownTiles + b.mt.tile[mtI]] != kTileMulti)
         return;
     const unsigned rgBase = b.mt.rgLo[mtI] + (mw - b.mt.waveBase[mtI]) * 64u, rgHi = b.mt.rgHi[mtI];
     const unsigned w = (unsigned)b.cells[cellIdx].window;
@@ -2068,21 +2117,21 @@ __global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView 
         }
         if (halfCount(farStart) != 0u && hl == 0)          // cannot be represented here: the tile goes to the generic kernels
         {
-            atomicMax(&b.tileMode[(size_t)cellIdx * b.ownTiles + b.mt.tile[mtI]], (unsigned)kTileGeneric);
+            atomicMax(&b.tileMode[(size_t)imgIdx * b.ownTiles + b.mt.tile[mtI]], (unsigned)kTileGeneric);
             atomicAdd(&b.counters[((size_t)b.rank * b.nCells + cellIdx) * 4 + 3], 1u);
         }
         const unsigned nDense = (n >= co.rg[rg].maxLoad) ? kDenseHighCov : n;   // n <= kDenseCap otherwise (else: kTileGeneric)
         if (hl == 0)
         {
             shN[inWt] = nDense;
-            b.mN[(size_t)cellIdx * b.nRg + rg] = (uint16_t)nDense;
+            b.mN[(size_t)imgIdx * b.nRg + rg] = (uint16_t)nDense;
             if (nDense != kDenseHighCov)
                 atomicMax(&shRows, nDense);
         }
     }
     __syncthreads();
     const unsigned rows = shRows;
-    const size_t wtGlobal = (size_t)cellIdx * b.mt.nWaves + mw;
+    const size_t wtGlobal = (size_t)imgIdx * b.mt.nWaves + mw;
     int16_t * outD = b.mDev + wtGlobal * (kDenseCap * 64);
     int16_t * outS = b.mStart + wtGlobal * (kDenseCap * 64);
     for (unsigned idx = threadIdx.x; idx < rows * 64u; idx += blockDim.x)
@@ -2106,9 +2155,10 @@ __global__ __launch_bounds__(kSampleTile) void dataLikMultiKernel(CohortView co,
         return;
     __shared__ double red[4];
     const unsigned cellIdx = blockIdx.y, mtI = blockIdx.x, tileIdx = b.mt.tile[mtI];
+    const unsigned imgIdx = b.cells[cellIdx].image;
     const CellState & cs = b.cells[cellIdx];
     const int wantPhase = mode == 0 ? kCellIterating : kCellConverged;
-    if (cs.phase != wantPhase || b.tileMode[(size_t)cellIdx * b.ownTiles + tileIdx] != kTileMulti)
+    if (cs.phase != wantPhase || b.tileMode[(size_t)imgIdx * b.ownTiles + tileIdx] != kTileMulti)
         return;
     const int len = (int)(mode == 0 ? cs.len : cs.prevLen);
     const unsigned rgLo = b.mt.rgLo[mtI], rgHi = b.mt.rgHi[mtI];
@@ -2117,7 +2167,7 @@ __global__ __launch_bounds__(kSampleTile) void dataLikMultiKernel(CohortView co,
     {
         const unsigned rg = base + threadIdx.x;
         const bool valid = rg < rgHi;
-        const size_t wtGlobal = (size_t)cellIdx * b.mt.nWaves + b.mt.waveBase[mtI] + ((base - rgLo) >> 6) + (threadIdx.x >> 6);
+        const size_t wtGlobal = (size_t)imgIdx * b.mt.nWaves + b.mt.waveBase[mtI] + ((base - rgLo) >> 6) + (threadIdx.x >> 6);
         const unsigned rows = (base - rgLo) + (threadIdx.x & ~63u) < rgHi - rgLo ? b.mWaveRows[wtGlobal] : 0u;
         const int16_t * col = b.mDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
         unsigned n = 0;
@@ -2126,7 +2176,7 @@ __global__ __launch_bounds__(kSampleTile) void dataLikMultiKernel(CohortView co,
         if (valid)
         {
             l = laneRg(co.rg[rg]);
-            n = b.mN[(size_t)cellIdx * b.nRg + rg];
+            n = b.mN[(size_t)imgIdx * b.nRg + rg];
             refShift = (mode == 0) ? b.shifts[(size_t)cellIdx * co.nRg + rg] : 0;
         }
         const bool highCov = n == kDenseHighCov;
@@ -2231,8 +2281,9 @@ __global__ __launch_bounds__(kSampleTile) void updateLenMultiKernel(CohortView c
         return;
     __shared__ double red[4];
     const unsigned cellIdx = blockIdx.y, mtI = blockIdx.x, tileIdx = b.mt.tile[mtI];
+    const unsigned imgIdx = b.cells[cellIdx].image;
     const CellState & cs = b.cells[cellIdx];
-    if (cs.phase != kCellIterating || b.tileMode[(size_t)cellIdx * b.ownTiles + tileIdx] != kTileMulti)
+    if (cs.phase != kCellIterating || b.tileMode[(size_t)imgIdx * b.ownTiles + tileIdx] != kTileMulti)
         return;
     const int len = (int)cs.len;
     const double g0 = cs.gt[0], g1 = cs.gt[1], g2 = cs.gt[2];
@@ -2267,7 +2318,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenMultiKernel(CohortView c
     {
         const unsigned rg = base + threadIdx.x;
         const bool valid = rg < rgHi;
-        const size_t wtGlobal = (size_t)cellIdx * b.mt.nWaves + b.mt.waveBase[mtI] + ((base - rgLo) >> 6) + (threadIdx.x >> 6);
+        const size_t wtGlobal = (size_t)imgIdx * b.mt.nWaves + b.mt.waveBase[mtI] + ((base - rgLo) >> 6) + (threadIdx.x >> 6);
         const unsigned rows = (base - rgLo) + (threadIdx.x & ~63u) < rgHi - rgLo ? b.mWaveRows[wtGlobal] : 0u;
         const int16_t * col = b.mDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
         unsigned n = 0;
@@ -2278,7 +2329,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenMultiKernel(CohortView c
         if (valid)
         {
             l = laneRg(co.rg[rg]);
-            n = b.mN[(size_t)cellIdx * b.nRg + rg];
+            n = b.mN[(size_t)imgIdx * b.nRg + rg];
             shiftSlot = b.shifts + (size_t)cellIdx * co.nRg + rg;
             refShift = *shiftSlot;
             const double * d = b.dl + ((size_t)cellIdx * co.nSamples + b.mt.rgSample[rg]) * 3;
@@ -2333,8 +2384,9 @@ __global__ __launch_bounds__(kSampleTile) void finalMultiKernel(CohortView co, S
         return;
     __shared__ unsigned shBorder[kSamplesPerBlock];        // per sample: its last read group below maxLoad, or ~0
     const unsigned cellIdx = blockIdx.y, mtI = blockIdx.x, tileIdx = b.mt.tile[mtI];
+    const unsigned imgIdx = b.cells[cellIdx].image;
     CellState & cs = b.cells[cellIdx];
-    if (cs.phase != kCellFinal || b.tileMode[(size_t)cellIdx * b.ownTiles + tileIdx] != kTileMulti)
+    if (cs.phase != kCellFinal || b.tileMode[(size_t)imgIdx * b.ownTiles + tileIdx] != kTileMulti)
         return;
     const unsigned w = (unsigned)cs.window;
     const unsigned stBase = firstPos + w * shift;
@@ -2345,7 +2397,7 @@ __global__ __launch_bounds__(kSampleTile) void finalMultiKernel(CohortView co, S
         unsigned border = 0xffffffffu;
         if (s < co.nSamples)
             for (unsigned rg = co.sampleRg[s]; rg < co.sampleRg[s + 1]; ++rg)
-                if (b.mN[(size_t)cellIdx * b.nRg + rg] != kDenseHighCov)
+                if (b.mN[(size_t)imgIdx * b.nRg + rg] != kDenseHighCov)
                     border = rg;
         shBorder[threadIdx.x] = border;
     }
@@ -2356,7 +2408,7 @@ __global__ __launch_bounds__(kSampleTile) void finalMultiKernel(CohortView co, S
     {
         const unsigned rg = base + threadIdx.x;
         const bool valid = rg < rgHi;
-        const size_t wtGlobal = (size_t)cellIdx * b.mt.nWaves + b.mt.waveBase[mtI] + ((base - rgLo) >> 6) + (threadIdx.x >> 6);
+        const size_t wtGlobal = (size_t)imgIdx * b.mt.nWaves + b.mt.waveBase[mtI] + ((base - rgLo) >> 6) + (threadIdx.x >> 6);
         const unsigned rows = (base - rgLo) + (threadIdx.x & ~63u) < rgHi - rgLo ? b.mWaveRows[wtGlobal] : 0u;
         const int16_t * col = b.mDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
         const int16_t * colSt = b.mStart + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
@@ -2367,7 +2419,7 @@ __global__ __launch_bounds__(kSampleTile) void finalMultiKernel(CohortView co, S
         if (valid)
         {
             rc = co.rg[rg];
-            n = b.mN[(size_t)cellIdx * b.nRg + rg];
+            n = b.mN[(size_t)imgIdx * b.nRg + rg];
             refShift = cs.restoreZeroShifts ? 0 : b.shifts[(size_t)cellIdx * co.nRg + rg];
             const unsigned border = shBorder[b.mt.rgSample[rg] - tileIdx * kSamplesPerBlock];
             if (border != 0xffffffffu)
@@ -2896,9 +2948,9 @@ void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers
     if (b.nCells == 0)
         return;
     const dim3 perCell((b.nCells + 127) / 128), cellBlock(128);
-    hipLaunchKernelGGL(cellGatherKernel, dim3(b.ownTiles * 4, b.nCells), dim3(kGatherThreads), 0, st, seg, co, b, flags);
+    hipLaunchKernelGGL(cellGatherKernel, dim3(b.ownTiles * 4, b.nImages), dim3(kGatherThreads), 0, st, seg, co, b, flags);
     if (b.mt.n != 0)
-        hipLaunchKernelGGL(multiGatherKernel, dim3(b.mt.nWaves, b.nCells), dim3(kGatherThreads), 0, st, seg, co, b);
+        hipLaunchKernelGGL(multiGatherKernel, dim3(b.mt.nWaves, b.nImages), dim3(kGatherThreads), 0, st, seg, co, b);
     x.allGather(b.counters, (size_t)b.nCells * 4 * sizeof(unsigned));
     hipLaunchKernelGGL(cellInitFinishKernel, perCell, cellBlock, 0, st, b);
     hipLaunchKernelGGL(suppScanKernel, dim3(1), dim3(256), 0, st, b);
