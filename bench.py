@@ -467,7 +467,7 @@ def main():
                             exchange=dict(all_gathers_per_pass=tot[4]["n_all_gathers"], all_gather_bytes_per_pass=tot[4]["all_gather_bytes"],
                                           backend="rccl (library-native, ncclAllGather on the context's stream)" if native else dist.get_backend(),
                                           note=exchange_note,
-                                          what="window flags, Q3 of flagged windows, candidate lists, a5 counts, per-iteration tile sums + read "
+                                          what="window flags, Q3 of flagged windows, a5 counts, per-iteration tile sums + read "
                                                "group 0's record, LR sums, support-percentile digit histograms"),
                             parallelism="ONE cohort of %d samples sharded by samples over %d ranks (%d each); every rank scans "
                                         "its own samples, stage 2 all-gathers per-tile sums (bit-identical to one context)"

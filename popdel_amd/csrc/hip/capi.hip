@@ -1784,8 +1784,6 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             in.world = 1;
             in.nFlagged = capF;
             in.nFlaggedDev = c->dCandHdr.p;
-            in.fwFirst = 0;
-            in.fwStride = 1;
             in.minInit = c->dMinInitGlobal.p;
             pd::launchCompactFlagged(o.winFlag.p, W, capF, c->dFlagged.p, c->dCandHdr.p, c->stream);
             pd::launchPackFlagged(o.q3.p, o.flags.p, c->dFlagged.p, W, S, in, 0, c->stream);
@@ -1847,43 +1845,33 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
                 std::memcpy(c->hFlagged.data(), flagged.data(), flagged.size() * sizeof(int));
                 c->dFlagged.uploadPinned(c->hFlagged, c->stream);
                 c->dClusterScratch.ensure(static_cast<size_t>(flagged.size()) * rowLen);
-                // Every context packs its samples' Q3 of the flagged windows and gets everybody's; the clustering of a
-                // window walks ALL samples of the cohort, so the windows are dealt out (window f to context f mod world)
-                // and the candidate lists -- a few integers per window -- are exchanged once more.
-                const size_t nF = flagged.size(), perCtx = (nF + world - 1) / world;
-                const size_t candChunk = alignUp(perCtx * (1 + pd::kMaxCandidatesPerWindow) * sizeof(int), 256);
+                c->dCandLen.ensure(flagged.size() * pd::kMaxCandidatesPerWindow);
+                c->dCandCount.ensure(flagged.size());
                 pd::ClusterInput in;
-                in.chunkBytes = alignUp(nF * static_cast<size_t>(sper) * 5, 256);
-                uint8_t * area = reserveArena(*c, in.chunkBytes * world + candChunk * world);
-                in.base = area;
-                uint8_t * candArea = area + in.chunkBytes * world;
+                in.chunkBytes = alignUp(flagged.size() * static_cast<size_t>(sper) * 5, 256);
+                in.base = reserveArena(*c, in.chunkBytes * world);
                 in.sper = sper;
                 in.world = world;
-                in.nFlagged = (unsigned)nF;
+                in.nFlagged = (unsigned)flagged.size();
                 in.nFlaggedDev = nullptr;
-                in.fwFirst = c->rank;
-                in.fwStride = world;
                 in.minInit = c->dMinInitGlobal.p;
                 pd::launchPackFlagged(o.q3.p, o.flags.p, c->dFlagged.p, W, S, in, c->rank, c->stream);
                 PD_HIP(hipGetLastError());
-                xch.allGather(area, in.chunkBytes);
-                int * myCount = reinterpret_cast<int *>(candArea + candChunk * c->rank);
-                pd::launchCluster(in, c->uniformThreshold, c->dClusterScratch.p, rowLen, myCount + perCtx, myCount, c->stream);
+                xch.allGather(c->arena, in.chunkBytes);
+                pd::launchCluster(in, c->uniformThreshold, c->dClusterScratch.p, rowLen, c->dCandLen.p, c->dCandCount.p, c->stream);
                 PD_HIP(hipGetLastError());
-                xch.allGather(candArea, candChunk);
-                PinnedBuf<int> & cand = c->hCandLen;
-                cand.resize(candChunk * world / sizeof(int));
-                PD_HIP(hipMemcpyAsync(cand.data(), candArea, candChunk * world, hipMemcpyDeviceToHost, c->stream));
+                PinnedBuf<int> &candLen = c->hCandLen, &candCount = c->hCandCount;
+                candLen.resize(flagged.size() * pd::kMaxCandidatesPerWindow);
+                candCount.resize(flagged.size());
+                PD_HIP(hipMemcpyAsync(candLen.data(), c->dCandLen.p, candLen.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                PD_HIP(hipMemcpyAsync(candCount.data(), c->dCandCount.p, candCount.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
                 PD_HIP(hipStreamSynchronize(c->stream));
-                for (size_t f = 0; f < nF; ++f)
+                for (size_t f = 0; f < flagged.size(); ++f)
                 {
-                    const int * chunk = cand.data() + (f % world) * (candChunk / sizeof(int));
-                    const size_t slot = f / world;
-                    const int count = chunk[slot];
-                    if (count > pd::kMaxCandidatesPerWindow)
+                    if (candCount[f] > pd::kMaxCandidatesPerWindow)
                         throw HipError{"more than 32 candidate deletion lengths in one window"};
-                    for (int k = 0; k < count; ++k)
-                        addCell(flagged[f], chunk[perCtx + slot * pd::kMaxCandidatesPerWindow + k]);
+                    for (int k = 0; k < candCount[f]; ++k)
+                        addCell(flagged[f], candLen[f * pd::kMaxCandidatesPerWindow + k]);
                 }
             }
         }

@@ -109,9 +109,6 @@ struct ClusterInput
     unsigned         world;
     unsigned         nFlagged;     // flagged windows; with nFlaggedDev set: the capacity the layout is made for
     const unsigned * nFlaggedDev;  // null, or where the device finds their number (the host has not seen it yet)
-    unsigned         fwFirst;      // the flagged windows this context clusters: fwFirst, fwFirst + fwStride, ... (a sharded
-    unsigned         fwStride;     // cohort deals them out: the walk over ALL samples' Q3 is what grows with the cohort);
-                                   // window fwFirst + i * fwStride writes candidate list i
     const unsigned * minInit;      // [read groups of the cohort] minInitDelLen, looked up BY SORTED RANK (quirk Q1)
 };
 

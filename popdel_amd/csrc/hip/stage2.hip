@@ -417,7 +417,7 @@ struct ClusterShared
 // One flagged window by one workgroup; every return is workgroup-uniform.
 __device__ __forceinline__ void clusterWindow(const ClusterInput & in, int uniformThreshold, int * __restrict__ scratch,
                                               unsigned rowLen, int * __restrict__ candLen, int * __restrict__ candCount,
-                                              unsigned fw, unsigned slot, ClusterShared & sh)
+                                              unsigned fw, ClusterShared & sh)
 {
     int (&hist)[kClusterBins] = sh.hist;
     unsigned (&occ)[kClusterBins / 32] = sh.occ;
@@ -450,7 +450,7 @@ __device__ __forceinline__ void clusterWindow(const ClusterInput & in, int unifo
     if (m == 0)
     {
         if (threadIdx.x == 0)
-            candCount[slot] = 0;
+            candCount[fw] = 0;
         return;
     }
     const long long range = (long long)vMax - (long long)vMin + 1;
@@ -487,7 +487,7 @@ __device__ __forceinline__ void clusterWindow(const ClusterInput & in, int unifo
                     const int v = base + bin;
                     if (n != 0 && !(prev + 50 > v))
                     {
-                        emitCluster(sum, n, thresholdOfRanks(in, uniformThreshold, i0, rank - 1), candLen, slot, nc);
+                        emitCluster(sum, n, thresholdOfRanks(in, uniformThreshold, i0, rank - 1), candLen, fw, nc);
                         sum = 0;
                         n = 0;
                         i0 = rank;
@@ -498,8 +498,8 @@ __device__ __forceinline__ void clusterWindow(const ClusterInput & in, int unifo
                     prev = v;
                 }
             }
-            emitCluster(sum, n, thresholdOfRanks(in, uniformThreshold, i0, rank - 1), candLen, slot, nc);
-            candCount[slot] = nc;
+            emitCluster(sum, n, thresholdOfRanks(in, uniformThreshold, i0, rank - 1), candLen, fw, nc);
+            candCount[fw] = nc;
         }
         return;
     }
@@ -552,14 +552,14 @@ __device__ __forceinline__ void clusterWindow(const ClusterInput & in, int unifo
             }
             else
             {
-                emitCluster(sum, n, thresholdOfRanks(in, uniformThreshold, i0, i - 1), candLen, slot, nc);
+                emitCluster(sum, n, thresholdOfRanks(in, uniformThreshold, i0, i - 1), candLen, fw, nc);
                 sum = row[i];
                 n = 1;
                 i0 = i;
             }
         }
-        emitCluster(sum, n, thresholdOfRanks(in, uniformThreshold, i0, m - 1), candLen, slot, nc);
-        candCount[slot] = nc;
+        emitCluster(sum, n, thresholdOfRanks(in, uniformThreshold, i0, m - 1), candLen, fw, nc);
+        candCount[fw] = nc;
     }
 }
 
@@ -569,9 +569,9 @@ __global__ __launch_bounds__(1024) void clusterKernel(ClusterInput in, int unifo
 {
     __shared__ ClusterShared sh;
     const unsigned n = in.nFlaggedDev ? min(*in.nFlaggedDev, in.nFlagged) : in.nFlagged;
-    for (unsigned i = blockIdx.x; in.fwFirst + i * in.fwStride < n; i += gridDim.x)
+    for (unsigned fw = blockIdx.x; fw < n; fw += gridDim.x)
     {
-        clusterWindow(in, uniformThreshold, scratch, rowLen, candLen, candCount, in.fwFirst + i * in.fwStride, i, sh);
+        clusterWindow(in, uniformThreshold, scratch, rowLen, candLen, candCount, fw, sh);
         __syncthreads();
     }
 }
@@ -2935,10 +2935,7 @@ void launchCopyBytes(const void * src, void * dst, size_t n, hipStream_t st)
 void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,
                    hipStream_t st)
 {
-    const unsigned own = (in.nFlagged + in.fwStride - 1u - in.fwFirst) / in.fwStride;      // (capacity, if the number is on the device)
-    if (own == 0)
-        return;
-    const unsigned groups = in.nFlaggedDev ? (own < 256u ? own : 256u) : own;
+    const unsigned groups = in.nFlaggedDev ? (in.nFlagged < 256u ? in.nFlagged : 256u) : in.nFlagged;
     hipLaunchKernelGGL(clusterKernel, dim3(groups), dim3(1024), 0, st, in, uniformThreshold, scratch, rowLen, candLen,
                        candCount);
 }
