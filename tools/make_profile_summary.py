@@ -8,7 +8,7 @@ import bench
 tag, name, passes = sys.argv[1], sys.argv[2], float(sys.argv[3])
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+stats = max(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)   # (the newest run's)
 shutil.copy(stats, os.path.join(dst, name + "_kernel_stats.csv"))
 table = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kstats.py"), stats, str(passes)], capture_output=True, text=True).stdout
 line = json.loads([l for l in open(os.path.join(src, "trace_bench.json")) if l.startswith("{")][0])
