@@ -75,6 +75,20 @@ def parse_args(argv=None):
     ap.add_argument("--small-cohort", type=int, default=1000,
                     help="samples of the configs[1] leg (1,000 profiles x chr20 windows); 0: skip")
     ap.add_argument("--no-legs", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--configs3-samples", type=int, default=10000,
+                    help="N > 1: TOTAL samples of the configs[3]-shaped leg (ONE cohort sharded by samples, pd_shard_samples(total, N) "
+                         "per rank, resident segment); 0: skip")
+    ap.add_argument("--configs4-samples", type=int, default=50000,
+                    help="N > 1: TOTAL samples of the configs[4]-shaped leg (the same, every segment streamed from host memory, "
+                         "double buffered); 0: skip")
+    ap.add_argument("--configs-passes", type=int, default=0,
+                    help="passes of the configs3 leg (default: chr20 = 323) -- the configs4 leg streams --configs4-segments")
+    ap.add_argument("--configs4-segments", type=int, default=6)
+    ap.add_argument("--e2e-samples", type=int, default=1000,
+                    help="N = 1: profiles of the end-to-end leg (`popdel call` on generated profile files, 1 Mb region); 0: skip")
+    ap.add_argument("--sharded-world1", default="1280,6400,0",
+                    help="N = 1: samples of the legs that run the sample-sharded code path with ONE rank (library RCCL): its own "
+                         "cost per pass next to the unsharded context; 0 = the headline cohort; empty: skip")
     return ap.parse_args(argv)
 
 
@@ -182,6 +196,11 @@ def cpu_model():
     return "unknown"
 
 
+def new_acc():
+    """[stage-1 ms, stage-2 ms, calls, candidate cells, last pd_timing, exchange ms] summed over passes"""
+    return [0.0, 0.0, 0, 0, None, 0.0]
+
+
 class Lane:
     """One context with one resident segment; runs passes the way a streaming host drives the library: the next
     segment's ticket is issued before the open one is collected."""
@@ -202,21 +221,24 @@ class Lane:
             acc[2] += res["n_calls"]
             acc[3] += t["n_candidate_cells"]
             acc[4] = t
+            if len(acc) > 5:
+                acc[5] += t.get("exchange_ms", 0.0)
 
 
 def run_lanes(lanes, n_passes):
     if len(lanes) == 1:
-        acc = [0.0, 0.0, 0, 0, None]
+        acc = new_acc()
         lanes[0].passes(n_passes, acc)
         return tuple(acc)
     share = [len(range(k, n_passes, len(lanes))) for k in range(len(lanes))]
-    accs = [[0.0, 0.0, 0, 0, None] for _ in lanes]
+    accs = [new_acc() for _ in lanes]
     threads = [threading.Thread(target=l.passes, args=(n, a)) for l, n, a in zip(lanes, share, accs)]
     for th in threads:
         th.start()
     for th in threads:
         th.join()
-    return (sum(a[0] for a in accs), sum(a[1] for a in accs), sum(a[2] for a in accs), sum(a[3] for a in accs), accs[0][4])
+    return (sum(a[0] for a in accs), sum(a[1] for a in accs), sum(a[2] for a in accs), sum(a[3] for a in accs), accs[0][4],
+            sum(a[5] for a in accs))
 
 
 def main():
@@ -297,14 +319,15 @@ def main():
             step_fn()
         sync()
         t0 = time.perf_counter()
-        tot = [0.0, 0.0, 0, 0, None]
+        tot = new_acc()
         for _ in range(steps):
-            a, b, c, d, tinfo = step_fn()
+            a, b, c, d, tinfo, x = step_fn()
             tot[0] += a
             tot[1] += b
             tot[2] += c
             tot[3] += d
             tot[4] = tinfo
+            tot[5] += x
         sync()
         return max_over_ranks(time.perf_counter() - t0), tot
 
@@ -322,7 +345,7 @@ def main():
                      samples_per_gpu=S, all_gathers_per_pass=0,
                      parallelism="%d rank(s), each a chr20-sized set of segments of its own %d-sample cohort "
                                  "(no collective in the data path)" % (world, S))
-    s1_ms, s2_ms, n_calls, n_cand, tinfo = tot
+    s1_ms, s2_ms, n_calls, n_cand, tinfo, _ = tot
     headline = dict(value=seg_value, elapsed=elapsed, steps=steps_done, s1_ms=s1_ms, s2_ms=s2_ms, n_calls=n_calls, n_cand=n_cand,
                     tinfo=tinfo, launches=my_passes * steps_done, exchange=dict(all_gathers_per_pass=0, all_gather_bytes_per_pass=0),
                     parallelism=seg_split["parallelism"], cohort=S, fallback=None)
@@ -428,7 +451,7 @@ def main():
                                              device=local_rank, native=use_native)
                 h = sh.ctx.stage(seg)
                 ln = Lane(sh.ctx, h, args.serial)
-                ln.passes(2, [0.0, 0.0, 0, 0, None])                # first exchanges (communicator set-up) outside the warm-up
+                ln.passes(2, new_acc())                # first exchanges (communicator set-up) outside the warm-up
                 return sh, h, ln
 
             # With --exchange auto a failure of the library's own RCCL exchange (set-up or first passes) on ANY rank sends
@@ -453,7 +476,7 @@ def main():
             shard, h_sh, lane = opened
 
             def step():
-                acc = [0.0, 0.0, 0, 0, None]
+                acc = new_acc()
                 lane.passes(total_passes, acc)
                 return tuple(acc)
 
@@ -465,6 +488,7 @@ def main():
                             s2_ms=tot[1], n_calls=tot[2], n_cand=tot[3], tinfo=tot[4], launches=passes_timed, cohort=S * world,
                             windows_per_step=total_passes * W,
                             exchange=dict(all_gathers_per_pass=tot[4]["n_all_gathers"], all_gather_bytes_per_pass=tot[4]["all_gather_bytes"],
+                                          exchange_ms_per_pass=tot[5] / passes_timed,
                                           backend="rccl (library-native, ncclAllGather on the context's stream)" if native else dist.get_backend(),
                                           note=exchange_note,
                                           what="window flags, Q3 of flagged windows, a5 counts, per-iteration tile sums + read "
@@ -474,6 +498,82 @@ def main():
                                         % (S * world, world, S))
             shard.ctx.unstage(h_sh)
             shard.close()
+
+            # ---- the shapes BASELINE names for several GPUs: a cohort of FIXED total size sharded by samples -------------
+            def fixed_cohort(total, seed):
+                """this rank's part (pd_shard_samples(total, world) samples, the last ranks fewer) of a `total`-sample cohort"""
+                per = hip.pd_shard_samples(total, world)
+                own = max(0, min(per, total - rank * per))
+                if per * (world - 1) >= total:
+                    raise RuntimeError("%d samples cannot be split over %d contexts in whole 256-sample tiles" % (total, world))
+                f3, W3, o3, a3, _ = device_tile(own, seed + rank, device, args.coverage, deletion_seed=seed)
+                sh3 = distributed.SampleShard(hip, [rg] * total, list(range(total + 1)), rank, world, device=local_rank, native=native)
+                return sh3, capi.Segment(f3, W3, o3, a3["dev"], a3["start"], a3["on"], a3["off"]), own, per
+
+            def configs3_leg():
+                total = args.configs3_samples
+                sh3, seg3, own, per = fixed_cohort(total, 31000)
+                n_pass = args.configs_passes or total_passes
+                ln = Lane(sh3.ctx, sh3.ctx.stage(seg3), args.serial)
+                ln.passes(3, new_acc())
+                sync()
+                q0 = time.perf_counter()
+                acc = new_acc()
+                ln.passes(n_pass, acc)
+                sync()
+                dt = max_over_ranks(time.perf_counter() - q0)
+                sh3.ctx.unstage(ln.handle)
+                sh3.close()
+                return dict(workload="%d synthetic profiles x chr20 windows sharded by samples over %d GPUs (configs[3] per "
+                                     "chromosome; resident segment re-scanned)" % (total, world),
+                            value=total * seg3.n_windows * n_pass / dt, unit="window*sample/s", samples=total,
+                            samples_per_rank=per, samples_last_rank=total - per * (world - 1), passes=n_pass,
+                            ms_per_pass=dt / n_pass * 1e3, stage1_ms_per_pass=acc[0] / n_pass, stage2_ms_per_pass=acc[1] / n_pass,
+                            exchange_ms_per_pass=acc[5] / n_pass, all_gathers_per_pass=acc[4]["n_all_gathers"],
+                            all_gather_bytes_per_pass=acc[4]["all_gather_bytes"], calls_per_pass=acc[2] / n_pass, scaling="strong")
+
+            def configs4_leg():
+                total = args.configs4_samples
+                sh4, seg4, own, per = fixed_cohort(total, 41000)
+                c4 = sh4.ctx
+                n_seg = max(2, args.configs4_segments)
+                # every segment comes from host memory: staged over the copy stream while the previous one computes
+                h_cur = c4.stage(seg4)
+                c4.collect(c4.run(h_cur), copy=False)               # first staging (page locking) and exchanges outside the clock
+                sync()
+                q0 = time.perf_counter()
+                t_cur = c4.run(h_cur)
+                xms = gathers = 0
+                for i in range(n_seg):
+                    last = i + 1 == n_seg
+                    if not last:
+                        h_nxt = c4.stage(seg4)
+                        t_nxt = c4.run(h_nxt)
+                    c4.collect(t_cur, copy=False)
+                    t4 = c4.timing()
+                    xms += t4["exchange_ms"]
+                    gathers = t4["n_all_gathers"]
+                    c4.unstage(h_cur)
+                    if not last:
+                        h_cur, t_cur = h_nxt, t_nxt
+                sync()
+                dt = max_over_ranks(time.perf_counter() - q0)
+                sh4.close()
+                return dict(workload="%d synthetic profiles sharded by samples over %d GPUs, every segment streamed host -> HBM "
+                                     "double buffered (configs[4] shape)" % (total, world),
+                            value=total * seg4.n_windows * n_seg / dt, unit="window*sample/s", samples=total, samples_per_rank=per,
+                            segments=n_seg, seconds_per_segment=dt / n_seg, exchange_ms_per_pass=xms / n_seg,
+                            all_gathers_per_pass=gathers, host_bytes_per_segment_per_rank=int(16 * len(seg4.dev)), scaling="strong")
+
+            # (collective legs: every rank runs them; a failure on one rank fails them on all through the watchdog)
+            for name, fn, on in (("configs3", configs3_leg, args.configs3_samples > 0), ("configs4", configs4_leg, args.configs4_samples > 0)):
+                if not on or args.no_legs:
+                    continue
+                try:
+                    legs[name] = fn()
+                except Exception as e:
+                    legs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    break               # the ranks are no longer in step: no further collective legs
         except Exception as e:
             headline["fallback"] = "value is the SEGMENT split: the sample-sharded headline failed: %s: %s" % (type(e).__name__, e)
         dog.cancel()

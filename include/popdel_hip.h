@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 9
+#define PD_ABI_VERSION 10
 
 /* One read group after start-up conditioning.
  * Replaces: `Histogram` (reference insert_histogram_popdel.h:19-43) after processHistogram()
@@ -172,6 +172,8 @@ typedef struct pd_timing
     uint64_t all_gather_bytes;   /* bytes gathered per context by them                        */
     uint64_t n_repeated_batches; /* stage-2 batches of this context (cumulative) that were launched before the host had
                                     seen their support-pool sizes and had to be run again the exact way */
+    double   exchange_ms;        /* time the ticket's exchanges took: HIP events around each on the context's stream (the
+                                    in-process group: host clock around its barriers and peer copies); part of stage2_ms */
 } pd_timing;
 int pd_last_timing(pd_ctx *ctx, pd_timing *out);
 

@@ -31,14 +31,14 @@ void launchStage1Fallback(const SegmentView & seg, const CohortView & co, int32_
 void launchPackFlagged(const int32_t * q3, const uint8_t * flags, const int * flaggedWindows, unsigned W, unsigned nLocal,
                        const ClusterInput & in, unsigned rank, hipStream_t st);
 void launchZero(const ZeroRanges & r, hipStream_t st);
-void launchCompactFlagged(const int * winFlag, unsigned W, unsigned cap, int * flagged, unsigned * hdr, hipStream_t st);
+void launchCompactFlagged(const int * winFlag, unsigned W, unsigned world, size_t rowStride, unsigned cap, int * flagged,
+                          unsigned * hdr, hipStream_t st);
 void launchListCells(const int * flagged, const int * candLen, const int * candCount, unsigned cap, unsigned listCap,
                      unsigned * hdr, hipStream_t st);
 void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,
                    hipStream_t st);
 void launchCopyBytes(const void * src, void * dst, size_t n, hipStream_t st);
-void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
-                   hipStream_t st);
+void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st);
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
                    bool anyGenericTile, unsigned * pinnedWord, hipStream_t st);
 void buildLogTables(const double * hist, double4 * tab, double2 * tab2, size_t n, RgConst * rg, unsigned nRg, hipStream_t st);
@@ -80,7 +80,8 @@ RcclApi & rccl()
         }
         if (!api.handle)
         {
-            api.error = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "librccl.so.1 not found");
+            const char * why = dlerror();                  // (a second call would return NULL: the first one clears it)
+            api.error = std::string("cannot load RCCL: ") + (why ? why : "librccl.so.1 not found");
             return;
         }
         api.getUniqueId = reinterpret_cast<decltype(api.getUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
@@ -285,6 +286,8 @@ struct pd_ctx
     int uniformThreshold = -1;      // minInitDelLen if it is the same for all read groups of the cohort, else -1
     // The cohort may be sharded by samples over several contexts (pd_ctx_set_shard); defaults describe "all samples here".
     uint32_t rank = 0, world = 1, nSamplesGlobal = 0, samplesPerRank = 0;
+    bool sharded = false;           // pd_ctx_set_shard*() was called (world may be 1): the exchanged code path runs
+    uint32_t flagCapGuess = 64;     // sharded: flagged windows the next segment's clustering input is laid out for
     pd_shard shard;
     ncclComm_t comm = nullptr;      // exchange by the library itself (pd_ctx_set_shard_rccl) instead of the host's callbacks
     pd_local_group * group = nullptr;   // ... or among the contexts of this process (pd_ctx_set_shard_local)
@@ -326,7 +329,7 @@ struct pd_ctx
     DevBuf<uint32_t> dScanSample, dEntChunks, dEntMax;
     DevBuf<unsigned long long> dLifeHist;
     DevBuf<unsigned> dProblems;
-    PinnedBuf<unsigned long long> hLifeHist;
+    PinnedBuf<unsigned long long> hLifeHist, hLifeXch;
     PinnedBuf<uint64_t> hTotals;
     PinnedBuf<uint32_t> hEntMax;
     uint64_t nextHandle = 1, nextTicket = 1;
@@ -355,11 +358,16 @@ struct pd_ctx
     pd_timing timing;
     // per-sample result arrays kept in HBM for pd_calls_merge (pd_ctx_keep_results_on_device)
     bool keepOnDevice = false;
-    const pd_calls * keptCalls = nullptr;   // the collect whose columns sit in dOutPl
+    uint64_t keptId = 0, nextKeptId = 1;    // identifies the collect whose columns sit in dOutPl (0: none); see CallsBox
     DevBuf<uint32_t> dMergeIdx, dMergeOut;
     DevBuf<unsigned> dMergeCounters;
     uint32_t nAllGathers = 0;       // of the collect in progress
     uint64_t allGatherBytes = 0;
+    // device time of the exchanges of the collect in progress: an event pair around each (recycled), summed at its end;
+    // the in-process group exchanges under host synchronisation and is timed on the host clock instead
+    std::vector<hipEvent_t> xchEvents;
+    size_t xchEventsUsed = 0;
+    double xchHostMs = 0;
 
     ~pd_ctx()
     {
@@ -367,6 +375,8 @@ struct pd_ctx
         spare.clear();
         if (comm)
             (void)rccl().commDestroy(comm);
+        for (hipEvent_t e : xchEvents)
+            (void)hipEventDestroy(e);
         if (resultsPacked)
             (void)hipEventDestroy(resultsPacked);
         if (cellsFetched)
@@ -430,12 +440,16 @@ struct CallsBox
 {
     pd_calls pub;
     PinnedBlock pinned;
+    pd_ctx * owner = nullptr;       // the context whose HBM holds the per-sample columns (pd_ctx_keep_results_on_device) ...
+    uint64_t keptId = 0;            // ... as long as this is still the context's keptId
 };
 
-// The exchange buffer: owned by the library for an unsharded cohort, by the host otherwise.
+// The exchange buffer: owned by the host if it runs the exchanges (pd_ctx_set_shard with callbacks), else by the library.
+bool hostOwnsArena(const pd_ctx & c) { return c.sharded && !c.comm && !c.group && c.shard.reserve && c.shard.all_gather; }
+
 uint8_t * reserveArena(pd_ctx & c, size_t bytes)
 {
-    if (c.world == 1 || c.comm || c.group)
+    if (!hostOwnsArena(c))
     {
         if (bytes > c.ownArena.n)
             PD_HIP(hipStreamSynchronize(c.stream));        // nothing in flight may still use the buffer that is replaced
@@ -484,19 +498,30 @@ void groupFail(pd_ctx * c)
 struct CtxExchange : pd::Exchange
 {
     pd_ctx & c;
-    explicit CtxExchange(pd_ctx & ctx) : c(ctx) {}
+    hipStream_t st;             // the stream the exchanges are ordered on (the context's compute stream by default)
+    explicit CtxExchange(pd_ctx & ctx, hipStream_t stream = nullptr) : c(ctx), st(stream ? stream : ctx.stream) {}
+    hipEvent_t nextEvent()
+    {
+        if (c.xchEventsUsed == c.xchEvents.size())
+        {
+            hipEvent_t e = nullptr;
+            PD_HIP(hipEventCreate(&e));
+            c.xchEvents.push_back(e);
+        }
+        return c.xchEvents[c.xchEventsUsed++];
+    }
     void allGather(void * area, size_t bytesPerRank) override
     {
-        if (c.world > 1 || c.comm || c.group)
-        {
-            ++c.nAllGathers;
-            c.allGatherBytes += static_cast<uint64_t>(bytesPerRank) * c.world;
-        }
+        if (!c.sharded)
+            return;
+        ++c.nAllGathers;
+        c.allGatherBytes += static_cast<uint64_t>(bytesPerRank) * c.world;
         if (c.group)
         {
             // every context pulls the other contexts' chunks out of their exchange buffers (same layout everywhere)
+            const auto t0 = std::chrono::steady_clock::now();
             const size_t off = static_cast<size_t>(static_cast<uint8_t *>(area) - c.arena);
-            PD_HIP(hipStreamSynchronize(c.stream));            // my chunk is written
+            PD_HIP(hipStreamSynchronize(st));                  // my chunk is written
             groupBarrier(c);
             for (uint32_t p = 0; p < c.world; ++p)
             {
@@ -504,27 +529,31 @@ struct CtxExchange : pd::Exchange
                     continue;
                 const pd_ctx * peer = c.group->members[p];
                 PD_HIP(hipMemcpyPeerAsync(c.arena + off + static_cast<size_t>(p) * bytesPerRank, c.device,
-                                          peer->arena + off + static_cast<size_t>(p) * bytesPerRank, peer->device, bytesPerRank, c.stream));
+                                          peer->arena + off + static_cast<size_t>(p) * bytesPerRank, peer->device, bytesPerRank, st));
             }
-            PD_HIP(hipStreamSynchronize(c.stream));
+            PD_HIP(hipStreamSynchronize(st));
             groupBarrier(c);                                   // nobody rewrites its chunk before everybody has copied it
+            c.xchHostMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             return;
         }
+        PD_HIP(hipEventRecord(nextEvent(), st));
         if (c.comm)
         {
             // in place: chunk `rank` of [area, area + world * bytesPerRank) is filled; stream-ordered between the kernels
             uint8_t * base = static_cast<uint8_t *>(area);
             const ncclResult_t r = rccl().allGather(base + static_cast<size_t>(c.rank) * bytesPerRank, base, bytesPerRank, ncclUint8,
-                                                    c.comm, c.stream);
+                                                    c.comm, st);
             if (r != ncclSuccess)
                 throw HipError{std::string("ncclAllGather: ") + rccl().getErrorString(r)};
-            return;
         }
-        if (c.world == 1)
-            return;
-        const uint64_t off = static_cast<uint64_t>(static_cast<uint8_t *>(area) - c.arena);
-        if (c.shard.all_gather(c.shard.user, off, bytesPerRank, c.stream) != 0)
-            throw HipError{"the host's all_gather() callback failed"};
+        else if (hostOwnsArena(c))
+        {
+            const uint64_t off = static_cast<uint64_t>(static_cast<uint8_t *>(area) - c.arena);
+            if (c.shard.all_gather(c.shard.user, off, bytesPerRank, st) != 0)
+                throw HipError{"the host's all_gather() callback failed"};
+        }
+        // (world == 1 without a carrier: nothing to move)
+        PD_HIP(hipEventRecord(nextEvent(), st));
     }
 };
 
@@ -539,12 +568,40 @@ T * mallocCopy(const std::vector<T> & v)
     return p;
 }
 
+// Stage 2 adds the pairs of a cell up in chunk order, and the chunk order depends on the chunk life K: the contexts of a
+// sharded cohort must all cut with the same K or their results differ in the last bits from the unsharded run (and with
+// the number of shards). K is therefore taken from the lifetime histogram of the WHOLE cohort: the contexts all-gather
+// their 66 counters when a segment is staged (on the copy stream; pd_segment_stage is collective for a sharded cohort).
+void cohortLifeHist(pd_ctx & c, unsigned long long * hist /* 66 counters, in: own samples, out: cohort */)
+{
+    if (!c.sharded || c.world == 1)
+        return;
+    hipStream_t cs = c.copyStream;
+    const size_t per = alignUp(66 * sizeof(unsigned long long), 256), words = per / sizeof(unsigned long long);
+    uint8_t * area = reserveArena(c, per * c.world);
+    c.hLifeXch.resize(words * c.world);
+    std::memcpy(c.hLifeXch.data() + static_cast<size_t>(c.rank) * words, hist, 66 * sizeof(unsigned long long));
+    PD_HIP(hipMemcpyAsync(area + static_cast<size_t>(c.rank) * per, c.hLifeXch.data() + static_cast<size_t>(c.rank) * words, per,
+                          hipMemcpyHostToDevice, cs));
+    CtxExchange xch(c, cs);
+    xch.allGather(area, per);
+    PD_HIP(hipMemcpyAsync(c.hLifeXch.data(), area, per * c.world, hipMemcpyDeviceToHost, cs));
+    PD_HIP(hipStreamSynchronize(cs));
+    for (int l = 0; l < 66; ++l)
+    {
+        unsigned long long sum = 0;
+        for (uint32_t r = 0; r < c.world; ++r)
+            sum += c.hLifeXch[static_cast<size_t>(r) * words + l];
+        hist[l] = sum;
+    }
+}
+
 // Split every pair instance into chunks that live at most K windows, order the chunks of each read group by their
 // first window and index them by window (winStart). K is chosen so that nearly all pairs need a single chunk.
 // `sized()` is called once the chunk totals are known (winStart is final then), `slabDone(lo, hi)` whenever the chunks
 // of the read groups [lo, hi) are in place: the caller uploads slab by slab while the next slab is being built.
 template <typename Sized, typename SlabDone>
-void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, PinnedBuf<pd::PairDO> & pairs,
+void buildChunks(pd_ctx & c, const pd_segment & seg, StagedSegment & out, PinnedBuf<pd::PairDO> & pairs,
                  PinnedBuf<uint32_t> & start, std::vector<uint64_t> & rgBase, PinnedBuf<uint32_t> & winStart,
                  PinnedBuf<uint2> & pairsPk, PinnedBuf<uint32_t> & endCount, std::vector<uint8_t> & rgPacked,
                  std::vector<uint8_t> & scanGeneric, Sized sized, SlabDone slabDone)
@@ -580,6 +637,18 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
         nInst += h;
     uint32_t K = 4;
     {
+        // K from the lives of the whole cohort (the same for every context of a sharded one)
+        unsigned long long cohort[66];
+        for (int l = 0; l < 66; ++l)
+            cohort[l] = lifeHist[l];
+        cohortLifeHist(c, cohort);
+        uint64_t all = 0;
+        for (int l = 0; l < 66; ++l)
+        {
+            lifeHist[l] = cohort[l];
+            all += cohort[l];
+        }
+        std::swap(all, nInst);                  // (nInst: cohort-wide inside this block; restored below)
         uint64_t acc = 0;
         // ~98.4 % of the pairs in one chunk. (A smaller share shortens the scan -- bench segment, K = 9 / 10 / 11 / 12: 1.127 /
         // 1.120 / 1.161 / 1.225 ms per pass; 95.1 % of the lives are <= 10 windows, 98.8 % <= 11 -- but where the
@@ -596,9 +665,8 @@ void buildChunks(const pd_ctx & c, const pd_segment & seg, StagedSegment & out, 
             }
         }
         K = std::min<uint32_t>(K, 48);
+        nInst = all;
     }
-    if (const char * e = getenv("POPDEL_HIP_MAXLIFE"))
-        K = std::max(1, atoi(e));
     out.maxLife = K;
     out.nPairs = nInst;
     out.nActivePairs = active;
@@ -1017,9 +1085,16 @@ bool buildChunksOnDevice(pd_ctx & c, const pd_segment & seg, StagedSegment & out
         }
         return 48u;
     };
-    uint32_t K = lifeAt(64), K1 = std::min(lifeAt(16), K);
-    if (const char * e = getenv("POPDEL_HIP_MAXLIFE"))
-        K1 = K = std::max(1, atoi(e));
+    // (K1 from the own samples' lives, then K from the whole cohort's: see cohortLifeHist)
+    const uint32_t K1own = lifeAt(16);
+    const unsigned long long ownActive = c.hLifeHist[66];
+    cohortLifeHist(c, c.hLifeHist.data());
+    uint64_t ownLiving = living;
+    living = 0;
+    for (int l = 0; l <= 65; ++l)
+        living += c.hLifeHist[l];
+    uint32_t K = lifeAt(64), K1 = std::min(K1own, K);
+    living = ownLiving;
     if (const char * e = getenv("POPDEL_HIP_MAXLIFE_SCAN"))
         K1 = std::min<uint32_t>(K, std::max(1, atoi(e)));
     if (pd::buildLdsBytes(W, K) > 160u * 1024u)
@@ -1029,7 +1104,7 @@ bool buildChunksOnDevice(pd_ctx & c, const pd_segment & seg, StagedSegment & out
     out.maxLifePk = K1;
     out.ownPkIndex = twoLives;
     out.nPairs = living;
-    out.nActivePairs = c.hLifeHist[66];
+    out.nActivePairs = ownActive;
     // ---- counts -> index rows, chunk totals -> bases (per image if the lives differ)
     out.winStart.ensure(static_cast<size_t>(twoLives ? nRg : nEnt) * (static_cast<size_t>(W) + K));
     out.endCount.ensure(static_cast<size_t>(twoLives ? nRg : nEnt) * (W + 1));
@@ -1394,6 +1469,7 @@ static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, p
             c->group = group;
         }
         c->shard = *sh;
+        c->sharded = true;
         c->rank = sh->rank;
         c->world = sh->world;
         c->nSamplesGlobal = sh->n_samples_global;
@@ -1732,6 +1808,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
     }
     StagedSegment & s = *sit->second;
     hipEvent_t s2Begin = nullptr, s2End = nullptr;
+    bool s2BeginRecorded = false;
     PinnedBlock pinned;
     int rc = 0;
     try
@@ -1748,6 +1825,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         CtxExchange xch(*c);
         c->nAllGathers = 0;
         c->allGatherBytes = 0;
+        c->xchEventsUsed = 0;
+        c->xchHostMs = 0;
         const uint32_t world = c->world, sper = c->samplesPerRank, SG = c->nSamplesGlobal;
         unsigned rowLen = 1;
         while (rowLen < SG)
@@ -1758,66 +1837,91 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             std::memset(&cs, 0, sizeof(cs));
             cs.window = window;
             cs.initLen = initLen;
+            cs.len = static_cast<unsigned>(initLen);             // (the likelihoods ahead of the EM loop run before the cell's set-up kernel)
             cs.phase = pd::kCellIterating;
             cells.push_back(cs);
         };
         // Flagged windows (some sample of the cohort has a Q3 above the smallest threshold) -> candidate lengths per
-        // window -> (window, length) cells. An unsharded context forms both lists on the device and the host reads the
-        // cells in ONE round trip; the kernels are launched for a capacity of flagged windows and find the number on the
-        // device. (A sharded cohort exchanges per flagged window: the host has to know their number in between.)
+        // window -> (window, length) cells. Both lists are formed on the device and the host reads the cells in ONE round
+        // trip; the kernels are launched for a capacity of flagged windows and find the number on the device. A sharded
+        // cohort exchanges the window flags, then the Q3 values of the flagged windows -- laid out for a capacity guessed
+        // from the previous segments (every context sees the same union of flagged windows, so all guess alike); a segment
+        // with more flagged windows is listed again with room for them.
+        const bool sharded = c->sharded;
         bool listed = false;
-        if (world == 1 && W != 0 && c->deviceLists)
+        if (W != 0 && c->deviceLists)
         {
             PD_HIP(hipEventRecord(s2Begin, c->stream));
-            const unsigned capF = std::min<unsigned>(W, std::max<unsigned>(256u, std::min<unsigned>(4096u, (1u << 28) / rowLen)));
+            s2BeginRecorded = true;
+            const unsigned capMax = std::min<unsigned>(W, std::max<unsigned>(256u, std::min<unsigned>(4096u, (1u << 28) / rowLen)));
+            unsigned capF = sharded ? std::min(capMax, std::max(64u, c->flagCapGuess)) : capMax;
             constexpr unsigned kListCap = 1022;                                 // cells the first copy brings along
-            const size_t listRoom = static_cast<size_t>(capF) * pd::kMaxCandidatesPerWindow;
-            c->dFlagged.ensure(capF);
-            c->dCandHdr.ensure(4 + 2 * listRoom);
-            c->dClusterScratch.ensure(static_cast<size_t>(capF) * rowLen);
-            c->dCandLen.ensure(listRoom);
-            c->dCandCount.ensure(capF);
-            pd::ClusterInput in;
-            in.chunkBytes = alignUp(capF * static_cast<size_t>(sper) * 5, 256);
-            in.base = reserveArena(*c, in.chunkBytes);
-            in.sper = sper;
-            in.world = 1;
-            in.nFlagged = capF;
-            in.nFlaggedDev = c->dCandHdr.p;
-            in.minInit = c->dMinInitGlobal.p;
-            pd::launchCompactFlagged(o.winFlag.p, W, capF, c->dFlagged.p, c->dCandHdr.p, c->stream);
-            pd::launchPackFlagged(o.q3.p, o.flags.p, c->dFlagged.p, W, S, in, 0, c->stream);
-            pd::launchCluster(in, c->uniformThreshold, c->dClusterScratch.p, rowLen, c->dCandLen.p, c->dCandCount.p, c->stream);
-            pd::launchListCells(c->dFlagged.p, c->dCandLen.p, c->dCandCount.p, capF, (unsigned)listRoom, c->dCandHdr.p, c->stream);
-            PD_HIP(hipGetLastError());
-            PinnedBuf<unsigned> & hdr = c->hCandHdr;
-            hdr.resize(4 + 2 * kListCap);
-            PD_HIP(hipMemcpyAsync(hdr.data(), c->dCandHdr.p, hdr.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-            PD_HIP(hipStreamSynchronize(c->stream));
-            const unsigned nFlagged = hdr[0], nListed = hdr[1];
-            if (getenv("POPDEL_HIP_DEBUG"))
-                fprintf(stderr, "[popdel_hip] %u flagged windows, %u candidate cells\n", nFlagged, nListed);
-            if (nFlagged <= capF)
+            const size_t flagBytes = sharded ? alignUp(static_cast<size_t>(W) * sizeof(int), 256) : 0;     // per context
+            for (;;)
             {
-                if (hdr[2] != 0)
-                    throw HipError{"more than 32 candidate deletion lengths in one window"};
-                if (nListed > kListCap)                         // a candidate-rich segment: fetch the rest of the list
+                const size_t listRoom = static_cast<size_t>(capF) * pd::kMaxCandidatesPerWindow;
+                c->dFlagged.ensure(capF);
+                c->dCandHdr.ensure(4 + 2 * listRoom);
+                c->dClusterScratch.ensure(static_cast<size_t>(capF) * rowLen);
+                c->dCandLen.ensure(listRoom);
+                c->dCandCount.ensure(capF);
+                pd::ClusterInput in;
+                in.chunkBytes = alignUp(capF * static_cast<size_t>(sper) * 5, 256);
+                uint8_t * area = reserveArena(*c, world * (flagBytes + in.chunkBytes));
+                const int * flagRows = o.winFlag.p;
+                if (sharded)
                 {
-                    hdr.resize(4 + 2 * static_cast<size_t>(nListed));
-                    PD_HIP(hipMemcpyAsync(hdr.data(), c->dCandHdr.p, hdr.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-                    PD_HIP(hipStreamSynchronize(c->stream));
+                    pd::launchCopyBytes(o.winFlag.p, area + static_cast<size_t>(c->rank) * flagBytes, W * sizeof(int), c->stream);
+                    xch.allGather(area, flagBytes);
+                    flagRows = reinterpret_cast<const int *>(area);
                 }
-                for (unsigned i = 0; i < nListed; ++i)
-                    addCell((int)hdr[4 + 2 * i], (int)hdr[5 + 2 * i]);
-                listed = true;
+                in.base = area + world * flagBytes;
+                in.sper = sper;
+                in.world = world;
+                in.nFlagged = capF;
+                in.nFlaggedDev = c->dCandHdr.p;
+                in.minInit = c->dMinInitGlobal.p;
+                pd::launchCompactFlagged(flagRows, W, world, flagBytes / sizeof(int), capF, c->dFlagged.p, c->dCandHdr.p, c->stream);
+                pd::launchPackFlagged(o.q3.p, o.flags.p, c->dFlagged.p, W, S, in, c->rank, c->stream);
+                PD_HIP(hipGetLastError());
+                xch.allGather(const_cast<uint8_t *>(in.base), in.chunkBytes);
+                pd::launchCluster(in, c->uniformThreshold, c->dClusterScratch.p, rowLen, c->dCandLen.p, c->dCandCount.p, c->stream);
+                pd::launchListCells(c->dFlagged.p, c->dCandLen.p, c->dCandCount.p, capF, (unsigned)listRoom, c->dCandHdr.p, c->stream);
+                PD_HIP(hipGetLastError());
+                PinnedBuf<unsigned> & hdr = c->hCandHdr;
+                hdr.resize(4 + 2 * kListCap);
+                PD_HIP(hipMemcpyAsync(hdr.data(), c->dCandHdr.p, hdr.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+                PD_HIP(hipStreamSynchronize(c->stream));
+                const unsigned nFlagged = hdr[0], nListed = hdr[1];
+                if (getenv("POPDEL_HIP_DEBUG"))
+                    fprintf(stderr, "[popdel_hip] %u flagged windows (room for %u), %u candidate cells\n", nFlagged, capF, nListed);
+                if (sharded)                                    // room for a quarter more next time
+                    c->flagCapGuess = std::min(capMax, (nFlagged + nFlagged / 4 + 32u + 63u) / 64u * 64u);
+                if (nFlagged <= capF)
+                {
+                    if (hdr[2] != 0)
+                        throw HipError{"more than 32 candidate deletion lengths in one window"};
+                    if (nListed > kListCap)                         // a candidate-rich segment: fetch the rest of the list
+                    {
+                        hdr.resize(4 + 2 * static_cast<size_t>(nListed));
+                        PD_HIP(hipMemcpyAsync(hdr.data(), c->dCandHdr.p, hdr.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+                        PD_HIP(hipStreamSynchronize(c->stream));
+                    }
+                    for (unsigned i = 0; i < nListed; ++i)
+                        addCell((int)hdr[4 + 2 * i], (int)hdr[5 + 2 * i]);
+                    listed = true;
+                    break;
+                }
+                if (capF >= capMax)
+                    break;          // more flagged windows than the device-side lists are made for: the host-side lists below
+                capF = std::min(capMax, (nFlagged + 63u) / 64u * 64u);
             }
-            // (more flagged windows than the capacity: the host-side lists below take over)
         }
         if (!listed)
         {
             PinnedBuf<int> & winFlag = c->hWinFlag;
             winFlag.resize(static_cast<size_t>(W) * world);
-            if (world == 1)
+            if (!sharded)
             {
                 PD_HIP(hipMemcpyAsync(winFlag.data(), o.winFlag.p, W * sizeof(int), hipMemcpyDeviceToHost, c->stream));
             }
@@ -1838,7 +1942,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
                 if (any)
                     flagged.push_back((int)w);
             }
-            PD_HIP(hipEventRecord(s2Begin, c->stream));
+            if (!s2BeginRecorded)
+                PD_HIP(hipEventRecord(s2Begin, c->stream));
             if (!flagged.empty())
             {
                 c->hFlagged.resize(flagged.size());
@@ -1887,7 +1992,9 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         // cohort must cut the cell list at the same places, the exchanges run per batch)
         const size_t bytesPerCell = static_cast<size_t>(sper) * (2 * pd::kDenseCap * 2 + 24 + 52 + 2 + 24) + 4096;
         // ((sweep, cell) is a grid's y dimension: at most 65,535 / sweeps cells per batch; pd::kTilesPerSweep)
-        const size_t sweeps = ((static_cast<size_t>(S) + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock + 7) / 8 * 8 / pd::kTilesPerSweep + 1;
+        // (like bytesPerCell from the partition's samples per context, not from S: a last context with fewer tiles must cut
+        // the cell list at the same places)
+        const size_t sweeps = ((static_cast<size_t>(sper) + pd::kSamplesPerBlock - 1) / pd::kSamplesPerBlock + 7) / 8 * 8 / pd::kTilesPerSweep + 1;
         const unsigned batchCells = static_cast<unsigned>(
             std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nCells ? nCells : 1, 65535 / sweeps), budget / bytesPerCell)));
         const unsigned nBatches = nCells ? (nCells + batchCells - 1) / batchCells : 0;
@@ -1911,15 +2018,14 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             b.rank = c->rank;
             b.world = world;
             b.nSamplesGlobal = SG;
-            // exchange areas: integer counts | per-tile sums + RG-0 record | digit histograms
-            b.xchChunk = (static_cast<size_t>(b.tilesPerRank) + 1) * nb * 4;
-            const size_t countersBytes = alignUp(static_cast<size_t>(world) * nb * 4 * sizeof(unsigned), 256);
+            b.sharded = sharded ? 1u : 0u;
+            // exchange areas: xch (header, integer counts, pool records, per-tile sums, RG-0 record) | digit histograms
+            b.xchChunk = pd::xchChunkDoubles(b.tilesPerRank, nb);
             const size_t xchBytes = alignUp(static_cast<size_t>(world) * b.xchChunk * sizeof(double), 256);
-            const size_t histBytes = static_cast<size_t>(world) * nb * 2 * 256 * sizeof(unsigned);
-            uint8_t * area = reserveArena(*c, countersBytes + xchBytes + histBytes);
-            b.counters = reinterpret_cast<unsigned *>(area);
-            b.xch = reinterpret_cast<double *>(area + countersBytes);
-            b.selHist = reinterpret_cast<unsigned *>(area + countersBytes + xchBytes);
+            const size_t histBytes = sharded ? static_cast<size_t>(world) * nb * 2 * 256 * sizeof(unsigned) : 0;
+            uint8_t * area = reserveArena(*c, xchBytes + histBytes);
+            b.xch = reinterpret_cast<double *>(area);
+            b.selHist = reinterpret_cast<unsigned *>(area + xchBytes);
             c->dCells.ensure(nb);
             c->dDl.ensure(static_cast<size_t>(nb) * S * 3);
             c->dShifts.ensure(static_cast<size_t>(nb) * c->nRg);
@@ -1992,20 +2098,35 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             // any tile needs the generic kernels. The first attempt does not wait for either (one host round trip less):
             // pools sized from the segment's average with headroom, generic kernels as earlier segments needed them, both
             // checked on the device (Stage2Buffers::guard); the second attempt, if the check failed, reads the counts.
-            // A cohort sharded over several contexts always reads them: every context must take the same path.
+            // The contexts of a sharded cohort exchange their verdicts with the first exchange of phase B, so all of them
+            // repeat a batch or none does; in the second attempt they read the counts of all contexts.
             for (int attempt = 0; attempt < 2; ++attempt)
             {
-                const bool optimistic = attempt == 0 && world == 1 && c->optimisticPools;
+                const bool optimistic = attempt == 0 && c->optimisticPools;
                 unsigned * guard = c->dIterFlags.p + pd::kMaxIterationsCap + 1;
                 pd::ZeroRanges zero{};
-                zero.add(area, countersBytes + xchBytes);
+                zero.add(area, xchBytes);
                 zero.add(c->dShifts.p, static_cast<size_t>(nb) * c->nRg * sizeof(int));
                 zero.add(c->dTileMode.p, static_cast<size_t>(nImg) * b.ownTiles * sizeof(unsigned));
                 zero.add(c->dIterFlags.p, (pd::kMaxIterationsCap + 2) * sizeof(unsigned));     // EM flags and the guard word
                 pd::launchZero(zero, c->stream);
+                if (attempt != 0)       // (the first attempt's cell records came back into the staging buffer)
+                {
+                    for (unsigned i = 0; i < nb; ++i)
+                    {
+                        pd::CellState fresh = cells[lo + i];
+                        fresh.image = c->hCells[lo + i].image;
+                        fresh.imageFirst = c->hCells[lo + i].imageFirst;
+                        fresh.imageEnd = c->hCells[lo + i].imageEnd;
+                        c->hCells[lo + i] = fresh;
+                    }
+                }
                 PD_HIP(hipMemcpyAsync(c->dCells.p, c->hCells.data() + lo, nb * sizeof(pd::CellState), hipMemcpyHostToDevice, c->stream));
                 bool generic = c->genericSeen;
                 b.guard = nullptr;
+                b.rangeSelect = 0;
+                pd::runStage2Init(view, c->cohort, b, o.flags.p, c->stream);
+                PD_HIP(hipGetLastError());
                 if (optimistic)
                 {
                     const uint64_t perCell = s.nActivePairs * 3 / (2 * static_cast<uint64_t>(W)) + 1024;
@@ -2013,39 +2134,39 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
                     c->dSuppLast.ensure(static_cast<size_t>(nb) * perCell + 1);
                     b.suppCap = std::min(c->dSuppFirst.n, c->dSuppLast.n) - 1;
                     b.genericLaunched = generic ? 1u : 0u;
+                    b.rangeSelect = sharded ? 1u : 0u;
                     b.guard = guard;
-                    b.suppFirst = c->dSuppFirst.p;
-                    b.suppLast = c->dSuppLast.p;
-                    pd::runStage2Init(view, c->cohort, b, o.flags.p, xch, c->stream);
-                    PD_HIP(hipGetLastError());
                 }
                 else
                 {
-                    pd::runStage2Init(view, c->cohort, b, o.flags.p, xch, c->stream);
-                    PD_HIP(hipGetLastError());
-                    PinnedBuf<unsigned> & counters = c->hCounters;                    // of this context's own samples
-                    counters.resize(static_cast<size_t>(nb) * 4);
-                    PD_HIP(hipMemcpyAsync(counters.data(), b.counters + static_cast<size_t>(c->rank) * nb * 4,
-                                          counters.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+                    // the integer counts of every context's samples (own ones: pool size; all: generic kernels or not)
+                    xch.allGather(b.xch, b.xchChunk * sizeof(double));
+                    PinnedBuf<unsigned> & counters = c->hCounters;
+                    counters.resize(static_cast<size_t>(world) * nb * 4);
+                    for (uint32_t r = 0; r < world; ++r)
+                        PD_HIP(hipMemcpyAsync(counters.data() + static_cast<size_t>(r) * nb * 4,
+                                              b.xch + static_cast<size_t>(r) * b.xchChunk + pd::kXchHeaderDoubles,
+                                              static_cast<size_t>(nb) * 4 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
                     PD_HIP(hipStreamSynchronize(c->stream));
                     uint64_t pool = 0, genericTiles = 0;
-                    for (unsigned i = 0; i < nb; ++i)
-                    {
-                        pool += counters[static_cast<size_t>(i) * 4 + 1];
-                        genericTiles += counters[static_cast<size_t>(i) * 4 + 3];
-                    }
+                    for (uint32_t r = 0; r < world; ++r)
+                        for (unsigned i = 0; i < nb; ++i)
+                        {
+                            if (r == c->rank)
+                                pool += counters[(static_cast<size_t>(r) * nb + i) * 4 + 1];
+                            genericTiles += counters[(static_cast<size_t>(r) * nb + i) * 4 + 3];
+                        }
                     if (getenv("POPDEL_HIP_DEBUG"))
-                        fprintf(stderr, "[popdel_hip] stage 2 batch %u/%u%s: %u cells, %llu of %llu (cell, 64-sample wave tile) units need the generic kernels\n",
-                                batch + 1, nBatches, attempt ? " (repeated)" : "", nb, (unsigned long long)genericTiles,
-                                (unsigned long long)nb * b.ownTiles * 4);
+                        fprintf(stderr, "[popdel_hip] stage 2 batch %u/%u%s: %u cells, %llu (cell, 64-sample wave tile) units of the cohort need the generic kernels\n",
+                                batch + 1, nBatches, attempt ? " (repeated)" : "", nb, (unsigned long long)genericTiles);
                     c->dSuppFirst.ensure(pool + 1);
                     c->dSuppLast.ensure(pool + 1);
-                    b.suppFirst = c->dSuppFirst.p;
-                    b.suppLast = c->dSuppLast.p;
                     generic = genericTiles != 0;
-                    if (generic && world == 1)
+                    if (generic)
                         c->genericSeen = true;      // from now on the generic kernels ride along (they exit early where not needed)
                 }
+                b.suppFirst = c->dSuppFirst.p;
+                b.suppLast = c->dSuppLast.p;
                 pd::runStage2Main(view, c->cohort, b, o.flags.p, xch, generic, c->hIterFlag.data(), c->stream);
                 PD_HIP(hipGetLastError());
                 // the columns of the emitted cells are packed before the host has seen which cells those are
@@ -2106,7 +2227,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         const size_t perSample = static_cast<size_t>(n) * S;
         // columns stay in HBM (pd_ctx_keep_results_on_device) if they are all there: one batch
         const bool keep = c->keepOnDevice && nBatches == 1 && nLastBatch != 0;
-        c->keptCalls = nullptr;
+        c->keptId = 0;
         if (n != 0 && !keep)
         {
             pinned = takePinned(perSample * 13 * sizeof(uint32_t));
@@ -2150,6 +2271,17 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         c->timing.n_candidate_cells = nCells;
         c->timing.max_life = s.maxLife;
         c->timing.n_all_gathers = c->nAllGathers;
+        {
+            // (everything on the stream has completed: s2End was waited for above and the exchanges precede it)
+            double ms = c->xchHostMs;
+            for (size_t i = 0; i + 1 < c->xchEventsUsed; i += 2)
+            {
+                float t = 0;
+                PD_HIP(hipEventElapsedTime(&t, c->xchEvents[i], c->xchEvents[i + 1]));
+                ms += t;
+            }
+            c->timing.exchange_ms = ms;
+        }
         c->timing.all_gather_bytes = c->allGatherBytes;
         c->timing.n_repeated_batches = c->nRepeatedBatches;
 
@@ -2187,7 +2319,10 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         pc->dad = hDad;
         pc->first_last = hFl;
         if (keep)
-            c->keptCalls = pc;
+        {
+            box->owner = c;
+            box->keptId = c->keptId = c->nextKeptId++;
+        }
         *out = pc;
     }
     catch (const HipError & e)
@@ -2340,13 +2475,21 @@ struct MergedBox
 };
 }  // namespace
 
+// Do the per-sample columns of `calls` still sit in this context's HBM? (Identity by an id the collect handed out, not by
+// address: a later pd_calls may live at a recycled address.)
+static bool columnsResident(const pd_ctx * c, const pd_calls * calls)
+{
+    const CallsBox * box = reinterpret_cast<const CallsBox *>(calls);     // pub is the first member
+    return box->owner == c && box->keptId != 0 && box->keptId == c->keptId;
+}
+
 int pd_calls_merge(pd_ctx * c, const pd_calls * calls, uint32_t n_groups, const uint32_t * member_offsets, const uint32_t * member_index,
                    const uint32_t * head_index, pd_merged ** out)
 {
     if (!c || !calls || !out || (n_groups != 0 && (!member_offsets || !member_index || !head_index)))
         return fail(c, "pd_calls_merge: invalid argument");
     *out = nullptr;
-    if (calls != c->keptCalls)
+    if (!columnsResident(c, calls))
         return fail(c, "pd_calls_merge: the per-sample arrays of these calls are not (or no longer) on the device");
     PinnedBlock pinned;
     int rc = 0;
@@ -2359,10 +2502,10 @@ int pd_calls_merge(pd_ctx * c, const pd_calls * calls, uint32_t n_groups, const 
             if (member_index[m] >= n)
                 return fail(c, "pd_calls_merge: member index out of range");
         for (uint32_t g = 0; g < n_groups; ++g)
-            if (head_index[g] >= n || member_offsets[g + 1] < member_offsets[g])
-                return fail(c, "pd_calls_merge: malformed group");
+            if (head_index[g] >= n || member_offsets[g + 1] <= member_offsets[g])
+                return fail(c, "pd_calls_merge: malformed group (every group needs at least one member)");
         const size_t perOut = static_cast<size_t>(n_groups) * S;
-        MergedBox * box = new MergedBox();
+        std::unique_ptr<MergedBox> box(new MergedBox());      // (released to the caller on success only)
         std::memset(&box->pub, 0, sizeof(pd_merged));
         box->pub.n_groups = n_groups;
         box->pub.n_samples = S;
@@ -2405,7 +2548,6 @@ int pd_calls_merge(pd_ctx * c, const pd_calls * calls, uint32_t n_groups, const 
             if (h[perOut * 13 + n_groups] != 0)
             {
                 givePinned(pinned);
-                delete box;
                 c->error = "pd_calls_merge: a LAD/DAD value beyond the median bins; merge this segment on the host";
                 return 2;
             }
@@ -2416,7 +2558,7 @@ int pd_calls_merge(pd_ctx * c, const pd_calls * calls, uint32_t n_groups, const 
             box->pub.alleles = h + perOut * 13;
         }
         box->pinned = pinned;
-        *out = &box->pub;
+        *out = &box.release()->pub;
     }
     catch (const HipError & e)
     {
@@ -2450,7 +2592,7 @@ int pd_calls_fetch_columns(pd_ctx * c, pd_calls * calls)
         return fail(c, "pd_calls_fetch_columns: invalid argument");
     if (calls->pl)
         return 0;                                   // they are there already
-    if (calls != c->keptCalls)
+    if (!columnsResident(c, calls))
         return fail(c, "pd_calls_fetch_columns: the per-sample arrays of these calls are not (or no longer) on the device");
     try
     {

@@ -197,6 +197,7 @@ struct CellState
     // distributed percentile selection over the support pools (0: starts, 1: ends): radix prefix and remaining rank
     unsigned selPrefix[2];
     unsigned selK[2];
+    unsigned selLo[2];            // the selection runs on x - selLo (0, or the cohort-wide minimum of the pool: rangeSelect)
 };
 
 // Device buffers and parameters of the stage-2 kernels.
@@ -208,15 +209,22 @@ struct Stage2Buffers
     int *       shifts;      // [nCells][nRg]   reference shifts
     // Exchange areas. The cohort may be sharded by samples over `world` contexts (one per GPU); every context owns
     // `tilesPerRank` consecutive 256-sample tiles. Whatever crosses samples is written into the context's own chunk of
-    // an area laid out [world][chunk] and all-gathered by the host between kernels; per-cell kernels then add the
-    // chunks in rank/tile order, so results do not depend on the number of shards (world == 1: no exchange at all).
-    double *    xch;         // [world][xchChunk]: [tilesPerRank][nCells][4] per-tile sums, then [nCells][4] RG-0 record
+    // an area laid out [world][chunk] and all-gathered between kernels; per-cell kernels then add the chunks in
+    // rank/tile order, so results do not depend on the number of shards (world == 1: no exchange at all).
+    // Area `xch`, one chunk per context (xchChunk doubles), always gathered as a whole (it is small, and one region means
+    // that things which are ready at the same time travel in ONE exchange):
+    //   [kXchHeaderDoubles]      header: word 0 = this context's guard (see `guard` below), rest unused
+    //   [nCells][4] unsigned     integer accumulators (a5 count, a5 total, low-coverage samples, generic wave tiles)
+    //   [nCells][2][4] unsigned  support pools of the context: {min, max, count, -} of pool 0 (starts) and 1 (ends)
+    //   [tilesPerRank][nCells][4] double   per-tile sums
+    //   [nCells][4] double       read group 0's record (published by rank 0)
+    double *    xch;
     size_t      xchChunk;    // doubles per chunk
-    unsigned *  counters;    // [world][nCells][4] integer accumulators (a5 count, a5 total, low coverage samples, unused)
     unsigned *  selHist;     // [world][nCells][2][256] digit histograms of the support pools
     unsigned    nTiles;      // tiles of the whole cohort
     unsigned    tilesPerRank;
     unsigned    rank, world;
+    unsigned    sharded;     // the cohort is sharded by samples (possibly over ONE context): the exchanged code path runs
     unsigned    nSamplesGlobal;
     // Dense image of the cells' active pairs, built once per cell by cellGatherKernel: for every 64-sample wave tile
     // the deviations (and start positions) transposed to [row j][lane = sample], so that the EM kernels run ONE LANE PER
@@ -251,11 +259,16 @@ struct Stage2Buffers
     unsigned *  suppFirst;   // support pools
     unsigned *  suppLast;
     // Launch without the host looking at the pool sizes first (one round trip less per segment): if `guard` is set, the
-    // pools hold suppCap entries sized from the segment's average, and the generic kernels are launched or not
-    // (genericLaunched) by what earlier segments needed; suppScanKernel checks both against the real counts, and if either
-    // does not hold it kills every cell and raises *guard -- the host then repeats the batch the exact way.
+    // pools hold suppCap entries sized from the segment's average, the generic kernels are launched or not
+    // (genericLaunched) by what earlier segments needed, and a sharded cohort selects its support percentiles on
+    // x - min(pool) with TWO exchanged digit passes (rangeSelect). suppScanKernel checks the first two against the real
+    // counts and publishes the verdict in the header of the context's xch chunk, which travels with the first exchange:
+    // cellInitFinishKernel kills every cell if ANY context's check failed; suppRangeKernel does the same if a pool spans
+    // 2^16 positions or more. Either raises *guard -- the host (every host of a sharded cohort, they see the same) then
+    // repeats the batch the exact way.
     uint64_t    suppCap;
     unsigned    genericLaunched;
+    unsigned    rangeSelect;
     unsigned *  guard;
     // parameters
     unsigned *  iterFlags;   // [maxIterations + 1]: 1 if any cell was still iterating after EM iteration i
@@ -267,14 +280,34 @@ struct Stage2Buffers
     int         windowWise;
 };
 
+constexpr unsigned kXchHeaderDoubles = 8;
+
+__device__ __forceinline__ unsigned * rankHeader(const Stage2Buffers & b, unsigned r)
+{
+    return reinterpret_cast<unsigned *>(b.xch + (size_t)r * b.xchChunk);
+}
+__device__ __forceinline__ unsigned * counterSlot(const Stage2Buffers & b, unsigned r, unsigned c)
+{
+    return reinterpret_cast<unsigned *>(b.xch + (size_t)r * b.xchChunk + kXchHeaderDoubles) + (size_t)c * 4;
+}
+__device__ __forceinline__ unsigned * poolSlot(const Stage2Buffers & b, unsigned r, unsigned c, unsigned pool)
+{
+    return reinterpret_cast<unsigned *>(b.xch + (size_t)r * b.xchChunk + kXchHeaderDoubles + (size_t)b.nCells * 2) +
+           ((size_t)c * 2 + pool) * 4;
+}
 __device__ __forceinline__ double * tileSlot(const Stage2Buffers & b, unsigned c, unsigned t)
 {
     const unsigned r = t / b.tilesPerRank, lt = t - r * b.tilesPerRank;
-    return b.xch + (size_t)r * b.xchChunk + ((size_t)lt * b.nCells + c) * 4;
+    return b.xch + (size_t)r * b.xchChunk + kXchHeaderDoubles + (size_t)b.nCells * 6 + ((size_t)lt * b.nCells + c) * 4;
 }
 __device__ __forceinline__ double * rg0Slot(const Stage2Buffers & b, unsigned c, unsigned r)
 {
-    return b.xch + (size_t)r * b.xchChunk + ((size_t)b.tilesPerRank * b.nCells + c) * 4;
+    return b.xch + (size_t)r * b.xchChunk + kXchHeaderDoubles + (size_t)b.nCells * 6 + ((size_t)b.tilesPerRank * b.nCells + c) * 4;
+}
+// doubles per context in the area
+inline size_t xchChunkDoubles(unsigned tilesPerRank, unsigned nCells)
+{
+    return kXchHeaderDoubles + (size_t)nCells * 6 + ((size_t)tilesPerRank + 1) * nCells * 4;
 }
 
 }  // namespace pd

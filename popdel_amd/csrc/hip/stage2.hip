@@ -578,8 +578,10 @@ __global__ __launch_bounds__(1024) void clusterKernel(ClusterInput in, int unifo
 
 // The flagged windows of a segment in ascending order (one workgroup): hdr[0] = their number (also if the list, which
 // holds `cap`, is too short for them).
-__global__ __launch_bounds__(1024) void compactFlaggedKernel(const int * __restrict__ winFlag, unsigned W, unsigned cap,
-                                                            int * __restrict__ flagged, unsigned * __restrict__ hdr)
+// winFlag: `world` rows `rowStride` ints apart (the contexts' window flags after their exchange; one row if unsharded).
+__global__ __launch_bounds__(1024) void compactFlaggedKernel(const int * __restrict__ winFlag, unsigned W, unsigned world,
+                                                            size_t rowStride, unsigned cap, int * __restrict__ flagged,
+                                                            unsigned * __restrict__ hdr)
 {
     __shared__ unsigned perWave[16];
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -587,7 +589,10 @@ __global__ __launch_bounds__(1024) void compactFlaggedKernel(const int * __restr
     for (unsigned base = 0; base < W; base += 1024u)
     {
         const unsigned w = base + threadIdx.x;
-        const bool v = w < W && winFlag[w] != 0;
+        bool v = false;
+        if (w < W)
+            for (unsigned r = 0; r < world; ++r)
+                v = v || winFlag[r * rowStride + w] != 0;
         const unsigned long long bal = __ballot(v);
         if (lane == 0)
             perWave[wave] = (unsigned)__popcll(bal);
@@ -843,7 +848,7 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
     // every cell of the image: its own hits, the image's usable pairs and low-coverage samples
     for (unsigned q = threadIdx.x; q < nc; q += blockDim.x)
     {
-        unsigned * mine = b.counters + ((size_t)b.rank * b.nCells + cell0 + q) * 4;
+        unsigned * mine = counterSlot(b, b.rank, cell0 + q);
         if (acc[2u + q])
             atomicAdd(&mine[0], acc[2u + q]);
         if (acc[0])
@@ -864,23 +869,79 @@ __global__ __launch_bounds__(kGatherThreads) void cellGatherKernel(SegmentView s
     }
 }
 
+// Exclusive scan of the support capacities of this context's own pools (one workgroup, 256 cells per round), and the
+// check of an optimistic launch (Stage2Buffers::guard): the verdict goes into the header of the context's xch chunk and
+// travels with the first exchange.
+__global__ __launch_bounds__(256) void suppScanKernel(Stage2Buffers b)
+{
+    __shared__ uint64_t sh[256];
+    uint64_t carry = 0;
+    for (unsigned base = 0; base < b.nCells; base += 256u)
+    {
+        const unsigned c = base + threadIdx.x;
+        const uint64_t v = c < b.nCells ? counterSlot(b, b.rank, c)[1] : 0u;      // usable pairs of this context's samples
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (unsigned o = 1; o < 256u; o <<= 1)
+        {
+            const uint64_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (c < b.nCells)
+        {
+            b.cells[c].suppCapacity = (unsigned)v;
+            b.cells[c].suppBase = carry + sh[threadIdx.x] - v;
+        }
+        carry += sh[255];
+        __syncthreads();
+    }
+    if (b.guard == nullptr)
+        return;
+    // launched ahead of the host's look at the counts: do the pools hold, are the generic kernels there if needed?
+    __shared__ unsigned bad;
+    if (threadIdx.x == 0)
+        bad = carry > b.suppCap ? 1u : 0u;
+    __syncthreads();
+    if (!b.genericLaunched)
+        for (unsigned c = threadIdx.x; c < b.nCells; c += 256u)
+            if (counterSlot(b, b.rank, c)[3] != 0u)
+                atomicOr(&bad, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        rankHeader(b, b.rank)[0] = bad;
+}
+
+__device__ __forceinline__ void loopHead(CellState & cs, const Stage2Buffers & b);
+
+// After the first exchange: first allele-frequency estimate from the integer counts of all contexts (reference :93-133),
+// then the head of the first EM iteration. If the optimistic launch failed in ANY context, every cell dies here.
 __global__ void cellInitFinishKernel(Stage2Buffers b)
 {
     const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= b.nCells)
         return;
     CellState & cs = b.cells[c];
-    unsigned count = 0, total = 0, low = 0;
+    unsigned count = 0, total = 0, low = 0, bad = 0;
     for (unsigned r = 0; r < b.world; ++r)
     {
-        const unsigned * k = b.counters + ((size_t)r * b.nCells + c) * 4;
+        const unsigned * k = counterSlot(b, r, c);
         count += k[0];
         total += k[1];
         low += k[2];
+        bad |= rankHeader(b, r)[0];
+    }
+    if (b.guard != nullptr && bad)
+    {
+        cs.phase = kCellDead;
+        if (c == 0)
+            *b.guard = 1u;
+        return;
     }
     cs.lowCovSamples = low;
-    cs.suppCapacity = b.counters[((size_t)b.rank * b.nCells + c) * 4 + 1];     // pool of this context's own samples
     cs.suppCount = 0;
+    cs.selPrefix[0] = cs.selPrefix[1] = cs.selK[0] = cs.selK[1] = cs.selLo[0] = cs.selLo[1] = 0;
     double freq = (total == 0u) ? 0.0 : (double)count / total;
     cs.freq = freq;
     cs.len = (unsigned)cs.initLen;
@@ -899,55 +960,13 @@ __global__ void cellInitFinishKernel(Stage2Buffers b)
     cs.prevGt[1] = cs.gt[1];
     cs.prevGt[2] = cs.gt[2];
     cs.phase = kCellIterating;
-}
-
-// Exclusive scan of the support capacities (one workgroup, 256 cells per round).
-__global__ __launch_bounds__(256) void suppScanKernel(Stage2Buffers b)
-{
-    __shared__ uint64_t sh[256];
-    uint64_t carry = 0;
-    for (unsigned base = 0; base < b.nCells; base += 256u)
-    {
-        const unsigned c = base + threadIdx.x;
-        const uint64_t v = c < b.nCells ? b.cells[c].suppCapacity : 0u;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (unsigned o = 1; o < 256u; o <<= 1)
-        {
-            const uint64_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (c < b.nCells)
-            b.cells[c].suppBase = carry + sh[threadIdx.x] - v;
-        carry += sh[255];
-        __syncthreads();
-    }
-    if (b.guard == nullptr)
-        return;
-    // launched ahead of the host's look at the counts: do the pools hold, are the generic kernels there if needed?
-    __shared__ unsigned bad;
-    if (threadIdx.x == 0)
-        bad = carry > b.suppCap ? 1u : 0u;
-    __syncthreads();
-    if (!b.genericLaunched)
-        for (unsigned c = threadIdx.x; c < b.nCells; c += 256u)
-            if (b.counters[((size_t)b.rank * b.nCells + c) * 4 + 3] != 0u)
-                atomicOr(&bad, 1u);
-    __syncthreads();
-    if (bad)
-    {
-        for (unsigned c = threadIdx.x; c < b.nCells; c += 256u)
-            b.cells[c].phase = kCellDead;
-        if (threadIdx.x == 0)
-            *b.guard = 1u;
-    }
+    loopHead(cs, b);                        // head of the first iteration
 }
 
 // =====================================================================================================================
 // Data likelihoods of one sample given (len, reference shifts), EM flavour (reference :179-253).
-// mode 0: current estimate (cells in kCellIterating); mode 1: previous estimate with zero shifts (kCellConverged).
+// mode 0: current estimate (cells in kCellIterating); mode 1: previous estimate with zero shifts (kCellConverged);
+// mode 2: the evaluation ahead of the loop -- like 0, but the cell's priors do not exist yet and no term is formed.
 // Also accumulates the per-sample term of the allele-frequency update with the cell's current priors.
 // =====================================================================================================================
 __device__ __forceinline__ void finishTriple(double * d, const double * logL, unsigned nUsed, bool allRefEqDel)
@@ -986,11 +1005,11 @@ __global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, Co
     const unsigned cellIdx = PD_CELL_IDX;
     [[maybe_unused]] const unsigned imgIdx = b.cells[cellIdx].image;          // dense image of the cell's window
     CellState & cs = b.cells[cellIdx];
-    const int wantPhase = mode == 0 ? kCellIterating : kCellConverged;
-    if (cs.phase != wantPhase || b.tileMode[(size_t)imgIdx * b.ownTiles + PD_TILE_IDX] != kTileGeneric)
+    const int wantPhase = mode == 1 ? kCellConverged : kCellIterating;
+    if ((mode != 2 && cs.phase != wantPhase) || b.tileMode[(size_t)imgIdx * b.ownTiles + PD_TILE_IDX] != kTileGeneric)
         return;
     const unsigned w = (unsigned)cs.window;
-    const int len = (int)(mode == 0 ? cs.len : cs.prevLen);
+    const int len = mode == 2 ? cs.initLen : (int)(mode == 1 ? cs.prevLen : cs.len);
     const unsigned hl = threadIdx.x & 31u, half = threadIdx.x >> 5;
     __shared__ SampleMeta shMeta[kSamplesPerBlock];
     loadTileMeta(seg, co, w, shMeta, PD_TILE_IDX);
@@ -1010,7 +1029,7 @@ __global__ __launch_bounds__(kSampleTile) void dataLikKernel(SegmentView seg, Co
             RgConst rc;
             PairRange r;
             rgOfSample(meta, seg, co, w, rg, rc, r);
-            const int refShift = (mode == 0) ? b.shifts[(size_t)cellIdx * co.nRg + rg] : 0;
+            const int refShift = (mode != 1) ? b.shifts[(size_t)cellIdx * co.nRg + rg] : 0;
             double g0 = 0, g1 = 0, g2 = 0;
             bool eq = true;
             const unsigned n = halfForEachActive<false>(r, w, hl, rc.maxLoad, shDev[half], nullptr, [&](int dv, unsigned) {
@@ -1146,10 +1165,10 @@ __global__ __launch_bounds__(kSampleTile) void dataLikDenseKernel(CohortView co,
     const unsigned cellIdx = PD_CELL_IDX;
     [[maybe_unused]] const unsigned imgIdx = b.cells[cellIdx].image;          // dense image of the cell's window
     const CellState & cs = b.cells[cellIdx];
-    const int wantPhase = mode == 0 ? kCellIterating : kCellConverged;
-    if (cs.phase != wantPhase || b.tileMode[(size_t)imgIdx * b.ownTiles + PD_TILE_IDX] != 0)
+    const int wantPhase = mode == 1 ? kCellConverged : kCellIterating;
+    if ((mode != 2 && cs.phase != wantPhase) || b.tileMode[(size_t)imgIdx * b.ownTiles + PD_TILE_IDX] != 0)
         return;
-    const int len = (int)(mode == 0 ? cs.len : cs.prevLen);
+    const int len = mode == 2 ? cs.initLen : (int)(mode == 1 ? cs.prevLen : cs.len);
     const unsigned s = PD_TILE_IDX * kSamplesPerBlock + threadIdx.x;
     const bool valid = s < co.nSamples;
     const size_t wtGlobal = (size_t)imgIdx * (b.ownTiles * 4) + PD_TILE_IDX * 4 + (threadIdx.x >> 6);
@@ -1164,7 +1183,7 @@ __global__ __launch_bounds__(kSampleTile) void dataLikDenseKernel(CohortView co,
         rg = co.sampleRg[s];
         l = laneRg(co.rg[rg]);
         n = b.cellN[(size_t)imgIdx * co.nSamples + s];
-        refShift = (mode == 0) ? b.shifts[(size_t)cellIdx * co.nRg + rg] : 0;
+        refShift = (mode != 1) ? b.shifts[(size_t)cellIdx * co.nRg + rg] : 0;
     }
     const bool highCov = n == kDenseHighCov;
     const unsigned nn = highCov ? 0u : n;
@@ -1263,14 +1282,6 @@ __device__ __forceinline__ void loopHead(CellState & cs, const Stage2Buffers & b
     cs.prevGt[0] = cs.gt[0];
     cs.prevGt[1] = cs.gt[1];
     cs.prevGt[2] = cs.gt[2];
-}
-
-// The head of the first iteration; the heads of the following ones run at the end of cellFreqFinishKernel.
-__global__ void cellLoopHeadKernel(Stage2Buffers b)
-{
-    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < b.nCells)
-        loopHead(b.cells[c], b);
 }
 
 // New reference shift of one read group (genotype_deletion_popdel_call.h:447-451): the weighted mean deviation of its
@@ -2118,7 +2129,7 @@ __global__ __launch_bounds__(kGatherThreads) void multiGatherKernel(SegmentView 
         if (halfCount(farStart) != 0u && hl == 0)          // cannot be represented here: the tile goes to the generic kernels
         {
             atomicMax(&b.tileMode[(size_t)imgIdx * b.ownTiles + b.mt.tile[mtI]], (unsigned)kTileGeneric);
-            atomicAdd(&b.counters[((size_t)b.rank * b.nCells + cellIdx) * 4 + 3], 1u);
+            atomicAdd(&counterSlot(b, b.rank, cellIdx)[3], 1u);
         }
         const unsigned nDense = (n >= co.rg[rg].maxLoad) ? kDenseHighCov : n;   // n <= kDenseCap otherwise (else: kTileGeneric)
         if (hl == 0)
@@ -2157,10 +2168,10 @@ __global__ __launch_bounds__(kSampleTile) void dataLikMultiKernel(CohortView co,
     const unsigned cellIdx = blockIdx.y, mtI = blockIdx.x, tileIdx = b.mt.tile[mtI];
     const unsigned imgIdx = b.cells[cellIdx].image;
     const CellState & cs = b.cells[cellIdx];
-    const int wantPhase = mode == 0 ? kCellIterating : kCellConverged;
-    if (cs.phase != wantPhase || b.tileMode[(size_t)imgIdx * b.ownTiles + tileIdx] != kTileMulti)
+    const int wantPhase = mode == 1 ? kCellConverged : kCellIterating;
+    if ((mode != 2 && cs.phase != wantPhase) || b.tileMode[(size_t)imgIdx * b.ownTiles + tileIdx] != kTileMulti)
         return;
-    const int len = (int)(mode == 0 ? cs.len : cs.prevLen);
+    const int len = mode == 2 ? cs.initLen : (int)(mode == 1 ? cs.prevLen : cs.len);
     const unsigned rgLo = b.mt.rgLo[mtI], rgHi = b.mt.rgHi[mtI];
     // phase 1: one lane per read group
     for (unsigned base = rgLo; base < rgHi; base += kSampleTile)
@@ -2177,7 +2188,7 @@ __global__ __launch_bounds__(kSampleTile) void dataLikMultiKernel(CohortView co,
         {
             l = laneRg(co.rg[rg]);
             n = b.mN[(size_t)imgIdx * b.nRg + rg];
-            refShift = (mode == 0) ? b.shifts[(size_t)cellIdx * co.nRg + rg] : 0;
+            refShift = (mode != 1) ? b.shifts[(size_t)cellIdx * co.nRg + rg] : 0;
         }
         const bool highCov = n == kDenseHighCov;
         const unsigned nn = highCov ? 0u : n;
@@ -2612,9 +2623,88 @@ __global__ __launch_bounds__(kSampleTile) void finalMultiKernel(CohortView co, S
     b.fl[o * 2 + 1] = mx;
 }
 
-// Percentiles of the support pools (reference :514-529) by 4 x 8-bit radix selection. The pool of a cell is spread over
-// the contexts of a sharded cohort, so every pass is: digit histogram of the own pool (suppHistKernel) -> exchange ->
-// sum of the histograms, pick the digit (suppPickKernel). Pool 0: pair starts (80th percentile), pool 1: pair ends (20th).
+// Percentiles of the support pools (reference :514-529) by 8-bit radix selection. The pool of a cell is spread over the
+// contexts of a sharded cohort, so every pass is: digit histogram of the own pool (suppHistKernel) -> exchange -> sum of
+// the histograms, pick the digit (suppPickKernel). Pool 0: pair starts (80th percentile), pool 1: pair ends (20th).
+// Two flavours. Exact: four passes over the raw values. Range-limited (Stage2Buffers::rangeSelect, the rule): the pool
+// holds positions of one deletion's supporting pairs, a few thousand bases wide, so the contexts first exchange
+// {min, max, count} of their pools (suppMinMaxKernel; the record rides in the xch area together with the likelihood-ratio
+// sums of the final estimate), and the selection runs on x - min over the two low bytes only: three exchanges instead of
+// five. A pool that spans 2^16 positions or more raises the guard and the batch is repeated the exact way.
+__global__ __launch_bounds__(256) void suppMinMaxKernel(Stage2Buffers b)
+{
+    __shared__ unsigned shLo[4], shHi[4];
+    const unsigned c = blockIdx.x, pool = blockIdx.y;
+    const CellState & cs = b.cells[c];
+    unsigned * out = poolSlot(b, b.rank, c, pool);
+    const unsigned n = cs.phase == kCellFinal ? cs.suppCount : 0u;
+    unsigned lo = 0xffffffffu, hi = 0;
+    const unsigned * v = (pool == 0 ? b.suppFirst : b.suppLast) + cs.suppBase;
+    for (unsigned i0 = threadIdx.x; i0 < n; i0 += 8u * blockDim.x)
+    {
+        unsigned x[8];
+#pragma unroll
+        for (unsigned u = 0; u < 8; ++u)
+            x[u] = (i0 + u * blockDim.x < n) ? v[i0 + u * blockDim.x] : v[i0];
+#pragma unroll
+        for (unsigned u = 0; u < 8; ++u)
+        {
+            lo = min(lo, x[u]);
+            hi = max(hi, x[u]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+    {
+        lo = min(lo, (unsigned)__shfl_xor((int)lo, o, 64));
+        hi = max(hi, (unsigned)__shfl_xor((int)hi, o, 64));
+    }
+    if ((threadIdx.x & 63u) == 0)
+    {
+        shLo[threadIdx.x >> 6] = lo;
+        shHi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        out[0] = min(min(shLo[0], shLo[1]), min(shLo[2], shLo[3]));
+        out[1] = max(max(shHi[0], shHi[1]), max(shHi[2], shHi[3]));
+        out[2] = n;
+        out[3] = 0;
+    }
+}
+
+// After the exchange of the pool records: cohort-wide minimum, count and rank of the percentile per pool.
+__global__ void suppRangeKernel(Stage2Buffers b)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= b.nCells)
+        return;
+    CellState & cs = b.cells[c];
+    if (cs.phase != kCellFinal)
+        return;
+    for (unsigned pool = 0; pool < 2; ++pool)
+    {
+        unsigned lo = 0xffffffffu, hi = 0, n = 0;
+        for (unsigned r = 0; r < b.world; ++r)
+        {
+            const unsigned * p = poolSlot(b, r, c, pool);
+            if (p[2] == 0)
+                continue;
+            lo = min(lo, p[0]);
+            hi = max(hi, p[1]);
+            n += p[2];
+        }
+        if (pool == 0)
+            cs.suppCapacity = n;                           // cohort-wide number of supporting pairs (parked here)
+        cs.selPrefix[pool] = 0;
+        cs.selLo[pool] = n ? lo : 0u;
+        cs.selK[pool] = n ? (unsigned)round((double)(n - 1) * (pool == 0 ? 0.8 : (1 - 0.8))) : 0u;
+        if (n != 0 && hi - lo >= 65536u && b.guard != nullptr)
+            *b.guard = 1u;                                 // (every context sees the same records and does the same)
+    }
+}
+
 __global__ __launch_bounds__(256) void suppHistKernel(Stage2Buffers b, int pass)
 {
     __shared__ unsigned hist[256];
@@ -2625,12 +2715,12 @@ __global__ __launch_bounds__(256) void suppHistKernel(Stage2Buffers b, int pass)
     hist[threadIdx.x] = 0;
     __syncthreads();
     const unsigned * v = (pool == 0 ? b.suppFirst : b.suppLast) + cs.suppBase;
-    const unsigned n = cs.suppCount;                       // own pool; replaced by the cohort-wide count after pass 0
+    const unsigned n = cs.suppCount;                       // own pool; replaced by the cohort-wide count by suppFinishKernel
     const int shift = pass * 8;
-    const unsigned mask = pass == 3 ? 0u : (0xffffffffu << (shift + 8)), prefix = cs.selPrefix[pool];
+    const unsigned mask = pass == 3 ? 0u : (0xffffffffu << (shift + 8)), prefix = cs.selPrefix[pool], lo = cs.selLo[pool];
     for (unsigned i = threadIdx.x; i < n; i += blockDim.x)
     {
-        const unsigned x = v[i];
+        const unsigned x = v[i] - lo;
         if ((x & mask) == prefix)
             atomicAdd(&hist[(x >> shift) & 255u], 1u);
     }
@@ -2638,7 +2728,9 @@ __global__ __launch_bounds__(256) void suppHistKernel(Stage2Buffers b, int pass)
     b.selHist[(((size_t)b.rank * b.nCells + c) * 2 + pool) * 256 + threadIdx.x] = hist[threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void suppPickKernel(Stage2Buffers b, int pass)
+// `first`: this is the first pass of the exact flavour -- the histogram also yields the cohort-wide count and with it the
+// rank of the percentile (the range-limited flavour has both from suppRangeKernel).
+__global__ __launch_bounds__(256) void suppPickKernel(Stage2Buffers b, int pass, int first)
 {
     __shared__ unsigned hist[256];
     const unsigned c = blockIdx.x, pool = blockIdx.y;
@@ -2653,7 +2745,7 @@ __global__ __launch_bounds__(256) void suppPickKernel(Stage2Buffers b, int pass)
     if (threadIdx.x != 0)
         return;
     unsigned k = cs.selK[pool];
-    if (pass == 3)
+    if (first)
     {
         unsigned n = 0;
         for (int d = 0; d < 256; ++d)
@@ -2798,8 +2890,8 @@ __global__ void suppFinishKernel(Stage2Buffers b)
     if (cs.phase != kCellFinal)
         return;
     cs.suppCount = cs.suppCapacity;
-    cs.suppStart = cs.suppCount ? cs.selPrefix[0] : 0u;
-    cs.suppEnd = cs.suppCount ? cs.selPrefix[1] : 0u;
+    cs.suppStart = cs.suppCount ? cs.selLo[0] + cs.selPrefix[0] : 0u;
+    cs.suppEnd = cs.suppCount ? cs.selLo[1] + cs.selPrefix[1] : 0u;
 }
 
 // Likelihood-ratio test and call emission (reference :685-724).
@@ -2888,9 +2980,10 @@ void launchPackFlagged(const int32_t * q3, const uint8_t * flags, const int * fl
                        nLocal, in, rank);
 }
 
-void launchCompactFlagged(const int * winFlag, unsigned W, unsigned cap, int * flagged, unsigned * hdr, hipStream_t st)
+void launchCompactFlagged(const int * winFlag, unsigned W, unsigned world, size_t rowStride, unsigned cap, int * flagged,
+                          unsigned * hdr, hipStream_t st)
 {
-    hipLaunchKernelGGL(compactFlaggedKernel, dim3(1), dim3(1024), 0, st, winFlag, W, cap, flagged, hdr);
+    hipLaunchKernelGGL(compactFlaggedKernel, dim3(1), dim3(1024), 0, st, winFlag, W, world, rowStride, cap, flagged, hdr);
 }
 
 void launchListCells(const int * flagged, const int * candLen, const int * candCount, unsigned cap, unsigned listCap,
@@ -2940,25 +3033,23 @@ void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch,
                        candCount);
 }
 
-// Phase A: first allele-frequency estimate and support-pool capacities (the host sizes the pools from them).
-// The caller has cleared counters, xch, shifts, tileMode and iterFlags[0 .. maxIterations] (one launchZero).
-void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
-                   hipStream_t st)
+// Phase A: the dense images of the cells' active pairs and the integer counts (own samples) in the context's xch chunk.
+// The caller has cleared the xch area, shifts, tileMode and iterFlags[0 .. maxIterations + 1] (one launchZero).
+void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st)
 {
     if (b.nCells == 0)
         return;
-    const dim3 perCell((b.nCells + 127) / 128), cellBlock(128);
     hipLaunchKernelGGL(cellGatherKernel, dim3(b.ownTiles * 4, b.nImages), dim3(kGatherThreads), 0, st, seg, co, b, flags);
     if (b.mt.n != 0)
         hipLaunchKernelGGL(multiGatherKernel, dim3(b.mt.nWaves, b.nImages), dim3(kGatherThreads), 0, st, seg, co, b);
-    x.allGather(b.counters, (size_t)b.nCells * 4 * sizeof(unsigned));
-    hipLaunchKernelGGL(cellInitFinishKernel, perCell, cellBlock, 0, st, b);
-    hipLaunchKernelGGL(suppScanKernel, dim3(1), dim3(256), 0, st, b);
 }
 
-// Phase B: EM loop, convergence comparison, final pass, support percentiles, likelihood-ratio test.
-// Every context of a sharded cohort runs the same sequence; the per-cell kernels see identical inputs everywhere
-// (all-gathered per-tile sums), so all contexts take the same decisions, including the early exit below.
+// Phase B: first allele-frequency estimate, EM loop, convergence comparison, final pass, support percentiles,
+// likelihood-ratio test. Every context of a sharded cohort runs the same sequence; the per-cell kernels see identical
+// inputs everywhere (all-gathered per-tile sums), so all contexts take the same decisions, including the early exit.
+// Exchanges of a sharded cohort (the xch area travels as a whole each time): counts + read group 0's first record | two
+// per EM iteration | both likelihood-ratio evaluations of the converged cells | pool records + the final estimate's
+// likelihood-ratio sums | two digit histograms (four, without the pool records' range, in the exact flavour).
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
                    bool anyGenericTile, unsigned * pinnedWord, hipStream_t st)
 {
@@ -2987,9 +3078,13 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
         if (anyGenericTile)
             hipLaunchKernelGGL(dataLikKernel, perSample, tile, 0, st, seg, co, b, mode);
     };
-    dataLik(0);
+    // pool bases (and the check of an optimistic launch) from the own counts; the likelihoods ahead of the loop do not
+    // depend on the first frequency estimate: they run before the counts are exchanged, and read group 0's record
+    // travels with them
+    hipLaunchKernelGGL(suppScanKernel, dim3(1), dim3(256), 0, st, b);
+    dataLik(2);
     x.allGather(b.xch, xchBytes);
-    hipLaunchKernelGGL(cellLoopHeadKernel, perCell, cellBlock, 0, st, b);
+    hipLaunchKernelGGL(cellInitFinishKernel, perCell, cellBlock, 0, st, b);
     for (unsigned it = 0; it < b.maxIterations; ++it)
     {
         hipLaunchKernelGGL(updateLenDenseKernel, perSample, tile, 0, st, co, b);
@@ -3003,8 +3098,9 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
         x.allGather(b.xch, xchBytes);
         hipLaunchKernelGGL(cellFreqFinishKernel, wavePerCell, dim3(64), 0, st, b, it);
         // Most cells leave the loop after 2-4 iterations: look at the "someone is still iterating" flag now and then
-        // instead of launching the remaining (empty) iterations (a look costs a round trip of ~50 us, an empty iteration ~20).
-        if (it == 3 || it == 5 || it == 8 || it == 11)
+        // instead of launching the remaining (empty) iterations (a look costs a round trip of ~50 us, an empty iteration ~20
+        // -- plus two exchanges in a sharded cohort, which therefore looks after every iteration from the second on).
+        if (it == 3 || it == 5 || it == 8 || it == 11 || (b.sharded && it >= 1))
         {
             *pinnedWord = 1;                               // page-locked: no bounce copy for four bytes
             (void)hipMemcpyAsync(pinnedWord, b.iterFlags + it, sizeof(unsigned), hipMemcpyDeviceToHost, st);
@@ -3025,22 +3121,29 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
         hipLaunchKernelGGL(finalMultiKernel, perMulti, tile, 0, st, co, b, flags, seg.nWindows, seg.firstPos, seg.shift);
     if (anyGenericTile)
         hipLaunchKernelGGL(finalKernel, perSample, tile, 0, st, seg, co, b, flags);
-    if (b.world == 1)
+    // the likelihood-ratio sums of the final estimate need the final pass only: they are formed now and travel with the
+    // first exchange of the percentile selection
+    hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellFinal, 0);
+    if (!b.sharded)
     {
         hipLaunchKernelGGL(suppSelectLocalKernel, dim3(b.nCells, 2), dim3(256), 0, st, b);
     }
     else
     {
-        for (int pass = 3; pass >= 0; --pass)
+        if (b.rangeSelect)
+            hipLaunchKernelGGL(suppMinMaxKernel, dim3(b.nCells, 2), dim3(256), 0, st, b);
+        x.allGather(b.xch, xchBytes);
+        if (b.rangeSelect)
+            hipLaunchKernelGGL(suppRangeKernel, perCell, cellBlock, 0, st, b);
+        const int topPass = b.rangeSelect ? 1 : 3;
+        for (int pass = topPass; pass >= 0; --pass)
         {
             hipLaunchKernelGGL(suppHistKernel, dim3(b.nCells, 2), dim3(256), 0, st, b, pass);
             x.allGather(b.selHist, (size_t)b.nCells * 2 * 256 * sizeof(unsigned));
-            hipLaunchKernelGGL(suppPickKernel, dim3(b.nCells, 2), dim3(256), 0, st, b, pass);
+            hipLaunchKernelGGL(suppPickKernel, dim3(b.nCells, 2), dim3(256), 0, st, b, pass, (!b.rangeSelect && pass == 3) ? 1 : 0);
         }
         hipLaunchKernelGGL(suppFinishKernel, perCell, cellBlock, 0, st, b);
     }
-    hipLaunchKernelGGL(lrKernel, perSample, tile, 0, st, co, b, (int)kCellFinal, 0);
-    x.allGather(b.xch, xchBytes);
     hipLaunchKernelGGL(cellEmitKernel, wavePerCell, dim3(64), 0, st, b);
 }
 

@@ -111,10 +111,19 @@ class SampleShardExchange:
 
 
 class NativeExchangeStats:
-    """Placeholder with the counters of SampleShardExchange: the library does not report its own collectives."""
-    calls = 0
-    bytes = 0
-    last_error = None
+    """The counters of SampleShardExchange for a context whose exchanges the library runs itself (RCCL): read from
+    ``pd_timing`` after every collect (``SampleShard.run`` calls ``update``)."""
+
+    def __init__(self):
+        self.calls = 0
+        self.bytes = 0
+        self.exchange_ms = 0.0
+        self.last_error = None
+
+    def update(self, timing):
+        self.calls += int(timing["n_all_gathers"])
+        self.bytes += int(timing["all_gather_bytes"])
+        self.exchange_ms += float(timing["exchange_ms"])
 
 
 class SampleShard:
@@ -167,7 +176,10 @@ class SampleShard:
         """Collective: every rank calls it with its part of the same segment. Returns the calls of the whole cohort with
         the per-sample columns of this rank's samples."""
         try:
-            return self.ctx.collect(self.ctx.submit(local_seg))
+            out = self.ctx.collect(self.ctx.submit(local_seg))
+            if self.native:
+                self.exchange.update(self.ctx.timing())
+            return out
         except Exception:
             if self.exchange.last_error is not None:
                 raise self.exchange.last_error

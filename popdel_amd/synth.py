@@ -216,17 +216,29 @@ def dense_deletions(k, region):
     return [Deletion(lo + 10000 + 20000 * j, 300 + 97 * j, [1, 2, 0, 0][(k + j) % 4]) for j in range(49)]
 
 
+def _write_cohort_part(args):
+    outdir, ks, region, deletions, lib, compressed, seed_base = args
+    for k in ks:
+        pos, dev = sample_pairs(seed_base + k, region, lib, deletions(k, region) if deletions else ())
+        write_profile(os.path.join(outdir, "s%05d.profile" % k), "RG%05d" % k, pos, dev, lib, compressed=compressed)
+    return len(ks)
+
+
 def write_cohort(outdir, n_samples, region=(1000000, 2000000), deletions=single_deletion, lib: Library | None = None,
-                 compressed=True, seed_base=1000):
-    """Write ``n_samples`` profiles plus ``profiles.txt``; returns the list file path."""
+                 compressed=True, seed_base=1000, workers=1):
+    """Write ``n_samples`` profiles plus ``profiles.txt``; returns the list file path. ``workers`` > 1 writes the
+    profiles from that many forked processes (``deletions`` must then be a module-level function)."""
     lib = lib or Library()
     os.makedirs(outdir, exist_ok=True)
-    paths = []
-    for k in range(n_samples):
-        pos, dev = sample_pairs(seed_base + k, region, lib, deletions(k, region) if deletions else ())
-        p = os.path.join(outdir, "s%05d.profile" % k)
-        write_profile(p, "RG%05d" % k, pos, dev, lib, compressed=compressed)
-        paths.append(p)
+    paths = [os.path.join(outdir, "s%05d.profile" % k) for k in range(n_samples)]
+    workers = max(1, min(int(workers), n_samples))
+    parts = [(outdir, list(range(w, n_samples, workers)), region, deletions, lib, compressed, seed_base) for w in range(workers)]
+    if workers == 1:
+        _write_cohort_part(parts[0])
+    else:
+        import multiprocessing
+        with multiprocessing.get_context("fork").Pool(workers) as pool:
+            pool.map(_write_cohort_part, parts)
     lst = os.path.join(outdir, "profiles.txt")
     with open(lst, "w") as fh:
         fh.write("\n".join(paths) + "\n")

@@ -30,10 +30,10 @@ seg = capi.Segment(first, W, offsets, arrays["dev"], arrays["start"], arrays["on
 ctx = capi.Context(hip, [rg] * S, list(range(S + 1)), device=0)
 h = ctx.stage(seg)
 lane = bench.Lane(ctx, h)
-lane.passes(5, [0.0, 0.0, 0, 0, None])
+lane.passes(5, bench.new_acc())
 torch.cuda.synchronize()
 for rep in range(2):
-    acc = [0.0, 0.0, 0, 0, None]
+    acc = bench.new_acc()
     t0 = time.perf_counter()
     lane.passes(200, acc)
     torch.cuda.synchronize()
