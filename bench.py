@@ -251,9 +251,20 @@ def main():
         sys.exit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to print a line whose "
                  "n_gpus would not be what was asked for" % (args.gpus, world))
 
+    # The one JSON line goes to the REAL stdout; everything else any library prints there (RCCL announces its version on
+    # stdout when a communicator is created) is sent to stderr for the lifetime of the process.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     from popdel_amd import capi, distributed, synth
+
+    t_bench0 = time.perf_counter()
+
+    def progress(msg):
+        print("[bench %7.1f s] %s" % (time.perf_counter() - t_bench0, msg), file=sys.stderr, flush=True)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -359,7 +370,7 @@ def main():
                 return False
             emitted.append(True)
             if rank == 0:
-                print(json.dumps(line), flush=True)
+                print(json.dumps(line), file=real_stdout, flush=True)
             return True
 
     def assemble(legs):
@@ -419,7 +430,11 @@ def main():
             # would be cells_per_pass / (stage_seconds + pass time): reported, never `value`
             "staging_seconds_per_segment": stage_seconds,
             "pcie_inclusive_value": (W * S) / (stage_seconds + seg_split["ms_per_step"] / 1e3 / max(1, my_passes)),
-            "roofline": roofline}
+            "roofline": roofline,
+            # the WHOLE hot path against the roofline SURVEY 8(d) states for it: value x algorithmic bytes per unit / HBM peak
+            # per GPU (the scan's own figure is roofline.frac)
+            "whole_path_frac": h["value"] * (alg_bytes / cells) / (HBM_PEAK_GBS * 1e9 * world),
+            "algorithmic_bytes_per_unit": alg_bytes / cells}
         if h["fallback"]:
             line["headline_fallback"] = h["fallback"]
         line.update(legs)
@@ -427,22 +442,36 @@ def main():
 
     headline["cohort_local"] = S
     headline["windows_per_step"] = total_passes * W * world
+    progress("headline (one context per rank) measured")
     legs = {}
 
     # ---- N > 1 headline: ONE cohort of world x S samples sharded by samples (collectives in the data path) ------------
     if is_dist:
         legs["segment_sharded"] = seg_split
 
+        progress = {"headline_done": False}
+
         def give_up():
+            if progress["headline_done"]:
+                # the headline stands; a configs3 / configs4 leg hangs (its collectives no longer match across the ranks)
+                legs.setdefault("configs_legs_timeout", "a configs3/configs4 leg did not finish within %.0f s" % args.sharded_timeout)
+                if emit(assemble(legs)):
+                    sys.stdout.flush()
+                    os._exit(0)
+                return
             headline["fallback"] = ("value is the SEGMENT split: the sample-sharded headline did not finish within %.0f s"
                                     % args.sharded_timeout)
             if emit(assemble(legs)):
                 sys.stdout.flush()
                 os._exit(3)
 
-        dog = threading.Timer(args.sharded_timeout, give_up)
-        dog.daemon = True
-        dog.start()
+        def watchdog():
+            t = threading.Timer(args.sharded_timeout, give_up)
+            t.daemon = True
+            t.start()
+            return t
+
+        dog = watchdog()
         try:
             native = args.exchange == "native" or (args.exchange == "auto" and args.backend == "nccl")
 
@@ -498,6 +527,9 @@ def main():
                                         % (S * world, world, S))
             shard.ctx.unstage(h_sh)
             shard.close()
+            progress["headline_done"] = True
+            dog.cancel()
+            dog = watchdog()
 
             # ---- the shapes BASELINE names for several GPUs: a cohort of FIXED total size sharded by samples -------------
             def fixed_cohort(total, seed):
@@ -585,10 +617,12 @@ def main():
 
     # ---- secondary legs (rank 0's own clock, no collectives; a failing leg is reported, never fatal) -------------------
     def leg(name, fn):
+        progress("leg %s ..." % name)
         try:
             legs[name] = fn()
         except Exception as e:
             legs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        progress("leg %s done" % name)
 
     def streaming_leg():
         # every segment comes from host memory -- layout built, uploaded over the copy stream while the previous segment
@@ -698,6 +732,21 @@ def main():
             merged = {"error": "%s: %s" % (type(e).__name__, e)}
         c2.unstage(l2.handle)
         c2.close()
+        # Stage 2's dominant kernel against ITS roofline: the data-likelihood launch ahead of the EM loop takes every
+        # candidate cell x every sample (the launches inside the loop take the cells still iterating: same kernel, fewer
+        # units); algorithmic bytes per (cell, sample) unit in the accounting of SURVEY 8(d): 4 B per active pair (int32
+        # deviation) + 4 B count in, the 24-byte likelihood triple out; lookup tables not counted (cache resident by design)
+        t2 = acc[4]
+        if t2 and t2.get("lik_first_units") and t2.get("lik_first_ms"):
+            per_unit = 4.0 * t2["n_active_pairs"] / t2["n_cells"] + 4 + 24
+            ach = t2["lik_first_units"] * per_unit / (t2["lik_first_ms"] / 1e3) / 1e9
+            legs["roofline_stage2"] = dict(
+                bound="hbm", kernel="dataLikDenseKernel", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                traffic=None, launch_ms=t2["lik_first_ms"], units_per_launch=t2["lik_first_units"],
+                algorithmic_bytes_per_unit=per_unit, workload="candidate_dense leg (%d cells x %d samples)" % (t2["n_candidate_cells"], S),
+                accounting="the launch ahead of the EM loop (all candidate cells x all samples), HIP events on the context's stream; "
+                           "bytes = 4 per active pair + 4 + 24 per (cell, sample)",
+                limiter="per-lane gathers into per-sample lookup tables (two per active pair): L1 miss handling, see DESIGN.md")
         return dict(workload="%d samples x %d windows, %d planted deletions in the segment" % (S, W2, args.dense_deletions),
                     value=n_pass * W2 * S / dt, unit="window*sample/s", ms_per_pass=dt / n_pass * 1e3,
                     stage1_ms_per_pass=acc[0] / n_pass, stage2_ms_per_pass=acc[1] / n_pass,
@@ -748,15 +797,113 @@ def main():
                                            % (n_thr, n_cpu, len(parts), cpu_all_s))
         return out
 
+    def sharded_world1_leg():
+        # The sample-sharded code path with ONE rank and the library's own RCCL exchange: every exchange is issued and
+        # timed, nothing crosses a wire -- what the path costs by itself next to the unsharded context (same segment).
+        out = []
+        for n in [int(x) for x in args.sharded_world1.split(",") if x.strip() != ""]:
+            n = S if n <= 0 else min(n, S)
+            o, a = take_samples(offsets, arrays, n * R)
+            sg = capi.Segment(first, W, o, a["dev"], a["start"], a["on"], a["off"])
+            n_pass = max(40, total_passes // 2)
+            row = dict(samples=n, passes=n_pass)
+            for kind in ("unsharded", "sharded"):
+                if kind == "unsharded":
+                    c2 = capi.Context(hip, [rg] * (R * n), sample_offsets[: n + 1], device=local_rank)
+                    closer = c2.close
+                else:
+                    sh = distributed.SampleShard(hip, [rg] * (R * n), sample_offsets[: n + 1], 0, 1, device=local_rank, native=True)
+                    c2, closer = sh.ctx, sh.close
+                l2 = Lane(c2, c2.stage(sg), args.serial)
+                l2.passes(5, new_acc())
+                torch.cuda.synchronize()
+                q0 = time.perf_counter()
+                acc = new_acc()
+                l2.passes(n_pass, acc)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - q0
+                c2.unstage(l2.handle)
+                closer()
+                row[kind + "_ms_per_pass"] = dt / n_pass * 1e3
+                if kind == "sharded":
+                    row.update(exchange_ms_per_pass=acc[5] / n_pass, all_gathers_per_pass=acc[4]["n_all_gathers"],
+                               all_gather_bytes_per_pass=acc[4]["all_gather_bytes"])
+            row["overhead_ms_per_pass"] = row["sharded_ms_per_pass"] - row["unsharded_ms_per_pass"]
+            out.append(row)
+        return dict(what="per pass over the resident segment: unsharded context vs. the sample-sharded path with a communicator of "
+                         "ONE rank (library RCCL; exchanges issued and event-timed, no wire)", rows=out)
+
+    def e2e_leg():
+        # `popdel call` from profile FILES to a VCF (what a user of the reference runs): generated profiles of a 1-Mb
+        # region, the product binary (HIP backend) against the oracle-backed driver (CPU; test infrastructure, here as the
+        # timed baseline) on the same files -- wall time of the whole process, phase split of the product
+        import re
+        import shutil
+        import subprocess
+        import tempfile
+        n = args.e2e_samples
+        region, n_win = (1000000, 2000000), 33334
+        d = tempfile.mkdtemp(prefix="popdel_e2e_")
+        try:
+            q0 = time.perf_counter()
+            lst = synth.write_cohort(d, n, region=region, deletions=synth.single_deletion, workers=usable_cores())
+            t_write = time.perf_counter() - q0
+            product = os.path.join(ROOT, "popdel_amd", "lib", "popdel")
+            oracle_bin = os.path.join(ROOT, "oracle", "_build", "popdel_oracle_call")
+
+            def call(binary, out, threads):
+                env = dict(os.environ, POPDEL_TIMING="1")
+                if threads:
+                    env["POPDEL_THREADS"] = str(threads)
+                q = time.perf_counter()
+                # (the oracle-backed driver IS `popdel call`: it takes the arguments without the sub-command)
+                sub = ["call"] if os.path.basename(binary) == "popdel" else []
+                r = subprocess.run([binary] + sub + [lst, "-o", out, "-r", "chr20:%d-%d" % region], env=env, capture_output=True,
+                                   text=True, timeout=600)
+                wall = time.perf_counter() - q
+                if r.returncode != 0:
+                    raise RuntimeError("%s exited %d: %s" % (os.path.basename(binary), r.returncode, (r.stderr or r.stdout)[-300:]))
+                phases = {}
+                for line in r.stderr.splitlines():
+                    if line.startswith("[popdel timing]"):
+                        for name, val in re.findall(r"([a-z][a-z+ ]*?) ([0-9][0-9.e+-]*) s", line):
+                            phases[name.strip().replace(" ", "_")] = float(val)
+                return wall, phases
+
+            call(product, os.path.join(d, "warm.vcf"), 0)          # page cache, GPU runtime start
+            wall, phases = call(product, os.path.join(d, "gpu.vcf"), 0)
+            out = dict(workload="popdel call on %d generated profiles, chr20:%d-%d (%d windows), merged VCF" % (n, region[0], region[1], n_win),
+                       value=n * n_win / wall, unit="window*sample/s", wall_seconds=wall, phases_seconds=phases,
+                       host_threads=usable_cores(), profile_bytes=sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.endswith(".profile")),
+                       cohort_written_in_seconds=t_write)
+            if os.path.exists(oracle_bin) and not args.no_cpu:
+                cpu = {}
+                for label, thr in (("all_cores", usable_cores()), ("one_thread", 1)):
+                    w, _ = call(oracle_bin, os.path.join(d, "cpu_%s.vcf" % label), thr)
+                    cpu[label] = dict(value=n * n_win / w, unit="window*sample/s", wall_seconds=w, cores=thr)
+                strip = lambda t: "\n".join(l for l in t.splitlines() if not l.startswith("##fileDate"))
+                cpu["identical_vcf"] = strip(open(os.path.join(d, "gpu.vcf")).read()) == strip(open(os.path.join(d, "cpu_all_cores.vcf")).read())
+                cpu["kind"] = "port"
+                out["cpu_baseline"] = cpu
+            return out
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
     if rank == 0 and not args.no_legs and not is_dist:      # N > 1 runs carry the two splits only
         if args.stream_segments > 0:
             leg("streaming", streaming_leg)
+        if args.sharded_world1.strip():
+            leg("sharded_world1", sharded_world1_leg)
         if args.concurrent > 1 and args.contexts == 1:
             leg("concurrent_segments", concurrent_leg)
         if args.small_cohort > 0:
             leg("small_cohort", small_cohort_leg)
         if args.dense_deletions > 0 and R == 1:
             leg("candidate_dense", dense_leg)
+        # (last of the GPU legs: its writer processes and host threads eat into the job's CPU quota, which the streaming
+        # leg's packing threads would miss)
+        if args.e2e_samples > 0:
+            leg("e2e", e2e_leg)
     if rank == 0:
         legs["cpu_baseline"] = None
         if not args.no_cpu and not is_dist:                 # timed on rank 0 at N = 1 only

@@ -174,6 +174,8 @@ typedef struct pd_timing
                                     seen their support-pool sizes and had to be run again the exact way */
     double   exchange_ms;        /* time the ticket's exchanges took: HIP events around each on the context's stream (the
                                     in-process group: host clock around its barriers and peer copies); part of stage2_ms */
+    double   lik_first_ms;       /* the data-likelihood kernels' launch ahead of the EM loop (last stage-2 batch): all cells of */
+    uint64_t lik_first_units;    /* the batch x all samples of the context = this many (cell, sample) units                   */
 } pd_timing;
 int pd_last_timing(pd_ctx *ctx, pd_timing *out);
 

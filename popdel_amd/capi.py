@@ -69,7 +69,8 @@ class PdTiming(C.Structure):
     _fields_ = [("stage1_ms", C.c_double), ("stage2_ms", C.c_double), ("n_cells", C.c_uint64),
                 ("n_active_pairs", C.c_uint64), ("n_pair_chunks", C.c_uint64), ("n_candidate_cells", C.c_uint64),
                 ("max_life", C.c_uint32), ("n_all_gathers", C.c_uint32), ("all_gather_bytes", C.c_uint64),
-                ("n_repeated_batches", C.c_uint64), ("exchange_ms", C.c_double)]
+                ("n_repeated_batches", C.c_uint64), ("exchange_ms", C.c_double),
+                ("lik_first_ms", C.c_double), ("lik_first_units", C.c_uint64)]
 
 
 RESERVE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)

@@ -40,7 +40,7 @@ void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch,
 void launchCopyBytes(const void * src, void * dst, size_t n, hipStream_t st);
 void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st);
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
-                   bool anyGenericTile, unsigned * pinnedWord, hipStream_t st);
+                   bool anyGenericTile, unsigned * pinnedWord, hipEvent_t likBegin, hipEvent_t likEnd, hipStream_t st);
 void buildLogTables(const double * hist, double4 * tab, double2 * tab2, size_t n, RgConst * rg, unsigned nRg, hipStream_t st);
 void launchGatherOut(const Stage2Buffers & b, unsigned * emitCells, unsigned nSamples, uint32_t * out, hipStream_t st);
 
@@ -270,6 +270,7 @@ struct pd_ctx
     hipStream_t copyStream = nullptr;   // segment uploads and the result D2H, so that the next segment's scan can run underneath it
     hipEvent_t resultsPacked = nullptr;
     hipEvent_t cellsFetched = nullptr;
+    hipEvent_t likBegin = nullptr, likEnd = nullptr;    // around the data-likelihood launch ahead of the EM loop (pd_timing)
     DevBuf<pd::RgConst> dRg;
     DevBuf<double> dHist;
     DevBuf<double4> dTab;
@@ -381,6 +382,10 @@ struct pd_ctx
             (void)hipEventDestroy(resultsPacked);
         if (cellsFetched)
             (void)hipEventDestroy(cellsFetched);
+        if (likBegin)
+            (void)hipEventDestroy(likBegin);
+        if (likEnd)
+            (void)hipEventDestroy(likEnd);
         if (copyStream)
             (void)hipStreamDestroy(copyStream);
         if (stream)
@@ -1984,6 +1989,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         // triples 24 B, outputs 52 B, ...) within a byte budget: a candidate-rich segment of a large cohort would not
         // fit otherwise (13,000 cells x 50,000 samples = 390 GB). One batch is the normal case.
         std::vector<unsigned> emit;
+        uint64_t likUnits = 0;          // (cell, sample) units of the last batch's data-likelihood launch ahead of the loop
         const unsigned nCells = (unsigned)cells.size();
         size_t budget = static_cast<size_t>(24) << 30;
         if (const char * e = getenv("POPDEL_HIP_STAGE2_BYTES"))
@@ -2167,7 +2173,13 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
                 }
                 b.suppFirst = c->dSuppFirst.p;
                 b.suppLast = c->dSuppLast.p;
-                pd::runStage2Main(view, c->cohort, b, o.flags.p, xch, generic, c->hIterFlag.data(), c->stream);
+                if (!c->likBegin)
+                {
+                    PD_HIP(hipEventCreate(&c->likBegin));
+                    PD_HIP(hipEventCreate(&c->likEnd));
+                }
+                pd::runStage2Main(view, c->cohort, b, o.flags.p, xch, generic, c->hIterFlag.data(), c->likBegin, c->likEnd, c->stream);
+                likUnits = static_cast<uint64_t>(nb) * S;
                 PD_HIP(hipGetLastError());
                 // the columns of the emitted cells are packed before the host has seen which cells those are
                 // (the list is formed on the device; room for all cells of the batch)
@@ -2281,6 +2293,14 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
                 ms += t;
             }
             c->timing.exchange_ms = ms;
+        }
+        c->timing.lik_first_ms = 0;
+        c->timing.lik_first_units = likUnits;
+        if (likUnits != 0)
+        {
+            float t = 0;
+            PD_HIP(hipEventElapsedTime(&t, c->likBegin, c->likEnd));
+            c->timing.lik_first_ms = t;
         }
         c->timing.all_gather_bytes = c->allGatherBytes;
         c->timing.n_repeated_batches = c->nRepeatedBatches;

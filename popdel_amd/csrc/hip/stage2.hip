@@ -3051,7 +3051,7 @@ void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers
 // per EM iteration | both likelihood-ratio evaluations of the converged cells | pool records + the final estimate's
 // likelihood-ratio sums | two digit histograms (four, without the pool records' range, in the exact flavour).
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
-                   bool anyGenericTile, unsigned * pinnedWord, hipStream_t st)
+                   bool anyGenericTile, unsigned * pinnedWord, hipEvent_t likBegin, hipEvent_t likEnd, hipStream_t st)
 {
     if (b.nCells == 0)
         return;
@@ -3082,7 +3082,11 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     // depend on the first frequency estimate: they run before the counts are exchanged, and read group 0's record
     // travels with them
     hipLaunchKernelGGL(suppScanKernel, dim3(1), dim3(256), 0, st, b);
+    // (timed: this launch of the data-likelihood kernels takes EVERY cell of the batch x every sample -- a known number of
+    // units, which the launches inside the loop, over the cells still iterating, do not have: pd_timing::lik_first_ms)
+    (void)hipEventRecord(likBegin, st);
     dataLik(2);
+    (void)hipEventRecord(likEnd, st);
     x.allGather(b.xch, xchBytes);
     hipLaunchKernelGGL(cellInitFinishKernel, perCell, cellBlock, 0, st, b);
     for (unsigned it = 0; it < b.maxIterations; ++it)

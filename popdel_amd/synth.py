@@ -227,18 +227,26 @@ def _write_cohort_part(args):
 def write_cohort(outdir, n_samples, region=(1000000, 2000000), deletions=single_deletion, lib: Library | None = None,
                  compressed=True, seed_base=1000, workers=1):
     """Write ``n_samples`` profiles plus ``profiles.txt``; returns the list file path. ``workers`` > 1 writes the
-    profiles from that many forked processes (``deletions`` must then be a module-level function)."""
-    lib = lib or Library()
+    profiles from that many child processes -- fresh interpreters running this module, not forks: the caller may hold a
+    GPU runtime and gigabytes of page-locked memory (``deletions`` must then be a function of this module, ``lib`` the
+    default library)."""
     os.makedirs(outdir, exist_ok=True)
     paths = [os.path.join(outdir, "s%05d.profile" % k) for k in range(n_samples)]
     workers = max(1, min(int(workers), n_samples))
-    parts = [(outdir, list(range(w, n_samples, workers)), region, deletions, lib, compressed, seed_base) for w in range(workers)]
     if workers == 1:
-        _write_cohort_part(parts[0])
+        _write_cohort_part((outdir, list(range(n_samples)), region, deletions, lib or Library(), compressed, seed_base))
     else:
-        import multiprocessing
-        with multiprocessing.get_context("fork").Pool(workers) as pool:
-            pool.map(_write_cohort_part, parts)
+        import subprocess
+        import sys
+        if lib is not None or (deletions is not None and globals().get(deletions.__name__) is not deletions):
+            raise ValueError("write_cohort(workers > 1) takes the default library and a deletion function of popdel_amd.synth")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        procs = [subprocess.Popen([sys.executable, "-m", "popdel_amd.synth", outdir, str(n_samples), str(w), str(workers),
+                                   str(region[0]), str(region[1]), deletions.__name__ if deletions else "-",
+                                   "1" if compressed else "0", str(seed_base)], cwd=root) for w in range(workers)]
+        for p in procs:
+            if p.wait() != 0:
+                raise RuntimeError("a profile writer process failed")
     lst = os.path.join(outdir, "profiles.txt")
     with open(lst, "w") as fh:
         fh.write("\n".join(paths) + "\n")
@@ -306,3 +314,10 @@ def cohort_segment(n_samples, region, first_window_pos, n_windows, lib: Library 
     return capi.Segment(first_window_pos=first_window_pos, n_windows=n_windows, rg_offsets=np.array(offsets, dtype=np.uint64),
                         dev=np.concatenate(devs), start=np.concatenate(starts), on=np.concatenate(ons),
                         off=np.concatenate(offs))
+
+
+if __name__ == "__main__":          # worker of write_cohort(workers > 1): the samples w, w + workers, ... of the cohort
+    import sys
+    _out, _n, _w, _workers, _r0, _r1, _dels, _comp, _seed = sys.argv[1:10]
+    _write_cohort_part((_out, list(range(int(_w), int(_n), int(_workers))), (int(_r0), int(_r1)),
+                        globals()[_dels] if _dels != "-" else None, Library(), _comp == "1", int(_seed)))

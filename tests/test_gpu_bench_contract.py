@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def test_bench_line_has_the_contract_fields(built):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--samples", "512", "--passes", "3", "--steps", "2",
                           "--warmup", "1", "--cpu-samples", "40", "--cpu-threads", "2", "--stream-segments", "2", "--small-cohort", "128",
-                          "--dense-deletions", "3"],
+                          "--dense-deletions", "3", "--e2e-samples", "24", "--sharded-world1", "256,0"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -45,6 +45,18 @@ def test_bench_line_has_the_contract_fields(built):
     assert d["small_cohort"]["value"] > 0 and d["candidate_dense"]["candidate_cells_per_pass"] > 0
     assert c["all_cores"]["cores"] == 2 and c["cpu_model"]
     assert r["limiter"] == "valu" and r["scan_source_stamp"]
+    # the whole path against its own roofline, next to the scan's
+    assert 0 < d["whole_path_frac"] < 1 and abs(d["whole_path_frac"] - d["value"] * d["algorithmic_bytes_per_unit"] / 8e12) < 1e-9
+    # the sample-sharded code path with one rank, costed per pass next to the unsharded context
+    rows = d["sharded_world1"]["rows"]
+    assert [x["samples"] for x in rows] == [256, 512]
+    for x in rows:
+        assert x["all_gathers_per_pass"] >= 9 and x["exchange_ms_per_pass"] > 0 and x["sharded_ms_per_pass"] > 0 and x["unsharded_ms_per_pass"] > 0
+    # end to end: the product binary on profile files, the oracle-backed driver beside it, same VCF
+    e = d["e2e"]
+    assert e["value"] > 0 and e["wall_seconds"] > 0 and "decode" in e["phases_seconds"]
+    assert e["cpu_baseline"]["identical_vcf"] is True and e["cpu_baseline"]["one_thread"]["cores"] == 1
+    assert e["cpu_baseline"]["all_cores"]["value"] > 0
 
 
 def test_gpus_2_spawns_two_ranks_and_reports_the_sample_split(built):
@@ -54,7 +66,8 @@ def test_gpus_2_spawns_two_ranks_and_reports_the_sample_split(built):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
-                          "--samples", "512", "--passes", "3", "--steps", "2", "--warmup", "1"],
+                          "--samples", "512", "--passes", "3", "--steps", "2", "--warmup", "1", "--configs3-samples", "768",
+                          "--configs4-samples", "1280", "--configs-passes", "3", "--configs4-segments", "3"],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
@@ -67,6 +80,13 @@ def test_gpus_2_spawns_two_ranks_and_reports_the_sample_split(built):
     assert abs(d["value"] - cells / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
     assert d["segment_sharded"]["value"] > 0 and d["segment_sharded"]["all_gathers_per_pass"] == 0
     assert d["calls_per_step"] > 0
+    assert d["exchange"]["exchange_ms_per_pass"] > 0
+    # the shapes BASELINE names for several GPUs: a cohort of FIXED total size, resident and streamed
+    c3, c4 = d["configs3"], d["configs4"]
+    assert c3["samples"] == 768 and c3["samples_per_rank"] == 512 and c3["samples_last_rank"] == 256 and c3["passes"] == 3
+    assert c3["value"] > 0 and c3["all_gathers_per_pass"] >= 9 and c3["exchange_ms_per_pass"] > 0 and c3["scaling"] == "strong"
+    assert c4["samples"] == 1280 and c4["samples_per_rank"] == 768 and c4["segments"] == 3
+    assert c4["value"] > 0 and c4["all_gathers_per_pass"] >= 9 and c4["exchange_ms_per_pass"] > 0
 
 
 def test_gpus_mismatch_fails_loudly(built):
