@@ -130,6 +130,9 @@ public:
         if (group_)
             pd_local_group_destroy(group_);
         printTiming();
+        if (walkCheck_ || walkUnchecked_)
+            std::cerr << "[popdel walk check] " << walkChecked_ << " segments planned in closed form and found equal to the walk, "
+                      << walkUnchecked_ << " not planned" << std::endl;
     }
     void printTiming()
     {
@@ -186,6 +189,13 @@ private:
     std::vector<int32_t> flatDev_;
     std::vector<uint32_t> flatStart_, flatOn_, flatOff_;
     std::vector<DecodedStream> decodedPool_;
+    // POPDEL_WALK_CHECK=1: every segment is planned and evaluated in closed form as well (ChromProfile::planSegment,
+    // WalkReference) and compared with what the walk logged -- shape, cursors, instances
+    std::unique_ptr<WalkReference> walkCheck_;
+    unsigned walkChecked_ = 0, walkUnchecked_ = 0;
+    void checkWalkAgainstPlan(const WalkShape & shape, const std::vector<uint8_t> & equalRun, const std::vector<uint8_t> & switches,
+                              const std::vector<std::pair<size_t, size_t>> & cursors, unsigned firstPos, unsigned nWindows,
+                              const std::vector<std::vector<PairInstance>> & log);
     bool timingPrinted_ = false;
     bool pending_ = false;
     std::string pendingContig_;
@@ -857,6 +867,30 @@ void CallRun::flushPending()
 void CallRun::processSegment()
 {
     ChromProfile & prof = *profile_;
+    // (check mode: plan the segment on the tables as they are now, note what the plan says, put the state back, then walk)
+    WalkShape planned;
+    std::vector<uint8_t> plannedRun, plannedSwitches;
+    std::vector<std::pair<size_t, size_t>> plannedCursors;
+    bool havePlan = false;
+    if (walkCheck_)
+    {
+        if (prof.canPlanSegment(p_.windowShift))
+        {
+            ChromProfile::PlanState saved = prof.savePlanState();
+            planned = prof.planSegment(p_.windowShift, plannedRun, plannedSwitches);
+            for (size_t rg = 0; rg < prof.starts.size(); ++rg)
+                plannedCursors.emplace_back(prof.starts[rg].readIdx, prof.ends[rg].readIdx);
+            prof.restorePlanState(saved);
+            havePlan = true;
+        }
+        else
+        {
+            walkCheck_.reset();             // the reference's own state would fall out of step from here on
+            ++walkUnchecked_;
+        }
+    }
+    else if (walkUnchecked_)
+        ++walkUnchecked_;
     prof.beginSegmentLog();
     if (prof.profilesAtEnd)
         prof.profilesAtEnd = !prof.nextWindow(p_.windowShift);
@@ -868,6 +902,9 @@ void CallRun::processSegment()
     windows_.current.pos += nWindows * p_.windowShift;
     clock_.walk += PhaseClock::now() - t0;
     std::vector<std::vector<PairInstance>> & log = prof.endSegmentLog();
+    prof.noteSegmentWalked();
+    if (havePlan)
+        checkWalkAgainstPlan(planned, plannedRun, plannedSwitches, plannedCursors, firstPos, nWindows, log);
     if (observer_ && observer_->onSegment)
         observer_->onSegment(firstPos, nWindows, log);
     if (observer_ && observer_->onActiveOps && nWindows != 0)
@@ -937,6 +974,53 @@ void CallRun::processSegment()
     clock_.submit += PhaseClock::now() - t0;
 }
 
+void CallRun::checkWalkAgainstPlan(const WalkShape & shape, const std::vector<uint8_t> & equalRun, const std::vector<uint8_t> & switches,
+                                   const std::vector<std::pair<size_t, size_t>> & cursors, unsigned firstPos, unsigned nWindows,
+                                   const std::vector<std::vector<PairInstance>> & log)
+{
+    ChromProfile & prof = *profile_;
+    auto fail = [&](const std::string & what) {
+        throw ProfileError("[PopDel] POPDEL_WALK_CHECK: the closed-form walk differs from the window loop: " + what);
+    };
+    if (shape.firstPos != firstPos || shape.nWindows != nWindows)
+        fail("segment shape: planned first window " + std::to_string(shape.firstPos) + " x " + std::to_string(shape.nWindows) +
+             ", walked " + std::to_string(firstPos) + " x " + std::to_string(nWindows));
+    std::vector<PairInstance> mine;
+    for (size_t rg = 0; rg < prof.starts.size(); ++rg)
+    {
+        const StartSlots & st = prof.starts[rg];
+        if (cursors[rg].first != st.readIdx || cursors[rg].second != prof.ends[rg].readIdx)
+            fail("cursors of read group " + std::to_string(rg));
+        mine.clear();
+        const InsertHistogram & h = p_.histograms[rg];
+        walkCheck_->segment(static_cast<unsigned>(rg), shape, p_.windowShift, switches[rg], equalRun[rg] != 0,
+                            switches[rg] ? &st.slots[st.readSlot] : nullptr, h.median, h.readLength, mine);
+        const std::vector<PairInstance> & theirs = log[rg];
+        bool same = mine.size() == theirs.size();
+        for (size_t i = 0; same && i < mine.size(); ++i)
+            same = mine[i].dev == theirs[i].dev && mine[i].start == theirs[i].start && mine[i].on == theirs[i].on &&
+                   mine[i].off == theirs[i].off && mine[i].id == theirs[i].id;
+        if (!same)
+        {
+            std::string what = "instances of read group " + std::to_string(rg) + " in the segment at " + std::to_string(firstPos) + " (" +
+                               std::to_string(mine.size()) + " planned, " + std::to_string(theirs.size()) + " walked)";
+            for (size_t i = 0; i < std::min(mine.size(), theirs.size()); ++i)
+                if (mine[i].start != theirs[i].start || mine[i].on != theirs[i].on || mine[i].off != theirs[i].off || mine[i].id != theirs[i].id)
+                {
+                    what += "; first difference at " + std::to_string(i) + ": planned start " + std::to_string(mine[i].start) + " id " +
+                            std::to_string(mine[i].id) + " [" + std::to_string(mine[i].on) + ", " + std::to_string(mine[i].off) + "), walked start " +
+                            std::to_string(theirs[i].start) + " id " + std::to_string(theirs[i].id) + " [" + std::to_string(theirs[i].on) + ", " +
+                            std::to_string(theirs[i].off) + ")";
+                    break;
+                }
+            fail(what);
+        }
+        if (walkCheck_->active(static_cast<unsigned>(rg)).size() != prof.active[rg].size())
+            fail("active pairs after the segment, read group " + std::to_string(rg));
+    }
+    ++walkChecked_;
+}
+
 bool CallRun::finalizeRoi()
 {
     if (!advanceRoi(p_))
@@ -947,6 +1031,10 @@ bool CallRun::finalizeRoi()
     }
     flushPending();                             // records of the finished ROI carry the old contig id
     profile_->fullReset();
+    // (the tables start afresh but pairs that are still active stay so: only with none left can the next ROI's first
+    // segment be planned in closed form)
+    if (walkCheck_ && walkCheck_->activeTotal() == 0)
+        profile_->setActiveKnownEmpty(true);
     nextReadPos_ = kNoPos;
     windows_.current.contig = p_.allRois[p_.nextRoi].seqName;
     windows_.current.pos = 0;
@@ -985,6 +1073,8 @@ int CallRun::run()
         profile_->enableActiveOpLog();
     profile_->currentPos = windows_.current.pos;
     profile_->resetTo(profile_->currentPos);
+    if (getenv("POPDEL_WALK_CHECK"))
+        walkCheck_.reset(new WalkReference(static_cast<unsigned>(p_.readGroups.size())));
 
     while (p_.fileCount != 0)
     {

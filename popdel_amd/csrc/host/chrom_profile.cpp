@@ -179,10 +179,21 @@ ChromProfile::ChromProfile(unsigned numReadGroups, const std::vector<unsigned> &
       ends(numReadGroups, EndSlots(0, bufferSize)),
       active(numReadGroups),
       activeLoad(numReadGroups, 0),
-      maxLoad(maximumLoad)
+      maxLoad(maximumLoad),
+      switches_(numReadGroups, 2)
 {
     currentRightBorder = starts[0].slots[2].right;
     log_.resize(numReadGroups);
+}
+
+// What the closed-form walk needs to know about a start slot beyond its entries: under which end slot's border their end
+// records are filed (constant while the slot is written), and that the entries arrive in start order.
+static inline void noteAdd(StartSlots & st, const EndSlots & en, unsigned startPos)
+{
+    StartSlots::Slot & slot = st.slots[st.writeSlot];
+    slot.endBorder = en.slots[en.writeSlot].right;
+    if (!slot.entries.empty() && startPos < slot.entries.back().startPos)
+        slot.sorted = false;
 }
 
 void ChromProfile::add(unsigned rg, unsigned startPos, unsigned endPos, int deviation)
@@ -197,6 +208,7 @@ void ChromProfile::add(unsigned rg, unsigned startPos, unsigned endPos, int devi
         activeLoad[rg] -= closing;
         if (activeLoad[rg] < maxLoad[rg])
         {
+            noteAdd(st, en, startPos);
             st.add(startPos, deviation);
             en.add(id, endPos);
             ++activeLoad[rg];
@@ -204,6 +216,7 @@ void ChromProfile::add(unsigned rg, unsigned startPos, unsigned endPos, int devi
     }
     else
     {
+        noteAdd(st, en, startPos);
         st.add(startPos, deviation);
         en.add(id, endPos);
         ++activeLoad[rg];
@@ -418,6 +431,8 @@ void ChromProfile::resetTo(unsigned pos)
     currentRightBorder = starts[0].slots[2].right;
     for (unsigned & l : activeLoad)
         l = 0;
+    for (uint8_t & c : switches_)
+        c = 2;                              // the tables are gone: whoever evaluates the walk drops pending and filed-ahead pairs
 }
 
 void ChromProfile::fullReset()
@@ -442,6 +457,7 @@ void ChromProfile::performSwitches(const std::vector<unsigned> & rgs, unsigned *
         ends[i].switchWrite();
         ends[i].fixConsecutiveSwitch(activeLoad[i]);
         ends[i].switchRead();
+        switches_[i] = static_cast<uint8_t>(std::min(2, switches_[i] + 1));
     }
 }
 
@@ -454,6 +470,7 @@ void ChromProfile::performPartialSwitches(const std::vector<unsigned> & rgs, uns
             nextEndWindow(i, logWindow_);
         starts[i].switchBoth(rightBorder);
         ends[i].switchRead();
+        switches_[i] = static_cast<uint8_t>(std::min(2, switches_[i] + 1));
     }
 }
 
@@ -509,6 +526,232 @@ std::vector<std::vector<PairInstance>> & ChromProfile::endSegmentLog()
     }
     logging_ = false;
     return log_;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// The window loop in closed form
+// ----------------------------------------------------------------------------------------------------------
+namespace {
+// first index >= from whose entry starts beyond pos (entries in start order)
+size_t startsUpTo(const std::vector<StartEntry> & v, size_t from, unsigned pos)
+{
+    return static_cast<size_t>(std::upper_bound(v.begin() + static_cast<std::ptrdiff_t>(std::min(from, v.size())), v.end(), pos,
+                                                [](unsigned p, const StartEntry & e) { return p < e.startPos; }) - v.begin());
+}
+// first index >= from whose entry is NOT yet over at pos: lastWindow + shift >= pos (entries ordered by lastWindow)
+size_t endsBefore(const std::vector<EndEntry> & v, size_t from, unsigned pos, unsigned shift)
+{
+    return static_cast<size_t>(std::lower_bound(v.begin() + static_cast<std::ptrdiff_t>(std::min(from, v.size())), v.end(), pos,
+                                                [shift](const EndEntry & e, unsigned p) { return e.lastWindow + shift < p; }) - v.begin());
+}
+}  // namespace
+
+bool ChromProfile::canPlanSegment(unsigned shift) const
+{
+    for (const StartSlots & st : starts)
+        if (!st.slots[st.readSlot].sorted)
+            return false;
+    if (!profilesAtEnd)
+        return activeKnownEmpty_;           // first segment: its set-up rule asks which read groups have no active pair
+    // the extra step must succeed: else the segment has no window, yet its set-up may activate pairs
+    if (currentPos + shift >= currentRightBorder)
+        return false;
+    for (size_t rg = 0; rg < starts.size(); ++rg)
+        if (!(ends[rg].readAtEnd() && starts[rg].readAtEnd()))
+            return true;
+    return false;
+}
+
+WalkShape ChromProfile::planSegment(unsigned shift, std::vector<uint8_t> & equalRun, std::vector<uint8_t> & switches)
+{
+    WalkShape sh;
+    const size_t nRg = starts.size();
+    equalRun.assign(nRg, 0);
+    switches = switches_;
+    std::fill(switches_.begin(), switches_.end(), static_cast<uint8_t>(0));
+    // ---- nextWindow(): the loader's step ahead of window 0 (canPlanSegment() made sure that it succeeds)
+    if (profilesAtEnd)
+    {
+        currentPos += shift;
+        sh.hasStep = true;
+        sh.stepPos = currentPos;
+        for (size_t rg = 0; rg < nRg; ++rg)
+        {
+            StartSlots & st = starts[rg];
+            EndSlots & en = ends[rg];
+            st.readIdx = startsUpTo(st.slots[st.readSlot].entries, st.readIdx, currentPos);
+            en.readIdx = endsBefore(en.slots[en.readSlot].entries, en.readIdx, currentPos, shift);
+        }
+        profilesAtEnd = false;
+    }
+    // ---- initializeActive(): window 0 sits at the smallest first start, if that lies before the current position
+    for (size_t rg = 0; rg < nRg; ++rg)
+    {
+        StartSlots & st = starts[rg];
+        st.readIdx = 0;
+        if (!st.readAtEnd() && st.current().startPos < currentPos)
+            currentPos = st.current().startPos;
+    }
+    globalMinPos = currentPos;
+    if (!sh.hasStep)
+    {
+        // first segment after a reset (no pair is active anywhere): the run of entries on the very first position is active
+        // in window 0. (With the extra step the rule changes nothing: such entries were activated by the step.)
+        for (size_t rg = 0; rg < nRg; ++rg)
+        {
+            StartSlots & st = starts[rg];
+            if (st.readAtEnd() || st.current().startPos != currentPos)
+                continue;
+            equalRun[rg] = 1;
+            const std::vector<StartEntry> & v = st.slots[st.readSlot].entries;
+            while (st.readIdx < v.size() && v[st.readIdx].startPos == currentPos)
+                ++st.readIdx;
+        }
+    }
+    sh.firstPos = currentPos;
+    // ---- walkSegment(): per read group the step at which both of its cursors are through, capped by the slot border
+    const unsigned pos0 = currentPos;
+    unsigned maxSteps = 0;
+    if (pos0 + shift < currentRightBorder)
+        maxSteps = (currentRightBorder - pos0 - 1) / shift;
+    unsigned steps = 0;
+    for (size_t rg = 0; rg < nRg; ++rg)
+    {
+        StartSlots & st = starts[rg];
+        EndSlots & en = ends[rg];
+        if (maxSteps == 0 || (en.readAtEnd() && st.readAtEnd()))
+            continue;
+        unsigned js = 0, je = 0;
+        if (!st.readAtEnd())
+        {
+            const unsigned last = st.slots[st.readSlot].entries.back().startPos;
+            js = last <= pos0 ? 1u : (last - pos0 + shift - 1) / shift;
+        }
+        if (!en.readAtEnd())
+        {
+            const unsigned last = en.slots[en.readSlot].entries.back().lastWindow + shift;
+            je = last < pos0 ? 1u : (last - pos0) / shift + 1;
+        }
+        const unsigned mine = std::min(maxSteps, std::max(js, je));
+        steps = std::max(steps, mine);
+        const unsigned lastPos = pos0 + mine * shift;
+        st.readIdx = startsUpTo(st.slots[st.readSlot].entries, st.readIdx, lastPos);
+        en.readIdx = endsBefore(en.slots[en.readSlot].entries, en.readIdx, lastPos, shift);
+    }
+    currentPos = pos0 + steps * shift;
+    profilesAtEnd = true;
+    logWindow_ = steps + 1;
+    sh.nWindows = steps + 1;
+    activeKnownEmpty_ = false;
+    return sh;
+}
+
+ChromProfile::PlanState ChromProfile::savePlanState() const
+{
+    PlanState s{currentPos, globalMinPos, logWindow_, profilesAtEnd, activeKnownEmpty_, switches_, {}};
+    for (size_t rg = 0; rg < starts.size(); ++rg)
+        s.cursors.emplace_back(starts[rg].readIdx, ends[rg].readIdx);
+    return s;
+}
+
+void ChromProfile::restorePlanState(const PlanState & s)
+{
+    currentPos = s.currentPos;
+    globalMinPos = s.globalMinPos;
+    logWindow_ = s.logWindow;
+    profilesAtEnd = s.profilesAtEnd;
+    activeKnownEmpty_ = s.activeKnownEmpty;
+    switches_ = s.switches;
+    for (size_t rg = 0; rg < starts.size(); ++rg)
+    {
+        starts[rg].readIdx = s.cursors[rg].first;
+        ends[rg].readIdx = s.cursors[rg].second;
+    }
+}
+
+size_t WalkReference::activeTotal() const
+{
+    size_t n = 0;
+    for (const auto & v : active_)
+        n += v.size();
+    return n;
+}
+
+void WalkReference::segment(unsigned rg, const WalkShape & shape, unsigned shift, unsigned switches, bool equalRun,
+                            const StartSlots::Slot * slot, unsigned median, unsigned readLength, std::vector<PairInstance> & out)
+{
+    std::vector<Pair> & act = active_[rg];
+    std::vector<Pair> & pend = pending_[rg];
+    // ---- what the loader's slot switches did since the last segment: a switch drains the end read slot (pairs whose end
+    // record sat there are gone; pairs filed ahead now sit in the read slot) and drops the start entries no window reached
+    if (switches != 0)
+    {
+        std::vector<Pair> keep;
+        if (switches == 1)
+            for (Pair p : act)
+                if (p.next)
+                {
+                    p.next = 0;
+                    keep.push_back(p);
+                }
+        act.swap(keep);
+        pend.clear();
+        if (slot)
+            for (size_t i = 0; i < slot->entries.size(); ++i)
+            {
+                const StartEntry & e = slot->entries[i];
+                const int inner = e.deviation + static_cast<int>(median) - 2 * static_cast<int>(readLength);
+                const uint32_t endPos = e.startPos + (inner > 0 ? static_cast<uint32_t>(inner) : 0u);
+                const uint32_t lastWin = posToWin(endPos, 30);
+                pend.push_back(Pair{e.startPos, e.deviation, slot->idOffset + static_cast<uint32_t>(i), lastWin,
+                                    static_cast<uint8_t>(lastWin >= slot->endBorder ? 1 : 0)});
+            }
+    }
+    const unsigned n = shape.nWindows, F = shape.firstPos;
+    // window index at which a pair whose end record sits in the read slot leaves; >= n: not within this segment
+    auto offOf = [&](const Pair & p) -> unsigned {
+        if (p.next)
+            return n;
+        const unsigned over = p.lastWin + shift;                 // last position at which the pair is still active
+        if (shape.hasStep && over < shape.stepPos)
+            return 0;
+        const unsigned j = over < F ? 1u : (over - F) / shift + 1;
+        return std::min(j, n);
+    };
+    std::vector<Pair> stillActive, stillPending;
+    for (const Pair & p : act)
+    {
+        const unsigned off = offOf(p);
+        if (off > 0)
+            out.push_back(PairInstance{p.dev, p.start, 0u, off, p.id});
+        if (off >= n)
+            stillActive.push_back(p);
+    }
+    bool inRun = equalRun;
+    for (const Pair & p : pend)
+    {
+        unsigned on;
+        if (shape.hasStep && p.start <= shape.stepPos)
+            on = 0;
+        else if (inRun && p.start == F)
+            on = 0;
+        else
+            on = p.start <= F ? 1u : (p.start - F + shift - 1) / shift;
+        if (p.start != F)
+            inRun = false;
+        if (on >= n)
+        {
+            stillPending.push_back(p);
+            continue;
+        }
+        const unsigned off = std::max(offOf(p), on);          // (the walk activates before it deactivates within a step)
+        if (on < off)
+            out.push_back(PairInstance{p.dev, p.start, on, off, p.id});
+        if (off >= n)
+            stillActive.push_back(p);
+    }
+    act.swap(stillActive);
+    pend.swap(stillPending);
 }
 
 }  // namespace pdh

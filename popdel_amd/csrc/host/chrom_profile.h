@@ -11,6 +11,7 @@
 #ifndef PDH_CHROM_PROFILE_H_
 #define PDH_CHROM_PROFILE_H_
 
+#include <algorithm>
 #include <cstdint>
 #include <cstddef>
 #include <limits>
@@ -40,8 +41,10 @@ public:
         std::vector<StartEntry> entries;
         unsigned right = 0;        // exclusive right border
         unsigned idOffset = 0;     // id of entries[0]
+        unsigned endBorder = 0;    // right border of the END slot the entries' end records were filed under (ChromProfile::add)
         bool readable = false;
-        void reset(unsigned idO, unsigned r) { entries.clear(); right = r; idOffset = idO; readable = false; }
+        bool sorted = true;        // entries arrived in non-decreasing start order (what the closed-form walk relies on)
+        void reset(unsigned idO, unsigned r) { entries.clear(); right = r; idOffset = idO; readable = false; sorted = true; }
     };
 
     explicit StartSlots(unsigned firstWin = 0, unsigned windows = 10000);
@@ -102,6 +105,20 @@ public:
     unsigned numWindows;
 };
 
+// ---- the window loop in closed form -----------------------------------------------------------------------------------
+// What the loop of processSegment() -- one extra step of nextWindow(), initializeActive(), then the walk -- does to a read
+// group is a function of a few numbers (WalkShape) and, per pair, of its start, its last window and the slot its end record
+// sits in. The GPU backend evaluates that per pair itself (pd_walk_submit, include/popdel_hip.h); the host then only plans
+// the segment (ChromProfile::planSegment: O(1) per read group from the heads and tails of the slot tables) instead of
+// walking it. WalkReference is the same evaluation on the host: the checker of the plan (POPDEL_WALK_CHECK) and of the kernel.
+struct WalkShape
+{
+    unsigned firstPos = 0;     // position of window 0
+    unsigned stepPos = 0;      // position of the loader's step ahead of window 0 (hasStep)
+    unsigned nWindows = 0;
+    bool     hasStep = false;
+};
+
 // A pair as seen by the window loop of one segment: active for window indices [on, off).
 struct PairInstance
 {
@@ -159,6 +176,30 @@ public:
     void enableActiveOpLog() { opLogging_ = true; ops_.resize(active.size()); }
     std::vector<std::vector<ActiveOp>> & activeOps() { return ops_; }
     void clearActiveOps() { for (auto & v : ops_) v.clear(); }
+
+    // --- closed-form walk (see WalkShape) -----------------------------------------------------------------------------
+    // Can the coming segment be planned instead of walked? (Not: a segment without windows whose set-up still activates
+    // pairs, unsorted start entries.) Call before planSegment().
+    bool canPlanSegment(unsigned shift) const;
+    // Everything processSegment() does to the positions and cursors, without touching a pair: returns the segment's
+    // shape and fills per read group the first-segment rule (equalRun) and the slot switches since the last plan.
+    WalkShape planSegment(unsigned shift, std::vector<uint8_t> & equalRun, std::vector<uint8_t> & switches);
+    // (after planSegment: forget the counted switches; the closed-form state of whoever evaluates the walk is in step)
+    const std::vector<uint8_t> & switchCounts() const { return switches_; }
+    // (check mode: plan, note the result, put everything planSegment() touches back, then walk)
+    struct PlanState
+    {
+        unsigned currentPos, globalMinPos, logWindow;
+        bool profilesAtEnd, activeKnownEmpty;
+        std::vector<uint8_t> switches;
+        std::vector<std::pair<size_t, size_t>> cursors;
+    };
+    // after a segment was WALKED (not planned): the bookkeeping planSegment() does for the next plan
+    void noteSegmentWalked() { std::fill(switches_.begin(), switches_.end(), static_cast<uint8_t>(0)); activeKnownEmpty_ = false; }
+    PlanState savePlanState() const;
+    void restorePlanState(const PlanState & s);
+    bool activeKnownEmpty() const { return activeKnownEmpty_; }
+    void setActiveKnownEmpty(bool v) { activeKnownEmpty_ = v; }
 
     std::vector<StartSlots> starts;
     std::vector<EndSlots> ends;
@@ -276,11 +317,39 @@ private:
     bool nextEndWindow(unsigned rg, unsigned logWindow);
     unsigned walkReadGroup(unsigned rg, unsigned pos0, unsigned shift, unsigned maxSteps);
 
+    std::vector<uint8_t> switches_;        // per read group: slot switches since the last planned / walked segment (2 = two or more)
+    bool activeKnownEmpty_ = true;         // no read group has an active pair (start of a run; closed-form mode keeps no active sets)
     bool logging_ = false;
     bool opLogging_ = false;
     std::vector<std::vector<ActiveOp>> ops_;
     unsigned logWindow_ = 0;
     std::vector<std::vector<PairInstance>> log_;
+};
+
+// The walk of one read group in closed form, with the state it carries from segment to segment: the pairs still active
+// (each knows whether its end record sits in the read slot or the one after) and the start entries of the read slot that
+// no window has reached yet. Host reference of the device kernel (walk.hip).
+class WalkReference
+{
+public:
+    struct Pair
+    {
+        uint32_t start;
+        int32_t  dev;
+        uint32_t id;
+        uint32_t lastWin;
+        uint8_t  next;         // its end record sits in the slot after the end read slot
+    };
+    explicit WalkReference(unsigned nReadGroups) : active_(nReadGroups), pending_(nReadGroups) {}
+    // One read group, one segment. `entries`: the new start slot (only looked at if switches != 0). Appends the instances
+    // in the order the walk logs them (carried pairs by id, then activations in entry order).
+    void segment(unsigned rg, const WalkShape & shape, unsigned shift, unsigned switches, bool equalRun,
+                 const StartSlots::Slot * slot, unsigned median, unsigned readLength, std::vector<PairInstance> & out);
+    const std::vector<Pair> & active(unsigned rg) const { return active_[rg]; }
+    size_t activeTotal() const;
+
+private:
+    std::vector<std::vector<Pair>> active_, pending_;
 };
 
 }  // namespace pdh
