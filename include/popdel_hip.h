@@ -235,6 +235,62 @@ uint32_t pd_shard_samples(uint32_t n_samples_global, uint32_t world);
 /* Must be called before the first segment is run. */
 int pd_ctx_set_shard(pd_ctx *ctx, const pd_shard *shard);
 
+/* ---- segments handed over as the loader's tables hold them: the window loop runs in closed form on the device ----------
+ * pd_segment asks the host for every pair's window interval, i.e. for a walk over all windows of the segment with its
+ * activations and deactivations (the reference's ChromosomeProfile::initializeActiveReads / nextWindow / nextStartWindow /
+ * nextEndWindow, profile_structure_popdel_call.h:1120-1213, as processSegment() drives them, workflow_popdel.h:58-86).
+ * What that walk does to a pair is a function of a few numbers per segment and, per pair, of its start, its last window and
+ * the end slot its end record was filed under ("The window loop in closed form"). With pd_walk the host hands
+ * over, per read group, the start entries of the slot the loader has just switched to reading (start position and
+ * deviation, in the order they were filed -- ChromosomeProfileStartEntry, :15-25) and plans the segment's shape; the
+ * library derives the pair instances itself and carries from segment to segment what the reference's active sets and
+ * read cursors carry: the pairs still active, and the start entries no window has reached yet. Segments must be submitted
+ * in the order the loader produces them, every read group in every one of them (its `switches` says what the loader did
+ * to its slots since the previous segment).
+ *   first_window_pos  position of window 0 (ChromosomeProfile::currentPos after initializeActiveReads)
+ *   step_pos/has_step position of the loader's extra nextWindow() step ahead of window 0 (workflow_popdel.h:64-65), if taken
+ *   switches[rg]      0: the read group's slots were not switched since the previous segment; 1: once (performSwitches /
+ *                     performPartialSwitches, :1878-1910); 2: twice or more, or the tables were reset (resetTo, :1717)
+ *   end_border[rg]    right border of the END slot the new entries' end records were filed under: a pair whose last window
+ *                     lies at or beyond it was filed one slot ahead (CyclicEndEntryTable::add, :760-790)
+ *   id_offset[rg]     the reference's id of the read group's first new entry (only reported back, pd_walk_active)
+ *   equal_run[rg]     first segment after a reset: the run of entries on first_window_pos is active in window 0 (:1143-1158)
+ */
+typedef struct pd_walk_entry    /* ChromosomeProfileStartEntry (profile_structure_popdel_call.h:15-25) */
+{
+    uint32_t start;             /* startPos */
+    int32_t  dev;               /* insertSizeDeviation */
+} pd_walk_entry;
+
+typedef struct pd_walk
+{
+    uint32_t        first_window_pos;
+    uint32_t        step_pos;
+    uint32_t        has_step;
+    uint32_t        n_windows;         /* > 0 */
+    uint32_t        window_shift;
+    uint32_t        n_readgroups;      /* must equal the context's read-group count */
+    const uint32_t *rg_counts;         /* per read group: entries of its new start slot (ignored where switches == 0) */
+    const pd_walk_entry *const *rg_entries;   /* per read group: the entries, in the order they were filed (the host's table itself) */
+    const uint32_t *end_border;
+    const uint32_t *id_offset;
+    const uint8_t  *switches;
+    const uint8_t  *equal_run;
+} pd_walk;
+
+/* Stage the segment (entries -> HBM -> pair instances -> layout) and enqueue the window loop's genotyping for it; the
+ * ticket is collected with pd_segment_collect() like that of pd_segment_submit(). */
+int pd_walk_submit(pd_ctx *ctx, const pd_walk *walk, uint64_t *ticket);
+
+/* 1 if the backend behind the ABI offers pd_walk_submit() (the oracle does not: it takes pd_segment only), else 0. */
+int pd_walk_supported(const pd_ctx *ctx);
+
+/* The pairs still active after the most recently submitted walk (waits for its kernels): their number, and -- if the
+ * arrays are given -- read group, start, deviation and id of each, read group by read group in id order (room for
+ * `capacity` pairs; the return code is 2 if there are more). A host that leaves the closed form (ROI change with pairs
+ * still active: the reference keeps them, profile_structure_popdel_call.h:1735-1760) rebuilds its active sets from them. */
+int pd_walk_active(pd_ctx *ctx, uint64_t *n_active, uint32_t *rg, uint32_t *start, int32_t *dev, uint32_t *id, uint64_t capacity);
+
 /* Wait for a ticket and hand back its calls (callee-owned; release with pd_calls_free).
  * Replaces: reading `String<Call> calls` after the window loop (reference workflow_popdel.h:48). */
 int pd_segment_collect(pd_ctx *ctx, uint64_t ticket, pd_calls **out);

@@ -1073,6 +1073,21 @@ void pd_merged_free(pd_merged *) {}
 
 int pd_rccl_unique_id(uint8_t *) { return 1; }
 
+// The oracle takes segments as pair instances (pd_segment) only: the host walks the windows itself.
+int pd_walk_supported(const pd_ctx *) { return 0; }
+int pd_walk_submit(pd_ctx * c, const pd_walk *, uint64_t *)
+{
+    if (c)
+        c->error = "pd_walk_submit: the oracle takes pair instances (pd_segment_submit)";
+    return 1;
+}
+int pd_walk_active(pd_ctx * c, uint64_t *, uint32_t *, uint32_t *, int32_t *, uint32_t *, uint64_t)
+{
+    if (c)
+        c->error = "pd_walk_active: the oracle takes pair instances (pd_segment_submit)";
+    return 1;
+}
+
 int pd_ctx_set_shard_rccl(pd_ctx * c, const pd_shard *, const uint8_t *)
 {
     if (c)

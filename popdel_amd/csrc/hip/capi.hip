@@ -1,6 +1,7 @@
 // C ABI of libpopdel_hip.so (include/popdel_hip.h): context, HBM staging of segments, launch orchestration and
 // result packing. No CPU fallback lives here: every entry point either runs the HIP kernels or fails.
 #include <dlfcn.h>
+#include <functional>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -20,6 +21,7 @@
 #include "parallel.h"
 #include "pd_build.h"
 #include "pd_device.h"
+#include "pd_walk.h"
 #include "popdel_hip.h"
 
 namespace pd {
@@ -333,6 +335,26 @@ struct pd_ctx
     PinnedBuf<unsigned long long> hLifeHist, hLifeXch;
     PinnedBuf<uint64_t> hTotals;
     PinnedBuf<uint32_t> hEntMax;
+    // the window loop in closed form (pd_walk_submit, walk.hip): the state that goes from segment to segment, in two sets
+    // (a segment's kernel reads one and writes the other), and the staging of the loader's tables
+    struct WalkBuffers
+    {
+        DevBuf<uint32_t> aStart, aId, aLast, nActive, pStart, pId, pLast, nPending;
+        DevBuf<int32_t> aDev, pDev;
+    } walkState[2];
+    int walkCur = 0;                        // the set that holds the state after the last submitted walk
+    bool walkReady = false;
+    uint32_t walkCapActive = 0, walkCapPending = 1024;
+    PinnedBuf<uint32_t> hWalkBorder, hWalkIdOffset;
+    PinnedBuf<uint2> hWalkEntries;
+    PinnedBuf<uint8_t> hWalkFlags;          // switches, then equal_run
+    DevBuf<uint32_t> dWalkBorder, dWalkIdOffset, dWalkCount;
+    DevBuf<uint2> dWalkEntries;
+    DevBuf<uint8_t> dWalkFlags;
+    DevBuf<uint64_t> dWalkEntryOffsets;
+    DevBuf<unsigned long long> dWalkTotals; // [0] instances of the segment, [1] pairs left active, [2] problems
+    PinnedBuf<unsigned long long> hWalkTotals;
+    uint64_t walkActive = 0;                // pairs left active after the last submitted walk
     uint64_t nextHandle = 1, nextTicket = 1;
     std::map<uint64_t, Run> runs;
 
@@ -803,6 +825,171 @@ void buildChunks(pd_ctx & c, const pd_segment & seg, StagedSegment & out, Pinned
     }, 4);
 }
 
+// The staged layout from pair instances that are in device memory already (uploaded, or derived there: walk.hip), on the
+// copy stream. `onUploaded` (optional) runs after the first synchronisation point: everything enqueued before the call
+// has completed then.
+bool buildLayoutOnDevice(pd_ctx & c, const pd::InstanceArrays & in, uint64_t nInst, uint32_t W, StagedSegment & out,
+                         const std::function<void()> & onUploaded)
+{
+    const uint32_t nRg = c.nRg, nV = static_cast<uint32_t>(c.scanSample.size()), nEnt = nRg + nV;
+    hipStream_t cs = c.copyStream;
+    pd::BuildEntities en;
+    en.rgOffsets = c.dRgOffsets.p;
+    en.sampleRg = c.dSampleRg.p;
+    en.scanSample = c.dScanSample.p;
+    en.nRg = nRg;
+    en.nScan = nV;
+    // ---- K from the lifetime histogram (the rule of the host builder)
+    c.dLifeHist.ensure(67);
+    c.hLifeHist.resize(67);
+    PD_HIP(hipMemsetAsync(c.dLifeHist.p, 0, 67 * sizeof(unsigned long long), cs));
+    pd::launchLifeStats(in, nInst, W, c.dLifeHist.p, cs);
+    PD_HIP(hipGetLastError());
+    PD_HIP(hipMemcpyAsync(c.hLifeHist.data(), c.dLifeHist.p, 67 * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+    PD_HIP(hipStreamSynchronize(cs));
+    if (onUploaded)
+        onUploaded();
+    uint64_t living = 0;
+    for (int l = 0; l <= 65; ++l)
+        living += c.hLifeHist[l];
+    // Chunk lives. Stage 2 (K): ~98.4 % of the pairs in one chunk, the rule of the host builder -- its chunk order is the
+    // order stage 2 adds pairs up in. Stage-1 image (K1 <= K): 15/16 in one chunk -- fewer slots per cell of the scan
+    // (bench segment, scan per pass with 9 / 10 / 11 / 12: 1.127 / 1.120 / 1.161 / 1.225 ms; 95.1 % of the lives are
+    // <= 10 windows, 98.8 % <= 11); Q3 does not depend on how the pairs are cut, so every context may pick its own.
+    auto lifeAt = [&](uint64_t tail) {
+        uint64_t acc = 0;
+        const uint64_t want = living - living / tail;
+        for (uint32_t l = 0; l <= 65; ++l)
+        {
+            acc += c.hLifeHist[l];
+            if (acc >= want)
+                return std::min<uint32_t>(std::max<uint32_t>(4, l), 48);
+        }
+        return 48u;
+    };
+    // (K1 from the own samples' lives, then K from the whole cohort's: see cohortLifeHist)
+    const uint32_t K1own = lifeAt(16);
+    const unsigned long long ownActive = c.hLifeHist[66];
+    cohortLifeHist(c, c.hLifeHist.data());
+    uint64_t ownLiving = living;
+    living = 0;
+    for (int l = 0; l <= 65; ++l)
+        living += c.hLifeHist[l];
+    uint32_t K = lifeAt(64), K1 = std::min(K1own, K);
+    living = ownLiving;
+    if (const char * e = getenv("POPDEL_HIP_MAXLIFE_SCAN"))
+        K1 = std::min<uint32_t>(K, std::max(1, atoi(e)));
+    if (pd::buildLdsBytes(W, K) > 160u * 1024u)
+        return false;
+    const bool twoLives = K1 != K;
+    out.maxLife = K;
+    out.maxLifePk = K1;
+    out.ownPkIndex = twoLives;
+    out.nPairs = living;
+    out.nActivePairs = ownActive;
+    // ---- counts -> index rows, chunk totals -> bases (per image if the lives differ)
+    out.winStart.ensure(static_cast<size_t>(twoLives ? nRg : nEnt) * (static_cast<size_t>(W) + K));
+    out.endCount.ensure(static_cast<size_t>(twoLives ? nRg : nEnt) * (W + 1));
+    out.rgBase.ensure(nEnt);
+    out.rgPacked.ensure(nEnt);
+    c.dEntChunks.ensure(2 * static_cast<size_t>(nEnt));
+    c.dEntMax.ensure(2 * static_cast<size_t>(nEnt));
+    c.dTotals.ensure(4);
+    c.dProblems.ensure(1);
+    c.hTotals.resize(5);
+    PD_HIP(hipMemsetAsync(c.dProblems.p, 0, sizeof(unsigned), cs));
+    pd::BuildEntities enReal = en;
+    enReal.nScan = 0;
+    if (twoLives)
+    {
+        out.winStartPk.ensure(static_cast<size_t>(nEnt) * (static_cast<size_t>(W) + K1));
+        out.endCountPk.ensure(static_cast<size_t>(nEnt) * (W + 1));
+        out.rgBasePk.ensure(nEnt);
+    }
+    {
+        // stage-2 arrays (real read groups; all entities if there is one life only)
+        pd::CountOut co;
+        co.winStart = out.winStart.p;
+        co.endCount = out.endCount.p;
+        co.entChunks = c.dEntChunks.p;
+        co.entMax = c.dEntMax.p;
+        co.rgPacked = out.rgPacked.p;
+        co.problems = c.dProblems.p;
+        if (!pd::launchCount(in, twoLives ? enReal : en, W, K, co, cs))
+            throw HipError{"the layout build kernel cannot get its LDS"};
+        PD_HIP(hipGetLastError());
+        pd::launchBaseScan(c.dEntChunks.p, twoLives ? nRg : nEnt, nRg, out.rgBase.p, c.dTotals.p, cs);
+        PD_HIP(hipGetLastError());
+    }
+    if (twoLives)
+    {
+        pd::CountOut co;
+        co.winStart = out.winStartPk.p;
+        co.endCount = out.endCountPk.p;
+        co.entChunks = c.dEntChunks.p + nEnt;
+        co.entMax = c.dEntMax.p + nEnt;
+        co.rgPacked = out.rgPacked.p;
+        co.problems = c.dProblems.p;
+        if (!pd::launchCount(in, en, W, K1, co, cs))
+            throw HipError{"the layout build kernel cannot get its LDS"};
+        PD_HIP(hipGetLastError());
+        pd::launchBaseScan(c.dEntChunks.p + nEnt, nEnt, nRg, out.rgBasePk.p, c.dTotals.p + 2, cs);
+        PD_HIP(hipGetLastError());
+    }
+    c.hEntMax.resize(nEnt);
+    PD_HIP(hipMemcpyAsync(c.hTotals.data(), c.dTotals.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
+    PD_HIP(hipMemcpyAsync(c.hTotals.data() + 4, c.dProblems.p, sizeof(unsigned), hipMemcpyDeviceToHost, cs));
+    PD_HIP(hipMemcpyAsync(c.hEntMax.data(), c.dEntMax.p + (twoLives ? nEnt : 0), nEnt * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+    PD_HIP(hipStreamSynchronize(cs));
+    if (static_cast<unsigned>(c.hTotals[4] & 0xffffffffu) != 0)
+        throw HipError{"pair instances of a read group are not ordered by their first window (pd_segment: non-decreasing `on`)"};
+    const uint64_t totalReal = c.hTotals[0], totalPk = twoLives ? c.hTotals[3] : c.hTotals[1];
+    out.nChunks = totalReal;
+    {
+        // ... of 99 % of the streams: a few unusually deep samples should not cost everybody else occupancy
+        std::vector<uint32_t> entMax(c.hEntMax.data(), c.hEntMax.data() + nEnt);
+        std::sort(entMax.begin(), entMax.end());
+        out.maxBlockChunks = entMax.empty() ? 0 : entMax[std::min(entMax.size() - 1, entMax.size() * 99 / 100)];
+    }
+    // ---- chunks to their places
+    out.pairs.ensure(totalReal);
+    out.start.ensure(totalReal);
+    out.pairsPk.ensure(totalPk + 128);             // the scan's LDS-DMA copies whole 128-chunk pieces (stage1.hip)
+    {
+        pd::ScatterOut so;
+        so.pairs = out.pairs.p;
+        so.start = out.start.p;
+        so.pairsPk = twoLives ? nullptr : out.pairsPk.p;
+        so.rgBase = out.rgBase.p;
+        so.winStart = out.winStart.p;
+        if (!pd::launchScatter(in, twoLives ? enReal : en, W, K, so, cs))
+            throw HipError{"the layout scatter kernel cannot get its LDS"};
+        PD_HIP(hipGetLastError());
+    }
+    if (twoLives)
+    {
+        pd::ScatterOut so;
+        so.pairs = nullptr;
+        so.start = nullptr;
+        so.pairsPk = out.pairsPk.p;
+        so.rgBase = out.rgBasePk.p;
+        so.winStart = out.winStartPk.p;
+        if (!pd::launchScatter(in, en, W, K1, so, cs))
+            throw HipError{"the layout scatter kernel cannot get its LDS"};
+        PD_HIP(hipGetLastError());
+    }
+    const size_t blocksPerSample = (static_cast<size_t>(W) + 2 * pd::kStage1Block - 1) / (2 * pd::kStage1Block);
+    out.hasScanGeneric = nV != 0;
+    if (nV != 0)
+    {
+        out.scanGeneric.ensure(static_cast<size_t>(nV) * blocksPerSample);
+        PD_HIP(hipMemsetAsync(out.scanGeneric.p, 0, static_cast<size_t>(nV) * blocksPerSample, cs));
+        pd::launchScanGeneric(en, c.dRg.p, out.winStart.p, out.endCount.p, W, K, out.scanGeneric.p, static_cast<unsigned>(blocksPerSample), cs);
+        PD_HIP(hipGetLastError());
+    }
+    return true;
+}
+
 // The same layout built on the device (build.hip) from instances that cross PCIe once: 8 bytes per instance when every
 // field fits 16 bits (deviation, window indices, distance of the pair start behind its first window), else 16.
 // Returns false if this segment has to take the host builder (window count beyond what the build kernels keep in LDS).
@@ -1053,164 +1240,14 @@ bool buildChunksOnDevice(pd_ctx & c, const pd_segment & seg, StagedSegment & out
     in.start32 = c.dIn32[3].p;
     in.firstPos = seg.first_window_pos;
     in.shift = seg.window_shift;
-    pd::BuildEntities en;
-    en.rgOffsets = c.dRgOffsets.p;
-    en.sampleRg = c.dSampleRg.p;
-    en.scanSample = c.dScanSample.p;
-    en.nRg = nRg;
-    en.nScan = nV;
-    // ---- K from the lifetime histogram (the rule of the host builder)
-    c.dLifeHist.ensure(67);
-    c.hLifeHist.resize(67);
-    PD_HIP(hipMemsetAsync(c.dLifeHist.p, 0, 67 * sizeof(unsigned long long), cs));
-    pd::launchLifeStats(in, nInst, W, c.dLifeHist.p, cs);
-    PD_HIP(hipGetLastError());
-    PD_HIP(hipMemcpyAsync(c.hLifeHist.data(), c.dLifeHist.p, 67 * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
-    PD_HIP(hipStreamSynchronize(cs));
-    if (debug)
-        fprintf(stderr, "[popdel_hip] device build: %llu instances uploaded %s, %zu exceptions; packing %.1f ms on the host threads, "
-                        "%.1f ms until the last byte was on the device\n", (unsigned long long)nInst,
-                narrow.load() ? (compact ? "compact (5 B)" : "narrow (8 B)") : "wide (16 B)", exceptions.size(), packSeconds * 1e3,
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild0).count() * 1e3);
-    uint64_t living = 0;
-    for (int l = 0; l <= 65; ++l)
-        living += c.hLifeHist[l];
-    // Chunk lives. Stage 2 (K): ~98.4 % of the pairs in one chunk, the rule of the host builder -- its chunk order is the
-    // order stage 2 adds pairs up in. Stage-1 image (K1 <= K): 15/16 in one chunk -- fewer slots per cell of the scan
-    // (bench segment, scan per pass with 9 / 10 / 11 / 12: 1.127 / 1.120 / 1.161 / 1.225 ms; 95.1 % of the lives are
-    // <= 10 windows, 98.8 % <= 11); Q3 does not depend on how the pairs are cut, so every context may pick its own.
-    auto lifeAt = [&](uint64_t tail) {
-        uint64_t acc = 0;
-        const uint64_t want = living - living / tail;
-        for (uint32_t l = 0; l <= 65; ++l)
-        {
-            acc += c.hLifeHist[l];
-            if (acc >= want)
-                return std::min<uint32_t>(std::max<uint32_t>(4, l), 48);
-        }
-        return 48u;
-    };
-    // (K1 from the own samples' lives, then K from the whole cohort's: see cohortLifeHist)
-    const uint32_t K1own = lifeAt(16);
-    const unsigned long long ownActive = c.hLifeHist[66];
-    cohortLifeHist(c, c.hLifeHist.data());
-    uint64_t ownLiving = living;
-    living = 0;
-    for (int l = 0; l <= 65; ++l)
-        living += c.hLifeHist[l];
-    uint32_t K = lifeAt(64), K1 = std::min(K1own, K);
-    living = ownLiving;
-    if (const char * e = getenv("POPDEL_HIP_MAXLIFE_SCAN"))
-        K1 = std::min<uint32_t>(K, std::max(1, atoi(e)));
-    if (pd::buildLdsBytes(W, K) > 160u * 1024u)
-        return false;
-    const bool twoLives = K1 != K;
-    out.maxLife = K;
-    out.maxLifePk = K1;
-    out.ownPkIndex = twoLives;
-    out.nPairs = living;
-    out.nActivePairs = ownActive;
-    // ---- counts -> index rows, chunk totals -> bases (per image if the lives differ)
-    out.winStart.ensure(static_cast<size_t>(twoLives ? nRg : nEnt) * (static_cast<size_t>(W) + K));
-    out.endCount.ensure(static_cast<size_t>(twoLives ? nRg : nEnt) * (W + 1));
-    out.rgBase.ensure(nEnt);
-    out.rgPacked.ensure(nEnt);
-    c.dEntChunks.ensure(2 * static_cast<size_t>(nEnt));
-    c.dEntMax.ensure(2 * static_cast<size_t>(nEnt));
-    c.dTotals.ensure(4);
-    c.dProblems.ensure(1);
-    c.hTotals.resize(5);
-    PD_HIP(hipMemsetAsync(c.dProblems.p, 0, sizeof(unsigned), cs));
-    pd::BuildEntities enReal = en;
-    enReal.nScan = 0;
-    if (twoLives)
-    {
-        out.winStartPk.ensure(static_cast<size_t>(nEnt) * (static_cast<size_t>(W) + K1));
-        out.endCountPk.ensure(static_cast<size_t>(nEnt) * (W + 1));
-        out.rgBasePk.ensure(nEnt);
-    }
-    {
-        // stage-2 arrays (real read groups; all entities if there is one life only)
-        pd::CountOut co;
-        co.winStart = out.winStart.p;
-        co.endCount = out.endCount.p;
-        co.entChunks = c.dEntChunks.p;
-        co.entMax = c.dEntMax.p;
-        co.rgPacked = out.rgPacked.p;
-        co.problems = c.dProblems.p;
-        if (!pd::launchCount(in, twoLives ? enReal : en, W, K, co, cs))
-            throw HipError{"the layout build kernel cannot get its LDS"};
-        PD_HIP(hipGetLastError());
-        pd::launchBaseScan(c.dEntChunks.p, twoLives ? nRg : nEnt, nRg, out.rgBase.p, c.dTotals.p, cs);
-        PD_HIP(hipGetLastError());
-    }
-    if (twoLives)
-    {
-        pd::CountOut co;
-        co.winStart = out.winStartPk.p;
-        co.endCount = out.endCountPk.p;
-        co.entChunks = c.dEntChunks.p + nEnt;
-        co.entMax = c.dEntMax.p + nEnt;
-        co.rgPacked = out.rgPacked.p;
-        co.problems = c.dProblems.p;
-        if (!pd::launchCount(in, en, W, K1, co, cs))
-            throw HipError{"the layout build kernel cannot get its LDS"};
-        PD_HIP(hipGetLastError());
-        pd::launchBaseScan(c.dEntChunks.p + nEnt, nEnt, nRg, out.rgBasePk.p, c.dTotals.p + 2, cs);
-        PD_HIP(hipGetLastError());
-    }
-    c.hEntMax.resize(nEnt);
-    PD_HIP(hipMemcpyAsync(c.hTotals.data(), c.dTotals.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
-    PD_HIP(hipMemcpyAsync(c.hTotals.data() + 4, c.dProblems.p, sizeof(unsigned), hipMemcpyDeviceToHost, cs));
-    PD_HIP(hipMemcpyAsync(c.hEntMax.data(), c.dEntMax.p + (twoLives ? nEnt : 0), nEnt * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
-    PD_HIP(hipStreamSynchronize(cs));
-    if (static_cast<unsigned>(c.hTotals[4] & 0xffffffffu) != 0)
-        throw HipError{"pair instances of a read group are not ordered by their first window (pd_segment: non-decreasing `on`)"};
-    const uint64_t totalReal = c.hTotals[0], totalPk = twoLives ? c.hTotals[3] : c.hTotals[1];
-    out.nChunks = totalReal;
-    {
-        // ... of 99 % of the streams: a few unusually deep samples should not cost everybody else occupancy
-        std::vector<uint32_t> entMax(c.hEntMax.data(), c.hEntMax.data() + nEnt);
-        std::sort(entMax.begin(), entMax.end());
-        out.maxBlockChunks = entMax.empty() ? 0 : entMax[std::min(entMax.size() - 1, entMax.size() * 99 / 100)];
-    }
-    // ---- chunks to their places
-    out.pairs.ensure(totalReal);
-    out.start.ensure(totalReal);
-    out.pairsPk.ensure(totalPk + 128);             // the scan's LDS-DMA copies whole 128-chunk pieces (stage1.hip)
-    {
-        pd::ScatterOut so;
-        so.pairs = out.pairs.p;
-        so.start = out.start.p;
-        so.pairsPk = twoLives ? nullptr : out.pairsPk.p;
-        so.rgBase = out.rgBase.p;
-        so.winStart = out.winStart.p;
-        if (!pd::launchScatter(in, twoLives ? enReal : en, W, K, so, cs))
-            throw HipError{"the layout scatter kernel cannot get its LDS"};
-        PD_HIP(hipGetLastError());
-    }
-    if (twoLives)
-    {
-        pd::ScatterOut so;
-        so.pairs = nullptr;
-        so.start = nullptr;
-        so.pairsPk = out.pairsPk.p;
-        so.rgBase = out.rgBasePk.p;
-        so.winStart = out.winStartPk.p;
-        if (!pd::launchScatter(in, en, W, K1, so, cs))
-            throw HipError{"the layout scatter kernel cannot get its LDS"};
-        PD_HIP(hipGetLastError());
-    }
-    const size_t blocksPerSample = (static_cast<size_t>(W) + 2 * pd::kStage1Block - 1) / (2 * pd::kStage1Block);
-    out.hasScanGeneric = nV != 0;
-    if (nV != 0)
-    {
-        out.scanGeneric.ensure(static_cast<size_t>(nV) * blocksPerSample);
-        PD_HIP(hipMemsetAsync(out.scanGeneric.p, 0, static_cast<size_t>(nV) * blocksPerSample, cs));
-        pd::launchScanGeneric(en, c.dRg.p, out.winStart.p, out.endCount.p, W, K, out.scanGeneric.p, static_cast<unsigned>(blocksPerSample), cs);
-        PD_HIP(hipGetLastError());
-    }
-    return true;
+    const bool isNarrow = narrow.load();
+    return buildLayoutOnDevice(c, in, nInst, W, out, [&]() {
+        if (debug)
+            fprintf(stderr, "[popdel_hip] device build: %llu instances uploaded %s, %zu exceptions; packing %.1f ms on the host threads, "
+                            "%.1f ms until the last byte was on the device\n", (unsigned long long)nInst,
+                    isNarrow ? (compact ? "compact (5 B)" : "narrow (8 B)") : "wide (16 B)", exceptions.size(), packSeconds * 1e3,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild0).count() * 1e3);
+    });
 }
 
 pd::SegmentView viewOf(const StagedSegment & s)
@@ -1788,6 +1825,294 @@ int pd_segment_submit(pd_ctx * c, const pd_segment * seg, uint64_t * ticket)
     {
         c->staged.erase(h);
         return rc;
+    }
+    return 0;
+}
+
+namespace {
+
+pd::WalkState walkStateOf(pd_ctx & c, int set)
+{
+    pd_ctx::WalkBuffers & b = c.walkState[set];
+    pd::WalkState st;
+    st.aStart = b.aStart.p;
+    st.aDev = b.aDev.p;
+    st.aId = b.aId.p;
+    st.aLast = b.aLast.p;
+    st.nActive = b.nActive.p;
+    st.pStart = b.pStart.p;
+    st.pDev = b.pDev.p;
+    st.pId = b.pId.p;
+    st.pLast = b.pLast.p;
+    st.nPending = b.nPending.p;
+    st.capActive = c.walkCapActive;
+    st.capPending = c.walkCapPending;
+    return st;
+}
+
+// First use: room for the lists of every read group (active pairs are bounded by the read groups' maxLoad -- the loader
+// stops filing pairs beyond it -- plus what is carried; the pending list holds the sliver of a slot no window reached).
+void prepareWalkState(pd_ctx & c)
+{
+    if (c.walkReady)
+        return;
+    uint32_t most = 0;
+    for (uint32_t m : c.maxLoad)
+        most = std::max(most, std::min<uint32_t>(m, 4096u));
+    c.walkCapActive = std::max<uint32_t>(256u, 2u * most + 64u);
+    for (int k = 0; k < 2; ++k)
+    {
+        pd_ctx::WalkBuffers & b = c.walkState[k];
+        const size_t na = static_cast<size_t>(c.nRg) * c.walkCapActive, np = static_cast<size_t>(c.nRg) * c.walkCapPending;
+        b.aStart.alloc(na);
+        b.aDev.alloc(na);
+        b.aId.alloc(na);
+        b.aLast.alloc(na);
+        b.pStart.alloc(np);
+        b.pDev.alloc(np);
+        b.pId.alloc(np);
+        b.pLast.alloc(np);
+        b.nActive.alloc(c.nRg);
+        b.nPending.alloc(c.nRg);
+        PD_HIP(hipMemsetAsync(b.nActive.p, 0, c.nRg * sizeof(uint32_t), c.copyStream));
+        PD_HIP(hipMemsetAsync(b.nPending.p, 0, c.nRg * sizeof(uint32_t), c.copyStream));
+    }
+    c.dWalkTotals.alloc(3);
+    c.hWalkTotals.resize(3);
+    c.walkCur = 0;
+    c.walkReady = true;
+}
+
+}  // namespace
+
+int pd_walk_supported(const pd_ctx * c) { return c ? 1 : 0; }
+
+int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
+{
+    if (!c || !wk || !ticket || !wk->rg_counts || !wk->rg_entries || !wk->end_border || !wk->id_offset || !wk->switches || !wk->equal_run)
+        return fail(c, "pd_walk_submit: invalid argument");
+    if (wk->n_readgroups != c->nRg)
+        return fail(c, "pd_walk_submit: read-group count mismatch");
+    if (wk->n_windows == 0 || wk->window_shift == 0)
+        return fail(c, "pd_walk_submit: a segment needs at least one window");
+    const uint32_t nRg = c->nRg, W = wk->n_windows;
+    uint64_t handle = 0;
+    try
+    {
+        PD_HIP(hipSetDevice(c->device));
+        hipStream_t cs = c->copyStream;
+        prepareWalkState(*c);
+        std::unique_ptr<StagedSegment> s;
+        if (!c->spare.empty())
+        {
+            s = std::move(c->spare.back());
+            c->spare.pop_back();
+        }
+        else
+            s.reset(new StagedSegment());
+        s->ownedBySubmit = true;
+        s->waitBuilt = false;
+        s->firstPos = wk->first_window_pos;
+        s->nWindows = W;
+        s->shift = wk->window_shift;
+        // ---- the loader's tables -> HBM (page-locked staging copy by the host threads, slab by slab under the upload)
+        c->hRgOffsets.resize(nRg + 1);
+        c->hRgOffsets[0] = 0;
+        for (uint32_t r = 0; r < nRg; ++r)
+        {
+            const uint32_t n = wk->switches[r] != 0 ? wk->rg_counts[r] : 0u;
+            if (n != 0 && !wk->rg_entries[r])
+                throw HipError{"a read group has entries but no table"};
+            c->hRgOffsets[r + 1] = c->hRgOffsets[r] + n;
+        }
+        const uint64_t nEntries = c->hRgOffsets[nRg];
+        DevBuf<uint64_t> & dEntryOffsets = c->dWalkEntryOffsets;
+        dEntryOffsets.uploadPinned(c->hRgOffsets, cs);
+        c->hWalkBorder.resize(nRg);
+        c->hWalkIdOffset.resize(nRg);
+        c->hWalkFlags.resize(2 * static_cast<size_t>(nRg));
+        std::memcpy(c->hWalkBorder.data(), wk->end_border, nRg * sizeof(uint32_t));
+        std::memcpy(c->hWalkIdOffset.data(), wk->id_offset, nRg * sizeof(uint32_t));
+        std::memcpy(c->hWalkFlags.data(), wk->switches, nRg);
+        std::memcpy(c->hWalkFlags.data() + nRg, wk->equal_run, nRg);
+        c->dWalkBorder.uploadPinned(c->hWalkBorder, cs);
+        c->dWalkIdOffset.uploadPinned(c->hWalkIdOffset, cs);
+        c->dWalkFlags.uploadPinned(c->hWalkFlags, cs);
+        c->hWalkEntries.resize(nEntries);
+        c->dWalkEntries.ensure(std::max<uint64_t>(1, nEntries));
+        {
+            // the read groups' tables -> one page-locked array (host threads), slab by slab under the upload
+            static_assert(sizeof(pd_walk_entry) == sizeof(uint2), "entry layout");
+            const size_t nSlabs = std::min<size_t>(8, std::max<size_t>(1, nRg / 64));
+            for (size_t slab = 0; slab < nSlabs; ++slab)
+            {
+                const size_t rLo = nRg * slab / nSlabs, rHi = nRg * (slab + 1) / nSlabs;
+                const uint64_t a = c->hRgOffsets[rLo], b = c->hRgOffsets[rHi];
+                if (b == a)
+                    continue;
+                pdh::parallelFor(rHi - rLo, [&](size_t k) {
+                    const size_t r = rLo + k;
+                    const uint64_t n = c->hRgOffsets[r + 1] - c->hRgOffsets[r];
+                    if (n)
+                        std::memcpy(c->hWalkEntries.data() + c->hRgOffsets[r], wk->rg_entries[r], n * sizeof(uint2));
+                }, 16);
+                PD_HIP(hipMemcpyAsync(c->dWalkEntries.p + a, c->hWalkEntries.data() + a, (b - a) * sizeof(uint2), hipMemcpyHostToDevice, cs));
+            }
+        }
+        // ---- instances per read group, their offsets (the build's rgOffsets), then the instances and the new state
+        pd::WalkInput in;
+        in.rgOffsets = dEntryOffsets.p;
+        in.entries = c->dWalkEntries.p;
+        in.endBorder = c->dWalkBorder.p;
+        in.idOffset = c->dWalkIdOffset.p;
+        in.switches = c->dWalkFlags.p;
+        in.equalRun = c->dWalkFlags.p + nRg;
+        pd::WalkParams wp{wk->first_window_pos, wk->step_pos, wk->has_step ? 1u : 0u, W, wk->window_shift};
+        const pd::WalkState cur = walkStateOf(*c, c->walkCur), nxt = walkStateOf(*c, c->walkCur ^ 1);
+        c->dWalkCount.ensure(nRg);
+        c->dRgOffsets.ensure(nRg + 1);
+        PD_HIP(hipMemsetAsync(c->dWalkTotals.p, 0, 3 * sizeof(unsigned long long), cs));
+        pd::launchWalkCount(in, cur, wp, c->dRg.p, nRg, c->dWalkCount.p, c->dRgOffsets.p, reinterpret_cast<uint64_t *>(c->dWalkTotals.p), cs);
+        PD_HIP(hipGetLastError());
+        PD_HIP(hipMemcpyAsync(c->hWalkTotals.data(), c->dWalkTotals.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+        PD_HIP(hipStreamSynchronize(cs));
+        const uint64_t nInst = c->hWalkTotals[0];
+        for (int k = 0; k < 4; ++k)
+            c->dIn32[k].ensure(std::max<uint64_t>(1, nInst));
+        pd::launchWalkEmit(in, cur, wp, c->dRg.p, nRg, c->dRgOffsets.p, reinterpret_cast<int32_t *>(c->dIn32[0].p), c->dIn32[1].p, c->dIn32[2].p,
+                           c->dIn32[3].p, nxt, reinterpret_cast<unsigned *>(c->dWalkTotals.p + 2), c->dWalkTotals.p + 1, cs);
+        PD_HIP(hipGetLastError());
+        c->walkCur ^= 1;
+        PD_HIP(hipMemcpyAsync(c->hWalkTotals.data() + 1, c->dWalkTotals.p + 1, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+        bool built = false;
+        const bool deviceBuild = pd::buildLdsBytes(W, 48) <= 160u * 1024u;     // (else: more windows than the build kernels keep in LDS)
+        if (nInst != 0 && deviceBuild)
+        {
+            pd::InstanceArrays ia;
+            std::memset(&ia, 0, sizeof(ia));
+            ia.wide = 1;
+            ia.dev32 = reinterpret_cast<const int32_t *>(c->dIn32[0].p);
+            ia.on32 = c->dIn32[1].p;
+            ia.off32 = c->dIn32[2].p;
+            ia.start32 = c->dIn32[3].p;
+            ia.firstPos = wk->first_window_pos;
+            ia.shift = wk->window_shift;
+            built = buildLayoutOnDevice(*c, ia, nInst, W, *s, nullptr);
+        }
+        else
+            PD_HIP(hipStreamSynchronize(cs));
+        // (the build's first synchronisation point lies behind the copy above)
+        c->walkActive = c->hWalkTotals[1];
+        if (c->hWalkTotals[2] != 0)
+            throw HipError{"a read group has more active or pending pairs than the device-side window loop keeps (run with POPDEL_HOST_WALK=1)"};
+        if (nInst == 0)
+        {
+            // no pair is active in any window: the (host-side) path for empty segments
+            c->spare.push_back(std::move(s));
+            std::vector<uint64_t> zeros(nRg + 1, 0);
+            pd_segment empty;
+            std::memset(&empty, 0, sizeof(empty));
+            empty.first_window_pos = wk->first_window_pos;
+            empty.n_windows = W;
+            empty.window_shift = wk->window_shift;
+            empty.n_readgroups = nRg;
+            empty.rg_offsets = zeros.data();
+            return pd_segment_submit(c, &empty, ticket);
+        }
+        if (!built)
+        {
+            // a segment the device-side layout build does not take: its instances come back and go the way of pd_segment
+            c->spare.push_back(std::move(s));
+            std::vector<uint64_t> off(nRg + 1);
+            std::vector<int32_t> dv(nInst);
+            std::vector<uint32_t> on(nInst), of(nInst), st(nInst);
+            PD_HIP(hipMemcpy(off.data(), c->dRgOffsets.p, (nRg + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            PD_HIP(hipMemcpy(dv.data(), c->dIn32[0].p, nInst * sizeof(int32_t), hipMemcpyDeviceToHost));
+            PD_HIP(hipMemcpy(on.data(), c->dIn32[1].p, nInst * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            PD_HIP(hipMemcpy(of.data(), c->dIn32[2].p, nInst * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            PD_HIP(hipMemcpy(st.data(), c->dIn32[3].p, nInst * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            pd_segment seg;
+            std::memset(&seg, 0, sizeof(seg));
+            seg.first_window_pos = wk->first_window_pos;
+            seg.n_windows = W;
+            seg.window_shift = wk->window_shift;
+            seg.n_readgroups = nRg;
+            seg.rg_offsets = off.data();
+            seg.pair_dev = dv.data();
+            seg.pair_start = st.data();
+            seg.pair_on = on.data();
+            seg.pair_off = of.data();
+            return pd_segment_submit(c, &seg, ticket);
+        }
+        s->scanRg = c->dScanRg.p;
+        s->nRealRg = c->nRg;
+        if (!s->built)
+            PD_HIP(hipEventCreateWithFlags(&s->built, hipEventDisableTiming));
+        PD_HIP(hipEventRecord(s->built, cs));
+        s->waitBuilt = true;
+        handle = c->nextHandle++;
+        c->staged[handle] = std::move(s);
+    }
+    catch (const HipError & e)
+    {
+        return fail(c, "pd_walk_submit: " + e.what);
+    }
+    catch (const std::exception & e)
+    {
+        return fail(c, std::string("pd_walk_submit: ") + e.what());
+    }
+    catch (...)
+    {
+        return fail(c, "pd_walk_submit: unknown exception");
+    }
+    if (int rc = pd_segment_run(c, handle, ticket))
+    {
+        c->staged.erase(handle);
+        return rc;
+    }
+    return 0;
+}
+
+int pd_walk_active(pd_ctx * c, uint64_t * nActive, uint32_t * rg, uint32_t * start, int32_t * dev, uint32_t * id, uint64_t capacity)
+{
+    if (!c || !nActive)
+        return fail(c, "pd_walk_active: invalid argument");
+    *nActive = c->walkReady ? c->walkActive : 0;
+    if (!rg || !start || !dev || !id || *nActive == 0)
+        return 0;
+    if (capacity < *nActive)
+        return 2;
+    try
+    {
+        PD_HIP(hipSetDevice(c->device));
+        PD_HIP(hipStreamSynchronize(c->copyStream));
+        pd_ctx::WalkBuffers & b = c->walkState[c->walkCur];
+        std::vector<uint32_t> n(c->nRg);
+        PD_HIP(hipMemcpy(n.data(), b.nActive.p, c->nRg * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint64_t at = 0;
+        for (uint32_t r = 0; r < c->nRg; ++r)
+        {
+            if (n[r] == 0)
+                continue;
+            if (at + n[r] > capacity)
+                return 2;
+            const size_t base = static_cast<size_t>(r) * c->walkCapActive;
+            PD_HIP(hipMemcpy(start + at, b.aStart.p + base, n[r] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            PD_HIP(hipMemcpy(dev + at, b.aDev.p + base, n[r] * sizeof(int32_t), hipMemcpyDeviceToHost));
+            PD_HIP(hipMemcpy(id + at, b.aId.p + base, n[r] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            for (uint32_t k = 0; k < n[r]; ++k)
+                rg[at + k] = r;
+            at += n[r];
+        }
+        *nActive = at;
+    }
+    catch (const HipError & e)
+    {
+        return fail(c, "pd_walk_active: " + e.what);
+    }
+    catch (...)
+    {
+        return fail(c, "pd_walk_active: unknown exception");
     }
     return 0;
 }

@@ -137,6 +137,9 @@ public:
     void printTiming()
     {
         if (getenv("POPDEL_TIMING") && !timingPrinted_)
+            std::cerr << "[popdel timing] window loop: " << deviceSegments_ << " segments in closed form on the device, " << hostSegments_
+                      << " walked on the host" << std::endl;
+        if (getenv("POPDEL_TIMING") && !timingPrinted_)
             std::cerr << "[popdel timing] threads " << hostThreads() << "; parameters " << clock_.params << " s; backend start " << clock_.backend << " s; switches " << clock_.switches << " s; decode " << clock_.decode << " s; replay " << clock_.replay << " s (" << clock_.parallelBatches << " batches in parallel, " << clock_.orderedBatches << " in order)"
                       << "; window walk " << clock_.walk << " s; flatten " << clock_.flatten << " s; stage+submit " << clock_.submit
                       << " s; collect+merge+write " << clock_.collect << " s" << std::endl;
@@ -196,6 +199,14 @@ private:
     void checkWalkAgainstPlan(const WalkShape & shape, const std::vector<uint8_t> & equalRun, const std::vector<uint8_t> & switches,
                               const std::vector<std::pair<size_t, size_t>> & cursors, unsigned firstPos, unsigned nWindows,
                               const std::vector<std::vector<PairInstance>> & log);
+    // The window loop in closed form on the device (pd_walk_submit) instead of walked here: whenever the backend offers it,
+    // nobody wants to see the instances (observers, POPDEL_WALK_CHECK) and POPDEL_HOST_WALK is not set. deviceWalk_ says
+    // whose turn it is: the device keeps the active pairs while it is on; leaving it (a segment that cannot be planned)
+    // fetches them back into the tables' active sets, and a ROI change with no pair left active turns it on again.
+    bool deviceWalkOffered_ = false, deviceWalk_ = false;
+    unsigned deviceSegments_ = 0, hostSegments_ = 0;
+    void leaveDeviceWalk();
+    void submitPlannedSegment(const WalkShape & shape, const std::vector<uint8_t> & equalRun, const std::vector<uint8_t> & switches);
     bool timingPrinted_ = false;
     bool pending_ = false;
     std::string pendingContig_;
@@ -867,6 +878,27 @@ void CallRun::flushPending()
 void CallRun::processSegment()
 {
     ChromProfile & prof = *profile_;
+    if (deviceWalk_)
+    {
+        if (prof.canPlanSegment(p_.windowShift))
+        {
+            double t0 = PhaseClock::now();
+            std::vector<uint8_t> equalRun, switches;
+            const WalkShape shape = prof.planSegment(p_.windowShift, equalRun, switches);
+            windows_.current.pos += shape.nWindows * p_.windowShift;
+            clock_.walk += PhaseClock::now() - t0;
+            t0 = PhaseClock::now();
+            flushPending();
+            clock_.collect += PhaseClock::now() - t0;
+            t0 = PhaseClock::now();
+            submitPlannedSegment(shape, equalRun, switches);
+            clock_.submit += PhaseClock::now() - t0;
+            ++deviceSegments_;
+            return;
+        }
+        leaveDeviceWalk();
+    }
+    ++hostSegments_;
     // (check mode: plan the segment on the tables as they are now, note what the plan says, put the state back, then walk)
     WalkShape planned;
     std::vector<uint8_t> plannedRun, plannedSwitches;
@@ -974,6 +1006,69 @@ void CallRun::processSegment()
     clock_.submit += PhaseClock::now() - t0;
 }
 
+// The segment as the tables hold it, to every context: the entries of the read slots of the read groups whose slots were
+// switched (the tables themselves -- no copy here), the borders their end records were filed under, the plan.
+void CallRun::submitPlannedSegment(const WalkShape & shape, const std::vector<uint8_t> & equalRun, const std::vector<uint8_t> & switches)
+{
+    ChromProfile & prof = *profile_;
+    const size_t nRg = prof.starts.size();
+    std::vector<uint32_t> counts(nRg), borders(nRg), idOffsets(nRg);
+    std::vector<const pd_walk_entry *> tables(nRg);
+    static_assert(sizeof(StartEntry) == sizeof(pd_walk_entry), "the start tables are handed over as they are");
+    for (size_t rg = 0; rg < nRg; ++rg)
+    {
+        const StartSlots & st = prof.starts[rg];
+        const StartSlots::Slot & slot = st.slots[st.readSlot];
+        counts[rg] = static_cast<uint32_t>(slot.entries.size());
+        tables[rg] = reinterpret_cast<const pd_walk_entry *>(slot.entries.data());
+        borders[rg] = slot.endBorder;
+        idOffsets[rg] = slot.idOffset;
+    }
+    onEveryContext([&](unsigned r) {
+        const uint32_t g0 = shardRg_[r], g1 = shardRg_[r + 1];
+        pd_walk wk;
+        std::memset(&wk, 0, sizeof(wk));
+        wk.first_window_pos = shape.firstPos;
+        wk.step_pos = shape.stepPos;
+        wk.has_step = shape.hasStep ? 1u : 0u;
+        wk.n_windows = shape.nWindows;
+        wk.window_shift = p_.windowShift;
+        wk.n_readgroups = g1 - g0;
+        wk.rg_counts = counts.data() + g0;
+        wk.rg_entries = tables.data() + g0;
+        wk.end_border = borders.data() + g0;
+        wk.id_offset = idOffsets.data() + g0;
+        wk.switches = switches.data() + g0;
+        wk.equal_run = equalRun.data() + g0;
+        if (pd_walk_submit(ctxs_[r], &wk, &tickets_[r]) != 0)
+            throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
+    });
+    pending_ = true;
+    pendingContig_ = windows_.current.contig;
+}
+
+// From the device's window loop back to the one here: the pairs the device holds as active become the tables' active
+// sets (the cursors have been kept where the walk would have left them all along).
+void CallRun::leaveDeviceWalk()
+{
+    ChromProfile & prof = *profile_;
+    for (size_t r = 0; r < ctxs_.size(); ++r)
+    {
+        uint64_t n = 0;
+        if (pd_walk_active(ctxs_[r], &n, nullptr, nullptr, nullptr, nullptr, 0) != 0)
+            throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
+        if (n == 0)
+            continue;
+        std::vector<uint32_t> rg(n), start(n), id(n);
+        std::vector<int32_t> dev(n);
+        if (pd_walk_active(ctxs_[r], &n, rg.data(), start.data(), dev.data(), id.data(), n) != 0)
+            throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
+        for (uint64_t i = 0; i < n; ++i)
+            prof.materializeActive(shardRg_[r] + rg[i], id[i], start[i], dev[i]);
+    }
+    deviceWalk_ = false;
+}
+
 void CallRun::checkWalkAgainstPlan(const WalkShape & shape, const std::vector<uint8_t> & equalRun, const std::vector<uint8_t> & switches,
                                    const std::vector<std::pair<size_t, size_t>> & cursors, unsigned firstPos, unsigned nWindows,
                                    const std::vector<std::vector<PairInstance>> & log)
@@ -1035,6 +1130,32 @@ bool CallRun::finalizeRoi()
     // segment be planned in closed form)
     if (walkCheck_ && walkCheck_->activeTotal() == 0)
         profile_->setActiveKnownEmpty(true);
+    if (deviceWalkOffered_)
+    {
+        uint64_t left = 0;
+        if (deviceWalk_)
+        {
+            for (pd_ctx * c : ctxs_)
+            {
+                uint64_t n = 0;
+                if (pd_walk_active(c, &n, nullptr, nullptr, nullptr, nullptr, 0) != 0)
+                    throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(c));
+                left += n;
+            }
+            if (left != 0)
+                leaveDeviceWalk();          // (the reference keeps such pairs active across the ROI change: the tables take over)
+        }
+        else
+        {
+            for (const auto & a : profile_->active)
+                left += a.size();
+        }
+        if (left == 0)
+        {
+            profile_->setActiveKnownEmpty(true);
+            deviceWalk_ = true;
+        }
+    }
     nextReadPos_ = kNoPos;
     windows_.current.contig = p_.allRois[p_.nextRoi].seqName;
     windows_.current.pos = 0;
@@ -1067,6 +1188,10 @@ int CallRun::run()
     tStart = PhaseClock::now();
     createBackend();
     chooseMergeSite();
+    deviceWalkOffered_ = !getenv("POPDEL_HOST_WALK") && !getenv("POPDEL_WALK_CHECK") && !observer_;
+    for (pd_ctx * c : ctxs_)
+        deviceWalkOffered_ = deviceWalkOffered_ && pd_walk_supported(c) == 1;
+    deviceWalk_ = deviceWalkOffered_;
     clock_.backend = PhaseClock::now() - tStart;
     profile_.reset(new ChromProfile(static_cast<unsigned>(p_.readGroups.size()), p_.maxLoad, p_.windowBuffer));
     if (observer_ && observer_->onActiveOps)
@@ -1075,6 +1200,19 @@ int CallRun::run()
     profile_->resetTo(profile_->currentPos);
     if (getenv("POPDEL_WALK_CHECK"))
         walkCheck_.reset(new WalkReference(static_cast<unsigned>(p_.readGroups.size())));
+    profile_->externalActive = [this]() -> size_t {
+        if (!deviceWalk_)
+            return 0;
+        uint64_t left = 0;
+        for (pd_ctx * c : ctxs_)
+        {
+            uint64_t n = 0;
+            if (pd_walk_active(c, &n, nullptr, nullptr, nullptr, nullptr, 0) != 0)
+                throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(c));
+            left += n;
+        }
+        return static_cast<size_t>(left);
+    };
 
     while (p_.fileCount != 0)
     {

@@ -485,6 +485,8 @@ bool ChromProfile::allEmpty() const
         if (!active[i].empty())
             return false;
     }
+    if (externalActive && externalActive() != 0)
+        return false;
     return true;
 }
 

@@ -12,6 +12,7 @@
 #define PDH_CHROM_PROFILE_H_
 
 #include <algorithm>
+#include <functional>
 #include <cstdint>
 #include <cstddef>
 #include <limits>
@@ -156,6 +157,8 @@ public:
     void performSwitches(const std::vector<unsigned> & rgs, unsigned * border = nullptr);
     void performPartialSwitches(const std::vector<unsigned> & rgs, unsigned * border = nullptr);
     bool allEmpty() const;
+    // while someone else evaluates the walk (and keeps the active pairs): how many pairs are active there
+    std::function<size_t()> externalActive;
 
     // --- event log (segment builder) -------------------------------------------------------------------
     // Call before the first genotyped window of a segment: carried-over pairs become instances with on = 0.
@@ -199,6 +202,8 @@ public:
     PlanState savePlanState() const;
     void restorePlanState(const PlanState & s);
     bool activeKnownEmpty() const { return activeKnownEmpty_; }
+    // a pair the evaluator of the closed-form walk holds as active, back into the tables' active set (leaving that mode)
+    void materializeActive(unsigned rg, uint32_t id, uint32_t start, int32_t dev) { active[rg].emplace(id, ActiveRec{dev, start, kNoLog}); }
     void setActiveKnownEmpty(bool v) { activeKnownEmpty_ = v; }
 
     std::vector<StartSlots> starts;
@@ -309,8 +314,9 @@ public:
     std::vector<unsigned> activeLoad;
     std::vector<unsigned> maxLoad;
 
-private:
     static constexpr uint32_t kNoLog = 0xffffffffu;
+
+private:
     void activate(unsigned rg, unsigned id, unsigned logWindow);
     void deactivate(unsigned rg, unsigned id, unsigned logWindow);
     void nextStartWindow(unsigned rg, unsigned logWindow);

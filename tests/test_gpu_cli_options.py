@@ -91,3 +91,28 @@ def test_more_than_65535_windows_per_segment(built, tmp_path):
     a = run(POPDEL_BIN, d, str(tmp_path / "gpu.vcf"), opts)
     b = run(ORACLE_CALL, d, str(tmp_path / "cpu.vcf"), opts)
     assert a == b and a.count("\n") > 60
+
+
+@pytest.mark.parametrize("opts", OPTION_SETS + [["-R", "rois.txt", "-A", "maxcov.txt", "-n"]],
+                         ids=lambda o: "_".join(x.replace(":", "").replace("-", "") for x in o)[:60])
+def test_window_loop_on_the_device_equals_the_walk_on_the_host(built, mixed_cohort, tmp_path, opts):
+    """`popdel call` hands the segments over as the loader's tables hold them and the library runs the window loop in closed
+    form on the device (pd_walk_submit); POPDEL_HOST_WALK=1 walks the windows on the host as the reference does and hands
+    over pair instances (pd_segment_submit). Same VCF, byte for byte -- and the device path must really have run."""
+    import re
+    opts = [os.path.join(mixed_cohort, o) if o.endswith(".txt") else o for o in opts]
+    outs = []
+    for host_walk in (False, True):
+        env = dict(os.environ, POPDEL_TIMING="1")
+        if host_walk:
+            env["POPDEL_HOST_WALK"] = "1"
+        out = str(tmp_path / ("h.vcf" if host_walk else "d.vcf"))
+        r = subprocess.run([POPDEL_BIN, "call", os.path.join(mixed_cohort, "profiles.txt"), "-o", out] + opts, env=env,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1500:]
+        m = re.search(r"window loop: (\d+) segments in closed form on the device, (\d+) walked on the host", r.stderr)
+        assert m, r.stderr[-800:]
+        on_device, on_host = int(m.group(1)), int(m.group(2))
+        assert (on_device == 0 and on_host >= 2) if host_walk else (on_device >= 2 and on_host == 0), (on_device, on_host)
+        outs.append(strip_date(open(out).read()))
+    assert outs[0] == outs[1] and outs[0].count("\n") > 25
