@@ -339,6 +339,11 @@ int pd_log_table_view(pd_ctx *ctx, uint32_t rg, double *value, double *log_value
 /* Text of the last error on this context (or of the last failed pd_ctx_create if ctx == NULL). */
 const char *pd_last_error(const pd_ctx *ctx);
 
+/* Start the GPU runtime on `device` ahead of pd_ctx_create() (loading the code objects and creating the device context
+ * takes 0.1-0.2 s): a host that has other start-up work -- `popdel call` reads its profile headers -- calls this from a
+ * second thread first. No reference counterpart. Returns 0 on success. */
+int pd_device_warmup(int device);
+
 /* Name of the implementation behind the ABI ("hip-gfx950" for the product library). */
 const char *pd_backend_name(void);
 

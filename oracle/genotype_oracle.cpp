@@ -1073,6 +1073,8 @@ void pd_merged_free(pd_merged *) {}
 
 int pd_rccl_unique_id(uint8_t *) { return 1; }
 
+int pd_device_warmup(int) { return 0; }
+
 // The oracle takes segments as pair instances (pd_segment) only: the host walks the windows itself.
 int pd_walk_supported(const pd_ctx *) { return 0; }
 int pd_walk_submit(pd_ctx * c, const pd_walk *, uint64_t *)

@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     "pd_abi_version", "pd_shard_samples", "pd_ctx_set_shard", "pd_ctx_set_shard_rccl", "pd_rccl_unique_id",
     "pd_local_group_create", "pd_local_group_destroy", "pd_ctx_set_shard_local", "pd_log_table_view",
     "pd_ctx_keep_results_on_device", "pd_calls_merge", "pd_calls_fetch_columns", "pd_merged_free",
-    "pd_walk_submit", "pd_walk_supported", "pd_walk_active",
+    "pd_walk_submit", "pd_walk_supported", "pd_walk_active", "pd_device_warmup",
 )
 RCCL_ID_BYTES = 128
 

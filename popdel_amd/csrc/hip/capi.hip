@@ -2978,6 +2978,17 @@ int pd_last_timing(pd_ctx * c, pd_timing * out)
 
 const char * pd_last_error(const pd_ctx * c) { return c ? c->error.c_str() : g_createError.c_str(); }
 
+int pd_device_warmup(int device)
+{
+    if (hipSetDevice(device) != hipSuccess)
+        return 1;
+    void * p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess)       // (the first allocation creates the context and loads the code objects)
+        return 1;
+    (void)hipFree(p);
+    return 0;
+}
+
 const char * pd_backend_name(void) { return "hip-gfx950"; }
 
 int pd_abi_version(void) { return PD_ABI_VERSION; }

@@ -1169,6 +1169,18 @@ bool CallRun::finalizeRoi()
 int CallRun::run()
 {
     double tStart = PhaseClock::now();
+    // the GPU runtime starts up (0.1-0.2 s) while the profile headers are read
+    std::thread warmup([] {
+        const char * d = getenv("POPDEL_DEVICES");
+        if (!d)
+            d = getenv("POPDEL_DEVICE");
+        (void)pd_device_warmup(d ? atoi(d) : 0);
+    });
+    struct Joiner
+    {
+        std::thread & t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joinWarmup{warmup};
     loadAndCalculateParameters(p_);
     clock_.params = PhaseClock::now() - tStart;
     printStatus("Finished parameter calculation.\n");
@@ -1186,6 +1198,7 @@ int CallRun::run()
     vcf_->appendContigName(windows_.current.contig);
 
     tStart = PhaseClock::now();
+    warmup.join();
     createBackend();
     chooseMergeSite();
     deviceWalkOffered_ = !getenv("POPDEL_HOST_WALK") && !getenv("POPDEL_WALK_CHECK") && !observer_;

@@ -110,10 +110,14 @@ void EndSlots::add(unsigned id, unsigned endPos)
     unsigned which = writeSlot;
     if (needsSwitch(lastWin))
         which = (which + 1) % 3;
+    // behind the last entry that does not end later (what upper_bound finds) -- looked for from the back: pairs arrive in
+    // start order, so a new pair's last window lies among the last few entries' (a binary search over the whole slot
+    // costs more than the handful of comparisons this takes)
     std::vector<EndEntry> & v = slots[which].entries;
-    auto at = std::upper_bound(v.begin(), v.end(), lastWin,
-                               [](unsigned l, const EndEntry & e) { return l < e.lastWindow; });
-    v.insert(at, EndEntry{id, lastWin});
+    size_t at = v.size();
+    while (at > 0 && v[at - 1].lastWindow > lastWin)
+        --at;
+    v.insert(v.begin() + static_cast<std::ptrdiff_t>(at), EndEntry{id, lastWin});
 }
 
 // Number of pairs of the current end-position slot (and, by look-ahead, of the following one) whose last

@@ -8,12 +8,16 @@ threads = sys.argv[2:] or ["64"]
 d = "/tmp/e2e_cohort_%d" % n
 if not os.path.exists(os.path.join(d, "profiles.txt")):
     t = time.time()
-    synth.write_cohort(d, n, deletions=synth.single_deletion)
+    synth.write_cohort(d, n, deletions=synth.single_deletion, workers=16)
     print("cohort written in %.1f s" % (time.time() - t), flush=True)
-for th in threads:
+if not os.path.exists(os.path.join(d, "profiles.txt")):
+    pass
+for th, host_walk in [(t, h) for t in threads for h in (False, True)]:
     env = dict(os.environ, POPDEL_TIMING="1", POPDEL_THREADS=th)
+    if host_walk:
+        env["POPDEL_HOST_WALK"] = "1"
     t = time.time()
     r = subprocess.run([os.path.join(ROOT, "popdel_amd", "lib", "popdel"), "call", os.path.join(d, "profiles.txt"), "-o", "/tmp/e2e.vcf",
                         "-r", "chr20:1000000-2000000"], env=env, capture_output=True, text=True)
-    print("threads", th, "wall %.2f s" % (time.time() - t), "rc", r.returncode)
+    print("threads", th, "window loop on the", "host" if host_walk else "device", "wall %.2f s" % (time.time() - t), "rc", r.returncode)
     print("\n".join(l for l in (r.stdout + r.stderr).splitlines() if "timing" in l.lower() or "phase" in l.lower() or "s " in l[-12:])[-1500:])
