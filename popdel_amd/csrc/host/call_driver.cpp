@@ -98,7 +98,7 @@ struct DecodedRaw
     uint32_t firstWin = 0, nWin = 0;       // its 30-bp windows in DecodedStream::wins
 };
 
-struct DecodedStream
+struct alignas(64) DecodedStream      // (neighbours in the pool are filled by different threads: no shared cache lines)
 {
     std::vector<DecodedRaw> raws;
     std::vector<FlatWindow> wins;          // all 30-bp windows, flat
@@ -615,15 +615,9 @@ unsigned CallRun::replaySegment(const DecodedStream & in, const std::string & fi
                 {
                     const uint32_t n = in.counts[static_cast<size_t>(wi) * rg.size() + r];
                     const InsertHistogram & h = p_.histograms[rg[r]];
-                    for (uint32_t q = r0; q < r0 + n; ++q)
-                    {
-                        const PairRecord & rec = in.recs[q];
-                        int inner = static_cast<int32_t>(rec.dev) + static_cast<int>(h.median) - 2 * static_cast<int>(h.readLength);
-                        unsigned endPos = rec.pos;
-                        if (inner > 0)
-                            endPos += static_cast<unsigned>(inner);
-                        prof.add(rg[r], rec.pos, endPos, static_cast<int32_t>(rec.dev));
-                    }
+                    static_assert(sizeof(PairRecord) == 2 * sizeof(uint32_t), "records are handed over as {pos, dev} words");
+                    prof.addRun(rg[r], reinterpret_cast<const uint32_t *>(in.recs.data() + r0), n,
+                                static_cast<int>(h.median) - 2 * static_cast<int>(h.readLength));
                     r0 += n;
                 }
             }

@@ -229,6 +229,45 @@ void ChromProfile::add(unsigned rg, unsigned startPos, unsigned endPos, int devi
     }
 }
 
+void ChromProfile::addRun(unsigned rg, const uint32_t * posDev, size_t n, int innerOffset)
+{
+    StartSlots & st = starts[rg];
+    EndSlots & en = ends[rg];
+    // (the load counter is kept in a register over the run: the counters of neighbouring read groups share cache lines,
+    // and neighbouring samples are replayed by different threads -- updating it in place per record cost half of the
+    // replay phase in false sharing)
+    unsigned load = activeLoad[rg];
+    const unsigned cap = maxLoad[rg];
+    for (size_t i = 0; i < n; ++i)
+    {
+        const unsigned startPos = posDev[2 * i];
+        const int deviation = static_cast<int32_t>(posDev[2 * i + 1]);
+        const int inner = deviation + innerOffset;
+        const unsigned endPos = startPos + (inner > 0 ? static_cast<unsigned>(inner) : 0u);
+        const unsigned id = st.insertionCount;
+        if (load >= cap)
+        {
+            load -= en.countEnded(startPos);
+            if (load < cap)
+            {
+                noteAdd(st, en, startPos);
+                st.add(startPos, deviation);
+                en.add(id, endPos);
+                ++load;
+            }
+        }
+        else
+        {
+            noteAdd(st, en, startPos);
+            st.add(startPos, deviation);
+            en.add(id, endPos);
+            ++load;
+            load -= en.countEnded(startPos);
+        }
+    }
+    activeLoad[rg] = load;
+}
+
 void ChromProfile::activate(unsigned rg, unsigned id, unsigned logWindow)
 {
     auto & set = active[rg];

@@ -34,7 +34,9 @@ struct EndEntry
 };
 
 // Three slots used round-robin: one is written while the previous one is read.
-class StartSlots
+// (Cache-line aligned, like EndSlots: neighbouring read groups are filed by different threads, and every record that is
+// filed writes to the object -- vector ends, counters.)
+class alignas(64) StartSlots
 {
 public:
     struct Slot
@@ -72,7 +74,7 @@ public:
     unsigned numWindows;
 };
 
-class EndSlots
+class alignas(64) EndSlots
 {
 public:
     struct Slot
@@ -148,6 +150,9 @@ public:
 
     bool isHighCov(unsigned rg) const { return active[rg].size() >= maxLoad[rg]; }
     void add(unsigned rg, unsigned startPos, unsigned endPos, int deviation);
+    // add() for a run of records of one read group ({pos, dev} pairs as the reader delivers them; the pair's end is
+    // pos + max(0, dev + innerOffset), innerOffset = median - 2 * read length): the same operations in the same order
+    void addRun(unsigned rg, const uint32_t * posDev, size_t n, int innerOffset);
     void initializeActive();
     bool nextWindow(unsigned shift);
     void resetTo(unsigned pos);

@@ -233,7 +233,7 @@ bool readWindow(ByteSource & src, ProfileWindow & win, unsigned numReadGroups)
     win.chrom = static_cast<int32_t>(chrom);
     win.beginPos = static_cast<int32_t>(begin);
     win.records.resize(numReadGroups);
-    std::vector<unsigned char> buf;
+    static thread_local std::vector<unsigned char> buf;        // (one heap block per thread instead of one per window)
     for (unsigned rg = 0; rg < numReadGroups; ++rg)
     {
         uint32_t n = 0;
@@ -313,9 +313,66 @@ bool splitWindowFlat(const ProfileWindow & in, std::vector<FlatWindow> & wins, s
         if (!in.records[rg].empty() && in.records[rg][0].pos < base)
             base = in.records[rg][0].pos;
     base = (base / newSize) * newSize;
-    // per slot and read group: number of records
-    std::vector<uint32_t> perSlot(slots * rgNum, 0);
-    std::vector<char> hasContent(slots, 0);
+    if (rgNum == 1)
+    {
+        // One read group (the rule): the records are position-sorted, so the 30-bp windows are runs of the record array as
+        // it is -- one pass, no scatter. (A record out of order ends this path; the general one below reports or handles it.)
+        const std::vector<PairRecord> & rs = in.records[0];
+        if (rs.empty())
+            return false;
+        const size_t wins0 = wins.size(), counts0 = counts.size();
+        const uint32_t first = static_cast<uint32_t>(recs.size());
+        size_t prev = static_cast<size_t>(-1);
+        bool ordered = true;
+        for (size_t i = 0; i < rs.size(); ++i)
+        {
+            const size_t idx = (rs[i].pos - base) / newSize;
+            if (idx != prev)
+            {
+                if (idx >= slots || (prev != static_cast<size_t>(-1) && idx < prev))
+                {
+                    ordered = false;
+                    break;
+                }
+                wins.push_back(FlatWindow{in.chrom, static_cast<int32_t>(base + idx * newSize), first + static_cast<uint32_t>(i)});
+                counts.push_back(0);
+                prev = idx;
+            }
+            ++counts.back();
+        }
+        if (ordered)
+        {
+            recs.insert(recs.end(), rs.begin(), rs.end());
+            return true;
+        }
+        wins.resize(wins0);
+        counts.resize(counts0);
+    }
+    // per slot and read group: number of records (scratch on the stack for the usual sizes: ten slots, a few read groups)
+    constexpr size_t kStack = 160;
+    uint32_t perSlotStack[kStack], cursorStack[kStack];
+    std::vector<uint32_t> perSlotHeap, cursorHeap;
+    uint32_t *perSlot = perSlotStack, *cursor = cursorStack;
+    if (slots * rgNum > kStack)
+    {
+        perSlotHeap.assign(slots * rgNum, 0);
+        cursorHeap.assign(slots * rgNum, 0);
+        perSlot = perSlotHeap.data();
+        cursor = cursorHeap.data();
+    }
+    else
+    {
+        std::fill(perSlot, perSlot + slots * rgNum, 0u);
+        std::fill(cursor, cursor + slots * rgNum, 0u);
+    }
+    char hasContentStack[64] = {0};
+    std::vector<char> hasContentHeap;
+    char * hasContent = hasContentStack;
+    if (slots > 64)
+    {
+        hasContentHeap.assign(slots, 0);
+        hasContent = hasContentHeap.data();
+    }
     for (size_t rg = 0; rg < rgNum; ++rg)
         for (const PairRecord & r : in.records[rg])
         {
@@ -331,7 +388,6 @@ bool splitWindowFlat(const ProfileWindow & in, std::vector<FlatWindow> & wins, s
     if (total == 0)
         return false;
     // layout: windows in slot order; within a window read groups in order
-    std::vector<uint32_t> cursor(slots * rgNum, 0);
     uint32_t next = static_cast<uint32_t>(recs.size());
     for (size_t i = 0; i < slots; ++i)
     {
