@@ -2983,10 +2983,15 @@ int pd_device_warmup(int device)
     if (hipSetDevice(device) != hipSuccess)
         return 1;
     void * p = nullptr;
-    if (hipMalloc(&p, 256) != hipSuccess)       // (the first allocation creates the context and loads the code objects)
+    if (hipMalloc(&p, 256) != hipSuccess)       // (the first allocation creates the device context)
         return 1;
+    // ... and the first kernel launch loads the library's code object
+    pd::ZeroRanges zero{};
+    zero.add(p, 256);
+    pd::launchZero(zero, nullptr);
+    const bool ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     (void)hipFree(p);
-    return 0;
+    return ok ? 0 : 1;
 }
 
 const char * pd_backend_name(void) { return "hip-gfx950"; }

@@ -125,6 +125,8 @@ public:
     CallRun(CallParams & p, SegmentObserver * obs) : p_(p), observer_(obs) {}
     ~CallRun()
     {
+        if (backendThread_.joinable())
+            backendThread_.join();
         for (pd_ctx * c : ctxs_)
             pd_ctx_destroy(c);
         if (group_)
@@ -203,6 +205,20 @@ private:
     // nobody wants to see the instances (observers, POPDEL_WALK_CHECK) and POPDEL_HOST_WALK is not set. deviceWalk_ says
     // whose turn it is: the device keeps the active pairs while it is on; leaving it (a segment that cannot be planned)
     // fetches them back into the tables' active sets, and a ROI change with no pair left active turns it on again.
+    // the backend comes up on its own thread while the first round of profiles is read (run(), ensureBackend())
+    std::thread backendThread_;
+    std::exception_ptr backendError_;
+    void ensureBackend()
+    {
+        if (backendThread_.joinable())
+        {
+            const double t0 = PhaseClock::now();
+            backendThread_.join();
+            clock_.backend += PhaseClock::now() - t0;           // (what the main thread still had to wait for)
+            if (backendError_)
+                std::rethrow_exception(backendError_);
+        }
+    }
     bool deviceWalkOffered_ = false, deviceWalk_ = false;
     unsigned deviceSegments_ = 0, hostSegments_ = 0;
     void leaveDeviceWalk();
@@ -871,6 +887,7 @@ void CallRun::flushPending()
 // backend. The previous segment is collected and written first so that records stay in order.
 void CallRun::processSegment()
 {
+    ensureBackend();
     ChromProfile & prof = *profile_;
     if (deviceWalk_)
     {
@@ -1112,6 +1129,7 @@ void CallRun::checkWalkAgainstPlan(const WalkShape & shape, const std::vector<ui
 
 bool CallRun::finalizeRoi()
 {
+    ensureBackend();
     if (!advanceRoi(p_))
     {
         flushPending();
@@ -1163,7 +1181,9 @@ bool CallRun::finalizeRoi()
 int CallRun::run()
 {
     double tStart = PhaseClock::now();
-    // the GPU runtime starts up (0.1-0.2 s) while the profile headers are read
+    // The GPU runtime starts up (~0.2 s) while the profile headers are read, and the backend is created (tables uploaded,
+    // logarithms taken) while the first window is looked for and the first round of profiles is decoded and filed: the main
+    // thread needs it only when the first segment is submitted (ensureBackend()).
     std::thread warmup([] {
         const char * d = getenv("POPDEL_DEVICES");
         if (!d)
@@ -1191,15 +1211,27 @@ int CallRun::run()
     vcf_.reset(new VcfOutput(p_.outfile, p_.inputFiles, p_.contigNames[0], p_.contigLengths[0]));
     vcf_->appendContigName(windows_.current.contig);
 
-    tStart = PhaseClock::now();
-    warmup.join();
-    createBackend();
-    chooseMergeSite();
-    deviceWalkOffered_ = !getenv("POPDEL_HOST_WALK") && !getenv("POPDEL_WALK_CHECK") && !observer_;
-    for (pd_ctx * c : ctxs_)
-        deviceWalkOffered_ = deviceWalkOffered_ && pd_walk_supported(c) == 1;
-    deviceWalk_ = deviceWalkOffered_;
-    clock_.backend = PhaseClock::now() - tStart;
+    backendThread_ = std::thread([this, &warmup] {
+        try
+        {
+            warmup.join();
+            createBackend();
+            chooseMergeSite();
+            deviceWalkOffered_ = !getenv("POPDEL_HOST_WALK") && !getenv("POPDEL_WALK_CHECK") && !observer_;
+            for (pd_ctx * c : ctxs_)
+                deviceWalkOffered_ = deviceWalkOffered_ && pd_walk_supported(c) == 1;
+            deviceWalk_ = deviceWalkOffered_;
+        }
+        catch (...)
+        {
+            backendError_ = std::current_exception();
+        }
+    });
+    struct BackendJoiner
+    {
+        CallRun & r;
+        ~BackendJoiner() { if (r.backendThread_.joinable()) r.backendThread_.join(); }
+    } joinBackend{*this};
     profile_.reset(new ChromProfile(static_cast<unsigned>(p_.readGroups.size()), p_.maxLoad, p_.windowBuffer));
     if (observer_ && observer_->onActiveOps)
         profile_->enableActiveOpLog();
@@ -1208,6 +1240,7 @@ int CallRun::run()
     if (getenv("POPDEL_WALK_CHECK"))
         walkCheck_.reset(new WalkReference(static_cast<unsigned>(p_.readGroups.size())));
     profile_->externalActive = [this]() -> size_t {
+        ensureBackend();            // (only asked from the main thread: the replay of a batch with a far window runs in order)
         if (!deviceWalk_)
             return 0;
         uint64_t left = 0;
