@@ -75,6 +75,13 @@ def parse_args(argv=None):
     ap.add_argument("--small-cohort", type=int, default=1000,
                     help="samples of the configs[1] leg (1,000 profiles x chr20 windows); 0: skip")
     ap.add_argument("--no-legs", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--resident-segments", type=int, default=1,
+                    help="N = 1: distinct 200-kb segments (own pairs, own planted deletion) kept resident and scanned in turn by the "
+                         "headline's passes (default 1: the workload of rounds 1 and 2)")
+    ap.add_argument("--distinct-segments", type=int, default=5,
+                    help="N = 1: segments of the `distinct_segments` leg -- the headline's step over that many different resident "
+                         "segments in turn, one of them without a deletion (SURVEY 8(d): one deletion per 250 kb): the stage-2 share of "
+                         "a pass depends on the planted deletion, and the headline's one segment is one sample of it; 0: skip")
     ap.add_argument("--configs3-samples", type=int, default=10000,
                     help="N > 1: TOTAL samples of the configs[3]-shaped leg (ONE cohort sharded by samples, pd_shard_samples(total, N) "
                          "per rank, resident segment); 0: skip")
@@ -206,15 +213,24 @@ class Lane:
     segment's ticket is issued before the open one is collected."""
 
     def __init__(self, ctx, handle, serial=False):
-        self.ctx, self.handle, self.serial = ctx, handle, serial
+        """handle: a staged segment, or a list of them (scanned in turn)"""
+        self.ctx, self.serial = ctx, serial
+        self.handles = list(handle) if isinstance(handle, (list, tuple)) else [handle]
+        self.handle = self.handles[0]
+        self.turn = 0
+
+    def next_handle(self):
+        h = self.handles[self.turn % len(self.handles)]
+        self.turn += 1
+        return h
 
     def passes(self, n, acc):
-        c, h = self.ctx, self.handle
-        ticket = c.run(h) if n else None
+        c = self.ctx
+        ticket = c.run(self.next_handle()) if n else None
         for i in range(n):
-            nxt = c.run(h) if (i + 1 < n and not self.serial) else None
+            nxt = c.run(self.next_handle()) if (i + 1 < n and not self.serial) else None
             res = c.collect(ticket, copy=False)
-            ticket = nxt if not self.serial else (c.run(h) if i + 1 < n else None)
+            ticket = nxt if not self.serial else (c.run(self.next_handle()) if i + 1 < n else None)
             t = c.timing()
             acc[0] += t["stage1_ms"]
             acc[1] += t["stage2_ms"]
@@ -318,12 +334,26 @@ def main():
     t_stage = time.perf_counter()
     handle = ctx.stage(seg)                   # host -> HBM, outside the timed region
     stage_seconds = time.perf_counter() - t_stage
-    lanes = [Lane(ctx, handle, args.serial)]
+    # further resident segments of the same cohort (N = 1, one read group per sample): other pairs, another deletion
+    handles, planted_all = [handle], [planted]
+    if not is_dist and R == 1 and args.contexts == 1:
+        for k in range(1, max(1, args.resident_segments)):
+            f_k, W_k, o_k, a_k, p_k = device_tile(S, 20260 + 1000 * k, device, args.coverage)
+            handles.append(ctx.stage(capi.Segment(f_k, W_k, o_k, a_k["dev"], a_k["start"], a_k["on"], a_k["off"])))
+            planted_all.append(p_k)
+            del o_k, a_k
+    lanes = [Lane(ctx, handles, args.serial)]
     for _ in range(max(0, args.contexts - 1)):   # optional: independent segments in flight on the same GPU
         c2 = capi.Context(hip, [rg] * (R * S), sample_offsets, device=local_rank)
         lanes.append(Lane(c2, c2.stage(seg), args.serial))
 
     total_passes = args.passes or -(-CHR20_WINDOWS // W)
+    # what one launch of the scan has to read, averaged over the resident segments (a pass each; also warms them up)
+    seg_sizes = []
+    for h in handles:
+        ctx.collect(ctx.run(h), copy=False)
+        t = ctx.timing()
+        seg_sizes.append((t["n_active_pairs"], t["n_pair_chunks"], t["n_candidate_cells"]))
 
     def timed_steps(step_fn, warmup, steps):
         for _ in range(warmup):
@@ -375,7 +405,10 @@ def main():
 
     def assemble(legs):
         h = headline
-        tinfo = h["tinfo"]
+        tinfo = dict(h["tinfo"])
+        if not is_dist and len(seg_sizes) > 1:      # the passes took the resident segments in turn
+            tinfo["n_active_pairs"] = sum(x[0] for x in seg_sizes) / len(seg_sizes)
+            tinfo["n_pair_chunks"] = sum(x[1] for x in seg_sizes) / len(seg_sizes)
         s1_mean_s = h["s1_ms"] / h["launches"] / 1e3
         cells = tinfo["n_cells"]
         # gather of the [samples x windows x pairs] SoA + cell index + Q3 out
@@ -418,8 +451,11 @@ def main():
                                     else "%d synthetic profiles x %d windows" % (h["cohort"], total_passes * W)),
                        "samples": h["cohort"], "samples_per_gpu": h["cohort_local"], "windows_per_step": h["windows_per_step"],
                        "segment_windows": W, "segment_passes_per_step": total_passes,
-                       "resident_segment": "one 200-kb segment of all samples, re-scanned",
-                       "planted_deletion": planted, "parallelism": h["parallelism"],
+                       "resident_segment": ("%d distinct 200-kb segments of all samples, resident and scanned in turn" % len(handles))
+                                           if (not is_dist and len(handles) > 1) else "one 200-kb segment of all samples, re-scanned",
+                       "planted_deletion": planted_all if (not is_dist and len(handles) > 1) else planted,
+                       "candidate_cells_per_segment": [x[2] for x in seg_sizes] if not is_dist else None,
+                       "parallelism": h["parallelism"],
                        "layout": "pair chunks [slot][chunk] of {dev16|dev16, off16|off16} + per-window slot index; "
                                  "Q3/flags [sample][window]; stage 2 dense image [cell][64-sample wave tile][row][lane]"},
             "exchange": h["exchange"],
@@ -673,6 +709,36 @@ def main():
         return dict(value=total_passes * W * S / dt, unit="window*sample/s", contexts_per_gpu=len(all_lanes),
                     ms_per_pass=dt / my_passes * 1e3, steps=1)
 
+    def distinct_segments_leg():
+        # the headline's step, but the passes take several DIFFERENT resident segments in turn (other pairs, other deletions
+        # -- length log-uniform 300..5,000 decides how many windows and candidate cells a deletion yields --, one segment
+        # without any): what a chromosome's worth of segments costs, where the headline re-scans one of them
+        c2 = capi.Context(hip, [rg] * S, list(range(S + 1)), device=local_rank)
+        hs, info = [], []
+        for k in range(args.distinct_segments):
+            n_del = 0 if k == args.distinct_segments - 1 and args.distinct_segments > 1 else 1
+            f_k, W_k, o_k, a_k, p_k = device_tile(S, 20260 + 1000 * (k + 1), device, args.coverage, n_deletions=n_del)
+            hs.append(c2.stage(capi.Segment(f_k, W_k, o_k, a_k["dev"], a_k["start"], a_k["on"], a_k["off"])))
+            c2.collect(c2.run(hs[-1]), copy=False)
+            t = c2.timing()
+            info.append(dict(del_len=(p_k["del_len"] if n_del else None), af=(round(p_k["af"], 4) if n_del else None),
+                             candidate_cells=t["n_candidate_cells"]))
+            del o_k, a_k
+        l2 = Lane(c2, hs, args.serial)
+        run_lanes([l2], max(len(hs), total_passes // 8))
+        torch.cuda.synchronize()
+        q0 = time.perf_counter()
+        acc = run_lanes([l2], total_passes)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - q0
+        for hh in hs:
+            c2.unstage(hh)
+        c2.close()
+        return dict(workload="%d samples x chr20 windows as %d passes over %d distinct resident segments in turn" % (S, total_passes, len(hs)),
+                    value=total_passes * W * S / dt, unit="window*sample/s", ms_per_pass=dt / total_passes * 1e3,
+                    stage1_ms_per_pass=acc[0] / total_passes, stage2_ms_per_pass=acc[1] / total_passes,
+                    candidate_cells_per_pass=acc[3] / total_passes, calls_per_pass=acc[2] / total_passes, segments=info)
+
     def small_cohort_leg():
         # BASELINE configs[1]: 1,000 synthetic profiles x chr20 windows on one GPU
         n = min(args.small_cohort, S)
@@ -898,6 +964,8 @@ def main():
             leg("concurrent_segments", concurrent_leg)
         if args.small_cohort > 0:
             leg("small_cohort", small_cohort_leg)
+        if args.distinct_segments > 0 and R == 1:
+            leg("distinct_segments", distinct_segments_leg)
         if args.dense_deletions > 0 and R == 1:
             leg("candidate_dense", dense_leg)
         # (last of the GPU legs: its writer processes and host threads eat into the job's CPU quota, which the streaming
@@ -909,7 +977,8 @@ def main():
         if not args.no_cpu and not is_dist:                 # timed on rank 0 at N = 1 only
             leg("cpu_baseline", cpu_leg)
     for l in lanes:
-        l.ctx.unstage(l.handle)
+        for hh in l.handles:
+            l.ctx.unstage(hh)
         l.ctx.close()
     emit(assemble(legs))
     if is_dist:

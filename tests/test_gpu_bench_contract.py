@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def test_bench_line_has_the_contract_fields(built):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--samples", "512", "--passes", "3", "--steps", "2",
                           "--warmup", "1", "--cpu-samples", "40", "--cpu-threads", "2", "--stream-segments", "2", "--small-cohort", "128",
-                          "--dense-deletions", "3", "--e2e-samples", "24", "--sharded-world1", "256,0"],
+                          "--dense-deletions", "3", "--e2e-samples", "24", "--sharded-world1", "256,0", "--distinct-segments", "3"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -52,6 +52,9 @@ def test_bench_line_has_the_contract_fields(built):
     assert [x["samples"] for x in rows] == [256, 512]
     for x in rows:
         assert x["all_gathers_per_pass"] >= 9 and x["exchange_ms_per_pass"] > 0 and x["sharded_ms_per_pass"] > 0 and x["unsharded_ms_per_pass"] > 0
+    # the headline's step over several different resident segments (one of them without a deletion)
+    ds = d["distinct_segments"]
+    assert ds["value"] > 0 and len(ds["segments"]) == 3 and ds["segments"][-1]["del_len"] is None
     # end to end: the product binary on profile files, the oracle-backed driver beside it, same VCF
     e = d["e2e"]
     assert e["value"] > 0 and e["wall_seconds"] > 0 and "decode" in e["phases_seconds"]
