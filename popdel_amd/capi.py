@@ -78,6 +78,17 @@ RESERVE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p)
 
 
+class PdWalkEntry(C.Structure):
+    _fields_ = [("start", C.c_uint32), ("dev", C.c_int32)]
+
+
+class PdWalk(C.Structure):
+    _fields_ = [("first_window_pos", C.c_uint32), ("step_pos", C.c_uint32), ("has_step", C.c_uint32), ("n_windows", C.c_uint32),
+                ("window_shift", C.c_uint32), ("n_readgroups", C.c_uint32), ("rg_counts", C.POINTER(C.c_uint32)),
+                ("rg_entries", C.POINTER(C.POINTER(PdWalkEntry))), ("end_border", C.POINTER(C.c_uint32)),
+                ("id_offset", C.POINTER(C.c_uint32)), ("switches", C.POINTER(C.c_uint8)), ("equal_run", C.POINTER(C.c_uint8))]
+
+
 class PdShard(C.Structure):
     _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("first_sample", C.c_uint32),
                 ("n_samples_global", C.c_uint32), ("n_readgroups_global", C.c_uint32),
@@ -133,6 +144,15 @@ def load_library(path):
     lib.pd_merged_free.restype = None
     lib.pd_rccl_unique_id.argtypes = [C.c_char_p]
     lib.pd_rccl_unique_id.restype = C.c_int
+    lib.pd_walk_submit.argtypes = [C.c_void_p, C.POINTER(PdWalk), C.POINTER(C.c_uint64)]
+    lib.pd_walk_submit.restype = C.c_int
+    lib.pd_walk_supported.argtypes = [C.c_void_p]
+    lib.pd_walk_supported.restype = C.c_int
+    lib.pd_walk_active.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_uint32), C.c_uint64]
+    lib.pd_walk_active.restype = C.c_int
+    lib.pd_device_warmup.argtypes = [C.c_int]
+    lib.pd_device_warmup.restype = C.c_int
     return lib
 
 
@@ -301,6 +321,39 @@ class Context:
         st = seg.as_struct()
         self._check(self.lib.pd_segment_submit(self.handle, C.byref(st), C.byref(t)))
         return t.value
+
+    def submit_walk(self, first_window_pos, n_windows, rg_starts, rg_devs, end_border, switches, equal_run, step_pos=None,
+                    id_offset=None, window_shift=30):
+        """pd_walk_submit: the segment as the loader's tables hold it. rg_starts / rg_devs: per read group the start
+        positions and deviations of its new start-slot entries (arrays; ignored where switches[rg] == 0)."""
+        n_rg = len(rg_starts)
+        tables = [np.ascontiguousarray(np.stack([np.asarray(s, np.uint32), np.asarray(d, np.int32).view(np.uint32)], axis=1))
+                  if len(s) else np.zeros((0, 2), np.uint32) for s, d in zip(rg_starts, rg_devs)]
+        counts = np.array([len(t) for t in tables], np.uint32)
+        ptrs = (C.POINTER(PdWalkEntry) * n_rg)(*[t.ctypes.data_as(C.POINTER(PdWalkEntry)) for t in tables])
+        border = np.ascontiguousarray(end_border, np.uint32)
+        ids = np.ascontiguousarray(id_offset if id_offset is not None else np.zeros(n_rg), np.uint32)
+        sw = np.ascontiguousarray(switches, np.uint8)
+        run = np.ascontiguousarray(equal_run, np.uint8)
+        wk = PdWalk(first_window_pos, step_pos or 0, 0 if step_pos is None else 1, n_windows, window_shift, n_rg,
+                    counts.ctypes.data_as(C.POINTER(C.c_uint32)), ptrs, border.ctypes.data_as(C.POINTER(C.c_uint32)),
+                    ids.ctypes.data_as(C.POINTER(C.c_uint32)), sw.ctypes.data_as(C.POINTER(C.c_uint8)),
+                    run.ctypes.data_as(C.POINTER(C.c_uint8)))
+        t = C.c_uint64()
+        self._check(self.lib.pd_walk_submit(self.handle, C.byref(wk), C.byref(t)))
+        return t.value
+
+    def walk_active(self):
+        """(read group, start, deviation, id) arrays of the pairs still active after the last submitted walk"""
+        n = C.c_uint64()
+        self._check(self.lib.pd_walk_active(self.handle, C.byref(n), None, None, None, None, 0))
+        k = n.value
+        rg, st, dv, ids = np.zeros(k, np.uint32), np.zeros(k, np.uint32), np.zeros(k, np.int32), np.zeros(k, np.uint32)
+        if k:
+            self._check(self.lib.pd_walk_active(self.handle, C.byref(n), rg.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                st.ctypes.data_as(C.POINTER(C.c_uint32)), dv.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                ids.ctypes.data_as(C.POINTER(C.c_uint32)), k))
+        return rg, st, dv, ids
 
     def stage(self, seg: Segment):
         h = C.c_uint64()

@@ -1982,7 +1982,6 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
         pd::launchWalkEmit(in, cur, wp, c->dRg.p, nRg, c->dRgOffsets.p, reinterpret_cast<int32_t *>(c->dIn32[0].p), c->dIn32[1].p, c->dIn32[2].p,
                            c->dIn32[3].p, nxt, reinterpret_cast<unsigned *>(c->dWalkTotals.p + 2), c->dWalkTotals.p + 1, cs);
         PD_HIP(hipGetLastError());
-        c->walkCur ^= 1;
         PD_HIP(hipMemcpyAsync(c->hWalkTotals.data() + 1, c->dWalkTotals.p + 1, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
         bool built = false;
         const bool deviceBuild = pd::buildLdsBytes(W, 48) <= 160u * 1024u;     // (else: more windows than the build kernels keep in LDS)
@@ -2002,9 +2001,11 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
         else
             PD_HIP(hipStreamSynchronize(cs));
         // (the build's first synchronisation point lies behind the copy above)
-        c->walkActive = c->hWalkTotals[1];
         if (c->hWalkTotals[2] != 0)
             throw HipError{"a read group has more active or pending pairs than the device-side window loop keeps (run with POPDEL_HOST_WALK=1)"};
+        // the segment is taken: from here on the state after it is the current one (a failure above leaves the old state)
+        c->walkCur ^= 1;
+        c->walkActive = c->hWalkTotals[1];
         if (nInst == 0)
         {
             // no pair is active in any window: the (host-side) path for empty segments
@@ -2191,7 +2192,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             {
                 const size_t listRoom = static_cast<size_t>(capF) * pd::kMaxCandidatesPerWindow;
                 c->dFlagged.ensure(capF);
-                c->dCandHdr.ensure(4 + 2 * listRoom);
+                c->dCandHdr.ensure(4 + 2 * std::max<size_t>(listRoom, kListCap));      // (the first copy always brings kListCap cells' room along)
                 c->dClusterScratch.ensure(static_cast<size_t>(capF) * rowLen);
                 c->dCandLen.ensure(listRoom);
                 c->dCandCount.ensure(capF);

@@ -1,0 +1,88 @@
+"""GPU: pd_walk_submit through the C ABI -- the window loop in closed form on the device -- against pd_segment_submit with
+the instances the same pairs have under the interval rule (popdel_amd.synth.instances_by_interval_rule), and the state it
+carries from one segment to the next."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def cohort(n, region, seed0=300):
+    from popdel_amd import synth
+    lib = synth.Library()
+    rg = synth.conditioned_readgroup(lib)
+    pairs = [synth.sample_pairs(seed0 + k, region, lib, [synth.Deletion(region[0] + 20000, 900, [1, 2, 0][k % 3])]) for k in range(n)]
+    return lib, rg, pairs
+
+
+def test_first_segment_equals_the_interval_rule(built):
+    """A first segment (no step ahead of window 0, nothing carried, every end record in the read slot): the instances the
+    device derives from the start entries are those of the interval rule, so both ways of handing the segment over must
+    give the same calls, bit for bit."""
+    from popdel_amd import capi, synth
+    n, region, first, W = 40, (1000000, 1090000), 1000020, 2900
+    lib, rg, pairs = cohort(n, region)
+    parts, offsets = [], [0]
+    starts, devs = [], []
+    for pos, dev in pairs:
+        # (the loader files the records of the windows from the first window position on, in start order)
+        keep = pos >= first
+        pos, dev = pos[keep], dev[keep]
+        d, s, a, b = synth.instances_by_interval_rule(pos, dev, lib, first, W)
+        parts.append((d, s, a, b))
+        offsets.append(offsets[-1] + len(d))
+        starts.append(pos)
+        devs.append(dev)
+    seg = capi.Segment(first, W, np.array(offsets, np.uint64), np.concatenate([p[0] for p in parts]).astype(np.int32),
+                       np.concatenate([p[1] for p in parts]).astype(np.uint32), np.concatenate([p[2] for p in parts]).astype(np.uint32),
+                       np.concatenate([p[3] for p in parts]).astype(np.uint32))
+    hip = capi.load_hip()
+    ctx = capi.Context(hip, [rg] * n, list(range(n + 1)))
+    a = ctx.collect(ctx.submit(seg))
+    ctx.close()
+    ctx = capi.Context(hip, [rg] * n, list(range(n + 1)))
+    assert hip.pd_walk_supported(ctx.handle) == 1
+    equal_run = [1 if len(s) and s[0] == first else 0 for s in starts]
+    t = ctx.submit_walk(first, W, starts, devs, end_border=[0xffffffff] * n, switches=[2] * n, equal_run=equal_run)
+    b = ctx.collect(t)
+    ctx.close()
+    assert a["n_calls"] > 10 and a["n_calls"] == b["n_calls"]
+    for k, v in a.items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(v, b[k]), k
+
+
+def test_state_from_segment_to_segment(built):
+    """Two segments of one read group, handed over by hand: pairs filed one end slot ahead stay active into the second
+    segment and leave at their time there; pairs whose end record sat in the first read slot are gone after the switch
+    (quirk B1); start entries no window reached are dropped by the switch (B2) but kept without one."""
+    from popdel_amd import capi, synth
+    lib = synth.Library()
+    rg = synth.conditioned_readgroup(lib)
+    hip = capi.load_hip()
+    ctx = capi.Context(hip, [rg], [0, 1])
+    inner = rg.median - 2 * rg.read_length                      # end = start + max(0, dev + inner)
+    F, n1 = 3000, 7                                             # windows at 3000, 3030, ..., 3180
+    border = 3300
+    #          start  dev            what
+    entries = [(3000, 0),          # ends at 3000 + inner (3200 for 500/150): last window 3180 < border: read slot; active in all 7 windows
+               (3010, 200),        # ends 3410: last window 3390 >= border: filed ahead, carried
+               (3100, -inner),     # ends at its start: leaves at the first window beyond 3090 + 30
+               (3290, 0)]          # no window reaches it: pending
+    st = [np.array([e[0] for e in entries], np.uint32)]
+    dv = [np.array([e[1] for e in entries], np.int32)]
+    ctx.collect(ctx.submit_walk(F, n1, st, dv, end_border=[border], switches=[2], equal_run=[1]))
+    _, a_start, _, a_id = ctx.walk_active()
+    assert sorted(a_start.tolist()) == [3000, 3010] and sorted(a_id.tolist()) == [0, 1]
+    # without a switch the pending entry is still a candidate and the read slot's pairs leave at their time
+    F2 = 3210
+    ctx.collect(ctx.submit_walk(F2, 8, [np.zeros(0, np.uint32)], [np.zeros(0, np.int32)], end_border=[border + 300], switches=[0],
+                                equal_run=[0], step_pos=3210))
+    _, a_start, _, _ = ctx.walk_active()
+    assert sorted(a_start.tolist()) == [3010, 3290]             # 3000 left at window 1 (last window 3180), 3010 is filed ahead: stays; 3290 came in
+    # a switch: the pair filed ahead moves into the read slot and leaves at its time; the other one's end record sat in the
+    # drained slot -> gone
+    ctx.collect(ctx.submit_walk(3540, 6, [np.zeros(0, np.uint32)], [np.zeros(0, np.int32)], end_border=[border + 600], switches=[1],
+                                equal_run=[0], step_pos=3540))
+    assert ctx.walk_active()[1].tolist() == []                  # last windows 3390 and 3480, both over before 3540: left at the step
+    ctx.close()
