@@ -2,6 +2,7 @@
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -20,11 +21,15 @@ private:
     FILE * fp_;
 };
 
-// Inflates a run of concatenated gzip members starting at the current file offset.
+// Inflates a run of concatenated gzip members starting at the current file offset. The reader asks for a few bytes at a
+// time (window header, record count, ~25 records of 5 bytes); handing those requests to inflate() one by one keeps zlib on
+// its byte-wise path (its fast loop wants 258 bytes of room), so the stream is inflated in blocks of 16 KB into a buffer
+// of its own and the requests are served from there (a bigger block would inflate too far beyond the window at which the
+// loader stops reading a round: a 200-kb slot is ~100 KB of records).
 class GzSource : public ByteSource
 {
 public:
-    explicit GzSource(FILE * fp) : fp_(fp), in_(1 << 16)
+    explicit GzSource(FILE * fp) : fp_(fp), in_(1 << 16), out_(1 << 14)
     {
         std::memset(&zs_, 0, sizeof(zs_));
         if (inflateInit2(&zs_, 15 + 32) != Z_OK)
@@ -34,8 +39,29 @@ public:
 
     size_t read(void * dst, size_t n) override
     {
-        zs_.next_out = static_cast<Bytef *>(dst);
-        zs_.avail_out = static_cast<uInt>(n);
+        unsigned char * to = static_cast<unsigned char *>(dst);
+        size_t done = 0;
+        while (done < n)
+        {
+            if (outPos_ == outEnd_ && !refill())
+                break;
+            const size_t take = std::min(n - done, outEnd_ - outPos_);
+            std::memcpy(to + done, out_.data() + outPos_, take);
+            outPos_ += take;
+            done += take;
+        }
+        return done;
+    }
+
+private:
+    // the next block of inflated bytes; false at the end of the data
+    bool refill()
+    {
+        outPos_ = outEnd_ = 0;
+        if (finished_)
+            return false;
+        zs_.next_out = out_.data();
+        zs_.avail_out = static_cast<uInt>(out_.size());
         while (zs_.avail_out != 0 && !finished_)
         {
             if (zs_.avail_in == 0)
@@ -66,12 +92,13 @@ public:
                 break;
             }
         }
-        return n - zs_.avail_out;
+        outEnd_ = out_.size() - zs_.avail_out;
+        return outEnd_ != 0;
     }
 
-private:
     FILE * fp_;
-    std::vector<unsigned char> in_;
+    std::vector<unsigned char> in_, out_;
+    size_t outPos_ = 0, outEnd_ = 0;
     z_stream zs_;
     bool finished_ = false;
 };
