@@ -1190,27 +1190,46 @@ __global__ __launch_bounds__(kSampleTile) void dataLikDenseKernel(CohortView co,
     double g0 = 0, g2 = 0, prod = 1.0;
     int esum = 0;
     bool eq = true;
-#pragma unroll 8
-    for (unsigned j = 0; j < rows; ++j)
+    // The rows are taken kRowBatch at a time in three steps -- their deviations are loaded, then all their table lookups are
+    // issued, then the arithmetic runs -- so that a wave has 2 x kRowBatch gathers in flight. Written row by row (round 2)
+    // the compiler has to wait for a row's deviation before it can issue that row's lookups and, with one counter for all
+    // outstanding loads, for the PREVIOUS row's lookups with it: a chain of two memory latencies per row, which is what
+    // bounded these kernels (0.17 VALU issue, 72 % of the wave cycles parked).
+    constexpr unsigned kRowBatch = 8;
+    for (unsigned j0 = 0; j0 < rows; j0 += kRowBatch)
     {
-        const bool use = j < nn;
-        const int dv = col[j * 64];
-        bool inR, inD;
-        const uint64_t pr = lanePosClamped(l, dv - refShift, inR), pdl = lanePosClamped(l, dv - len, inD);
-        // only in-range lookups touch memory: every lane reads its own sample's table, so each one costs a cache line
-        double2 tr = make_double2(l.minProb, l.logMinProb), td = tr;
-        if (use && inR)
-            tr = co.tab2[pr];
-        if (use && inD)
-            td = co.tab2[pdl];
-        const double ref = tr.x, lref = tr.y, del = td.x, ldel = td.y;
-        int e;
-        const double m = frexp(ref + del, &e);
-        g0 += use ? lref : 0.0;
-        g2 += use ? ldel : 0.0;
-        prod *= use ? m : 1.0;
-        esum += use ? e : 0;
-        eq = eq && (!use || ref == del);
+        int dvs[kRowBatch];
+#pragma unroll
+        for (unsigned q = 0; q < kRowBatch; ++q)
+            dvs[q] = col[min(j0 + q, (unsigned)kDenseCap - 1u) * 64];
+        double2 trs[kRowBatch], tds[kRowBatch];
+#pragma unroll
+        for (unsigned q = 0; q < kRowBatch; ++q)
+        {
+            const bool use = j0 + q < nn;
+            bool inR, inD;
+            const uint64_t pr = lanePosClamped(l, dvs[q] - refShift, inR), pdl = lanePosClamped(l, dvs[q] - len, inD);
+            // only in-range lookups touch memory: every lane reads its own sample's table, so each one costs a cache line
+            trs[q] = make_double2(l.minProb, l.logMinProb);
+            tds[q] = trs[q];
+            if (use && inR)
+                trs[q] = co.tab2[pr];
+            if (use && inD)
+                tds[q] = co.tab2[pdl];
+        }
+#pragma unroll
+        for (unsigned q = 0; q < kRowBatch; ++q)
+        {
+            const bool use = j0 + q < nn;
+            const double ref = trs[q].x, lref = trs[q].y, del = tds[q].x, ldel = tds[q].y;
+            int e;
+            const double m = frexp(ref + del, &e);
+            g0 += use ? lref : 0.0;
+            g2 += use ? ldel : 0.0;
+            prod *= use ? m : 1.0;
+            esum += use ? e : 0;
+            eq = eq && (!use || ref == del);
+        }
     }
     if (valid)
     {
@@ -1471,24 +1490,41 @@ __global__ __launch_bounds__(kSampleTile) void updateLenDenseKernel(CohortView c
     const bool highCov = n == kDenseHighCov;
     const unsigned nn = highCov ? 0u : n;
     double sumDel = 0, wSumDel = 0, sumRef = 0, wSumRef = 0;
-#pragma unroll 8
-    for (unsigned j = 0; j < rows; ++j)
+    // (rows in batches: deviations, then all lookups, then the arithmetic -- see dataLikDenseKernel)
+    constexpr unsigned kRowBatch = 8;
+    for (unsigned j0 = 0; j0 < rows; j0 += kRowBatch)
     {
-        const bool use = j < nn;
-        const int dv = col[j * 64];
-        bool inD, inN;
-        const uint64_t pd_ = lanePosClamped(l, dv - len, inD), pn = lanePosClamped(l, dv - refShift, inN);
-        double del = l.minProb, noDel = l.minProb;
-        if (use && inD)
-            del = co.hist[pd_];
-        if (use && inN)
-            noDel = co.hist[pn];
-        const double probDel = ea1 * del / (del + noDel) + ea2;
-        const double probRef = ea1Rg * noDel / (del + noDel) + ea0Rg;
-        sumDel += use ? probDel : 0.0;
-        sumRef += use ? probRef : 0.0;
-        wSumDel += use ? probDel * dv : 0.0;
-        wSumRef += use ? probRef * dv : 0.0;
+        int dvs[kRowBatch];
+#pragma unroll
+        for (unsigned q = 0; q < kRowBatch; ++q)
+            dvs[q] = col[min(j0 + q, (unsigned)kDenseCap - 1u) * 64];
+        double dels[kRowBatch], noDels[kRowBatch];
+#pragma unroll
+        for (unsigned q = 0; q < kRowBatch; ++q)
+        {
+            const bool use = j0 + q < nn;
+            bool inD, inN;
+            const uint64_t pd_ = lanePosClamped(l, dvs[q] - len, inD), pn = lanePosClamped(l, dvs[q] - refShift, inN);
+            dels[q] = l.minProb;
+            noDels[q] = l.minProb;
+            if (use && inD)
+                dels[q] = co.hist[pd_];
+            if (use && inN)
+                noDels[q] = co.hist[pn];
+        }
+#pragma unroll
+        for (unsigned q = 0; q < kRowBatch; ++q)
+        {
+            const bool use = j0 + q < nn;
+            const int dv = dvs[q];
+            const double del = dels[q], noDel = noDels[q];
+            const double probDel = ea1 * del / (del + noDel) + ea2;
+            const double probRef = ea1Rg * noDel / (del + noDel) + ea0Rg;
+            sumDel += use ? probDel : 0.0;
+            sumRef += use ? probRef : 0.0;
+            wSumDel += use ? probDel * dv : 0.0;
+            wSumRef += use ? probRef * dv : 0.0;
+        }
     }
     if (valid && !highCov)
     {
@@ -1916,23 +1952,43 @@ __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, S
     bool eq = true;
     unsigned mn = 0xffffffffu, mx = 0, nSupp = 0;
     unsigned lad[3] = {0, 0, 0}, dad[5] = {0, 0, 0, 0, 0};
-#pragma unroll 2
-    for (unsigned j = 0; j < rows; ++j)
+    // (rows in batches: deviations and starts, then all lookups, then the arithmetic -- see dataLikDenseKernel)
+    constexpr unsigned kRowBatch = 4;
+    for (unsigned j0 = 0; j0 < rows; j0 += kRowBatch)
     {
-        const bool use = j < nn;
-        const int dv = col[j * 64];
-        const unsigned st = stBase + (unsigned)(int)colSt[j * 64];
+    int dvs[kRowBatch], sts[kRowBatch];
+#pragma unroll
+    for (unsigned q = 0; q < kRowBatch; ++q)
+    {
+        const unsigned jj = min(j0 + q, (unsigned)kDenseCap - 1u);
+        dvs[q] = col[jj * 64];
+        sts[q] = colSt[jj * 64];
+    }
+    double4 trs[kRowBatch], tds[kRowBatch];
+#pragma unroll
+    for (unsigned q = 0; q < kRowBatch; ++q)
+    {
+        const bool use = j0 + q < nn;
+        const long long pr = lookupPos(rc, dvs[q] - refShift), pdl = lookupPos(rc, dvs[q] - len);
+        trs[q] = make_double4(rc.minProb, rc.logMinProb, rc.log10MinProb, 0.0);
+        tds[q] = trs[q];
+        if (use && pr >= 0)
+            trs[q] = co.tab[pr];
+        if (use && pdl >= 0)
+            tds[q] = co.tab[pdl];
+    }
+#pragma unroll
+    for (unsigned q = 0; q < kRowBatch; ++q)
+    {
+        const bool use = j0 + q < nn;       // (rows past the image's are padding like rows past the lane's own count)
+        const int dv = dvs[q];
+        const unsigned st = stBase + (unsigned)sts[q];
         int cls;
         if (dv > rc.upperQ)
             cls = (dv < rgLower) ? 2 : ((dv <= rgUpper) ? 3 : 4);
         else
             cls = (dv < rgUpper) ? 0 : 1;
-        const long long pr = lookupPos(rc, dv - refShift), pdl = lookupPos(rc, dv - len);
-        double4 tr = make_double4(rc.minProb, rc.logMinProb, rc.log10MinProb, 0.0), td = tr;
-        if (use && pr >= 0)
-            tr = co.tab[pr];
-        if (use && pdl >= 0)
-            td = co.tab[pdl];
+        const double4 tr = trs[q], td = tds[q];
         const double ref = tr.x, del = td.x;
         const int lcls = (ref >= 2 * del) ? 0 : ((del >= 2 * ref) ? 2 : 1);
         int e;
@@ -1954,6 +2010,7 @@ __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, S
         for (int c = 0; c < 3; ++c)
             lad[c] += (use && lcls == c) ? 1u : 0u;
         nSupp += (use && dv >= rgLower && dv <= rgUpper) ? 1u : 0u;
+    }
     }
     // supporting pairs: one pool allocation per wave, lanes fill their own stretch
     {
