@@ -39,6 +39,18 @@ namespace pd {
 // per-tile sums of this context's own tile PD_TILE_IDX
 #define PD_OWN_TILE_SLOT(b, c) tileSlot(b, c, (b).rank * (b).tilesPerRank + PD_TILE_IDX)
 
+// The deviations of a batch of rows have all been loaded before the first lookup is issued: an explicit wait, with the
+// values tied to it. Left to itself the compiler waits for deviation q just before row q's lookups, and since it cannot
+// know whether the (conditional) lookups of the rows before were issued, it words that wait so that it also covers
+// them -- the lookups of a batch would again queue behind each other.
+#define PD_ALL_LOADS_DONE(arr)                                              \
+    do                                                                      \
+    {                                                                       \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    \
+        _Pragma("unroll") for (unsigned q_ = 0; q_ < kRowBatch; ++q_)       \
+            asm volatile("" : "+v"((arr)[q_]));                            \
+    } while (0)
+
 #define PD_LN2 0.69314718055994530942
 #define PD_LOG10_2 0.30102999566398119521
 
@@ -1202,6 +1214,7 @@ __global__ __launch_bounds__(kSampleTile) void dataLikDenseKernel(CohortView co,
 #pragma unroll
         for (unsigned q = 0; q < kRowBatch; ++q)
             dvs[q] = col[min(j0 + q, (unsigned)kDenseCap - 1u) * 64];
+        PD_ALL_LOADS_DONE(dvs);
         double2 trs[kRowBatch], tds[kRowBatch];
 #pragma unroll
         for (unsigned q = 0; q < kRowBatch; ++q)
@@ -1498,6 +1511,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenDenseKernel(CohortView c
 #pragma unroll
         for (unsigned q = 0; q < kRowBatch; ++q)
             dvs[q] = col[min(j0 + q, (unsigned)kDenseCap - 1u) * 64];
+        PD_ALL_LOADS_DONE(dvs);
         double dels[kRowBatch], noDels[kRowBatch];
 #pragma unroll
         for (unsigned q = 0; q < kRowBatch; ++q)
@@ -1959,11 +1973,8 @@ __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, S
     int dvs[kRowBatch], sts[kRowBatch];
 #pragma unroll
     for (unsigned q = 0; q < kRowBatch; ++q)
-    {
-        const unsigned jj = min(j0 + q, (unsigned)kDenseCap - 1u);
-        dvs[q] = col[jj * 64];
-        sts[q] = colSt[jj * 64];
-    }
+        dvs[q] = col[min(j0 + q, (unsigned)kDenseCap - 1u) * 64];
+    PD_ALL_LOADS_DONE(dvs);
     double4 trs[kRowBatch], tds[kRowBatch];
 #pragma unroll
     for (unsigned q = 0; q < kRowBatch; ++q)
@@ -1977,6 +1988,10 @@ __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, S
         if (use && pdl >= 0)
             tds[q] = co.tab[pdl];
     }
+    // (the starts are wanted by the arithmetic only: loaded behind the lookups, so that no lookup is issued behind a wait for them)
+#pragma unroll
+    for (unsigned q = 0; q < kRowBatch; ++q)
+        sts[q] = colSt[min(j0 + q, (unsigned)kDenseCap - 1u) * 64];
 #pragma unroll
     for (unsigned q = 0; q < kRowBatch; ++q)
     {
