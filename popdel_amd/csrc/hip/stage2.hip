@@ -2267,25 +2267,42 @@ __global__ __launch_bounds__(kSampleTile) void dataLikMultiKernel(CohortView co,
         double g0 = 0, g2 = 0, prod = 1.0;
         int esum = 0;
         bool eq = true;
-#pragma unroll 8
-        for (unsigned j = 0; j < rows; ++j)
+        // (rows in batches: deviations, then all lookups, then the arithmetic -- see dataLikDenseKernel)
+        constexpr unsigned kRowBatch = 8;
+        for (unsigned j0 = 0; j0 < rows; j0 += kRowBatch)
         {
-            const bool use = j < nn;
-            const int dv = col[j * 64];
-            bool inR, inD;
-            const uint64_t pr = lanePosClamped(l, dv - refShift, inR), pdl = lanePosClamped(l, dv - len, inD);
-            double2 tr = make_double2(l.minProb, l.logMinProb), td = tr;
-            if (use && inR)
-                tr = co.tab2[pr];
-            if (use && inD)
-                td = co.tab2[pdl];
-            int e;
-            const double m = frexp(tr.x + td.x, &e);
-            g0 += use ? tr.y : 0.0;
-            g2 += use ? td.y : 0.0;
-            prod *= use ? m : 1.0;
-            esum += use ? e : 0;
-            eq = eq && (!use || tr.x == td.x);
+            int dvs[kRowBatch];
+#pragma unroll
+            for (unsigned q = 0; q < kRowBatch; ++q)
+                dvs[q] = col[min(j0 + q, (unsigned)kDenseCap - 1u) * 64];
+            PD_ALL_LOADS_DONE(dvs);
+            double2 trs[kRowBatch], tds[kRowBatch];
+#pragma unroll
+            for (unsigned q = 0; q < kRowBatch; ++q)
+            {
+                const bool use = j0 + q < nn;
+                bool inR, inD;
+                const uint64_t pr = lanePosClamped(l, dvs[q] - refShift, inR), pdl = lanePosClamped(l, dvs[q] - len, inD);
+                trs[q] = make_double2(l.minProb, l.logMinProb);
+                tds[q] = trs[q];
+                if (use && inR)
+                    trs[q] = co.tab2[pr];
+                if (use && inD)
+                    tds[q] = co.tab2[pdl];
+            }
+#pragma unroll
+            for (unsigned q = 0; q < kRowBatch; ++q)
+            {
+                const bool use = j0 + q < nn;
+                const double2 tr = trs[q], td = tds[q];
+                int e;
+                const double m = frexp(tr.x + td.x, &e);
+                g0 += use ? tr.y : 0.0;
+                g2 += use ? td.y : 0.0;
+                prod *= use ? m : 1.0;
+                esum += use ? e : 0;
+                eq = eq && (!use || tr.x == td.x);
+            }
         }
         if (valid)
         {
@@ -2423,24 +2440,41 @@ __global__ __launch_bounds__(kSampleTile) void updateLenMultiKernel(CohortView c
         const bool highCov = n == kDenseHighCov;
         const unsigned nn = highCov ? 0u : n;
         double sumDel = 0, wSumDel = 0, sumRef = 0, wSumRef = 0;
-#pragma unroll 8
-        for (unsigned j = 0; j < rows; ++j)
+        constexpr unsigned kRowBatch = 8;
+        for (unsigned j0 = 0; j0 < rows; j0 += kRowBatch)
         {
-            const bool use = j < nn;
-            const int dv = col[j * 64];
-            bool inD, inN;
-            const uint64_t pd_ = lanePosClamped(l, dv - len, inD), pn = lanePosClamped(l, dv - refShift, inN);
-            double del = l.minProb, noDel = l.minProb;
-            if (use && inD)
-                del = co.hist[pd_];
-            if (use && inN)
-                noDel = co.hist[pn];
-            const double probDel = ea1 * del / (del + noDel) + ea2;
-            const double probRef = ea1Rg * noDel / (del + noDel) + ea0Rg;
-            sumDel += use ? probDel : 0.0;
-            sumRef += use ? probRef : 0.0;
-            wSumDel += use ? probDel * dv : 0.0;
-            wSumRef += use ? probRef * dv : 0.0;
+            int dvs[kRowBatch];
+#pragma unroll
+            for (unsigned q = 0; q < kRowBatch; ++q)
+                dvs[q] = col[min(j0 + q, (unsigned)kDenseCap - 1u) * 64];
+            PD_ALL_LOADS_DONE(dvs);
+            double dels[kRowBatch], noDels[kRowBatch];
+#pragma unroll
+            for (unsigned q = 0; q < kRowBatch; ++q)
+            {
+                const bool use = j0 + q < nn;
+                bool inD, inN;
+                const uint64_t pd_ = lanePosClamped(l, dvs[q] - len, inD), pn = lanePosClamped(l, dvs[q] - refShift, inN);
+                dels[q] = l.minProb;
+                noDels[q] = l.minProb;
+                if (use && inD)
+                    dels[q] = co.hist[pd_];
+                if (use && inN)
+                    noDels[q] = co.hist[pn];
+            }
+#pragma unroll
+            for (unsigned q = 0; q < kRowBatch; ++q)
+            {
+                const bool use = j0 + q < nn;
+                const int dv = dvs[q];
+                const double del = dels[q], noDel = noDels[q];
+                const double probDel = ea1 * del / (del + noDel) + ea2;
+                const double probRef = ea1Rg * noDel / (del + noDel) + ea0Rg;
+                sumDel += use ? probDel : 0.0;
+                sumRef += use ? probRef : 0.0;
+                wSumDel += use ? probDel * dv : 0.0;
+                wSumRef += use ? probRef * dv : 0.0;
+            }
         }
         if (valid && !highCov)
         {
