@@ -1288,6 +1288,131 @@ __global__ __launch_bounds__(kSampleTile) void dataLikDenseKernel(CohortView co,
     }
 }
 
+// The same for the two evaluations that run with ZERO reference shifts -- ahead of the loop (mode 2) and the converged
+// cells' previous estimate (mode 1; the reference's prevShifts never leave zero, quirk Q3): the reference-allele lookups of
+// a pair then do not depend on the cell, and a window carries two cells on average, so one workgroup takes an IMAGE and
+// walks its cells two at a time: deviations and reference-allele lookups once per row, the deletion-allele lookups (mostly
+// outside the table: no memory access) and the sums per cell. Per cell the arithmetic and its order are those of
+// dataLikDenseKernel: bit-identical results.
+__global__ __launch_bounds__(kSampleTile) void dataLikZeroShiftDenseKernel(CohortView co, Stage2Buffers b, int mode)
+{
+    const unsigned imgIdx = blockIdx.y % b.nImages;
+    const unsigned tileIdx = (blockIdx.y / b.nImages) * gridDim.x + blockIdx.x;
+    if (tileIdx >= b.ownTiles || b.tileMode[(size_t)imgIdx * b.ownTiles + tileIdx] != 0)
+        return;
+    const unsigned c0 = b.cells[imgIdx].imageFirst, c1 = b.cells[imgIdx].imageEnd;
+    const unsigned s = tileIdx * kSamplesPerBlock + threadIdx.x;
+    const bool valid = s < co.nSamples;
+    const size_t wtGlobal = (size_t)imgIdx * (b.ownTiles * 4) + tileIdx * 4 + (threadIdx.x >> 6);
+    const unsigned rows = b.waveRows[wtGlobal];
+    const int16_t * col = b.cellDev + wtGlobal * (kDenseCap * 64) + (threadIdx.x & 63u);
+    unsigned rg = 0, n = 0;
+    LaneRg l = {};
+    if (valid)
+    {
+        rg = co.sampleRg[s];
+        l = laneRg(co.rg[rg]);
+        n = b.cellN[(size_t)imgIdx * co.nSamples + s];
+    }
+    const bool highCov = n == kDenseHighCov;
+    const unsigned nn = highCov ? 0u : n;
+    for (unsigned ca = c0; ca < c1; ca += 2u)
+    {
+        const unsigned cb = ca + 1u < c1 ? ca + 1u : ca;       // (an odd cell out is walked alone: its twin is itself, not stored twice)
+        const CellState & csA = b.cells[ca];
+        const CellState & csB = b.cells[cb];
+        const bool doA = mode == 2 || csA.phase == kCellConverged;
+        const bool doB = cb != ca && (mode == 2 || csB.phase == kCellConverged);
+        if (!doA && !doB)                                      // workgroup-uniform
+            continue;
+        const int lenA = mode == 2 ? csA.initLen : (int)csA.prevLen;
+        const int lenB = mode == 2 ? csB.initLen : (int)csB.prevLen;
+        double g0 = 0, g2A = 0, g2B = 0, prodA = 1.0, prodB = 1.0;
+        int esumA = 0, esumB = 0;
+        bool eqA = true, eqB = true;
+        constexpr unsigned kRowBatch = 4;
+        for (unsigned j0 = 0; j0 < rows; j0 += kRowBatch)
+        {
+            int dvs[kRowBatch];
+#pragma unroll
+            for (unsigned q = 0; q < kRowBatch; ++q)
+                dvs[q] = col[min(j0 + q, (unsigned)kDenseCap - 1u) * 64];
+            PD_ALL_LOADS_DONE(dvs);
+            double2 trs[kRowBatch], tdA[kRowBatch], tdB[kRowBatch];
+#pragma unroll
+            for (unsigned q = 0; q < kRowBatch; ++q)
+            {
+                const bool use = j0 + q < nn;
+                bool inR, inA, inB;
+                const uint64_t pr = lanePosClamped(l, dvs[q], inR);
+                const uint64_t pa = lanePosClamped(l, dvs[q] - lenA, inA), pb = lanePosClamped(l, dvs[q] - lenB, inB);
+                trs[q] = make_double2(l.minProb, l.logMinProb);
+                tdA[q] = trs[q];
+                tdB[q] = trs[q];
+                if (use && inR)
+                    trs[q] = co.tab2[pr];
+                if (use && inA && doA)
+                    tdA[q] = co.tab2[pa];
+                if (use && inB && doB)
+                    tdB[q] = co.tab2[pb];
+            }
+#pragma unroll
+            for (unsigned q = 0; q < kRowBatch; ++q)
+            {
+                const bool use = j0 + q < nn;
+                const double ref = trs[q].x;
+                int eA, eB;
+                const double mA = frexp(ref + tdA[q].x, &eA), mB = frexp(ref + tdB[q].x, &eB);
+                g0 += use ? trs[q].y : 0.0;
+                g2A += use ? tdA[q].y : 0.0;
+                g2B += use ? tdB[q].y : 0.0;
+                prodA *= use ? mA : 1.0;
+                prodB *= use ? mB : 1.0;
+                esumA += use ? eA : 0;
+                esumB += use ? eB : 0;
+                eqA = eqA && (!use || ref == tdA[q].x);
+                eqB = eqB && (!use || ref == tdB[q].x);
+            }
+        }
+        if (!valid)
+            continue;
+        for (int which = 0; which < 2; ++which)
+        {
+            if (!(which == 0 ? doA : doB))
+                continue;
+            const unsigned cellIdx = which == 0 ? ca : cb;
+            const double g2 = which == 0 ? g2A : g2B, prod = which == 0 ? prodA : prodB;
+            const int esum = which == 0 ? esumA : esumB;
+            const bool eq = which == 0 ? eqA : eqB;
+            const double g1 = log(prod) + (double)(esum - (int)nn) * PD_LN2;
+            if (rg == 0 && b.rank == 0)
+            {
+                double * r0 = rg0Slot(b, cellIdx, 0);
+                if (highCov)
+                {
+                    r0[0] = r0[1] = r0[2] = 0;
+                    r0[3] = 1;
+                }
+                else
+                {
+                    const double m = fmax(fmax(g0, g1), g2);
+                    r0[0] = g0 - m;
+                    r0[1] = g1 - m;
+                    r0[2] = g2 - m;
+                    r0[3] = 0;
+                }
+            }
+            double d[3];
+            const double logL[3] = {g0, nn ? g1 : 0.0, g2};
+            finishTriple(d, logL, nn, eq);
+            double * out = b.dl + ((size_t)cellIdx * co.nSamples + s) * 3;
+            out[0] = d[0];
+            out[1] = d[1];
+            out[2] = d[2];
+        }
+    }
+}
+
 // =====================================================================================================================
 // EM loop head (reference :598-604): loop condition, bookkeeping of the visited table and the previous estimate.
 // =====================================================================================================================
@@ -3177,8 +3302,12 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     const size_t xchBytes = b.xchChunk * sizeof(double);
     // every (cell, tile) is served by exactly one of the two kernels of a pair (tileMode)
     const dim3 perMulti(b.mt.n <= 12u ? b.mt.n : (b.mt.n + 7u) / 8u * 8u, b.nCells);   // (same XCD-stable tile order)
+    const dim3 perImage(perSample.x, b.nImages * sweeps);
     auto dataLik = [&](int mode) {
-        hipLaunchKernelGGL(dataLikDenseKernel, perSample, tile, 0, st, co, b, mode);
+        if (mode != 0)      // zero reference shifts: the cells of a window share their reference-allele lookups
+            hipLaunchKernelGGL(dataLikZeroShiftDenseKernel, perImage, tile, 0, st, co, b, mode);
+        else
+            hipLaunchKernelGGL(dataLikDenseKernel, perSample, tile, 0, st, co, b, mode);
         if (b.mt.n != 0)
             hipLaunchKernelGGL(dataLikMultiKernel, perMulti, tile, 0, st, co, b, mode);
         if (anyGenericTile)
