@@ -110,6 +110,9 @@ struct HipError
             throw HipError{std::string(#expr) + ": " + hipGetErrorString(e_)};                                \
     } while (0)
 
+// What the process holds in HBM and in page-locked host memory (POPDEL_HIP_MEMSTAT=1 prints it at every collect).
+std::atomic<uint64_t> g_devBytes{0}, g_pinnedBytes{0}, g_devAllocs{0}, g_pinnedAllocs{0};
+
 // Device allocation that frees itself.
 template <typename T>
 struct DevBuf
@@ -123,16 +126,23 @@ struct DevBuf
     void release()
     {
         if (p)
+        {
             (void)hipFree(p);
+            g_devBytes -= n * sizeof(T);
+        }
         p = nullptr;
         n = 0;
     }
     void alloc(size_t count)
     {
         release();
-        n = count;
         if (count)
+        {
             PD_HIP(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+            g_devBytes += count * sizeof(T);
+            ++g_devAllocs;
+        }
+        n = count;
     }
     void ensure(size_t count)
     {
@@ -166,17 +176,27 @@ struct PinnedBuf
     ~PinnedBuf()
     {
         if (p)
+        {
             (void)hipHostFree(p);
+            g_pinnedBytes -= cap * sizeof(T);
+        }
     }
     void resize(size_t count)
     {
         if (count > cap)
         {
             if (p)
+            {
                 (void)hipHostFree(p);
+                g_pinnedBytes -= cap * sizeof(T);
+            }
             p = nullptr;
-            cap = count + count / 8 + 1024;
-            PD_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), cap * sizeof(T), hipHostMallocDefault));
+            cap = 0;
+            const size_t want = count + count / 8 + 1024;
+            PD_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), want * sizeof(T), hipHostMallocDefault));
+            cap = want;
+            g_pinnedBytes += cap * sizeof(T);
+            ++g_pinnedAllocs;
         }
         n = count;
     }
@@ -444,6 +464,8 @@ PinnedBlock takePinned(size_t bytes)
     PinnedBlock b;
     b.bytes = bytes + bytes / 4 + 4096;
     PD_HIP(hipHostMalloc(&b.p, b.bytes, hipHostMallocDefault));
+    g_pinnedBytes += b.bytes;
+    ++g_pinnedAllocs;
     return b;
 }
 
@@ -474,6 +496,7 @@ void givePinned(PinnedBlock b)
             drop = b;
     }
     (void)hipHostFree(drop.p);
+    g_pinnedBytes -= drop.bytes;
 }
 
 // pd_calls plus what pd_calls_free() needs to know.
@@ -2702,6 +2725,14 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         givePinned(pinned);                 // nobody owns the result block of a failed collect
         *out = nullptr;
         groupFail(c);                       // the other contexts of a local group must not wait for this one
+    }
+    if (getenv("POPDEL_HIP_MEMSTAT"))
+    {
+        size_t freeB = 0, totalB = 0;
+        (void)hipMemGetInfo(&freeB, &totalB);
+        std::fprintf(stderr, "[popdel_hip memory] HBM %.1f MB in %llu allocations (device reports %.1f MB in use), page-locked %.1f MB in %llu\n",
+                     g_devBytes.load() / 1048576.0, (unsigned long long)g_devAllocs.load(), (totalB - freeB) / 1048576.0,
+                     g_pinnedBytes.load() / 1048576.0, (unsigned long long)g_pinnedAllocs.load());
     }
     if (s2Begin)
         (void)hipEventDestroy(s2Begin);

@@ -26,6 +26,30 @@ struct PhaseClock
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 };
 
+// POPDEL_TIMING=2: a time line of the run (seconds since the program's first instruction in main), printed at exit.
+struct EventTrace
+{
+    bool on = false;
+    double t0 = 0, epoch0 = 0;
+    std::mutex m;
+    std::vector<std::pair<double, std::string>> events;
+    void mark(const char * what)
+    {
+        if (!on)
+            return;
+        std::lock_guard<std::mutex> g(m);
+        events.emplace_back(PhaseClock::now() - t0, what);
+    }
+    void print()
+    {
+        std::lock_guard<std::mutex> g(m);
+        for (const auto & e : events)
+            std::cerr << "[popdel timeline] " << e.first << " " << e.second << "\n";
+        events.clear();
+    }
+};
+EventTrace gTrace;
+
 struct Coord
 {
     std::string contig;
@@ -127,10 +151,18 @@ public:
     {
         if (backendThread_.joinable())
             backendThread_.join();
+        const double t0 = PhaseClock::now();
         for (pd_ctx * c : ctxs_)
             pd_ctx_destroy(c);
         if (group_)
             pd_local_group_destroy(group_);
+        const double t1 = PhaseClock::now();
+        profile_.reset();
+        const double t2 = PhaseClock::now();
+        std::vector<DecodedStream>().swap(decodedPool_);
+        if (getenv("POPDEL_TIMING"))
+            std::cerr << "[popdel timing] teardown: backend " << t1 - t0 << " s, window tables " << t2 - t1 << " s, decoded streams "
+                      << PhaseClock::now() - t2 << " s" << std::endl;
         printTiming();
         if (walkCheck_ || walkUnchecked_)
             std::cerr << "[popdel walk check] " << walkChecked_ << " segments planned in closed form and found equal to the walk, "
@@ -145,6 +177,8 @@ public:
             std::cerr << "[popdel timing] threads " << hostThreads() << "; parameters " << clock_.params << " s; backend start " << clock_.backend << " s; switches " << clock_.switches << " s; decode " << clock_.decode << " s; replay " << clock_.replay << " s (" << clock_.parallelBatches << " batches in parallel, " << clock_.orderedBatches << " in order)"
                       << "; window walk " << clock_.walk << " s; flatten " << clock_.flatten << " s; stage+submit " << clock_.submit
                       << " s; collect+merge+write " << clock_.collect << " s" << std::endl;
+        if (!timingPrinted_)
+            gTrace.print();
         timingPrinted_ = true;
     }
     void closeOutput() { vcf_.reset(); }
@@ -519,10 +553,10 @@ void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned
     in.jumpToRegion(contigNames, p_.contigLengths[contigIdx], p_.indexRegionSizes[contigIdx], roi.seqName, roi.beginPos);
     auto src = in.openSource(p_.uncompressedIn);
     const unsigned nRg = static_cast<unsigned>(p_.rgs[i].size());
-    ProfileWindow window;
+    WindowHead window;
     for (;;)
     {
-        if (!readWindow(*src, window, nRg))
+        if (!readWindowHead(*src, window))
         {
             out.eof = true;
             return;
@@ -532,13 +566,17 @@ void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned
         raw.beginPos = window.beginPos;
         if (contigNames[window.chrom] != coordContig)
         {
+            skipWindowBody(*src, nRg);
             out.raws.push_back(std::move(raw));
             return;
         }
         if (window.beginPos + 255 < roi.beginPos)
+        {
+            skipWindowBody(*src, nRg);
             continue;
+        }
         raw.firstWin = static_cast<uint32_t>(out.wins.size());
-        if (!splitWindowFlat(window, out.wins, out.counts, out.recs, 256, 30))
+        if (!readWindowBodyFlat(*src, window, nRg, out.wins, out.counts, out.recs, 256, 30))
         {
             raw.splitFailed = true;
             out.raws.push_back(std::move(raw));
@@ -579,6 +617,9 @@ unsigned CallRun::replaySegment(const DecodedStream & in, const std::string & fi
                                 const std::vector<std::string> & contigNames, Coord & coordinate, const Region & roi, unsigned * border)
 {
     ChromProfile & prof = *profile_;
+    const bool oneRg = rg.size() == 1;
+    if (oneRg)
+        prof.reserveRun(rg[0], in.recs.size());
     for (const DecodedRaw & raw : in.raws)
     {
         if (contigNames[raw.chrom] != coordinate.contig)
@@ -591,10 +632,12 @@ unsigned CallRun::replaySegment(const DecodedStream & in, const std::string & fi
         if (raw.splitFailed)
             throw ProfileError("[PopDel] Could not convert window at " + contigNames[raw.chrom] + ":" +
                                std::to_string(raw.beginPos) + ". The profile \"" + fileName + "\" might be corrupted.");
-        for (uint32_t wi = raw.firstWin; wi < raw.firstWin + raw.nWin; ++wi)
+        const bool onRoiContig = contigNames[raw.chrom] == roi.seqName;         // (the 30-bp windows of a raw window share its contig)
+        const uint32_t wEnd = raw.firstWin + raw.nWin;
+        for (uint32_t wi = raw.firstWin; wi < wEnd; ++wi)
         {
             const FlatWindow & w = in.wins[wi];
-            if (contigNames[w.chrom] != roi.seqName || w.beginPos >= roi.endPos)
+            if (!onRoiContig || w.beginPos >= roi.endPos)
             {
                 prof.performPartialSwitches(rg, border);
                 coordinate.contig = contigNames[w.chrom];
@@ -625,17 +668,32 @@ unsigned CallRun::replaySegment(const DecodedStream & in, const std::string & fi
                 return 0;
             }
             // add all records of the window, read group by read group (load_profile_popdel_call.h:463-480)
+            static_assert(sizeof(PairRecord) == 2 * sizeof(uint32_t), "records are handed over as {pos, dev} words");
+            if (oneRg)
             {
-                uint32_t r0 = w.firstRec;
-                for (size_t r = 0; r < rg.size(); ++r)
-                {
-                    const uint32_t n = in.counts[static_cast<size_t>(wi) * rg.size() + r];
-                    const InsertHistogram & h = p_.histograms[rg[r]];
-                    static_assert(sizeof(PairRecord) == 2 * sizeof(uint32_t), "records are handed over as {pos, dev} words");
-                    prof.addRun(rg[r], reinterpret_cast<const uint32_t *>(in.recs.data() + r0), n,
-                                static_cast<int>(h.median) - 2 * static_cast<int>(h.readLength));
-                    r0 += n;
-                }
+                // ... and with it those of the windows behind it that the checks above let pass as well (they begin later,
+                // inside the region and before the write slot's border): their records follow in the stream, and filing
+                // them is the same sequence of operations
+                const StartSlots & st = prof.starts[rg[0]];
+                const unsigned right = st.slots[st.writeSlot].right;
+                uint32_t n = in.counts[wi];
+                uint32_t wj = wi + 1;
+                for (; wj < wEnd && in.wins[wj].beginPos < roi.endPos && static_cast<unsigned>(in.wins[wj].beginPos) < right; ++wj)
+                    n += in.counts[wj];
+                const InsertHistogram & h = p_.histograms[rg[0]];
+                prof.addRun(rg[0], reinterpret_cast<const uint32_t *>(in.recs.data() + w.firstRec), n,
+                            static_cast<int>(h.median) - 2 * static_cast<int>(h.readLength));
+                wi = wj - 1;
+                continue;
+            }
+            uint32_t r0 = w.firstRec;
+            for (size_t r = 0; r < rg.size(); ++r)
+            {
+                const uint32_t n = in.counts[static_cast<size_t>(wi) * rg.size() + r];
+                const InsertHistogram & h = p_.histograms[rg[r]];
+                prof.addRun(rg[r], reinterpret_cast<const uint32_t *>(in.recs.data() + r0), n,
+                            static_cast<int>(h.median) - 2 * static_cast<int>(h.readLength));
+                r0 += n;
             }
         }
     }
@@ -888,6 +946,7 @@ void CallRun::flushPending()
 void CallRun::processSegment()
 {
     ensureBackend();
+    gTrace.mark("segment: backend there");
     ChromProfile & prof = *profile_;
     if (deviceWalk_)
     {
@@ -898,9 +957,11 @@ void CallRun::processSegment()
             const WalkShape shape = prof.planSegment(p_.windowShift, equalRun, switches);
             windows_.current.pos += shape.nWindows * p_.windowShift;
             clock_.walk += PhaseClock::now() - t0;
+            gTrace.mark("segment: planned");
             t0 = PhaseClock::now();
             flushPending();
             clock_.collect += PhaseClock::now() - t0;
+            gTrace.mark("segment: previous collected and written");
             t0 = PhaseClock::now();
             submitPlannedSegment(shape, equalRun, switches);
             clock_.submit += PhaseClock::now() - t0;
@@ -1189,6 +1250,7 @@ int CallRun::run()
         if (!d)
             d = getenv("POPDEL_DEVICE");
         (void)pd_device_warmup(d ? atoi(d) : 0);
+        gTrace.mark("device warm");
     });
     struct Joiner
     {
@@ -1197,6 +1259,7 @@ int CallRun::run()
     } joinWarmup{warmup};
     loadAndCalculateParameters(p_);
     clock_.params = PhaseClock::now() - tStart;
+    gTrace.mark("parameters read");
     printStatus("Finished parameter calculation.\n");
     {
         std::ostringstream msg;
@@ -1221,6 +1284,7 @@ int CallRun::run()
             for (pd_ctx * c : ctxs_)
                 deviceWalkOffered_ = deviceWalkOffered_ && pd_walk_supported(c) == 1;
             deviceWalk_ = deviceWalkOffered_;
+            gTrace.mark("backend created");
         }
         catch (...)
         {
@@ -1303,6 +1367,7 @@ int CallRun::run()
                     readers.push_back(members[k]);
             }
             clock_.switches += PhaseClock::now() - t0;
+            gTrace.mark("batch: switches done");
             // (2) parallel: inflate, parse and split the profile windows of this round
             t0 = PhaseClock::now();
             if (decodedPool_.size() < readers.size())
@@ -1316,6 +1381,7 @@ int CallRun::run()
                 decodeSample(i, nextCandidate_[i].contig, st.slots[st.writeSlot].right, st.numWindows, decoded[k]);
             });
             clock_.decode += PhaseClock::now() - t0;
+            gTrace.mark("batch: decoded");
             t0 = PhaseClock::now();
             // (3) insert the records and switch slots: per sample independent unless a stream contains a window beyond the
             //     next slot (then the loader looks at ALL tables and order matters -> this batch is replayed in order)
@@ -1347,8 +1413,10 @@ int CallRun::run()
             for (size_t k = 0; k < readers.size(); ++k)
                 processSegmentCode(readers[k], codes[k]);
             clock_.replay += PhaseClock::now() - t0;
+            gTrace.mark("batch: replayed");
         }
         processSegment();
+        gTrace.mark("segment handed over");
         if (allTrue(finishedRois_))
         {
             if (!finalizeRoi())
@@ -1378,16 +1446,24 @@ int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer, bool
     CallParams params;
     try
     {
+        const double t0 = PhaseClock::now();
+        if (const char * t = getenv("POPDEL_TIMING"))
+        {
+            gTrace.on = atoi(t) >= 2;
+            gTrace.t0 = t0;
+            gTrace.epoch0 = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+        }
         int res = parseCallCommandLine(params, argc, argv);
         if (res >= 0)
             return res;
-        const double t0 = PhaseClock::now();
+        gTrace.mark("command line parsed");
         int rc;
         double tRun;
         {
             CallRun run(params, observer);
             rc = run.run();
             tRun = PhaseClock::now();
+            gTrace.mark("run over");
             if (quickExit)
             {
                 // A command-line run ends here: the records are written; tearing down a thousand window tables, HBM and
@@ -1396,6 +1472,9 @@ int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer, bool
                 run.printTiming();
                 if (getenv("POPDEL_TIMING"))
                     std::cerr << "[popdel timing] run " << tRun - t0 << " s; teardown skipped" << std::endl;
+                if (gTrace.on)      // (wall-clock stamps: what the caller's clock sees before main and after the exit call)
+                    std::cerr << "[popdel timeline] epoch seconds at main " << std::fixed << gTrace.epoch0 << ", at exit "
+                              << std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count() << std::endl;
                 std::cout.flush();
                 std::cerr.flush();
                 fflush(nullptr);

@@ -229,6 +229,16 @@ void ChromProfile::add(unsigned rg, unsigned startPos, unsigned endPos, int devi
     }
 }
 
+void ChromProfile::reserveRun(unsigned rg, size_t n)
+{
+    std::vector<StartEntry> & s = starts[rg].slots[starts[rg].writeSlot].entries;
+    if (s.capacity() < s.size() + n)
+        s.reserve(s.size() + n);
+    std::vector<EndEntry> & e = ends[rg].slots[ends[rg].writeSlot].entries;
+    if (e.capacity() < e.size() + n)
+        e.reserve(e.size() + n);
+}
+
 void ChromProfile::addRun(unsigned rg, const uint32_t * posDev, size_t n, int innerOffset)
 {
     StartSlots & st = starts[rg];

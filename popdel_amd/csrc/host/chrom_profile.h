@@ -153,6 +153,8 @@ public:
     // add() for a run of records of one read group ({pos, dev} pairs as the reader delivers them; the pair's end is
     // pos + max(0, dev + innerOffset), innerOffset = median - 2 * read length): the same operations in the same order
     void addRun(unsigned rg, const uint32_t * posDev, size_t n, int innerOffset);
+    // room for n more records in the slots being written (one allocation instead of the doublings of push_back)
+    void reserveRun(unsigned rg, size_t n);
     void initializeActive();
     bool nextWindow(unsigned shift);
     void resetTo(unsigned pos);

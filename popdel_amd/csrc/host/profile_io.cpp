@@ -283,6 +283,116 @@ bool readWindow(ByteSource & src, ProfileWindow & win, unsigned numReadGroups)
     return true;
 }
 
+bool readWindowHead(ByteSource & src, WindowHead & head)
+{
+    uint32_t chrom = 0, begin = 0;
+    if (src.read(&chrom, 4) != 4)
+        return false;
+    if (src.read(&begin, 4) != 4)
+        throw ProfileError("[PopDel] Unable to read contig position.");
+    head.chrom = static_cast<int32_t>(chrom);
+    head.beginPos = static_cast<int32_t>(begin);
+    return true;
+}
+
+namespace {
+// the 5-byte records of one read group of the window, raw; the thread's scratch buffer holds them until the next call
+const unsigned char * readRawRecords(ByteSource & src, uint32_t & n)
+{
+    static thread_local std::vector<unsigned char> buf;
+    n = 0;
+    if (src.read(&n, 4) != 4)
+        throw ProfileError("[PopDel] Unable to read number of read pairs.");
+    if (buf.size() < static_cast<size_t>(n) * 5)
+        buf.resize(static_cast<size_t>(n) * 5);
+    if (n != 0 && src.read(buf.data(), static_cast<size_t>(n) * 5) != static_cast<size_t>(n) * 5)
+        throw ProfileError("[PopDel] Unable to read insert size deviation.");
+    return buf.data();
+}
+}  // namespace
+
+void skipWindowBody(ByteSource & src, unsigned numReadGroups)
+{
+    uint32_t n;
+    for (unsigned rg = 0; rg < numReadGroups; ++rg)
+        (void)readRawRecords(src, n);
+}
+
+bool readWindowBodyFlat(ByteSource & src, const WindowHead & head, unsigned numReadGroups, std::vector<FlatWindow> & wins,
+                        std::vector<uint32_t> & counts, std::vector<PairRecord> & recs, unsigned oldSize, unsigned newSize)
+{
+    const uint32_t begin = static_cast<uint32_t>(head.beginPos);
+    if (numReadGroups == 1)
+    {
+        // One read group (the rule): the records are position-sorted, so the 30-bp windows are runs of the record array as
+        // it is -- converted in place behind `recs`, cut into windows on the way.
+        uint32_t n;
+        const unsigned char * p = readRawRecords(src, n);
+        if (n == 0)
+            return false;
+        const size_t first = recs.size();
+        recs.resize(first + n);
+        PairRecord * o = recs.data() + first;
+        bool ordered = true;
+        uint32_t prev = 0;
+        for (uint32_t i = 0; i < n; ++i, p += 5)
+        {
+            uint32_t dev;
+            std::memcpy(&dev, p + 1, 4);
+            const uint32_t pos = static_cast<uint32_t>(p[0]) + begin;
+            o[i].pos = pos;
+            o[i].dev = dev;
+            ordered = ordered && pos >= prev;
+            prev = pos;
+        }
+        const size_t slots = static_cast<size_t>(std::ceil(static_cast<double>(oldSize + newSize) / newSize));
+        const unsigned base = (o[0].pos / newSize) * newSize;
+        if (ordered && (o[n - 1].pos - base) / newSize < slots)
+        {
+            uint32_t boundary = 0;          // first position beyond the current 30-bp window (0: none yet)
+            uint32_t * count = nullptr;
+            for (uint32_t i = 0; i < n; ++i)
+            {
+                if (o[i].pos >= boundary)
+                {
+                    const uint32_t winBegin = base + ((o[i].pos - base) / newSize) * newSize;
+                    wins.push_back(FlatWindow{head.chrom, static_cast<int32_t>(winBegin), static_cast<uint32_t>(first + i)});
+                    counts.push_back(0);
+                    count = &counts.back();
+                    boundary = winBegin + newSize;
+                }
+                ++*count;
+            }
+            return true;
+        }
+        // (out of order: the general path reports or handles it)
+        ProfileWindow win;
+        win.chrom = head.chrom;
+        win.beginPos = head.beginPos;
+        win.records.resize(1);
+        win.records[0].assign(o, o + n);
+        recs.resize(first);
+        return splitWindowFlat(win, wins, counts, recs, oldSize, newSize);
+    }
+    static thread_local ProfileWindow win;
+    win.chrom = head.chrom;
+    win.beginPos = head.beginPos;
+    win.records.resize(numReadGroups);
+    for (unsigned rg = 0; rg < numReadGroups; ++rg)
+    {
+        uint32_t n;
+        const unsigned char * p = readRawRecords(src, n);
+        std::vector<PairRecord> & r = win.records[rg];
+        r.resize(n);
+        for (uint32_t i = 0; i < n; ++i, p += 5)
+        {
+            std::memcpy(&r[i].dev, p + 1, 4);
+            r[i].pos = static_cast<uint32_t>(p[0]) + begin;
+        }
+    }
+    return splitWindowFlat(win, wins, counts, recs, oldSize, newSize);
+}
+
 bool splitWindow(const ProfileWindow & in, std::vector<ProfileWindow> & out, unsigned oldSize, unsigned newSize)
 {
     const size_t rgNum = in.records.size();

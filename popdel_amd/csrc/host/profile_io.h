@@ -99,6 +99,20 @@ struct FlatWindow
 bool splitWindowFlat(const ProfileWindow & in, std::vector<FlatWindow> & wins, std::vector<uint32_t> & counts,
                      std::vector<PairRecord> & recs, unsigned oldSize = 256, unsigned newSize = 30);
 
+// readWindow() + splitWindowFlat() in two steps for bulk decoding, so that a window the caller does not want is not
+// converted and the records of a one-read-group file go from the inflated bytes to `recs` in one pass. Same data, same
+// errors (a truncated body throws where readWindow() would).
+struct WindowHead
+{
+    int32_t chrom = 0;
+    int32_t beginPos = 0;
+};
+bool readWindowHead(ByteSource & src, WindowHead & head);                       // false at the end of the data
+void skipWindowBody(ByteSource & src, unsigned numReadGroups);
+// false if the window holds no records (nothing appended)
+bool readWindowBodyFlat(ByteSource & src, const WindowHead & head, unsigned numReadGroups, std::vector<FlatWindow> & wins,
+                        std::vector<uint32_t> & counts, std::vector<PairRecord> & recs, unsigned oldSize = 256, unsigned newSize = 30);
+
 inline unsigned posToWin(unsigned pos, unsigned windowSize = 30u) { return (pos / windowSize) * windowSize; }
 
 }  // namespace pdh

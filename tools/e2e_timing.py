@@ -13,11 +13,12 @@ if not os.path.exists(os.path.join(d, "profiles.txt")):
 if not os.path.exists(os.path.join(d, "profiles.txt")):
     pass
 for th, host_walk in [(t, h) for t in threads for h in (False, True)]:
-    env = dict(os.environ, POPDEL_TIMING="1", POPDEL_THREADS=th)
+    env = dict(os.environ, POPDEL_TIMING=os.environ.get("POPDEL_TIMING", "1"), POPDEL_THREADS=th)
     if host_walk:
         env["POPDEL_HOST_WALK"] = "1"
     t = time.time()
     r = subprocess.run([os.path.join(ROOT, "popdel_amd", "lib", "popdel"), "call", os.path.join(d, "profiles.txt"), "-o", "/tmp/e2e.vcf",
                         "-r", "chr20:1000000-2000000"], env=env, capture_output=True, text=True)
+    print("spawned at %.4f, returned at %.4f" % (t, time.time()))
     print("threads", th, "window loop on the", "host" if host_walk else "device", "wall %.2f s" % (time.time() - t), "rc", r.returncode)
-    print("\n".join(l for l in (r.stdout + r.stderr).splitlines() if "timing" in l.lower() or "phase" in l.lower() or "s " in l[-12:])[-1500:])
+    print("\n".join(l for l in (r.stdout + r.stderr).splitlines() if "timing" in l.lower() or "timeline" in l.lower() or "memory]" in l or "phase" in l.lower() or "s " in l[-12:])[-6000:])
