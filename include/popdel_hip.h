@@ -282,7 +282,9 @@ typedef struct pd_walk
  * ticket is collected with pd_segment_collect() like that of pd_segment_submit(). */
 int pd_walk_submit(pd_ctx *ctx, const pd_walk *walk, uint64_t *ticket);
 
-/* 1 if the backend behind the ABI offers pd_walk_submit() (the oracle does not: it takes pd_segment only), else 0. */
+/* 1 if the backend behind the ABI offers pd_walk_submit() (the oracle does not: it takes pd_segment only), else 0. A
+ * property of the library: `ctx` may be NULL (a caller that plans its first segment while the context is still being
+ * created asks without one). */
 int pd_walk_supported(const pd_ctx *ctx);
 
 /* The pairs still active after the most recently submitted walk (waits for its kernels): their number, and -- if the

@@ -125,9 +125,9 @@ struct DecodedRaw
 struct alignas(64) DecodedStream      // (neighbours in the pool are filled by different threads: no shared cache lines)
 {
     std::vector<DecodedRaw> raws;
-    std::vector<FlatWindow> wins;          // all 30-bp windows, flat
-    std::vector<uint32_t> counts;          // per window: records per read group of the file
-    std::vector<PairRecord> recs;
+    FlatWindows wins;                      // all 30-bp windows, flat
+    FlatCounts counts;                     // per window: records per read group of the file
+    FlatRecords recs;
     bool eof = false;
     bool sawFarWindow = false;     // a window beyond the next slot: the replay may consult ALL tables (allEmpty/resetTo)
     // Streams are pooled per batch position and reused round after round: their vectors keep their capacity, so the
@@ -149,6 +149,8 @@ public:
     CallRun(CallParams & p, SegmentObserver * obs) : p_(p), observer_(obs) {}
     ~CallRun()
     {
+        if (submitThread_.joinable())
+            submitThread_.join();
         if (backendThread_.joinable())
             backendThread_.join();
         const double t0 = PhaseClock::now();
@@ -242,8 +244,10 @@ private:
     // the backend comes up on its own thread while the first round of profiles is read (run(), ensureBackend())
     std::thread backendThread_;
     std::exception_ptr backendError_;
+    std::mutex backendLock_;            // (the main thread and the thread that hands a segment over may both come asking)
     void ensureBackend()
     {
+        std::lock_guard<std::mutex> guard(backendLock_);
         if (backendThread_.joinable())
         {
             const double t0 = PhaseClock::now();
@@ -257,6 +261,12 @@ private:
     unsigned deviceSegments_ = 0, hostSegments_ = 0;
     void leaveDeviceWalk();
     void submitPlannedSegment(const WalkShape & shape, const std::vector<uint8_t> & equalRun, const std::vector<uint8_t> & switches);
+    // The hand-over of a planned segment runs beside the next round of decoding: it reads the tables' READ slots, which the
+    // next round leaves alone (a round fills the write slot and recycles the slot after it), and everything that needs its
+    // ticket or the device's walk state waits for it first (joinSubmit()).
+    std::thread submitThread_;
+    std::exception_ptr submitError_;
+    void joinSubmit();
     bool timingPrinted_ = false;
     bool pending_ = false;
     std::string pendingContig_;
@@ -451,26 +461,58 @@ bool CallRun::goNextRegion()
 Coord CallRun::firstWindowCoordinate()
 {
     Coord minCoord{"", kNoPos};
-    ProfileWindow window;
-    std::vector<ProfileWindow> converted;
+    bool windowSeen = false;
     while (true)
     {
+        // every profile's first window of the region in parallel (open, index jump, one block inflated); the minimum is
+        // taken in file order, as the loop over the files takes it
+        if (allTrue(finishedRois_))         // (what goNextRoi() does for whichever file comes first)
+        {
+            if (!advanceRoi(p_))
+                break;
+            for (char & b : finishedRois_)
+                b = 0;
+        }
+        struct First
+        {
+            Coord at{"", kNoPos};
+            int32_t chrom = 0, beginPos = 0;
+            char state = 0;         // 0: no window (end of the data), 1: a window with records, 2: a window that does not convert
+        };
+        std::vector<First> firsts(p_.fileCount);
+        parallelFor(p_.fileCount, [&](size_t i) {
+            const unsigned contigIdx = p_.representativeContigs ? 0 : static_cast<unsigned>(i);
+            ProfileFile in(p_.inputFiles[i]);
+            jumpToRoi(in, static_cast<unsigned>(i));
+            auto src = in.openSource(p_.uncompressedIn);
+            ProfileWindow window;
+            std::vector<ProfileWindow> converted;
+            if (!readWindow(*src, window, static_cast<unsigned>(p_.rgs[i].size())))
+                return;
+            First & f = firsts[i];
+            f.chrom = window.chrom;
+            f.beginPos = window.beginPos;
+            f.state = 2;
+            if (!splitWindow(window, converted, 256, 30))
+                return;
+            f.at = Coord{p_.contigNames[contigIdx][converted[0].chrom], static_cast<unsigned>(converted[0].beginPos)};
+            f.state = 1;
+        }, 8);
         for (unsigned i = 0; i < p_.fileCount; ++i)
         {
-            unsigned contigIdx = p_.representativeContigs ? 0 : i;
-            ProfileFile in(p_.inputFiles[i]);
-            goNextRoi(in, i);
-            auto src = in.openSource(p_.uncompressedIn);
-            readWindow(*src, window, static_cast<unsigned>(p_.rgs[i].size()));
-            if (window.empty())
+            // (the reference reads every file into the same window object, which keeps its read groups once a file had
+            // some: from then on a file without data in the region is not skipped but fails to convert)
+            const unsigned contigIdx = p_.representativeContigs ? 0 : i;
+            First & f = firsts[i];
+            if (f.state == 0 && !windowSeen)
                 continue;
-            if (!splitWindow(window, converted, 256, 30))
-                throw ProfileError("[PopDel] Could not convert window " + p_.contigNames[contigIdx][window.chrom] + ":" +
-                                   std::to_string(window.beginPos) + ". The profile \"" + p_.inputFiles[i] +
+            if (f.state != 1)
+                throw ProfileError("[PopDel] Could not convert window " + p_.contigNames[contigIdx][f.chrom] + ":" +
+                                   std::to_string(f.beginPos) + ". The profile \"" + p_.inputFiles[i] +
                                    "\" might be corrupted.");
-            Coord cur{p_.contigNames[contigIdx][converted[0].chrom], static_cast<unsigned>(converted[0].beginPos)};
-            if (minCoord.contig.empty() || !lowerCoord(minCoord, cur, p_))
-                minCoord = cur;
+            windowSeen = true;
+            if (minCoord.contig.empty() || !lowerCoord(minCoord, f.at, p_))
+                minCoord = f.at;
         }
         if (minCoord.contig == p_.allRois[p_.nextRoi].seqName)
             break;
@@ -852,6 +894,7 @@ bool CallRun::mergeCallsOnDevice(std::vector<WindowCall> & calls, const std::vec
 // Collect the calls of the segment that is in flight, merge them and write the records.
 void CallRun::flushPending()
 {
+    joinSubmit();
     if (!pending_)
         return;
     pending_ = false;
@@ -945,8 +988,6 @@ void CallRun::flushPending()
 // backend. The previous segment is collected and written first so that records stay in order.
 void CallRun::processSegment()
 {
-    ensureBackend();
-    gTrace.mark("segment: backend there");
     ChromProfile & prof = *profile_;
     if (deviceWalk_)
     {
@@ -970,6 +1011,7 @@ void CallRun::processSegment()
         }
         leaveDeviceWalk();
     }
+    ensureBackend();
     ++hostSegments_;
     // (check mode: plan the segment on the tables as they are now, note what the plan says, put the state back, then walk)
     WalkShape planned;
@@ -1096,33 +1138,77 @@ void CallRun::submitPlannedSegment(const WalkShape & shape, const std::vector<ui
         borders[rg] = slot.endBorder;
         idOffsets[rg] = slot.idOffset;
     }
-    onEveryContext([&](unsigned r) {
-        const uint32_t g0 = shardRg_[r], g1 = shardRg_[r + 1];
-        pd_walk wk;
-        std::memset(&wk, 0, sizeof(wk));
-        wk.first_window_pos = shape.firstPos;
-        wk.step_pos = shape.stepPos;
-        wk.has_step = shape.hasStep ? 1u : 0u;
-        wk.n_windows = shape.nWindows;
-        wk.window_shift = p_.windowShift;
-        wk.n_readgroups = g1 - g0;
-        wk.rg_counts = counts.data() + g0;
-        wk.rg_entries = tables.data() + g0;
-        wk.end_border = borders.data() + g0;
-        wk.id_offset = idOffsets.data() + g0;
-        wk.switches = switches.data() + g0;
-        wk.equal_run = equalRun.data() + g0;
-        if (pd_walk_submit(ctxs_[r], &wk, &tickets_[r]) != 0)
-            throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
-    });
+    joinSubmit();
+    struct Job
+    {
+        std::vector<uint32_t> counts, borders, idOffsets;
+        std::vector<const pd_walk_entry *> tables;
+        std::vector<uint8_t> equalRun, switches;
+        WalkShape shape;
+    };
+    auto job = std::make_shared<Job>();
+    job->counts = std::move(counts);
+    job->borders = std::move(borders);
+    job->idOffsets = std::move(idOffsets);
+    job->tables = std::move(tables);
+    job->equalRun = equalRun;
+    job->switches = switches;
+    job->shape = shape;
     pending_ = true;
     pendingContig_ = windows_.current.contig;
+    submitThread_ = std::thread([this, job] {
+        try
+        {
+            ensureBackend();
+            onEveryContext([&](unsigned r) {
+                const uint32_t g0 = shardRg_[r], g1 = shardRg_[r + 1];
+                pd_walk wk;
+                std::memset(&wk, 0, sizeof(wk));
+                wk.first_window_pos = job->shape.firstPos;
+                wk.step_pos = job->shape.stepPos;
+                wk.has_step = job->shape.hasStep ? 1u : 0u;
+                wk.n_windows = job->shape.nWindows;
+                wk.window_shift = p_.windowShift;
+                wk.n_readgroups = g1 - g0;
+                wk.rg_counts = job->counts.data() + g0;
+                wk.rg_entries = job->tables.data() + g0;
+                wk.end_border = job->borders.data() + g0;
+                wk.id_offset = job->idOffsets.data() + g0;
+                wk.switches = job->switches.data() + g0;
+                wk.equal_run = job->equalRun.data() + g0;
+                if (pd_walk_submit(ctxs_[r], &wk, &tickets_[r]) != 0)
+                    throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
+            });
+            gTrace.mark("segment: on the device");
+        }
+        catch (...)
+        {
+            submitError_ = std::current_exception();
+        }
+    });
+}
+
+void CallRun::joinSubmit()
+{
+    if (!submitThread_.joinable())
+        return;
+    const double t0 = PhaseClock::now();
+    submitThread_.join();
+    clock_.submit += PhaseClock::now() - t0;
+    if (submitError_)
+    {
+        std::exception_ptr e = submitError_;
+        submitError_ = nullptr;
+        std::rethrow_exception(e);
+    }
 }
 
 // From the device's window loop back to the one here: the pairs the device holds as active become the tables' active
 // sets (the cursors have been kept where the walk would have left them all along).
 void CallRun::leaveDeviceWalk()
 {
+    ensureBackend();
+    joinSubmit();
     ChromProfile & prof = *profile_;
     for (size_t r = 0; r < ctxs_.size(); ++r)
     {
@@ -1274,16 +1360,16 @@ int CallRun::run()
     vcf_.reset(new VcfOutput(p_.outfile, p_.inputFiles, p_.contigNames[0], p_.contigLengths[0]));
     vcf_->appendContigName(windows_.current.contig);
 
+    // (whose window loop: decided here, so that the first segment can be planned and handed over -- by a thread that waits
+    // for the backend -- while the main thread already decodes the next round)
+    deviceWalkOffered_ = !getenv("POPDEL_HOST_WALK") && !getenv("POPDEL_WALK_CHECK") && !observer_ && pd_walk_supported(nullptr) == 1;
+    deviceWalk_ = deviceWalkOffered_;
     backendThread_ = std::thread([this, &warmup] {
         try
         {
             warmup.join();
             createBackend();
             chooseMergeSite();
-            deviceWalkOffered_ = !getenv("POPDEL_HOST_WALK") && !getenv("POPDEL_WALK_CHECK") && !observer_;
-            for (pd_ctx * c : ctxs_)
-                deviceWalkOffered_ = deviceWalkOffered_ && pd_walk_supported(c) == 1;
-            deviceWalk_ = deviceWalkOffered_;
             gTrace.mark("backend created");
         }
         catch (...)
@@ -1307,6 +1393,7 @@ int CallRun::run()
         ensureBackend();            // (only asked from the main thread: the replay of a batch with a far window runs in order)
         if (!deviceWalk_)
             return 0;
+        joinSubmit();
         uint64_t left = 0;
         for (pd_ctx * c : ctxs_)
         {

@@ -113,7 +113,7 @@ void EndSlots::add(unsigned id, unsigned endPos)
     // behind the last entry that does not end later (what upper_bound finds) -- looked for from the back: pairs arrive in
     // start order, so a new pair's last window lies among the last few entries' (a binary search over the whole slot
     // costs more than the handful of comparisons this takes)
-    std::vector<EndEntry> & v = slots[which].entries;
+    HugeVector<EndEntry> & v = slots[which].entries;
     size_t at = v.size();
     while (at > 0 && v[at - 1].lastWindow > lastWin)
         --at;
@@ -231,10 +231,10 @@ void ChromProfile::add(unsigned rg, unsigned startPos, unsigned endPos, int devi
 
 void ChromProfile::reserveRun(unsigned rg, size_t n)
 {
-    std::vector<StartEntry> & s = starts[rg].slots[starts[rg].writeSlot].entries;
+    HugeVector<StartEntry> & s = starts[rg].slots[starts[rg].writeSlot].entries;
     if (s.capacity() < s.size() + n)
         s.reserve(s.size() + n);
-    std::vector<EndEntry> & e = ends[rg].slots[ends[rg].writeSlot].entries;
+    HugeVector<EndEntry> & e = ends[rg].slots[ends[rg].writeSlot].entries;
     if (e.capacity() < e.size() + n)
         e.reserve(e.size() + n);
 }
@@ -588,13 +588,13 @@ std::vector<std::vector<PairInstance>> & ChromProfile::endSegmentLog()
 // ----------------------------------------------------------------------------------------------------------
 namespace {
 // first index >= from whose entry starts beyond pos (entries in start order)
-size_t startsUpTo(const std::vector<StartEntry> & v, size_t from, unsigned pos)
+size_t startsUpTo(const HugeVector<StartEntry> & v, size_t from, unsigned pos)
 {
     return static_cast<size_t>(std::upper_bound(v.begin() + static_cast<std::ptrdiff_t>(std::min(from, v.size())), v.end(), pos,
                                                 [](unsigned p, const StartEntry & e) { return p < e.startPos; }) - v.begin());
 }
 // first index >= from whose entry is NOT yet over at pos: lastWindow + shift >= pos (entries ordered by lastWindow)
-size_t endsBefore(const std::vector<EndEntry> & v, size_t from, unsigned pos, unsigned shift)
+size_t endsBefore(const HugeVector<EndEntry> & v, size_t from, unsigned pos, unsigned shift)
 {
     return static_cast<size_t>(std::lower_bound(v.begin() + static_cast<std::ptrdiff_t>(std::min(from, v.size())), v.end(), pos,
                                                 [shift](const EndEntry & e, unsigned p) { return e.lastWindow + shift < p; }) - v.begin());
@@ -658,7 +658,7 @@ WalkShape ChromProfile::planSegment(unsigned shift, std::vector<uint8_t> & equal
             if (st.readAtEnd() || st.current().startPos != currentPos)
                 continue;
             equalRun[rg] = 1;
-            const std::vector<StartEntry> & v = st.slots[st.readSlot].entries;
+            const HugeVector<StartEntry> & v = st.slots[st.readSlot].entries;
             while (st.readIdx < v.size() && v[st.readIdx].startPos == currentPos)
                 ++st.readIdx;
         }

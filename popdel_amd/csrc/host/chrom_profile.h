@@ -19,6 +19,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include "huge_pool.h"
+
 namespace pdh {
 
 struct StartEntry
@@ -41,7 +43,7 @@ class alignas(64) StartSlots
 public:
     struct Slot
     {
-        std::vector<StartEntry> entries;
+        HugeVector<StartEntry> entries;
         unsigned right = 0;        // exclusive right border
         unsigned idOffset = 0;     // id of entries[0]
         unsigned endBorder = 0;    // right border of the END slot the entries' end records were filed under (ChromProfile::add)
@@ -79,7 +81,7 @@ class alignas(64) EndSlots
 public:
     struct Slot
     {
-        std::vector<EndEntry> entries;   // ordered by lastWindow (stable)
+        HugeVector<EndEntry> entries;    // ordered by lastWindow (stable)
         unsigned right = 0;
         bool readable = false;
         void reset(unsigned r) { entries.clear(); right = r; readable = false; }

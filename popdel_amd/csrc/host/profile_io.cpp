@@ -318,8 +318,8 @@ void skipWindowBody(ByteSource & src, unsigned numReadGroups)
         (void)readRawRecords(src, n);
 }
 
-bool readWindowBodyFlat(ByteSource & src, const WindowHead & head, unsigned numReadGroups, std::vector<FlatWindow> & wins,
-                        std::vector<uint32_t> & counts, std::vector<PairRecord> & recs, unsigned oldSize, unsigned newSize)
+bool readWindowBodyFlat(ByteSource & src, const WindowHead & head, unsigned numReadGroups, FlatWindows & wins, FlatCounts & counts,
+                        FlatRecords & recs, unsigned oldSize, unsigned newSize)
 {
     const uint32_t begin = static_cast<uint32_t>(head.beginPos);
     if (numReadGroups == 1)
@@ -440,8 +440,8 @@ bool splitWindow(const ProfileWindow & in, std::vector<ProfileWindow> & out, uns
     return true;
 }
 
-bool splitWindowFlat(const ProfileWindow & in, std::vector<FlatWindow> & wins, std::vector<uint32_t> & counts,
-                     std::vector<PairRecord> & recs, unsigned oldSize, unsigned newSize)
+bool splitWindowFlat(const ProfileWindow & in, FlatWindows & wins, FlatCounts & counts, FlatRecords & recs, unsigned oldSize,
+                     unsigned newSize)
 {
     const size_t rgNum = in.records.size();
     const size_t slots = static_cast<size_t>(std::ceil(static_cast<double>(oldSize + newSize) / newSize));

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "histogram.h"
+#include "huge_pool.h"
 
 namespace pdh {
 
@@ -96,8 +97,12 @@ struct FlatWindow
     int32_t  beginPos;
     uint32_t firstRec;     // index into the record array
 };
-bool splitWindowFlat(const ProfileWindow & in, std::vector<FlatWindow> & wins, std::vector<uint32_t> & counts,
-                     std::vector<PairRecord> & recs, unsigned oldSize = 256, unsigned newSize = 30);
+// (the arrays of a decoded stream: hundreds of kilobytes per sample and round, see huge_pool.h)
+using FlatWindows = HugeVector<FlatWindow>;
+using FlatCounts = HugeVector<uint32_t>;
+using FlatRecords = HugeVector<PairRecord>;
+bool splitWindowFlat(const ProfileWindow & in, FlatWindows & wins, FlatCounts & counts, FlatRecords & recs, unsigned oldSize = 256,
+                     unsigned newSize = 30);
 
 // readWindow() + splitWindowFlat() in two steps for bulk decoding, so that a window the caller does not want is not
 // converted and the records of a one-read-group file go from the inflated bytes to `recs` in one pass. Same data, same
@@ -110,8 +115,8 @@ struct WindowHead
 bool readWindowHead(ByteSource & src, WindowHead & head);                       // false at the end of the data
 void skipWindowBody(ByteSource & src, unsigned numReadGroups);
 // false if the window holds no records (nothing appended)
-bool readWindowBodyFlat(ByteSource & src, const WindowHead & head, unsigned numReadGroups, std::vector<FlatWindow> & wins,
-                        std::vector<uint32_t> & counts, std::vector<PairRecord> & recs, unsigned oldSize = 256, unsigned newSize = 30);
+bool readWindowBodyFlat(ByteSource & src, const WindowHead & head, unsigned numReadGroups, FlatWindows & wins, FlatCounts & counts,
+                        FlatRecords & recs, unsigned oldSize = 256, unsigned newSize = 30);
 
 inline unsigned posToWin(unsigned pos, unsigned windowSize = 30u) { return (pos / windowSize) * windowSize; }
 

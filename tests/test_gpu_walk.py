@@ -41,7 +41,7 @@ def test_first_segment_equals_the_interval_rule(built):
     a = ctx.collect(ctx.submit(seg))
     ctx.close()
     ctx = capi.Context(hip, [rg] * n, list(range(n + 1)))
-    assert hip.pd_walk_supported(ctx.handle) == 1
+    assert hip.pd_walk_supported(ctx.handle) == 1 and hip.pd_walk_supported(None) == 1
     equal_run = [1 if len(s) and s[0] == first else 0 for s in starts]
     t = ctx.submit_walk(first, W, starts, devs, end_border=[0xffffffff] * n, switches=[2] * n, equal_run=equal_run)
     b = ctx.collect(t)

@@ -7,12 +7,10 @@ n = int(sys.argv[1])
 d = "/tmp/e2e_cohort_%d" % n
 if not os.path.exists(os.path.join(d, "profiles.txt")):
     synth.write_cohort(d, n, deletions=synth.single_deletion, workers=16)
-variants = [("plain", {}, []), ("taskset 0-15", {}, ["taskset", "-c", "0-15"]), ("taskset 0-31", {}, ["taskset", "-c", "0-31"]),
-            ("taskset 0-7,128-135", {}, ["taskset", "-c", "0-7,128-135"]), ("32 threads", {"POPDEL_THREADS": "32"}, []),
-            ("taskset 0-15, 32 threads", {"POPDEL_THREADS": "32"}, ["taskset", "-c", "0-15"])]
-for rep in range(2):
+variants = [("16 threads", {"POPDEL_THREADS": "16"}, []), ("default threads", {}, []), ("16 threads, teardown in the process", {"POPDEL_THREADS": "16", "POPDEL_KEEP_TEARDOWN": "1"}, [])]
+for rep in range(3):
     for name, extra, prefix in variants:
-        env = dict(os.environ, POPDEL_TIMING="2", POPDEL_THREADS="16")
+        env = dict(os.environ, POPDEL_TIMING="2")
         env.update(extra)
         t = time.time()
         r = subprocess.run(prefix + [os.path.join(ROOT, "popdel_amd", "lib", "popdel"), "call", os.path.join(d, "profiles.txt"), "-o", "/tmp/e2e.vcf",
@@ -26,5 +24,5 @@ for rep in range(2):
         at_main = float(ep[0].split("at main")[1].split(",")[0]) if ep else 0
         print("%-32s wall %.3f s  (before main %.3f, main to exit call %.3f, exit to return %.3f) %s" %
               (name, t1 - t, at_main - t, at_exit - at_main, t1 - at_exit, run[0].split("]")[1] if run else r.returncode), flush=True)
-        for l in ph if rep == 1 else []:
+        for l in ph if rep == 2 else []:
             print("   ", l[:400])
