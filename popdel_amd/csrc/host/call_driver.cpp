@@ -7,6 +7,7 @@
 #include <iostream>
 #include <exception>
 #include <memory>
+#include <sys/resource.h>
 #include <thread>
 
 #include "parallel.h"
@@ -1558,7 +1559,13 @@ int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer, bool
                 run.closeOutput();
                 run.printTiming();
                 if (getenv("POPDEL_TIMING"))
-                    std::cerr << "[popdel timing] run " << tRun - t0 << " s; teardown skipped" << std::endl;
+                {
+                    struct rusage ru;
+                    std::memset(&ru, 0, sizeof(ru));
+                    getrusage(RUSAGE_SELF, &ru);
+                    std::cerr << "[popdel timing] run " << tRun - t0 << " s; teardown skipped; CPU time " << ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec
+                              << " s user, " << ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec << " s system, " << ru.ru_minflt << " page faults" << std::endl;
+                }
                 if (gTrace.on)      // (wall-clock stamps: what the caller's clock sees before main and after the exit call)
                     std::cerr << "[popdel timeline] epoch seconds at main " << std::fixed << gTrace.epoch0 << ", at exit "
                               << std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count() << std::endl;
