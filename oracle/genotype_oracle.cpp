@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <set>
 #include <string>
 #include <unordered_map>
@@ -24,6 +25,7 @@
 
 #include "popdel_hip.h"
 #include "oracle_side_channel.h"
+#include "chrom_profile.h"      // pdh::WalkReference (POPDEL_ORACLE_WALK, see pd_walk_submit below)
 
 namespace {
 
@@ -114,6 +116,7 @@ struct pd_ctx
     // in which the pairs of a window are visited.
     std::vector<std::unordered_set<uint32_t>> refActive;
     pd_timing timing;
+    std::unique_ptr<pdh::WalkReference> walk;      // POPDEL_ORACLE_WALK: the closed-form walk's state from segment to segment
 
     unsigned nSamples() const { return static_cast<unsigned>(sampleOffsets.size() - 1); }
     bool isHighCov(unsigned rg) const { return active[rg].size() >= rgs[rg].maxLoad; }
@@ -1075,19 +1078,93 @@ int pd_rccl_unique_id(uint8_t *) { return 1; }
 
 int pd_device_warmup(int) { return 0; }
 
-// The oracle takes segments as pair instances (pd_segment) only: the host walks the windows itself.
-int pd_walk_supported(const pd_ctx *) { return 0; }
-int pd_walk_submit(pd_ctx * c, const pd_walk *, uint64_t *)
+// The oracle takes segments as pair instances (pd_segment): the host walks the windows itself. With POPDEL_ORACLE_WALK=1 it
+// also accepts the loader's tables (pd_walk) and derives the instances with the host's closed-form evaluation of the window
+// loop (pdh::WalkReference, the host reference of walk.hip) -- a TEST path for the hand-over protocol of the call driver
+// (planned segments, the hand-over thread, leaving and re-entering the mode) on machines without a GPU and under the
+// sanitizers; the checker of the closed form itself is the walked loop (POPDEL_WALK_CHECK, tests/test_walk_closed_form.py).
+int pd_walk_supported(const pd_ctx *) { return getenv("POPDEL_ORACLE_WALK") ? 1 : 0; }
+int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
 {
-    if (c)
-        c->error = "pd_walk_submit: the oracle takes pair instances (pd_segment_submit)";
-    return 1;
+    if (!c || !wk || !ticket || !getenv("POPDEL_ORACLE_WALK"))
+    {
+        if (c)
+            c->error = "pd_walk_submit: the oracle takes pair instances (pd_segment_submit)";
+        return 1;
+    }
+    if (wk->n_readgroups != c->rgs.size())
+    {
+        c->error = "pd_walk_submit: read-group count mismatch";
+        return 1;
+    }
+    const uint32_t nRg = wk->n_readgroups;
+    if (!c->walk)
+        c->walk.reset(new pdh::WalkReference(nRg));
+    pdh::WalkShape shape;
+    shape.firstPos = wk->first_window_pos;
+    shape.stepPos = wk->step_pos;
+    shape.nWindows = wk->n_windows;
+    shape.hasStep = wk->has_step != 0;
+    std::vector<uint64_t> offsets(nRg + 1, 0);
+    std::vector<int32_t> dev;
+    std::vector<uint32_t> start, on, off;
+    std::vector<pdh::PairInstance> inst;
+    for (uint32_t r = 0; r < nRg; ++r)
+    {
+        pdh::StartSlots::Slot slot;
+        if (wk->switches[r] != 0)
+        {
+            slot.entries.resize(wk->rg_counts[r]);
+            for (uint32_t i = 0; i < wk->rg_counts[r]; ++i)
+                slot.entries[i] = pdh::StartEntry{wk->rg_entries[r][i].start, wk->rg_entries[r][i].dev};
+            slot.endBorder = wk->end_border[r];
+            slot.idOffset = wk->id_offset[r];
+        }
+        inst.clear();
+        c->walk->segment(r, shape, wk->window_shift, wk->switches[r], wk->equal_run[r] != 0, wk->switches[r] ? &slot : nullptr,
+                         c->rgs[r].median, c->rgs[r].readLength, inst);
+        for (const pdh::PairInstance & p : inst)
+        {
+            dev.push_back(p.dev);
+            start.push_back(p.start);
+            on.push_back(p.on);
+            off.push_back(p.off);
+        }
+        offsets[r + 1] = dev.size();
+    }
+    pd_segment seg;
+    std::memset(&seg, 0, sizeof(seg));
+    seg.first_window_pos = wk->first_window_pos;
+    seg.n_windows = wk->n_windows;
+    seg.window_shift = wk->window_shift;
+    seg.n_readgroups = nRg;
+    seg.rg_offsets = offsets.data();
+    seg.pair_dev = dev.data();
+    seg.pair_start = start.data();
+    seg.pair_on = on.data();
+    seg.pair_off = off.data();
+    return runSegment(c, &seg, ticket);
 }
-int pd_walk_active(pd_ctx * c, uint64_t *, uint32_t *, uint32_t *, int32_t *, uint32_t *, uint64_t)
+int pd_walk_active(pd_ctx * c, uint64_t * n, uint32_t * rg, uint32_t * start, int32_t * dev, uint32_t * id, uint64_t capacity)
 {
-    if (c)
-        c->error = "pd_walk_active: the oracle takes pair instances (pd_segment_submit)";
-    return 1;
+    if (!c || !n)
+        return 1;
+    uint64_t total = 0;
+    if (c->walk)
+        for (unsigned r = 0; r < c->rgs.size(); ++r)
+            for (const pdh::WalkReference::Pair & p : c->walk->active(r))
+            {
+                if (rg && total < capacity)
+                {
+                    rg[total] = r;
+                    start[total] = p.start;
+                    dev[total] = p.dev;
+                    id[total] = p.id;
+                }
+                ++total;
+            }
+    *n = total;
+    return (rg && total > capacity) ? 2 : 0;
 }
 
 int pd_ctx_set_shard_rccl(pd_ctx * c, const pd_shard *, const uint8_t *)

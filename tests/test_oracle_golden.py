@@ -191,3 +191,31 @@ def test_reference_algorithm_hangs_off_the_last_bit_of_the_allele_frequency(buil
         assert np.allclose(a["likelihood_ratio"], b["likelihood_ratio"], rtol=1e-6, atol=1e-4)
         changed += int((a["pl"] != b["pl"]).any(axis=2).sum())
     assert 1 <= changed <= 10
+
+
+def test_planned_segments_and_the_hand_over_thread_through_the_oracle(built, cohort_dir, tmp_path, monkeypatch):
+    """The call driver's closed-form mode without a GPU: with POPDEL_ORACLE_WALK=1 the oracle accepts the loader's tables
+    (pd_walk) and derives the pair instances with the host's own closed-form walk, so that planned segments, the hand-over
+    thread beside the next round's decoding and the way in and out of the mode run here too -- same VCFs as the walked loop."""
+    from popdel_amd import synth
+    monkeypatch.setenv("POPDEL_ORACLE_WALK", "1")
+    monkeypatch.setenv("POPDEL_TIMING", "1")
+    d = cohort_dir("s2", 2, synth.single_deletion)
+    out = tmp_path / "a.vcf"
+    r = subprocess.run([ORACLE_CALL, os.path.join(d, "profiles.txt"), "-o", str(out), "-r", "chr20:1000000-2000000"],
+                       capture_output=True, text=True, check=True)
+    assert strip_date(out.read_text()) == golden_text("s2_default.vcf")
+    line = [l for l in r.stderr.splitlines() if "window loop:" in l][0]
+    assert int(line.split("window loop:")[1].split()[0]) >= 4, line          # segments in closed form, not walked
+    assert run_call(ORACLE_CALL, d, str(tmp_path / "b.vcf"), "-n") == golden_text("s2_windowwise.vcf")
+    d = cohort_dir("s200", 200, synth.single_deletion)
+    assert run_call(ORACLE_CALL, d, str(tmp_path / "c.vcf")) == golden_text("s200_default.vcf")
+    # several regions: the mode is left and entered again at region changes
+    for args in (["-r", "chr20:1000000-1300000", "-r", "chr20:1500000-2000000"], ["-b", "50000"], ["-b", "3000000"]):
+        a, b = tmp_path / "w.vcf", tmp_path / "h.vcf"
+        base = [ORACLE_CALL, os.path.join(d, "profiles.txt")] + args
+        subprocess.check_call(base + ["-o", str(a)], stdout=subprocess.DEVNULL)
+        env = dict(os.environ)
+        del env["POPDEL_ORACLE_WALK"]
+        subprocess.check_call(base + ["-o", str(b)], stdout=subprocess.DEVNULL, env=env)
+        assert strip_date(a.read_text()) == strip_date(b.read_text()), args
