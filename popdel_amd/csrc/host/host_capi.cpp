@@ -1,5 +1,6 @@
 // Small C exports of host-side start-up code for Python callers (bench.py / tests build synthetic cohorts in memory
 // and need exactly the histogram conditioning that `popdel call` applies when it loads a profile header).
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <random>
@@ -7,6 +8,7 @@
 
 #include "call_params.h"
 #include "histogram.h"
+#include "profile_io.h"
 #include "window_call.h"
 
 extern "C" {
@@ -84,6 +86,102 @@ int pdh_bench_merge_and_format(unsigned samples, unsigned windows, unsigned reco
         bytes = pdh::formatRecord(q, calls[0], "chr20").size();
     out[1] = std::chrono::duration<double>(clock::now() - t2).count();
     out[2] = static_cast<double>(bytes);
+    return 0;
+}
+
+// Self-test of the bulk decoder (tests/test_abi_and_host.py): `rounds` random 256-bp window records -- one to three read
+// groups, empty read groups, records out of position order now and then -- are decoded by readWindow() + splitWindowFlat()
+// and by readWindowHead() + readWindowBodyFlat() (what `popdel call` uses); windows, counts and records must be the same,
+// and so must the verdict "not position-sorted". Returns 0 if they are, else 1 + the number of the first round that differs.
+int pdh_selftest_window_decode(unsigned seed, unsigned rounds)
+{
+    struct MemorySource : pdh::ByteSource
+    {
+        const std::vector<unsigned char> & bytes;
+        size_t at = 0;
+        explicit MemorySource(const std::vector<unsigned char> & b) : bytes(b) {}
+        size_t read(void * dst, size_t n) override
+        {
+            const size_t take = std::min(n, bytes.size() - at);
+            std::memcpy(dst, bytes.data() + at, take);
+            at += take;
+            return take;
+        }
+    };
+    std::mt19937 gen(seed);
+    for (unsigned round = 0; round < rounds; ++round)
+    {
+        const unsigned nRg = 1 + gen() % 3;
+        const uint32_t chrom = gen() % 3, begin = 256u * (gen() % 100000u);
+        std::vector<unsigned char> bytes;
+        auto put32 = [&bytes](uint32_t v) {
+            for (int i = 0; i < 4; ++i)
+                bytes.push_back(static_cast<unsigned char>(v >> (8 * i)));
+        };
+        put32(chrom);
+        put32(begin);
+        const bool shuffle = gen() % 8 == 0;
+        for (unsigned rg = 0; rg < nRg; ++rg)
+        {
+            const uint32_t n = gen() % 4 == 0 ? 0u : gen() % 60;
+            std::vector<unsigned> offs(n);
+            for (unsigned & o : offs)
+                o = gen() % 256;
+            std::sort(offs.begin(), offs.end());
+            if (shuffle && n > 1)
+                std::swap(offs[gen() % n], offs[gen() % n]);
+            put32(n);
+            for (uint32_t i = 0; i < n; ++i)
+            {
+                bytes.push_back(static_cast<unsigned char>(offs[i]));
+                put32(static_cast<uint32_t>(static_cast<int32_t>(gen() % 2000) - 1000));
+            }
+        }
+        pdh::FlatWindows winsA, winsB;
+        pdh::FlatCounts countsA, countsB;
+        pdh::FlatRecords recsA, recsB;
+        // (something in front, as in a stream that already holds windows)
+        winsA.push_back(pdh::FlatWindow{7, 30, 0});
+        countsA.assign(nRg, 1);
+        recsA.assign(nRg, pdh::PairRecord{31, 5});
+        winsB = winsA;
+        countsB = countsA;
+        recsB = recsA;
+        int a = -1, b = -1;
+        try
+        {
+            MemorySource src(bytes);
+            pdh::ProfileWindow win;
+            a = pdh::readWindow(src, win, nRg) && pdh::splitWindowFlat(win, winsA, countsA, recsA, 256, 30) ? 1 : 0;
+        }
+        catch (const pdh::ProfileError &)
+        {
+            a = 2;
+        }
+        try
+        {
+            MemorySource src(bytes);
+            pdh::WindowHead head;
+            b = pdh::readWindowHead(src, head) && pdh::readWindowBodyFlat(src, head, nRg, winsB, countsB, recsB, 256, 30) ? 1 : 0;
+        }
+        catch (const pdh::ProfileError &)
+        {
+            b = 2;
+        }
+        bool same = a == b;
+        if (same && a != 2)
+        {
+            same = winsA.size() == winsB.size() && countsA.size() == countsB.size() && recsA.size() == recsB.size();
+            for (size_t i = 0; same && i < winsA.size(); ++i)
+                same = winsA[i].chrom == winsB[i].chrom && winsA[i].beginPos == winsB[i].beginPos && winsA[i].firstRec == winsB[i].firstRec;
+            for (size_t i = 0; same && i < countsA.size(); ++i)
+                same = countsA[i] == countsB[i];
+            for (size_t i = 0; same && i < recsA.size(); ++i)
+                same = recsA[i].pos == recsB[i].pos && recsA[i].dev == recsB[i].dev;
+        }
+        if (!same)
+            return 1 + static_cast<int>(round);
+    }
     return 0;
 }
 

@@ -66,3 +66,11 @@ def test_interval_rule_matches_state_machine_inside_a_segment(built):
     assert on[k] == (int(s[k]) - 1000020) // 30
     life = (off - on).astype(int)
     assert 6 <= life.mean() <= 10
+
+
+def test_bulk_decoder_equals_the_window_reader(built):
+    """readWindowHead() + readWindowBodyFlat() (what `popdel call` decodes with) against readWindow() + splitWindowFlat()
+    on random window records: one to three read groups, empty ones, records out of position order."""
+    host = ctypes.CDLL(os.path.join(ROOT, "popdel_amd", "lib", "libpopdel_host.so"))
+    for seed in (1, 2, 3):
+        assert host.pdh_selftest_window_decode(ctypes.c_uint(seed), ctypes.c_uint(20000)) == 0
