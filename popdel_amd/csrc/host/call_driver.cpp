@@ -1544,6 +1544,7 @@ int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer, bool
         int res = parseCallCommandLine(params, argc, argv);
         if (res >= 0)
             return res;
+        stayOnOneMemoryNode();          // (before the first thread is started: they inherit the mask)
         gTrace.mark("command line parsed");
         int rc;
         double tRun;
