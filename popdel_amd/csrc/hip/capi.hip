@@ -3026,17 +3026,26 @@ const char * pd_last_error(const pd_ctx * c) { return c ? c->error.c_str() : g_c
 
 int pd_device_warmup(int device)
 {
+    const bool timed = getenv("POPDEL_HIP_MEMSTAT") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     if (hipSetDevice(device) != hipSuccess)
         return 1;
+    const double t1 = now();
     void * p = nullptr;
     if (hipMalloc(&p, 256) != hipSuccess)       // (the first allocation creates the device context)
         return 1;
+    const double t2 = now();
     // ... and the first kernel launch loads the library's code object
     pd::ZeroRanges zero{};
     zero.add(p, 256);
     pd::launchZero(zero, nullptr);
     const bool ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    const double t3 = now();
     (void)hipFree(p);
+    if (timed)
+        std::fprintf(stderr, "[popdel_hip warm-up] runtime start + device %.3f s, first allocation %.3f s, first kernel (code object) %.3f s\n",
+                     t1 - t0, t2 - t1, t3 - t2);
     return ok ? 0 : 1;
 }
 
