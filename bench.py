@@ -934,13 +934,20 @@ def main():
                     if line.startswith("[popdel timing]"):
                         for name, val in re.findall(r"([a-z][a-z+ ]*?) ([0-9][0-9.e+-]*) s", line):
                             phases[name.strip().replace(" ", "_")] = float(val)
+                        m = re.search(r"threads (\d+);", line)
+                        if m:
+                            phases["host_threads"] = int(m.group(1))
+                        m = re.search(r"CPU time ([0-9.e+-]+) s user, ([0-9.e+-]+) s system", line)
+                        if m:
+                            phases["cpu_seconds"] = float(m.group(1)) + float(m.group(2))
+                            phases.pop("time", None)            # (the phase pattern's reading of "CPU time x s user")
                 return wall, phases
 
             call(product, os.path.join(d, "warm.vcf"), 0)          # page cache, GPU runtime start
             wall, phases = call(product, os.path.join(d, "gpu.vcf"), 0)
             out = dict(workload="popdel call on %d generated profiles, chr20:%d-%d (%d windows), merged VCF" % (n, region[0], region[1], n_win),
                        value=n * n_win / wall, unit="window*sample/s", wall_seconds=wall, phases_seconds=phases,
-                       host_threads=usable_cores(), profile_bytes=sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.endswith(".profile")),
+                       host_threads=phases.pop("host_threads", None), usable_cores=usable_cores(), profile_bytes=sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.endswith(".profile")),
                        cohort_written_in_seconds=t_write)
             if os.path.exists(oracle_bin) and not args.no_cpu:
                 cpu = {}
