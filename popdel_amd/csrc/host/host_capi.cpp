@@ -185,4 +185,38 @@ int pdh_selftest_window_decode(unsigned seed, unsigned rounds)
     return 0;
 }
 
+// Self-test of the two inflaters (tests/test_abi_and_host.py): the compressed stream of `path` from byte `offset` on, read
+// through zlib and through the source `popdel call` uses (libdeflate where the system has it), in requests of `request`
+// bytes. Returns 0 if both deliver the same bytes (their number in *bytes), 1 if not, 2 if the file cannot be opened.
+int pdh_selftest_inflate(const char * path, unsigned long long offset, unsigned request, unsigned long long * bytes)
+{
+    if (!path || request == 0 || !bytes)
+        return 2;
+    try
+    {
+        pdh::ProfileFile a(path), b(path);
+        if (fseeko(a.handle(), static_cast<off_t>(offset), SEEK_SET) != 0 || fseeko(b.handle(), static_cast<off_t>(offset), SEEK_SET) != 0)
+            return 2;
+        auto za = a.openSource(false, true);
+        auto zb = b.openSource(false, false);
+        std::vector<unsigned char> ba(request), bb(request);
+        unsigned long long total = 0;
+        for (;;)
+        {
+            const size_t na = za->read(ba.data(), request), nb = zb->read(bb.data(), request);
+            if (na != nb || std::memcmp(ba.data(), bb.data(), na) != 0)
+                return 1;
+            total += na;
+            if (na < request)
+                break;
+        }
+        *bytes = total;
+        return 0;
+    }
+    catch (const std::exception &)
+    {
+        return 2;
+    }
+}
+
 }  // extern "C"

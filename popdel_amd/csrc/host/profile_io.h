@@ -71,8 +71,10 @@ public:
     // Seek to the first data block of the index region that contains `beginPos` on `contig`.
     void jumpToRegion(const std::vector<std::string> & contigNames, const std::vector<int32_t> & contigLengths,
                       unsigned indexRegionSize, const std::string & contig, int32_t beginPos);
-    // Byte source starting at the current file offset.
-    std::unique_ptr<ByteSource> openSource(bool uncompressed);
+    // Byte source starting at the current file offset. Compressed profiles are inflated with libdeflate where the system
+    // has it (member by member, the file mapped), else -- or with forceZlib, or POPDEL_ZLIB_INFLATE=1 -- with zlib; the
+    // bytes delivered are the same, on damaged files too.
+    std::unique_ptr<ByteSource> openSource(bool uncompressed, bool forceZlib = false);
 
     FILE * handle() { return fp_; }
 

@@ -74,3 +74,36 @@ def test_bulk_decoder_equals_the_window_reader(built):
     host = ctypes.CDLL(os.path.join(ROOT, "popdel_amd", "lib", "libpopdel_host.so"))
     for seed in (1, 2, 3):
         assert host.pdh_selftest_window_decode(ctypes.c_uint(seed), ctypes.c_uint(20000)) == 0
+
+
+def test_inflate_through_libdeflate_equals_zlib(built, tmp_path):
+    """What `popdel call` reads compressed profiles with (libdeflate member by member where the system has it, zlib for
+    whatever libdeflate does not take) delivers the bytes zlib delivers -- on whole, truncated and damaged streams, stored
+    blocks, empty members, a member beyond the decoder's 64-MB limit, and bytes that are no gzip member."""
+    import gzip
+    import random
+    host = ctypes.CDLL(os.path.join(ROOT, "popdel_amd", "lib", "libpopdel_host.so"))
+    host.pdh_selftest_inflate.argtypes = [ctypes.c_char_p, ctypes.c_ulonglong, ctypes.c_uint, ctypes.POINTER(ctypes.c_ulonglong)]
+    rng = random.Random(1)
+    noise = bytes(rng.getrandbits(8) for _ in range(300000))
+    member = lambda data, level=6: gzip.compress(data, level, mtime=0)
+    normal = b"".join(member(noise[i:i + 5000]) for i in range(0, 100000, 5000))
+    damaged = bytearray(normal)
+    damaged[len(damaged) // 2] ^= 0x55
+    streams = {
+        "normal": (normal, 100000),
+        "large members": (member(noise) + member(b"abcdefgh" * 40000), 620000),
+        "stored block": (member(noise[:70000], 0) + member(b"tail"), 70004),
+        "truncated": (normal[:-37], None),
+        "damaged": (bytes(damaged), None),
+        "garbage behind": (member(b"x" * 1000) + b"not a gzip member at all", 1000),
+        "empty members": (member(b"") + member(b"abc") + member(b"") + member(b"def"), 6),
+        "beyond the limit": (member(b"\0" * (80 << 20), 1) + member(b"after"), (80 << 20) + 5),
+    }
+    n = ctypes.c_ulonglong()
+    for name, (blob, want) in streams.items():
+        path = tmp_path / "stream.bin"
+        path.write_bytes(b"HEADER" + blob)
+        for request in ((125, 1, 70000) if want is None or want < (1 << 20) else (4096,)):
+            assert host.pdh_selftest_inflate(str(path).encode(), 6, request, ctypes.byref(n)) == 0, (name, request)
+            assert want is None or n.value == want, (name, request, n.value)

@@ -31,6 +31,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         continue
     cols = gpu[0]["pl"].shape[0] * gpu[0]["pl"].shape[1] if gpu[0]["n_calls"] else 0
     tot_bad += nb; tot_cols += cols; tot_calls += gpu[0]["n_calls"]
-    print("seed", seed, "calls", gpu[0]["n_calls"], "columns", cols, "knife-edge", nb, flush=True)
+    print("seed", seed, "calls", gpu[0]["n_calls"], "columns", cols, "knife-edge", nb,
+          ("touched %d worst dLR %.3g dAF %.3g" % (_calls, wlr, waf)) if not snap and _calls else "", flush=True)
 print("total knife-edge", tot_bad, "of", tot_cols, "columns; diverged calls", tot_div, "; failures", fails)
 print("touched calls", tot_touched, "of", tot_calls, "; worst |dLR| (relative to max(1, |LR|))", worst_lr, "; worst |dAF|", worst_af)
