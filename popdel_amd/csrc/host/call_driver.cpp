@@ -6,6 +6,8 @@
 #include <cstring>
 #include <iostream>
 #include <exception>
+#include <condition_variable>
+#include <deque>
 #include <memory>
 #include <sys/resource.h>
 #include <thread>
@@ -150,8 +152,15 @@ public:
     CallRun(CallParams & p, SegmentObserver * obs) : p_(p), observer_(obs) {}
     ~CallRun()
     {
-        if (submitThread_.joinable())
-            submitThread_.join();
+        if (handOverThread_.joinable())
+        {
+            {
+                std::lock_guard<std::mutex> guard(handOverLock_);
+                handOverStop_ = true;
+            }
+            handOverWake_.notify_all();
+            handOverThread_.join();
+        }
         if (backendThread_.joinable())
             backendThread_.join();
         const double t0 = PhaseClock::now();
@@ -179,7 +188,8 @@ public:
         if (getenv("POPDEL_TIMING") && !timingPrinted_)
             std::cerr << "[popdel timing] threads " << hostThreads() << "; parameters " << clock_.params << " s; backend start " << clock_.backend << " s; switches " << clock_.switches << " s; decode " << clock_.decode << " s; replay " << clock_.replay << " s (" << clock_.parallelBatches << " batches in parallel, " << clock_.orderedBatches << " in order)"
                       << "; window walk " << clock_.walk << " s; flatten " << clock_.flatten << " s; stage+submit " << clock_.submit
-                      << " s; collect+merge+write " << clock_.collect << " s" << std::endl;
+                      << " s; collect+merge+write " << clock_.collect << " s; on the hand-over thread: hand-over " << workerSubmitSeconds_
+                      << " s, collect+merge+write " << workerCollectSeconds_ << " s" << std::endl;
         if (!timingPrinted_)
             gTrace.print();
         timingPrinted_ = true;
@@ -253,21 +263,51 @@ private:
         {
             const double t0 = PhaseClock::now();
             backendThread_.join();
-            clock_.backend += PhaseClock::now() - t0;           // (what the main thread still had to wait for)
-            if (backendError_)
-                std::rethrow_exception(backendError_);
+            clock_.backend += PhaseClock::now() - t0;           // (what the caller still had to wait for)
         }
+        if (backendError_)                      // (to every caller: the hand-over thread may be the first to ask)
+            std::rethrow_exception(backendError_);
     }
     bool deviceWalkOffered_ = false, deviceWalk_ = false;
     unsigned deviceSegments_ = 0, hostSegments_ = 0;
     void leaveDeviceWalk();
     void submitPlannedSegment(const WalkShape & shape, const std::vector<uint8_t> & equalRun, const std::vector<uint8_t> & switches);
-    // The hand-over of a planned segment runs beside the next round of decoding: it reads the tables' READ slots, which the
-    // next round leaves alone (a round fills the write slot and recycles the slot after it), and everything that needs its
-    // ticket or the device's walk state waits for it first (joinSubmit()).
-    std::thread submitThread_;
-    std::exception_ptr submitError_;
-    void joinSubmit();
+    // Planned segments go to the backend through a queue with a thread of its own behind it (collect + merge + write of the
+    // previous segment, then the hand-over of the next one: the order of the sequential loop), beside the next rounds of
+    // decoding. A job normally points INTO the tables' read slots, which the next round leaves alone (a round fills the write
+    // slot and recycles the slot after it): the main thread waits for such a job's hand-over before it plans the next
+    // segment. While the backend is still coming up (the first 0.2-0.3 s of a run) jobs carry a COPY of their entries instead
+    // and nobody waits: the main thread decodes round after round until the device is there. Everything that needs the
+    // device's state, the output in order or the contexts themselves drains the queue first (drainHandOver()).
+    struct HandOverJob
+    {
+        std::vector<uint32_t> counts, borders, idOffsets;
+        std::vector<const pd_walk_entry *> tables;
+        HugeVector<pd_walk_entry> copy;             // (empty: the tables point into the slot tables)
+        std::vector<uint8_t> equalRun, switches;
+        WalkShape shape;
+        std::string contig;
+        uint64_t seq = 0;
+    };
+    std::thread handOverThread_;
+    std::mutex handOverLock_;
+    std::condition_variable handOverWake_, handOverDone_;
+    std::deque<std::shared_ptr<HandOverJob>> handOverQueue_;
+    uint64_t handOverEnqueued_ = 0, handOverFinished_ = 0;      // jobs queued / handed over (or failed)
+    uint64_t lastDirectJob_ = 0;                                // newest job that points into the tables
+    bool handOverStop_ = false, handOverIdle_ = true;
+    std::exception_ptr handOverError_;
+    std::atomic<bool> backendReady_{false};
+    // (state of the hand-over thread alone: the segment whose results it has yet to collect)
+    bool workerPending_ = false;
+    std::vector<uint64_t> workerTickets_;
+    std::string workerContig_;
+    double workerSubmitSeconds_ = 0, workerCollectSeconds_ = 0;
+    void handOverLoop();
+    void handOver(HandOverJob & job);
+    void waitForHandOver(uint64_t seq);         // until job `seq` has been handed over
+    void drainHandOver();                       // ... all of them, and the last one's results written
+    void collectAndWrite(const std::vector<uint64_t> & tickets, const std::string & contig);
     bool timingPrinted_ = false;
     bool pending_ = false;
     std::string pendingContig_;
@@ -895,13 +935,19 @@ bool CallRun::mergeCallsOnDevice(std::vector<WindowCall> & calls, const std::vec
 // Collect the calls of the segment that is in flight, merge them and write the records.
 void CallRun::flushPending()
 {
-    joinSubmit();
+    drainHandOver();
     if (!pending_)
         return;
     pending_ = false;
+    collectAndWrite(tickets_, pendingContig_);
+}
+
+// Results of one segment: collected from every context, merged, written.
+void CallRun::collectAndWrite(const std::vector<uint64_t> & tickets, const std::string & contig)
+{
     std::vector<pd_calls *> parts(ctxs_.size(), nullptr);
     onEveryContext([&](unsigned r) {
-        if (pd_segment_collect(ctxs_[r], tickets_[r], &parts[r]) != 0)
+        if (pd_segment_collect(ctxs_[r], tickets[r], &parts[r]) != 0)
             throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
     });
     // every context returns the calls of the whole cohort with the columns of its own samples
@@ -971,7 +1017,7 @@ void CallRun::flushPending()
     {
         if (merged ? mergedAny : unifyCalls(calls, p_.meanStddev, p_.minRelWinCover, p_.outputFailed))
         {
-            vcf_->appendContigName(pendingContig_);
+            vcf_->appendContigName(contig);
             vcf_->writeCalls(calls, p_);
             vcf_->flush();
         }
@@ -979,7 +1025,7 @@ void CallRun::flushPending()
     else
     {
         if (!calls.empty())
-            vcf_->appendContigName(pendingContig_);
+            vcf_->appendContigName(contig);
         vcf_->writeCalls(calls, p_);
         vcf_->flush();
     }
@@ -1001,10 +1047,9 @@ void CallRun::processSegment()
             clock_.walk += PhaseClock::now() - t0;
             gTrace.mark("segment: planned");
             t0 = PhaseClock::now();
-            flushPending();
-            clock_.collect += PhaseClock::now() - t0;
-            gTrace.mark("segment: previous collected and written");
-            t0 = PhaseClock::now();
+            if (pending_)                           // (a segment of the host's window loop is still out)
+                flushPending();
+            waitForHandOver(lastDirectJob_);        // jobs that point into the tables: handed over before the next one is cut
             submitPlannedSegment(shape, equalRun, switches);
             clock_.submit += PhaseClock::now() - t0;
             ++deviceSegments_;
@@ -1139,67 +1184,183 @@ void CallRun::submitPlannedSegment(const WalkShape & shape, const std::vector<ui
         borders[rg] = slot.endBorder;
         idOffsets[rg] = slot.idOffset;
     }
-    joinSubmit();
-    struct Job
+    auto job = std::make_shared<HandOverJob>();
+    job->equalRun = equalRun;
+    job->switches = switches;
+    job->shape = shape;
+    job->contig = windows_.current.contig;
+    if (!backendReady_.load() || getenv("POPDEL_COPY_HAND_OVER"))
     {
-        std::vector<uint32_t> counts, borders, idOffsets;
-        std::vector<const pd_walk_entry *> tables;
-        std::vector<uint8_t> equalRun, switches;
-        WalkShape shape;
-    };
-    auto job = std::make_shared<Job>();
+        // the device is not there yet: the job takes the entries along, and the tables are free again
+        std::vector<size_t> offsets(nRg + 1, 0);
+        for (size_t rg = 0; rg < nRg; ++rg)
+            offsets[rg + 1] = offsets[rg] + (switches[rg] != 0 ? counts[rg] : 0u);
+        job->copy.resize(offsets[nRg]);
+        pd_walk_entry * base = job->copy.data();
+        parallelFor(nRg, [&](size_t rg) {
+            const size_t n = offsets[rg + 1] - offsets[rg];
+            if (n)
+                std::memcpy(base + offsets[rg], tables[rg], n * sizeof(pd_walk_entry));
+            tables[rg] = base + offsets[rg];
+        }, 16);
+    }
     job->counts = std::move(counts);
     job->borders = std::move(borders);
     job->idOffsets = std::move(idOffsets);
     job->tables = std::move(tables);
-    job->equalRun = equalRun;
-    job->switches = switches;
-    job->shape = shape;
-    pending_ = true;
-    pendingContig_ = windows_.current.contig;
-    submitThread_ = std::thread([this, job] {
+    {
+        std::unique_lock<std::mutex> lock(handOverLock_);
+        if (handOverError_)
+        {
+            std::exception_ptr e = handOverError_;
+            handOverError_ = nullptr;
+            std::rethrow_exception(e);
+        }
+        // (at most four segments' worth of copied entries wait for the device)
+        handOverDone_.wait(lock, [this] { return handOverEnqueued_ - handOverFinished_ < 4 || handOverError_; });
+        job->seq = ++handOverEnqueued_;
+        if (job->copy.empty())
+            lastDirectJob_ = job->seq;
+        handOverQueue_.push_back(job);
+        handOverIdle_ = false;
+        if (!handOverThread_.joinable())
+            handOverThread_ = std::thread([this] { handOverLoop(); });
+    }
+    handOverWake_.notify_all();
+}
+
+void CallRun::handOverLoop()
+{
+    for (;;)
+    {
+        std::shared_ptr<HandOverJob> job;
+        {
+            std::unique_lock<std::mutex> lock(handOverLock_);
+            handOverWake_.wait(lock, [this] { return handOverStop_ || !handOverQueue_.empty(); });
+            if (handOverQueue_.empty())
+                return;                             // (stop: nothing left to do)
+            job = handOverQueue_.front();
+            handOverQueue_.pop_front();
+        }
+        bool failed = false;
         try
         {
-            ensureBackend();
-            onEveryContext([&](unsigned r) {
-                const uint32_t g0 = shardRg_[r], g1 = shardRg_[r + 1];
-                pd_walk wk;
-                std::memset(&wk, 0, sizeof(wk));
-                wk.first_window_pos = job->shape.firstPos;
-                wk.step_pos = job->shape.stepPos;
-                wk.has_step = job->shape.hasStep ? 1u : 0u;
-                wk.n_windows = job->shape.nWindows;
-                wk.window_shift = p_.windowShift;
-                wk.n_readgroups = g1 - g0;
-                wk.rg_counts = job->counts.data() + g0;
-                wk.rg_entries = job->tables.data() + g0;
-                wk.end_border = job->borders.data() + g0;
-                wk.id_offset = job->idOffsets.data() + g0;
-                wk.switches = job->switches.data() + g0;
-                wk.equal_run = job->equalRun.data() + g0;
-                if (pd_walk_submit(ctxs_[r], &wk, &tickets_[r]) != 0)
-                    throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
-            });
-            gTrace.mark("segment: on the device");
+            handOver(*job);
         }
         catch (...)
         {
-            submitError_ = std::current_exception();
+            std::lock_guard<std::mutex> guard(handOverLock_);
+            if (!handOverError_)
+                handOverError_ = std::current_exception();
+            failed = true;
         }
-    });
+        bool last;
+        {
+            std::lock_guard<std::mutex> guard(handOverLock_);
+            handOverFinished_ = job->seq;
+            if (failed)
+            {
+                // nothing behind a failed job is handed over: the main thread finds the error at its next call
+                handOverFinished_ = handOverEnqueued_;
+                handOverQueue_.clear();
+                workerPending_ = false;
+                handOverIdle_ = true;
+            }
+            last = handOverQueue_.empty();
+        }
+        if (last && !failed)
+        {
+            // nothing queued behind it: its results are collected and written right away (the end of the run, a change of
+            // mode or a main thread that waits for the output need them; with more jobs queued the next hand-over does it)
+            std::unique_lock<std::mutex> lock(handOverLock_);
+            if (handOverQueue_.empty())
+            {
+                lock.unlock();
+                try
+                {
+                    if (workerPending_)
+                    {
+                        const double t0 = PhaseClock::now();
+                        workerPending_ = false;
+                        collectAndWrite(workerTickets_, workerContig_);
+                        workerCollectSeconds_ += PhaseClock::now() - t0;
+                        gTrace.mark("segment: collected and written");
+                    }
+                }
+                catch (...)
+                {
+                    std::lock_guard<std::mutex> guard(handOverLock_);
+                    if (!handOverError_)
+                        handOverError_ = std::current_exception();
+                }
+                lock.lock();
+                if (handOverQueue_.empty())
+                    handOverIdle_ = true;
+            }
+        }
+        handOverDone_.notify_all();
+    }
 }
 
-void CallRun::joinSubmit()
+// One job on the hand-over thread: the previous segment's results first (records stay in order), then this segment.
+void CallRun::handOver(HandOverJob & job)
 {
-    if (!submitThread_.joinable())
-        return;
-    const double t0 = PhaseClock::now();
-    submitThread_.join();
-    clock_.submit += PhaseClock::now() - t0;
-    if (submitError_)
+    ensureBackend();
+    if (workerPending_)
     {
-        std::exception_ptr e = submitError_;
-        submitError_ = nullptr;
+        const double t0 = PhaseClock::now();
+        workerPending_ = false;
+        collectAndWrite(workerTickets_, workerContig_);
+        workerCollectSeconds_ += PhaseClock::now() - t0;
+        gTrace.mark("segment: previous collected and written");
+    }
+    const double t0 = PhaseClock::now();
+    workerTickets_.assign(ctxs_.size(), 0);
+    onEveryContext([&](unsigned r) {
+        const uint32_t g0 = shardRg_[r], g1 = shardRg_[r + 1];
+        pd_walk wk;
+        std::memset(&wk, 0, sizeof(wk));
+        wk.first_window_pos = job.shape.firstPos;
+        wk.step_pos = job.shape.stepPos;
+        wk.has_step = job.shape.hasStep ? 1u : 0u;
+        wk.n_windows = job.shape.nWindows;
+        wk.window_shift = p_.windowShift;
+        wk.n_readgroups = g1 - g0;
+        wk.rg_counts = job.counts.data() + g0;
+        wk.rg_entries = job.tables.data() + g0;
+        wk.end_border = job.borders.data() + g0;
+        wk.id_offset = job.idOffsets.data() + g0;
+        wk.switches = job.switches.data() + g0;
+        wk.equal_run = job.equalRun.data() + g0;
+        if (pd_walk_submit(ctxs_[r], &wk, &workerTickets_[r]) != 0)
+            throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
+    });
+    workerPending_ = true;
+    workerContig_ = job.contig;
+    workerSubmitSeconds_ += PhaseClock::now() - t0;
+    gTrace.mark("segment: on the device");
+}
+
+void CallRun::waitForHandOver(uint64_t seq)
+{
+    std::unique_lock<std::mutex> lock(handOverLock_);
+    handOverDone_.wait(lock, [this, seq] { return handOverFinished_ >= seq || handOverError_; });
+    if (handOverError_)
+    {
+        std::exception_ptr e = handOverError_;
+        handOverError_ = nullptr;
+        std::rethrow_exception(e);
+    }
+}
+
+void CallRun::drainHandOver()
+{
+    std::unique_lock<std::mutex> lock(handOverLock_);
+    handOverDone_.wait(lock, [this] { return handOverIdle_ || handOverError_; });
+    if (handOverError_)
+    {
+        std::exception_ptr e = handOverError_;
+        handOverError_ = nullptr;
         std::rethrow_exception(e);
     }
 }
@@ -1209,7 +1370,7 @@ void CallRun::joinSubmit()
 void CallRun::leaveDeviceWalk()
 {
     ensureBackend();
-    joinSubmit();
+    drainHandOver();
     ChromProfile & prof = *profile_;
     for (size_t r = 0; r < ctxs_.size(); ++r)
     {
@@ -1371,6 +1532,7 @@ int CallRun::run()
             warmup.join();
             createBackend();
             chooseMergeSite();
+            backendReady_.store(true);
             gTrace.mark("backend created");
         }
         catch (...)
@@ -1394,7 +1556,7 @@ int CallRun::run()
         ensureBackend();            // (only asked from the main thread: the replay of a batch with a far window runs in order)
         if (!deviceWalk_)
             return 0;
-        joinSubmit();
+        drainHandOver();
         uint64_t left = 0;
         for (pd_ctx * c : ctxs_)
         {

@@ -210,6 +210,13 @@ def test_planned_segments_and_the_hand_over_thread_through_the_oracle(built, coh
     assert run_call(ORACLE_CALL, d, str(tmp_path / "b.vcf"), "-n") == golden_text("s2_windowwise.vcf")
     d = cohort_dir("s200", 200, synth.single_deletion)
     assert run_call(ORACLE_CALL, d, str(tmp_path / "c.vcf")) == golden_text("s200_default.vcf")
+    # ... and with every job carrying a copy of its entries, as while the device is still coming up: the main thread does not
+    # wait for hand-overs then, up to four segments are queued
+    monkeypatch.setenv("POPDEL_COPY_HAND_OVER", "1")
+    assert run_call(ORACLE_CALL, d, str(tmp_path / "c2.vcf")) == golden_text("s200_default.vcf")
+    copied = run_call(ORACLE_CALL, d, str(tmp_path / "c3.vcf"), "-b", "50000")         # (twenty segments: the queue fills)
+    monkeypatch.delenv("POPDEL_COPY_HAND_OVER")
+    assert copied == run_call(ORACLE_CALL, d, str(tmp_path / "c4.vcf"), "-b", "50000")
     # several regions: the mode is left and entered again at region changes
     for args in (["-r", "chr20:1000000-1300000", "-r", "chr20:1500000-2000000"], ["-b", "50000"], ["-b", "3000000"]):
         a, b = tmp_path / "w.vcf", tmp_path / "h.vcf"
