@@ -17,6 +17,7 @@
 #include <mutex>
 #include <new>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 #ifdef __linux__
 #include <sys/mman.h>
@@ -71,6 +72,23 @@ public:
         free_[classOf(bytes)].push_back(p);
     }
 
+    // The regions handed out so far (begin, bytes): for a process about to end, which gives their pages back from several
+    // threads at once instead of leaving them to the kernel's single-threaded exit path (discardRegion()).
+    std::vector<std::pair<char *, size_t>> regions()
+    {
+        std::lock_guard<std::mutex> guard(lock_);
+        return regions_;
+    }
+    static void discardRegion(char * begin, size_t bytes)
+    {
+#ifdef __linux__
+        (void)madvise(begin, bytes, MADV_DONTNEED);
+#else
+        (void)begin;
+        (void)bytes;
+#endif
+    }
+
 private:
     HugePool() {}
     void newRegion(size_t atLeast)
@@ -90,12 +108,14 @@ private:
 #endif
         cursor_ = aligned;
         left_ = bytes;
+        regions_.emplace_back(aligned, bytes);
     }
 
     std::mutex lock_;
     std::unordered_map<size_t, std::vector<void *>> free_;
     char * cursor_ = nullptr;
     size_t left_ = 0;
+    std::vector<std::pair<char *, size_t>> regions_;
 };
 
 template <typename T>
