@@ -7,7 +7,7 @@ n = int(sys.argv[1])
 d = "/tmp/e2e_cohort_%d" % n
 if not os.path.exists(os.path.join(d, "profiles.txt")):
     synth.write_cohort(d, n, deletions=synth.single_deletion, workers=16)
-variants = [("default", {}, []), ("exit frees alone", {"POPDEL_NO_PARALLEL_DISCARD": "1"}, [])]
+variants = [("default", {}, []), ("fused decode+replay", {"POPDEL_EXPERIMENT_FUSE": "1"}, [])]
 for rep in range(3):
     for name, extra, prefix in variants:
         env = dict(os.environ, POPDEL_TIMING="2")
