@@ -1,4 +1,5 @@
-"""Wall time of the product binary under a few process environments (GPU box): python tools/e2e_env_probe.py <samples>"""
+"""Wall time of the product binary under its A/B switches (GPU box): python tools/e2e_env_probe.py <samples>
+Per run: wall, time before main / inside / after the exit call, CPU seconds, page faults; phase split of the last round."""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,7 +8,9 @@ n = int(sys.argv[1])
 d = "/tmp/e2e_cohort_%d" % n
 if not os.path.exists(os.path.join(d, "profiles.txt")):
     synth.write_cohort(d, n, deletions=synth.single_deletion, workers=16)
-variants = [("default", {}, []), ("fused decode+replay", {"POPDEL_EXPERIMENT_FUSE": "1"}, [])]
+variants = [("default", {}, []), ("zlib instead of libdeflate", {"POPDEL_ZLIB_INFLATE": "1"}, []), ("no node pin", {"POPDEL_NO_NODE_PIN": "1"}, []),
+            ("every hand-over a copy", {"POPDEL_COPY_HAND_OVER": "1"}, []), ("exit frees alone", {"POPDEL_NO_PARALLEL_DISCARD": "1"}, []),
+            ("16 threads", {"POPDEL_THREADS": "16"}, [])]
 for rep in range(3):
     for name, extra, prefix in variants:
         env = dict(os.environ, POPDEL_TIMING="2")
