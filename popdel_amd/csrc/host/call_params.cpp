@@ -1,4 +1,5 @@
 #include "call_params.h"
+#include "parallel.h"
 
 #include <algorithm>
 #include <cctype>
@@ -494,12 +495,11 @@ bool registerReadGroup(std::map<std::string, unsigned> & readGroups, unsigned & 
     return true;
 }
 
-void loadProfileHeaderInto(CallParams & p, std::vector<unsigned> & sampleRgs, const std::string & filename)
+// (the header has been read and its histograms conditioned by loadAndCalculateParameters(): in parallel over the files; what
+// follows is the order-dependent part -- read-group registration, the checks and their messages -- file by file)
+void loadProfileHeaderInto(CallParams & p, std::vector<unsigned> & sampleRgs, const std::string & filename, ProfileHeader & hdr)
 {
-    ProfileFile file(filename);
-    ProfileHeader hdr;
     const bool dropContigs = !p.contigNames.empty() && p.representativeContigs;
-    file.readHeader(hdr, dropContigs);
     if (p.representativeContigs && !p.indexRegionSizes.empty() && hdr.indexRegionSize != p.indexRegionSizes[0])
         throw ProfileError("Index region sizes are not equal! Terminating.");
     unsigned rg = static_cast<unsigned>(p.readGroups.size());
@@ -527,8 +527,7 @@ void loadProfileHeaderInto(CallParams & p, std::vector<unsigned> & sampleRgs, co
         }
         sampleRgs.push_back(rg - 1);
         added = true;
-        conditionHistogram(hdr.histograms[i], 256, p.smoothing, p.pseudoCountFraction);
-        p.histograms.push_back(hdr.histograms[i]);
+        p.histograms.push_back(std::move(hdr.histograms[i]));
     }
     if (!added)
         throw ProfileError("All read group IDs of sample '" + filename + "' are duplicates of previously observed read group IDs.");
@@ -691,9 +690,32 @@ void loadAndCalculateParameters(CallParams & p)
     const size_t n = p.inputFiles.size();
     p.rgs.assign(n, std::vector<unsigned>());
     unsigned long long totalSize = 0;
+    // headers read and histograms conditioned in parallel (a thousand files: 50 ms one after the other); a file that cannot
+    // be read reports when its turn comes, behind the messages of the files before it
+    struct Loaded
+    {
+        ProfileHeader hdr;
+        std::exception_ptr error;
+    };
+    std::vector<Loaded> loaded(n);
+    parallelFor(n, [&](size_t i) {
+        try
+        {
+            ProfileFile file(p.inputFiles[i]);
+            file.readHeader(loaded[i].hdr, i != 0 && p.representativeContigs);      // (contig table: the first file's, or every file's)
+            for (InsertHistogram & h : loaded[i].hdr.histograms)
+                conditionHistogram(h, 256, p.smoothing, p.pseudoCountFraction);
+        }
+        catch (...)
+        {
+            loaded[i].error = std::current_exception();
+        }
+    }, 4);
     for (size_t i = 0; i < n; ++i)
     {
-        loadProfileHeaderInto(p, p.rgs[i], p.inputFiles[i]);
+        if (loaded[i].error)
+            std::rethrow_exception(loaded[i].error);
+        loadProfileHeaderInto(p, p.rgs[i], p.inputFiles[i], loaded[i].hdr);
         // Size report of the reference: 24-byte string object + values + 4 doubles + 1 int + 5 unsigned,
         // taken from the histogram with the FILE's index.
         const InsertHistogram & h = p.histograms[i < p.histograms.size() ? i : p.histograms.size() - 1];
