@@ -4,7 +4,7 @@ passes = float(sys.argv[2])
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = 0
 for r in rows:
-    name = r["Name"].split("(")[0]
+    name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0]
     if name.startswith("void "):                 # template kernels are printed with their return type
         name = name[5:]
     if not (name.startswith("pd::") or "copyBuffer" in name or "fillBuffer" in name):
