@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 CHR20_WINDOWS = 2148139
 SEG_WINDOWS = 6667            # windows walked per 200-kb segment (windowBuffer 200000 / 30)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
-SCAN_SOURCES = ("popdel_amd/csrc/hip/stage1.hip", "popdel_amd/csrc/hip/sortnet_gen.h")
+SCAN_SOURCES = ("popdel_amd/csrc/hip/stage1.hip", "popdel_amd/csrc/hip/sortnet_gen.h", "popdel_amd/csrc/Makefile")   # (the Makefile: the scan's own compiler flags)
 
 
 def parse_args(argv=None):
