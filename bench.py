@@ -93,6 +93,15 @@ def parse_args(argv=None):
     ap.add_argument("--configs4-segments", type=int, default=6)
     ap.add_argument("--e2e-samples", type=int, default=1000,
                     help="N = 1: profiles of the end-to-end leg (`popdel call` on generated profile files, 1 Mb region); 0: skip")
+    ap.add_argument("--e2e-cohort-samples", type=int, default=4000,
+                    help="N = 1: profiles of the cohort-scale end-to-end leg (`popdel call` on generated profiles x 2 Mb = 10 segments; "
+                         "steady state: start-up and teardown excluded); 0: skip")
+    ap.add_argument("--e2e-cohort-mb", type=int, default=2, help="region of that leg in Mb")
+    ap.add_argument("--e2e-cohort-budget", type=float, default=150.0,
+                    help="wall-time budget of that leg in seconds (cohort writing included): the cohort is cut down to what the "
+                         "writing rate measured on the first profiles allows")
+    ap.add_argument("--inflate-members", type=int, default=100000,
+                    help="N = 1: gzip members of the device-gunzip leg (pd_inflate_members against libdeflate on the host cores); 0: skip")
     ap.add_argument("--sharded-world1", default="1280,6400,0",
                     help="N = 1: samples of the legs that run the sample-sharded code path with ONE rank (library RCCL): its own "
                          "cost per pass next to the unsharded context; 0 = the headline cohort; empty: skip")
@@ -485,15 +494,16 @@ def main():
     if is_dist:
         legs["segment_sharded"] = seg_split
 
-        progress = {"headline_done": False}
+        wd_state = {"headline_done": False}
 
         def give_up():
-            if progress["headline_done"]:
-                # the headline stands; a configs3 / configs4 leg hangs (its collectives no longer match across the ranks)
+            if wd_state["headline_done"]:
+                # the headline stands; a configs3 / configs4 leg hangs (its collectives no longer match across the ranks):
+                # the line is printed with the note, and the process says so with its exit code
                 legs.setdefault("configs_legs_timeout", "a configs3/configs4 leg did not finish within %.0f s" % args.sharded_timeout)
                 if emit(assemble(legs)):
                     sys.stdout.flush()
-                    os._exit(0)
+                    os._exit(4)
                 return
             headline["fallback"] = ("value is the SEGMENT split: the sample-sharded headline did not finish within %.0f s"
                                     % args.sharded_timeout)
@@ -563,7 +573,7 @@ def main():
                                         % (S * world, world, S))
             shard.ctx.unstage(h_sh)
             shard.close()
-            progress["headline_done"] = True
+            wd_state["headline_done"] = True
             dog.cancel()
             dog = watchdog()
 
@@ -962,6 +972,86 @@ def main():
         finally:
             shutil.rmtree(d, ignore_errors=True)
 
+    def e2e_cohort_leg():
+        # `popdel call` at cohort scale, steady state: >= 4,000 generated profiles x 2 Mb (10 segments of 200 kb), the product
+        # binary on all usable cores; what counts is the time per segment once the backend is up (POPDEL_TIMING's
+        # "steady state" line: from the first round that began after the backend was created to the last record written),
+        # the share of it the device works, and the host phases behind it
+        import re
+        import shutil
+        import subprocess
+        import tempfile
+        n = args.e2e_cohort_samples
+        region = (1000000, 1000000 + args.e2e_cohort_mb * 1000000)
+        d = tempfile.mkdtemp(prefix="popdel_e2e_cohort_")
+        try:
+            # what does a profile cost to write here? (then the cohort that fits the budget: writing takes most of it)
+            q0 = time.perf_counter()
+            synth.write_cohort(d, min(n, 4 * usable_cores()), region=region, deletions=synth.single_deletion, workers=usable_cores())
+            per = (time.perf_counter() - q0) / min(n, 4 * usable_cores())
+            afford = int(0.6 * args.e2e_cohort_budget / per)
+            if afford < n:
+                n = max(256, afford // 256 * 256)
+            q0 = time.perf_counter()
+            lst = synth.write_cohort(d, n, region=region, deletions=synth.single_deletion, workers=usable_cores())
+            t_write = time.perf_counter() - q0
+            product = os.path.join(ROOT, "popdel_amd", "lib", "popdel")
+            env = dict(os.environ, POPDEL_TIMING="1")
+            q = time.perf_counter()
+            r = subprocess.run([product, "call", lst, "-o", os.path.join(d, "out.vcf"), "-r", "chr20:%d-%d" % region], env=env,
+                               capture_output=True, text=True, timeout=600)
+            wall = time.perf_counter() - q
+            if r.returncode != 0:
+                raise RuntimeError("popdel exited %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
+            m = re.search(r"steady state: segments (\d+) of (\d+); windows (\d+); samples (\d+); wall ([0-9.e+-]+) s; decode ([0-9.e+-]+) s; "
+                          r"replay ([0-9.e+-]+) s; device kernels ([0-9.e+-]+) s", r.stderr)
+            if not m:
+                raise RuntimeError("no steady-state line in the binary's timing output: %s" % r.stderr[-300:])
+            segs, segs_all, windows, samples = (int(x) for x in m.groups()[:4])
+            t_wall, t_decode, t_replay, t_device = (float(x) for x in m.groups()[4:])
+            cpu = re.search(r"CPU time ([0-9.e+-]+) s user, ([0-9.e+-]+) s system", r.stderr)
+            par = re.search(r"parity: (\d+) reference-shift quotients .* in (\d+) candidate cells, (\d+) window calls", r.stderr)
+            n_records = sum(1 for l in open(os.path.join(d, "out.vcf")) if not l.startswith("#"))
+            return dict(workload="popdel call on %d generated profiles, chr20:%d-%d (%d segments of 200 kb), merged VCF; steady state = "
+                                 "the segments whose round began after the backend was up, start-up and teardown excluded" % (n, region[0], region[1], segs_all),
+                        value=windows * samples / t_wall, unit="window*sample/s", steady_segments=segs, segments=segs_all,
+                        steady_seconds_per_segment=t_wall / segs, steady_wall_seconds=t_wall, steady_windows=windows, samples=samples,
+                        decode_seconds_per_segment=t_decode / segs, replay_seconds_per_segment=t_replay / segs,
+                        device_kernel_seconds_per_segment=t_device / segs, gpu_busy_share=t_device / t_wall,
+                        whole_run_wall_seconds=wall, whole_run_value=n * (region[1] - region[0]) / 30.0 / wall,
+                        cpu_seconds=(float(cpu.group(1)) + float(cpu.group(2))) if cpu else None, usable_cores=usable_cores(),
+                        vcf_records=n_records, near_integer_shifts=int(par.group(1)) if par else None,
+                        candidate_cells=int(par.group(2)) if par else None,
+                        profile_bytes=sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.endswith(".profile")),
+                        cohort_written_in_seconds=t_write)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
+    def inflate_leg():
+        # gunzip of profile blocks on the device (prototype: pd_inflate_members, one lane per gzip member) against the loader's
+        # own host path (libdeflate, all usable cores) on profile-shaped members: compressed bytes over PCIe + kernel vs. host
+        import gzip
+        from concurrent.futures import ThreadPoolExecutor
+        from popdel_amd import inflate
+        distinct = min(args.inflate_members, 4000)
+        blocks = inflate.profile_blocks(distinct, seed=77)
+        with ThreadPoolExecutor(max_workers=usable_cores()) as ex:          # (zlib releases the GIL)
+            blobs = list(ex.map(lambda b: gzip.compress(b, 6, mtime=0), blocks))
+        blobs = (blobs * (-(-args.inflate_members // distinct)))[: args.inflate_members]
+        data, offs, out_offs = inflate.pack_members(blobs)
+        inflate.inflate_gpu(hip, data[: int(offs[64])], offs[:65], out_offs[:65], device=local_rank)
+        out, status, lengths, timing = inflate.inflate_gpu(hip, data, offs, out_offs, device=local_rank, repeat=5)
+        out_c, secs, which, failures = inflate.inflate_cpu(data, offs, out_offs, usable_cores())
+        return dict(what="gzip members of profile index regions (level 6, ~1,000 pairs each): device = one lane per member, host = %s on %d "
+                         "threads; identical output" % (which, usable_cores()),
+                    members=len(blobs), distinct_members=distinct, compressed_bytes=int(offs[-1]), inflated_bytes=int(out_offs[-1]),
+                    all_accepted=bool((status == 0).all()), identical_to_host=bool(failures == 0 and np.array_equal(out, out_c)),
+                    kernel_ms=timing["kernel_ms"], h2d_ms=timing["h2d_ms"], d2h_ms=timing["d2h_ms"],
+                    device_inflated_GBs=int(out_offs[-1]) / timing["kernel_ms"] / 1e6,
+                    host_seconds=secs, host_inflated_GBs=int(out_offs[-1]) / secs / 1e9, host_library=which, host_threads=usable_cores(),
+                    kernel_speedup_over_host=secs * 1e3 / timing["kernel_ms"],
+                    h2d_plus_kernel_speedup_over_host=secs * 1e3 / (timing["kernel_ms"] + timing["h2d_ms"]))
+
     if rank == 0 and not args.no_legs and not is_dist:      # N > 1 runs carry the two splits only
         if args.stream_segments > 0:
             leg("streaming", streaming_leg)
@@ -977,8 +1067,12 @@ def main():
             leg("candidate_dense", dense_leg)
         # (last of the GPU legs: its writer processes and host threads eat into the job's CPU quota, which the streaming
         # leg's packing threads would miss)
+        if args.inflate_members > 0:
+            leg("device_gunzip", inflate_leg)
         if args.e2e_samples > 0:
             leg("e2e", e2e_leg)
+        if args.e2e_cohort_samples > 0:
+            leg("e2e_cohort", e2e_cohort_leg)
     if rank == 0:
         legs["cpu_baseline"] = None
         if not args.no_cpu and not is_dist:                 # timed on rank 0 at N = 1 only

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 10
+#define PD_ABI_VERSION 11
 
 /* One read group after start-up conditioning.
  * Replaces: `Histogram` (reference insert_histogram_popdel.h:19-43) after processHistogram()
@@ -176,6 +176,12 @@ typedef struct pd_timing
                                     in-process group: host clock around its barriers and peer copies); part of stage2_ms */
     double   lik_first_ms;       /* the data-likelihood kernels' launch ahead of the EM loop (last stage-2 batch): all cells of */
     uint64_t lik_first_units;    /* the batch x all samples of the context = this many (cell, sample) units                   */
+    /* Parity instrumentation (ABI 11). A reference shift is int(sum(p * dev) / sum(p)) (reference
+     * genotype_deletion_popdel_call.h:447-450); where the quotient sits within 1e-9 of an integer the truncation is decided by
+     * the last bit of weights that the reference forms in x87 extended precision and this backend in FP64 -- the one place
+     * where the two may take different decisions (Numerics). Counted per ticket over all cells, EM iterations and
+     * read groups of the COHORT (all contexts of a sharded cohort report the same number); the results are not changed. */
+    uint64_t n_near_integer_shifts;
 } pd_timing;
 int pd_last_timing(pd_ctx *ctx, pd_timing *out);
 
@@ -337,6 +343,30 @@ int pd_stage1_last(pd_ctx *ctx, pd_stage1_view *out);
  * Replaces nothing in the reference's interface; the reference evaluates logl()/log10l() of Histogram::values per read
  * pair (genotype_deletion_popdel_call.h:205-215, 290-300). */
 int pd_log_table_view(pd_ctx *ctx, uint32_t rg, double *value, double *log_value, double *log10_value, uint32_t *n);
+
+/* ---- gunzip of profile blocks on the device (prototype, ABI 11) ----------------------------------------------------------
+ * A profile holds one gzip member per 10,000-bp index region (the writer ends a member per region, reference
+ * workflow_popdel.h:201-241; the reader jumps to one through the index, insert_histogram_popdel.h:531-562, and inflates it
+ * with zlib, seqan/stream/iostream_zip_impl.h:336-349). The members of a segment are independent: pd_inflate_members()
+ * inflates `n_members` of them on GPU `device`, one lane each. data[member_offsets[m] .. member_offsets[m + 1]) is member m
+ * (header, deflate stream, trailer); its output goes to out[out_offsets[m] .. out_offsets[m + 1]) -- the caller sizes that from
+ * the ISIZE word that ends a member. status[m]: 0, or why the member was refused (1 not gzip/deflate, 2 truncated, 3 bad
+ * block header, 4 bad code set, 5 distance before the start, 6 more output than room, 7 CRC-32 mismatch, 8 ISIZE mismatch --
+ * the cases zlib's inflate refuses); out_lengths[m]: bytes produced. All pointers are host memory. The kernel is launched
+ * `repeat` times (>= 1) and `timing` reports its mean duration next to the two copies. Returns 0, or non-zero with
+ * pd_inflate_last_error() saying why. Not wired into `popdel call` (DESIGN.md says what the number decided). */
+typedef struct pd_inflate_timing
+{
+    double   h2d_ms;        /* compressed bytes, page-locked host memory -> HBM */
+    double   kernel_ms;     /* one launch */
+    double   d2h_ms;        /* inflated bytes back (a loader that parses on the device would not pay this) */
+    uint64_t in_bytes, out_bytes;
+    uint32_t workgroups;    /* of one wave each */
+} pd_inflate_timing;
+int pd_inflate_members(int device, const uint8_t *data, const uint64_t *member_offsets, uint32_t n_members, uint8_t *out,
+                       const uint64_t *out_offsets, uint32_t *status, uint64_t *out_lengths, uint32_t repeat,
+                       pd_inflate_timing *timing);
+const char *pd_inflate_last_error(void);
 
 /* Text of the last error on this context (or of the last failed pd_ctx_create if ctx == NULL). */
 const char *pd_last_error(const pd_ctx *ctx);

@@ -1083,6 +1083,11 @@ int pd_device_warmup(int) { return 0; }
 // loop (pdh::WalkReference, the host reference of walk.hip) -- a TEST path for the hand-over protocol of the call driver
 // (planned segments, the hand-over thread, leaving and re-entering the mode) on machines without a GPU and under the
 // sanitizers; the checker of the closed form itself is the walked loop (POPDEL_WALK_CHECK, tests/test_walk_closed_form.py).
+// (device-only entry points of ABI 11: the oracle declines)
+int pd_inflate_members(int, const uint8_t *, const uint64_t *, uint32_t, uint8_t *, const uint64_t *, uint32_t *, uint64_t *, uint32_t,
+                       pd_inflate_timing *) { return 1; }
+const char * pd_inflate_last_error(void) { return "the oracle backend has no device"; }
+
 int pd_walk_supported(const pd_ctx *) { return getenv("POPDEL_ORACLE_WALK") ? 1 : 0; }
 int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
 {

@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     "pd_abi_version", "pd_shard_samples", "pd_ctx_set_shard", "pd_ctx_set_shard_rccl", "pd_rccl_unique_id",
     "pd_local_group_create", "pd_local_group_destroy", "pd_ctx_set_shard_local", "pd_log_table_view",
     "pd_ctx_keep_results_on_device", "pd_calls_merge", "pd_calls_fetch_columns", "pd_merged_free",
-    "pd_walk_submit", "pd_walk_supported", "pd_walk_active", "pd_device_warmup",
+    "pd_walk_submit", "pd_walk_supported", "pd_walk_active", "pd_device_warmup", "pd_inflate_members", "pd_inflate_last_error",
 )
 RCCL_ID_BYTES = 128
 
@@ -71,7 +71,7 @@ class PdTiming(C.Structure):
                 ("n_active_pairs", C.c_uint64), ("n_pair_chunks", C.c_uint64), ("n_candidate_cells", C.c_uint64),
                 ("max_life", C.c_uint32), ("n_all_gathers", C.c_uint32), ("all_gather_bytes", C.c_uint64),
                 ("n_repeated_batches", C.c_uint64), ("exchange_ms", C.c_double),
-                ("lik_first_ms", C.c_double), ("lik_first_units", C.c_uint64)]
+                ("lik_first_ms", C.c_double), ("lik_first_units", C.c_uint64), ("n_near_integer_shifts", C.c_uint64)]
 
 
 RESERVE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)

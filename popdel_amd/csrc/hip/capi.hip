@@ -27,7 +27,8 @@
 namespace pd {
 
 void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
-                  uint8_t * tileTodo, unsigned * todoList, unsigned * bigList, unsigned maxBlockChunks, hipStream_t stream);
+                  uint8_t * tileTodo, unsigned * todoList, unsigned * bigList, unsigned maxBlockChunks, const ScanRoom & room,
+                  hipStream_t stream);
 void launchStage1Fallback(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
                           uint8_t * tileTodo, unsigned * todoList, const unsigned * bigList, hipStream_t stream);
 void launchPackFlagged(const int32_t * q3, const uint8_t * flags, const int * flaggedWindows, unsigned W, unsigned nLocal,
@@ -40,6 +41,7 @@ void launchListCells(const int * flagged, const int * candLen, const int * candC
 void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,
                    hipStream_t st);
 void launchCopyBytes(const void * src, void * dst, size_t n, hipStream_t st);
+void launchSpin(unsigned long long ticks, hipStream_t st);
 void runStage2Init(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, hipStream_t st);
 void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers & b, const uint8_t * flags, Exchange & x,
                    bool anyGenericTile, unsigned * pinnedWord, hipEvent_t likBegin, hipEvent_t likEnd, hipStream_t st);
@@ -247,6 +249,7 @@ struct Run
 {
     uint64_t handle = 0;
     hipEvent_t s1Begin = nullptr, s1End = nullptr;      // around the scan kernel (timing)
+    hipEvent_t scanDone = nullptr;                      // behind the scan's last kernel when it runs on the scan stream
     int set = 0;                                        // which of the two stage-1 output sets the scan writes
     bool launched = false;          // false: accepted while the previous ticket was still open, scan not enqueued yet
 };
@@ -290,6 +293,17 @@ struct pd_ctx
     std::string error;
     hipStream_t stream = nullptr;       // all kernels
     hipStream_t copyStream = nullptr;   // segment uploads and the result D2H, so that the next segment's scan can run underneath it
+    // The scan of the WAITING ticket beside the open ticket's stage 2 (round 4): a stream of its own, lower priority, and a
+    // launch that leaves room on every CU (pd::ScanRoom) -- stage 2 of a sparse segment is ~45 short dependent launches
+    // that use a fraction of the chip, the scan is one VALU-bound launch. POPDEL_HIP_SCAN_OVERLAP: "0" = the scan on the
+    // kernel stream behind the open ticket's last kernel (rounds 1-3), "p<N>" persistent grid of N workgroups per CU,
+    // "l<N>" plain grid capped at N per CU through LDS, "s" plain grid, stream only.
+    hipStream_t scanStream = nullptr;
+    pd::ScanRoom scanRoom{pd::ScanRoom::kFull, 7, 256, nullptr};
+    DevBuf<unsigned> dScanCounter;      // two words, one per stage-1 output set
+    // POPDEL_HIP_XCH_DELAY_US: every exchange of a sharded context is followed by a one-wave kernel that waits this long on
+    // the stream (wall-clock ticks): the wire time an exchange over xGMI would add, for measurements with one rank
+    unsigned long long xchDelayTicks = 0;
     hipEvent_t resultsPacked = nullptr;
     hipEvent_t cellsFetched = nullptr;
     hipEvent_t likBegin = nullptr, likEnd = nullptr;    // around the data-likelihood launch ahead of the EM loop (pd_timing)
@@ -428,6 +442,8 @@ struct pd_ctx
             (void)hipEventDestroy(likBegin);
         if (likEnd)
             (void)hipEventDestroy(likEnd);
+        if (scanStream)
+            (void)hipStreamDestroy(scanStream);
         if (copyStream)
             (void)hipStreamDestroy(copyStream);
         if (stream)
@@ -617,6 +633,8 @@ struct CtxExchange : pd::Exchange
                 throw HipError{"the host's all_gather() callback failed"};
         }
         // (world == 1 without a carrier: nothing to move)
+        if (c.xchDelayTicks)
+            pd::launchSpin(c.xchDelayTicks, st);
         PD_HIP(hipEventRecord(nextEvent(), st));
     }
 };
@@ -1351,7 +1369,32 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
         c->nRg = n_readgroups;
         c->nSamples = n_samples;
         c->sampleRg.assign(sample_rg_offsets, sample_rg_offsets + n_samples + 1);
-        PD_HIP(hipStreamCreate(&c->stream));
+        {
+            const char * e = getenv("POPDEL_HIP_SCAN_OVERLAP");
+            std::string how = e ? e : "0";
+            int lowest = 0, highest = 0;
+            PD_HIP(hipDeviceGetStreamPriorityRange(&lowest, &highest));
+            if (how != "0" && !how.empty())
+            {
+                PD_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamDefault, highest));
+                PD_HIP(hipStreamCreateWithPriority(&c->scanStream, hipStreamDefault, lowest));
+                int nCu = 0;
+                PD_HIP(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, device));
+                c->scanRoom.nCu = nCu > 0 ? (unsigned)nCu : 256u;
+                const unsigned n = how.size() > 1 ? (unsigned)atoi(how.c_str() + 1) : 7u;
+                c->scanRoom.wgPerCu = std::max(1u, std::min(7u, n ? n : 7u));
+                c->scanRoom.mode = how[0] == 'p' ? pd::ScanRoom::kPersistent : (how[0] == 'l' ? pd::ScanRoom::kLdsCap : pd::ScanRoom::kFull);
+                c->dScanCounter.alloc(2);
+            }
+            else
+                PD_HIP(hipStreamCreate(&c->stream));
+        }
+        if (const char * e = getenv("POPDEL_HIP_XCH_DELAY_US"))
+        {
+            int khz = 0;
+            PD_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device));
+            c->xchDelayTicks = static_cast<unsigned long long>(std::max(0.0, atof(e)) * (khz > 0 ? khz : 100000) / 1000.0);
+        }
         PD_HIP(hipStreamCreate(&c->copyStream));
         PD_HIP(hipEventCreateWithFlags(&c->resultsPacked, hipEventDisableTiming));
         PD_HIP(hipEventCreateWithFlags(&c->cellsFetched, hipEventDisableTiming));
@@ -1640,6 +1683,8 @@ void pd_ctx_destroy(pd_ctx * ctx)
             (void)hipEventDestroy(r.second.s1Begin);
         if (r.second.s1End)
             (void)hipEventDestroy(r.second.s1End);
+        if (r.second.scanDone)
+            (void)hipEventDestroy(r.second.scanDone);
     }
     delete ctx;
 }
@@ -1755,7 +1800,7 @@ static void launchScan(pd_ctx * c, Run & run)
         throw HipError{"the segment of a ticket was unstaged"};
     StagedSegment & s = *sit->second;
     Stage1Out & o = c->s1[run.set];
-    hipStream_t st = c->stream;
+    hipStream_t st = c->scanStream ? c->scanStream : c->stream;
     if (s.waitBuilt)
     {
         PD_HIP(hipStreamWaitEvent(st, s.built, 0));
@@ -1773,9 +1818,15 @@ static void launchScan(pd_ctx * c, Run & run)
     zero.add(o.winFlag.p, s.nWindows * sizeof(int));
     zero.add(o.todoList.p, sizeof(unsigned));
     zero.add(o.bigList.p, sizeof(unsigned));
+    pd::ScanRoom room = c->scanRoom;
+    if (room.mode == pd::ScanRoom::kPersistent)
+    {
+        room.counter = c->dScanCounter.p + run.set;
+        zero.add(room.counter, sizeof(unsigned));
+    }
     pd::launchZero(zero, st);
     PD_HIP(hipEventRecord(run.s1Begin, st));
-    pd::launchStage1(viewOf(s), c->cohort, o.q3.p, o.flags.p, o.winFlag.p, o.tileTodo.p, o.todoList.p, o.bigList.p, s.maxBlockChunks, st);
+    pd::launchStage1(viewOf(s), c->cohort, o.q3.p, o.flags.p, o.winFlag.p, o.tileTodo.p, o.todoList.p, o.bigList.p, s.maxBlockChunks, room, st);
     PD_HIP(hipGetLastError());
     PD_HIP(hipEventRecord(run.s1End, st));
     pd::launchStage1Fallback(viewOf(s), c->cohort, o.q3.p, o.flags.p, o.winFlag.p, o.tileTodo.p, o.todoList.p, o.bigList.p, st);
@@ -1792,6 +1843,12 @@ static void launchScan(pd_ctx * c, Run & run)
         PD_HIP(hipMemcpy(&nBig, o.bigList.p, sizeof(unsigned), hipMemcpyDeviceToHost));
         fprintf(stderr, "[popdel_hip] stage 1: %u 512-window blocks through the 128-candidate kernel, %zu of %zu 256-window tiles through the "
                         "32-bit fallback kernel (K=%u, densest block %u chunks)\n", nBig, nTodo, tiles, s.maxLife, s.maxBlockChunks);
+    }
+    if (c->scanStream)
+    {
+        if (!run.scanDone)
+            PD_HIP(hipEventCreateWithFlags(&run.scanDone, hipEventDisableTiming));
+        PD_HIP(hipEventRecord(run.scanDone, st));
     }
     o.windows = s.nWindows;
     run.launched = true;
@@ -1819,7 +1876,9 @@ int pd_segment_run(pd_ctx * c, uint64_t handle, uint64_t * ticket)
         run.set = static_cast<int>(*ticket & 1u);          // tickets alternate between the two output sets
         auto & slot = c->runs[*ticket];
         slot = run;
-        if (c->runs.size() == 1)
+        // (with a scan stream the scan starts at once, beside the open ticket's stage 2; its output set was last read by
+        // the ticket before the open one, which has been collected)
+        if (c->runs.size() == 1 || c->scanStream)
             launchScan(c, slot);
     }
     catch (const HipError & e)
@@ -1843,6 +1902,8 @@ int pd_segment_unstage(pd_ctx * c, uint64_t handle)
         return 1;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->scanStream)
+        (void)hipStreamSynchronize(c->scanStream);
     auto it = c->staged.find(handle);
     if (it == c->staged.end())
         return fail(c, "pd_segment_unstage: unknown segment handle");
@@ -1897,6 +1958,8 @@ void prepareWalkState(pd_ctx & c)
     for (uint32_t m : c.maxLoad)
         most = std::max(most, std::min<uint32_t>(m, 4096u));
     c.walkCapActive = std::max<uint32_t>(256u, 2u * most + 64u);
+    if (const char * e = getenv("POPDEL_HIP_WALK_CAP"))         // (tests: start small so that the lists have to grow)
+        c.walkCapActive = c.walkCapPending = std::max(1, atoi(e));
     for (int k = 0; k < 2; ++k)
     {
         pd_ctx::WalkBuffers & b = c.walkState[k];
@@ -1914,10 +1977,47 @@ void prepareWalkState(pd_ctx & c)
         PD_HIP(hipMemsetAsync(b.nActive.p, 0, c.nRg * sizeof(uint32_t), c.copyStream));
         PD_HIP(hipMemsetAsync(b.nPending.p, 0, c.nRg * sizeof(uint32_t), c.copyStream));
     }
-    c.dWalkTotals.alloc(3);
-    c.hWalkTotals.resize(3);
+    c.dWalkTotals.alloc(5);             // instances, pairs left active, problems, longest active / pending list needed
+    c.hWalkTotals.resize(5);
     c.walkCur = 0;
     c.walkReady = true;
+}
+
+// A read group needs longer lists than the state holds (a pile-up under an unlimited maxLoad, -A; the sliver of a slot no
+// window reached): both sets get the new row length, the current set's rows move over (the other set is written afresh by
+// the emit pass). Runs on the copy stream behind the count pass.
+void growWalkState(pd_ctx & c, uint32_t needActive, uint32_t needPending)
+{
+    const uint32_t capA = needActive > c.walkCapActive ? needActive + needActive / 2 + 64u : c.walkCapActive;
+    const uint32_t capP = needPending > c.walkCapPending ? needPending + needPending / 2 + 64u : c.walkCapPending;
+    hipStream_t cs = c.copyStream;
+    auto regrow = [&](auto & buf, uint32_t oldCap, uint32_t newCap, bool keep) {
+        if (newCap == oldCap)
+            return;
+        std::remove_reference_t<decltype(buf)> bigger;
+        bigger.alloc(static_cast<size_t>(c.nRg) * newCap);
+        if (keep)
+            PD_HIP(hipMemcpy2DAsync(bigger.p, static_cast<size_t>(newCap) * 4, buf.p, static_cast<size_t>(oldCap) * 4,
+                                    static_cast<size_t>(oldCap) * 4, c.nRg, hipMemcpyDeviceToDevice, cs));
+        PD_HIP(hipStreamSynchronize(cs));          // (the old rows are freed below)
+        std::swap(buf.p, bigger.p);
+        std::swap(buf.n, bigger.n);
+    };
+    for (int k = 0; k < 2; ++k)
+    {
+        pd_ctx::WalkBuffers & b = c.walkState[k];
+        const bool keep = k == c.walkCur;
+        regrow(b.aStart, c.walkCapActive, capA, keep);
+        regrow(b.aDev, c.walkCapActive, capA, keep);
+        regrow(b.aId, c.walkCapActive, capA, keep);
+        regrow(b.aLast, c.walkCapActive, capA, keep);
+        regrow(b.pStart, c.walkCapPending, capP, keep);
+        regrow(b.pDev, c.walkCapPending, capP, keep);
+        regrow(b.pId, c.walkCapPending, capP, keep);
+        regrow(b.pLast, c.walkCapPending, capP, keep);
+    }
+    c.walkCapActive = capA;
+    c.walkCapPending = capP;
 }
 
 }  // namespace
@@ -2005,15 +2105,23 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
         in.switches = c->dWalkFlags.p;
         in.equalRun = c->dWalkFlags.p + nRg;
         pd::WalkParams wp{wk->first_window_pos, wk->step_pos, wk->has_step ? 1u : 0u, W, wk->window_shift};
-        const pd::WalkState cur = walkStateOf(*c, c->walkCur), nxt = walkStateOf(*c, c->walkCur ^ 1);
         c->dWalkCount.ensure(nRg);
         c->dRgOffsets.ensure(nRg + 1);
-        PD_HIP(hipMemsetAsync(c->dWalkTotals.p, 0, 3 * sizeof(unsigned long long), cs));
-        pd::launchWalkCount(in, cur, wp, c->dRg.p, nRg, c->dWalkCount.p, c->dRgOffsets.p, reinterpret_cast<uint64_t *>(c->dWalkTotals.p), cs);
+        PD_HIP(hipMemsetAsync(c->dWalkTotals.p, 0, 5 * sizeof(unsigned long long), cs));
+        pd::launchWalkCount(in, walkStateOf(*c, c->walkCur), wp, c->dRg.p, nRg, c->dWalkCount.p, c->dRgOffsets.p,
+                            reinterpret_cast<uint64_t *>(c->dWalkTotals.p), reinterpret_cast<unsigned *>(c->dWalkTotals.p + 3), cs);
         PD_HIP(hipGetLastError());
-        PD_HIP(hipMemcpyAsync(c->hWalkTotals.data(), c->dWalkTotals.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+        PD_HIP(hipMemcpyAsync(c->hWalkTotals.data(), c->dWalkTotals.p, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
         PD_HIP(hipStreamSynchronize(cs));
         const uint64_t nInst = c->hWalkTotals[0];
+        {
+            // the count pass evaluates the predicates of the emit pass: the lists are made long enough before it runs
+            // (need[0], need[1]: two 32-bit words at the start of totals[3])
+            const unsigned * need = reinterpret_cast<const unsigned *>(c->hWalkTotals.data() + 3);
+            if (need[0] > c->walkCapActive || need[1] > c->walkCapPending)
+                growWalkState(*c, need[0], need[1]);
+        }
+        const pd::WalkState cur = walkStateOf(*c, c->walkCur), nxt = walkStateOf(*c, c->walkCur ^ 1);
         for (int k = 0; k < 4; ++k)
             c->dIn32[k].ensure(std::max<uint64_t>(1, nInst));
         pd::launchWalkEmit(in, cur, wp, c->dRg.p, nRg, c->dRgOffsets.p, reinterpret_cast<int32_t *>(c->dIn32[0].p), c->dIn32[1].p, c->dIn32[2].p,
@@ -2172,6 +2280,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
     {
         (void)hipEventDestroy(run.s1Begin);
         (void)hipEventDestroy(run.s1End);
+        if (run.scanDone)
+            (void)hipEventDestroy(run.scanDone);
         return fail(c, "pd_segment_collect: segment was unstaged before collect");
     }
     StagedSegment & s = *sit->second;
@@ -2184,6 +2294,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         PD_HIP(hipSetDevice(c->device));
         if (!run.launched)              // the collect that should have started it failed
             launchScan(c, run);
+        if (run.scanDone)
+            PD_HIP(hipStreamWaitEvent(c->stream, run.scanDone, 0));
         Stage1Out & o = c->s1[run.set];
         const uint32_t W = s.nWindows, S = c->nSamples;
         const pd::SegmentView view = viewOf(s);
@@ -2665,6 +2777,12 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             PD_HIP(hipEventElapsedTime(&t, c->likBegin, c->likEnd));
             c->timing.lik_first_ms = t;
         }
+        {
+            uint64_t nearInteger = 0;
+            for (const pd::CellState & cs : cells)
+                nearInteger += cs.nearIntegerShifts;
+            c->timing.n_near_integer_shifts = nearInteger;
+        }
         c->timing.all_gather_bytes = c->allGatherBytes;
         c->timing.n_repeated_batches = c->nRepeatedBatches;
 
@@ -2740,6 +2858,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         (void)hipEventDestroy(s2End);
     (void)hipEventDestroy(run.s1Begin);
     (void)hipEventDestroy(run.s1End);
+    if (run.scanDone)
+        (void)hipEventDestroy(run.scanDone);
     c->lastSet = run.set;
     if (s.ownedBySubmit)
     {

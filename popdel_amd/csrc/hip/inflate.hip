@@ -1,0 +1,157 @@
+// Gunzip on the device (round 4, prototype of SURVEY 8(f) row f1's first stage): the gzip members of the profiles -- one per
+// 10,000-bp index region and sample, 3-4 KB each, 200,000 of them per 200-kb segment of a 10,000-sample cohort -- are
+// independent, so one LANE inflates one member (inflate_core.h) and a segment is 3,125 waves of work. Host counterpart:
+// profile_io.cpp's MemberSource (libdeflate / zlib, one member per call); reference: the zlib stream behind
+// seqan/stream/iostream_zip_impl.h:336-349, fed from the index jump of insert_histogram_popdel.h:531-562.
+//
+// pd_inflate_members() takes host buffers, copies the compressed bytes up (page-locked staging, so that the copy runs at
+// PCIe rate), inflates, copies the result back and reports the three times: what `popdel call` would pay per segment if
+// its decode phase handed compressed members to the device instead of inflating them on the host threads.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "inflate_core.h"
+#include "popdel_hip.h"
+
+namespace {
+
+constexpr unsigned kLanes = 64;
+
+// Workgroups of ONE wave: the 64 decoders' tables (366 16-bit words each) take 47 KB of LDS, three workgroups fit a CU.
+// Workgroups stride over the batches of 64 members; the code lengths of a dynamic block header (only touched while a
+// header is parsed) live in a global workspace, one 20-KB slab per workgroup.
+__global__ __launch_bounds__(kLanes) void inflateMembersKernel(const uint8_t * __restrict__ data, const uint64_t * __restrict__ inOff,
+                                                               uint32_t n, uint8_t * __restrict__ out,
+                                                               const uint64_t * __restrict__ outOff, uint32_t * __restrict__ status,
+                                                               uint64_t * __restrict__ outLen, uint8_t * __restrict__ lengthsWs,
+                                                               unsigned nBatches)
+{
+    __shared__ uint16_t tabs[pdinf::kTabWords * kLanes];
+    __shared__ uint32_t crcTab[256];
+    for (unsigned i = threadIdx.x; i < 256u; i += kLanes)
+        crcTab[i] = pdinf::crcTableEntry(i);
+    __syncthreads();
+    pdinf::StridedTables t;
+    t.base = tabs + threadIdx.x;
+    t.lengths = lengthsWs + (size_t)blockIdx.x * (pdinf::kCodeLengths * kLanes) + threadIdx.x;
+    for (unsigned batch = blockIdx.x; batch < nBatches; batch += gridDim.x)
+    {
+        const unsigned m = batch * kLanes + threadIdx.x;
+        if (m >= n)
+            continue;
+        uint64_t got = 0, used = 0;
+        const uint64_t a = inOff[m], b = outOff[m];
+        status[m] = pdinf::inflateGzipMember(data + a, inOff[m + 1] - a, out + b, outOff[m + 1] - b, &got, &used, t, crcTab);
+        outLen[m] = got;
+    }
+}
+
+struct Fail
+{
+    std::string what;
+};
+#define PD_INF_HIP(expr)                                                                                     \
+    do                                                                                                        \
+    {                                                                                                         \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            throw Fail{std::string(#expr) + ": " + hipGetErrorString(e_)};                                    \
+    } while (0)
+
+std::string g_inflateError;
+
+}  // namespace
+
+extern "C" const char * pd_inflate_last_error(void) { return g_inflateError.c_str(); }
+
+extern "C" int pd_inflate_members(int device, const uint8_t * data, const uint64_t * member_offsets, uint32_t n_members, uint8_t * out,
+                                  const uint64_t * out_offsets, uint32_t * status, uint64_t * out_lengths, uint32_t repeat,
+                                  pd_inflate_timing * timing)
+{
+    if (!data || !member_offsets || !out || !out_offsets || !status || !out_lengths || n_members == 0)
+    {
+        g_inflateError = "pd_inflate_members: invalid argument";
+        return 1;
+    }
+    void *dData = nullptr, *dOut = nullptr, *dInOff = nullptr, *dOutOff = nullptr, *dStatus = nullptr, *dLen = nullptr, *dWs = nullptr;
+    void *hIn = nullptr, *hOut = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t st = nullptr;
+    int rc = 0;
+    try
+    {
+        PD_INF_HIP(hipSetDevice(device));
+        const uint64_t inBytes = member_offsets[n_members], outBytes = out_offsets[n_members];
+        int nCu = 0;
+        PD_INF_HIP(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, device));
+        const unsigned nBatches = (n_members + kLanes - 1) / kLanes;
+        const unsigned groups = std::min<unsigned>(nBatches, 3u * (unsigned)std::max(1, nCu));
+        PD_INF_HIP(hipStreamCreate(&st));
+        for (hipEvent_t & e : ev)
+            PD_INF_HIP(hipEventCreate(&e));
+        PD_INF_HIP(hipMalloc(&dData, inBytes + 8));
+        PD_INF_HIP(hipMalloc(&dOut, std::max<uint64_t>(outBytes, 1)));
+        PD_INF_HIP(hipMalloc(&dInOff, (n_members + 1) * sizeof(uint64_t)));
+        PD_INF_HIP(hipMalloc(&dOutOff, (n_members + 1) * sizeof(uint64_t)));
+        PD_INF_HIP(hipMalloc(&dStatus, n_members * sizeof(uint32_t)));
+        PD_INF_HIP(hipMalloc(&dLen, n_members * sizeof(uint64_t)));
+        PD_INF_HIP(hipMalloc(&dWs, static_cast<size_t>(groups) * pdinf::kCodeLengths * kLanes));
+        PD_INF_HIP(hipHostMalloc(&hIn, inBytes + 8, hipHostMallocDefault));
+        PD_INF_HIP(hipHostMalloc(&hOut, std::max<uint64_t>(outBytes, 1), hipHostMallocDefault));
+        std::memcpy(hIn, data, inBytes);
+        PD_INF_HIP(hipMemcpyAsync(dInOff, member_offsets, (n_members + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        PD_INF_HIP(hipMemcpyAsync(dOutOff, out_offsets, (n_members + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        PD_INF_HIP(hipStreamSynchronize(st));
+        PD_INF_HIP(hipEventRecord(ev[0], st));
+        PD_INF_HIP(hipMemcpyAsync(dData, hIn, inBytes, hipMemcpyHostToDevice, st));
+        PD_INF_HIP(hipEventRecord(ev[1], st));
+        const uint32_t times = std::max<uint32_t>(1, repeat);
+        for (uint32_t k = 0; k < times; ++k)
+            hipLaunchKernelGGL(inflateMembersKernel, dim3(groups), dim3(kLanes), 0, st, static_cast<const uint8_t *>(dData),
+                               static_cast<const uint64_t *>(dInOff), n_members, static_cast<uint8_t *>(dOut),
+                               static_cast<const uint64_t *>(dOutOff), static_cast<uint32_t *>(dStatus), static_cast<uint64_t *>(dLen),
+                               static_cast<uint8_t *>(dWs), nBatches);
+        PD_INF_HIP(hipGetLastError());
+        PD_INF_HIP(hipEventRecord(ev[2], st));
+        PD_INF_HIP(hipMemcpyAsync(hOut, dOut, outBytes, hipMemcpyDeviceToHost, st));
+        PD_INF_HIP(hipEventRecord(ev[3], st));
+        PD_INF_HIP(hipMemcpyAsync(status, dStatus, n_members * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PD_INF_HIP(hipMemcpyAsync(out_lengths, dLen, n_members * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        PD_INF_HIP(hipStreamSynchronize(st));
+        std::memcpy(out, hOut, outBytes);
+        if (timing)
+        {
+            float a = 0, b = 0, c = 0;
+            PD_INF_HIP(hipEventElapsedTime(&a, ev[0], ev[1]));
+            PD_INF_HIP(hipEventElapsedTime(&b, ev[1], ev[2]));
+            PD_INF_HIP(hipEventElapsedTime(&c, ev[2], ev[3]));
+            timing->h2d_ms = a;
+            timing->kernel_ms = b / times;
+            timing->d2h_ms = c;
+            timing->in_bytes = inBytes;
+            timing->out_bytes = outBytes;
+            timing->workgroups = groups;
+        }
+    }
+    catch (const Fail & f)
+    {
+        g_inflateError = "pd_inflate_members: " + f.what;
+        rc = 2;
+    }
+    for (void * p : {dData, dOut, dInOff, dOutOff, dStatus, dLen, dWs})
+        if (p)
+            (void)hipFree(p);
+    for (void * p : {hIn, hOut})
+        if (p)
+            (void)hipHostFree(p);
+    for (hipEvent_t e : ev)
+        if (e)
+            (void)hipEventDestroy(e);
+    if (st)
+        (void)hipStreamDestroy(st);
+    return rc;
+}

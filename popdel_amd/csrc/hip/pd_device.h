@@ -99,6 +99,21 @@ struct CohortView
     int              minThreshold; // min over read groups of minInitDelLen
 };
 
+// How the scan's launch shares the chip with the kernels of the context's other stream (stage 2 of the previous ticket).
+struct ScanRoom
+{
+    enum Mode : unsigned
+    {
+        kFull = 0,           // one workgroup per (sample, 512-window block): fills every wave slot
+        kLdsCap = 1,         // the same launch with unused dynamic LDS so that at most wgPerCu workgroups fit a CU
+        kPersistent = 2      // wgPerCu x nCu workgroups that draw their blocks from `counter` (zeroed by the caller)
+    };
+    unsigned   mode;
+    unsigned   wgPerCu;
+    unsigned   nCu;
+    unsigned * counter;
+};
+
 // Input of the clustering kernel: Q3 values and flags of the flagged windows of ALL samples of the cohort, one chunk
 // per context (all-gathered when the cohort is sharded): int32 q3[nFlagged][sper], then uint8 flags[nFlagged][sper].
 struct ClusterInput
@@ -194,6 +209,7 @@ struct CellState
     uint64_t suppBase;
     unsigned suppStart, suppEnd;
     unsigned lowCovSamples;
+    unsigned nearIntegerShifts;   // reference-shift quotients within 1e-9 of an integer, all samples, all EM iterations (reported only)
     // distributed percentile selection over the support pools (0: starts, 1: ends): radix prefix and remaining rank
     unsigned selPrefix[2];
     unsigned selK[2];

@@ -40,9 +40,10 @@ struct WalkState
     uint32_t   capActive, capPending;
 };
 
-// instances per read group -> instCount, their exclusive scan -> instOffsets[0 .. nRg], sum -> total[0]
+// instances per read group -> instCount, their exclusive scan -> instOffsets[0 .. nRg], sum -> total[0]; need[0] / need[1]
+// (cleared by the caller): the longest active / pending list the state after the segment will hold
 void launchWalkCount(const WalkInput & in, const WalkState & st, const WalkParams & w, const RgConst * rgConst, unsigned nRg,
-                     uint32_t * instCount, uint64_t * instOffsets, uint64_t * total, hipStream_t stream);
+                     uint32_t * instCount, uint64_t * instOffsets, uint64_t * total, unsigned * need, hipStream_t stream);
 // the instances (wide arrays of pd::InstanceArrays) and the state after the segment (nxt; must not alias st);
 // problems: bit 0 = an active list overflowed, bit 1 = a pending list; activeTotal += pairs left active
 void launchWalkEmit(const WalkInput & in, const WalkState & st, const WalkParams & w, const RgConst * rgConst, unsigned nRg,

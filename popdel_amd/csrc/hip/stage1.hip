@@ -581,6 +581,47 @@ __global__ __launch_bounds__(kStage1Block) void stage1KernelDeep(SegmentView seg
     scanKernelBody<kLdsPairs>(seg, co, q3, flags, winFlag, tileTodo, todoList, bigList, tilesPerSample);
 }
 
+// The same scan as a PERSISTENT grid (round 4): wgPerCu x CUs workgroups that draw their (sample, block) from a counter.
+// A launch of 140,000 workgroups holds every wave slot of the chip for its whole 1.1 ms; this one leaves the slots, VGPRs
+// and LDS of 7 - wgPerCu workgroups per CU free for as long as it runs, which is where the short stage-2 kernels of the
+// PREVIOUS segment run (on the context's other stream) instead of waiting for the scan to drain. Same registers, same
+// LDS, same results; blocks are drawn in the order of the plain launch (x fastest).
+__global__ __launch_bounds__(kStage1Block) __attribute__((amdgpu_waves_per_eu(7, 7))) void stage1KernelPersistent(
+    SegmentView seg, CohortView co, int32_t * __restrict__ q3, uint8_t * __restrict__ flags, int * __restrict__ winFlag,
+    uint8_t * __restrict__ tileTodo, unsigned * __restrict__ todoList, unsigned * __restrict__ bigList, unsigned tilesPerSample,
+    unsigned blocksPerSample, unsigned nBlocks, unsigned * __restrict__ counter)
+{
+    __shared__ __attribute__((aligned(16))) PairPk ldsPairs[kPackedLdsSmall + 128];
+    __shared__ uint32_t ldsWs[kPackedWsLen];
+    __shared__ unsigned short ldsN[kPackedWindows];
+    __shared__ unsigned short unitOrder[kStage1Block];
+    __shared__ unsigned classCount[6][kStage1Block / 64];
+    __shared__ unsigned drawn;
+    for (;;)
+    {
+        __syncthreads();                                           // LDS reuse across blocks (and of `drawn`)
+        if (threadIdx.x == 0)
+            drawn = atomicAdd(counter, 1u);
+        __syncthreads();
+        const unsigned id = drawn;
+        if (id >= nBlocks)
+            return;
+        const unsigned s = id / blocksPerSample, bx = id - s * blocksPerSample;
+        const int st = scanBlock<kPackedLdsSmall, false>(seg, co, q3, flags, winFlag, s, bx, blocksPerSample, ldsPairs, ldsWs, ldsN,
+                                                         unitOrder, classCount);
+        if (st == 2)
+        {
+            if (threadIdx.x == 0)
+            {
+                deferToFallback(s, bx, seg.nWindows, tilesPerSample, tileTodo, todoList, false);
+                bigList[1 + atomicAdd(&bigList[0], 1u)] = id;
+            }
+        }
+        else
+            deferToFallback(s, bx, seg.nWindows, tilesPerSample, tileTodo, todoList, st == 1);
+    }
+}
+
 // Second pass over the blocks with 65..128 candidates somewhere (deeper coverage): same scan with networks of up to
 // 128 inputs and the largest LDS stage; 128 value registers per lane, hence its own kernel (the register budget of a
 // kernel is that of its largest path). Workgroups stride over the list.
@@ -700,13 +741,32 @@ __global__ __launch_bounds__(kStage1Block) void stage1FallbackKernel(SegmentView
     }
 }
 
+// room: how the scan shares the chip with the other stream's kernels (ScanRoom, pd_device.h); ordinary coverage only --
+// the deeper LDS stages are bounded by LDS already and launch as before.
 void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
-                  uint8_t * tileTodo, unsigned * todoList, unsigned * bigList, unsigned maxBlockChunks, hipStream_t stream)
+                  uint8_t * tileTodo, unsigned * todoList, unsigned * bigList, unsigned maxBlockChunks, const ScanRoom & room,
+                  hipStream_t stream)
 {
     const unsigned tilesPerSample = (seg.nWindows + kStage1Block - 1) / kStage1Block;
     dim3 grid((seg.nWindows + kPackedWindows - 1) / kPackedWindows, co.nSamples);
     // maxBlockChunks: chunks of the densest 512-window block of (99 % of) the streams, host-computed at staging time
-    if (maxBlockChunks <= (unsigned)kPackedLdsSmall)
+    if (maxBlockChunks <= (unsigned)kPackedLdsSmall && room.mode == ScanRoom::kPersistent)
+    {
+        const unsigned nBlocks = grid.x * grid.y;
+        const unsigned groups = min(nBlocks, room.wgPerCu * room.nCu);
+        hipLaunchKernelGGL(stage1KernelPersistent, dim3(groups), dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag,
+                           tileTodo, todoList, bigList, tilesPerSample, grid.x, nBlocks, room.counter);
+    }
+    else if (maxBlockChunks <= (unsigned)kPackedLdsSmall && room.mode == ScanRoom::kLdsCap)
+    {
+        // unused dynamic LDS on top of the kernel's own so that at most wgPerCu workgroups fit the CU's 160 KB
+        constexpr unsigned kOwn = (kPackedLdsSmall + 128) * 8 + kPackedWsLen * 4 + kPackedWindows * 2 + kStage1Block * 2 + 6 * (kStage1Block / 64) * 4;
+        const unsigned want = 163840u / (room.wgPerCu + 1u) + 1536u;
+        const unsigned pad = want > kOwn ? want - kOwn : 0u;
+        hipLaunchKernelGGL(stage1Kernel, grid, dim3(kStage1Block), pad, stream, seg, co, q3, flags, winFlag, tileTodo,
+                           todoList, bigList, tilesPerSample);
+    }
+    else if (maxBlockChunks <= (unsigned)kPackedLdsSmall)
         hipLaunchKernelGGL(stage1Kernel, grid, dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, tileTodo,
                            todoList, bigList, tilesPerSample);
     else if (maxBlockChunks <= (unsigned)kPackedLdsMedium)

@@ -1447,16 +1447,22 @@ __device__ __forceinline__ void loopHead(CellState & cs, const Stage2Buffers & b
 // the matching knob): a quotient within 1e-9 of an integer is first moved onto it. Single-pair and equal-weight read
 // groups put the exact quotient on an integer, and which side of it the rounded one lands on is decided by the last bit
 // of the weights (Numerics); with the switch on both sides HIP and oracle must agree everywhere.
-__device__ __forceinline__ int referenceShiftOf(double wSumRef, double sumRef, bool rgNan, double stddev)
+// `nearInteger` counts the quotients within 1e-9 of an integer -- the truncations whose outcome hangs off the last bit of
+// the weights, i.e. where this FP64 evaluation and the reference's x87 one may disagree; the count is reported
+// (pd_timing::n_near_integer_shifts), it changes nothing.
+__device__ __forceinline__ int referenceShiftOf(double wSumRef, double sumRef, bool rgNan, double stddev, double & nearInteger)
 {
     double q = wSumRef / sumRef;
-#ifdef PD_TEST_SNAP_SHIFTS
     {
         const double r = rint(q);
         if (fabs(q - r) <= 1e-9 * fmax(1.0, fabs(r)))
+        {
+            nearInteger += 1.0;
+#ifdef PD_TEST_SNAP_SHIFTS
             q = r;
-    }
 #endif
+        }
+    }
     int newShift;
     if (rgNan || !(q > -2147483649.0 && q < 2147483648.0))
         newShift = (int)0x80000000;          // what x86 yields for NaN / out-of-range conversions
@@ -1514,7 +1520,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, 
         }
     }
     __syncthreads();
-    double sumDelAcc = 0, wSumDelAcc = 0;
+    double sumDelAcc = 0, wSumDelAcc = 0, nearAcc = 0;
     for (unsigned k = 0; k < (unsigned)(kSamplesPerBlock / kHalvesPerBlock); ++k)
     {
         const unsigned slot = half + k * kHalvesPerBlock;
@@ -1550,18 +1556,20 @@ __global__ __launch_bounds__(kSampleTile) void updateLenKernel(SegmentView seg, 
             wSumRef = halfSum(wSumRef);
             sumDelAcc += sumDel;
             wSumDelAcc += wSumDel;
-            const int newShift = referenceShiftOf(wSumRef, sumRef, rgNan, rc.stddev);
+            const int newShift = referenceShiftOf(wSumRef, sumRef, rgNan, rc.stddev, nearAcc);
             if (hl == 0)
                 *shiftSlot = newShift;
         }
     }
     const double t0 = blockSumHalves(sumDelAcc, red);
     const double t1 = blockSumHalves(wSumDelAcc, red);
+    const double t3 = blockSumHalves(nearAcc, red);           // (every lane of a half counted the same events)
     if (threadIdx.x == 0)
     {
         double * p = PD_OWN_TILE_SLOT(b, cellIdx);
         p[0] = t0;
         p[1] = t1;
+        p[3] = t3;          // free during the EM loop (the likelihood-ratio sums use it afterwards); cellLenFinishKernel adds it up
     }
 }
 
@@ -1665,18 +1673,21 @@ __global__ __launch_bounds__(kSampleTile) void updateLenDenseKernel(CohortView c
             wSumRef += use ? probRef * dv : 0.0;
         }
     }
+    double nearInteger = 0;
     if (valid && !highCov)
     {
-        const int newShift = referenceShiftOf(wSumRef, sumRef, rgNan, l.stddev);
+        const int newShift = referenceShiftOf(wSumRef, sumRef, rgNan, l.stddev, nearInteger);
         *shiftSlot = newShift;
     }
     const double t0 = blockSum(sumDel, red);
     const double t1 = blockSum(wSumDel, red);
+    const double t3 = blockSum(nearInteger, red);
     if (threadIdx.x == 0)
     {
         double * p = PD_OWN_TILE_SLOT(b, cellIdx);
         p[0] = t0;
         p[1] = t1;
+        p[3] = t3;          // (see updateLenKernel)
     }
 }
 
@@ -1715,8 +1726,14 @@ __global__ __launch_bounds__(64) void cellLenFinishKernel(Stage2Buffers b)
         return;
     double sumDel, wSumDel, unused;
     waveTileSums(b, c, sumDel, wSumDel, unused);
+    // reference shifts of this iteration whose quotient sat within 1e-9 of an integer (counts: the order does not matter)
+    double nearInteger = 0;
+    for (unsigned t = threadIdx.x; t < b.nTiles; t += 64u)
+        nearInteger += tileSlot(b, c, t)[3];
+    nearInteger = waveSum(nearInteger);
     if (threadIdx.x != 0)
         return;
+    cs.nearIntegerShifts += (unsigned)nearInteger;
     unsigned len;
     if (sumDel == 0)
         len = 0;
@@ -2539,6 +2556,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenMultiKernel(CohortView c
     const bool rgNan = shCell[2] != 0.0;
     const unsigned rgLo = b.mt.rgLo[mtI], rgHi = b.mt.rgHi[mtI];
     double sumDelAcc = 0, wSumDelAcc = 0;                  // over the read groups this lane handles, in read-group order
+    double nearAcc = 0;
     for (unsigned base = rgLo; base < rgHi; base += kSampleTile)
     {
         const unsigned rg = base + threadIdx.x;
@@ -2603,7 +2621,7 @@ __global__ __launch_bounds__(kSampleTile) void updateLenMultiKernel(CohortView c
         }
         if (valid && !highCov)
         {
-            const int newShift = referenceShiftOf(wSumRef, sumRef, rgNan, l.stddev);
+            const int newShift = referenceShiftOf(wSumRef, sumRef, rgNan, l.stddev, nearAcc);
             *shiftSlot = newShift;
             sumDelAcc += sumDel;
             wSumDelAcc += wSumDel;
@@ -2611,11 +2629,13 @@ __global__ __launch_bounds__(kSampleTile) void updateLenMultiKernel(CohortView c
     }
     const double t0 = blockSum(sumDelAcc, red);
     const double t1 = blockSum(wSumDelAcc, red);
+    const double t3 = blockSum(nearAcc, red);
     if (threadIdx.x == 0)
     {
         double * p = tileSlot(b, cellIdx, b.rank * b.tilesPerRank + tileIdx);
         p[0] = t0;
         p[1] = t1;
+        p[3] = t3;          // (see updateLenKernel)
     }
 }
 
@@ -3254,6 +3274,20 @@ void launchCopyBytes(const void * src, void * dst, size_t n, hipStream_t st)
     if (n)
         hipLaunchKernelGGL(copyBytesKernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, st,
                            static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), n);
+}
+
+// One wave that does nothing for `ticks` of the constant-rate wall clock: stands in for the wire time of an exchange when
+// the sample-sharded path is measured with one rank (POPDEL_HIP_XCH_DELAY_US; bench.py's latency model).
+__global__ void spinKernel(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(8);
+}
+
+void launchSpin(unsigned long long ticks, hipStream_t st)
+{
+    hipLaunchKernelGGL(spinKernel, dim3(1), dim3(64), 0, st, ticks);
 }
 
 void launchCluster(const ClusterInput & in, int uniformThreshold, int * scratch, unsigned rowLen, int * candLen, int * candCount,

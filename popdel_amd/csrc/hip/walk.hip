@@ -217,6 +217,9 @@ __device__ void walkReadGroup(const WalkInput & in, const WalkState & st, const 
         if (Count)
         {
             instCount[rg] = nInst;
+            // what the lists of the state AFTER the segment must hold (the host grows them before the emit pass)
+            atomicMax(problems, nA);
+            atomicMax(problems + 1, nP);
         }
         else
         {
@@ -233,12 +236,12 @@ __device__ void walkReadGroup(const WalkInput & in, const WalkState & st, const 
 }
 
 __global__ __launch_bounds__(256) void walkCountKernel(WalkInput in, WalkState st, WalkParams w, const RgConst * rgConst,
-                                                       uint32_t * instCount)
+                                                       uint32_t * instCount, unsigned * need)
 {
     __shared__ unsigned shWave[4], shAcc[1];
     WalkState none = st;
     walkReadGroup<true>(in, st, w, rgConst, blockIdx.x, shWave, shAcc, nullptr, instCount, nullptr, nullptr, nullptr, nullptr, none,
-                        nullptr, nullptr);
+                        need, nullptr);
 }
 
 __global__ __launch_bounds__(256) void walkEmitKernel(WalkInput in, WalkState st, WalkParams w, const RgConst * rgConst,
@@ -285,9 +288,9 @@ __global__ __launch_bounds__(256) void walkScanKernel(const uint32_t * __restric
 }  // namespace
 
 void launchWalkCount(const WalkInput & in, const WalkState & st, const WalkParams & w, const RgConst * rgConst, unsigned nRg,
-                     uint32_t * instCount, uint64_t * instOffsets, uint64_t * total, hipStream_t stream)
+                     uint32_t * instCount, uint64_t * instOffsets, uint64_t * total, unsigned * need, hipStream_t stream)
 {
-    hipLaunchKernelGGL(walkCountKernel, dim3(nRg), dim3(256), 0, stream, in, st, w, rgConst, instCount);
+    hipLaunchKernelGGL(walkCountKernel, dim3(nRg), dim3(256), 0, stream, in, st, w, rgConst, instCount, need);
     hipLaunchKernelGGL(walkScanKernel, dim3(1), dim3(256), 0, stream, instCount, nRg, instOffsets, total);
 }
 

@@ -190,6 +190,33 @@ public:
                       << "; window walk " << clock_.walk << " s; flatten " << clock_.flatten << " s; stage+submit " << clock_.submit
                       << " s; collect+merge+write " << clock_.collect << " s; on the hand-over thread: hand-over " << workerSubmitSeconds_
                       << " s, collect+merge+write " << workerCollectSeconds_ << " s" << std::endl;
+        if (getenv("POPDEL_TIMING") && !timingPrinted_)
+        {
+            std::lock_guard<std::mutex> guard(deviceNotesLock_);
+            std::cerr << "[popdel timing] parity: " << nearIntegerShifts_ << " reference-shift quotients within 1e-9 of an integer (their truncation "
+                         "may differ from the x87 reference's) in " << candidateCells_ << " candidate cells, " << windowCalls_ << " window calls" << std::endl;
+            // steady state: the rounds that began after the backend was up, to the end of the loop (last results written)
+            size_t k0 = 0;
+            while (k0 < rounds_.size() && rounds_[k0].start < backendReadyAt_)
+                ++k0;
+            if (k0 < rounds_.size() && loopEnd_ > rounds_[k0].start)
+            {
+                double decode = 0, replay = 0, device = 0;
+                uint64_t windows = 0;
+                for (size_t k = k0; k < rounds_.size(); ++k)
+                {
+                    decode += rounds_[k].decode;
+                    replay += rounds_[k].replay;
+                    windows += rounds_[k].windows;
+                    if (k < deviceMs_.size())
+                        device += deviceMs_[k] / 1e3;
+                }
+                const double wall = loopEnd_ - rounds_[k0].start;
+                std::cerr << "[popdel timing] steady state: segments " << rounds_.size() - k0 << " of " << rounds_.size() << "; windows " << windows
+                          << "; samples " << p_.sampleNum << "; wall " << wall << " s; decode " << decode << " s; replay " << replay
+                          << " s; device kernels " << device << " s" << std::endl;
+            }
+        }
         if (!timingPrinted_)
             gTrace.print();
         timingPrinted_ = true;
@@ -309,6 +336,19 @@ private:
     void drainHandOver();                       // ... all of them, and the last one's results written
     void collectAndWrite(const std::vector<uint64_t> & tickets, const std::string & contig);
     bool timingPrinted_ = false;
+    // POPDEL_TIMING: the rounds of the segment loop one by one (start, windows of the segment, decode and replay seconds) and
+    // what the backend reports per collected segment -- for the steady-state figures of a long run (start-up excluded) and
+    // for the count of reference-shift truncations that sit on the knife edge (pd_timing::n_near_integer_shifts)
+    struct RoundNote
+    {
+        double start = 0, decode = 0, replay = 0;
+        unsigned windows = 0;
+    };
+    std::vector<RoundNote> rounds_;
+    std::mutex deviceNotesLock_;            // (collects run on the hand-over thread)
+    std::vector<double> deviceMs_;          // kernel time per collected segment (context 0)
+    uint64_t nearIntegerShifts_ = 0, candidateCells_ = 0, windowCalls_ = 0;
+    double backendReadyAt_ = 0, loopEnd_ = 0;
     bool pending_ = false;
     std::string pendingContig_;
 };
@@ -950,6 +990,17 @@ void CallRun::collectAndWrite(const std::vector<uint64_t> & tickets, const std::
         if (pd_segment_collect(ctxs_[r], tickets[r], &parts[r]) != 0)
             throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
     });
+    {
+        pd_timing t;
+        if (pd_last_timing(ctxs_[0], &t) == 0)
+        {
+            std::lock_guard<std::mutex> guard(deviceNotesLock_);
+            deviceMs_.push_back(t.stage1_ms + t.stage2_ms);
+            nearIntegerShifts_ += t.n_near_integer_shifts;
+            candidateCells_ += t.n_candidate_cells;
+            windowCalls_ += parts[0]->n_calls;
+        }
+    }
     // every context returns the calls of the whole cohort with the columns of its own samples
     pd_calls * pc = parts[0];
     for (pd_calls * q : parts)
@@ -1044,6 +1095,8 @@ void CallRun::processSegment()
             std::vector<uint8_t> equalRun, switches;
             const WalkShape shape = prof.planSegment(p_.windowShift, equalRun, switches);
             windows_.current.pos += shape.nWindows * p_.windowShift;
+            if (!rounds_.empty())
+                rounds_.back().windows = shape.nWindows;
             clock_.walk += PhaseClock::now() - t0;
             gTrace.mark("segment: planned");
             t0 = PhaseClock::now();
@@ -1092,6 +1145,8 @@ void CallRun::processSegment()
     double t0 = PhaseClock::now();
     const unsigned nWindows = prof.walkSegment(p_.windowShift);
     windows_.current.pos += nWindows * p_.windowShift;
+    if (!rounds_.empty())
+        rounds_.back().windows = nWindows;
     clock_.walk += PhaseClock::now() - t0;
     std::vector<std::vector<PairInstance>> & log = prof.endSegmentLog();
     prof.noteSegmentWalked();
@@ -1218,6 +1273,12 @@ void CallRun::submitPlannedSegment(const WalkShape & shape, const std::vector<ui
         }
         // (at most four segments' worth of copied entries wait for the device)
         handOverDone_.wait(lock, [this] { return handOverEnqueued_ - handOverFinished_ < 4 || handOverError_; });
+        if (handOverError_)                 // (the worker failed while this thread waited: nothing more is queued behind it)
+        {
+            std::exception_ptr e = handOverError_;
+            handOverError_ = nullptr;
+            std::rethrow_exception(e);
+        }
         job->seq = ++handOverEnqueued_;
         if (job->copy.empty())
             lastDirectJob_ = job->seq;
@@ -1241,6 +1302,16 @@ void CallRun::handOverLoop()
                 return;                             // (stop: nothing left to do)
             job = handOverQueue_.front();
             handOverQueue_.pop_front();
+            if (handOverError_)
+            {
+                // an earlier job failed and the main thread has not picked the error up yet: the device's walk state missed a
+                // segment, nothing behind it may run (or be written)
+                handOverFinished_ = std::max(handOverFinished_, job->seq);
+                if (handOverQueue_.empty())
+                    handOverIdle_ = true;
+                handOverDone_.notify_all();
+                continue;
+            }
         }
         bool failed = false;
         try
@@ -1532,6 +1603,7 @@ int CallRun::run()
             warmup.join();
             createBackend();
             chooseMergeSite();
+            backendReadyAt_ = PhaseClock::now();
             backendReady_.store(true);
             gTrace.mark("backend created");
         }
@@ -1573,8 +1645,11 @@ int CallRun::run()
         if (!goNextRegion())
         {
             flushPending();
+            loopEnd_ = PhaseClock::now();
             return 0;
         }
+        rounds_.emplace_back();
+        rounds_.back().start = PhaseClock::now();
         // (large batches: 16 threads replayed 1000 samples in 0.57 s with batches of 128 and in 0.22 s with 512)
         const unsigned batch = std::max(512u, 8u * hostThreads());
         for (unsigned b0 = 0; b0 < p_.sampleNum; b0 += batch)
@@ -1631,6 +1706,7 @@ int CallRun::run()
                 decodeSample(i, nextCandidate_[i].contig, st.slots[st.writeSlot].right, st.numWindows, decoded[k]);
             });
             clock_.decode += PhaseClock::now() - t0;
+            rounds_.back().decode += PhaseClock::now() - t0;
             gTrace.mark("batch: decoded");
             t0 = PhaseClock::now();
             // (3) insert the records and switch slots: per sample independent unless a stream contains a window beyond the
@@ -1663,6 +1739,7 @@ int CallRun::run()
             for (size_t k = 0; k < readers.size(); ++k)
                 processSegmentCode(readers[k], codes[k]);
             clock_.replay += PhaseClock::now() - t0;
+            rounds_.back().replay += PhaseClock::now() - t0;
             gTrace.mark("batch: replayed");
         }
         processSegment();
@@ -1670,7 +1747,10 @@ int CallRun::run()
         if (allTrue(finishedRois_))
         {
             if (!finalizeRoi())
+            {
+                loopEnd_ = PhaseClock::now();
                 return 0;
+            }
             firstWindowOnNextRoi(windows_.current);
             profile_->currentPos = windows_.current.pos;
             profile_->resetTo(profile_->currentPos);
@@ -1685,6 +1765,7 @@ int CallRun::run()
         }
     }
     flushPending();
+    loopEnd_ = PhaseClock::now();
     printStatus("Output written to '" + p_.outfile + "'.");
     return 0;
 }

@@ -4,10 +4,16 @@
 #include <chrono>
 #include <cstring>
 #include <random>
+#include <thread>
 #include <vector>
+
+#include <dlfcn.h>
+#include <zlib.h>
 
 #include "call_params.h"
 #include "histogram.h"
+#include "inflate_core.h"
+#include "parallel.h"
 #include "profile_io.h"
 #include "window_call.h"
 
@@ -219,4 +225,100 @@ int pdh_selftest_inflate(const char * path, unsigned long long offset, unsigned 
     }
 }
 
+
+// The device's gunzip (popdel_amd/csrc/hip/inflate_core.h, the source inflate.hip compiles for the GPU) run on the CPU, one
+// member after the other: tests compare it with zlib bit for bit, including damaged and truncated members (-m "not gpu").
+int pdh_inflate_members_core(const uint8_t * data, const uint64_t * offsets, uint32_t n, uint8_t * out, const uint64_t * outOffsets,
+                             uint32_t * status, uint64_t * outLengths)
+{
+    if (!data || !offsets || !out || !outOffsets || !status || !outLengths)
+        return 1;
+    uint32_t crcTable[256];
+    for (unsigned i = 0; i < 256u; ++i)
+        crcTable[i] = pdinf::crcTableEntry(i);
+    pdinf::FlatTables tab;
+    for (uint32_t m = 0; m < n; ++m)
+    {
+        uint64_t got = 0, used = 0;
+        status[m] = pdinf::inflateGzipMember(data + offsets[m], offsets[m + 1] - offsets[m], out + outOffsets[m],
+                                             outOffsets[m + 1] - outOffsets[m], &got, &used, tab, crcTable);
+        outLengths[m] = got;
+    }
+    return 0;
+}
+
+// The host's own way through the same members, as the loader takes it (profile_io.cpp: libdeflate where the system has it,
+// else zlib; one member per call), on `threads` threads: the CPU figure beside pd_inflate_members(). which: 0 libdeflate
+// (falls back to zlib if it is not there; *used says which ran: 0 / 1), 1 zlib. Returns seconds through *seconds.
+int pdh_inflate_members_cpu(const uint8_t * data, const uint64_t * offsets, uint32_t n, uint8_t * out, const uint64_t * outOffsets,
+                            int which, unsigned threads, double * seconds, int * used, uint32_t * failures)
+{
+    if (!data || !offsets || !out || !outOffsets || !seconds)
+        return 1;
+    struct Lib
+    {
+        void * (*alloc)() = nullptr;
+        void (*release)(void *) = nullptr;
+        int (*gunzip)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;
+    } lib;
+    if (which == 0)
+        if (void * h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL))
+        {
+            lib.alloc = reinterpret_cast<void * (*)()>(dlsym(h, "libdeflate_alloc_decompressor"));
+            lib.release = reinterpret_cast<void (*)(void *)>(dlsym(h, "libdeflate_free_decompressor"));
+            lib.gunzip = reinterpret_cast<int (*)(void *, const void *, size_t, void *, size_t, size_t *, size_t *)>(
+                dlsym(h, "libdeflate_gzip_decompress_ex"));
+        }
+    const bool fast = lib.alloc && lib.release && lib.gunzip;
+    if (used)
+        *used = fast ? 0 : 1;
+    threads = std::max(1u, threads);
+    std::vector<uint32_t> bad(threads, 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            void * dec = fast ? lib.alloc() : nullptr;
+            const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(n) * t / threads), hi = static_cast<uint32_t>(static_cast<uint64_t>(n) * (t + 1) / threads);
+            for (uint32_t m = lo; m < hi; ++m)
+            {
+                const size_t inLen = offsets[m + 1] - offsets[m], room = outOffsets[m + 1] - outOffsets[m];
+                if (fast)
+                {
+                    size_t usedIn = 0, got = 0;
+                    if (lib.gunzip(dec, data + offsets[m], inLen, out + outOffsets[m], room, &usedIn, &got) != 0)
+                        ++bad[t];
+                }
+                else
+                {
+                    z_stream zs;
+                    std::memset(&zs, 0, sizeof(zs));
+                    if (inflateInit2(&zs, 15 + 16) != Z_OK)
+                    {
+                        ++bad[t];
+                        continue;
+                    }
+                    zs.next_in = const_cast<Bytef *>(data + offsets[m]);
+                    zs.avail_in = static_cast<uInt>(inLen);
+                    zs.next_out = out + outOffsets[m];
+                    zs.avail_out = static_cast<uInt>(room);
+                    if (inflate(&zs, Z_FINISH) != Z_STREAM_END)
+                        ++bad[t];
+                    inflateEnd(&zs);
+                }
+            }
+            if (dec)
+                lib.release(dec);
+        });
+    for (std::thread & th : pool)
+        th.join();
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (failures)
+    {
+        *failures = 0;
+        for (uint32_t b : bad)
+            *failures += b;
+    }
+    return 0;
+}
 }  // extern "C"

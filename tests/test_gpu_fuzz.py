@@ -63,11 +63,6 @@ def random_case(seed):
     return seg, rgs, sample_offsets, opts
 
 
-# What the unsnapped cohorts of this session showed, summed up by test_session_budgets() at the end of the file.
-SESSION = dict(cohorts=0, calls=0, columns=0, differing_columns=0, touched_calls=0, diverged_calls=0, diverged_seeds=[],
-               worst_lr=0.0, worst_af=0.0, lr_outliers=0, lr_outlier_seeds=[], worst_lr_outlier=0.0)
-
-
 def assert_same_up_to_knife_edges(gpu, cpu, allowed_diverged=0):
     """Everything the hand-made cases demand, with one documented exception (Numerics): a reference shift is
     int(sum(p * dev) / sum(p)), zeroed if it exceeds the library's standard deviation. For a read group with a single
@@ -81,9 +76,12 @@ def assert_same_up_to_knife_edges(gpu, cpu, allowed_diverged=0):
     LR/AF beyond 1e-6; everything else must be exact. A flip inside an EM that oscillates up to the iteration cap can send
     it down another path altogether (seed 155: two shifts on -24 with sigma 23.1, lengths wandering between 5041 and 5105
     for 15 iterations); such a call counts as diverged.
-    Per cohort only the invariants are asserted here; HOW MANY calls and columns may be touched is a budget over the whole
-    session (test_session_budgets). Returns (touched calls, differing columns, diverged calls, worst |dLR| relative to
-    max(1, |LR|) and worst |dAF| over the touched calls)."""
+    Per cohort the invariants are asserted here together with a loose FLOOR on the magnitudes (every call: LR within 1e-3,
+    AF within 1e-4; at most max(2, n / 10) calls touched; a touched call differs in at most a third of its columns) -- so
+    that a regression which moves LR by per cents without flipping a genotype fails in whatever subset of the sweep is run
+    (-k, --lf, xdist); the tight figures -- HOW MANY calls and columns may be touched over the sweep -- are budgets over the
+    whole session (test_session_budgets, conftest.py). Returns (touched calls, differing columns, diverged calls, worst
+    |dLR| relative to max(1, |LR|) and worst |dAF| over the touched calls)."""
     (gc, gq, gf), (oc, oq, of) = gpu, cpu
     assert np.array_equal(gf, of)
     assert np.array_equal(gq, oq)
@@ -106,6 +104,11 @@ def assert_same_up_to_knife_edges(gpu, cpu, allowed_diverged=0):
     lr_ok = np.isclose(gc["likelihood_ratio"], oc["likelihood_ratio"], rtol=1e-6, atol=1e-6)
     af_ok = np.isclose(gc["frequency"], oc["frequency"], rtol=0, atol=1e-6)
     touched = (cols.any(axis=1) | ~lr_ok | ~af_ok | (gc["iterations"] != oc["iterations"])) & keep
+    # the floor (per cohort, whatever else ran in this session)
+    assert np.allclose(gc["likelihood_ratio"][keep], oc["likelihood_ratio"][keep], rtol=1e-3, atol=1e-3), "LR beyond 1e-3"
+    assert np.allclose(gc["frequency"][keep], oc["frequency"][keep], rtol=0, atol=1e-4), "AF beyond 1e-4"
+    assert touched.sum() <= max(2, n // 10), ("touched calls", int(touched.sum()), n)
+    assert (cols.sum(axis=1) <= max(3, cols.shape[1] // 3)).all(), "a touched call differs in more than a third of its columns"
     worst_lr = worst_af = 0.0
     if touched.any():
         # never a changed implied genotype, never a zero phred value that moves
@@ -118,6 +121,17 @@ def assert_same_up_to_knife_edges(gpu, cpu, allowed_diverged=0):
     else:
         LAST_TOUCHED_LR[:] = []
     return int(touched.sum()), int(cols.sum()), int(diverged.sum()), worst_lr, worst_af
+
+
+def note_cohort(seed, figures):
+    """One file per unsnapped cohort under the session's note directory (conftest.FUZZ_NOTES): whoever runs the cohorts --
+    one process, xdist workers, a rerun -- the budgets are checked over the files (conftest.fuzz_session_figures)."""
+    import json
+    import os
+    from conftest import FUZZ_NOTES
+    os.makedirs(FUZZ_NOTES, exist_ok=True)
+    with open(os.path.join(FUZZ_NOTES, "seed_%d.json" % seed), "w") as fh:
+        json.dump(figures, fh)
 
 
 # (side channel of assert_same_up_to_knife_edges: the relative LR differences of the touched calls of the cohort it looked at last)
@@ -137,22 +151,8 @@ def test_random_cohort(built, seed):
     gpu, cpu = both(seg, rgs, offs, **opts)
     calls, cols, div, worst_lr, worst_af = assert_same_up_to_knife_edges(gpu, cpu, allowed_diverged=1 if seed == 155 else 0)
     n = gpu[0]["n_calls"]
-    SESSION["cohorts"] += 1
-    SESSION["calls"] += n
-    SESSION["columns"] += n * gpu[0]["pl"].shape[1] if n else 0
-    SESSION["differing_columns"] += cols
-    SESSION["touched_calls"] += calls
-    SESSION["diverged_calls"] += div
-    if div:
-        SESSION["diverged_seeds"].append(seed)
-    for d in LAST_TOUCHED_LR:
-        if d > LR_BUDGET:
-            SESSION["lr_outliers"] += 1
-            SESSION["lr_outlier_seeds"].append(seed)
-            SESSION["worst_lr_outlier"] = max(SESSION["worst_lr_outlier"], d)
-        else:
-            SESSION["worst_lr"] = max(SESSION["worst_lr"], d)
-    SESSION["worst_af"] = max(SESSION["worst_af"], worst_af)
+    note_cohort(seed, dict(calls=n, columns=(n * gpu[0]["pl"].shape[1] if n else 0), differing_columns=cols, touched_calls=calls,
+                           diverged_calls=div, touched_lr=list(LAST_TOUCHED_LR), worst_af=worst_af))
     if calls or div:
         print("seed %d: %d of %d calls touched by a knife-edge shift, %d sample column(s) differ, %d diverged; worst dLR %.3g, "
               "dAF %.3g" % (seed, calls, n, cols, div, worst_lr, worst_af))
@@ -188,38 +188,17 @@ def test_the_sweep_is_not_vacuous(built):
     assert total > 150
 
 
-# Budgets of the knife-edge class over the unsnapped cohorts of this session, independent of any single cohort's size.
-# Observed in round 3 (profiles/r03_fuzz_sweeps.md; tools/debug_fuzz_sweep.py prints the same figures for wider sweeps): on the
-# 66 cohorts of seeds 0-63, 132, 155: 12,020 calls, 1,868,732 sample columns; 39 columns differ (1 in 47,900), 41 calls touched
-# (1 in 293), one diverged call (seed 155); worst |dLR| on a touched call 1.5e-7 relative, worst |dAF| 1.7e-5. On 300 more
-# (seeds 200-499): 51,517 calls, 7,532,016 columns; 287 differ (1 in 26,200), 140 calls touched (1 in 368), none diverged;
-# worst |dAF| 3.0e-5; |dLR| up to 8e-7 -- inside north_star's own 1e-6, which therefore is the budget -- on all but ONE call
-# (seed 483, in the suite since): 1.29e-4, with length, iteration count and all columns equal.
-LR_BUDGET = 1e-6
-AF_BUDGET = 3.4e-5
-LR_OUTLIER_BUDGET = 2.6e-4          # (twice the one observed: 1.29e-4, seed 483)
+# (budgets of the knife-edge class over the whole sweep: conftest.py)
 
 
 def test_session_budgets(built):
-    s = SESSION
+    """The budgets over the cohorts THIS session has noted so far (one process: all 67, this test runs last in the file). Under
+    xdist or a partial selection fewer may be there: then the check is left to conftest.pytest_sessionfinish, which sees the
+    notes of all workers and fails the session the same way (and never skips once the whole sweep has run)."""
+    from conftest import check_fuzz_budgets, fuzz_session_figures
+    s = fuzz_session_figures()
     if s["cohorts"] < 60:
-        pytest.skip("only %d unsnapped cohorts ran in this session (the budgets are stated for the whole sweep)" % s["cohorts"])
-    print("unsnapped sweep: %(cohorts)d cohorts, %(calls)d calls, %(columns)d sample columns; %(differing_columns)d columns differ, "
-          "%(touched_calls)d calls touched, %(diverged_calls)d diverged (seeds %(diverged_seeds)s); worst |dLR| %(worst_lr).3g "
-          "(relative to max(1, |LR|)) apart from %(lr_outliers)d outlier(s) of up to %(worst_lr_outlier).3g (seeds %(lr_outlier_seeds)s), "
-          "worst |dAF| %(worst_af).3g" % s)
-    try:                                    # (pytest -q swallows the line above: keep the figures of the run next to its other logs)
-        import json, os
-        from conftest import ROOT
-        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "fuzz_session.json"), "w") as fh:
-            json.dump(s, fh)
-    except OSError:
-        pass
-    assert s["differing_columns"] * 20000 <= s["columns"], "more than 1 differing column per 20,000"
-    assert s["touched_calls"] * 200 <= s["calls"], "more than 1 touched call per 200"
-    assert s["diverged_calls"] <= max(1, s["calls"] // 20000) and set(s["diverged_seeds"]) <= {155}
-    assert s["worst_lr"] <= LR_BUDGET and s["worst_af"] <= AF_BUDGET
-    # LR beyond north_star's 1e-6 on a call that is otherwise the same: the wider sweep's one case, and no further
-    assert s["lr_outliers"] <= max(1, s["calls"] // 20000) and set(s["lr_outlier_seeds"]) <= {483}
-    assert s["worst_lr_outlier"] <= LR_OUTLIER_BUDGET
+        pytest.skip("only %d unsnapped cohorts noted so far (the budgets are stated for the whole sweep; conftest checks them at the "
+                    "end of the session)" % s["cohorts"])
+    problems = check_fuzz_budgets(s)
+    assert not problems, problems

@@ -139,6 +139,29 @@ def test_product_binary_dense_200_golden(built, cohort_dir, tmp_path):
     assert "".join(out) == golden_text("dd200_windowwise.digest.tsv.gz")
 
 
+def test_product_binary_200_samples_golden(built, cohort_dir, tmp_path):
+    """The 200-sample default-mode capture of the reference, through the product binary (the oracle-backed driver
+    reproduces it in tests/test_oracle_golden.py::test_200_samples_default), with the loop on the device and walked on the
+    host; the run's own count of knife-edge truncations (pd_timing::n_near_integer_shifts, printed under POPDEL_TIMING)
+    goes into the session's parity notes."""
+    import re
+    import subprocess
+    from conftest import FUZZ_NOTES, strip_date
+    from popdel_amd import synth
+    d = cohort_dir("s200", 200, synth.single_deletion)
+    assert run_call(POPDEL_BIN, d, str(tmp_path / "a.vcf")) == golden_text("s200_default.vcf")
+    env = dict(os.environ, POPDEL_HOST_WALK="1", POPDEL_TIMING="1")
+    r = subprocess.run([POPDEL_BIN, "call", os.path.join(d, "profiles.txt"), "-o", str(tmp_path / "b.vcf"), "-r", "chr20:1000000-2000000"],
+                       env=env, capture_output=True, text=True, check=True)
+    assert strip_date(open(tmp_path / "b.vcf").read()) == golden_text("s200_default.vcf")
+    m = re.search(r"\[popdel timing\] parity: (\d+) reference-shift quotients .* in (\d+) candidate cells, (\d+) window calls", r.stderr)
+    assert m, r.stderr[-400:]
+    os.makedirs(FUZZ_NOTES, exist_ok=True)
+    with open(os.path.join(FUZZ_NOTES, "parity_notes.txt"), "a") as fh:
+        fh.write("popdel call, 200 samples x 1 Mb (golden s200_default.vcf, byte-identical): %s reference-shift quotients within 1e-9 of an "
+                 "integer in %s candidate cells, %s window calls\n" % m.groups())
+
+
 def test_product_binary_1000_samples_golden(built, cohort_dir, tmp_path):
     """BASELINE.md's largest survey run of the reference (1000 samples x 1 Mb, default mode): byte-identical VCF."""
     from popdel_amd import synth

@@ -86,3 +86,20 @@ def test_state_from_segment_to_segment(built):
                                 equal_run=[0], step_pos=3540))
     assert ctx.walk_active()[1].tolist() == []                  # last windows 3390 and 3480, both over before 3540: left at the step
     ctx.close()
+
+
+def test_lists_grow_instead_of_failing(built, cohort_dir, tmp_path, monkeypatch):
+    """A read group with more active (or not-yet-reached) pairs than the device-side window loop has room for -- a pile-up
+    under an unlimited maxLoad (-A), the reference's parameter_calculation_popdel_call.h:129 -- makes the lists longer; it
+    used to abort `popdel call` mid-run. Forced here by starting with room for 4 pairs per read group (POPDEL_HIP_WALK_CAP,
+    a test lever): every segment of the golden cohort outgrows that several times, and the VCF must be the golden one."""
+    import os
+    from conftest import GOLDEN, POPDEL_BIN, run_call
+    from popdel_amd import synth
+    d = cohort_dir("s2", 2, synth.single_deletion)
+    monkeypatch.setenv("POPDEL_HIP_WALK_CAP", "4")
+    assert run_call(POPDEL_BIN, d, str(tmp_path / "a.vcf")) == open(os.path.join(GOLDEN, "s2_default.vcf")).read()
+    assert run_call(POPDEL_BIN, d, str(tmp_path / "b.vcf"), "-n") == open(os.path.join(GOLDEN, "s2_windowwise.vcf")).read()
+    d = cohort_dir("dd200", 200, synth.dense_deletions)
+    import gzip
+    assert run_call(POPDEL_BIN, d, str(tmp_path / "t.vcf")) == gzip.open(os.path.join(GOLDEN, "dd200_default.vcf.gz"), "rt").read()

@@ -12,4 +12,15 @@ g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -I"$R
 g++ -std=c++17 -O1 -g -fsanitize=thread -fno-omit-frame-pointer -I"$ROOT/include" -I"$ROOT/oracle" -I"$H" -o "$OUT/call_tsan" $SRC -lz -lpthread
 POPDEL_THREADS=4 "$OUT/call_asan" "$@" -o "$OUT/asan.vcf" > /dev/null
 POPDEL_THREADS=8 "$OUT/call_tsan" "$@" -o "$OUT/tsan.vcf" > /dev/null
+# the planned-segment path: the closed-form walk behind pd_walk_submit (the oracle offers it with POPDEL_ORACLE_WALK=1), i.e. the
+# hand-over thread reading the slot tables in place beside the next round's decode, and the same with jobs that carry copies
+check() {
+    grep -v '^##fileDate' "$OUT/$1.vcf" > "$OUT/$1.body"
+    grep -v '^##fileDate' "$OUT/asan.vcf" | cmp -s - "$OUT/$1.body" || { echo "$1.vcf differs from the host-walk output" >&2; exit 1; }
+}
+POPDEL_ORACLE_WALK=1 POPDEL_THREADS=4 "$OUT/call_asan" "$@" -o "$OUT/asan_walk.vcf" > /dev/null
+POPDEL_ORACLE_WALK=1 POPDEL_THREADS=8 "$OUT/call_tsan" "$@" -o "$OUT/tsan_walk.vcf" > /dev/null
+POPDEL_ORACLE_WALK=1 POPDEL_COPY_HAND_OVER=1 POPDEL_THREADS=4 "$OUT/call_asan" "$@" -o "$OUT/asan_walk_copy.vcf" > /dev/null
+POPDEL_ORACLE_WALK=1 POPDEL_COPY_HAND_OVER=1 POPDEL_THREADS=8 "$OUT/call_tsan" "$@" -o "$OUT/tsan_walk_copy.vcf" > /dev/null
+for f in asan_walk tsan_walk asan_walk_copy tsan_walk_copy; do check $f; done
 echo "sanitizer runs finished without findings"
