@@ -221,9 +221,10 @@ class Lane:
     """One context with one resident segment; runs passes the way a streaming host drives the library: the next
     segment's ticket is issued before the open one is collected."""
 
-    def __init__(self, ctx, handle, serial=False):
-        """handle: a staged segment, or a list of them (scanned in turn)"""
-        self.ctx, self.serial = ctx, serial
+    def __init__(self, ctx, handle, serial=False, depth=2):
+        """handle: a staged segment, or a list of them (scanned in turn); depth: tickets kept in flight (2: the next segment's
+        ticket is issued before the open one is collected; a context with K lanes takes K)"""
+        self.ctx, self.serial, self.depth = ctx, serial, max(1, depth)
         self.handles = list(handle) if isinstance(handle, (list, tuple)) else [handle]
         self.handle = self.handles[0]
         self.turn = 0
@@ -235,11 +236,13 @@ class Lane:
 
     def passes(self, n, acc):
         c = self.ctx
-        ticket = c.run(self.next_handle()) if n else None
+        depth = 1 if self.serial else self.depth
+        open_tickets, issued = [], 0
         for i in range(n):
-            nxt = c.run(self.next_handle()) if (i + 1 < n and not self.serial) else None
-            res = c.collect(ticket, copy=False)
-            ticket = nxt if not self.serial else (c.run(self.next_handle()) if i + 1 < n else None)
+            while issued < n and len(open_tickets) < depth:
+                open_tickets.append(c.run(self.next_handle()))
+                issued += 1
+            res = c.collect(open_tickets.pop(0), copy=False)
             t = c.timing()
             acc[0] += t["stage1_ms"]
             acc[1] += t["stage2_ms"]

@@ -12,7 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
+#include <thread>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -272,6 +274,44 @@ struct Stage1Out
 
 }  // namespace
 
+// Lanes of a context (POPDEL_HIP_LANES = K > 1; round 4). Stage 2 of a sparse segment is ~45 short dependent launches and
+// three host round trips during which most of the chip idles, and a sharded cohort adds the wire time of ~15 exchanges:
+// what fills those gaps is ANOTHER segment's stage 2. A context with lanes owns K child contexts -- streams, stage-1
+// outputs and stage-2 scratch of their own, the cohort's tables uploaded once more -- that take the tickets in turn
+// (ticket t -> lane t mod K), each on a host thread of its own running the ordinary run + collect sequence; the parent
+// keeps what is per cohort and per segment (staged segments, the window loop's state, the upload path) and hands the
+// finished calls out in ticket order. Results are those of a plain context, bit for bit (the lanes run the same code on the
+// same staged segments). Up to 2 K tickets may be outstanding.
+struct LaneJob
+{
+    uint64_t ticket = 0, handle = 0;
+};
+struct LaneResult
+{
+    bool done = false;
+    int rc = 0;
+    pd_calls * calls = nullptr;
+    std::string error;
+    pd_timing timing;
+    unsigned lane = 0;
+};
+struct LaneWorker
+{
+    pd_ctx * ctx = nullptr;
+    std::thread thread;
+    std::deque<LaneJob> jobs;           // (guarded by LanesState::m)
+};
+struct LanesState
+{
+    std::vector<std::unique_ptr<LaneWorker>> workers;
+    unsigned active = 0;                // lanes that take tickets (a sharded cohort of several ranks uses one)
+    std::mutex m;
+    std::condition_variable wake, done;
+    std::map<uint64_t, LaneResult> results;     // by ticket: everything outstanding
+    bool stop = false;
+    unsigned lastLane = 0;              // lane of the most recently collected ticket (pd_stage1_last)
+};
+
 // Contexts of one process that exchange among themselves (pd_ctx_set_shard_local).
 struct pd_local_group
 {
@@ -334,6 +374,11 @@ struct pd_ctx
 
     std::map<uint64_t, std::unique_ptr<StagedSegment>> staged;
     std::vector<std::unique_ptr<StagedSegment>> spare;      // released segments: their HBM buffers are reused (no hipMalloc per segment)
+    // lanes (see LanesState): a lane runs the segments its `owner` has staged; `stagedLock` guards the owner's two containers
+    // above against its lanes' threads
+    pd_ctx * owner = nullptr;
+    std::mutex stagedLock;
+    std::unique_ptr<LanesState> lanes;
     // host-side scratch of pd_segment_stage(), kept between calls
     PinnedBuf<pd::PairDO> hPairs;
     PinnedBuf<uint32_t> hStart, hWinStart, hEndCount;
@@ -1342,8 +1387,44 @@ int fail(pd_ctx * c, const std::string & msg)
 
 extern "C" {
 
+static int createContext(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_readgroups, const uint32_t * sample_rg_offsets,
+                         uint32_t n_samples, int device, pd_ctx ** out);
+static void laneLoop(pd_ctx * parent, unsigned k);
+
 int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_readgroups, const uint32_t * sample_rg_offsets,
                   uint32_t n_samples, int device, pd_ctx ** out)
+{
+    if (int rc = createContext(cfg, rgs, n_readgroups, sample_rg_offsets, n_samples, device, out))
+        return rc;
+    // POPDEL_HIP_LANES = K > 1: K lanes behind this context (LanesState)
+    unsigned k = 1;
+    if (const char * e = getenv("POPDEL_HIP_LANES"))
+        k = static_cast<unsigned>(std::max(1, std::min(8, atoi(e))));
+    if (k < 2)
+        return 0;
+    pd_ctx * c = *out;
+    c->lanes.reset(new LanesState());
+    for (unsigned i = 0; i < k; ++i)
+    {
+        pd_ctx * lane = nullptr;
+        if (int rc = createContext(cfg, rgs, n_readgroups, sample_rg_offsets, n_samples, device, &lane))
+        {
+            pd_ctx_destroy(c);
+            *out = nullptr;
+            return rc;
+        }
+        lane->owner = c;
+        c->lanes->workers.emplace_back(new LaneWorker());
+        c->lanes->workers.back()->ctx = lane;
+    }
+    c->lanes->active = k;
+    for (unsigned i = 0; i < k; ++i)
+        c->lanes->workers[i]->thread = std::thread(laneLoop, c, i);
+    return 0;
+}
+
+static int createContext(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_readgroups, const uint32_t * sample_rg_offsets,
+                         uint32_t n_samples, int device, pd_ctx ** out)
 {
     if (!cfg || !rgs || !sample_rg_offsets || !out || n_readgroups == 0 || n_samples == 0)
         return fail(nullptr, "pd_ctx_create: invalid argument");
@@ -1539,6 +1620,8 @@ uint32_t pd_shard_samples(uint32_t n_samples_global, uint32_t world)
     return (tiles + world - 1) / world * pd::kSamplesPerBlock;
 }
 
+static void laneTeardown(pd_ctx * c);
+
 static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, pd_local_group * group, const char * who)
 {
     const std::string name = who;
@@ -1550,6 +1633,31 @@ static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, p
         return fail(c, name + ": invalid rank/world or missing threshold table");
     if (group && (group->world != sh->world || group->members.size() != sh->world))
         return fail(c, name + ": the group was created for another number of contexts");
+    if (c->lanes)
+    {
+        // Lanes exchange on communicators of their own (their exchanges interleave in an order no other rank could
+        // reproduce on ONE communicator). With one rank every lane makes itself one; a cohort over several ranks -- or one
+        // that exchanges through host callbacks or between the contexts of a process -- runs without lanes.
+        if (sh->world == 1 && rcclId && !group)
+        {
+            RcclApi & api = rccl();
+            if (!api.error.empty())
+                return fail(c, name + ": " + api.error);
+            for (auto & w : c->lanes->workers)
+            {
+                ncclUniqueId own;
+                if (api.getUniqueId(&own) != ncclSuccess)
+                    return fail(c, name + ": ncclGetUniqueId failed");
+                if (int rc = applyShard(w->ctx, sh, reinterpret_cast<const uint8_t *>(&own), nullptr, who))
+                {
+                    c->error = w->ctx->error;
+                    return rc;
+                }
+            }
+        }
+        else
+            laneTeardown(c);
+    }
     if (!rcclId && !group && sh->world > 1 && (!sh->reserve || !sh->all_gather))
         return fail(c, name + ": a sharded cohort needs the reserve() and all_gather() callbacks");
     const uint32_t per = pd_shard_samples(sh->n_samples_global, sh->world);
@@ -1672,11 +1780,14 @@ int pd_rccl_unique_id(uint8_t * id)
     return 0;
 }
 
+static void laneTeardown(pd_ctx * c);
+
 void pd_ctx_destroy(pd_ctx * ctx)
 {
     if (!ctx)
         return;
     (void)hipSetDevice(ctx->device);
+    laneTeardown(ctx);
     for (auto & r : ctx->runs)
     {
         if (r.second.s1Begin)
@@ -1687,6 +1798,167 @@ void pd_ctx_destroy(pd_ctx * ctx)
             (void)hipEventDestroy(r.second.scanDone);
     }
     delete ctx;
+}
+
+static std::unique_ptr<StagedSegment> takeSpare(pd_ctx * c)
+{
+    std::lock_guard<std::mutex> guard(c->stagedLock);
+    if (c->spare.empty())
+        return std::unique_ptr<StagedSegment>(new StagedSegment());
+    std::unique_ptr<StagedSegment> s = std::move(c->spare.back());
+    c->spare.pop_back();
+    return s;
+}
+
+static void putSpare(pd_ctx * c, std::unique_ptr<StagedSegment> s)
+{
+    std::lock_guard<std::mutex> guard(c->stagedLock);
+    c->spare.push_back(std::move(s));
+}
+
+static void putStaged(pd_ctx * c, uint64_t handle, std::unique_ptr<StagedSegment> s)
+{
+    std::lock_guard<std::mutex> guard(c->stagedLock);
+    c->staged[handle] = std::move(s);
+}
+
+static StagedSegment * findStaged(pd_ctx * c, uint64_t handle);
+
+// ---- lanes ---------------------------------------------------------------------------------------------------------------
+// A lane's thread: the ordinary sequence on the lane's own context, pipelined the way a streaming host drives a plain
+// context -- with work queued, the next job's ticket is issued before the open one is collected, so that its scan goes onto
+// the lane's stream right behind the open segment's last kernel.
+static void laneLoop(pd_ctx * parent, unsigned k)
+{
+    LanesState & L = *parent->lanes;
+    LaneWorker & w = *L.workers[k];
+    (void)hipSetDevice(w.ctx->device);
+    struct Open
+    {
+        uint64_t ticket, child;
+        int rc;
+    };
+    std::deque<Open> open;
+    for (;;)
+    {
+        // top up to two open tickets; wait only if there is nothing to collect
+        for (;;)
+        {
+            LaneJob job;
+            {
+                std::unique_lock<std::mutex> lock(L.m);
+                if (open.empty())
+                    L.wake.wait(lock, [&] { return L.stop || !w.jobs.empty(); });
+                if (w.jobs.empty() || open.size() >= 2)
+                {
+                    if (open.empty())
+                        return;                 // (stop)
+                    break;
+                }
+                job = w.jobs.front();
+                w.jobs.pop_front();
+            }
+            Open o{job.ticket, 0, 0};
+            o.rc = pd_segment_run(w.ctx, job.handle, &o.child);
+            open.push_back(o);
+        }
+        const Open o = open.front();
+        open.pop_front();
+        LaneResult r;
+        r.lane = k;
+        r.rc = o.rc;
+        if (r.rc == 0)
+            r.rc = pd_segment_collect(w.ctx, o.child, &r.calls);
+        if (r.rc != 0)
+            r.error = w.ctx->error;
+        r.timing = w.ctx->timing;
+        r.done = true;
+        {
+            std::lock_guard<std::mutex> lock(L.m);
+            L.results[o.ticket] = std::move(r);
+        }
+        L.done.notify_all();
+    }
+}
+
+static int laneRun(pd_ctx * c, uint64_t handle, uint64_t * ticket)
+{
+    LanesState & L = *c->lanes;
+    if (!findStaged(c, handle))
+        return fail(c, "pd_segment_run: unknown segment handle");
+    std::unique_lock<std::mutex> lock(L.m);
+    // (columns kept on the device live until the lane's next collect: then no lane gets a second ticket before its first is out)
+    if (L.results.size() >= (c->keepOnDevice ? 1u : 2u) * L.active)
+        return fail(c, "pd_segment_run: too many tickets outstanding (collect the oldest one first)");
+    *ticket = c->nextTicket++;
+    L.results[*ticket] = LaneResult();
+    LaneJob job;
+    job.ticket = *ticket;
+    job.handle = handle;
+    L.workers[*ticket % L.active]->jobs.push_back(job);
+    lock.unlock();
+    L.wake.notify_all();
+    return 0;
+}
+
+static int laneCollect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
+{
+    LanesState & L = *c->lanes;
+    std::unique_lock<std::mutex> lock(L.m);
+    auto it = L.results.find(ticket);
+    if (it == L.results.end())
+        return fail(c, "pd_segment_collect: unknown ticket");
+    if (it != L.results.begin())
+        return fail(c, "pd_segment_collect: tickets are collected in the order they were issued");
+    L.done.wait(lock, [&] { return it->second.done; });
+    LaneResult r = std::move(it->second);
+    L.results.erase(it);
+    L.lastLane = r.lane;
+    lock.unlock();
+    c->timing = r.timing;
+    if (r.rc != 0)
+    {
+        c->error = r.error;
+        return r.rc;
+    }
+    *out = r.calls;
+    return 0;
+}
+
+// until no lane has work left (results stay where they are: collect takes them)
+static void laneDrain(pd_ctx * c)
+{
+    LanesState & L = *c->lanes;
+    std::unique_lock<std::mutex> lock(L.m);
+    L.done.wait(lock, [&] {
+        for (const auto & r : L.results)
+            if (!r.second.done)
+                return false;
+        return true;
+    });
+}
+
+static void laneTeardown(pd_ctx * c)
+{
+    if (!c->lanes)
+        return;
+    LanesState & L = *c->lanes;
+    {
+        std::lock_guard<std::mutex> lock(L.m);
+        L.stop = true;
+        for (auto & w : L.workers)
+            w->jobs.clear();
+    }
+    L.wake.notify_all();
+    for (auto & w : L.workers)
+        if (w->thread.joinable())
+            w->thread.join();
+    for (auto & r : L.results)
+        if (r.second.calls)
+            pd_calls_free(r.second.calls);
+    for (auto & w : L.workers)
+        pd_ctx_destroy(w->ctx);
+    c->lanes.reset();
 }
 
 int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
@@ -1701,15 +1973,7 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
     {
         PD_HIP(hipSetDevice(c->device));
         std::unique_ptr<StagedSegment> s;
-        if (!c->spare.empty())
-        {
-            s = std::move(c->spare.back());
-            c->spare.pop_back();
-        }
-        else
-        {
-            s.reset(new StagedSegment());
-        }
+        s = takeSpare(c);
         s->ownedBySubmit = false;
         s->waitBuilt = false;
         s->firstPos = seg->first_window_pos;
@@ -1730,7 +1994,7 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
             PD_HIP(hipEventRecord(s->built, c->copyStream));
             s->waitBuilt = true;
             *handle = c->nextHandle++;
-            c->staged[*handle] = std::move(s);
+            putStaged(c, *handle, std::move(s));
             return 0;
         }
         PinnedBuf<pd::PairDO> & pairs = c->hPairs;
@@ -1775,7 +2039,7 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
         s->nRealRg = c->nRg;
         PD_HIP(hipStreamSynchronize(cs));              // the host scratch is reused by the next call
         *handle = c->nextHandle++;
-        c->staged[*handle] = std::move(s);
+        putStaged(c, *handle, std::move(s));
     }
     catch (const HipError & e)
     {
@@ -1793,18 +2057,29 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
 }
 
 // Enqueues the stage-1 scan of a run on the context's stream.
+// The staged segment behind a handle: a lane looks in its owner's table (the owner does not unstage a segment while one of its
+// lanes has a ticket for it: pd_segment_unstage drains them first).
+static StagedSegment * findStaged(pd_ctx * c, uint64_t handle)
+{
+    pd_ctx * o = c->owner ? c->owner : c;
+    std::lock_guard<std::mutex> guard(o->stagedLock);
+    auto it = o->staged.find(handle);
+    return it == o->staged.end() ? nullptr : it->second.get();
+}
+
 static void launchScan(pd_ctx * c, Run & run)
 {
-    auto sit = c->staged.find(run.handle);
-    if (sit == c->staged.end())
+    StagedSegment * found = findStaged(c, run.handle);
+    if (!found)
         throw HipError{"the segment of a ticket was unstaged"};
-    StagedSegment & s = *sit->second;
+    StagedSegment & s = *found;
     Stage1Out & o = c->s1[run.set];
     hipStream_t st = c->scanStream ? c->scanStream : c->stream;
     if (s.waitBuilt)
     {
         PD_HIP(hipStreamWaitEvent(st, s.built, 0));
-        s.waitBuilt = false;
+        if (!c->owner)              // (lanes: every lane's stream waits, whichever runs the segment first)
+            s.waitBuilt = false;
     }
     const size_t cells = static_cast<size_t>(c->nSamples) * s.nWindows;
     o.q3.ensure(cells);
@@ -1858,8 +2133,9 @@ int pd_segment_run(pd_ctx * c, uint64_t handle, uint64_t * ticket)
 {
     if (!c || !ticket)
         return fail(c, "pd_segment_run: invalid argument");
-    auto it = c->staged.find(handle);
-    if (it == c->staged.end())
+    if (c->lanes)
+        return laneRun(c, handle, ticket);
+    if (!findStaged(c, handle))
         return fail(c, "pd_segment_run: unknown segment handle");
     // One ticket may be open plus one waiting: the waiting one's scan is enqueued by pd_segment_collect() of the open one,
     // right behind its last kernel, so that it runs while the open ticket's results travel to the host.
@@ -1901,9 +2177,12 @@ int pd_segment_unstage(pd_ctx * c, uint64_t handle)
     if (!c)
         return 1;
     (void)hipSetDevice(c->device);
+    if (c->lanes)
+        laneDrain(c);               // no lane may still be running the segment
     (void)hipStreamSynchronize(c->stream);
     if (c->scanStream)
         (void)hipStreamSynchronize(c->scanStream);
+    std::lock_guard<std::mutex> guard(c->stagedLock);
     auto it = c->staged.find(handle);
     if (it == c->staged.end())
         return fail(c, "pd_segment_unstage: unknown segment handle");
@@ -1918,9 +2197,13 @@ int pd_segment_submit(pd_ctx * c, const pd_segment * seg, uint64_t * ticket)
     uint64_t h = 0;
     if (int rc = pd_segment_stage(c, seg, &h))
         return rc;
-    c->staged[h]->ownedBySubmit = true;
+    {
+        std::lock_guard<std::mutex> guard(c->stagedLock);
+        c->staged[h]->ownedBySubmit = true;
+    }
     if (int rc = pd_segment_run(c, h, ticket))
     {
+        std::lock_guard<std::mutex> guard(c->stagedLock);
         c->staged.erase(h);
         return rc;
     }
@@ -2040,13 +2323,7 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
         hipStream_t cs = c->copyStream;
         prepareWalkState(*c);
         std::unique_ptr<StagedSegment> s;
-        if (!c->spare.empty())
-        {
-            s = std::move(c->spare.back());
-            c->spare.pop_back();
-        }
-        else
-            s.reset(new StagedSegment());
+        s = takeSpare(c);
         s->ownedBySubmit = true;
         s->waitBuilt = false;
         s->firstPos = wk->first_window_pos;
@@ -2154,7 +2431,7 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
         if (nInst == 0)
         {
             // no pair is active in any window: the (host-side) path for empty segments
-            c->spare.push_back(std::move(s));
+            putSpare(c, std::move(s));
             std::vector<uint64_t> zeros(nRg + 1, 0);
             pd_segment empty;
             std::memset(&empty, 0, sizeof(empty));
@@ -2168,7 +2445,7 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
         if (!built)
         {
             // a segment the device-side layout build does not take: its instances come back and go the way of pd_segment
-            c->spare.push_back(std::move(s));
+            putSpare(c, std::move(s));
             std::vector<uint64_t> off(nRg + 1);
             std::vector<int32_t> dv(nInst);
             std::vector<uint32_t> on(nInst), of(nInst), st(nInst);
@@ -2197,7 +2474,7 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
         PD_HIP(hipEventRecord(s->built, cs));
         s->waitBuilt = true;
         handle = c->nextHandle++;
-        c->staged[handle] = std::move(s);
+        putStaged(c, handle, std::move(s));
     }
     catch (const HipError & e)
     {
@@ -2213,6 +2490,7 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
     }
     if (int rc = pd_segment_run(c, handle, ticket))
     {
+        std::lock_guard<std::mutex> guard(c->stagedLock);
         c->staged.erase(handle);
         return rc;
     }
@@ -2268,6 +2546,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
     if (!c || !out)
         return fail(c, "pd_segment_collect: invalid argument");
     *out = nullptr;
+    if (c->lanes)
+        return laneCollect(c, ticket, out);
     auto rit = c->runs.find(ticket);
     if (rit == c->runs.end())
         return fail(c, "pd_segment_collect: unknown ticket");
@@ -2275,8 +2555,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         return fail(c, "pd_segment_collect: tickets are collected in the order they were issued");
     Run run = rit->second;
     c->runs.erase(rit);
-    auto sit = c->staged.find(run.handle);
-    if (sit == c->staged.end())
+    StagedSegment * found = findStaged(c, run.handle);
+    if (!found)
     {
         (void)hipEventDestroy(run.s1Begin);
         (void)hipEventDestroy(run.s1End);
@@ -2284,7 +2564,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             (void)hipEventDestroy(run.scanDone);
         return fail(c, "pd_segment_collect: segment was unstaged before collect");
     }
-    StagedSegment & s = *sit->second;
+    StagedSegment & s = *found;
     hipEvent_t s2Begin = nullptr, s2End = nullptr;
     bool s2BeginRecorded = false;
     PinnedBlock pinned;
@@ -2863,9 +3143,15 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
     c->lastSet = run.set;
     if (s.ownedBySubmit)
     {
-        if (c->spare.size() < 2)
-            c->spare.push_back(std::move(sit->second));
-        c->staged.erase(sit);
+        pd_ctx * o = c->owner ? c->owner : c;
+        std::lock_guard<std::mutex> guard(o->stagedLock);
+        auto sit = o->staged.find(run.handle);
+        if (sit != o->staged.end())
+        {
+            if (o->spare.size() < 2 + (o->lanes ? o->lanes->workers.size() : 0))
+                o->spare.push_back(std::move(sit->second));
+            o->staged.erase(sit);
+        }
     }
     return rc;
 }
@@ -2892,6 +3178,8 @@ int pd_stage1_last(pd_ctx * c, pd_stage1_view * out)
 {
     if (!c || !out)
         return 1;
+    if (c->lanes)
+        return pd_stage1_last(c->lanes->workers[c->lanes->lastLane]->ctx, out);
     try
     {
         PD_HIP(hipSetDevice(c->device));
@@ -2975,6 +3263,9 @@ int pd_ctx_keep_results_on_device(pd_ctx * c, int on)
     if (!c)
         return 1;
     c->keepOnDevice = on != 0;
+    if (c->lanes)
+        for (auto & w : c->lanes->workers)
+            w->ctx->keepOnDevice = on != 0;
     return 0;
 }
 
@@ -3000,6 +3291,17 @@ int pd_calls_merge(pd_ctx * c, const pd_calls * calls, uint32_t n_groups, const 
     if (!c || !calls || !out || (n_groups != 0 && (!member_offsets || !member_index || !head_index)))
         return fail(c, "pd_calls_merge: invalid argument");
     *out = nullptr;
+    if (c->lanes)
+    {
+        // the columns sit in the HBM of the lane that ran the segment
+        pd_ctx * lane = reinterpret_cast<const CallsBox *>(calls)->owner;
+        if (!lane || lane->owner != c)
+            return fail(c, "pd_calls_merge: the per-sample arrays of these calls are not (or no longer) on the device");
+        const int rc = pd_calls_merge(lane, calls, n_groups, member_offsets, member_index, head_index, out);
+        if (rc != 0)
+            c->error = lane->error;
+        return rc;
+    }
     if (!columnsResident(c, calls))
         return fail(c, "pd_calls_merge: the per-sample arrays of these calls are not (or no longer) on the device");
     PinnedBlock pinned;
@@ -3103,6 +3405,16 @@ int pd_calls_fetch_columns(pd_ctx * c, pd_calls * calls)
         return fail(c, "pd_calls_fetch_columns: invalid argument");
     if (calls->pl)
         return 0;                                   // they are there already
+    if (c->lanes)
+    {
+        pd_ctx * lane = reinterpret_cast<const CallsBox *>(calls)->owner;
+        if (!lane || lane->owner != c)
+            return fail(c, "pd_calls_fetch_columns: the per-sample arrays of these calls are not (or no longer) on the device");
+        const int rc = pd_calls_fetch_columns(lane, calls);
+        if (rc != 0)
+            c->error = lane->error;
+        return rc;
+    }
     if (!columnsResident(c, calls))
         return fail(c, "pd_calls_fetch_columns: the per-sample arrays of these calls are not (or no longer) on the device");
     try

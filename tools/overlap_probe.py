@@ -36,7 +36,10 @@ def main():
     ref = None
     rows = []
     for mode in modes:
-        os.environ["POPDEL_HIP_SCAN_OVERLAP"] = mode
+        # "L<k>": a context with k lanes (POPDEL_HIP_LANES); everything else: POPDEL_HIP_SCAN_OVERLAP
+        lanes = int(mode[1:]) if mode.startswith("L") else 1
+        os.environ["POPDEL_HIP_LANES"] = str(lanes)
+        os.environ["POPDEL_HIP_SCAN_OVERLAP"] = "0" if mode.startswith("L") else mode
         ctx = capi.Context(hip, [rg] * S, list(range(S + 1)), device=0)
         hs = [ctx.stage(s) for s in segs]
         got = []
@@ -50,7 +53,7 @@ def main():
                    for g, r in zip(got, ref))
         row = dict(mode=mode, identical_to_first=bool(same), cells=cells)
         for label, handles in (("one_segment", hs[:1]), ("all_segments", hs)):
-            lane = bench.Lane(ctx, handles)
+            lane = bench.Lane(ctx, handles, depth=(2 * lanes if lanes > 1 else 2))
             lane.passes(max(10, len(handles) * 2), bench.new_acc())
             torch.cuda.synchronize()
             t0 = time.perf_counter()
