@@ -75,13 +75,17 @@ def parse_args(argv=None):
     ap.add_argument("--small-cohort", type=int, default=1000,
                     help="samples of the configs[1] leg (1,000 profiles x chr20 windows); 0: skip")
     ap.add_argument("--no-legs", action="store_true", help="headline only (profiling runs)")
-    ap.add_argument("--resident-segments", type=int, default=1,
+    ap.add_argument("--resident-segments", type=int, default=10,
                     help="N = 1: distinct 200-kb segments (own pairs, own planted deletion) kept resident and scanned in turn by the "
-                         "headline's passes (default 1: the workload of rounds 1 and 2)")
-    ap.add_argument("--distinct-segments", type=int, default=5,
-                    help="N = 1: segments of the `distinct_segments` leg -- the headline's step over that many different resident "
-                         "segments in turn, one of them without a deletion (SURVEY 8(d): one deletion per 250 kb): the stage-2 share of "
-                         "a pass depends on the planted deletion, and the headline's one segment is one sample of it; 0: skip")
+                         "headline's passes. Deletions as SURVEY 8(d) plants them -- one per 250 kb, length log-uniform 300..5,000 bp, "
+                         "AF ~ Beta(0.5, 2) -- so of every five consecutive 200-kb segments one has none (default 10: eight with a "
+                         "deletion, two without; 1: the single re-scanned segment of rounds 1-3)")
+    ap.add_argument("--distinct-segments", type=int, default=0,
+                    help="N = 1: segments of the `distinct_segments` leg of round 3 (superseded by the headline's own mix); 0: skip")
+    ap.add_argument("--lanes", type=int, default=3,
+                    help="lanes of every context the bench creates (POPDEL_HIP_LANES; the library's default is 3): child contexts that "
+                         "take the tickets in turn so that one segment's stage 2 fills the gaps of another's; the passes keep "
+                         "2 x lanes tickets in flight. 1: the plain context of rounds 1-3")
     ap.add_argument("--configs3-samples", type=int, default=10000,
                     help="N > 1: TOTAL samples of the configs[3]-shaped leg (ONE cohort sharded by samples, pd_shard_samples(total, N) "
                          "per rank, resident segment); 0: skip")
@@ -217,14 +221,18 @@ def new_acc():
     return [0.0, 0.0, 0, 0, None, 0.0]
 
 
+LANES = 1       # lanes of the contexts the bench creates (set in main from --lanes)
+
+
 class Lane:
     """One context with one resident segment; runs passes the way a streaming host drives the library: the next
     segment's ticket is issued before the open one is collected."""
 
-    def __init__(self, ctx, handle, serial=False, depth=2):
-        """handle: a staged segment, or a list of them (scanned in turn); depth: tickets kept in flight (2: the next segment's
-        ticket is issued before the open one is collected; a context with K lanes takes K)"""
-        self.ctx, self.serial, self.depth = ctx, serial, max(1, depth)
+    def __init__(self, ctx, handle, serial=False, depth=None):
+        """handle: a staged segment, or a list of them (scanned in turn); depth: tickets kept in flight (2 for a plain context:
+        the next segment's ticket is issued before the open one is collected; 2 per lane for a context with lanes)"""
+        self.ctx, self.serial = ctx, serial
+        self.depth = max(1, depth if depth is not None else (2 * LANES if LANES > 1 else 2))
         self.handles = list(handle) if isinstance(handle, (list, tuple)) else [handle]
         self.handle = self.handles[0]
         self.turn = 0
@@ -272,6 +280,9 @@ def run_lanes(lanes, n_passes):
 def main():
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
+    if int(env_world or "1") > 1:
+        args.lanes = 1              # (a cohort over several ranks runs without lanes)
+    os.environ["POPDEL_HIP_LANES"] = str(max(1, args.lanes))
     if env_world is None and args.gpus > 1:
         sys.exit(spawn_ranks(args))
     world = int(env_world or "1")
@@ -289,6 +300,8 @@ def main():
     import torch
     from popdel_amd import capi, distributed, synth
 
+    global LANES
+    LANES = max(1, args.lanes) if int(env_world or "1") == 1 else 1     # (a cohort over several ranks runs without lanes)
     t_bench0 = time.perf_counter()
 
     def progress(msg):
@@ -350,9 +363,11 @@ def main():
     handles, planted_all = [handle], [planted]
     if not is_dist and R == 1 and args.contexts == 1:
         for k in range(1, max(1, args.resident_segments)):
-            f_k, W_k, o_k, a_k, p_k = device_tile(S, 20260 + 1000 * k, device, args.coverage)
+            # one deletion per 250 kb: of five consecutive 200-kb segments the third has none
+            n_del = 0 if k % 5 == 2 else 1
+            f_k, W_k, o_k, a_k, p_k = device_tile(S, 20260 + 1000 * k, device, args.coverage, n_deletions=n_del)
             handles.append(ctx.stage(capi.Segment(f_k, W_k, o_k, a_k["dev"], a_k["start"], a_k["on"], a_k["off"])))
-            planted_all.append(p_k)
+            planted_all.append(p_k if n_del else None)
             del o_k, a_k
     lanes = [Lane(ctx, handles, args.serial)]
     for _ in range(max(0, args.contexts - 1)):   # optional: independent segments in flight on the same GPU
@@ -366,6 +381,16 @@ def main():
         ctx.collect(ctx.run(h), copy=False)
         t = ctx.timing()
         seg_sizes.append((t["n_active_pairs"], t["n_pair_chunks"], t["n_candidate_cells"]))
+    # The scan's launch duration with the kernel ALONE on the chip (HIP events around it on its stream, one ticket at a time):
+    # what the roofline of the dominant kernel is quoted on. In the timed region below a context with lanes runs other
+    # segments' stage 2 -- and scans -- beside it, which stretches every launch while the job as a whole gets faster; that
+    # figure is reported next to it (roofline.mean_launch_ms_in_timed_region).
+    scan_alone = []
+    for _ in range(3 if len(handles) > 1 else 12):
+        for h in handles:
+            ctx.collect(ctx.run(h), copy=False)
+            scan_alone.append(ctx.timing()["stage1_ms"])
+    scan_alone_ms = sum(scan_alone[len(handles):]) / max(1, len(scan_alone) - len(handles))
 
     def timed_steps(step_fn, warmup, steps):
         for _ in range(warmup):
@@ -421,7 +446,9 @@ def main():
         if not is_dist and len(seg_sizes) > 1:      # the passes took the resident segments in turn
             tinfo["n_active_pairs"] = sum(x[0] for x in seg_sizes) / len(seg_sizes)
             tinfo["n_pair_chunks"] = sum(x[1] for x in seg_sizes) / len(seg_sizes)
-        s1_mean_s = h["s1_ms"] / h["launches"] / 1e3
+        s1_shared_ms = h["s1_ms"] / h["launches"]
+        # (N > 1: the headline's context is another one -- sharded, no lanes -- and its scans run alone anyway)
+        s1_mean_s = (scan_alone_ms if not is_dist else s1_shared_ms) / 1e3
         cells = tinfo["n_cells"]
         # gather of the [samples x windows x pairs] SoA + cell index + Q3 out
         alg_bytes = 4 * tinfo["n_active_pairs"] + 4 * cells + 4 * cells
@@ -452,7 +479,12 @@ def main():
                         scan_source_stamp=stamp,
                         algorithmic_bytes_per_launch=alg_bytes,
                         compact_bytes_per_launch=compact_bytes, compact_GBs=compact_bytes / s1_mean_s / 1e9,
-                        mean_launch_ms=s1_mean_s * 1e3, mean_active_pairs_per_cell=tinfo["n_active_pairs"] / cells)
+                        mean_launch_ms=s1_mean_s * 1e3, mean_launch_ms_in_timed_region=s1_shared_ms,
+                        launch_timing="HIP events around the kernel on its stream inside bench.py: mean_launch_ms with one ticket "
+                                      "at a time (the kernel alone on the chip; %d launches over the resident segments ahead of the timed "
+                                      "region), mean_launch_ms_in_timed_region over the timed passes, where the context's %d lanes run other "
+                                      "segments' kernels beside it" % (max(1, len(scan_alone) - len(handles)), LANES),
+                        mean_active_pairs_per_cell=tinfo["n_active_pairs"] / cells)
         steps = h["steps"]
         line = {
             "metric": "window x sample likelihood evals/sec", "value": h["value"], "unit": "window*sample/s",
@@ -474,6 +506,7 @@ def main():
             "stage1_ms_per_step": h["s1_ms"] / steps, "stage2_ms_per_step": h["s2_ms"] / steps,
             "calls_per_step": h["n_calls"] / steps, "candidate_cells_per_step": h["n_cand"] / steps,
             "max_life": tinfo["max_life"], "contexts_per_gpu": args.contexts, "pipelined_tickets": not args.serial,
+            "lanes_per_context": LANES, "tickets_in_flight": (1 if args.serial else (2 * LANES if LANES > 1 else 2)),
             # host arrays -> chunked layout -> HBM for one segment of all samples; with it inside every pass the rate
             # would be cells_per_pass / (stage_seconds + pass time): reported, never `value`
             "staging_seconds_per_segment": stage_seconds,
@@ -705,11 +738,16 @@ def main():
 
     def concurrent_leg():
         # the same step with several independent segments in flight on the GPU, one context and host thread each
+        # (plain contexts, no lanes: what a context with three lanes is measured against)
+        os.environ["POPDEL_HIP_LANES"] = "1"
         more = []
-        for _ in range(args.concurrent - 1):
-            c2 = capi.Context(hip, [rg] * (R * S), sample_offsets, device=local_rank)
-            more.append(Lane(c2, c2.stage(seg), args.serial))
-        all_lanes = lanes[:1] + more
+        try:
+            for _ in range(args.concurrent):
+                c2 = capi.Context(hip, [rg] * (R * S), sample_offsets, device=local_rank)
+                more.append(Lane(c2, c2.stage(seg), args.serial, depth=2))
+        finally:
+            os.environ["POPDEL_HIP_LANES"] = str(max(1, args.lanes))
+        all_lanes = more
         run_lanes(all_lanes, max(len(all_lanes), my_passes // 8))          # warm-up of the new contexts
         torch.cuda.synchronize()
         q0 = time.perf_counter()
@@ -751,6 +789,52 @@ def main():
                     value=total_passes * W * S / dt, unit="window*sample/s", ms_per_pass=dt / total_passes * 1e3,
                     stage1_ms_per_pass=acc[0] / total_passes, stage2_ms_per_pass=acc[1] / total_passes,
                     candidate_cells_per_pass=acc[3] / total_passes, calls_per_pass=acc[2] / total_passes, segments=info)
+
+    def one_segment_leg():
+        # the headline of rounds 1-3: the step as passes over ONE resident segment (615-bp deletion, 74 candidate cells),
+        # same context
+        l1 = Lane(ctx, handles[0], args.serial)
+        run_lanes([l1], max(4, total_passes // 8))
+        torch.cuda.synchronize()
+        q0 = time.perf_counter()
+        acc = run_lanes([l1], total_passes)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - q0
+        per_unit = 4.0 * seg_sizes[0][0] / (W * S) + 8
+        return dict(workload="%d samples x chr20 windows as %d passes over one resident segment (the headline of rounds 1-3)" % (S, total_passes),
+                    value=total_passes * W * S / dt, unit="window*sample/s", ms_per_pass=dt / total_passes * 1e3,
+                    whole_path_frac=total_passes * W * S / dt * per_unit / (HBM_PEAK_GBS * 1e9),
+                    stage1_ms_per_pass=acc[0] / total_passes, stage2_ms_per_pass=acc[1] / total_passes,
+                    candidate_cells_per_pass=acc[3] / total_passes, calls_per_pass=acc[2] / total_passes, planted_deletion=planted)
+
+    def plain_context_leg():
+        # the same step through a context WITHOUT lanes (POPDEL_HIP_LANES=1: the context of rounds 1-3, two tickets in flight)
+        os.environ["POPDEL_HIP_LANES"] = "1"
+        try:
+            c1 = capi.Context(hip, [rg] * S, list(range(S + 1)), device=local_rank)
+        finally:
+            os.environ["POPDEL_HIP_LANES"] = str(max(1, args.lanes))
+        # (its own staging of the same segments would double the resident set: it takes the first four)
+        hs = []
+        for k in range(min(4, len(handles))):
+            n_del = 0 if k % 5 == 2 else 1
+            f_k, W_k, o_k, a_k, _ = device_tile(S, 20260 + 1000 * k, device, args.coverage, n_deletions=n_del, **({"deletion_seed": 20260} if k == 0 else {}))
+            hs.append(c1.stage(capi.Segment(f_k, W_k, o_k, a_k["dev"], a_k["start"], a_k["on"], a_k["off"])))
+            del o_k, a_k
+        l1 = Lane(c1, hs, args.serial, depth=2)
+        n_pass = max(8, total_passes // 2)
+        run_lanes([l1], max(len(hs), n_pass // 8))
+        torch.cuda.synchronize()
+        q0 = time.perf_counter()
+        acc = run_lanes([l1], n_pass)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - q0
+        for hh in hs:
+            c1.unstage(hh)
+        c1.close()
+        return dict(workload="%d passes over the first %d of the headline's segments, one context without lanes, two tickets in flight" % (n_pass, len(hs)),
+                    value=n_pass * W * S / dt, unit="window*sample/s", ms_per_pass=dt / n_pass * 1e3,
+                    stage1_ms_per_pass=acc[0] / n_pass, stage2_ms_per_pass=acc[1] / n_pass, candidate_cells_per_pass=acc[3] / n_pass)
 
     def small_cohort_leg():
         # BASELINE configs[1]: 1,000 synthetic profiles x chr20 windows on one GPU
@@ -885,13 +969,21 @@ def main():
             o, a = take_samples(offsets, arrays, n * R)
             sg = capi.Segment(first, W, o, a["dev"], a["start"], a["on"], a["off"])
             n_pass = max(40, total_passes // 2)
-            row = dict(samples=n, passes=n_pass)
-            for kind in ("unsharded", "sharded"):
+            row = dict(samples=n, passes=n_pass, lanes=LANES)
+            # modelled_<d>us: the sharded path with the wire time of an exchange over xGMI injected behind every one of them
+            # (a one-wave kernel that holds the stream for d microseconds, POPDEL_HIP_XCH_DELAY_US): what a rank of a cohort
+            # sharded over several GPUs would see; modelled_efficiency = unsharded / modelled time per pass on the same samples
+            for kind in ("unsharded", "sharded", "modelled_20us", "modelled_40us"):
+                if kind.startswith("modelled"):
+                    os.environ["POPDEL_HIP_XCH_DELAY_US"] = kind[9:11]
                 if kind == "unsharded":
                     c2 = capi.Context(hip, [rg] * (R * n), sample_offsets[: n + 1], device=local_rank)
                     closer = c2.close
                 else:
-                    sh = distributed.SampleShard(hip, [rg] * (R * n), sample_offsets[: n + 1], 0, 1, device=local_rank, native=True)
+                    try:
+                        sh = distributed.SampleShard(hip, [rg] * (R * n), sample_offsets[: n + 1], 0, 1, device=local_rank, native=True)
+                    finally:
+                        os.environ.pop("POPDEL_HIP_XCH_DELAY_US", None)
                     c2, closer = sh.ctx, sh.close
                 l2 = Lane(c2, c2.stage(sg), args.serial)
                 l2.passes(5, new_acc())
@@ -907,10 +999,16 @@ def main():
                 if kind == "sharded":
                     row.update(exchange_ms_per_pass=acc[5] / n_pass, all_gathers_per_pass=acc[4]["n_all_gathers"],
                                all_gather_bytes_per_pass=acc[4]["all_gather_bytes"])
+                if kind.startswith("modelled"):
+                    row[kind + "_efficiency"] = row["unsharded_ms_per_pass"] / row[kind + "_ms_per_pass"]
             row["overhead_ms_per_pass"] = row["sharded_ms_per_pass"] - row["unsharded_ms_per_pass"]
+            row["modelled_ms_per_pass"] = row["modelled_40us_ms_per_pass"]
+            row["modelled_efficiency"] = row["modelled_40us_efficiency"]
             out.append(row)
         return dict(what="per pass over the resident segment: unsharded context vs. the sample-sharded path with a communicator of "
-                         "ONE rank (library RCCL; exchanges issued and event-timed, no wire)", rows=out)
+                         "ONE rank (library RCCL; exchanges issued and event-timed, no wire), and the same with 20 / 40 us of wire time "
+                         "injected behind every exchange (modelled_*: the latency model of a cohort sharded over several GPUs; "
+                         "modelled_efficiency = the 40-us row); all contexts with the bench's lanes", rows=out)
 
     def e2e_leg():
         # `popdel call` from profile FILES to a VCF (what a user of the reference runs): generated profiles of a 1-Mb
@@ -1009,7 +1107,10 @@ def main():
             m = re.search(r"steady state: segments (\d+) of (\d+); windows (\d+); samples (\d+); wall ([0-9.e+-]+) s; decode ([0-9.e+-]+) s; "
                           r"replay ([0-9.e+-]+) s; device kernels ([0-9.e+-]+) s", r.stderr)
             if not m:
-                raise RuntimeError("no steady-state line in the binary's timing output: %s" % r.stderr[-300:])
+                # (a cohort so small that every round was decoded before the GPU runtime had started)
+                return dict(workload="popdel call on %d generated profiles, chr20:%d-%d" % (n, region[0], region[1]), value=None,
+                            note="no round began after the backend was up: the run is over before the steady state starts",
+                            whole_run_wall_seconds=wall, whole_run_value=n * (region[1] - region[0]) / 30.0 / wall)
             segs, segs_all, windows, samples = (int(x) for x in m.groups()[:4])
             t_wall, t_decode, t_replay, t_device = (float(x) for x in m.groups()[4:])
             cpu = re.search(r"CPU time ([0-9.e+-]+) s user, ([0-9.e+-]+) s system", r.stderr)
@@ -1062,6 +1163,10 @@ def main():
             leg("sharded_world1", sharded_world1_leg)
         if args.concurrent > 1 and args.contexts == 1:
             leg("concurrent_segments", concurrent_leg)
+        if len(handles) > 1 and args.contexts == 1:
+            leg("one_segment", one_segment_leg)
+        if LANES > 1 and R == 1 and args.contexts == 1:
+            leg("plain_context", plain_context_leg)
         if args.small_cohort > 0:
             leg("small_cohort", small_cohort_leg)
         if args.distinct_segments > 0 and R == 1:

@@ -14,8 +14,10 @@
  *
  * Conventions: all functions return 0 on success, non-zero on error (pd_last_error() gives
  * text); no exceptions cross the boundary; a context is bound to one GPU and calls on one
- * context must be serialised by the caller. Tickets: at most TWO may be outstanding per context
- * (one running, one waiting), collected in the order issued; see pd_segment_run(). Pointers
+ * context must be serialised by the caller. Tickets: at most two PER LANE may be outstanding per context
+ * (a context has three lanes unless POPDEL_HIP_LANES says otherwise; a plain context -- one lane -- and a
+ * cohort sharded over several ranks take two: one running, one waiting), collected in the order issued;
+ * see pd_segment_run(). Pointers
  * passed in are caller-owned host memory unless stated otherwise; pd_calls is callee-owned
  * until pd_calls_free().
  *
@@ -150,9 +152,13 @@ int pd_segment_submit(pd_ctx *ctx, const pd_segment *seg, uint64_t *ticket);
  * loop for a staged segment (may be repeated), pd_segment_unstage() releases it.
  * pd_segment_submit(seg) == stage + run + unstage-after-collect. No reference counterpart (the reference computes
  * in place on the host).
- * Tickets: at most two may be outstanding per context, collected in the order issued. Issuing the next ticket BEFORE
- * collecting the open one lets the library start the next segment's scan right behind the open segment's last kernel,
- * underneath the device-to-host copy of its results (software pipelining across segments). */
+ * Tickets: at most two per lane may be outstanding per context, collected in the order issued. Issuing the next ticket
+ * BEFORE collecting the open one lets the library start the next segment's scan right behind the open segment's last
+ * kernel, underneath the device-to-host copy of its results (software pipelining across segments); with lanes
+ * (POPDEL_HIP_LANES, default 3: child contexts that take the tickets in turn, each driven by a host thread of the
+ * library's) several segments' stage 2 run side by side and fill each other's gaps -- a host that wants the context's
+ * full rate keeps 2 x lanes tickets in flight. With columns kept on the device (pd_ctx_keep_results_on_device) one
+ * ticket per lane. */
 int pd_segment_stage(pd_ctx *ctx, const pd_segment *seg, uint64_t *handle);
 int pd_segment_run(pd_ctx *ctx, uint64_t handle, uint64_t *ticket);
 int pd_segment_unstage(pd_ctx *ctx, uint64_t handle);

@@ -310,6 +310,7 @@ struct LanesState
     std::map<uint64_t, LaneResult> results;     // by ticket: everything outstanding
     bool stop = false;
     unsigned lastLane = 0;              // lane of the most recently collected ticket (pd_stage1_last)
+    std::vector<uint64_t> repeatedSeen; // per lane: its cumulative count of repeated stage-2 batches as last reported
 };
 
 // Contexts of one process that exchange among themselves (pd_ctx_set_shard_local).
@@ -394,6 +395,8 @@ struct pd_ctx
     bool deviceLists = true;              // POPDEL_HIP_HOST_LISTS=1: the host forms the flagged-window and cell lists
     // stage 2 launched without waiting for the pool sizes (see pd_segment_collect); POPDEL_HIP_EXACT_POOLS=1 turns it off
     bool optimisticPools = true;
+    size_t stage2Budget = static_cast<size_t>(24) << 30;    // bytes of per-(cell, sample) buffers per stage-2 batch (POPDEL_HIP_STAGE2_BYTES)
+    bool shardSettingsChecked = false;    // sharded over several ranks: the first collect compares the ranks' settings
     bool genericSeen = false;             // some segment needed the generic stage-2 kernels
     uint64_t nRepeatedBatches = 0;
     // device-side layout build (build.hip): the uploaded instances and the small tables around them
@@ -412,7 +415,7 @@ struct pd_ctx
     DevBuf<unsigned long long> dLifeHist;
     DevBuf<unsigned> dProblems;
     PinnedBuf<unsigned long long> hLifeHist, hLifeXch;
-    PinnedBuf<uint64_t> hTotals;
+    PinnedBuf<uint64_t> hTotals, hShardCheck;
     PinnedBuf<uint32_t> hEntMax;
     // the window loop in closed form (pd_walk_submit, walk.hip): the state that goes from segment to segment, in two sets
     // (a segment's kernel reads one and writes the other), and the staging of the loader's tables
@@ -1396,8 +1399,10 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
 {
     if (int rc = createContext(cfg, rgs, n_readgroups, sample_rg_offsets, n_samples, device, out))
         return rc;
-    // POPDEL_HIP_LANES = K > 1: K lanes behind this context (LanesState)
-    unsigned k = 1;
+    // K lanes behind this context (LanesState): three by default -- measured on 10,000 samples x 6,667 windows: 2.28 / 2.08 /
+    // 1.92 / 2.00 ms per pass with 1 / 2 / 3 / 4 lanes (profiles/r04_b_lanes_probe.json); POPDEL_HIP_LANES = 1 gives the plain
+    // context of rounds 1-3
+    unsigned k = 3;
     if (const char * e = getenv("POPDEL_HIP_LANES"))
         k = static_cast<unsigned>(std::max(1, std::min(8, atoi(e))));
     if (k < 2)
@@ -1571,6 +1576,8 @@ static int createContext(const pd_config * cfg, const pd_readgroup * rgs, uint32
             c->deviceLists = atoi(e) == 0;
         if (const char * e = getenv("POPDEL_HIP_PLAIN_UPLOAD"))
             c->compactUpload = atoi(e) == 0;
+        if (const char * e = getenv("POPDEL_HIP_STAGE2_BYTES"))
+            c->stage2Budget = static_cast<size_t>(std::max(1.0, atof(e)));
         pd::buildLogTables(c->dHist.p, c->dTab.p, c->dTab2.p, pool.size(), c->dRg.p, n_readgroups, c->stream);
         PD_HIP(hipGetLastError());
         PD_HIP(hipStreamSynchronize(c->stream));
@@ -1914,8 +1921,14 @@ static int laneCollect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
     LaneResult r = std::move(it->second);
     L.results.erase(it);
     L.lastLane = r.lane;
+    L.repeatedSeen.resize(L.workers.size(), 0);
+    L.repeatedSeen[r.lane] = r.timing.n_repeated_batches;
+    uint64_t repeated = 0;
+    for (uint64_t v : L.repeatedSeen)
+        repeated += v;
     lock.unlock();
     c->timing = r.timing;
+    c->timing.n_repeated_batches = repeated;            // (cumulative over the context = over its lanes)
     if (r.rc != 0)
     {
         c->error = r.error;
@@ -2583,6 +2596,40 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         PD_HIP(hipEventCreate(&s2End));
 
         CtxExchange xch(*c);
+        if (c->sharded && c->world > 1 && !c->shardSettingsChecked)
+        {
+            // The contexts of a cohort take the same decisions only if they were set up alike: calling parameters, the byte
+            // budget that cuts stage 2 into batches, which lists and pools are formed where. One exchange at the first
+            // segment compares a fingerprint of them; ranks that differ fail here instead of hanging in mismatched exchanges.
+            uint64_t fp = 1469598103934665603ull;
+            auto mix = [&fp](const void * p, size_t n) {
+                const uint8_t * b = static_cast<const uint8_t *>(p);
+                for (size_t i = 0; i < n; ++i)
+                    fp = (fp ^ b[i]) * 1099511628211ull;
+            };
+            const uint64_t budgetWord = c->stage2Budget;
+            const uint32_t words[8] = {c->cfg.iterations, c->cfg.min_len, (uint32_t)c->cfg.somatic, (uint32_t)c->cfg.window_wise_output,
+                                       c->optimisticPools ? 1u : 0u, c->deviceLists ? 1u : 0u, c->nSamplesGlobal, (uint32_t)PD_ABI_VERSION};
+            mix(&budgetWord, sizeof(budgetWord));
+            mix(words, sizeof(words));
+            mix(&c->cfg.min_likelihood_ratio, sizeof(double));
+            mix(&c->cfg.min_sample_fraction, sizeof(double));
+            const size_t per = 256;
+            uint8_t * area = reserveArena(*c, per * c->world);
+            PinnedBuf<uint64_t> & h = c->hShardCheck;
+            h.resize(static_cast<size_t>(c->world) * (per / sizeof(uint64_t)));
+            h[0] = fp;
+            PD_HIP(hipMemcpyAsync(area + static_cast<size_t>(c->rank) * per, h.data(), sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+            xch.allGather(area, per);
+            PD_HIP(hipMemcpyAsync(h.data(), area, per * c->world, hipMemcpyDeviceToHost, c->stream));
+            PD_HIP(hipStreamSynchronize(c->stream));
+            for (uint32_t r = 0; r < c->world; ++r)
+                if (h[static_cast<size_t>(r) * (per / sizeof(uint64_t))] != fp)
+                    throw HipError{"the contexts of the sharded cohort were set up differently (calling parameters, POPDEL_HIP_STAGE2_BYTES, "
+                                   "POPDEL_HIP_EXACT_POOLS or POPDEL_HIP_HOST_LISTS differ between rank " + std::to_string(c->rank) + " and rank " +
+                                   std::to_string(r) + ")"};
+            c->shardSettingsChecked = true;
+        }
         c->nAllGathers = 0;
         c->allGatherBytes = 0;
         c->xchEventsUsed = 0;
@@ -2746,9 +2793,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         std::vector<unsigned> emit;
         uint64_t likUnits = 0;          // (cell, sample) units of the last batch's data-likelihood launch ahead of the loop
         const unsigned nCells = (unsigned)cells.size();
-        size_t budget = static_cast<size_t>(24) << 30;
-        if (const char * e = getenv("POPDEL_HIP_STAGE2_BYTES"))
-            budget = static_cast<size_t>(std::max(1.0, atof(e)));
+        const size_t budget = c->stage2Budget;
         // (from the samples per context of the partition, not from this context's own count: all contexts of a sharded
         // cohort must cut the cell list at the same places, the exchanges run per batch)
         const size_t bytesPerCell = static_cast<size_t>(sper) * (2 * pd::kDenseCap * 2 + 24 + 52 + 2 + 24) + 4096;

@@ -39,8 +39,9 @@ enum Status : uint32_t
 };
 
 constexpr unsigned kMaxBits = 15, kLitLenCodes = 288, kDistCodes = 30, kCodeLengths = 320;
-// 16-bit table words per decoder: lenCount[16] lenSymbol[288] distCount[16] distSymbol[30] offs[16]
-constexpr unsigned kTabLenCount = 0, kTabLenSymbol = 16, kTabDistCount = 304, kTabDistSymbol = 320, kTabOffs = 350, kTabWords = 366;
+// 16-bit table words per decoder: lenCount[16] lenSymbol[288] distCount[16] distSymbol[30] offs[16] lenBase[16] distBase[16]
+constexpr unsigned kTabLenCount = 0, kTabLenSymbol = 16, kTabDistCount = 304, kTabDistSymbol = 320, kTabOffs = 350, kTabLenBase = 366,
+                   kTabDistBase = 382, kTabWords = 398;
 
 // Plain-array tables (host; one decoder).
 struct FlatTables
@@ -64,22 +65,43 @@ struct StridedTables
 struct BitReader
 {
     const uint8_t * in;
-    uint64_t pos, end;
+    uint64_t pos, end;     // pos: first byte that is neither in `buf` nor in `ahead`
     uint64_t buf;
     unsigned cnt;
+    uint32_t ahead;        // the next four input bytes, loaded when the previous word went into `buf`: the load's latency
+    bool     haveAhead;    // passes while the decoder works through the bits it has (a lane has nothing else to hide it)
     bool     shortInput;
 
+    PD_INF_FN void start(const uint8_t * data, uint64_t from, uint64_t to)
+    {
+        in = data;
+        pos = from;
+        end = to;
+        buf = 0;
+        cnt = 0;
+        ahead = 0;
+        haveAhead = false;
+        shortInput = false;
+        fetchAhead();
+    }
+    PD_INF_FN void fetchAhead()
+    {
+        haveAhead = pos + 4u <= end;
+        if (haveAhead)
+        {
+            __builtin_memcpy(&ahead, in + pos, 4);
+            pos += 4u;
+        }
+    }
     PD_INF_FN void refill()
     {
         if (cnt <= 32u)
         {
-            if (pos + 4u <= end)
+            if (haveAhead)
             {
-                uint32_t v;
-                __builtin_memcpy(&v, in + pos, 4);
-                buf |= (uint64_t)v << cnt;
-                pos += 4u;
+                buf |= (uint64_t)ahead << cnt;
                 cnt += 32u;
+                fetchAhead();
             }
             else
             {
@@ -112,7 +134,7 @@ struct BitReader
         cnt -= drop;
     }
     // offset of the first byte that has not been consumed (call after alignToByte)
-    PD_INF_FN uint64_t bytePos() const { return pos - (cnt >> 3); }
+    PD_INF_FN uint64_t bytePos() const { return pos - (haveAhead ? 4u : 0u) - (cnt >> 3); }
 };
 
 // One symbol of a canonical code (counts at countAt + 1 .. 15, symbols at symbolAt): -1 if the bits are no code of the set,
@@ -174,6 +196,71 @@ PD_INF_FN int buildCode(Tab & tab, unsigned from, unsigned n, unsigned countAt, 
     return left;
 }
 
+// A canonical code as the symbol loop wants it: limit[len] = one past the last code of length len, left-aligned to 15 bits
+// (non-decreasing in len), in REGISTERS (every use below is unrolled); base[len] = index of the length's first symbol minus
+// its first code, in the table words at baseAt (biased by 0x8000). One symbol then costs a bit reversal, fifteen compares and
+// two dependent table reads instead of one table read per code bit.
+struct FastCode
+{
+    uint32_t limit[kMaxBits + 1];
+};
+
+template <class Tab>
+PD_INF_FN void buildFast(Tab & tab, unsigned countAt, unsigned baseAt, FastCode & fc)
+{
+    uint32_t first = 0, index = 0;
+    fc.limit[0] = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (unsigned len = 1; len <= kMaxBits; ++len)
+    {
+        const uint32_t count = tab.w(countAt + len);
+        tab.w(baseAt + len) = (uint16_t)(0x8000u + index - first);
+        first += count;
+        fc.limit[len] = first << (kMaxBits - len);
+        index += count;
+        first <<= 1;
+    }
+}
+
+PD_INF_FN uint32_t reverse15(uint32_t v)
+{
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bitreverse32(v) >> 17;
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < 15; ++i)
+        r |= ((v >> i) & 1u) << (14 - i);
+    return r;
+#endif
+}
+
+// -1: the bits are no code of the set; -2: the input ends inside the code
+template <class Tab>
+PD_INF_FN int decodeFast(BitReader & br, Tab & tab, const FastCode & fc, unsigned baseAt, unsigned symbolAt)
+{
+    br.refill();
+    const uint32_t v = reverse15((uint32_t)br.buf & 0x7fffu);          // (bits beyond the input read as zeros)
+    unsigned len = 1;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (unsigned k = 1; k <= kMaxBits; ++k)
+        len += v >= fc.limit[k] ? 1u : 0u;
+    if (len > kMaxBits)
+        return -1;
+    if (len > br.cnt)
+    {
+        br.shortInput = true;
+        return -2;
+    }
+    br.buf >>= len;
+    br.cnt -= len;
+    const uint32_t code = v >> (kMaxBits - len);
+    return tab.w(symbolAt + ((code + tab.w(baseAt + len) - 0x8000u) & 0xffffu));
+}
+
 struct Output
 {
     uint8_t * out;
@@ -192,9 +279,12 @@ struct Output
 template <class Tab>
 PD_INF_FN uint32_t inflateCodes(BitReader & br, Output & o, Tab & tab)
 {
+    FastCode lenCode, distCode;
+    buildFast(tab, kTabLenCount, kTabLenBase, lenCode);
+    buildFast(tab, kTabDistCount, kTabDistBase, distCode);
     for (;;)
     {
-        int sym = decodeSymbol(br, tab, kTabLenCount, kTabLenSymbol);
+        int sym = decodeFast(br, tab, lenCode, kTabLenBase, kTabLenSymbol);
         if (sym < 0)
             return sym == -2 ? kTruncated : kBadCode;
         if (sym < 256)
@@ -220,7 +310,7 @@ PD_INF_FN uint32_t inflateCodes(BitReader & br, Output & o, Tab & tab)
             const unsigned ext = ((unsigned)sym >> 2) - 1u;
             len = 3u + ((4u + ((unsigned)sym & 3u)) << ext) + br.bits(ext);
         }
-        const int dsym = decodeSymbol(br, tab, kTabDistCount, kTabDistSymbol);
+        const int dsym = decodeFast(br, tab, distCode, kTabDistBase, kTabDistSymbol);
         if (dsym < 0)
             return dsym == -2 ? kTruncated : kBadCode;
         if (dsym >= 30)
@@ -394,12 +484,7 @@ PD_INF_FN uint32_t inflateGzipMember(const uint8_t * in, uint64_t inLen, uint8_t
     if (p >= inLen)
         return kTruncated;
     BitReader br;
-    br.in = in;
-    br.pos = p;
-    br.end = inLen;
-    br.buf = 0;
-    br.cnt = 0;
-    br.shortInput = false;
+    br.start(in, p, inLen);
     Output o;
     o.out = out;
     o.n = 0;

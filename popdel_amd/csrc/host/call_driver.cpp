@@ -355,6 +355,9 @@ private:
 
 void CallRun::createBackend()
 {
+    // (one segment is in flight here at a time -- the device works a per cent of a host round -- so the context's lanes would
+    // only cost their set-up: one lane unless the user asks)
+    setenv("POPDEL_HIP_LANES", "1", 0);
     std::vector<pd_readgroup> rgs(p_.histograms.size());
     for (size_t i = 0; i < rgs.size(); ++i)
     {

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 def test_bench_line_has_the_contract_fields(built):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--samples", "512", "--passes", "3", "--steps", "2",
                           "--warmup", "1", "--cpu-samples", "40", "--cpu-threads", "2", "--stream-segments", "2", "--small-cohort", "128",
-                          "--dense-deletions", "3", "--e2e-samples", "24", "--sharded-world1", "256,0", "--distinct-segments", "3"],
+                          "--dense-deletions", "3", "--e2e-samples", "24", "--sharded-world1", "256,0", "--distinct-segments", "3",
+                          "--resident-segments", "3", "--e2e-cohort-samples", "32", "--e2e-cohort-mb", "1", "--inflate-members", "600"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -52,9 +53,24 @@ def test_bench_line_has_the_contract_fields(built):
     assert [x["samples"] for x in rows] == [256, 512]
     for x in rows:
         assert x["all_gathers_per_pass"] >= 9 and x["exchange_ms_per_pass"] > 0 and x["sharded_ms_per_pass"] > 0 and x["unsharded_ms_per_pass"] > 0
-    # the headline's step over several different resident segments (one of them without a deletion)
+        # ... and with the wire time of an exchange injected behind every one of them (the latency model of several GPUs)
+        assert x["modelled_40us_ms_per_pass"] > x["sharded_ms_per_pass"] and 0 < x["modelled_efficiency"] == x["modelled_40us_efficiency"]
+        assert x["modelled_20us_ms_per_pass"] > 0 and x["lanes"] == d["lanes_per_context"]
+    # the headline's passes take several different resident segments in turn (the third of five has no deletion); the
+    # single re-scanned segment of rounds 1-3 and the context without lanes are legs
+    assert d["lanes_per_context"] == 3 and d["tickets_in_flight"] == 6
+    assert d["config"]["candidate_cells_per_segment"][2] == 0 and len(d["config"]["planted_deletion"]) == 3
+    assert d["one_segment"]["value"] > 0 and 0 < d["one_segment"]["whole_path_frac"] < 1
+    assert d["plain_context"]["value"] > 0
+    assert d["roofline"]["mean_launch_ms"] > 0 and d["roofline"]["mean_launch_ms_in_timed_region"] > 0
     ds = d["distinct_segments"]
     assert ds["value"] > 0 and len(ds["segments"]) == 3 and ds["segments"][-1]["del_len"] is None
+    # gunzip of profile blocks on the device against the host's libdeflate path: same bytes
+    g = d["device_gunzip"]
+    assert g["members"] == 600 and g["all_accepted"] and g["identical_to_host"] and g["kernel_ms"] > 0 and g["host_seconds"] > 0
+    # the cohort-scale end-to-end leg (here a toy cohort: over before the steady state starts, or with its figures)
+    ec = d["e2e_cohort"]
+    assert "error" not in ec and ec["whole_run_wall_seconds"] > 0 and (ec["value"] is None or ec["steady_seconds_per_segment"] > 0)
     # end to end: the product binary on profile files, the oracle-backed driver beside it, same VCF
     e = d["e2e"]
     assert e["value"] > 0 and e["wall_seconds"] > 0 and "decode" in e["phases_seconds"]

@@ -183,10 +183,12 @@ def test_wide_q3_range_takes_the_sorting_path(built):
     assert_same(gpu, cpu)
 
 
-def test_two_tickets_pipelined_equal_sequential(built):
+def test_two_tickets_pipelined_equal_sequential(built, monkeypatch):
     """A second ticket may be issued before the open one is collected (its scan then starts underneath the result copy
-    of the open one); results must equal the one-at-a-time order, a third ticket and out-of-order collects are refused."""
+    of the open one); results must equal the one-at-a-time order, a third ticket and out-of-order collects are refused.
+    (A plain context, one lane: tests/test_gpu_lanes.py has the same for contexts with lanes.)"""
     from popdel_amd import capi, synth
+    monkeypatch.setenv("POPDEL_HIP_LANES", "1")
     lib = synth.Library()
     rg = synth.conditioned_readgroup(lib)
     n = 20
