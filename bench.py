@@ -1030,6 +1030,7 @@ def main():
 
             def call(binary, out, threads):
                 env = dict(os.environ, POPDEL_TIMING="1")
+                env.pop("POPDEL_HIP_LANES", None)          # (the binary's own default: one lane)
                 if threads:
                     env["POPDEL_THREADS"] = str(threads)
                 q = time.perf_counter()
@@ -1098,6 +1099,7 @@ def main():
             t_write = time.perf_counter() - q0
             product = os.path.join(ROOT, "popdel_amd", "lib", "popdel")
             env = dict(os.environ, POPDEL_TIMING="1")
+            env.pop("POPDEL_HIP_LANES", None)              # (the binary's own default: one lane)
             q = time.perf_counter()
             r = subprocess.run([product, "call", lst, "-o", os.path.join(d, "out.vcf"), "-r", "chr20:%d-%d" % region], env=env,
                                capture_output=True, text=True, timeout=600)

@@ -289,6 +289,7 @@ struct LaneJob
 struct LaneResult
 {
     bool done = false;
+    uint64_t handle = 0;
     int rc = 0;
     pd_calls * calls = nullptr;
     std::string error;
@@ -379,6 +380,11 @@ struct pd_ctx
     // above against its lanes' threads
     pd_ctx * owner = nullptr;
     std::mutex stagedLock;
+    // Lanes share the chip well while stage 2 is a string of short launches; a candidate-rich segment's stage 2 fills the chip
+    // by itself (its kernels are bound by the rate of table gathers), and two of them side by side only evict each other's
+    // tables (measured: 45 ms per candidate-dense pass with three lanes against 27 with one). A lane whose segment has more
+    // than kHeavyUnits (cell, sample) units therefore takes this lock for the length of its stage 2.
+    std::mutex heavyStage2;
     std::unique_ptr<LanesState> lanes;
     // host-side scratch of pd_segment_stage(), kept between calls
     PinnedBuf<pd::PairDO> hPairs;
@@ -542,7 +548,7 @@ void givePinned(PinnedBlock b)
         // keep the four LARGEST blocks seen: a full pool of small blocks (earlier, smaller segments) must not send every
         // large result block of a later segment through hipHostMalloc / hipHostFree (~70 ms for 0.5 GB)
         std::lock_guard<std::mutex> guard(g_pinnedLock);
-        if (g_pinnedPool.size() < 4)
+        if (g_pinnedPool.size() < 8)           // (a context with three lanes has up to six results in flight)
         {
             g_pinnedPool.push_back(b);
             return;
@@ -1423,6 +1429,8 @@ int pd_ctx_create(const pd_config * cfg, const pd_readgroup * rgs, uint32_t n_re
         c->lanes->workers.back()->ctx = lane;
     }
     c->lanes->active = k;
+    // (measured and dropped: the lanes' scans one after the other on ONE shared low-priority stream instead of each on its
+    // lane's stream -- 2.32 ms per pass against 1.92 with three lanes, profiles/r04_c_lanes_probe.json)
     for (unsigned i = 0; i < k; ++i)
         c->lanes->workers[i]->thread = std::thread(laneLoop, c, i);
     return 0;
@@ -1882,6 +1890,7 @@ static void laneLoop(pd_ctx * parent, unsigned k)
         r.done = true;
         {
             std::lock_guard<std::mutex> lock(L.m);
+            r.handle = L.results[o.ticket].handle;
             L.results[o.ticket] = std::move(r);
         }
         L.done.notify_all();
@@ -1899,6 +1908,7 @@ static int laneRun(pd_ctx * c, uint64_t handle, uint64_t * ticket)
         return fail(c, "pd_segment_run: too many tickets outstanding (collect the oldest one first)");
     *ticket = c->nextTicket++;
     L.results[*ticket] = LaneResult();
+    L.results[*ticket].handle = handle;
     LaneJob job;
     job.ticket = *ticket;
     job.handle = handle;
@@ -1938,14 +1948,14 @@ static int laneCollect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
     return 0;
 }
 
-// until no lane has work left (results stay where they are: collect takes them)
-static void laneDrain(pd_ctx * c)
+// until no lane has a ticket for segment `handle` left to run (results stay where they are: collect takes them)
+static void laneDrain(pd_ctx * c, uint64_t handle)
 {
     LanesState & L = *c->lanes;
     std::unique_lock<std::mutex> lock(L.m);
     L.done.wait(lock, [&] {
         for (const auto & r : L.results)
-            if (!r.second.done)
+            if (!r.second.done && r.second.handle == handle)
                 return false;
         return true;
     });
@@ -2132,7 +2142,7 @@ static void launchScan(pd_ctx * c, Run & run)
         fprintf(stderr, "[popdel_hip] stage 1: %u 512-window blocks through the 128-candidate kernel, %zu of %zu 256-window tiles through the "
                         "32-bit fallback kernel (K=%u, densest block %u chunks)\n", nBig, nTodo, tiles, s.maxLife, s.maxBlockChunks);
     }
-    if (c->scanStream)
+    if (st != c->stream)
     {
         if (!run.scanDone)
             PD_HIP(hipEventCreateWithFlags(&run.scanDone, hipEventDisableTiming));
@@ -2191,7 +2201,7 @@ int pd_segment_unstage(pd_ctx * c, uint64_t handle)
         return 1;
     (void)hipSetDevice(c->device);
     if (c->lanes)
-        laneDrain(c);               // no lane may still be running the segment
+        laneDrain(c, handle);       // no lane may still be running the segment
     (void)hipStreamSynchronize(c->stream);
     if (c->scanStream)
         (void)hipStreamSynchronize(c->scanStream);
@@ -2793,6 +2803,10 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         std::vector<unsigned> emit;
         uint64_t likUnits = 0;          // (cell, sample) units of the last batch's data-likelihood launch ahead of the loop
         const unsigned nCells = (unsigned)cells.size();
+        constexpr uint64_t kHeavyUnits = 5000000;
+        std::unique_lock<std::mutex> heavy;
+        if (c->owner && static_cast<uint64_t>(nCells) * S > kHeavyUnits)
+            heavy = std::unique_lock<std::mutex>(c->owner->heavyStage2);
         const size_t budget = c->stage2Budget;
         // (from the samples per context of the partition, not from this context's own count: all contexts of a sharded
         // cohort must cut the cell list at the same places, the exchanges run per batch)
@@ -3070,6 +3084,8 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
             std::memcpy(hFl, accFl.data(), accFl.size() * sizeof(uint32_t));
         }
         PD_HIP(hipEventSynchronize(s2End));
+        if (heavy.owns_lock())
+            heavy.unlock();
         PD_HIP(hipStreamSynchronize(c->copyStream));
 
         float ms1 = 0, ms2 = 0;

@@ -295,7 +295,7 @@ private:
         if (backendError_)                      // (to every caller: the hand-over thread may be the first to ask)
             std::rethrow_exception(backendError_);
     }
-    bool deviceWalkOffered_ = false, deviceWalk_ = false;
+    bool deviceWalkOffered_ = false, deviceWalk_ = false, lightTables_ = false;
     unsigned deviceSegments_ = 0, hostSegments_ = 0;
     void leaveDeviceWalk();
     void submitPlannedSegment(const WalkShape & shape, const std::vector<uint8_t> & equalRun, const std::vector<uint8_t> & switches);
@@ -1446,6 +1446,7 @@ void CallRun::leaveDeviceWalk()
     ensureBackend();
     drainHandOver();
     ChromProfile & prof = *profile_;
+    prof.setLightEnds(false);           // the window loop comes back to the host: it walks ordered end tables
     for (size_t r = 0; r < ctxs_.size(); ++r)
     {
         uint64_t n = 0;
@@ -1549,6 +1550,8 @@ bool CallRun::finalizeRoi()
         {
             profile_->setActiveKnownEmpty(true);
             deviceWalk_ = true;
+            if (lightTables_)
+                profile_->setLightEnds(true);
         }
     }
     nextReadPos_ = kNoPos;
@@ -1625,6 +1628,11 @@ int CallRun::run()
         profile_->enableActiveOpLog();
     profile_->currentPos = windows_.current.pos;
     profile_->resetTo(profile_->currentPos);
+    // (while the device runs the window loop nobody walks the end tables: they are kept as counts per window -- EndSlots,
+    // chrom_profile.h; POPDEL_HEAVY_TABLES=1 keeps the ordered arrays, A/B runs)
+    lightTables_ = !getenv("POPDEL_HEAVY_TABLES");
+    if (deviceWalk_ && lightTables_)
+        profile_->setLightEnds(true);
     if (getenv("POPDEL_WALK_CHECK"))
         walkCheck_.reset(new WalkReference(static_cast<unsigned>(p_.readGroups.size())));
     profile_->externalActive = [this]() -> size_t {

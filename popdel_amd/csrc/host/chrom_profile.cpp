@@ -104,12 +104,224 @@ bool EndSlots::switchRead()
     return !readAtEnd();
 }
 
+// ---- light slots ---------------------------------------------------------------------------------------------------------
+namespace {
+// bins of a slot's histogram: from a little below the slot's left border (right - numWindows) to well beyond its right one
+// (records are filed one slot ahead when their pair ends beyond the write slot); a record outside sends the read group back
+// to heavy tables
+constexpr unsigned kBinsBelow = 256, kBinsAbove = 2304;
+}
+
+void EndSlots::prepareHist(Slot & slot)
+{
+    const unsigned nBins = numWindows / 30u + 2u + kBinsBelow + kBinsAbove;
+    if (slot.hist.size() != nBins)
+    {
+        slot.hist.assign(nBins, 0);
+        slot.lowBin = slot.highBin = 0;
+    }
+    const unsigned leftBin = slot.right >= numWindows ? (slot.right - numWindows) / 30u : 0u;
+    slot.baseBin = leftBin >= kBinsBelow ? leftBin - kBinsBelow : 0u;
+}
+
+void EndSlots::addLight(Slot & slot, unsigned id, unsigned lastWin)
+{
+    if (slot.entries.empty() && slot.highBin == 0)
+        prepareHist(slot);
+    const unsigned bin = lastWin / 30u;
+    if (bin < slot.baseBin || bin - slot.baseBin >= slot.hist.size() || slot.hist[bin - slot.baseBin] == 0xffffu)
+    {
+        // a pair that ends outside the windows a slot's counts cover (or 65,535 pairs ending in one window): this read
+        // group keeps ordered tables from here on
+        leaveLight();
+        slot.entries.insert(std::upper_bound(slot.entries.begin(), slot.entries.end(), lastWin,
+                                             [](unsigned w, const EndEntry & e) { return w < e.lastWindow; }),
+                            EndEntry{id, lastWin});
+        return;
+    }
+    const unsigned b = bin - slot.baseBin;
+    if (slot.entries.empty())
+    {
+        slot.lowBin = b;
+        slot.highBin = b + 1;
+        slot.maxWin = lastWin;
+    }
+    else
+    {
+        slot.ordered = slot.ordered && lastWin >= slot.entries.back().lastWindow;
+        slot.lowBin = std::min(slot.lowBin, b);
+        slot.highBin = std::max(slot.highBin, b + 1);
+        slot.maxWin = std::max(slot.maxWin, lastWin);
+    }
+    ++slot.hist[b];
+    for (int side = 0; side < 2; ++side)
+        if (b < slot.curBin[side])
+            ++slot.curCum[side];
+    slot.entries.push_back(EndEntry{id, lastWin});
+}
+
+// entries of the slot with lastWindow < pos (last windows are multiples of 30)
+unsigned EndSlots::lessCount(Slot & slot, unsigned pos, int side)
+{
+    if (slot.entries.empty())
+        return 0;
+    const unsigned bins = (pos + 29u) / 30u;                     // windows 0 .. bins-1 end before pos
+    unsigned t = bins > slot.baseBin ? bins - slot.baseBin : 0u;
+    t = std::min<unsigned>(t, static_cast<unsigned>(slot.hist.size()));
+    unsigned & cb = slot.curBin[side];
+    unsigned & cc = slot.curCum[side];
+    if (t < cb)
+    {
+        cb = 0;
+        cc = 0;
+    }
+    // (nothing below lowBin, nothing from highBin on)
+    unsigned from = std::max(cb, slot.lowBin), to = std::min(t, slot.highBin);
+    for (unsigned b = from; b < to; ++b)
+        cc += slot.hist[b];
+    cb = t;
+    return cc;
+}
+
+// getEndCount() on counts: the loop over entries of the ordered array, taken a slot at a time -- entry i of the ordered
+// array ends before `win` exactly if i < lessCount(win).
+unsigned EndSlots::countEndedLight(unsigned pos)
+{
+    bool lookAhead = false;
+    unsigned i = dNext;
+    unsigned c = 0;
+    unsigned cSlot = endPosSlot;
+    unsigned n = static_cast<unsigned>(slots[cSlot].entries.size());
+    if (i == n)
+    {
+        if (endPosSlot != writeSlot)
+        {
+            endPosSlot = (endPosSlot + 1) % 3;
+            dNext = dNextOffset;
+            dNextOffset = 0;
+            i = dNext;
+            cSlot = endPosSlot;
+            n = static_cast<unsigned>(slots[cSlot].entries.size());
+        }
+        else
+        {
+            return 0;
+        }
+    }
+    if (n == 0)
+        return 0;
+    const unsigned win = posToWin(pos);
+    for (;;)
+    {
+        const unsigned below = lessCount(slots[cSlot], win, 0);
+        if (!(i < n && i < below))
+            break;
+        const unsigned k = std::min(n, below) - i;
+        if (lookAhead)
+            dNextOffset += k;
+        c += k;
+        i += k;
+        if (i != n)
+            break;
+        if (endPosSlot != writeSlot)
+        {
+            endPosSlot = (endPosSlot + 1) % 3;
+            dNext = dNextOffset;
+            dNextOffset = 0;
+            return c;
+        }
+        cSlot = (cSlot + 1) % 3;
+        n = static_cast<unsigned>(slots[cSlot].entries.size());
+        if (n == 0)
+            break;
+        i = dNextOffset;
+        lookAhead = true;
+    }
+    dNext += c - dNextOffset;
+    return c;
+}
+
+void EndSlots::leaveLight()
+{
+    if (!light)
+        return;
+    light = false;
+    for (Slot & s : slots)
+        if (!s.ordered)
+        {
+            std::stable_sort(s.entries.begin(), s.entries.end(), [](const EndEntry & a, const EndEntry & b) { return a.lastWindow < b.lastWindow; });
+            s.ordered = true;
+        }
+}
+
+void EndSlots::setLight(bool on)
+{
+    if (on == light)
+        return;
+    if (!on)
+    {
+        leaveLight();
+        return;
+    }
+    light = true;
+    for (Slot & s : slots)
+    {
+        // (entries are ordered: heavy tables) -> counts
+        for (unsigned b = s.lowBin; b < s.highBin && b < s.hist.size(); ++b)
+            s.hist[b] = 0;
+        s.lowBin = s.highBin = 0;
+        s.curBin[0] = s.curBin[1] = s.curCum[0] = s.curCum[1] = 0;
+        s.ordered = true;
+        if (s.entries.empty())
+            continue;
+        prepareHist(s);
+        HugeVector<EndEntry> kept;
+        kept.swap(s.entries);
+        for (const EndEntry & e : kept)
+        {
+            addLight(s, e.id, e.lastWindow);
+            if (!light)                         // (a record outside the counts' range: this read group stays heavy)
+            {
+                s.entries.swap(kept);
+                return;
+            }
+        }
+    }
+}
+
+void EndSlots::advanceReadTo(unsigned pos, unsigned shift)
+{
+    Slot & slot = slots[readSlot];
+    const size_t n = slot.entries.size();
+    const size_t from = std::min(readIdx, n);
+    if (light)
+    {
+        const size_t over = pos > shift ? lessCount(slot, pos - shift, 1) : 0u;
+        readIdx = std::max(from, over);
+        return;
+    }
+    readIdx = static_cast<size_t>(std::lower_bound(slot.entries.begin() + static_cast<std::ptrdiff_t>(from), slot.entries.end(), pos,
+                                                   [shift](const EndEntry & e, unsigned p) { return e.lastWindow + shift < p; }) -
+                                  slot.entries.begin());
+}
+
+unsigned EndSlots::lastWindowOfReadSlot() const
+{
+    const Slot & slot = slots[readSlot];
+    return light ? slot.maxWin : slot.entries.back().lastWindow;
+}
+
 void EndSlots::add(unsigned id, unsigned endPos)
 {
     const unsigned lastWin = posToWin(endPos, 30);
     unsigned which = writeSlot;
     if (needsSwitch(lastWin))
         which = (which + 1) % 3;
+    if (light)
+    {
+        addLight(slots[which], id, lastWin);
+        return;
+    }
     // behind the last entry that does not end later (what upper_bound finds) -- looked for from the back: pairs arrive in
     // start order, so a new pair's last window lies among the last few entries' (a binary search over the whole slot
     // costs more than the handful of comparisons this takes)
@@ -124,6 +336,8 @@ void EndSlots::add(unsigned id, unsigned endPos)
 // window lies before the window of `pos`; advances the dNext cursor. Reference: getEndCount(), :870-924.
 unsigned EndSlots::countEnded(unsigned pos)
 {
+    if (light)
+        return countEndedLight(pos);
     bool lookAhead = false;
     unsigned i = dNext;
     unsigned c = 0;
@@ -499,13 +713,32 @@ void ChromProfile::fullReset()
     currentRightBorder = starts[0].slots[2].right;
 }
 
+// A slot switch drains the end read slot: every pair whose end record sits there leaves the active set. With light tables
+// nobody is in the active sets (the window loop runs elsewhere): the cursor simply goes to the end.
+void ChromProfile::drainEndReadSlot(unsigned rg)
+{
+    EndSlots & en = ends[rg];
+    if (en.light)
+    {
+        en.readIdx = en.slots[en.readSlot].entries.size();
+        return;
+    }
+    while (!en.readAtEnd())
+        nextEndWindow(rg, logWindow_);
+}
+
+void ChromProfile::setLightEnds(bool on)
+{
+    lightEnds_ = on;
+    parallelFor(ends.size(), [&](size_t rg) { ends[rg].setLight(on); }, 64);
+}
+
 void ChromProfile::performSwitches(const std::vector<unsigned> & rgs, unsigned * border)
 {
     unsigned & rightBorder = border ? *border : currentRightBorder;
     for (unsigned i : rgs)
     {
-        while (!ends[i].readAtEnd())
-            nextEndWindow(i, logWindow_);
+        drainEndReadSlot(i);
         starts[i].switchBoth(rightBorder);
         ends[i].switchWrite();
         ends[i].fixConsecutiveSwitch(activeLoad[i]);
@@ -519,8 +752,7 @@ void ChromProfile::performPartialSwitches(const std::vector<unsigned> & rgs, uns
     unsigned & rightBorder = border ? *border : currentRightBorder;
     for (unsigned i : rgs)
     {
-        while (!ends[i].readAtEnd())
-            nextEndWindow(i, logWindow_);
+        drainEndReadSlot(i);
         starts[i].switchBoth(rightBorder);
         ends[i].switchRead();
         switches_[i] = static_cast<uint8_t>(std::min(2, switches_[i] + 1));
@@ -593,12 +825,6 @@ size_t startsUpTo(const HugeVector<StartEntry> & v, size_t from, unsigned pos)
     return static_cast<size_t>(std::upper_bound(v.begin() + static_cast<std::ptrdiff_t>(std::min(from, v.size())), v.end(), pos,
                                                 [](unsigned p, const StartEntry & e) { return p < e.startPos; }) - v.begin());
 }
-// first index >= from whose entry is NOT yet over at pos: lastWindow + shift >= pos (entries ordered by lastWindow)
-size_t endsBefore(const HugeVector<EndEntry> & v, size_t from, unsigned pos, unsigned shift)
-{
-    return static_cast<size_t>(std::lower_bound(v.begin() + static_cast<std::ptrdiff_t>(std::min(from, v.size())), v.end(), pos,
-                                                [shift](const EndEntry & e, unsigned p) { return e.lastWindow + shift < p; }) - v.begin());
-}
 }  // namespace
 
 bool ChromProfile::canPlanSegment(unsigned shift) const
@@ -635,7 +861,7 @@ WalkShape ChromProfile::planSegment(unsigned shift, std::vector<uint8_t> & equal
             StartSlots & st = starts[rg];
             EndSlots & en = ends[rg];
             st.readIdx = startsUpTo(st.slots[st.readSlot].entries, st.readIdx, currentPos);
-            en.readIdx = endsBefore(en.slots[en.readSlot].entries, en.readIdx, currentPos, shift);
+            en.advanceReadTo(currentPos, shift);
         }
         profilesAtEnd = false;
     }
@@ -684,14 +910,14 @@ WalkShape ChromProfile::planSegment(unsigned shift, std::vector<uint8_t> & equal
         }
         if (!en.readAtEnd())
         {
-            const unsigned last = en.slots[en.readSlot].entries.back().lastWindow + shift;
+            const unsigned last = en.lastWindowOfReadSlot() + shift;
             je = last < pos0 ? 1u : (last - pos0) / shift + 1;
         }
         const unsigned mine = std::min(maxSteps, std::max(js, je));
         steps = std::max(steps, mine);
         const unsigned lastPos = pos0 + mine * shift;
         st.readIdx = startsUpTo(st.slots[st.readSlot].entries, st.readIdx, lastPos);
-        en.readIdx = endsBefore(en.slots[en.readSlot].entries, en.readIdx, lastPos, shift);
+        en.advanceReadTo(lastPos, shift);
     }
     currentPos = pos0 + steps * shift;
     profilesAtEnd = true;

@@ -76,15 +76,42 @@ public:
     unsigned numWindows;
 };
 
+// Two ways to keep the end tables (round 4). HEAVY: every slot's entries ordered by last window at all times, a new record
+// inserted behind the last entry that does not end later (the reference's upper_bound insert) -- what the window loop on the
+// host walks. LIGHT: while the window loop runs in closed form on the device nobody walks these entries; what the loader
+// itself needs of them is how many end before a position (the maxLoad rule's getEndCount(), the plan's cursors) and the
+// last window of a slot. A light slot therefore keeps its records in FILING order (an append) plus a count per 30-bp window,
+// and answers the counting questions from the counts -- entry for entry what the ordered array would answer, because an
+// entry's index in the ordered array is the number of entries that end before it (ties in filing order). Going back to
+// heavy orders the log once (stable by last window = the order the inserts would have produced), so the host's window loop
+// can take over at any segment.
 class alignas(64) EndSlots
 {
 public:
     struct Slot
     {
-        HugeVector<EndEntry> entries;    // ordered by lastWindow (stable)
+        HugeVector<EndEntry> entries;    // heavy: ordered by lastWindow (stable); light: in filing order, `ordered` says if that is the same
         unsigned right = 0;
         bool readable = false;
-        void reset(unsigned r) { entries.clear(); right = r; readable = false; }
+        // light:
+        HugeVector<uint16_t> hist;       // entries per 30-bp window, bin b = window (baseBin + b) * 30
+        unsigned baseBin = 0;
+        unsigned maxWin = 0;             // largest lastWindow filed (meaningful while there are entries)
+        unsigned lowBin = 0, highBin = 0;    // bins in use: [lowBin, highBin)
+        bool ordered = true;
+        unsigned curBin[2] = {0, 0}, curCum[2] = {0, 0};    // prefix cursors over hist: filing side, reading side
+        void reset(unsigned r)
+        {
+            entries.clear();
+            right = r;
+            readable = false;
+            for (unsigned b = lowBin; b < highBin && b < hist.size(); ++b)
+                hist[b] = 0;
+            lowBin = highBin = 0;
+            maxWin = 0;
+            ordered = true;
+            curBin[0] = curBin[1] = curCum[0] = curCum[1] = 0;
+        }
     };
 
     explicit EndSlots(unsigned firstWin = 0, unsigned windows = 10000);
@@ -98,7 +125,13 @@ public:
 
     bool readAtEnd() const { return readIdx >= slots[readSlot].entries.size(); }
     bool goNext() { ++readIdx; return !readAtEnd(); }
-    const EndEntry & current() const { return slots[readSlot].entries[readIdx]; }
+    const EndEntry & current() const { return slots[readSlot].entries[readIdx]; }   // heavy only
+
+    // the read cursor behind every entry of the read slot that is over at `pos` (lastWindow + shift < pos), never backwards
+    void advanceReadTo(unsigned pos, unsigned shift);
+    unsigned lastWindowOfReadSlot() const;      // of its last entry in lastWindow order (the slot must not be empty)
+    void setLight(bool on);
+    bool light = false;
 
     Slot     slots[3];
     size_t   readIdx = 0;
@@ -108,6 +141,13 @@ public:
     unsigned endPosSlot = 0;
     unsigned readSlot = 2;
     unsigned numWindows;
+
+private:
+    void addLight(Slot & slot, unsigned id, unsigned lastWin);
+    unsigned countEndedLight(unsigned pos);
+    unsigned lessCount(Slot & slot, unsigned pos, int side);      // entries of the slot with lastWindow < pos
+    void prepareHist(Slot & slot);
+    void leaveLight();
 };
 
 // ---- the window loop in closed form -----------------------------------------------------------------------------------
@@ -166,6 +206,9 @@ public:
     void performSwitches(const std::vector<unsigned> & rgs, unsigned * border = nullptr);
     void performPartialSwitches(const std::vector<unsigned> & rgs, unsigned * border = nullptr);
     bool allEmpty() const;
+    // light end tables (see EndSlots) while nobody walks them: the driver turns this on with the device's window loop
+    void setLightEnds(bool on);
+    bool lightEnds() const { return lightEnds_; }
     // while someone else evaluates the walk (and keeps the active pairs): how many pairs are active there
     std::function<size_t()> externalActive;
 
@@ -330,10 +373,12 @@ private:
     void deactivate(unsigned rg, unsigned id, unsigned logWindow);
     void nextStartWindow(unsigned rg, unsigned logWindow);
     bool nextEndWindow(unsigned rg, unsigned logWindow);
+    void drainEndReadSlot(unsigned rg);
     unsigned walkReadGroup(unsigned rg, unsigned pos0, unsigned shift, unsigned maxSteps);
 
     std::vector<uint8_t> switches_;        // per read group: slot switches since the last planned / walked segment (2 = two or more)
     bool activeKnownEmpty_ = true;         // no read group has an active pair (start of a run; closed-form mode keeps no active sets)
+    bool lightEnds_ = false;
     bool logging_ = false;
     bool opLogging_ = false;
     std::vector<std::vector<ActiveOp>> ops_;

@@ -13,8 +13,8 @@ shutil.copy(stats, os.path.join(dst, name + "_kernel_stats.csv"))
 table = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kstats.py"), stats, str(passes)], capture_output=True, text=True).stdout
 line = json.loads([l for l in open(os.path.join(src, "trace_bench.json")) if l.startswith("{")][0])
 with open(os.path.join(dst, name + "_kernel_stats.md"), "w") as f:
-    f.write("# %s: rocprofv3 --kernel-trace --stats of `bench.py --serial --no-legs --no-cpu --steps 1 --warmup 1`\n\n" % name)
-    f.write("(%d passes over the resident 10,000-sample segment in the trace; one ticket at a time, see bench.py --serial.\n" % passes)
+    f.write("# %s: rocprofv3 --kernel-trace --stats of `bench.py --serial --lanes 1 --no-legs --no-cpu --steps 1 --warmup 1`\n\n" % name)
+    f.write("(%d passes over the resident 10,000-sample segments in the trace -- warm-up, the timed step and the passes that size the segments and time the scan alone --, one ticket at a time on a context without lanes: see bench.py --serial.\n" % passes)
     f.write("Bench line of the traced run: value %.4g, stage 1 %.3f ms and stage 2 %.3f ms per pass by HIP events, frac %.3f.)\n\n```\n" % (
         line["value"], line["stage1_ms_per_step"] / line["config"]["segment_passes_per_step"],
         line["stage2_ms_per_step"] / line["config"]["segment_passes_per_step"], line["roofline"]["frac"]))
@@ -33,7 +33,7 @@ fetch_raw, write = s1["FETCH_SIZE"] * 1024.0, s1["WRITE_SIZE"] * 1024.0
 out = {
     "kernel": "pd::stage1Kernel", "config": {"samples": 10000, "windows": 6667},
     "scan_source_stamp": bench.scan_source_stamp(),
-    "command": "tools/profile_round.sh: rocprofv3 --pmc <one block's counters> --kernel-trace -- python3 bench.py --serial --no-legs --no-cpu --passes 4 --steps 1 --warmup 0 (one pass per counter group, no other trace domains)",
+    "command": "tools/profile_round.sh: rocprofv3 --pmc <one block's counters> --kernel-trace -- python3 bench.py --serial --lanes 1 --no-legs --no-cpu --passes 4 --steps 1 --warmup 0 (one pass per counter group, no other trace domains)",
     "raw_mean_per_launch": s1,
     "fetch_bytes_raw": fetch_raw, "write_bytes": write,
     "gfx950_correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM: 128-B requests tallied at 64 B for coalesced streams); calibrated on this access pattern in round 1: 2.159 GB to read by construction, 2 x FETCH_SIZE = 2.28 GB. WRITE_SIZE is exact.",
