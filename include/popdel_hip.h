@@ -374,6 +374,19 @@ int pd_inflate_members(int device, const uint8_t *data, const uint64_t *member_o
                        pd_inflate_timing *timing);
 const char *pd_inflate_last_error(void);
 
+/* The same as an object that keeps its stream, device buffers and page-locked staging from call to call (how `popdel call`
+ * inflates the profile blocks of a round: a chunk of samples per call, two inflaters alternating). The caller gathers the
+ * members into the page-locked buffer pd_inflater_input() returns (room for `bytes`; valid until the next call of it),
+ * pd_inflater_run() copies them up, inflates and copies back: *out (page-locked, callee-owned, valid until the next run on
+ * this inflater) holds member m's bytes at out_offsets[m], *status / *out_lengths as in pd_inflate_members(). One inflater
+ * is used from one thread at a time. pd_inflater_create() returns NULL if the backend has no device (the oracle). */
+typedef struct pd_inflater pd_inflater;
+pd_inflater *pd_inflater_create(int device);
+void pd_inflater_destroy(pd_inflater *inflater);
+uint8_t *pd_inflater_input(pd_inflater *inflater, uint64_t bytes);
+int pd_inflater_run(pd_inflater *inflater, const uint64_t *member_offsets, uint32_t n_members, const uint64_t *out_offsets,
+                    const uint8_t **out, const uint32_t **status, const uint64_t **out_lengths, double *kernel_ms);
+
 /* Text of the last error on this context (or of the last failed pd_ctx_create if ctx == NULL). */
 const char *pd_last_error(const pd_ctx *ctx);
 

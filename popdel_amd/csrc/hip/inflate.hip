@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -65,6 +66,185 @@ struct Fail
 std::string g_inflateError;
 
 }  // namespace
+
+// A persistent inflater: stream, device buffers and page-locked staging on both sides kept from call to call (what the
+// loader of `popdel call` uses: a chunk of samples' members per call, two inflaters alternating so that one chunk is on the
+// device while the next is gathered).
+struct pd_inflater
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    unsigned groups = 0;
+    void *dData = nullptr, *dOut = nullptr, *dInOff = nullptr, *dOutOff = nullptr, *dStatus = nullptr, *dLen = nullptr, *dWs = nullptr;
+    size_t capData = 0, capOut = 0, capMembers = 0;
+    void *hIn = nullptr, *hOut = nullptr, *hMeta = nullptr;     // page-locked: compressed bytes in, inflated bytes out, status + lengths
+    size_t capHIn = 0, capHOut = 0, capHMeta = 0;
+    std::string error;
+};
+
+namespace {
+
+void growDevice(void *& p, size_t & cap, size_t want)
+{
+    if (want <= cap)
+        return;
+    if (p)
+        (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t take = want + want / 4 + 4096;
+    PD_INF_HIP(hipMalloc(&p, take));
+    cap = take;
+}
+
+void growPinned(void *& p, size_t & cap, size_t want)
+{
+    if (want <= cap)
+        return;
+    if (p)
+        (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t take = want + want / 4 + 4096;
+    PD_INF_HIP(hipHostMalloc(&p, take, hipHostMallocDefault));
+    cap = take;
+}
+
+}  // namespace
+
+extern "C" pd_inflater * pd_inflater_create(int device)
+{
+    pd_inflater * f = new (std::nothrow) pd_inflater();
+    if (!f)
+        return nullptr;
+    try
+    {
+        f->device = device;
+        PD_INF_HIP(hipSetDevice(device));
+        int nCu = 0;
+        PD_INF_HIP(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, device));
+        f->groups = 3u * (unsigned)std::max(1, nCu);
+        PD_INF_HIP(hipStreamCreate(&f->stream));
+        PD_INF_HIP(hipMalloc(&f->dWs, static_cast<size_t>(f->groups) * pdinf::kCodeLengths * kLanes));
+    }
+    catch (const Fail & e)
+    {
+        g_inflateError = "pd_inflater_create: " + e.what;
+        pd_inflater_destroy(f);
+        return nullptr;
+    }
+    return f;
+}
+
+extern "C" void pd_inflater_destroy(pd_inflater * f)
+{
+    if (!f)
+        return;
+    (void)hipSetDevice(f->device);
+    for (void * p : {f->dData, f->dOut, f->dInOff, f->dOutOff, f->dStatus, f->dLen, f->dWs})
+        if (p)
+            (void)hipFree(p);
+    for (void * p : {f->hIn, f->hOut, f->hMeta})
+        if (p)
+            (void)hipHostFree(p);
+    if (f->stream)
+        (void)hipStreamDestroy(f->stream);
+    delete f;
+}
+
+extern "C" uint8_t * pd_inflater_input(pd_inflater * f, uint64_t bytes)
+{
+    if (!f)
+        return nullptr;
+    try
+    {
+        PD_INF_HIP(hipSetDevice(f->device));
+        growPinned(f->hIn, f->capHIn, bytes + 8);
+    }
+    catch (const Fail & e)
+    {
+        f->error = "pd_inflater_input: " + e.what;
+        return nullptr;
+    }
+    return static_cast<uint8_t *>(f->hIn);
+}
+
+extern "C" int pd_inflater_run(pd_inflater * f, const uint64_t * member_offsets, uint32_t n_members, const uint64_t * out_offsets,
+                               const uint8_t ** out, const uint32_t ** status, const uint64_t ** out_lengths, double * kernel_ms)
+{
+    if (!f || !member_offsets || !out_offsets || !out || !status || !out_lengths || n_members == 0)
+        return 1;
+    try
+    {
+        PD_INF_HIP(hipSetDevice(f->device));
+        const uint64_t inBytes = member_offsets[n_members], outBytes = out_offsets[n_members];
+        if (inBytes + 8 > f->capHIn)
+            throw Fail{"the members were not gathered into pd_inflater_input()'s buffer"};
+        growDevice(f->dData, f->capData, inBytes + 8);
+        growDevice(f->dOut, f->capOut, std::max<uint64_t>(outBytes, 1));
+        if (n_members + 1 > f->capMembers)
+        {
+            size_t a = 0, b = 0, c = 0, d = 0;
+            for (void * p : {f->dInOff, f->dOutOff, f->dStatus, f->dLen})
+                if (p)
+                    (void)hipFree(p);
+            f->dInOff = f->dOutOff = f->dStatus = f->dLen = nullptr;
+            f->capMembers = 0;
+            const size_t m = n_members + n_members / 4 + 1024;
+            growDevice(f->dInOff, a, m * sizeof(uint64_t));
+            growDevice(f->dOutOff, b, m * sizeof(uint64_t));
+            growDevice(f->dStatus, c, m * sizeof(uint32_t));
+            growDevice(f->dLen, d, m * sizeof(uint64_t));
+            f->capMembers = m;
+        }
+        growPinned(f->hOut, f->capHOut, std::max<uint64_t>(outBytes, 1));
+        growPinned(f->hMeta, f->capHMeta, static_cast<size_t>(n_members) * (sizeof(uint64_t) + sizeof(uint32_t)) + 16);
+        hipStream_t st = f->stream;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (kernel_ms)
+        {
+            PD_INF_HIP(hipEventCreate(&e0));
+            PD_INF_HIP(hipEventCreate(&e1));
+        }
+        PD_INF_HIP(hipMemcpyAsync(f->dInOff, member_offsets, (n_members + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        PD_INF_HIP(hipMemcpyAsync(f->dOutOff, out_offsets, (n_members + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        PD_INF_HIP(hipMemcpyAsync(f->dData, f->hIn, inBytes, hipMemcpyHostToDevice, st));
+        const unsigned nBatches = (n_members + kLanes - 1) / kLanes;
+        if (e0)
+            PD_INF_HIP(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(inflateMembersKernel, dim3(std::min(nBatches, f->groups)), dim3(kLanes), 0, st, static_cast<const uint8_t *>(f->dData),
+                           static_cast<const uint64_t *>(f->dInOff), n_members, static_cast<uint8_t *>(f->dOut),
+                           static_cast<const uint64_t *>(f->dOutOff), static_cast<uint32_t *>(f->dStatus), static_cast<uint64_t *>(f->dLen),
+                           static_cast<uint8_t *>(f->dWs), nBatches);
+        PD_INF_HIP(hipGetLastError());
+        if (e1)
+            PD_INF_HIP(hipEventRecord(e1, st));
+        uint64_t * hLen = static_cast<uint64_t *>(f->hMeta);
+        uint32_t * hStatus = reinterpret_cast<uint32_t *>(hLen + n_members);
+        PD_INF_HIP(hipMemcpyAsync(f->hOut, f->dOut, outBytes, hipMemcpyDeviceToHost, st));
+        PD_INF_HIP(hipMemcpyAsync(hLen, f->dLen, n_members * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        PD_INF_HIP(hipMemcpyAsync(hStatus, f->dStatus, n_members * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PD_INF_HIP(hipStreamSynchronize(st));
+        if (kernel_ms)
+        {
+            float ms = 0;
+            PD_INF_HIP(hipEventElapsedTime(&ms, e0, e1));
+            *kernel_ms = ms;
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+        *out = static_cast<const uint8_t *>(f->hOut);
+        *status = hStatus;
+        *out_lengths = hLen;
+    }
+    catch (const Fail & e)
+    {
+        f->error = "pd_inflater_run: " + e.what;
+        g_inflateError = f->error;
+        return 2;
+    }
+    return 0;
+}
 
 extern "C" const char * pd_inflate_last_error(void) { return g_inflateError.c_str(); }
 

@@ -11,6 +11,7 @@
 #include <memory>
 #include <sys/resource.h>
 #include <thread>
+#include <unordered_map>
 
 #include "parallel.h"
 #include "popdel_hip.h"
@@ -146,6 +147,306 @@ struct alignas(64) DecodedStream      // (neighbours in the pool are filled by d
     }
 };
 
+// Gunzip of a round's profile blocks on the device (round 4). Which samples read in a round, from where and up to where is
+// known before the round starts (the readers are the samples whose slots are not switched; they read from the index block
+// of the region's begin to the window behind their write slot's border), and the index brackets every gzip member of that
+// stretch. A thread of its own takes the readers in chunks: their members' bytes go from the files into an inflater's
+// page-locked buffer (pd_inflater_input), the device inflates them one lane per member (pd_inflater_run, inflate.hip) and the
+// decoder threads parse a sample's bytes from memory instead of inflating them -- with the file behind them if the stretch
+// turns out too short (ProfileFile::openPrefetched). Two inflaters alternate: one chunk is on the device while the decoder
+// threads work through the previous one. A sample whose index, members or inflated sizes look wrong in any way is left to the
+// host's own path (zlib's behaviour on damaged files is the specification there).
+class GunzipPrefetch
+{
+public:
+    struct Item
+    {
+        unsigned sample = 0;
+        int32_t beginPos = 0, endPos = 0;
+    };
+    struct Ready
+    {
+        const unsigned char * data = nullptr;
+        size_t size = 0;
+        uint64_t resume = 0;
+        bool usable = false;
+    };
+    // items per chunk: a short first one (the decoder threads wait for it at the start of every round; a launch takes ~10 ms
+    // however few members it has -- one lane works through its member alone), then chunks that fill the device's wave slots
+    static constexpr size_t kFirstChunk = 256, kChunk = 1024;
+    static size_t chunkOf(size_t item) { return item < kFirstChunk ? 0 : 1 + (item - kFirstChunk) / kChunk; }
+    static size_t chunkBegin(size_t c) { return c == 0 ? 0 : kFirstChunk + (c - 1) * kChunk; }
+
+    GunzipPrefetch(const CallParams & p, int device) : p_(p)
+    {
+        for (pd_inflater *& f : inflater_)
+            f = pd_inflater_create(device);
+        ok_ = inflater_[0] && inflater_[1];
+    }
+    ~GunzipPrefetch()
+    {
+        finish();
+        for (pd_inflater * f : inflater_)
+            pd_inflater_destroy(f);
+    }
+    bool ok() const { return ok_; }
+
+    // the round's readers, in sample order; `contig`: the region's contig (the index jump's)
+    void start(std::vector<Item> items, const std::string & contig)
+    {
+        finish();
+        items_ = std::move(items);
+        contig_ = contig;
+        ready_.assign(items_.size(), Ready());
+        slotOf_.clear();
+        for (size_t k = 0; k < items_.size(); ++k)
+            slotOf_[items_[k].sample] = k;
+        chunksDone_ = 0;
+        releasedBelow_ = 0;
+        stop_ = false;
+        failed_ = false;
+        if (!items_.empty())
+            worker_ = std::thread([this] { run(); });
+    }
+    // the sample's inflated bytes (waits for its chunk), or nullptr: inflate it yourself
+    const Ready * wait(unsigned sample)
+    {
+        auto it = slotOf_.find(sample);
+        if (it == slotOf_.end())
+            return nullptr;
+        const size_t chunk = chunkOf(it->second);
+        std::unique_lock<std::mutex> lock(m_);
+        cv_.wait(lock, [&] { return chunksDone_ > chunk || failed_; });
+        const Ready & r = ready_[it->second];
+        return (!failed_ && r.usable) ? &r : nullptr;
+    }
+    // every sample below `sample` has been decoded: their chunks' buffers may be used again
+    void releaseBelow(unsigned sample)
+    {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            releasedBelow_ = std::max(releasedBelow_, sample);
+        }
+        cv_.notify_all();
+    }
+    void finish()
+    {
+        if (worker_.joinable())
+        {
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                stop_ = true;
+                releasedBelow_ = 0xffffffffu;
+            }
+            cv_.notify_all();
+            worker_.join();
+        }
+    }
+    double kernelMs = 0, gatherSeconds = 0, runSeconds = 0;
+    uint64_t members = 0, compressedBytes = 0, inflatedBytes = 0, samplesServed = 0, samplesLeft = 0;
+
+private:
+    void run()
+    {
+        const size_t nChunks = items_.empty() ? 0 : chunkOf(items_.size() - 1) + 1;
+        for (size_t c = 0; c < nChunks; ++c)
+        {
+            const size_t lo = chunkBegin(c), hi = std::min(items_.size(), chunkBegin(c + 1));
+            if (c >= 2)
+            {
+                // the inflater's buffers still hold chunk c - 2: wait until its last sample has been decoded
+                // (a batch of the decoder is at most 512 samples wide: the one that holds this sample needs nothing beyond chunk c - 1)
+                const unsigned lastOfOld = items_[chunkBegin(c - 1) - 1].sample;
+                std::unique_lock<std::mutex> lock(m_);
+                cv_.wait(lock, [&] { return releasedBelow_ > lastOfOld || stop_; });
+            }
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                if (stop_)
+                    break;
+            }
+            try
+            {
+                chunk(c, lo, hi);
+            }
+            catch (...)
+            {
+                // (whatever it was: the remaining samples, and the rounds to come, are inflated on the host)
+                std::lock_guard<std::mutex> lock(m_);
+                failed_ = true;
+                ok_ = false;
+            }
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                chunksDone_ = c + 1;
+            }
+            cv_.notify_all();
+            if (failed_)
+                break;
+        }
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            chunksDone_ = nChunks;
+        }
+        cv_.notify_all();
+    }
+
+    void chunk(size_t c, size_t lo, size_t hi)
+    {
+        pd_inflater * inf = inflater_[c % 2];
+        const size_t n = hi - lo;
+        const double t0 = PhaseClock::now();
+        // 1. the members' file offsets from the index
+        std::vector<std::vector<uint64_t>> cuts(n);
+        parallelFor(n, [&](size_t k) {
+            const Item & it = items_[lo + k];
+            const unsigned contigIdx = p_.representativeContigs ? 0 : it.sample;
+            try
+            {
+                ProfileFile in(p_.inputFiles[it.sample]);
+                if (!in.blockOffsets(p_.contigNames[contigIdx], p_.contigLengths[contigIdx], p_.indexRegionSizes[contigIdx], contig_, it.beginPos,
+                                     it.endPos, cuts[k]) || cuts[k].size() < 2 || cuts[k].back() - cuts[k].front() > (static_cast<uint64_t>(256) << 20))
+                    cuts[k].clear();
+            }
+            catch (...)
+            {
+                cuts[k].clear();
+            }
+        }, 16, 8);
+        std::vector<uint64_t> base(n + 1, 0);
+        for (size_t k = 0; k < n; ++k)
+            base[k + 1] = base[k] + (cuts[k].empty() ? 0 : cuts[k].back() - cuts[k].front());
+        if (base[n] == 0)
+            return;
+        unsigned char * buf = pd_inflater_input(inf, base[n]);
+        if (!buf)
+            throw ProfileError("pd_inflater_input failed");
+        // 2. their bytes
+        std::vector<char> good(n, 0);
+        parallelFor(n, [&](size_t k) {
+            if (cuts[k].empty())
+                return;
+            const Item & it = items_[lo + k];
+            FILE * fp = fopen(p_.inputFiles[it.sample].c_str(), "rb");
+            if (!fp)
+                return;
+            const size_t want = static_cast<size_t>(base[k + 1] - base[k]);
+            size_t got = 0;
+            while (got < want)
+            {
+                const ssize_t r = pread(fileno(fp), buf + base[k] + got, want - got, static_cast<off_t>(cuts[k].front() + got));
+                if (r <= 0)
+                    break;
+                got += static_cast<size_t>(r);
+            }
+            fclose(fp);
+            good[k] = got == want ? 1 : 0;
+        }, 8, 8);
+        // 3. member table: every member must begin like a gzip member with deflate data and end with a plausible size
+        std::vector<uint64_t> inOff, outOff(1, 0);
+        std::vector<uint32_t> firstMember(n + 1, 0);
+        for (size_t k = 0; k < n; ++k)
+        {
+            firstMember[k] = static_cast<uint32_t>(inOff.size());
+            if (!good[k])
+                continue;
+            const std::vector<uint64_t> & cut = cuts[k];
+            bool fine = true;
+            for (size_t m = 0; m + 1 < cut.size() && fine; ++m)
+            {
+                const uint64_t a = base[k] + (cut[m] - cut.front()), b = base[k] + (cut[m + 1] - cut.front());
+                uint32_t isize = 0;
+                fine = b - a >= 18 && buf[a] == 0x1f && buf[a + 1] == 0x8b && buf[a + 2] == 8;
+                if (fine)
+                {
+                    std::memcpy(&isize, buf + b - 4, 4);
+                    fine = isize <= (64u << 20);
+                }
+                if (fine)
+                {
+                    inOff.push_back(a);
+                    outOff.push_back(outOff.back() + isize);
+                }
+            }
+            if (!fine)
+            {
+                // (not what the index promised: drop the sample's members again)
+                outOff.resize(firstMember[k] + 1);
+                inOff.resize(firstMember[k]);
+                good[k] = 0;
+            }
+        }
+        firstMember[n] = static_cast<uint32_t>(inOff.size());
+        if (inOff.empty())
+            return;
+        // (member m ends where member m + 1 begins; the members of dropped samples leave gaps, so the ends are explicit)
+        std::vector<uint64_t> ends;
+        {
+            size_t m = 0;
+            for (size_t k = 0; k < n; ++k)
+            {
+                if (!good[k])
+                    continue;
+                for (size_t j = 0; j + 1 < cuts[k].size(); ++j, ++m)
+                    ends.push_back(base[k] + (cuts[k][j + 1] - cuts[k].front()));
+            }
+        }
+        // pd_inflater_run() takes one offset array (member m = [off[m], off[m + 1])): close the gaps by treating each gap as
+        // belonging to the member before it -- a gzip member ends where its trailer ends, trailing bytes are never read
+        inOff.push_back(ends.back());
+        const double t1 = PhaseClock::now();
+        const uint8_t * out = nullptr;
+        const uint32_t * status = nullptr;
+        const uint64_t * lengths = nullptr;
+        double ms = 0;
+        if (pd_inflater_run(inf, inOff.data(), static_cast<uint32_t>(inOff.size() - 1), outOff.data(), &out, &status, &lengths, &ms) != 0)
+            throw ProfileError("pd_inflater_run failed");
+        const double t2 = PhaseClock::now();
+        for (size_t k = 0; k < n; ++k)
+        {
+            Ready & r = ready_[lo + k];
+            if (!good[k])
+            {
+                ++samplesLeft;
+                continue;
+            }
+            bool fine = true;
+            for (uint32_t m = firstMember[k]; m < firstMember[k + 1] && fine; ++m)
+                fine = status[m] == 0 && lengths[m] == outOff[m + 1] - outOff[m];
+            if (!fine)
+            {
+                ++samplesLeft;
+                continue;
+            }
+            r.data = out + outOff[firstMember[k]];
+            r.size = static_cast<size_t>(outOff[firstMember[k + 1]] - outOff[firstMember[k]]);
+            r.resume = cuts[k].back();
+            r.usable = true;
+            ++samplesServed;
+        }
+        kernelMs += ms;
+        gatherSeconds += t1 - t0;
+        runSeconds += t2 - t1;
+        members += inOff.size() - 1;
+        compressedBytes += base[n];
+        inflatedBytes += outOff.back();
+    }
+
+    const CallParams & p_;
+    pd_inflater * inflater_[2] = {nullptr, nullptr};
+    bool ok_ = false;
+    std::vector<Item> items_;
+    std::string contig_;
+    std::vector<Ready> ready_;
+    std::unordered_map<unsigned, size_t> slotOf_;
+    std::thread worker_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    size_t chunksDone_ = 0;
+    unsigned releasedBelow_ = 0;
+    bool stop_ = false, failed_ = false;
+};
+
 class CallRun
 {
 public:
@@ -193,6 +494,11 @@ public:
         if (getenv("POPDEL_TIMING") && !timingPrinted_)
         {
             std::lock_guard<std::mutex> guard(deviceNotesLock_);
+            if (gunzip_)
+                std::cerr << "[popdel timing] loader: profile blocks inflated on the device for " << gunzip_->samplesServed << " sample rounds (" << gunzip_->samplesLeft
+                          << " left to the host); " << gunzip_->members << " members, " << gunzip_->compressedBytes << " -> " << gunzip_->inflatedBytes
+                          << " bytes; gather " << gunzip_->gatherSeconds << " s, copies + kernel " << gunzip_->runSeconds << " s (kernel "
+                          << gunzip_->kernelMs / 1e3 << " s)" << std::endl;
             std::cerr << "[popdel timing] parity: " << nearIntegerShifts_ << " reference-shift quotients within 1e-9 of an integer (their truncation "
                          "may differ from the x87 reference's) in " << candidateCells_ << " candidate cells, " << windowCalls_ << " window calls" << std::endl;
             // steady state: the rounds that began after the backend was up, to the end of the loop (last results written)
@@ -296,6 +602,11 @@ private:
             std::rethrow_exception(backendError_);
     }
     bool deviceWalkOffered_ = false, deviceWalk_ = false, lightTables_ = false;
+    // the round's profile blocks inflated on the device (GunzipPrefetch) once the backend is up; POPDEL_HOST_GUNZIP=1: never
+    std::unique_ptr<GunzipPrefetch> gunzip_;
+    bool gunzipTried_ = false;
+    int gunzipDevice_ = 0;
+    void startGunzipPrefetch();
     unsigned deviceSegments_ = 0, hostSegments_ = 0;
     void leaveDeviceWalk();
     void submitPlannedSegment(const WalkShape & shape, const std::vector<uint8_t> & equalRun, const std::vector<uint8_t> & switches);
@@ -409,6 +720,7 @@ void CallRun::createBackend()
         const char * d = getenv("POPDEL_DEVICE");
         devices.push_back(d ? atoi(d) : 0);
     }
+    gunzipDevice_ = devices[0];
     const uint32_t S = static_cast<uint32_t>(p_.rgs.size()), world = static_cast<uint32_t>(devices.size());
     ctxs_.assign(world, nullptr);
     tickets_.assign(world, 0);
@@ -647,6 +959,49 @@ bool CallRun::firstWindowOnNextRoi(Coord & minCoord)
     return true;
 }
 
+// Who reads in the round that begins, from where and up to where (see GunzipPrefetch): the samples that are not through
+// with the file or the region and whose slots will not be switched (checkAndSwitch() below: a switch ends a sample's turn).
+void CallRun::startGunzipPrefetch()
+{
+    if (!gunzipTried_ && backendReady_.load())
+    {
+        gunzipTried_ = true;
+        if (deviceWalkOffered_ && !p_.uncompressedIn && !getenv("POPDEL_HOST_GUNZIP"))
+        {
+            gunzip_.reset(new GunzipPrefetch(p_, gunzipDevice_));
+            if (!gunzip_->ok())
+                gunzip_.reset();
+        }
+    }
+    if (!gunzip_)
+        return;
+    if (!gunzip_->ok())
+    {
+        gunzip_->finish();
+        return;
+    }
+    const Region & roi = p_.allRois[p_.nextRoi];
+    std::vector<GunzipPrefetch::Item> items;
+    for (unsigned i = 0; i < p_.sampleNum; ++i)
+    {
+        if (finishedFiles_[i] || finishedRois_[i])
+            continue;
+        const StartSlots & st = profile_->starts[p_.rgs[i][0]];
+        const unsigned pos = nextCandidate_[i].pos;
+        if (st.tooBigForNext(pos) || st.needsSwitch(pos))
+            continue;
+        GunzipPrefetch::Item it;
+        it.sample = i;
+        it.beginPos = roi.beginPos;
+        // (the decoder stops at the first window at or beyond the border; 256-bp windows may begin up to 255 bp before it)
+        const int64_t end = std::min<int64_t>(static_cast<int64_t>(st.slots[st.writeSlot].right) + 256, static_cast<int64_t>(roi.endPos) + 256);
+        it.endPos = static_cast<int32_t>(std::min<int64_t>(end, 0x7fffffff));
+        if (it.endPos >= it.beginPos)
+            items.push_back(it);
+    }
+    gunzip_->start(std::move(items), roi.seqName);
+}
+
 bool CallRun::checkAndSwitch(const std::vector<unsigned> & rg, unsigned beginPos, unsigned * border)
 {
     ChromProfile & prof = *profile_;
@@ -676,8 +1031,14 @@ void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned
     const std::vector<std::string> & contigNames = p_.contigNames[contigIdx];
     const Region & roi = p_.allRois[p_.nextRoi];
     ProfileFile in(p_.inputFiles[i]);
-    in.jumpToRegion(contigNames, p_.contigLengths[contigIdx], p_.indexRegionSizes[contigIdx], roi.seqName, roi.beginPos);
-    auto src = in.openSource(p_.uncompressedIn);
+    std::unique_ptr<ByteSource> src;
+    if (const GunzipPrefetch::Ready * pre = gunzip_ ? gunzip_->wait(i) : nullptr)
+        src = in.openPrefetched(pre->data, pre->size, pre->resume);     // (the device has inflated the blocks from the jump position on)
+    else
+    {
+        in.jumpToRegion(contigNames, p_.contigLengths[contigIdx], p_.indexRegionSizes[contigIdx], roi.seqName, roi.beginPos);
+        src = in.openSource(p_.uncompressedIn);
+    }
     const unsigned nRg = static_cast<unsigned>(p_.rgs[i].size());
     WindowHead window;
     for (;;)
@@ -1661,6 +2022,7 @@ int CallRun::run()
         }
         rounds_.emplace_back();
         rounds_.back().start = PhaseClock::now();
+        startGunzipPrefetch();
         // (large batches: 16 threads replayed 1000 samples in 0.57 s with batches of 128 and in 0.22 s with 512)
         const unsigned batch = std::max(512u, 8u * hostThreads());
         for (unsigned b0 = 0; b0 < p_.sampleNum; b0 += batch)
@@ -1718,6 +2080,8 @@ int CallRun::run()
             });
             clock_.decode += PhaseClock::now() - t0;
             rounds_.back().decode += PhaseClock::now() - t0;
+            if (gunzip_)
+                gunzip_->releaseBelow(b1);
             gTrace.mark("batch: decoded");
             t0 = PhaseClock::now();
             // (3) insert the records and switch slots: per sample independent unless a stream contains a window beyond the

@@ -462,6 +462,43 @@ void ChromProfile::addRun(unsigned rg, const uint32_t * posDev, size_t n, int in
     // replay phase in false sharing)
     unsigned load = activeLoad[rg];
     const unsigned cap = maxLoad[rg];
+    if (en.light)
+    {
+        // the same operations with the everyday case of each inlined (EndSlots::addFast / countEndedFast)
+        auto file = [&](unsigned startPos, int deviation, unsigned endPos) {
+            StartSlots::Slot & slot = st.slots[st.writeSlot];
+            slot.endBorder = en.slots[en.writeSlot].right;
+            if (!slot.entries.empty() && startPos < slot.entries.back().startPos)
+                slot.sorted = false;
+            const unsigned id = st.insertionCount++;
+            slot.entries.push_back(StartEntry{startPos, deviation});
+            en.addFast(id, endPos);
+        };
+        for (size_t i = 0; i < n; ++i)
+        {
+            const unsigned startPos = posDev[2 * i];
+            const int deviation = static_cast<int32_t>(posDev[2 * i + 1]);
+            const int inner = deviation + innerOffset;
+            const unsigned endPos = startPos + (inner > 0 ? static_cast<unsigned>(inner) : 0u);
+            if (load >= cap)
+            {
+                load -= en.countEndedFast(startPos);
+                if (load < cap)
+                {
+                    file(startPos, deviation, endPos);
+                    ++load;
+                }
+            }
+            else
+            {
+                file(startPos, deviation, endPos);
+                ++load;
+                load -= en.countEndedFast(startPos);
+            }
+        }
+        activeLoad[rg] = load;
+        return;
+    }
     for (size_t i = 0; i < n; ++i)
     {
         const unsigned startPos = posDev[2 * i];

@@ -133,6 +133,62 @@ public:
     void setLight(bool on);
     bool light = false;
 
+    // add() / countEnded() with the everyday case of light tables spelled out inline (a record filed into a slot that has
+    // entries, inside the windows its counts cover; a question that moves the counting cursor a window or two forward and
+    // leaves the end-position cursor inside its slot); everything else goes through the general functions. Same state
+    // afterwards, same answers.
+    void addFast(unsigned id, unsigned endPos)
+    {
+        const unsigned bin = endPos / 30u, lastWin = bin * 30u;
+        Slot & slot = slots[lastWin >= slots[writeSlot].right ? (writeSlot + 1) % 3 : writeSlot];
+        const unsigned b = bin - slot.baseBin;              // (wraps below the base: out of range)
+        if (light && !slot.entries.empty() && b < slot.hist.size() && slot.hist[b] != 0xffffu)
+        {
+            slot.ordered = slot.ordered && lastWin >= slot.entries.back().lastWindow;
+            if (b < slot.lowBin)
+                slot.lowBin = b;
+            if (b >= slot.highBin)
+                slot.highBin = b + 1;
+            if (lastWin > slot.maxWin)
+                slot.maxWin = lastWin;
+            ++slot.hist[b];
+            slot.curCum[0] += b < slot.curBin[0] ? 1u : 0u;
+            slot.curCum[1] += b < slot.curBin[1] ? 1u : 0u;
+            slot.entries.push_back(EndEntry{id, lastWin});
+            return;
+        }
+        add(id, endPos);
+    }
+    unsigned countEndedFast(unsigned pos)
+    {
+        Slot & slot = slots[endPosSlot];
+        const unsigned n = static_cast<unsigned>(slot.entries.size());
+        if (light && dNextOffset == 0 && dNext < n)
+        {
+            const unsigned bins = pos / 30u;                // windows 0 .. bins-1 end before the window of pos
+            const unsigned t = bins > slot.baseBin ? bins - slot.baseBin : 0u;
+            if (t >= slot.curBin[0] && t <= slot.hist.size())
+            {
+                unsigned cc = slot.curCum[0];
+                const unsigned from = slot.curBin[0] > slot.lowBin ? slot.curBin[0] : slot.lowBin;
+                const unsigned to = t < slot.highBin ? t : slot.highBin;
+                for (unsigned b = from; b < to; ++b)
+                    cc += slot.hist[b];
+                slot.curBin[0] = t;
+                slot.curCum[0] = cc;
+                if (cc <= dNext)
+                    return 0;
+                const unsigned k = cc - dNext;              // (cc <= n: it counts entries of this slot)
+                if (dNext + k < n)
+                {
+                    dNext += k;
+                    return k;
+                }
+            }
+        }
+        return countEnded(pos);
+    }
+
     Slot     slots[3];
     size_t   readIdx = 0;
     unsigned dNext = 0;

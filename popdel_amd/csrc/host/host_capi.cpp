@@ -2,6 +2,7 @@
 // and need exactly the histogram conditioning that `popdel call` applies when it loads a profile header).
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <random>
 #include <thread>
@@ -11,6 +12,7 @@
 #include <zlib.h>
 
 #include "call_params.h"
+#include "chrom_profile.h"
 #include "histogram.h"
 #include "inflate_core.h"
 #include "parallel.h"
@@ -319,6 +321,79 @@ int pdh_inflate_members_cpu(const uint8_t * data, const uint64_t * offsets, uint
         for (uint32_t b : bad)
             *failures += b;
     }
+    return 0;
+}
+
+// Micro-benchmark and self-check of the loader's table filing (ChromProfile::addRun): `rounds` slot-lengths of synthetic
+// records (30x coverage: one pair per 10 bp, insert 500 +- 50) of ONE read group are filed the way the driver files them --
+// a run per round, slots switched in between -- with heavy or light end tables. Returns seconds through *seconds and a
+// checksum of what the loader reads off the tables (load counter, cursors, slot sizes, last windows) through *checksum:
+// light and heavy must give the same.
+int pdh_bench_filing(unsigned rounds, int light, unsigned maxLoad, double * seconds, uint64_t * checksum)
+{
+    if (!seconds || !checksum || rounds == 0)
+        return 1;
+    const unsigned buffer = 200000;
+    pdh::ChromProfile prof(1, std::vector<unsigned>(1, maxLoad), buffer);
+    prof.currentPos = 1000000;
+    prof.resetTo(1000000);
+    if (light)
+        prof.setLightEnds(true);
+    std::mt19937 gen(4242);
+    std::normal_distribution<double> ins(0.0, 50.0);
+    std::vector<uint32_t> rec;
+    uint64_t sum = 1469598103934665603ull;
+    auto mix = [&sum](uint64_t v) { sum = (sum ^ v) * 1099511628211ull; };
+    double total = 0;
+    unsigned pos = 1000000;
+    const std::vector<unsigned> rgs(1, 0);
+    for (unsigned r = 0; r < rounds; ++r)
+    {
+        rec.clear();
+        const unsigned right = prof.starts[0].slots[prof.starts[0].writeSlot].right;
+        while (pos < right)
+        {
+            rec.push_back(pos);
+            rec.push_back(static_cast<uint32_t>(static_cast<int32_t>(std::lround(ins(gen)))));
+            pos += 1 + gen() % 19;
+        }
+        prof.reserveRun(0, rec.size() / 2);
+        const auto t0 = std::chrono::steady_clock::now();
+        prof.addRun(0, rec.data(), rec.size() / 2, 500 - 300);
+        total += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        mix(prof.activeLoad[0]);
+        mix(prof.starts[0].insertionCount);
+        unsigned border = 0;
+        prof.performPartialSwitches(rgs, &border);
+        if (prof.ends[0].readSlot == prof.ends[0].writeSlot)
+        {
+            prof.ends[0].switchWrite();
+            prof.ends[0].fixConsecutiveSwitch(prof.activeLoad[0]);
+        }
+        std::vector<uint8_t> run, sw;
+        if (prof.canPlanSegment(30))
+        {
+            const pdh::WalkShape sh = prof.planSegment(30, run, sw);
+            mix(sh.firstPos);
+            mix(sh.nWindows);
+            mix(sh.stepPos);
+        }
+        mix(prof.ends[0].readIdx);
+        mix(prof.ends[0].dNext);
+        mix(prof.ends[0].dNextOffset);
+        mix(prof.ends[0].endPosSlot);
+        for (int k = 0; k < 3; ++k)
+            mix(prof.ends[0].slots[k].entries.size());
+    }
+    prof.setLightEnds(false);               // (back to ordered tables: what the host's window loop would find)
+    for (int k = 0; k < 3; ++k)
+        for (const pdh::EndEntry & e : prof.ends[0].slots[k].entries)
+        {
+            mix(e.id);
+            mix(e.lastWindow);
+        }
+    *seconds = total;
+    *checksum = sum;
     return 0;
 }
 }  // extern "C"

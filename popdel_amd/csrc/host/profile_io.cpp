@@ -1,5 +1,7 @@
 #include "profile_io.h"
 
+#include <functional>
+
 #include <dlfcn.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -408,6 +410,102 @@ void ProfileFile::jumpToRegion(const std::vector<std::string> & contigNames, con
     if (!readPod(fp_, offset))
         offset = 0;
     fseeko(fp_, static_cast<off_t>(offset), SEEK_SET);
+}
+
+bool ProfileFile::blockOffsets(const std::vector<std::string> & contigNames, const std::vector<int32_t> & contigLengths,
+                               unsigned indexRegionSize, const std::string & contig, int32_t beginPos, int32_t endPos,
+                               std::vector<uint64_t> & offsets)
+{
+    offsets.clear();
+    const int fd = fileno(fp_);
+    uint32_t numRegions = 0;
+    if (pread(fd, &numRegions, sizeof(numRegions), 7 + sizeof(uint32_t)) != static_cast<ssize_t>(sizeof(numRegions)) || numRegions == 0)
+        return false;
+    uint64_t base = 0;
+    size_t c = 0;
+    for (; c < contigNames.size(); ++c)
+    {
+        if (contig == contigNames[c])
+            break;
+        base += static_cast<uint64_t>(contigLengths[c] / static_cast<int32_t>(indexRegionSize)) + 1;
+    }
+    if (c == contigNames.size() || beginPos < 0 || endPos < beginPos)
+        return false;
+    const uint64_t lastOfContig = base + static_cast<uint64_t>(contigLengths[c] / static_cast<int32_t>(indexRegionSize));
+    const uint64_t s0 = base + static_cast<uint64_t>(beginPos / static_cast<int32_t>(indexRegionSize));
+    uint64_t s1 = std::min(lastOfContig, base + static_cast<uint64_t>(endPos / static_cast<int32_t>(indexRegionSize))) + 1;     // one past
+    if (s0 >= numRegions)
+        return false;
+    s1 = std::min<uint64_t>(s1, numRegions);
+    std::vector<uint64_t> raw(static_cast<size_t>(s1 - s0) + 1, 0);
+    const size_t have = static_cast<size_t>(std::min<uint64_t>(s1 + 1, numRegions) - s0);
+    if (pread(fd, raw.data(), have * sizeof(uint64_t), static_cast<off_t>(kIndexStart + s0 * sizeof(uint64_t))) !=
+        static_cast<ssize_t>(have * sizeof(uint64_t)))
+        return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0)
+        return false;
+    if (have < raw.size())
+        raw.back() = static_cast<uint64_t>(st.st_size);          // (behind the last region of the file)
+    for (uint64_t o : raw)
+    {
+        if (o > static_cast<uint64_t>(st.st_size) || (!offsets.empty() && o < offsets.back()))
+            return false;                                       // (not an index this reader understands)
+        if (offsets.empty() || o != offsets.back())
+            offsets.push_back(o);
+    }
+    return offsets.size() >= 1;
+}
+
+namespace {
+// `size` bytes that are there already, then whatever `next()` opens (called once, when they are used up)
+class PrefetchedSource : public ByteSource
+{
+public:
+    PrefetchedSource(const unsigned char * data, size_t size, std::function<std::unique_ptr<ByteSource>()> next)
+        : p_(data), left_(size), next_(std::move(next))
+    {
+    }
+    size_t read(void * dst, size_t n) override
+    {
+        unsigned char * to = static_cast<unsigned char *>(dst);
+        size_t done = std::min(n, left_);
+        if (done)
+        {
+            std::memcpy(to, p_, done);
+            p_ += done;
+            left_ -= done;
+        }
+        if (done < n)
+        {
+            if (!rest_ && next_)
+            {
+                rest_ = next_();
+                next_ = nullptr;
+            }
+            if (rest_)
+                done += rest_->read(to + done, n - done);
+        }
+        return done;
+    }
+
+private:
+    const unsigned char * p_;
+    size_t left_;
+    std::function<std::unique_ptr<ByteSource>()> next_;
+    std::unique_ptr<ByteSource> rest_;
+};
+}  // namespace
+
+std::unique_ptr<ByteSource> ProfileFile::openPrefetched(const unsigned char * data, size_t size, uint64_t resumeOffset, bool forceZlib)
+{
+    return std::unique_ptr<ByteSource>(new PrefetchedSource(data, size, [this, resumeOffset, forceZlib]() -> std::unique_ptr<ByteSource> {
+        struct stat st;
+        if (fstat(fileno(fp_), &st) != 0 || resumeOffset >= static_cast<uint64_t>(st.st_size))
+            return nullptr;                                     // (the end of the data)
+        fseeko(fp_, static_cast<off_t>(resumeOffset), SEEK_SET);
+        return openSource(false, forceZlib);
+    }));
 }
 
 std::unique_ptr<ByteSource> ProfileFile::openSource(bool uncompressed, bool forceZlib)

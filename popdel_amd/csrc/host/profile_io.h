@@ -78,6 +78,18 @@ public:
 
     FILE * handle() { return fp_; }
 
+    // File offsets that cut the data of [beginPos, endPos] on `contig` into the blocks the index knows: the offsets of the
+    // index regions from the one that holds beginPos to the one behind the one that holds endPos (clipped to the contig's
+    // regions; the end of the file behind the last region), duplicates removed -- a compressed profile holds one gzip member
+    // per non-empty index region, so consecutive offsets bracket one member each. Leaves the file position alone.
+    // Returns false if the index cannot be read.
+    bool blockOffsets(const std::vector<std::string> & contigNames, const std::vector<int32_t> & contigLengths, unsigned indexRegionSize,
+                      const std::string & contig, int32_t beginPos, int32_t endPos, std::vector<uint64_t> & offsets);
+    // Byte source over `size` bytes already inflated (the blocks from the jump position on) that goes on reading the file at
+    // `resumeOffset` when they are used up -- what openSource() would deliver from the jump position, with the first blocks
+    // inflated by someone else (the device).
+    std::unique_ptr<ByteSource> openPrefetched(const unsigned char * data, size_t size, uint64_t resumeOffset, bool forceZlib = false);
+
 private:
     std::string path_;
     FILE * fp_ = nullptr;
