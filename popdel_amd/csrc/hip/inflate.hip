@@ -74,6 +74,8 @@ struct pd_inflater
 {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t finished = nullptr;      // blocking-sync event: the calling thread sleeps instead of spinning on the stream (the host's
+                                        // cores are what `popdel call` is short of)
     unsigned groups = 0;
     void *dData = nullptr, *dOut = nullptr, *dInOff = nullptr, *dOutOff = nullptr, *dStatus = nullptr, *dLen = nullptr, *dWs = nullptr;
     size_t capData = 0, capOut = 0, capMembers = 0;
@@ -125,6 +127,7 @@ extern "C" pd_inflater * pd_inflater_create(int device)
         PD_INF_HIP(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, device));
         f->groups = 3u * (unsigned)std::max(1, nCu);
         PD_INF_HIP(hipStreamCreate(&f->stream));
+        PD_INF_HIP(hipEventCreateWithFlags(&f->finished, hipEventBlockingSync | hipEventDisableTiming));
         PD_INF_HIP(hipMalloc(&f->dWs, static_cast<size_t>(f->groups) * pdinf::kCodeLengths * kLanes));
     }
     catch (const Fail & e)
@@ -147,6 +150,8 @@ extern "C" void pd_inflater_destroy(pd_inflater * f)
     for (void * p : {f->hIn, f->hOut, f->hMeta})
         if (p)
             (void)hipHostFree(p);
+    if (f->finished)
+        (void)hipEventDestroy(f->finished);
     if (f->stream)
         (void)hipStreamDestroy(f->stream);
     delete f;
@@ -224,7 +229,8 @@ extern "C" int pd_inflater_run(pd_inflater * f, const uint64_t * member_offsets,
         PD_INF_HIP(hipMemcpyAsync(f->hOut, f->dOut, outBytes, hipMemcpyDeviceToHost, st));
         PD_INF_HIP(hipMemcpyAsync(hLen, f->dLen, n_members * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         PD_INF_HIP(hipMemcpyAsync(hStatus, f->dStatus, n_members * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        PD_INF_HIP(hipStreamSynchronize(st));
+        PD_INF_HIP(hipEventRecord(f->finished, st));
+        PD_INF_HIP(hipEventSynchronize(f->finished));
         if (kernel_ms)
         {
             float ms = 0;

@@ -171,9 +171,10 @@ public:
         uint64_t resume = 0;
         bool usable = false;
     };
-    // items per chunk: a short first one (the decoder threads wait for it at the start of every round; a launch takes ~10 ms
-    // however few members it has -- one lane works through its member alone), then chunks that fill the device's wave slots
-    static constexpr size_t kFirstChunk = 256, kChunk = 1024;
+    // items per chunk: a launch takes ~10 ms however few members it has (one lane works through its member alone), so what
+    // keeps the decoder threads fed is SEVERAL chunks on the device at a time -- four inflaters, a thread each, chunks as wide
+    // as a batch of the decoder (a chunk of 512 samples is 168 of the device's 768 wave slots) -- and a short first chunk
+    static constexpr size_t kFirstChunk = 256, kChunk = 1024, kInflaters = 3;
     static size_t chunkOf(size_t item) { return item < kFirstChunk ? 0 : 1 + (item - kFirstChunk) / kChunk; }
     static size_t chunkBegin(size_t c) { return c == 0 ? 0 : kFirstChunk + (c - 1) * kChunk; }
 
@@ -181,7 +182,9 @@ public:
     {
         for (pd_inflater *& f : inflater_)
             f = pd_inflater_create(device);
-        ok_ = inflater_[0] && inflater_[1];
+        ok_ = true;
+        for (pd_inflater * f : inflater_)
+            ok_ = ok_ && f;
     }
     ~GunzipPrefetch()
     {
@@ -201,7 +204,7 @@ public:
         slotOf_.clear();
         for (size_t k = 0; k < items_.size(); ++k)
             slotOf_[items_[k].sample] = k;
-        chunksDone_ = 0;
+        done_.assign(items_.empty() ? 0 : chunkOf(items_.size() - 1) + 1, 0);
         releasedBelow_ = 0;
         stop_ = false;
         failed_ = false;
@@ -215,8 +218,10 @@ public:
         if (it == slotOf_.end())
             return nullptr;
         const size_t chunk = chunkOf(it->second);
+        const double t0 = PhaseClock::now();
         std::unique_lock<std::mutex> lock(m_);
-        cv_.wait(lock, [&] { return chunksDone_ > chunk || failed_; });
+        cv_.wait(lock, [&] { return done_[chunk] || failed_; });
+        waitSeconds += PhaseClock::now() - t0;
         const Ready & r = ready_[it->second];
         return (!failed_ && r.usable) ? &r : nullptr;
     }
@@ -242,62 +247,125 @@ public:
             worker_.join();
         }
     }
-    double kernelMs = 0, gatherSeconds = 0, runSeconds = 0;
+    double kernelMs = 0, gatherSeconds = 0, runSeconds = 0, waitSeconds = 0;      // (waitSeconds: summed over the decoder threads)
     uint64_t members = 0, compressedBytes = 0, inflatedBytes = 0, samplesServed = 0, samplesLeft = 0;
 
 private:
+    // what the gathering thread hands to the one that drives the device
+    struct Prepared
+    {
+        size_t lo = 0, hi = 0;
+        std::vector<std::vector<uint64_t>> cuts;
+        std::vector<char> good;
+        std::vector<uint64_t> inOff, outOff;
+        std::vector<uint32_t> firstMember;
+        uint64_t bytes = 0;
+        double seconds = 0;
+    };
+
+    // Three threads per round: this one gathers chunk after chunk (index offsets, the members' bytes into an inflater's
+    // page-locked buffer); one per inflater runs its chunks on the device and publishes them -- the copies of one chunk
+    // overlap the kernel of the next. The buffers of an inflater go round when the chunk before last has been decoded.
     void run()
     {
         const size_t nChunks = items_.empty() ? 0 : chunkOf(items_.size() - 1) + 1;
+        std::deque<std::unique_ptr<Prepared>> queue[kInflaters];
+        bool gatherDone = false;
+        auto deviceLoop = [&](size_t which) {
+            for (size_t c = which; c < nChunks; c += kInflaters)
+            {
+                std::unique_ptr<Prepared> job;
+                {
+                    std::unique_lock<std::mutex> lock(m_);
+                    cv_.wait(lock, [&] { return !queue[which].empty() || gatherDone || stop_ || failed_; });
+                    if (queue[which].empty() || failed_)
+                        break;
+                    job = std::move(queue[which].front());
+                    queue[which].pop_front();
+                    if (c >= kInflaters)
+                    {
+                        // the inflater's output still holds the chunk it ran last: wait until that chunk's last sample has been decoded
+                        // (a batch of the decoder is at most 512 samples wide: the one that holds this sample needs nothing beyond the chunk after it)
+                        const unsigned lastOfOld = items_[chunkBegin(c - kInflaters + 1) - 1].sample;
+                        cv_.wait(lock, [&] { return releasedBelow_ > lastOfOld || stop_; });
+                    }
+                    if (stop_)
+                        break;
+                }
+                try
+                {
+                    execute(c, *job);
+                }
+                catch (...)
+                {
+                    // (whatever it was: the remaining samples, and the rounds to come, are inflated on the host)
+                    std::lock_guard<std::mutex> lock(m_);
+                    failed_ = true;
+                    ok_ = false;
+                }
+                {
+                    std::lock_guard<std::mutex> lock(m_);
+                    done_[c] = 1;
+                }
+                cv_.notify_all();
+            }
+            {
+                // (whatever this thread leaves undone counts as done: the decoders then inflate those samples themselves)
+                std::lock_guard<std::mutex> lock(m_);
+                for (size_t c = which; c < nChunks; c += kInflaters)
+                    done_[c] = 1;
+            }
+            cv_.notify_all();
+        };
+        std::vector<std::thread> device;
+        for (size_t k = 0; k < kInflaters; ++k)
+            device.emplace_back(deviceLoop, k);
         for (size_t c = 0; c < nChunks; ++c)
         {
-            const size_t lo = chunkBegin(c), hi = std::min(items_.size(), chunkBegin(c + 1));
-            if (c >= 2)
             {
-                // the inflater's buffers still hold chunk c - 2: wait until its last sample has been decoded
-                // (a batch of the decoder is at most 512 samples wide: the one that holds this sample needs nothing beyond chunk c - 1)
-                const unsigned lastOfOld = items_[chunkBegin(c - 1) - 1].sample;
+                // the inflater's input buffer was read by chunk c - 2's copy: that chunk must be through
                 std::unique_lock<std::mutex> lock(m_);
-                cv_.wait(lock, [&] { return releasedBelow_ > lastOfOld || stop_; });
-            }
-            {
-                std::lock_guard<std::mutex> lock(m_);
-                if (stop_)
+                cv_.wait(lock, [&] { return c < kInflaters || done_[c - kInflaters] || stop_ || failed_; });
+                if (stop_ || failed_)
                     break;
             }
+            std::unique_ptr<Prepared> job(new Prepared());
+            job->lo = chunkBegin(c);
+            job->hi = std::min(items_.size(), chunkBegin(c + 1));
             try
             {
-                chunk(c, lo, hi);
+                prepare(c, *job);
             }
             catch (...)
             {
-                // (whatever it was: the remaining samples, and the rounds to come, are inflated on the host)
                 std::lock_guard<std::mutex> lock(m_);
                 failed_ = true;
                 ok_ = false;
+                break;
             }
             {
                 std::lock_guard<std::mutex> lock(m_);
-                chunksDone_ = c + 1;
+                queue[c % kInflaters].push_back(std::move(job));
             }
             cv_.notify_all();
-            if (failed_)
-                break;
         }
         {
             std::lock_guard<std::mutex> lock(m_);
-            chunksDone_ = nChunks;
+            gatherDone = true;
         }
         cv_.notify_all();
+        for (std::thread & t : device)
+            t.join();
     }
 
-    void chunk(size_t c, size_t lo, size_t hi)
+    void prepare(size_t c, Prepared & j)
     {
-        pd_inflater * inf = inflater_[c % 2];
-        const size_t n = hi - lo;
+        pd_inflater * inf = inflater_[c % kInflaters];
+        const size_t lo = j.lo, n = j.hi - j.lo;
         const double t0 = PhaseClock::now();
         // 1. the members' file offsets from the index
-        std::vector<std::vector<uint64_t>> cuts(n);
+        std::vector<std::vector<uint64_t>> & cuts = j.cuts;
+        cuts.assign(n, std::vector<uint64_t>());
         parallelFor(n, [&](size_t k) {
             const Item & it = items_[lo + k];
             const unsigned contigIdx = p_.representativeContigs ? 0 : it.sample;
@@ -316,13 +384,17 @@ private:
         std::vector<uint64_t> base(n + 1, 0);
         for (size_t k = 0; k < n; ++k)
             base[k + 1] = base[k] + (cuts[k].empty() ? 0 : cuts[k].back() - cuts[k].front());
+        j.good.assign(n, 0);
+        j.outOff.assign(1, 0);
+        j.firstMember.assign(n + 1, 0);
+        j.bytes = base[n];
         if (base[n] == 0)
             return;
         unsigned char * buf = pd_inflater_input(inf, base[n]);
         if (!buf)
             throw ProfileError("pd_inflater_input failed");
         // 2. their bytes
-        std::vector<char> good(n, 0);
+        std::vector<char> & good = j.good;
         parallelFor(n, [&](size_t k) {
             if (cuts[k].empty())
                 return;
@@ -343,8 +415,9 @@ private:
             good[k] = got == want ? 1 : 0;
         }, 8, 8);
         // 3. member table: every member must begin like a gzip member with deflate data and end with a plausible size
-        std::vector<uint64_t> inOff, outOff(1, 0);
-        std::vector<uint32_t> firstMember(n + 1, 0);
+        std::vector<uint64_t> &inOff = j.inOff, &outOff = j.outOff;
+        std::vector<uint32_t> & firstMember = j.firstMember;
+        uint64_t lastEnd = 0;
         for (size_t k = 0; k < n; ++k)
         {
             firstMember[k] = static_cast<uint32_t>(inOff.size());
@@ -375,65 +448,68 @@ private:
                 inOff.resize(firstMember[k]);
                 good[k] = 0;
             }
+            else
+                lastEnd = base[k + 1];
         }
         firstMember[n] = static_cast<uint32_t>(inOff.size());
-        if (inOff.empty())
-            return;
-        // (member m ends where member m + 1 begins; the members of dropped samples leave gaps, so the ends are explicit)
-        std::vector<uint64_t> ends;
+        // pd_inflater_run() takes one offset array (member m = [off[m], off[m + 1])); the bytes of a dropped sample between two
+        // kept ones simply trail the member before them -- a gzip member ends where its trailer ends, what follows is not read
+        if (!inOff.empty())
+            inOff.push_back(lastEnd);
+        j.seconds = PhaseClock::now() - t0;
+    }
+
+    void execute(size_t c, Prepared & j)
+    {
+        const size_t lo = j.lo, n = j.hi - j.lo;
+        if (j.inOff.empty())
         {
-            size_t m = 0;
-            for (size_t k = 0; k < n; ++k)
-            {
-                if (!good[k])
-                    continue;
-                for (size_t j = 0; j + 1 < cuts[k].size(); ++j, ++m)
-                    ends.push_back(base[k] + (cuts[k][j + 1] - cuts[k].front()));
-            }
+            std::lock_guard<std::mutex> lock(m_);
+            samplesLeft += n;
+            return;
         }
-        // pd_inflater_run() takes one offset array (member m = [off[m], off[m + 1])): close the gaps by treating each gap as
-        // belonging to the member before it -- a gzip member ends where its trailer ends, trailing bytes are never read
-        inOff.push_back(ends.back());
+        pd_inflater * inf = inflater_[c % kInflaters];
         const double t1 = PhaseClock::now();
         const uint8_t * out = nullptr;
         const uint32_t * status = nullptr;
         const uint64_t * lengths = nullptr;
         double ms = 0;
-        if (pd_inflater_run(inf, inOff.data(), static_cast<uint32_t>(inOff.size() - 1), outOff.data(), &out, &status, &lengths, &ms) != 0)
+        if (pd_inflater_run(inf, j.inOff.data(), static_cast<uint32_t>(j.inOff.size() - 1), j.outOff.data(), &out, &status, &lengths, &ms) != 0)
             throw ProfileError("pd_inflater_run failed");
         const double t2 = PhaseClock::now();
+        std::lock_guard<std::mutex> lock(m_);           // (the counters below; ready_[] of this chunk is read once done_ says so)
         for (size_t k = 0; k < n; ++k)
         {
             Ready & r = ready_[lo + k];
-            if (!good[k])
+            if (!j.good[k])
             {
                 ++samplesLeft;
                 continue;
             }
             bool fine = true;
-            for (uint32_t m = firstMember[k]; m < firstMember[k + 1] && fine; ++m)
-                fine = status[m] == 0 && lengths[m] == outOff[m + 1] - outOff[m];
+            for (uint32_t m = j.firstMember[k]; m < j.firstMember[k + 1] && fine; ++m)
+                fine = status[m] == 0 && lengths[m] == j.outOff[m + 1] - j.outOff[m];
             if (!fine)
             {
                 ++samplesLeft;
                 continue;
             }
-            r.data = out + outOff[firstMember[k]];
-            r.size = static_cast<size_t>(outOff[firstMember[k + 1]] - outOff[firstMember[k]]);
-            r.resume = cuts[k].back();
+            r.data = out + j.outOff[j.firstMember[k]];
+            r.size = static_cast<size_t>(j.outOff[j.firstMember[k + 1]] - j.outOff[j.firstMember[k]]);
+            r.resume = j.cuts[k].back();
             r.usable = true;
             ++samplesServed;
         }
         kernelMs += ms;
-        gatherSeconds += t1 - t0;
+        gatherSeconds += j.seconds;
         runSeconds += t2 - t1;
-        members += inOff.size() - 1;
-        compressedBytes += base[n];
-        inflatedBytes += outOff.back();
+        members += j.inOff.size() - 1;
+        compressedBytes += j.bytes;
+        inflatedBytes += j.outOff.back();
     }
 
     const CallParams & p_;
-    pd_inflater * inflater_[2] = {nullptr, nullptr};
+    pd_inflater * inflater_[kInflaters] = {};
     bool ok_ = false;
     std::vector<Item> items_;
     std::string contig_;
@@ -442,7 +518,7 @@ private:
     std::thread worker_;
     std::mutex m_;
     std::condition_variable cv_;
-    size_t chunksDone_ = 0;
+    std::vector<char> done_;            // per chunk
     unsigned releasedBelow_ = 0;
     bool stop_ = false, failed_ = false;
 };
@@ -498,7 +574,7 @@ public:
                 std::cerr << "[popdel timing] loader: profile blocks inflated on the device for " << gunzip_->samplesServed << " sample rounds (" << gunzip_->samplesLeft
                           << " left to the host); " << gunzip_->members << " members, " << gunzip_->compressedBytes << " -> " << gunzip_->inflatedBytes
                           << " bytes; gather " << gunzip_->gatherSeconds << " s, copies + kernel " << gunzip_->runSeconds << " s (kernel "
-                          << gunzip_->kernelMs / 1e3 << " s)" << std::endl;
+                          << gunzip_->kernelMs / 1e3 << " s); decoder threads waited " << gunzip_->waitSeconds << " thread-seconds for it" << std::endl;
             std::cerr << "[popdel timing] parity: " << nearIntegerShifts_ << " reference-shift quotients within 1e-9 of an integer (their truncation "
                          "may differ from the x87 reference's) in " << candidateCells_ << " candidate cells, " << windowCalls_ << " window calls" << std::endl;
             // steady state: the rounds that began after the backend was up, to the end of the loop (last results written)
@@ -963,6 +1039,8 @@ bool CallRun::firstWindowOnNextRoi(Coord & minCoord)
 // with the file or the region and whose slots will not be switched (checkAndSwitch() below: a switch ends a sample's turn).
 void CallRun::startGunzipPrefetch()
 {
+    if (!gunzipTried_ && !backendReady_.load() && getenv("POPDEL_DEVICE_GUNZIP_WAIT") && deviceWalkOffered_)
+        ensureBackend();            // (tests: short runs are over before the backend is up and would never take this path)
     if (!gunzipTried_ && backendReady_.load())
     {
         gunzipTried_ = true;

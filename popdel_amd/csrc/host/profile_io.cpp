@@ -489,6 +489,17 @@ public:
         return done;
     }
 
+    const unsigned char * peek(size_t & avail) override
+    {
+        avail = left_;
+        return left_ ? p_ : nullptr;
+    }
+    void consume(size_t n) override
+    {
+        p_ += n;
+        left_ -= n;
+    }
+
 private:
     const unsigned char * p_;
     size_t left_;
@@ -558,6 +569,17 @@ bool readWindow(ByteSource & src, ProfileWindow & win, unsigned numReadGroups)
 bool readWindowHead(ByteSource & src, WindowHead & head)
 {
     uint32_t chrom = 0, begin = 0;
+    size_t avail = 0;
+    if (const unsigned char * p = src.peek(avail))
+        if (avail >= 8)
+        {
+            std::memcpy(&chrom, p, 4);
+            std::memcpy(&begin, p + 4, 4);
+            src.consume(8);
+            head.chrom = static_cast<int32_t>(chrom);
+            head.beginPos = static_cast<int32_t>(begin);
+            return true;
+        }
     if (src.read(&chrom, 4) != 4)
         return false;
     if (src.read(&begin, 4) != 4)
@@ -573,6 +595,22 @@ const unsigned char * readRawRecords(ByteSource & src, uint32_t & n)
 {
     static thread_local std::vector<unsigned char> buf;
     n = 0;
+    {
+        // (bytes that sit in memory already -- blocks the device has inflated -- are parsed where they are)
+        size_t avail = 0;
+        if (const unsigned char * p = src.peek(avail))
+            if (avail >= 4)
+            {
+                std::memcpy(&n, p, 4);
+                const size_t body = static_cast<size_t>(n) * 5;
+                if (avail - 4 >= body)
+                {
+                    src.consume(4 + body);
+                    return p + 4;
+                }
+                n = 0;
+            }
+    }
     if (src.read(&n, 4) != 4)
         throw ProfileError("[PopDel] Unable to read number of read pairs.");
     if (buf.size() < static_cast<size_t>(n) * 5)
@@ -602,11 +640,16 @@ bool readWindowBodyFlat(ByteSource & src, const WindowHead & head, unsigned numR
         const unsigned char * p = readRawRecords(src, n);
         if (n == 0)
             return false;
-        const size_t first = recs.size();
+        const size_t first = recs.size(), wins0 = wins.size(), counts0 = counts.size();
         recs.resize(first + n);
         PairRecord * o = recs.data() + first;
+        const size_t slots = static_cast<size_t>(std::ceil(static_cast<double>(oldSize + newSize) / newSize));
+        const unsigned base = ((static_cast<uint32_t>(p[0]) + begin) / newSize) * newSize;
         bool ordered = true;
         uint32_t prev = 0;
+        uint32_t boundary = 0;          // first position beyond the current 30-bp window (0: none yet)
+        uint32_t * count = nullptr;
+        // one pass: the record array as it is, cut into 30-bp windows on the way (a record out of order undoes the cuts)
         for (uint32_t i = 0; i < n; ++i, p += 5)
         {
             uint32_t dev;
@@ -616,27 +659,20 @@ bool readWindowBodyFlat(ByteSource & src, const WindowHead & head, unsigned numR
             o[i].dev = dev;
             ordered = ordered && pos >= prev;
             prev = pos;
-        }
-        const size_t slots = static_cast<size_t>(std::ceil(static_cast<double>(oldSize + newSize) / newSize));
-        const unsigned base = (o[0].pos / newSize) * newSize;
-        if (ordered && (o[n - 1].pos - base) / newSize < slots)
-        {
-            uint32_t boundary = 0;          // first position beyond the current 30-bp window (0: none yet)
-            uint32_t * count = nullptr;
-            for (uint32_t i = 0; i < n; ++i)
+            if (pos >= boundary)
             {
-                if (o[i].pos >= boundary)
-                {
-                    const uint32_t winBegin = base + ((o[i].pos - base) / newSize) * newSize;
-                    wins.push_back(FlatWindow{head.chrom, static_cast<int32_t>(winBegin), static_cast<uint32_t>(first + i)});
-                    counts.push_back(0);
-                    count = &counts.back();
-                    boundary = winBegin + newSize;
-                }
-                ++*count;
+                const uint32_t winBegin = base + ((pos - base) / newSize) * newSize;
+                wins.push_back(FlatWindow{head.chrom, static_cast<int32_t>(winBegin), static_cast<uint32_t>(first + i)});
+                counts.push_back(0);
+                count = &counts.back();
+                boundary = winBegin + newSize;
             }
-            return true;
+            ++*count;
         }
+        if (ordered && (o[n - 1].pos - base) / newSize < slots)
+            return true;
+        wins.resize(wins0);
+        counts.resize(counts0);
         // (out of order: the general path reports or handles it)
         ProfileWindow win;
         win.chrom = head.chrom;

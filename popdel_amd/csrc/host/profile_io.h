@@ -55,6 +55,14 @@ public:
     virtual ~ByteSource() {}
     // Reads exactly n bytes unless the data ends; returns the number of bytes delivered.
     virtual size_t read(void * dst, size_t n) = 0;
+    // A source that has its next bytes in memory may show them (`avail` of them at the returned address, valid as long as the
+    // source's buffer lives) and be told how many were taken: the parser then works on them in place. Default: nothing to show.
+    virtual const unsigned char * peek(size_t & avail)
+    {
+        avail = 0;
+        return nullptr;
+    }
+    virtual void consume(size_t) {}
 };
 
 class ProfileFile

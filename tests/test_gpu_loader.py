@@ -1,0 +1,65 @@
+"""GPU: the loader changes of round 4 in the product binary -- profile blocks inflated on the device (GunzipPrefetch,
+pd_inflater_*) and light end tables (counts per window while the device runs the window loop) -- against the host-only
+configuration of round 3: same bytes on a cohort large enough for several prefetch chunks, with several regions, and with a
+profile whose data is damaged (the device refuses the member, the host's zlib path takes the sample and decides what the
+run does)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import POPDEL_BIN, strip_date
+
+pytestmark = pytest.mark.gpu
+
+
+def call(cohort, out, *args, env=None):
+    e = dict(os.environ, POPDEL_TIMING="1", POPDEL_DEVICE_GUNZIP_WAIT="1")     # (wait for the backend: every round takes the device path)
+    e.pop("POPDEL_HIP_LANES", None)
+    e.update(env or {})
+    r = subprocess.run([POPDEL_BIN, "call", os.path.join(cohort, "profiles.txt"), "-o", out] + list(args), env=e,
+                       capture_output=True, text=True)
+    text = strip_date(open(out).read()) if r.returncode == 0 and os.path.exists(out) else None
+    return r, text
+
+
+def test_device_gunzip_and_light_tables_write_the_same_vcf(built, cohort_dir, tmp_path):
+    from popdel_amd import synth
+    d = cohort_dir("s600", 600, synth.single_deletion)
+    host = {"POPDEL_HOST_GUNZIP": "1", "POPDEL_HEAVY_TABLES": "1"}
+    for args in (["-r", "chr20:1000000-2000000"], ["-r", "chr20:1000000-1300000", "-r", "chr20:1500000-2000000"], ["-r", "chr20:1003001-2000000", "-n"],
+                 ["-r", "chr20:1000000-2000000", "-b", "50000"]):
+        r1, new = call(d, str(tmp_path / "new.vcf"), *args)
+        r0, old = call(d, str(tmp_path / "old.vcf"), *args, env=host)
+        assert r0.returncode == 0 and r1.returncode == 0, (r0.stderr[-300:], r1.stderr[-300:])
+        assert new == old and len(new.splitlines()) > 20, args
+        # (the device did take the blocks: every round that began once the backend was up)
+        line = [l for l in r1.stderr.splitlines() if "loader: profile blocks inflated on the device" in l]
+        assert line, r1.stderr[-400:]
+        assert int(line[0].split("for ")[1].split()[0]) >= 600 and "(0 left to the host)" in line[0], line[0]
+        assert "loader:" not in r0.stderr
+
+
+def test_a_damaged_profile_behaves_as_on_the_host(built, cohort_dir, tmp_path):
+    from popdel_amd import synth
+    src = cohort_dir("s40", 40, synth.single_deletion)
+    d = str(tmp_path / "cohort")
+    shutil.copytree(src, d)
+    with open(os.path.join(d, "profiles.txt"), "w") as fh:
+        fh.write("\n".join(os.path.join(d, "s%05d.profile" % k) for k in range(40)) + "\n")
+    # flip a byte in the middle of the data of one profile (inside some gzip member's deflate stream)
+    victim = os.path.join(d, "s00007.profile")
+    size = os.path.getsize(victim)
+    with open(victim, "r+b") as fh:
+        fh.seek(size * 2 // 3)
+        b = fh.read(1)
+        fh.seek(size * 2 // 3)
+        fh.write(bytes([b[0] ^ 0x5a]))
+    args = ["-r", "chr20:1000000-2000000"]
+    r1, new = call(d, str(tmp_path / "new.vcf"), *args)
+    r0, old = call(d, str(tmp_path / "old.vcf"), *args, env={"POPDEL_HOST_GUNZIP": "1"})
+    assert r1.returncode == r0.returncode
+    assert new == old
+    if r0.returncode != 0:
+        assert r1.stderr.splitlines()[-1] == r0.stderr.splitlines()[-1]
