@@ -860,7 +860,7 @@ def main():
         c2 = capi.Context(hip, [rg] * S, list(range(S + 1)), device=local_rank)
         l2 = Lane(c2, c2.stage(capi.Segment(f2, W2, o2, a2["dev"], a2["start"], a2["on"], a2["off"])), args.serial)
         n_pass = 12
-        run_lanes([l2], 2)
+        run_lanes([l2], max(2, l2.depth + 1))       # (every ticket in flight has had its page-locked result block once)
         torch.cuda.synchronize()
         q0 = time.perf_counter()
         acc = run_lanes([l2], n_pass)
