@@ -387,6 +387,33 @@ uint8_t *pd_inflater_input(pd_inflater *inflater, uint64_t bytes);
 int pd_inflater_run(pd_inflater *inflater, const uint64_t *member_offsets, uint32_t n_members, const uint64_t *out_offsets,
                     const uint8_t **out, const uint32_t **status, const uint64_t **out_lengths, double *kernel_ms);
 
+/* ... and with the blocks PARSED on the device as well: what the loader reads out of a block's bytes (reference: readWindow(),
+ * popdel_profile/window_podel.h:211-251, per 256-bp window, then convertWindow(), :314-418 -- the 256 -> 30 split). For every block
+ * m with parse_member[m] != 0 (a file with ONE read group) whose bytes inflate and parse without anything the host's reader would
+ * report, the device leaves
+ *   profile_windows[profile_window_offsets[m] ..[m + 1])   the block's 256-bp windows {chrom, beginPos, splitFailed = 0, first 30-bp
+ *                                                          window, number of 30-bp windows} (20 bytes each)
+ *   call_windows[call_window_offsets[m] ..)                its 30-bp windows with content {chrom, beginPos, first record} (12 bytes)
+ *   call_window_records[...]                               their record counts
+ *   records[record_offsets[m] ..)                          the records {position, deviation} (8 bytes)
+ * with window and record indices relative to the first block of the block's sample (sample_first[m]: index of that block; the
+ * blocks of a sample are consecutive). block_flags[4 * m + 3] != 0: the block is not parsed (not asked for, refused by the
+ * inflater, or irregular) -- parse the sample on the host. The inflated bytes are copied back (*out) only if some block was left
+ * unparsed (bytes_copied). Arrays are page-locked, callee-owned, valid until the next run on this inflater. */
+typedef struct pd_parsed_blocks
+{
+    const void     *profile_windows;
+    const void     *call_windows;
+    const uint32_t *call_window_records;
+    const void     *records;
+    const uint64_t *profile_window_offsets, *call_window_offsets, *record_offsets;     /* n_members + 1 each */
+    const uint32_t *block_flags;            /* 4 words per block: 256-bp windows, 30-bp windows, records, flags */
+    uint32_t        bytes_copied;
+} pd_parsed_blocks;
+int pd_inflater_run_parsed(pd_inflater *inflater, const uint64_t *member_offsets, uint32_t n_members, const uint64_t *out_offsets,
+                           const uint32_t *sample_first, const uint8_t *parse_member, const uint8_t **out, const uint32_t **status,
+                           const uint64_t **out_lengths, pd_parsed_blocks *parsed, double *kernel_ms);
+
 /* Text of the last error on this context (or of the last failed pd_ctx_create if ctx == NULL). */
 const char *pd_last_error(const pd_ctx *ctx);
 

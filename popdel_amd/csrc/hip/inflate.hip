@@ -51,6 +51,172 @@ __global__ __launch_bounds__(kLanes) void inflateMembersKernel(const uint8_t * _
     }
 }
 
+// ---- parse + 256 -> 30 split of the inflated blocks (round 4) ---------------------------------------------------------------
+// What the loader does with the bytes of a block (reference: readWindow(), popdel_profile/window_podel.h:211-251, then
+// convertWindow(), :314-418, per 256-bp window; host counterpart: readWindowHead() + readWindowBodyFlat(), profile_io.cpp):
+// a block is a run of 256-bp windows {chrom u32, beginPos u32, n u32, n x {offset u8, deviation i32}} (one read group per
+// file: the rule; files with several are parsed on the host), a record's position is beginPos + offset, and the records of a
+// window -- position-sorted -- are cut into the 30-bp windows of the global grid that have content. One lane per block, two
+// passes: counts (-> offsets by a scan), then the arrays the host's replay reads -- per 256-bp window {chrom, beginPos, first
+// 30-bp window, their number}, per 30-bp window {chrom, beginPos, first record} and its record count, the records {pos, dev}.
+// Anything the host's reader would stumble over (a window cut off by the end of the block, a window without records, records
+// out of order or spread over more than ten 30-bp windows) flags the block: its sample is parsed by the host, which reports
+// what the reference reports.
+struct ParsedWindow     // (= pdh::DecodedRaw)
+{
+    int32_t  chrom, beginPos;
+    uint32_t splitFailed, firstWin, nWin;
+};
+struct CallWindow       // (= pdh::FlatWindow)
+{
+    int32_t  chrom, beginPos;
+    uint32_t firstRec;
+};
+struct BlockCounts
+{
+    uint32_t raws, wins, recs, flags;
+};
+
+__device__ __forceinline__ uint32_t loadU32(const uint8_t * p)
+{
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+template <bool Write>
+__device__ __forceinline__ BlockCounts walkBlock(const uint8_t * p, const uint8_t * end, ParsedWindow * raws, CallWindow * wins,
+                                                 uint32_t * counts, uint2 * recs, uint32_t winBase, uint32_t recBase)
+{
+    BlockCounts c = {0, 0, 0, 0};
+    while (p < end)
+    {
+        if (end - p < 12)
+        {
+            c.flags = 1;
+            break;
+        }
+        const uint32_t chrom = loadU32(p), begin = loadU32(p + 4), n = loadU32(p + 8);
+        if (n == 0 || (uint64_t)(end - p - 12) < (uint64_t)n * 5u)
+        {
+            c.flags = 1;
+            break;
+        }
+        p += 12;
+        const uint32_t base = ((begin + p[0]) / 30u) * 30u;
+        uint32_t prev = 0, boundary = 0, firstWin = c.wins, inWin = 0;
+        for (uint32_t i = 0; i < n; ++i, p += 5)
+        {
+            const uint32_t pos = begin + p[0];
+            if (pos < prev)
+                c.flags = 1;
+            prev = pos;
+            if (pos >= boundary)
+            {
+                const uint32_t winBegin = base + ((pos - base) / 30u) * 30u;
+                if (Write)
+                {
+                    if (inWin)
+                        counts[c.wins - 1] = inWin;
+                    wins[c.wins] = CallWindow{(int32_t)chrom, (int32_t)winBegin, recBase + c.recs + i};
+                }
+                inWin = 0;
+                ++c.wins;
+                boundary = winBegin + 30u;
+            }
+            ++inWin;
+            if (Write)
+                recs[c.recs + i] = make_uint2(pos, loadU32(p + 1));
+        }
+        if (Write)
+        {
+            counts[c.wins - 1] = inWin;
+            raws[c.raws] = ParsedWindow{(int32_t)chrom, (int32_t)begin, 0u, winBase + firstWin, c.wins - firstWin};
+        }
+        if ((prev - base) / 30u >= 10u)
+            c.flags = 1;
+        ++c.raws;
+        c.recs += n;
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(64) void parseCountKernel(const uint8_t * __restrict__ data, const uint64_t * __restrict__ outOff,
+                                                       const uint64_t * __restrict__ outLen, const uint32_t * __restrict__ status,
+                                                       const uint8_t * __restrict__ wanted, uint32_t n, BlockCounts * __restrict__ counts)
+{
+    const uint32_t m = blockIdx.x * 64u + threadIdx.x;
+    if (m >= n)
+        return;
+    BlockCounts c = {0, 0, 0, 2};
+    if (wanted[m] && status[m] == 0 && outLen[m] == outOff[m + 1] - outOff[m])
+        c = walkBlock<false>(data + outOff[m], data + outOff[m] + outLen[m], nullptr, nullptr, nullptr, nullptr, 0, 0);
+    if (c.flags)
+        c.raws = c.wins = c.recs = 0;           // (nothing is written for a flagged block)
+    counts[m] = c;
+}
+
+// exclusive scans of the three counts over the blocks (offsets[k][0 .. n]); one workgroup
+__global__ __launch_bounds__(256) void parseScanKernel(const BlockCounts * __restrict__ counts, uint32_t n, uint64_t * __restrict__ rawOff,
+                                                       uint64_t * __restrict__ winOff, uint64_t * __restrict__ recOff)
+{
+    __shared__ uint64_t sh[3][256];
+    uint64_t carry[3] = {0, 0, 0};
+    for (uint32_t base = 0; base < n; base += 256u)
+    {
+        const uint32_t e = base + threadIdx.x;
+        uint64_t v[3] = {0, 0, 0};
+        if (e < n)
+        {
+            v[0] = counts[e].raws;
+            v[1] = counts[e].wins;
+            v[2] = counts[e].recs;
+        }
+        for (int k = 0; k < 3; ++k)
+            sh[k][threadIdx.x] = v[k];
+        __syncthreads();
+        for (unsigned o = 1; o < 256u; o <<= 1)
+        {
+            uint64_t t[3];
+            for (int k = 0; k < 3; ++k)
+                t[k] = threadIdx.x >= o ? sh[k][threadIdx.x - o] : 0u;
+            __syncthreads();
+            for (int k = 0; k < 3; ++k)
+                sh[k][threadIdx.x] += t[k];
+            __syncthreads();
+        }
+        if (e < n)
+        {
+            rawOff[e] = carry[0] + sh[0][threadIdx.x] - v[0];
+            winOff[e] = carry[1] + sh[1][threadIdx.x] - v[1];
+            recOff[e] = carry[2] + sh[2][threadIdx.x] - v[2];
+        }
+        for (int k = 0; k < 3; ++k)
+            carry[k] += sh[k][255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        rawOff[n] = carry[0];
+        winOff[n] = carry[1];
+        recOff[n] = carry[2];
+    }
+}
+
+__global__ __launch_bounds__(64) void parseWriteKernel(const uint8_t * __restrict__ data, const uint64_t * __restrict__ outOff,
+                                                       const uint64_t * __restrict__ outLen, const BlockCounts * __restrict__ counts,
+                                                       const uint32_t * __restrict__ sampleFirst, const uint64_t * __restrict__ rawOff,
+                                                       const uint64_t * __restrict__ winOff, const uint64_t * __restrict__ recOff, uint32_t n,
+                                                       ParsedWindow * __restrict__ raws, CallWindow * __restrict__ wins,
+                                                       uint32_t * __restrict__ winCounts, uint2 * __restrict__ recs)
+{
+    const uint32_t m = blockIdx.x * 64u + threadIdx.x;
+    if (m >= n || counts[m].flags)
+        return;
+    // indices are relative to the block's SAMPLE (its first block is sampleFirst[m])
+    const uint32_t f = sampleFirst[m];
+    walkBlock<true>(data + outOff[m], data + outOff[m] + outLen[m], raws + rawOff[m], wins + winOff[m], winCounts + winOff[m],
+                    recs + recOff[m], (uint32_t)(winOff[m] - winOff[f]), (uint32_t)(recOff[m] - recOff[f]));
+}
+
 struct Fail
 {
     std::string what;
@@ -81,6 +247,11 @@ struct pd_inflater
     size_t capData = 0, capOut = 0, capMembers = 0;
     void *hIn = nullptr, *hOut = nullptr, *hMeta = nullptr;     // page-locked: compressed bytes in, inflated bytes out, status + lengths
     size_t capHIn = 0, capHOut = 0, capHMeta = 0;
+    // parsed blocks (pd_inflater_run_parsed): per-block tables and the four arrays, device and page-locked host
+    void *dWanted = nullptr, *dSampleFirst = nullptr, *dCounts = nullptr, *dOffsets = nullptr, *dRaws = nullptr, *dWins = nullptr, *dWinCounts = nullptr, *dRecs = nullptr;
+    size_t capWanted = 0, capSampleFirst = 0, capCounts = 0, capOffsets = 0, capRaws = 0, capWins = 0, capWinCounts = 0, capRecs = 0;
+    void *hOffsets = nullptr, *hFlags = nullptr, *hRaws = nullptr, *hWins = nullptr, *hWinCounts = nullptr, *hRecs = nullptr;
+    size_t capHOffsets = 0, capHFlags = 0, capHRaws = 0, capHWins = 0, capHWinCounts = 0, capHRecs = 0;
     std::string error;
 };
 
@@ -144,10 +315,11 @@ extern "C" void pd_inflater_destroy(pd_inflater * f)
     if (!f)
         return;
     (void)hipSetDevice(f->device);
-    for (void * p : {f->dData, f->dOut, f->dInOff, f->dOutOff, f->dStatus, f->dLen, f->dWs})
+    for (void * p : {f->dData, f->dOut, f->dInOff, f->dOutOff, f->dStatus, f->dLen, f->dWs, f->dWanted, f->dSampleFirst, f->dCounts, f->dOffsets, f->dRaws,
+                     f->dWins, f->dWinCounts, f->dRecs})
         if (p)
             (void)hipFree(p);
-    for (void * p : {f->hIn, f->hOut, f->hMeta})
+    for (void * p : {f->hIn, f->hOut, f->hMeta, f->hOffsets, f->hFlags, f->hRaws, f->hWins, f->hWinCounts, f->hRecs})
         if (p)
             (void)hipHostFree(p);
     if (f->finished)
@@ -174,10 +346,11 @@ extern "C" uint8_t * pd_inflater_input(pd_inflater * f, uint64_t bytes)
     return static_cast<uint8_t *>(f->hIn);
 }
 
-extern "C" int pd_inflater_run(pd_inflater * f, const uint64_t * member_offsets, uint32_t n_members, const uint64_t * out_offsets,
-                               const uint8_t ** out, const uint32_t ** status, const uint64_t ** out_lengths, double * kernel_ms)
+static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_t n_members, const uint64_t * out_offsets,
+                       const uint32_t * sample_first, const uint8_t * parse_member, const uint8_t ** out, const uint32_t ** status,
+                       const uint64_t ** out_lengths, pd_parsed_blocks * parsed, double * kernel_ms)
 {
-    if (!f || !member_offsets || !out_offsets || !out || !status || !out_lengths || n_members == 0)
+    if (!f || !member_offsets || !out_offsets || !out || !status || !out_lengths || n_members == 0 || (parsed && (!sample_first || !parse_member)))
         return 1;
     try
     {
@@ -202,7 +375,6 @@ extern "C" int pd_inflater_run(pd_inflater * f, const uint64_t * member_offsets,
             growDevice(f->dLen, d, m * sizeof(uint64_t));
             f->capMembers = m;
         }
-        growPinned(f->hOut, f->capHOut, std::max<uint64_t>(outBytes, 1));
         growPinned(f->hMeta, f->capHMeta, static_cast<size_t>(n_members) * (sizeof(uint64_t) + sizeof(uint32_t)) + 16);
         hipStream_t st = f->stream;
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -226,7 +398,71 @@ extern "C" int pd_inflater_run(pd_inflater * f, const uint64_t * member_offsets,
             PD_INF_HIP(hipEventRecord(e1, st));
         uint64_t * hLen = static_cast<uint64_t *>(f->hMeta);
         uint32_t * hStatus = reinterpret_cast<uint32_t *>(hLen + n_members);
-        PD_INF_HIP(hipMemcpyAsync(f->hOut, f->dOut, outBytes, hipMemcpyDeviceToHost, st));
+        bool needBytes = true;
+        if (parsed)
+        {
+            // counts per block -> offsets -> (sizes to the host) -> the arrays
+            growDevice(f->dWanted, f->capWanted, n_members);
+            growDevice(f->dSampleFirst, f->capSampleFirst, static_cast<size_t>(n_members) * sizeof(uint32_t));
+            growDevice(f->dCounts, f->capCounts, static_cast<size_t>(n_members) * sizeof(BlockCounts));
+            growDevice(f->dOffsets, f->capOffsets, 3 * (static_cast<size_t>(n_members) + 1) * sizeof(uint64_t));
+            growPinned(f->hOffsets, f->capHOffsets, 3 * (static_cast<size_t>(n_members) + 1) * sizeof(uint64_t));
+            growPinned(f->hFlags, f->capHFlags, static_cast<size_t>(n_members) * sizeof(BlockCounts));
+            PD_INF_HIP(hipMemcpyAsync(f->dWanted, parse_member, n_members, hipMemcpyHostToDevice, st));
+            PD_INF_HIP(hipMemcpyAsync(f->dSampleFirst, sample_first, static_cast<size_t>(n_members) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            uint64_t * dRawOff = static_cast<uint64_t *>(f->dOffsets), *dWinOff = dRawOff + n_members + 1, *dRecOff = dWinOff + n_members + 1;
+            hipLaunchKernelGGL(parseCountKernel, dim3((n_members + 63) / 64), dim3(64), 0, st, static_cast<const uint8_t *>(f->dOut),
+                               static_cast<const uint64_t *>(f->dOutOff), static_cast<const uint64_t *>(f->dLen),
+                               static_cast<const uint32_t *>(f->dStatus), static_cast<const uint8_t *>(f->dWanted), n_members,
+                               static_cast<BlockCounts *>(f->dCounts));
+            hipLaunchKernelGGL(parseScanKernel, dim3(1), dim3(256), 0, st, static_cast<const BlockCounts *>(f->dCounts), n_members, dRawOff, dWinOff, dRecOff);
+            PD_INF_HIP(hipGetLastError());
+            PD_INF_HIP(hipMemcpyAsync(f->hOffsets, f->dOffsets, 3 * (static_cast<size_t>(n_members) + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+            PD_INF_HIP(hipMemcpyAsync(f->hFlags, f->dCounts, static_cast<size_t>(n_members) * sizeof(BlockCounts), hipMemcpyDeviceToHost, st));
+            PD_INF_HIP(hipEventRecord(f->finished, st));
+            PD_INF_HIP(hipEventSynchronize(f->finished));
+            const uint64_t * hRawOff = static_cast<const uint64_t *>(f->hOffsets), *hWinOff = hRawOff + n_members + 1, *hRecOff = hWinOff + n_members + 1;
+            const uint64_t nRaws = hRawOff[n_members], nWins = hWinOff[n_members], nRecs = hRecOff[n_members];
+            growDevice(f->dRaws, f->capRaws, std::max<uint64_t>(1, nRaws) * sizeof(ParsedWindow));
+            growDevice(f->dWins, f->capWins, std::max<uint64_t>(1, nWins) * sizeof(CallWindow));
+            growDevice(f->dWinCounts, f->capWinCounts, std::max<uint64_t>(1, nWins) * sizeof(uint32_t));
+            growDevice(f->dRecs, f->capRecs, std::max<uint64_t>(1, nRecs) * sizeof(uint2));
+            growPinned(f->hRaws, f->capHRaws, std::max<uint64_t>(1, nRaws) * sizeof(ParsedWindow));
+            growPinned(f->hWins, f->capHWins, std::max<uint64_t>(1, nWins) * sizeof(CallWindow));
+            growPinned(f->hWinCounts, f->capHWinCounts, std::max<uint64_t>(1, nWins) * sizeof(uint32_t));
+            growPinned(f->hRecs, f->capHRecs, std::max<uint64_t>(1, nRecs) * sizeof(uint2));
+            hipLaunchKernelGGL(parseWriteKernel, dim3((n_members + 63) / 64), dim3(64), 0, st, static_cast<const uint8_t *>(f->dOut),
+                               static_cast<const uint64_t *>(f->dOutOff), static_cast<const uint64_t *>(f->dLen),
+                               static_cast<const BlockCounts *>(f->dCounts), static_cast<const uint32_t *>(f->dSampleFirst), dRawOff, dWinOff, dRecOff,
+                               n_members, static_cast<ParsedWindow *>(f->dRaws), static_cast<CallWindow *>(f->dWins),
+                               static_cast<uint32_t *>(f->dWinCounts), static_cast<uint2 *>(f->dRecs));
+            PD_INF_HIP(hipGetLastError());
+            PD_INF_HIP(hipMemcpyAsync(f->hRaws, f->dRaws, nRaws * sizeof(ParsedWindow), hipMemcpyDeviceToHost, st));
+            PD_INF_HIP(hipMemcpyAsync(f->hWins, f->dWins, nWins * sizeof(CallWindow), hipMemcpyDeviceToHost, st));
+            PD_INF_HIP(hipMemcpyAsync(f->hWinCounts, f->dWinCounts, nWins * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            PD_INF_HIP(hipMemcpyAsync(f->hRecs, f->dRecs, nRecs * sizeof(uint2), hipMemcpyDeviceToHost, st));
+            // the inflated bytes themselves travel only if some block is left to the host's parser
+            const BlockCounts * fl = static_cast<const BlockCounts *>(f->hFlags);
+            needBytes = false;
+            for (uint32_t m = 0; m < n_members && !needBytes; ++m)
+                needBytes = fl[m].flags != 0;
+            parsed->profile_windows = f->hRaws;
+            parsed->call_windows = f->hWins;
+            parsed->call_window_records = static_cast<const uint32_t *>(f->hWinCounts);
+            parsed->records = f->hRecs;
+            parsed->profile_window_offsets = hRawOff;
+            parsed->call_window_offsets = hWinOff;
+            parsed->record_offsets = hRecOff;
+            parsed->block_flags = reinterpret_cast<const uint32_t *>(f->hFlags);
+            parsed->bytes_copied = needBytes ? 1 : 0;
+        }
+        if (needBytes && outBytes)
+        {
+            // (page-locked room for the inflated bytes only when somebody will read them: with every block parsed on the device
+            // nobody does)
+            growPinned(f->hOut, f->capHOut, outBytes);
+            PD_INF_HIP(hipMemcpyAsync(f->hOut, f->dOut, outBytes, hipMemcpyDeviceToHost, st));
+        }
         PD_INF_HIP(hipMemcpyAsync(hLen, f->dLen, n_members * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         PD_INF_HIP(hipMemcpyAsync(hStatus, f->dStatus, n_members * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PD_INF_HIP(hipEventRecord(f->finished, st));
@@ -250,6 +486,21 @@ extern "C" int pd_inflater_run(pd_inflater * f, const uint64_t * member_offsets,
         return 2;
     }
     return 0;
+}
+
+extern "C" int pd_inflater_run(pd_inflater * f, const uint64_t * member_offsets, uint32_t n_members, const uint64_t * out_offsets,
+                               const uint8_t ** out, const uint32_t ** status, const uint64_t ** out_lengths, double * kernel_ms)
+{
+    return runInflater(f, member_offsets, n_members, out_offsets, nullptr, nullptr, out, status, out_lengths, nullptr, kernel_ms);
+}
+
+extern "C" int pd_inflater_run_parsed(pd_inflater * f, const uint64_t * member_offsets, uint32_t n_members, const uint64_t * out_offsets,
+                                      const uint32_t * sample_first, const uint8_t * parse_member, const uint8_t ** out,
+                                      const uint32_t ** status, const uint64_t ** out_lengths, pd_parsed_blocks * parsed, double * kernel_ms)
+{
+    if (!parsed)
+        return 1;
+    return runInflater(f, member_offsets, n_members, out_offsets, sample_first, parse_member, out, status, out_lengths, parsed, kernel_ms);
 }
 
 extern "C" const char * pd_inflate_last_error(void) { return g_inflateError.c_str(); }

@@ -44,6 +44,11 @@ struct EventTrace
         std::lock_guard<std::mutex> g(m);
         events.emplace_back(PhaseClock::now() - t0, what);
     }
+    void mark(const std::string & what)
+    {
+        if (on)
+            mark(what.c_str());
+    }
     void print()
     {
         std::lock_guard<std::mutex> g(m);
@@ -118,13 +123,14 @@ bool adaptRegions(Coord & cand, Region & roi, unsigned w)
 // What a decoder thread produced for one sample and one round: the 256-bp windows from the index jump up to (and
 // including) the window at which the loader will stop, each already split into 30-bp windows. Decoding (inflate, parse,
 // split) touches no shared state; inserting the records into the window state machine is replayed sequentially.
-struct DecodedRaw
+struct DecodedRaw                          // (the device writes the same 20 bytes: ParsedWindow, inflate.hip)
 {
     int32_t  chrom = 0;
     int32_t  beginPos = 0;
-    bool     splitFailed = false;
+    uint32_t splitFailed = 0;
     uint32_t firstWin = 0, nWin = 0;       // its 30-bp windows in DecodedStream::wins
 };
+static_assert(sizeof(DecodedRaw) == 20 && sizeof(FlatWindow) == 12 && sizeof(PairRecord) == 8, "layouts shared with the device's parser");
 
 struct alignas(64) DecodedStream      // (neighbours in the pool are filled by different threads: no shared cache lines)
 {
@@ -134,6 +140,23 @@ struct alignas(64) DecodedStream      // (neighbours in the pool are filled by d
     FlatRecords recs;
     bool eof = false;
     bool sawFarWindow = false;     // a window beyond the next slot: the replay may consult ALL tables (allEmpty/resetTo)
+    // What the replay reads: the vectors above (the host parsed the sample) or arrays the device's parser left in an
+    // inflater's page-locked buffers (valid until the batch has been replayed).
+    const DecodedRaw * rawsV = nullptr;
+    size_t nRawsV = 0;
+    const FlatWindow * winsV = nullptr;
+    const uint32_t * countsV = nullptr;
+    const PairRecord * recsV = nullptr;
+    size_t nRecsV = 0;
+    void viewOwn()
+    {
+        rawsV = raws.data();
+        nRawsV = raws.size();
+        winsV = wins.data();
+        countsV = counts.data();
+        recsV = recs.data();
+        nRecsV = recs.size();
+    }
     // Streams are pooled per batch position and reused round after round: their vectors keep their capacity, so the
     // steady state allocates nothing (hundreds of kilobytes per sample and round otherwise -- mmap/munmap from 64 threads).
     void reuse()
@@ -144,6 +167,12 @@ struct alignas(64) DecodedStream      // (neighbours in the pool are filled by d
         recs.clear();
         eof = false;
         sawFarWindow = false;
+        rawsV = nullptr;
+        nRawsV = 0;
+        winsV = nullptr;
+        countsV = nullptr;
+        recsV = nullptr;
+        nRecsV = 0;
     }
 };
 
@@ -163,13 +192,28 @@ public:
     {
         unsigned sample = 0;
         int32_t beginPos = 0, endPos = 0;
+        bool parse = false;             // one read group: the device parses the blocks as well
+        uint32_t firstRegion = 0;       // beginPos / the file's index region size: what the index jump depends on
     };
     struct Ready
     {
-        const unsigned char * data = nullptr;
+        const unsigned char * data = nullptr;       // the inflated bytes (bytesValid) ...
         size_t size = 0;
         uint64_t resume = 0;
-        bool usable = false;
+        bool usable = false, bytesValid = false;
+        // ... and / or the blocks parsed (the sample's 256-bp windows, 30-bp windows with their record counts, records)
+        bool parsed = false;
+        const DecodedRaw * raws = nullptr;
+        size_t nRaws = 0;
+        const FlatWindow * wins = nullptr;
+        const uint32_t * counts = nullptr;
+        const PairRecord * recs = nullptr;
+        size_t nRecs = 0;
+        // (adopt(): the reader's jump lands `skip` index regions behind the guess -> its stream begins at a later block)
+        const uint64_t * rawsByBlock = nullptr;      // first 256-bp window of each of the sample's blocks (and one past)
+        const uint64_t * bytesByBlock = nullptr;     // first inflated byte of each
+        const std::vector<uint64_t> * cuts = nullptr;        // the blocks' file offsets
+        const std::vector<uint64_t> * regionOffsets = nullptr;
     };
     // items per chunk: a launch takes ~10 ms however few members it has (one lane works through its member alone), so what
     // keeps the decoder threads fed is SEVERAL chunks on the device at a time -- four inflaters, a thread each, chunks as wide
@@ -185,6 +229,7 @@ public:
         ok_ = true;
         for (pd_inflater * f : inflater_)
             ok_ = ok_ && f;
+        parseOnDevice_ = !getenv("POPDEL_HOST_PARSE");
     }
     ~GunzipPrefetch()
     {
@@ -201,6 +246,9 @@ public:
         items_ = std::move(items);
         contig_ = contig;
         ready_.assign(items_.size(), Ready());
+        valid_.assign(items_.size(), 1);
+        skip_.assign(items_.size(), 0);
+        kept_.clear();
         slotOf_.clear();
         for (size_t k = 0; k < items_.size(); ++k)
             slotOf_[items_[k].sample] = k;
@@ -211,19 +259,77 @@ public:
         if (!items_.empty())
             worker_ = std::thread([this] { run(); });
     }
+    // A round started AHEAD of time (on a guess of who will read from where) meets the round as it is: a sample's blocks are
+    // good if the sample reads and its index jump lands where the guess said or up to two index regions further on (same contig;
+    // the bytes from the block at which the jump lands are what its reader would inflate, however far the guess went -- wait()
+    // finds that block by its file offset). Returns the number of `actual` covered.
+    size_t adopt(const std::vector<Item> & actual, const std::string & contig)
+    {
+        std::fill(valid_.begin(), valid_.end(), 0);
+        std::fill(skip_.begin(), skip_.end(), 0);
+        if (contig != contig_)
+            return 0;
+        size_t covered = 0;
+        for (const Item & a : actual)
+        {
+            auto it = slotOf_.find(a.sample);
+            if (it == slotOf_.end() || a.firstRegion < items_[it->second].firstRegion || a.firstRegion - items_[it->second].firstRegion > 2)
+                continue;
+            valid_[it->second] = 1;
+            skip_[it->second] = static_cast<unsigned char>(a.firstRegion - items_[it->second].firstRegion);
+            ++covered;
+        }
+        return covered;
+    }
+    // every chunk of the round is through the device (or given up)
+    bool allDone()
+    {
+        std::lock_guard<std::mutex> lock(m_);
+        for (char d : done_)
+            if (!d)
+                return false;
+        return true;
+    }
     // the sample's inflated bytes (waits for its chunk), or nullptr: inflate it yourself
     const Ready * wait(unsigned sample)
     {
         auto it = slotOf_.find(sample);
-        if (it == slotOf_.end())
+        if (it == slotOf_.end() || !valid_[it->second])
             return nullptr;
         const size_t chunk = chunkOf(it->second);
         const double t0 = PhaseClock::now();
         std::unique_lock<std::mutex> lock(m_);
         cv_.wait(lock, [&] { return done_[chunk] || failed_; });
         waitSeconds += PhaseClock::now() - t0;
-        const Ready & r = ready_[it->second];
-        return (!failed_ && r.usable) ? &r : nullptr;
+        Ready & r = ready_[it->second];
+        if (failed_ || !r.usable)
+            return nullptr;
+        if (skip_[it->second])
+        {
+            // the stream begins at the block whose file offset the index holds for the reader's region
+            const unsigned d = skip_[it->second];
+            skip_[it->second] = 0;
+            r.usable = false;
+            if (!r.cuts || !r.regionOffsets || d >= r.regionOffsets->size())
+                return nullptr;
+            const uint64_t at = (*r.regionOffsets)[d];
+            const auto pos = std::lower_bound(r.cuts->begin(), r.cuts->end(), at);
+            if (pos == r.cuts->end() || *pos != at || pos + 1 == r.cuts->end())
+                return nullptr;             // (nothing of the stretch lies behind the jump: the reader goes to the file itself)
+            const size_t b = static_cast<size_t>(pos - r.cuts->begin());
+            const uint64_t bytes = r.bytesByBlock[b] - r.bytesByBlock[0];
+            if (r.data)
+                r.data += bytes;
+            r.size -= static_cast<size_t>(bytes);
+            if (r.parsed)
+            {
+                const uint64_t n = r.rawsByBlock[b] - r.rawsByBlock[0];
+                r.raws += n;
+                r.nRaws -= static_cast<size_t>(n);
+            }
+            r.usable = true;
+        }
+        return &r;
     }
     // every sample below `sample` has been decoded: their chunks' buffers may be used again
     void releaseBelow(unsigned sample)
@@ -248,17 +354,19 @@ public:
         }
     }
     double kernelMs = 0, gatherSeconds = 0, runSeconds = 0, waitSeconds = 0;      // (waitSeconds: summed over the decoder threads)
-    uint64_t members = 0, compressedBytes = 0, inflatedBytes = 0, samplesServed = 0, samplesLeft = 0;
+    uint64_t members = 0, compressedBytes = 0, inflatedBytes = 0, samplesServed = 0, samplesLeft = 0, samplesParsed = 0;
+    bool parseOnDevice_ = true;         // POPDEL_HOST_PARSE=1: the device inflates, the host parses
 
 private:
     // what the gathering thread hands to the one that drives the device
     struct Prepared
     {
         size_t lo = 0, hi = 0;
-        std::vector<std::vector<uint64_t>> cuts;
+        std::vector<std::vector<uint64_t>> cuts, regionOffsets;
         std::vector<char> good;
         std::vector<uint64_t> inOff, outOff;
-        std::vector<uint32_t> firstMember;
+        std::vector<uint32_t> firstMember, sampleFirst;
+        std::vector<uint8_t> parseMember;
         uint64_t bytes = 0;
         double seconds = 0;
     };
@@ -294,7 +402,13 @@ private:
                 }
                 try
                 {
+                    if (gTrace.on)
+                        gTrace.mark("loader " + std::to_string(reinterpret_cast<uintptr_t>(this) % 997) + ": chunk " + std::to_string(c) + " goes to the device");
                     execute(c, *job);
+                    if (gTrace.on)
+                        gTrace.mark("loader " + std::to_string(reinterpret_cast<uintptr_t>(this) % 997) + ": chunk " + std::to_string(c) + " is there");
+                    std::lock_guard<std::mutex> lock(m_);
+                    kept_.push_back(std::move(job));
                 }
                 catch (...)
                 {
@@ -334,7 +448,11 @@ private:
             job->hi = std::min(items_.size(), chunkBegin(c + 1));
             try
             {
+                if (gTrace.on)
+                    gTrace.mark("loader " + std::to_string(reinterpret_cast<uintptr_t>(this) % 997) + ": gathering chunk " + std::to_string(c));
                 prepare(c, *job);
+                if (gTrace.on)
+                    gTrace.mark("loader " + std::to_string(reinterpret_cast<uintptr_t>(this) % 997) + ": chunk " + std::to_string(c) + " gathered");
             }
             catch (...)
             {
@@ -366,6 +484,7 @@ private:
         // 1. the members' file offsets from the index
         std::vector<std::vector<uint64_t>> & cuts = j.cuts;
         cuts.assign(n, std::vector<uint64_t>());
+        j.regionOffsets.assign(n, std::vector<uint64_t>());
         parallelFor(n, [&](size_t k) {
             const Item & it = items_[lo + k];
             const unsigned contigIdx = p_.representativeContigs ? 0 : it.sample;
@@ -373,7 +492,7 @@ private:
             {
                 ProfileFile in(p_.inputFiles[it.sample]);
                 if (!in.blockOffsets(p_.contigNames[contigIdx], p_.contigLengths[contigIdx], p_.indexRegionSizes[contigIdx], contig_, it.beginPos,
-                                     it.endPos, cuts[k]) || cuts[k].size() < 2 || cuts[k].back() - cuts[k].front() > (static_cast<uint64_t>(256) << 20))
+                                     it.endPos, cuts[k], &j.regionOffsets[k]) || cuts[k].size() < 2 || cuts[k].back() - cuts[k].front() > (static_cast<uint64_t>(256) << 20))
                     cuts[k].clear();
             }
             catch (...)
@@ -439,6 +558,8 @@ private:
                 {
                     inOff.push_back(a);
                     outOff.push_back(outOff.back() + isize);
+                    j.sampleFirst.push_back(firstMember[k]);
+                    j.parseMember.push_back(items_[lo + k].parse && parseOnDevice_ ? 1 : 0);
                 }
             }
             if (!fine)
@@ -446,6 +567,8 @@ private:
                 // (not what the index promised: drop the sample's members again)
                 outOff.resize(firstMember[k] + 1);
                 inOff.resize(firstMember[k]);
+                j.sampleFirst.resize(firstMember[k]);
+                j.parseMember.resize(firstMember[k]);
                 good[k] = 0;
             }
             else
@@ -474,8 +597,11 @@ private:
         const uint32_t * status = nullptr;
         const uint64_t * lengths = nullptr;
         double ms = 0;
-        if (pd_inflater_run(inf, j.inOff.data(), static_cast<uint32_t>(j.inOff.size() - 1), j.outOff.data(), &out, &status, &lengths, &ms) != 0)
-            throw ProfileError("pd_inflater_run failed");
+        pd_parsed_blocks pb;
+        std::memset(&pb, 0, sizeof(pb));
+        if (pd_inflater_run_parsed(inf, j.inOff.data(), static_cast<uint32_t>(j.inOff.size() - 1), j.outOff.data(), j.sampleFirst.data(),
+                                   j.parseMember.data(), &out, &status, &lengths, &pb, &ms) != 0)
+            throw ProfileError("pd_inflater_run_parsed failed");
         const double t2 = PhaseClock::now();
         std::lock_guard<std::mutex> lock(m_);           // (the counters below; ready_[] of this chunk is read once done_ says so)
         for (size_t k = 0; k < n; ++k)
@@ -494,10 +620,35 @@ private:
                 ++samplesLeft;
                 continue;
             }
-            r.data = out + j.outOff[j.firstMember[k]];
+            r.bytesValid = pb.bytes_copied != 0 && out;
+            r.data = r.bytesValid ? out + j.outOff[j.firstMember[k]] : nullptr;
             r.size = static_cast<size_t>(j.outOff[j.firstMember[k + 1]] - j.outOff[j.firstMember[k]]);
             r.resume = j.cuts[k].back();
-            r.usable = true;
+            r.cuts = &j.cuts[k];
+            r.regionOffsets = &j.regionOffsets[k];
+            r.bytesByBlock = j.outOff.data() + j.firstMember[k];
+            r.rawsByBlock = pb.profile_window_offsets + j.firstMember[k];
+            bool parsedAll = j.firstMember[k + 1] > j.firstMember[k];
+            for (uint32_t m = j.firstMember[k]; m < j.firstMember[k + 1] && parsedAll; ++m)
+                parsedAll = pb.block_flags[4 * static_cast<size_t>(m) + 3] == 0;
+            if (parsedAll)
+            {
+                const uint32_t m0 = j.firstMember[k], m1 = j.firstMember[k + 1];
+                r.parsed = true;
+                r.raws = static_cast<const DecodedRaw *>(pb.profile_windows) + pb.profile_window_offsets[m0];
+                r.nRaws = static_cast<size_t>(pb.profile_window_offsets[m1] - pb.profile_window_offsets[m0]);
+                r.wins = static_cast<const FlatWindow *>(pb.call_windows) + pb.call_window_offsets[m0];
+                r.counts = pb.call_window_records + pb.call_window_offsets[m0];
+                r.recs = static_cast<const PairRecord *>(pb.records) + pb.record_offsets[m0];
+                r.nRecs = static_cast<size_t>(pb.record_offsets[m1] - pb.record_offsets[m0]);
+                ++samplesParsed;
+            }
+            r.usable = r.parsed || r.bytesValid;
+            if (!r.usable)
+            {
+                ++samplesLeft;
+                continue;
+            }
             ++samplesServed;
         }
         kernelMs += ms;
@@ -514,6 +665,9 @@ private:
     std::vector<Item> items_;
     std::string contig_;
     std::vector<Ready> ready_;
+    std::vector<char> valid_;           // per item: its blocks are the ones its reader wants (adopt())
+    std::vector<unsigned char> skip_;   // ... from the block of the skip_-th index region behind the guess on
+    std::vector<std::unique_ptr<Prepared>> kept_;      // the chunks' tables (Ready points into them)
     std::unordered_map<unsigned, size_t> slotOf_;
     std::thread worker_;
     std::mutex m_;
@@ -570,11 +724,16 @@ public:
         if (getenv("POPDEL_TIMING") && !timingPrinted_)
         {
             std::lock_guard<std::mutex> guard(deviceNotesLock_);
-            if (gunzip_)
-                std::cerr << "[popdel timing] loader: profile blocks inflated on the device for " << gunzip_->samplesServed << " sample rounds (" << gunzip_->samplesLeft
-                          << " left to the host); " << gunzip_->members << " members, " << gunzip_->compressedBytes << " -> " << gunzip_->inflatedBytes
-                          << " bytes; gather " << gunzip_->gatherSeconds << " s, copies + kernel " << gunzip_->runSeconds << " s (kernel "
-                          << gunzip_->kernelMs / 1e3 << " s); decoder threads waited " << gunzip_->waitSeconds << " thread-seconds for it" << std::endl;
+            if (gunzipSet_[0])
+            {
+                GunzipPrefetch & a = *gunzipSet_[0];
+                GunzipPrefetch & b = *gunzipSet_[1];
+                std::cerr << "[popdel timing] loader: profile blocks inflated on the device for " << a.samplesServed + b.samplesServed << " sample rounds (" << a.samplesLeft + b.samplesLeft
+                          << " left to the host), parsed there for " << a.samplesParsed + b.samplesParsed << "; " << a.members + b.members << " members, " << a.compressedBytes + b.compressedBytes << " -> " << a.inflatedBytes + b.inflatedBytes
+                          << " bytes; gather " << a.gatherSeconds + b.gatherSeconds << " s, copies + kernel " << a.runSeconds + b.runSeconds << " s (kernel "
+                          << (a.kernelMs + b.kernelMs) / 1e3 << " s); decoder threads waited " << a.waitSeconds + b.waitSeconds << " thread-seconds for it; " << roundsAhead_
+                          << " rounds fetched ahead, " << roundsOnDemand_ << " when they began (" << roundsGuessedWrong_ << " of them after a wrong guess)" << std::endl;
+            }
             std::cerr << "[popdel timing] parity: " << nearIntegerShifts_ << " reference-shift quotients within 1e-9 of an integer (their truncation "
                          "may differ from the x87 reference's) in " << candidateCells_ << " candidate cells, " << windowCalls_ << " window calls" << std::endl;
             // steady state: the rounds that began after the backend was up, to the end of the loop (last results written)
@@ -597,6 +756,21 @@ public:
                 std::cerr << "[popdel timing] steady state: segments " << rounds_.size() - k0 << " of " << rounds_.size() << "; windows " << windows
                           << "; samples " << p_.sampleNum << "; wall " << wall << " s; decode " << decode << " s; replay " << replay
                           << " s; device kernels " << device << " s" << std::endl;
+                // ... and without the ends: the first two of those rounds (the loaders' buffers are allocated and page-locked, the
+                // tables' pages touched for the first time) and the last (the drain) -- begin of the third to begin of the last
+                if (rounds_.size() >= k0 + 6)
+                {
+                    uint64_t w = 0;
+                    double dec = 0, rep = 0;
+                    for (size_t k = k0 + 2; k + 1 < rounds_.size(); ++k)
+                    {
+                        w += rounds_[k].windows;
+                        dec += rounds_[k].decode;
+                        rep += rounds_[k].replay;
+                    }
+                    std::cerr << "[popdel timing] warmed rounds: segments " << rounds_.size() - k0 - 3 << "; windows " << w << "; samples " << p_.sampleNum
+                              << "; wall " << rounds_.back().start - rounds_[k0 + 2].start << " s; decode " << dec << " s; replay " << rep << " s" << std::endl;
+                }
             }
         }
         if (!timingPrinted_)
@@ -679,10 +853,20 @@ private:
     }
     bool deviceWalkOffered_ = false, deviceWalk_ = false, lightTables_ = false;
     // the round's profile blocks inflated on the device (GunzipPrefetch) once the backend is up; POPDEL_HOST_GUNZIP=1: never
-    std::unique_ptr<GunzipPrefetch> gunzip_;
-    bool gunzipTried_ = false;
+    // two loaders: one serves the round that runs, the other works AHEAD on the round to come (startGunzipPrefetch())
+    std::unique_ptr<GunzipPrefetch> gunzipSet_[2];
+    GunzipPrefetch * gunzip_ = nullptr;         // the running round's, if any
+    int gunzipAhead_ = -1;                      // index of the loader that was started for the round to come
+    bool loaderAhead_ = true;                   // POPDEL_LOADER_AHEAD=0: every round's blocks are fetched when the round starts
+    int64_t guessedBegin_ = 0;
+    std::vector<GunzipPrefetch::Item> pendingGuess_;
+    std::string pendingGuessContig_;
+    int pendingGuessSet_ = 0;
+    uint64_t roundsAhead_ = 0, roundsOnDemand_ = 0, roundsGuessedWrong_ = 0;
     int gunzipDevice_ = 0;
     void startGunzipPrefetch();
+    void startLoaderAhead();
+    void createLoaders();
     unsigned deviceSegments_ = 0, hostSegments_ = 0;
     void leaveDeviceWalk();
     void submitPlannedSegment(const WalkShape & shape, const std::vector<uint8_t> & equalRun, const std::vector<uint8_t> & switches);
@@ -1039,27 +1223,23 @@ bool CallRun::firstWindowOnNextRoi(Coord & minCoord)
 // with the file or the region and whose slots will not be switched (checkAndSwitch() below: a switch ends a sample's turn).
 void CallRun::startGunzipPrefetch()
 {
-    if (!gunzipTried_ && !backendReady_.load() && getenv("POPDEL_DEVICE_GUNZIP_WAIT") && deviceWalkOffered_)
+    gunzip_ = nullptr;
+    pendingGuess_.clear();
+    if (!backendReady_.load() && getenv("POPDEL_DEVICE_GUNZIP_WAIT") && deviceWalkOffered_)
         ensureBackend();            // (tests: short runs are over before the backend is up and would never take this path)
-    if (!gunzipTried_ && backendReady_.load())
-    {
-        gunzipTried_ = true;
-        if (deviceWalkOffered_ && !p_.uncompressedIn && !getenv("POPDEL_HOST_GUNZIP"))
-        {
-            gunzip_.reset(new GunzipPrefetch(p_, gunzipDevice_));
-            if (!gunzip_->ok())
-                gunzip_.reset();
-        }
-    }
-    if (!gunzip_)
+    if (!backendReady_.load() || !gunzipSet_[0])      // (the loaders are created by the backend's thread, before it says ready)
         return;
-    if (!gunzip_->ok())
+    if (!gunzipSet_[0]->ok() || !gunzipSet_[1]->ok())
     {
-        gunzip_->finish();
+        // (a loader gave up: this and the rounds to come are inflated on the host)
+        for (auto & g : gunzipSet_)
+            g->finish();
+        gunzipAhead_ = -1;
         return;
     }
     const Region & roi = p_.allRois[p_.nextRoi];
     std::vector<GunzipPrefetch::Item> items;
+    int64_t farthest = -1, nearestBorder = -1;
     for (unsigned i = 0; i < p_.sampleNum; ++i)
     {
         if (finishedFiles_[i] || finishedRois_[i])
@@ -1068,16 +1248,108 @@ void CallRun::startGunzipPrefetch()
         const unsigned pos = nextCandidate_[i].pos;
         if (st.tooBigForNext(pos) || st.needsSwitch(pos))
             continue;
+        const int64_t right = st.slots[st.writeSlot].right;
+        nearestBorder = nearestBorder < 0 ? right : std::min(nearestBorder, right);
         GunzipPrefetch::Item it;
         it.sample = i;
+        it.parse = p_.rgs[i].size() == 1;
         it.beginPos = roi.beginPos;
+        it.firstRegion = static_cast<uint32_t>(roi.beginPos) / p_.indexRegionSizes[p_.representativeContigs ? 0 : i];
         // (the decoder stops at the first window at or beyond the border; 256-bp windows may begin up to 255 bp before it)
         const int64_t end = std::min<int64_t>(static_cast<int64_t>(st.slots[st.writeSlot].right) + 256, static_cast<int64_t>(roi.endPos) + 256);
         it.endPos = static_cast<int32_t>(std::min<int64_t>(end, 0x7fffffff));
         if (it.endPos >= it.beginPos)
+        {
             items.push_back(it);
+            farthest = std::max<int64_t>(farthest, it.endPos);
+        }
     }
-    gunzip_->start(std::move(items), roi.seqName);
+    // 1. this round: the loader that went ahead if its guess holds for (nearly) all readers, else a fresh one
+    const int ahead = gunzipAhead_;
+    gunzipAhead_ = -1;
+    int current = -1;
+    static const bool trace = getenv("POPDEL_LOADER_TRACE") != nullptr;
+    if (trace)
+        std::cerr << "[popdel loader] round begins at " << roi.seqName << ":" << roi.beginPos << " (region ends at " << roi.endPos << "), " << items.size()
+                  << " readers, farthest end " << farthest << (ahead >= 0 ? "; guessed begin " + std::to_string(guessedBegin_) : std::string()) << std::endl;
+    if (ahead >= 0)
+    {
+        const size_t covered = items.empty() ? 0 : gunzipSet_[ahead]->adopt(items, roi.seqName);
+        if (trace)
+            std::cerr << "[popdel loader] the guess covers " << covered << " of them" << std::endl;
+        if (!items.empty() && covered * 10 >= items.size() * 9)
+        {
+            current = ahead;
+            ++roundsAhead_;
+        }
+        else
+        {
+            gunzipSet_[ahead]->finish();
+            ++roundsGuessedWrong_;
+        }
+    }
+    if (current < 0 && !items.empty())
+    {
+        current = ahead >= 0 ? 1 - ahead : 0;
+        gunzipSet_[current]->start(items, roi.seqName);
+        ++roundsOnDemand_;
+    }
+    if (current >= 0)
+        gunzip_ = gunzipSet_[current].get();
+    // 2. the round to come, guessed: everybody who still has data reads, from the border at which this round's readers stop
+    //    (the next round begins at the first window at or beyond it: the same index region unless the border lies within a
+    //    window's length of the region's end) and one slot further. Its first chunks are inflated and parsed while this round is
+    //    decoded and replayed; the rest follows as that round releases the buffers. A wrong guess costs device time, never a
+    //    result (adopt()).
+    if (!loaderAhead_ || current < 0 || farthest < 0 || nearestBorder <= roi.beginPos)
+        return;
+    const int64_t nextBegin = nearestBorder;
+    if (nextBegin >= roi.endPos)
+        return;
+    const int64_t step = nextBegin - roi.beginPos;
+    const int64_t nextEnd = std::min<int64_t>(std::min<int64_t>(farthest + step, static_cast<int64_t>(roi.endPos) + 256), 0x7fffffff);
+    std::vector<GunzipPrefetch::Item> guess;
+    for (unsigned i = 0; i < p_.sampleNum; ++i)
+    {
+        if (finishedFiles_[i])
+            continue;
+        GunzipPrefetch::Item it;
+        it.sample = i;
+        it.parse = p_.rgs[i].size() == 1;
+        it.beginPos = static_cast<int32_t>(nextBegin);
+        it.firstRegion = static_cast<uint32_t>(nextBegin) / p_.indexRegionSizes[p_.representativeContigs ? 0 : i];
+        it.endPos = static_cast<int32_t>(nextEnd);
+        if (it.endPos >= it.beginPos)
+            guess.push_back(it);
+    }
+    if (guess.empty())
+        return;
+    // (started once this round's loader has all its chunks through: the blocks this round still waits for go first --
+    // startLoaderAhead(), called batch by batch)
+    pendingGuess_ = std::move(guess);
+    pendingGuessContig_ = roi.seqName;
+    pendingGuessSet_ = 1 - current;
+    guessedBegin_ = nextBegin;
+    startLoaderAhead();
+}
+
+void CallRun::createLoaders()
+{
+    if (!deviceWalkOffered_ || p_.uncompressedIn || getenv("POPDEL_HOST_GUNZIP"))
+        return;
+    for (auto & g : gunzipSet_)
+        g.reset(new GunzipPrefetch(p_, gunzipDevice_));
+    const char * ahead = getenv("POPDEL_LOADER_AHEAD");
+    loaderAhead_ = !(ahead && ahead[0] == '0');
+}
+
+void CallRun::startLoaderAhead()
+{
+    if (pendingGuess_.empty() || !gunzip_ || !gunzip_->allDone())
+        return;
+    gunzipAhead_ = pendingGuessSet_;
+    gunzipSet_[gunzipAhead_]->start(std::move(pendingGuess_), pendingGuessContig_);
+    pendingGuess_.clear();
 }
 
 bool CallRun::checkAndSwitch(const std::vector<unsigned> & rg, unsigned beginPos, unsigned * border)
@@ -1108,9 +1380,73 @@ void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned
     const unsigned contigIdx = p_.representativeContigs ? 0 : i;
     const std::vector<std::string> & contigNames = p_.contigNames[contigIdx];
     const Region & roi = p_.allRois[p_.nextRoi];
+    const unsigned borderIn = border;
+    const GunzipPrefetch::Ready * pre = gunzip_ ? gunzip_->wait(i) : nullptr;
+    if (pre && pre->parsed)
+    {
+        // The device has inflated AND parsed the blocks from the jump position on: the loop below, on its arrays. If the point at
+        // which the loader stops lies within them (the rule) the replay reads them where they are; if not, the sample is decoded
+        // the ordinary way.
+        size_t r0 = 0;
+        bool stopped = false;
+        size_t r = 0;
+        for (; r < pre->nRaws && !stopped; ++r)
+        {
+            const DecodedRaw & raw = pre->raws[r];
+            if (contigNames[raw.chrom] != coordContig)
+            {
+                stopped = true;             // (the window of the other contig is the last one the replay sees)
+                break;
+            }
+            if (raw.beginPos + 255 < roi.beginPos)
+            {
+                if (r == r0)
+                    ++r0;                   // (windows ahead of the region: a prefix, not handed on)
+                continue;
+            }
+            for (uint32_t wi = raw.firstWin; wi < raw.firstWin + raw.nWin; ++wi)
+            {
+                const FlatWindow & w = pre->wins[wi];
+                if (contigNames[w.chrom] != roi.seqName || w.beginPos >= roi.endPos)
+                {
+                    stopped = true;
+                    break;
+                }
+                if (w.beginPos < roi.beginPos)
+                    continue;
+                const unsigned pos = static_cast<unsigned>(w.beginPos);
+                if (pos >= border + numWindows)
+                {
+                    border = pos + numWindows;
+                    out.sawFarWindow = true;
+                }
+                else if (pos >= border)
+                {
+                    stopped = true;
+                    break;
+                }
+            }
+            if (stopped)
+                break;
+        }
+        if (stopped)
+        {
+            out.rawsV = pre->raws + r0;
+            out.nRawsV = r + 1 - r0;
+            out.winsV = pre->wins;
+            out.countsV = pre->counts;
+            out.recsV = pre->recs;
+            out.nRecsV = pre->nRecs;
+            return;
+        }
+        out.sawFarWindow = false;           // (decoded again below)
+        border = borderIn;
+        if (!pre->bytesValid)
+            pre = nullptr;
+    }
     ProfileFile in(p_.inputFiles[i]);
     std::unique_ptr<ByteSource> src;
-    if (const GunzipPrefetch::Ready * pre = gunzip_ ? gunzip_->wait(i) : nullptr)
+    if (pre && pre->bytesValid)
         src = in.openPrefetched(pre->data, pre->size, pre->resume);     // (the device has inflated the blocks from the jump position on)
     else
     {
@@ -1184,9 +1520,10 @@ unsigned CallRun::replaySegment(const DecodedStream & in, const std::string & fi
     ChromProfile & prof = *profile_;
     const bool oneRg = rg.size() == 1;
     if (oneRg)
-        prof.reserveRun(rg[0], in.recs.size());
-    for (const DecodedRaw & raw : in.raws)
+        prof.reserveRun(rg[0], in.nRecsV);
+    for (size_t rawIdx = 0; rawIdx < in.nRawsV; ++rawIdx)
     {
+        const DecodedRaw & raw = in.rawsV[rawIdx];
         if (contigNames[raw.chrom] != coordinate.contig)
         {
             prof.performPartialSwitches(rg, border);
@@ -1201,7 +1538,7 @@ unsigned CallRun::replaySegment(const DecodedStream & in, const std::string & fi
         const uint32_t wEnd = raw.firstWin + raw.nWin;
         for (uint32_t wi = raw.firstWin; wi < wEnd; ++wi)
         {
-            const FlatWindow & w = in.wins[wi];
+            const FlatWindow & w = in.winsV[wi];
             if (!onRoiContig || w.beginPos >= roi.endPos)
             {
                 prof.performPartialSwitches(rg, border);
@@ -1241,12 +1578,12 @@ unsigned CallRun::replaySegment(const DecodedStream & in, const std::string & fi
                 // them is the same sequence of operations
                 const StartSlots & st = prof.starts[rg[0]];
                 const unsigned right = st.slots[st.writeSlot].right;
-                uint32_t n = in.counts[wi];
+                uint32_t n = in.countsV[wi];
                 uint32_t wj = wi + 1;
-                for (; wj < wEnd && in.wins[wj].beginPos < roi.endPos && static_cast<unsigned>(in.wins[wj].beginPos) < right; ++wj)
-                    n += in.counts[wj];
+                for (; wj < wEnd && in.winsV[wj].beginPos < roi.endPos && static_cast<unsigned>(in.winsV[wj].beginPos) < right; ++wj)
+                    n += in.countsV[wj];
                 const InsertHistogram & h = p_.histograms[rg[0]];
-                prof.addRun(rg[0], reinterpret_cast<const uint32_t *>(in.recs.data() + w.firstRec), n,
+                prof.addRun(rg[0], reinterpret_cast<const uint32_t *>(in.recsV + w.firstRec), n,
                             static_cast<int>(h.median) - 2 * static_cast<int>(h.readLength));
                 wi = wj - 1;
                 continue;
@@ -1254,9 +1591,9 @@ unsigned CallRun::replaySegment(const DecodedStream & in, const std::string & fi
             uint32_t r0 = w.firstRec;
             for (size_t r = 0; r < rg.size(); ++r)
             {
-                const uint32_t n = in.counts[static_cast<size_t>(wi) * rg.size() + r];
+                const uint32_t n = in.countsV[static_cast<size_t>(wi) * rg.size() + r];
                 const InsertHistogram & h = p_.histograms[rg[r]];
-                prof.addRun(rg[r], reinterpret_cast<const uint32_t *>(in.recs.data() + r0), n,
+                prof.addRun(rg[r], reinterpret_cast<const uint32_t *>(in.recsV + r0), n,
                             static_cast<int>(h.median) - 2 * static_cast<int>(h.readLength));
                 r0 += n;
             }
@@ -2048,6 +2385,7 @@ int CallRun::run()
             warmup.join();
             createBackend();
             chooseMergeSite();
+            createLoaders();            // (streams, events: 0.15 s that the main thread spends on the first round anyway)
             backendReadyAt_ = PhaseClock::now();
             backendReady_.store(true);
             gTrace.mark("backend created");
@@ -2100,6 +2438,14 @@ int CallRun::run()
         }
         rounds_.emplace_back();
         rounds_.back().start = PhaseClock::now();
+        if (gTrace.on)
+        {
+            struct rusage ru;
+            std::memset(&ru, 0, sizeof(ru));
+            getrusage(RUSAGE_SELF, &ru);
+            gTrace.mark("round begins; process CPU so far " + std::to_string(ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec) + " s user, " +
+                        std::to_string(ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec) + " s system, " + std::to_string(ru.ru_minflt) + " page faults");
+        }
         startGunzipPrefetch();
         // (large batches: 16 threads replayed 1000 samples in 0.57 s with batches of 128 and in 0.22 s with 512)
         const unsigned batch = std::max(512u, 8u * hostThreads());
@@ -2155,11 +2501,12 @@ int CallRun::run()
                 const unsigned i = readers[k];
                 const StartSlots & st = profile_->starts[p_.rgs[i][0]];
                 decodeSample(i, nextCandidate_[i].contig, st.slots[st.writeSlot].right, st.numWindows, decoded[k]);
+                if (!decoded[k].rawsV)              // (parsed on the host: the replay reads the stream's own arrays)
+                    decoded[k].viewOwn();
             });
             clock_.decode += PhaseClock::now() - t0;
             rounds_.back().decode += PhaseClock::now() - t0;
-            if (gunzip_)
-                gunzip_->releaseBelow(b1);
+            startLoaderAhead();
             gTrace.mark("batch: decoded");
             t0 = PhaseClock::now();
             // (3) insert the records and switch slots: per sample independent unless a stream contains a window beyond the
@@ -2193,6 +2540,11 @@ int CallRun::run()
                 processSegmentCode(readers[k], codes[k]);
             clock_.replay += PhaseClock::now() - t0;
             rounds_.back().replay += PhaseClock::now() - t0;
+            if (gunzip_)
+            {
+                gunzip_->releaseBelow(b1);      // (the replay has read the device-parsed arrays where they lay)
+                startLoaderAhead();
+            }
             gTrace.mark("batch: replayed");
         }
         processSegment();

@@ -474,8 +474,7 @@ void ChromProfile::addRun(unsigned rg, const uint32_t * posDev, size_t n, int in
             slot.entries.push_back(StartEntry{startPos, deviation});
             en.addFast(id, endPos);
         };
-        for (size_t i = 0; i < n; ++i)
-        {
+        auto one = [&](size_t i) {
             const unsigned startPos = posDev[2 * i];
             const int deviation = static_cast<int32_t>(posDev[2 * i + 1]);
             const int inner = deviation + innerOffset;
@@ -495,6 +494,66 @@ void ChromProfile::addRun(unsigned rg, const uint32_t * posDev, size_t n, int in
                 ++load;
                 load -= en.countEndedFast(startPos);
             }
+        };
+        // Record by record the rule asks the end table after every record how many pairs are over. Where that cannot matter --
+        // a block of records short enough for the load to stay below the cap whatever the answers, in non-decreasing order,
+        // with the counting cursor certain to stay inside its slot (EndSlots::quietBlock) -- the block is filed in one go and the
+        // table asked once, behind its last record: the answers add up to the same number and leave the same cursors.
+        constexpr size_t kBlock = 64;
+        unsigned endBuf[kBlock];
+        size_t i = 0;
+        while (i < n)
+        {
+            size_t block = 0;
+            bool below = true;
+            if (load < cap && cap - load >= 8u && n - i >= 8u)
+            {
+                // the block: as many records as the cap leaves room for, as long as they come in order (and, if the end table's
+                // counting cursor is in its write slot, as long as they end below that slot's border)
+                const size_t want = std::min<size_t>(std::min<size_t>(kBlock, cap - load), n - i);
+                const unsigned border = en.slots[en.writeSlot].right;
+                const bool cursorInWriteSlot = en.endPosSlot == en.writeSlot;
+                unsigned prev = posDev[2 * i];
+                for (; block < want; ++block)
+                {
+                    const unsigned startPos = posDev[2 * (i + block)];
+                    const int inner = static_cast<int32_t>(posDev[2 * (i + block) + 1]) + innerOffset;
+                    const unsigned endPos = startPos + (inner > 0 ? static_cast<unsigned>(inner) : 0u);
+                    const bool in = (endPos / 30u) * 30u < border;
+                    if (startPos < prev || (cursorInWriteSlot && !in && block >= 4))
+                        break;
+                    below = below && in;
+                    prev = startPos;
+                    endBuf[block] = endPos;
+                }
+                if (block >= 4)
+                    block = en.quietBlock(posDev[2 * i], posDev[2 * (i + block - 1)], block, below);
+            }
+            if (block < 4)
+            {
+                // (not now: a few records one by one before the next try)
+                const size_t upTo = std::min(n, i + 8);
+                for (; i < upTo; ++i)
+                    one(i);
+                continue;
+            }
+            StartSlots::Slot & slot = st.slots[st.writeSlot];
+            slot.endBorder = en.slots[en.writeSlot].right;
+            if (!slot.entries.empty() && posDev[2 * i] < slot.entries.back().startPos)
+                slot.sorted = false;
+            const unsigned id = st.insertionCount;
+            st.insertionCount += static_cast<unsigned>(block);
+            static_assert(sizeof(StartEntry) == 2 * sizeof(uint32_t), "a record {pos, dev} is a start entry");
+            const StartEntry * src = reinterpret_cast<const StartEntry *>(posDev + 2 * i);
+            slot.entries.insert(slot.entries.end(), src, src + block);
+            if (below)
+                en.addBlockToWriteSlot(id, endBuf, block);
+            else
+                for (size_t j = 0; j < block; ++j)
+                    en.addFast(id + static_cast<unsigned>(j), endBuf[j]);
+            load += static_cast<unsigned>(block);
+            load -= en.countEndedFast(posDev[2 * (i + block - 1)]);
+            i += block;
         }
         activeLoad[rg] = load;
         return;

@@ -159,6 +159,76 @@ public:
         }
         add(id, endPos);
     }
+    // How many of `n` records (n >= 1, start positions in non-decreasing order from firstPos to lastPos) may be filed without
+    // asking countEnded() in between: n (or fewer) if the answers to the questions left out are certain to come from the
+    // everyday case of countEndedFast() -- light tables, positions from the counting cursor on and inside the windows the
+    // counts cover, and the cursor unable to reach the end of its slot: either every record of the block is filed into that
+    // very slot (intoWriteSlot, and the cursor is in the write slot: the record filed last is never over when the question
+    // behind it is asked) or the slot holds more entries than could be over even if all of the block were (the cases in which
+    // getEndCount() moves on to the next slot answer question by question what one question would not) -- so that one
+    // question behind the block gives the sum of their answers and leaves the same state. Else 0.
+    size_t quietBlock(unsigned firstPos, unsigned lastPos, size_t n, bool intoWriteSlot) const
+    {
+        const Slot & slot = slots[endPosSlot];
+        const size_t have = slot.entries.size();
+        if (!light || dNextOffset != 0 || dNext >= have)
+            return 0;
+        const unsigned firstBins = firstPos / 30u, lastBins = lastPos / 30u;
+        const unsigned tFirst = firstBins > slot.baseBin ? firstBins - slot.baseBin : 0u;
+        const unsigned tLast = lastBins > slot.baseBin ? lastBins - slot.baseBin : 0u;
+        if (tFirst < slot.curBin[0] || tLast > slot.hist.size())
+            return 0;
+        if (intoWriteSlot && endPosSlot == writeSlot)
+            return n;
+        size_t over = slot.curCum[0];
+        const unsigned from = slot.curBin[0] > slot.lowBin ? slot.curBin[0] : slot.lowBin;
+        const unsigned to = tLast < slot.highBin ? tLast : slot.highBin;
+        for (unsigned b = from; b < to; ++b)
+            over += slot.hist[b];
+        // (fewer records reach no further: what holds for n holds for any shorter block)
+        if (over + 1 >= have)
+            return 0;
+        return std::min<size_t>(n, have - over - 1);
+    }
+    // addFast() for records id, id + 1, ... whose last windows all lie below the write slot's border, the everyday case kept in
+    // registers over the block
+    void addBlockToWriteSlot(unsigned id, const unsigned * endPos, size_t n)
+    {
+        Slot & slot = slots[writeSlot];
+        size_t j = 0;
+        if (light && !slot.entries.empty())
+        {
+            const unsigned base = slot.baseBin, cur0 = slot.curBin[0], cur1 = slot.curBin[1];
+            const size_t bins = slot.hist.size();
+            uint16_t * hist = slot.hist.data();
+            unsigned low = slot.lowBin, high = slot.highBin, maxWin = slot.maxWin, cum0 = slot.curCum[0], cum1 = slot.curCum[1];
+            unsigned before = slot.entries.back().lastWindow;
+            bool ordered = slot.ordered;
+            for (; j < n; ++j)
+            {
+                const unsigned bin = endPos[j] / 30u, lastWin = bin * 30u, b = bin - base;      // (b wraps below the base: out of range)
+                if (b >= bins || hist[b] == 0xffffu)
+                    break;
+                ordered = ordered && lastWin >= before;
+                before = lastWin;
+                low = b < low ? b : low;
+                high = b >= high ? b + 1 : high;
+                maxWin = lastWin > maxWin ? lastWin : maxWin;
+                ++hist[b];
+                cum0 += b < cur0 ? 1u : 0u;
+                cum1 += b < cur1 ? 1u : 0u;
+                slot.entries.push_back(EndEntry{id + static_cast<unsigned>(j), lastWin});
+            }
+            slot.ordered = ordered;
+            slot.lowBin = low;
+            slot.highBin = high;
+            slot.maxWin = maxWin;
+            slot.curCum[0] = cum0;
+            slot.curCum[1] = cum1;
+        }
+        for (; j < n; ++j)
+            addFast(id + static_cast<unsigned>(j), endPos[j]);
+    }
     unsigned countEndedFast(unsigned pos)
     {
         Slot & slot = slots[endPosSlot];

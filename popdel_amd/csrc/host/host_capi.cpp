@@ -329,7 +329,15 @@ int pdh_inflate_members_cpu(const uint8_t * data, const uint64_t * offsets, uint
 // a run per round, slots switched in between -- with heavy or light end tables. Returns seconds through *seconds and a
 // checksum of what the loader reads off the tables (load counter, cursors, slot sizes, last windows) through *checksum:
 // light and heavy must give the same.
+// `flavour` shapes the records: 0 the everyday stream; 1 bursts of pairs a base or two apart (the load reaches the cap and
+// records are dropped); 2 one record in twenty steps back by up to 40 bp (blocks out of order); 3 wide inserts (sd 400: end
+// records beyond the write slot's border, negative inner distances); 4 all of these and gaps of several slot lengths.
+int pdh_bench_filing_ex(unsigned rounds, int light, unsigned maxLoad, unsigned seed, int flavour, double * seconds, uint64_t * checksum);
 int pdh_bench_filing(unsigned rounds, int light, unsigned maxLoad, double * seconds, uint64_t * checksum)
+{
+    return pdh_bench_filing_ex(rounds, light, maxLoad, 4242u, 0, seconds, checksum);
+}
+int pdh_bench_filing_ex(unsigned rounds, int light, unsigned maxLoad, unsigned seed, int flavour, double * seconds, uint64_t * checksum)
 {
     if (!seconds || !checksum || rounds == 0)
         return 1;
@@ -339,8 +347,9 @@ int pdh_bench_filing(unsigned rounds, int light, unsigned maxLoad, double * seco
     prof.resetTo(1000000);
     if (light)
         prof.setLightEnds(true);
-    std::mt19937 gen(4242);
-    std::normal_distribution<double> ins(0.0, 50.0);
+    std::mt19937 gen(seed);
+    std::normal_distribution<double> ins(0.0, flavour >= 3 ? 400.0 : 50.0);
+    unsigned burst = 0;
     std::vector<uint32_t> rec;
     uint64_t sum = 1469598103934665603ull;
     auto mix = [&sum](uint64_t v) { sum = (sum ^ v) * 1099511628211ull; };
@@ -353,10 +362,23 @@ int pdh_bench_filing(unsigned rounds, int light, unsigned maxLoad, double * seco
         const unsigned right = prof.starts[0].slots[prof.starts[0].writeSlot].right;
         while (pos < right)
         {
-            rec.push_back(pos);
+            unsigned at = pos;
+            if ((flavour == 2 || flavour == 4) && gen() % 20 == 0 && at > 1000040)
+                at -= gen() % 41;
+            rec.push_back(at);
             rec.push_back(static_cast<uint32_t>(static_cast<int32_t>(std::lround(ins(gen)))));
-            pos += 1 + gen() % 19;
+            if ((flavour == 1 || flavour == 4) && burst == 0 && gen() % 400 == 0)
+                burst = 50 + gen() % 400;
+            if (burst)
+            {
+                --burst;
+                pos += gen() % 3;
+            }
+            else
+                pos += 1 + gen() % 19;
         }
+        if (flavour == 4 && gen() % 7 == 0)
+            pos += buffer * (1 + gen() % 3) + gen() % 5000;      // (a gap: the next round's records lie slots ahead)
         prof.reserveRun(0, rec.size() / 2);
         const auto t0 = std::chrono::steady_clock::now();
         prof.addRun(0, rec.data(), rec.size() / 2, 500 - 300);
@@ -392,6 +414,15 @@ int pdh_bench_filing(unsigned rounds, int light, unsigned maxLoad, double * seco
             mix(e.id);
             mix(e.lastWindow);
         }
+    for (int k = 0; k < 3; ++k)
+    {
+        mix(prof.starts[0].slots[k].sorted ? 1u : 0u);
+        for (const pdh::StartEntry & e : prof.starts[0].slots[k].entries)
+        {
+            mix(e.startPos);
+            mix(static_cast<uint32_t>(e.deviation));
+        }
+    }
     *seconds = total;
     *checksum = sum;
     return 0;

@@ -414,9 +414,11 @@ void ProfileFile::jumpToRegion(const std::vector<std::string> & contigNames, con
 
 bool ProfileFile::blockOffsets(const std::vector<std::string> & contigNames, const std::vector<int32_t> & contigLengths,
                                unsigned indexRegionSize, const std::string & contig, int32_t beginPos, int32_t endPos,
-                               std::vector<uint64_t> & offsets)
+                               std::vector<uint64_t> & offsets, std::vector<uint64_t> * perRegion)
 {
     offsets.clear();
+    if (perRegion)
+        perRegion->clear();
     const int fd = fileno(fp_);
     uint32_t numRegions = 0;
     if (pread(fd, &numRegions, sizeof(numRegions), 7 + sizeof(uint32_t)) != static_cast<ssize_t>(sizeof(numRegions)) || numRegions == 0)
@@ -454,6 +456,8 @@ bool ProfileFile::blockOffsets(const std::vector<std::string> & contigNames, con
         if (offsets.empty() || o != offsets.back())
             offsets.push_back(o);
     }
+    if (perRegion)
+        *perRegion = raw;
     return offsets.size() >= 1;
 }
 

@@ -90,9 +90,11 @@ public:
     // index regions from the one that holds beginPos to the one behind the one that holds endPos (clipped to the contig's
     // regions; the end of the file behind the last region), duplicates removed -- a compressed profile holds one gzip member
     // per non-empty index region, so consecutive offsets bracket one member each. Leaves the file position alone.
-    // Returns false if the index cannot be read.
+    // Returns false if the index cannot be read. perRegion (optional): the same offsets region by region, duplicates kept --
+    // perRegion[d] is where a jump to the d-th region behind beginPos's lands.
     bool blockOffsets(const std::vector<std::string> & contigNames, const std::vector<int32_t> & contigLengths, unsigned indexRegionSize,
-                      const std::string & contig, int32_t beginPos, int32_t endPos, std::vector<uint64_t> & offsets);
+                      const std::string & contig, int32_t beginPos, int32_t endPos, std::vector<uint64_t> & offsets,
+                      std::vector<uint64_t> * perRegion = nullptr);
     // Byte source over `size` bytes already inflated (the blocks from the jump position on) that goes on reading the file at
     // `resumeOffset` when they are used up -- what openSource() would deliver from the jump position, with the first blocks
     // inflated by someone else (the device).

@@ -63,3 +63,27 @@ def test_a_damaged_profile_behaves_as_on_the_host(built, cohort_dir, tmp_path):
     assert new == old
     if r0.returncode != 0:
         assert r1.stderr.splitlines()[-1] == r0.stderr.splitlines()[-1]
+
+
+def test_loader_variants_write_the_same_vcf(built, cohort_dir, tmp_path):
+    """The loader's switches -- blocks parsed on the host (POPDEL_HOST_PARSE=1), every round fetched when it begins
+    (POPDEL_LOADER_AHEAD=0) -- against the default (parsed on the device, the next round's blocks fetched ahead on a guess):
+    same bytes; and the default did fetch rounds ahead."""
+    from popdel_amd import synth
+    d = cohort_dir("s600", 600, synth.single_deletion)
+    args = ["-r", "chr20:1000000-2000000"]
+    r, base = call(d, str(tmp_path / "base.vcf"), *args)
+    assert r.returncode == 0, r.stderr[-300:]
+    line = [l for l in r.stderr.splitlines() if "loader: profile blocks" in l][0]
+    ahead = int(line.split("thread-seconds for it; ")[1].split()[0])
+    parsed = int(line.split("parsed there for ")[1].split(";")[0])
+    assert ahead >= 1 and parsed >= 600, line
+    for env in ({"POPDEL_HOST_PARSE": "1"}, {"POPDEL_LOADER_AHEAD": "0"}, {"POPDEL_HOST_PARSE": "1", "POPDEL_LOADER_AHEAD": "0"}):
+        r1, other = call(d, str(tmp_path / "other.vcf"), *args, env=env)
+        assert r1.returncode == 0, r1.stderr[-300:]
+        assert other == base, env
+        line = [l for l in r1.stderr.splitlines() if "loader: profile blocks" in l][0]
+        if "POPDEL_LOADER_AHEAD" in env:
+            assert " 0 rounds fetched ahead" in line, line
+        if "POPDEL_HOST_PARSE" in env:
+            assert "parsed there for 0;" in line, line

@@ -52,17 +52,30 @@ def main():
                           r"replay ([0-9.e+-]+) s; device kernels ([0-9.e+-]+) s", r.stderr)
             cpu = re.search(r"CPU time ([0-9.e+-]+) s user, ([0-9.e+-]+) s system", r.stderr)
             row = dict(variant=v, wall_seconds=round(wall, 3), same_vcf_as_first=text == first,
-                       cpu_seconds=(float(cpu.group(1)) + float(cpu.group(2))) if cpu else None)
+                       cpu_seconds=(float(cpu.group(1)) + float(cpu.group(2))) if cpu else None,
+                       cpu_system_seconds=float(cpu.group(2)) if cpu else None)
             if m:
                 segs, _, windows, samples = (int(x) for x in m.groups()[:4])
                 t_wall, t_dec, t_rep, t_dev = (float(x) for x in m.groups()[4:])
                 row.update(steady_seconds_per_segment=round(t_wall / segs, 4), value=windows * samples / t_wall,
                            decode_per_segment=round(t_dec / segs, 4), replay_per_segment=round(t_rep / segs, 4),
                            device_kernels_per_segment=round(t_dev / segs, 5), steady_segments=segs)
+            mw = re.search(r"warmed rounds: segments (\d+); windows (\d+); samples (\d+); wall ([0-9.e+-]+) s; decode ([0-9.e+-]+) s; replay ([0-9.e+-]+) s", r.stderr)
+            if mw:
+                row.update(warmed_segments=int(mw.group(1)), warmed_seconds_per_segment=round(float(mw.group(4)) / int(mw.group(1)), 4),
+                           warmed_value=int(mw.group(2)) * int(mw.group(3)) / float(mw.group(4)))
             ph = [l for l in r.stderr.splitlines() if "[popdel timing] threads" in l]
             if ph:
                 row["phases"] = {k.strip().replace(" ", "_"): float(v) for k, v in re.findall(r"([a-z][a-z+ ]*?) ([0-9][0-9.e+-]*) s", ph[-1])}
             extra = [l for l in r.stderr.splitlines() if "[popdel timing] loader" in l]
+            trace = [l[len("[popdel loader] "):] for l in r.stderr.splitlines() if l.startswith("[popdel loader]")]
+            if trace:
+                row["loader_trace"] = trace
+            timeline = [l for l in r.stderr.splitlines() if l.startswith("[popdel timeline]")]
+            if timeline:            # (POPDEL_TIMING=2 among the variant's settings)
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "e2e_timeline_%d.txt" % len(rows)), "w") as f:
+                    f.write("\n".join(timeline) + "\n")
             if extra:
                 row["loader"] = extra[-1][len("[popdel timing] "):]
             rows.append(row)
