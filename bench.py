@@ -98,9 +98,9 @@ def parse_args(argv=None):
     ap.add_argument("--e2e-samples", type=int, default=1000,
                     help="N = 1: profiles of the end-to-end leg (`popdel call` on generated profile files, 1 Mb region); 0: skip")
     ap.add_argument("--e2e-cohort-samples", type=int, default=4000,
-                    help="N = 1: profiles of the cohort-scale end-to-end leg (`popdel call` on generated profiles x 2 Mb = 10 segments; "
+                    help="N = 1: profiles of the cohort-scale end-to-end leg (`popdel call` on generated profiles x 4 Mb = 20 segments; "
                          "steady state: start-up and teardown excluded); 0: skip")
-    ap.add_argument("--e2e-cohort-mb", type=int, default=2, help="region of that leg in Mb")
+    ap.add_argument("--e2e-cohort-mb", type=int, default=4, help="region of that leg in Mb")
     ap.add_argument("--e2e-cohort-budget", type=float, default=150.0,
                     help="wall-time budget of that leg in seconds (cohort writing included): the cohort is cut down to what the "
                          "writing rate measured on the first profiles allows")
@@ -206,6 +206,44 @@ def usable_cores():
     return n
 
 
+def bind_to_gpu_node(device_index):
+    """Binds this process to the CPUs of the NUMA node its GPU hangs off (before anything touches the GPU, and before the big
+    host arrays are allocated: first touch then puts them next to the GPU's PCIe root). On the two-socket GPU boxes an
+    unbound run lands on either socket from run to run -- the streaming leg was seen at 0.55 and at 1.8e9 window x sample/s
+    on one box. Which node: the k-th GPU of the KFD topology this job may see -> its PCI address -> sysfs. Returns the node,
+    or None if anything is not as expected (the process is then left as it is). BENCH_NO_NUMA_BIND=1 switches it off."""
+    if os.environ.get("BENCH_NO_NUMA_BIND") or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        gpus = []
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        for name in sorted(os.listdir(base), key=int):
+            try:
+                props = dict(l.split()[:2] for l in open(os.path.join(base, name, "properties")) if len(l.split()) >= 2)
+            except OSError:
+                continue            # (other jobs' GPUs are hidden from this one)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(props)
+        if device_index >= len(gpus):
+            return None
+        loc, dom = int(gpus[device_index]["location_id"]), int(gpus[device_index].get("domain", "0"))
+        bdf = "%04x:%02x:%02x.%x" % (dom & 0xffff, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -295,6 +333,8 @@ def main():
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+
+    numa_node = bind_to_gpu_node(0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0")))
 
     import numpy as np
     import torch
@@ -507,6 +547,7 @@ def main():
             "calls_per_step": h["n_calls"] / steps, "candidate_cells_per_step": h["n_cand"] / steps,
             "max_life": tinfo["max_life"], "contexts_per_gpu": args.contexts, "pipelined_tickets": not args.serial,
             "lanes_per_context": LANES, "tickets_in_flight": (1 if args.serial else (2 * LANES if LANES > 1 else 2)),
+            "host_numa_node": numa_node,        # (rank 0's: the process runs on its GPU's node, bind_to_gpu_node())
             # host arrays -> chunked layout -> HBM for one segment of all samples; with it inside every pass the rate
             # would be cells_per_pass / (stage_seconds + pass time): reported, never `value`
             "staging_seconds_per_segment": stage_seconds,
@@ -1075,7 +1116,7 @@ def main():
             shutil.rmtree(d, ignore_errors=True)
 
     def e2e_cohort_leg():
-        # `popdel call` at cohort scale, steady state: >= 4,000 generated profiles x 2 Mb (10 segments of 200 kb), the product
+        # `popdel call` at cohort scale, steady state: >= 4,000 generated profiles x 4 Mb (20 segments of 200 kb), the product
         # binary on all usable cores; what counts is the time per segment once the backend is up (POPDEL_TIMING's
         # "steady state" line: from the first round that began after the backend was created to the last record written),
         # the share of it the device works, and the host phases behind it
@@ -1118,7 +1159,21 @@ def main():
             cpu = re.search(r"CPU time ([0-9.e+-]+) s user, ([0-9.e+-]+) s system", r.stderr)
             par = re.search(r"parity: (\d+) reference-shift quotients .* in (\d+) candidate cells, (\d+) window calls", r.stderr)
             n_records = sum(1 for l in open(os.path.join(d, "out.vcf")) if not l.startswith("#"))
-            return dict(workload="popdel call on %d generated profiles, chr20:%d-%d (%d segments of 200 kb), merged VCF; steady state = "
+            # ... and the same without the ends: the first two of those rounds pay for the loaders' page-locked buffers and the
+            # tables' first touch, the last ends with the drain (POPDEL_TIMING's "warmed rounds" line: begin of the third such
+            # round to begin of the last) -- what a whole-genome run (15,000 rounds) sees
+            mw = re.search(r"warmed rounds: segments (\d+); windows (\d+); samples (\d+); wall ([0-9.e+-]+) s; decode ([0-9.e+-]+) s; replay ([0-9.e+-]+) s",
+                           r.stderr)
+            warmed = {}
+            if mw:
+                ws, ww, wn = int(mw.group(1)), int(mw.group(2)), int(mw.group(3))
+                wt = float(mw.group(4))
+                warmed = dict(warmed_segments=ws, warmed_seconds_per_segment=wt / ws, warmed_value=ww * wn / wt,
+                              warmed_decode_seconds_per_segment=float(mw.group(5)) / ws, warmed_replay_seconds_per_segment=float(mw.group(6)) / ws)
+            loader = [l for l in r.stderr.splitlines() if "[popdel timing] loader:" in l]
+            if loader:
+                warmed["loader"] = loader[-1][len("[popdel timing] loader: "):]
+            return dict(warmed, workload="popdel call on %d generated profiles, chr20:%d-%d (%d segments of 200 kb), merged VCF; steady state = "
                                  "the segments whose round began after the backend was up, start-up and teardown excluded" % (n, region[0], region[1], segs_all),
                         value=windows * samples / t_wall, unit="window*sample/s", steady_segments=segs, segments=segs_all,
                         steady_seconds_per_segment=t_wall / segs, steady_wall_seconds=t_wall, steady_windows=windows, samples=samples,

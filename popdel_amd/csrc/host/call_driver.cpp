@@ -4,6 +4,8 @@
 
 #include <chrono>
 #include <cstring>
+#include <fstream>
+#include <sched.h>
 #include <iostream>
 #include <exception>
 #include <condition_variable>
@@ -2340,9 +2342,88 @@ bool CallRun::finalizeRoi()
     return true;
 }
 
+// The host side of a device lives on the device's NUMA node: the process is bound to that node's CPUs before any thread is
+// started (page-locked buffers, tables and staging copies then sit next to the GPU's PCIe root; on the two-socket GPU boxes an
+// unbound run lands on either socket from run to run). Which node: the k-th GPU of the KFD topology the job may see ->
+// its PCI address -> sysfs. Anything unexpected leaves the process as it is. POPDEL_NO_NUMA_BIND=1 switches it off.
+static int bindToDeviceNode(int device)
+{
+#ifdef __linux__
+    if (getenv("POPDEL_NO_NUMA_BIND") || device < 0)
+        return -1;
+    int seen = 0;
+    for (int node = 0; node < 64; ++node)
+    {
+        std::ifstream props("/sys/class/kfd/kfd/topology/nodes/" + std::to_string(node) + "/properties");
+        if (!props)
+            continue;           // (other jobs' GPUs are hidden from this one; gaps in the numbering are normal)
+        std::string key;
+        unsigned long long value = 0, simd = 0, location = 0, domain = 0;
+        while (props >> key >> value)
+        {
+            if (key == "simd_count")
+                simd = value;
+            else if (key == "location_id")
+                location = value;
+            else if (key == "domain")
+                domain = value;
+        }
+        if (simd == 0)
+            continue;
+        if (seen++ != device)
+            continue;
+        char bdf[32];
+        snprintf(bdf, sizeof(bdf), "%04llx:%02llx:%02llx.%llx", domain & 0xffffull, (location >> 8) & 0xffull, (location >> 3) & 0x1full, location & 7ull);
+        std::ifstream nodeFile(std::string("/sys/bus/pci/devices/") + bdf + "/numa_node");
+        int numa = -1;
+        if (!(nodeFile >> numa) || numa < 0)
+            return -1;
+        std::ifstream list("/sys/devices/system/node/node" + std::to_string(numa) + "/cpulist");
+        std::string ranges;
+        if (!(list >> ranges))
+            return -1;
+        cpu_set_t now, want;
+        CPU_ZERO(&want);
+        if (sched_getaffinity(0, sizeof(now), &now) != 0)
+            return -1;
+        for (size_t i = 0; i < ranges.size();)
+        {
+            size_t j = ranges.find(',', i);
+            if (j == std::string::npos)
+                j = ranges.size();
+            const std::string part = ranges.substr(i, j - i);
+            const size_t dash = part.find('-');
+            const int a = atoi(part.c_str()), b = dash == std::string::npos ? a : atoi(part.c_str() + dash + 1);
+            for (int c = a; c <= b && c < CPU_SETSIZE; ++c)
+                if (CPU_ISSET(c, &now))
+                    CPU_SET(c, &want);
+            i = j + 1;
+        }
+        if (CPU_COUNT(&want) == 0 || sched_setaffinity(0, sizeof(want), &want) != 0)
+            return -1;
+        return numa;
+    }
+#else
+    (void)device;
+#endif
+    return -1;
+}
+
 int CallRun::run()
 {
     double tStart = PhaseClock::now();
+    {
+        const char * d = getenv("POPDEL_DEVICES");
+        const bool several = d && strchr(d, ',');
+        if (!d)
+            d = getenv("POPDEL_DEVICE");
+        if (!several)       // (several devices may sit on several nodes: left to the scheduler)
+        {
+            const int node = bindToDeviceNode(d ? atoi(d) : 0);
+            if (getenv("POPDEL_TIMING"))
+                std::cerr << "[popdel timing] host bound to NUMA node " << node << " (the device's; -1: left unbound)" << std::endl;
+        }
+    }
     // The GPU runtime starts up (~0.2 s) while the profile headers are read, and the backend is created (tables uploaded,
     // logarithms taken) while the first window is looked for and the first round of profiles is decoded and filed: the main
     // thread needs it only when the first segment is submitted (ensureBackend()).
@@ -2448,6 +2529,7 @@ int CallRun::run()
         }
         startGunzipPrefetch();
         // (large batches: 16 threads replayed 1000 samples in 0.57 s with batches of 128 and in 0.22 s with 512)
+        // (wider batches, 1024 and 2048 samples, were measured no faster with the blocks parsed on the device: 0.085-0.098 against 0.088-0.091 s per round)
         const unsigned batch = std::max(512u, 8u * hostThreads());
         for (unsigned b0 = 0; b0 < p_.sampleNum; b0 += batch)
         {

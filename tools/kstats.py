@@ -7,7 +7,7 @@ for r in rows:
     name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0]
     if name.startswith("void "):                 # template kernels are printed with their return type
         name = name[5:]
-    if not (name.startswith("pd::") or "copyBuffer" in name or "fillBuffer" in name or "inflateMembersKernel" in name):
+    if not (name.startswith("pd::") or "copyBuffer" in name or "fillBuffer" in name or "inflateMembersKernel" in name or name.startswith("parse")):
         continue
     ms = float(r["TotalDurationNs"]) / 1e6 / passes
     tot += ms
