@@ -3517,6 +3517,18 @@ int pd_last_timing(pd_ctx * c, pd_timing * out)
 
 const char * pd_last_error(const pd_ctx * c) { return c ? c->error.c_str() : g_createError.c_str(); }
 
+// POPDEL_HIP_BLOCKING_SYNC=1: host threads that wait for the device sleep in the driver instead of spinning in the runtime
+// (hipDeviceScheduleBlockingSync). For callers short of CPU time, not of latency: `popdel call` sets it -- a sixth of its CPU
+// time went into the runtime's wait loops, on a job whose rounds are bound by its CPU quota. Must come before the device's
+// context exists; failures are ignored (the default schedule then stays).
+static void applyDeviceSchedule()
+{
+    const char * e = getenv("POPDEL_HIP_BLOCKING_SYNC");
+    if (e && e[0] == '1')
+        (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+    (void)hipGetLastError();
+}
+
 int pd_device_warmup(int device)
 {
     const bool timed = getenv("POPDEL_HIP_MEMSTAT") != nullptr;
@@ -3524,6 +3536,7 @@ int pd_device_warmup(int device)
     const double t0 = now();
     if (hipSetDevice(device) != hipSuccess)
         return 1;
+    applyDeviceSchedule();
     const double t1 = now();
     void * p = nullptr;
     if (hipMalloc(&p, 256) != hipSuccess)       // (the first allocation creates the device context)

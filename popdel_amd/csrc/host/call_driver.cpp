@@ -1,10 +1,12 @@
 #include <unistd.h>
 
 #include "call_driver.h"
+#include "cpu_sampler.h"
 
 #include <chrono>
 #include <cstring>
 #include <fstream>
+#include <pthread.h>
 #include <sched.h>
 #include <iostream>
 #include <exception>
@@ -2412,18 +2414,6 @@ static int bindToDeviceNode(int device)
 int CallRun::run()
 {
     double tStart = PhaseClock::now();
-    {
-        const char * d = getenv("POPDEL_DEVICES");
-        const bool several = d && strchr(d, ',');
-        if (!d)
-            d = getenv("POPDEL_DEVICE");
-        if (!several)       // (several devices may sit on several nodes: left to the scheduler)
-        {
-            const int node = bindToDeviceNode(d ? atoi(d) : 0);
-            if (getenv("POPDEL_TIMING"))
-                std::cerr << "[popdel timing] host bound to NUMA node " << node << " (the device's; -1: left unbound)" << std::endl;
-        }
-    }
     // The GPU runtime starts up (~0.2 s) while the profile headers are read, and the backend is created (tables uploaded,
     // logarithms taken) while the first window is looked for and the first round of profiles is decoded and filed: the main
     // thread needs it only when the first segment is submitted (ensureBackend()).
@@ -2674,7 +2664,22 @@ int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer, bool
         int res = parseCallCommandLine(params, argc, argv);
         if (res >= 0)
             return res;
-        stayOnOneMemoryNode();          // (before the first thread is started: they inherit the mask)
+        {
+            // (before the first thread is started: they inherit the mask) the device's memory node if it can be told, else the
+            // node the process happens to be on; several devices may sit on several nodes: left to the scheduler
+            const char * d = getenv("POPDEL_DEVICES");
+            const bool several = d && strchr(d, ',');
+            if (!d)
+                d = getenv("POPDEL_DEVICE");
+            const int node = several ? -1 : bindToDeviceNode(d ? atoi(d) : 0);
+            if (node < 0)
+                stayOnOneMemoryNode();
+            if (getenv("POPDEL_TIMING"))
+                std::cerr << "[popdel timing] host bound to NUMA node " << node << " (the device's; -1: the node the process started on)" << std::endl;
+        }
+        // (threads that wait for the device sleep instead of spinning: the rounds are bound by the job's CPU time)
+        setenv("POPDEL_HIP_BLOCKING_SYNC", "1", 0);
+        CpuSampler::start();
         gTrace.mark("command line parsed");
         int rc;
         double tRun;
@@ -2689,6 +2694,7 @@ int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer, bool
                 // gigabytes of page-locked memory costs a few hundred milliseconds that the process exit does for free.
                 run.closeOutput();
                 run.printTiming();
+                CpuSampler::stopAndWrite();
                 if (!getenv("POPDEL_NO_PARALLEL_DISCARD"))
                 {
                     // ... and the big arrays' pages go back from all threads at once (the exit path frees page by page on

@@ -445,12 +445,14 @@ void ChromProfile::add(unsigned rg, unsigned startPos, unsigned endPos, int devi
 
 void ChromProfile::reserveRun(unsigned rg, size_t n)
 {
+    // (with room to spare: a slot that already holds a round's entries is copied when it has to grow, and record counts
+    // drift by a few per cent from round to round -- an exact reserve moved 170 KB per table and sample in most rounds)
     HugeVector<StartEntry> & s = starts[rg].slots[starts[rg].writeSlot].entries;
     if (s.capacity() < s.size() + n)
-        s.reserve(s.size() + n);
+        s.reserve(std::max(s.size() + n + n / 4, s.capacity() + s.capacity() / 2));
     HugeVector<EndEntry> & e = ends[rg].slots[ends[rg].writeSlot].entries;
     if (e.capacity() < e.size() + n)
-        e.reserve(e.size() + n);
+        e.reserve(std::max(e.size() + n + n / 4, e.capacity() + e.capacity() / 2));
 }
 
 void ChromProfile::addRun(unsigned rg, const uint32_t * posDev, size_t n, int innerOffset)
@@ -500,7 +502,7 @@ void ChromProfile::addRun(unsigned rg, const uint32_t * posDev, size_t n, int in
         // with the counting cursor certain to stay inside its slot (EndSlots::quietBlock) -- the block is filed in one go and the
         // table asked once, behind its last record: the answers add up to the same number and leave the same cursors.
         constexpr size_t kBlock = 64;
-        unsigned endBuf[kBlock];
+        unsigned endBuf[kBlock];        // the records' last windows, as window numbers (end position / 30)
         size_t i = 0;
         while (i < n)
         {
@@ -511,20 +513,20 @@ void ChromProfile::addRun(unsigned rg, const uint32_t * posDev, size_t n, int in
                 // the block: as many records as the cap leaves room for, as long as they come in order (and, if the end table's
                 // counting cursor is in its write slot, as long as they end below that slot's border)
                 const size_t want = std::min<size_t>(std::min<size_t>(kBlock, cap - load), n - i);
-                const unsigned border = en.slots[en.writeSlot].right;
+                const unsigned borderBin = (en.slots[en.writeSlot].right + 29u) / 30u;      // (a last window 30 * bin lies below the border iff bin < borderBin)
                 const bool cursorInWriteSlot = en.endPosSlot == en.writeSlot;
                 unsigned prev = posDev[2 * i];
                 for (; block < want; ++block)
                 {
                     const unsigned startPos = posDev[2 * (i + block)];
                     const int inner = static_cast<int32_t>(posDev[2 * (i + block) + 1]) + innerOffset;
-                    const unsigned endPos = startPos + (inner > 0 ? static_cast<unsigned>(inner) : 0u);
-                    const bool in = (endPos / 30u) * 30u < border;
+                    const unsigned bin = (startPos + (inner > 0 ? static_cast<unsigned>(inner) : 0u)) / 30u;
+                    const bool in = bin < borderBin;
                     if (startPos < prev || (cursorInWriteSlot && !in && block >= 4))
                         break;
                     below = below && in;
                     prev = startPos;
-                    endBuf[block] = endPos;
+                    endBuf[block] = bin;
                 }
                 if (block >= 4)
                     block = en.quietBlock(posDev[2 * i], posDev[2 * (i + block - 1)], block, below);
@@ -550,7 +552,7 @@ void ChromProfile::addRun(unsigned rg, const uint32_t * posDev, size_t n, int in
                 en.addBlockToWriteSlot(id, endBuf, block);
             else
                 for (size_t j = 0; j < block; ++j)
-                    en.addFast(id + static_cast<unsigned>(j), endBuf[j]);
+                    en.addFast(id + static_cast<unsigned>(j), endBuf[j] * 30u);     // (any end position inside the window files the same)
             load += static_cast<unsigned>(block);
             load -= en.countEndedFast(posDev[2 * (i + block - 1)]);
             i += block;

@@ -190,44 +190,65 @@ public:
             return 0;
         return std::min<size_t>(n, have - over - 1);
     }
-    // addFast() for records id, id + 1, ... whose last windows all lie below the write slot's border, the everyday case kept in
-    // registers over the block
-    void addBlockToWriteSlot(unsigned id, const unsigned * endPos, size_t n)
+    // addFast() for records id, id + 1, ... whose last windows (30 * bins[j]) all lie below the write slot's border. The everyday
+    // case -- the slot has entries, all bins inside the counted range, none of their counts near saturation -- is taken for the
+    // whole block at once: one pass for what the slot remembers about its entries (extremes, order), one for the counts, the
+    // entries appended in one copy. Anything else: record by record through addFast().
+    void addBlockToWriteSlot(unsigned id, const unsigned * bins, size_t n)
     {
+        constexpr size_t kMost = 64;
         Slot & slot = slots[writeSlot];
-        size_t j = 0;
-        if (light && !slot.entries.empty())
+        if (light && !slot.entries.empty() && n <= kMost)
         {
-            const unsigned base = slot.baseBin, cur0 = slot.curBin[0], cur1 = slot.curBin[1];
-            const size_t bins = slot.hist.size();
-            uint16_t * hist = slot.hist.data();
-            unsigned low = slot.lowBin, high = slot.highBin, maxWin = slot.maxWin, cum0 = slot.curCum[0], cum1 = slot.curCum[1];
-            unsigned before = slot.entries.back().lastWindow;
-            bool ordered = slot.ordered;
-            for (; j < n; ++j)
+            EndEntry fresh[kMost];
+            unsigned minBin = 0xffffffffu, maxBin = 0, before = slot.entries.back().lastWindow;
+            bool ordered = true;
+            for (size_t j = 0; j < n; ++j)
             {
-                const unsigned bin = endPos[j] / 30u, lastWin = bin * 30u, b = bin - base;      // (b wraps below the base: out of range)
-                if (b >= bins || hist[b] == 0xffffu)
-                    break;
+                const unsigned bin = bins[j], lastWin = bin * 30u;
+                fresh[j] = EndEntry{id + static_cast<unsigned>(j), lastWin};
+                minBin = bin < minBin ? bin : minBin;
+                maxBin = bin > maxBin ? bin : maxBin;
                 ordered = ordered && lastWin >= before;
                 before = lastWin;
-                low = b < low ? b : low;
-                high = b >= high ? b + 1 : high;
-                maxWin = lastWin > maxWin ? lastWin : maxWin;
-                ++hist[b];
-                cum0 += b < cur0 ? 1u : 0u;
-                cum1 += b < cur1 ? 1u : 0u;
-                slot.entries.push_back(EndEntry{id + static_cast<unsigned>(j), lastWin});
             }
-            slot.ordered = ordered;
-            slot.lowBin = low;
-            slot.highBin = high;
-            slot.maxWin = maxWin;
-            slot.curCum[0] = cum0;
-            slot.curCum[1] = cum1;
+            const unsigned base = slot.baseBin;
+            if (minBin >= base && maxBin - base < slot.hist.size())
+            {
+                uint16_t * hist = slot.hist.data();
+                unsigned fullest = 0;
+                for (size_t j = 0; j < n; ++j)
+                {
+                    const unsigned v = hist[bins[j] - base];
+                    fullest = v > fullest ? v : fullest;
+                }
+                if (fullest < 0xffffu - kMost)
+                {
+                    const unsigned cur0 = slot.curBin[0], cur1 = slot.curBin[1];
+                    unsigned cum0 = 0, cum1 = 0;
+                    for (size_t j = 0; j < n; ++j)
+                    {
+                        const unsigned b = bins[j] - base;
+                        ++hist[b];
+                        cum0 += b < cur0 ? 1u : 0u;
+                        cum1 += b < cur1 ? 1u : 0u;
+                    }
+                    slot.curCum[0] += cum0;
+                    slot.curCum[1] += cum1;
+                    slot.ordered = slot.ordered && ordered;
+                    if (minBin - base < slot.lowBin)
+                        slot.lowBin = minBin - base;
+                    if (maxBin - base >= slot.highBin)
+                        slot.highBin = maxBin - base + 1;
+                    if (maxBin * 30u > slot.maxWin)
+                        slot.maxWin = maxBin * 30u;
+                    slot.entries.insert(slot.entries.end(), fresh, fresh + n);
+                    return;
+                }
+            }
         }
-        for (; j < n; ++j)
-            addFast(id + static_cast<unsigned>(j), endPos[j]);
+        for (size_t j = 0; j < n; ++j)
+            addFast(id + static_cast<unsigned>(j), bins[j] * 30u);     // (any end position inside the window files the same)
     }
     unsigned countEndedFast(unsigned pos)
     {

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <exception>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 #ifdef __linux__
@@ -154,6 +155,28 @@ inline unsigned hostThreads()
 // Threads are spawned per call on purpose: a persistent pool (condition-variable hand-off to parked workers) was
 // measured 10-20 % SLOWER on the 256-core GPU host for the memory-bound staging passes.
 // `maxThreads` (0: no extra limit) caps the threads of passes that were measured to get SLOWER with more of them.
+// The threads get 256-KB stacks (their bodies are loops over table entries and bytes; nothing here recurses): glibc keeps the
+// stacks of finished threads for re-use up to 40 MB in all, which is five default-sized ones -- a round of `popdel call`
+// starts a thousand threads and spent a tenth of its CPU time mapping and unmapping their stacks.
+namespace detail {
+inline const pthread_attr_t * smallStack()
+{
+    static const pthread_attr_t * attr = [] {
+        static pthread_attr_t a;
+        if (pthread_attr_init(&a) != 0 || pthread_attr_setstacksize(&a, 256u * 1024u) != 0)
+            return static_cast<const pthread_attr_t *>(nullptr);
+        return static_cast<const pthread_attr_t *>(&a);
+    }();
+    return attr;
+}
+template <typename W>
+void * runWorker(void * w)
+{
+    (*static_cast<W *>(w))();
+    return nullptr;
+}
+}  // namespace detail
+
 template <typename F>
 void parallelFor(size_t n, F fn, size_t grain = 1, unsigned maxThreads = 0)
 {
@@ -190,13 +213,18 @@ void parallelFor(size_t n, F fn, size_t grain = 1, unsigned maxThreads = 0)
             next.store(n);
         }
     };
-    std::vector<std::thread> pool;
+    std::vector<pthread_t> pool;
     pool.reserve(threads - 1);
     for (unsigned t = 1; t < threads; ++t)
-        pool.emplace_back(worker);
+    {
+        pthread_t id;
+        if (pthread_create(&id, detail::smallStack(), &detail::runWorker<decltype(worker)>, &worker) != 0)
+            break;              // (no more threads to be had: the ones there are take the work)
+        pool.push_back(id);
+    }
     worker();
-    for (std::thread & t : pool)
-        t.join();
+    for (pthread_t id : pool)
+        (void)pthread_join(id, nullptr);
     if (error)
         std::rethrow_exception(error);
 }
