@@ -428,3 +428,103 @@ int pdh_bench_filing_ex(unsigned rounds, int light, unsigned maxLoad, unsigned s
     return 0;
 }
 }  // extern "C"
+
+namespace {
+// inflated bytes of one block, as the loader's reader sees them
+class BlockSource : public pdh::ByteSource
+{
+public:
+    BlockSource(const unsigned char * p, size_t n) : p_(p), left_(n) {}
+    size_t read(void * dst, size_t n) override
+    {
+        const size_t k = std::min(n, left_);
+        std::memcpy(dst, p_, k);
+        p_ += k;
+        left_ -= k;
+        return k;
+    }
+    const unsigned char * peek(size_t & avail) override
+    {
+        avail = left_;
+        return p_;
+    }
+    void consume(size_t n) override
+    {
+        p_ += n;
+        left_ -= n;
+    }
+
+private:
+    const unsigned char * p_;
+    size_t left_;
+};
+}  // namespace
+
+extern "C" {
+// What the host's reader makes of inflated profile blocks of a one-read-group file (readWindowHead + readWindowBodyFlat,
+// profile_io.cpp: the reference's readWindow + convertWindow) -- the yardstick for the device's parser (pd_inflater_run_parsed,
+// tests/test_gpu_parse.py). Block b = data[offsets[b], offsets[b + 1]). Two calls: with the arrays null it fills counts[3 * b
+// .. ] = {256-bp windows, 30-bp windows, records} and state[b] (0: read to the end; 1: the reader threw -- a window cut short;
+// 2: a window without records, where the loader stops); with the arrays (sized by the counts of the blocks with state 0, in
+// block order) it fills them: profile windows as {chrom, beginPos, splitFailed, firstWin, nWin} with indices relative to the
+// block, call windows {chrom, beginPos, firstRec}, their record counts, records {pos, dev}.
+int pdh_parse_blocks(const uint8_t * data, const uint64_t * offsets, uint32_t n, uint64_t * counts, uint32_t * state, uint32_t * profileWindows,
+                     uint32_t * callWindows, uint32_t * callWindowRecords, uint32_t * records)
+{
+    if (!data || !offsets || !counts || !state)
+        return 1;
+    uint64_t atRaw = 0, atWin = 0, atRec = 0;
+    for (uint32_t b = 0; b < n; ++b)
+    {
+        BlockSource src(data + offsets[b], static_cast<size_t>(offsets[b + 1] - offsets[b]));
+        pdh::FlatWindows wins;
+        pdh::FlatCounts cnt;
+        pdh::FlatRecords recs;
+        std::vector<uint32_t> raws;
+        uint32_t st = 0;
+        try
+        {
+            pdh::WindowHead head;
+            while (pdh::readWindowHead(src, head))
+            {
+                const uint32_t firstWin = static_cast<uint32_t>(wins.size());
+                if (!pdh::readWindowBodyFlat(src, head, 1, wins, cnt, recs, 256, 30))
+                {
+                    st = 2;
+                    break;
+                }
+                const uint32_t row[5] = {static_cast<uint32_t>(head.chrom), static_cast<uint32_t>(head.beginPos), 0u, firstWin,
+                                         static_cast<uint32_t>(wins.size()) - firstWin};
+                raws.insert(raws.end(), row, row + 5);
+            }
+        }
+        catch (const std::exception &)
+        {
+            st = 1;
+        }
+        state[b] = st;
+        counts[3 * b] = raws.size() / 5;
+        counts[3 * b + 1] = wins.size();
+        counts[3 * b + 2] = recs.size();
+        if (st != 0 || !profileWindows)
+            continue;
+        std::memcpy(profileWindows + 5 * atRaw, raws.data(), raws.size() * sizeof(uint32_t));
+        for (size_t w = 0; w < wins.size(); ++w)
+        {
+            callWindows[3 * (atWin + w)] = static_cast<uint32_t>(wins[w].chrom);
+            callWindows[3 * (atWin + w) + 1] = static_cast<uint32_t>(wins[w].beginPos);
+            callWindows[3 * (atWin + w) + 2] = wins[w].firstRec;
+            callWindowRecords[atWin + w] = cnt[w];
+        }
+        for (size_t r = 0; r < recs.size(); ++r)
+        {
+            records[2 * (atRec + r)] = recs[r].pos;
+            records[2 * (atRec + r) + 1] = recs[r].dev;
+        }
+        atRaw += raws.size() / 5;
+        atWin += wins.size();
+        atRec += recs.size();
+    }
+    return 0;
+}
+}  // extern "C"

@@ -103,3 +103,82 @@ def profile_blocks(n_members, seed=1, pairs_per_member=1000):
             blk += rec.tobytes()
         blocks.append(bytes(blk))
     return blocks
+
+
+class PdParsedBlocks(C.Structure):
+    _fields_ = [("profile_windows", C.c_void_p), ("call_windows", C.c_void_p), ("call_window_records", C.POINTER(C.c_uint32)),
+                ("records", C.c_void_p), ("profile_window_offsets", C.POINTER(C.c_uint64)),
+                ("call_window_offsets", C.POINTER(C.c_uint64)), ("record_offsets", C.POINTER(C.c_uint64)),
+                ("block_flags", C.POINTER(C.c_uint32)), ("bytes_copied", C.c_uint32)]
+
+
+def parse_gpu(hip_lib, blobs, sample_first=None, device=0):
+    """pd_inflater_run_parsed on gzip members (one sample unless `sample_first` says otherwise). Returns a dict: status[n],
+    flags[n], counts[n, 3] (256-bp windows, 30-bp windows, records per block), profile_windows[.., 5], call_windows[.., 3],
+    call_window_records[..], records[.., 2] (all blocks' rows in block order), bytes_copied."""
+    data, offsets, out_offsets = pack_members(blobs)
+    n = len(blobs)
+    first = np.zeros(n, np.uint32) if sample_first is None else np.asarray(sample_first, np.uint32)
+    want = np.ones(n, np.uint8)
+    hip_lib.pd_inflater_create.restype = C.c_void_p
+    hip_lib.pd_inflater_input.restype = C.POINTER(C.c_uint8)
+    hip_lib.pd_inflater_input.argtypes = [C.c_void_p, C.c_uint64]
+    hip_lib.pd_inflater_destroy.argtypes = [C.c_void_p]
+    hip_lib.pd_inflater_run_parsed.restype = C.c_int
+    inf = hip_lib.pd_inflater_create(C.c_int(device))
+    if not inf:
+        raise RuntimeError("pd_inflater_create failed")
+    try:
+        buf = hip_lib.pd_inflater_input(inf, C.c_uint64(len(data)))
+        C.memmove(buf, data.ctypes.data, len(data))
+        out, status, lengths, pb, ms = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint64)(), PdParsedBlocks(), C.c_double()
+        rc = hip_lib.pd_inflater_run_parsed(C.c_void_p(inf), _ptr(offsets, C.c_uint64), C.c_uint32(n), _ptr(out_offsets, C.c_uint64),
+                                            _ptr(first, C.c_uint32), _ptr(want, C.c_uint8), C.byref(out), C.byref(status), C.byref(lengths),
+                                            C.byref(pb), C.byref(ms))
+        if rc != 0:
+            raise RuntimeError("pd_inflater_run_parsed failed (%d)" % rc)
+        st = np.ctypeslib.as_array(status, (n,)).copy()
+        fl = np.ctypeslib.as_array(pb.block_flags, (n, 4)).copy()
+        ro = np.ctypeslib.as_array(pb.profile_window_offsets, (n + 1,)).copy()
+        wo = np.ctypeslib.as_array(pb.call_window_offsets, (n + 1,)).copy()
+        co = np.ctypeslib.as_array(pb.record_offsets, (n + 1,)).copy()
+
+        def rows(ptr, count, width):
+            if count == 0:
+                return np.zeros((0, width), np.uint32)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), (count * width,)).reshape(count, width).copy()
+
+        return dict(status=st, flags=fl[:, 3], counts=np.stack([np.diff(ro), np.diff(wo), np.diff(co)], axis=1),
+                    profile_windows=rows(pb.profile_windows, int(ro[-1]), 5), call_windows=rows(pb.call_windows, int(wo[-1]), 3),
+                    call_window_records=rows(pb.call_window_records, int(wo[-1]), 1)[:, 0], records=rows(pb.records, int(co[-1]), 2),
+                    bytes_copied=int(pb.bytes_copied))
+    finally:
+        hip_lib.pd_inflater_destroy(C.c_void_p(inf))
+
+
+def parse_host(blocks):
+    """The loader's own reader on inflated blocks (pdh_parse_blocks). Returns a dict like parse_gpu's (`state` instead of flags:
+    0 read to the end, 1 the reader threw, 2 a window without records); rows of the blocks with state 0 only, indices relative to the block."""
+    data = np.frombuffer(b"".join(blocks), dtype=np.uint8).copy() if blocks else np.zeros(1, np.uint8)
+    offsets = np.zeros(len(blocks) + 1, np.uint64)
+    np.cumsum([len(b) for b in blocks], out=offsets[1:])
+    n = len(blocks)
+    counts = np.zeros((n, 3), np.uint64)
+    state = np.zeros(n, np.uint32)
+    lib = _host()
+    lib.pdh_parse_blocks.restype = C.c_int
+    null = C.POINTER(C.c_uint32)()
+    if lib.pdh_parse_blocks(_ptr(data, C.c_uint8), _ptr(offsets, C.c_uint64), C.c_uint32(n), _ptr(counts, C.c_uint64), _ptr(state, C.c_uint32),
+                            null, null, null, null) != 0:
+        raise RuntimeError("pdh_parse_blocks failed")
+    ok = state == 0
+    tot = counts[ok].sum(axis=0).astype(np.int64) if ok.any() else np.zeros(3, np.int64)
+    pw = np.zeros((max(1, int(tot[0])), 5), np.uint32)
+    cw = np.zeros((max(1, int(tot[1])), 3), np.uint32)
+    cr = np.zeros(max(1, int(tot[1])), np.uint32)
+    rc = np.zeros((max(1, int(tot[2])), 2), np.uint32)
+    if lib.pdh_parse_blocks(_ptr(data, C.c_uint8), _ptr(offsets, C.c_uint64), C.c_uint32(n), _ptr(counts, C.c_uint64), _ptr(state, C.c_uint32),
+                            _ptr(pw, C.c_uint32), _ptr(cw, C.c_uint32), _ptr(cr, C.c_uint32), _ptr(rc, C.c_uint32)) != 0:
+        raise RuntimeError("pdh_parse_blocks failed")
+    return dict(state=state, counts=counts.astype(np.int64), profile_windows=pw[: int(tot[0])], call_windows=cw[: int(tot[1])],
+                call_window_records=cr[: int(tot[1])], records=rc[: int(tot[2])])
