@@ -2509,6 +2509,9 @@ int CallRun::run()
         }
         rounds_.emplace_back();
         rounds_.back().start = PhaseClock::now();
+        if (const char * from = getenv("POPDEL_CPU_PROFILE_FROM_ROUND"))       // (diagnosis: the warmed rounds only)
+            if (rounds_.size() == static_cast<size_t>(atoi(from)))
+                CpuSampler::start();
         if (gTrace.on)
         {
             struct rusage ru;
@@ -2679,7 +2682,8 @@ int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer, bool
         }
         // (threads that wait for the device sleep instead of spinning: the rounds are bound by the job's CPU time)
         setenv("POPDEL_HIP_BLOCKING_SYNC", "1", 0);
-        CpuSampler::start();
+        if (!getenv("POPDEL_CPU_PROFILE_FROM_ROUND"))
+            CpuSampler::start();
         gTrace.mark("command line parsed");
         int rc;
         double tRun;
