@@ -101,7 +101,7 @@ def parse_args(argv=None):
                     help="N = 1: profiles of the cohort-scale end-to-end leg (`popdel call` on generated profiles x 4 Mb = 20 segments; "
                          "steady state: start-up and teardown excluded); 0: skip")
     ap.add_argument("--e2e-cohort-mb", type=int, default=4, help="region of that leg in Mb")
-    ap.add_argument("--e2e-cohort-budget", type=float, default=150.0,
+    ap.add_argument("--e2e-cohort-budget", type=float, default=300.0,
                     help="wall-time budget of that leg in seconds (cohort writing included): the cohort is cut down to what the "
                          "writing rate measured on the first profiles allows")
     ap.add_argument("--inflate-members", type=int, default=100000,
