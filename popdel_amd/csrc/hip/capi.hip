@@ -24,6 +24,7 @@
 #include "pd_build.h"
 #include "pd_device.h"
 #include "pd_walk.h"
+#include "pinned_host.h"
 #include "popdel_hip.h"
 
 namespace pd {
@@ -181,7 +182,7 @@ struct PinnedBuf
     {
         if (p)
         {
-            (void)hipHostFree(p);
+            pd::pinnedFree(p);
             g_pinnedBytes -= cap * sizeof(T);
         }
     }
@@ -191,13 +192,15 @@ struct PinnedBuf
         {
             if (p)
             {
-                (void)hipHostFree(p);
+                pd::pinnedFree(p);
                 g_pinnedBytes -= cap * sizeof(T);
             }
             p = nullptr;
             cap = 0;
             const size_t want = count + count / 8 + 1024;
-            PD_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), want * sizeof(T), hipHostMallocDefault));
+            p = static_cast<T *>(pd::pinnedAlloc(want * sizeof(T)));
+            if (!p)
+                throw HipError{"page-locked host memory: " + std::to_string(want * sizeof(T)) + " bytes not to be had"};
             cap = want;
             g_pinnedBytes += cap * sizeof(T);
             ++g_pinnedAllocs;
@@ -533,7 +536,9 @@ PinnedBlock takePinned(size_t bytes)
     guard.unlock();
     PinnedBlock b;
     b.bytes = bytes + bytes / 4 + 4096;
-    PD_HIP(hipHostMalloc(&b.p, b.bytes, hipHostMallocDefault));
+    b.p = pd::pinnedAlloc(b.bytes);
+    if (!b.p)
+        throw HipError{"page-locked host memory: " + std::to_string(b.bytes) + " bytes not to be had"};
     g_pinnedBytes += b.bytes;
     ++g_pinnedAllocs;
     return b;
@@ -565,7 +570,7 @@ void givePinned(PinnedBlock b)
         else
             drop = b;
     }
-    (void)hipHostFree(drop.p);
+    pd::pinnedFree(drop.p);
     g_pinnedBytes -= drop.bytes;
 }
 

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "pinned_host.h"
 #include "inflate_core.h"
 #include "popdel_hip.h"
 
@@ -275,11 +276,13 @@ void growPinned(void *& p, size_t & cap, size_t want)
     if (want <= cap)
         return;
     if (p)
-        (void)hipHostFree(p);
+        pd::pinnedFree(p);
     p = nullptr;
     cap = 0;
     const size_t take = want + want / 4 + 4096;
-    PD_INF_HIP(hipHostMalloc(&p, take, hipHostMallocDefault));
+    p = pd::pinnedAlloc(take);
+    if (!p)
+        throw Fail{"page-locked host memory: " + std::to_string(take) + " bytes not to be had"};
     cap = take;
 }
 
@@ -321,7 +324,7 @@ extern "C" void pd_inflater_destroy(pd_inflater * f)
             (void)hipFree(p);
     for (void * p : {f->hIn, f->hOut, f->hMeta, f->hOffsets, f->hFlags, f->hRaws, f->hWins, f->hWinCounts, f->hRecs})
         if (p)
-            (void)hipHostFree(p);
+            pd::pinnedFree(p);
     if (f->finished)
         (void)hipEventDestroy(f->finished);
     if (f->stream)
