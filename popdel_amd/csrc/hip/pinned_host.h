@@ -58,12 +58,22 @@ inline void * pinnedAlloc(size_t bytes)
             // first touch from a few threads (a huge page is zeroed by whoever faults it in)
             const unsigned threads = want >= (64u << 20) ? 4u : 1u;
             std::vector<std::thread> pool;
-            for (unsigned k = 1; k < threads; ++k)
-                pool.emplace_back([=] {
-                    for (size_t o = want / threads * k; o < want / threads * (k + 1); o += 4096)
-                        al[o] = 0;
-                });
-            for (size_t o = 0; o < want / threads; o += 4096)
+            size_t mine = want;             // (what no helper thread takes is touched here)
+            try
+            {
+                for (unsigned k = threads - 1; k >= 1; --k)
+                {
+                    pool.emplace_back([=] {
+                        for (size_t o = want / threads * k; o < want / threads * (k + 1); o += 4096)
+                            al[o] = 0;
+                    });
+                    mine = want / threads * k;
+                }
+            }
+            catch (...)
+            {
+            }
+            for (size_t o = 0; o < mine; o += 4096)
                 al[o] = 0;
             for (std::thread & t : pool)
                 t.join();

@@ -2117,23 +2117,36 @@ __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, S
     for (unsigned q = 0; q < kRowBatch; ++q)
         dvs[q] = col[min(j0 + q, (unsigned)kDenseCap - 1u) * 64];
     PD_ALL_LOADS_DONE(dvs);
-    double4 trs[kRowBatch], tds[kRowBatch];
+    // (the 16-byte entries {value, log} of the EM kernels, log10 taken here by the function that fills the 32-byte table
+    // (logTableKernel): the same bits, half the bytes -- the 32-byte table of 10,000 samples is 320 MB, twice what the
+    // last-level cache holds beside the image, and this kernel read 10.3 GB of HBM per candidate-dense launch through it)
+    double2 trs2[kRowBatch], tds2[kRowBatch];
+    bool inR[kRowBatch], inD[kRowBatch];
 #pragma unroll
     for (unsigned q = 0; q < kRowBatch; ++q)
     {
         const bool use = j0 + q < nn;
         const long long pr = lookupPos(rc, dvs[q] - refShift), pdl = lookupPos(rc, dvs[q] - len);
-        trs[q] = make_double4(rc.minProb, rc.logMinProb, rc.log10MinProb, 0.0);
-        tds[q] = trs[q];
-        if (use && pr >= 0)
-            trs[q] = co.tab[pr];
-        if (use && pdl >= 0)
-            tds[q] = co.tab[pdl];
+        trs2[q] = make_double2(rc.minProb, rc.logMinProb);
+        tds2[q] = trs2[q];
+        inR[q] = use && pr >= 0;
+        inD[q] = use && pdl >= 0;
+        if (inR[q])
+            trs2[q] = co.tab2[pr];
+        if (inD[q])
+            tds2[q] = co.tab2[pdl];
     }
+    double4 trs[kRowBatch], tds[kRowBatch];
     // (the starts are wanted by the arithmetic only: loaded behind the lookups, so that no lookup is issued behind a wait for them)
 #pragma unroll
     for (unsigned q = 0; q < kRowBatch; ++q)
         sts[q] = colSt[min(j0 + q, (unsigned)kDenseCap - 1u) * 64];
+#pragma unroll
+    for (unsigned q = 0; q < kRowBatch; ++q)
+    {
+        trs[q] = make_double4(trs2[q].x, trs2[q].y, inR[q] ? log10(trs2[q].x) : rc.log10MinProb, 0.0);
+        tds[q] = make_double4(tds2[q].x, tds2[q].y, inD[q] ? log10(tds2[q].x) : rc.log10MinProb, 0.0);
+    }
 #pragma unroll
     for (unsigned q = 0; q < kRowBatch; ++q)
     {

@@ -6,6 +6,7 @@
 #ifndef PDH_CPU_SAMPLER_H_
 #define PDH_CPU_SAMPLER_H_
 #ifdef __linux__
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
