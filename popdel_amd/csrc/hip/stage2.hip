@@ -2109,7 +2109,7 @@ __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, S
     unsigned mn = 0xffffffffu, mx = 0, nSupp = 0;
     unsigned lad[3] = {0, 0, 0}, dad[5] = {0, 0, 0, 0, 0};
     // (rows in batches: deviations and starts, then all lookups, then the arithmetic -- see dataLikDenseKernel)
-    constexpr unsigned kRowBatch = 4;
+    constexpr unsigned kRowBatch = 6;
     for (unsigned j0 = 0; j0 < rows; j0 += kRowBatch)
     {
     int dvs[kRowBatch], sts[kRowBatch];
