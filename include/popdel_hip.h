@@ -220,6 +220,16 @@ typedef struct pd_shard
     void *user;
 } pd_shard;
 
+/* A context with lanes (POPDEL_HIP_LANES, pd_ctx_create) runs its tickets on several child contexts at once; their exchanges
+ * must not share a channel (they would interleave in an order no other rank reproduces). pd_ctx_set_shard() therefore runs a
+ * cohort over several ranks without lanes. pd_ctx_set_shard_lanes() keeps them: `shard` as above for the context itself (the
+ * exchanges of pd_segment_stage), and one pd_shard per lane -- same rank and cohort, its OWN reserve / all_gather / user, i.e.
+ * its own buffer and its own group of the caller's collective library; lane k of every rank then exchanges with lane k of the
+ * others, from a thread of the library (the callbacks must be callable from any thread). Tickets go to min(lanes of the
+ * context, n_lane_shards) lanes, ticket t to lane t mod that number, on every rank alike. Results are bit-identical to the
+ * unsharded run (tests/test_gpu_sample_shard.py: two processes over gloo with two lanes). */
+int pd_ctx_set_shard_lanes(pd_ctx *ctx, const pd_shard *shard, const pd_shard *lane_shards, uint32_t n_lane_shards);
+
 /* The same with the exchange done by the library itself: RCCL all-gathers issued on the context's own HIP stream, in place
  * in an exchange buffer the library owns (no host callbacks in the data path; `reserve`, `all_gather` and `user` of
  * `shard` are ignored). One process calls pd_rccl_unique_id() and hands the 128 bytes to all others over any channel;

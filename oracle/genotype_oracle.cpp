@@ -1091,6 +1091,7 @@ pd_inflater * pd_inflater_create(int) { return nullptr; }
 void pd_inflater_destroy(pd_inflater *) {}
 uint8_t * pd_inflater_input(pd_inflater *, uint64_t) { return nullptr; }
 int pd_inflater_run(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *, const uint8_t **, const uint32_t **, const uint64_t **, double *) { return 1; }
+int pd_ctx_set_shard_lanes(pd_ctx *, const pd_shard *, const pd_shard *, uint32_t) { return 1; }
 int pd_inflater_run_parsed(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t **, const uint32_t **,
                            const uint64_t **, pd_parsed_blocks *, double *) { return 1; }
 

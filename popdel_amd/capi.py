@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "pd_local_group_create", "pd_local_group_destroy", "pd_ctx_set_shard_local", "pd_log_table_view",
     "pd_ctx_keep_results_on_device", "pd_calls_merge", "pd_calls_fetch_columns", "pd_merged_free",
     "pd_walk_submit", "pd_walk_supported", "pd_walk_active", "pd_device_warmup", "pd_inflate_members", "pd_inflate_last_error",
-    "pd_inflater_create", "pd_inflater_destroy", "pd_inflater_input", "pd_inflater_run", "pd_inflater_run_parsed",
+    "pd_inflater_create", "pd_inflater_destroy", "pd_inflater_input", "pd_inflater_run", "pd_inflater_run_parsed", "pd_ctx_set_shard_lanes",
 )
 RCCL_ID_BYTES = 128
 
@@ -305,6 +305,27 @@ class Context:
         sh.reserve, sh.all_gather = self._shard_fns
         sh.user = None
         self._check(self.lib.pd_ctx_set_shard(self.handle, C.byref(sh)))
+
+    def set_shard_lanes(self, rank, world, first_sample, n_samples_global, min_init_del_len_global, channels):
+        """pd_ctx_set_shard_lanes: the context keeps its lanes in a cohort over several ranks. ``channels``: a list of
+        (reserve, all_gather) pairs of Python callables -- the first for the context itself, one more per lane (each with its
+        own buffer and group: popdel_amd.distributed.SampleShardExchange)."""
+        table = np.ascontiguousarray(min_init_del_len_global, dtype=np.uint32)
+        self._shard_fns = []
+        structs = (PdShard * len(channels))()
+        for k, (reserve, all_gather) in enumerate(channels):
+            fns = (RESERVE_FN(lambda user, nbytes, f=reserve: f(nbytes)),
+                   ALL_GATHER_FN(lambda user, off, per, stream, f=all_gather: f(off, per, stream)))
+            self._shard_fns.append(fns)
+            sh = structs[k]
+            sh.rank, sh.world, sh.first_sample = rank, world, first_sample
+            sh.n_samples_global, sh.n_readgroups_global = n_samples_global, len(table)
+            sh.min_init_del_len_global = table.ctypes.data_as(C.POINTER(C.c_uint32))
+            sh.reserve, sh.all_gather = fns
+            sh.user = None
+        self.lib.pd_ctx_set_shard_lanes.restype = C.c_int
+        self._check(self.lib.pd_ctx_set_shard_lanes(self.handle, C.byref(structs[0]), C.cast(C.byref(structs, C.sizeof(PdShard)), C.POINTER(PdShard)),
+                                                    C.c_uint32(len(channels) - 1)))
 
     def set_shard_rccl(self, rank, world, first_sample, n_samples_global, min_init_del_len_global, rccl_id: bytes):
         """The same with the exchange done by the library itself over RCCL (pd_ctx_set_shard_rccl); collective: every

@@ -1642,7 +1642,8 @@ uint32_t pd_shard_samples(uint32_t n_samples_global, uint32_t world)
 
 static void laneTeardown(pd_ctx * c);
 
-static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, pd_local_group * group, const char * who)
+static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, pd_local_group * group, const char * who,
+                      const pd_shard * laneShards = nullptr, uint32_t nLaneShards = 0)
 {
     const std::string name = who;
     if (!c || !sh)
@@ -1655,9 +1656,11 @@ static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, p
         return fail(c, name + ": the group was created for another number of contexts");
     if (c->lanes)
     {
-        // Lanes exchange on communicators of their own (their exchanges interleave in an order no other rank could
-        // reproduce on ONE communicator). With one rank every lane makes itself one; a cohort over several ranks -- or one
-        // that exchanges through host callbacks or between the contexts of a process -- runs without lanes.
+        // Lanes exchange on channels of their own (their exchanges interleave in an order no other rank could reproduce on
+        // ONE channel). With one rank every lane makes itself an RCCL communicator; a caller that exchanges through host
+        // callbacks may hand over one pair of callbacks per lane (pd_ctx_set_shard_lanes: the tickets go to as many lanes as
+        // it gave channels for); any other cohort over several ranks -- or between the contexts of a process -- runs
+        // without lanes.
         if (sh->world == 1 && rcclId && !group)
         {
             RcclApi & api = rccl();
@@ -1674,6 +1677,18 @@ static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, p
                     return rc;
                 }
             }
+        }
+        else if (laneShards && nLaneShards > 0 && !rcclId && !group)
+        {
+            LanesState & L = *c->lanes;
+            const unsigned use = std::min<unsigned>(L.active, nLaneShards);
+            for (unsigned k = 0; k < use; ++k)
+                if (int rc = applyShard(L.workers[k]->ctx, &laneShards[k], nullptr, nullptr, who))
+                {
+                    c->error = L.workers[k]->ctx->error;
+                    return rc;
+                }
+            L.active = use;
         }
         else
             laneTeardown(c);
@@ -1755,6 +1770,17 @@ static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, p
 }
 
 int pd_ctx_set_shard(pd_ctx * c, const pd_shard * sh) { return applyShard(c, sh, nullptr, nullptr, "pd_ctx_set_shard"); }
+
+int pd_ctx_set_shard_lanes(pd_ctx * c, const pd_shard * sh, const pd_shard * lane_shards, uint32_t n_lane_shards)
+{
+    if (!lane_shards || n_lane_shards == 0)
+        return fail(c, "pd_ctx_set_shard_lanes: no lane channels given");
+    for (uint32_t k = 0; k < n_lane_shards; ++k)
+        if (!sh || lane_shards[k].rank != sh->rank || lane_shards[k].world != sh->world || lane_shards[k].first_sample != sh->first_sample ||
+            lane_shards[k].n_samples_global != sh->n_samples_global || !lane_shards[k].reserve || !lane_shards[k].all_gather)
+            return fail(c, "pd_ctx_set_shard_lanes: a lane's pd_shard must describe the same rank and cohort and carry its own callbacks");
+    return applyShard(c, sh, nullptr, nullptr, "pd_ctx_set_shard_lanes", lane_shards, n_lane_shards);
+}
 
 int pd_local_group_create(uint32_t world, pd_local_group ** out)
 {
@@ -2810,7 +2836,9 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         const unsigned nCells = (unsigned)cells.size();
         constexpr uint64_t kHeavyUnits = 5000000;
         std::unique_lock<std::mutex> heavy;
-        if (c->owner && static_cast<uint64_t>(nCells) * S > kHeavyUnits)
+        // (not in a cohort over several ranks: lane k here exchanges with lane k there, and two ranks that hold the lock for
+        // different lanes would wait for each other)
+        if (c->owner && c->world == 1 && static_cast<uint64_t>(nCells) * S > kHeavyUnits)
             heavy = std::unique_lock<std::mutex>(c->owner->heavyStage2);
         const size_t budget = c->stage2Budget;
         // (from the samples per context of the partition, not from this context's own count: all contexts of a sharded

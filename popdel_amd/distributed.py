@@ -133,10 +133,12 @@ class SampleShard:
     loader would parse only its own profiles and exchange the per-read-group ``min_init_del_len`` values); the context is
     created for this rank's samples only."""
 
-    def __init__(self, lib, readgroups, sample_rg_offsets, rank, world, group=None, device=0, native=False, **config):
+    def __init__(self, lib, readgroups, sample_rg_offsets, rank, world, group=None, device=0, native=False, lane_groups=None, **config):
         """native=True: the library runs the all-gathers itself with RCCL on its own stream (pd_ctx_set_shard_rccl; the
         communicator's id travels over `group` once); otherwise through the two host callbacks implemented by
-        SampleShardExchange (any torch.distributed backend; what the CPU and one-GPU tests use)."""
+        SampleShardExchange (any torch.distributed backend; what the CPU and one-GPU tests use). lane_groups: a list of
+        process groups, one per lane of the context (POPDEL_HIP_LANES) -- the cohort then keeps its lanes, lane k exchanging
+        over lane_groups[k] (pd_ctx_set_shard_lanes); every rank must pass groups created in the same order."""
         import torch
         from . import capi
         offs = np.asarray(sample_rg_offsets, dtype=np.int64)
@@ -159,6 +161,11 @@ class SampleShard:
                 dist.broadcast_object_list(box, src=0, group=group)
             self.exchange = NativeExchangeStats()
             self.ctx.set_shard_rccl(rank, world, self.first, n_samples, [r.min_init_del_len for r in readgroups], box[0])
+        elif lane_groups:
+            self.exchange = SampleShardExchange(rank, world, dev, group)
+            self.lane_exchanges = [SampleShardExchange(rank, world, dev, g) for g in lane_groups]
+            self.ctx.set_shard_lanes(rank, world, self.first, n_samples, [r.min_init_del_len for r in readgroups],
+                                     [(x.reserve, x.all_gather) for x in [self.exchange] + self.lane_exchanges])
         else:
             self.exchange = SampleShardExchange(rank, world, dev, group)
             self.ctx.set_shard(rank, world, self.first, n_samples, [r.min_init_del_len for r in readgroups],

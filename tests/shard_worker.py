@@ -91,6 +91,26 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group(os.environ.get("POPDEL_TEST_BACKEND", "gloo"), rank=rank, world_size=world)
     seg, rgs, offs, opts = make_case(case)
+    lanes = int(os.environ.get("POPDEL_TEST_LANES", "0"))
+    if lanes:
+        # the cohort keeps its lanes: one process group per lane (created in the same order on every rank), several tickets
+        # in flight, every one of them the whole segment
+        os.environ["POPDEL_HIP_LANES"] = str(lanes)
+        groups = [dist.new_group(backend=os.environ.get("POPDEL_TEST_BACKEND", "gloo")) for _ in range(lanes)]
+        shard = distributed.SampleShard(capi.load_hip(), rgs, offs, rank, world, device=device, lane_groups=groups, **opts)
+        handle = shard.ctx.stage(shard.local_segment(seg))
+        tickets = [shard.ctx.run(handle) for _ in range(2 * lanes)]
+        results = [shard.gather_columns(shard.ctx.collect(t)) for t in tickets]
+        shard.ctx.unstage(handle)
+        for x in [shard.exchange] + shard.lane_exchanges:
+            if x.last_error is not None:
+                raise x.last_error
+        if rank == 0:
+            pickle.dump(dict(calls=results, exchanges=shard.exchange.calls, lane_exchanges=[x.calls for x in shard.lane_exchanges]), open(out, "wb"))
+        dist.barrier()
+        shard.close()
+        dist.destroy_process_group()
+        return
     shard = distributed.SampleShard(capi.load_hip(), rgs, offs, rank, world, device=device, **opts)
     res = shard.run(shard.local_segment(seg))
     assert res["n_samples"] == shard.last - shard.first

@@ -78,3 +78,28 @@ def test_sample_shards_with_stage2_batches(built, tmp_path):
     assert sharded["exchanges"] > 60          # several batches, each with its own round of exchanges
     for k, v in single.items():
         assert np.array_equal(np.asarray(sharded["calls"][k]), np.asarray(v)), k
+
+
+@pytest.mark.parametrize("case,world,lanes", [("deletions600", 2, 2), ("stress3", 3, 3)])
+def test_sample_shards_keep_their_lanes(built, tmp_path, case, world, lanes):
+    """A cohort over two (three) ranks whose contexts keep two (three) lanes (pd_ctx_set_shard_lanes: one pair of callbacks and one process
+    group per lane): two tickets per lane in flight, lane k here exchanging with lane k there from the library's own threads --
+    every ticket's calls are bit for bit those of one plain context."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from shard_worker import make_case
+    from popdel_amd import capi
+    sharded = run_world(case, world, tmp_path / "sharded.pkl", {"POPDEL_TEST_LANES": str(lanes)})
+    seg, rgs, offs, opts = make_case(case)
+    os.environ["POPDEL_HIP_LANES"] = "1"
+    try:
+        ctx = capi.Context(capi.load_hip(), rgs, offs, **opts)
+    finally:
+        os.environ.pop("POPDEL_HIP_LANES", None)
+    single = ctx.collect(ctx.submit(seg))
+    ctx.close()
+    assert single["n_calls"] > 20 and len(sharded["calls"]) == 2 * lanes
+    assert len(sharded["lane_exchanges"]) == lanes and min(sharded["lane_exchanges"]) > 20   # every lane exchanged: two tickets each
+    for got in sharded["calls"]:
+        assert got["n_calls"] == single["n_calls"] and got["n_samples"] == single["n_samples"]
+        for k, v in single.items():
+            assert np.array_equal(np.asarray(got[k]), np.asarray(v)), k
