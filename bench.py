@@ -1014,10 +1014,18 @@ def main():
             # modelled_<d>us: the sharded path with the wire time of an exchange over xGMI injected behind every one of them
             # (a one-wave kernel that holds the stream for d microseconds, POPDEL_HIP_XCH_DELAY_US): what a rank of a cohort
             # sharded over several GPUs would see; modelled_efficiency = unsharded / modelled time per pass on the same samples
-            for kind in ("unsharded", "sharded", "modelled_20us", "modelled_40us"):
+            for kind in ("unsharded_plain", "unsharded", "sharded", "modelled_20us", "modelled_40us"):
                 if kind.startswith("modelled"):
                     os.environ["POPDEL_HIP_XCH_DELAY_US"] = kind[9:11]
-                if kind == "unsharded":
+                if kind == "unsharded_plain":
+                    # (a context without lanes, two tickets in flight: what rounds 1-3 measured the sharded path against)
+                    os.environ["POPDEL_HIP_LANES"] = "1"
+                    try:
+                        c2 = capi.Context(hip, [rg] * (R * n), sample_offsets[: n + 1], device=local_rank)
+                    finally:
+                        os.environ["POPDEL_HIP_LANES"] = str(max(1, args.lanes))
+                    closer = c2.close
+                elif kind == "unsharded":
                     c2 = capi.Context(hip, [rg] * (R * n), sample_offsets[: n + 1], device=local_rank)
                     closer = c2.close
                 else:
@@ -1026,7 +1034,7 @@ def main():
                     finally:
                         os.environ.pop("POPDEL_HIP_XCH_DELAY_US", None)
                     c2, closer = sh.ctx, sh.close
-                l2 = Lane(c2, c2.stage(sg), args.serial)
+                l2 = Lane(c2, c2.stage(sg), args.serial, depth=2 if kind == "unsharded_plain" else None)
                 l2.passes(5, new_acc())
                 torch.cuda.synchronize()
                 q0 = time.perf_counter()
@@ -1042,14 +1050,17 @@ def main():
                                all_gather_bytes_per_pass=acc[4]["all_gather_bytes"])
                 if kind.startswith("modelled"):
                     row[kind + "_efficiency"] = row["unsharded_ms_per_pass"] / row[kind + "_ms_per_pass"]
+                    row[kind + "_efficiency_vs_plain_context"] = row["unsharded_plain_ms_per_pass"] / row[kind + "_ms_per_pass"]
             row["overhead_ms_per_pass"] = row["sharded_ms_per_pass"] - row["unsharded_ms_per_pass"]
             row["modelled_ms_per_pass"] = row["modelled_40us_ms_per_pass"]
             row["modelled_efficiency"] = row["modelled_40us_efficiency"]
+            row["modelled_efficiency_vs_plain_context"] = row["modelled_40us_efficiency_vs_plain_context"]
             out.append(row)
         return dict(what="per pass over the resident segment: unsharded context vs. the sample-sharded path with a communicator of "
                          "ONE rank (library RCCL; exchanges issued and event-timed, no wire), and the same with 20 / 40 us of wire time "
                          "injected behind every exchange (modelled_*: the latency model of a cohort sharded over several GPUs; "
-                         "modelled_efficiency = the 40-us row); all contexts with the bench's lanes", rows=out)
+                         "modelled_efficiency = the 40-us row against the unsharded context WITH the bench's lanes, "
+                         "..._vs_plain_context against an unsharded context without lanes)", rows=out)
 
     def e2e_leg():
         # `popdel call` from profile FILES to a VCF (what a user of the reference runs): generated profiles of a 1-Mb
