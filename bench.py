@@ -1003,64 +1003,50 @@ def main():
 
     def sharded_world1_leg():
         # The sample-sharded code path with ONE rank and the library's own RCCL exchange: every exchange is issued and
-        # timed, nothing crosses a wire -- what the path costs by itself next to the unsharded context (same segment).
+        # timed, nothing crosses a wire -- what the path costs by itself next to the unsharded context (same segment) --, and
+        # the same with the wire time of an exchange over xGMI injected behind every one of them (a one-wave kernel that holds
+        # the stream for d microseconds, POPDEL_HIP_XCH_DELAY_US): what a rank of a cohort sharded over several GPUs would see.
+        # Measured in a process of its own (tools/sharded_model_probe.py), as a rank of such a cohort is one: beside this
+        # process's contexts (ten resident segments, three lanes' streams) the lanes of the measured context share hardware
+        # queues with them and a held stream holds its neighbours (1,280 samples, 40 us: 1.02 ms per pass in here, 0.65 alone).
+        import subprocess
+        sizes = ",".join(str(S if int(x) <= 0 else min(int(x), S)) for x in args.sharded_world1.split(",") if x.strip() != "")
+        n_pass = max(40, total_passes // 2)
+        env = dict(os.environ)
+        env.pop("POPDEL_HIP_LANES", None)
+        env.pop("POPDEL_HIP_XCH_DELAY_US", None)
+        lanes_arg = "1" if LANES == 1 else "1,%d" % LANES
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sharded_model_probe.py"), sizes, "0,20,40", lanes_arg, str(n_pass)],
+                           env=env, capture_output=True, text=True, timeout=args.sharded_timeout)
+        probe = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not probe:
+            raise RuntimeError("sharded_model_probe.py exited %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
         out = []
-        for n in [int(x) for x in args.sharded_world1.split(",") if x.strip() != ""]:
-            n = S if n <= 0 else min(n, S)
-            o, a = take_samples(offsets, arrays, n * R)
-            sg = capi.Segment(first, W, o, a["dev"], a["start"], a["on"], a["off"])
-            n_pass = max(40, total_passes // 2)
-            row = dict(samples=n, passes=n_pass, lanes=LANES)
-            # modelled_<d>us: the sharded path with the wire time of an exchange over xGMI injected behind every one of them
-            # (a one-wave kernel that holds the stream for d microseconds, POPDEL_HIP_XCH_DELAY_US): what a rank of a cohort
-            # sharded over several GPUs would see; modelled_efficiency = unsharded / modelled time per pass on the same samples
-            for kind in ("unsharded_plain", "unsharded", "sharded", "modelled_20us", "modelled_40us"):
-                if kind.startswith("modelled"):
-                    os.environ["POPDEL_HIP_XCH_DELAY_US"] = kind[9:11]
-                if kind == "unsharded_plain":
-                    # (a context without lanes, two tickets in flight: what rounds 1-3 measured the sharded path against)
-                    os.environ["POPDEL_HIP_LANES"] = "1"
-                    try:
-                        c2 = capi.Context(hip, [rg] * (R * n), sample_offsets[: n + 1], device=local_rank)
-                    finally:
-                        os.environ["POPDEL_HIP_LANES"] = str(max(1, args.lanes))
-                    closer = c2.close
-                elif kind == "unsharded":
-                    c2 = capi.Context(hip, [rg] * (R * n), sample_offsets[: n + 1], device=local_rank)
-                    closer = c2.close
-                else:
-                    try:
-                        sh = distributed.SampleShard(hip, [rg] * (R * n), sample_offsets[: n + 1], 0, 1, device=local_rank, native=True)
-                    finally:
-                        os.environ.pop("POPDEL_HIP_XCH_DELAY_US", None)
-                    c2, closer = sh.ctx, sh.close
-                l2 = Lane(c2, c2.stage(sg), args.serial, depth=2 if kind == "unsharded_plain" else None)
-                l2.passes(5, new_acc())
-                torch.cuda.synchronize()
-                q0 = time.perf_counter()
-                acc = new_acc()
-                l2.passes(n_pass, acc)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - q0
-                c2.unstage(l2.handle)
-                closer()
-                row[kind + "_ms_per_pass"] = dt / n_pass * 1e3
-                if kind == "sharded":
-                    row.update(exchange_ms_per_pass=acc[5] / n_pass, all_gathers_per_pass=acc[4]["n_all_gathers"],
-                               all_gather_bytes_per_pass=acc[4]["all_gather_bytes"])
-                if kind.startswith("modelled"):
-                    row[kind + "_efficiency"] = row["unsharded_ms_per_pass"] / row[kind + "_ms_per_pass"]
-                    row[kind + "_efficiency_vs_plain_context"] = row["unsharded_plain_ms_per_pass"] / row[kind + "_ms_per_pass"]
+        for n in [int(x) for x in sizes.split(",")]:
+            mine = {(p["lanes"], p["delay_us_per_exchange"]): p for p in probe if p["samples_per_rank"] == n}
+            k = LANES if (LANES, 0.0) in mine else 1
+            zero, d20, d40 = mine[(k, 0.0)], mine[(k, 20.0)], mine[(k, 40.0)]
+            row = dict(samples=n, passes=n_pass, lanes=k, unsharded_plain_ms_per_pass=zero["unsharded_one_lane_ms_per_pass"],
+                       unsharded_ms_per_pass=zero["unsharded_same_lanes_ms_per_pass"], sharded_ms_per_pass=zero["modelled_ms_per_pass"],
+                       exchange_ms_per_pass=zero["exchange_ms_per_pass"], all_gathers_per_pass=zero["all_gathers_per_pass"],
+                       all_gather_bytes_per_pass=zero.get("all_gather_bytes_per_pass"),
+                       modelled_20us_ms_per_pass=d20["modelled_ms_per_pass"], modelled_40us_ms_per_pass=d40["modelled_ms_per_pass"])
+            for kind, p in (("modelled_20us", d20), ("modelled_40us", d40)):
+                row[kind + "_efficiency"] = p["modelled_efficiency_vs_same_lanes"]
+                row[kind + "_efficiency_vs_plain_context"] = p["modelled_efficiency"]
+            if (1, 40.0) in mine:
+                row["modelled_40us_one_lane_ms_per_pass"] = mine[(1, 40.0)]["modelled_ms_per_pass"]
+                row["modelled_40us_one_lane_efficiency"] = mine[(1, 40.0)]["modelled_efficiency"]
             row["overhead_ms_per_pass"] = row["sharded_ms_per_pass"] - row["unsharded_ms_per_pass"]
             row["modelled_ms_per_pass"] = row["modelled_40us_ms_per_pass"]
             row["modelled_efficiency"] = row["modelled_40us_efficiency"]
             row["modelled_efficiency_vs_plain_context"] = row["modelled_40us_efficiency_vs_plain_context"]
             out.append(row)
-        return dict(what="per pass over the resident segment: unsharded context vs. the sample-sharded path with a communicator of "
-                         "ONE rank (library RCCL; exchanges issued and event-timed, no wire), and the same with 20 / 40 us of wire time "
-                         "injected behind every exchange (modelled_*: the latency model of a cohort sharded over several GPUs; "
-                         "modelled_efficiency = the 40-us row against the unsharded context WITH the bench's lanes, "
-                         "..._vs_plain_context against an unsharded context without lanes)", rows=out)
+        return dict(what="per pass over the resident segment, in a process of its own (tools/sharded_model_probe.py): unsharded context vs. "
+                         "the sample-sharded path with a communicator of ONE rank (library RCCL; exchanges issued and event-timed, no wire), and "
+                         "the same with 20 / 40 us of wire time injected behind every exchange (modelled_*: the latency model of a cohort "
+                         "sharded over several GPUs; modelled_efficiency = the 40-us row against the unsharded context WITH the bench's lanes, "
+                         "..._vs_plain_context against an unsharded context without lanes, ..._one_lane_* the sharded context without lanes)", rows=out)
 
     def e2e_leg():
         # `popdel call` from profile FILES to a VCF (what a user of the reference runs): generated profiles of a 1-Mb

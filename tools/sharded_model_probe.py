@@ -36,7 +36,7 @@ def measure(make_ctx, seg, n_pass, depth):
 
 
 def main():
-    samples = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1280,6400,10000").split(",")]
+    samples = [int(x) if int(x) > 0 else 10000 for x in (sys.argv[1] if len(sys.argv) > 1 else "1280,6400,10000").split(",")]
     delays = [float(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,20,40").split(",")]
     lanes = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1,2,3").split(",")]
     n_pass = int(sys.argv[4]) if len(sys.argv) > 4 else 160
@@ -77,7 +77,8 @@ def main():
                 row = dict(samples_per_rank=n, lanes=k, delay_us_per_exchange=d, unsharded_one_lane_ms_per_pass=round(base_ms, 4),
                            unsharded_same_lanes_ms_per_pass=round(lanes_ms, 4), modelled_ms_per_pass=round(ms, 4),
                            modelled_efficiency=round(base_ms / ms, 4), modelled_efficiency_vs_same_lanes=round(lanes_ms / ms, 4),
-                           all_gathers_per_pass=acc[4]["n_all_gathers"], exchange_ms_per_pass=round(acc[5] / n_pass, 4))
+                           all_gathers_per_pass=acc[4]["n_all_gathers"], all_gather_bytes_per_pass=acc[4]["all_gather_bytes"],
+                           exchange_ms_per_pass=round(acc[5] / n_pass, 4))
                 rows.append(row)
                 print(json.dumps(row), flush=True)
     os.environ.pop("POPDEL_HIP_XCH_DELAY_US", None)
