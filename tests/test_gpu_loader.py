@@ -67,8 +67,8 @@ def test_a_damaged_profile_behaves_as_on_the_host(built, cohort_dir, tmp_path):
 
 def test_loader_variants_write_the_same_vcf(built, cohort_dir, tmp_path):
     """The loader's switches -- blocks parsed on the host (POPDEL_HOST_PARSE=1), every round fetched when it begins
-    (POPDEL_LOADER_AHEAD=0) -- against the default (parsed on the device, the next round's blocks fetched ahead on a guess):
-    same bytes; and the default did fetch rounds ahead."""
+    (POPDEL_LOADER_AHEAD=0), page-locked memory from hipHostMalloc with spinning waits and no NUMA binding -- against the default
+    (parsed on the device, the next round's blocks fetched ahead on a guess): same bytes; and the default did fetch rounds ahead."""
     from popdel_amd import synth
     d = cohort_dir("s600", 600, synth.single_deletion)
     args = ["-r", "chr20:1000000-2000000"]
@@ -78,7 +78,8 @@ def test_loader_variants_write_the_same_vcf(built, cohort_dir, tmp_path):
     ahead = int(line.split("thread-seconds for it; ")[1].split()[0])
     parsed = int(line.split("parsed there for ")[1].split(";")[0])
     assert ahead >= 1 and parsed >= 600, line
-    for env in ({"POPDEL_HOST_PARSE": "1"}, {"POPDEL_LOADER_AHEAD": "0"}, {"POPDEL_HOST_PARSE": "1", "POPDEL_LOADER_AHEAD": "0"}):
+    for env in ({"POPDEL_HOST_PARSE": "1"}, {"POPDEL_LOADER_AHEAD": "0"}, {"POPDEL_HOST_PARSE": "1", "POPDEL_LOADER_AHEAD": "0"},
+                {"POPDEL_HIP_PINNED": "malloc", "POPDEL_HIP_BLOCKING_SYNC": "0", "POPDEL_NO_NUMA_BIND": "1"}):
         r1, other = call(d, str(tmp_path / "other.vcf"), *args, env=env)
         assert r1.returncode == 0, r1.stderr[-300:]
         assert other == base, env
