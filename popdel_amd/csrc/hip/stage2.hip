@@ -2070,6 +2070,10 @@ __global__ __launch_bounds__(kSampleTile) void finalKernel(SegmentView seg, Coho
 
 // The final pass on the dense image, one lane per sample. log / log10 of the heterozygous term again come from one
 // mantissa product per sample; the supporting pairs are appended to the pool with one atomic per wave.
+// NarrowTable: gather the EM kernels' 16-byte entries and take log10 here (candidate-rich batches: the 32-byte table of 10,000
+// samples is 320 MB, twice what the last-level cache holds beside the image -- 10.3 GB of HBM per launch through it, 5.3 GB
+// this way, same time); else the 32-byte entries {value, log, log10} (sparse batches: 221 us per launch against 260).
+template <bool NarrowTable>
 __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, Stage2Buffers b, const uint8_t * __restrict__ flags,
                                                                 unsigned nWindows, unsigned firstPos, unsigned shift)
 {
@@ -2117,35 +2121,48 @@ __global__ __launch_bounds__(kSampleTile) void finalDenseKernel(CohortView co, S
     for (unsigned q = 0; q < kRowBatch; ++q)
         dvs[q] = col[min(j0 + q, (unsigned)kDenseCap - 1u) * 64];
     PD_ALL_LOADS_DONE(dvs);
-    // (the 16-byte entries {value, log} of the EM kernels, log10 taken here by the function that fills the 32-byte table
-    // (logTableKernel): the same bits, half the bytes -- the 32-byte table of 10,000 samples is 320 MB, twice what the
-    // last-level cache holds beside the image, and this kernel read 10.3 GB of HBM per candidate-dense launch through it)
+    // (log10 by the function that fills the 32-byte table, logTableKernel: the same bits)
     double2 trs2[kRowBatch], tds2[kRowBatch];
+    double4 trs[kRowBatch], tds[kRowBatch];
     bool inR[kRowBatch], inD[kRowBatch];
 #pragma unroll
     for (unsigned q = 0; q < kRowBatch; ++q)
     {
         const bool use = j0 + q < nn;
         const long long pr = lookupPos(rc, dvs[q] - refShift), pdl = lookupPos(rc, dvs[q] - len);
-        trs2[q] = make_double2(rc.minProb, rc.logMinProb);
-        tds2[q] = trs2[q];
         inR[q] = use && pr >= 0;
         inD[q] = use && pdl >= 0;
-        if (inR[q])
-            trs2[q] = co.tab2[pr];
-        if (inD[q])
-            tds2[q] = co.tab2[pdl];
+        if constexpr (NarrowTable)
+        {
+            trs2[q] = make_double2(rc.minProb, rc.logMinProb);
+            tds2[q] = trs2[q];
+            if (inR[q])
+                trs2[q] = co.tab2[pr];
+            if (inD[q])
+                tds2[q] = co.tab2[pdl];
+        }
+        else
+        {
+            trs[q] = make_double4(rc.minProb, rc.logMinProb, rc.log10MinProb, 0.0);
+            tds[q] = trs[q];
+            if (inR[q])
+                trs[q] = co.tab[pr];
+            if (inD[q])
+                tds[q] = co.tab[pdl];
+        }
     }
-    double4 trs[kRowBatch], tds[kRowBatch];
     // (the starts are wanted by the arithmetic only: loaded behind the lookups, so that no lookup is issued behind a wait for them)
 #pragma unroll
     for (unsigned q = 0; q < kRowBatch; ++q)
         sts[q] = colSt[min(j0 + q, (unsigned)kDenseCap - 1u) * 64];
-#pragma unroll
-    for (unsigned q = 0; q < kRowBatch; ++q)
+    if constexpr (NarrowTable)
     {
-        trs[q] = make_double4(trs2[q].x, trs2[q].y, inR[q] ? log10(trs2[q].x) : rc.log10MinProb, 0.0);
-        tds[q] = make_double4(tds2[q].x, tds2[q].y, inD[q] ? log10(tds2[q].x) : rc.log10MinProb, 0.0);
+#pragma unroll
+        for (unsigned q = 0; q < kRowBatch; ++q)
+        {
+            trs[q] = make_double4(trs2[q].x, trs2[q].y, inR[q] ? log10(trs2[q].x) : rc.log10MinProb, 0.0);
+            tds[q] = make_double4(tds2[q].x, tds2[q].y, inD[q] ? log10(tds2[q].x) : rc.log10MinProb, 0.0);
+        }
     }
 #pragma unroll
     for (unsigned q = 0; q < kRowBatch; ++q)
@@ -3402,7 +3419,10 @@ void runStage2Main(const SegmentView & seg, const CohortView & co, Stage2Buffers
     x.allGather(b.xch, xchBytes);
     hipLaunchKernelGGL(cellConvergedKernel, wavePerCell, dim3(64), 0, st, b);
     hipLaunchKernelGGL(cellPostLoopKernel, perCell, cellBlock, 0, st, b);
-    hipLaunchKernelGGL(finalDenseKernel, perSample, tile, 0, st, co, b, flags, seg.nWindows, seg.firstPos, seg.shift);
+    if (static_cast<uint64_t>(b.nCells) * co.nSamples > 2000000ull)
+        hipLaunchKernelGGL(finalDenseKernel<true>, perSample, tile, 0, st, co, b, flags, seg.nWindows, seg.firstPos, seg.shift);
+    else
+        hipLaunchKernelGGL(finalDenseKernel<false>, perSample, tile, 0, st, co, b, flags, seg.nWindows, seg.firstPos, seg.shift);
     if (b.mt.n != 0)
         hipLaunchKernelGGL(finalMultiKernel, perMulti, tile, 0, st, co, b, flags, seg.nWindows, seg.firstPos, seg.shift);
     if (anyGenericTile)
