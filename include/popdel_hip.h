@@ -385,7 +385,7 @@ int pd_inflate_members(int device, const uint8_t *data, const uint64_t *member_o
 const char *pd_inflate_last_error(void);
 
 /* The same as an object that keeps its stream, device buffers and page-locked staging from call to call (how `popdel call`
- * inflates the profile blocks of a round: a chunk of samples per call, two inflaters alternating). The caller gathers the
+ * inflates the profile blocks of a round: a chunk of samples per call, several inflaters in turn). The caller gathers the
  * members into the page-locked buffer pd_inflater_input() returns (room for `bytes`; valid until the next call of it),
  * pd_inflater_run() copies them up, inflates and copies back: *out (page-locked, callee-owned, valid until the next run on
  * this inflater) holds member m's bytes at out_offsets[m], *status / *out_lengths as in pd_inflate_members(). One inflater

@@ -235,7 +235,7 @@ std::string g_inflateError;
 }  // namespace
 
 // A persistent inflater: stream, device buffers and page-locked staging on both sides kept from call to call (what the
-// loader of `popdel call` uses: a chunk of samples' members per call, two inflaters alternating so that one chunk is on the
+// loader of `popdel call` uses: a chunk of samples' members per call, several inflaters in turn so that one chunk is on the
 // device while the next is gathered).
 struct pd_inflater
 {

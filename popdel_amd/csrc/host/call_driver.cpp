@@ -180,15 +180,17 @@ struct alignas(64) DecodedStream      // (neighbours in the pool are filled by d
     }
 };
 
-// Gunzip of a round's profile blocks on the device (round 4). Which samples read in a round, from where and up to where is
-// known before the round starts (the readers are the samples whose slots are not switched; they read from the index block
-// of the region's begin to the window behind their write slot's border), and the index brackets every gzip member of that
-// stretch. A thread of its own takes the readers in chunks: their members' bytes go from the files into an inflater's
-// page-locked buffer (pd_inflater_input), the device inflates them one lane per member (pd_inflater_run, inflate.hip) and the
-// decoder threads parse a sample's bytes from memory instead of inflating them -- with the file behind them if the stretch
-// turns out too short (ProfileFile::openPrefetched). Two inflaters alternate: one chunk is on the device while the decoder
-// threads work through the previous one. A sample whose index, members or inflated sizes look wrong in any way is left to the
-// host's own path (zlib's behaviour on damaged files is the specification there).
+// The loader's blocks on the device (round 4). Which samples read in a round, from where and up to where is known when the
+// round starts (the readers are the samples whose slots are not switched; they read from the index block of the region's begin
+// to the window behind their write slot's border), and the index brackets every gzip member of that stretch. A thread of its
+// own takes the readers in chunks (256, then 1,024 samples): their members' bytes go from the files into an inflater's
+// page-locked buffer (pd_inflater_input); a thread per inflater (three) has the device inflate them one lane per member and
+// parse the blocks (pd_inflater_run_parsed, inflate.hip) and publishes, per sample, the arrays the replay reads -- or, for a
+// sample with a block the device's parser left alone, the inflated bytes, which the decoder threads parse from memory with
+// the file behind them if the stretch turns out too short (ProfileFile::openPrefetched). An inflater's buffers go round when
+// the chunk that used them last has been replayed. A sample whose index, members or inflated sizes look wrong in any way is
+// left to the host's own path (zlib's behaviour on damaged files is the specification there). CallRun keeps two of these:
+// one serves the running round, the other works ahead on a guess of the next (startGunzipPrefetch(), adopt()).
 class GunzipPrefetch
 {
 public:
@@ -220,8 +222,8 @@ public:
         const std::vector<uint64_t> * regionOffsets = nullptr;
     };
     // items per chunk: a launch takes ~10 ms however few members it has (one lane works through its member alone), so what
-    // keeps the decoder threads fed is SEVERAL chunks on the device at a time -- four inflaters, a thread each, chunks as wide
-    // as a batch of the decoder (a chunk of 512 samples is 168 of the device's 768 wave slots) -- and a short first chunk
+    // keeps the decoder threads fed is SEVERAL chunks on the device at a time -- three inflaters, a thread each -- and a
+    // short first chunk (measured: 2,048-sample chunks and four inflaters of 512 were no better)
     static constexpr size_t kFirstChunk = 256, kChunk = 1024, kInflaters = 3;
     static size_t chunkOf(size_t item) { return item < kFirstChunk ? 0 : 1 + (item - kFirstChunk) / kChunk; }
     static size_t chunkBegin(size_t c) { return c == 0 ? 0 : kFirstChunk + (c - 1) * kChunk; }
