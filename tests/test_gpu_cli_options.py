@@ -116,3 +116,28 @@ def test_window_loop_on_the_device_equals_the_walk_on_the_host(built, mixed_coho
         assert (on_device == 0 and on_host >= 2) if host_walk else (on_device >= 2 and on_host == 0), (on_device, on_host)
         outs.append(strip_date(open(out).read()))
     assert outs[0] == outs[1] and outs[0].count("\n") > 25
+
+
+@pytest.mark.parametrize("opts", [["-r", "chr20:1000000-1400000"], ["-r", "chr20:1000000-1400000", "-A", "MAXCOV", "-n"],
+                                  ["-r", "chr20:1050001-1150000", "-r", "chr20:1240001-1290000", "-n"],
+                                  ["-b", "100000", "-r", "chr20:1000000-1400000", "-n"]],
+                         ids=["default", "coverage_file", "two_regions", "small_buffer"])
+def test_device_loader_on_the_mixed_cohort(built, mixed_cohort, tmp_path, opts):
+    """The round-4 loader (blocks inflated and parsed on the device, fetched a round ahead, light end tables, records filed in
+    blocks) against the host-only configuration of round 3 on the cohort with three-read-group samples (their blocks are
+    inflated on the device and parsed by the host), heterogeneous libraries, a low-coverage sample and read groups whose
+    active-coverage cap binds (records dropped by the rule: filed one by one). Same bytes."""
+    opts = [os.path.join(mixed_cohort, "maxcov.txt") if o == "MAXCOV" else o for o in opts]
+
+    def call(out, env):
+        e = dict(os.environ, POPDEL_TIMING="1", **env)
+        e.pop("POPDEL_HIP_LANES", None)
+        r = subprocess.run([POPDEL_BIN, "call", os.path.join(mixed_cohort, "profiles.txt"), "-o", out] + opts, env=e, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-300:]
+        return strip_date(open(out).read()), r.stderr
+
+    new, log = call(str(tmp_path / "new.vcf"), {"POPDEL_DEVICE_GUNZIP_WAIT": "1"})
+    old, _ = call(str(tmp_path / "old.vcf"), {"POPDEL_HOST_GUNZIP": "1", "POPDEL_HEAVY_TABLES": "1"})
+    assert new == old and new.count("\n") > 25
+    line = [l for l in log.splitlines() if "loader: profile blocks inflated on the device" in l]
+    assert line and int(line[0].split("for ")[1].split()[0]) >= 12, log[-400:]
