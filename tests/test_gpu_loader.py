@@ -37,6 +37,7 @@ def test_device_gunzip_and_light_tables_write_the_same_vcf(built, cohort_dir, tm
         # (the device did take the blocks: every round that began once the backend was up)
         line = [l for l in r1.stderr.splitlines() if "loader: profile blocks inflated on the device" in l]
         assert line, r1.stderr[-400:]
+        print("region size %d, %s: %s" % (region_size, " ".join(args), line[0].split("thread-seconds for it; ")[1]))
         assert int(line[0].split("for ")[1].split()[0]) >= 600 and "(0 left to the host)" in line[0], line[0]
         assert "loader:" not in r0.stderr
 
@@ -88,3 +89,39 @@ def test_loader_variants_write_the_same_vcf(built, cohort_dir, tmp_path):
             assert " 0 rounds fetched ahead" in line, line
         if "POPDEL_HOST_PARSE" in env:
             assert "parsed there for 0;" in line, line
+
+
+@pytest.mark.parametrize("region_size", [2000, 50000])
+def test_uneven_profiles_behave_as_on_the_host(built, tmp_path, region_size):
+    """Profiles that differ where the prefetch has to be careful: index regions of 2,000 or 50,000 bp instead of 10,000 (the
+    guess for the round to come lands several regions away from where the round begins, or in the same one for rounds on
+    end), stretches without any pair (index entries that repeat), a profile whose data ends early, a sparse one -- device
+    loader against the host-only configuration, with the default and small window buffers (more rounds), same bytes."""
+    from popdel_amd import synth
+    d = str(tmp_path / "uneven")
+    os.makedirs(d)
+    region = (1000000, 1600000)
+    paths = []
+    for k in range(30):
+        lib = synth.Library(hist_seed=300 + k, coverage=3.0 if k == 11 else 30.0)
+        dels = [synth.Deletion(1200000, 1200, [1, 2, 0][k % 3]), synth.Deletion(1450000, 600, [2, 1, 1][k % 3])]
+        pos, dev = synth.sample_pairs(7000 + k, region, lib, dels)
+        if k % 4 == 1:                      # a stretch without pairs (several empty index regions)
+            keep = (pos < 1280000 + 3000 * k) | (pos >= 1420000)
+            pos, dev = pos[keep], dev[keep]
+        if k == 17:                         # the data ends early
+            keep = pos < 1330000
+            pos, dev = pos[keep], dev[keep]
+        p = os.path.join(d, "u%02d.profile" % k)
+        synth.write_profile(p, "U%02d" % k, pos, dev, lib, region_size=region_size)
+        paths.append(p)
+    with open(os.path.join(d, "profiles.txt"), "w") as fh:
+        fh.write("\n".join(paths) + "\n")
+    for args in (["-r", "chr20:1000000-1600000"], ["-r", "chr20:1000000-1600000", "-b", "40000", "-n"], ["-r", "chr20:1030000-1590000", "-b", "70000"]):
+        r1, new = call(d, str(tmp_path / "new.vcf"), *args)
+        r0, old = call(d, str(tmp_path / "old.vcf"), *args, env={"POPDEL_HOST_GUNZIP": "1", "POPDEL_HEAVY_TABLES": "1"})
+        assert r0.returncode == 0 and r1.returncode == 0, (r0.stderr[-300:], r1.stderr[-300:])
+        assert new == old and len(new.splitlines()) > 20, args
+        line = [l for l in r1.stderr.splitlines() if "loader: profile blocks inflated on the device" in l]
+        assert line, r1.stderr[-400:]
+        print("region size %d, %s: %s" % (region_size, " ".join(args), line[0].split("thread-seconds for it; ")[1]))
