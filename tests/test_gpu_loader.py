@@ -37,7 +37,6 @@ def test_device_gunzip_and_light_tables_write_the_same_vcf(built, cohort_dir, tm
         # (the device did take the blocks: every round that began once the backend was up)
         line = [l for l in r1.stderr.splitlines() if "loader: profile blocks inflated on the device" in l]
         assert line, r1.stderr[-400:]
-        print("region size %d, %s: %s" % (region_size, " ".join(args), line[0].split("thread-seconds for it; ")[1]))
         assert int(line[0].split("for ")[1].split()[0]) >= 600 and "(0 left to the host)" in line[0], line[0]
         assert "loader:" not in r0.stderr
 
