@@ -1,6 +1,7 @@
 #include "chrom_profile.h"
 
 #include <algorithm>
+#include <atomic>
 
 #include "parallel.h"
 #include "profile_io.h"   // posToWin
@@ -954,13 +955,14 @@ WalkShape ChromProfile::planSegment(unsigned shift, std::vector<uint8_t> & equal
         currentPos += shift;
         sh.hasStep = true;
         sh.stepPos = currentPos;
-        for (size_t rg = 0; rg < nRg; ++rg)
-        {
+        // (read group by read group on its own tables: in parallel -- 4,000 of them took 9 ms of every round one after another)
+        const unsigned at = currentPos;
+        parallelFor(nRg, [&](size_t rg) {
             StartSlots & st = starts[rg];
             EndSlots & en = ends[rg];
-            st.readIdx = startsUpTo(st.slots[st.readSlot].entries, st.readIdx, currentPos);
-            en.advanceReadTo(currentPos, shift);
-        }
+            st.readIdx = startsUpTo(st.slots[st.readSlot].entries, st.readIdx, at);
+            en.advanceReadTo(at, shift);
+        }, 128);
         profilesAtEnd = false;
     }
     // ---- initializeActive(): window 0 sits at the smallest first start, if that lies before the current position
@@ -993,13 +995,12 @@ WalkShape ChromProfile::planSegment(unsigned shift, std::vector<uint8_t> & equal
     unsigned maxSteps = 0;
     if (pos0 + shift < currentRightBorder)
         maxSteps = (currentRightBorder - pos0 - 1) / shift;
-    unsigned steps = 0;
-    for (size_t rg = 0; rg < nRg; ++rg)
-    {
+    std::atomic<unsigned> stepsSeen(0);
+    parallelFor(nRg, [&](size_t rg) {
         StartSlots & st = starts[rg];
         EndSlots & en = ends[rg];
         if (maxSteps == 0 || (en.readAtEnd() && st.readAtEnd()))
-            continue;
+            return;
         unsigned js = 0, je = 0;
         if (!st.readAtEnd())
         {
@@ -1012,11 +1013,15 @@ WalkShape ChromProfile::planSegment(unsigned shift, std::vector<uint8_t> & equal
             je = last < pos0 ? 1u : (last - pos0) / shift + 1;
         }
         const unsigned mine = std::min(maxSteps, std::max(js, je));
-        steps = std::max(steps, mine);
+        unsigned seen = stepsSeen.load(std::memory_order_relaxed);
+        while (seen < mine && !stepsSeen.compare_exchange_weak(seen, mine, std::memory_order_relaxed))
+        {
+        }
         const unsigned lastPos = pos0 + mine * shift;
         st.readIdx = startsUpTo(st.slots[st.readSlot].entries, st.readIdx, lastPos);
         en.advanceReadTo(lastPos, shift);
-    }
+    }, 128);
+    const unsigned steps = stepsSeen.load();
     currentPos = pos0 + steps * shift;
     profilesAtEnd = true;
     logWindow_ = steps + 1;
