@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 11
+#define PD_ABI_VERSION 12
 
 /* One read group after start-up conditioning.
  * Replaces: `Histogram` (reference insert_histogram_popdel.h:19-43) after processHistogram()
@@ -114,6 +114,11 @@ typedef struct pd_calls
     uint32_t *lad;                /* Call::lads, 3 per sample                                       */
     uint32_t *dad;                /* Call::dads, 5 per sample (ref, both, between, alt, right)      */
     uint32_t *first_last;         /* Call::firstLast, 2 per sample                                  */
+    /* Parity instrumentation (ABI 12; no reference counterpart): per call, how many reference-shift quotients of ITS
+     * EM (all samples, read groups and iterations; reference genotype_deletion_popdel_call.h:447-450) sat within 1e-9
+     * of an integer -- the truncations whose outcome hangs off the last bit of x87 weights (pd_timing below, DESIGN.md
+     * "Numerics"). A call that differs from the reference's anywhere has a non-zero count; the results are untouched. */
+    uint32_t *near_integer_shifts;
 } pd_calls;
 
 /* Per-window stage-1 results of the last collected segment (diagnostics / parity tests).

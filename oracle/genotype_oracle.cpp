@@ -81,6 +81,7 @@ struct OracleCall
     double likelihoodRatio, frequency;
     uint32_t windowPosition, position, endPosition;
     uint8_t filter;
+    uint32_t nearIntegerShifts;       // instrumentation (pd_calls::near_integer_shifts), not a field of the reference's Call
     std::vector<uint32_t> pl, lad, dad, firstLast;
 };
 
@@ -460,6 +461,7 @@ DTriple genotypePriors(double f, bool somatic)
 }
 
 static bool g_snapShifts = false;    // POPDEL_SNAP_SHIFTS, read per segment
+static uint32_t g_nearIntegerShifts = 0;   // quotients within 1e-9 of an integer since the current cell's EM began (reported per call)
 static int g_perturbFreq = 0;        // POPDEL_ORACLE_PERTURB_FREQ, read per segment
 static bool g_traceKnife = false;   // set while the window named by POPDEL_TRACE_POS is processed
 
@@ -499,6 +501,11 @@ unsigned updateDeletionLength(const pd_ctx & c, const std::vector<LTriple> & dat
                 weightedSumRef += probRef * p.dev;
             }
             double quotient = weightedSumRef / sumRef;
+            {
+                const double r = std::rint(quotient);
+                if (std::fabs(quotient - r) <= 1e-9 * std::max(1.0, std::fabs(r)))
+                    ++g_nearIntegerShifts;
+            }
             if (g_snapShifts)
             {
                 // Test knob POPDEL_SNAP_SHIFTS (the test build libpopdel_hip_snap.so does the same): a quotient within 1e-9 of an integer is
@@ -590,6 +597,7 @@ void genotypeWindow(pd_ctx & c, int32_t * q3Out, uint8_t * flagOut)
     for (int initLen : lengths)
     {
         std::fill(referenceShifts.begin(), referenceShifts.end(), 0);
+        g_nearIntegerShifts = 0;
         std::map<int, double> visited;
         double freq = initializeAlleleFrequency(c, static_cast<unsigned>(initLen));
         if (freq == 0)
@@ -682,6 +690,7 @@ void genotypeWindow(pd_ctx & c, int32_t * q3Out, uint8_t * flagOut)
             continue;
         call.initialLength = static_cast<uint32_t>(initLen);
         call.iterations = iterations;
+        call.nearIntegerShifts = g_nearIntegerShifts;
         call.deletionLength = len;
         call.likelihoodRatio = logLR;
         call.frequency = freq;
@@ -956,6 +965,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
     PD_FIELD_U(window_position, windowPosition)
     PD_FIELD_U(position, position)
     PD_FIELD_U(end_position, endPosition)
+    PD_FIELD_U(near_integer_shifts, nearIntegerShifts)
 #undef PD_FIELD_U
     for (uint32_t i = 0; i < n; ++i) d[i] = c->calls[i].likelihoodRatio;
     pc->likelihood_ratio = copyArray(d);
@@ -990,6 +1000,7 @@ void pd_calls_free(pd_calls * pc)
     std::free(pc->position);
     std::free(pc->end_position);
     std::free(pc->filter);
+    std::free(pc->near_integer_shifts);
     std::free(pc->pl);
     std::free(pc->lad);
     std::free(pc->dad);

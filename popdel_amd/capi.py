@@ -54,7 +54,8 @@ class PdCalls(C.Structure):
                 ("likelihood_ratio", C.POINTER(C.c_double)), ("frequency", C.POINTER(C.c_double)),
                 ("window_position", C.POINTER(C.c_uint32)), ("position", C.POINTER(C.c_uint32)),
                 ("end_position", C.POINTER(C.c_uint32)), ("filter", C.POINTER(C.c_uint8)), ("pl", C.POINTER(C.c_uint32)),
-                ("lad", C.POINTER(C.c_uint32)), ("dad", C.POINTER(C.c_uint32)), ("first_last", C.POINTER(C.c_uint32))]
+                ("lad", C.POINTER(C.c_uint32)), ("dad", C.POINTER(C.c_uint32)), ("first_last", C.POINTER(C.c_uint32)),
+                ("near_integer_shifts", C.POINTER(C.c_uint32))]
 
 
 class PdMerged(C.Structure):
@@ -416,7 +417,8 @@ class Context:
             window_position=arr(c.window_position, (n,), np.uint32), position=arr(c.position, (n,), np.uint32),
             end_position=arr(c.end_position, (n,), np.uint32), filter=arr(c.filter, (n,), np.uint8),
             pl=arr(c.pl, (n, S, 3), np.uint32), lad=arr(c.lad, (n, S, 3), np.uint32), dad=arr(c.dad, (n, S, 5), np.uint32),
-            first_last=arr(c.first_last, (n, S, 2), np.uint32))
+            first_last=arr(c.first_last, (n, S, 2), np.uint32),
+            near_integer_shifts=arr(c.near_integer_shifts, (n,), np.uint32))
         self.lib.pd_calls_free(p)
         return out
 

@@ -3177,6 +3177,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
         PD_FILL_U(window_position, firstPos + (uint32_t)cs.window * shift - 1u)
         PD_FILL_U(position, c->cfg.window_wise_output ? firstPos + (uint32_t)cs.window * shift - 1u : cs.suppStart)
         PD_FILL_U(end_position, c->cfg.window_wise_output ? 0u : cs.suppEnd)
+        PD_FILL_U(near_integer_shifts, cs.nearIntegerShifts)
 #undef PD_FILL_U
         for (uint32_t i = 0; i < n; ++i) d[i] = cells[emit[i]].logLR;
         pc->likelihood_ratio = mallocCopy(d);
@@ -3263,6 +3264,7 @@ void pd_calls_free(pd_calls * pc)
     std::free(pc->position);
     std::free(pc->end_position);
     std::free(pc->filter);
+    std::free(pc->near_integer_shifts);
     CallsBox * box = reinterpret_cast<CallsBox *>(pc);       // pub is the first member
     givePinned(box->pinned);
     delete box;

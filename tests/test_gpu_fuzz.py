@@ -138,11 +138,61 @@ def note_cohort(seed, figures):
 LAST_TOUCHED_LR = []
 
 
-# 67 cohorts as the reference computes them; seed 155 holds the one diverged call of round 2's 200-cohort sweep, seed 483
-# the one call of round 3's 300-cohort sweep (seeds 200-499, 51,517 calls) whose LR moves by more than 1e-6 although length,
-# iteration count and every sample column agree: a flipped shift under a pair that sits on a steep flank of its histogram
-# (5309.86 against 5309.18)
-UNSNAPPED_SEEDS = list(range(64)) + [132, 155, 483]
+# 64 cohorts as the reference computes them -- seeds 0-63, taken as they come: an UNBIASED sample of the knife-edge class
+# (Numerics), on which the rates of conftest.py are checked. The cohorts that the builder's wider sweeps
+# (1,050 cohorts, ~190,000 calls; profiles/r04_fuzz_sweeps.md) singled out for the largest footprints are NOT mixed into that
+# sample (they would be a selection); they run below, against the shipped library, with their residual pinned call by call.
+UNSNAPPED_SEEDS = list(range(64))
+
+
+@pytest.mark.parametrize("seed", UNSNAPPED_SEEDS)
+def test_random_cohort(built, seed):
+    seg, rgs, offs, opts = random_case(seed)
+    gpu, cpu = both(seg, rgs, offs, **opts)
+    calls, cols, div, worst_lr, worst_af = assert_same_up_to_knife_edges(gpu, cpu, allowed_diverged=0)
+    n = gpu[0]["n_calls"]
+    note_cohort(seed, dict(calls=n, columns=(n * gpu[0]["pl"].shape[1] if n else 0), differing_columns=cols, touched_calls=calls,
+                           diverged_calls=div, touched_lr=list(LAST_TOUCHED_LR), worst_af=worst_af))
+    if calls or div:
+        print("seed %d: %d of %d calls touched by a knife-edge shift, %d sample column(s) differ, %d diverged; worst dLR %.3g, "
+              "dAF %.3g" % (seed, calls, n, cols, div, worst_lr, worst_af))
+
+
+# The worst cohorts of every sweep so far, against the SHIPPED library: 155 and 887 hold the two diverged calls seen in
+# ~190,000 (length / position differ after an EM that oscillates up to the iteration cap); 533 and 1003 a call with more than a
+# third of its sample columns touched (same length, position, genotypes); 632, 483, 620 the largest LR differences on calls
+# that are otherwise the same (3.4e-4, 1.3e-4, 3.2e-5 relative); 693 and 515 the largest AF differences (7.0e-5, 5.5e-5); 132 a
+# long oscillating EM. What the shipped library does on them is pinned, call by call, in tests/golden/residual_<seed>.json
+# (tools/make_residual_goldens.py; tests/residual.py says what a record holds and which invariants hold regardless).
+RESIDUAL_SEEDS = [132, 155, 483, 515, 533, 620, 632, 693, 887, 1003]
+
+
+@pytest.mark.parametrize("seed", RESIDUAL_SEEDS)
+def test_pinned_residual(built, seed):
+    """The shipped library's known parity residual, asserted EXACTLY: which calls differ from the oracle's, whether they
+    diverged, in how many sample columns, by how much in LR and AF. A change that makes the residual larger fails here; one
+    that makes it smaller fails too and asks for the expectation to be re-generated and read. Every difference must coincide
+    with a counted near-integer shift quotient in that call's own EM (asserted inside residual_record)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from residual import compare_records, residual_record, summary
+    seg, rgs, offs, opts = random_case(seed)
+    gpu, cpu = both(seg, rgs, offs, **opts)
+    got = residual_record(seed, gpu, cpu)
+    with open(os.path.join(GOLDEN, "residual_%d.json" % seed)) as fh:
+        want = json.load(fh)
+    problems = compare_records(got, want)
+    assert not problems, problems
+    from conftest import FUZZ_NOTES
+    os.makedirs(FUZZ_NOTES, exist_ok=True)
+    with open(os.path.join(FUZZ_NOTES, "parity_notes.txt"), "a") as fh:
+        fh.write("pinned residual, seed %(seed)d: %(calls)d calls, %(touched_calls)d touched, %(diverged_calls)d diverged, %(differing_columns)d "
+                 "columns, worst dLR %(worst_dlr).3g, dAF %(worst_daf).3g, largest share of a call's columns %(worst_column_share).2f\n"
+                 % summary(got))
+
+
+SNAPPED_SEEDS = list(range(64)) + [132, 155, 483]
 
 
 @pytest.mark.parametrize("seed", UNSNAPPED_SEEDS)
@@ -158,7 +208,7 @@ def test_random_cohort(built, seed):
               "dAF %.3g" % (seed, calls, n, cols, div, worst_lr, worst_af))
 
 
-SNAPPED_SEEDS = list(range(16, 64)) + [132, 155, 483, 533, 887, 1003]      # (533, 1003: round 4's sweeps -- one call with a third of its columns touched; 887: a diverged call)
+SNAPPED_SEEDS = list(range(16, 64)) + RESIDUAL_SEEDS       # every pinned-residual cohort is EXACT once the knife edge is out
 
 
 @pytest.mark.parametrize("seed", SNAPPED_SEEDS)
@@ -192,7 +242,7 @@ def test_the_sweep_is_not_vacuous(built):
 
 
 def test_session_budgets(built):
-    """The budgets over the cohorts THIS session has noted so far (one process: all 67, this test runs last in the file). Under
+    """The budgets over the cohorts THIS session has noted so far (one process: all 64, this test runs last in the file). Under
     xdist or a partial selection fewer may be there: then the check is left to conftest.pytest_sessionfinish, which sees the
     notes of all workers and fails the session the same way (and never skips once the whole sweep has run)."""
     from conftest import check_fuzz_budgets, fuzz_session_figures
