@@ -365,7 +365,7 @@ int pd_stage1_last(pd_ctx *ctx, pd_stage1_view *out);
  * pair (genotype_deletion_popdel_call.h:205-215, 290-300). */
 int pd_log_table_view(pd_ctx *ctx, uint32_t rg, double *value, double *log_value, double *log10_value, uint32_t *n);
 
-/* ---- gunzip of profile blocks on the device (prototype, ABI 11) ----------------------------------------------------------
+/* ---- gunzip of profile blocks on the device (ABI 11) ---------------------------------------------------------------------
  * A profile holds one gzip member per 10,000-bp index region (the writer ends a member per region, reference
  * workflow_popdel.h:201-241; the reader jumps to one through the index, insert_histogram_popdel.h:531-562, and inflates it
  * with zlib, seqan/stream/iostream_zip_impl.h:336-349). The members of a segment are independent: pd_inflate_members()
@@ -375,7 +375,9 @@ int pd_log_table_view(pd_ctx *ctx, uint32_t rg, double *value, double *log_value
  * block header, 4 bad code set, 5 distance before the start, 6 more output than room, 7 CRC-32 mismatch, 8 ISIZE mismatch --
  * the cases zlib's inflate refuses); out_lengths[m]: bytes produced. All pointers are host memory. The kernel is launched
  * `repeat` times (>= 1) and `timing` reports its mean duration next to the two copies. Returns 0, or non-zero with
- * pd_inflate_last_error() saying why. Not wired into `popdel call` (DESIGN.md says what the number decided). */
+ * pd_inflate_last_error() saying why (the message of the calling thread's last failed call). This one-shot form serves the
+ * bench and the tests; `popdel call` inflates through the persistent pd_inflater objects below (call_driver.cpp,
+ * GunzipPrefetch: a chunk of samples' members per call, three inflaters in turn). */
 typedef struct pd_inflate_timing
 {
     double   h2d_ms;        /* compressed bytes, page-locked host memory -> HBM */
@@ -397,6 +399,7 @@ const char *pd_inflate_last_error(void);
  * is used from one thread at a time. pd_inflater_create() returns NULL if the backend has no device (the oracle). */
 typedef struct pd_inflater pd_inflater;
 pd_inflater *pd_inflater_create(int device);
+const char *pd_inflater_last_error(pd_inflater *inflater);     /* why this inflater's last run failed (ABI 12) */
 void pd_inflater_destroy(pd_inflater *inflater);
 uint8_t *pd_inflater_input(pd_inflater *inflater, uint64_t bytes);
 int pd_inflater_run(pd_inflater *inflater, const uint64_t *member_offsets, uint32_t n_members, const uint64_t *out_offsets,

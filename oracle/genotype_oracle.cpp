@@ -1099,6 +1099,7 @@ int pd_inflate_members(int, const uint8_t *, const uint64_t *, uint32_t, uint8_t
                        pd_inflate_timing *) { return 1; }
 const char * pd_inflate_last_error(void) { return "the oracle backend has no device"; }
 pd_inflater * pd_inflater_create(int) { return nullptr; }
+const char * pd_inflater_last_error(pd_inflater *) { return "the oracle backend has no device"; }
 void pd_inflater_destroy(pd_inflater *) {}
 uint8_t * pd_inflater_input(pd_inflater *, uint64_t) { return nullptr; }
 int pd_inflater_run(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *, const uint8_t **, const uint32_t **, const uint64_t **, double *) { return 1; }

@@ -230,7 +230,8 @@ struct Fail
             throw Fail{std::string(#expr) + ": " + hipGetErrorString(e_)};                                    \
     } while (0)
 
-std::string g_inflateError;
+// (per calling thread: several inflaters run on threads of their own, each reads the message of ITS last failed call)
+thread_local std::string g_inflateError;
 
 }  // namespace
 
@@ -241,6 +242,7 @@ struct pd_inflater
 {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t timeBegin = nullptr, timeEnd = nullptr;   // around the kernels when the caller asks for kernel_ms (created on first use)
     hipEvent_t finished = nullptr;      // blocking-sync event: the calling thread sleeps instead of spinning on the stream (the host's
                                         // cores are what `popdel call` is short of)
     unsigned groups = 0;
@@ -325,8 +327,9 @@ extern "C" void pd_inflater_destroy(pd_inflater * f)
     for (void * p : {f->hIn, f->hOut, f->hMeta, f->hOffsets, f->hFlags, f->hRaws, f->hWins, f->hWinCounts, f->hRecs})
         if (p)
             pd::pinnedFree(p);
-    if (f->finished)
-        (void)hipEventDestroy(f->finished);
+    for (hipEvent_t e : {f->finished, f->timeBegin, f->timeEnd})
+        if (e)
+            (void)hipEventDestroy(e);
     if (f->stream)
         (void)hipStreamDestroy(f->stream);
     delete f;
@@ -383,8 +386,12 @@ static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (kernel_ms)
         {
-            PD_INF_HIP(hipEventCreate(&e0));
-            PD_INF_HIP(hipEventCreate(&e1));
+            if (!f->timeBegin)
+                PD_INF_HIP(hipEventCreate(&f->timeBegin));
+            if (!f->timeEnd)
+                PD_INF_HIP(hipEventCreate(&f->timeEnd));
+            e0 = f->timeBegin;
+            e1 = f->timeEnd;
         }
         PD_INF_HIP(hipMemcpyAsync(f->dInOff, member_offsets, (n_members + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         PD_INF_HIP(hipMemcpyAsync(f->dOutOff, out_offsets, (n_members + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
@@ -475,8 +482,6 @@ static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_
             float ms = 0;
             PD_INF_HIP(hipEventElapsedTime(&ms, e0, e1));
             *kernel_ms = ms;
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
         }
         *out = static_cast<const uint8_t *>(f->hOut);
         *status = hStatus;
@@ -507,6 +512,7 @@ extern "C" int pd_inflater_run_parsed(pd_inflater * f, const uint64_t * member_o
 }
 
 extern "C" const char * pd_inflate_last_error(void) { return g_inflateError.c_str(); }
+extern "C" const char * pd_inflater_last_error(pd_inflater * f) { return f ? f->error.c_str() : "pd_inflater_last_error: no inflater"; }
 
 extern "C" int pd_inflate_members(int device, const uint8_t * data, const uint64_t * member_offsets, uint32_t n_members, uint8_t * out,
                                   const uint64_t * out_offsets, uint32_t * status, uint64_t * out_lengths, uint32_t repeat,

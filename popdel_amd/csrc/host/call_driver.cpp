@@ -14,6 +14,7 @@
 #include <deque>
 #include <memory>
 #include <sys/resource.h>
+#include <sys/syscall.h>
 #include <thread>
 #include <unordered_map>
 
@@ -932,9 +933,7 @@ private:
 
 void CallRun::createBackend()
 {
-    // (one segment is in flight here at a time -- the device works a per cent of a host round -- so the context's lanes would
-    // only cost their set-up: one lane unless the user asks)
-    setenv("POPDEL_HIP_LANES", "1", 0);
+    // (POPDEL_HIP_LANES: set by runPopdelCall() before any thread exists)
     std::vector<pd_readgroup> rgs(p_.histograms.size());
     for (size_t i = 0; i < rgs.size(); ++i)
     {
@@ -2348,13 +2347,74 @@ bool CallRun::finalizeRoi()
 
 // The host side of a device lives on the device's NUMA node: the process is bound to that node's CPUs before any thread is
 // started (page-locked buffers, tables and staging copies then sit next to the GPU's PCIe root; on the two-socket GPU boxes an
-// unbound run lands on either socket from run to run). Which node: the k-th GPU of the KFD topology the job may see ->
-// its PCI address -> sysfs. Anything unexpected leaves the process as it is. POPDEL_NO_NUMA_BIND=1 switches it off.
+// unbound run lands on either socket from run to run). Which node: HIP device k -> the GPU of the KFD topology it is (the k-th
+// the job may see, re-dealt by ROCR_VISIBLE_DEVICES and HIP_/CUDA_VISIBLE_DEVICES when they are lists of ordinals; a list of
+// UUIDs cannot be resolved without starting the runtime, and then nothing is bound) -> its PCI address -> sysfs. The CPU mask
+// is narrowed only if the node's share of it still holds as many CPUs as the job may use (affinity and CFS quota,
+// usableCpus()): a cpuset that spans both sockets with few CPUs on each keeps them all and only PREFERS the node's memory.
+// Anything unexpected leaves the process as it is. POPDEL_NO_NUMA_BIND=1 switches it off.
+#ifdef __linux__
+static bool ordinalList(const char * text, std::vector<int> & out)
+{
+    out.clear();
+    for (const char * p = text; *p;)
+    {
+        char * end = nullptr;
+        const long v = strtol(p, &end, 10);
+        if (end == p || v < 0 || (*end != ',' && *end != 0))
+            return false;                    // ("GPU-<uuid>" and anything else that is not a plain ordinal)
+        out.push_back(static_cast<int>(v));
+        p = *end ? end + 1 : end;
+    }
+    return true;
+}
+
+// The ordinal among the KFD GPUs this job can see that the runtime will call HIP device `device`; -1: cannot be told.
+static int kfdOrdinalOfHipDevice(int device)
+{
+    std::vector<int> rocr, hip;
+    bool haveRocr = false, haveHip = false;
+    if (const char * e = getenv("ROCR_VISIBLE_DEVICES"))
+    {
+        if (!ordinalList(e, rocr))
+            return -1;
+        haveRocr = true;
+    }
+    const char * h = getenv("HIP_VISIBLE_DEVICES");
+    if (!h)
+        h = getenv("CUDA_VISIBLE_DEVICES");
+    if (h)
+    {
+        if (!ordinalList(h, hip))
+            return -1;
+        haveHip = true;
+    }
+    int k = device;
+    if (haveHip)
+    {
+        if (k >= static_cast<int>(hip.size()))
+            return -1;
+        k = hip[static_cast<size_t>(k)];
+    }
+    if (haveRocr)
+    {
+        if (k >= static_cast<int>(rocr.size()))
+            return -1;
+        k = rocr[static_cast<size_t>(k)];
+    }
+    return k;
+}
+#endif
+
 static int bindToDeviceNode(int device)
 {
 #ifdef __linux__
     if (getenv("POPDEL_NO_NUMA_BIND") || device < 0)
         return -1;
+    device = kfdOrdinalOfHipDevice(device);
+    if (device < 0)
+        return -1;
+    const unsigned mayUse = usableCpus();
     int seen = 0;
     for (int node = 0; node < 64; ++node)
     {
@@ -2403,7 +2463,20 @@ static int bindToDeviceNode(int device)
                     CPU_SET(c, &want);
             i = j + 1;
         }
-        if (CPU_COUNT(&want) == 0 || sched_setaffinity(0, sizeof(want), &want) != 0)
+        if (CPU_COUNT(&want) == 0)
+            return -1;
+        if (static_cast<unsigned>(CPU_COUNT(&want)) < mayUse && CPU_COUNT(&want) < CPU_COUNT(&now))
+        {
+            // narrowing would cost CPUs the job has been granted: keep them, prefer the node's memory
+            unsigned long mask[16] = {0};
+            if (numa < static_cast<int>(sizeof(mask) * 8))
+            {
+                mask[numa / (8 * sizeof(unsigned long))] |= 1ul << (numa % (8 * sizeof(unsigned long)));
+                (void)syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, sizeof(mask) * 8);
+            }
+            return numa;
+        }
+        if (sched_setaffinity(0, sizeof(want), &want) != 0)
             return -1;
         return numa;
     }
@@ -2525,7 +2598,11 @@ int CallRun::run()
         startGunzipPrefetch();
         // (large batches: 16 threads replayed 1000 samples in 0.57 s with batches of 128 and in 0.22 s with 512)
         // (wider batches, 1024 and 2048 samples, were measured no faster with the blocks parsed on the device: 0.085-0.098 against 0.088-0.091 s per round)
-        const unsigned batch = std::max(512u, 8u * hostThreads());
+        // (never wider than the first two chunks of the device gunzip: an inflater's buffers are recycled once the replay has
+        // passed the chunk three before it, and the replay releases a batch as a whole -- a batch that spanned four chunks would
+        // wait for a chunk whose buffers it holds itself)
+        const unsigned batch = std::min<unsigned>(std::max(512u, 8u * hostThreads()),
+                                                  static_cast<unsigned>(GunzipPrefetch::kFirstChunk + GunzipPrefetch::kChunk));
         for (unsigned b0 = 0; b0 < p_.sampleNum; b0 += batch)
         {
             const unsigned b1 = std::min(p_.sampleNum, b0 + batch);
@@ -2684,6 +2761,10 @@ int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer, bool
         }
         // (threads that wait for the device sleep instead of spinning: the rounds are bound by the job's CPU time)
         setenv("POPDEL_HIP_BLOCKING_SYNC", "1", 0);
+        // (one segment is in flight here at a time -- the device works a per cent of a host round -- so the context's lanes would
+        // only cost their set-up: one lane unless the user asks. Here, not in createBackend(): that runs on a thread of its own
+        // while the main thread reads the environment every round)
+        setenv("POPDEL_HIP_LANES", "1", 0);
         if (!getenv("POPDEL_CPU_PROFILE_FROM_ROUND"))
             CpuSampler::start();
         gTrace.mark("command line parsed");
