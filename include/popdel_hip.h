@@ -136,6 +136,16 @@ typedef struct pd_stage1_view
 
 typedef struct pd_ctx pd_ctx;
 
+/* pd_stage1_last() needs the Q3 of EVERY cell; since ABI 12 the HIP backend screens the windows first (counts, per cell, the
+ * active pairs whose deviation exceeds the smallest threshold -- which decides whether the window can carry a candidate at
+ * all) and takes exact Q3 values only in the windows that may, so the values of the other windows do not exist unless
+ * asked for: pd_ctx_stage1_view(ctx, 1), before a segment is run, makes the context ALSO run the full scan (exact Q3 of
+ * every cell, the round-1..4 kernel) for that purpose. pd_stage1_last() then returns the full scan's values after checking
+ * them against the product path cell by cell (flags everywhere; every window with a Q3 above the threshold flagged by the
+ * screen; the exact pass's Q3 equal in every flagged window) and fails if they disagree. Diagnostics and parity tests only;
+ * costs a second scan per segment. The oracle computes every cell anyway (the call is accepted and changes nothing). */
+int pd_ctx_stage1_view(pd_ctx *ctx, int on);
+
 /* Create a calling context on GPU `device`.
  * sample_rg_offsets has n_samples + 1 entries; sample s owns read groups
  * [sample_rg_offsets[s], sample_rg_offsets[s+1]) (reference TRGs, utils_popdel.h:21-22; read groups

@@ -1098,6 +1098,7 @@ int pd_device_warmup(int) { return 0; }
 int pd_inflate_members(int, const uint8_t *, const uint64_t *, uint32_t, uint8_t *, const uint64_t *, uint32_t *, uint64_t *, uint32_t,
                        pd_inflate_timing *) { return 1; }
 const char * pd_inflate_last_error(void) { return "the oracle backend has no device"; }
+int pd_ctx_stage1_view(pd_ctx * c, int) { return c ? 0 : 1; }
 pd_inflater * pd_inflater_create(int) { return nullptr; }
 const char * pd_inflater_last_error(pd_inflater *) { return "the oracle backend has no device"; }
 void pd_inflater_destroy(pd_inflater *) {}

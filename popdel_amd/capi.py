@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "pd_ctx_keep_results_on_device", "pd_calls_merge", "pd_calls_fetch_columns", "pd_merged_free",
     "pd_walk_submit", "pd_walk_supported", "pd_walk_active", "pd_device_warmup", "pd_inflate_members", "pd_inflate_last_error",
     "pd_inflater_create", "pd_inflater_destroy", "pd_inflater_input", "pd_inflater_run", "pd_inflater_run_parsed", "pd_ctx_set_shard_lanes",
-    "pd_inflater_last_error",
+    "pd_inflater_last_error", "pd_ctx_stage1_view",
 )
 RCCL_ID_BYTES = 128
 
@@ -248,7 +248,9 @@ class Context:
     """A calling context (pd_ctx) on one device."""
 
     def __init__(self, lib, readgroups, sample_rg_offsets, iterations=15, min_len=200, min_likelihood_ratio=12.527629,
-                 min_sample_fraction=0.1, somatic=False, window_wise_output=False, device=0):
+                 min_sample_fraction=0.1, somatic=False, window_wise_output=False, device=0, stage1_view=False):
+        """stage1_view: keep every cell's Q3 for stage1() (pd_ctx_stage1_view: the HIP backend otherwise takes exact Q3 values in
+        the flagged windows only; diagnostics and parity tests)."""
         self.lib = lib
         self._keep = []
         n = len(readgroups)
@@ -277,6 +279,8 @@ class Context:
         if rc != 0:
             raise BackendError(lib.pd_last_error(None).decode())
         self.handle = handle
+        if stage1_view:
+            self._check(lib.pd_ctx_stage1_view(handle, 1))
 
     def close(self):
         if self.handle:

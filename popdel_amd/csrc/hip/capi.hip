@@ -34,6 +34,13 @@ void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, 
                   hipStream_t stream);
 void launchStage1Fallback(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
                           uint8_t * tileTodo, unsigned * todoList, const unsigned * bigList, hipStream_t stream);
+void launchScreen(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag, uint8_t * tileTodo,
+                  unsigned * todoList, hipStream_t stream);
+void launchScreenFallback(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
+                          const unsigned * todoList, hipStream_t stream);
+void launchExactFlagged(const SegmentView & seg, const CohortView & co, const int * flagged, unsigned nFlagged,
+                        const unsigned * nFlaggedDev, const int * ownWinFlag, const uint8_t * tileTodo, int32_t * q3, uint8_t * flags,
+                        int * winFlag, unsigned * rest, hipStream_t stream);
 void launchPackFlagged(const int32_t * q3, const uint8_t * flags, const int * flaggedWindows, unsigned W, unsigned nLocal,
                        const ClusterInput & in, unsigned rank, hipStream_t st);
 void launchZero(const ZeroRanges & r, hipStream_t st);
@@ -272,6 +279,14 @@ struct Stage1Out
     DevBuf<uint8_t> tileTodo;
     DevBuf<unsigned> todoList;      // [0] = number of entries, then the 256-window tiles left to the fallback kernel
     DevBuf<unsigned> bigList;       // [0] = number of entries, then the 512-window blocks left to the 128-candidate kernel
+    DevBuf<unsigned> exactRest;     // screen mode: [0] = number of entries, then the (flagged window, 64-sample wave tile) units left
+                                    // to the 128-candidate networks of the exact pass
+    bool screened = false;          // q3 holds exact values in the flagged windows only (screen + exact pass), else everywhere
+    // pd_ctx_stage1_view(): the full scan's outputs beside the screen's, for pd_stage1_last()
+    DevBuf<int32_t> fullQ3;
+    DevBuf<uint8_t> fullFlags;
+    DevBuf<int> fullWinFlag;
+    bool fullValid = false;
     uint32_t windows = 0;
 };
 
@@ -402,6 +417,10 @@ struct pd_ctx
     PinnedBuf<unsigned> hCounters, hIterFlag, hCandHdr;
     DevBuf<unsigned> dCandHdr;            // flagged-window count, cell count, cell list (listCellsKernel)
     bool deviceLists = true;              // POPDEL_HIP_HOST_LISTS=1: the host forms the flagged-window and cell lists
+    // Stage 1 as a SCREEN (stage1.hip): count the pairs beyond the smallest threshold per cell, take exact Q3 values in the
+    // flagged windows only. POPDEL_HIP_SCAN=full: the round-1..4 scan (exact Q3 of every cell).
+    bool screenScan = true;
+    bool stage1View = false;              // pd_ctx_stage1_view(): keep the full scan's Q3 of every cell for pd_stage1_last()
     // stage 2 launched without waiting for the pool sizes (see pd_segment_collect); POPDEL_HIP_EXACT_POOLS=1 turns it off
     bool optimisticPools = true;
     size_t stage2Budget = static_cast<size_t>(24) << 30;    // bytes of per-(cell, sample) buffers per stage-2 batch (POPDEL_HIP_STAGE2_BYTES)
@@ -1587,6 +1606,8 @@ static int createContext(const pd_config * cfg, const pd_readgroup * rgs, uint32
             c->optimisticPools = atoi(e) == 0;
         if (const char * e = getenv("POPDEL_HIP_HOST_LISTS"))
             c->deviceLists = atoi(e) == 0;
+        if (const char * e = getenv("POPDEL_HIP_SCAN"))
+            c->screenScan = std::strcmp(e, "full") != 0;
         if (const char * e = getenv("POPDEL_HIP_PLAIN_UPLOAD"))
             c->compactUpload = atoi(e) == 0;
         if (const char * e = getenv("POPDEL_HIP_STAGE2_BYTES"))
@@ -2154,12 +2175,44 @@ static void launchScan(pd_ctx * c, Run & run)
         zero.add(room.counter, sizeof(unsigned));
     }
     pd::launchZero(zero, st);
-    PD_HIP(hipEventRecord(run.s1Begin, st));
-    pd::launchStage1(viewOf(s), c->cohort, o.q3.p, o.flags.p, o.winFlag.p, o.tileTodo.p, o.todoList.p, o.bigList.p, s.maxBlockChunks, room, st);
-    PD_HIP(hipGetLastError());
-    PD_HIP(hipEventRecord(run.s1End, st));
-    pd::launchStage1Fallback(viewOf(s), c->cohort, o.q3.p, o.flags.p, o.winFlag.p, o.tileTodo.p, o.todoList.p, o.bigList.p, st);
-    PD_HIP(hipGetLastError());
+    o.screened = c->screenScan;
+    o.fullValid = false;
+    if (c->screenScan)
+    {
+        if (c->stage1View)
+        {
+            // the diagnostic view: the full scan's Q3 / flags / window flags of every cell beside the screen's outputs (the todo and
+            // big lists are shared: the full scan runs first and leaves them as it found them for the screen -- re-zeroed below)
+            o.fullQ3.ensure(cells);
+            o.fullFlags.ensure(cells);
+            o.fullWinFlag.ensure(s.nWindows);
+            PD_HIP(hipMemsetAsync(o.fullWinFlag.p, 0, s.nWindows * sizeof(int), st));
+            pd::launchStage1(viewOf(s), c->cohort, o.fullQ3.p, o.fullFlags.p, o.fullWinFlag.p, o.tileTodo.p, o.todoList.p, o.bigList.p, s.maxBlockChunks,
+                             room, st);
+            pd::launchStage1Fallback(viewOf(s), c->cohort, o.fullQ3.p, o.fullFlags.p, o.fullWinFlag.p, o.tileTodo.p, o.todoList.p, o.bigList.p, st);
+            PD_HIP(hipGetLastError());
+            pd::ZeroRanges again{};
+            again.add(o.todoList.p, sizeof(unsigned));
+            again.add(o.bigList.p, sizeof(unsigned));
+            pd::launchZero(again, st);
+            o.fullValid = true;
+        }
+        PD_HIP(hipEventRecord(run.s1Begin, st));
+        pd::launchScreen(viewOf(s), c->cohort, o.q3.p, o.flags.p, o.winFlag.p, o.tileTodo.p, o.todoList.p, st);
+        PD_HIP(hipGetLastError());
+        PD_HIP(hipEventRecord(run.s1End, st));
+        pd::launchScreenFallback(viewOf(s), c->cohort, o.q3.p, o.flags.p, o.winFlag.p, o.todoList.p, st);
+        PD_HIP(hipGetLastError());
+    }
+    else
+    {
+        PD_HIP(hipEventRecord(run.s1Begin, st));
+        pd::launchStage1(viewOf(s), c->cohort, o.q3.p, o.flags.p, o.winFlag.p, o.tileTodo.p, o.todoList.p, o.bigList.p, s.maxBlockChunks, room, st);
+        PD_HIP(hipGetLastError());
+        PD_HIP(hipEventRecord(run.s1End, st));
+        pd::launchStage1Fallback(viewOf(s), c->cohort, o.q3.p, o.flags.p, o.winFlag.p, o.tileTodo.p, o.todoList.p, o.bigList.p, st);
+        PD_HIP(hipGetLastError());
+    }
     if (getenv("POPDEL_HIP_DEBUG"))
     {
         std::vector<uint8_t> todo(tiles);
@@ -2730,6 +2783,14 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
                 in.nFlaggedDev = c->dCandHdr.p;
                 in.minInit = c->dMinInitGlobal.p;
                 pd::launchCompactFlagged(flagRows, W, world, flagBytes / sizeof(int), capF, c->dFlagged.p, c->dCandHdr.p, c->stream);
+                if (o.screened)
+                {
+                    // the screen knows WHICH windows may carry a candidate; their exact Q3 values, all samples, now
+                    o.exactRest.ensure(1 + static_cast<size_t>(capF) * ((S + 63) / 64));
+                    PD_HIP(hipMemsetAsync(o.exactRest.p, 0, sizeof(unsigned), c->stream));
+                    pd::launchExactFlagged(view, c->cohort, c->dFlagged.p, capF, c->dCandHdr.p, o.winFlag.p, o.tileTodo.p, o.q3.p, o.flags.p,
+                                           o.winFlag.p, o.exactRest.p, c->stream);
+                }
                 pd::launchPackFlagged(o.q3.p, o.flags.p, c->dFlagged.p, W, S, in, c->rank, c->stream);
                 PD_HIP(hipGetLastError());
                 xch.allGather(const_cast<uint8_t *>(in.base), in.chunkBytes);
@@ -2808,6 +2869,16 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
                 in.nFlagged = (unsigned)flagged.size();
                 in.nFlaggedDev = nullptr;
                 in.minInit = c->dMinInitGlobal.p;
+                if (o.screened)
+                {
+                    o.exactRest.ensure(1 + std::min<size_t>(32768, flagged.size()) * ((S + 63) / 64));
+                    for (size_t f0 = 0; f0 < flagged.size(); f0 += 32768)       // (a grid's y dimension holds 65,535)
+                    {
+                        PD_HIP(hipMemsetAsync(o.exactRest.p, 0, sizeof(unsigned), c->stream));
+                        pd::launchExactFlagged(view, c->cohort, c->dFlagged.p + f0, (unsigned)std::min<size_t>(32768, flagged.size() - f0), nullptr,
+                                               o.winFlag.p, o.tileTodo.p, o.q3.p, o.flags.p, o.winFlag.p, o.exactRest.p, c->stream);
+                    }
+                }
                 pd::launchPackFlagged(o.q3.p, o.flags.p, c->dFlagged.p, W, S, in, c->rank, c->stream);
                 PD_HIP(hipGetLastError());
                 xch.allGather(c->arena, in.chunkBytes);
@@ -3285,10 +3356,41 @@ int pd_stage1_last(pd_ctx * c, pd_stage1_view * out)
         std::vector<int32_t> q(cells);
         std::vector<uint8_t> f(cells);
         PD_HIP(hipStreamSynchronize(c->stream));
+        if (o.screened && !o.fullValid)
+            return fail(c, "pd_stage1_last: this context screens the windows and takes exact Q3 values in the flagged ones only; call "
+                           "pd_ctx_stage1_view(ctx, 1) before the segment is run (or set POPDEL_HIP_SCAN=full) to have every cell's value");
         if (cells)
         {
-            PD_HIP(hipMemcpy(q.data(), o.q3.p, cells * sizeof(int32_t), hipMemcpyDeviceToHost));
-            PD_HIP(hipMemcpy(f.data(), o.flags.p, cells, hipMemcpyDeviceToHost));
+            PD_HIP(hipMemcpy(q.data(), o.screened ? o.fullQ3.p : o.q3.p, cells * sizeof(int32_t), hipMemcpyDeviceToHost));
+            PD_HIP(hipMemcpy(f.data(), o.screened ? o.fullFlags.p : o.flags.p, cells, hipMemcpyDeviceToHost));
+        }
+        if (o.screened && cells)
+        {
+            // The view doubles as the check of the screen against the full scan, cell by cell: the flags agree everywhere; every
+            // window in which the full scan saw a Q3 above the smallest threshold was flagged by the screen; and in every window
+            // the screen flagged the exact pass left the full scan's Q3 for every sample. (In a sharded cohort the exact pass also
+            // covers the windows other contexts flagged; the check looks at this context's own flags.)
+            std::vector<int32_t> q2(cells);
+            std::vector<uint8_t> f2(cells);
+            std::vector<int> wf(W), wfFull(W);
+            PD_HIP(hipMemcpy(q2.data(), o.q3.p, cells * sizeof(int32_t), hipMemcpyDeviceToHost));
+            PD_HIP(hipMemcpy(f2.data(), o.flags.p, cells, hipMemcpyDeviceToHost));
+            PD_HIP(hipMemcpy(wf.data(), o.winFlag.p, W * sizeof(int), hipMemcpyDeviceToHost));
+            PD_HIP(hipMemcpy(wfFull.data(), o.fullWinFlag.p, W * sizeof(int), hipMemcpyDeviceToHost));
+            if (f != f2)
+                return fail(c, "pd_stage1_last: the screen's cell flags differ from the full scan's");
+            for (uint32_t w = 0; w < W; ++w)
+            {
+                if (wfFull[w] && !wf[w])
+                    return fail(c, "pd_stage1_last: window " + std::to_string(w) + " holds a Q3 above the threshold and was not flagged by the screen");
+                if (!wf[w])
+                    continue;
+                for (uint32_t smp = 0; smp < S; ++smp)
+                    if (q2[static_cast<size_t>(smp) * W + w] != q[static_cast<size_t>(smp) * W + w])
+                        return fail(c, "pd_stage1_last: window " + std::to_string(w) + ", sample " + std::to_string(smp) + ": the exact pass left Q3 " +
+                                           std::to_string(q2[static_cast<size_t>(smp) * W + w]) + ", the full scan " +
+                                           std::to_string(q[static_cast<size_t>(smp) * W + w]));
+            }
         }
         // device layout is [sample][window]; the view is [window][sample]
         c->hQ3View.resize(cells);
@@ -3351,6 +3453,17 @@ int pd_log_table_view(pd_ctx * c, uint32_t rg, double * value, double * logValue
     {
         return fail(c, "pd_log_table_view: unknown exception");
     }
+    return 0;
+}
+
+int pd_ctx_stage1_view(pd_ctx * c, int on)
+{
+    if (!c)
+        return 1;
+    c->stage1View = on != 0;
+    if (c->lanes)
+        for (auto & w : c->lanes->workers)
+            w->ctx->stage1View = on != 0;
     return 0;
 }
 

@@ -741,6 +741,281 @@ __global__ __launch_bounds__(kStage1Block) void stage1FallbackKernel(SegmentView
     }
 }
 
+// ---- the SCREEN (round 5): which windows can have a candidate at all, without taking a single order statistic --------
+// What stage 1 is for (reference initialize_deletion_lengths(), genotype_deletion_popdel_call.h:33-87): a window yields
+// candidate lengths only if some sample's Q3 exceeds a threshold, and every threshold is at least T = co.minThreshold.
+// Q3 interpolates the order statistics a = x(l0) <= b = x(l0 + 1) of the n active deviations with weights (4 - k, k) / 4:
+//     Q3 > T  <=  a > T  <=>  c >= n - l0          (c = number of active deviations > T)
+//     Q3 <= T <=  b <= T <=>  c <= n - l0 - 2      (k = 0 or n < 4: Q3 = a, the first line decides alone)
+// and in between (c == n - l0 - 1) the window is a MAYBE. So the scan only has to COUNT, per cell, the active pairs whose
+// deviation exceeds T -- and those are rare (T sits at several standard deviations): instead of every window looking at
+// its ~3 K candidate chunks (each chunk is looked at K times, 22 packed VALU operations per look with the selection
+// network), every CHUNK is looked at once -- one coalesced 16-byte load per two chunks straight from HBM, one compare --
+// and the few that exceed T add one to the LDS counters of the windows they are active in (slot found by bisection in the
+// block's window index). n(w) comes from the prefix counts as before. The kernel is bound by reading the chunk stream.
+// Windows flagged here (sure or maybe) get their exact Q3 -- for all samples, as the clustering needs them -- from
+// exactFlaggedKernel below, which runs the selection networks for those windows only; a maybe that turns out at or below T
+// stays in the flagged list and yields no candidate (every cluster threshold is >= T), exactly like a window whose Q3
+// values exceed T but not their cluster's threshold. flags[] are written for every cell (they follow from n alone).
+// Blocks the screen cannot take (deviations beyond 16 bits, a multi-read-group sample with a read group at its maxLoad,
+// K > 64) go to stage1FallbackKernel through the same list as before, which leaves exact Q3, flags and window flags.
+__device__ __forceinline__ bool screenMaybe(unsigned n, unsigned c)
+{
+    // n >= 2, n < maxLoad
+    if (n < 4u)
+        return c >= 1u;                                 // Q3 is the largest value
+    const unsigned pos4 = 3u * n + 2u + (n & 1u) - 4u;
+    const unsigned l0 = pos4 >> 2, k = pos4 & 3u;
+    const unsigned need = n - l0;                       // c >= need: a > T
+    return k == 0u ? c >= need : c + 1u >= need;        // c == need - 1: only b > T, decided by the exact pass
+}
+
+// A workgroup takes kScreenBlocks adjacent 512-window blocks of one sample (1,024 windows, ~3,200 chunks = 26 KB of
+// stream): every global load it needs -- the window index into LDS, the end counts, the chunks themselves (eight 16-byte
+// loads per lane, held in registers) -- is issued before its first barrier, so that a CU's eight resident workgroups keep
+// ~200 KB in flight. Lane t owns the windows t, t + 256, ... of the workgroup (byte stores of a wave are contiguous).
+constexpr int kScreenBlocks = 2;
+constexpr int kScreenWindows = kScreenBlocks * kPackedWindows;
+constexpr int kScreenPre = 8;                     // chunk loads per lane issued ahead of the barrier (2 chunks each)
+
+__global__ __launch_bounds__(kStage1Block) void screenKernel(SegmentView seg, CohortView co, uint8_t * __restrict__ flags,
+                                                             int * __restrict__ winFlag, uint8_t * __restrict__ tileTodo,
+                                                             unsigned * __restrict__ todoList, unsigned tilesPerSample,
+                                                             unsigned blocksPerSample)
+{
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    __shared__ uint32_t ldsWs[kScreenWindows + 64 + 2];
+    __shared__ unsigned ldsCnt[kScreenWindows];
+    const unsigned s = blockIdx.y, bx0 = blockIdx.x * kScreenBlocks;
+    const unsigned w0 = bx0 * kPackedWindows;
+    const unsigned W = seg.nWindows;
+    const unsigned K = seg.maxLifePk;
+    const unsigned tid = threadIdx.x;
+    const unsigned rg0 = seg.scanRg[s];
+    bool take = K <= 64u && seg.rgPacked[rg0];                                   // workgroup-uniform
+    if (rg0 >= seg.nRealRg)
+        for (unsigned k = 0; k < (unsigned)kScreenBlocks && bx0 + k < blocksPerSample; ++k)
+            take = take && seg.scanGeneric[(size_t)(rg0 - seg.nRealRg) * blocksPerSample + bx0 + k] == 0;
+    for (unsigned k = 0; k < (unsigned)kScreenBlocks && bx0 + k < blocksPerSample; ++k)
+        deferToFallback(s, bx0 + k, W, tilesPerSample, tileTodo, todoList, !take);
+    if (!take)
+        return;
+    const uint32_t * ws = seg.winStartPk + (size_t)rg0 * (W + K);
+    const unsigned whi = min(W, w0 + kScreenWindows);
+    const unsigned nWs = whi - w0 + K;
+    // (the stream's extent straight from HBM -- a uniform address, a scalar load -- so that the chunk loads do not wait for LDS)
+    const unsigned A0 = ws[w0];
+    const unsigned nPairs = ws[w0 + nWs - 1u] - A0;
+    const size_t g0 = seg.rgBasePk[rg0] + A0;
+    const unsigned mis = (unsigned)(g0 & 1u);
+    const unsigned nCopy = nPairs + mis;                                        // stream entries [A0 - mis, A0 + nPairs)
+    const v4u * src = reinterpret_cast<const v4u *>(seg.pairsPk + (g0 - mis));
+    const unsigned nLoads = (nCopy + 1u) >> 1;
+    v4u pre[kScreenPre];
+#pragma unroll
+    for (int k = 0; k < kScreenPre; ++k)
+    {
+        const unsigned i = tid + (unsigned)k * kStage1Block;
+        pre[k] = __builtin_nontemporal_load(src + min(i, nLoads ? nLoads - 1u : 0u));        // (clamped: the value is ignored)
+    }
+    for (unsigned i = tid; i < nWs; i += kStage1Block)
+        ldsWs[i] = ws[w0 + i];
+    const uint32_t * ec = seg.endCountPk + (size_t)rg0 * (W + 1);
+    unsigned ended[kScreenWindows / kStage1Block];
+#pragma unroll
+    for (int k = 0; k < kScreenWindows / kStage1Block; ++k)
+    {
+        const unsigned w = w0 + tid + (unsigned)k * kStage1Block;
+        ended[k] = w < W ? ec[w] : 0u;
+        ldsCnt[tid + (unsigned)k * kStage1Block] = 0u;
+    }
+    const int T = co.minThreshold;
+    __syncthreads();
+    // a chunk that exceeds T: one more active big pair in every window it is active in (slot x sees windows (x - K, x])
+    auto hit = [&](unsigned j, unsigned offoff) {
+        if (j < mis || j >= nCopy)
+            return;
+        const unsigned pos = A0 - mis + j;
+        unsigned lo = 0u, hi = nWs - 1u;                 // ldsWs[lo] <= pos < ldsWs[hi]
+        while (hi - lo > 1u)
+        {
+            const unsigned mid = (lo + hi) >> 1;
+            if (ldsWs[mid] <= pos)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const int slot = (int)(w0 + lo);
+        const int off = (int)(offoff & 0xffffu);
+        const int first = max((int)w0, slot - (int)K + 1);
+        const int last = min(min(slot, off - 1), (int)whi - 1);
+        for (int w = first; w <= last; ++w)
+            atomicAdd(&ldsCnt[w - (int)w0], 1u);
+    };
+    auto look = [&](unsigned i, const v4u & v) {
+        const int d0 = (int)(short)((v.x & 0xffffu) ^ 0x8000u), d1 = (int)(short)((v.z & 0xffffu) ^ 0x8000u);
+        if (d0 > T)
+            hit(2u * i, v.y);
+        if (d1 > T)
+            hit(2u * i + 1u, v.w);
+    };
+#pragma unroll
+    for (int k = 0; k < kScreenPre; ++k)
+    {
+        const unsigned i = tid + (unsigned)k * kStage1Block;
+        if (i < nLoads)
+            look(i, pre[k]);
+    }
+    for (unsigned i = tid + (unsigned)kScreenPre * kStage1Block; i < nLoads; i += kStage1Block)         // (deeper coverage)
+        look(i, __builtin_nontemporal_load(src + i));
+    __syncthreads();
+    const unsigned maxLoad = co.rg[rg0].maxLoad;
+#pragma unroll
+    for (int k = 0; k < kScreenWindows / kStage1Block; ++k)
+    {
+        const unsigned w = w0 + tid + (unsigned)k * kStage1Block;
+        if (w < W)
+        {
+            const unsigned n = ldsWs[w + K - w0] - ended[k];
+            const unsigned fl = n < 2u ? 1u : (n < maxLoad ? 2u : 0u);
+            flags[(size_t)s * W + w] = (uint8_t)fl;
+            if (fl == 2u && screenMaybe(n, ldsCnt[w - w0]))
+                winFlag[w] = 1;
+        }
+    }
+}
+
+// Exact Q3 of ALL samples in the flagged windows (what the clustering reads): one lane per sample takes the window PAIR
+// (w & ~1, w | 1) of a flagged window w straight from the chunk stream in HBM -- its candidates are one contiguous run
+// of ~3 K chunks -- into the register array of the scan's selection networks. flagged[] holds nFlagged (or *nFlaggedDev)
+// window numbers; an odd window whose even neighbour is flagged too is left to that one. Cells in blocks the screen
+// handed to the fallback kernel are exact already. Wave tiles with more than 64 candidates somewhere are appended to
+// `rest` (count in rest[0]) for exactFlaggedRestKernel.
+__device__ __forceinline__ bool exactLaneSetup(const SegmentView & seg, unsigned s, unsigned wA, unsigned tilesPerSample,
+                                               const uint8_t * tileTodo, unsigned & rg0, unsigned & xA, unsigned & cntA, unsigned & endB,
+                                               unsigned & nA, unsigned & nB)
+{
+    const unsigned W = seg.nWindows, K = seg.maxLifePk, wB = wA + 1u;
+    if (tileTodo[(size_t)s * tilesPerSample + wA / kStage1Block] != 0)
+        return false;                                   // the fallback kernel has done this tile
+    rg0 = seg.scanRg[s];
+    const uint32_t * ws = seg.winStartPk + (size_t)rg0 * (W + K);
+    const uint32_t * ec = seg.endCountPk + (size_t)rg0 * (W + 1);
+    xA = ws[wA];
+    const unsigned eA = ws[wA + K];
+    cntA = eA - xA;
+    nA = eA - ec[wA];
+    endB = 0u;
+    nB = 0u;
+    if (wB < W)
+    {
+        const unsigned eB = ws[wB + K];
+        endB = eB - xA;
+        nB = eB - ec[wB];
+    }
+    return true;
+}
+
+template <int C>
+__device__ __forceinline__ void exactPairStore(const SegmentView & seg, const CohortView & co, unsigned s, unsigned rg0, unsigned wA,
+                                               unsigned xA, unsigned cntA, unsigned endB, unsigned nA, unsigned nB,
+                                               int32_t * __restrict__ q3, uint8_t * __restrict__ flags, int * __restrict__ winFlag)
+{
+    const unsigned W = seg.nWindows, wB = wA + 1u;
+    const PairPk * stream = reinterpret_cast<const PairPk *>(seg.pairsPk + seg.rgBasePk[rg0]);
+    int vaA, vbA, vaB, vbB;
+    stage1PairFast<C>(stream, xA, wA | (wB << 16), cntA | (endB << 16), nA, nB, vaA, vbA, vaB, vbB);
+    const unsigned maxLoad = co.rg[rg0].maxLoad;
+    storeCell(nA, maxLoad, vaA, vbA, (size_t)s * W + wA, wA, co.minThreshold, q3, flags, winFlag);
+    if (wB < W)
+        storeCell(nB, maxLoad, vaB, vbB, (size_t)s * W + wB, wB, co.minThreshold, q3, flags, winFlag);
+}
+
+__global__ __launch_bounds__(256) void exactFlaggedKernel(SegmentView seg, CohortView co, const int * __restrict__ flagged,
+                                                          unsigned nFlagged, const unsigned * __restrict__ nFlaggedDev,
+                                                          const int * __restrict__ ownWinFlag, const uint8_t * __restrict__ tileTodo,
+                                                          unsigned tilesPerSample, int32_t * __restrict__ q3, uint8_t * __restrict__ flags,
+                                                          int * __restrict__ winFlag, unsigned * __restrict__ rest)
+{
+    const unsigned f = blockIdx.y;
+    const unsigned nF = nFlaggedDev ? min(*nFlaggedDev, nFlagged) : nFlagged;
+    if (f >= nF)
+        return;
+    const unsigned w = (unsigned)flagged[f];
+    if ((w & 1u) && ownWinFlag[w - 1u] != 0 && f != 0u && (unsigned)flagged[f - 1u] == w - 1u)
+        return;                                         // the even neighbour's lanes take the pair
+    const unsigned wA = w & ~1u;
+    const unsigned s = blockIdx.x * 256u + threadIdx.x;
+    unsigned rg0 = 0, xA = 0, cntA = 0, endB = 0, nA = 0, nB = 0;
+    const bool mine = s < co.nSamples && exactLaneSetup(seg, s, wA, tilesPerSample, tileTodo, rg0, xA, cntA, endB, nA, nB);
+    const unsigned cnt = mine ? max(cntA, endB) : 0u;
+    const unsigned cmax = waveMaxU32(cnt);
+    if (cmax > 64u)
+    {
+        if ((threadIdx.x & 63u) == 0u)
+            rest[1u + atomicAdd(&rest[0], 1u)] = f * ((co.nSamples + 63u) / 64u) + (s >> 6);
+        return;
+    }
+    if (!mine)
+        return;
+    if (cmax <= 32u)
+        exactPairStore<32>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
+    else if (cmax <= 40u)
+        exactPairStore<40>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
+    else if (cmax <= 48u)
+        exactPairStore<48>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
+    else if (cmax <= 56u)
+        exactPairStore<56>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
+    else
+        exactPairStore<64>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
+}
+
+// The wave tiles with 65 or more candidates in some lane (deeper coverage): networks of up to 128 inputs, and rank
+// counting from the 32-bit image for lanes beyond that.
+__global__ __launch_bounds__(64) void exactFlaggedRestKernel(SegmentView seg, CohortView co, const int * __restrict__ flagged,
+                                                             const uint8_t * __restrict__ tileTodo, unsigned tilesPerSample,
+                                                             int32_t * __restrict__ q3, uint8_t * __restrict__ flags,
+                                                             int * __restrict__ winFlag, const unsigned * __restrict__ rest)
+{
+    const unsigned nRest = rest[0], wavesPerWindow = (co.nSamples + 63u) / 64u, W = seg.nWindows;
+    for (unsigned k = blockIdx.x; k < nRest; k += gridDim.x)
+    {
+        const unsigned id = rest[1u + k], f = id / wavesPerWindow, s = (id % wavesPerWindow) * 64u + threadIdx.x;
+        const unsigned wA = (unsigned)flagged[f] & ~1u, wB = wA + 1u;
+        unsigned rg0 = 0, xA = 0, cntA = 0, endB = 0, nA = 0, nB = 0;
+        const bool mine = s < co.nSamples && exactLaneSetup(seg, s, wA, tilesPerSample, tileTodo, rg0, xA, cntA, endB, nA, nB);
+        const unsigned cnt = mine ? max(cntA, endB) : 0u;
+        const bool network = cnt <= 128u;
+        const unsigned cmax = waveMaxU32(network ? cnt : 0u);
+        if (mine && network)
+        {
+            if (cmax <= 64u)
+                exactPairStore<64>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
+            else if (cmax <= 80u)
+                exactPairStore<80>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
+            else if (cmax <= 96u)
+                exactPairStore<96>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
+            else if (cmax <= 112u)
+                exactPairStore<112>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
+            else
+                exactPairStore<128>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
+        }
+        else if (mine)
+        {
+            for (unsigned w = wA; w <= wB && w < W; ++w)
+            {
+                int q;
+                unsigned fl;
+                stage1CellGeneric(seg, co, s, w, q, fl);
+                q3[(size_t)s * W + w] = q;
+                flags[(size_t)s * W + w] = (uint8_t)fl;
+                if ((fl & 2u) && q > co.minThreshold)
+                    winFlag[w] = 1;
+            }
+        }
+    }
+}
+
 // room: how the scan shares the chip with the other stream's kernels (ScanRoom, pd_device.h); ordinary coverage only --
 // the deeper LDS stages are bounded by LDS already and launch as before.
 void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
@@ -793,6 +1068,41 @@ void launchStage1Fallback(const SegmentView & seg, const CohortView & co, int32_
     const unsigned blocks = nTiles < 2048u ? nTiles : 2048u;
     hipLaunchKernelGGL(stage1FallbackKernel, dim3(blocks), dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, todoList,
                        tilesPerSample);
+}
+
+// The screen over the whole segment, then the 32-bit fallback kernel for the blocks it handed on.
+void launchScreen(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag, uint8_t * tileTodo,
+                  unsigned * todoList, hipStream_t stream)
+{
+    const unsigned tilesPerSample = (seg.nWindows + kStage1Block - 1) / kStage1Block;
+    const unsigned blocksPerSample = (seg.nWindows + kPackedWindows - 1) / kPackedWindows;
+    dim3 grid((blocksPerSample + kScreenBlocks - 1) / kScreenBlocks, co.nSamples);
+    hipLaunchKernelGGL(screenKernel, grid, dim3(kStage1Block), 0, stream, seg, co, flags, winFlag, tileTodo, todoList, tilesPerSample,
+                       blocksPerSample);
+}
+
+void launchScreenFallback(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
+                          const unsigned * todoList, hipStream_t stream)
+{
+    const unsigned tilesPerSample = (seg.nWindows + kStage1Block - 1) / kStage1Block;
+    const unsigned nTiles = tilesPerSample * co.nSamples;
+    const unsigned blocks = nTiles < 2048u ? nTiles : 2048u;
+    hipLaunchKernelGGL(stage1FallbackKernel, dim3(blocks), dim3(kStage1Block), 0, stream, seg, co, q3, flags, winFlag, todoList,
+                       tilesPerSample);
+}
+
+// rest: room for 1 + nFlagged x ceil(nSamples / 64) words, rest[0] zeroed by the caller
+void launchExactFlagged(const SegmentView & seg, const CohortView & co, const int * flagged, unsigned nFlagged,
+                        const unsigned * nFlaggedDev, const int * ownWinFlag, const uint8_t * tileTodo, int32_t * q3, uint8_t * flags,
+                        int * winFlag, unsigned * rest, hipStream_t stream)
+{
+    if (nFlagged == 0 || co.nSamples == 0)
+        return;
+    const unsigned tilesPerSample = (seg.nWindows + kStage1Block - 1) / kStage1Block;
+    hipLaunchKernelGGL(exactFlaggedKernel, dim3((co.nSamples + 255u) / 256u, nFlagged), dim3(256), 0, stream, seg, co, flagged, nFlagged,
+                       nFlaggedDev, ownWinFlag, tileTodo, tilesPerSample, q3, flags, winFlag, rest);
+    hipLaunchKernelGGL(exactFlaggedRestKernel, dim3(1024), dim3(64), 0, stream, seg, co, flagged, tileTodo, tilesPerSample, q3, flags,
+                       winFlag, rest);
 }
 
 }  // namespace pd

@@ -111,7 +111,7 @@ def main():
         shard.close()
         dist.destroy_process_group()
         return
-    shard = distributed.SampleShard(capi.load_hip(), rgs, offs, rank, world, device=device, **opts)
+    shard = distributed.SampleShard(capi.load_hip(), rgs, offs, rank, world, device=device, stage1_view=True, **opts)
     res = shard.run(shard.local_segment(seg))
     assert res["n_samples"] == shard.last - shard.first
     full = shard.gather_columns(res)

@@ -20,7 +20,7 @@ def huge():
     first, w, offsets, arrays, planted = bench.device_tile(S, 4242, torch.device("cuda", 0))
     assert w == W
     rg = synth.conditioned_readgroup(synth.Library())
-    ctx = capi.Context(capi.load_hip(), [rg] * S, list(range(S + 1)))
+    ctx = capi.Context(capi.load_hip(), [rg] * S, list(range(S + 1)), stage1_view=True)
     seg = capi.Segment(first, w, offsets, arrays["dev"], arrays["start"], arrays["on"], arrays["off"])
     handle = ctx.stage(seg)
     yield ctx, handle, offsets, arrays

@@ -18,7 +18,7 @@ def run(lib, seg, rgs, offs, opts, monkeypatch=None, host_build=False):
             monkeypatch.setenv("POPDEL_HIP_HOST_BUILD", "1")
         else:
             monkeypatch.delenv("POPDEL_HIP_HOST_BUILD", raising=False)
-    ctx = capi.Context(lib, rgs, offs, **opts)
+    ctx = capi.Context(lib, rgs, offs, stage1_view=True, **opts)
     calls = ctx.collect(ctx.submit(seg))
     q3, fl = ctx.stage1()
     tm = ctx.timing()

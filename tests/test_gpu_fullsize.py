@@ -18,7 +18,7 @@ def big():
     first, w, offsets, arrays, planted = bench.device_tile(S, 77, torch.device("cuda", 0))
     assert (first, w) == (FIRST, W)
     rg = synth.conditioned_readgroup(synth.Library())
-    ctx = capi.Context(capi.load_hip(), [rg] * S, list(range(S + 1)))
+    ctx = capi.Context(capi.load_hip(), [rg] * S, list(range(S + 1)), stage1_view=True)
     seg = capi.Segment(first, w, offsets, arrays["dev"], arrays["start"], arrays["on"], arrays["off"])
     return ctx, seg, offsets, arrays
 

@@ -38,13 +38,13 @@ def test_lanes_return_what_a_plain_context_returns(built, monkeypatch, lanes):
     rg, segs = segments(n, 5)
     hip = capi.load_hip()
     monkeypatch.setenv("POPDEL_HIP_LANES", "1")
-    ctx = capi.Context(hip, [rg] * n, list(range(n + 1)))
+    ctx = capi.Context(hip, [rg] * n, list(range(n + 1)), stage1_view=True)
     want = [ctx.collect(ctx.submit(s)) for s in segs]
     want_q3 = ctx.stage1()
     ctx.close()
     assert sum(w["n_calls"] for w in want) > 30 and want[2]["n_calls"] == 0
     monkeypatch.setenv("POPDEL_HIP_LANES", str(lanes))
-    ctx = capi.Context(hip, [rg] * n, list(range(n + 1)))
+    ctx = capi.Context(hip, [rg] * n, list(range(n + 1)), stage1_view=True)
     # staged segments, as many tickets in flight as the context takes (2 per lane), collected in order
     handles = [ctx.stage(s) for s in segs]
     order = [i % len(segs) for i in range(4 * lanes + 3)]

@@ -19,9 +19,9 @@ def both(seg, rgs, offsets, hip_library=None, **kw):
     from popdel_amd import capi
     out = []
     for lib in (capi.load_library(hip_library) if hip_library else capi.load_hip(), capi.load_library(ORACLE_LIB)):
-        ctx = capi.Context(lib, rgs, offsets, **kw)
+        ctx = capi.Context(lib, rgs, offsets, stage1_view=True, **kw)
         calls = ctx.collect(ctx.submit(seg))
-        q3, fl = ctx.stage1()
+        q3, fl = ctx.stage1()        # (HIP: the full scan's values, checked cell by cell against the screen + exact pass that produced the calls)
         out.append((calls, q3, fl))
         ctx.close()
     return out
