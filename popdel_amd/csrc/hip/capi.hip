@@ -3346,7 +3346,13 @@ int pd_stage1_last(pd_ctx * c, pd_stage1_view * out)
     if (!c || !out)
         return 1;
     if (c->lanes)
-        return pd_stage1_last(c->lanes->workers[c->lanes->lastLane]->ctx, out);
+    {
+        pd_ctx * lane = c->lanes->workers[c->lanes->lastLane]->ctx;
+        const int rc = pd_stage1_last(lane, out);
+        if (rc != 0)
+            c->error = lane->error;
+        return rc;
+    }
     try
     {
         PD_HIP(hipSetDevice(c->device));

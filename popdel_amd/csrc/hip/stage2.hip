@@ -302,16 +302,42 @@ __device__ __forceinline__ unsigned halfForEachActive(const PairRange & r, unsig
     }
     else
     {
+        // More active pairs than the buffer holds (n > 128: only with a maxLoad raised beyond that): the same compaction again,
+        // the buffer handed to f whenever another 32 candidates might not fit. f relies on DENSE calls -- lane 0 of the half
+        // takes part in every call that any lane takes part in (its class counts, its pool allocation); calling it straight
+        // from the candidate loop, as rounds 1-4 did here, broke that: the support pools of such cells were filled at undefined
+        // slots and the DAD / LAD counts of lane 0 missed pairs (found by tests/test_gpu_screen.py at 170x, round 5).
+        unsigned fill = 0;
         for (unsigned base = r.begin; base < r.end; base += 32u)
         {
             const unsigned i = base + hl;
+            bool act = false;
+            PairDO p;
+            p.dev = 0;
+            p.off = 0;
             if (i < r.end)
             {
-                const PairDO p = r.p[i];
-                if (p.off > w)
-                    f(p.dev, NeedStart ? r.st[i] : 0u);
+                p = r.p[i];
+                act = p.off > w;
+            }
+            const unsigned long long bal = __ballot(act) & hm;
+            if (act)
+            {
+                const unsigned slot = fill + (unsigned)__popcll(bal & below);
+                devBuf[slot] = p.dev;
+                if (NeedStart)
+                    stBuf[slot] = r.st[i];
+            }
+            fill += (unsigned)__popcll(bal);
+            if (fill + 32u > kHalfBufCap)
+            {
+                for (unsigned j = hl; j < fill; j += 32u)
+                    f(devBuf[j], NeedStart ? stBuf[j] : 0u);
+                fill = 0;
             }
         }
+        for (unsigned j = hl; j < fill; j += 32u)
+            f(devBuf[j], NeedStart ? stBuf[j] : 0u);
     }
     return n;
 }

@@ -45,7 +45,8 @@ def test_bench_line_has_the_contract_fields(built):
     assert d["exchange"]["all_gathers_per_pass"] == 0
     assert d["small_cohort"]["value"] > 0 and d["candidate_dense"]["candidate_cells_per_pass"] > 0
     assert c["all_cores"]["cores"] == 2 and c["cpu_model"]
-    assert r["limiter"] == "valu" and r["scan_source_stamp"]
+    assert r["limiter"] == "hbm" and r["scan_source_stamp"] and r["kernel"] == "screenKernel" and 0 < r["frac"] < 1
+    assert r["contract_frac"] > r["frac"] and r["algorithmic_bytes_per_launch"] < r["contract_bytes_per_launch"]
     # the whole path against its own roofline, next to the scan's
     assert 0 < d["whole_path_frac"] < 1 and abs(d["whole_path_frac"] - d["value"] * d["algorithmic_bytes_per_unit"] / 8e12) < 1e-9
     # the sample-sharded code path with one rank, costed per pass next to the unsharded context

@@ -27,11 +27,12 @@ for fn in sorted(glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection
         if k.startswith("pd::"):
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 mean = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
-s1 = mean["pd::stage1Kernel"]
+SCAN = "pd::screenKernel" if "pd::screenKernel" in mean else "pd::stage1Kernel"
+s1 = mean[SCAN]
 cycles = s1["GRBM_GUI_ACTIVE"] / 8.0                     # summed over the 8 XCDs
 fetch_raw, write = s1["FETCH_SIZE"] * 1024.0, s1["WRITE_SIZE"] * 1024.0
 out = {
-    "kernel": "pd::stage1Kernel", "config": {"samples": 10000, "windows": 6667},
+    "kernel": SCAN, "config": {"samples": 10000, "windows": 6667},
     "scan_source_stamp": bench.scan_source_stamp(),
     "command": "tools/profile_round.sh: rocprofv3 --pmc <one block's counters> --kernel-trace -- python3 bench.py --serial --lanes 1 --no-legs --no-cpu --passes 4 --steps 1 --warmup 0 (one pass per counter group, no other trace domains)",
     "raw_mean_per_launch": s1,
@@ -40,7 +41,7 @@ out = {
     "hbm_bytes_per_launch": 2.0 * fetch_raw + write,
     "kernel_cycles": cycles,
     "valu_issue_utilisation": s1["SQ_INSTS_VALU"] * 4.0 / (cycles * 1024.0),
-    "lds_bank_conflict_share_of_lds_active": s1["SQ_LDS_BANK_CONFLICT"] / s1["SQ_LDS_IDX_ACTIVE"],
+    "lds_bank_conflict_share_of_lds_active": s1["SQ_LDS_BANK_CONFLICT"] / max(1.0, s1["SQ_LDS_IDX_ACTIVE"]),
     "wave_cycles_waiting_on_instruction_operands": s1["SQ_WAIT_INST_ANY"] / s1["SQ_WAVE_CYCLES"],
     "wave_cycles_parked": s1["SQ_WAIT_ANY"] / s1["SQ_WAVE_CYCLES"],
 }
@@ -51,7 +52,7 @@ with open(os.path.join(dst, name + "_pmc_kernels.md"), "w") as f:
             "operand stall = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES; L2 hit = TCC_HIT / (TCC_HIT + TCC_MISS); L1->L2 = TCP_TCC_READ_REQ per cycle and CU; "
             "LDS conflicts = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; HBM = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction).\n\n")
     f.write("| kernel | launches | cycles | VALU issue | parked | operand stall | L2 hit | L1->L2 req/clk/CU | LDS conflicts | HBM MB |\n|---|---|---|---|---|---|---|---|---|---|\n")
-    for k in ("pd::stage1Kernel", "pd::stage1BigKernel", "pd::cellGatherKernel", "pd::dataLikDenseKernel", "pd::updateLenDenseKernel",
+    for k in ("pd::screenKernel", "pd::exactFlaggedKernel", "pd::stage1Kernel", "pd::stage1BigKernel", "pd::cellGatherKernel", "pd::dataLikDenseKernel", "pd::updateLenDenseKernel",
               "pd::finalDenseKernel", "pd::clusterKernel", "pd::suppSelectLocalKernel"):
         if k not in mean:
             continue

@@ -26,7 +26,7 @@ for t, d in events:
 total = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in win)
 wall = end - t0
 queues = sorted({r.get("Queue_Id", "?") for r in win})
-scans = [r for r in win if "stage1Kernel" in r["Kernel_Name"]]
+scans = [r for r in win if ("screenKernel" in r["Kernel_Name"] or "stage1Kernel" in r["Kernel_Name"])]
 print("window: last %.1f ms of the trace, %d kernels on %d queues (%s), %d scans -> %.3f ms per scan" % (
     ms, len(win), len(queues), ", ".join(queues), len(scans), wall / 1e6 / max(1, len(scans))))
 print("chip idle %.1f %%, one kernel %.1f %%, two or more kernels %.1f %% of the window; kernel durations add up to %.2f x the wall time" % (
