@@ -52,6 +52,9 @@ def parse_args(argv=None):
                          "with the segment split as value and the process exits 3)")
     ap.add_argument("--stream-segments", type=int, default=4,
                     help="segments of the streaming leg (host memory -> HBM -> calls, double buffered); 0 switches it off")
+    ap.add_argument("--stream50k-samples", type=int, default=50000,
+                    help="cohort of the streaming_50000 leg (configs[4]'s size through one GPU; 0: skip)")
+    ap.add_argument("--stream50k-segments", type=int, default=3)
     ap.add_argument("--coverage", type=float, default=30.0, help="sequencing depth of the synthetic samples (headline: 30)")
     ap.add_argument("--rgs-per-sample", type=int, default=1,
                     help="split every sample's pairs over this many read groups (same library): measures the kernels "
@@ -756,35 +759,90 @@ def main():
             legs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         progress("leg %s done" % name)
 
-    def streaming_leg():
-        # every segment comes from host memory -- layout built, uploaded over the copy stream while the previous segment
-        # computes, results collected -- i.e. what a host that has the pair instances in RAM sustains through one GPU
+    def stream_through(c, sg, n_segments):
+        """`n_segments` times the segment `sg` from host memory through context `c`, double buffered: stage(N + 1) -- packing on
+        the host threads, upload and layout build on the copy stream -- while ticket N computes; collect(N). Returns the
+        wall time and what pd_last_stage_timing() said about the stagings."""
         torch.cuda.synchronize()
         q0 = time.perf_counter()
         t_stage = t_collect = 0.0
-        h_cur = ctx.stage(seg)
+        st_acc = dict(pack_seconds=0.0, uploaded_seconds=0.0, bytes_uploaded=0, n=0)
+
+        def note():
+            st = c.stage_timing()
+            st_acc["pack_seconds"] += st["pack_seconds"]
+            st_acc["uploaded_seconds"] += st["uploaded_seconds"]
+            st_acc["bytes_uploaded"] += st["bytes_uploaded"]
+            st_acc["flavour"] = st["flavour"]
+            st_acc["host_threads"] = st["host_threads"]
+            st_acc["n"] += 1
+
+        h_cur = c.stage(sg)
+        note()
         t_first = time.perf_counter() - q0
-        t_cur = ctx.run(h_cur)
-        for i in range(args.stream_segments):
-            last = i + 1 == args.stream_segments
+        t_cur = c.run(h_cur)
+        for i in range(n_segments):
+            last = i + 1 == n_segments
             if not last:
                 a = time.perf_counter()
-                h_nxt = ctx.stage(seg)
-                t_nxt = ctx.run(h_nxt)
+                h_nxt = c.stage(sg)
+                note()
+                t_nxt = c.run(h_nxt)
                 t_stage += time.perf_counter() - a
             a = time.perf_counter()
-            ctx.collect(t_cur, copy=False)
-            ctx.unstage(h_cur)
+            c.collect(t_cur, copy=False)
+            c.unstage(h_cur)
             t_collect += time.perf_counter() - a
             if not last:
                 h_cur, t_cur = h_nxt, t_nxt
         torch.cuda.synchronize()
         dt = time.perf_counter() - q0
-        return dict(value=args.stream_segments * W * S / dt, unit="window*sample/s", segments=args.stream_segments,
-                    seconds_per_segment=dt / args.stream_segments,
-                    stage_seconds_per_segment=t_stage / max(1, args.stream_segments - 1),
-                    collect_seconds_per_segment=t_collect / args.stream_segments, first_stage_seconds=t_first,
-                    host_bytes_per_segment=int(16 * len(arrays["dev"]) + 8 * (S + 1)))
+        k = max(1, st_acc["n"])
+        return dt, dict(seconds_per_segment=dt / n_segments, stage_seconds_per_segment=t_stage / max(1, n_segments - 1),
+                        collect_seconds_per_segment=t_collect / n_segments, first_stage_seconds=t_first,
+                        pack_seconds_per_segment=st_acc["pack_seconds"] / k, uploaded_seconds_per_segment=st_acc["uploaded_seconds"] / k,
+                        h2d_bytes_per_segment=st_acc["bytes_uploaded"] // k,
+                        # the link's rate over the window in which bytes were travelling (packing of later slabs included: the
+                        # upload of a slab runs under the packing of the next)
+                        h2d_GBs_while_staging=st_acc["bytes_uploaded"] / max(1e-9, st_acc["uploaded_seconds"]) / 1e9,
+                        bytes_per_instance_on_the_link=st_acc.get("flavour"), host_threads=st_acc.get("host_threads"))
+
+    def streaming_leg():
+        # every segment comes from host memory -- layout built, uploaded over the copy stream while the previous segment
+        # computes, results collected -- i.e. what a host that has the pair instances in RAM sustains through one GPU.
+        # What bounds it is the packing pass on the host threads (16 B per instance read from the caller's pageable arrays,
+        # 5 B written to page-locked staging): the probe beside it says what the host's memory system gives those threads in
+        # this very run -- rounds 3/4 saw this leg in two modes (0.03 and 0.1 s per segment) on the same build, box to box.
+        probe = [hip.pd_host_copy_gbs(1 << 30)]
+        dt, d = stream_through(ctx, seg, args.stream_segments)
+        probe.append(hip.pd_host_copy_gbs(1 << 30))
+        d.update(value=args.stream_segments * W * S / dt, unit="window*sample/s", segments=args.stream_segments,
+                 host_bytes_per_segment=int(16 * len(arrays["dev"]) + 8 * (S + 1)),
+                 host_pack_read_GBs=16 * len(arrays["dev"]) / max(1e-9, d["pack_seconds_per_segment"]) / 1e9,
+                 host_copy_probe_GBs=probe,
+                 host_copy_probe="pageable -> page-locked copy of 1 GiB on the library's host threads, before and after the leg")
+        return d
+
+    def streaming_50000_leg():
+        # configs[4]'s mechanism at its cohort size on ONE GPU: 50,000 samples x one 200-kb segment (10^9 pair instances,
+        # 16 GB in the caller's arrays, 5 GB on the link) streamed from host memory, double buffered
+        n50 = args.stream50k_samples
+        if n50 <= 0:
+            return {"skipped": "--stream50k-samples 0"}
+        f5, W5, o5, a5, _ = device_tile(n50, 777, device, args.coverage)
+        c5 = capi.Context(hip, [rg] * n50, list(range(n50 + 1)), device=local_rank)
+        try:
+            sg5 = capi.Segment(f5, W5, o5, a5["dev"], a5["start"], a5["on"], a5["off"])
+            dt, d = stream_through(c5, sg5, args.stream50k_segments)
+            t5 = c5.timing()
+            d.update(value=args.stream50k_segments * W5 * n50 / dt, unit="window*sample/s", samples=n50, segments=args.stream50k_segments,
+                     pair_instances_per_segment=int(len(a5["dev"])), host_bytes_per_segment=int(16 * len(a5["dev"]) + 8 * (n50 + 1)),
+                     host_pack_read_GBs=16 * len(a5["dev"]) / max(1e-9, d["pack_seconds_per_segment"]) / 1e9,
+                     scan_ms=t5["stage1_ms"], stage2_ms=t5["stage2_ms"], candidate_cells=t5["n_candidate_cells"])
+        finally:
+            c5.close()
+            del a5
+        return d
 
     def concurrent_leg():
         # the same step with several independent segments in flight on the GPU, one context and host thread each
@@ -1222,6 +1280,7 @@ def main():
     if rank == 0 and not args.no_legs and not is_dist:      # N > 1 runs carry the two splits only
         if args.stream_segments > 0:
             leg("streaming", streaming_leg)
+            leg("streaming_50000", streaming_50000_leg)
         if args.sharded_world1.strip():
             leg("sharded_world1", sharded_world1_leg)
         if args.concurrent > 1 and args.contexts == 1:

@@ -206,6 +206,28 @@ typedef struct pd_timing
 } pd_timing;
 int pd_last_timing(pd_ctx *ctx, pd_timing *out);
 
+/* What the last pd_segment_stage() / pd_segment_submit() of the context cost on the host side and on the link (ABI 12;
+ * instrumentation, no reference counterpart): the pair instances cross PCIe once in a compact form that the library's host
+ * threads pack from the caller's four 32-bit arrays (16 B per instance read from the caller's memory, `flavour` bytes per
+ * instance written to page-locked staging and uploaded slab by slab while the next slab is packed).
+ *   pack_seconds      wall time of the packing passes (sum over the slabs)
+ *   uploaded_seconds  from the start of the call until the last uploaded byte had reached the device
+ *   bytes_uploaded    n_instances x flavour (+ the small tables)
+ * pd_host_copy_gbs(bytes): a probe of what the host's memory system gives those threads right now -- `bytes` copied from
+ * pageable to page-locked memory by the same threads in the same way, GB/s (read + write counted once). The streaming rate of
+ * a context is bound by the packing pass, i.e. by this figure, not by PCIe (streaming). */
+typedef struct pd_stage_timing
+{
+    uint64_t n_instances;
+    uint64_t bytes_uploaded;
+    double   pack_seconds;
+    double   uploaded_seconds;
+    uint32_t flavour;            /* bytes per instance on the link: 5 (compact), 8 (narrow), 16 (wide); 0: built on the host */
+    uint32_t host_threads;
+} pd_stage_timing;
+int pd_last_stage_timing(pd_ctx *ctx, pd_stage_timing *out);
+double pd_host_copy_gbs(uint64_t bytes);
+
 /* ---- cohort sharded by samples over several contexts (one per GPU) -------------------------------------------------
  * The reference has no counterpart (single process); this is how `genotype_deletion_window()` is split over GPUs:
  * context r of `world` owns the samples [first_sample, first_sample + n_samples) of the cohort, where the partition is

@@ -1099,6 +1099,13 @@ int pd_inflate_members(int, const uint8_t *, const uint64_t *, uint32_t, uint8_t
                        pd_inflate_timing *) { return 1; }
 const char * pd_inflate_last_error(void) { return "the oracle backend has no device"; }
 int pd_ctx_stage1_view(pd_ctx * c, int) { return c ? 0 : 1; }
+int pd_last_stage_timing(pd_ctx *, pd_stage_timing * out)
+{
+    if (out)
+        std::memset(out, 0, sizeof(*out));
+    return out ? 0 : 1;
+}
+double pd_host_copy_gbs(uint64_t) { return 0; }
 pd_inflater * pd_inflater_create(int) { return nullptr; }
 const char * pd_inflater_last_error(pd_inflater *) { return "the oracle backend has no device"; }
 void pd_inflater_destroy(pd_inflater *) {}

@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "pd_ctx_keep_results_on_device", "pd_calls_merge", "pd_calls_fetch_columns", "pd_merged_free",
     "pd_walk_submit", "pd_walk_supported", "pd_walk_active", "pd_device_warmup", "pd_inflate_members", "pd_inflate_last_error",
     "pd_inflater_create", "pd_inflater_destroy", "pd_inflater_input", "pd_inflater_run", "pd_inflater_run_parsed", "pd_ctx_set_shard_lanes",
-    "pd_inflater_last_error", "pd_ctx_stage1_view",
+    "pd_inflater_last_error", "pd_ctx_stage1_view", "pd_last_stage_timing", "pd_host_copy_gbs",
 )
 RCCL_ID_BYTES = 128
 
@@ -92,6 +92,11 @@ class PdWalk(C.Structure):
                 ("id_offset", C.POINTER(C.c_uint32)), ("switches", C.POINTER(C.c_uint8)), ("equal_run", C.POINTER(C.c_uint8))]
 
 
+class PdStageTiming(C.Structure):
+    _fields_ = [("n_instances", C.c_uint64), ("bytes_uploaded", C.c_uint64), ("pack_seconds", C.c_double), ("uploaded_seconds", C.c_double),
+                ("flavour", C.c_uint32), ("host_threads", C.c_uint32)]
+
+
 class PdShard(C.Structure):
     _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("first_sample", C.c_uint32),
                 ("n_samples_global", C.c_uint32), ("n_readgroups_global", C.c_uint32),
@@ -122,6 +127,12 @@ def load_library(path):
     lib.pd_stage1_last.argtypes = [C.c_void_p, C.POINTER(PdStage1View)]
     lib.pd_stage1_last.restype = C.c_int
     lib.pd_last_timing.argtypes = [C.c_void_p, C.POINTER(PdTiming)]
+    lib.pd_last_stage_timing.argtypes = [C.c_void_p, C.POINTER(PdStageTiming)]
+    lib.pd_last_stage_timing.restype = C.c_int
+    lib.pd_host_copy_gbs.argtypes = [C.c_uint64]
+    lib.pd_host_copy_gbs.restype = C.c_double
+    lib.pd_ctx_stage1_view.argtypes = [C.c_void_p, C.c_int]
+    lib.pd_ctx_stage1_view.restype = C.c_int
     lib.pd_last_timing.restype = C.c_int
     lib.pd_last_error.argtypes = [C.c_void_p]
     lib.pd_last_error.restype = C.c_char_p
@@ -486,6 +497,12 @@ class Context:
         p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
         self._check(self.lib.pd_log_table_view(self.handle, rg, p(v), p(l), p(l10), C.byref(n)))
         return v[:n.value], l[:n.value], l10[:n.value]
+
+    def stage_timing(self):
+        """Host and link cost of the context's last stage() / submit() (pd_last_stage_timing)."""
+        t = PdStageTiming()
+        self._check(self.lib.pd_last_stage_timing(self.handle, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in PdStageTiming._fields_}
 
     def timing(self):
         t = PdTiming()

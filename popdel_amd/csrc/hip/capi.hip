@@ -420,6 +420,7 @@ struct pd_ctx
     // Stage 1 as a SCREEN (stage1.hip): count the pairs beyond the smallest threshold per cell, take exact Q3 values in the
     // flagged windows only. POPDEL_HIP_SCAN=full: the round-1..4 scan (exact Q3 of every cell).
     bool screenScan = true;
+    pd_stage_timing stageTiming{};        // pd_last_stage_timing()
     bool stage1View = false;              // pd_ctx_stage1_view(): keep the full scan's Q3 of every cell for pd_stage1_last()
     // stage 2 launched without waiting for the pool sizes (see pd_segment_collect); POPDEL_HIP_EXACT_POOLS=1 turns it off
     bool optimisticPools = true;
@@ -1375,6 +1376,12 @@ bool buildChunksOnDevice(pd_ctx & c, const pd_segment & seg, StagedSegment & out
     in.shift = seg.window_shift;
     const bool isNarrow = narrow.load();
     return buildLayoutOnDevice(c, in, nInst, W, out, [&]() {
+        c.stageTiming.n_instances = nInst;
+        c.stageTiming.flavour = isNarrow ? (compact ? 5u : 8u) : 16u;
+        c.stageTiming.bytes_uploaded = nInst * c.stageTiming.flavour + (nRg + 1) * sizeof(uint64_t) + exceptions.size() * 16u;
+        c.stageTiming.pack_seconds = packSeconds;
+        c.stageTiming.uploaded_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild0).count();
+        c.stageTiming.host_threads = pdh::hostThreads();
         if (debug)
             fprintf(stderr, "[popdel_hip] device build: %llu instances uploaded %s, %zu exceptions; packing %.1f ms on the host threads, "
                             "%.1f ms until the last byte was on the device\n", (unsigned long long)nInst,
@@ -3659,6 +3666,42 @@ int pd_calls_fetch_columns(pd_ctx * c, pd_calls * calls)
         return fail(c, "pd_calls_fetch_columns: unknown exception");
     }
     return 0;
+}
+
+int pd_last_stage_timing(pd_ctx * c, pd_stage_timing * out)
+{
+    if (!c || !out)
+        return 1;
+    *out = c->stageTiming;
+    return 0;
+}
+
+// pageable -> page-locked on the library's host threads, the way the packing pass of pd_segment_stage() touches memory
+double pd_host_copy_gbs(uint64_t bytes)
+{
+    if (bytes < (1u << 20))
+        return 0;
+    std::vector<uint8_t> src(bytes);
+    void * dst = pd::pinnedAlloc(bytes);
+    if (!dst)
+        return 0;
+    const size_t pieces = 256;
+    auto pass = [&](bool write) {
+        pdh::parallelFor(pieces, [&](size_t j) {
+            const size_t lo = bytes * j / pieces, hi = bytes * (j + 1) / pieces;
+            if (write)
+                std::memset(src.data() + lo, (int)(j & 0xff), hi - lo);           // (first touch by the threads that read it later)
+            else
+                std::memcpy(static_cast<uint8_t *>(dst) + lo, src.data() + lo, hi - lo);
+        });
+    };
+    pass(true);
+    pass(false);                                                                   // (warm: page tables of the destination)
+    const auto t0 = std::chrono::steady_clock::now();
+    pass(false);
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    pd::pinnedFree(dst);
+    return s > 0 ? static_cast<double>(bytes) / s / 1e9 : 0;
 }
 
 int pd_last_timing(pd_ctx * c, pd_timing * out)

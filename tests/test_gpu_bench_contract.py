@@ -15,7 +15,8 @@ def test_bench_line_has_the_contract_fields(built):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--samples", "512", "--passes", "3", "--steps", "2",
                           "--warmup", "1", "--cpu-samples", "40", "--cpu-threads", "2", "--stream-segments", "2", "--small-cohort", "128",
                           "--dense-deletions", "3", "--e2e-samples", "24", "--sharded-world1", "256,0", "--distinct-segments", "3",
-                          "--resident-segments", "3", "--e2e-cohort-samples", "32", "--e2e-cohort-mb", "1", "--inflate-members", "600"],
+                          "--resident-segments", "3", "--e2e-cohort-samples", "32", "--e2e-cohort-mb", "1", "--inflate-members", "600",
+                          "--stream50k-samples", "768", "--stream50k-segments", "2"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -67,6 +68,14 @@ def test_bench_line_has_the_contract_fields(built):
     assert d["roofline"]["mean_launch_ms"] > 0 and d["roofline"]["mean_launch_ms_in_timed_region"] > 0
     ds = d["distinct_segments"]
     assert ds["value"] > 0 and len(ds["segments"]) == 3 and ds["segments"][-1]["del_len"] is None
+    # segments streamed from host memory: the leg says what the staging cost on the host and on the link, and what the host's
+    # memory system gave in the same run
+    st = d["streaming"]
+    assert st["value"] > 0 and st["pack_seconds_per_segment"] > 0 and st["uploaded_seconds_per_segment"] >= st["pack_seconds_per_segment"] * 0.5
+    assert st["bytes_per_instance_on_the_link"] == 5 and st["h2d_bytes_per_segment"] > 0 and len(st["host_copy_probe_GBs"]) == 2
+    assert min(st["host_copy_probe_GBs"]) > 0.1
+    s5 = d["streaming_50000"]
+    assert s5["samples"] == 768 and s5["segments"] == 2 and s5["value"] > 0 and s5["pair_instances_per_segment"] > 0
     # gunzip of profile blocks on the device against the host's libdeflate path: same bytes
     g = d["device_gunzip"]
     assert g["members"] == 600 and g["all_accepted"] and g["identical_to_host"] and g["kernel_ms"] > 0 and g["host_seconds"] > 0
