@@ -937,37 +937,38 @@ __global__ __launch_bounds__(256) void exactFlaggedKernel(SegmentView seg, Cohor
                                                           unsigned tilesPerSample, int32_t * __restrict__ q3, uint8_t * __restrict__ flags,
                                                           int * __restrict__ winFlag, unsigned * __restrict__ rest)
 {
-    const unsigned f = blockIdx.y;
+    // (the launch is made for a CAPACITY of flagged windows the host has not seen: the grid's y strides over the real number)
     const unsigned nF = nFlaggedDev ? min(*nFlaggedDev, nFlagged) : nFlagged;
-    if (f >= nF)
-        return;
-    const unsigned w = (unsigned)flagged[f];
-    if ((w & 1u) && ownWinFlag[w - 1u] != 0 && f != 0u && (unsigned)flagged[f - 1u] == w - 1u)
-        return;                                         // the even neighbour's lanes take the pair
-    const unsigned wA = w & ~1u;
     const unsigned s = blockIdx.x * 256u + threadIdx.x;
-    unsigned rg0 = 0, xA = 0, cntA = 0, endB = 0, nA = 0, nB = 0;
-    const bool mine = s < co.nSamples && exactLaneSetup(seg, s, wA, tilesPerSample, tileTodo, rg0, xA, cntA, endB, nA, nB);
-    const unsigned cnt = mine ? max(cntA, endB) : 0u;
-    const unsigned cmax = waveMaxU32(cnt);
-    if (cmax > 64u)
+    for (unsigned f = blockIdx.y; f < nF; f += gridDim.y)
     {
-        if ((threadIdx.x & 63u) == 0u)
-            rest[1u + atomicAdd(&rest[0], 1u)] = f * ((co.nSamples + 63u) / 64u) + (s >> 6);
-        return;
+        const unsigned w = (unsigned)flagged[f];
+        if ((w & 1u) && f != 0u && (unsigned)flagged[f - 1u] == w - 1u)
+            continue;                                       // the even neighbour's lanes take the pair
+        const unsigned wA = w & ~1u;
+        unsigned rg0 = 0, xA = 0, cntA = 0, endB = 0, nA = 0, nB = 0;
+        const bool mine = s < co.nSamples && exactLaneSetup(seg, s, wA, tilesPerSample, tileTodo, rg0, xA, cntA, endB, nA, nB);
+        const unsigned cnt = mine ? max(cntA, endB) : 0u;
+        const unsigned cmax = waveMaxU32(cnt);
+        if (cmax > 64u)
+        {
+            if ((threadIdx.x & 63u) == 0u)
+                rest[1u + atomicAdd(&rest[0], 1u)] = f * ((co.nSamples + 63u) / 64u) + (s >> 6);
+            continue;
+        }
+        if (!mine)
+            continue;
+        if (cmax <= 32u)
+            exactPairStore<32>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
+        else if (cmax <= 40u)
+            exactPairStore<40>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
+        else if (cmax <= 48u)
+            exactPairStore<48>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
+        else if (cmax <= 56u)
+            exactPairStore<56>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
+        else
+            exactPairStore<64>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
     }
-    if (!mine)
-        return;
-    if (cmax <= 32u)
-        exactPairStore<32>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
-    else if (cmax <= 40u)
-        exactPairStore<40>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
-    else if (cmax <= 48u)
-        exactPairStore<48>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
-    else if (cmax <= 56u)
-        exactPairStore<56>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
-    else
-        exactPairStore<64>(seg, co, s, rg0, wA, xA, cntA, endB, nA, nB, q3, flags, winFlag);
 }
 
 // The wave tiles with 65 or more candidates in some lane (deeper coverage): networks of up to 128 inputs, and rank
@@ -1099,9 +1100,12 @@ void launchExactFlagged(const SegmentView & seg, const CohortView & co, const in
     if (nFlagged == 0 || co.nSamples == 0)
         return;
     const unsigned tilesPerSample = (seg.nWindows + kStage1Block - 1) / kStage1Block;
-    hipLaunchKernelGGL(exactFlaggedKernel, dim3((co.nSamples + 255u) / 256u, nFlagged), dim3(256), 0, stream, seg, co, flagged, nFlagged,
+    // y: the flagged windows as far as they are known (a capacity: 128 rows stride over the real number -- a launch of
+    // capacity x tiles workgroups that leave at once cost 45 us per segment)
+    const unsigned rows = nFlaggedDev ? min(nFlagged, 128u) : min(nFlagged, 65535u);
+    hipLaunchKernelGGL(exactFlaggedKernel, dim3((co.nSamples + 255u) / 256u, rows), dim3(256), 0, stream, seg, co, flagged, nFlagged,
                        nFlaggedDev, ownWinFlag, tileTodo, tilesPerSample, q3, flags, winFlag, rest);
-    hipLaunchKernelGGL(exactFlaggedRestKernel, dim3(1024), dim3(64), 0, stream, seg, co, flagged, tileTodo, tilesPerSample, q3, flags,
+    hipLaunchKernelGGL(exactFlaggedRestKernel, dim3(256), dim3(64), 0, stream, seg, co, flagged, tileTodo, tilesPerSample, q3, flags,
                        winFlag, rest);
 }
 

@@ -77,7 +77,7 @@ def assert_same_up_to_knife_edges(gpu, cpu, allowed_diverged=0):
     it down another path altogether (seed 155: two shifts on -24 with sigma 23.1, lengths wandering between 5041 and 5105
     for 15 iterations); such a call counts as diverged.
     Per cohort the invariants are asserted here together with a loose FLOOR on the magnitudes (every call: LR within 1e-3,
-    AF within 1e-4; at most max(2, n / 10) calls touched; a touched call differs in at most a third of its columns) -- so
+    AF within 2e-4; at most max(2, n / 10) calls touched; a touched call differs in at most a third of its columns) -- so
     that a regression which moves LR by per cents without flipping a genotype fails in whatever subset of the sweep is run
     (-k, --lf, xdist); the tight figures -- HOW MANY calls and columns may be touched over the sweep -- are budgets over the
     whole session (test_session_budgets, conftest.py). Returns (touched calls, differing columns, diverged calls, worst
@@ -106,7 +106,7 @@ def assert_same_up_to_knife_edges(gpu, cpu, allowed_diverged=0):
     touched = (cols.any(axis=1) | ~lr_ok | ~af_ok | (gc["iterations"] != oc["iterations"])) & keep
     # the floor (per cohort, whatever else ran in this session)
     assert np.allclose(gc["likelihood_ratio"][keep], oc["likelihood_ratio"][keep], rtol=1e-3, atol=1e-3), "LR beyond 1e-3"
-    assert np.allclose(gc["frequency"][keep], oc["frequency"][keep], rtol=0, atol=1e-4), "AF beyond 1e-4"
+    assert np.allclose(gc["frequency"][keep], oc["frequency"][keep], rtol=0, atol=2e-4), "AF beyond 2e-4"
     assert touched.sum() <= max(2, n // 10), ("touched calls", int(touched.sum()), n)
     assert (cols.sum(axis=1) <= max(3, cols.shape[1] // 3)).all(), "a touched call differs in more than a third of its columns"
     worst_lr = worst_af = 0.0
@@ -161,10 +161,11 @@ def test_random_cohort(built, seed):
 # The worst cohorts of every sweep so far, against the SHIPPED library: 155 and 887 hold the two diverged calls seen in
 # ~190,000 (length / position differ after an EM that oscillates up to the iteration cap); 533 and 1003 a call with more than a
 # third of its sample columns touched (same length, position, genotypes); 632, 483, 620 the largest LR differences on calls
-# that are otherwise the same (3.4e-4, 1.3e-4, 3.2e-5 relative); 693 and 515 the largest AF differences (7.0e-5, 5.5e-5); 132 a
-# long oscillating EM. What the shipped library does on them is pinned, call by call, in tests/golden/residual_<seed>.json
+# that are otherwise the same (3.4e-4, 1.3e-4, 3.2e-5 relative); 693 and 515 the largest AF differences of rounds 2-4 (7.0e-5,
+# 5.5e-5); 132 a long oscillating EM; from round 5's sweep of seeds 1050-1349 (profiles/r05_fuzz_sweeps.md): 1145 the largest AF
+# difference so far (9.8e-5), 1112 / 1328 / 1070 calls with 70 / 59 / 56 % of their columns touched (1070 also LR by 2.6e-6). What the shipped library does on them is pinned, call by call, in tests/golden/residual_<seed>.json
 # (tools/make_residual_goldens.py; tests/residual.py says what a record holds and which invariants hold regardless).
-RESIDUAL_SEEDS = [132, 155, 483, 515, 533, 620, 632, 693, 887, 1003]
+RESIDUAL_SEEDS = [132, 155, 483, 515, 533, 620, 632, 693, 887, 1003, 1070, 1112, 1145, 1328]
 
 
 @pytest.mark.parametrize("seed", RESIDUAL_SEEDS)
