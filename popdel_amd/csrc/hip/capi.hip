@@ -23,6 +23,7 @@
 #include "parallel.h"
 #include "pd_build.h"
 #include "pd_device.h"
+#include "pd_exchange.h"
 #include "pd_walk.h"
 #include "pinned_host.h"
 #include "popdel_hip.h"
@@ -124,6 +125,9 @@ struct HipError
 
 // What the process holds in HBM and in page-locked host memory (POPDEL_HIP_MEMSTAT=1 prints it at every collect).
 std::atomic<uint64_t> g_devBytes{0}, g_pinnedBytes{0}, g_devAllocs{0}, g_pinnedAllocs{0};
+std::atomic<bool> g_parkFrees{false};
+std::mutex g_parkLock;
+std::vector<void *> g_parked;
 
 // Device allocation that frees itself.
 template <typename T>
@@ -139,7 +143,16 @@ struct DevBuf
     {
         if (p)
         {
-            (void)hipFree(p);
+            // hipFree() waits for the whole device. Where contexts of one process share a GPU AND exchange through kernels that
+            // wait for each other (exchange.hip on one device: tests), a context that frees while its peer's exchange kernel
+            // waits for its next push would wait for that kernel in turn: such processes park replaced buffers until they end.
+            if (g_parkFrees.load())
+            {
+                std::lock_guard<std::mutex> lock(g_parkLock);
+                g_parked.push_back(p);
+            }
+            else
+                (void)hipFree(p);
             g_devBytes -= n * sizeof(T);
         }
         p = nullptr;
@@ -391,6 +404,13 @@ struct pd_ctx
     DevBuf<unsigned> dMinInitGlobal;
     DevBuf<uint8_t> ownArena;       // exchange areas when world == 1 (otherwise the host owns the buffer)
     uint8_t * arena = nullptr;
+    // contexts of one process (pd_ctx_set_shard_local): the device-side carrier (exchange.hip) unless POPDEL_HIP_GROUP_CARRIER=host
+    bool flagCarrier = false;       // (decided at the group's first collective step: groupDecide)
+    bool flagsWanted = false, groupDecided = false;
+    unsigned * xchFlags = nullptr;  // this context's flag block (fine-grained device memory)
+    unsigned * xchErr = nullptr;    // page-locked host word raised by a wait that gave up
+    unsigned xchSeq = 0;            // running number of the context's exchanges
+    bool peersEnabled = false;
 
     std::map<uint64_t, std::unique_ptr<StagedSegment>> staged;
     std::vector<std::unique_ptr<StagedSegment>> spare;      // released segments: their HBM buffers are reused (no hipMalloc per segment)
@@ -604,14 +624,65 @@ struct CallsBox
 };
 
 // The exchange buffer: owned by the host if it runs the exchanges (pd_ctx_set_shard with callbacks), else by the library.
+void groupBarrier(pd_ctx & c);
+
+// Which carrier the contexts of a local group use, decided once, by all of them alike, at their first collective step (all
+// members are registered then): the device-side one (exchange.hip) unless POPDEL_HIP_GROUP_CARRIER=host -- or two contexts
+// sit on the SAME GPU (tests, debugging): there a waiting exchange kernel can end up in front of what it waits for (a
+// shared hardware queue; a call of the peer's host thread that waits for the whole device), so the host-driven carrier stays
+// the rule and the device-side one runs only if asked for by name (POPDEL_HIP_GROUP_CARRIER=flags) with hardware queues to
+// spare (GPU_MAX_HW_QUEUES >= 8; tests/conftest.py sets 16).
+void groupDecide(pd_ctx & c)
+{
+    groupBarrier(c);
+    bool flags = c.flagsWanted;
+    bool shared = false;
+    for (uint32_t p = 0; p < c.world; ++p)
+        for (uint32_t q = p + 1; q < c.world; ++q)
+            if (c.group->members[p] && c.group->members[q] && c.group->members[p]->device == c.group->members[q]->device)
+                shared = true;
+    for (uint32_t p = 0; p < c.world; ++p)
+        flags = flags && c.group->members[p] && c.group->members[p]->xchFlags;
+    if (shared)
+    {
+        // (one GPU standing in for several: only when asked for by name, with hardware queues to spare; frees are parked)
+        const char * q = getenv("GPU_MAX_HW_QUEUES");
+        const char * how = getenv("POPDEL_HIP_GROUP_CARRIER");
+        flags = flags && how && std::strcmp(how, "flags") == 0 && q && atoi(q) >= 8;
+        if (flags)
+            g_parkFrees.store(true);
+    }
+    c.flagCarrier = flags;
+    c.groupDecided = true;
+    if (getenv("POPDEL_HIP_GROUP_TRACE"))
+        fprintf(stderr, "[popdel_hip] local group of %u contexts: %s carrier\n", c.world, flags ? "device-side (flags)" : "host-driven");
+    groupBarrier(c);
+}
+
 bool hostOwnsArena(const pd_ctx & c) { return c.sharded && !c.comm && !c.group && c.shard.reserve && c.shard.all_gather; }
 
 uint8_t * reserveArena(pd_ctx & c, size_t bytes)
 {
     if (!hostOwnsArena(c))
     {
+        if (c.group && !c.groupDecided)
+            groupDecide(c);
         if (bytes > c.ownArena.n)
+        {
             PD_HIP(hipStreamSynchronize(c.stream));        // nothing in flight may still use the buffer that is replaced
+            if (c.flagCarrier && c.world > 1)
+            {
+                // The peers write into this buffer through its address: growth is a collective step (every context asks for the
+                // same sizes in the same order, so all arrive here together) -- everybody drains, the buffers are replaced, and
+                // nobody goes on before all new addresses are published. After the first segments the sizes settle.
+                PD_HIP(hipStreamSynchronize(c.copyStream));
+                groupBarrier(c);
+                c.ownArena.ensure(bytes);
+                c.arena = c.ownArena.p;
+                groupBarrier(c);
+                return c.arena;
+            }
+        }
         c.ownArena.ensure(bytes);
         c.arena = c.ownArena.p;
     }
@@ -675,6 +746,57 @@ struct CtxExchange : pd::Exchange
             return;
         ++c.nAllGathers;
         c.allGatherBytes += static_cast<uint64_t>(bytesPerRank) * c.world;
+        if (c.group && !c.groupDecided)
+            groupDecide(c);
+        if (c.group && c.flagCarrier)
+        {
+            // exchange.hip: ack / push / wait in ONE kernel on the stream, the host stays out of it
+            if (c.world > pd::kXchMaxWorld)
+                throw HipError{"the device-side carrier holds 16 contexts; set POPDEL_HIP_GROUP_CARRIER=host"};
+            if (bytesPerRank % 16u != 0 || (static_cast<uint8_t *>(area) - c.arena) % 16 != 0)
+                throw HipError{"exchange area not 16-byte aligned"};
+            if (!c.peersEnabled)
+            {
+                for (uint32_t p = 0; p < c.world; ++p)
+                {
+                    const pd_ctx * peer = c.group->members[p];
+                    if (!peer)
+                        throw HipError{"a context of the local group is missing"};
+                    if (peer->device != c.device)
+                    {
+                        const hipError_t e = hipDeviceEnablePeerAccess(peer->device, 0);
+                        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                            throw HipError{std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e)};
+                        (void)hipGetLastError();
+                    }
+                }
+                c.peersEnabled = true;
+            }
+            PD_HIP(hipEventRecord(nextEvent(), st));
+            pd::FlagExchange x;
+            std::memset(&x, 0, sizeof(x));
+            x.myArena = c.arena;
+            x.myFlags = c.xchFlags;
+            for (uint32_t p = 0; p < c.world; ++p)
+            {
+                const pd_ctx * peer = c.group->members[p];
+                x.peerArena[p] = peer->arena;          // (stable: the buffers are replaced in a collective step, reserveArena)
+                x.peerFlags[p] = peer->xchFlags;
+            }
+            x.offset = static_cast<size_t>(static_cast<uint8_t *>(area) - c.arena);
+            x.bytesPerRank = bytesPerRank;
+            x.rank = c.rank;
+            x.world = c.world;
+            x.seq = ++c.xchSeq;
+            x.timeoutTicks = 300000000ull;              // 3 s of the 100-MHz wall clock
+            x.err = c.xchErr;
+            pd::launchFlagExchange(x, st);
+            PD_HIP(hipGetLastError());
+            if (c.xchDelayTicks)
+                pd::launchSpin(c.xchDelayTicks, st);
+            PD_HIP(hipEventRecord(nextEvent(), st));
+            return;
+        }
         if (c.group)
         {
             // every context pulls the other contexts' chunks out of their exchange buffers (same layout everywhere)
@@ -718,6 +840,18 @@ struct CtxExchange : pd::Exchange
     }
 };
 
+// The device-side carrier reports a wait that gave up through a page-locked word; call after a synchronisation point.
+void checkExchange(pd_ctx & c)
+{
+    if (c.xchErr && *c.xchErr != 0)
+    {
+        const unsigned code = *c.xchErr;
+        throw HipError{std::string("an exchange between the contexts of the local group timed out (waiting for a peer's ") +
+                       (code == 1 ? "acknowledgement" : "chunk") + "): a peer failed, or -- several contexts on ONE GPU -- their streams share a hardware "
+                       "queue (raise GPU_MAX_HW_QUEUES, or set POPDEL_HIP_GROUP_CARRIER=host for the host-driven carrier)"};
+    }
+}
+
 inline size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 template <typename T>
@@ -748,6 +882,7 @@ void cohortLifeHist(pd_ctx & c, unsigned long long * hist /* 66 counters, in: ow
     xch.allGather(area, per);
     PD_HIP(hipMemcpyAsync(c.hLifeXch.data(), area, per * c.world, hipMemcpyDeviceToHost, cs));
     PD_HIP(hipStreamSynchronize(cs));
+    checkExchange(c);
     for (int l = 0; l < 66; ++l)
     {
         unsigned long long sum = 0;
@@ -1757,6 +1892,22 @@ static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, p
         }
         if (group)
         {
+            const char * how = getenv("POPDEL_HIP_GROUP_CARRIER");
+            c->flagsWanted = !(how && std::strcmp(how, "host") == 0) && sh->world <= pd::kXchMaxWorld;
+            c->groupDecided = false;
+            if (c->flagsWanted)
+            {
+                void * f = nullptr;
+                PD_HIP(hipExtMallocWithFlags(&f, 2 * pd::kXchMaxWorld * sizeof(unsigned), hipDeviceMallocFinegrained));
+                PD_HIP(hipMemset(f, 0, 2 * pd::kXchMaxWorld * sizeof(unsigned)));
+                c->xchFlags = static_cast<unsigned *>(f);
+                void * e = nullptr;
+                PD_HIP(hipHostMalloc(&e, 64, hipHostMallocMapped));
+                c->xchErr = static_cast<unsigned *>(e);
+                *c->xchErr = 0;
+                c->xchSeq = 0;
+                PD_HIP(hipDeviceSynchronize());
+            }
             std::lock_guard<std::mutex> lock(group->m);
             group->members[sh->rank] = c;
             c->group = group;
@@ -1862,6 +2013,10 @@ void pd_ctx_destroy(pd_ctx * ctx)
         return;
     (void)hipSetDevice(ctx->device);
     laneTeardown(ctx);
+    if (ctx->xchFlags)
+        (void)hipFree(ctx->xchFlags);
+    if (ctx->xchErr)
+        (void)hipHostFree(ctx->xchErr);
     for (auto & r : ctx->runs)
     {
         if (r.second.s1Begin)
@@ -2808,6 +2963,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
                 hdr.resize(4 + 2 * kListCap);
                 PD_HIP(hipMemcpyAsync(hdr.data(), c->dCandHdr.p, hdr.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
                 PD_HIP(hipStreamSynchronize(c->stream));
+                checkExchange(*c);
                 const unsigned nFlagged = hdr[0], nListed = hdr[1];
                 if (getenv("POPDEL_HIP_DEBUG"))
                     fprintf(stderr, "[popdel_hip] %u flagged windows (room for %u), %u candidate cells\n", nFlagged, capF, nListed);
@@ -3129,6 +3285,7 @@ int pd_segment_collect(pd_ctx * c, uint64_t ticket, pd_calls ** out)
                 if (lastBatch && nBatches == 1 && !c->runs.empty() && !c->runs.begin()->second.launched)
                     launchScan(c, c->runs.begin()->second);
                 PD_HIP(hipEventSynchronize(c->cellsFetched));
+                checkExchange(*c);
                 if (!optimistic || c->hIterFlag[1] == 0)
                     break;
                 ++c->nRepeatedBatches;

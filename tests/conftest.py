@@ -6,6 +6,10 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# Several contexts of one process on ONE GPU (the local-group tests, `popdel call` with POPDEL_DEVICES=0,0) exchange through
+# kernels that wait for each other (exchange.hip): their streams must not share a hardware queue. Read by the HIP runtime when
+# it starts, hence set here, before anything imports torch; the library falls back to its host-driven carrier without it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "libpopdel_oracle.so")
 ORACLE_CALL = os.path.join(ROOT, "oracle", "_build", "popdel_oracle_call")

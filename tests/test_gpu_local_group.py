@@ -1,7 +1,10 @@
 """GPU (one device): several contexts of ONE process sharing a cohort by samples, the library exchanging between them itself
-(pd_ctx_set_shard_local: peer copies between the contexts' exchange buffers, bracketed by barriers of the host threads) --
-what `popdel call` does with POPDEL_DEVICES. On the one-GPU box all contexts sit on device 0; with several GPUs the
-same code copies over xGMI."""
+(pd_ctx_set_shard_local) -- what `popdel call` does with POPDEL_DEVICES. Two carriers: the device-side one of round 5
+(exchange.hip: one kernel per exchange acknowledges, pushes the context's chunk into the peers' buffers through peer-mapped
+pointers and waits for their flags; no host in the data path) and the host-driven one it replaces (peer copies bracketed by
+barriers of the host threads; POPDEL_HIP_GROUP_CARRIER=host, and the fallback when contexts share a GPU without hardware
+queues to spare). On the one-GPU box all contexts sit on device 0 (tests/conftest.py raises GPU_MAX_HW_QUEUES so that their
+streams do not share a queue); with several GPUs the same code writes over xGMI."""
 import os
 import subprocess
 import threading
@@ -14,8 +17,11 @@ from conftest import GOLDEN, POPDEL_BIN, run_call, strip_date
 pytestmark = pytest.mark.gpu
 
 
-def test_two_and_three_contexts_in_one_process_equal_one_context(built):
+@pytest.mark.parametrize("carrier", ["flags", "host"])
+def test_two_contexts_in_one_process_equal_one_context(built, monkeypatch, capfd, carrier):
     import ctypes as C
+    monkeypatch.setenv("POPDEL_HIP_GROUP_CARRIER", carrier)
+    monkeypatch.setenv("POPDEL_HIP_GROUP_TRACE", "1")
     from popdel_amd import capi
     from test_gpu_fuzz import random_case
     seg, rgs, offs, opts = random_case(13)                  # 300 samples? the cohort must fill the contexts with whole tiles
@@ -66,8 +72,11 @@ def test_two_and_three_contexts_in_one_process_equal_one_context(built):
     for t in threads:
         t.join()
     assert not errors, errors
+    assert all(c.timing()["n_all_gathers"] >= 9 for c in ctxs)
     for c in ctxs:
         c.close()
+    said = capfd.readouterr().err
+    assert ("device-side (flags) carrier" if carrier == "flags" else "host-driven carrier") in said
     hip.pd_local_group_destroy(group)
     for k in ("initial_length", "iterations", "deletion_length", "likelihood_ratio", "frequency", "window_position", "position",
               "end_position", "filter"):
