@@ -1088,7 +1088,7 @@ def main():
         env.pop("POPDEL_HIP_LANES", None)
         env.pop("POPDEL_HIP_XCH_DELAY_US", None)
         lanes_arg = "1" if LANES == 1 else "1,%d" % LANES
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sharded_model_probe.py"), sizes, "0,20,40", lanes_arg, str(n_pass)],
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sharded_model_probe.py"), sizes, "0,10,20,40", lanes_arg, str(n_pass)],
                            env=env, capture_output=True, text=True, timeout=args.sharded_timeout)
         probe = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not probe:
@@ -1097,13 +1097,14 @@ def main():
         for n in [int(x) for x in sizes.split(",")]:
             mine = {(p["lanes"], p["delay_us_per_exchange"]): p for p in probe if p["samples_per_rank"] == n}
             k = LANES if (LANES, 0.0) in mine else 1
-            zero, d20, d40 = mine[(k, 0.0)], mine[(k, 20.0)], mine[(k, 40.0)]
+            zero, d10, d20, d40 = mine[(k, 0.0)], mine[(k, 10.0)], mine[(k, 20.0)], mine[(k, 40.0)]
             row = dict(samples=n, passes=n_pass, lanes=k, unsharded_plain_ms_per_pass=zero["unsharded_one_lane_ms_per_pass"],
                        unsharded_ms_per_pass=zero["unsharded_same_lanes_ms_per_pass"], sharded_ms_per_pass=zero["modelled_ms_per_pass"],
                        exchange_ms_per_pass=zero["exchange_ms_per_pass"], all_gathers_per_pass=zero["all_gathers_per_pass"],
                        all_gather_bytes_per_pass=zero.get("all_gather_bytes_per_pass"),
                        modelled_20us_ms_per_pass=d20["modelled_ms_per_pass"], modelled_40us_ms_per_pass=d40["modelled_ms_per_pass"])
-            for kind, p in (("modelled_20us", d20), ("modelled_40us", d40)):
+            row["modelled_10us_ms_per_pass"] = d10["modelled_ms_per_pass"]
+            for kind, p in (("modelled_10us", d10), ("modelled_20us", d20), ("modelled_40us", d40)):
                 row[kind + "_efficiency"] = p["modelled_efficiency_vs_same_lanes"]
                 row[kind + "_efficiency_vs_plain_context"] = p["modelled_efficiency"]
             if (1, 40.0) in mine:
@@ -1116,7 +1117,7 @@ def main():
             out.append(row)
         return dict(what="per pass over the resident segment, in a process of its own (tools/sharded_model_probe.py): unsharded context vs. "
                          "the sample-sharded path with a communicator of ONE rank (library RCCL; exchanges issued and event-timed, no wire), and "
-                         "the same with 20 / 40 us of wire time injected behind every exchange (modelled_*: the latency model of a cohort "
+                         "the same with 10 / 20 / 40 us of wire time injected behind every exchange (modelled_*: the latency model of a cohort "
                          "sharded over several GPUs; modelled_efficiency = the 40-us row against the unsharded context WITH the bench's lanes, "
                          "..._vs_plain_context against an unsharded context without lanes, ..._one_lane_* the sharded context without lanes)", rows=out)
 

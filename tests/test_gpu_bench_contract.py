@@ -58,7 +58,7 @@ def test_bench_line_has_the_contract_fields(built):
         # ... and with the wire time of an exchange injected behind every one of them (the latency model of several GPUs)
         assert x["modelled_40us_ms_per_pass"] > x["sharded_ms_per_pass"] and 0 < x["modelled_efficiency"] == x["modelled_40us_efficiency"]
         assert x["modelled_efficiency_vs_plain_context"] > 0 and x["unsharded_plain_ms_per_pass"] > 0
-        assert x["modelled_20us_ms_per_pass"] > 0 and x["lanes"] == d["lanes_per_context"]
+        assert x["modelled_20us_ms_per_pass"] > 0 and x["modelled_10us_ms_per_pass"] > 0 and x["lanes"] == d["lanes_per_context"]
     # the headline's passes take several different resident segments in turn (the third of five has no deletion); the
     # single re-scanned segment of rounds 1-3 and the context without lanes are legs
     assert d["lanes_per_context"] == 3 and d["tickets_in_flight"] == 6
