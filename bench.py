@@ -1016,11 +1016,24 @@ def main():
         if t2 and t2.get("lik_first_units") and t2.get("lik_first_ms"):
             per_unit = 4.0 * t2["n_active_pairs"] / t2["n_cells"] + 4 + 24
             ach = t2["lik_first_units"] * per_unit / (t2["lik_first_ms"] / 1e3) / 1e9
+            # HBM bytes of that launch from the PMC passes of tools/profile_dense.sh on this very shape (the largest launch of the
+            # kernel in the probe = the one ahead of the loop; FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950 correction)
+            traffic2 = traffic2_src = None
+            for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+                if not name.endswith("_dense_pmc.json"):
+                    continue
+                pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+                k = pm.get("kernels", {}).get("pd::dataLikZeroShiftDenseKernel")
+                if pm.get("config") == {"samples": S, "cells": int(t2["n_candidate_cells"])} and k and "FETCH_SIZE" in k:
+                    traffic2 = (2.0 * k["FETCH_SIZE"]["max"] + k.get("WRITE_SIZE", {"max": 0.0})["max"]) * 1024.0
+                    traffic2_src = "profiles/" + name
+                    break
             legs["roofline_stage2"] = dict(
-                bound="hbm", kernel="dataLikDenseKernel", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                traffic=None, launch_ms=t2["lik_first_ms"], units_per_launch=t2["lik_first_units"],
+                bound="hbm", kernel="dataLikZeroShiftDenseKernel", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                traffic=traffic2, traffic_source=traffic2_src, launch_ms=t2["lik_first_ms"], units_per_launch=t2["lik_first_units"],
                 algorithmic_bytes_per_unit=per_unit, workload="candidate_dense leg (%d cells x %d samples)" % (t2["n_candidate_cells"], S),
-                accounting="the launch ahead of the EM loop (all candidate cells x all samples), HIP events on the context's stream; "
+                accounting="the data-likelihood launch ahead of the EM loop (zero reference shifts: all candidate cells x all samples, "
+                           "one workgroup per window image and sample tile), HIP events on the context's stream; "
                            "bytes = 4 per active pair + 4 + 24 per (cell, sample)",
                 limiter="per-lane gathers into per-sample lookup tables (two per active pair): L1 miss handling, see DESIGN.md")
         return dict(workload="%d samples x %d windows, %d planted deletions in the segment" % (S, W2, args.dense_deletions),

@@ -12,7 +12,7 @@ for f in sorted(glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k in sorted(acc):
-    out[k] = {c: {"launches": len(v), "mean": sum(v) / len(v)} for c, v in sorted(acc[k].items())}
+    out[k] = {c: {"launches": len(v), "mean": sum(v) / len(v), "max": max(v)} for c, v in sorted(acc[k].items())}
     print(k)
     for c, d in out[k].items():
         print("    %-34s launches %5d  mean %.6g" % (c, d["launches"], d["mean"]))

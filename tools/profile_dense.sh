@@ -18,5 +18,6 @@ pass sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum
 pass fetch FETCH_SIZE
+pass write WRITE_SIZE
 pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
 ls "$OUT"
