@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64) void scatterKernel(InstanceArrays in, BuildEnti
                         out.start[base + place] = p.start;
                     }
                     if (packed)
-                        out.pairsPk[base + place] = make_uint2(d16 | (d16 << 16), (chunkOff & 0xffffu) | (chunkOff << 16));
+                        out.pairsPk[base + place] = d16 | ((chunkOff & 0xffffu) << 16);
                 }
             }
         }

@@ -248,7 +248,7 @@ struct StagedSegment
     DevBuf<uint32_t> start;
     DevBuf<uint64_t> rgBase;
     DevBuf<uint32_t> winStart;
-    DevBuf<uint2> pairsPk;
+    DevBuf<uint32_t> pairsPk;
     DevBuf<uint32_t> endCount;
     DevBuf<uint8_t> rgPacked;
     // index of the stage-1 image when it is cut with its own chunk life (SegmentView::maxLifePk); else the arrays above
@@ -428,7 +428,7 @@ struct pd_ctx
     PinnedBuf<pd::PairDO> hPairs;
     PinnedBuf<uint32_t> hStart, hWinStart, hEndCount;
     std::vector<uint64_t> hRgBase;
-    PinnedBuf<uint2> hPairsPk;
+    PinnedBuf<uint32_t> hPairsPk;
     std::vector<uint8_t> hRgPacked, hScanGeneric;
     // page-locked staging for the small control transfers of a collect (window flags, candidate lists, cell records,
     // counters): pageable memory costs every one of these round trips an extra bounce copy
@@ -899,7 +899,7 @@ void cohortLifeHist(pd_ctx & c, unsigned long long * hist /* 66 counters, in: ow
 template <typename Sized, typename SlabDone>
 void buildChunks(pd_ctx & c, const pd_segment & seg, StagedSegment & out, PinnedBuf<pd::PairDO> & pairs,
                  PinnedBuf<uint32_t> & start, std::vector<uint64_t> & rgBase, PinnedBuf<uint32_t> & winStart,
-                 PinnedBuf<uint2> & pairsPk, PinnedBuf<uint32_t> & endCount, std::vector<uint8_t> & rgPacked,
+                 PinnedBuf<uint32_t> & pairsPk, PinnedBuf<uint32_t> & endCount, std::vector<uint8_t> & rgPacked,
                  std::vector<uint8_t> & scanGeneric, Sized sized, SlabDone slabDone)
 {
     const uint32_t W = seg.n_windows;
@@ -1063,7 +1063,7 @@ void buildChunks(pd_ctx & c, const pd_segment & seg, StagedSegment & out, Pinned
                         pairs[base + slot] = pd::PairDO{dv, chunkOff};
                         start[base + slot] = seg.pair_start[i];
                     }
-                    pairsPk[base + slot] = make_uint2(d16 | (d16 << 16), (chunkOff & 0xffffu) | (chunkOff << 16));
+                    pairsPk[base + slot] = d16 | ((chunkOff & 0xffffu) << 16);
                     ++ec[chunkOff];
                 }
             }
@@ -1223,7 +1223,7 @@ bool buildLayoutOnDevice(pd_ctx & c, const pd::InstanceArrays & in, uint64_t nIn
     // ---- chunks to their places
     out.pairs.ensure(totalReal);
     out.start.ensure(totalReal);
-    out.pairsPk.ensure(totalPk + 128);             // the scan's LDS-DMA copies whole 128-chunk pieces (stage1.hip)
+    out.pairsPk.ensure(totalPk + 256);             // the scan's LDS-DMA copies whole 256-chunk pieces (stage1.hip)
     {
         pd::ScatterOut so;
         so.pairs = out.pairs.p;
@@ -2237,7 +2237,7 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
         PinnedBuf<pd::PairDO> & pairs = c->hPairs;
         PinnedBuf<uint32_t> &start = c->hStart, &winStart = c->hWinStart, &endCount = c->hEndCount;
         std::vector<uint64_t> & rgBase = c->hRgBase;
-        PinnedBuf<uint2> & pairsPk = c->hPairsPk;
+        PinnedBuf<uint32_t> & pairsPk = c->hPairsPk;
         std::vector<uint8_t> & rgPacked = c->hRgPacked;
         // Uploads go over the copy stream: a ticket that is running on the compute stream is not held up by the staging
         // of the next segment (double-buffered streaming: run(N), stage(N+1), collect(N), run(N+1), ...), and they go
@@ -2247,7 +2247,7 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
         auto sized = [&]() {
             s->pairs.ensure(pairs.size());
             s->start.ensure(start.size());
-            s->pairsPk.ensure(pairsPk.size() + 128);     // the scan's LDS-DMA copies whole 128-chunk pieces (stage1.hip)
+            s->pairsPk.ensure(pairsPk.size() + 256);     // the scan's LDS-DMA copies whole 256-chunk pieces (stage1.hip)
             s->endCount.ensure(endCount.size());
             s->rgBase.upload(rgBase, cs);
             s->winStart.uploadPinned(winStart, cs);
@@ -2261,7 +2261,7 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
                     PD_HIP(hipMemcpyAsync(s->pairs.p + a, pairs.data() + a, (b - a) * sizeof(pd::PairDO), hipMemcpyHostToDevice, cs));
                     PD_HIP(hipMemcpyAsync(s->start.p + a, start.data() + a, (b - a) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
                 }
-                PD_HIP(hipMemcpyAsync(s->pairsPk.p + a, pairsPk.data() + a, (b - a) * sizeof(uint2), hipMemcpyHostToDevice, cs));
+                PD_HIP(hipMemcpyAsync(s->pairsPk.p + a, pairsPk.data() + a, (b - a) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
             }
             const size_t e0 = lo * (static_cast<size_t>(W) + 1), e1 = hi * (static_cast<size_t>(W) + 1);
             PD_HIP(hipMemcpyAsync(s->endCount.p + e0, endCount.data() + e0, (e1 - e0) * sizeof(uint32_t), hipMemcpyHostToDevice, cs));

@@ -46,7 +46,7 @@ struct ScatterOut
 {
     PairDO *         pairs;       // [real chunks]   stage-2 arrays, or null
     uint32_t *       start;       // [real chunks]
-    uint2 *          pairsPk;     // [all chunks]    stage-1 image, or null
+    uint32_t *       pairsPk;     // [all chunks]    stage-1 image (dev16 biased | end window << 16), or null
     const uint64_t * rgBase;
     const uint32_t * winStart;
 };

@@ -58,9 +58,10 @@ struct SegmentView
     // (carried over or new) has slot (its end window - 1), so carried-over pairs leave the candidate range exactly when
     // they end. Window w sees the slots [w, w + K): chunks [winStart[w], winStart[w + K]). Row length W + K.
     const uint32_t * winStart;     // [nRg * (W + K)] first chunk (relative to rgBase) whose slot >= x
-    // stage-1 image of the chunks: deviation and end window as int16, each duplicated into both halves of a dword
-    // (ready for packed 16-bit arithmetic on two windows at once); only valid for read groups with rgPacked != 0
-    const uint2 *    pairsPk;      // [chunks of the stage-1 image]
+    // stage-1 image of the chunks, 4 bytes each (round 5; 8 in rounds 1-4, each half duplicated for the packed arithmetic of the
+    // full scan, which now duplicates on the fly): the deviation as int16 biased by 0x8000 in the low half, the end window in
+    // the high half; only valid for read groups with rgPacked != 0
+    const uint32_t * pairsPk;      // [chunks of the stage-1 image]
     const uint32_t * endCount;     // [nRg * (W + 1)] number of chunks of the read group that ended at or before w
     // The stage-1 image is cut with ITS OWN chunk life (maxLifePk <= maxLife) and has its own index: Q3 is an order
     // statistic of integers and does not depend on how the pairs are cut, so the scan takes the life that makes it

@@ -249,12 +249,21 @@ __device__ __forceinline__ unsigned pkSignMask(unsigned a)          // 0xFFFF in
     return __builtin_bit_cast(unsigned, (v2s)(__builtin_bit_cast(v2s, a) >> 15));
 }
 
-// LDS image of a staged chunk: deviation and (segment-relative) end window, each duplicated into both halves.
+// A staged chunk is one dword: deviation (biased int16) in the low half, (segment-relative) end window in the high half. The
+// packed arithmetic below wants each of them in BOTH halves of a register: one v_perm_b32 each (rounds 1-4 kept the chunks
+// expanded, 8 bytes each, in HBM and LDS: twice the bytes for the screen, which reads every chunk once and duplicates nothing).
 struct PairPk
 {
     unsigned devdev;
     unsigned offoff;
 };
+__device__ __forceinline__ PairPk expandChunk(unsigned e)
+{
+    PairPk p;
+    p.devdev = __builtin_amdgcn_perm(e, e, 0x01000100u);
+    p.offoff = __builtin_amdgcn_perm(e, e, 0x03020302u);
+    return p;
+}
 
 // Two ADJACENT windows per lane (w in the low halves, w + 1 in the high halves). Their candidate ranges overlap almost
 // completely, so every LDS entry is read once and feeds both cells: slot c of the lane is entry (aA + c) for both.
@@ -289,7 +298,7 @@ __device__ __forceinline__ unsigned asmPkSign(unsigned a)                       
 }
 
 template <int C>
-__device__ __forceinline__ void stage1PairFast(const PairPk * lds, unsigned aA, unsigned wPk, unsigned cntPk, unsigned nA,
+__device__ __forceinline__ void stage1PairFast(const uint32_t * lds, unsigned aA, unsigned wPk, unsigned cntPk, unsigned nA,
                                                unsigned nB, int & vaA, int & vbA, int & vaB, int & vbB)
 {
     constexpr unsigned T = (3u * C + 2u - 4u) >> 2;        // l0(C): 23 / 29 / 35 / 41 / 47 for 32 / 40 / 48 / 56 / 64 slots
@@ -304,8 +313,8 @@ __device__ __forceinline__ void stage1PairFast(const PairPk * lds, unsigned aA, 
 #pragma unroll
     for (int c = 0; c < C; ++c)
     {
-        const PairPk e = lds[aA + c];
-        // INACTIVE <=> off <= w (off - (w + 1) negative) or c >= cnt: 7 VALU per slot for the two cells
+        const PairPk e = expandChunk(lds[aA + c]);
+        // INACTIVE <=> off <= w (off - (w + 1) negative) or c >= cnt: 7 VALU per slot for the two cells (+ 2 for the expansion)
         // (a native formulation -- vector types, shift amount hidden from the optimiser -- compiled to 8 and ran 7 % slower)
         const unsigned mI = asmPkSign(asmPkSub(e.offoff, w1Pk) | rPk);
         vPk = asmPkAdd(vPk, mI);                           // one filler more
@@ -355,7 +364,7 @@ __device__ __forceinline__ void storeCell(unsigned n, unsigned maxLoad, int va, 
 template <int kLdsPairs, bool kBig>
 __device__ __forceinline__ int scanBlock(const SegmentView & seg, const CohortView & co, int32_t * __restrict__ q3,
                                          uint8_t * __restrict__ flags, int * __restrict__ winFlag, unsigned s, unsigned bx,
-                                         unsigned blocksPerSample, PairPk * ldsPairs, uint32_t * ldsWs, unsigned short * ldsN,
+                                         unsigned blocksPerSample, uint32_t * ldsPairs, uint32_t * ldsWs, unsigned short * ldsN,
                                          unsigned short * unitOrder, unsigned (*classCount)[kStage1Block / 64])
 {
     constexpr unsigned kMaxCand = kBig ? 128u : 64u;
@@ -383,19 +392,19 @@ __device__ __forceinline__ int scanBlock(const SegmentView & seg, const CohortVi
     const unsigned nPairs = ldsWs[nWs - 1] - A0;
     const bool tooMany = nPairs > (unsigned)kLdsPairs;               // workgroup-uniform
     // The LDS image is the HBM image: the chunks of the block are copied by LDS-DMA (global_load_lds_dwordx4: 64 lanes x
-    // 16 B = 128 chunks per wave instruction, no VGPR round trip, no ds_write, no per-element address arithmetic; the
+    // 16 B = 256 chunks per wave instruction, no VGPR round trip, no ds_write, no per-element address arithmetic; the
     // register-staged copy cost ~100 VALU per wave). The source is aligned down to 16 bytes: LDS entry i is stream entry
-    // A + i with A = A0 - mis; the last instruction may copy up to 127 chunks beyond the block's (both arrays are padded).
+    // A + i with A = A0 - mis; the last instruction may copy up to 255 chunks beyond the block's (both arrays are padded).
     const size_t g0 = seg.rgBasePk[rg0] + A0;
-    const unsigned mis = (unsigned)(g0 & 1u);
+    const unsigned mis = (unsigned)(g0 & 3u);
     const unsigned A = A0 - mis;
     if (!tooMany)
     {
-        const uint2 * src = seg.pairsPk + (g0 - mis);
+        const uint32_t * src = seg.pairsPk + (g0 - mis);
         const unsigned nCopy = nPairs + mis;
         const unsigned lane = tid & 63u;
-        for (unsigned base = (tid >> 6) * 128u; base < nCopy; base += (unsigned)(kStage1Block / 64) * 128u)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + base + 2u * lane),
+        for (unsigned base = (tid >> 6) * 256u; base < nCopy; base += (unsigned)(kStage1Block / 64) * 256u)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + base + 4u * lane),
                                              (__attribute__((address_space(3))) void *)(ldsPairs + base), 16, 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -541,7 +550,7 @@ __device__ __forceinline__ void scanKernelBody(const SegmentView & seg, const Co
                                                uint8_t * __restrict__ flags, int * __restrict__ winFlag, uint8_t * __restrict__ tileTodo,
                                                unsigned * __restrict__ todoList, unsigned * __restrict__ bigList, unsigned tilesPerSample)
 {
-    __shared__ __attribute__((aligned(16))) PairPk ldsPairs[kLdsPairs + 128];
+    __shared__ __attribute__((aligned(16))) uint32_t ldsPairs[kLdsPairs + 256];
     __shared__ uint32_t ldsWs[kPackedWsLen];
     __shared__ unsigned short ldsN[kPackedWindows];
     __shared__ unsigned short unitOrder[kStage1Block];
@@ -591,7 +600,7 @@ __global__ __launch_bounds__(kStage1Block) __attribute__((amdgpu_waves_per_eu(7,
     uint8_t * __restrict__ tileTodo, unsigned * __restrict__ todoList, unsigned * __restrict__ bigList, unsigned tilesPerSample,
     unsigned blocksPerSample, unsigned nBlocks, unsigned * __restrict__ counter)
 {
-    __shared__ __attribute__((aligned(16))) PairPk ldsPairs[kPackedLdsSmall + 128];
+    __shared__ __attribute__((aligned(16))) uint32_t ldsPairs[kPackedLdsSmall + 256];
     __shared__ uint32_t ldsWs[kPackedWsLen];
     __shared__ unsigned short ldsN[kPackedWindows];
     __shared__ unsigned short unitOrder[kStage1Block];
@@ -631,7 +640,7 @@ __global__ __launch_bounds__(kStage1Block) void stage1BigKernel(SegmentView seg,
                                                                 const unsigned * __restrict__ bigList, unsigned tilesPerSample,
                                                                 unsigned blocksPerSample)
 {
-    __shared__ __attribute__((aligned(16))) PairPk ldsPairs[kPackedLdsHuge + 128];
+    __shared__ __attribute__((aligned(16))) uint32_t ldsPairs[kPackedLdsHuge + 256];
     __shared__ uint32_t ldsWs[kPackedWsLen];
     __shared__ unsigned short ldsN[kPackedWindows];
     __shared__ unsigned short unitOrder[kStage1Block];
@@ -697,13 +706,13 @@ __global__ __launch_bounds__(kStage1Block) void stage1FallbackKernel(SegmentView
                 }
                 else
                 {
-                    const uint2 * src = seg.pairsPk + seg.rgBasePk[rg0] + A;
+                    const uint32_t * src = seg.pairsPk + seg.rgBasePk[rg0] + A;
                     for (unsigned i = tid; i < nPairs; i += kStage1Block)
                     {
-                        const uint2 e = src[i];
+                        const uint32_t e = src[i];
                         PairDO p;
-                        p.dev = (int)(short)((e.x & 0xffffu) ^ 0x8000u);      // the packed image is biased
-                        p.off = e.y & 0xffffu;
+                        p.dev = (int)(short)((e & 0xffffu) ^ 0x8000u);        // the packed image is biased
+                        p.off = e >> 16;
                         ldsPairs[i] = p;
                     }
                 }
@@ -770,13 +779,13 @@ __device__ __forceinline__ bool screenMaybe(unsigned n, unsigned c)
     return k == 0u ? c >= need : c + 1u >= need;        // c == need - 1: only b > T, decided by the exact pass
 }
 
-// A workgroup takes kScreenBlocks adjacent 512-window blocks of one sample (1,024 windows, ~3,200 chunks = 26 KB of
-// stream): every global load it needs -- the window index into LDS, the end counts, the chunks themselves (eight 16-byte
-// loads per lane, held in registers) -- is issued before its first barrier, so that a CU's eight resident workgroups keep
-// ~200 KB in flight. Lane t owns the windows t, t + 256, ... of the workgroup (byte stores of a wave are contiguous).
+// A workgroup takes kScreenBlocks adjacent 512-window blocks of one sample (1,024 windows, ~3,200 chunks = 13 KB of
+// stream): every global load it needs -- the window index into LDS, the end counts, the chunks themselves (four 16-byte
+// loads per lane, four chunks each, held in registers) -- is issued before its first barrier. Lane t owns the windows t,
+// t + 256, ... of the workgroup (byte stores of a wave are contiguous).
 constexpr int kScreenBlocks = 2;
 constexpr int kScreenWindows = kScreenBlocks * kPackedWindows;
-constexpr int kScreenPre = 8;                     // chunk loads per lane issued ahead of the barrier (2 chunks each)
+constexpr int kScreenPre = 4;                     // chunk loads per lane issued ahead of the barrier (4 chunks each)
 
 __global__ __launch_bounds__(kStage1Block) void screenKernel(SegmentView seg, CohortView co, uint8_t * __restrict__ flags,
                                                              int * __restrict__ winFlag, uint8_t * __restrict__ tileTodo,
@@ -807,10 +816,10 @@ __global__ __launch_bounds__(kStage1Block) void screenKernel(SegmentView seg, Co
     const unsigned A0 = ws[w0];
     const unsigned nPairs = ws[w0 + nWs - 1u] - A0;
     const size_t g0 = seg.rgBasePk[rg0] + A0;
-    const unsigned mis = (unsigned)(g0 & 1u);
+    const unsigned mis = (unsigned)(g0 & 3u);
     const unsigned nCopy = nPairs + mis;                                        // stream entries [A0 - mis, A0 + nPairs)
     const v4u * src = reinterpret_cast<const v4u *>(seg.pairsPk + (g0 - mis));
-    const unsigned nLoads = (nCopy + 1u) >> 1;
+    const unsigned nLoads = (nCopy + 3u) >> 2;
     v4u pre[kScreenPre];
 #pragma unroll
     for (int k = 0; k < kScreenPre; ++k)
@@ -832,7 +841,7 @@ __global__ __launch_bounds__(kStage1Block) void screenKernel(SegmentView seg, Co
     const int T = co.minThreshold;
     __syncthreads();
     // a chunk that exceeds T: one more active big pair in every window it is active in (slot x sees windows (x - K, x])
-    auto hit = [&](unsigned j, unsigned offoff) {
+    auto hit = [&](unsigned j, unsigned chunk) {
         if (j < mis || j >= nCopy)
             return;
         const unsigned pos = A0 - mis + j;
@@ -846,18 +855,17 @@ __global__ __launch_bounds__(kStage1Block) void screenKernel(SegmentView seg, Co
                 hi = mid;
         }
         const int slot = (int)(w0 + lo);
-        const int off = (int)(offoff & 0xffffu);
+        const int off = (int)(chunk >> 16);
         const int first = max((int)w0, slot - (int)K + 1);
         const int last = min(min(slot, off - 1), (int)whi - 1);
         for (int w = first; w <= last; ++w)
             atomicAdd(&ldsCnt[w - (int)w0], 1u);
     };
     auto look = [&](unsigned i, const v4u & v) {
-        const int d0 = (int)(short)((v.x & 0xffffu) ^ 0x8000u), d1 = (int)(short)((v.z & 0xffffu) ^ 0x8000u);
-        if (d0 > T)
-            hit(2u * i, v.y);
-        if (d1 > T)
-            hit(2u * i + 1u, v.w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((int)(short)((v[k] & 0xffffu) ^ 0x8000u) > T)
+                hit(4u * i + (unsigned)k, v[k]);
     };
 #pragma unroll
     for (int k = 0; k < kScreenPre; ++k)
@@ -922,7 +930,7 @@ __device__ __forceinline__ void exactPairStore(const SegmentView & seg, const Co
                                                int32_t * __restrict__ q3, uint8_t * __restrict__ flags, int * __restrict__ winFlag)
 {
     const unsigned W = seg.nWindows, wB = wA + 1u;
-    const PairPk * stream = reinterpret_cast<const PairPk *>(seg.pairsPk + seg.rgBasePk[rg0]);
+    const uint32_t * stream = seg.pairsPk + seg.rgBasePk[rg0];
     int vaA, vbA, vaB, vbB;
     stage1PairFast<C>(stream, xA, wA | (wB << 16), cntA | (endB << 16), nA, nB, vaA, vbA, vaB, vbB);
     const unsigned maxLoad = co.rg[rg0].maxLoad;
@@ -1036,7 +1044,7 @@ void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, 
     else if (maxBlockChunks <= (unsigned)kPackedLdsSmall && room.mode == ScanRoom::kLdsCap)
     {
         // unused dynamic LDS on top of the kernel's own so that at most wgPerCu workgroups fit the CU's 160 KB
-        constexpr unsigned kOwn = (kPackedLdsSmall + 128) * 8 + kPackedWsLen * 4 + kPackedWindows * 2 + kStage1Block * 2 + 6 * (kStage1Block / 64) * 4;
+        constexpr unsigned kOwn = (kPackedLdsSmall + 256) * 4 + kPackedWsLen * 4 + kPackedWindows * 2 + kStage1Block * 2 + 6 * (kStage1Block / 64) * 4;
         const unsigned want = 163840u / (room.wgPerCu + 1u) + 1536u;
         const unsigned pad = want > kOwn ? want - kOwn : 0u;
         hipLaunchKernelGGL(stage1Kernel, grid, dim3(kStage1Block), pad, stream, seg, co, q3, flags, winFlag, tileTodo,
