@@ -497,11 +497,11 @@ def main():
         # `value`, whole_path_frac and contract_frac are quoted on
         alg_bytes = 4 * tinfo["n_active_pairs"] + 4 * cells + 4 * cells
         # What the scan's own algorithm has to move (round 5: the screen looks at every pair CHUNK once instead of once per window
-        # it is active in): 4 B per chunk + the slot index and the end counts (4 B each per window and sample) + 1 B of flags
-        # per cell. This is what `achieved` / `frac` are quoted on -- a true fraction of the HBM peak, to be read next to the
+        # it is active in): 4 B per chunk + 1 B of active count in and 1 B of flags out per cell (the slot index is touched at the
+        # block borders and by the rare chunks beyond the threshold only). This is what `achieved` / `frac` are quoted on -- a true fraction of the HBM peak, to be read next to the
         # counters' `traffic`; in the contract's accounting the kernel would stand ABOVE the peak (contract_frac), which only says
         # that the expanded gather the survey priced is not what is read.
-        compact_bytes = 4 * tinfo["n_pair_chunks"] + 4 * (W + tinfo["max_life"]) * h["cohort_local"] + 4 * (W + 1) * h["cohort_local"] + 1 * cells
+        compact_bytes = 4 * tinfo["n_pair_chunks"] + 1 * cells + 1 * cells
         achieved = compact_bytes / s1_mean_s / 1e9
         # HBM bytes per launch and SQ counters from rocprofv3 --pmc passes on exactly this launch shape and THIS build of
         # the scan kernel (the summary carries a hash of the kernel's sources); dropped when either does not match.
@@ -518,7 +518,7 @@ def main():
         roofline = dict(bound="hbm", kernel="screenKernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                         accounting="achieved = the bytes the scan's algorithm must read and write per launch (4 B per pair chunk -- "
-                                   "each chunk is read ONCE --, 8 B of slot index and end count and 1 B of flags per cell: "
+                                   "each chunk is read ONCE --, 1 B of active count and 1 B of flags per cell: "
                                    "algorithmic_bytes_per_launch) / mean launch time; `traffic` = the PMC counters' HBM bytes of the "
                                    "same launch. SURVEY 8(d)'s contract figure (4 B per active pair of the expanded [samples x windows "
                                    "x pairs] gather + 8 B per cell: contract_bytes_per_launch) prices every pair once per window it is "

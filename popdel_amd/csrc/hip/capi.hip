@@ -35,6 +35,8 @@ void launchStage1(const SegmentView & seg, const CohortView & co, int32_t * q3, 
                   hipStream_t stream);
 void launchStage1Fallback(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
                           uint8_t * tileTodo, unsigned * todoList, const unsigned * bigList, hipStream_t stream);
+void launchActive8(const uint32_t * winStartPk, const uint32_t * endCountPk, unsigned nEntities, unsigned W, unsigned K, uint8_t * out,
+                   hipStream_t stream);
 void launchScreen(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag, uint8_t * tileTodo,
                   unsigned * todoList, hipStream_t stream);
 void launchScreenFallback(const SegmentView & seg, const CohortView & co, int32_t * q3, uint8_t * flags, int * winFlag,
@@ -254,6 +256,7 @@ struct StagedSegment
     // index of the stage-1 image when it is cut with its own chunk life (SegmentView::maxLifePk); else the arrays above
     DevBuf<uint64_t> rgBasePk;
     DevBuf<uint32_t> winStartPk, endCountPk;
+    DevBuf<uint8_t> active8;                // n(w) per (stream, window), capped at 255 (SegmentView::active8)
     uint32_t maxLifePk = 0;
     bool ownPkIndex = false;
     hipEvent_t built = nullptr;             // device-side build: recorded behind its last kernel (copy stream); runs wait for it
@@ -1256,6 +1259,11 @@ bool buildLayoutOnDevice(pd_ctx & c, const pd::InstanceArrays & in, uint64_t nIn
         pd::launchScanGeneric(en, c.dRg.p, out.winStart.p, out.endCount.p, W, K, out.scanGeneric.p, static_cast<unsigned>(blocksPerSample), cs);
         PD_HIP(hipGetLastError());
     }
+    // the screen's one byte per cell (after the index of the stage-1 image is final)
+    out.active8.ensure(static_cast<size_t>(nEnt) * W);
+    pd::launchActive8(out.ownPkIndex ? out.winStartPk.p : out.winStart.p, out.ownPkIndex ? out.endCountPk.p : out.endCount.p, nEnt, W,
+                      out.ownPkIndex ? out.maxLifePk : out.maxLife, out.active8.p, cs);
+    PD_HIP(hipGetLastError());
     return true;
 }
 
@@ -1538,6 +1546,7 @@ pd::SegmentView viewOf(const StagedSegment & s)
     v.winStartPk = s.ownPkIndex ? s.winStartPk.p : s.winStart.p;
     v.endCountPk = s.ownPkIndex ? s.endCountPk.p : s.endCount.p;
     v.maxLifePk = s.ownPkIndex ? s.maxLifePk : s.maxLife;
+    v.active8 = s.active8.p;
     v.rgPacked = s.rgPacked.p;
     v.scanRg = s.scanRg;
     v.scanGeneric = s.hasScanGeneric ? s.scanGeneric.p : nullptr;
@@ -2274,6 +2283,12 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
             s->scanGeneric.upload(c->hScanGeneric, cs);
         s->scanRg = c->dScanRg.p;
         s->nRealRg = c->nRg;
+        {
+            const uint32_t nEnt = static_cast<uint32_t>(winStart.size() / (static_cast<size_t>(W) + s->maxLife));
+            s->active8.ensure(static_cast<size_t>(nEnt) * W);
+            pd::launchActive8(s->winStart.p, s->endCount.p, nEnt, W, s->maxLife, s->active8.p, cs);
+            PD_HIP(hipGetLastError());
+        }
         PD_HIP(hipStreamSynchronize(cs));              // the host scratch is reused by the next call
         *handle = c->nextHandle++;
         putStaged(c, *handle, std::move(s));

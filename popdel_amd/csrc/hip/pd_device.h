@@ -71,6 +71,8 @@ struct SegmentView
     const uint32_t * winStartPk;   // [(nRg + nScanRg) * (W + maxLifePk)]
     const uint32_t * endCountPk;   // [(nRg + nScanRg) * (W + 1)]
     uint32_t         maxLifePk;
+    const uint8_t *  active8;      // [(nRg + nScanRg) * W] active chunks of the stream in window w = winStartPk[w + K] - endCountPk[w],
+                                   // capped at 255 (255: look the two up): all the screen needs of the index per cell (round 5)
     const uint8_t *  rgPacked;     // [nRg + nScanRg] 1 if all deviations fit int16 and W fits 16 bits
     // Samples with several read groups get a "scan read group" appended behind the real ones: the chunks of all their
     // read groups as ONE stream (stage-1 image, winStart and endCount rows only), so that the scan kernel treats them

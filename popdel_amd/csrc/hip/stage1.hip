@@ -780,12 +780,33 @@ __device__ __forceinline__ bool screenMaybe(unsigned n, unsigned c)
 }
 
 // A workgroup takes kScreenBlocks adjacent 512-window blocks of one sample (1,024 windows, ~3,200 chunks = 13 KB of
-// stream): every global load it needs -- the window index into LDS, the end counts, the chunks themselves (four 16-byte
-// loads per lane, four chunks each, held in registers) -- is issued before its first barrier. Lane t owns the windows t,
-// t + 256, ... of the workgroup (byte stores of a wave are contiguous).
+// stream): every global load it needs -- the active counts, the chunks themselves (four 16-byte loads per lane, four chunks
+// each, held in registers) -- is issued before its first barrier. Lane t owns the windows t, t + 256, ... of the workgroup
+// (byte loads and stores of a wave are contiguous). Measured per 10,000 x 6,667 launch: 512 / 1,024 / 2,048 windows per
+// workgroup 0.288 / 0.217 / 0.255 ms.
 constexpr int kScreenBlocks = 2;
 constexpr int kScreenWindows = kScreenBlocks * kPackedWindows;
 constexpr int kScreenPre = 4;                     // chunk loads per lane issued ahead of the barrier (4 chunks each)
+
+// n(w) of every (stream, window) as one byte (capped at 255), from the index the build leaves: the screen reads 1 B per cell
+// instead of the two 4-byte index rows (which were 0.53 of its 1.42 GB per 10,000 x 6,667 launch). Part of staging.
+__global__ __launch_bounds__(256) void active8Kernel(const uint32_t * __restrict__ winStartPk, const uint32_t * __restrict__ endCountPk,
+                                                     unsigned W, unsigned K, uint8_t * __restrict__ out)
+{
+    const unsigned e = blockIdx.y, w = blockIdx.x * 256u + threadIdx.x;
+    if (w >= W)
+        return;
+    const unsigned n = winStartPk[(size_t)e * (W + K) + w + K] - endCountPk[(size_t)e * (W + 1) + w];
+    out[(size_t)e * W + w] = (uint8_t)min(n, 255u);
+}
+
+void launchActive8(const uint32_t * winStartPk, const uint32_t * endCountPk, unsigned nEntities, unsigned W, unsigned K, uint8_t * out,
+                   hipStream_t stream)
+{
+    if (nEntities == 0 || W == 0)
+        return;
+    hipLaunchKernelGGL(active8Kernel, dim3((W + 255u) / 256u, nEntities), dim3(256), 0, stream, winStartPk, endCountPk, W, K, out);
+}
 
 __global__ __launch_bounds__(kStage1Block) void screenKernel(SegmentView seg, CohortView co, uint8_t * __restrict__ flags,
                                                              int * __restrict__ winFlag, uint8_t * __restrict__ tileTodo,
@@ -793,7 +814,6 @@ __global__ __launch_bounds__(kStage1Block) void screenKernel(SegmentView seg, Co
                                                              unsigned blocksPerSample)
 {
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    __shared__ uint32_t ldsWs[kScreenWindows + 64 + 2];
     __shared__ unsigned ldsCnt[kScreenWindows];
     const unsigned s = blockIdx.y, bx0 = blockIdx.x * kScreenBlocks;
     const unsigned w0 = bx0 * kPackedWindows;
@@ -812,7 +832,7 @@ __global__ __launch_bounds__(kStage1Block) void screenKernel(SegmentView seg, Co
     const uint32_t * ws = seg.winStartPk + (size_t)rg0 * (W + K);
     const unsigned whi = min(W, w0 + kScreenWindows);
     const unsigned nWs = whi - w0 + K;
-    // (the stream's extent straight from HBM -- a uniform address, a scalar load -- so that the chunk loads do not wait for LDS)
+    // (the stream's extent: uniform addresses, scalar loads)
     const unsigned A0 = ws[w0];
     const unsigned nPairs = ws[w0 + nWs - 1u] - A0;
     const size_t g0 = seg.rgBasePk[rg0] + A0;
@@ -827,29 +847,28 @@ __global__ __launch_bounds__(kStage1Block) void screenKernel(SegmentView seg, Co
         const unsigned i = tid + (unsigned)k * kStage1Block;
         pre[k] = __builtin_nontemporal_load(src + min(i, nLoads ? nLoads - 1u : 0u));        // (clamped: the value is ignored)
     }
-    for (unsigned i = tid; i < nWs; i += kStage1Block)
-        ldsWs[i] = ws[w0 + i];
-    const uint32_t * ec = seg.endCountPk + (size_t)rg0 * (W + 1);
-    unsigned ended[kScreenWindows / kStage1Block];
+    const uint8_t * n8 = seg.active8 + (size_t)rg0 * W;
+    unsigned nAct[kScreenWindows / kStage1Block];
 #pragma unroll
     for (int k = 0; k < kScreenWindows / kStage1Block; ++k)
     {
         const unsigned w = w0 + tid + (unsigned)k * kStage1Block;
-        ended[k] = w < W ? ec[w] : 0u;
+        nAct[k] = w < W ? n8[w] : 0u;
         ldsCnt[tid + (unsigned)k * kStage1Block] = 0u;
     }
     const int T = co.minThreshold;
     __syncthreads();
-    // a chunk that exceeds T: one more active big pair in every window it is active in (slot x sees windows (x - K, x])
+    // a chunk that exceeds T (rare): one more active big pair in every window it is active in (slot x sees windows (x - K, x]);
+    // its slot by bisection in the stream's window index, read where it lies
     auto hit = [&](unsigned j, unsigned chunk) {
         if (j < mis || j >= nCopy)
             return;
         const unsigned pos = A0 - mis + j;
-        unsigned lo = 0u, hi = nWs - 1u;                 // ldsWs[lo] <= pos < ldsWs[hi]
+        unsigned lo = 0u, hi = nWs - 1u;                 // ws[w0 + lo] <= pos < ws[w0 + hi]
         while (hi - lo > 1u)
         {
             const unsigned mid = (lo + hi) >> 1;
-            if (ldsWs[mid] <= pos)
+            if (ws[w0 + mid] <= pos)
                 lo = mid;
             else
                 hi = mid;
@@ -878,13 +897,16 @@ __global__ __launch_bounds__(kStage1Block) void screenKernel(SegmentView seg, Co
         look(i, __builtin_nontemporal_load(src + i));
     __syncthreads();
     const unsigned maxLoad = co.rg[rg0].maxLoad;
+    const uint32_t * ec = seg.endCountPk + (size_t)rg0 * (W + 1);
 #pragma unroll
     for (int k = 0; k < kScreenWindows / kStage1Block; ++k)
     {
         const unsigned w = w0 + tid + (unsigned)k * kStage1Block;
         if (w < W)
         {
-            const unsigned n = ldsWs[w + K - w0] - ended[k];
+            unsigned n = nAct[k];
+            if (n == 255u)                              // (capped: the two index words say how many)
+                n = ws[w + K] - ec[w];
             const unsigned fl = n < 2u ? 1u : (n < maxLoad ? 2u : 0u);
             flags[(size_t)s * W + w] = (uint8_t)fl;
             if (fl == 2u && screenMaybe(n, ldsCnt[w - w0]))
