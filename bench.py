@@ -50,7 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--sharded-timeout", type=float, default=420.0,
                     help="N > 1: give up on the sample-sharded headline after this many seconds (the line is then printed "
                          "with the segment split as value and the process exits 3)")
-    ap.add_argument("--stream-segments", type=int, default=4,
+    ap.add_argument("--stream-segments", type=int, default=8,
                     help="segments of the streaming leg (host memory -> HBM -> calls, double buffered); 0 switches it off")
     ap.add_argument("--stream50k-samples", type=int, default=50000,
                     help="cohort of the streaming_50000 leg (configs[4]'s size through one GPU; 0: skip)")
@@ -194,6 +194,20 @@ def scan_source_stamp():
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
+
+
+def cfs_throttle():
+    """(periods throttled, seconds throttled) of this job's CPU controller so far, or None: the GPU boxes give a job a CFS quota
+    (16 CPUs' worth per period); a phase that runs more threads than that is stopped for the rest of the period."""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat", "/sys/fs/cgroup/cpu,cpuacct/cpu.stat"):
+        try:
+            kv = dict(l.split()[:2] for l in open(path) if len(l.split()) >= 2)
+        except OSError:
+            continue
+        if "nr_throttled" in kv:
+            t = float(kv["throttled_usec"]) / 1e6 if "throttled_usec" in kv else float(kv.get("throttled_time", 0)) / 1e9
+            return int(kv["nr_throttled"]), t
+    return None
 
 
 def usable_cores():
@@ -764,19 +778,31 @@ def main():
         the host threads, upload and layout build on the copy stream -- while ticket N computes; collect(N). Returns the
         wall time and what pd_last_stage_timing() said about the stagings. warm: one untimed segment first (a fresh context
         allocates and page-locks its staging buffers on the first one)."""
+        cold = None
         if warm:
+            # two segments staged side by side, as the double-buffered loop below holds them, then given back: the context
+            # keeps their device buffers for re-use. The FIRST stagings of a context allocate the layout's 3.3 GB per
+            # 10,000-sample segment, which costs 0-140 ms per staging depending on the box (fresh VRAM) -- round 3/4's second
+            # "mode" of this leg was these two cold stagings averaged over its four segments (DESIGN 5a).
+            a = time.perf_counter()
             h0 = c.stage(sg)
+            h1 = c.stage(sg)
+            cold = (time.perf_counter() - a) / 2
             c.collect(c.run(h0), copy=False)
+            c.collect(c.run(h1), copy=False)
             c.unstage(h0)
+            c.unstage(h1)
         torch.cuda.synchronize()
         q0 = time.perf_counter()
         t_stage = t_collect = 0.0
-        st_acc = dict(pack_seconds=0.0, uploaded_seconds=0.0, bytes_uploaded=0, n=0)
+        st_acc = dict(pack_seconds=0.0, uploaded_seconds=0.0, counted_seconds=0.0, total_seconds=0.0, bytes_uploaded=0, n=0)
 
         def note():
             st = c.stage_timing()
             st_acc["pack_seconds"] += st["pack_seconds"]
             st_acc["uploaded_seconds"] += st["uploaded_seconds"]
+            st_acc["counted_seconds"] += st["counted_seconds"]
+            st_acc["total_seconds"] += st["total_seconds"]
             st_acc["bytes_uploaded"] += st["bytes_uploaded"]
             st_acc["flavour"] = st["flavour"]
             st_acc["host_threads"] = st["host_threads"]
@@ -803,9 +829,13 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - q0
         k = max(1, st_acc["n"])
-        return dt, dict(seconds_per_segment=dt / n_segments, stage_seconds_per_segment=t_stage / max(1, n_segments - 1),
+        return dt, dict(seconds_per_segment=dt / n_segments, cold_stage_seconds_per_segment=cold,
+                        stage_seconds_per_segment=t_stage / max(1, n_segments - 1),
                         collect_seconds_per_segment=t_collect / n_segments, first_stage_seconds=t_first,
                         pack_seconds_per_segment=st_acc["pack_seconds"] / k, uploaded_seconds_per_segment=st_acc["uploaded_seconds"] / k,
+                        # (the two waits for the device inside a stage call and its end, all from its start: the last uploaded byte
+                        # there, the totals of the counting pass back, return)
+                        counted_seconds_per_segment=st_acc["counted_seconds"] / k, stage_call_seconds_per_segment=st_acc["total_seconds"] / k,
                         h2d_bytes_per_segment=st_acc["bytes_uploaded"] // k,
                         # the link's rate over the window in which bytes were travelling (packing of later slabs included: the
                         # upload of a slab runs under the packing of the next)
@@ -819,8 +849,14 @@ def main():
         # 5 B written to page-locked staging): the probe beside it says what the host's memory system gives those threads in
         # this very run -- rounds 3/4 saw this leg in two modes (0.03 and 0.1 s per segment) on the same build, box to box.
         probe = [hip.pd_host_copy_gbs(1 << 30)]
-        dt, d = stream_through(ctx, seg, args.stream_segments)
+        thr0 = cfs_throttle()
+        dt, d = stream_through(ctx, seg, args.stream_segments, warm=True)
+        thr1 = cfs_throttle()
         probe.append(hip.pd_host_copy_gbs(1 << 30))
+        if thr0 and thr1:
+            # the packing pass runs 2 threads per usable CPU: on a box that enforces the job's CPU quota per period the process is
+            # stopped for the rest of the period once the quota is burnt -- the second "mode" of this leg
+            d.update(cfs_periods_throttled=thr1[0] - thr0[0], cfs_seconds_throttled=thr1[1] - thr0[1])
         d.update(value=args.stream_segments * W * S / dt, unit="window*sample/s", segments=args.stream_segments,
                  host_bytes_per_segment=int(16 * len(arrays["dev"]) + 8 * (S + 1)),
                  host_pack_read_GBs=16 * len(arrays["dev"]) / max(1e-9, d["pack_seconds_per_segment"]) / 1e9,

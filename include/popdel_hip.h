@@ -224,6 +224,9 @@ typedef struct pd_stage_timing
     double   uploaded_seconds;
     uint32_t flavour;            /* bytes per instance on the link: 5 (compact), 8 (narrow), 16 (wide); 0: built on the host */
     uint32_t host_threads;
+    double   counted_seconds;    /* from the start of the call until the device's counting pass had reported the layout's size
+                                    (the build's second and last wait for the device; the scatter that follows is not waited for) */
+    double   total_seconds;      /* the whole call */
 } pd_stage_timing;
 int pd_last_stage_timing(pd_ctx *ctx, pd_stage_timing *out);
 double pd_host_copy_gbs(uint64_t bytes);

@@ -94,7 +94,7 @@ class PdWalk(C.Structure):
 
 class PdStageTiming(C.Structure):
     _fields_ = [("n_instances", C.c_uint64), ("bytes_uploaded", C.c_uint64), ("pack_seconds", C.c_double), ("uploaded_seconds", C.c_double),
-                ("flavour", C.c_uint32), ("host_threads", C.c_uint32)]
+                ("flavour", C.c_uint32), ("host_threads", C.c_uint32), ("counted_seconds", C.c_double), ("total_seconds", C.c_double)]
 
 
 class PdShard(C.Structure):

@@ -444,6 +444,7 @@ struct pd_ctx
     // flagged windows only. POPDEL_HIP_SCAN=full: the round-1..4 scan (exact Q3 of every cell).
     bool screenScan = true;
     pd_stage_timing stageTiming{};        // pd_last_stage_timing()
+    std::chrono::steady_clock::time_point stageBegan;
     bool stage1View = false;              // pd_ctx_stage1_view(): keep the full scan's Q3 of every cell for pd_stage1_last()
     // stage 2 launched without waiting for the pool sizes (see pd_segment_collect); POPDEL_HIP_EXACT_POOLS=1 turns it off
     bool optimisticPools = true;
@@ -1213,6 +1214,7 @@ bool buildLayoutOnDevice(pd_ctx & c, const pd::InstanceArrays & in, uint64_t nIn
     PD_HIP(hipMemcpyAsync(c.hTotals.data() + 4, c.dProblems.p, sizeof(unsigned), hipMemcpyDeviceToHost, cs));
     PD_HIP(hipMemcpyAsync(c.hEntMax.data(), c.dEntMax.p + (twoLives ? nEnt : 0), nEnt * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
     PD_HIP(hipStreamSynchronize(cs));
+    c.stageTiming.counted_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - c.stageBegan).count();
     if (static_cast<unsigned>(c.hTotals[4] & 0xffffffffu) != 0)
         throw HipError{"pair instances of a read group are not ordered by their first window (pd_segment: non-decreasing `on`)"};
     const uint64_t totalReal = c.hTotals[0], totalPk = twoLives ? c.hTotals[3] : c.hTotals[1];
@@ -1224,9 +1226,17 @@ bool buildLayoutOnDevice(pd_ctx & c, const pd::InstanceArrays & in, uint64_t nIn
         out.maxBlockChunks = entMax.empty() ? 0 : entMax[std::min(entMax.size() - 1, entMax.size() * 99 / 100)];
     }
     // ---- chunks to their places
+    const bool trace = getenv("POPDEL_HIP_STAGE_TRACE") != nullptr;
+    auto mark = [&](const char * what) {
+        if (trace)
+            fprintf(stderr, "[popdel_hip stage] %7.2f ms  %s\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c.stageBegan).count(), what);
+    };
+    mark("totals read");
     out.pairs.ensure(totalReal);
     out.start.ensure(totalReal);
     out.pairsPk.ensure(totalPk + 256);             // the scan's LDS-DMA copies whole 256-chunk pieces (stage1.hip)
+    mark("chunk arrays ensured");
     {
         pd::ScatterOut so;
         so.pairs = out.pairs.p;
@@ -1259,11 +1269,13 @@ bool buildLayoutOnDevice(pd_ctx & c, const pd::InstanceArrays & in, uint64_t nIn
         pd::launchScanGeneric(en, c.dRg.p, out.winStart.p, out.endCount.p, W, K, out.scanGeneric.p, static_cast<unsigned>(blocksPerSample), cs);
         PD_HIP(hipGetLastError());
     }
+    mark("scatter launched");
     // the screen's one byte per cell (after the index of the stage-1 image is final)
     out.active8.ensure(static_cast<size_t>(nEnt) * W);
     pd::launchActive8(out.ownPkIndex ? out.winStartPk.p : out.winStart.p, out.ownPkIndex ? out.endCountPk.p : out.endCount.p, nEnt, W,
                       out.ownPkIndex ? out.maxLifePk : out.maxLife, out.active8.p, cs);
     PD_HIP(hipGetLastError());
+    mark("active8 launched");
     return true;
 }
 
@@ -1272,7 +1284,7 @@ bool buildLayoutOnDevice(pd_ctx & c, const pd::InstanceArrays & in, uint64_t nIn
 // Returns false if this segment has to take the host builder (window count beyond what the build kernels keep in LDS).
 bool buildChunksOnDevice(pd_ctx & c, const pd_segment & seg, StagedSegment & out)
 {
-    const uint32_t W = seg.n_windows, nRg = seg.n_readgroups, nV = static_cast<uint32_t>(c.scanSample.size()), nEnt = nRg + nV;
+    const uint32_t W = seg.n_windows, nRg = seg.n_readgroups;
     const uint64_t nInst = seg.rg_offsets[nRg];
     if (pd::buildLdsBytes(W, 48) > 160u * 1024u || nInst == 0)
         return false;
@@ -2218,6 +2230,8 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
     try
     {
         PD_HIP(hipSetDevice(c->device));
+        c->stageBegan = std::chrono::steady_clock::now();
+        std::memset(&c->stageTiming, 0, sizeof(c->stageTiming));
         std::unique_ptr<StagedSegment> s;
         s = takeSpare(c);
         s->ownedBySubmit = false;
@@ -2241,6 +2255,7 @@ int pd_segment_stage(pd_ctx * c, const pd_segment * seg, uint64_t * handle)
             s->waitBuilt = true;
             *handle = c->nextHandle++;
             putStaged(c, *handle, std::move(s));
+            c->stageTiming.total_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - c->stageBegan).count();
             return 0;
         }
         PinnedBuf<pd::PairDO> & pairs = c->hPairs;
