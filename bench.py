@@ -1094,7 +1094,10 @@ def main():
         out = dict(value=n_cpu * W / cpu_s, unit="window*sample/s", cores=1, kind="port", cpu_model=cpu_model(),
                    host_cores=os.cpu_count(), usable_cores=usable_cores(),
                    sample="%d of the %d samples x the same %d-window segment, oracle/ (x87 long double), %.1f s"
-                          % (n_cpu, S, W, cpu_s))
+                          % (n_cpu, S, W, cpu_s),
+                   scope="hot path only: the CPU restatement of genotype_deletion_window() over the staged pair instances of the "
+                         "segment (no profile reading, no window walk, no merging, no VCF). The like-for-like CPU figure of the "
+                         "drop-in -- `popdel call` from profile files to VCF -- is e2e.cpu_baseline")
         # the same on all host cores the way a CPU run would use them: independent cohorts of n_cpu samples each (the
         # oracle is single-threaded; ctypes releases the GIL)
         # every core this job may use (cgroup quota / affinity; more threads than that are only throttled)

@@ -73,6 +73,8 @@ def test_bench_line_has_the_contract_fields(built):
     st = d["streaming"]
     assert st["value"] > 0 and st["pack_seconds_per_segment"] > 0 and st["uploaded_seconds_per_segment"] >= st["pack_seconds_per_segment"] * 0.5
     assert st["bytes_per_instance_on_the_link"] == 5 and st["h2d_bytes_per_segment"] > 0 and len(st["host_copy_probe_GBs"]) == 2
+    assert st["cold_stage_seconds_per_segment"] > 0 and st["stage_call_seconds_per_segment"] >= st["counted_seconds_per_segment"] > 0
+    assert "hot path only" in c["scope"]
     assert min(st["host_copy_probe_GBs"]) > 0.1
     s5 = d["streaming_50000"]
     assert s5["samples"] == 768 and s5["segments"] == 2 and s5["value"] > 0 and s5["pair_instances_per_segment"] > 0
