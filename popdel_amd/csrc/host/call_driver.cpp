@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <deque>
 #include <memory>
+#include <fcntl.h>
 #include <sys/resource.h>
 #include <sys/syscall.h>
 #include <thread>
@@ -229,8 +230,35 @@ public:
     static size_t chunkOf(size_t item) { return item < kFirstChunk ? 0 : 1 + (item - kFirstChunk) / kChunk; }
     static size_t chunkBegin(size_t c) { return c == 0 ? 0 : kFirstChunk + (c - 1) * kChunk; }
 
+    // Descriptors of the profiles, kept open from round to round as far as the process's limit allows (every sample's file is
+    // asked twice per round: its index, then its bytes); a sample beyond the limit is opened and closed per use as before.
+    // One thread works on a sample at a time within a pass (the passes are parallel over samples).
+    int descriptorOf(unsigned sample)
+    {
+        if (sample < fds_.size() && fds_[sample] >= 0)
+            return fds_[sample];
+        const int fd = ::open(p_.inputFiles[sample].c_str(), O_RDONLY | O_CLOEXEC);
+        if (fd >= 0 && sample < fds_.size())
+            fds_[sample] = fd;
+        return fd;
+    }
+    void giveBack(unsigned sample, int fd)
+    {
+        if (fd >= 0 && !(sample < fds_.size() && fds_[sample] == fd))
+            ::close(fd);
+    }
+
     GunzipPrefetch(const CallParams & p, int device) : p_(p)
     {
+        {
+            // (each of the two loaders keeps its own descriptors: a third of the limit each, the rest is the process's own)
+            struct rlimit lim;
+            size_t keep = 256;
+            if (getrlimit(RLIMIT_NOFILE, &lim) == 0)           // (raised as far as the cohort needs when the run began: runPopdelCall)
+                keep = lim.rlim_cur == RLIM_INFINITY ? static_cast<size_t>(1) << 20
+                                                     : (static_cast<size_t>(lim.rlim_cur) > 1024 ? (static_cast<size_t>(lim.rlim_cur) - 1024) / 3 : 0);
+            fds_.assign(std::min<size_t>(p.inputFiles.size(), keep), -1);
+        }
         for (pd_inflater *& f : inflater_)
             f = pd_inflater_create(device);
         ok_ = true;
@@ -241,6 +269,9 @@ public:
     ~GunzipPrefetch()
     {
         finish();
+        for (int fd : fds_)
+            if (fd >= 0)
+                ::close(fd);
         for (pd_inflater * f : inflater_)
             pd_inflater_destroy(f);
     }
@@ -363,6 +394,7 @@ public:
     double kernelMs = 0, gatherSeconds = 0, runSeconds = 0, waitSeconds = 0;      // (waitSeconds: summed over the decoder threads)
     uint64_t members = 0, compressedBytes = 0, inflatedBytes = 0, samplesServed = 0, samplesLeft = 0, samplesParsed = 0;
     bool parseOnDevice_ = true;         // POPDEL_HOST_PARSE=1: the device inflates, the host parses
+    std::vector<int> fds_;              // descriptorOf()
 
 private:
     // what the gathering thread hands to the one that drives the device
@@ -497,10 +529,13 @@ private:
             const unsigned contigIdx = p_.representativeContigs ? 0 : it.sample;
             try
             {
-                ProfileFile in(p_.inputFiles[it.sample]);
-                if (!in.blockOffsets(p_.contigNames[contigIdx], p_.contigLengths[contigIdx], p_.indexRegionSizes[contigIdx], contig_, it.beginPos,
-                                     it.endPos, cuts[k], &j.regionOffsets[k]) || cuts[k].size() < 2 || cuts[k].back() - cuts[k].front() > (static_cast<uint64_t>(256) << 20))
+                const int fd = descriptorOf(it.sample);
+                if (fd < 0 ||
+                    !ProfileFile::blockOffsetsOf(fd, p_.contigNames[contigIdx], p_.contigLengths[contigIdx], p_.indexRegionSizes[contigIdx], contig_,
+                                                 it.beginPos, it.endPos, cuts[k], &j.regionOffsets[k]) ||
+                    cuts[k].size() < 2 || cuts[k].back() - cuts[k].front() > (static_cast<uint64_t>(256) << 20))
                     cuts[k].clear();
+                giveBack(it.sample, fd);
             }
             catch (...)
             {
@@ -525,19 +560,19 @@ private:
             if (cuts[k].empty())
                 return;
             const Item & it = items_[lo + k];
-            FILE * fp = fopen(p_.inputFiles[it.sample].c_str(), "rb");
-            if (!fp)
+            const int fd = descriptorOf(it.sample);
+            if (fd < 0)
                 return;
             const size_t want = static_cast<size_t>(base[k + 1] - base[k]);
             size_t got = 0;
             while (got < want)
             {
-                const ssize_t r = pread(fileno(fp), buf + base[k] + got, want - got, static_cast<off_t>(cuts[k].front() + got));
+                const ssize_t r = pread(fd, buf + base[k] + got, want - got, static_cast<off_t>(cuts[k].front() + got));
                 if (r <= 0)
                     break;
                 got += static_cast<size_t>(r);
             }
-            fclose(fp);
+            giveBack(it.sample, fd);
             good[k] = got == want ? 1 : 0;
         }, 8, 8);
         // 3. member table: every member must begin like a gzip member with deflate data and end with a plausible size
@@ -2765,6 +2800,33 @@ int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer, bool
         // only cost their set-up: one lane unless the user asks. Here, not in createBackend(): that runs on a thread of its own
         // while the main thread reads the environment every round)
         setenv("POPDEL_HIP_LANES", "1", 0);
+        {
+            // The loaders keep the profiles' descriptors open from round to round (GunzipPrefetch::descriptorOf): room for them in
+            // the limit, and the descriptor TABLE grown to its final size now, while the process has one thread -- once it has
+            // more, every doubling of the table waits for an RCU grace period (0.6 s in all on the way to 8,000 descriptors,
+            // seen as one round of 0.7 s).
+            struct rlimit lim;
+            if (getrlimit(RLIMIT_NOFILE, &lim) == 0)
+            {
+                const rlim_t want = static_cast<rlim_t>(3 * params.inputFiles.size() + 1024);
+                if (lim.rlim_cur != RLIM_INFINITY && lim.rlim_cur < want && lim.rlim_cur < lim.rlim_max)
+                {
+                    lim.rlim_cur = lim.rlim_max == RLIM_INFINITY ? want : std::min(lim.rlim_max, want);
+                    (void)setrlimit(RLIMIT_NOFILE, &lim);
+                    (void)getrlimit(RLIMIT_NOFILE, &lim);
+                }
+                const rlim_t top = lim.rlim_cur == RLIM_INFINITY ? want : std::min(want, lim.rlim_cur);
+                const int null = ::open("/dev/null", O_RDONLY | O_CLOEXEC);
+                if (null >= 0 && top > 16)
+                {
+                    const int high = fcntl(null, F_DUPFD_CLOEXEC, static_cast<int>(top - 1));
+                    if (high >= 0)
+                        ::close(high);
+                }
+                if (null >= 0)
+                    ::close(null);
+            }
+        }
         if (!getenv("POPDEL_CPU_PROFILE_FROM_ROUND"))
             CpuSampler::start();
         gTrace.mark("command line parsed");

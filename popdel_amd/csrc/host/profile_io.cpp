@@ -416,10 +416,16 @@ bool ProfileFile::blockOffsets(const std::vector<std::string> & contigNames, con
                                unsigned indexRegionSize, const std::string & contig, int32_t beginPos, int32_t endPos,
                                std::vector<uint64_t> & offsets, std::vector<uint64_t> * perRegion)
 {
+    return blockOffsetsOf(fileno(fp_), contigNames, contigLengths, indexRegionSize, contig, beginPos, endPos, offsets, perRegion);
+}
+
+bool ProfileFile::blockOffsetsOf(int fd, const std::vector<std::string> & contigNames, const std::vector<int32_t> & contigLengths,
+                                 unsigned indexRegionSize, const std::string & contig, int32_t beginPos, int32_t endPos,
+                                 std::vector<uint64_t> & offsets, std::vector<uint64_t> * perRegion)
+{
     offsets.clear();
     if (perRegion)
         perRegion->clear();
-    const int fd = fileno(fp_);
     uint32_t numRegions = 0;
     if (pread(fd, &numRegions, sizeof(numRegions), 7 + sizeof(uint32_t)) != static_cast<ssize_t>(sizeof(numRegions)) || numRegions == 0)
         return false;
