@@ -1,6 +1,6 @@
 // Gunzip on the device (round 4, prototype of SURVEY 8(f) row f1's first stage): the gzip members of the profiles -- one per
 // 10,000-bp index region and sample, 3-4 KB each, 200,000 of them per 200-kb segment of a 10,000-sample cohort -- are
-// independent, so one LANE inflates one member (inflate_core.h) and a segment is 3,125 waves of work. Host counterpart:
+// independent, so one LANE inflates one member (inflate_core.h), eight members to a wave: a segment is 25,000 waves of work. Host counterpart:
 // profile_io.cpp's MemberSource (libdeflate / zlib, one member per call); reference: the zlib stream behind
 // seqan/stream/iostream_zip_impl.h:336-349, fed from the index jump of insert_histogram_popdel.h:531-562.
 //
@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -21,28 +22,33 @@
 
 namespace {
 
-constexpr unsigned kLanes = 64;
-
-// Workgroups of ONE wave: the 64 decoders' tables (366 16-bit words each) take 47 KB of LDS, three workgroups fit a CU.
-// Workgroups stride over the batches of 64 members; the code lengths of a dynamic block header (only touched while a
-// header is parsed) live in a global workspace, one 20-KB slab per workgroup.
-__global__ __launch_bounds__(kLanes) void inflateMembersKernel(const uint8_t * __restrict__ data, const uint64_t * __restrict__ inOff,
-                                                               uint32_t n, uint8_t * __restrict__ out,
-                                                               const uint64_t * __restrict__ outOff, uint32_t * __restrict__ status,
-                                                               uint64_t * __restrict__ outLen, uint8_t * __restrict__ lengthsWs,
-                                                               unsigned nBatches)
+// Workgroups of ONE wave that holds L members (one per lane, lanes L..63 absent): the decoders' tables (398 16-bit words each)
+// and the code lengths of a dynamic block header (320 bytes each) take L x 1,116 bytes of LDS. Workgroups stride over the
+// batches of L members. What a small L buys: a wave executes the UNION of its lanes' paths through the decoder (literal /
+// match / header / refill), so fewer members per wave is fewer instructions per wave, and the smaller table set lets more
+// waves share a SIMD -- a wave here is a chain of dependent instructions with nothing of its own to hide their latencies.
+// Measured on MI355X (tools/inflate_lanes_sweep.py, profiles/r05_j_inflate_lanes_sweep.md), 21,000 members (the chunk a decoder
+// thread of `popdel call` hands over at 4,000 samples) / 200,000 members (a 10,000-sample segment): 64 per wave 9.5 / 52.6 ms,
+// 32: 8.4 / 46.3, 16: 7.4 / 51.4, 8: 6.3 / 42.9, 4: 10.1 / 62.5 (too many waves for the chip to hold at once); with the
+// eight-byte loads of the far copies (inflate_core.h) and the code lengths in LDS, 8 per wave: 5.6 / 38.7 ms.
+template <unsigned L>
+__global__ __launch_bounds__(L) void inflateMembersKernel(const uint8_t * __restrict__ data, const uint64_t * __restrict__ inOff,
+                                                          uint32_t n, uint8_t * __restrict__ out,
+                                                          const uint64_t * __restrict__ outOff, uint32_t * __restrict__ status,
+                                                          uint64_t * __restrict__ outLen, unsigned nBatches)
 {
-    __shared__ uint16_t tabs[pdinf::kTabWords * kLanes];
+    __shared__ uint16_t tabs[pdinf::kTabWords * L];
     __shared__ uint32_t crcTab[256];
-    for (unsigned i = threadIdx.x; i < 256u; i += kLanes)
+    for (unsigned i = threadIdx.x; i < 256u; i += L)
         crcTab[i] = pdinf::crcTableEntry(i);
     __syncthreads();
-    pdinf::StridedTables t;
+    pdinf::StridedTablesOf<L> t;
     t.base = tabs + threadIdx.x;
-    t.lengths = lengthsWs + (size_t)blockIdx.x * (pdinf::kCodeLengths * kLanes) + threadIdx.x;
+    __shared__ uint8_t lens[pdinf::kCodeLengths * L];
+    t.lengths = lens + threadIdx.x;
     for (unsigned batch = blockIdx.x; batch < nBatches; batch += gridDim.x)
     {
-        const unsigned m = batch * kLanes + threadIdx.x;
+        const unsigned m = batch * L + threadIdx.x;
         if (m >= n)
             continue;
         uint64_t got = 0, used = 0;
@@ -50,6 +56,51 @@ __global__ __launch_bounds__(kLanes) void inflateMembersKernel(const uint8_t * _
         status[m] = pdinf::inflateGzipMember(data + a, inOff[m + 1] - a, out + b, outOff[m + 1] - b, &got, &used, t, crcTab);
         outLen[m] = got;
     }
+}
+
+// Members per wave (4 | 8 | 16 | 32) and the waves of that shape a CU holds (the runtime's occupancy figure: LDS and VGPRs).
+// Eight unless POPDEL_HIP_INFLATE_LANES says otherwise (measurements).
+template <unsigned L>
+unsigned wavesPerCuOf()
+{
+    static const unsigned n = [] {
+        int blocks = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, inflateMembersKernel<L>, (int)L, 0) != hipSuccess || blocks < 1)
+            blocks = 1;
+        return (unsigned)blocks;
+    }();
+    return n;
+}
+unsigned wavesPerCu(unsigned lanes)
+{
+    return lanes == 4u ? wavesPerCuOf<4u>() : lanes == 8u ? wavesPerCuOf<8u>() : lanes == 16u ? wavesPerCuOf<16u>() : wavesPerCuOf<32u>();
+}
+
+unsigned membersPerWave()
+{
+    static const unsigned fixed = [] {
+        const char * e = std::getenv("POPDEL_HIP_INFLATE_LANES");
+        const unsigned v = e ? (unsigned)std::atoi(e) : 0u;
+        return (v == 4u || v == 8u || v == 16u || v == 32u) ? v : 0u;
+    }();
+    return fixed ? fixed : 8u;
+}
+
+// (returns the number of workgroups launched)
+unsigned launchInflate(unsigned nCu, hipStream_t st, const uint8_t * data, const uint64_t * inOff, uint32_t n, uint8_t * out,
+                       const uint64_t * outOff, uint32_t * status, uint64_t * outLen)
+{
+    const unsigned lanes = membersPerWave();
+    const unsigned nBatches = (n + lanes - 1u) / lanes;
+    const unsigned groups = std::min(nBatches, wavesPerCu(lanes) * nCu);
+    switch (lanes)
+    {
+    case 4u: hipLaunchKernelGGL(inflateMembersKernel<4u>, dim3(groups), dim3(4u), 0, st, data, inOff, n, out, outOff, status, outLen, nBatches); break;
+    case 8u: hipLaunchKernelGGL(inflateMembersKernel<8u>, dim3(groups), dim3(8u), 0, st, data, inOff, n, out, outOff, status, outLen, nBatches); break;
+    case 16u: hipLaunchKernelGGL(inflateMembersKernel<16u>, dim3(groups), dim3(16u), 0, st, data, inOff, n, out, outOff, status, outLen, nBatches); break;
+    default: hipLaunchKernelGGL(inflateMembersKernel<32u>, dim3(groups), dim3(32u), 0, st, data, inOff, n, out, outOff, status, outLen, nBatches); break;
+    }
+    return groups;
 }
 
 // ---- parse + 256 -> 30 split of the inflated blocks (round 4) ---------------------------------------------------------------
@@ -245,8 +296,8 @@ struct pd_inflater
     hipEvent_t timeBegin = nullptr, timeEnd = nullptr;   // around the kernels when the caller asks for kernel_ms (created on first use)
     hipEvent_t finished = nullptr;      // blocking-sync event: the calling thread sleeps instead of spinning on the stream (the host's
                                         // cores are what `popdel call` is short of)
-    unsigned groups = 0;
-    void *dData = nullptr, *dOut = nullptr, *dInOff = nullptr, *dOutOff = nullptr, *dStatus = nullptr, *dLen = nullptr, *dWs = nullptr;
+    unsigned nCu = 1;
+    void *dData = nullptr, *dOut = nullptr, *dInOff = nullptr, *dOutOff = nullptr, *dStatus = nullptr, *dLen = nullptr;
     size_t capData = 0, capOut = 0, capMembers = 0;
     void *hIn = nullptr, *hOut = nullptr, *hMeta = nullptr;     // page-locked: compressed bytes in, inflated bytes out, status + lengths
     size_t capHIn = 0, capHOut = 0, capHMeta = 0;
@@ -301,10 +352,9 @@ extern "C" pd_inflater * pd_inflater_create(int device)
         PD_INF_HIP(hipSetDevice(device));
         int nCu = 0;
         PD_INF_HIP(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, device));
-        f->groups = 3u * (unsigned)std::max(1, nCu);
+        f->nCu = (unsigned)std::max(1, nCu);
         PD_INF_HIP(hipStreamCreate(&f->stream));
         PD_INF_HIP(hipEventCreateWithFlags(&f->finished, hipEventBlockingSync | hipEventDisableTiming));
-        PD_INF_HIP(hipMalloc(&f->dWs, static_cast<size_t>(f->groups) * pdinf::kCodeLengths * kLanes));
     }
     catch (const Fail & e)
     {
@@ -320,7 +370,7 @@ extern "C" void pd_inflater_destroy(pd_inflater * f)
     if (!f)
         return;
     (void)hipSetDevice(f->device);
-    for (void * p : {f->dData, f->dOut, f->dInOff, f->dOutOff, f->dStatus, f->dLen, f->dWs, f->dWanted, f->dSampleFirst, f->dCounts, f->dOffsets, f->dRaws,
+    for (void * p : {f->dData, f->dOut, f->dInOff, f->dOutOff, f->dStatus, f->dLen, f->dWanted, f->dSampleFirst, f->dCounts, f->dOffsets, f->dRaws,
                      f->dWins, f->dWinCounts, f->dRecs})
         if (p)
             (void)hipFree(p);
@@ -396,13 +446,11 @@ static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_
         PD_INF_HIP(hipMemcpyAsync(f->dInOff, member_offsets, (n_members + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         PD_INF_HIP(hipMemcpyAsync(f->dOutOff, out_offsets, (n_members + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         PD_INF_HIP(hipMemcpyAsync(f->dData, f->hIn, inBytes, hipMemcpyHostToDevice, st));
-        const unsigned nBatches = (n_members + kLanes - 1) / kLanes;
         if (e0)
             PD_INF_HIP(hipEventRecord(e0, st));
-        hipLaunchKernelGGL(inflateMembersKernel, dim3(std::min(nBatches, f->groups)), dim3(kLanes), 0, st, static_cast<const uint8_t *>(f->dData),
-                           static_cast<const uint64_t *>(f->dInOff), n_members, static_cast<uint8_t *>(f->dOut),
-                           static_cast<const uint64_t *>(f->dOutOff), static_cast<uint32_t *>(f->dStatus), static_cast<uint64_t *>(f->dLen),
-                           static_cast<uint8_t *>(f->dWs), nBatches);
+        launchInflate(f->nCu, st, static_cast<const uint8_t *>(f->dData),
+                      static_cast<const uint64_t *>(f->dInOff), n_members, static_cast<uint8_t *>(f->dOut),
+                      static_cast<const uint64_t *>(f->dOutOff), static_cast<uint32_t *>(f->dStatus), static_cast<uint64_t *>(f->dLen));
         PD_INF_HIP(hipGetLastError());
         if (e1)
             PD_INF_HIP(hipEventRecord(e1, st));
@@ -523,7 +571,7 @@ extern "C" int pd_inflate_members(int device, const uint8_t * data, const uint64
         g_inflateError = "pd_inflate_members: invalid argument";
         return 1;
     }
-    void *dData = nullptr, *dOut = nullptr, *dInOff = nullptr, *dOutOff = nullptr, *dStatus = nullptr, *dLen = nullptr, *dWs = nullptr;
+    void *dData = nullptr, *dOut = nullptr, *dInOff = nullptr, *dOutOff = nullptr, *dStatus = nullptr, *dLen = nullptr;
     void *hIn = nullptr, *hOut = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t st = nullptr;
@@ -534,8 +582,7 @@ extern "C" int pd_inflate_members(int device, const uint8_t * data, const uint64
         const uint64_t inBytes = member_offsets[n_members], outBytes = out_offsets[n_members];
         int nCu = 0;
         PD_INF_HIP(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, device));
-        const unsigned nBatches = (n_members + kLanes - 1) / kLanes;
-        const unsigned groups = std::min<unsigned>(nBatches, 3u * (unsigned)std::max(1, nCu));
+        unsigned groups = 0;
         PD_INF_HIP(hipStreamCreate(&st));
         for (hipEvent_t & e : ev)
             PD_INF_HIP(hipEventCreate(&e));
@@ -545,7 +592,6 @@ extern "C" int pd_inflate_members(int device, const uint8_t * data, const uint64
         PD_INF_HIP(hipMalloc(&dOutOff, (n_members + 1) * sizeof(uint64_t)));
         PD_INF_HIP(hipMalloc(&dStatus, n_members * sizeof(uint32_t)));
         PD_INF_HIP(hipMalloc(&dLen, n_members * sizeof(uint64_t)));
-        PD_INF_HIP(hipMalloc(&dWs, static_cast<size_t>(groups) * pdinf::kCodeLengths * kLanes));
         PD_INF_HIP(hipHostMalloc(&hIn, inBytes + 8, hipHostMallocDefault));
         PD_INF_HIP(hipHostMalloc(&hOut, std::max<uint64_t>(outBytes, 1), hipHostMallocDefault));
         std::memcpy(hIn, data, inBytes);
@@ -557,10 +603,9 @@ extern "C" int pd_inflate_members(int device, const uint8_t * data, const uint64
         PD_INF_HIP(hipEventRecord(ev[1], st));
         const uint32_t times = std::max<uint32_t>(1, repeat);
         for (uint32_t k = 0; k < times; ++k)
-            hipLaunchKernelGGL(inflateMembersKernel, dim3(groups), dim3(kLanes), 0, st, static_cast<const uint8_t *>(dData),
-                               static_cast<const uint64_t *>(dInOff), n_members, static_cast<uint8_t *>(dOut),
-                               static_cast<const uint64_t *>(dOutOff), static_cast<uint32_t *>(dStatus), static_cast<uint64_t *>(dLen),
-                               static_cast<uint8_t *>(dWs), nBatches);
+            groups = launchInflate((unsigned)std::max(1, nCu), st, static_cast<const uint8_t *>(dData),
+                                   static_cast<const uint64_t *>(dInOff), n_members, static_cast<uint8_t *>(dOut),
+                                   static_cast<const uint64_t *>(dOutOff), static_cast<uint32_t *>(dStatus), static_cast<uint64_t *>(dLen));
         PD_INF_HIP(hipGetLastError());
         PD_INF_HIP(hipEventRecord(ev[2], st));
         PD_INF_HIP(hipMemcpyAsync(hOut, dOut, outBytes, hipMemcpyDeviceToHost, st));
@@ -588,7 +633,7 @@ extern "C" int pd_inflate_members(int device, const uint8_t * data, const uint64
         g_inflateError = "pd_inflate_members: " + f.what;
         rc = 2;
     }
-    for (void * p : {dData, dOut, dInOff, dOutOff, dStatus, dLen, dWs})
+    for (void * p : {dData, dOut, dInOff, dOutOff, dStatus, dLen})
         if (p)
             (void)hipFree(p);
     for (void * p : {hIn, hOut})

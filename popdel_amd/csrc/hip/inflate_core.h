@@ -1,6 +1,7 @@
 // DEFLATE (RFC 1951) decoder for ONE gzip member (RFC 1952), written so that one LANE can run it: no heap, no recursion,
 // canonical Huffman decoding from per-length counts and a symbol list (a few hundred 16-bit words of table per decoder
-// instead of the kilobytes a lookup-table decoder wants -- 64 decoders share a workgroup's LDS), the last eight output
+// instead of the kilobytes a lookup-table decoder wants -- the decoders of a wave share its LDS; a table of the next nine
+// bits per code was built and measured slower on the device: the rare longer codes stall the lanes beside them), the last eight output
 // bytes in a register so that the short back-references the profiles are made of (the zero / ff bytes of the 32-bit
 // deviations, five bytes back) cost no memory round trip.
 //
@@ -52,14 +53,15 @@ struct FlatTables
     PD_INF_FN uint8_t & len(unsigned i) { return length[i]; }
 };
 
-// Tables of 64 decoders interleaved word by word (device: word i of lane l at base[i * 64 + l]; lanes that look at the same
+// Tables of `Stride` decoders interleaved word by word (device: word i of lane l at base[i * Stride + l]; lanes that look at the same
 // entry hit consecutive LDS banks), code lengths likewise in a global workspace.
-struct StridedTables
+template <unsigned Stride>
+struct StridedTablesOf
 {
     uint16_t * base;       // + lane
     uint8_t *  lengths;    // + lane
-    PD_INF_FN uint16_t & w(unsigned i) { return base[i * 64u]; }
-    PD_INF_FN uint8_t & len(unsigned i) { return lengths[i * 64u]; }
+    PD_INF_FN uint16_t & w(unsigned i) { return base[i * Stride]; }
+    PD_INF_FN uint8_t & len(unsigned i) { return lengths[i * Stride]; }
 };
 
 struct BitReader
@@ -337,8 +339,18 @@ PD_INF_FN uint32_t inflateCodes(BitReader & br, Output & o, Tab & tab)
         }
         else
         {
-            for (unsigned i = 0; i < len; ++i)
-                o.put(o.out[o.n - dist]);
+            // more than eight bytes back: the eight bytes at the source are all there, one load serves up to eight of the
+            // match's bytes (70 % of a profile block's bytes come this way, four to a match)
+            unsigned left = len;
+            while (left != 0u)
+            {
+                uint64_t v;
+                __builtin_memcpy(&v, o.out + (o.n - dist), 8);
+                const unsigned take = left < 8u ? left : 8u;
+                for (unsigned i = 0; i < take; ++i, v >>= 8)
+                    o.put((unsigned)v & 0xffu);
+                left -= take;
+            }
         }
     }
 }
