@@ -248,7 +248,9 @@ public:
             ::close(fd);
     }
 
-    GunzipPrefetch(const CallParams & p, int device) : p_(p)
+    // `devices`: the GPUs of the run (POPDEL_DEVICES); the loader's inflaters are dealt over them, beginning at devices[first],
+    // so that the gunzip + parse of a round is not one GPU's work while the others wait for their samples
+    GunzipPrefetch(const CallParams & p, const std::vector<int> & devices, size_t first) : p_(p)
     {
         {
             // (each of the two loaders keeps its own descriptors: a third of the limit each, the rest is the process's own)
@@ -259,8 +261,8 @@ public:
                                                      : (static_cast<size_t>(lim.rlim_cur) > 1024 ? (static_cast<size_t>(lim.rlim_cur) - 1024) / 3 : 0);
             fds_.assign(std::min<size_t>(p.inputFiles.size(), keep), -1);
         }
-        for (pd_inflater *& f : inflater_)
-            f = pd_inflater_create(device);
+        for (size_t k = 0; k < kInflaters; ++k)
+            inflater_[k] = pd_inflater_create(devices[(first + k) % devices.size()]);
         ok_ = true;
         for (pd_inflater * f : inflater_)
             ok_ = ok_ && f;
@@ -905,7 +907,7 @@ private:
     std::string pendingGuessContig_;
     int pendingGuessSet_ = 0;
     uint64_t roundsAhead_ = 0, roundsOnDemand_ = 0, roundsGuessedWrong_ = 0;
-    int gunzipDevice_ = 0;
+    std::vector<int> gunzipDevices_ = {0};
     void startGunzipPrefetch();
     void startLoaderAhead();
     void createLoaders();
@@ -1020,7 +1022,7 @@ void CallRun::createBackend()
         const char * d = getenv("POPDEL_DEVICE");
         devices.push_back(d ? atoi(d) : 0);
     }
-    gunzipDevice_ = devices[0];
+    gunzipDevices_ = devices;
     const uint32_t S = static_cast<uint32_t>(p_.rgs.size()), world = static_cast<uint32_t>(devices.size());
     ctxs_.assign(world, nullptr);
     tickets_.assign(world, 0);
@@ -1377,8 +1379,12 @@ void CallRun::createLoaders()
 {
     if (!deviceWalkOffered_ || p_.uncompressedIn || getenv("POPDEL_HOST_GUNZIP"))
         return;
+    size_t first = 0;
     for (auto & g : gunzipSet_)
-        g.reset(new GunzipPrefetch(p_, gunzipDevice_));
+    {
+        g.reset(new GunzipPrefetch(p_, gunzipDevices_, first));
+        first += GunzipPrefetch::kInflaters;
+    }
     const char * ahead = getenv("POPDEL_LOADER_AHEAD");
     loaderAhead_ = !(ahead && ahead[0] == '0');
 }
