@@ -209,6 +209,7 @@ public:
         size_t size = 0;
         uint64_t resume = 0;
         bool usable = false, bytesValid = false;
+        bool toFileEnd = false;                     // the blocks are all that is left of the file
         // ... and / or the blocks parsed (the sample's 256-bp windows, 30-bp windows with their record counts, records)
         bool parsed = false;
         const DecodedRaw * raws = nullptr;
@@ -404,6 +405,7 @@ private:
     {
         size_t lo = 0, hi = 0;
         std::vector<std::vector<uint64_t>> cuts, regionOffsets;
+        std::vector<uint64_t> fileSize;
         std::vector<char> good;
         std::vector<uint64_t> inOff, outOff;
         std::vector<uint32_t> firstMember, sampleFirst;
@@ -526,6 +528,7 @@ private:
         std::vector<std::vector<uint64_t>> & cuts = j.cuts;
         cuts.assign(n, std::vector<uint64_t>());
         j.regionOffsets.assign(n, std::vector<uint64_t>());
+        j.fileSize.assign(n, 0);
         parallelFor(n, [&](size_t k) {
             const Item & it = items_[lo + k];
             const unsigned contigIdx = p_.representativeContigs ? 0 : it.sample;
@@ -534,7 +537,7 @@ private:
                 const int fd = descriptorOf(it.sample);
                 if (fd < 0 ||
                     !ProfileFile::blockOffsetsOf(fd, p_.contigNames[contigIdx], p_.contigLengths[contigIdx], p_.indexRegionSizes[contigIdx], contig_,
-                                                 it.beginPos, it.endPos, cuts[k], &j.regionOffsets[k]) ||
+                                                 it.beginPos, it.endPos, cuts[k], &j.regionOffsets[k], &j.fileSize[k]) ||
                     cuts[k].size() < 2 || cuts[k].back() - cuts[k].front() > (static_cast<uint64_t>(256) << 20))
                     cuts[k].clear();
                 giveBack(it.sample, fd);
@@ -668,6 +671,7 @@ private:
             r.data = r.bytesValid ? out + j.outOff[j.firstMember[k]] : nullptr;
             r.size = static_cast<size_t>(j.outOff[j.firstMember[k + 1]] - j.outOff[j.firstMember[k]]);
             r.resume = j.cuts[k].back();
+            r.toFileEnd = r.resume == j.fileSize[k];
             r.cuts = &j.cuts[k];
             r.regionOffsets = &j.regionOffsets[k];
             r.bytesByBlock = j.outOff.data() + j.firstMember[k];
@@ -776,7 +780,8 @@ public:
                           << " left to the host), parsed there for " << a.samplesParsed + b.samplesParsed << "; " << a.members + b.members << " members, " << a.compressedBytes + b.compressedBytes << " -> " << a.inflatedBytes + b.inflatedBytes
                           << " bytes; gather " << a.gatherSeconds + b.gatherSeconds << " s, copies + kernel " << a.runSeconds + b.runSeconds << " s (kernel "
                           << (a.kernelMs + b.kernelMs) / 1e3 << " s); decoder threads waited " << a.waitSeconds + b.waitSeconds << " thread-seconds for it; " << roundsAhead_
-                          << " rounds fetched ahead, " << roundsOnDemand_ << " when they began (" << roundsGuessedWrong_ << " of them after a wrong guess)" << std::endl;
+                          << " rounds fetched ahead, " << roundsOnDemand_ << " when they began (" << roundsGuessedWrong_ << " of them after a wrong guess); read by the decoder threads all the same: "
+                          << hostDecodes_[0].load() << " sample rounds without usable blocks, " << hostDecodes_[1].load() << " whose parsed blocks ended early" << std::endl;
             }
             std::cerr << "[popdel timing] parity: " << nearIntegerShifts_ << " reference-shift quotients within 1e-9 of an integer (their truncation "
                          "may differ from the x87 reference's) in " << candidateCells_ << " candidate cells, " << windowCalls_ << " window calls" << std::endl;
@@ -908,6 +913,9 @@ private:
     int pendingGuessSet_ = 0;
     uint64_t roundsAhead_ = 0, roundsOnDemand_ = 0, roundsGuessedWrong_ = 0;
     std::vector<int> gunzipDevices_ = {0};
+    // sample rounds the decoder threads read themselves although a loader ran: [0] it had nothing usable for the sample, [1] its
+    // parsed blocks end before the point at which the round's reader stops
+    mutable std::atomic<uint64_t> hostDecodes_[2] = {};
     void startGunzipPrefetch();
     void startLoaderAhead();
     void createLoaders();
@@ -1428,6 +1436,8 @@ void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned
     const Region & roi = p_.allRois[p_.nextRoi];
     const unsigned borderIn = border;
     const GunzipPrefetch::Ready * pre = gunzip_ ? gunzip_->wait(i) : nullptr;
+    if (gunzip_ && !pre)
+        ++hostDecodes_[0];
     if (pre && pre->parsed)
     {
         // The device has inflated AND parsed the blocks from the jump position on: the loop below, on its arrays. If the point at
@@ -1475,16 +1485,20 @@ void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned
             if (stopped)
                 break;
         }
-        if (stopped)
+        // (the file ends before the loader would stop: the reader runs into the end of the file behind the last window)
+        const bool atEnd = !stopped && pre->toFileEnd;
+        if (stopped || atEnd)
         {
+            out.eof = atEnd;
             out.rawsV = pre->raws + r0;
-            out.nRawsV = r + 1 - r0;
+            out.nRawsV = (atEnd ? pre->nRaws : r + 1) - r0;
             out.winsV = pre->wins;
             out.countsV = pre->counts;
             out.recsV = pre->recs;
             out.nRecsV = pre->nRecs;
             return;
         }
+        ++hostDecodes_[1];
         out.sawFarWindow = false;           // (decoded again below)
         border = borderIn;
         if (!pre->bytesValid)

@@ -421,7 +421,7 @@ bool ProfileFile::blockOffsets(const std::vector<std::string> & contigNames, con
 
 bool ProfileFile::blockOffsetsOf(int fd, const std::vector<std::string> & contigNames, const std::vector<int32_t> & contigLengths,
                                  unsigned indexRegionSize, const std::string & contig, int32_t beginPos, int32_t endPos,
-                                 std::vector<uint64_t> & offsets, std::vector<uint64_t> * perRegion)
+                                 std::vector<uint64_t> & offsets, std::vector<uint64_t> * perRegion, uint64_t * fileSize)
 {
     offsets.clear();
     if (perRegion)
@@ -453,6 +453,8 @@ bool ProfileFile::blockOffsetsOf(int fd, const std::vector<std::string> & contig
     struct stat st;
     if (fstat(fd, &st) != 0)
         return false;
+    if (fileSize)
+        *fileSize = static_cast<uint64_t>(st.st_size);
     if (have < raw.size())
         raw.back() = static_cast<uint64_t>(st.st_size);          // (behind the last region of the file)
     for (uint64_t o : raw)

@@ -10,5 +10,5 @@ d = "/tmp/e2e_cohort_4000"
 if not os.path.exists(os.path.join(d, "profiles.txt")):
     synth.write_cohort(d, 4000, region=(1000000, 5000000), deletions=synth.single_deletion, workers=16)
 PY
-for k in 1 2; do for B in popdel_old popdel; do POPDEL_TIMING=1 ./popdel_amd/lib/$B call /tmp/e2e_cohort_4000/profiles.txt -o /tmp/o_$B.vcf -r chr20:1000000-5000000 2>&1 >/dev/null | grep -E "popdel timing" | grep -v "parity\|loader\|window loop\|NUMA" | sed "s/^/$B: /" | cut -c1-420; done; done
+for k in 1 2 3; do for B in popdel_old popdel; do POPDEL_TIMING=1 ./popdel_amd/lib/$B call /tmp/e2e_cohort_4000/profiles.txt -o /tmp/o_$B.vcf -r chr20:1000000-5000000 2>&1 >/dev/null | grep -E "popdel timing" | grep -v "parity\|window loop\|NUMA" | sed "s/^/$B: /" | cut -c1-420; done; done
 cmp <(grep -v fileDate /tmp/o_popdel.vcf) <(grep -v fileDate /tmp/o_popdel_old.vcf) && echo same_vcf
