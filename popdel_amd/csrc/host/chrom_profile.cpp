@@ -502,7 +502,7 @@ void ChromProfile::addRun(unsigned rg, const uint32_t * posDev, size_t n, int in
         // a block of records short enough for the load to stay below the cap whatever the answers, in non-decreasing order,
         // with the counting cursor certain to stay inside its slot (EndSlots::quietBlock) -- the block is filed in one go and the
         // table asked once, behind its last record: the answers add up to the same number and leave the same cursors.
-        constexpr size_t kBlock = 64;
+        constexpr size_t kBlock = 256;
         unsigned endBuf[kBlock];        // the records' last windows, as window numbers (end position / 30)
         size_t i = 0;
         while (i < n)

@@ -196,7 +196,7 @@ public:
     // entries appended in one copy. Anything else: record by record through addFast().
     void addBlockToWriteSlot(unsigned id, const unsigned * bins, size_t n)
     {
-        constexpr size_t kMost = 64;
+        constexpr size_t kMost = 256;
         Slot & slot = slots[writeSlot];
         if (light && !slot.entries.empty() && n <= kMost)
         {
