@@ -56,10 +56,10 @@ def main():
     path = os.path.join(ROOT, "gpurun_out", "_lanes_members.npz")
     np.savez(path, data=data, offs=offs, out_offs=out_offs, want=want)
     result = {}
-    variants = [("", l) for l in (16, 8)]
+    variants = [("", l) for l in (8, 4)]
     vdir = os.path.join(ROOT, "popdel_amd", "lib", "variants")          # experiment builds of the library, if any
     if os.path.isdir(vdir):
-        variants += [(os.path.join(vdir, f), l) for f in sorted(os.listdir(vdir)) if f.endswith(".so") for l in (16, 8)]
+        variants += [(os.path.join(vdir, f), l) for f in sorted(os.listdir(vdir)) if f.endswith(".so") for l in (8, 4)]
     for lib, lanes in variants:
         env = dict(os.environ, POPDEL_HIP_INFLATE_LANES=str(lanes))
         if lib:
