@@ -67,14 +67,14 @@ struct StridedTablesOf
 struct BitReader
 {
     const uint8_t * in;
-    uint64_t pos, end;     // pos: first byte that is neither in `buf` nor in `ahead`
+    uint32_t pos, end;     // pos: first byte that is neither in `buf` nor in `ahead` (a member is far below 4 GB: inflateGzipMember)
     uint64_t buf;
     unsigned cnt;
     uint32_t ahead;        // the next four input bytes, loaded when the previous word went into `buf`: the load's latency
     bool     haveAhead;    // passes while the decoder works through the bits it has (a lane has nothing else to hide it)
     bool     shortInput;
 
-    PD_INF_FN void start(const uint8_t * data, uint64_t from, uint64_t to)
+    PD_INF_FN void start(const uint8_t * data, uint32_t from, uint32_t to)
     {
         in = data;
         pos = from;
@@ -136,7 +136,7 @@ struct BitReader
         cnt -= drop;
     }
     // offset of the first byte that has not been consumed (call after alignToByte)
-    PD_INF_FN uint64_t bytePos() const { return pos - (haveAhead ? 4u : 0u) - (cnt >> 3); }
+    PD_INF_FN uint32_t bytePos() const { return pos - (haveAhead ? 4u : 0u) - (cnt >> 3); }
 };
 
 // One symbol of a canonical code (counts at countAt + 1 .. 15, symbols at symbolAt): -1 if the bits are no code of the set,
@@ -266,7 +266,7 @@ PD_INF_FN int decodeFast(BitReader & br, Tab & tab, const FastCode & fc, unsigne
 struct Output
 {
     uint8_t * out;
-    uint64_t  n, cap;
+    uint32_t  n, cap;
     uint64_t  tail;        // the last eight bytes written, most recent in the low byte
     uint32_t  crc;
     const uint32_t * crcTable;
@@ -472,6 +472,8 @@ PD_INF_FN uint32_t inflateGzipMember(const uint8_t * in, uint64_t inLen, uint8_t
 {
     *outLen = 0;
     *used = 0;
+    if (inLen > 0xffff0000ull)
+        return kBadHeader;          // (positions are kept in 32 bits: nothing the profiles hold comes near)
     if (inLen < 18u)
         return inLen >= 3u && !(in[0] == 0x1f && in[1] == 0x8b && in[2] == 8) ? kBadHeader : kTruncated;
     if (in[0] != 0x1f || in[1] != 0x8b || in[2] != 8 || (in[3] & 0xe0u) != 0u)
@@ -496,11 +498,11 @@ PD_INF_FN uint32_t inflateGzipMember(const uint8_t * in, uint64_t inLen, uint8_t
     if (p >= inLen)
         return kTruncated;
     BitReader br;
-    br.start(in, p, inLen);
+    br.start(in, (uint32_t)p, (uint32_t)inLen);
     Output o;
     o.out = out;
     o.n = 0;
-    o.cap = outCap;
+    o.cap = outCap > 0xffff0000ull ? 0xffff0000u : (uint32_t)outCap;
     o.tail = 0;
     o.crc = 0xffffffffu;
     o.crcTable = crcTable;
