@@ -1292,6 +1292,10 @@ def main():
                 wt = float(mw.group(4))
                 warmed = dict(warmed_segments=ws, warmed_seconds_per_segment=wt / ws, warmed_value=ww * wn / wt,
                               warmed_decode_seconds_per_segment=float(mw.group(5)) / ws, warmed_replay_seconds_per_segment=float(mw.group(6)) / ws)
+                mc = re.search(r"warmed rounds: .*; CPU ([0-9.e+-]+) s \(all threads\)", r.stderr)
+                if mc:
+                    # CPU seconds of all threads per warmed round and the CPUs that kept busy: at the job's quota the round is CPU-bound
+                    warmed.update(warmed_cpu_seconds_per_segment=float(mc.group(1)) / ws, warmed_cpus_busy=float(mc.group(1)) / wt)
             loader = [l for l in r.stderr.splitlines() if "[popdel timing] loader:" in l]
             if loader:
                 warmed["loader"] = loader[-1][len("[popdel timing] loader: "):]

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 12
+#define PD_ABI_VERSION 13
 
 /* One read group after start-up conditioning.
  * Replaces: `Histogram` (reference insert_histogram_popdel.h:19-43) after processHistogram()
@@ -343,6 +343,19 @@ typedef struct pd_walk
 /* Stage the segment (entries -> HBM -> pair instances -> layout) and enqueue the window loop's genotyping for it; the
  * ticket is collected with pd_segment_collect() like that of pd_segment_submit(). */
 int pd_walk_submit(pd_ctx *ctx, const pd_walk *walk, uint64_t *ticket);
+
+/* Host address ranges that hold the tables pd_walk::rg_entries point into and stay mapped for the rest of the process (the
+ * host's table pool hands them out region by region). The library may page-lock a range the first time a walk's entries lie
+ * inside it and from then on lets the DEVICE fetch such entries from the tables themselves (one gather kernel over the link)
+ * instead of copying them into a page-locked array on the host threads first -- 8 bytes per pair and segment of host CPU
+ * time, a twelfth of a round's in `popdel call`. Ranges may be offered again; entries outside every offered range take the
+ * staging copy as before. Must not be called for memory that will be unmapped or given back (MADV_DONTNEED) while a context
+ * lives. Returns 0. (ABI 13) */
+int pd_host_regions_offer(const void *const *begin, const uint64_t *bytes, uint32_t n);
+/* Diagnosis: entries of all pd_walk_submit() calls of the context so far that the device fetched from the host's tables
+ * (*gathered) and that went through the staging copy (*staged); bytes of offered ranges page-locked so far (*locked_bytes).
+ * Any pointer may be NULL. */
+int pd_walk_entry_counts(pd_ctx *ctx, uint64_t *gathered, uint64_t *staged, uint64_t *locked_bytes);
 
 /* 1 if the backend behind the ABI offers pd_walk_submit() (the oracle does not: it takes pd_segment only), else 0. A
  * property of the library: `ctx` may be NULL (a caller that plans its first segment while the context is still being

@@ -1106,6 +1106,14 @@ int pd_last_stage_timing(pd_ctx *, pd_stage_timing * out)
     return out ? 0 : 1;
 }
 double pd_host_copy_gbs(uint64_t) { return 0; }
+int pd_host_regions_offer(const void * const *, const uint64_t *, uint32_t) { return 0; }
+int pd_walk_entry_counts(pd_ctx *, uint64_t * g, uint64_t * s, uint64_t * l)
+{
+    if (g) *g = 0;
+    if (s) *s = 0;
+    if (l) *l = 0;
+    return 0;
+}
 pd_inflater * pd_inflater_create(int) { return nullptr; }
 const char * pd_inflater_last_error(pd_inflater *) { return "the oracle backend has no device"; }
 void pd_inflater_destroy(pd_inflater *) {}

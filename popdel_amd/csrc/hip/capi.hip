@@ -482,6 +482,8 @@ struct pd_ctx
     uint32_t walkCapActive = 0, walkCapPending = 1024;
     PinnedBuf<uint32_t> hWalkBorder, hWalkIdOffset;
     PinnedBuf<uint2> hWalkEntries;
+    PinnedBuf<uint64_t> hWalkSrc;           // per read group: device-visible address of its entries in the host's own tables (0: staged)
+    DevBuf<uint64_t> dWalkSrc;
     PinnedBuf<uint8_t> hWalkFlags;          // switches, then equal_run
     DevBuf<uint32_t> dWalkBorder, dWalkIdOffset, dWalkCount;
     DevBuf<uint2> dWalkEntries;
@@ -490,6 +492,7 @@ struct pd_ctx
     DevBuf<unsigned long long> dWalkTotals; // [0] instances of the segment, [1] pairs left active, [2] problems
     PinnedBuf<unsigned long long> hWalkTotals;
     uint64_t walkActive = 0;                // pairs left active after the last submitted walk
+    uint64_t walkGathered = 0, walkStaged = 0;      // entries the device fetched from the host's tables / the host threads staged
     uint64_t nextHandle = 1, nextTicket = 1;
     std::map<uint64_t, Run> runs;
 
@@ -2604,6 +2607,94 @@ void growWalkState(pd_ctx & c, uint32_t needActive, uint32_t needPending)
 
 }  // namespace
 
+namespace {
+// Host ranges offered by pd_host_regions_offer(): page-locked (and mapped for the device) the first time a walk's entries lie
+// inside one. POPDEL_HIP_WALK_GATHER=0 keeps the staging copy for everything.
+struct HostRange
+{
+    uintptr_t begin = 0, end = 0;
+    uintptr_t deviceBase = 0;       // device-visible address of `begin` once registered
+    int state = 0;                  // 0 offered, 1 registered, 2 the runtime refused (left to the staging copy)
+};
+std::mutex g_hostRangeLock;
+std::vector<HostRange> g_hostRanges;        // sorted by begin, disjoint
+std::atomic<uint64_t> g_hostBytesRegistered{0};
+
+bool walkGatherWanted()
+{
+    static const bool on = [] {
+        const char * e = std::getenv("POPDEL_HIP_WALK_GATHER");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// device-visible address of [p, p + bytes) if it lies inside an offered range (registering that range on first use), else 0
+uintptr_t deviceViewOfHost(const void * p, size_t bytes)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    std::lock_guard<std::mutex> guard(g_hostRangeLock);
+    auto it = std::upper_bound(g_hostRanges.begin(), g_hostRanges.end(), a, [](uintptr_t v, const HostRange & r) { return v < r.begin; });
+    if (it == g_hostRanges.begin())
+        return 0;
+    HostRange & r = *(it - 1);
+    if (a < r.begin || a + bytes > r.end)
+        return 0;
+    if (r.state == 0)
+    {
+        void * dev = nullptr;
+        if (hipHostRegister(reinterpret_cast<void *>(r.begin), r.end - r.begin, hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess &&
+            hipHostGetDevicePointer(&dev, reinterpret_cast<void *>(r.begin), 0) == hipSuccess && dev)
+        {
+            r.deviceBase = reinterpret_cast<uintptr_t>(dev);
+            r.state = 1;
+            g_hostBytesRegistered += r.end - r.begin;
+        }
+        else
+        {
+            (void)hipGetLastError();
+            r.state = 2;
+        }
+    }
+    return r.state == 1 ? r.deviceBase + (a - r.begin) : 0;
+}
+}  // namespace
+
+int pd_host_regions_offer(const void * const * begin, const uint64_t * bytes, uint32_t n)
+{
+    if (n != 0 && (!begin || !bytes))
+        return 1;
+    std::lock_guard<std::mutex> guard(g_hostRangeLock);
+    for (uint32_t k = 0; k < n; ++k)
+    {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(begin[k]), b = a + bytes[k];
+        if (a == 0 || bytes[k] == 0)
+            continue;
+        auto it = std::lower_bound(g_hostRanges.begin(), g_hostRanges.end(), a, [](const HostRange & r, uintptr_t v) { return r.begin < v; });
+        // (offered before, or overlapping something offered before: ignored)
+        if ((it != g_hostRanges.end() && it->begin < b) || (it != g_hostRanges.begin() && (it - 1)->end > a))
+            continue;
+        HostRange r;
+        r.begin = a;
+        r.end = b;
+        g_hostRanges.insert(it, r);
+    }
+    return 0;
+}
+
+int pd_walk_entry_counts(pd_ctx * c, uint64_t * gathered, uint64_t * staged, uint64_t * locked_bytes)
+{
+    if (!c)
+        return 1;
+    if (gathered)
+        *gathered = c->walkGathered;
+    if (staged)
+        *staged = c->walkStaged;
+    if (locked_bytes)
+        *locked_bytes = g_hostBytesRegistered.load();
+    return 0;
+}
+
 int pd_walk_supported(const pd_ctx *) { return 1; }
 
 int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
@@ -2654,23 +2745,63 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
         c->hWalkEntries.resize(nEntries);
         c->dWalkEntries.ensure(std::max<uint64_t>(1, nEntries));
         {
-            // the read groups' tables -> one page-locked array (host threads), slab by slab under the upload
+            // Where the entries lie in host memory the device can read (ranges the host offered, page-locked on first use) it
+            // fetches them itself: one gather kernel over the link instead of 8 bytes per pair copied by the host threads.
+            // Everything else: the read groups' tables -> one page-locked array (host threads), slab by slab under the upload.
             static_assert(sizeof(pd_walk_entry) == sizeof(uint2), "entry layout");
-            const size_t nSlabs = std::min<size_t>(8, std::max<size_t>(1, nRg / 64));
-            for (size_t slab = 0; slab < nSlabs; ++slab)
+            c->hWalkSrc.resize(nRg);
+            uint64_t gathered = 0;
+            for (uint32_t r = 0; r < nRg; ++r)
             {
-                const size_t rLo = nRg * slab / nSlabs, rHi = nRg * (slab + 1) / nSlabs;
-                const uint64_t a = c->hRgOffsets[rLo], b = c->hRgOffsets[rHi];
-                if (b == a)
-                    continue;
-                pdh::parallelFor(rHi - rLo, [&](size_t k) {
-                    const size_t r = rLo + k;
-                    const uint64_t n = c->hRgOffsets[r + 1] - c->hRgOffsets[r];
-                    if (n)
-                        std::memcpy(c->hWalkEntries.data() + c->hRgOffsets[r], wk->rg_entries[r], n * sizeof(uint2));
-                }, 16);
-                PD_HIP(hipMemcpyAsync(c->dWalkEntries.p + a, c->hWalkEntries.data() + a, (b - a) * sizeof(uint2), hipMemcpyHostToDevice, cs));
+                const uint64_t n = c->hRgOffsets[r + 1] - c->hRgOffsets[r];
+                c->hWalkSrc[r] = n != 0 && walkGatherWanted() ? deviceViewOfHost(wk->rg_entries[r], n * sizeof(uint2)) : 0u;
+                gathered += c->hWalkSrc[r] ? n : 0u;
             }
+            if (gathered != nEntries)
+            {
+                const size_t nSlabs = std::min<size_t>(8, std::max<size_t>(1, nRg / 64));
+                for (size_t slab = 0; slab < nSlabs; ++slab)
+                {
+                    const size_t rLo = nRg * slab / nSlabs, rHi = nRg * (slab + 1) / nSlabs;
+                    const uint64_t a = c->hRgOffsets[rLo], b = c->hRgOffsets[rHi];
+                    uint64_t staged = 0;
+                    for (size_t r = rLo; r < rHi; ++r)
+                        staged += c->hWalkSrc[r] ? 0u : c->hRgOffsets[r + 1] - c->hRgOffsets[r];
+                    if (staged == 0)
+                        continue;
+                    pdh::parallelFor(rHi - rLo, [&](size_t k) {
+                        const size_t r = rLo + k;
+                        const uint64_t n = c->hRgOffsets[r + 1] - c->hRgOffsets[r];
+                        if (n && !c->hWalkSrc[r])
+                            std::memcpy(c->hWalkEntries.data() + c->hRgOffsets[r], wk->rg_entries[r], n * sizeof(uint2));
+                    }, 16);
+                    // (the whole slab goes up; the stretches of gathered read groups are written by the kernel behind it)
+                    PD_HIP(hipMemcpyAsync(c->dWalkEntries.p + a, c->hWalkEntries.data() + a, (b - a) * sizeof(uint2), hipMemcpyHostToDevice, cs));
+                }
+            }
+            if (gathered != 0)
+            {
+                // One kernel of a few workgroups reads the tables over the link (pd::launchGatherHostEntries). Measured against it on
+                // 4,000 samples x 4 Mb, same box: a copy per read group on the copy engines (POPDEL_HIP_WALK_GATHER=copies) -- 4,000
+                // hipMemcpyAsync calls per segment, 0.083 instead of 0.064 s per round.
+                static const bool byCopies = [] {
+                    const char * e = std::getenv("POPDEL_HIP_WALK_GATHER");
+                    return e && e[0] == 'c';
+                }();
+                if (!byCopies)
+                {
+                    c->dWalkSrc.uploadPinned(c->hWalkSrc, cs);
+                    pd::launchGatherHostEntries(c->dWalkSrc.p, dEntryOffsets.p, c->dWalkEntries.p, nRg, cs);
+                    PD_HIP(hipGetLastError());
+                }
+                else
+                    for (uint32_t r = 0; r < nRg; ++r)
+                        if (c->hWalkSrc[r])
+                            PD_HIP(hipMemcpyAsync(c->dWalkEntries.p + c->hRgOffsets[r], wk->rg_entries[r],
+                                                  (c->hRgOffsets[r + 1] - c->hRgOffsets[r]) * sizeof(uint2), hipMemcpyHostToDevice, cs));
+            }
+            c->walkGathered += gathered;
+            c->walkStaged += nEntries - gathered;
         }
         // ---- instances per read group, their offsets (the build's rgOffsets), then the instances and the new state
         pd::WalkInput in;

@@ -50,5 +50,10 @@ void launchWalkEmit(const WalkInput & in, const WalkState & st, const WalkParams
                     const uint64_t * instOffsets, int32_t * outDev, uint32_t * outOn, uint32_t * outOff, uint32_t * outStart,
                     const WalkState & nxt, unsigned * problems, unsigned long long * activeTotal, hipStream_t stream);
 
+// Entries fetched by the device from the host's tables themselves: src[rg] is the device-visible address of the read group's
+// entries in page-locked host memory (0: none / taken care of by a staging copy), rgOffsets as in WalkInput; one workgroup
+// walks a read group's entries, 16 bytes per lane and trip (the link wants many requests in flight: nRg workgroups of 256).
+void launchGatherHostEntries(const uint64_t * src, const uint64_t * rgOffsets, uint2 * entries, unsigned nRg, hipStream_t stream);
+
 }  // namespace pd
 #endif

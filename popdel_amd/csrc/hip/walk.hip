@@ -13,6 +13,9 @@
 //   walkScanKernel    exclusive scan -> instance offsets of the read groups (the build's rgOffsets), total
 //   walkEmitKernel    per read group: the instances in the order the walk logs them (carried pairs by id, then
 //                     activations in entry order), the new active and pending lists
+#include <algorithm>
+#include <cstdlib>
+
 #include "pd_walk.h"
 
 namespace pd {
@@ -300,6 +303,58 @@ void launchWalkEmit(const WalkInput & in, const WalkState & st, const WalkParams
 {
     hipLaunchKernelGGL(walkEmitKernel, dim3(nRg), dim3(256), 0, stream, in, st, w, rgConst, instOffsets, outDev, outOn, outOff, outStart, nxt,
                        problems, activeTotal);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void gatherHostEntriesKernel(const uint64_t * __restrict__ src, const uint64_t * __restrict__ rgOffsets,
+                                                               uint2 * __restrict__ entries, unsigned nRg)
+{
+    for (unsigned r = blockIdx.x; r < nRg; r += gridDim.x)
+    {
+        const uint64_t a = src[r];
+        if (a == 0)
+            continue;
+        const uint64_t lo = rgOffsets[r], n = rgOffsets[r + 1] - lo;
+        const uint2 * from = reinterpret_cast<const uint2 *>(a);
+        uint2 * to = entries + lo;
+        // (table blocks and `entries` are 16-byte aligned as wholes; a read group's run begins on any 8-byte entry)
+        uint64_t i = 0;
+        if (n != 0 && ((reinterpret_cast<uintptr_t>(from) ^ reinterpret_cast<uintptr_t>(to)) & 8u) == 0)
+        {
+            const uint64_t head = (reinterpret_cast<uintptr_t>(from) & 8u) ? 1u : 0u;
+            if (threadIdx.x == 0 && head)
+                to[0] = from[0];
+            const uint64_t pairs = (n - head) / 2;
+            const uint4 * f4 = reinterpret_cast<const uint4 *>(from + head);
+            uint4 * t4 = reinterpret_cast<uint4 *>(to + head);
+            for (uint64_t k = threadIdx.x; k < pairs; k += 256u)
+                t4[k] = f4[k];
+            i = head + 2 * pairs;
+        }
+        for (uint64_t k = i + threadIdx.x; k < n; k += 256u)
+            to[k] = from[k];
+    }
+}
+}  // namespace
+
+// Few workgroups: the link needs ~100 KB of requests in flight, not the chip. `popdel call` on 4,000 samples x 4 Mb, warmed
+// rounds on one box: one workgroup per read group (4,000) 0.0638 s per round -- they hold workgroup slots for the length of the
+// transfer and the loader's gunzip kernels beside them wait --, 512: 0.0651, 128: 0.0654, 32: 0.0611 (the staging copy: 0.0637).
+static unsigned gatherGroups()
+{
+    static const unsigned n = [] {
+        const char * e = std::getenv("POPDEL_HIP_GATHER_GROUPS");
+        const int v = e ? std::atoi(e) : 0;
+        return v > 0 ? (unsigned)v : 32u;
+    }();
+    return n;
+}
+
+void launchGatherHostEntries(const uint64_t * src, const uint64_t * rgOffsets, uint2 * entries, unsigned nRg, hipStream_t stream)
+{
+    if (nRg == 0)
+        return;
+    hipLaunchKernelGGL(gatherHostEntriesKernel, dim3(std::min(nRg, gatherGroups())), dim3(256), 0, stream, src, rgOffsets, entries, nRg);
 }
 
 }  // namespace pd

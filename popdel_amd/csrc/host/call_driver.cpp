@@ -783,6 +783,18 @@ public:
                           << " rounds fetched ahead, " << roundsOnDemand_ << " when they began (" << roundsGuessedWrong_ << " of them after a wrong guess); read by the decoder threads all the same: "
                           << hostDecodes_[0].load() << " sample rounds without usable blocks, " << hostDecodes_[1].load() << " whose parsed blocks ended early" << std::endl;
             }
+            if (!ctxs_.empty() && ctxs_[0])
+            {
+                uint64_t gathered = 0, staged = 0, locked = 0, g = 0, st = 0;
+                for (pd_ctx * c : ctxs_)
+                    if (c && pd_walk_entry_counts(c, &g, &st, &locked) == 0)
+                    {
+                        gathered += g;
+                        staged += st;
+                    }
+                std::cerr << "[popdel timing] start entries of the window loop: " << gathered << " fetched by the device from the tables themselves ("
+                          << locked << " bytes of the table pool page-locked), " << staged << " copied by the host threads first" << std::endl;
+            }
             std::cerr << "[popdel timing] parity: " << nearIntegerShifts_ << " reference-shift quotients within 1e-9 of an integer (their truncation "
                          "may differ from the x87 reference's) in " << candidateCells_ << " candidate cells, " << windowCalls_ << " window calls" << std::endl;
             // steady state: the rounds that began after the backend was up, to the end of the loop (last results written)
@@ -818,7 +830,8 @@ public:
                         rep += rounds_[k].replay;
                     }
                     std::cerr << "[popdel timing] warmed rounds: segments " << rounds_.size() - k0 - 3 << "; windows " << w << "; samples " << p_.sampleNum
-                              << "; wall " << rounds_.back().start - rounds_[k0 + 2].start << " s; decode " << dec << " s; replay " << rep << " s" << std::endl;
+                              << "; wall " << rounds_.back().start - rounds_[k0 + 2].start << " s; decode " << dec << " s; replay " << rep << " s; CPU "
+                              << rounds_.back().cpu - rounds_[k0 + 2].cpu << " s (all threads)" << std::endl;
                 }
             }
         }
@@ -913,6 +926,7 @@ private:
     int pendingGuessSet_ = 0;
     uint64_t roundsAhead_ = 0, roundsOnDemand_ = 0, roundsGuessedWrong_ = 0;
     std::vector<int> gunzipDevices_ = {0};
+    size_t regionsOffered_ = 0;             // regions of the table pool the backend has been told of (hand-over thread)
     // sample rounds the decoder threads read themselves although a loader ran: [0] it had nothing usable for the sample, [1] its
     // parsed blocks end before the point at which the round's reader stops
     mutable std::atomic<uint64_t> hostDecodes_[2] = {};
@@ -959,12 +973,14 @@ private:
     void drainHandOver();                       // ... all of them, and the last one's results written
     void collectAndWrite(const std::vector<uint64_t> & tickets, const std::string & contig);
     bool timingPrinted_ = false;
+    const bool timingWanted_ = getenv("POPDEL_TIMING") != nullptr;
     // POPDEL_TIMING: the rounds of the segment loop one by one (start, windows of the segment, decode and replay seconds) and
     // what the backend reports per collected segment -- for the steady-state figures of a long run (start-up excluded) and
     // for the count of reference-shift truncations that sit on the knife edge (pd_timing::n_near_integer_shifts)
     struct RoundNote
     {
         double start = 0, decode = 0, replay = 0;
+        double cpu = 0;                 // the process's CPU time (user + system) when the round began (POPDEL_TIMING)
         unsigned windows = 0;
     };
     std::vector<RoundNote> rounds_;
@@ -1399,6 +1415,8 @@ void CallRun::createLoaders()
 
 void CallRun::startLoaderAhead()
 {
+    // (not before the running round's loader is through: started at once, the two loaders share the device and the round
+    // that is waited for gets its blocks later -- 0.064 instead of 0.061 s per warmed round)
     if (pendingGuess_.empty() || !gunzip_ || !gunzip_->allDone())
         return;
     gunzipAhead_ = pendingGuessSet_;
@@ -2226,6 +2244,23 @@ void CallRun::handOver(HandOverJob & job)
     }
     const double t0 = PhaseClock::now();
     workerTickets_.assign(ctxs_.size(), 0);
+    {
+        // the table pool's regions (they live as long as the process): the backend may page-lock them and fetch the entries
+        // from the tables themselves instead of having the host threads copy them into a page-locked array first
+        const auto regions = HugePool::instance().regions();
+        if (regions.size() != regionsOffered_)
+        {
+            std::vector<const void *> begin;
+            std::vector<uint64_t> bytes;
+            for (size_t k = regionsOffered_; k < regions.size(); ++k)
+            {
+                begin.push_back(regions[k].first);
+                bytes.push_back(regions[k].second);
+            }
+            (void)pd_host_regions_offer(begin.data(), bytes.data(), static_cast<uint32_t>(begin.size()));
+            regionsOffered_ = regions.size();
+        }
+    }
     onEveryContext([&](unsigned r) {
         const uint32_t g0 = shardRg_[r], g1 = shardRg_[r + 1];
         pd_walk wk;
@@ -2639,6 +2674,12 @@ int CallRun::run()
         }
         rounds_.emplace_back();
         rounds_.back().start = PhaseClock::now();
+        if (timingWanted_)
+        {
+            struct rusage ru;
+            getrusage(RUSAGE_SELF, &ru);
+            rounds_.back().cpu = ru.ru_utime.tv_sec + ru.ru_stime.tv_sec + 1e-6 * (ru.ru_utime.tv_usec + ru.ru_stime.tv_usec);
+        }
         if (const char * from = getenv("POPDEL_CPU_PROFILE_FROM_ROUND"))       // (diagnosis: the warmed rounds only)
             if (rounds_.size() == static_cast<size_t>(atoi(from)))
                 CpuSampler::start();
