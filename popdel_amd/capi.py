@@ -197,6 +197,15 @@ def _let_torch_initialise_first():
         torch.cuda.init()
 
 
+def offer_host_region(lib, array):
+    """pd_host_regions_offer for the memory of `array` (which must stay mapped for the rest of the process)."""
+    lib.pd_host_regions_offer.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32]
+    lib.pd_host_regions_offer.restype = C.c_int
+    begin = (C.c_void_p * 1)(array.ctypes.data)
+    size = (C.c_uint64 * 1)(array.nbytes)
+    return lib.pd_host_regions_offer(begin, size, 1)
+
+
 def load_hip():
     """The product backend. Fails loudly when the HIP library has not been built."""
     if not os.path.exists(HIP_LIBRARY):
@@ -362,12 +371,22 @@ class Context:
         return t.value
 
     def submit_walk(self, first_window_pos, n_windows, rg_starts, rg_devs, end_border, switches, equal_run, step_pos=None,
-                    id_offset=None, window_shift=30):
+                    id_offset=None, window_shift=30, table_arena=None, in_arena=None):
         """pd_walk_submit: the segment as the loader's tables hold it. rg_starts / rg_devs: per read group the start
-        positions and deviations of its new start-slot entries (arrays; ignored where switches[rg] == 0)."""
+        positions and deviations of its new start-slot entries (arrays; ignored where switches[rg] == 0). table_arena: a
+        (N, 2) uint32 array the tables are laid out in one behind the other (a stand-in for the host's table pool, see
+        offer_host_region); in_arena: which read groups go there (default: all)."""
         n_rg = len(rg_starts)
         tables = [np.ascontiguousarray(np.stack([np.asarray(s, np.uint32), np.asarray(d, np.int32).view(np.uint32)], axis=1))
                   if len(s) else np.zeros((0, 2), np.uint32) for s, d in zip(rg_starts, rg_devs)]
+        if table_arena is not None:
+            at = 1                          # (an odd entry: runs begin on any 8-byte boundary)
+            for r in range(n_rg):
+                if len(tables[r]) and (in_arena is None or in_arena[r]):
+                    view = table_arena[at:at + len(tables[r])]
+                    view[:] = tables[r]
+                    tables[r] = view
+                    at += len(view) + (r % 2)
         counts = np.array([len(t) for t in tables], np.uint32)
         ptrs = (C.POINTER(PdWalkEntry) * n_rg)(*[t.ctypes.data_as(C.POINTER(PdWalkEntry)) for t in tables])
         border = np.ascontiguousarray(end_border, np.uint32)
@@ -381,6 +400,13 @@ class Context:
         t = C.c_uint64()
         self._check(self.lib.pd_walk_submit(self.handle, C.byref(wk), C.byref(t)))
         return t.value
+
+    def walk_entry_counts(self):
+        """(entries the device fetched from offered host regions, entries staged by the host threads, bytes page-locked)"""
+        g, st, lk = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.lib.pd_walk_entry_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        self._check(self.lib.pd_walk_entry_counts(self.handle, C.byref(g), C.byref(st), C.byref(lk)))
+        return g.value, st.value, lk.value
 
     def walk_active(self):
         """(read group, start, deviation, id) arrays of the pairs still active after the last submitted walk"""

@@ -52,6 +52,55 @@ def test_first_segment_equals_the_interval_rule(built):
             assert np.array_equal(v, b[k]), k
 
 
+_ARENA = None
+
+
+def arena():
+    """16 MB of anonymous memory that lives as long as the process (what the library page-locks is never given back)."""
+    global _ARENA
+    if _ARENA is None:
+        import mmap
+        _ARENA = (mmap.mmap(-1, 16 << 20), )
+        _ARENA = _ARENA + (np.frombuffer(_ARENA[0], np.uint32).reshape(-1, 2), )
+    return _ARENA[1]
+
+
+@pytest.mark.parametrize("share", ["all", "half"])
+def test_entries_fetched_from_offered_host_regions(built, share):
+    """pd_host_regions_offer(): start entries that lie in a range the host offered are fetched by the device from the tables
+    themselves (a gather kernel over the link), the others go through the staging copy -- same calls, bit for bit, as with
+    POPDEL_HIP_WALK_GATHER unset and nothing offered (the test above), and the counters say which way the entries went."""
+    from popdel_amd import capi
+    n, region, first, W = 40, (1000000, 1090000), 1000020, 2900
+    lib, rg, pairs = cohort(n, region)
+    starts, devs = [], []
+    for pos, dev in pairs:
+        keep = pos >= first
+        starts.append(pos[keep])
+        devs.append(dev[keep])
+    equal_run = [1 if len(s) and s[0] == first else 0 for s in starts]
+    hip = capi.load_hip()
+    kw = dict(end_border=[0xffffffff] * n, switches=[2] * n, equal_run=equal_run)
+    ctx = capi.Context(hip, [rg] * n, list(range(n + 1)))
+    a = ctx.collect(ctx.submit_walk(first, W, starts, devs, **kw))
+    assert ctx.walk_entry_counts()[0] == 0
+    ctx.close()
+    buf = arena()
+    assert capi.offer_host_region(hip, buf) == 0 and capi.offer_host_region(hip, buf) == 0      # (offering again is harmless)
+    inside = [share == "all" or k % 2 == 0 for k in range(n)]
+    ctx = capi.Context(hip, [rg] * n, list(range(n + 1)))
+    b = ctx.collect(ctx.submit_walk(first, W, starts, devs, table_arena=buf, in_arena=inside, **kw))
+    gathered, staged, locked = ctx.walk_entry_counts()
+    ctx.close()
+    total = sum(len(s) for s in starts)
+    want = sum(len(s) for s, i in zip(starts, inside) if i)
+    assert gathered == want and staged == total - want and locked >= buf.nbytes
+    assert a["n_calls"] > 10 and a["n_calls"] == b["n_calls"]
+    for k, v in a.items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(v, b[k]), k
+
+
 def test_state_from_segment_to_segment(built):
     """Two segments of one read group, handed over by hand: pairs filed one end slot ahead stay active into the second
     segment and leave at their time there; pairs whose end record sat in the first read slot are gone after the switch
