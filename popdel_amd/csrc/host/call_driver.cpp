@@ -224,12 +224,40 @@ public:
         const std::vector<uint64_t> * cuts = nullptr;        // the blocks' file offsets
         const std::vector<uint64_t> * regionOffsets = nullptr;
     };
-    // items per chunk: a launch takes ~10 ms however few members it has (one lane works through its member alone), so what
-    // keeps the decoder threads fed is SEVERAL chunks on the device at a time -- three inflaters, a thread each -- and a
-    // short first chunk (measured: 2,048-sample chunks and four inflaters of 512 were no better)
-    static constexpr size_t kFirstChunk = 256, kChunk = 1024, kInflaters = 3;
-    static size_t chunkOf(size_t item) { return item < kFirstChunk ? 0 : 1 + (item - kFirstChunk) / kChunk; }
-    static size_t chunkBegin(size_t c) { return c == 0 ? 0 : kFirstChunk + (c - 1) * kChunk; }
+    // Items per chunk: a round's readers are dealt to the three inflaters (a thread each) in three equal chunks -- the gunzip
+    // kernel is a chain of dependent instructions per member and wants many members per launch (a launch of 21,000 takes 5.4 ms,
+    // one of 200,000 takes 37), and with the staging copy of the walk gone the device's work on the blocks is what a warmed
+    // round of `popdel call` waits for. Measured on 4,000 samples x 4 Mb, same box (first chunk : the others, seconds per
+    // warmed round): 256 : 1024 (rounds 4-5: five chunks) 0.0604, 512 : 2048 0.0546, 1344 : 1344 (three) 0.0545, 1024 : 3072
+    // 0.0574, 512 : 4096 0.0615. At most 4,096 items per chunk (its buffers: ~0.5 GB page-locked and on the device); cohorts
+    // beyond 12,288 readers take more chunks, an inflater's buffers go round as before. POPDEL_LOADER_CHUNK /
+    // POPDEL_LOADER_FIRST_CHUNK fix the sizes (measurements).
+    static constexpr size_t kInflaters = 3;
+    static size_t envOr(const char * name, size_t dflt)
+    {
+        const char * e = getenv(name);
+        const long v = e ? atol(e) : 0;
+        return v >= 64 ? static_cast<size_t>(v) : dflt;
+    }
+    static size_t chunkFor(size_t readers)
+    {
+        static const size_t fixed = envOr("POPDEL_LOADER_CHUNK", 0);
+        if (fixed)
+            return fixed;
+        const size_t per = ((readers + kInflaters - 1) / kInflaters + 63) / 64 * 64;
+        return std::min<size_t>(4096, std::max<size_t>(256, per));
+    }
+    static size_t firstChunkFor(size_t readers)
+    {
+        static const size_t fixed = envOr("POPDEL_LOADER_FIRST_CHUNK", 0);
+        return fixed ? fixed : chunkFor(readers);
+    }
+    size_t firstChunk_ = 256, chunk_ = 1024;            // of the round the loader is on (start())
+    size_t chunkOf(size_t item) const { return item < firstChunk_ ? 0 : 1 + (item - firstChunk_) / chunk_; }
+    size_t chunkBegin(size_t c) const { return c == 0 ? 0 : firstChunk_ + (c - 1) * chunk_; }
+    // samples a batch of the replay may span: the first two chunks (an inflater's buffers are recycled once the replay has
+    // passed the chunk three before it, and the replay releases a batch as a whole)
+    static size_t batchLimitFor(size_t readers) { return firstChunkFor(readers) + chunkFor(readers); }
 
     // Descriptors of the profiles, kept open from round to round as far as the process's limit allows (every sample's file is
     // asked twice per round: its index, then its bytes); a sample beyond the limit is opened and closed per use as before.
@@ -285,6 +313,8 @@ public:
     {
         finish();
         items_ = std::move(items);
+        firstChunk_ = firstChunkFor(items_.size());
+        chunk_ = chunkFor(items_.size());
         contig_ = contig;
         ready_.assign(items_.size(), Ready());
         valid_.assign(items_.size(), 1);
@@ -2697,8 +2727,10 @@ int CallRun::run()
         // (never wider than the first two chunks of the device gunzip: an inflater's buffers are recycled once the replay has
         // passed the chunk three before it, and the replay releases a batch as a whole -- a batch that spanned four chunks would
         // wait for a chunk whose buffers it holds itself)
+        // (the loader chunks its READERS -- at most the samples; with the limit taken for the smallest number of readers that
+        // still needs more than three chunks, a batch of samples never spans more than two chunks of any round)
         const unsigned batch = std::min<unsigned>(std::max(512u, 8u * hostThreads()),
-                                                  static_cast<unsigned>(GunzipPrefetch::kFirstChunk + GunzipPrefetch::kChunk));
+                                                  static_cast<unsigned>(GunzipPrefetch::batchLimitFor(p_.sampleNum)));
         for (unsigned b0 = 0; b0 < p_.sampleNum; b0 += batch)
         {
             const unsigned b1 = std::min(p_.sampleNum, b0 + batch);
