@@ -1299,6 +1299,12 @@ def main():
             loader = [l for l in r.stderr.splitlines() if "[popdel timing] loader:" in l]
             if loader:
                 warmed["loader"] = loader[-1][len("[popdel timing] loader: "):]
+                # gpu_busy_share counts the genotyping kernels of the context only; the loader's gunzip + parse kernels (all
+                # rounds of the run) are the larger part of what the device does in the product
+                mk = re.search(r"copies \+ kernel ([0-9.e+-]+) s \(kernel ([0-9.e+-]+) s\)", loader[-1])
+                if mk:
+                    warmed["loader_kernel_seconds_per_segment"] = float(mk.group(2)) / segs_all
+                    warmed["gpu_busy_share_with_loader"] = t_device / t_wall + float(mk.group(2)) / segs_all / (t_wall / segs)
             return dict(warmed, workload="popdel call on %d generated profiles, chr20:%d-%d (%d segments of 200 kb), merged VCF; steady state = "
                                  "the segments whose round began after the backend was up, start-up and teardown excluded" % (n, region[0], region[1], segs_all),
                         value=windows * samples / t_wall, unit="window*sample/s", steady_segments=segs, segments=segs_all,
