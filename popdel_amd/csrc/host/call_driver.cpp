@@ -1494,19 +1494,36 @@ void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned
         size_t r0 = 0;
         bool stopped = false;
         size_t r = 0;
+        // (contig names are compared once per contig, not per window; a 256-bp window whose 30-bp windows all lie inside the
+        // region and below the border -- they are in position order and share the window's contig -- changes nothing below and
+        // is passed in one step: all but the last of a round's 800 per sample)
+        int32_t coordChrom = -1, roiChrom = -1;
         for (; r < pre->nRaws && !stopped; ++r)
         {
             const DecodedRaw & raw = pre->raws[r];
-            if (contigNames[raw.chrom] != coordContig)
+            if (raw.chrom != coordChrom)
             {
-                stopped = true;             // (the window of the other contig is the last one the replay sees)
-                break;
+                if (contigNames[raw.chrom] != coordContig)
+                {
+                    stopped = true;             // (the window of the other contig is the last one the replay sees)
+                    break;
+                }
+                coordChrom = raw.chrom;
             }
             if (raw.beginPos + 255 < roi.beginPos)
             {
                 if (r == r0)
                     ++r0;                   // (windows ahead of the region: a prefix, not handed on)
                 continue;
+            }
+            if (raw.nWin != 0)
+            {
+                if (raw.chrom != roiChrom && contigNames[raw.chrom] == roi.seqName)
+                    roiChrom = raw.chrom;
+                const FlatWindow & head = pre->wins[raw.firstWin], & tail = pre->wins[raw.firstWin + raw.nWin - 1];
+                if (raw.chrom == roiChrom && head.chrom == raw.chrom && tail.chrom == raw.chrom && head.beginPos >= roi.beginPos &&
+                    tail.beginPos < roi.endPos && static_cast<unsigned>(tail.beginPos) < border && head.beginPos <= tail.beginPos)
+                    continue;
             }
             for (uint32_t wi = raw.firstWin; wi < raw.firstWin + raw.nWin; ++wi)
             {
