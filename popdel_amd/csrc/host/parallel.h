@@ -143,9 +143,11 @@ inline unsigned hostThreads()
             if (v >= 1)
                 return static_cast<unsigned>(v);
         }
-        // twice the usable CPUs: the passes are memory-bound and fault pages in, a second thread per CPU fills the stalls
-        // (GPU box, 16 usable CPUs, popdel call on 1000 samples: 16 threads 1.84 s, 32 and 64 threads 1.62 s)
-        const unsigned hw = 2u * usableCpus();
+        // one and a half times the usable CPUs: the passes are memory-bound and fault pages in, extra threads fill the stalls
+        // (GPU box, 16 usable CPUs, popdel call on 1000 samples, round 2: 16 threads 1.84 s, 32 and 64 threads 1.62 s; round 5,
+        // 4,000 samples x 4 Mb with the round bound by the CPU quota, seconds per warmed round / CPU-seconds per round:
+        // 16 threads 0.0543 / 0.77, 24: 0.0513 / 0.82, 32: 0.0535 / 0.85, 48: 0.0564 / 0.88 -- every thread started costs)
+        const unsigned hw = usableCpus() + usableCpus() / 2u;
         return hw > 64u ? 64u : hw;
     }();
     return n;
