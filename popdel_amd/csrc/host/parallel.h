@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
@@ -154,8 +156,9 @@ inline unsigned hostThreads()
 }
 
 // Calls fn(i) for i in [0, n) on up to hostThreads() threads (dynamic chunks). Exceptions are re-thrown on the caller.
-// Threads are spawned per call on purpose: a persistent pool (condition-variable hand-off to parked workers) was
-// measured 10-20 % SLOWER on the 256-core GPU host for the memory-bound staging passes.
+// Round 3 measured a persistent pool (condition-variable hand-off to parked workers) 10-20 % SLOWER than threads spawned per
+// call on the 256-core GPU host for the memory-bound staging passes, with 64 threads and no CPU quota in the way; with 24
+// threads on 16 CPUs the pool below wins by 3 % (detail::Pool) -- passes that find it taken still spawn.
 // `maxThreads` (0: no extra limit) caps the threads of passes that were measured to get SLOWER with more of them.
 // The threads get 256-KB stacks (their bodies are loops over table entries and bytes; nothing here recurses): glibc keeps the
 // stacks of finished threads for re-use up to 40 MB in all, which is five default-sized ones -- a round of `popdel call`
@@ -177,6 +180,93 @@ void * runWorker(void * w)
     (*static_cast<W *>(w))();
     return nullptr;
 }
+}  // namespace detail
+
+namespace detail {
+// Parked workers for the passes of ONE caller at a time: whoever finds the pool taken -- another thread's pass is running on
+// it, or the caller is itself one of its workers -- starts threads as before (POPDEL_THREAD_POOL=0: always). Round 5, `popdel
+// call` on 4,000 samples x 4 Mb under the job's CPU quota, same box, seconds / CPU-seconds per warmed round: 0.0507 / 0.803
+// with threads started per pass, 0.0494 / 0.768 with the pool (a pass of the round loop finds it free, the loaders' and the
+// hand-over thread's passes mostly start their own).
+class Pool
+{
+public:
+    static Pool & instance()
+    {
+        static Pool * p = new Pool();       // (never destroyed: its workers are parked for the life of the process)
+        return *p;
+    }
+    static bool wanted()
+    {
+        static const bool on = [] {
+            const char * e = getenv("POPDEL_THREAD_POOL");
+            return !(e && e[0] == '0');
+        }();
+        return on;
+    }
+    // runs job() on up to `helpers` parked workers and on the caller; false: the pool is taken (nothing was run)
+    template <typename W>
+    bool run(W & job, unsigned helpers)
+    {
+        if (busy_.exchange(true, std::memory_order_acquire))
+            return false;
+        {
+            std::unique_lock<std::mutex> lock(m_);
+            while (workers_.size() < helpers)
+            {
+                pthread_t id;
+                if (pthread_create(&id, smallStack(), &Pool::park, this) != 0)
+                    break;
+                workers_.push_back(id);
+            }
+            helpers = std::min<unsigned>(helpers, static_cast<unsigned>(workers_.size()));
+            call_ = [](void * w) { (*static_cast<W *>(w))(); };
+            arg_ = &job;
+            wanted_ = helpers;
+            running_ = helpers;
+            ++generation_;
+        }
+        wake_.notify_all();
+        job();
+        {
+            std::unique_lock<std::mutex> lock(m_);
+            done_.wait(lock, [this] { return running_ == 0; });
+            wanted_ = 0;
+        }
+        busy_.store(false, std::memory_order_release);
+        return true;
+    }
+
+private:
+    static void * park(void * self)
+    {
+        Pool & p = *static_cast<Pool *>(self);
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lock(p.m_);
+        for (;;)
+        {
+            p.wake_.wait(lock, [&] { return p.generation_ != seen && p.wanted_ != 0; });
+            seen = p.generation_;
+            --p.wanted_;
+            void (*call)(void *) = p.call_;
+            void * arg = p.arg_;
+            lock.unlock();
+            call(arg);
+            lock.lock();
+            if (--p.running_ == 0)
+                p.done_.notify_one();
+        }
+        return nullptr;
+    }
+    std::atomic<bool> busy_{false};
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    std::vector<pthread_t> workers_;
+    void (*call_)(void *) = nullptr;
+    void * arg_ = nullptr;
+    unsigned wanted_ = 0, running_ = 0;
+    uint64_t generation_ = 0;
+};
 }  // namespace detail
 
 template <typename F>
@@ -215,6 +305,12 @@ void parallelFor(size_t n, F fn, size_t grain = 1, unsigned maxThreads = 0)
             next.store(n);
         }
     };
+    if (detail::Pool::wanted() && detail::Pool::instance().run(worker, threads - 1))
+    {
+        if (error)
+            std::rethrow_exception(error);
+        return;
+    }
     std::vector<pthread_t> pool;
     pool.reserve(threads - 1);
     for (unsigned t = 1; t < threads; ++t)
