@@ -145,11 +145,12 @@ inline unsigned hostThreads()
             if (v >= 1)
                 return static_cast<unsigned>(v);
         }
-        // one and a half times the usable CPUs: the passes are memory-bound and fault pages in, extra threads fill the stalls
-        // (GPU box, 16 usable CPUs, popdel call on 1000 samples, round 2: 16 threads 1.84 s, 32 and 64 threads 1.62 s; round 5,
-        // 4,000 samples x 4 Mb with the round bound by the CPU quota, seconds per warmed round / CPU-seconds per round:
-        // 16 threads 0.0543 / 0.77, 24: 0.0513 / 0.82, 32: 0.0535 / 0.85, 48: 0.0564 / 0.88 -- every thread started costs)
-        const unsigned hw = usableCpus() + usableCpus() / 2u;
+        // a quarter more than the usable CPUs: the passes are memory-bound and fault pages in, a few extra threads fill the
+        // stalls (GPU box, 16 usable CPUs, popdel call on 1000 samples, round 2: 16 threads 1.84 s, 32 and 64 threads 1.62 s;
+        // round 5, 4,000 samples x 4 Mb with the round bound by the CPU quota, seconds per warmed round / CPU-seconds per round,
+        // threads started per pass: 16 threads 0.0543 / 0.77, 24: 0.0513 / 0.82, 32: 0.0535 / 0.85, 48: 0.0564 / 0.88; with the
+        // parked workers: 20: 0.0478 / 0.73, 24: 0.0500 / 0.77, 28: 0.0523 / 0.83 -- every thread a pass uses costs)
+        const unsigned hw = usableCpus() + usableCpus() / 4u;
         return hw > 64u ? 64u : hw;
     }();
     return n;
