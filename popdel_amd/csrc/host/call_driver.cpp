@@ -869,6 +869,7 @@ public:
             gTrace.print();
         timingPrinted_ = true;
     }
+    bool tableRegionsOffered() const { return regionsOffered_ != 0; }
     void closeOutput() { vcf_.reset(); }
     int run();
 
@@ -2954,7 +2955,8 @@ int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer, bool
                 run.closeOutput();
                 run.printTiming();
                 CpuSampler::stopAndWrite();
-                if (!getenv("POPDEL_NO_PARALLEL_DISCARD"))
+                // (not once the backend has been offered the regions: page-locked memory is the driver's to release)
+                if (!getenv("POPDEL_NO_PARALLEL_DISCARD") && !run.tableRegionsOffered())
                 {
                     // ... and the big arrays' pages go back from all threads at once (the exit path frees page by page on
                     // one CPU: 1.2 GB of them for 1,000 samples)
