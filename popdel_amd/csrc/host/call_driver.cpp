@@ -19,6 +19,7 @@
 #include <thread>
 #include <unordered_map>
 
+#include "loader_chunks.h"
 #include "parallel.h"
 #include "popdel_hip.h"
 #include "profile_io.h"
@@ -224,40 +225,14 @@ public:
         const std::vector<uint64_t> * cuts = nullptr;        // the blocks' file offsets
         const std::vector<uint64_t> * regionOffsets = nullptr;
     };
-    // Items per chunk: a round's readers are dealt to the three inflaters (a thread each) in three equal chunks -- the gunzip
-    // kernel is a chain of dependent instructions per member and wants many members per launch (a launch of 21,000 takes 5.4 ms,
-    // one of 200,000 takes 37), and with the staging copy of the walk gone the device's work on the blocks is what a warmed
-    // round of `popdel call` waits for. Measured on 4,000 samples x 4 Mb, same box (first chunk : the others, seconds per
-    // warmed round): 256 : 1024 (rounds 4-5: five chunks) 0.0604, 512 : 2048 0.0546, 1344 : 1344 (three) 0.0545, 1024 : 3072
-    // 0.0574, 512 : 4096 0.0615. At most 4,096 items per chunk (its buffers: ~0.5 GB page-locked and on the device); cohorts
-    // beyond 12,288 readers take more chunks, an inflater's buffers go round as before. POPDEL_LOADER_CHUNK /
-    // POPDEL_LOADER_FIRST_CHUNK fix the sizes (measurements).
-    static constexpr size_t kInflaters = 3;
-    static size_t envOr(const char * name, size_t dflt)
-    {
-        const char * e = getenv(name);
-        const long v = e ? atol(e) : 0;
-        return v >= 64 ? static_cast<size_t>(v) : dflt;
-    }
-    static size_t chunkFor(size_t readers)
-    {
-        static const size_t fixed = envOr("POPDEL_LOADER_CHUNK", 0);
-        if (fixed)
-            return fixed;
-        const size_t per = ((readers + kInflaters - 1) / kInflaters + 63) / 64 * 64;
-        return std::min<size_t>(4096, std::max<size_t>(256, per));
-    }
-    static size_t firstChunkFor(size_t readers)
-    {
-        static const size_t fixed = envOr("POPDEL_LOADER_FIRST_CHUNK", 0);
-        return fixed ? fixed : chunkFor(readers);
-    }
+    // items per chunk and the batch limit of the replay: loader_chunks.h
+    static constexpr size_t kInflaters = kLoaderInflaters;
+    static size_t chunkFor(size_t readers) { return loaderChunkFor(readers); }
+    static size_t firstChunkFor(size_t readers) { return loaderFirstChunkFor(readers); }
     size_t firstChunk_ = 256, chunk_ = 1024;            // of the round the loader is on (start())
     size_t chunkOf(size_t item) const { return item < firstChunk_ ? 0 : 1 + (item - firstChunk_) / chunk_; }
     size_t chunkBegin(size_t c) const { return c == 0 ? 0 : firstChunk_ + (c - 1) * chunk_; }
-    // samples a batch of the replay may span: the first two chunks (an inflater's buffers are recycled once the replay has
-    // passed the chunk three before it, and the replay releases a batch as a whole)
-    static size_t batchLimitFor(size_t readers) { return firstChunkFor(readers) + chunkFor(readers); }
+    static size_t batchLimitFor(size_t samples) { return loaderBatchLimitFor(samples); }
 
     // Descriptors of the profiles, kept open from round to round as far as the process's limit allows (every sample's file is
     // asked twice per round: its index, then its bytes); a sample beyond the limit is opened and closed per use as before.

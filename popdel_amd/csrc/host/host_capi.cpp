@@ -14,7 +14,11 @@
 #include "call_params.h"
 #include "chrom_profile.h"
 #include "histogram.h"
+#include <atomic>
+#include <stdexcept>
 #include "inflate_core.h"
+#include "loader_chunks.h"
+#include "parallel.h"
 #include "parallel.h"
 #include "profile_io.h"
 #include "window_call.h"
@@ -227,6 +231,60 @@ int pdh_selftest_inflate(const char * path, unsigned long long offset, unsigned 
     }
 }
 
+
+// The device loader's chunking of a round's readers and the replay's batch limit (loader_chunks.h), for the test that holds
+// the relation between them: out[0] = first chunk, out[1] = the other chunks (for `readers`), out[2] = batch limit (for `samples`).
+int pdh_loader_chunks(uint64_t readers, uint64_t samples, uint64_t * out)
+{
+    if (!out)
+        return 1;
+    out[0] = pdh::loaderFirstChunkFor(readers);
+    out[1] = pdh::loaderChunkFor(readers);
+    out[2] = pdh::loaderBatchLimitFor(samples);
+    return 0;
+}
+
+// parallelFor() under fire (parallel.h: parked workers when they are free, threads per pass otherwise): `callers` threads
+// run `rounds` passes each over `n` items at the same time, every fourth item starts a nested pass, one pass in sixteen
+// throws from an item. Returns 0 if every pass added up (or re-threw), else the number of passes that did not.
+int pdh_selftest_parallel(unsigned callers, unsigned rounds, unsigned n)
+{
+    std::atomic<unsigned> bad(0);
+    std::vector<std::thread> pool;
+    for (unsigned c = 0; c < callers; ++c)
+        pool.emplace_back([&, c] {
+            for (unsigned r = 0; r < rounds; ++r)
+            {
+                std::atomic<uint64_t> sum(0);
+                const bool throws = (r + c) % 16u == 5u;
+                bool threw = false;
+                try
+                {
+                    pdh::parallelFor(n, [&](size_t i) {
+                        if (throws && i == n / 2)
+                            throw std::runtime_error("item");
+                        uint64_t add = i + 1;
+                        if (i % 4u == 0)
+                        {
+                            std::atomic<uint64_t> inner(0);
+                            pdh::parallelFor(8, [&](size_t j) { inner += j; });
+                            add += inner.load() - 28u;          // (0 + ... + 7)
+                        }
+                        sum += add;
+                    }, 1 + r % 3u);
+                }
+                catch (const std::runtime_error &)
+                {
+                    threw = true;
+                }
+                if (throws ? !threw : (threw || sum.load() != static_cast<uint64_t>(n) * (n + 1) / 2))
+                    ++bad;
+            }
+        });
+    for (std::thread & t : pool)
+        t.join();
+    return static_cast<int>(bad.load());
+}
 
 // The device's gunzip (popdel_amd/csrc/hip/inflate_core.h, the source inflate.hip compiles for the GPU) run on the CPU, one
 // member after the other: tests compare it with zlib bit for bit, including damaged and truncated members (-m "not gpu").

@@ -107,3 +107,32 @@ def test_inflate_through_libdeflate_equals_zlib(built, tmp_path):
         for request in ((125, 1, 70000) if want is None or want < (1 << 20) else (4096,)):
             assert host.pdh_selftest_inflate(str(path).encode(), 6, request, ctypes.byref(n)) == 0, (name, request)
             assert want is None or n.value == want, (name, request, n.value)
+
+
+def test_loader_chunks_and_the_replays_batch_limit(built):
+    """The device loader cuts a round's READERS into chunks (three equal ones up to 12,288 readers, 4,096 each beyond) and
+    recycles an inflater's buffers once the replay has passed the chunk three before it; the replay releases a batch of SAMPLES as
+    a whole. Whatever the numbers: a batch must never touch four consecutive chunks (it would wait for a chunk whose buffers it
+    holds itself) -- the limit on its samples is two chunks' worth, so it touches at most three."""
+    host = ctypes.CDLL(os.path.join(ROOT, "popdel_amd", "lib", "libpopdel_host.so"))
+    host.pdh_loader_chunks.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+    out = (ctypes.c_uint64 * 3)()
+    for samples in (1, 40, 255, 256, 1000, 4000, 4033, 10000, 12288, 12289, 20000, 50000, 100000):
+        for readers in sorted({1, samples // 7 + 1, samples // 2 + 1, max(1, samples - 1), samples}):
+            assert host.pdh_loader_chunks(readers, samples, out) == 0
+            first, chunk, batch = out[0], out[1], out[2]
+            assert 256 <= chunk <= 4096 and first == chunk
+            n_chunks = 1 + max(0, -(-(readers - first) // chunk)) if readers > first else 1
+            if readers <= 12288:
+                assert n_chunks <= 3, (samples, readers, n_chunks)          # one per inflater: nothing is recycled
+            # a batch holds at most `batch` readers: they lie in at most three consecutive chunks
+            assert batch <= 2 * 4096 and (n_chunks <= 3 or batch <= first + chunk), (samples, readers)
+
+
+def test_parallel_passes_under_fire(built):
+    """parallel.h: the parked workers serve one caller at a time, everybody else (other threads, nested passes) starts threads --
+    concurrent callers, nested passes and passes that throw all add up."""
+    host = ctypes.CDLL(os.path.join(ROOT, "popdel_amd", "lib", "libpopdel_host.so"))
+    host.pdh_selftest_parallel.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]
+    assert host.pdh_selftest_parallel(4, 60, 200) == 0
+    assert host.pdh_selftest_parallel(1, 40, 3) == 0
