@@ -120,6 +120,7 @@ void EndSlots::prepareHist(Slot & slot)
     {
         slot.hist.assign(nBins, 0);
         slot.lowBin = slot.highBin = 0;
+        slot.peak = 0;
     }
     const unsigned leftBin = slot.right >= numWindows ? (slot.right - numWindows) / 30u : 0u;
     slot.baseBin = leftBin >= kBinsBelow ? leftBin - kBinsBelow : 0u;
@@ -154,7 +155,9 @@ void EndSlots::addLight(Slot & slot, unsigned id, unsigned lastWin)
         slot.highBin = std::max(slot.highBin, b + 1);
         slot.maxWin = std::max(slot.maxWin, lastWin);
     }
-    ++slot.hist[b];
+    const unsigned count = ++slot.hist[b];
+    if (count > slot.peak)
+        slot.peak = count;
     for (int side = 0; side < 2; ++side)
         if (b < slot.curBin[side])
             ++slot.curCum[side];
@@ -271,6 +274,7 @@ void EndSlots::setLight(bool on)
         for (unsigned b = s.lowBin; b < s.highBin && b < s.hist.size(); ++b)
             s.hist[b] = 0;
         s.lowBin = s.highBin = 0;
+        s.peak = 0;
         s.curBin[0] = s.curBin[1] = s.curCum[0] = s.curCum[1] = 0;
         s.ordered = true;
         if (s.entries.empty())

@@ -99,6 +99,7 @@ public:
         unsigned maxWin = 0;             // largest lastWindow filed (meaningful while there are entries)
         unsigned lowBin = 0, highBin = 0;    // bins in use: [lowBin, highBin)
         bool ordered = true;
+        unsigned peak = 0;               // the largest count in hist (kept exact: every increment looks at it)
         unsigned curBin[2] = {0, 0}, curCum[2] = {0, 0};    // prefix cursors over hist: filing side, reading side
         void reset(unsigned r)
         {
@@ -109,6 +110,7 @@ public:
                 hist[b] = 0;
             lowBin = highBin = 0;
             maxWin = 0;
+            peak = 0;
             ordered = true;
             curBin[0] = curBin[1] = curCum[0] = curCum[1] = 0;
         }
@@ -151,7 +153,9 @@ public:
                 slot.highBin = b + 1;
             if (lastWin > slot.maxWin)
                 slot.maxWin = lastWin;
-            ++slot.hist[b];
+            const unsigned count = ++slot.hist[b];
+            if (count > slot.peak)
+                slot.peak = count;
             slot.curCum[0] += b < slot.curBin[0] ? 1u : 0u;
             slot.curCum[1] += b < slot.curBin[1] ? 1u : 0u;
             slot.entries.push_back(EndEntry{id, lastWin});
@@ -216,23 +220,21 @@ public:
             if (minBin >= base && maxBin - base < slot.hist.size())
             {
                 uint16_t * hist = slot.hist.data();
-                unsigned fullest = 0;
-                for (size_t j = 0; j < n; ++j)
-                {
-                    const unsigned v = hist[bins[j] - base];
-                    fullest = v > fullest ? v : fullest;
-                }
-                if (fullest < 0xffffu - kMost)
+                // (no count of the slot near saturation: `peak` is the largest of them -- a pass over the block's own counts
+                // used to ask this, a tenth of the filing's time)
+                if (slot.peak < 0xffffu - kMost)
                 {
                     const unsigned cur0 = slot.curBin[0], cur1 = slot.curBin[1];
-                    unsigned cum0 = 0, cum1 = 0;
+                    unsigned cum0 = 0, cum1 = 0, peak = slot.peak;
                     for (size_t j = 0; j < n; ++j)
                     {
                         const unsigned b = bins[j] - base;
-                        ++hist[b];
+                        const unsigned count = ++hist[b];
+                        peak = count > peak ? count : peak;
                         cum0 += b < cur0 ? 1u : 0u;
                         cum1 += b < cur1 ? 1u : 0u;
                     }
+                    slot.peak = peak;
                     slot.curCum[0] += cum0;
                     slot.curCum[1] += cum1;
                     slot.ordered = slot.ordered && ordered;
