@@ -127,9 +127,11 @@ struct HipError
 
 // What the process holds in HBM and in page-locked host memory (POPDEL_HIP_MEMSTAT=1 prints it at every collect).
 std::atomic<uint64_t> g_devBytes{0}, g_pinnedBytes{0}, g_devAllocs{0}, g_pinnedAllocs{0};
+// (parking lasts as long as a local group that asked for it: pd_local_group_destroy frees what was parked)
 std::atomic<bool> g_parkFrees{false};
 std::mutex g_parkLock;
 std::vector<void *> g_parked;
+unsigned g_parkingGroups = 0;
 
 // Device allocation that frees itself.
 template <typename T>
@@ -137,6 +139,7 @@ struct DevBuf
 {
     T *    p = nullptr;
     size_t n = 0;
+    bool   fineGrained = false;     // allocate with hipDeviceMallocFinegrained (memory that peers write and this device reads)
     DevBuf() {}
     DevBuf(const DevBuf &) = delete;
     DevBuf & operator=(const DevBuf &) = delete;
@@ -165,7 +168,10 @@ struct DevBuf
         release();
         if (count)
         {
-            PD_HIP(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+            if (fineGrained)
+                PD_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&p), count * sizeof(T), hipDeviceMallocFinegrained));
+            else
+                PD_HIP(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
             g_devBytes += count * sizeof(T);
             ++g_devAllocs;
         }
@@ -357,6 +363,8 @@ struct pd_local_group
     uint32_t arrived = 0;
     uint64_t generation = 0;
     bool failed = false;
+    bool parksFrees = false;        // this group turned the parking of replaced device buffers on (groupDecide)
+    std::vector<int> devices;       // of its members, as they registered (pd_local_group_destroy drains them)
     std::vector<pd_ctx *> members;
 };
 
@@ -634,11 +642,12 @@ struct CallsBox
 void groupBarrier(pd_ctx & c);
 
 // Which carrier the contexts of a local group use, decided once, by all of them alike, at their first collective step (all
-// members are registered then): the device-side one (exchange.hip) unless POPDEL_HIP_GROUP_CARRIER=host -- or two contexts
-// sit on the SAME GPU (tests, debugging): there a waiting exchange kernel can end up in front of what it waits for (a
-// shared hardware queue; a call of the peer's host thread that waits for the whole device), so the host-driven carrier stays
-// the rule and the device-side one runs only if asked for by name (POPDEL_HIP_GROUP_CARRIER=flags) with hardware queues to
-// spare (GPU_MAX_HW_QUEUES >= 8; tests/conftest.py sets 16).
+// members are registered then): the host-driven one unless the device-side one (exchange.hip) is asked for by name
+// (POPDEL_HIP_GROUP_CARRIER=flags; it has never run with its contexts on different GPUs, pd_ctx_set_shard_local). Where two
+// contexts sit on the SAME GPU (tests, debugging) a waiting exchange kernel can end up in front of what it waits for (a shared
+// hardware queue; a call of the peer's host thread that waits for the whole device): the device-side carrier then also needs
+// hardware queues to spare (GPU_MAX_HW_QUEUES >= 8; tests/conftest.py sets 16), and replaced device buffers are parked until
+// the group is destroyed.
 void groupDecide(pd_ctx & c)
 {
     groupBarrier(c);
@@ -657,7 +666,15 @@ void groupDecide(pd_ctx & c)
         const char * how = getenv("POPDEL_HIP_GROUP_CARRIER");
         flags = flags && how && std::strcmp(how, "flags") == 0 && q && atoi(q) >= 8;
         if (flags)
-            g_parkFrees.store(true);
+        {
+            std::lock_guard<std::mutex> lock(g_parkLock);
+            if (!c.group->parksFrees)
+            {
+                c.group->parksFrees = true;
+                ++g_parkingGroups;
+                g_parkFrees.store(true);
+            }
+        }
     }
     c.flagCarrier = flags;
     c.groupDecided = true;
@@ -684,6 +701,10 @@ uint8_t * reserveArena(pd_ctx & c, size_t bytes)
                 // nobody goes on before all new addresses are published. After the first segments the sizes settle.
                 PD_HIP(hipStreamSynchronize(c.copyStream));
                 groupBarrier(c);
+                // (peers store into this buffer through peer-mapped pointers and this device's kernels read it right after a
+                // flag wait: fine-grained memory, like the flag block -- a coarse-grained allocation may keep stale lines of
+                // the previous exchange in this device's L2 across kernels when the writer sits on another GPU)
+                c.ownArena.fineGrained = true;
                 c.ownArena.ensure(bytes);
                 c.arena = c.ownArena.p;
                 groupBarrier(c);
@@ -730,6 +751,24 @@ void groupFail(pd_ctx * c)
     std::lock_guard<std::mutex> lock(c->group->m);
     c->group->failed = true;
     c->group->cv.notify_all();
+}
+
+// How long a kernel of the device-side carrier waits for a peer before it gives up. The peer's host thread may lag by
+// seconds for good reasons (page-locking a table region for the first time, code objects loaded lazily, device memory
+// growing, a CPU quota, a profiler): generous by default, POPDEL_HIP_XCH_TIMEOUT_S (seconds, fractions allowed) for tests.
+unsigned long long exchangeTimeoutTicks()
+{
+    static const unsigned long long ticks = [] {
+        double seconds = 60.0;
+        if (const char * t = getenv("POPDEL_HIP_XCH_TIMEOUT_S"))
+        {
+            const double v = atof(t);
+            if (v > 0)
+                seconds = v;
+        }
+        return static_cast<unsigned long long>(seconds * 1e8);
+    }();
+    return ticks;
 }
 
 struct CtxExchange : pd::Exchange
@@ -795,7 +834,7 @@ struct CtxExchange : pd::Exchange
             x.rank = c.rank;
             x.world = c.world;
             x.seq = ++c.xchSeq;
-            x.timeoutTicks = 300000000ull;              // 3 s of the 100-MHz wall clock
+            x.timeoutTicks = exchangeTimeoutTicks();    // of the 100-MHz wall clock (60 s unless POPDEL_HIP_XCH_TIMEOUT_S says otherwise)
             x.err = c.xchErr;
             pd::launchFlagExchange(x, st);
             PD_HIP(hipGetLastError());
@@ -853,9 +892,12 @@ void checkExchange(pd_ctx & c)
     if (c.xchErr && *c.xchErr != 0)
     {
         const unsigned code = *c.xchErr;
+        *c.xchErr = 0;              // (reported once; the group is failed below: its exchange sequence is out of step from here on,
+                                    // every member's next collective step says so instead of repeating this message)
+        groupFail(&c);
         throw HipError{std::string("an exchange between the contexts of the local group timed out (waiting for a peer's ") +
                        (code == 1 ? "acknowledgement" : "chunk") + "): a peer failed, or -- several contexts on ONE GPU -- their streams share a hardware "
-                       "queue (raise GPU_MAX_HW_QUEUES, or set POPDEL_HIP_GROUP_CARRIER=host for the host-driven carrier)"};
+                       "queue (raise GPU_MAX_HW_QUEUES or POPDEL_HIP_XCH_TIMEOUT_S, or leave POPDEL_HIP_GROUP_CARRIER unset for the host-driven carrier)"};
     }
 }
 
@@ -1916,8 +1958,12 @@ static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, p
         }
         if (group)
         {
+            // The device-side carrier (exchange.hip) has only ever run with its contexts on ONE GPU -- no box with two was
+            // available to this project -- so the host-driven carrier is what a local group uses unless the device-side one is
+            // asked for by name (POPDEL_HIP_GROUP_CARRIER=flags); tests/test_gpu_local_group.py holds the two against each
+            // other, on distinct GPUs where the box has them.
             const char * how = getenv("POPDEL_HIP_GROUP_CARRIER");
-            c->flagsWanted = !(how && std::strcmp(how, "host") == 0) && sh->world <= pd::kXchMaxWorld;
+            c->flagsWanted = how && std::strcmp(how, "flags") == 0 && sh->world <= pd::kXchMaxWorld;
             c->groupDecided = false;
             if (c->flagsWanted)
             {
@@ -1934,6 +1980,8 @@ static int applyShard(pd_ctx * c, const pd_shard * sh, const uint8_t * rcclId, p
             }
             std::lock_guard<std::mutex> lock(group->m);
             group->members[sh->rank] = c;
+            if (std::find(group->devices.begin(), group->devices.end(), c->device) == group->devices.end())
+                group->devices.push_back(c->device);
             c->group = group;
         }
         c->shard = *sh;
@@ -1998,7 +2046,39 @@ int pd_local_group_create(uint32_t world, pd_local_group ** out)
     return 0;
 }
 
-void pd_local_group_destroy(pd_local_group * group) { delete group; }
+void pd_local_group_destroy(pd_local_group * group)
+{
+    if (!group)
+        return;
+    if (group->parksFrees)
+    {
+        // the last group that parked replaced device buffers (contexts sharing a GPU under the device-side carrier) gives them
+        // back: nothing of the group is in flight any more once its devices are idle
+        std::vector<void *> parked;
+        {
+            std::lock_guard<std::mutex> lock(g_parkLock);
+            if (--g_parkingGroups == 0)
+            {
+                g_parkFrees.store(false);
+                parked.swap(g_parked);
+            }
+        }
+        if (!parked.empty())
+        {
+            int before = 0;
+            (void)hipGetDevice(&before);
+            for (int d : group->devices)
+            {
+                (void)hipSetDevice(d);
+                (void)hipDeviceSynchronize();
+            }
+            for (void * p : parked)
+                (void)hipFree(p);
+            (void)hipSetDevice(before);
+        }
+    }
+    delete group;
+}
 
 int pd_ctx_set_shard_local(pd_ctx * c, const pd_shard * sh, pd_local_group * group)
 {

@@ -432,7 +432,7 @@ static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_
         if (inBytes + 8 > f->capHIn)
             throw Fail{"the members were not gathered into pd_inflater_input()'s buffer"};
         growDevice(f->dData, f->capData, inBytes + 8);
-        growDevice(f->dOut, f->capOut, std::max<uint64_t>(outBytes, 1));
+        growDevice(f->dOut, f->capOut, outBytes + 8);      // (+ 8: the parser reads a record's five bytes with one eight-byte load, walkBlock())
         if (n_members + 1 > f->capMembers)
         {
             size_t a = 0, b = 0, c = 0, d = 0;

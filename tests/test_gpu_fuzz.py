@@ -199,22 +199,6 @@ def test_pinned_residual(built, seed):
                  % summary(got))
 
 
-SNAPPED_SEEDS = list(range(64)) + [132, 155, 483]
-
-
-@pytest.mark.parametrize("seed", UNSNAPPED_SEEDS)
-def test_random_cohort(built, seed):
-    seg, rgs, offs, opts = random_case(seed)
-    gpu, cpu = both(seg, rgs, offs, **opts)
-    calls, cols, div, worst_lr, worst_af = assert_same_up_to_knife_edges(gpu, cpu, allowed_diverged=1 if seed == 155 else 0)
-    n = gpu[0]["n_calls"]
-    note_cohort(seed, dict(calls=n, columns=(n * gpu[0]["pl"].shape[1] if n else 0), differing_columns=cols, touched_calls=calls,
-                           diverged_calls=div, touched_lr=list(LAST_TOUCHED_LR), worst_af=worst_af))
-    if calls or div:
-        print("seed %d: %d of %d calls touched by a knife-edge shift, %d sample column(s) differ, %d diverged; worst dLR %.3g, "
-              "dAF %.3g" % (seed, calls, n, cols, div, worst_lr, worst_af))
-
-
 SNAPPED_SEEDS = list(range(16, 64)) + RESIDUAL_SEEDS       # every pinned-residual cohort is EXACT once the knife edge is out
 
 

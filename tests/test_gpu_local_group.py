@@ -1,10 +1,11 @@
 """GPU (one device): several contexts of ONE process sharing a cohort by samples, the library exchanging between them itself
 (pd_ctx_set_shard_local) -- what `popdel call` does with POPDEL_DEVICES. Two carriers: the device-side one of round 5
 (exchange.hip: one kernel per exchange acknowledges, pushes the context's chunk into the peers' buffers through peer-mapped
-pointers and waits for their flags; no host in the data path) and the host-driven one it replaces (peer copies bracketed by
-barriers of the host threads; POPDEL_HIP_GROUP_CARRIER=host, and the fallback when contexts share a GPU without hardware
-queues to spare). On the one-GPU box all contexts sit on device 0 (tests/conftest.py raises GPU_MAX_HW_QUEUES so that their
-streams do not share a queue); with several GPUs the same code writes over xGMI."""
+pointers and waits for their flags; no host in the data path; asked for by name, POPDEL_HIP_GROUP_CARRIER=flags) and the
+host-driven one that is the default (peer copies bracketed by barriers of the host threads). On a one-GPU box all contexts sit
+on device 0 (tests/conftest.py raises GPU_MAX_HW_QUEUES so that their streams do not share a queue); on a box with several GPUs
+context r sits on GPU r and the same code writes over xGMI -- the run the device-side carrier has to pass before it may
+become the default (it never ran on such a box: none was available to this project)."""
 import os
 import subprocess
 import threading
@@ -36,6 +37,8 @@ def test_two_contexts_in_one_process_equal_one_context(built, monkeypatch, capfd
     one.close()
     assert want["n_calls"] > 0
     world = 2
+    import torch
+    n_gpus = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
     per = hip.pd_shard_samples(n, world)
     group = C.c_void_p()
     hip.pd_local_group_create.argtypes = [C.c_uint32, C.POINTER(C.c_void_p)]
@@ -47,7 +50,7 @@ def test_two_contexts_in_one_process_equal_one_context(built, monkeypatch, capfd
     ctxs, parts = [], []
     for r in range(world):
         s0, s1 = min(n, r * per), min(n, (r + 1) * per)
-        ctx = capi.Context(hip, rgs[s0:s1], list(range(s1 - s0 + 1)), **opts)
+        ctx = capi.Context(hip, rgs[s0:s1], list(range(s1 - s0 + 1)), device=(r if n_gpus >= world else 0), **opts)
         sh = capi.PdShard()
         sh.rank, sh.world, sh.first_sample, sh.n_samples_global, sh.n_readgroups_global = r, world, s0, n, n
         sh.min_init_del_len_global = table.ctypes.data_as(C.POINTER(C.c_uint32))
@@ -77,7 +80,7 @@ def test_two_contexts_in_one_process_equal_one_context(built, monkeypatch, capfd
         c.close()
     said = capfd.readouterr().err
     assert ("device-side (flags) carrier" if carrier == "flags" else "host-driven carrier") in said
-    hip.pd_local_group_destroy(group)
+    hip.pd_local_group_destroy(group)           # (frees what the flags carrier parked while two contexts shared a GPU)
     for k in ("initial_length", "iterations", "deletion_length", "likelihood_ratio", "frequency", "window_position", "position",
               "end_position", "filter"):
         for r in range(world):
