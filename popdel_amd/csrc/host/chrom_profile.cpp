@@ -128,7 +128,7 @@ void EndSlots::prepareHist(Slot & slot)
 
 void EndSlots::addLight(Slot & slot, unsigned id, unsigned lastWin)
 {
-    if (slot.entries.empty() && slot.highBin == 0)
+    if (slot.total == 0 && slot.highBin == 0)
         prepareHist(slot);
     const unsigned bin = lastWin / 30u;
     if (bin < slot.baseBin || bin - slot.baseBin >= slot.hist.size() || slot.hist[bin - slot.baseBin] == 0xffffu)
@@ -139,10 +139,11 @@ void EndSlots::addLight(Slot & slot, unsigned id, unsigned lastWin)
         slot.entries.insert(std::upper_bound(slot.entries.begin(), slot.entries.end(), lastWin,
                                              [](unsigned w, const EndEntry & e) { return w < e.lastWindow; }),
                             EndEntry{id, lastWin});
+        ++slot.total;
         return;
     }
     const unsigned b = bin - slot.baseBin;
-    if (slot.entries.empty())
+    if (slot.total == 0)
     {
         slot.lowBin = b;
         slot.highBin = b + 1;
@@ -150,7 +151,7 @@ void EndSlots::addLight(Slot & slot, unsigned id, unsigned lastWin)
     }
     else
     {
-        slot.ordered = slot.ordered && lastWin >= slot.entries.back().lastWindow;
+        slot.ordered = slot.ordered && lastWin >= slot.backWin;
         slot.lowBin = std::min(slot.lowBin, b);
         slot.highBin = std::max(slot.highBin, b + 1);
         slot.maxWin = std::max(slot.maxWin, lastWin);
@@ -162,12 +163,54 @@ void EndSlots::addLight(Slot & slot, unsigned id, unsigned lastWin)
         if (b < slot.curBin[side])
             ++slot.curCum[side];
     slot.entries.push_back(EndEntry{id, lastWin});
+    ++slot.total;
+    slot.backWin = lastWin;
+}
+
+// ---- runs filed in bulk -----------------------------------------------------------------------------------------------------
+void EndSlots::settle(Slot & slot)
+{
+    if (slot.deferred.empty())
+        return;
+    HugeVector<EndEntry> all;
+    all.reserve(slot.total);
+    size_t at = 0;
+    for (const Deferred & d : slot.deferred)
+    {
+        all.insert(all.end(), slot.entries.begin() + static_cast<std::ptrdiff_t>(at), slot.entries.begin() + static_cast<std::ptrdiff_t>(d.explicitBefore));
+        at = d.explicitBefore;
+        const StartEntry * src = startsOf->slots[d.startSlot].entries.data() + d.first;
+        for (uint32_t j = 0; j < d.n; ++j)
+        {
+            const int inner = src[j].deviation + d.innerOffset;
+            const unsigned endPos = src[j].startPos + (inner > 0 ? static_cast<unsigned>(inner) : 0u);
+            all.push_back(EndEntry{d.firstId + j, posToWin(endPos, 30)});
+        }
+    }
+    all.insert(all.end(), slot.entries.begin() + static_cast<std::ptrdiff_t>(at), slot.entries.end());
+    slot.entries.swap(all);
+    slot.deferred.clear();
+}
+
+void EndSlots::settleRefsTo(unsigned startSlot, unsigned spare)
+{
+    for (unsigned k = 0; k < 3; ++k)
+    {
+        if (k == spare)
+            continue;
+        for (const Deferred & d : slots[k].deferred)
+            if (d.startSlot == startSlot)
+            {
+                settle(slots[k]);
+                break;
+            }
+    }
 }
 
 // entries of the slot with lastWindow < pos (last windows are multiples of 30)
 unsigned EndSlots::lessCount(Slot & slot, unsigned pos, int side)
 {
-    if (slot.entries.empty())
+    if (slot.total == 0)
         return 0;
     const unsigned bins = (pos + 29u) / 30u;                     // windows 0 .. bins-1 end before pos
     unsigned t = bins > slot.baseBin ? bins - slot.baseBin : 0u;
@@ -195,7 +238,7 @@ unsigned EndSlots::countEndedLight(unsigned pos)
     unsigned i = dNext;
     unsigned c = 0;
     unsigned cSlot = endPosSlot;
-    unsigned n = static_cast<unsigned>(slots[cSlot].entries.size());
+    unsigned n = static_cast<unsigned>(slots[cSlot].total);
     if (i == n)
     {
         if (endPosSlot != writeSlot)
@@ -205,7 +248,7 @@ unsigned EndSlots::countEndedLight(unsigned pos)
             dNextOffset = 0;
             i = dNext;
             cSlot = endPosSlot;
-            n = static_cast<unsigned>(slots[cSlot].entries.size());
+            n = static_cast<unsigned>(slots[cSlot].total);
         }
         else
         {
@@ -235,7 +278,7 @@ unsigned EndSlots::countEndedLight(unsigned pos)
             return c;
         }
         cSlot = (cSlot + 1) % 3;
-        n = static_cast<unsigned>(slots[cSlot].entries.size());
+        n = static_cast<unsigned>(slots[cSlot].total);
         if (n == 0)
             break;
         i = dNextOffset;
@@ -250,6 +293,8 @@ void EndSlots::leaveLight()
     if (!light)
         return;
     light = false;
+    for (Slot & s : slots)
+        settle(s);                      // (runs filed in bulk: their entries are needed from here on)
     for (Slot & s : slots)
         if (!s.ordered)
         {
@@ -282,12 +327,14 @@ void EndSlots::setLight(bool on)
         prepareHist(s);
         HugeVector<EndEntry> kept;
         kept.swap(s.entries);
+        s.total = 0;
         for (const EndEntry & e : kept)
         {
             addLight(s, e.id, e.lastWindow);
             if (!light)                         // (a record outside the counts' range: this read group stays heavy)
             {
                 s.entries.swap(kept);
+                s.total = s.entries.size();
                 return;
             }
         }
@@ -297,7 +344,7 @@ void EndSlots::setLight(bool on)
 void EndSlots::advanceReadTo(unsigned pos, unsigned shift)
 {
     Slot & slot = slots[readSlot];
-    const size_t n = slot.entries.size();
+    const size_t n = slot.total;
     const size_t from = std::min(readIdx, n);
     if (light)
     {
@@ -335,6 +382,7 @@ void EndSlots::add(unsigned id, unsigned endPos)
     while (at > 0 && v[at - 1].lastWindow > lastWin)
         --at;
     v.insert(v.begin() + static_cast<std::ptrdiff_t>(at), EndEntry{id, lastWin});
+    ++slots[which].total;
 }
 
 // Number of pairs of the current end-position slot (and, by look-ahead, of the following one) whose last
@@ -407,6 +455,8 @@ ChromProfile::ChromProfile(unsigned numReadGroups, const std::vector<unsigned> &
 {
     currentRightBorder = starts[0].slots[2].right;
     log_.resize(numReadGroups);
+    for (unsigned rg = 0; rg < numReadGroups; ++rg)
+        ends[rg].startsOf = &starts[rg];            // (neither vector is ever resized)
 }
 
 // What the closed-form walk needs to know about a start slot beyond its entries: under which end slot's border their end
@@ -593,6 +643,175 @@ void ChromProfile::addRun(unsigned rg, const uint32_t * posDev, size_t n, int in
         }
     }
     activeLoad[rg] = load;
+}
+
+void summarizeRun(const uint32_t * posDev, size_t nRecords, int innerOffset, uint32_t borderBin, uint32_t room, RunSummary & out,
+                  uint8_t * starts, uint8_t * ends)
+{
+    out = RunSummary();
+    if (nRecords == 0)
+        return;
+    auto endBinOf = [&](size_t i) {
+        const int inner = static_cast<int32_t>(posDev[2 * i + 1]) + innerOffset;
+        return (posDev[2 * i] + (inner > 0 ? static_cast<unsigned>(inner) : 0u)) / 30u;
+    };
+    size_t n = 0;
+    while (n < nRecords && endBinOf(n) < borderBin)
+        ++n;
+    out.n = static_cast<uint32_t>(n);
+    if (n == 0)
+        return;
+    out.firstPos = posDev[0];
+    out.lastPos = posDev[2 * (n - 1)];
+    out.binBase = out.firstPos / 30u;
+    out.firstEndBin = endBinOf(0);
+    out.lastEndBin = endBinOf(n - 1);
+    out.minEndBin = 0xffffffffu;
+    out.maxEndBin = 0;
+    out.flags = RunSummary::kStartsInOrder | RunSummary::kEndsInOrder;
+    std::fill(starts, starts + room, static_cast<uint8_t>(0));
+    std::fill(ends, ends + room, static_cast<uint8_t>(0));
+    uint32_t prevPos = out.firstPos, prevEnd = out.firstEndBin;
+    for (size_t i = 0; i < n; ++i)
+    {
+        const uint32_t pos = posDev[2 * i], sb = pos / 30u, eb = endBinOf(i);
+        if (pos < prevPos)
+            out.flags &= ~RunSummary::kStartsInOrder;
+        if (eb < prevEnd)
+            out.flags &= ~RunSummary::kEndsInOrder;
+        prevPos = pos;
+        prevEnd = eb;
+        out.minEndBin = std::min(out.minEndBin, eb);
+        out.maxEndBin = std::max(out.maxEndBin, eb);
+        // (a start below the first one's window, or windows beyond the room: flagged, the counts are not used then)
+        if (sb < out.binBase || sb - out.binBase >= room || eb < out.binBase || eb - out.binBase >= room)
+        {
+            out.flags |= RunSummary::kNoRoom;
+            continue;
+        }
+        uint8_t & cs = starts[sb - out.binBase];
+        uint8_t & ce = ends[eb - out.binBase];
+        if (cs == 255u || ce == 255u)
+            out.flags |= RunSummary::kSaturated;
+        if (cs != 255u)
+            ++cs;
+        if (ce != 255u)
+            ++ce;
+    }
+    // (a count that reached 255 may have missed records: saturated either way)
+    out.nBins = (out.flags & RunSummary::kNoRoom) ? 0u : out.maxEndBin - out.binBase + 1u;
+    for (uint32_t b = 0; b < out.nBins; ++b)
+        if (starts[b] == 255u || ends[b] == 255u)
+            out.flags |= RunSummary::kSaturated;
+}
+
+bool ChromProfile::addBulk(unsigned rg, const uint32_t * posDev, const RunSummary & s, const uint8_t * startCounts, const uint8_t * endCounts,
+                           int innerOffset)
+{
+    StartSlots & st = starts[rg];
+    EndSlots & en = ends[rg];
+    const unsigned cap = maxLoad[rg];
+    const unsigned load0 = activeLoad[rg];
+    constexpr uint32_t kWanted = RunSummary::kStartsInOrder;
+    if (!en.light || s.n == 0 || (s.flags & kWanted) != kWanted || (s.flags & (RunSummary::kSaturated | RunSummary::kNoRoom)) != 0 || load0 >= cap)
+        return false;
+    // ---- the end table: the counting cursor at home in the write slot, in the everyday state, and it stays there
+    if (en.endPosSlot != en.writeSlot || en.dNextOffset != 0)
+        return false;
+    EndSlots::Slot & slot = en.slots[en.writeSlot];
+    const size_t have = slot.total;
+    if (en.dNext >= have)                       // (also: the slot has entries -- its counts are set up)
+        return false;
+    const unsigned base = slot.baseBin;
+    const unsigned firstBin = s.firstPos / 30u, lastBin = s.lastPos / 30u;
+    if (firstBin != s.binBase || lastBin < firstBin || lastBin - s.binBase >= s.nBins)
+        return false;
+    const unsigned tFirst = firstBin > base ? firstBin - base : 0u;
+    if (tFirst < slot.curBin[0] || lastBin < base || lastBin - base > slot.hist.size())
+        return false;
+    // every pair ends below the write slot's border (the summary was cut there) and inside the windows the counts cover
+    const unsigned borderBin = (slot.right + 29u) / 30u;
+    if (s.maxEndBin >= borderBin || s.minEndBin < base || s.maxEndBin - base >= slot.hist.size() || s.minEndBin < s.binBase ||
+        s.maxEndBin - s.binBase >= s.nBins)
+        return false;
+    if (slot.peak >= 0xffffu - 256u)            // (no count of the slot may saturate: each takes at most 255 more)
+        return false;
+    // ---- the load behind every record, window by window: behind the last record that begins in window b the counting cursor
+    // stands at max(where it stood, entries of the slot that end before b) -- the records of the run that end before b began
+    // before b, so they are filed by then -- and the load is what it was, plus the records filed, minus the cursor's way
+    {
+        const uint16_t * hist = slot.hist.data();
+        uint64_t oldBelow = slot.curCum[0];     // entries already in the slot that end before window (base + at)
+        unsigned at = slot.curBin[0];
+        uint64_t runBelow = 0;                  // records of the run that end before window b
+        uint64_t filed = 0;
+        const uint64_t dNext0 = en.dNext;
+        const unsigned histBins = static_cast<unsigned>(slot.hist.size());
+        for (unsigned b = firstBin; b <= lastBin; ++b)
+        {
+            const unsigned rel = b - s.binBase;
+            const unsigned t = b - base;        // (b >= base: tFirst >= curBin[0] >= 0 with firstBin > base, or firstBin <= base -> t clamps)
+            // old entries ending before b: advance the prefix to t
+            const unsigned upTo = b > base ? std::min(t, histBins) : 0u;
+            for (; at < upTo; ++at)
+                if (at >= slot.lowBin && at < slot.highBin)
+                    oldBelow += hist[at];
+            if (startCounts[rel] != 0)
+            {
+                filed += startCounts[rel];
+                const uint64_t below = oldBelow + runBelow;
+                const uint64_t cursor = std::max<uint64_t>(dNext0, below);
+                if (load0 + filed - (cursor - dNext0) >= cap)
+                    return false;
+            }
+            runBelow += endCounts[rel];
+        }
+        if (filed != s.n)
+            return false;                       // (the counts do not add up to the records: not a summary of this run)
+    }
+    // ---- file: the start entries in one copy, the end entries as counts and a reference
+    StartSlots::Slot & sslot = st.slots[st.writeSlot];
+    sslot.endBorder = slot.right;
+    if (!sslot.entries.empty() && s.firstPos < sslot.entries.back().startPos)
+        sslot.sorted = false;
+    const unsigned id = st.insertionCount;
+    st.insertionCount += s.n;
+    const uint32_t firstEntry = static_cast<uint32_t>(sslot.entries.size());
+    const StartEntry * src = reinterpret_cast<const StartEntry *>(posDev);
+    sslot.entries.insert(sslot.entries.end(), src, src + s.n);
+    {
+        uint16_t * hist = slot.hist.data();
+        const unsigned cur0 = slot.curBin[0], cur1 = slot.curBin[1];
+        unsigned cum0 = 0, cum1 = 0, peak = slot.peak;
+        for (unsigned b = s.minEndBin; b <= s.maxEndBin; ++b)
+        {
+            const unsigned add = endCounts[b - s.binBase];
+            if (add == 0)
+                continue;
+            const unsigned t = b - base;
+            const unsigned count = (hist[t] = static_cast<uint16_t>(hist[t] + add));
+            peak = count > peak ? count : peak;
+            cum0 += t < cur0 ? add : 0u;
+            cum1 += t < cur1 ? add : 0u;
+        }
+        slot.peak = peak;
+        slot.curCum[0] += cum0;
+        slot.curCum[1] += cum1;
+        slot.ordered = slot.ordered && (s.flags & RunSummary::kEndsInOrder) != 0 && s.firstEndBin * 30u >= slot.backWin;
+        slot.backWin = s.lastEndBin * 30u;
+        if (s.minEndBin - base < slot.lowBin)
+            slot.lowBin = s.minEndBin - base;
+        if (s.maxEndBin - base >= slot.highBin)
+            slot.highBin = s.maxEndBin - base + 1;
+        if (s.maxEndBin * 30u > slot.maxWin)
+            slot.maxWin = s.maxEndBin * 30u;
+        slot.deferred.push_back(EndSlots::Deferred{slot.entries.size(), st.writeSlot, firstEntry, s.n, id, innerOffset});
+        slot.total += s.n;
+    }
+    unsigned load = load0 + s.n;
+    load -= en.countEndedFast(s.lastPos);
+    activeLoad[rg] = load;
+    return true;
 }
 
 void ChromProfile::activate(unsigned rg, unsigned id, unsigned logWindow)
@@ -823,7 +1042,7 @@ void ChromProfile::drainEndReadSlot(unsigned rg)
     EndSlots & en = ends[rg];
     if (en.light)
     {
-        en.readIdx = en.slots[en.readSlot].entries.size();
+        en.readIdx = en.slots[en.readSlot].total;
         return;
     }
     while (!en.readAtEnd())
@@ -842,6 +1061,10 @@ void ChromProfile::performSwitches(const std::vector<unsigned> & rgs, unsigned *
     for (unsigned i : rgs)
     {
         drainEndReadSlot(i);
+        // (the start slot that is recycled may still back end entries filed in bulk: written out first -- except those of
+        // the end slot that is reset in the same breath)
+        if (ends[i].hasDeferred())
+            ends[i].settleRefsTo((starts[i].writeSlot + 1) % 3, (ends[i].writeSlot + 2) % 3);
         starts[i].switchBoth(rightBorder);
         ends[i].switchWrite();
         ends[i].fixConsecutiveSwitch(activeLoad[i]);
@@ -856,6 +1079,8 @@ void ChromProfile::performPartialSwitches(const std::vector<unsigned> & rgs, uns
     for (unsigned i : rgs)
     {
         drainEndReadSlot(i);
+        if (ends[i].hasDeferred())
+            ends[i].settleRefsTo((starts[i].writeSlot + 1) % 3, 3u);
         starts[i].switchBoth(rightBorder);
         ends[i].switchRead();
         switches_[i] = static_cast<uint8_t>(std::min(2, switches_[i] + 1));
@@ -868,7 +1093,7 @@ bool ChromProfile::allEmpty() const
     {
         if (!starts[i].slots[starts[i].writeSlot].entries.empty())
             return false;
-        if (!ends[i].slots[ends[i].writeSlot].entries.empty())
+        if (ends[i].slots[ends[i].writeSlot].total != 0)
             return false;
         if (!active[i].empty())
             return false;

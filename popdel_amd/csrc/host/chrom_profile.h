@@ -88,9 +88,26 @@ public:
 class alignas(64) EndSlots
 {
 public:
+    // Light slots need not write their entries out at all (round 6): a long run of records filed at once (ChromProfile::
+    // addBulk) is remembered as WHERE its start entries lie -- which start slot of the read group, from which entry on, how
+    // many, the id of the first, the inner offset that turns {position, deviation} into an end position -- and becomes
+    // EndEntry records only if somebody asks for them (leaving light mode; a record outside the counts' range). A start slot
+    // that is about to be recycled under such a reference has it written out first (ChromProfile::settleDeferred).
+    struct Deferred
+    {
+        size_t   explicitBefore;    // entries.size() when the run was filed: its place in filing order
+        uint32_t startSlot;         // the start slot (of the same read group) that holds its records
+        uint32_t first, n;          // start entries [first, first + n) of that slot
+        uint32_t firstId;           // id of the first of them (ids are consecutive)
+        int32_t  innerOffset;       // end position = start + max(0, deviation + innerOffset)
+    };
     struct Slot
     {
         HugeVector<EndEntry> entries;    // heavy: ordered by lastWindow (stable); light: in filing order, `ordered` says if that is the same
+                                         // (light: without the runs in `deferred`)
+        std::vector<Deferred> deferred;  // light: runs filed in bulk, not written out
+        size_t total = 0;                // entries filed (entries.size() + the deferred runs' records), both modes
+        unsigned backWin = 0;            // last window of the entry filed last (meaningful while total != 0; light)
         unsigned right = 0;
         bool readable = false;
         // light:
@@ -104,6 +121,9 @@ public:
         void reset(unsigned r)
         {
             entries.clear();
+            deferred.clear();
+            total = 0;
+            backWin = 0;
             right = r;
             readable = false;
             for (unsigned b = lowBin; b < highBin && b < hist.size(); ++b)
@@ -125,7 +145,7 @@ public:
     void add(unsigned id, unsigned endPos);
     unsigned countEnded(unsigned pos);      // getEndCount() of the reference
 
-    bool readAtEnd() const { return readIdx >= slots[readSlot].entries.size(); }
+    bool readAtEnd() const { return readIdx >= slots[readSlot].total; }
     bool goNext() { ++readIdx; return !readAtEnd(); }
     const EndEntry & current() const { return slots[readSlot].entries[readIdx]; }   // heavy only
 
@@ -144,9 +164,11 @@ public:
         const unsigned bin = endPos / 30u, lastWin = bin * 30u;
         Slot & slot = slots[lastWin >= slots[writeSlot].right ? (writeSlot + 1) % 3 : writeSlot];
         const unsigned b = bin - slot.baseBin;              // (wraps below the base: out of range)
-        if (light && !slot.entries.empty() && b < slot.hist.size() && slot.hist[b] != 0xffffu)
+        if (light && slot.total != 0 && b < slot.hist.size() && slot.hist[b] != 0xffffu)
         {
-            slot.ordered = slot.ordered && lastWin >= slot.entries.back().lastWindow;
+            slot.ordered = slot.ordered && lastWin >= slot.backWin;
+            slot.backWin = lastWin;
+            ++slot.total;
             if (b < slot.lowBin)
                 slot.lowBin = b;
             if (b >= slot.highBin)
@@ -174,7 +196,7 @@ public:
     size_t quietBlock(unsigned firstPos, unsigned lastPos, size_t n, bool intoWriteSlot) const
     {
         const Slot & slot = slots[endPosSlot];
-        const size_t have = slot.entries.size();
+        const size_t have = slot.total;
         if (!light || dNextOffset != 0 || dNext >= have)
             return 0;
         const unsigned firstBins = firstPos / 30u, lastBins = lastPos / 30u;
@@ -202,10 +224,10 @@ public:
     {
         constexpr size_t kMost = 256;
         Slot & slot = slots[writeSlot];
-        if (light && !slot.entries.empty() && n <= kMost)
+        if (light && slot.total != 0 && n <= kMost)
         {
             EndEntry fresh[kMost];
-            unsigned minBin = 0xffffffffu, maxBin = 0, before = slot.entries.back().lastWindow;
+            unsigned minBin = 0xffffffffu, maxBin = 0, before = slot.backWin;
             bool ordered = true;
             for (size_t j = 0; j < n; ++j)
             {
@@ -245,6 +267,8 @@ public:
                     if (maxBin * 30u > slot.maxWin)
                         slot.maxWin = maxBin * 30u;
                     slot.entries.insert(slot.entries.end(), fresh, fresh + n);
+                    slot.total += n;
+                    slot.backWin = before;
                     return;
                 }
             }
@@ -255,7 +279,7 @@ public:
     unsigned countEndedFast(unsigned pos)
     {
         Slot & slot = slots[endPosSlot];
-        const unsigned n = static_cast<unsigned>(slot.entries.size());
+        const unsigned n = static_cast<unsigned>(slot.total);
         if (light && dNextOffset == 0 && dNext < n)
         {
             const unsigned bins = pos / 30u;                // windows 0 .. bins-1 end before the window of pos
@@ -291,6 +315,16 @@ public:
     unsigned readSlot = 2;
     unsigned numWindows;
 
+    // ---- runs filed in bulk (Deferred) ------------------------------------------------------------------------------------
+    // the start table of the same read group (ChromProfile sets it): where the deferred runs' records lie
+    const StartSlots * startsOf = nullptr;
+    // every deferred run of `slot` written out as EndEntry records, in filing order
+    void settle(Slot & slot);
+    // ... those of all slots that refer to start slot `startSlot` (it is about to be recycled), except in end slot `spare`
+    // (3: none), which is about to be reset itself
+    void settleRefsTo(unsigned startSlot, unsigned spare);
+    bool hasDeferred() const { return !slots[0].deferred.empty() || !slots[1].deferred.empty() || !slots[2].deferred.empty(); }
+
 private:
     void addLight(Slot & slot, unsigned id, unsigned lastWin);
     unsigned countEndedLight(unsigned pos);
@@ -298,6 +332,27 @@ private:
     void prepareHist(Slot & slot);
     void leaveLight();
 };
+
+// ---- a run of records summarised (round 6: filing without looking at the records) ------------------------------------------
+// What ChromProfile::addBulk() needs to know about records [0, n) of a run -- {position, deviation} pairs of one read group in
+// the order the reader delivers them -- instead of the records: how many begin and how many END in each 30-bp window
+// (counts[0][b], counts[1][b] for window binBase + b, one byte each, 255 = saturated), the extremes, and whether positions and
+// last windows come in non-decreasing order. The device computes it where the records were parsed (inflate.hip,
+// pd_inflater_summarize); summarizeRun() is the same on the host (tests, and the yardstick of the kernel).
+struct RunSummary
+{
+    uint32_t n = 0;                     // records covered: the longest prefix of the run whose pairs all end below the border
+    uint32_t firstPos = 0, lastPos = 0; // start positions of the first and the last of them
+    uint32_t binBase = 0;               // window (position / 30) of counts[.][0] = window of firstPos
+    uint32_t nBins = 0;                 // windows the counts cover (the last end window is binBase + nBins - 1)
+    uint32_t minEndBin = 0, maxEndBin = 0, firstEndBin = 0, lastEndBin = 0;     // absolute window numbers
+    uint32_t flags = 0;
+    static constexpr uint32_t kStartsInOrder = 1u, kEndsInOrder = 2u, kSaturated = 4u, kNoRoom = 8u;
+};
+// records {pos, dev} x nRecords, end position = pos + max(0, dev + innerOffset); the prefix ends ahead of the first record whose
+// last window lies at or beyond window `borderBin`; starts[] / ends[] have room for `room` windows
+void summarizeRun(const uint32_t * posDev, size_t nRecords, int innerOffset, uint32_t borderBin, uint32_t room, RunSummary & out,
+                  uint8_t * starts, uint8_t * ends);
 
 // ---- the window loop in closed form -----------------------------------------------------------------------------------
 // What the loop of processSegment() -- one extra step of nextWindow(), initializeActive(), then the walk -- does to a read
@@ -344,6 +399,15 @@ public:
     // add() for a run of records of one read group ({pos, dev} pairs as the reader delivers them; the pair's end is
     // pos + max(0, dev + innerOffset), innerOffset = median - 2 * read length): the same operations in the same order
     void addRun(unsigned rg, const uint32_t * posDev, size_t n, int innerOffset);
+    // addRun() for records [0, s.n) WITHOUT reading them (they are only copied into the start slot): from the summary the tables
+    // can tell whether filing them record by record would have been the everyday case throughout -- light tables, the end
+    // table's counting cursor at home in the write slot, every pair ending below that slot's border and inside the windows its
+    // counts cover, positions in order, and the load below the cap behind EVERY record (followed window by window from the
+    // counts: exact, not a bound) -- and if so files them at once: the same tables, cursors and load as addRun() leaves, the end
+    // entries remembered as a reference to the start entries (EndSlots::Deferred). Returns false, with nothing changed, if any of
+    // it does not hold: the caller then files the records with addRun().
+    bool addBulk(unsigned rg, const uint32_t * posDev, const RunSummary & s, const uint8_t * startCounts, const uint8_t * endCounts,
+                 int innerOffset);
     // room for n more records in the slots being written (one allocation instead of the doublings of push_back)
     void reserveRun(unsigned rg, size_t n);
     void initializeActive();

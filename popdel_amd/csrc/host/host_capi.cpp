@@ -391,6 +391,16 @@ int pdh_inflate_members_cpu(const uint8_t * data, const uint64_t * offsets, uint
 // records are dropped); 2 one record in twenty steps back by up to 40 bp (blocks out of order); 3 wide inserts (sd 400: end
 // records beyond the write slot's border, negative inner distances); 4 all of these and gaps of several slot lengths.
 int pdh_bench_filing_ex(unsigned rounds, int light, unsigned maxLoad, unsigned seed, int flavour, double * seconds, uint64_t * checksum);
+// (light == 2: runs filed from their summaries where the tables allow it; how many runs / records went that way since the
+// process began)
+static uint64_t g_bulkRuns = 0, g_bulkRecords = 0;
+void pdh_bench_filing_bulk_counts(uint64_t * runs, uint64_t * records)
+{
+    if (runs)
+        *runs = g_bulkRuns;
+    if (records)
+        *records = g_bulkRecords;
+}
 int pdh_bench_filing(unsigned rounds, int light, unsigned maxLoad, double * seconds, uint64_t * checksum)
 {
     return pdh_bench_filing_ex(rounds, light, maxLoad, 4242u, 0, seconds, checksum);
@@ -405,7 +415,7 @@ int pdh_bench_filing_ex(unsigned rounds, int light, unsigned maxLoad, unsigned s
     prof.resetTo(1000000);
     if (light)
         prof.setLightEnds(true);
-    std::mt19937 gen(seed);
+    std::mt19937 gen(seed), headGen(seed + 17u);       // (headGen: choices of the filing mode that must not change the records)
     std::normal_distribution<double> ins(0.0, flavour >= 3 ? 400.0 : 50.0);
     unsigned burst = 0;
     std::vector<uint32_t> rec;
@@ -439,7 +449,40 @@ int pdh_bench_filing_ex(unsigned rounds, int light, unsigned maxLoad, unsigned s
             pos += buffer * (1 + gen() % 3) + gen() % 5000;      // (a gap: the next round's records lie slots ahead)
         prof.reserveRun(0, rec.size() / 2);
         const auto t0 = std::chrono::steady_clock::now();
-        prof.addRun(0, rec.data(), rec.size() / 2, 500 - 300);
+        if (light >= 2)
+        {
+            // the way the driver files a device-parsed sample since round 6: a head of records one by one (the end table's
+            // counting cursor comes home to the write slot), the run up to the first pair that ends beyond the border from its
+            // summary (ChromProfile::addBulk; light == 3: the summary is taken but the records are filed by addRun() all the
+            // same -- the yardstick of the timing), the rest record by record again
+            const size_t n = rec.size() / 2;
+            const size_t head = std::min<size_t>(n, light == 2 ? headGen() % 200 : 64);
+            prof.addRun(0, rec.data(), head, 500 - 300);
+            size_t done = head;
+            if (done < n)
+            {
+                const pdh::EndSlots & en = prof.ends[0];
+                const uint32_t borderBin = (en.slots[en.writeSlot].right + 29u) / 30u;
+                const uint32_t room = buffer / 30u + 512u;
+                static std::vector<uint8_t> counts;
+                counts.resize(2 * static_cast<size_t>(room));
+                pdh::RunSummary sum;
+                const auto s0 = std::chrono::steady_clock::now();
+                pdh::summarizeRun(rec.data() + 2 * done, n - done, 500 - 300, borderBin, room, sum, counts.data(), counts.data() + room);
+                total -= std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count();     // (the device's work in the product)
+                if (light == 3)
+                    sum.n = 0;
+                if (sum.n >= 16 && prof.addBulk(0, rec.data() + 2 * done, sum, counts.data(), counts.data() + room, 500 - 300))
+                {
+                    done += sum.n;
+                    ++g_bulkRuns;
+                    g_bulkRecords += sum.n;
+                }
+            }
+            prof.addRun(0, rec.data() + 2 * done, n - done, 500 - 300);
+        }
+        else
+            prof.addRun(0, rec.data(), rec.size() / 2, 500 - 300);
         total += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         mix(prof.activeLoad[0]);
         mix(prof.starts[0].insertionCount);
@@ -463,7 +506,7 @@ int pdh_bench_filing_ex(unsigned rounds, int light, unsigned maxLoad, unsigned s
         mix(prof.ends[0].dNextOffset);
         mix(prof.ends[0].endPosSlot);
         for (int k = 0; k < 3; ++k)
-            mix(prof.ends[0].slots[k].entries.size());
+            mix(prof.ends[0].slots[k].total);
     }
     prof.setLightEnds(false);               // (back to ordered tables: what the host's window loop would find)
     for (int k = 0; k < 3; ++k)
