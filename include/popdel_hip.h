@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 13
+#define PD_ABI_VERSION 14
 
 /* One read group after start-up conditioning.
  * Replaces: `Histogram` (reference insert_histogram_popdel.h:19-43) after processHistogram()
@@ -479,6 +479,38 @@ typedef struct pd_parsed_blocks
 int pd_inflater_run_parsed(pd_inflater *inflater, const uint64_t *member_offsets, uint32_t n_members, const uint64_t *out_offsets,
                            const uint32_t *sample_first, const uint8_t *parse_member, const uint8_t **out, const uint32_t **status,
                            const uint64_t **out_lengths, pd_parsed_blocks *parsed, double *kernel_ms);
+
+/* ... and the records of a sample's round SUMMARISED for the loader's tables (ABI 14): what filing them needs to know when the
+ * maxLoad rule cannot bite (reference: ChromosomeProfile::add, profile_structure_popdel_call.h:1084-1112, asks
+ * CyclicEndEntryTable::getEndCount, :870-924, after every record how many pairs are over -- a function of how many pairs BEGIN and
+ * how many END in each 30-bp window as long as no record is dropped and the counting cursor stays in its slot). For run r --
+ * records [first_record, first_record + n_records) of the records array the inflater's last pd_inflater_run_parsed() left on the
+ * device, a pair's end position being position + max(0, deviation + inner_offset) -- the device takes the longest prefix whose
+ * pairs all have their last window (end position / 30) below border_window and leaves
+ *   summaries[r]                    number of records of that prefix (n; 0: nothing else is filled in), the first and last start
+ *                                   position, the window of counts[.][0] (= first position / 30), the number of windows the counts
+ *                                   span, smallest / largest / first / last end window, flags: 1 start positions in non-decreasing
+ *                                   order, 2 last windows in non-decreasing order, 4 a count reached 255 (saturated), 8 a window
+ *                                   outside the room (counts unusable)
+ *   counts[(2 * r + 0) * room + b]  records of the prefix that BEGIN in window bin_base + b (one byte, saturating)
+ *   counts[(2 * r + 1) * room + b]  records of the prefix that END there
+ * `room` windows per row (at most 8,000: the rows are built in LDS). Arrays are page-locked, callee-owned, valid until the next
+ * call on this inflater. The host's ChromProfile::addBulk() files a prefix from this without reading its records; summarizeRun()
+ * (chrom_profile.cpp) is the same computation on the host, the kernel's yardstick (tests/test_gpu_summarize.py). */
+typedef struct pd_run_request
+{
+    uint64_t first_record;
+    uint32_t n_records;
+    int32_t  inner_offset;
+    uint32_t border_window;
+    uint32_t reserved;
+} pd_run_request;
+typedef struct pd_run_summary
+{
+    uint32_t n, first_pos, last_pos, bin_base, n_bins, min_end_bin, max_end_bin, first_end_bin, last_end_bin, flags;
+} pd_run_summary;
+int pd_inflater_summarize(pd_inflater *inflater, const pd_run_request *runs, uint32_t n_runs, uint32_t room,
+                          const pd_run_summary **summaries, const uint8_t **counts, double *kernel_ms);
 
 /* Text of the last error on this context (or of the last failed pd_ctx_create if ctx == NULL). */
 const char *pd_last_error(const pd_ctx *ctx);

@@ -530,6 +530,22 @@ int pdh_bench_filing_ex(unsigned rounds, int light, unsigned maxLoad, unsigned s
 }
 }  // extern "C"
 
+extern "C" {
+// pdh::summarizeRun() for the tests: what the device's summarizeRunsKernel (pd_inflater_summarize) must reproduce. `summary`: the ten
+// words of pd_run_summary / pdh::RunSummary; `counts`: 2 * room bytes (records that begin / end per window).
+int pdh_summarize_run(const uint32_t * posDev, uint64_t nRecords, int innerOffset, uint32_t borderBin, uint32_t room, uint32_t * summary,
+                      uint8_t * counts)
+{
+    if (!posDev || !summary || !counts || room == 0)
+        return 1;
+    static_assert(sizeof(pdh::RunSummary) == 10 * sizeof(uint32_t), "RunSummary is pd_run_summary");
+    pdh::RunSummary s;
+    pdh::summarizeRun(posDev, static_cast<size_t>(nRecords), innerOffset, borderBin, room, s, counts, counts + room);
+    std::memcpy(summary, &s, sizeof(s));
+    return 0;
+}
+}  // extern "C"
+
 namespace {
 // inflated bytes of one block, as the loader's reader sees them
 class BlockSource : public pdh::ByteSource

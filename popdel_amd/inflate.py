@@ -112,10 +112,35 @@ class PdParsedBlocks(C.Structure):
                 ("block_flags", C.POINTER(C.c_uint32)), ("bytes_copied", C.c_uint32)]
 
 
-def parse_gpu(hip_lib, blobs, sample_first=None, device=0):
+class PdRunRequest(C.Structure):
+    _fields_ = [("first_record", C.c_uint64), ("n_records", C.c_uint32), ("inner_offset", C.c_int32), ("border_window", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+SUMMARY_FIELDS = ("n", "first_pos", "last_pos", "bin_base", "n_bins", "min_end_bin", "max_end_bin", "first_end_bin", "last_end_bin", "flags")
+
+
+def summarize_host(records, first, n, inner_offset, border_window, room):
+    """pdh::summarizeRun (chrom_profile.cpp) on records[first : first + n] ({pos, dev} rows). Returns (summary dict, counts uint8[2, room])."""
+    rec = np.ascontiguousarray(records[first: first + n], dtype=np.uint32)
+    if len(rec) == 0:
+        rec = np.zeros((1, 2), np.uint32)
+    summary = np.zeros(10, np.uint32)
+    counts = np.zeros((2, room), np.uint8)
+    lib = _host()
+    lib.pdh_summarize_run.restype = C.c_int
+    if lib.pdh_summarize_run(_ptr(rec, C.c_uint32), C.c_uint64(n), C.c_int(inner_offset), C.c_uint32(border_window), C.c_uint32(room),
+                             _ptr(summary, C.c_uint32), _ptr(counts, C.c_uint8)) != 0:
+        raise RuntimeError("pdh_summarize_run failed")
+    return dict(zip(SUMMARY_FIELDS, (int(v) for v in summary))), counts
+
+
+def parse_gpu(hip_lib, blobs, sample_first=None, device=0, summarize=None, room=0):
     """pd_inflater_run_parsed on gzip members (one sample unless `sample_first` says otherwise). Returns a dict: status[n],
     flags[n], counts[n, 3] (256-bp windows, 30-bp windows, records per block), profile_windows[.., 5], call_windows[.., 3],
-    call_window_records[..], records[.., 2] (all blocks' rows in block order), bytes_copied."""
+    call_window_records[..], records[.., 2] (all blocks' rows in block order), bytes_copied. `summarize`: a list of
+    (first_record, n_records, inner_offset, border_window) runs over those records for pd_inflater_summarize with `room` windows per
+    row -> 'summaries' (list of dicts) and 'run_counts' uint8[runs, 2, room] as well ('summarize_rc' if the call was refused)."""
     data, offsets, out_offsets = pack_members(blobs)
     n = len(blobs)
     first = np.zeros(n, np.uint32) if sample_first is None else np.asarray(sample_first, np.uint32)
@@ -148,10 +173,25 @@ def parse_gpu(hip_lib, blobs, sample_first=None, device=0):
                 return np.zeros((0, width), np.uint32)
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), (count * width,)).reshape(count, width).copy()
 
-        return dict(status=st, flags=fl[:, 3], counts=np.stack([np.diff(ro), np.diff(wo), np.diff(co)], axis=1),
-                    profile_windows=rows(pb.profile_windows, int(ro[-1]), 5), call_windows=rows(pb.call_windows, int(wo[-1]), 3),
-                    call_window_records=rows(pb.call_window_records, int(wo[-1]), 1)[:, 0], records=rows(pb.records, int(co[-1]), 2),
-                    bytes_copied=int(pb.bytes_copied))
+        res = dict(status=st, flags=fl[:, 3], counts=np.stack([np.diff(ro), np.diff(wo), np.diff(co)], axis=1),
+                   profile_windows=rows(pb.profile_windows, int(ro[-1]), 5), call_windows=rows(pb.call_windows, int(wo[-1]), 3),
+                   call_window_records=rows(pb.call_window_records, int(wo[-1]), 1)[:, 0], records=rows(pb.records, int(co[-1]), 2),
+                   bytes_copied=int(pb.bytes_copied))
+        if summarize:
+            req = (PdRunRequest * len(summarize))()
+            for k, (first_record, n_records, inner, border) in enumerate(summarize):
+                req[k].first_record, req[k].n_records, req[k].inner_offset, req[k].border_window = first_record, n_records, inner, border
+            hip_lib.pd_inflater_summarize.restype = C.c_int
+            sums, cnts, kms = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint8)(), C.c_double()
+            rc = hip_lib.pd_inflater_summarize(C.c_void_p(inf), req, C.c_uint32(len(summarize)), C.c_uint32(room), C.byref(sums), C.byref(cnts),
+                                               C.byref(kms))
+            res["summarize_rc"] = rc
+            if rc == 0:
+                words = np.ctypeslib.as_array(sums, (len(summarize) * 10,)).reshape(len(summarize), 10).copy()
+                res["summaries"] = [dict(zip(SUMMARY_FIELDS, (int(v) for v in row))) for row in words]
+                res["run_counts"] = np.ctypeslib.as_array(cnts, (len(summarize) * 2 * room,)).reshape(len(summarize), 2, room).copy()
+                res["summarize_kernel_ms"] = kms.value
+        return res
     finally:
         hip_lib.pd_inflater_destroy(C.c_void_p(inf))
 
