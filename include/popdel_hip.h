@@ -324,6 +324,19 @@ typedef struct pd_walk_entry    /* ChromosomeProfileStartEntry (profile_structur
     int32_t  dev;               /* insertSizeDeviation */
 } pd_walk_entry;
 
+typedef struct pd_inflater pd_inflater;     /* (a persistent device gunzip + parser: pd_inflater_create() below) */
+
+/* Where a read group's new entries ALSO lie on the device (ABI 14): records [first_record, first_record + rg_counts[rg]) of the
+ * records array the inflater's last pd_inflater_run_parsed() / _summarized() left in HBM -- the loader parsed them there, the host
+ * filed them into its table in the same order. If given (inflater != NULL) and the inflater works on the context's GPU, the
+ * library takes the entries from there instead of fetching the host's table over the link; rg_entries[rg] must still point to the
+ * table (it is what every other case reads). The inflater must not run again before pd_walk_submit() returns. */
+typedef struct pd_walk_source
+{
+    pd_inflater *inflater;
+    uint64_t     first_record;
+} pd_walk_source;
+
 typedef struct pd_walk
 {
     uint32_t        first_window_pos;
@@ -338,6 +351,7 @@ typedef struct pd_walk
     const uint32_t *id_offset;
     const uint8_t  *switches;
     const uint8_t  *equal_run;
+    const pd_walk_source *rg_sources;  /* NULL, or per read group where its entries lie on the device as well (see pd_walk_source) */
 } pd_walk;
 
 /* Stage the segment (entries -> HBM -> pair instances -> layout) and enqueue the window loop's genotyping for it; the
@@ -356,6 +370,9 @@ int pd_host_regions_offer(const void *const *begin, const uint64_t *bytes, uint3
  * (*gathered) and that went through the staging copy (*staged); bytes of offered ranges page-locked so far (*locked_bytes).
  * Any pointer may be NULL. */
 int pd_walk_entry_counts(pd_ctx *ctx, uint64_t *gathered, uint64_t *staged, uint64_t *locked_bytes);
+
+/* ... and how many entries were taken from records already on the device (pd_walk_source; ABI 14). */
+int pd_walk_source_counts(pd_ctx *ctx, uint64_t *from_device);
 
 /* 1 if the backend behind the ABI offers pd_walk_submit() (the oracle does not: it takes pd_segment only), else 0. A
  * property of the library: `ctx` may be NULL (a caller that plans its first segment while the context is still being
@@ -445,7 +462,6 @@ const char *pd_inflate_last_error(void);
  * pd_inflater_run() copies them up, inflates and copies back: *out (page-locked, callee-owned, valid until the next run on
  * this inflater) holds member m's bytes at out_offsets[m], *status / *out_lengths as in pd_inflate_members(). One inflater
  * is used from one thread at a time. pd_inflater_create() returns NULL if the backend has no device (the oracle). */
-typedef struct pd_inflater pd_inflater;
 pd_inflater *pd_inflater_create(int device);
 const char *pd_inflater_last_error(pd_inflater *inflater);     /* why this inflater's last run failed (ABI 12) */
 void pd_inflater_destroy(pd_inflater *inflater);
@@ -480,37 +496,38 @@ int pd_inflater_run_parsed(pd_inflater *inflater, const uint64_t *member_offsets
                            const uint32_t *sample_first, const uint8_t *parse_member, const uint8_t **out, const uint32_t **status,
                            const uint64_t **out_lengths, pd_parsed_blocks *parsed, double *kernel_ms);
 
-/* ... and the records of a sample's round SUMMARISED for the loader's tables (ABI 14): what filing them needs to know when the
+/* ... and the parsed records SUMMARISED block by block for the loader's tables (ABI 14): what filing them needs to know when the
  * maxLoad rule cannot bite (reference: ChromosomeProfile::add, profile_structure_popdel_call.h:1084-1112, asks
  * CyclicEndEntryTable::getEndCount, :870-924, after every record how many pairs are over -- a function of how many pairs BEGIN and
- * how many END in each 30-bp window as long as no record is dropped and the counting cursor stays in its slot). For run r --
- * records [first_record, first_record + n_records) of the records array the inflater's last pd_inflater_run_parsed() left on the
- * device, a pair's end position being position + max(0, deviation + inner_offset) -- the device takes the longest prefix whose
- * pairs all have their last window (end position / 30) below border_window and leaves
- *   summaries[r]                    number of records of that prefix (n; 0: nothing else is filled in), the first and last start
- *                                   position, the window of counts[.][0] (= first position / 30), the number of windows the counts
- *                                   span, smallest / largest / first / last end window, flags: 1 start positions in non-decreasing
- *                                   order, 2 last windows in non-decreasing order, 4 a count reached 255 (saturated), 8 a window
- *                                   outside the room (counts unusable)
- *   counts[(2 * r + 0) * room + b]  records of the prefix that BEGIN in window bin_base + b (one byte, saturating)
- *   counts[(2 * r + 1) * room + b]  records of the prefix that END there
- * `room` windows per row (at most 8,000: the rows are built in LDS). Arrays are page-locked, callee-owned, valid until the next
- * call on this inflater. The host's ChromProfile::addBulk() files a prefix from this without reading its records; summarizeRun()
- * (chrom_profile.cpp) is the same computation on the host, the kernel's yardstick (tests/test_gpu_summarize.py). */
-typedef struct pd_run_request
-{
-    uint64_t first_record;
-    uint32_t n_records;
-    int32_t  inner_offset;
-    uint32_t border_window;
-    uint32_t reserved;
-} pd_run_request;
-typedef struct pd_run_summary
+ * how many END in each 30-bp window as long as no record is dropped and the counting cursor stays in its slot).
+ * pd_inflater_run_summarized() is pd_inflater_run_parsed() with, for every parsed block m (a pair's end position being position +
+ * max(0, deviation + inner_offset[m]); inner_offset[m] = median - 2 * read length of the block's read group),
+ *   block_summaries[m]                      number of records (n; 0: nothing else is filled in), first and last start position, the
+ *                                           window (position / 30) of the counts' first entry (= that of the first position), the
+ *                                           number of windows up to the last end window, smallest / largest / first / last end window,
+ *                                           flags: 1 start positions in non-decreasing order, 2 last windows in non-decreasing order,
+ *                                           4 a count reached 255 (saturated), 8 a window outside the room (counts unusable)
+ *   block_counts[m * (starts_room + ends_room) + b]                records that BEGIN in window bin_base + b (b < starts_room; one
+ *                                                                  byte, saturating)
+ *   block_counts[m * (starts_room + ends_room) + starts_room + b]  records that END there (b < ends_room)
+ * in the same page-locked, callee-owned arrays' lifetime as the rest of pd_parsed_blocks. A block spans one index region (10,000 bp
+ * by default: 335 windows of starts, ends a little further). The host's ChromProfile::addBulk() files whole blocks from this without
+ * reading their records; summarizeRun() (chrom_profile.cpp) is the same computation on the host, the kernel's yardstick
+ * (tests/test_gpu_summarize.py). */
+typedef struct pd_block_summary
 {
     uint32_t n, first_pos, last_pos, bin_base, n_bins, min_end_bin, max_end_bin, first_end_bin, last_end_bin, flags;
-} pd_run_summary;
-int pd_inflater_summarize(pd_inflater *inflater, const pd_run_request *runs, uint32_t n_runs, uint32_t room,
-                          const pd_run_summary **summaries, const uint8_t **counts, double *kernel_ms);
+} pd_block_summary;
+typedef struct pd_block_summaries
+{
+    const pd_block_summary *block_summaries;    /* n_members */
+    const uint8_t          *block_counts;       /* n_members x (starts_room + ends_room) */
+    uint32_t                starts_room, ends_room;
+} pd_block_summaries;
+int pd_inflater_run_summarized(pd_inflater *inflater, const uint64_t *member_offsets, uint32_t n_members, const uint64_t *out_offsets,
+                               const uint32_t *sample_first, const uint8_t *parse_member, const int32_t *inner_offset,
+                               uint32_t starts_room, uint32_t ends_room, const uint8_t **out, const uint32_t **status,
+                               const uint64_t **out_lengths, pd_parsed_blocks *parsed, pd_block_summaries *summaries, double *kernel_ms);
 
 /* Text of the last error on this context (or of the last failed pd_ctx_create if ctx == NULL). */
 const char *pd_last_error(const pd_ctx *ctx);

@@ -1122,8 +1122,15 @@ int pd_inflater_run(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *,
 int pd_ctx_set_shard_lanes(pd_ctx *, const pd_shard *, const pd_shard *, uint32_t) { return 1; }
 int pd_inflater_run_parsed(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t **, const uint32_t **,
                            const uint64_t **, pd_parsed_blocks *, double *) { return 1; }
-int pd_inflater_summarize(pd_inflater *, const pd_run_request *, uint32_t, uint32_t, const pd_run_summary **, const uint8_t **, double *) { return 1; }
+int pd_inflater_run_summarized(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *, const uint32_t *, const uint8_t *, const int32_t *, uint32_t, uint32_t,
+                               const uint8_t **, const uint32_t **, const uint64_t **, pd_parsed_blocks *, pd_block_summaries *, double *) { return 1; }
 
+int pd_walk_source_counts(pd_ctx *, uint64_t * from_device)
+{
+    if (from_device)
+        *from_device = 0;
+    return 0;
+}
 int pd_walk_supported(const pd_ctx *) { return getenv("POPDEL_ORACLE_WALK") ? 1 : 0; }
 int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
 {

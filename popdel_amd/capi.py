@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "pd_local_group_create", "pd_local_group_destroy", "pd_ctx_set_shard_local", "pd_log_table_view",
     "pd_ctx_keep_results_on_device", "pd_calls_merge", "pd_calls_fetch_columns", "pd_merged_free",
     "pd_walk_submit", "pd_walk_supported", "pd_walk_active", "pd_device_warmup", "pd_inflate_members", "pd_inflate_last_error",
-    "pd_inflater_create", "pd_inflater_destroy", "pd_inflater_input", "pd_inflater_run", "pd_inflater_run_parsed", "pd_inflater_summarize", "pd_ctx_set_shard_lanes",
+    "pd_inflater_create", "pd_inflater_destroy", "pd_inflater_input", "pd_inflater_run", "pd_inflater_run_parsed", "pd_inflater_run_summarized", "pd_walk_source_counts", "pd_ctx_set_shard_lanes",
     "pd_inflater_last_error", "pd_ctx_stage1_view", "pd_last_stage_timing", "pd_host_copy_gbs", "pd_host_regions_offer", "pd_walk_entry_counts",
 )
 RCCL_ID_BYTES = 128
@@ -89,7 +89,8 @@ class PdWalk(C.Structure):
     _fields_ = [("first_window_pos", C.c_uint32), ("step_pos", C.c_uint32), ("has_step", C.c_uint32), ("n_windows", C.c_uint32),
                 ("window_shift", C.c_uint32), ("n_readgroups", C.c_uint32), ("rg_counts", C.POINTER(C.c_uint32)),
                 ("rg_entries", C.POINTER(C.POINTER(PdWalkEntry))), ("end_border", C.POINTER(C.c_uint32)),
-                ("id_offset", C.POINTER(C.c_uint32)), ("switches", C.POINTER(C.c_uint8)), ("equal_run", C.POINTER(C.c_uint8))]
+                ("id_offset", C.POINTER(C.c_uint32)), ("switches", C.POINTER(C.c_uint8)), ("equal_run", C.POINTER(C.c_uint8)),
+                ("rg_sources", C.c_void_p)]
 
 
 class PdStageTiming(C.Structure):
@@ -396,7 +397,7 @@ class Context:
         wk = PdWalk(first_window_pos, step_pos or 0, 0 if step_pos is None else 1, n_windows, window_shift, n_rg,
                     counts.ctypes.data_as(C.POINTER(C.c_uint32)), ptrs, border.ctypes.data_as(C.POINTER(C.c_uint32)),
                     ids.ctypes.data_as(C.POINTER(C.c_uint32)), sw.ctypes.data_as(C.POINTER(C.c_uint8)),
-                    run.ctypes.data_as(C.POINTER(C.c_uint8)))
+                    run.ctypes.data_as(C.POINTER(C.c_uint8)), None)
         t = C.c_uint64()
         self._check(self.lib.pd_walk_submit(self.handle, C.byref(wk), C.byref(t)))
         return t.value

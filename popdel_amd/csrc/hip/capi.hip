@@ -492,6 +492,8 @@ struct pd_ctx
     PinnedBuf<uint2> hWalkEntries;
     PinnedBuf<uint64_t> hWalkSrc;           // per read group: device-visible address of its entries in the host's own tables (0: staged)
     DevBuf<uint64_t> dWalkSrc;
+    PinnedBuf<uint64_t> hWalkDevSrc;        // ... or their address in an inflater's records on this GPU (0: none)
+    DevBuf<uint64_t> dWalkDevSrc;
     PinnedBuf<uint8_t> hWalkFlags;          // switches, then equal_run
     DevBuf<uint32_t> dWalkBorder, dWalkIdOffset, dWalkCount;
     DevBuf<uint2> dWalkEntries;
@@ -501,6 +503,7 @@ struct pd_ctx
     PinnedBuf<unsigned long long> hWalkTotals;
     uint64_t walkActive = 0;                // pairs left active after the last submitted walk
     uint64_t walkGathered = 0, walkStaged = 0;      // entries the device fetched from the host's tables / the host threads staged
+    uint64_t walkFromDevice = 0;                    // ... / taken from the records an inflater left on the device (pd_walk_source)
     uint64_t nextHandle = 1, nextTicket = 1;
     std::map<uint64_t, Run> runs;
 
@@ -2775,6 +2778,15 @@ int pd_walk_entry_counts(pd_ctx * c, uint64_t * gathered, uint64_t * staged, uin
     return 0;
 }
 
+int pd_walk_source_counts(pd_ctx * c, uint64_t * from_device)
+{
+    if (!c)
+        return 1;
+    if (from_device)
+        *from_device = c->walkFromDevice;
+    return 0;
+}
+
 int pd_walk_supported(const pd_ctx *) { return 1; }
 
 int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
@@ -2831,13 +2843,43 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
             static_assert(sizeof(pd_walk_entry) == sizeof(uint2), "entry layout");
             c->hWalkSrc.resize(nRg);
             uint64_t gathered = 0;
+            // (read groups whose entries lie on this GPU already -- the records the loader's inflater parsed there, pd_walk_source --
+            // are copied from there: nothing crosses the link for them)
+            uint64_t fromDevice = 0;
+            static const bool deviceSources = [] {
+                const char * e = std::getenv("POPDEL_HIP_WALK_SOURCES");
+                return !(e && e[0] == '0');
+            }();
+            c->hWalkDevSrc.resize(nRg);
+            std::fill(c->hWalkDevSrc.data(), c->hWalkDevSrc.data() + nRg, static_cast<uint64_t>(0));
+            if (wk->rg_sources && deviceSources)
+                for (uint32_t r = 0; r < nRg; ++r)
+                {
+                    const uint64_t n = c->hRgOffsets[r + 1] - c->hRgOffsets[r];
+                    if (n == 0 || !wk->rg_sources[r].inflater)
+                        continue;
+                    uint64_t have = 0;
+                    int dev = -1;
+                    const uint2 * base = pd::inflaterDeviceRecords(wk->rg_sources[r].inflater, have, dev);
+                    if (!base || dev != c->device || wk->rg_sources[r].first_record > have || n > have - wk->rg_sources[r].first_record)
+                        continue;
+                    c->hWalkDevSrc[r] = reinterpret_cast<uintptr_t>(base + wk->rg_sources[r].first_record);
+                    fromDevice += n;
+                }
             for (uint32_t r = 0; r < nRg; ++r)
             {
                 const uint64_t n = c->hRgOffsets[r + 1] - c->hRgOffsets[r];
-                c->hWalkSrc[r] = n != 0 && walkGatherWanted() ? deviceViewOfHost(wk->rg_entries[r], n * sizeof(uint2)) : 0u;
+                c->hWalkSrc[r] = n != 0 && !c->hWalkDevSrc[r] && walkGatherWanted() ? deviceViewOfHost(wk->rg_entries[r], n * sizeof(uint2)) : 0u;
                 gathered += c->hWalkSrc[r] ? n : 0u;
             }
-            if (gathered != nEntries)
+            if (fromDevice != 0)
+            {
+                c->dWalkDevSrc.uploadPinned(c->hWalkDevSrc, cs);
+                pd::launchGatherDeviceEntries(c->dWalkDevSrc.p, dEntryOffsets.p, c->dWalkEntries.p, nRg, cs);
+                PD_HIP(hipGetLastError());
+            }
+            c->walkFromDevice += fromDevice;
+            if (gathered + fromDevice != nEntries)
             {
                 const size_t nSlabs = std::min<size_t>(8, std::max<size_t>(1, nRg / 64));
                 for (size_t slab = 0; slab < nSlabs; ++slab)
@@ -2846,13 +2888,13 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
                     const uint64_t a = c->hRgOffsets[rLo], b = c->hRgOffsets[rHi];
                     uint64_t staged = 0;
                     for (size_t r = rLo; r < rHi; ++r)
-                        staged += c->hWalkSrc[r] ? 0u : c->hRgOffsets[r + 1] - c->hRgOffsets[r];
+                        staged += c->hWalkSrc[r] || c->hWalkDevSrc[r] ? 0u : c->hRgOffsets[r + 1] - c->hRgOffsets[r];
                     if (staged == 0)
                         continue;
                     pdh::parallelFor(rHi - rLo, [&](size_t k) {
                         const size_t r = rLo + k;
                         const uint64_t n = c->hRgOffsets[r + 1] - c->hRgOffsets[r];
-                        if (n && !c->hWalkSrc[r])
+                        if (n && !c->hWalkSrc[r] && !c->hWalkDevSrc[r])
                             std::memcpy(c->hWalkEntries.data() + c->hRgOffsets[r], wk->rg_entries[r], n * sizeof(uint2));
                     }, 16);
                     // (the whole slab goes up; the stretches of gathered read groups are written by the kernel behind it)
@@ -2881,7 +2923,7 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
                                                   (c->hRgOffsets[r + 1] - c->hRgOffsets[r]) * sizeof(uint2), hipMemcpyHostToDevice, cs));
             }
             c->walkGathered += gathered;
-            c->walkStaged += nEntries - gathered;
+            c->walkStaged += nEntries - gathered - fromDevice;
         }
         // ---- instances per read group, their offsets (the build's rgOffsets), then the instances and the new state
         pd::WalkInput in;

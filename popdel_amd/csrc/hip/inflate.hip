@@ -19,6 +19,7 @@
 #include "pinned_host.h"
 #include "inflate_core.h"
 #include "popdel_hip.h"
+#include "pd_walk.h"
 
 namespace {
 
@@ -286,63 +287,50 @@ __global__ __launch_bounds__(kParseLanes) void parseWriteKernel(const uint8_t * 
                     recs + recOff[m], (uint32_t)(winOff[m] - winOff[f]), (uint32_t)(recOff[m] - recOff[f]));
 }
 
-// ---- a run of records summarised for the loader's tables (round 6; pd_inflater_summarize, include/popdel_hip.h) -----------------
-// One workgroup per run: (1) the first record whose pair ends at or beyond the border window cuts the prefix; (2) the prefix's
-// records are counted by the window they begin in and the window they end in (LDS, then one saturating byte per window), with
-// the extremes and the two order flags. The host's twin: pdh::summarizeRun() (chrom_profile.cpp).
-constexpr unsigned kSummaryThreads = 256;
-constexpr unsigned kSummaryRoomMax = 8000;          // windows per row: 2 rows x 4 bytes in LDS
+// ---- the parsed records summarised block by block for the loader's tables (round 6; pd_inflater_run_summarized) ----------------
+// One workgroup per block: its records are counted by the window they begin in and the window they end in (LDS, then one
+// saturating byte per window), with the extremes and the two order flags. The host's twin: pdh::summarizeRun() (chrom_profile.cpp).
+constexpr unsigned kSummaryThreads = 128;
+constexpr unsigned kSummaryRoomMax = 12000;         // windows per block, starts and ends together: 4 bytes each in LDS
 
-__global__ __launch_bounds__(kSummaryThreads) void summarizeRunsKernel(const uint2 * __restrict__ recs, const pd_run_request * __restrict__ runs,
-                                                                       uint32_t room, pd_run_summary * __restrict__ summaries,
-                                                                       uint8_t * __restrict__ counts)
+__global__ __launch_bounds__(kSummaryThreads) void summarizeBlocksKernel(const uint2 * __restrict__ recs, const uint64_t * __restrict__ recOff,
+                                                                         const BlockCounts * __restrict__ blocks, const int32_t * __restrict__ innerOffset,
+                                                                         uint32_t startsRoom, uint32_t endsRoom,
+                                                                         pd_block_summary * __restrict__ summaries, uint8_t * __restrict__ counts)
 {
-    extern __shared__ unsigned shCounts[];          // [2][room]
-    __shared__ unsigned shCut, shMinEnd, shMaxEnd, shFlags;
-    const pd_run_request run = runs[blockIdx.x];
-    const uint2 * r = recs + run.first_record;
-    const unsigned n = run.n_records;
+    extern __shared__ unsigned shCounts[];          // [startsRoom + endsRoom]
+    __shared__ unsigned shMinEnd, shMaxEnd, shFlags;
+    const uint32_t m = blockIdx.x;
+    const uint2 * r = recs + recOff[m];
+    const unsigned n = blocks[m].flags ? 0u : (unsigned)(recOff[m + 1] - recOff[m]);
+    const int inner = innerOffset[m];
+    const unsigned room = startsRoom + endsRoom;
     auto endBinOf = [&](uint2 rec) {
-        const int inner = (int)rec.y + run.inner_offset;
-        return (rec.x + (inner > 0 ? (unsigned)inner : 0u)) / 30u;
+        const int d = (int)rec.y + inner;
+        return (rec.x + (d > 0 ? (unsigned)d : 0u)) / 30u;
     };
+    pd_block_summary out;
+    out.n = n;
+    out.first_pos = out.last_pos = out.bin_base = out.n_bins = out.min_end_bin = out.max_end_bin = out.first_end_bin = out.last_end_bin = out.flags = 0;
+    uint8_t * row = counts + (size_t)m * room;
+    if (n == 0)
+    {
+        if (threadIdx.x == 0)
+            summaries[m] = out;
+        return;                                     // (its counts are not looked at)
+    }
     if (threadIdx.x == 0)
     {
-        shCut = n;
         shMinEnd = 0xffffffffu;
         shMaxEnd = 0;
         shFlags = 1u | 2u;
     }
-    for (unsigned b = threadIdx.x; b < 2u * room; b += kSummaryThreads)
+    for (unsigned b = threadIdx.x; b < room; b += kSummaryThreads)
         shCounts[b] = 0;
     __syncthreads();
-    // (1) the cut: the smallest index whose pair ends at or beyond the border (records are looked at in index order per lane, so a
-    // lane stops at its first)
-    for (unsigned i = threadIdx.x; i < n; i += kSummaryThreads)
-    {
-        if (i >= *(volatile unsigned *)&shCut)
-            break;
-        if (endBinOf(r[i]) >= run.border_window)
-        {
-            atomicMin(&shCut, i);
-            break;
-        }
-    }
-    __syncthreads();
-    const unsigned m = shCut;
-    pd_run_summary out;
-    out.n = m;
-    out.first_pos = out.last_pos = out.bin_base = out.n_bins = out.min_end_bin = out.max_end_bin = out.first_end_bin = out.last_end_bin = out.flags = 0;
-    if (m == 0)
-    {
-        if (threadIdx.x == 0)
-            summaries[blockIdx.x] = out;
-        return;
-    }
     const unsigned base = r[0].x / 30u;
-    // (2) counts, extremes, order
     unsigned myMin = 0xffffffffu, myMax = 0, myFlags = 0;       // myFlags: bits to CLEAR (1, 2) or to set (8)
-    for (unsigned i = threadIdx.x; i < m; i += kSummaryThreads)
+    for (unsigned i = threadIdx.x; i < n; i += kSummaryThreads)
     {
         const uint2 rec = r[i];
         const unsigned sb = rec.x / 30u, eb = endBinOf(rec);
@@ -356,12 +344,12 @@ __global__ __launch_bounds__(kSummaryThreads) void summarizeRunsKernel(const uin
         }
         myMin = min(myMin, eb);
         myMax = max(myMax, eb);
-        if (sb < base || sb - base >= room || eb < base || eb - base >= room)
+        if (sb < base || sb - base >= startsRoom || eb < base || eb - base >= endsRoom)
             myFlags |= 8u;
         else
         {
             atomicAdd(&shCounts[sb - base], 1u);
-            atomicAdd(&shCounts[room + eb - base], 1u);
+            atomicAdd(&shCounts[startsRoom + eb - base], 1u);
         }
     }
     atomicMin(&shMinEnd, myMin);
@@ -372,8 +360,7 @@ __global__ __launch_bounds__(kSummaryThreads) void summarizeRunsKernel(const uin
         atomicOr(&shFlags, 8u);
     __syncthreads();
     bool saturated = false;
-    uint8_t * row = counts + (size_t)blockIdx.x * 2u * room;
-    for (unsigned b = threadIdx.x; b < 2u * room; b += kSummaryThreads)
+    for (unsigned b = threadIdx.x; b < room; b += kSummaryThreads)
     {
         const unsigned c = shCounts[b];
         saturated = saturated || c >= 255u;
@@ -385,15 +372,15 @@ __global__ __launch_bounds__(kSummaryThreads) void summarizeRunsKernel(const uin
     if (threadIdx.x == 0)
     {
         out.first_pos = r[0].x;
-        out.last_pos = r[m - 1].x;
+        out.last_pos = r[n - 1].x;
         out.bin_base = base;
         out.min_end_bin = shMinEnd;
         out.max_end_bin = shMaxEnd;
         out.first_end_bin = endBinOf(r[0]);
-        out.last_end_bin = endBinOf(r[m - 1]);
+        out.last_end_bin = endBinOf(r[n - 1]);
         out.flags = shFlags;
         out.n_bins = (shFlags & 8u) ? 0u : shMaxEnd - base + 1u;
-        summaries[blockIdx.x] = out;
+        summaries[m] = out;
     }
 }
 
@@ -434,10 +421,10 @@ struct pd_inflater
     size_t capWanted = 0, capSampleFirst = 0, capCounts = 0, capOffsets = 0, capRaws = 0, capWins = 0, capWinCounts = 0, capRecs = 0;
     void *hOffsets = nullptr, *hFlags = nullptr, *hRaws = nullptr, *hWins = nullptr, *hWinCounts = nullptr, *hRecs = nullptr;
     size_t capHOffsets = 0, capHFlags = 0, capHRaws = 0, capHWins = 0, capHWinCounts = 0, capHRecs = 0;
-    uint64_t nRecsLast = 0;             // records the last pd_inflater_run_parsed() left in dRecs
-    // runs summarised (pd_inflater_summarize): requests up, summaries and counts back
-    void *dRuns = nullptr, *dSummaries = nullptr, *dRunCounts = nullptr, *hRuns = nullptr, *hSummaries = nullptr, *hRunCounts = nullptr;
-    size_t capDRuns = 0, capDSummaries = 0, capDRunCounts = 0, capHRuns = 0, capHSummaries = 0, capHRunCounts = 0;
+    uint64_t nRecsLast = 0;             // records the last parsed chunk left in dRecs
+    // blocks summarised (pd_inflater_run_summarized): inner offsets up, summaries and counts back
+    void *dInner = nullptr, *dSummaries = nullptr, *dBlockCounts = nullptr, *hSummaries = nullptr, *hBlockCounts = nullptr;
+    size_t capDInner = 0, capDSummaries = 0, capDBlockCounts = 0, capHSummaries = 0, capHBlockCounts = 0;
     std::string error;
 };
 
@@ -473,6 +460,15 @@ void growPinned(void *& p, size_t & cap, size_t want)
 
 }  // namespace
 
+namespace pd {
+const uint2 * inflaterDeviceRecords(pd_inflater * f, uint64_t & count, int & device)
+{
+    count = f ? f->nRecsLast : 0;
+    device = f ? f->device : -1;
+    return f ? static_cast<const uint2 *>(f->dRecs) : nullptr;
+}
+}  // namespace pd
+
 extern "C" pd_inflater * pd_inflater_create(int device)
 {
     pd_inflater * f = new (std::nothrow) pd_inflater();
@@ -503,10 +499,10 @@ extern "C" void pd_inflater_destroy(pd_inflater * f)
         return;
     (void)hipSetDevice(f->device);
     for (void * p : {f->dData, f->dOut, f->dInOff, f->dOutOff, f->dStatus, f->dLen, f->dWanted, f->dSampleFirst, f->dCounts, f->dOffsets, f->dRaws,
-                     f->dWins, f->dWinCounts, f->dRecs, f->dRuns, f->dSummaries, f->dRunCounts})
+                     f->dWins, f->dWinCounts, f->dRecs, f->dInner, f->dSummaries, f->dBlockCounts})
         if (p)
             (void)hipFree(p);
-    for (void * p : {f->hIn, f->hOut, f->hMeta, f->hOffsets, f->hFlags, f->hRaws, f->hWins, f->hWinCounts, f->hRecs, f->hRuns, f->hSummaries, f->hRunCounts})
+    for (void * p : {f->hIn, f->hOut, f->hMeta, f->hOffsets, f->hFlags, f->hRaws, f->hWins, f->hWinCounts, f->hRecs, f->hSummaries, f->hBlockCounts})
         if (p)
             pd::pinnedFree(p);
     for (hipEvent_t e : {f->finished, f->timeBegin, f->timeEnd})
@@ -536,10 +532,16 @@ extern "C" uint8_t * pd_inflater_input(pd_inflater * f, uint64_t bytes)
 
 static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_t n_members, const uint64_t * out_offsets,
                        const uint32_t * sample_first, const uint8_t * parse_member, const uint8_t ** out, const uint32_t ** status,
-                       const uint64_t ** out_lengths, pd_parsed_blocks * parsed, double * kernel_ms)
+                       const uint64_t ** out_lengths, pd_parsed_blocks * parsed, double * kernel_ms, const int32_t * inner_offset = nullptr,
+                       uint32_t starts_room = 0, uint32_t ends_room = 0, pd_block_summaries * summaries = nullptr)
 {
     if (!f || !member_offsets || !out_offsets || !out || !status || !out_lengths || n_members == 0 || (parsed && (!sample_first || !parse_member)))
         return 1;
+    if (summaries && (!parsed || !inner_offset || starts_room == 0 || ends_room == 0 || starts_room + ends_room > kSummaryRoomMax))
+    {
+        f->error = "pd_inflater_run_summarized: invalid argument (no inner offsets, or more than 12,000 windows of room per block)";
+        return 1;
+    }
     try
     {
         PD_INF_HIP(hipSetDevice(f->device));
@@ -632,6 +634,27 @@ static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_
             PD_INF_HIP(hipMemcpyAsync(f->hWins, f->dWins, nWins * sizeof(CallWindow), hipMemcpyDeviceToHost, st));
             PD_INF_HIP(hipMemcpyAsync(f->hWinCounts, f->dWinCounts, nWins * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             PD_INF_HIP(hipMemcpyAsync(f->hRecs, f->dRecs, nRecs * sizeof(uint2), hipMemcpyDeviceToHost, st));
+            if (summaries)
+            {
+                const size_t room = static_cast<size_t>(starts_room) + ends_room;
+                growDevice(f->dInner, f->capDInner, static_cast<size_t>(n_members) * sizeof(int32_t));
+                growDevice(f->dSummaries, f->capDSummaries, static_cast<size_t>(n_members) * sizeof(pd_block_summary));
+                growDevice(f->dBlockCounts, f->capDBlockCounts, static_cast<size_t>(n_members) * room);
+                growPinned(f->hSummaries, f->capHSummaries, static_cast<size_t>(n_members) * sizeof(pd_block_summary));
+                growPinned(f->hBlockCounts, f->capHBlockCounts, static_cast<size_t>(n_members) * room);
+                PD_INF_HIP(hipMemcpyAsync(f->dInner, inner_offset, static_cast<size_t>(n_members) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(summarizeBlocksKernel, dim3(n_members), dim3(kSummaryThreads), room * sizeof(unsigned), st,
+                                   static_cast<const uint2 *>(f->dRecs), dRecOff, static_cast<const BlockCounts *>(f->dCounts),
+                                   static_cast<const int32_t *>(f->dInner), starts_room, ends_room, static_cast<pd_block_summary *>(f->dSummaries),
+                                   static_cast<uint8_t *>(f->dBlockCounts));
+                PD_INF_HIP(hipGetLastError());
+                PD_INF_HIP(hipMemcpyAsync(f->hSummaries, f->dSummaries, static_cast<size_t>(n_members) * sizeof(pd_block_summary), hipMemcpyDeviceToHost, st));
+                PD_INF_HIP(hipMemcpyAsync(f->hBlockCounts, f->dBlockCounts, static_cast<size_t>(n_members) * room, hipMemcpyDeviceToHost, st));
+                summaries->block_summaries = static_cast<const pd_block_summary *>(f->hSummaries);
+                summaries->block_counts = static_cast<const uint8_t *>(f->hBlockCounts);
+                summaries->starts_room = starts_room;
+                summaries->ends_room = ends_room;
+            }
             // the inflated bytes themselves travel only if some block is left to the host's parser
             const BlockCounts * fl = static_cast<const BlockCounts *>(f->hFlags);
             needBytes = false;
@@ -692,69 +715,15 @@ extern "C" int pd_inflater_run_parsed(pd_inflater * f, const uint64_t * member_o
     return runInflater(f, member_offsets, n_members, out_offsets, sample_first, parse_member, out, status, out_lengths, parsed, kernel_ms);
 }
 
-extern "C" int pd_inflater_summarize(pd_inflater * f, const pd_run_request * runs, uint32_t n_runs, uint32_t room, const pd_run_summary ** summaries,
-                                     const uint8_t ** counts, double * kernel_ms)
+extern "C" int pd_inflater_run_summarized(pd_inflater * f, const uint64_t * member_offsets, uint32_t n_members, const uint64_t * out_offsets,
+                                          const uint32_t * sample_first, const uint8_t * parse_member, const int32_t * inner_offset,
+                                          uint32_t starts_room, uint32_t ends_room, const uint8_t ** out, const uint32_t ** status,
+                                          const uint64_t ** out_lengths, pd_parsed_blocks * parsed, pd_block_summaries * summaries, double * kernel_ms)
 {
-    if (!f || !runs || !summaries || !counts || n_runs == 0 || room == 0 || room > kSummaryRoomMax)
-    {
-        if (f)
-            f->error = "pd_inflater_summarize: invalid argument (no runs, or more than 8,000 windows of room)";
+    if (!parsed || !summaries)
         return 1;
-    }
-    try
-    {
-        PD_INF_HIP(hipSetDevice(f->device));
-        for (uint32_t r = 0; r < n_runs; ++r)
-            if (runs[r].first_record > f->nRecsLast || runs[r].n_records > f->nRecsLast - runs[r].first_record)
-                throw Fail{"a run lies outside the records of the inflater's last parsed chunk"};
-        const size_t countBytes = static_cast<size_t>(n_runs) * 2u * room;
-        growDevice(f->dRuns, f->capDRuns, static_cast<size_t>(n_runs) * sizeof(pd_run_request));
-        growDevice(f->dSummaries, f->capDSummaries, static_cast<size_t>(n_runs) * sizeof(pd_run_summary));
-        growDevice(f->dRunCounts, f->capDRunCounts, countBytes);
-        growPinned(f->hRuns, f->capHRuns, static_cast<size_t>(n_runs) * sizeof(pd_run_request));
-        growPinned(f->hSummaries, f->capHSummaries, static_cast<size_t>(n_runs) * sizeof(pd_run_summary));
-        growPinned(f->hRunCounts, f->capHRunCounts, countBytes);
-        std::memcpy(f->hRuns, runs, static_cast<size_t>(n_runs) * sizeof(pd_run_request));
-        hipStream_t st = f->stream;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (kernel_ms)
-        {
-            if (!f->timeBegin)
-                PD_INF_HIP(hipEventCreate(&f->timeBegin));
-            if (!f->timeEnd)
-                PD_INF_HIP(hipEventCreate(&f->timeEnd));
-            e0 = f->timeBegin;
-            e1 = f->timeEnd;
-        }
-        PD_INF_HIP(hipMemcpyAsync(f->dRuns, f->hRuns, static_cast<size_t>(n_runs) * sizeof(pd_run_request), hipMemcpyHostToDevice, st));
-        if (e0)
-            PD_INF_HIP(hipEventRecord(e0, st));
-        hipLaunchKernelGGL(summarizeRunsKernel, dim3(n_runs), dim3(kSummaryThreads), 2u * room * sizeof(unsigned), st,
-                           static_cast<const uint2 *>(f->dRecs), static_cast<const pd_run_request *>(f->dRuns), room,
-                           static_cast<pd_run_summary *>(f->dSummaries), static_cast<uint8_t *>(f->dRunCounts));
-        PD_INF_HIP(hipGetLastError());
-        if (e1)
-            PD_INF_HIP(hipEventRecord(e1, st));
-        PD_INF_HIP(hipMemcpyAsync(f->hSummaries, f->dSummaries, static_cast<size_t>(n_runs) * sizeof(pd_run_summary), hipMemcpyDeviceToHost, st));
-        PD_INF_HIP(hipMemcpyAsync(f->hRunCounts, f->dRunCounts, countBytes, hipMemcpyDeviceToHost, st));
-        PD_INF_HIP(hipEventRecord(f->finished, st));
-        PD_INF_HIP(hipEventSynchronize(f->finished));
-        if (kernel_ms)
-        {
-            float ms = 0;
-            PD_INF_HIP(hipEventElapsedTime(&ms, e0, e1));
-            *kernel_ms = ms;
-        }
-        *summaries = static_cast<const pd_run_summary *>(f->hSummaries);
-        *counts = static_cast<const uint8_t *>(f->hRunCounts);
-    }
-    catch (const Fail & e)
-    {
-        f->error = "pd_inflater_summarize: " + e.what;
-        g_inflateError = f->error;
-        return 2;
-    }
-    return 0;
+    return runInflater(f, member_offsets, n_members, out_offsets, sample_first, parse_member, out, status, out_lengths, parsed, kernel_ms,
+                       inner_offset, starts_room, ends_room, summaries);
 }
 
 extern "C" const char * pd_inflate_last_error(void) { return g_inflateError.c_str(); }

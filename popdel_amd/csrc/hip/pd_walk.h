@@ -4,6 +4,8 @@
 
 #include "pd_device.h"
 
+struct pd_inflater;
+
 namespace pd {
 
 // Shape of a segment (pdh::WalkShape): position of window 0, position of the loader's extra step ahead of it, windows.
@@ -54,6 +56,10 @@ void launchWalkEmit(const WalkInput & in, const WalkState & st, const WalkParams
 // entries in page-locked host memory (0: none / taken care of by a staging copy), rgOffsets as in WalkInput; one workgroup
 // walks a read group's entries, 16 bytes per lane and trip (the link wants many requests in flight: nRg workgroups of 256).
 void launchGatherHostEntries(const uint64_t * src, const uint64_t * rgOffsets, uint2 * entries, unsigned nRg, hipStream_t stream);
+// ... and from device memory (the records an inflater parsed, pd_walk_source): the same copy with a workgroup per read group
+void launchGatherDeviceEntries(const uint64_t * src, const uint64_t * rgOffsets, uint2 * entries, unsigned nRg, hipStream_t stream);
+// (inflate.hip) the records array the inflater's last parsed chunk left on the device: base, count, device
+const uint2 * inflaterDeviceRecords(::pd_inflater * inflater, uint64_t & count, int & device);
 
 }  // namespace pd
 #endif

@@ -357,4 +357,11 @@ void launchGatherHostEntries(const uint64_t * src, const uint64_t * rgOffsets, u
     hipLaunchKernelGGL(gatherHostEntriesKernel, dim3(std::min(nRg, gatherGroups())), dim3(256), 0, stream, src, rgOffsets, entries, nRg);
 }
 
+void launchGatherDeviceEntries(const uint64_t * src, const uint64_t * rgOffsets, uint2 * entries, unsigned nRg, hipStream_t stream)
+{
+    if (nRg == 0)
+        return;
+    hipLaunchKernelGGL(gatherHostEntriesKernel, dim3(nRg), dim3(256), 0, stream, src, rgOffsets, entries, nRg);
+}
+
 }  // namespace pd

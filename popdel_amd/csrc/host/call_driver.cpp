@@ -155,6 +155,15 @@ struct alignas(64) DecodedStream      // (neighbours in the pool are filled by d
     const uint32_t * countsV = nullptr;
     const PairRecord * recsV = nullptr;
     size_t nRecsV = 0;
+    // (device-parsed arrays: the sample's blocks summarised for the tables -- block b holds records [blockRecs[b] - blockRecs[0],
+    // blockRecs[b + 1] - blockRecs[0]) of recsV; pd_inflater_run_summarized)
+    const uint64_t * blockRecs = nullptr;
+    size_t nBlocks = 0;
+    const pd_block_summary * blockSums = nullptr;
+    const uint8_t * blockCounts = nullptr;
+    uint32_t startsRoom = 0, endsRoom = 0;
+    pd_inflater * inflater = nullptr;          // the inflater whose device buffers hold the same records, recsV[0] at index recBase
+    uint64_t recBase = 0;
     void viewOwn()
     {
         rawsV = raws.data();
@@ -180,7 +189,29 @@ struct alignas(64) DecodedStream      // (neighbours in the pool are filled by d
         countsV = nullptr;
         recsV = nullptr;
         nRecsV = 0;
+        blockRecs = nullptr;
+        nBlocks = 0;
+        blockSums = nullptr;
+        blockCounts = nullptr;
+        startsRoom = endsRoom = 0;
+        inflater = nullptr;
+        recBase = 0;
     }
+};
+
+// The sequential half of readSegment() as a loop that can be left and entered again: it runs until the stream is through or the
+// loader stops (finished, code), or -- a file with one read group -- until it has found the next RUN of records that are filed
+// one after the other with nothing in between (haveRun: records [runFirst, runFirst + runCount) of the stream), which the caller
+// files before it lets the loop go on (CallRun::fileRun: from the blocks' summaries where the device took them).
+struct ReplayState
+{
+    size_t   rawIdx = 0;
+    uint32_t wi = 0;
+    bool     inRaw = false, onRoiContig = false;
+    bool     finished = false;
+    unsigned code = 0;
+    bool     haveRun = false;
+    uint32_t runFirst = 0, runCount = 0;
 };
 
 // The loader's blocks on the device (round 4). Which samples read in a round, from where and up to where is known when the
@@ -203,6 +234,7 @@ public:
         int32_t beginPos = 0, endPos = 0;
         bool parse = false;             // one read group: the device parses the blocks as well
         uint32_t firstRegion = 0;       // beginPos / the file's index region size: what the index jump depends on
+        int32_t innerOffset = 0;        // parse: median - 2 * read length of that read group (a pair ends at position + max(0, deviation + this))
     };
     struct Ready
     {
@@ -219,6 +251,15 @@ public:
         const uint32_t * counts = nullptr;
         const PairRecord * recs = nullptr;
         size_t nRecs = 0;
+        // ... and the blocks summarised for the tables (block b of the sample: records [blockRecs[b], blockRecs[b + 1]) of the
+        // chunk's records array, recs[0] being record blockRecs[0])
+        const uint64_t * blockRecs = nullptr;
+        size_t nBlocks = 0;
+        const pd_block_summary * blockSums = nullptr;
+        const uint8_t * blockCounts = nullptr;
+        uint32_t startsRoom = 0, endsRoom = 0;
+        pd_inflater * inflater = nullptr;           // whose device buffers hold the records as well (recs[0] = record recBase there)
+        uint64_t recBase = 0;
         // (adopt(): the reader's jump lands `skip` index regions behind the guess -> its stream begins at a later block)
         const uint64_t * rawsByBlock = nullptr;      // first 256-bp window of each of the sample's blocks (and one past)
         const uint64_t * bytesByBlock = nullptr;     // first inflated byte of each
@@ -402,6 +443,9 @@ public:
     double kernelMs = 0, gatherSeconds = 0, runSeconds = 0, waitSeconds = 0;      // (waitSeconds: summed over the decoder threads)
     uint64_t members = 0, compressedBytes = 0, inflatedBytes = 0, samplesServed = 0, samplesLeft = 0, samplesParsed = 0;
     bool parseOnDevice_ = true;         // POPDEL_HOST_PARSE=1: the device inflates, the host parses
+    // the parsed blocks summarised for the tables as well (CallRun: runs filed from summaries), with this much room per block
+    bool summariesWanted = false;
+    uint32_t startsRoom = 0, endsRoom = 0;
     std::vector<int> fds_;              // descriptorOf()
 
 private:
@@ -415,6 +459,7 @@ private:
         std::vector<uint64_t> inOff, outOff;
         std::vector<uint32_t> firstMember, sampleFirst;
         std::vector<uint8_t> parseMember;
+        std::vector<int32_t> innerOffset;       // per member: median - 2 * read length of its (one) read group (block summaries)
         uint64_t bytes = 0;
         double seconds = 0;
     };
@@ -612,6 +657,7 @@ private:
                     outOff.push_back(outOff.back() + isize);
                     j.sampleFirst.push_back(firstMember[k]);
                     j.parseMember.push_back(items_[lo + k].parse && parseOnDevice_ ? 1 : 0);
+                    j.innerOffset.push_back(items_[lo + k].innerOffset);
                 }
             }
             if (!fine)
@@ -621,6 +667,7 @@ private:
                 inOff.resize(firstMember[k]);
                 j.sampleFirst.resize(firstMember[k]);
                 j.parseMember.resize(firstMember[k]);
+                j.innerOffset.resize(firstMember[k]);
                 good[k] = 0;
             }
             else
@@ -651,8 +698,17 @@ private:
         double ms = 0;
         pd_parsed_blocks pb;
         std::memset(&pb, 0, sizeof(pb));
-        if (pd_inflater_run_parsed(inf, j.inOff.data(), static_cast<uint32_t>(j.inOff.size() - 1), j.outOff.data(), j.sampleFirst.data(),
-                                   j.parseMember.data(), &out, &status, &lengths, &pb, &ms) != 0)
+        pd_block_summaries sums;
+        std::memset(&sums, 0, sizeof(sums));
+        const bool haveSums = summariesWanted && parseOnDevice_;
+        if (haveSums)
+        {
+            if (pd_inflater_run_summarized(inf, j.inOff.data(), static_cast<uint32_t>(j.inOff.size() - 1), j.outOff.data(), j.sampleFirst.data(),
+                                           j.parseMember.data(), j.innerOffset.data(), startsRoom, endsRoom, &out, &status, &lengths, &pb, &sums, &ms) != 0)
+                throw ProfileError("pd_inflater_run_summarized failed");
+        }
+        else if (pd_inflater_run_parsed(inf, j.inOff.data(), static_cast<uint32_t>(j.inOff.size() - 1), j.outOff.data(), j.sampleFirst.data(),
+                                        j.parseMember.data(), &out, &status, &lengths, &pb, &ms) != 0)
             throw ProfileError("pd_inflater_run_parsed failed");
         const double t2 = PhaseClock::now();
         std::lock_guard<std::mutex> lock(m_);           // (the counters below; ready_[] of this chunk is read once done_ says so)
@@ -694,6 +750,17 @@ private:
                 r.counts = pb.call_window_records + pb.call_window_offsets[m0];
                 r.recs = static_cast<const PairRecord *>(pb.records) + pb.record_offsets[m0];
                 r.nRecs = static_cast<size_t>(pb.record_offsets[m1] - pb.record_offsets[m0]);
+                r.inflater = inf;
+                r.recBase = pb.record_offsets[m0];
+                if (haveSums)
+                {
+                    r.blockRecs = pb.record_offsets + m0;
+                    r.nBlocks = m1 - m0;
+                    r.blockSums = sums.block_summaries + m0;
+                    r.blockCounts = sums.block_counts + static_cast<size_t>(m0) * (sums.starts_room + sums.ends_room);
+                    r.startsRoom = sums.starts_room;
+                    r.endsRoom = sums.ends_room;
+                }
                 ++samplesParsed;
             }
             r.usable = r.parsed || r.bytesValid;
@@ -790,16 +857,21 @@ public:
             }
             if (!ctxs_.empty() && ctxs_[0])
             {
-                uint64_t gathered = 0, staged = 0, locked = 0, g = 0, st = 0;
+                uint64_t gathered = 0, staged = 0, locked = 0, g = 0, st = 0, fromDevice = 0, fd = 0;
                 for (pd_ctx * c : ctxs_)
                     if (c && pd_walk_entry_counts(c, &g, &st, &locked) == 0)
                     {
                         gathered += g;
                         staged += st;
+                        if (pd_walk_source_counts(c, &fd) == 0)
+                            fromDevice += fd;
                     }
-                std::cerr << "[popdel timing] start entries of the window loop: " << gathered << " fetched by the device from the tables themselves ("
+                std::cerr << "[popdel timing] start entries of the window loop: " << fromDevice << " taken from the loader's records on the device, " << gathered << " fetched by the device from the tables themselves ("
                           << locked << " bytes of the table pool page-locked), " << staged << " copied by the host threads first" << std::endl;
             }
+            std::cerr << "[popdel timing] filing: " << filedRecords_.load() << " records of one-read-group files filed in runs, " << bulkRecords_.load()
+                      << " of them from the device's block summaries (" << bulkRuns_.load() << " runs; " << bulkRefused_.load()
+                      << " refused by the tables, " << bulkNone_.load() << " without enough usable blocks)" << std::endl;
             std::cerr << "[popdel timing] parity: " << nearIntegerShifts_ << " reference-shift quotients within 1e-9 of an integer (their truncation "
                          "may differ from the x87 reference's) in " << candidateCells_ << " candidate cells, " << windowCalls_ << " window calls" << std::endl;
             // steady state: the rounds that began after the backend was up, to the end of the loop (last results written)
@@ -859,6 +931,32 @@ private:
     void decodeSample(unsigned i, const std::string & coordContig, unsigned border, unsigned numWindows, DecodedStream & out) const;
     unsigned replaySegment(const DecodedStream & in, const std::string & fileName, const std::vector<unsigned> & rg,
                            const std::vector<std::string> & contigNames, Coord & coordinate, const Region & roi, unsigned * border);
+    bool replayAdvance(ReplayState & st, const DecodedStream & in, const std::string & fileName, const std::vector<unsigned> & rg,
+                       const std::vector<std::string> & contigNames, Coord & coordinate, const Region & roi, unsigned * border);
+    // runs filed from the summaries the device takes of the parsed blocks (round 6)
+    void fileRun(unsigned sample, const DecodedStream & in, const ReplayState & st);
+    int32_t innerOffsetOf(unsigned sample) const
+    {
+        const InsertHistogram & h = p_.histograms[p_.rgs[sample][0]];
+        return static_cast<int32_t>(h.median) - 2 * static_cast<int32_t>(h.readLength);
+    }
+    static constexpr uint32_t kBulkHead = 64;       // records filed one by one ahead of the summarised blocks: the end table's counting cursor comes home
+    static constexpr uint32_t kBulkLeast = 256;     // fewer records are not worth it
+    bool bulkFiling_ = false;                       // light tables, the device parses the blocks, POPDEL_HOST_FILING not set
+    uint32_t bulkRoom_ = 0;                         // windows a run's counts may span (a slot's worth and some)
+    std::atomic<uint64_t> bulkRuns_{0}, bulkRecords_{0}, bulkRefused_{0}, bulkNone_{0}, filedRecords_{0};
+    // Where the content of a read group's start slot lies on the device as well: the one run of device-parsed records that was
+    // filed into it, none dropped (fileRun). Handed to the window loop with the table (pd_walk_source): the device copies the
+    // entries from the loader's records there instead of reading the table over the link. A loader must not start on new blocks
+    // before the segment that points into its records has been handed over (loaderJob_, startLoaderAhead()).
+    std::vector<pd_walk_source> slotSource_;
+    std::vector<uint32_t> slotSourceCount_;
+    uint64_t loaderJob_[2] = {0, 0};            // per loader: the newest hand-over job that points into its inflaters' records
+    bool handedOver(uint64_t seq)
+    {
+        std::lock_guard<std::mutex> lock(handOverLock_);
+        return handOverFinished_ >= seq || handOverError_;
+    }
     bool processSegmentCode(unsigned i, unsigned code);
     void processSegment();
     void flushPending();
@@ -953,6 +1051,7 @@ private:
     {
         std::vector<uint32_t> counts, borders, idOffsets;
         std::vector<const pd_walk_entry *> tables;
+        std::vector<pd_walk_source> sources;        // (empty: none) where the entries lie on the device as well
         HugeVector<pd_walk_entry> copy;             // (empty: the tables point into the slot tables)
         std::vector<uint8_t> equalRun, switches;
         WalkShape shape;
@@ -1325,6 +1424,7 @@ void CallRun::startGunzipPrefetch()
         GunzipPrefetch::Item it;
         it.sample = i;
         it.parse = p_.rgs[i].size() == 1;
+        it.innerOffset = innerOffsetOf(i);
         it.beginPos = roi.beginPos;
         it.firstRegion = static_cast<uint32_t>(roi.beginPos) / p_.indexRegionSizes[p_.representativeContigs ? 0 : i];
         // (the decoder stops at the first window at or beyond the border; 256-bp windows may begin up to 255 bp before it)
@@ -1363,6 +1463,7 @@ void CallRun::startGunzipPrefetch()
     if (current < 0 && !items.empty())
     {
         current = ahead >= 0 ? 1 - ahead : 0;
+        waitForHandOver(loaderJob_[current]);       // (no segment may still point into that loader's records on the device)
         gunzipSet_[current]->start(items, roi.seqName);
         ++roundsOnDemand_;
     }
@@ -1388,6 +1489,7 @@ void CallRun::startGunzipPrefetch()
         GunzipPrefetch::Item it;
         it.sample = i;
         it.parse = p_.rgs[i].size() == 1;
+        it.innerOffset = innerOffsetOf(i);
         it.beginPos = static_cast<int32_t>(nextBegin);
         it.firstRegion = static_cast<uint32_t>(nextBegin) / p_.indexRegionSizes[p_.representativeContigs ? 0 : i];
         it.endPos = static_cast<int32_t>(nextEnd);
@@ -1414,6 +1516,15 @@ void CallRun::createLoaders()
     {
         g.reset(new GunzipPrefetch(p_, gunzipDevices_, first));
         first += GunzipPrefetch::kInflaters;
+        // (the parsed blocks summarised for the tables: whenever the tables can make use of it -- light end tables, which go with
+        // the device's window loop; a block spans one index region, its pairs end a little further on)
+        uint32_t region = 0;
+        for (uint32_t r : p_.indexRegionSizes)
+            region = std::max(region, r);
+        g->startsRoom = (region + 256u) / 30u + 3u;         // (a block's last 256-bp window may reach a window's length beyond its region)
+        g->endsRoom = g->startsRoom + 128u;
+        g->summariesWanted = deviceWalkOffered_ && !getenv("POPDEL_HEAVY_TABLES") && !getenv("POPDEL_HOST_FILING") && region != 0 &&
+                             g->startsRoom + g->endsRoom <= 12000u;
     }
     const char * ahead = getenv("POPDEL_LOADER_AHEAD");
     loaderAhead_ = !(ahead && ahead[0] == '0');
@@ -1424,6 +1535,8 @@ void CallRun::startLoaderAhead()
     // (not before the running round's loader is through: started at once, the two loaders share the device and the round
     // that is waited for gets its blocks later -- 0.064 instead of 0.061 s per warmed round)
     if (pendingGuess_.empty() || !gunzip_ || !gunzip_->allDone())
+        return;
+    if (!handedOver(loaderJob_[pendingGuessSet_]))      // (a segment still points into that loader's records on the device: at the next call)
         return;
     gunzipAhead_ = pendingGuessSet_;
     gunzipSet_[gunzipAhead_]->start(std::move(pendingGuess_), pendingGuessContig_);
@@ -1537,6 +1650,14 @@ void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned
             out.countsV = pre->counts;
             out.recsV = pre->recs;
             out.nRecsV = pre->nRecs;
+            out.blockRecs = pre->blockRecs;
+            out.nBlocks = pre->nBlocks;
+            out.blockSums = pre->blockSums;
+            out.blockCounts = pre->blockCounts;
+            out.startsRoom = pre->startsRoom;
+            out.endsRoom = pre->endsRoom;
+            out.inflater = pre->inflater;
+            out.recBase = pre->recBase;
             return;
         }
         ++hostDecodes_[1];
@@ -1614,98 +1735,316 @@ void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned
     }
 }
 
-// Sequential half of readSegment(): same decisions, same order, fed from a decoded stream.
-unsigned CallRun::replaySegment(const DecodedStream & in, const std::string & fileName, const std::vector<unsigned> & rg,
-                                const std::vector<std::string> & contigNames, Coord & coordinate, const Region & roi, unsigned * border)
+// Sequential half of readSegment(): same decisions, same order, fed from a decoded stream. Returns true with st.haveRun set when a
+// run of records of a one-read-group file is to be filed (fileRun()), false when the loop is over (st.code says how).
+bool CallRun::replayAdvance(ReplayState & st, const DecodedStream & in, const std::string & fileName, const std::vector<unsigned> & rg,
+                            const std::vector<std::string> & contigNames, Coord & coordinate, const Region & roi, unsigned * border)
 {
     ChromProfile & prof = *profile_;
     const bool oneRg = rg.size() == 1;
-    if (oneRg)
-        prof.reserveRun(rg[0], in.nRecsV);
-    for (size_t rawIdx = 0; rawIdx < in.nRawsV; ++rawIdx)
+    st.haveRun = false;
+    auto stop = [&](unsigned code) {
+        st.finished = true;
+        st.code = code;
+        return false;
+    };
+    while (!st.finished)
     {
-        const DecodedRaw & raw = in.rawsV[rawIdx];
-        if (contigNames[raw.chrom] != coordinate.contig)
+        if (!st.inRaw)
+        {
+            if (st.rawIdx >= in.nRawsV)
+            {
+                if (!in.eof)
+                    throw ProfileError("[PopDel] Internal error: decoded stream of \"" + fileName + "\" ended before the loader stopped.");
+                prof.performPartialSwitches(rg, border);
+                coordinate.contig = "";
+                coordinate.pos = kNoPos;
+                return stop(3);
+            }
+            const DecodedRaw & raw = in.rawsV[st.rawIdx];
+            if (contigNames[raw.chrom] != coordinate.contig)
+            {
+                prof.performPartialSwitches(rg, border);
+                coordinate.contig = contigNames[raw.chrom];
+                coordinate.pos = static_cast<unsigned>(raw.beginPos);
+                return stop(2);
+            }
+            if (raw.splitFailed)
+                throw ProfileError("[PopDel] Could not convert window at " + contigNames[raw.chrom] + ":" +
+                                   std::to_string(raw.beginPos) + ". The profile \"" + fileName + "\" might be corrupted.");
+            st.onRoiContig = contigNames[raw.chrom] == roi.seqName;         // (the 30-bp windows of a raw window share its contig)
+            st.wi = raw.firstWin;
+            st.inRaw = true;
+        }
+        const DecodedRaw & raw = in.rawsV[st.rawIdx];
+        const uint32_t wEnd = raw.firstWin + raw.nWin;
+        if (st.wi >= wEnd)
+        {
+            st.inRaw = false;
+            ++st.rawIdx;
+            continue;
+        }
+        const uint32_t wi = st.wi;
+        const FlatWindow & w = in.winsV[wi];
+        if (!st.onRoiContig || w.beginPos >= roi.endPos)
         {
             prof.performPartialSwitches(rg, border);
-            coordinate.contig = contigNames[raw.chrom];
-            coordinate.pos = static_cast<unsigned>(raw.beginPos);
-            return 2;
+            coordinate.contig = contigNames[w.chrom];
+            coordinate.pos = static_cast<unsigned>(w.beginPos);
+            return stop(2);
         }
-        if (raw.splitFailed)
-            throw ProfileError("[PopDel] Could not convert window at " + contigNames[raw.chrom] + ":" +
-                               std::to_string(raw.beginPos) + ". The profile \"" + fileName + "\" might be corrupted.");
-        const bool onRoiContig = contigNames[raw.chrom] == roi.seqName;         // (the 30-bp windows of a raw window share its contig)
-        const uint32_t wEnd = raw.firstWin + raw.nWin;
-        for (uint32_t wi = raw.firstWin; wi < wEnd; ++wi)
+        if (w.beginPos < roi.beginPos)
         {
-            const FlatWindow & w = in.winsV[wi];
-            if (!onRoiContig || w.beginPos >= roi.endPos)
+            ++st.wi;
+            continue;
+        }
+        if (prof.starts[rg[0]].tooBigForNext(static_cast<unsigned>(w.beginPos)))
+        {
+            if (prof.allEmpty())
+            {
+                prof.resetTo(static_cast<unsigned>(w.beginPos));
+            }
+            else
             {
                 prof.performPartialSwitches(rg, border);
                 coordinate.contig = contigNames[w.chrom];
                 coordinate.pos = static_cast<unsigned>(w.beginPos);
-                return 2;
-            }
-            if (w.beginPos < roi.beginPos)
-                continue;
-            if (prof.starts[rg[0]].tooBigForNext(static_cast<unsigned>(w.beginPos)))
-            {
-                if (prof.allEmpty())
-                {
-                    prof.resetTo(static_cast<unsigned>(w.beginPos));
-                }
-                else
-                {
-                    prof.performPartialSwitches(rg, border);
-                    coordinate.contig = contigNames[w.chrom];
-                    coordinate.pos = static_cast<unsigned>(w.beginPos);
-                    return 0;
-                }
-            }
-            else if (prof.starts[rg[0]].needsSwitch(static_cast<unsigned>(w.beginPos)))
-            {
-                prof.performPartialSwitches(rg, border);
-                coordinate.contig = contigNames[w.chrom];
-                coordinate.pos = static_cast<unsigned>(w.beginPos);
-                return 0;
-            }
-            // add all records of the window, read group by read group (load_profile_popdel_call.h:463-480)
-            static_assert(sizeof(PairRecord) == 2 * sizeof(uint32_t), "records are handed over as {pos, dev} words");
-            if (oneRg)
-            {
-                // ... and with it those of the windows behind it that the checks above let pass as well (they begin later,
-                // inside the region and before the write slot's border): their records follow in the stream, and filing
-                // them is the same sequence of operations
-                const StartSlots & st = prof.starts[rg[0]];
-                const unsigned right = st.slots[st.writeSlot].right;
-                uint32_t n = in.countsV[wi];
-                uint32_t wj = wi + 1;
-                for (; wj < wEnd && in.winsV[wj].beginPos < roi.endPos && static_cast<unsigned>(in.winsV[wj].beginPos) < right; ++wj)
-                    n += in.countsV[wj];
-                const InsertHistogram & h = p_.histograms[rg[0]];
-                prof.addRun(rg[0], reinterpret_cast<const uint32_t *>(in.recsV + w.firstRec), n,
-                            static_cast<int>(h.median) - 2 * static_cast<int>(h.readLength));
-                wi = wj - 1;
-                continue;
-            }
-            uint32_t r0 = w.firstRec;
-            for (size_t r = 0; r < rg.size(); ++r)
-            {
-                const uint32_t n = in.countsV[static_cast<size_t>(wi) * rg.size() + r];
-                const InsertHistogram & h = p_.histograms[rg[r]];
-                prof.addRun(rg[r], reinterpret_cast<const uint32_t *>(in.recsV + r0), n,
-                            static_cast<int>(h.median) - 2 * static_cast<int>(h.readLength));
-                r0 += n;
+                return stop(0);
             }
         }
+        else if (prof.starts[rg[0]].needsSwitch(static_cast<unsigned>(w.beginPos)))
+        {
+            prof.performPartialSwitches(rg, border);
+            coordinate.contig = contigNames[w.chrom];
+            coordinate.pos = static_cast<unsigned>(w.beginPos);
+            return stop(0);
+        }
+        // add all records of the window, read group by read group (load_profile_popdel_call.h:463-480)
+        static_assert(sizeof(PairRecord) == 2 * sizeof(uint32_t), "records are handed over as {pos, dev} words");
+        if (oneRg)
+        {
+            // ... and with it those of the windows behind it that the checks above let pass as well -- they begin inside the
+            // region and before the write slot's border, on the same contig, in this 256-bp window or the ones that follow: their
+            // records follow in the stream, and filing them is the same sequence of operations. (A 256-bp window whose first and
+            // last 30-bp windows pass is taken whole: its windows are in position order.)
+            const StartSlots & sst = prof.starts[rg[0]];
+            const unsigned right = sst.slots[sst.writeSlot].right;
+            auto passes = [&](const FlatWindow & x) {
+                return x.beginPos >= roi.beginPos && x.beginPos < roi.endPos && static_cast<unsigned>(x.beginPos) < right;
+            };
+            uint32_t wj = wi + 1;
+            size_t rj = st.rawIdx;
+            uint32_t endOfRaw = wEnd;
+            int32_t knownChrom = raw.chrom;         // (its name equals coordinate.contig and roi.seqName)
+            for (;;)
+            {
+                while (wj < endOfRaw && passes(in.winsV[wj]))
+                    ++wj;
+                if (wj < endOfRaw)
+                    break;
+                // the next 256-bp windows, whole ones first
+                bool more = false;
+                while (rj + 1 < in.nRawsV)
+                {
+                    const DecodedRaw & nx = in.rawsV[rj + 1];
+                    if (nx.splitFailed || nx.nWin == 0 || nx.firstWin != endOfRaw)
+                        break;
+                    if (nx.chrom != knownChrom)
+                    {
+                        if (contigNames[nx.chrom] != coordinate.contig || contigNames[nx.chrom] != roi.seqName)
+                            break;
+                        knownChrom = nx.chrom;
+                    }
+                    const FlatWindow & head = in.winsV[nx.firstWin], & tail = in.winsV[nx.firstWin + nx.nWin - 1];
+                    ++rj;
+                    endOfRaw = nx.firstWin + nx.nWin;
+                    if (passes(head) && passes(tail) && head.beginPos <= tail.beginPos)
+                    {
+                        wj = endOfRaw;
+                        continue;
+                    }
+                    wj = nx.firstWin;
+                    more = true;                    // (window by window through this one)
+                    break;
+                }
+                if (!more)
+                    break;
+            }
+            // the run's records: from this window's first to the last of the last window taken (windows wi .. wj - 1 follow each
+            // other in the stream, and so do their records)
+            const uint32_t firstRec = w.firstRec;
+            const uint32_t endRec = in.winsV[wj - 1].firstRec + in.countsV[wj - 1];
+            st.haveRun = true;
+            st.runFirst = firstRec;
+            st.runCount = endRec - firstRec;
+            // (the loop goes on at window wj of 256-bp window rj)
+            st.rawIdx = rj;
+            st.wi = wj;
+            st.inRaw = true;
+            return true;
+        }
+        uint32_t r0 = w.firstRec;
+        for (size_t r = 0; r < rg.size(); ++r)
+        {
+            const uint32_t n = in.countsV[static_cast<size_t>(wi) * rg.size() + r];
+            const InsertHistogram & h = p_.histograms[rg[r]];
+            prof.addRun(rg[r], reinterpret_cast<const uint32_t *>(in.recsV + r0), n,
+                        static_cast<int>(h.median) - 2 * static_cast<int>(h.readLength));
+            r0 += n;
+        }
+        ++st.wi;
     }
-    if (!in.eof)
-        throw ProfileError("[PopDel] Internal error: decoded stream of \"" + fileName + "\" ended before the loader stopped.");
-    prof.performPartialSwitches(rg, border);
-    coordinate.contig = "";
-    coordinate.pos = kNoPos;
-    return 3;
+    return false;
+}
+
+// The whole loop, every run filed record by record as it is found (batches that are replayed in order; the reference's sequence).
+unsigned CallRun::replaySegment(const DecodedStream & in, const std::string & fileName, const std::vector<unsigned> & rg,
+                                const std::vector<std::string> & contigNames, Coord & coordinate, const Region & roi, unsigned * border)
+{
+    ReplayState st;
+    if (rg.size() == 1)
+        profile_->reserveRun(rg[0], in.nRecsV);
+    while (replayAdvance(st, in, fileName, rg, contigNames, coordinate, roi, border))
+    {
+        slotSource_[rg[0]].inflater = nullptr;
+        const InsertHistogram & h = p_.histograms[rg[0]];
+        profile_->addRun(rg[0], reinterpret_cast<const uint32_t *>(in.recsV + st.runFirst), st.runCount,
+                         static_cast<int>(h.median) - 2 * static_cast<int>(h.readLength));
+    }
+    return st.code;
+}
+
+// One run of a one-read-group file into the tables. With the sample's blocks summarised by the device: a head of records one by
+// one (the blocks the run begins in the middle of, and at least kBulkHead records: the end table's counting cursor comes home to the
+// write slot), then every whole block whose pairs all end below the write slot's border at once -- their counts added up window
+// by window, ChromProfile::addBulk, which checks the rest and never reads a record --, then what is left record by record.
+void CallRun::fileRun(unsigned sample, const DecodedStream & in, const ReplayState & st)
+{
+    ChromProfile & prof = *profile_;
+    const unsigned rg = p_.rgs[sample][0];
+    const int inner = innerOffsetOf(sample);
+    const uint32_t * rec = reinterpret_cast<const uint32_t *>(in.recsV + st.runFirst);
+    const size_t n = st.runCount;
+    filedRecords_.fetch_add(n, std::memory_order_relaxed);
+    size_t done = 0;
+    const EndSlots & en = prof.ends[rg];
+    const StartSlots::Slot & target = prof.starts[rg].slots[prof.starts[rg].writeSlot];
+    const size_t heldBefore = target.entries.size();
+    if (bulkFiling_ && in.blockSums && en.light && n >= kBulkHead + kBulkLeast)
+    {
+        // the blocks that lie inside [runFirst + kBulkHead, runFirst + n), in record indices of the sample's stream
+        const uint64_t base = in.blockRecs[0];
+        const uint64_t lo = st.runFirst + kBulkHead, hi = static_cast<uint64_t>(st.runFirst) + n;
+        size_t j0 = static_cast<size_t>(std::lower_bound(in.blockRecs, in.blockRecs + in.nBlocks + 1, base + lo) - in.blockRecs);
+        const uint32_t borderBin = (en.slots[en.writeSlot].right + 29u) / 30u;
+        constexpr uint32_t kBad = RunSummary::kSaturated | RunSummary::kNoRoom;
+        RunSummary sum;
+        size_t j1 = j0;
+        uint32_t lastPos = 0, lastEnd = 0;
+        bool endsInOrder = true;
+        for (; j1 < in.nBlocks && in.blockRecs[j1 + 1] - base <= hi; ++j1)
+        {
+            const pd_block_summary & b = in.blockSums[j1];
+            if (b.n == 0)
+            {
+                if (in.blockRecs[j1 + 1] != in.blockRecs[j1])
+                    break;                      // (records the device did not summarise)
+                continue;
+            }
+            if ((b.flags & kBad) != 0 || !(b.flags & RunSummary::kStartsInOrder) || b.max_end_bin >= borderBin || b.n != in.blockRecs[j1 + 1] - in.blockRecs[j1])
+                break;
+            if (sum.n == 0)
+            {
+                sum.firstPos = b.first_pos;
+                sum.binBase = b.bin_base;
+                sum.firstEndBin = b.first_end_bin;
+                sum.minEndBin = b.min_end_bin;
+                sum.maxEndBin = b.max_end_bin;
+            }
+            else
+            {
+                if (b.first_pos < lastPos || b.bin_base < sum.binBase)
+                    break;                      // (positions step back between two blocks)
+                endsInOrder = endsInOrder && b.first_end_bin >= lastEnd;
+            }
+            if (std::max(b.max_end_bin, sum.maxEndBin) - sum.binBase >= bulkRoom_)
+                break;
+            sum.n += b.n;
+            sum.minEndBin = std::min(sum.minEndBin, b.min_end_bin);
+            sum.maxEndBin = std::max(sum.maxEndBin, b.max_end_bin);
+            endsInOrder = endsInOrder && (b.flags & RunSummary::kEndsInOrder) != 0;
+            lastPos = b.last_pos;
+            lastEnd = b.last_end_bin;
+        }
+        static const bool traceFiling = getenv("POPDEL_FILING_TRACE") != nullptr;
+        if (traceFiling && sample < 2)
+        {
+            std::ostringstream msg;
+            msg << "[popdel filing] sample " << sample << ": run of " << n << " records from " << st.runFirst << ", blocks " << in.nBlocks << ", first whole block " << j0
+                << ", taken up to " << j1 << " (" << sum.n << " records), border window " << borderBin;
+            if (j1 < in.nBlocks)
+            {
+                const pd_block_summary & b = in.blockSums[j1];
+                msg << "; block " << j1 << ": n " << b.n << " records " << in.blockRecs[j1] - base << ".." << in.blockRecs[j1 + 1] - base << " flags " << b.flags
+                    << " first " << b.first_pos << " last " << b.last_pos << " bin base " << b.bin_base << " end windows " << b.min_end_bin << ".." << b.max_end_bin;
+            }
+            std::cerr << msg.str() << std::endl;
+        }
+        if (sum.n >= kBulkLeast)
+        {
+            // the head: up to the first block taken
+            size_t first = j0;
+            while (in.blockSums[first].n == 0)
+                ++first;
+            const size_t headEnd = static_cast<size_t>(in.blockRecs[first] - base) - st.runFirst;
+            prof.reserveStarts(rg, n);
+            prof.addRun(rg, rec, headEnd, inner);
+            done = headEnd;
+            sum.lastPos = lastPos;
+            sum.lastEndBin = lastEnd;
+            sum.nBins = sum.maxEndBin - sum.binBase + 1u;
+            sum.flags = RunSummary::kStartsInOrder | (endsInOrder ? RunSummary::kEndsInOrder : 0u);
+            // the blocks' counts added up into one row of starts and one of ends (per thread: kept from run to run)
+            thread_local std::vector<uint16_t> rows;
+            rows.assign(2 * static_cast<size_t>(sum.nBins), 0);
+            uint16_t * starts = rows.data(), * ends = rows.data() + sum.nBins;
+            const size_t stride = static_cast<size_t>(in.startsRoom) + in.endsRoom;
+            for (size_t j = first; j < j1; ++j)
+            {
+                const pd_block_summary & b = in.blockSums[j];
+                if (b.n == 0)
+                    continue;
+                const uint8_t * cs = in.blockCounts + j * stride, * ce = cs + in.startsRoom;
+                const uint32_t off = b.bin_base - sum.binBase;
+                const uint32_t nStarts = b.last_pos / 30u - b.bin_base + 1u;
+                for (uint32_t w = 0; w < nStarts; ++w)
+                    starts[off + w] = static_cast<uint16_t>(starts[off + w] + cs[w]);
+                for (uint32_t w = b.min_end_bin - b.bin_base; w <= b.max_end_bin - b.bin_base; ++w)
+                    ends[off + w] = static_cast<uint16_t>(ends[off + w] + ce[w]);
+            }
+            if (prof.addBulk(rg, rec + 2 * done, sum, starts, ends, inner))
+            {
+                done += sum.n;
+                bulkRuns_.fetch_add(1, std::memory_order_relaxed);
+                bulkRecords_.fetch_add(sum.n, std::memory_order_relaxed);
+            }
+            else
+                bulkRefused_.fetch_add(1, std::memory_order_relaxed);
+        }
+        else
+            bulkNone_.fetch_add(1, std::memory_order_relaxed);
+    }
+    if (done == 0)
+        prof.reserveRun(rg, n);
+    prof.addRun(rg, rec + 2 * done, n - done, inner);
+    // (the slot holds exactly this run: the device has the same entries in the loader's records)
+    if (in.inflater && heldBefore == 0 && target.entries.size() == n)
+    {
+        slotSource_[rg] = pd_walk_source{in.inflater, in.recBase + st.runFirst};
+        slotSourceCount_[rg] = static_cast<uint32_t>(n);
+    }
+    else
+        slotSource_[rg].inflater = nullptr;
 }
 
 bool CallRun::processSegmentCode(unsigned i, unsigned code)
@@ -1983,7 +2322,9 @@ void CallRun::processSegment()
             if (pending_)                           // (a segment of the host's window loop is still out)
                 flushPending();
             waitForHandOver(lastDirectJob_);        // jobs that point into the tables: handed over before the next one is cut
+            gTrace.mark("segment: the previous one has been handed over");
             submitPlannedSegment(shape, equalRun, switches);
+            gTrace.mark("segment: queued");
             clock_.submit += PhaseClock::now() - t0;
             ++deviceSegments_;
             return;
@@ -2109,6 +2450,8 @@ void CallRun::submitPlannedSegment(const WalkShape & shape, const std::vector<ui
     const size_t nRg = prof.starts.size();
     std::vector<uint32_t> counts(nRg), borders(nRg), idOffsets(nRg);
     std::vector<const pd_walk_entry *> tables(nRg);
+    std::vector<pd_walk_source> sources(nRg, pd_walk_source{nullptr, 0});
+    bool anySource = false;
     static_assert(sizeof(StartEntry) == sizeof(pd_walk_entry), "the start tables are handed over as they are");
     for (size_t rg = 0; rg < nRg; ++rg)
     {
@@ -2118,6 +2461,12 @@ void CallRun::submitPlannedSegment(const WalkShape & shape, const std::vector<ui
         tables[rg] = reinterpret_cast<const pd_walk_entry *>(slot.entries.data());
         borders[rg] = slot.endBorder;
         idOffsets[rg] = slot.idOffset;
+        if (switches[rg] != 0 && slotSource_[rg].inflater && slotSourceCount_[rg] == counts[rg] && counts[rg] != 0 && gunzip_)
+        {
+            sources[rg] = slotSource_[rg];
+            anySource = true;
+        }
+        slotSource_[rg].inflater = nullptr;         // (the slot it described is the read slot now)
     }
     auto job = std::make_shared<HandOverJob>();
     job->equalRun = equalRun;
@@ -2143,6 +2492,8 @@ void CallRun::submitPlannedSegment(const WalkShape & shape, const std::vector<ui
     job->borders = std::move(borders);
     job->idOffsets = std::move(idOffsets);
     job->tables = std::move(tables);
+    if (anySource && job->copy.empty())
+        job->sources = std::move(sources);
     {
         std::unique_lock<std::mutex> lock(handOverLock_);
         if (handOverError_)
@@ -2162,6 +2513,8 @@ void CallRun::submitPlannedSegment(const WalkShape & shape, const std::vector<ui
         job->seq = ++handOverEnqueued_;
         if (job->copy.empty())
             lastDirectJob_ = job->seq;
+        if (!job->sources.empty() && gunzip_)
+            loaderJob_[gunzip_ == gunzipSet_[0].get() ? 0 : 1] = job->seq;
         handOverQueue_.push_back(job);
         handOverIdle_ = false;
         if (!handOverThread_.joinable())
@@ -2300,6 +2653,7 @@ void CallRun::handOver(HandOverJob & job)
         wk.id_offset = job.idOffsets.data() + g0;
         wk.switches = job.switches.data() + g0;
         wk.equal_run = job.equalRun.data() + g0;
+        wk.rg_sources = job.sources.empty() ? nullptr : job.sources.data() + g0;
         if (pd_walk_submit(ctxs_[r], &wk, &workerTickets_[r]) != 0)
             throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
     });
@@ -2669,6 +3023,12 @@ int CallRun::run()
     lightTables_ = !getenv("POPDEL_HEAVY_TABLES");
     if (deviceWalk_ && lightTables_)
         profile_->setLightEnds(true);
+    // (runs of device-parsed records are filed from summaries the device takes: ChromProfile::addBulk; POPDEL_HOST_FILING=1
+    // files every record on the host as rounds 4-5 did -- A/B runs, tests)
+    slotSource_.assign(p_.readGroups.size(), pd_walk_source{nullptr, 0});
+    slotSourceCount_.assign(p_.readGroups.size(), 0);
+    bulkRoom_ = p_.windowBuffer / 30u + 512u;
+    bulkFiling_ = deviceWalk_ && lightTables_ && !getenv("POPDEL_HOST_FILING");
     if (getenv("POPDEL_WALK_CHECK"))
         walkCheck_.reset(new WalkReference(static_cast<unsigned>(p_.readGroups.size())));
     profile_->externalActive = [this]() -> size_t {
@@ -2792,21 +3152,31 @@ int CallRun::run()
             std::vector<unsigned> codes(readers.size(), 0);
             std::fill(border.begin(), border.end(), kNoBorder);
             border.resize(readers.size(), kNoBorder);
-            auto replayOne = [&](size_t k, unsigned * borderOut) {
-                const unsigned i = readers[k];
-                const unsigned contigIdx = p_.representativeContigs ? 0 : i;
-                codes[k] = replaySegment(decoded[k], p_.inputFiles[i], p_.rgs[i], p_.contigNames[contigIdx], nextCandidate_[i],
-                                         p_.allRois[p_.nextRoi], borderOut);
-            };
             ++(ordered ? clock_.orderedBatches : clock_.parallelBatches);
             if (ordered)
             {
                 for (size_t k = 0; k < readers.size(); ++k)
-                    replayOne(k, nullptr);
+                {
+                    const unsigned i = readers[k];
+                    const unsigned contigIdx = p_.representativeContigs ? 0 : i;
+                    codes[k] = replaySegment(decoded[k], p_.inputFiles[i], p_.rgs[i], p_.contigNames[contigIdx], nextCandidate_[i],
+                                             p_.allRois[p_.nextRoi], nullptr);
+                }
             }
             else
             {
-                parallelFor(readers.size(), [&](size_t k) { replayOne(k, &border[k]); }, 8);   // blocks of neighbours: the per-read-group tables of adjacent samples share cache lines
+                // (round 6: a one-read-group sample's records are filed run by run -- a run is what the loop files with nothing in
+                // between, as a rule everything a round reads -- from the summaries the device took of its blocks where the tables
+                // allow it: replayAdvance / fileRun)
+                parallelFor(readers.size(), [&](size_t k) {     // blocks of neighbours: the per-read-group tables of adjacent samples share cache lines
+                    const unsigned i = readers[k];
+                    const unsigned contigIdx = p_.representativeContigs ? 0 : i;
+                    ReplayState st;
+                    while (replayAdvance(st, decoded[k], p_.inputFiles[i], p_.rgs[i], p_.contigNames[contigIdx], nextCandidate_[i],
+                                         p_.allRois[p_.nextRoi], &border[k]))
+                        fileRun(i, decoded[k], st);
+                    codes[k] = st.code;
+                }, 8);
                 for (size_t k = 0; k < readers.size(); ++k)
                     if (border[k] != kNoBorder)
                         profile_->currentRightBorder = border[k];

@@ -510,6 +510,13 @@ void ChromProfile::reserveRun(unsigned rg, size_t n)
         e.reserve(std::max(e.size() + n + n / 4, e.capacity() + e.capacity() / 2));
 }
 
+void ChromProfile::reserveStarts(unsigned rg, size_t n)
+{
+    HugeVector<StartEntry> & s = starts[rg].slots[starts[rg].writeSlot].entries;
+    if (s.capacity() < s.size() + n)
+        s.reserve(std::max(s.size() + n + n / 4, s.capacity() + s.capacity() / 2));
+}
+
 void ChromProfile::addRun(unsigned rg, const uint32_t * posDev, size_t n, int innerOffset)
 {
     StartSlots & st = starts[rg];
@@ -645,8 +652,8 @@ void ChromProfile::addRun(unsigned rg, const uint32_t * posDev, size_t n, int in
     activeLoad[rg] = load;
 }
 
-void summarizeRun(const uint32_t * posDev, size_t nRecords, int innerOffset, uint32_t borderBin, uint32_t room, RunSummary & out,
-                  uint8_t * starts, uint8_t * ends)
+void summarizeRun(const uint32_t * posDev, size_t nRecords, int innerOffset, uint32_t borderBin, uint32_t roomStarts, uint32_t roomEnds,
+                  RunSummary & out, uint8_t * starts, uint8_t * ends)
 {
     out = RunSummary();
     if (nRecords == 0)
@@ -669,8 +676,8 @@ void summarizeRun(const uint32_t * posDev, size_t nRecords, int innerOffset, uin
     out.minEndBin = 0xffffffffu;
     out.maxEndBin = 0;
     out.flags = RunSummary::kStartsInOrder | RunSummary::kEndsInOrder;
-    std::fill(starts, starts + room, static_cast<uint8_t>(0));
-    std::fill(ends, ends + room, static_cast<uint8_t>(0));
+    std::fill(starts, starts + roomStarts, static_cast<uint8_t>(0));
+    std::fill(ends, ends + roomEnds, static_cast<uint8_t>(0));
     uint32_t prevPos = out.firstPos, prevEnd = out.firstEndBin;
     for (size_t i = 0; i < n; ++i)
     {
@@ -684,7 +691,7 @@ void summarizeRun(const uint32_t * posDev, size_t nRecords, int innerOffset, uin
         out.minEndBin = std::min(out.minEndBin, eb);
         out.maxEndBin = std::max(out.maxEndBin, eb);
         // (a start below the first one's window, or windows beyond the room: flagged, the counts are not used then)
-        if (sb < out.binBase || sb - out.binBase >= room || eb < out.binBase || eb - out.binBase >= room)
+        if (sb < out.binBase || sb - out.binBase >= roomStarts || eb < out.binBase || eb - out.binBase >= roomEnds)
         {
             out.flags |= RunSummary::kNoRoom;
             continue;
@@ -700,12 +707,15 @@ void summarizeRun(const uint32_t * posDev, size_t nRecords, int innerOffset, uin
     }
     // (a count that reached 255 may have missed records: saturated either way)
     out.nBins = (out.flags & RunSummary::kNoRoom) ? 0u : out.maxEndBin - out.binBase + 1u;
-    for (uint32_t b = 0; b < out.nBins; ++b)
-        if (starts[b] == 255u || ends[b] == 255u)
+    for (uint32_t b = 0; b < roomStarts; ++b)
+        if (starts[b] == 255u)
+            out.flags |= RunSummary::kSaturated;
+    for (uint32_t b = 0; b < roomEnds; ++b)
+        if (ends[b] == 255u)
             out.flags |= RunSummary::kSaturated;
 }
 
-bool ChromProfile::addBulk(unsigned rg, const uint32_t * posDev, const RunSummary & s, const uint8_t * startCounts, const uint8_t * endCounts,
+bool ChromProfile::addBulk(unsigned rg, const uint32_t * posDev, const RunSummary & s, const uint16_t * startCounts, const uint16_t * endCounts,
                            int innerOffset)
 {
     StartSlots & st = starts[rg];
@@ -734,8 +744,11 @@ bool ChromProfile::addBulk(unsigned rg, const uint32_t * posDev, const RunSummar
     if (s.maxEndBin >= borderBin || s.minEndBin < base || s.maxEndBin - base >= slot.hist.size() || s.minEndBin < s.binBase ||
         s.maxEndBin - s.binBase >= s.nBins)
         return false;
-    if (slot.peak >= 0xffffu - 256u)            // (no count of the slot may saturate: each takes at most 255 more)
+    if (slot.peak >= 0x8000u)                   // (no count of the slot may saturate: checked count by count below)
         return false;
+    for (unsigned b = s.minEndBin; b <= s.maxEndBin; ++b)
+        if (endCounts[b - s.binBase] >= 0x7fffu)
+            return false;
     // ---- the load behind every record, window by window: behind the last record that begins in window b the counting cursor
     // stands at max(where it stood, entries of the slot that end before b) -- the records of the run that end before b began
     // before b, so they are filed by then -- and the load is what it was, plus the records filed, minus the cursor's way

@@ -333,26 +333,26 @@ private:
     void leaveLight();
 };
 
-// ---- a run of records summarised (round 6: filing without looking at the records) ------------------------------------------
-// What ChromProfile::addBulk() needs to know about records [0, n) of a run -- {position, deviation} pairs of one read group in
-// the order the reader delivers them -- instead of the records: how many begin and how many END in each 30-bp window
-// (counts[0][b], counts[1][b] for window binBase + b, one byte each, 255 = saturated), the extremes, and whether positions and
-// last windows come in non-decreasing order. The device computes it where the records were parsed (inflate.hip,
-// pd_inflater_summarize); summarizeRun() is the same on the host (tests, and the yardstick of the kernel).
+// ---- records summarised (round 6: filing without looking at the records) ---------------------------------------------------
+// What ChromProfile::addBulk() needs to know about a run of records -- {position, deviation} pairs of one read group in the order
+// the reader delivers them -- instead of the records: how many begin and how many END in each 30-bp window (window binBase + b),
+// the extremes, and whether positions and last windows come in non-decreasing order. The device computes it per profile block
+// where the records were parsed (inflate.hip, pd_inflater_run_summarized: one byte per window, 255 = saturated); the driver adds
+// the blocks of a run up (CallRun::fileRun); summarizeRun() is the kernel's computation on the host (tests, its yardstick).
 struct RunSummary
 {
-    uint32_t n = 0;                     // records covered: the longest prefix of the run whose pairs all end below the border
+    uint32_t n = 0;                     // records covered
     uint32_t firstPos = 0, lastPos = 0; // start positions of the first and the last of them
-    uint32_t binBase = 0;               // window (position / 30) of counts[.][0] = window of firstPos
-    uint32_t nBins = 0;                 // windows the counts cover (the last end window is binBase + nBins - 1)
+    uint32_t binBase = 0;               // window (position / 30) of the counts' first entry = window of firstPos
+    uint32_t nBins = 0;                 // windows up to the last end window: binBase + nBins - 1
     uint32_t minEndBin = 0, maxEndBin = 0, firstEndBin = 0, lastEndBin = 0;     // absolute window numbers
     uint32_t flags = 0;
     static constexpr uint32_t kStartsInOrder = 1u, kEndsInOrder = 2u, kSaturated = 4u, kNoRoom = 8u;
 };
-// records {pos, dev} x nRecords, end position = pos + max(0, dev + innerOffset); the prefix ends ahead of the first record whose
-// last window lies at or beyond window `borderBin`; starts[] / ends[] have room for `room` windows
-void summarizeRun(const uint32_t * posDev, size_t nRecords, int innerOffset, uint32_t borderBin, uint32_t room, RunSummary & out,
-                  uint8_t * starts, uint8_t * ends);
+// records {pos, dev} x nRecords, end position = pos + max(0, dev + innerOffset); covered is the longest prefix whose pairs all
+// have their last window below `borderBin`; starts[] has room for `roomStarts` windows, ends[] for `roomEnds`
+void summarizeRun(const uint32_t * posDev, size_t nRecords, int innerOffset, uint32_t borderBin, uint32_t roomStarts, uint32_t roomEnds,
+                  RunSummary & out, uint8_t * starts, uint8_t * ends);
 
 // ---- the window loop in closed form -----------------------------------------------------------------------------------
 // What the loop of processSegment() -- one extra step of nextWindow(), initializeActive(), then the walk -- does to a read
@@ -406,10 +406,12 @@ public:
     // counts: exact, not a bound) -- and if so files them at once: the same tables, cursors and load as addRun() leaves, the end
     // entries remembered as a reference to the start entries (EndSlots::Deferred). Returns false, with nothing changed, if any of
     // it does not hold: the caller then files the records with addRun().
-    bool addBulk(unsigned rg, const uint32_t * posDev, const RunSummary & s, const uint8_t * startCounts, const uint8_t * endCounts,
+    bool addBulk(unsigned rg, const uint32_t * posDev, const RunSummary & s, const uint16_t * startCounts, const uint16_t * endCounts,
                  int innerOffset);
     // room for n more records in the slots being written (one allocation instead of the doublings of push_back)
     void reserveRun(unsigned rg, size_t n);
+    // ... for a run that will mostly be filed from its summary (addBulk): the start slot takes every record, the end slot a few
+    void reserveStarts(unsigned rg, size_t n);
     void initializeActive();
     bool nextWindow(unsigned shift);
     void resetTo(unsigned pos);

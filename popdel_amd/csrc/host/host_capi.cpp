@@ -465,14 +465,16 @@ int pdh_bench_filing_ex(unsigned rounds, int light, unsigned maxLoad, unsigned s
                 const uint32_t borderBin = (en.slots[en.writeSlot].right + 29u) / 30u;
                 const uint32_t room = buffer / 30u + 512u;
                 static std::vector<uint8_t> counts;
+                static std::vector<uint16_t> wide;
                 counts.resize(2 * static_cast<size_t>(room));
                 pdh::RunSummary sum;
                 const auto s0 = std::chrono::steady_clock::now();
-                pdh::summarizeRun(rec.data() + 2 * done, n - done, 500 - 300, borderBin, room, sum, counts.data(), counts.data() + room);
+                pdh::summarizeRun(rec.data() + 2 * done, n - done, 500 - 300, borderBin, room, room, sum, counts.data(), counts.data() + room);
+                wide.assign(counts.begin(), counts.end());
                 total -= std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count();     // (the device's work in the product)
                 if (light == 3)
                     sum.n = 0;
-                if (sum.n >= 16 && prof.addBulk(0, rec.data() + 2 * done, sum, counts.data(), counts.data() + room, 500 - 300))
+                if (sum.n >= 16 && prof.addBulk(0, rec.data() + 2 * done, sum, wide.data(), wide.data() + room, 500 - 300))
                 {
                     done += sum.n;
                     ++g_bulkRuns;
@@ -531,16 +533,16 @@ int pdh_bench_filing_ex(unsigned rounds, int light, unsigned maxLoad, unsigned s
 }  // extern "C"
 
 extern "C" {
-// pdh::summarizeRun() for the tests: what the device's summarizeRunsKernel (pd_inflater_summarize) must reproduce. `summary`: the ten
-// words of pd_run_summary / pdh::RunSummary; `counts`: 2 * room bytes (records that begin / end per window).
-int pdh_summarize_run(const uint32_t * posDev, uint64_t nRecords, int innerOffset, uint32_t borderBin, uint32_t room, uint32_t * summary,
-                      uint8_t * counts)
+// pdh::summarizeRun() for the tests: what the device's summarizeBlocksKernel (pd_inflater_run_summarized) must reproduce per block.
+// `summary`: the ten words of pd_block_summary / pdh::RunSummary; `counts`: roomStarts + roomEnds bytes (records that begin / end per window).
+int pdh_summarize_run(const uint32_t * posDev, uint64_t nRecords, int innerOffset, uint32_t borderBin, uint32_t roomStarts, uint32_t roomEnds,
+                      uint32_t * summary, uint8_t * counts)
 {
-    if (!posDev || !summary || !counts || room == 0)
+    if (!posDev || !summary || !counts || roomStarts == 0 || roomEnds == 0)
         return 1;
     static_assert(sizeof(pdh::RunSummary) == 10 * sizeof(uint32_t), "RunSummary is pd_run_summary");
     pdh::RunSummary s;
-    pdh::summarizeRun(posDev, static_cast<size_t>(nRecords), innerOffset, borderBin, room, s, counts, counts + room);
+    pdh::summarizeRun(posDev, static_cast<size_t>(nRecords), innerOffset, borderBin, roomStarts, roomEnds, s, counts, counts + roomStarts);
     std::memcpy(summary, &s, sizeof(s));
     return 0;
 }

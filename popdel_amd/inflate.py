@@ -112,35 +112,36 @@ class PdParsedBlocks(C.Structure):
                 ("block_flags", C.POINTER(C.c_uint32)), ("bytes_copied", C.c_uint32)]
 
 
-class PdRunRequest(C.Structure):
-    _fields_ = [("first_record", C.c_uint64), ("n_records", C.c_uint32), ("inner_offset", C.c_int32), ("border_window", C.c_uint32),
-                ("reserved", C.c_uint32)]
-
-
 SUMMARY_FIELDS = ("n", "first_pos", "last_pos", "bin_base", "n_bins", "min_end_bin", "max_end_bin", "first_end_bin", "last_end_bin", "flags")
 
 
-def summarize_host(records, first, n, inner_offset, border_window, room):
-    """pdh::summarizeRun (chrom_profile.cpp) on records[first : first + n] ({pos, dev} rows). Returns (summary dict, counts uint8[2, room])."""
+class PdBlockSummaries(C.Structure):
+    _fields_ = [("block_summaries", C.POINTER(C.c_uint32)), ("block_counts", C.POINTER(C.c_uint8)), ("starts_room", C.c_uint32),
+                ("ends_room", C.c_uint32)]
+
+
+def summarize_host(records, first, n, inner_offset, border_window, starts_room, ends_room):
+    """pdh::summarizeRun (chrom_profile.cpp) on records[first : first + n] ({pos, dev} rows). Returns (summary dict, counts
+    uint8[starts_room + ends_room]: records that begin / end per window)."""
     rec = np.ascontiguousarray(records[first: first + n], dtype=np.uint32)
     if len(rec) == 0:
         rec = np.zeros((1, 2), np.uint32)
     summary = np.zeros(10, np.uint32)
-    counts = np.zeros((2, room), np.uint8)
+    counts = np.zeros(starts_room + ends_room, np.uint8)
     lib = _host()
     lib.pdh_summarize_run.restype = C.c_int
-    if lib.pdh_summarize_run(_ptr(rec, C.c_uint32), C.c_uint64(n), C.c_int(inner_offset), C.c_uint32(border_window), C.c_uint32(room),
-                             _ptr(summary, C.c_uint32), _ptr(counts, C.c_uint8)) != 0:
+    if lib.pdh_summarize_run(_ptr(rec, C.c_uint32), C.c_uint64(n), C.c_int(inner_offset), C.c_uint32(border_window), C.c_uint32(starts_room),
+                             C.c_uint32(ends_room), _ptr(summary, C.c_uint32), _ptr(counts, C.c_uint8)) != 0:
         raise RuntimeError("pdh_summarize_run failed")
     return dict(zip(SUMMARY_FIELDS, (int(v) for v in summary))), counts
 
 
-def parse_gpu(hip_lib, blobs, sample_first=None, device=0, summarize=None, room=0):
+def parse_gpu(hip_lib, blobs, sample_first=None, device=0, inner_offsets=None, starts_room=0, ends_room=0):
     """pd_inflater_run_parsed on gzip members (one sample unless `sample_first` says otherwise). Returns a dict: status[n],
     flags[n], counts[n, 3] (256-bp windows, 30-bp windows, records per block), profile_windows[.., 5], call_windows[.., 3],
-    call_window_records[..], records[.., 2] (all blocks' rows in block order), bytes_copied. `summarize`: a list of
-    (first_record, n_records, inner_offset, border_window) runs over those records for pd_inflater_summarize with `room` windows per
-    row -> 'summaries' (list of dicts) and 'run_counts' uint8[runs, 2, room] as well ('summarize_rc' if the call was refused)."""
+    call_window_records[..], records[.., 2] (all blocks' rows in block order), bytes_copied. `inner_offsets` (one per member):
+    pd_inflater_run_summarized instead, with `starts_room` / `ends_room` windows per block -> 'summaries' (a dict per block) and
+    'block_counts' uint8[n, starts_room + ends_room] as well ('summarize_rc' != 0 if the call was refused: nothing else then)."""
     data, offsets, out_offsets = pack_members(blobs)
     n = len(blobs)
     first = np.zeros(n, np.uint32) if sample_first is None else np.asarray(sample_first, np.uint32)
@@ -157,11 +158,22 @@ def parse_gpu(hip_lib, blobs, sample_first=None, device=0, summarize=None, room=
         buf = hip_lib.pd_inflater_input(inf, C.c_uint64(len(data)))
         C.memmove(buf, data.ctypes.data, len(data))
         out, status, lengths, pb, ms = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint64)(), PdParsedBlocks(), C.c_double()
-        rc = hip_lib.pd_inflater_run_parsed(C.c_void_p(inf), _ptr(offsets, C.c_uint64), C.c_uint32(n), _ptr(out_offsets, C.c_uint64),
-                                            _ptr(first, C.c_uint32), _ptr(want, C.c_uint8), C.byref(out), C.byref(status), C.byref(lengths),
-                                            C.byref(pb), C.byref(ms))
-        if rc != 0:
-            raise RuntimeError("pd_inflater_run_parsed failed (%d)" % rc)
+        sums = PdBlockSummaries()
+        if inner_offsets is not None:
+            inner = np.ascontiguousarray(inner_offsets, dtype=np.int32)
+            hip_lib.pd_inflater_run_summarized.restype = C.c_int
+            rc = hip_lib.pd_inflater_run_summarized(C.c_void_p(inf), _ptr(offsets, C.c_uint64), C.c_uint32(n), _ptr(out_offsets, C.c_uint64),
+                                                    _ptr(first, C.c_uint32), _ptr(want, C.c_uint8), _ptr(inner, C.c_int32), C.c_uint32(starts_room),
+                                                    C.c_uint32(ends_room), C.byref(out), C.byref(status), C.byref(lengths), C.byref(pb),
+                                                    C.byref(sums), C.byref(ms))
+            if rc != 0:
+                return dict(summarize_rc=rc)
+        else:
+            rc = hip_lib.pd_inflater_run_parsed(C.c_void_p(inf), _ptr(offsets, C.c_uint64), C.c_uint32(n), _ptr(out_offsets, C.c_uint64),
+                                                _ptr(first, C.c_uint32), _ptr(want, C.c_uint8), C.byref(out), C.byref(status), C.byref(lengths),
+                                                C.byref(pb), C.byref(ms))
+            if rc != 0:
+                raise RuntimeError("pd_inflater_run_parsed failed (%d)" % rc)
         st = np.ctypeslib.as_array(status, (n,)).copy()
         fl = np.ctypeslib.as_array(pb.block_flags, (n, 4)).copy()
         ro = np.ctypeslib.as_array(pb.profile_window_offsets, (n + 1,)).copy()
@@ -177,20 +189,11 @@ def parse_gpu(hip_lib, blobs, sample_first=None, device=0, summarize=None, room=
                    profile_windows=rows(pb.profile_windows, int(ro[-1]), 5), call_windows=rows(pb.call_windows, int(wo[-1]), 3),
                    call_window_records=rows(pb.call_window_records, int(wo[-1]), 1)[:, 0], records=rows(pb.records, int(co[-1]), 2),
                    bytes_copied=int(pb.bytes_copied))
-        if summarize:
-            req = (PdRunRequest * len(summarize))()
-            for k, (first_record, n_records, inner, border) in enumerate(summarize):
-                req[k].first_record, req[k].n_records, req[k].inner_offset, req[k].border_window = first_record, n_records, inner, border
-            hip_lib.pd_inflater_summarize.restype = C.c_int
-            sums, cnts, kms = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint8)(), C.c_double()
-            rc = hip_lib.pd_inflater_summarize(C.c_void_p(inf), req, C.c_uint32(len(summarize)), C.c_uint32(room), C.byref(sums), C.byref(cnts),
-                                               C.byref(kms))
-            res["summarize_rc"] = rc
-            if rc == 0:
-                words = np.ctypeslib.as_array(sums, (len(summarize) * 10,)).reshape(len(summarize), 10).copy()
-                res["summaries"] = [dict(zip(SUMMARY_FIELDS, (int(v) for v in row))) for row in words]
-                res["run_counts"] = np.ctypeslib.as_array(cnts, (len(summarize) * 2 * room,)).reshape(len(summarize), 2, room).copy()
-                res["summarize_kernel_ms"] = kms.value
+        if inner_offsets is not None:
+            res["summarize_rc"] = 0
+            words = np.ctypeslib.as_array(sums.block_summaries, (n * 10,)).reshape(n, 10).copy()
+            res["summaries"] = [dict(zip(SUMMARY_FIELDS, (int(v) for v in row))) for row in words]
+            res["block_counts"] = np.ctypeslib.as_array(sums.block_counts, (n * (starts_room + ends_room),)).reshape(n, starts_room + ends_room).copy()
         return res
     finally:
         hip_lib.pd_inflater_destroy(C.c_void_p(inf))

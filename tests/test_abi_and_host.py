@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_by_both_libraries(built):
     from popdel_amd import capi
     assert sorted(capi.ABI_SYMBOLS) == names
     hip = capi.load_hip()
-    assert hip.pd_backend_name() == b"hip-gfx950" and hip.pd_abi_version() == 13
+    assert hip.pd_backend_name() == b"hip-gfx950" and hip.pd_abi_version() == 14
 
 
 def test_product_binary_links_only_the_hip_library(built):

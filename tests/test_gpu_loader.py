@@ -78,7 +78,11 @@ def test_loader_variants_write_the_same_vcf(built, cohort_dir, tmp_path):
     ahead = int(line.split("thread-seconds for it; ")[1].split()[0])
     parsed = int(line.split("parsed there for ")[1].split(";")[0])
     assert ahead >= 1 and parsed >= 600, line
-    for env in ({"POPDEL_HOST_PARSE": "1"}, {"POPDEL_LOADER_AHEAD": "0"}, {"POPDEL_HOST_PARSE": "1", "POPDEL_LOADER_AHEAD": "0"},
+    # (round 6: most records are filed from the device's block summaries, none with POPDEL_HOST_FILING=1 -- same bytes)
+    filed = [l for l in r.stderr.splitlines() if "[popdel timing] filing:" in l][0]
+    total, bulk = int(filed.split("filing: ")[1].split()[0]), int(filed.split("files filed in runs, ")[1].split()[0])
+    assert total > 5000000 and bulk > 0.7 * total and " 0 refused by the tables" in filed, filed
+    for env in ({"POPDEL_HOST_FILING": "1"}, {"POPDEL_HOST_PARSE": "1"}, {"POPDEL_LOADER_AHEAD": "0"}, {"POPDEL_HOST_PARSE": "1", "POPDEL_LOADER_AHEAD": "0"},
                 {"POPDEL_HIP_PINNED": "malloc", "POPDEL_HIP_BLOCKING_SYNC": "0", "POPDEL_NO_NUMA_BIND": "1"}):
         r1, other = call(d, str(tmp_path / "other.vcf"), *args, env=env)
         assert r1.returncode == 0, r1.stderr[-300:]
@@ -88,6 +92,8 @@ def test_loader_variants_write_the_same_vcf(built, cohort_dir, tmp_path):
             assert " 0 rounds fetched ahead" in line, line
         if "POPDEL_HOST_PARSE" in env:
             assert "parsed there for 0;" in line, line
+        if "POPDEL_HOST_FILING" in env or "POPDEL_HOST_PARSE" in env:
+            assert "files filed in runs, 0 of them" in [l for l in r1.stderr.splitlines() if "[popdel timing] filing:" in l][0]
 
 
 @pytest.mark.parametrize("region_size", [2000, 50000])
@@ -124,3 +130,4 @@ def test_uneven_profiles_behave_as_on_the_host(built, tmp_path, region_size):
         line = [l for l in r1.stderr.splitlines() if "loader: profile blocks inflated on the device" in l]
         assert line, r1.stderr[-400:]
         print("region size %d, %s: %s" % (region_size, " ".join(args), line[0].split("thread-seconds for it; ")[1]))
+        print([l for l in r1.stderr.splitlines() if "[popdel timing] filing:" in l][0])

@@ -78,6 +78,12 @@ def main():
                     f.write("\n".join(timeline) + "\n")
             if extra:
                 row["loader"] = extra[-1][len("[popdel timing] "):]
+            filing = [l for l in r.stderr.splitlines() if "[popdel timing] filing" in l]
+            if filing:
+                row["filing"] = filing[-1][len("[popdel timing] "):]
+            mc = re.search(r"warmed rounds: .*CPU ([0-9.e+-]+) s", r.stderr)
+            if mc and mw:
+                row["warmed_cpu_seconds_per_segment"] = round(float(mc.group(1)) / int(mw.group(1)), 4)
             rows.append(row)
             print(json.dumps(row), flush=True)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
