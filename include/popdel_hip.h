@@ -513,7 +513,12 @@ int pd_inflater_run_parsed(pd_inflater *inflater, const uint64_t *member_offsets
  * in the same page-locked, callee-owned arrays' lifetime as the rest of pd_parsed_blocks. A block spans one index region (10,000 bp
  * by default: 335 windows of starts, ends a little further). The host's ChromProfile::addBulk() files whole blocks from this without
  * reading their records; summarizeRun() (chrom_profile.cpp) is the same computation on the host, the kernel's yardstick
- * (tests/test_gpu_summarize.py). */
+ * (tests/test_gpu_summarize.py).
+ * lean != 0: the 30-bp windows are not written out. profile_windows then holds per 256-bp window {chrom, beginPos, first record,
+ * number of records, position of the first record, position of the last} (24 bytes; record indices relative to the sample's first
+ * block), call_windows and call_window_records are NULL: the 30-bp windows of a 256-bp window are the runs of equal position / 30
+ * among its records (convertWindow anchors the grid at a multiple of 30), which a host reads off the records where it needs them --
+ * at the two ends of what a round files -- and a third less is copied back. */
 typedef struct pd_block_summary
 {
     uint32_t n, first_pos, last_pos, bin_base, n_bins, min_end_bin, max_end_bin, first_end_bin, last_end_bin, flags;
@@ -526,7 +531,7 @@ typedef struct pd_block_summaries
 } pd_block_summaries;
 int pd_inflater_run_summarized(pd_inflater *inflater, const uint64_t *member_offsets, uint32_t n_members, const uint64_t *out_offsets,
                                const uint32_t *sample_first, const uint8_t *parse_member, const int32_t *inner_offset,
-                               uint32_t starts_room, uint32_t ends_room, const uint8_t **out, const uint32_t **status,
+                               uint32_t starts_room, uint32_t ends_room, uint32_t lean, const uint8_t **out, const uint32_t **status,
                                const uint64_t **out_lengths, pd_parsed_blocks *parsed, pd_block_summaries *summaries, double *kernel_ms);
 
 /* Text of the last error on this context (or of the last failed pd_ctx_create if ctx == NULL). */

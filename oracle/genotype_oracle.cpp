@@ -1122,7 +1122,7 @@ int pd_inflater_run(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *,
 int pd_ctx_set_shard_lanes(pd_ctx *, const pd_shard *, const pd_shard *, uint32_t) { return 1; }
 int pd_inflater_run_parsed(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t **, const uint32_t **,
                            const uint64_t **, pd_parsed_blocks *, double *) { return 1; }
-int pd_inflater_run_summarized(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *, const uint32_t *, const uint8_t *, const int32_t *, uint32_t, uint32_t,
+int pd_inflater_run_summarized(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *, const uint32_t *, const uint8_t *, const int32_t *, uint32_t, uint32_t, uint32_t,
                                const uint8_t **, const uint32_t **, const uint64_t **, pd_parsed_blocks *, pd_block_summaries *, double *) { return 1; }
 
 int pd_walk_source_counts(pd_ctx *, uint64_t * from_device)

@@ -120,6 +120,15 @@ struct ParsedWindow     // (= pdh::DecodedRaw)
     int32_t  chrom, beginPos;
     uint32_t splitFailed, firstWin, nWin;
 };
+// Lean form (round 6; pd_inflater_run_summarized with lean != 0): per 256-bp window where its records lie and the positions of
+// the first and the last -- the 30-bp windows are the runs of equal position / 30 among them (the first record of a window
+// anchors the 30-grid at a multiple of 30, convertWindow), which the host reads off the records where it needs them: at the two
+// ends of what a round files. No call windows, no record counts per window: a third less to copy back.
+struct LeanWindow       // (= pdh::LeanRaw)
+{
+    int32_t  chrom, beginPos;
+    uint32_t firstRec, nRecs, firstPos, lastPos;
+};
 struct CallWindow       // (= pdh::FlatWindow)
 {
     int32_t  chrom, beginPos;
@@ -150,7 +159,7 @@ __device__ __forceinline__ uint64_t loadU64(const uint8_t * p)
 // switch between (parseCount + parseWrite per 1,024-sample chunk: 0.56 + 1.03 ms with 64).
 constexpr unsigned kParseLanes = 16;
 
-template <bool Write>
+template <bool Write, bool Lean = false>
 __device__ __forceinline__ BlockCounts walkBlock(const uint8_t * p, const uint8_t * end, ParsedWindow * raws, CallWindow * wins,
                                                  uint32_t * counts, uint2 * recs, uint32_t winBase, uint32_t recBase)
 {
@@ -172,6 +181,7 @@ __device__ __forceinline__ BlockCounts walkBlock(const uint8_t * p, const uint8_
         p += 12;
         const uint32_t base = ((begin + p[0]) / 30u) * 30u;
         uint32_t prev = 0, boundary = 0, firstWin = c.wins, inWin = 0;
+        const uint32_t firstPos = begin + p[0];
         for (uint32_t i = 0; i < n; ++i, p += 5)
         {
             const uint64_t rec = loadU64(p);
@@ -182,7 +192,7 @@ __device__ __forceinline__ BlockCounts walkBlock(const uint8_t * p, const uint8_
             if (pos >= boundary)
             {
                 const uint32_t winBegin = base + ((pos - base) / 30u) * 30u;
-                if (Write)
+                if (Write && !Lean)
                 {
                     if (inWin)
                         counts[c.wins - 1] = inWin;
@@ -196,11 +206,13 @@ __device__ __forceinline__ BlockCounts walkBlock(const uint8_t * p, const uint8_
             if (Write)
                 recs[c.recs + i] = make_uint2(pos, (uint32_t)(rec >> 8));
         }
-        if (Write)
+        if (Write && !Lean)
         {
             counts[c.wins - 1] = inWin;
             raws[c.raws] = ParsedWindow{(int32_t)chrom, (int32_t)begin, 0u, winBase + firstWin, c.wins - firstWin};
         }
+        if (Write && Lean)
+            reinterpret_cast<LeanWindow *>(raws)[c.raws] = LeanWindow{(int32_t)chrom, (int32_t)begin, recBase + c.recs, n, firstPos, prev};
         if ((prev - base) / 30u >= 10u)
             c.flags = 1;
         ++c.raws;
@@ -276,15 +288,20 @@ __global__ __launch_bounds__(kParseLanes) void parseWriteKernel(const uint8_t * 
                                                        const uint32_t * __restrict__ sampleFirst, const uint64_t * __restrict__ rawOff,
                                                        const uint64_t * __restrict__ winOff, const uint64_t * __restrict__ recOff, uint32_t n,
                                                        ParsedWindow * __restrict__ raws, CallWindow * __restrict__ wins,
-                                                       uint32_t * __restrict__ winCounts, uint2 * __restrict__ recs)
+                                                       uint32_t * __restrict__ winCounts, uint2 * __restrict__ recs, uint32_t lean)
 {
     const uint32_t m = blockIdx.x * kParseLanes + threadIdx.x;
     if (m >= n || counts[m].flags)
         return;
     // indices are relative to the block's SAMPLE (its first block is sampleFirst[m])
     const uint32_t f = sampleFirst[m];
-    walkBlock<true>(data + outOff[m], data + outOff[m] + outLen[m], raws + rawOff[m], wins + winOff[m], winCounts + winOff[m],
-                    recs + recOff[m], (uint32_t)(winOff[m] - winOff[f]), (uint32_t)(recOff[m] - recOff[f]));
+    if (lean)
+        walkBlock<true, true>(data + outOff[m], data + outOff[m] + outLen[m],
+                              reinterpret_cast<ParsedWindow *>(reinterpret_cast<LeanWindow *>(raws) + rawOff[m]), nullptr, nullptr,
+                              recs + recOff[m], 0u, (uint32_t)(recOff[m] - recOff[f]));
+    else
+        walkBlock<true>(data + outOff[m], data + outOff[m] + outLen[m], raws + rawOff[m], wins + winOff[m], winCounts + winOff[m],
+                        recs + recOff[m], (uint32_t)(winOff[m] - winOff[f]), (uint32_t)(recOff[m] - recOff[f]));
 }
 
 // ---- the parsed records summarised block by block for the loader's tables (round 6; pd_inflater_run_summarized) ----------------
@@ -533,7 +550,7 @@ extern "C" uint8_t * pd_inflater_input(pd_inflater * f, uint64_t bytes)
 static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_t n_members, const uint64_t * out_offsets,
                        const uint32_t * sample_first, const uint8_t * parse_member, const uint8_t ** out, const uint32_t ** status,
                        const uint64_t ** out_lengths, pd_parsed_blocks * parsed, double * kernel_ms, const int32_t * inner_offset = nullptr,
-                       uint32_t starts_room = 0, uint32_t ends_room = 0, pd_block_summaries * summaries = nullptr)
+                       uint32_t starts_room = 0, uint32_t ends_room = 0, pd_block_summaries * summaries = nullptr, uint32_t lean = 0)
 {
     if (!f || !member_offsets || !out_offsets || !out || !status || !out_lengths || n_members == 0 || (parsed && (!sample_first || !parse_member)))
         return 1;
@@ -616,24 +633,36 @@ static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_
             const uint64_t * hRawOff = static_cast<const uint64_t *>(f->hOffsets), *hWinOff = hRawOff + n_members + 1, *hRecOff = hWinOff + n_members + 1;
             const uint64_t nRaws = hRawOff[n_members], nWins = hWinOff[n_members], nRecs = hRecOff[n_members];
             f->nRecsLast = nRecs;
-            growDevice(f->dRaws, f->capRaws, std::max<uint64_t>(1, nRaws) * sizeof(ParsedWindow));
-            growDevice(f->dWins, f->capWins, std::max<uint64_t>(1, nWins) * sizeof(CallWindow));
-            growDevice(f->dWinCounts, f->capWinCounts, std::max<uint64_t>(1, nWins) * sizeof(uint32_t));
+            const size_t rawBytes = lean ? sizeof(LeanWindow) : sizeof(ParsedWindow);
+            growDevice(f->dRaws, f->capRaws, std::max<uint64_t>(1, nRaws) * rawBytes);
             growDevice(f->dRecs, f->capRecs, std::max<uint64_t>(1, nRecs) * sizeof(uint2));
-            growPinned(f->hRaws, f->capHRaws, std::max<uint64_t>(1, nRaws) * sizeof(ParsedWindow));
-            growPinned(f->hWins, f->capHWins, std::max<uint64_t>(1, nWins) * sizeof(CallWindow));
-            growPinned(f->hWinCounts, f->capHWinCounts, std::max<uint64_t>(1, nWins) * sizeof(uint32_t));
+            growPinned(f->hRaws, f->capHRaws, std::max<uint64_t>(1, nRaws) * rawBytes);
             growPinned(f->hRecs, f->capHRecs, std::max<uint64_t>(1, nRecs) * sizeof(uint2));
+            if (!lean)
+            {
+                growDevice(f->dWins, f->capWins, std::max<uint64_t>(1, nWins) * sizeof(CallWindow));
+                growDevice(f->dWinCounts, f->capWinCounts, std::max<uint64_t>(1, nWins) * sizeof(uint32_t));
+                growPinned(f->hWins, f->capHWins, std::max<uint64_t>(1, nWins) * sizeof(CallWindow));
+                growPinned(f->hWinCounts, f->capHWinCounts, std::max<uint64_t>(1, nWins) * sizeof(uint32_t));
+            }
             hipLaunchKernelGGL(parseWriteKernel, dim3((n_members + kParseLanes - 1) / kParseLanes), dim3(kParseLanes), 0, st, static_cast<const uint8_t *>(f->dOut),
                                static_cast<const uint64_t *>(f->dOutOff), static_cast<const uint64_t *>(f->dLen),
                                static_cast<const BlockCounts *>(f->dCounts), static_cast<const uint32_t *>(f->dSampleFirst), dRawOff, dWinOff, dRecOff,
                                n_members, static_cast<ParsedWindow *>(f->dRaws), static_cast<CallWindow *>(f->dWins),
-                               static_cast<uint32_t *>(f->dWinCounts), static_cast<uint2 *>(f->dRecs));
+                               static_cast<uint32_t *>(f->dWinCounts), static_cast<uint2 *>(f->dRecs), lean);
             PD_INF_HIP(hipGetLastError());
-            PD_INF_HIP(hipMemcpyAsync(f->hRaws, f->dRaws, nRaws * sizeof(ParsedWindow), hipMemcpyDeviceToHost, st));
-            PD_INF_HIP(hipMemcpyAsync(f->hWins, f->dWins, nWins * sizeof(CallWindow), hipMemcpyDeviceToHost, st));
-            PD_INF_HIP(hipMemcpyAsync(f->hWinCounts, f->dWinCounts, nWins * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            PD_INF_HIP(hipMemcpyAsync(f->hRaws, f->dRaws, nRaws * rawBytes, hipMemcpyDeviceToHost, st));
+            if (!lean)
+            {
+                PD_INF_HIP(hipMemcpyAsync(f->hWins, f->dWins, nWins * sizeof(CallWindow), hipMemcpyDeviceToHost, st));
+                PD_INF_HIP(hipMemcpyAsync(f->hWinCounts, f->dWinCounts, nWins * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            }
             PD_INF_HIP(hipMemcpyAsync(f->hRecs, f->dRecs, nRecs * sizeof(uint2), hipMemcpyDeviceToHost, st));
+            {
+                static const int extra = [] { const char * e = std::getenv("POPDEL_EXPERIMENT_D2H_EXTRA"); return e ? std::atoi(e) : 0; }();
+                for (int k = 0; k < extra; ++k)     // (measurement: is the copy back what a round waits for?)
+                    PD_INF_HIP(hipMemcpyAsync(f->hRecs, f->dRecs, nRecs * sizeof(uint2), hipMemcpyDeviceToHost, st));
+            }
             if (summaries)
             {
                 const size_t room = static_cast<size_t>(starts_room) + ends_room;
@@ -661,8 +690,8 @@ static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_
             for (uint32_t m = 0; m < n_members && !needBytes; ++m)
                 needBytes = fl[m].flags != 0;
             parsed->profile_windows = f->hRaws;
-            parsed->call_windows = f->hWins;
-            parsed->call_window_records = static_cast<const uint32_t *>(f->hWinCounts);
+            parsed->call_windows = lean ? nullptr : f->hWins;
+            parsed->call_window_records = lean ? nullptr : static_cast<const uint32_t *>(f->hWinCounts);
             parsed->records = f->hRecs;
             parsed->profile_window_offsets = hRawOff;
             parsed->call_window_offsets = hWinOff;
@@ -717,13 +746,13 @@ extern "C" int pd_inflater_run_parsed(pd_inflater * f, const uint64_t * member_o
 
 extern "C" int pd_inflater_run_summarized(pd_inflater * f, const uint64_t * member_offsets, uint32_t n_members, const uint64_t * out_offsets,
                                           const uint32_t * sample_first, const uint8_t * parse_member, const int32_t * inner_offset,
-                                          uint32_t starts_room, uint32_t ends_room, const uint8_t ** out, const uint32_t ** status,
+                                          uint32_t starts_room, uint32_t ends_room, uint32_t lean, const uint8_t ** out, const uint32_t ** status,
                                           const uint64_t ** out_lengths, pd_parsed_blocks * parsed, pd_block_summaries * summaries, double * kernel_ms)
 {
     if (!parsed || !summaries)
         return 1;
     return runInflater(f, member_offsets, n_members, out_offsets, sample_first, parse_member, out, status, out_lengths, parsed, kernel_ms,
-                       inner_offset, starts_room, ends_room, summaries);
+                       inner_offset, starts_room, ends_room, summaries, lean);
 }
 
 extern "C" const char * pd_inflate_last_error(void) { return g_inflateError.c_str(); }

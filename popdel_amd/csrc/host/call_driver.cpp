@@ -137,7 +137,15 @@ struct DecodedRaw                          // (the device writes the same 20 byt
     uint32_t splitFailed = 0;
     uint32_t firstWin = 0, nWin = 0;       // its 30-bp windows in DecodedStream::wins
 };
-static_assert(sizeof(DecodedRaw) == 20 && sizeof(FlatWindow) == 12 && sizeof(PairRecord) == 8, "layouts shared with the device's parser");
+// The device's lean form of a 256-bp window (round 6; LeanWindow, inflate.hip): where its records lie in the sample's stream and the
+// positions of the first and the last. Its 30-bp windows are the runs of equal position / 30 among its records -- read off the
+// records where the loader's decisions need them, at the two ends of what a round files; everywhere else the two positions do.
+struct LeanRaw
+{
+    int32_t  chrom = 0, beginPos = 0;
+    uint32_t firstRec = 0, nRecs = 0, firstPos = 0, lastPos = 0;
+};
+static_assert(sizeof(DecodedRaw) == 20 && sizeof(FlatWindow) == 12 && sizeof(PairRecord) == 8 && sizeof(LeanRaw) == 24, "layouts shared with the device's parser");
 
 struct alignas(64) DecodedStream      // (neighbours in the pool are filled by different threads: no shared cache lines)
 {
@@ -155,6 +163,9 @@ struct alignas(64) DecodedStream      // (neighbours in the pool are filled by d
     const uint32_t * countsV = nullptr;
     const PairRecord * recsV = nullptr;
     size_t nRecsV = 0;
+    // (device-parsed, lean form: these instead of rawsV / winsV / countsV)
+    const LeanRaw * leanV = nullptr;
+    size_t nLeanV = 0;
     // (device-parsed arrays: the sample's blocks summarised for the tables -- block b holds records [blockRecs[b] - blockRecs[0],
     // blockRecs[b + 1] - blockRecs[0]) of recsV; pd_inflater_run_summarized)
     const uint64_t * blockRecs = nullptr;
@@ -189,6 +200,8 @@ struct alignas(64) DecodedStream      // (neighbours in the pool are filled by d
         countsV = nullptr;
         recsV = nullptr;
         nRecsV = 0;
+        leanV = nullptr;
+        nLeanV = 0;
         blockRecs = nullptr;
         nBlocks = 0;
         blockSums = nullptr;
@@ -246,6 +259,7 @@ public:
         // ... and / or the blocks parsed (the sample's 256-bp windows, 30-bp windows with their record counts, records)
         bool parsed = false;
         const DecodedRaw * raws = nullptr;
+        const LeanRaw * lean = nullptr;             // (lean form: instead of raws / wins / counts; nRaws of them)
         size_t nRaws = 0;
         const FlatWindow * wins = nullptr;
         const uint32_t * counts = nullptr;
@@ -411,7 +425,10 @@ public:
             if (r.parsed)
             {
                 const uint64_t n = r.rawsByBlock[b] - r.rawsByBlock[0];
-                r.raws += n;
+                if (r.lean)
+                    r.lean += n;
+                else
+                    r.raws += n;
                 r.nRaws -= static_cast<size_t>(n);
             }
             r.usable = true;
@@ -446,6 +463,7 @@ public:
     // the parsed blocks summarised for the tables as well (CallRun: runs filed from summaries), with this much room per block
     bool summariesWanted = false;
     uint32_t startsRoom = 0, endsRoom = 0;
+    bool leanWanted = false;            // ... and the 30-bp windows not written out (LeanRaw; POPDEL_FULL_PARSE=1 keeps them)
     std::vector<int> fds_;              // descriptorOf()
 
 private:
@@ -701,10 +719,12 @@ private:
         pd_block_summaries sums;
         std::memset(&sums, 0, sizeof(sums));
         const bool haveSums = summariesWanted && parseOnDevice_;
+        const bool lean = haveSums && leanWanted;
         if (haveSums)
         {
             if (pd_inflater_run_summarized(inf, j.inOff.data(), static_cast<uint32_t>(j.inOff.size() - 1), j.outOff.data(), j.sampleFirst.data(),
-                                           j.parseMember.data(), j.innerOffset.data(), startsRoom, endsRoom, &out, &status, &lengths, &pb, &sums, &ms) != 0)
+                                           j.parseMember.data(), j.innerOffset.data(), startsRoom, endsRoom, lean ? 1u : 0u, &out, &status, &lengths, &pb,
+                                           &sums, &ms) != 0)
                 throw ProfileError("pd_inflater_run_summarized failed");
         }
         else if (pd_inflater_run_parsed(inf, j.inOff.data(), static_cast<uint32_t>(j.inOff.size() - 1), j.outOff.data(), j.sampleFirst.data(),
@@ -744,10 +764,15 @@ private:
             {
                 const uint32_t m0 = j.firstMember[k], m1 = j.firstMember[k + 1];
                 r.parsed = true;
-                r.raws = static_cast<const DecodedRaw *>(pb.profile_windows) + pb.profile_window_offsets[m0];
                 r.nRaws = static_cast<size_t>(pb.profile_window_offsets[m1] - pb.profile_window_offsets[m0]);
-                r.wins = static_cast<const FlatWindow *>(pb.call_windows) + pb.call_window_offsets[m0];
-                r.counts = pb.call_window_records + pb.call_window_offsets[m0];
+                if (lean)
+                    r.lean = static_cast<const LeanRaw *>(pb.profile_windows) + pb.profile_window_offsets[m0];
+                else
+                {
+                    r.raws = static_cast<const DecodedRaw *>(pb.profile_windows) + pb.profile_window_offsets[m0];
+                    r.wins = static_cast<const FlatWindow *>(pb.call_windows) + pb.call_window_offsets[m0];
+                    r.counts = pb.call_window_records + pb.call_window_offsets[m0];
+                }
                 r.recs = static_cast<const PairRecord *>(pb.records) + pb.record_offsets[m0];
                 r.nRecs = static_cast<size_t>(pb.record_offsets[m1] - pb.record_offsets[m0]);
                 r.inflater = inf;
@@ -1525,6 +1550,7 @@ void CallRun::createLoaders()
         g->endsRoom = g->startsRoom + 128u;
         g->summariesWanted = deviceWalkOffered_ && !getenv("POPDEL_HEAVY_TABLES") && !getenv("POPDEL_HOST_FILING") && region != 0 &&
                              g->startsRoom + g->endsRoom <= 12000u;
+        g->leanWanted = !getenv("POPDEL_FULL_PARSE");
     }
     const char * ahead = getenv("POPDEL_LOADER_AHEAD");
     loaderAhead_ = !(ahead && ahead[0] == '0');
@@ -1575,7 +1601,96 @@ void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned
     const GunzipPrefetch::Ready * pre = gunzip_ ? gunzip_->wait(i) : nullptr;
     if (gunzip_ && !pre)
         ++hostDecodes_[0];
-    if (pre && pre->parsed)
+    if (pre && pre->parsed && pre->lean)
+    {
+        // The device's lean arrays: the same scan, a 256-bp window taken by the positions of its first and last record where
+        // that decides it, window by window over its records where not.
+        size_t r0 = 0, r = 0;
+        bool stopped = false;
+        int32_t coordChrom = -1, roiChrom = -1, otherChrom = -1;
+        for (; r < pre->nRaws && !stopped; ++r)
+        {
+            const LeanRaw & raw = pre->lean[r];
+            if (raw.chrom != coordChrom)
+            {
+                if (contigNames[raw.chrom] != coordContig)
+                {
+                    stopped = true;             // (the window of the other contig is the last one the replay sees)
+                    break;
+                }
+                coordChrom = raw.chrom;
+            }
+            if (raw.beginPos + 255 < roi.beginPos)
+            {
+                if (r == r0)
+                    ++r0;                   // (windows ahead of the region: a prefix, not handed on)
+                continue;
+            }
+            if (raw.nRecs == 0)
+                continue;
+            if (raw.chrom != roiChrom && raw.chrom != otherChrom)
+            {
+                if (contigNames[raw.chrom] == roi.seqName)
+                    roiChrom = raw.chrom;
+                else
+                    otherChrom = raw.chrom;
+            }
+            const uint32_t head = raw.firstPos / 30u * 30u, tail = raw.lastPos / 30u * 30u;
+            if (raw.chrom == roiChrom && static_cast<int64_t>(head) >= roi.beginPos && static_cast<int64_t>(tail) < roi.endPos && tail < border && head <= tail)
+                continue;
+            uint32_t last = 0xffffffffu;
+            for (uint32_t k = raw.firstRec; k < raw.firstRec + raw.nRecs; ++k)
+            {
+                const uint32_t wb = pre->recs[k].pos / 30u * 30u;
+                if (wb == last)
+                    continue;
+                last = wb;
+                if (raw.chrom != roiChrom || static_cast<int64_t>(wb) >= roi.endPos)
+                {
+                    stopped = true;
+                    break;
+                }
+                if (static_cast<int64_t>(wb) < roi.beginPos)
+                    continue;
+                if (wb >= border + numWindows)
+                {
+                    border = wb + numWindows;
+                    out.sawFarWindow = true;
+                }
+                else if (wb >= border)
+                {
+                    stopped = true;
+                    break;
+                }
+            }
+            if (stopped)
+                break;
+        }
+        const bool atEnd = !stopped && pre->toFileEnd;
+        if (stopped || atEnd)
+        {
+            out.eof = atEnd;
+            out.leanV = pre->lean + r0;
+            out.nLeanV = (atEnd ? pre->nRaws : r + 1) - r0;
+            out.recsV = pre->recs;
+            out.nRecsV = pre->nRecs;
+            out.blockRecs = pre->blockRecs;
+            out.nBlocks = pre->nBlocks;
+            out.blockSums = pre->blockSums;
+            out.blockCounts = pre->blockCounts;
+            out.startsRoom = pre->startsRoom;
+            out.endsRoom = pre->endsRoom;
+            out.inflater = pre->inflater;
+            out.recBase = pre->recBase;
+            return;
+        }
+        ++hostDecodes_[1];
+        out.sawFarWindow = false;           // (decoded again below)
+        border = borderIn;
+        if (!pre->bytesValid)
+            pre = nullptr;
+    }
+    else if (pre && pre->parsed)
     {
         // The device has inflated AND parsed the blocks from the jump position on: the loop below, on its arrays. If the point at
         // which the loader stops lies within them (the rule) the replay reads them where they are; if not, the sample is decoded
@@ -1748,6 +1863,134 @@ bool CallRun::replayAdvance(ReplayState & st, const DecodedStream & in, const st
         st.code = code;
         return false;
     };
+    if (in.leanV)
+    {
+        // ---- the device's lean arrays (one read group): the same loop with the 30-bp windows read off the records. st.wi is the
+        // index of the next record to look at (in the sample's stream).
+        const StartSlots & sst = prof.starts[rg[0]];
+        while (!st.finished)
+        {
+            if (!st.inRaw)
+            {
+                if (st.rawIdx >= in.nLeanV)
+                {
+                    if (!in.eof)
+                        throw ProfileError("[PopDel] Internal error: decoded stream of \"" + fileName + "\" ended before the loader stopped.");
+                    prof.performPartialSwitches(rg, border);
+                    coordinate.contig = "";
+                    coordinate.pos = kNoPos;
+                    return stop(3);
+                }
+                const LeanRaw & raw = in.leanV[st.rawIdx];
+                if (contigNames[raw.chrom] != coordinate.contig)
+                {
+                    prof.performPartialSwitches(rg, border);
+                    coordinate.contig = contigNames[raw.chrom];
+                    coordinate.pos = static_cast<unsigned>(raw.beginPos);
+                    return stop(2);
+                }
+                st.onRoiContig = contigNames[raw.chrom] == roi.seqName;
+                st.wi = raw.firstRec;
+                st.inRaw = true;
+            }
+            const LeanRaw & raw = in.leanV[st.rawIdx];
+            const uint32_t endOfThis = raw.firstRec + raw.nRecs;
+            if (st.wi >= endOfThis)
+            {
+                st.inRaw = false;
+                ++st.rawIdx;
+                continue;
+            }
+            // the 30-bp window of record st.wi: its records are [st.wi, we)
+            const uint32_t wb = in.recsV[st.wi].pos / 30u * 30u;
+            uint32_t we = st.wi + 1;
+            while (we < endOfThis && in.recsV[we].pos / 30u * 30u == wb)
+                ++we;
+            if (!st.onRoiContig || static_cast<int64_t>(wb) >= roi.endPos)
+            {
+                prof.performPartialSwitches(rg, border);
+                coordinate.contig = contigNames[raw.chrom];
+                coordinate.pos = wb;
+                return stop(2);
+            }
+            if (static_cast<int64_t>(wb) < roi.beginPos)
+            {
+                st.wi = we;
+                continue;
+            }
+            if (sst.tooBigForNext(wb))
+            {
+                if (prof.allEmpty())
+                {
+                    prof.resetTo(wb);
+                }
+                else
+                {
+                    prof.performPartialSwitches(rg, border);
+                    coordinate.contig = contigNames[raw.chrom];
+                    coordinate.pos = wb;
+                    return stop(0);
+                }
+            }
+            else if (sst.needsSwitch(wb))
+            {
+                prof.performPartialSwitches(rg, border);
+                coordinate.contig = contigNames[raw.chrom];
+                coordinate.pos = wb;
+                return stop(0);
+            }
+            // the run: this window's records and those of the windows behind it that pass as well (see below for the full form)
+            const unsigned right = sst.slots[sst.writeSlot].right;
+            auto passes = [&](uint32_t pos) {
+                const uint32_t b = pos / 30u * 30u;
+                return static_cast<int64_t>(b) >= roi.beginPos && static_cast<int64_t>(b) < roi.endPos && b < right;
+            };
+            uint32_t j = we;
+            size_t rj = st.rawIdx;
+            uint32_t endOfRaw = endOfThis;
+            int32_t knownChrom = raw.chrom;         // (its name equals coordinate.contig and roi.seqName)
+            for (;;)
+            {
+                while (j < endOfRaw && passes(in.recsV[j].pos))
+                    ++j;
+                if (j < endOfRaw)
+                    break;
+                bool more = false;
+                while (rj + 1 < in.nLeanV)
+                {
+                    const LeanRaw & nx = in.leanV[rj + 1];
+                    if (nx.nRecs == 0 || nx.firstRec != endOfRaw)
+                        break;
+                    if (nx.chrom != knownChrom)
+                    {
+                        if (contigNames[nx.chrom] != coordinate.contig || contigNames[nx.chrom] != roi.seqName)
+                            break;
+                        knownChrom = nx.chrom;
+                    }
+                    ++rj;
+                    endOfRaw = nx.firstRec + nx.nRecs;
+                    if (passes(nx.firstPos) && passes(nx.lastPos) && nx.firstPos <= nx.lastPos)
+                    {
+                        j = endOfRaw;
+                        continue;
+                    }
+                    j = nx.firstRec;
+                    more = true;                    // (record by record through this one)
+                    break;
+                }
+                if (!more)
+                    break;
+            }
+            st.haveRun = true;
+            st.runFirst = st.wi;
+            st.runCount = j - st.wi;
+            st.rawIdx = rj;
+            st.wi = j;
+            st.inRaw = true;
+            return true;
+        }
+        return false;
+    }
     while (!st.finished)
     {
         if (!st.inRaw)
@@ -3136,7 +3379,7 @@ int CallRun::run()
                 const unsigned i = readers[k];
                 const StartSlots & st = profile_->starts[p_.rgs[i][0]];
                 decodeSample(i, nextCandidate_[i].contig, st.slots[st.writeSlot].right, st.numWindows, decoded[k]);
-                if (!decoded[k].rawsV)              // (parsed on the host: the replay reads the stream's own arrays)
+                if (!decoded[k].rawsV && !decoded[k].leanV)     // (parsed on the host: the replay reads the stream's own arrays)
                     decoded[k].viewOwn();
             });
             clock_.decode += PhaseClock::now() - t0;

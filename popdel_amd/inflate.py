@@ -136,12 +136,14 @@ def summarize_host(records, first, n, inner_offset, border_window, starts_room, 
     return dict(zip(SUMMARY_FIELDS, (int(v) for v in summary))), counts
 
 
-def parse_gpu(hip_lib, blobs, sample_first=None, device=0, inner_offsets=None, starts_room=0, ends_room=0):
+def parse_gpu(hip_lib, blobs, sample_first=None, device=0, inner_offsets=None, starts_room=0, ends_room=0, lean=False):
     """pd_inflater_run_parsed on gzip members (one sample unless `sample_first` says otherwise). Returns a dict: status[n],
     flags[n], counts[n, 3] (256-bp windows, 30-bp windows, records per block), profile_windows[.., 5], call_windows[.., 3],
     call_window_records[..], records[.., 2] (all blocks' rows in block order), bytes_copied. `inner_offsets` (one per member):
     pd_inflater_run_summarized instead, with `starts_room` / `ends_room` windows per block -> 'summaries' (a dict per block) and
-    'block_counts' uint8[n, starts_room + ends_room] as well ('summarize_rc' != 0 if the call was refused: nothing else then)."""
+    'block_counts' uint8[n, starts_room + ends_room] as well ('summarize_rc' != 0 if the call was refused: nothing else then).
+    `lean`: the lean form -- 'profile_windows' holds rows {chrom, beginPos, first record, records, first position, last position},
+    'call_windows' / 'call_window_records' are empty."""
     data, offsets, out_offsets = pack_members(blobs)
     n = len(blobs)
     first = np.zeros(n, np.uint32) if sample_first is None else np.asarray(sample_first, np.uint32)
@@ -164,8 +166,8 @@ def parse_gpu(hip_lib, blobs, sample_first=None, device=0, inner_offsets=None, s
             hip_lib.pd_inflater_run_summarized.restype = C.c_int
             rc = hip_lib.pd_inflater_run_summarized(C.c_void_p(inf), _ptr(offsets, C.c_uint64), C.c_uint32(n), _ptr(out_offsets, C.c_uint64),
                                                     _ptr(first, C.c_uint32), _ptr(want, C.c_uint8), _ptr(inner, C.c_int32), C.c_uint32(starts_room),
-                                                    C.c_uint32(ends_room), C.byref(out), C.byref(status), C.byref(lengths), C.byref(pb),
-                                                    C.byref(sums), C.byref(ms))
+                                                    C.c_uint32(ends_room), C.c_uint32(1 if lean else 0), C.byref(out), C.byref(status),
+                                                    C.byref(lengths), C.byref(pb), C.byref(sums), C.byref(ms))
             if rc != 0:
                 return dict(summarize_rc=rc)
         else:
@@ -185,9 +187,10 @@ def parse_gpu(hip_lib, blobs, sample_first=None, device=0, inner_offsets=None, s
                 return np.zeros((0, width), np.uint32)
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), (count * width,)).reshape(count, width).copy()
 
+        n_cw = 0 if lean else int(wo[-1])
         res = dict(status=st, flags=fl[:, 3], counts=np.stack([np.diff(ro), np.diff(wo), np.diff(co)], axis=1),
-                   profile_windows=rows(pb.profile_windows, int(ro[-1]), 5), call_windows=rows(pb.call_windows, int(wo[-1]), 3),
-                   call_window_records=rows(pb.call_window_records, int(wo[-1]), 1)[:, 0], records=rows(pb.records, int(co[-1]), 2),
+                   profile_windows=rows(pb.profile_windows, int(ro[-1]), 6 if lean else 5), call_windows=rows(pb.call_windows, n_cw, 3),
+                   call_window_records=rows(pb.call_window_records, n_cw, 1)[:, 0], records=rows(pb.records, int(co[-1]), 2),
                    bytes_copied=int(pb.bytes_copied))
         if inner_offsets is not None:
             res["summarize_rc"] = 0

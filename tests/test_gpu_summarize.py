@@ -90,6 +90,54 @@ def test_block_summaries_equal_the_host_computation(built):
         assert np.array_equal(plain[k], dev[k]), k
 
 
+def test_lean_arrays_are_the_full_ones_without_the_call_windows(built):
+    """pd_inflater_run_summarized with lean != 0: per 256-bp window where its records lie and the positions of its first and last
+    record instead of the 30-bp windows -- held against the full form of the same blocks (which tests/test_gpu_parse.py holds
+    against the loader's reader): same windows, same records; first record = the first 30-bp window's, record count = the sum of
+    the 30-bp windows' counts; and the 30-bp windows ARE the runs of equal position / 30 among the records."""
+    from popdel_amd import capi, inflate
+    hip = capi.load_hip()
+    rng = np.random.default_rng(6)
+    blocks = inflate.profile_blocks(120, seed=21) + inflate.profile_blocks(30, seed=22, pairs_per_member=40)
+    for k in range(40):         # windows whose first record sits anywhere on the 30-grid, single-record windows, records on one position
+        begin = 7000000 + int(rng.integers(0, 30)) + 2560 * k
+        blk = b""
+        for w in range(int(rng.integers(1, 6))):
+            n = int(rng.choice([1, 1, 2, 7, 40, 255]))
+            offs = np.sort(rng.integers(0, 256, n)) if k % 5 else np.full(n, int(rng.integers(0, 256)))
+            pos = begin + 256 * w + offs
+            blk += block(begin + 256 * w, pos, rng.integers(-2000, 40000, n).astype(np.int32))
+        blocks.append(blk)
+    blobs = [gzip.compress(b, 6, mtime=0) for b in blocks]
+    inner = np.full(len(blocks), 200, np.int32)
+    first = np.zeros(len(blocks), np.uint32)
+    first[100:] = 100                                          # two samples: indices are relative to the sample's first block
+    full = inflate.parse_gpu(hip, blobs, sample_first=first)
+    lean = inflate.parse_gpu(hip, blobs, sample_first=first, inner_offsets=inner, starts_room=345, ends_room=473, lean=True)
+    assert lean["summarize_rc"] == 0 and (lean["flags"] == 0).all() and (full["flags"] == 0).all()
+    assert np.array_equal(lean["records"], full["records"]) and np.array_equal(lean["counts"][:, [0, 2]], full["counts"][:, [0, 2]])
+    assert len(lean["call_windows"]) == 0
+    pw, lw, cw, cr, rec = full["profile_windows"], lean["profile_windows"], full["call_windows"], full["call_window_records"], full["records"]
+    assert len(pw) == len(lw) > 3000
+    assert np.array_equal(pw[:, :2], lw[:, :2])
+    # a sample's indices restart at its first block: rows of sample 0, then rows of sample 1
+    raws_per_block, wins_per_block, recs_per_block = full["counts"][:, 0], full["counts"][:, 1], full["counts"][:, 2]
+    for lo, hi in ((0, 100), (100, len(blocks))):
+        r0, r1 = int(raws_per_block[:lo].sum()), int(raws_per_block[:hi].sum())
+        w0, c0 = int(wins_per_block[:lo].sum()), int(recs_per_block[:lo].sum())
+        for k in range(r0, r1):
+            fw, nw = int(pw[k, 3]) + w0, int(pw[k, 4])
+            assert int(lw[k, 2]) == int(cw[fw, 2]), k                                      # first record (sample-relative)
+            assert int(lw[k, 3]) == int(cr[fw: fw + nw].sum()), k                          # records
+            a, b = c0 + int(lw[k, 2]), c0 + int(lw[k, 2]) + int(lw[k, 3])
+            assert int(lw[k, 4]) == int(rec[a, 0]) and int(lw[k, 5]) == int(rec[b - 1, 0]), k
+            # the 30-bp windows: runs of equal position // 30
+            bins = rec[a:b, 0] // 30
+            starts = np.flatnonzero(np.concatenate([[True], bins[1:] != bins[:-1]]))
+            assert len(starts) == nw and np.array_equal(bins[starts] * 30, cw[fw: fw + nw, 1]), k
+            assert np.array_equal(np.diff(np.concatenate([starts, [b - a]])), cr[fw: fw + nw]), k
+
+
 def test_summaries_are_refused_without_room(built):
     from popdel_amd import capi, inflate
     hip = capi.load_hip()
