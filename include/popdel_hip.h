@@ -384,6 +384,13 @@ int pd_walk_supported(const pd_ctx *ctx);
  * `capacity` pairs; the return code is 2 if there are more). A host that leaves the closed form (ROI change with pairs
  * still active: the reference keeps them, profile_structure_popdel_call.h:1735-1760) rebuilds its active sets from them. */
 int pd_walk_active(pd_ctx *ctx, uint64_t *n_active, uint32_t *rg, uint32_t *start, int32_t *dev, uint32_t *id, uint64_t capacity);
+/* ... with, per pair, its last window and -- bit 31 -- whether its end record was filed one end slot AHEAD (ABI 14; `last` may be
+ * NULL). A host that takes the window loop back after the loader has switched slots once more (a round was read, its segment never
+ * submitted) must do to these pairs what that switch does to the reference's active set: a switch drains the end read slot
+ * (profile_structure_popdel_call.h:1878-1910 -> every pair whose end record sits there leaves), so after ONE switch only the pairs
+ * filed ahead remain, after two or more none. */
+int pd_walk_active_ex(pd_ctx *ctx, uint64_t *n_active, uint32_t *rg, uint32_t *start, int32_t *dev, uint32_t *id, uint32_t *last,
+                      uint64_t capacity);
 
 /* Wait for a ticket and hand back its calls (callee-owned; release with pd_calls_free).
  * Replaces: reading `String<Call> calls` after the window loop (reference workflow_popdel.h:48). */
@@ -501,7 +508,8 @@ int pd_inflater_run_parsed(pd_inflater *inflater, const uint64_t *member_offsets
  * CyclicEndEntryTable::getEndCount, :870-924, after every record how many pairs are over -- a function of how many pairs BEGIN and
  * how many END in each 30-bp window as long as no record is dropped and the counting cursor stays in its slot).
  * pd_inflater_run_summarized() is pd_inflater_run_parsed() with, for every parsed block m (a pair's end position being position +
- * max(0, deviation + inner_offset[m]); inner_offset[m] = median - 2 * read length of the block's read group),
+ * max(0, deviation + inner_offset[m]); inner_offset[m] = median - 2 * read length of the block's read group; options->starts_room /
+ * ends_room windows of counts per block),
  *   block_summaries[m]                      number of records (n; 0: nothing else is filled in), first and last start position, the
  *                                           window (position / 30) of the counts' first entry (= that of the first position), the
  *                                           number of windows up to the last end window, smallest / largest / first / last end window,
@@ -514,7 +522,7 @@ int pd_inflater_run_parsed(pd_inflater *inflater, const uint64_t *member_offsets
  * by default: 335 windows of starts, ends a little further). The host's ChromProfile::addBulk() files whole blocks from this without
  * reading their records; summarizeRun() (chrom_profile.cpp) is the same computation on the host, the kernel's yardstick
  * (tests/test_gpu_summarize.py).
- * lean != 0: the 30-bp windows are not written out. profile_windows then holds per 256-bp window {chrom, beginPos, first record,
+ * options->lean != 0: the 30-bp windows are not written out. profile_windows then holds per 256-bp window {chrom, beginPos, first record,
  * number of records, position of the first record, position of the last} (24 bytes; record indices relative to the sample's first
  * block), call_windows and call_window_records are NULL: the 30-bp windows of a 256-bp window are the runs of equal position / 30
  * among its records (convertWindow anchors the grid at a multiple of 30), which a host reads off the records where it needs them --
@@ -528,11 +536,25 @@ typedef struct pd_block_summaries
     const pd_block_summary *block_summaries;    /* n_members */
     const uint8_t          *block_counts;       /* n_members x (starts_room + ends_room) */
     uint32_t                starts_room, ends_room;
+    const uint64_t         *record_index;       /* n_members: see keep_below / keep_from (NULL if all records were copied back) */
 } pd_block_summaries;
+/* keep_below / keep_from (both or neither; per member): with them the RECORDS of a block are copied back only if one of them begins
+ * below keep_below[m] or at / beyond keep_from[m] -- a loader that files whole blocks from their summaries reads records only at the
+ * two ends of what a round files, and the window loop takes its entries from the device's copy (pd_walk_source): four fifths of
+ * the records never cross the link. parsed->records then holds the kept blocks' records packed in block order, record_index[m] says
+ * where block m's begin (UINT64_MAX: not copied back; kept blocks that follow each other in a sample follow each other there),
+ * and parsed->record_offsets keeps counting ALL records (what indices into the device's array and the lean windows refer to). */
+typedef struct pd_summarize_options
+{
+    const int32_t  *inner_offset;       /* n_members */
+    uint32_t        starts_room, ends_room;
+    uint32_t        lean;
+    const uint32_t *keep_below, *keep_from;
+} pd_summarize_options;
 int pd_inflater_run_summarized(pd_inflater *inflater, const uint64_t *member_offsets, uint32_t n_members, const uint64_t *out_offsets,
-                               const uint32_t *sample_first, const uint8_t *parse_member, const int32_t *inner_offset,
-                               uint32_t starts_room, uint32_t ends_room, uint32_t lean, const uint8_t **out, const uint32_t **status,
-                               const uint64_t **out_lengths, pd_parsed_blocks *parsed, pd_block_summaries *summaries, double *kernel_ms);
+                               const uint32_t *sample_first, const uint8_t *parse_member, const pd_summarize_options *options,
+                               const uint8_t **out, const uint32_t **status, const uint64_t **out_lengths, pd_parsed_blocks *parsed,
+                               pd_block_summaries *summaries, double *kernel_ms);
 
 /* Text of the last error on this context (or of the last failed pd_ctx_create if ctx == NULL). */
 const char *pd_last_error(const pd_ctx *ctx);

@@ -1122,7 +1122,7 @@ int pd_inflater_run(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *,
 int pd_ctx_set_shard_lanes(pd_ctx *, const pd_shard *, const pd_shard *, uint32_t) { return 1; }
 int pd_inflater_run_parsed(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t **, const uint32_t **,
                            const uint64_t **, pd_parsed_blocks *, double *) { return 1; }
-int pd_inflater_run_summarized(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *, const uint32_t *, const uint8_t *, const int32_t *, uint32_t, uint32_t, uint32_t,
+int pd_inflater_run_summarized(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *, const uint32_t *, const uint8_t *, const pd_summarize_options *,
                                const uint8_t **, const uint32_t **, const uint64_t **, pd_parsed_blocks *, pd_block_summaries *, double *) { return 1; }
 
 int pd_walk_source_counts(pd_ctx *, uint64_t * from_device)
@@ -1193,7 +1193,12 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
     seg.pair_off = off.data();
     return runSegment(c, &seg, ticket);
 }
+int pd_walk_active_ex(pd_ctx * c, uint64_t * n, uint32_t * rg, uint32_t * start, int32_t * dev, uint32_t * id, uint32_t * last, uint64_t capacity);
 int pd_walk_active(pd_ctx * c, uint64_t * n, uint32_t * rg, uint32_t * start, int32_t * dev, uint32_t * id, uint64_t capacity)
+{
+    return pd_walk_active_ex(c, n, rg, start, dev, id, nullptr, capacity);
+}
+int pd_walk_active_ex(pd_ctx * c, uint64_t * n, uint32_t * rg, uint32_t * start, int32_t * dev, uint32_t * id, uint32_t * last, uint64_t capacity)
 {
     if (!c || !n)
         return 1;
@@ -1208,6 +1213,8 @@ int pd_walk_active(pd_ctx * c, uint64_t * n, uint32_t * rg, uint32_t * start, in
                     start[total] = p.start;
                     dev[total] = p.dev;
                     id[total] = p.id;
+                    if (last)
+                        last[total] = p.lastWin | (p.next ? 0x80000000u : 0u);
                 }
                 ++total;
             }

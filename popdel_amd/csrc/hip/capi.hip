@@ -2817,7 +2817,7 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
         for (uint32_t r = 0; r < nRg; ++r)
         {
             const uint32_t n = wk->switches[r] != 0 ? wk->rg_counts[r] : 0u;
-            if (n != 0 && !wk->rg_entries[r])
+            if (n != 0 && !wk->rg_entries[r] && !(wk->rg_sources && wk->rg_sources[r].inflater))
                 throw HipError{"a read group has entries but no table"};
             c->hRgOffsets[r + 1] = c->hRgOffsets[r] + n;
         }
@@ -2869,6 +2869,9 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
             for (uint32_t r = 0; r < nRg; ++r)
             {
                 const uint64_t n = c->hRgOffsets[r + 1] - c->hRgOffsets[r];
+                if (n != 0 && !c->hWalkDevSrc[r] && !wk->rg_entries[r])
+                    throw HipError{"a read group's entries were to be taken from an inflater's records on the device, which are not there (another GPU, "
+                                   "or POPDEL_HIP_WALK_SOURCES=0), and the host gave no table"};
                 c->hWalkSrc[r] = n != 0 && !c->hWalkDevSrc[r] && walkGatherWanted() ? deviceViewOfHost(wk->rg_entries[r], n * sizeof(uint2)) : 0u;
                 gathered += c->hWalkSrc[r] ? n : 0u;
             }
@@ -3051,6 +3054,11 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
 
 int pd_walk_active(pd_ctx * c, uint64_t * nActive, uint32_t * rg, uint32_t * start, int32_t * dev, uint32_t * id, uint64_t capacity)
 {
+    return pd_walk_active_ex(c, nActive, rg, start, dev, id, nullptr, capacity);
+}
+
+int pd_walk_active_ex(pd_ctx * c, uint64_t * nActive, uint32_t * rg, uint32_t * start, int32_t * dev, uint32_t * id, uint32_t * last, uint64_t capacity)
+{
     if (!c || !nActive)
         return fail(c, "pd_walk_active: invalid argument");
     *nActive = c->walkReady ? c->walkActive : 0;
@@ -3076,6 +3084,8 @@ int pd_walk_active(pd_ctx * c, uint64_t * nActive, uint32_t * rg, uint32_t * sta
             PD_HIP(hipMemcpy(start + at, b.aStart.p + base, n[r] * sizeof(uint32_t), hipMemcpyDeviceToHost));
             PD_HIP(hipMemcpy(dev + at, b.aDev.p + base, n[r] * sizeof(int32_t), hipMemcpyDeviceToHost));
             PD_HIP(hipMemcpy(id + at, b.aId.p + base, n[r] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            if (last)
+                PD_HIP(hipMemcpy(last + at, b.aLast.p + base, n[r] * sizeof(uint32_t), hipMemcpyDeviceToHost));
             for (uint32_t k = 0; k < n[r]; ++k)
                 rg[at + k] = r;
             at += n[r];

@@ -161,7 +161,7 @@ constexpr unsigned kParseLanes = 16;
 
 template <bool Write, bool Lean = false>
 __device__ __forceinline__ BlockCounts walkBlock(const uint8_t * p, const uint8_t * end, ParsedWindow * raws, CallWindow * wins,
-                                                 uint32_t * counts, uint2 * recs, uint32_t winBase, uint32_t recBase)
+                                                 uint32_t * counts, uint2 * recs, uint32_t winBase, uint32_t recBase, uint2 * span = nullptr)
 {
     BlockCounts c = {0, 0, 0, 0};
     while (p < end)
@@ -215,6 +215,11 @@ __device__ __forceinline__ BlockCounts walkBlock(const uint8_t * p, const uint8_
             reinterpret_cast<LeanWindow *>(raws)[c.raws] = LeanWindow{(int32_t)chrom, (int32_t)begin, recBase + c.recs, n, firstPos, prev};
         if ((prev - base) / 30u >= 10u)
             c.flags = 1;
+        if (!Write && span)
+        {
+            span->x = min(span->x, firstPos);
+            span->y = max(span->y, prev);
+        }
         ++c.raws;
         c.recs += n;
     }
@@ -223,17 +228,36 @@ __device__ __forceinline__ BlockCounts walkBlock(const uint8_t * p, const uint8_
 
 __global__ __launch_bounds__(kParseLanes) void parseCountKernel(const uint8_t * __restrict__ data, const uint64_t * __restrict__ outOff,
                                                        const uint64_t * __restrict__ outLen, const uint32_t * __restrict__ status,
-                                                       const uint8_t * __restrict__ wanted, uint32_t n, BlockCounts * __restrict__ counts)
+                                                       const uint8_t * __restrict__ wanted, uint32_t n, BlockCounts * __restrict__ counts,
+                                                       uint2 * __restrict__ spans)
 {
     const uint32_t m = blockIdx.x * kParseLanes + threadIdx.x;
     if (m >= n)
         return;
     BlockCounts c = {0, 0, 0, 2};
+    uint2 span = make_uint2(0xffffffffu, 0u);   // (smallest, largest start position among the block's records)
     if (wanted[m] && status[m] == 0 && outLen[m] == outOff[m + 1] - outOff[m])
-        c = walkBlock<false>(data + outOff[m], data + outOff[m] + outLen[m], nullptr, nullptr, nullptr, nullptr, 0, 0);
+        c = walkBlock<false>(data + outOff[m], data + outOff[m] + outLen[m], nullptr, nullptr, nullptr, nullptr, 0, 0, &span);
     if (c.flags)
         c.raws = c.wins = c.recs = 0;           // (nothing is written for a flagged block)
     counts[m] = c;
+    if (spans)
+        spans[m] = span;
+}
+
+// the kept blocks' records packed: range r = records [src[r], src[r] + n[r]) of the chunk's array -> packed[dst[r] ..)
+struct PackRange
+{
+    uint64_t src, dst;
+    uint32_t n, pad;
+};
+__global__ __launch_bounds__(256) void packRecordsKernel(const uint2 * __restrict__ recs, const PackRange * __restrict__ ranges, uint2 * __restrict__ packed)
+{
+    const PackRange r = ranges[blockIdx.x];
+    const uint2 * from = recs + r.src;
+    uint2 * to = packed + r.dst;
+    for (uint32_t i = threadIdx.x; i < r.n; i += 256u)
+        to[i] = from[i];
 }
 
 // exclusive scans of the three counts over the blocks (offsets[k][0 .. n]); one workgroup
@@ -439,6 +463,10 @@ struct pd_inflater
     void *hOffsets = nullptr, *hFlags = nullptr, *hRaws = nullptr, *hWins = nullptr, *hWinCounts = nullptr, *hRecs = nullptr;
     size_t capHOffsets = 0, capHFlags = 0, capHRaws = 0, capHWins = 0, capHWinCounts = 0, capHRecs = 0;
     uint64_t nRecsLast = 0;             // records the last parsed chunk left in dRecs
+    // records copied back for some blocks only (pd_summarize_options::keep_below / keep_from)
+    void *dSpans = nullptr, *hSpans = nullptr, *dRanges = nullptr, *hRanges = nullptr, *dPacked = nullptr;
+    size_t capDSpans = 0, capHSpans = 0, capDRanges = 0, capHRanges = 0, capDPacked = 0;
+    std::vector<uint64_t> recordIndex;
     // blocks summarised (pd_inflater_run_summarized): inner offsets up, summaries and counts back
     void *dInner = nullptr, *dSummaries = nullptr, *dBlockCounts = nullptr, *hSummaries = nullptr, *hBlockCounts = nullptr;
     size_t capDInner = 0, capDSummaries = 0, capDBlockCounts = 0, capHSummaries = 0, capHBlockCounts = 0;
@@ -516,10 +544,10 @@ extern "C" void pd_inflater_destroy(pd_inflater * f)
         return;
     (void)hipSetDevice(f->device);
     for (void * p : {f->dData, f->dOut, f->dInOff, f->dOutOff, f->dStatus, f->dLen, f->dWanted, f->dSampleFirst, f->dCounts, f->dOffsets, f->dRaws,
-                     f->dWins, f->dWinCounts, f->dRecs, f->dInner, f->dSummaries, f->dBlockCounts})
+                     f->dWins, f->dWinCounts, f->dRecs, f->dInner, f->dSummaries, f->dBlockCounts, f->dSpans, f->dRanges, f->dPacked})
         if (p)
             (void)hipFree(p);
-    for (void * p : {f->hIn, f->hOut, f->hMeta, f->hOffsets, f->hFlags, f->hRaws, f->hWins, f->hWinCounts, f->hRecs, f->hSummaries, f->hBlockCounts})
+    for (void * p : {f->hIn, f->hOut, f->hMeta, f->hOffsets, f->hFlags, f->hRaws, f->hWins, f->hWinCounts, f->hRecs, f->hSummaries, f->hBlockCounts, f->hSpans, f->hRanges})
         if (p)
             pd::pinnedFree(p);
     for (hipEvent_t e : {f->finished, f->timeBegin, f->timeEnd})
@@ -550,7 +578,8 @@ extern "C" uint8_t * pd_inflater_input(pd_inflater * f, uint64_t bytes)
 static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_t n_members, const uint64_t * out_offsets,
                        const uint32_t * sample_first, const uint8_t * parse_member, const uint8_t ** out, const uint32_t ** status,
                        const uint64_t ** out_lengths, pd_parsed_blocks * parsed, double * kernel_ms, const int32_t * inner_offset = nullptr,
-                       uint32_t starts_room = 0, uint32_t ends_room = 0, pd_block_summaries * summaries = nullptr, uint32_t lean = 0)
+                       uint32_t starts_room = 0, uint32_t ends_room = 0, pd_block_summaries * summaries = nullptr, uint32_t lean = 0,
+                       const uint32_t * keep_below = nullptr, const uint32_t * keep_from = nullptr)
 {
     if (!f || !member_offsets || !out_offsets || !out || !status || !out_lengths || n_members == 0 || (parsed && (!sample_first || !parse_member)))
         return 1;
@@ -620,14 +649,22 @@ static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_
             PD_INF_HIP(hipMemcpyAsync(f->dWanted, parse_member, n_members, hipMemcpyHostToDevice, st));
             PD_INF_HIP(hipMemcpyAsync(f->dSampleFirst, sample_first, static_cast<size_t>(n_members) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             uint64_t * dRawOff = static_cast<uint64_t *>(f->dOffsets), *dWinOff = dRawOff + n_members + 1, *dRecOff = dWinOff + n_members + 1;
+            const bool partial = summaries && keep_below && keep_from;
+            if (partial)
+            {
+                growDevice(f->dSpans, f->capDSpans, static_cast<size_t>(n_members) * sizeof(uint2));
+                growPinned(f->hSpans, f->capHSpans, static_cast<size_t>(n_members) * sizeof(uint2));
+            }
             hipLaunchKernelGGL(parseCountKernel, dim3((n_members + kParseLanes - 1) / kParseLanes), dim3(kParseLanes), 0, st, static_cast<const uint8_t *>(f->dOut),
                                static_cast<const uint64_t *>(f->dOutOff), static_cast<const uint64_t *>(f->dLen),
                                static_cast<const uint32_t *>(f->dStatus), static_cast<const uint8_t *>(f->dWanted), n_members,
-                               static_cast<BlockCounts *>(f->dCounts));
+                               static_cast<BlockCounts *>(f->dCounts), partial ? static_cast<uint2 *>(f->dSpans) : nullptr);
             hipLaunchKernelGGL(parseScanKernel, dim3(1), dim3(256), 0, st, static_cast<const BlockCounts *>(f->dCounts), n_members, dRawOff, dWinOff, dRecOff);
             PD_INF_HIP(hipGetLastError());
             PD_INF_HIP(hipMemcpyAsync(f->hOffsets, f->dOffsets, 3 * (static_cast<size_t>(n_members) + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
             PD_INF_HIP(hipMemcpyAsync(f->hFlags, f->dCounts, static_cast<size_t>(n_members) * sizeof(BlockCounts), hipMemcpyDeviceToHost, st));
+            if (partial)
+                PD_INF_HIP(hipMemcpyAsync(f->hSpans, f->dSpans, static_cast<size_t>(n_members) * sizeof(uint2), hipMemcpyDeviceToHost, st));
             PD_INF_HIP(hipEventRecord(f->finished, st));
             PD_INF_HIP(hipEventSynchronize(f->finished));
             const uint64_t * hRawOff = static_cast<const uint64_t *>(f->hOffsets), *hWinOff = hRawOff + n_members + 1, *hRecOff = hWinOff + n_members + 1;
@@ -637,7 +674,28 @@ static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_
             growDevice(f->dRaws, f->capRaws, std::max<uint64_t>(1, nRaws) * rawBytes);
             growDevice(f->dRecs, f->capRecs, std::max<uint64_t>(1, nRecs) * sizeof(uint2));
             growPinned(f->hRaws, f->capHRaws, std::max<uint64_t>(1, nRaws) * rawBytes);
-            growPinned(f->hRecs, f->capHRecs, std::max<uint64_t>(1, nRecs) * sizeof(uint2));
+            // which blocks' records go back: all, or those with a record below keep_below / at or beyond keep_from
+            uint64_t nBack = nRecs;
+            std::vector<PackRange> ranges;
+            if (partial)
+            {
+                const uint2 * span = static_cast<const uint2 *>(f->hSpans);
+                f->recordIndex.assign(n_members, ~static_cast<uint64_t>(0));
+                nBack = 0;
+                for (uint32_t m = 0; m < n_members; ++m)
+                {
+                    const uint64_t n = hRecOff[m + 1] - hRecOff[m];
+                    if (n == 0 || !(span[m].x < keep_below[m] || span[m].y >= keep_from[m]))
+                        continue;
+                    f->recordIndex[m] = nBack;
+                    if (!ranges.empty() && ranges.back().src + ranges.back().n == hRecOff[m] && ranges.back().n + n < 0x7fffffffu)
+                        ranges.back().n += static_cast<uint32_t>(n);
+                    else
+                        ranges.push_back(PackRange{hRecOff[m], nBack, static_cast<uint32_t>(n), 0u});
+                    nBack += n;
+                }
+            }
+            growPinned(f->hRecs, f->capHRecs, std::max<uint64_t>(1, nBack) * sizeof(uint2));
             if (!lean)
             {
                 growDevice(f->dWins, f->capWins, std::max<uint64_t>(1, nWins) * sizeof(CallWindow));
@@ -657,11 +715,19 @@ static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_
                 PD_INF_HIP(hipMemcpyAsync(f->hWins, f->dWins, nWins * sizeof(CallWindow), hipMemcpyDeviceToHost, st));
                 PD_INF_HIP(hipMemcpyAsync(f->hWinCounts, f->dWinCounts, nWins * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             }
-            PD_INF_HIP(hipMemcpyAsync(f->hRecs, f->dRecs, nRecs * sizeof(uint2), hipMemcpyDeviceToHost, st));
+            if (!partial)
+                PD_INF_HIP(hipMemcpyAsync(f->hRecs, f->dRecs, nRecs * sizeof(uint2), hipMemcpyDeviceToHost, st));
+            else if (!ranges.empty())
             {
-                static const int extra = [] { const char * e = std::getenv("POPDEL_EXPERIMENT_D2H_EXTRA"); return e ? std::atoi(e) : 0; }();
-                for (int k = 0; k < extra; ++k)     // (measurement: is the copy back what a round waits for?)
-                    PD_INF_HIP(hipMemcpyAsync(f->hRecs, f->dRecs, nRecs * sizeof(uint2), hipMemcpyDeviceToHost, st));
+                growDevice(f->dRanges, f->capDRanges, ranges.size() * sizeof(PackRange));
+                growPinned(f->hRanges, f->capHRanges, ranges.size() * sizeof(PackRange));
+                growDevice(f->dPacked, f->capDPacked, nBack * sizeof(uint2));
+                std::memcpy(f->hRanges, ranges.data(), ranges.size() * sizeof(PackRange));
+                PD_INF_HIP(hipMemcpyAsync(f->dRanges, f->hRanges, ranges.size() * sizeof(PackRange), hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(packRecordsKernel, dim3(static_cast<unsigned>(ranges.size())), dim3(256), 0, st, static_cast<const uint2 *>(f->dRecs),
+                                   static_cast<const PackRange *>(f->dRanges), static_cast<uint2 *>(f->dPacked));
+                PD_INF_HIP(hipGetLastError());
+                PD_INF_HIP(hipMemcpyAsync(f->hRecs, f->dPacked, nBack * sizeof(uint2), hipMemcpyDeviceToHost, st));
             }
             if (summaries)
             {
@@ -683,6 +749,7 @@ static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_
                 summaries->block_counts = static_cast<const uint8_t *>(f->hBlockCounts);
                 summaries->starts_room = starts_room;
                 summaries->ends_room = ends_room;
+                summaries->record_index = partial ? f->recordIndex.data() : nullptr;
             }
             // the inflated bytes themselves travel only if some block is left to the host's parser
             const BlockCounts * fl = static_cast<const BlockCounts *>(f->hFlags);
@@ -745,14 +812,14 @@ extern "C" int pd_inflater_run_parsed(pd_inflater * f, const uint64_t * member_o
 }
 
 extern "C" int pd_inflater_run_summarized(pd_inflater * f, const uint64_t * member_offsets, uint32_t n_members, const uint64_t * out_offsets,
-                                          const uint32_t * sample_first, const uint8_t * parse_member, const int32_t * inner_offset,
-                                          uint32_t starts_room, uint32_t ends_room, uint32_t lean, const uint8_t ** out, const uint32_t ** status,
-                                          const uint64_t ** out_lengths, pd_parsed_blocks * parsed, pd_block_summaries * summaries, double * kernel_ms)
+                                          const uint32_t * sample_first, const uint8_t * parse_member, const pd_summarize_options * opt,
+                                          const uint8_t ** out, const uint32_t ** status, const uint64_t ** out_lengths, pd_parsed_blocks * parsed,
+                                          pd_block_summaries * summaries, double * kernel_ms)
 {
-    if (!parsed || !summaries)
+    if (!parsed || !summaries || !opt || ((opt->keep_below == nullptr) != (opt->keep_from == nullptr)))
         return 1;
     return runInflater(f, member_offsets, n_members, out_offsets, sample_first, parse_member, out, status, out_lengths, parsed, kernel_ms,
-                       inner_offset, starts_room, ends_room, summaries, lean);
+                       opt->inner_offset, opt->starts_room, opt->ends_room, summaries, opt->lean, opt->keep_below, opt->keep_from);
 }
 
 extern "C" const char * pd_inflate_last_error(void) { return g_inflateError.c_str(); }

@@ -147,6 +147,33 @@ struct LeanRaw
 };
 static_assert(sizeof(DecodedRaw) == 20 && sizeof(FlatWindow) == 12 && sizeof(PairRecord) == 8 && sizeof(LeanRaw) == 24, "layouts shared with the device's parser");
 
+// Records [first, first + count) of a sample's stream (count >= 1) where the host has them, else nullptr. `recs`: the sample's
+// records when all were copied back (recIndex == nullptr); else the records are those of the blocks recIndex does not mark ~0,
+// packed (pd_summarize_options::keep_below / keep_from): block b = records [blockRecs[b], blockRecs[b + 1]) of the chunk, kept
+// blocks that follow each other lie one behind the other at packed + recIndex[b].
+inline const PairRecord * recordsOf(const PairRecord * recs, const PairRecord * packed, const uint64_t * recIndex, const uint64_t * blockRecs,
+                                    size_t nBlocks, uint32_t first, uint32_t count)
+{
+    if (!recIndex)
+        return recs + first;
+    const uint64_t a = blockRecs[0] + first, b = a + count - 1;
+    size_t j = static_cast<size_t>(std::upper_bound(blockRecs, blockRecs + nBlocks + 1, a) - blockRecs);
+    if (j == 0 || j > nBlocks)
+        return nullptr;
+    --j;                                    // (the block that holds record a)
+    if (recIndex[j] == ~static_cast<uint64_t>(0))
+        return nullptr;
+    const PairRecord * p = packed + recIndex[j] + (a - blockRecs[j]);
+    for (; blockRecs[j + 1] <= b; ++j)      // (... and every block up to the one that holds record b)
+    {
+        if (j + 1 >= nBlocks)
+            return nullptr;
+        if (blockRecs[j + 2] != blockRecs[j + 1] && recIndex[j + 1] == ~static_cast<uint64_t>(0))
+            return nullptr;
+    }
+    return p;
+}
+
 struct alignas(64) DecodedStream      // (neighbours in the pool are filled by different threads: no shared cache lines)
 {
     std::vector<DecodedRaw> raws;
@@ -175,6 +202,10 @@ struct alignas(64) DecodedStream      // (neighbours in the pool are filled by d
     uint32_t startsRoom = 0, endsRoom = 0;
     pd_inflater * inflater = nullptr;          // the inflater whose device buffers hold the same records, recsV[0] at index recBase
     uint64_t recBase = 0;
+    // (records copied back for the blocks at the two ends only: recsV is null, see recordsOf())
+    const uint64_t * recIndex = nullptr;
+    const PairRecord * recsPacked = nullptr;
+    const PairRecord * records(uint32_t first, uint32_t count) const { return recordsOf(recsV, recsPacked, recIndex, blockRecs, nBlocks, first, count); }
     void viewOwn()
     {
         rawsV = raws.data();
@@ -209,6 +240,8 @@ struct alignas(64) DecodedStream      // (neighbours in the pool are filled by d
         startsRoom = endsRoom = 0;
         inflater = nullptr;
         recBase = 0;
+        recIndex = nullptr;
+        recsPacked = nullptr;
     }
 };
 
@@ -225,6 +258,7 @@ struct ReplayState
     unsigned code = 0;
     bool     haveRun = false;
     uint32_t runFirst = 0, runCount = 0;
+    uint32_t runFirstWindow = 0;        // the 30-bp window (position) of the run's first record
 };
 
 // The loader's blocks on the device (round 4). Which samples read in a round, from where and up to where is known when the
@@ -248,6 +282,7 @@ public:
         bool parse = false;             // one read group: the device parses the blocks as well
         uint32_t firstRegion = 0;       // beginPos / the file's index region size: what the index jump depends on
         int32_t innerOffset = 0;        // parse: median - 2 * read length of that read group (a pair ends at position + max(0, deviation + this))
+        uint32_t keepBelow = 0xffffffffu, keepFrom = 0;     // records come back for blocks with a record below / at or beyond (edgesOnly)
     };
     struct Ready
     {
@@ -274,6 +309,9 @@ public:
         uint32_t startsRoom = 0, endsRoom = 0;
         pd_inflater * inflater = nullptr;           // whose device buffers hold the records as well (recs[0] = record recBase there)
         uint64_t recBase = 0;
+        const uint64_t * recIndex = nullptr;        // records copied back for some blocks only (recs is null then): recordsOf()
+        const PairRecord * recsPacked = nullptr;
+        const PairRecord * records(uint32_t first, uint32_t count) const { return recordsOf(recs, recsPacked, recIndex, blockRecs, nBlocks, first, count); }
         // (adopt(): the reader's jump lands `skip` index regions behind the guess -> its stream begins at a later block)
         const uint64_t * rawsByBlock = nullptr;      // first 256-bp window of each of the sample's blocks (and one past)
         const uint64_t * bytesByBlock = nullptr;     // first inflated byte of each
@@ -464,6 +502,7 @@ public:
     bool summariesWanted = false;
     uint32_t startsRoom = 0, endsRoom = 0;
     bool leanWanted = false;            // ... and the 30-bp windows not written out (LeanRaw; POPDEL_FULL_PARSE=1 keeps them)
+    bool edgesOnly = false;             // ... and records copied back for the blocks at the two ends of a sample's stretch only (Item::keepBelow / keepFrom)
     std::vector<int> fds_;              // descriptorOf()
 
 private:
@@ -478,6 +517,7 @@ private:
         std::vector<uint32_t> firstMember, sampleFirst;
         std::vector<uint8_t> parseMember;
         std::vector<int32_t> innerOffset;       // per member: median - 2 * read length of its (one) read group (block summaries)
+        std::vector<uint32_t> keepBelow, keepFrom;
         uint64_t bytes = 0;
         double seconds = 0;
     };
@@ -676,6 +716,8 @@ private:
                     j.sampleFirst.push_back(firstMember[k]);
                     j.parseMember.push_back(items_[lo + k].parse && parseOnDevice_ ? 1 : 0);
                     j.innerOffset.push_back(items_[lo + k].innerOffset);
+                    j.keepBelow.push_back(items_[lo + k].keepBelow);
+                    j.keepFrom.push_back(items_[lo + k].keepFrom);
                 }
             }
             if (!fine)
@@ -686,6 +728,8 @@ private:
                 j.sampleFirst.resize(firstMember[k]);
                 j.parseMember.resize(firstMember[k]);
                 j.innerOffset.resize(firstMember[k]);
+                j.keepBelow.resize(firstMember[k]);
+                j.keepFrom.resize(firstMember[k]);
                 good[k] = 0;
             }
             else
@@ -720,11 +764,19 @@ private:
         std::memset(&sums, 0, sizeof(sums));
         const bool haveSums = summariesWanted && parseOnDevice_;
         const bool lean = haveSums && leanWanted;
+        const bool partial = lean && edgesOnly;
         if (haveSums)
         {
+            pd_summarize_options opt;
+            std::memset(&opt, 0, sizeof(opt));
+            opt.inner_offset = j.innerOffset.data();
+            opt.starts_room = startsRoom;
+            opt.ends_room = endsRoom;
+            opt.lean = lean ? 1u : 0u;
+            opt.keep_below = partial ? j.keepBelow.data() : nullptr;
+            opt.keep_from = partial ? j.keepFrom.data() : nullptr;
             if (pd_inflater_run_summarized(inf, j.inOff.data(), static_cast<uint32_t>(j.inOff.size() - 1), j.outOff.data(), j.sampleFirst.data(),
-                                           j.parseMember.data(), j.innerOffset.data(), startsRoom, endsRoom, lean ? 1u : 0u, &out, &status, &lengths, &pb,
-                                           &sums, &ms) != 0)
+                                           j.parseMember.data(), &opt, &out, &status, &lengths, &pb, &sums, &ms) != 0)
                 throw ProfileError("pd_inflater_run_summarized failed");
         }
         else if (pd_inflater_run_parsed(inf, j.inOff.data(), static_cast<uint32_t>(j.inOff.size() - 1), j.outOff.data(), j.sampleFirst.data(),
@@ -773,7 +825,14 @@ private:
                     r.wins = static_cast<const FlatWindow *>(pb.call_windows) + pb.call_window_offsets[m0];
                     r.counts = pb.call_window_records + pb.call_window_offsets[m0];
                 }
-                r.recs = static_cast<const PairRecord *>(pb.records) + pb.record_offsets[m0];
+                if (haveSums && sums.record_index)
+                {
+                    r.recs = nullptr;
+                    r.recIndex = sums.record_index + m0;
+                    r.recsPacked = static_cast<const PairRecord *>(pb.records);
+                }
+                else
+                    r.recs = static_cast<const PairRecord *>(pb.records) + pb.record_offsets[m0];
                 r.nRecs = static_cast<size_t>(pb.record_offsets[m1] - pb.record_offsets[m0]);
                 r.inflater = inf;
                 r.recBase = pb.record_offsets[m0];
@@ -856,8 +915,11 @@ public:
             std::cerr << "[popdel walk check] " << walkChecked_ << " segments planned in closed form and found equal to the walk, "
                       << walkUnchecked_ << " not planned" << std::endl;
     }
+    uint64_t profile_materialized_ = 0;
     void printTiming()
     {
+        if (profile_)
+            profile_materialized_ = profile_->materialized();
         if (getenv("POPDEL_TIMING") && !timingPrinted_)
             std::cerr << "[popdel timing] window loop: " << deviceSegments_ << " segments in closed form on the device, " << hostSegments_
                       << " walked on the host" << std::endl;
@@ -878,7 +940,8 @@ public:
                           << " bytes; gather " << a.gatherSeconds + b.gatherSeconds << " s, copies + kernel " << a.runSeconds + b.runSeconds << " s (kernel "
                           << (a.kernelMs + b.kernelMs) / 1e3 << " s); decoder threads waited " << a.waitSeconds + b.waitSeconds << " thread-seconds for it; " << roundsAhead_
                           << " rounds fetched ahead, " << roundsOnDemand_ << " when they began (" << roundsGuessedWrong_ << " of them after a wrong guess); read by the decoder threads all the same: "
-                          << hostDecodes_[0].load() << " sample rounds without usable blocks, " << hostDecodes_[1].load() << " whose parsed blocks ended early" << std::endl;
+                          << hostDecodes_[0].load() << " sample rounds without usable blocks, " << hostDecodes_[1].load() << " whose parsed blocks ended early, "
+                          << hostDecodes_[2].load() << " whose records at an end of the round had stayed on the device" << std::endl;
             }
             if (!ctxs_.empty() && ctxs_[0])
             {
@@ -896,7 +959,9 @@ public:
             }
             std::cerr << "[popdel timing] filing: " << filedRecords_.load() << " records of one-read-group files filed in runs, " << bulkRecords_.load()
                       << " of them from the device's block summaries (" << bulkRuns_.load() << " runs; " << bulkRefused_.load()
-                      << " refused by the tables, " << bulkNone_.load() << " without enough usable blocks)" << std::endl;
+                      << " refused by the tables, " << bulkNone_.load() << " without enough usable blocks); " << virtualRecords_.load()
+                      << " start entries never left the device, " << profile_materialized_ << " of them were read again from the profiles for the tables, "
+                      << runsReadAgain_.load() << " runs for records that had stayed there" << std::endl;
             std::cerr << "[popdel timing] parity: " << nearIntegerShifts_ << " reference-shift quotients within 1e-9 of an integer (their truncation "
                          "may differ from the x87 reference's) in " << candidateCells_ << " candidate cells, " << windowCalls_ << " window calls" << std::endl;
             // steady state: the rounds that began after the backend was up, to the end of the loop (last results written)
@@ -954,12 +1019,31 @@ private:
     bool firstWindowOnNextRoi(Coord & minCoord);
     bool checkAndSwitch(const std::vector<unsigned> & rg, unsigned beginPos, unsigned * border);
     void decodeSample(unsigned i, const std::string & coordContig, unsigned border, unsigned numWindows, DecodedStream & out) const;
-    unsigned replaySegment(const DecodedStream & in, const std::string & fileName, const std::vector<unsigned> & rg,
-                           const std::vector<std::string> & contigNames, Coord & coordinate, const Region & roi, unsigned * border);
+    unsigned replaySegment(unsigned sample, const DecodedStream & in, const std::vector<std::string> & contigNames, Coord & coordinate,
+                           const Region & roi, unsigned * border);
     bool replayAdvance(ReplayState & st, const DecodedStream & in, const std::string & fileName, const std::vector<unsigned> & rg,
                        const std::vector<std::string> & contigNames, Coord & coordinate, const Region & roi, unsigned * border);
     // runs filed from the summaries the device takes of the parsed blocks (round 6)
     void fileRun(unsigned sample, const DecodedStream & in, const ReplayState & st);
+    void readRunFromProfile(unsigned sample, const std::string & contig, uint32_t jumpPos, uint32_t firstWindow, uint64_t skip, uint64_t n,
+                            StartEntry * dst) const;
+    // (virtual runs of start entries: which contig a round files -- the note ChromProfile hands back to refill)
+    std::vector<std::string> contigTable_;
+    std::string roundContig_;
+    uint32_t roundContigTag_ = 0;
+    std::vector<unsigned> sampleOfRg_;
+    std::atomic<uint64_t> virtualRecords_{0}, runsReadAgain_{0};
+    bool edgesOnly_ = false;                        // the loaders copy records back for the blocks at a stretch's two ends only
+    // Which blocks' records a loader copies back when the middle of a stretch stays on the device: those with a record below the
+    // begin + two index regions (the run's head: the blocks it begins in the middle of, and the first whole one) and those with a
+    // record within an index region and the longest plausible pair of the end (the block in which the first pair reaches the
+    // write slot's border, and what follows). A run that needs more reads it again from the profile (fileRun).
+    void setKeepLimits(GunzipPrefetch::Item & it, unsigned sample) const
+    {
+        const int64_t region = p_.indexRegionSizes[p_.representativeContigs ? 0 : sample];
+        it.keepBelow = static_cast<uint32_t>(std::min<int64_t>(static_cast<int64_t>(it.beginPos) + 2 * region + 512, 0xffffffffll));
+        it.keepFrom = static_cast<uint32_t>(std::max<int64_t>(static_cast<int64_t>(it.endPos) - 256 - region - 2048, 0));
+    }
     int32_t innerOffsetOf(unsigned sample) const
     {
         const InsertHistogram & h = p_.histograms[p_.rgs[sample][0]];
@@ -1058,7 +1142,7 @@ private:
     size_t regionsOffered_ = 0;             // regions of the table pool the backend has been told of (hand-over thread)
     // sample rounds the decoder threads read themselves although a loader ran: [0] it had nothing usable for the sample, [1] its
     // parsed blocks end before the point at which the round's reader stops
-    mutable std::atomic<uint64_t> hostDecodes_[2] = {};
+    mutable std::atomic<uint64_t> hostDecodes_[3] = {};     // ([2]: a window at an end of the round whose records had not been copied back)
     void startGunzipPrefetch();
     void startLoaderAhead();
     void createLoaders();
@@ -1455,6 +1539,7 @@ void CallRun::startGunzipPrefetch()
         // (the decoder stops at the first window at or beyond the border; 256-bp windows may begin up to 255 bp before it)
         const int64_t end = std::min<int64_t>(static_cast<int64_t>(st.slots[st.writeSlot].right) + 256, static_cast<int64_t>(roi.endPos) + 256);
         it.endPos = static_cast<int32_t>(std::min<int64_t>(end, 0x7fffffff));
+        setKeepLimits(it, i);
         if (it.endPos >= it.beginPos)
         {
             items.push_back(it);
@@ -1518,6 +1603,7 @@ void CallRun::startGunzipPrefetch()
         it.beginPos = static_cast<int32_t>(nextBegin);
         it.firstRegion = static_cast<uint32_t>(nextBegin) / p_.indexRegionSizes[p_.representativeContigs ? 0 : i];
         it.endPos = static_cast<int32_t>(nextEnd);
+        setKeepLimits(it, i);
         if (it.endPos >= it.beginPos)
             guess.push_back(it);
     }
@@ -1551,6 +1637,12 @@ void CallRun::createLoaders()
         g->summariesWanted = deviceWalkOffered_ && !getenv("POPDEL_HEAVY_TABLES") && !getenv("POPDEL_HOST_FILING") && region != 0 &&
                              g->startsRoom + g->endsRoom <= 12000u;
         g->leanWanted = !getenv("POPDEL_FULL_PARSE");
+        // (... and the records of the blocks in the middle of a stretch stay on the device: one context on the loaders' GPU, whose
+        // window loop takes its entries from there; POPDEL_HOST_RECORDS=1 copies every record back as before)
+        const char * src = getenv("POPDEL_HIP_WALK_SOURCES");
+        g->edgesOnly = g->summariesWanted && g->leanWanted && ctxs_.size() == 1 && gunzipDevices_.size() == 1 && !getenv("POPDEL_HOST_RECORDS") &&
+                       !getenv("POPDEL_COPY_HAND_OVER") && !(src && src[0] == '0');
+        edgesOnly_ = g->edgesOnly;
     }
     const char * ahead = getenv("POPDEL_LOADER_AHEAD");
     loaderAhead_ = !(ahead && ahead[0] == '0');
@@ -1606,7 +1698,7 @@ void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned
         // The device's lean arrays: the same scan, a 256-bp window taken by the positions of its first and last record where
         // that decides it, window by window over its records where not.
         size_t r0 = 0, r = 0;
-        bool stopped = false;
+        bool stopped = false, missed = false;
         int32_t coordChrom = -1, roiChrom = -1, otherChrom = -1;
         for (; r < pre->nRaws && !stopped; ++r)
         {
@@ -1639,9 +1731,15 @@ void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned
             if (raw.chrom == roiChrom && static_cast<int64_t>(head) >= roi.beginPos && static_cast<int64_t>(tail) < roi.endPos && tail < border && head <= tail)
                 continue;
             uint32_t last = 0xffffffffu;
-            for (uint32_t k = raw.firstRec; k < raw.firstRec + raw.nRecs; ++k)
+            const PairRecord * rr = pre->records(raw.firstRec, raw.nRecs);
+            if (!rr)
             {
-                const uint32_t wb = pre->recs[k].pos / 30u * 30u;
+                missed = true;                  // (its records were not copied back: the guess of where the round's ends lie was off)
+                break;
+            }
+            for (uint32_t k = 0; k < raw.nRecs; ++k)
+            {
+                const uint32_t wb = rr[k].pos / 30u * 30u;
                 if (wb == last)
                     continue;
                 last = wb;
@@ -1666,8 +1764,10 @@ void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned
             if (stopped)
                 break;
         }
-        const bool atEnd = !stopped && pre->toFileEnd;
-        if (stopped || atEnd)
+        const bool atEnd = !stopped && !missed && pre->toFileEnd;
+        if (missed)
+            ++hostDecodes_[2];
+        if (!missed && (stopped || atEnd))
         {
             out.eof = atEnd;
             out.leanV = pre->lean + r0;
@@ -1682,9 +1782,12 @@ void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned
             out.endsRoom = pre->endsRoom;
             out.inflater = pre->inflater;
             out.recBase = pre->recBase;
+            out.recIndex = pre->recIndex;
+            out.recsPacked = pre->recsPacked;
             return;
         }
-        ++hostDecodes_[1];
+        if (!missed)
+            ++hostDecodes_[1];
         out.sawFarWindow = false;           // (decoded again below)
         border = borderIn;
         if (!pre->bytesValid)
@@ -1866,8 +1969,15 @@ bool CallRun::replayAdvance(ReplayState & st, const DecodedStream & in, const st
     if (in.leanV)
     {
         // ---- the device's lean arrays (one read group): the same loop with the 30-bp windows read off the records. st.wi is the
-        // index of the next record to look at (in the sample's stream).
+        // index of the next record to look at (in the sample's stream). Records are read only in 256-bp windows that do not pass
+        // as a whole -- the ones at the two ends of what the round files, whose records decodeSample() found copied back.
         const StartSlots & sst = prof.starts[rg[0]];
+        auto recordsOfRaw = [&](const LeanRaw & raw) {
+            const PairRecord * rr = in.records(raw.firstRec, raw.nRecs);
+            if (!rr)
+                throw ProfileError("[PopDel] Internal error: the records of a window at an end of the round (\"" + fileName + "\") were not copied back from the device.");
+            return rr - raw.firstRec;           // (indexed by the record's number in the stream)
+        };
         while (!st.finished)
         {
             if (!st.inRaw)
@@ -1901,57 +2011,73 @@ bool CallRun::replayAdvance(ReplayState & st, const DecodedStream & in, const st
                 ++st.rawIdx;
                 continue;
             }
-            // the 30-bp window of record st.wi: its records are [st.wi, we)
-            const uint32_t wb = in.recsV[st.wi].pos / 30u * 30u;
-            uint32_t we = st.wi + 1;
-            while (we < endOfThis && in.recsV[we].pos / 30u * 30u == wb)
-                ++we;
-            if (!st.onRoiContig || static_cast<int64_t>(wb) >= roi.endPos)
+            unsigned right = sst.slots[sst.writeSlot].right;
+            auto passes = [&](uint32_t pos) {
+                const uint32_t b = pos / 30u * 30u;
+                return static_cast<int64_t>(b) >= roi.beginPos && static_cast<int64_t>(b) < roi.endPos && b < right;
+            };
+            auto passesWhole = [&](const LeanRaw & x) { return passes(x.firstPos) && passes(x.lastPos) && x.firstPos <= x.lastPos; };
+            uint32_t j;                         // the run will be records [st.wi, j)
+            const PairRecord * rr = nullptr;    // the records of the 256-bp window the loop stands in, if they are looked at
+            if (st.wi == raw.firstRec && st.onRoiContig && passesWhole(raw))
             {
-                prof.performPartialSwitches(rg, border);
-                coordinate.contig = contigNames[raw.chrom];
-                coordinate.pos = wb;
-                return stop(2);
+                // (all its 30-bp windows begin inside the region and below the write slot's border: nothing stops the loader, the
+                // run begins with its first record)
+                j = endOfThis;
+                st.runFirstWindow = raw.firstPos / 30u * 30u;
             }
-            if (static_cast<int64_t>(wb) < roi.beginPos)
+            else
             {
-                st.wi = we;
-                continue;
-            }
-            if (sst.tooBigForNext(wb))
-            {
-                if (prof.allEmpty())
+                rr = recordsOfRaw(raw);
+                // the 30-bp window of record st.wi: its records are [st.wi, we)
+                const uint32_t wb = rr[st.wi].pos / 30u * 30u;
+                uint32_t we = st.wi + 1;
+                while (we < endOfThis && rr[we].pos / 30u * 30u == wb)
+                    ++we;
+                if (!st.onRoiContig || static_cast<int64_t>(wb) >= roi.endPos)
                 {
-                    prof.resetTo(wb);
+                    prof.performPartialSwitches(rg, border);
+                    coordinate.contig = contigNames[raw.chrom];
+                    coordinate.pos = wb;
+                    return stop(2);
                 }
-                else
+                if (static_cast<int64_t>(wb) < roi.beginPos)
+                {
+                    st.wi = we;
+                    continue;
+                }
+                if (sst.tooBigForNext(wb))
+                {
+                    if (prof.allEmpty())
+                    {
+                        prof.resetTo(wb);
+                        right = sst.slots[sst.writeSlot].right;
+                    }
+                    else
+                    {
+                        prof.performPartialSwitches(rg, border);
+                        coordinate.contig = contigNames[raw.chrom];
+                        coordinate.pos = wb;
+                        return stop(0);
+                    }
+                }
+                else if (sst.needsSwitch(wb))
                 {
                     prof.performPartialSwitches(rg, border);
                     coordinate.contig = contigNames[raw.chrom];
                     coordinate.pos = wb;
                     return stop(0);
                 }
+                j = we;
+                st.runFirstWindow = wb;
             }
-            else if (sst.needsSwitch(wb))
-            {
-                prof.performPartialSwitches(rg, border);
-                coordinate.contig = contigNames[raw.chrom];
-                coordinate.pos = wb;
-                return stop(0);
-            }
-            // the run: this window's records and those of the windows behind it that pass as well (see below for the full form)
-            const unsigned right = sst.slots[sst.writeSlot].right;
-            auto passes = [&](uint32_t pos) {
-                const uint32_t b = pos / 30u * 30u;
-                return static_cast<int64_t>(b) >= roi.beginPos && static_cast<int64_t>(b) < roi.endPos && b < right;
-            };
-            uint32_t j = we;
+            // the run: these records and those of the windows behind them that pass as well (see the full form below)
             size_t rj = st.rawIdx;
             uint32_t endOfRaw = endOfThis;
             int32_t knownChrom = raw.chrom;         // (its name equals coordinate.contig and roi.seqName)
             for (;;)
             {
-                while (j < endOfRaw && passes(in.recsV[j].pos))
+                while (j < endOfRaw && passes(rr[j].pos))      // (j < endOfRaw only inside a window whose records are at hand)
                     ++j;
                 if (j < endOfRaw)
                     break;
@@ -1969,12 +2095,13 @@ bool CallRun::replayAdvance(ReplayState & st, const DecodedStream & in, const st
                     }
                     ++rj;
                     endOfRaw = nx.firstRec + nx.nRecs;
-                    if (passes(nx.firstPos) && passes(nx.lastPos) && nx.firstPos <= nx.lastPos)
+                    if (passesWhole(nx))
                     {
                         j = endOfRaw;
                         continue;
                     }
                     j = nx.firstRec;
+                    rr = recordsOfRaw(nx);
                     more = true;                    // (record by record through this one)
                     break;
                 }
@@ -2120,6 +2247,7 @@ bool CallRun::replayAdvance(ReplayState & st, const DecodedStream & in, const st
             st.haveRun = true;
             st.runFirst = firstRec;
             st.runCount = endRec - firstRec;
+            st.runFirstWindow = static_cast<uint32_t>(w.beginPos);
             // (the loop goes on at window wj of 256-bp window rj)
             st.rawIdx = rj;
             st.wi = wj;
@@ -2140,51 +2268,105 @@ bool CallRun::replayAdvance(ReplayState & st, const DecodedStream & in, const st
     return false;
 }
 
-// The whole loop, every run filed record by record as it is found (batches that are replayed in order; the reference's sequence).
-unsigned CallRun::replaySegment(const DecodedStream & in, const std::string & fileName, const std::vector<unsigned> & rg,
-                                const std::vector<std::string> & contigNames, Coord & coordinate, const Region & roi, unsigned * border)
+// The whole loop for one sample, every run filed as it is found (batches that are replayed in order: the reference's sequence).
+unsigned CallRun::replaySegment(unsigned sample, const DecodedStream & in, const std::vector<std::string> & contigNames, Coord & coordinate,
+                                const Region & roi, unsigned * border)
 {
     ReplayState st;
-    if (rg.size() == 1)
-        profile_->reserveRun(rg[0], in.nRecsV);
-    while (replayAdvance(st, in, fileName, rg, contigNames, coordinate, roi, border))
-    {
-        slotSource_[rg[0]].inflater = nullptr;
-        const InsertHistogram & h = p_.histograms[rg[0]];
-        profile_->addRun(rg[0], reinterpret_cast<const uint32_t *>(in.recsV + st.runFirst), st.runCount,
-                         static_cast<int>(h.median) - 2 * static_cast<int>(h.readLength));
-    }
+    while (replayAdvance(st, in, p_.inputFiles[sample], p_.rgs[sample], contigNames, coordinate, roi, border))
+        fileRun(sample, in, st);
     return st.code;
+}
+
+// The records of a stretch that was filed, read again from the profile by the host's own reader: those of the 30-bp windows from
+// `firstWindow` on (contig `contig`), `skip` of them passed over, the next `n` to dst. What a start slot's virtual runs are
+// materialised from (ChromProfile::refill), and what fileRun() falls back to when records it needs had stayed on the device.
+void CallRun::readRunFromProfile(unsigned sample, const std::string & contig, uint32_t jumpPos, uint32_t firstWindow, uint64_t skip, uint64_t n,
+                                 StartEntry * dst) const
+{
+    const unsigned contigIdx = p_.representativeContigs ? 0 : sample;
+    const std::vector<std::string> & contigNames = p_.contigNames[contigIdx];
+    ProfileFile in(p_.inputFiles[sample]);
+    // (from where the round's reader had jumped to -- the region's begin then --: the stream is the one it saw)
+    in.jumpToRegion(contigNames, p_.contigLengths[contigIdx], p_.indexRegionSizes[contigIdx], contig, static_cast<int>(jumpPos));
+    std::unique_ptr<ByteSource> src = in.openSource(p_.uncompressedIn);
+    const unsigned nRg = static_cast<unsigned>(p_.rgs[sample].size());
+    WindowHead window;
+    FlatWindows wins;
+    FlatCounts counts;
+    FlatRecords recs;
+    uint64_t done = 0;
+    while (done < n)
+    {
+        if (!readWindowHead(*src, window))
+            break;
+        if (contigNames[window.chrom] != contig)
+        {
+            if (done + skip != 0 || !wins.empty())
+                break;                          // (beyond the contig)
+            skipWindowBody(*src, nRg);
+            continue;
+        }
+        if (static_cast<int64_t>(window.beginPos) + 255 < static_cast<int64_t>(firstWindow))
+        {
+            skipWindowBody(*src, nRg);
+            continue;
+        }
+        wins.clear();
+        counts.clear();
+        recs.clear();
+        if (!readWindowBodyFlat(*src, window, nRg, wins, counts, recs, 256, 30))
+            break;
+        for (size_t w = 0; w < wins.size() && done < n; ++w)
+        {
+            if (static_cast<int64_t>(wins[w].beginPos) < static_cast<int64_t>(firstWindow))
+                continue;
+            const uint32_t c = counts[w * nRg];
+            for (uint32_t k = 0; k < c && done < n; ++k)
+            {
+                if (skip != 0)
+                {
+                    --skip;
+                    continue;
+                }
+                const PairRecord & r = recs[wins[w].firstRec + k];
+                dst[done++] = StartEntry{r.pos, static_cast<int32_t>(r.dev)};
+            }
+        }
+    }
+    if (done != n)
+        throw ProfileError("[PopDel] Internal error: records of \"" + p_.inputFiles[sample] + "\" that had been filed were not found again in the profile.");
 }
 
 // One run of a one-read-group file into the tables. With the sample's blocks summarised by the device: a head of records one by
 // one (the blocks the run begins in the middle of, and at least kBulkHead records: the end table's counting cursor comes home to the
 // write slot), then every whole block whose pairs all end below the write slot's border at once -- their counts added up window
-// by window, ChromProfile::addBulk, which checks the rest and never reads a record --, then what is left record by record.
+// by window, ChromProfile::addBulk, which checks the rest and never reads a record: where the device kept those blocks' records to
+// itself (DecodedStream::recIndex) the start slot holds them as a virtual run --, then what is left record by record.
 void CallRun::fileRun(unsigned sample, const DecodedStream & in, const ReplayState & st)
 {
     ChromProfile & prof = *profile_;
     const unsigned rg = p_.rgs[sample][0];
     const int inner = innerOffsetOf(sample);
-    const uint32_t * rec = reinterpret_cast<const uint32_t *>(in.recsV + st.runFirst);
     const size_t n = st.runCount;
     filedRecords_.fetch_add(n, std::memory_order_relaxed);
-    size_t done = 0;
     const EndSlots & en = prof.ends[rg];
     const StartSlots::Slot & target = prof.starts[rg].slots[prof.starts[rg].writeSlot];
-    const size_t heldBefore = target.entries.size();
+    const size_t heldBefore = target.total;
+    // ---- the plan: which whole blocks can be taken from their summaries
+    RunSummary sum;
+    size_t firstBlock = 0, endBlock = 0;            // blocks [firstBlock, endBlock) (empty ones among them)
+    uint32_t lastPos = 0, lastEnd = 0;
+    bool endsInOrder = true;
     if (bulkFiling_ && in.blockSums && en.light && n >= kBulkHead + kBulkLeast)
     {
         // the blocks that lie inside [runFirst + kBulkHead, runFirst + n), in record indices of the sample's stream
         const uint64_t base = in.blockRecs[0];
         const uint64_t lo = st.runFirst + kBulkHead, hi = static_cast<uint64_t>(st.runFirst) + n;
-        size_t j0 = static_cast<size_t>(std::lower_bound(in.blockRecs, in.blockRecs + in.nBlocks + 1, base + lo) - in.blockRecs);
+        const size_t j0 = static_cast<size_t>(std::lower_bound(in.blockRecs, in.blockRecs + in.nBlocks + 1, base + lo) - in.blockRecs);
         const uint32_t borderBin = (en.slots[en.writeSlot].right + 29u) / 30u;
         constexpr uint32_t kBad = RunSummary::kSaturated | RunSummary::kNoRoom;
-        RunSummary sum;
         size_t j1 = j0;
-        uint32_t lastPos = 0, lastEnd = 0;
-        bool endsInOrder = true;
         for (; j1 < in.nBlocks && in.blockRecs[j1 + 1] - base <= hi; ++j1)
         {
             const pd_block_summary & b = in.blockSums[j1];
@@ -2235,59 +2417,119 @@ void CallRun::fileRun(unsigned sample, const DecodedStream & in, const ReplaySta
         }
         if (sum.n >= kBulkLeast)
         {
-            // the head: up to the first block taken
-            size_t first = j0;
-            while (in.blockSums[first].n == 0)
-                ++first;
-            const size_t headEnd = static_cast<size_t>(in.blockRecs[first] - base) - st.runFirst;
-            prof.reserveStarts(rg, n);
-            prof.addRun(rg, rec, headEnd, inner);
-            done = headEnd;
-            sum.lastPos = lastPos;
-            sum.lastEndBin = lastEnd;
-            sum.nBins = sum.maxEndBin - sum.binBase + 1u;
-            sum.flags = RunSummary::kStartsInOrder | (endsInOrder ? RunSummary::kEndsInOrder : 0u);
-            // the blocks' counts added up into one row of starts and one of ends (per thread: kept from run to run)
-            thread_local std::vector<uint16_t> rows;
-            rows.assign(2 * static_cast<size_t>(sum.nBins), 0);
-            uint16_t * starts = rows.data(), * ends = rows.data() + sum.nBins;
-            const size_t stride = static_cast<size_t>(in.startsRoom) + in.endsRoom;
-            for (size_t j = first; j < j1; ++j)
-            {
-                const pd_block_summary & b = in.blockSums[j];
-                if (b.n == 0)
-                    continue;
-                const uint8_t * cs = in.blockCounts + j * stride, * ce = cs + in.startsRoom;
-                const uint32_t off = b.bin_base - sum.binBase;
-                const uint32_t nStarts = b.last_pos / 30u - b.bin_base + 1u;
-                for (uint32_t w = 0; w < nStarts; ++w)
-                    starts[off + w] = static_cast<uint16_t>(starts[off + w] + cs[w]);
-                for (uint32_t w = b.min_end_bin - b.bin_base; w <= b.max_end_bin - b.bin_base; ++w)
-                    ends[off + w] = static_cast<uint16_t>(ends[off + w] + ce[w]);
-            }
-            if (prof.addBulk(rg, rec + 2 * done, sum, starts, ends, inner))
-            {
-                done += sum.n;
-                bulkRuns_.fetch_add(1, std::memory_order_relaxed);
-                bulkRecords_.fetch_add(sum.n, std::memory_order_relaxed);
-            }
-            else
-                bulkRefused_.fetch_add(1, std::memory_order_relaxed);
+            firstBlock = j0;
+            while (in.blockSums[firstBlock].n == 0)
+                ++firstBlock;
+            endBlock = j1;
+            while (in.blockSums[endBlock - 1].n == 0)
+                --endBlock;
         }
         else
+        {
+            sum = RunSummary();
             bulkNone_.fetch_add(1, std::memory_order_relaxed);
+        }
     }
-    if (done == 0)
+    // ---- the records: [0, headEnd) and [bulkEnd, n) of the run are filed one by one; those in between only if the tables refuse
+    const size_t headEnd = sum.n ? static_cast<size_t>(in.blockRecs[firstBlock] - in.blockRecs[0]) - st.runFirst : n;
+    const size_t bulkEnd = headEnd + sum.n;
+    // (where the device kept the middle blocks' records to itself the start slot notes a virtual run: the window loop takes the
+    // entries from the device's copy, pd_walk_source)
+    const bool keptOnDevice = in.recIndex != nullptr;
+    const uint32_t * head = headEnd ? reinterpret_cast<const uint32_t *>(in.records(st.runFirst, static_cast<uint32_t>(headEnd))) : nullptr;
+    const uint32_t * tail = bulkEnd < n ? reinterpret_cast<const uint32_t *>(in.records(st.runFirst + static_cast<uint32_t>(bulkEnd), static_cast<uint32_t>(n - bulkEnd))) : nullptr;
+    const uint32_t * middle = sum.n && !keptOnDevice ? reinterpret_cast<const uint32_t *>(in.records(st.runFirst + static_cast<uint32_t>(headEnd), sum.n)) : nullptr;
+    thread_local HugeVector<StartEntry> again;
+    // (the run's first 30-bp window, for whoever reads it again from the profile)
+    const uint32_t firstWindow = st.runFirstWindow;
+    auto readAgain = [&]() {
+        // (records this needs had stayed on the device: the whole run, from the profile)
+        again.resize(n);
+        readRunFromProfile(sample, nextCandidate_[sample].contig, static_cast<uint32_t>(std::max(0, p_.allRois[p_.nextRoi].beginPos)), firstWindow, 0, n,
+                           again.data());
+        runsReadAgain_.fetch_add(1, std::memory_order_relaxed);
+        const uint32_t * all = reinterpret_cast<const uint32_t *>(again.data());
+        head = all;
+        tail = all + 2 * bulkEnd;
+        middle = all + 2 * headEnd;
+    };
+    if ((headEnd && !head) || (bulkEnd < n && !tail))
+        readAgain();
+    size_t done = 0;
+    if (sum.n)
+    {
+        prof.reserveStarts(rg, keptOnDevice && !middle ? n - sum.n : n);
+        prof.addRun(rg, head, headEnd, inner);
+        done = headEnd;
+        sum.lastPos = lastPos;
+        sum.lastEndBin = lastEnd;
+        sum.nBins = sum.maxEndBin - sum.binBase + 1u;
+        sum.flags = RunSummary::kStartsInOrder | (endsInOrder ? RunSummary::kEndsInOrder : 0u);
+        // the blocks' counts added up into one row of starts and one of ends (per thread: kept from run to run)
+        thread_local std::vector<uint16_t> rows;
+        rows.assign(2 * static_cast<size_t>(sum.nBins), 0);
+        uint16_t * starts = rows.data(), * ends = rows.data() + sum.nBins;
+        const size_t stride = static_cast<size_t>(in.startsRoom) + in.endsRoom;
+        for (size_t j = firstBlock; j < endBlock; ++j)
+        {
+            const pd_block_summary & b = in.blockSums[j];
+            if (b.n == 0)
+                continue;
+            const uint8_t * cs = in.blockCounts + j * stride, * ce = cs + in.startsRoom;
+            const uint32_t off = b.bin_base - sum.binBase;
+            const uint32_t nStarts = b.last_pos / 30u - b.bin_base + 1u;
+            for (uint32_t w = 0; w < nStarts; ++w)
+                starts[off + w] = static_cast<uint16_t>(starts[off + w] + cs[w]);
+            for (uint32_t w = b.min_end_bin - b.bin_base; w <= b.max_end_bin - b.bin_base; ++w)
+                ends[off + w] = static_cast<uint16_t>(ends[off + w] + ce[w]);
+        }
+        VirtualNote note;
+        note.firstWindow = firstWindow;
+        note.skip = static_cast<uint32_t>(headEnd);
+        note.jumpPos = static_cast<uint32_t>(std::max(0, p_.allRois[p_.nextRoi].beginPos));
+        note.tag = roundContigTag_;
+        const bool virtualRun = !middle && nextCandidate_[sample].contig == roundContig_;
+        if (!middle && !virtualRun)
+            readAgain();
+        if (prof.addBulk(rg, virtualRun ? nullptr : middle, sum, starts, ends, inner, note))
+        {
+            done += sum.n;
+            bulkRuns_.fetch_add(1, std::memory_order_relaxed);
+            bulkRecords_.fetch_add(sum.n, std::memory_order_relaxed);
+            if (virtualRun)
+                virtualRecords_.fetch_add(sum.n, std::memory_order_relaxed);
+        }
+        else
+        {
+            bulkRefused_.fetch_add(1, std::memory_order_relaxed);
+            if (!middle)
+                readAgain();
+            prof.addRun(rg, middle, sum.n, inner);
+            done += sum.n;
+        }
+        prof.addRun(rg, tail, n - done, inner);
+    }
+    else
+    {
         prof.reserveRun(rg, n);
-    prof.addRun(rg, rec + 2 * done, n - done, inner);
+        prof.addRun(rg, head, n, inner);
+    }
+    // (tests: POPDEL_TEST_MATERIALIZE=k reads every k-th sample's virtual runs back from the profile right away)
+    static const unsigned materializeEvery = [] { const char * e = getenv("POPDEL_TEST_MATERIALIZE"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
+    if (materializeEvery && sample % materializeEvery == 0 && target.isVirtual())
+        prof.materializeStarts(rg, prof.starts[rg].writeSlot);
     // (the slot holds exactly this run: the device has the same entries in the loader's records)
-    if (in.inflater && heldBefore == 0 && target.entries.size() == n)
+    if (in.inflater && heldBefore == 0 && target.total == n)
     {
         slotSource_[rg] = pd_walk_source{in.inflater, in.recBase + st.runFirst};
         slotSourceCount_[rg] = static_cast<uint32_t>(n);
     }
     else
+    {
         slotSource_[rg].inflater = nullptr;
+        if (target.isVirtual())             // (nothing the window loop could take from the device: the entries, then)
+            prof.materializeStarts(rg, prof.starts[rg].writeSlot);
+    }
 }
 
 bool CallRun::processSegmentCode(unsigned i, unsigned code)
@@ -2551,7 +2793,11 @@ void CallRun::processSegment()
     ChromProfile & prof = *profile_;
     if (deviceWalk_)
     {
-        if (prof.canPlanSegment(p_.windowShift))
+        // (tests: POPDEL_TEST_LEAVE_WALK_AT=k hands the window loop back to the host at the k-th round -- the pairs the device
+        // holds as active, the entries it kept to itself and the end tables' deferred runs all come back, and the rest of the run
+        // is walked here: same output)
+        static const int leaveAt = [] { const char * e = getenv("POPDEL_TEST_LEAVE_WALK_AT"); return e ? atoi(e) : 0; }();
+        if (prof.canPlanSegment(p_.windowShift) && !(leaveAt > 0 && rounds_.size() == static_cast<size_t>(leaveAt)))
         {
             double t0 = PhaseClock::now();
             std::vector<uint8_t> equalRun, switches;
@@ -2696,27 +2942,39 @@ void CallRun::submitPlannedSegment(const WalkShape & shape, const std::vector<ui
     std::vector<pd_walk_source> sources(nRg, pd_walk_source{nullptr, 0});
     bool anySource = false;
     static_assert(sizeof(StartEntry) == sizeof(pd_walk_entry), "the start tables are handed over as they are");
+    const bool direct = backendReady_.load() && !getenv("POPDEL_COPY_HAND_OVER");
+    std::vector<unsigned> toMaterialize;
     for (size_t rg = 0; rg < nRg; ++rg)
     {
         const StartSlots & st = prof.starts[rg];
         const StartSlots::Slot & slot = st.slots[st.readSlot];
-        counts[rg] = static_cast<uint32_t>(slot.entries.size());
-        tables[rg] = reinterpret_cast<const pd_walk_entry *>(slot.entries.data());
-        borders[rg] = slot.endBorder;
-        idOffsets[rg] = slot.idOffset;
-        if (switches[rg] != 0 && slotSource_[rg].inflater && slotSourceCount_[rg] == counts[rg] && counts[rg] != 0 && gunzip_)
+        counts[rg] = static_cast<uint32_t>(slot.total);
+        if (direct && switches[rg] != 0 && slotSource_[rg].inflater && slotSourceCount_[rg] == counts[rg] && counts[rg] != 0 && gunzip_)
         {
             sources[rg] = slotSource_[rg];
             anySource = true;
         }
+        else if (slot.isVirtual() && (switches[rg] != 0 || !direct))
+            toMaterialize.push_back(static_cast<unsigned>(rg));      // (the window loop will want the entries themselves)
         slotSource_[rg].inflater = nullptr;         // (the slot it described is the read slot now)
+    }
+    if (!toMaterialize.empty())
+        parallelFor(toMaterialize.size(), [&](size_t k) { prof.materializeStarts(toMaterialize[k], prof.starts[toMaterialize[k]].readSlot); }, 4);
+    for (size_t rg = 0; rg < nRg; ++rg)
+    {
+        const StartSlots & st = prof.starts[rg];
+        const StartSlots::Slot & slot = st.slots[st.readSlot];
+        // (a slot with virtual runs has no table: its entries come from the loader's records on the device, sources[rg])
+        tables[rg] = slot.isVirtual() ? nullptr : reinterpret_cast<const pd_walk_entry *>(slot.entries.data());
+        borders[rg] = slot.endBorder;
+        idOffsets[rg] = slot.idOffset;
     }
     auto job = std::make_shared<HandOverJob>();
     job->equalRun = equalRun;
     job->switches = switches;
     job->shape = shape;
     job->contig = windows_.current.contig;
-    if (!backendReady_.load() || getenv("POPDEL_COPY_HAND_OVER"))
+    if (!direct)
     {
         // the device is not there yet: the job takes the entries along, and the tables are free again
         std::vector<size_t> offsets(nRg + 1, 0);
@@ -2937,6 +3195,7 @@ void CallRun::leaveDeviceWalk()
     ensureBackend();
     drainHandOver();
     ChromProfile & prof = *profile_;
+    prof.materializeAllStarts();        // (entries the device kept to itself: read again from the profiles)
     prof.setLightEnds(false);           // the window loop comes back to the host: it walks ordered end tables
     for (size_t r = 0; r < ctxs_.size(); ++r)
     {
@@ -2945,12 +3204,22 @@ void CallRun::leaveDeviceWalk()
             throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
         if (n == 0)
             continue;
-        std::vector<uint32_t> rg(n), start(n), id(n);
+        std::vector<uint32_t> rg(n), start(n), id(n), last(n);
         std::vector<int32_t> dev(n);
-        if (pd_walk_active(ctxs_[r], &n, rg.data(), start.data(), dev.data(), id.data(), n) != 0)
+        if (pd_walk_active_ex(ctxs_[r], &n, rg.data(), start.data(), dev.data(), id.data(), last.data(), n) != 0)
             throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(ctxs_[r]));
+        // The device holds the pairs as they stood after the last segment it was given. A round that was read since then has
+        // switched the slots (its segment is the one the host walks now), and a switch drains the end read slot -- every pair
+        // whose end record sits there leaves the active set (quirk B1; ChromProfile::drainEndReadSlot found nobody: the pairs
+        // were here) --: after one switch the pairs filed one slot ahead remain, after two or more none.
+        const std::vector<uint8_t> & pendingSwitches = prof.switchCounts();
         for (uint64_t i = 0; i < n; ++i)
-            prof.materializeActive(shardRg_[r] + rg[i], id[i], start[i], dev[i]);
+        {
+            const unsigned g = shardRg_[r] + rg[i];
+            const unsigned sw = pendingSwitches[g];
+            if (sw == 0 || (sw == 1 && (last[i] & 0x80000000u) != 0))
+                prof.materializeActive(g, id[i], start[i], dev[i]);
+        }
     }
     deviceWalk_ = false;
 }
@@ -3268,6 +3537,13 @@ int CallRun::run()
         profile_->setLightEnds(true);
     // (runs of device-parsed records are filed from summaries the device takes: ChromProfile::addBulk; POPDEL_HOST_FILING=1
     // files every record on the host as rounds 4-5 did -- A/B runs, tests)
+    sampleOfRg_.assign(p_.readGroups.size(), 0);
+    for (unsigned i = 0; i < p_.sampleNum; ++i)
+        for (unsigned r : p_.rgs[i])
+            sampleOfRg_[r] = i;
+    profile_->refill = [this](unsigned rg, const StartSlots::VirtualRun & run, StartEntry * dst) {
+        readRunFromProfile(sampleOfRg_[rg], contigTable_[run.tag], run.jumpPos, run.firstWindow, run.skip, run.n, dst);
+    };
     slotSource_.assign(p_.readGroups.size(), pd_walk_source{nullptr, 0});
     slotSourceCount_.assign(p_.readGroups.size(), 0);
     bulkRoom_ = p_.windowBuffer / 30u + 512u;
@@ -3316,6 +3592,17 @@ int CallRun::run()
             getrusage(RUSAGE_SELF, &ru);
             gTrace.mark("round begins; process CPU so far " + std::to_string(ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec) + " s user, " +
                         std::to_string(ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec) + " s system, " + std::to_string(ru.ru_minflt) + " page faults");
+        }
+        if (windows_.current.contig != roundContig_ || contigTable_.empty())
+        {
+            // (what a virtual run of start entries notes of its contig: an index into this table, which only grows)
+            roundContig_ = windows_.current.contig;
+            size_t t = 0;
+            while (t < contigTable_.size() && contigTable_[t] != roundContig_)
+                ++t;
+            if (t == contigTable_.size())
+                contigTable_.push_back(roundContig_);
+            roundContigTag_ = static_cast<uint32_t>(t);
         }
         startGunzipPrefetch();
         // (large batches: 16 threads replayed 1000 samples in 0.57 s with batches of 128 and in 0.22 s with 512)
@@ -3402,8 +3689,7 @@ int CallRun::run()
                 {
                     const unsigned i = readers[k];
                     const unsigned contigIdx = p_.representativeContigs ? 0 : i;
-                    codes[k] = replaySegment(decoded[k], p_.inputFiles[i], p_.rgs[i], p_.contigNames[contigIdx], nextCandidate_[i],
-                                             p_.allRois[p_.nextRoi], nullptr);
+                    codes[k] = replaySegment(i, decoded[k], p_.contigNames[contigIdx], nextCandidate_[i], p_.allRois[p_.nextRoi], nullptr);
                 }
             }
             else
@@ -3414,11 +3700,7 @@ int CallRun::run()
                 parallelFor(readers.size(), [&](size_t k) {     // blocks of neighbours: the per-read-group tables of adjacent samples share cache lines
                     const unsigned i = readers[k];
                     const unsigned contigIdx = p_.representativeContigs ? 0 : i;
-                    ReplayState st;
-                    while (replayAdvance(st, decoded[k], p_.inputFiles[i], p_.rgs[i], p_.contigNames[contigIdx], nextCandidate_[i],
-                                         p_.allRois[p_.nextRoi], &border[k]))
-                        fileRun(i, decoded[k], st);
-                    codes[k] = st.code;
+                    codes[k] = replaySegment(i, decoded[k], p_.contigNames[contigIdx], nextCandidate_[i], p_.allRois[p_.nextRoi], &border[k]);
                 }, 8);
                 for (size_t k = 0; k < readers.size(); ++k)
                     if (border[k] != kNoBorder)

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <stdexcept>
 
 #include "parallel.h"
 #include "profile_io.h"   // posToWin
@@ -30,8 +31,30 @@ void StartSlots::switchWrite()
 bool StartSlots::switchRead()
 {
     readSlot = (readSlot + 1) % 3;
-    readIdx = 0;
+    cursorToStart();
     return !readAtEnd();
+}
+
+void StartSlots::cursorUpTo(unsigned pos)
+{
+    const Slot & slot = slots[readSlot];
+    if (readIdx >= slot.total)
+        return;
+    if (!slot.isVirtual())
+    {
+        const HugeVector<StartEntry> & v = slot.entries;
+        readIdx = static_cast<size_t>(std::upper_bound(v.begin() + static_cast<std::ptrdiff_t>(readIdx), v.end(), pos,
+                                                       [](unsigned p, const StartEntry & e) { return p < e.startPos; }) - v.begin());
+        return;
+    }
+    if (slot.backPos <= pos)
+    {
+        readIdx = slot.total;
+        readByPos = false;
+        return;
+    }
+    readPos = readByPos ? std::max(readPos, pos) : pos;
+    readByPos = true;
 }
 
 bool StartSlots::switchBoth(unsigned & rightBorderOut)
@@ -45,6 +68,7 @@ bool StartSlots::switchBoth(unsigned & rightBorderOut)
 void StartSlots::add(unsigned startPos, int deviation)
 {
     slots[writeSlot].entries.push_back(StartEntry{startPos, deviation});
+    slots[writeSlot].note(startPos, startPos, 1);
     ++insertionCount;
 }
 
@@ -179,6 +203,8 @@ void EndSlots::settle(Slot & slot)
     {
         all.insert(all.end(), slot.entries.begin() + static_cast<std::ptrdiff_t>(at), slot.entries.begin() + static_cast<std::ptrdiff_t>(d.explicitBefore));
         at = d.explicitBefore;
+        if (owner && startsOf->slots[d.startSlot].isVirtual())
+            owner->materializeStarts(rgIndex, d.startSlot);
         const StartEntry * src = startsOf->slots[d.startSlot].entries.data() + d.first;
         for (uint32_t j = 0; j < d.n; ++j)
         {
@@ -456,7 +482,11 @@ ChromProfile::ChromProfile(unsigned numReadGroups, const std::vector<unsigned> &
     currentRightBorder = starts[0].slots[2].right;
     log_.resize(numReadGroups);
     for (unsigned rg = 0; rg < numReadGroups; ++rg)
+    {
         ends[rg].startsOf = &starts[rg];            // (neither vector is ever resized)
+        ends[rg].owner = this;
+        ends[rg].rgIndex = rg;
+    }
 }
 
 // What the closed-form walk needs to know about a start slot beyond its entries: under which end slot's border their end
@@ -465,8 +495,7 @@ static inline void noteAdd(StartSlots & st, const EndSlots & en, unsigned startP
 {
     StartSlots::Slot & slot = st.slots[st.writeSlot];
     slot.endBorder = en.slots[en.writeSlot].right;
-    if (!slot.entries.empty() && startPos < slot.entries.back().startPos)
-        slot.sorted = false;
+    (void)startPos;                     // (whether the entries arrive in order: Slot::note, with the entry itself)
 }
 
 void ChromProfile::add(unsigned rg, unsigned startPos, unsigned endPos, int deviation)
@@ -532,8 +561,7 @@ void ChromProfile::addRun(unsigned rg, const uint32_t * posDev, size_t n, int in
         auto file = [&](unsigned startPos, int deviation, unsigned endPos) {
             StartSlots::Slot & slot = st.slots[st.writeSlot];
             slot.endBorder = en.slots[en.writeSlot].right;
-            if (!slot.entries.empty() && startPos < slot.entries.back().startPos)
-                slot.sorted = false;
+            slot.note(startPos, startPos, 1);
             const unsigned id = st.insertionCount++;
             slot.entries.push_back(StartEntry{startPos, deviation});
             en.addFast(id, endPos);
@@ -603,8 +631,7 @@ void ChromProfile::addRun(unsigned rg, const uint32_t * posDev, size_t n, int in
             }
             StartSlots::Slot & slot = st.slots[st.writeSlot];
             slot.endBorder = en.slots[en.writeSlot].right;
-            if (!slot.entries.empty() && posDev[2 * i] < slot.entries.back().startPos)
-                slot.sorted = false;
+            slot.note(posDev[2 * i], posDev[2 * (i + block - 1)], block);
             const unsigned id = st.insertionCount;
             st.insertionCount += static_cast<unsigned>(block);
             static_assert(sizeof(StartEntry) == 2 * sizeof(uint32_t), "a record {pos, dev} is a start entry");
@@ -716,7 +743,7 @@ void summarizeRun(const uint32_t * posDev, size_t nRecords, int innerOffset, uin
 }
 
 bool ChromProfile::addBulk(unsigned rg, const uint32_t * posDev, const RunSummary & s, const uint16_t * startCounts, const uint16_t * endCounts,
-                           int innerOffset)
+                           int innerOffset, const VirtualNote & note)
 {
     StartSlots & st = starts[rg];
     EndSlots & en = ends[rg];
@@ -785,13 +812,17 @@ bool ChromProfile::addBulk(unsigned rg, const uint32_t * posDev, const RunSummar
     // ---- file: the start entries in one copy, the end entries as counts and a reference
     StartSlots::Slot & sslot = st.slots[st.writeSlot];
     sslot.endBorder = slot.right;
-    if (!sslot.entries.empty() && s.firstPos < sslot.entries.back().startPos)
-        sslot.sorted = false;
     const unsigned id = st.insertionCount;
     st.insertionCount += s.n;
-    const uint32_t firstEntry = static_cast<uint32_t>(sslot.entries.size());
-    const StartEntry * src = reinterpret_cast<const StartEntry *>(posDev);
-    sslot.entries.insert(sslot.entries.end(), src, src + s.n);
+    const uint32_t firstEntry = static_cast<uint32_t>(sslot.total);         // (its place among ALL the slot's entries)
+    sslot.note(s.firstPos, s.lastPos, s.n);
+    if (posDev)
+    {
+        const StartEntry * src = reinterpret_cast<const StartEntry *>(posDev);
+        sslot.entries.insert(sslot.entries.end(), src, src + s.n);
+    }
+    else
+        sslot.virtualRuns.push_back(StartSlots::VirtualRun{sslot.entries.size(), s.n, note.firstWindow, note.skip, note.jumpPos, note.tag});
     {
         uint16_t * hist = slot.hist.data();
         const unsigned cur0 = slot.curBin[0], cur1 = slot.curBin[1];
@@ -825,6 +856,49 @@ bool ChromProfile::addBulk(unsigned rg, const uint32_t * posDev, const RunSummar
     load -= en.countEndedFast(s.lastPos);
     activeLoad[rg] = load;
     return true;
+}
+
+void ChromProfile::materializeStarts(unsigned rg, unsigned slotIdx)
+{
+    StartSlots & st = starts[rg];
+    StartSlots::Slot & slot = st.slots[slotIdx];
+    if (!slot.isVirtual())
+        return;
+    if (!refill)
+        throw std::runtime_error("[PopDel] Internal error: a start slot holds runs of entries that nobody can read back.");
+    HugeVector<StartEntry> all;
+    all.resize(slot.total);
+    size_t at = 0, out = 0;
+    for (const StartSlots::VirtualRun & run : slot.virtualRuns)
+    {
+        std::copy(slot.entries.begin() + static_cast<std::ptrdiff_t>(at), slot.entries.begin() + static_cast<std::ptrdiff_t>(run.explicitBefore),
+                  all.begin() + static_cast<std::ptrdiff_t>(out));
+        out += run.explicitBefore - at;
+        at = run.explicitBefore;
+        refill(rg, run, all.data() + out);
+        out += run.n;
+        materialized_ += run.n;
+    }
+    std::copy(slot.entries.begin() + static_cast<std::ptrdiff_t>(at), slot.entries.end(), all.begin() + static_cast<std::ptrdiff_t>(out));
+    slot.entries.swap(all);
+    slot.virtualRuns.clear();
+    if (slotIdx == st.readSlot && st.readByPos)
+    {
+        // the cursor as a number again: behind every entry that starts at or before readPos (and not before where it stood)
+        const HugeVector<StartEntry> & v = slot.entries;
+        const size_t from = std::min(st.readIdx, v.size());
+        st.readIdx = static_cast<size_t>(std::upper_bound(v.begin() + static_cast<std::ptrdiff_t>(from), v.end(), st.readPos,
+                                                          [](unsigned p, const StartEntry & e) { return p < e.startPos; }) - v.begin());
+        st.readByPos = false;
+    }
+}
+
+void ChromProfile::materializeAllStarts()
+{
+    parallelFor(starts.size(), [&](size_t rg) {
+        for (unsigned k = 0; k < 3; ++k)
+            materializeStarts(static_cast<unsigned>(rg), k);
+    }, 16);
 }
 
 void ChromProfile::activate(unsigned rg, unsigned id, unsigned logWindow)
@@ -1016,7 +1090,7 @@ void ChromProfile::resetTo(unsigned pos)
         st.slots[2].reset(idO, r3);
         st.writeSlot = 0;
         st.readSlot = 2;
-        st.readIdx = 0;
+        st.cursorToStart();
     }
     for (EndSlots & en : ends)
     {
@@ -1104,7 +1178,7 @@ bool ChromProfile::allEmpty() const
 {
     for (size_t i = 0; i < starts.size(); ++i)
     {
-        if (!starts[i].slots[starts[i].writeSlot].entries.empty())
+        if (starts[i].slots[starts[i].writeSlot].total != 0)
             return false;
         if (ends[i].slots[ends[i].writeSlot].total != 0)
             return false;
@@ -1159,15 +1233,6 @@ std::vector<std::vector<PairInstance>> & ChromProfile::endSegmentLog()
 // ----------------------------------------------------------------------------------------------------------
 // The window loop in closed form
 // ----------------------------------------------------------------------------------------------------------
-namespace {
-// first index >= from whose entry starts beyond pos (entries in start order)
-size_t startsUpTo(const HugeVector<StartEntry> & v, size_t from, unsigned pos)
-{
-    return static_cast<size_t>(std::upper_bound(v.begin() + static_cast<std::ptrdiff_t>(std::min(from, v.size())), v.end(), pos,
-                                                [](unsigned p, const StartEntry & e) { return p < e.startPos; }) - v.begin());
-}
-}  // namespace
-
 bool ChromProfile::canPlanSegment(unsigned shift) const
 {
     for (const StartSlots & st : starts)
@@ -1202,7 +1267,7 @@ WalkShape ChromProfile::planSegment(unsigned shift, std::vector<uint8_t> & equal
         parallelFor(nRg, [&](size_t rg) {
             StartSlots & st = starts[rg];
             EndSlots & en = ends[rg];
-            st.readIdx = startsUpTo(st.slots[st.readSlot].entries, st.readIdx, at);
+            st.cursorUpTo(at);
             en.advanceReadTo(at, shift);
         }, 128);
         profilesAtEnd = false;
@@ -1211,9 +1276,9 @@ WalkShape ChromProfile::planSegment(unsigned shift, std::vector<uint8_t> & equal
     for (size_t rg = 0; rg < nRg; ++rg)
     {
         StartSlots & st = starts[rg];
-        st.readIdx = 0;
-        if (!st.readAtEnd() && st.current().startPos < currentPos)
-            currentPos = st.current().startPos;
+        st.cursorToStart();
+        if (!st.readAtEnd() && st.firstStart() < currentPos)
+            currentPos = st.firstStart();
     }
     globalMinPos = currentPos;
     if (!sh.hasStep)
@@ -1223,12 +1288,10 @@ WalkShape ChromProfile::planSegment(unsigned shift, std::vector<uint8_t> & equal
         for (size_t rg = 0; rg < nRg; ++rg)
         {
             StartSlots & st = starts[rg];
-            if (st.readAtEnd() || st.current().startPos != currentPos)
+            if (st.readAtEnd() || st.firstStart() != currentPos)
                 continue;
             equalRun[rg] = 1;
-            const HugeVector<StartEntry> & v = st.slots[st.readSlot].entries;
-            while (st.readIdx < v.size() && v[st.readIdx].startPos == currentPos)
-                ++st.readIdx;
+            st.cursorUpTo(currentPos);          // (behind the run of entries on that position: the slot is in start order)
         }
     }
     sh.firstPos = currentPos;
@@ -1246,7 +1309,7 @@ WalkShape ChromProfile::planSegment(unsigned shift, std::vector<uint8_t> & equal
         unsigned js = 0, je = 0;
         if (!st.readAtEnd())
         {
-            const unsigned last = st.slots[st.readSlot].entries.back().startPos;
+            const unsigned last = st.slots[st.readSlot].backPos;
             js = last <= pos0 ? 1u : (last - pos0 + shift - 1) / shift;
         }
         if (!en.readAtEnd())
@@ -1260,7 +1323,7 @@ WalkShape ChromProfile::planSegment(unsigned shift, std::vector<uint8_t> & equal
         {
         }
         const unsigned lastPos = pos0 + mine * shift;
-        st.readIdx = startsUpTo(st.slots[st.readSlot].entries, st.readIdx, lastPos);
+        st.cursorUpTo(lastPos);
         en.advanceReadTo(lastPos, shift);
     }, 128);
     const unsigned steps = stepsSeen.load();

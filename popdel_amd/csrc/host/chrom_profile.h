@@ -12,6 +12,7 @@
 #define PDH_CHROM_PROFILE_H_
 
 #include <algorithm>
+#include <atomic>
 #include <functional>
 #include <cstdint>
 #include <cstddef>
@@ -41,15 +42,54 @@ struct EndEntry
 class alignas(64) StartSlots
 {
 public:
+    // A run of entries that is NOT held here (round 6): the records a device parsed and summarised, filed by
+    // ChromProfile::addBulk() without a copy -- the window loop on the device takes them from the loader's records where they lie
+    // (pd_walk_source), and this table needs of them what `total`, `frontPos`, `backPos` and `sorted` say. Whoever does need the
+    // entries themselves (the host's window loop taking over, end entries written out) has them read again from the profile:
+    // ChromProfile::materializeStarts(), through the filer's `refill` callback.
+    struct VirtualRun
+    {
+        size_t   explicitBefore;    // entries.size() when the run was filed: its place in filing order
+        uint32_t n;                 // entries
+        // where a reader of the profile finds them again: the 30-bp window (position) at which the stretch of records they were
+        // filed with begins -- the first record at or beyond it is that stretch's first, positions being in order --, how many
+        // records of the stretch precede them, the position the round's reader had jumped to (it sees what a jump there sees:
+        // a 256-bp window that begins in the index region before reaches over the border), the filer's own note (CallRun: which contig)
+        uint32_t firstWindow, skip, jumpPos, tag;
+    };
     struct Slot
     {
-        HugeVector<StartEntry> entries;
+        HugeVector<StartEntry> entries;            // (without the virtual runs)
+        std::vector<VirtualRun> virtualRuns;
+        size_t   total = 0;        // entries filed: entries.size() + the virtual runs'
+        unsigned frontPos = 0, backPos = 0;        // start positions of the first and the last entry filed (total != 0)
         unsigned right = 0;        // exclusive right border
         unsigned idOffset = 0;     // id of entries[0]
         unsigned endBorder = 0;    // right border of the END slot the entries' end records were filed under (ChromProfile::add)
         bool readable = false;
         bool sorted = true;        // entries arrived in non-decreasing start order (what the closed-form walk relies on)
-        void reset(unsigned idO, unsigned r) { entries.clear(); right = r; idOffset = idO; readable = false; sorted = true; }
+        void reset(unsigned idO, unsigned r)
+        {
+            entries.clear();
+            virtualRuns.clear();
+            total = 0;
+            frontPos = backPos = 0;
+            right = r;
+            idOffset = idO;
+            readable = false;
+            sorted = true;
+        }
+        bool isVirtual() const { return !virtualRuns.empty(); }
+        // an entry is filed (any way): what the slot remembers about its entries beyond the entries
+        void note(unsigned firstPos, unsigned lastPos, size_t n)
+        {
+            if (total == 0)
+                frontPos = firstPos;
+            else if (firstPos < backPos)
+                sorted = false;
+            backPos = lastPos;
+            total += n;
+        }
     };
 
     explicit StartSlots(unsigned firstWin = 0, unsigned windows = 10000);
@@ -61,10 +101,23 @@ public:
     bool switchBoth(unsigned & rightBorderOut);
     void add(unsigned startPos, int deviation);
 
-    bool readAtEnd() const { return readIdx >= slots[readSlot].entries.size(); }
+    bool readAtEnd() const { return readIdx >= slots[readSlot].total; }
     bool goNext() { ++readIdx; return !readAtEnd(); }
-    const StartEntry & current() const { return slots[readSlot].entries[readIdx]; }
+    const StartEntry & current() const { return slots[readSlot].entries[readIdx]; }     // (the read slot holds all its entries: host's window loop)
     unsigned currentId() const { return static_cast<unsigned>(readIdx) + slots[readSlot].idOffset; }
+    // The read cursor as the closed-form plan moves it (entries of the read slot in start order): behind every entry that starts at
+    // or before `pos`, never backwards. With virtual runs in the read slot the entries cannot be counted: the cursor is then kept
+    // as that position (readByPos / readPos; readIdx stays a lower bound and is exact at 0 and at the end -- all the plan asks),
+    // and becomes a number again when the slot is materialised.
+    void cursorToStart()
+    {
+        readIdx = 0;
+        readByPos = false;
+    }
+    void cursorUpTo(unsigned pos);
+    unsigned firstStart() const { return slots[readSlot].frontPos; }        // start position of the slot's first entry (total != 0)
+    bool     readByPos = false;
+    unsigned readPos = 0;
     unsigned slotOfId(unsigned id) const;
     const StartEntry & entryOfId(unsigned id) const;
 
@@ -316,8 +369,11 @@ public:
     unsigned numWindows;
 
     // ---- runs filed in bulk (Deferred) ------------------------------------------------------------------------------------
-    // the start table of the same read group (ChromProfile sets it): where the deferred runs' records lie
+    // the start table of the same read group (ChromProfile sets it): where the deferred runs' records lie; a start slot with
+    // virtual runs is materialised first (owner / rgIndex)
     const StartSlots * startsOf = nullptr;
+    class ChromProfile * owner = nullptr;
+    unsigned rgIndex = 0;
     // every deferred run of `slot` written out as EndEntry records, in filing order
     void settle(Slot & slot);
     // ... those of all slots that refer to start slot `startSlot` (it is about to be recycled), except in end slot `spare`
@@ -389,6 +445,12 @@ struct ActiveOp
     uint32_t add;
 };
 
+// (what a virtual run notes of where its records are found again: StartSlots::VirtualRun)
+struct VirtualNote
+{
+    uint32_t firstWindow = 0, skip = 0, jumpPos = 0, tag = 0;
+};
+
 class ChromProfile
 {
 public:
@@ -399,7 +461,8 @@ public:
     // add() for a run of records of one read group ({pos, dev} pairs as the reader delivers them; the pair's end is
     // pos + max(0, dev + innerOffset), innerOffset = median - 2 * read length): the same operations in the same order
     void addRun(unsigned rg, const uint32_t * posDev, size_t n, int innerOffset);
-    // addRun() for records [0, s.n) WITHOUT reading them (they are only copied into the start slot): from the summary the tables
+    // addRun() for records [0, s.n) WITHOUT reading them (posDev: they are only copied into the start slot; nullptr: not even that --
+    // the start slot notes a virtual run, StartSlots::VirtualRun, with `note` saying where its refill finds the records): from the summary the tables
     // can tell whether filing them record by record would have been the everyday case throughout -- light tables, the end
     // table's counting cursor at home in the write slot, every pair ending below that slot's border and inside the windows its
     // counts cover, positions in order, and the load below the cap behind EVERY record (followed window by window from the
@@ -407,7 +470,14 @@ public:
     // entries remembered as a reference to the start entries (EndSlots::Deferred). Returns false, with nothing changed, if any of
     // it does not hold: the caller then files the records with addRun().
     bool addBulk(unsigned rg, const uint32_t * posDev, const RunSummary & s, const uint16_t * startCounts, const uint16_t * endCounts,
-                 int innerOffset);
+                 int innerOffset, const VirtualNote & note = VirtualNote());
+    // The entries of virtual runs, for whoever needs them: `refill(rg, run, dst)` writes run.n entries -- those of the records that
+    // were filed, in order -- to dst (the filer reads them again from the profile). materializeStarts() makes a slot hold all its
+    // entries again (and its read cursor a number); materializeAllStarts(): every slot of every read group.
+    std::function<void(unsigned rg, const StartSlots::VirtualRun & run, StartEntry * dst)> refill;
+    void materializeStarts(unsigned rg, unsigned slot);
+    void materializeAllStarts();
+    uint64_t materialized() const { return materialized_; }
     // room for n more records in the slots being written (one allocation instead of the doublings of push_back)
     void reserveRun(unsigned rg, size_t n);
     // ... for a run that will mostly be filed from its summary (addBulk): the start slot takes every record, the end slot a few
@@ -591,6 +661,7 @@ private:
     void drainEndReadSlot(unsigned rg);
     unsigned walkReadGroup(unsigned rg, unsigned pos0, unsigned shift, unsigned maxSteps);
 
+    std::atomic<uint64_t> materialized_{0};       // entries of virtual runs read back (refill)
     std::vector<uint8_t> switches_;        // per read group: slot switches since the last planned / walked segment (2 = two or more)
     bool activeKnownEmpty_ = true;         // no read group has an active pair (start of a run; closed-form mode keeps no active sets)
     bool lightEnds_ = false;

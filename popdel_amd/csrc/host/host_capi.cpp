@@ -416,6 +416,15 @@ int pdh_bench_filing_ex(unsigned rounds, int light, unsigned maxLoad, unsigned s
     if (light)
         prof.setLightEnds(true);
     std::mt19937 gen(seed), headGen(seed + 17u);       // (headGen: choices of the filing mode that must not change the records)
+    // light == 4: as 2, and the summarised runs' start entries are not copied either (StartSlots::VirtualRun); they are read back --
+    // here: from the rounds' records, which are kept -- when the tables are asked for them (at the end, and where a start slot is
+    // recycled under end entries that refer to it)
+    std::vector<std::vector<uint32_t>> kept;
+    if (light == 4)
+        prof.refill = [&kept](unsigned, const pdh::StartSlots::VirtualRun & run, pdh::StartEntry * dst) {
+            const std::vector<uint32_t> & r = kept[run.tag];
+            std::memcpy(dst, r.data() + 2 * static_cast<size_t>(run.skip), static_cast<size_t>(run.n) * sizeof(pdh::StartEntry));
+        };
     std::normal_distribution<double> ins(0.0, flavour >= 3 ? 400.0 : 50.0);
     unsigned burst = 0;
     std::vector<uint32_t> rec;
@@ -456,7 +465,9 @@ int pdh_bench_filing_ex(unsigned rounds, int light, unsigned maxLoad, unsigned s
             // summary (ChromProfile::addBulk; light == 3: the summary is taken but the records are filed by addRun() all the
             // same -- the yardstick of the timing), the rest record by record again
             const size_t n = rec.size() / 2;
-            const size_t head = std::min<size_t>(n, light == 2 ? headGen() % 200 : 64);
+            const size_t head = std::min<size_t>(n, light == 2 || light == 4 ? headGen() % 200 : 64);
+            if (light == 4)
+                kept.push_back(rec);
             prof.addRun(0, rec.data(), head, 500 - 300);
             size_t done = head;
             if (done < n)
@@ -474,7 +485,11 @@ int pdh_bench_filing_ex(unsigned rounds, int light, unsigned maxLoad, unsigned s
                 total -= std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count();     // (the device's work in the product)
                 if (light == 3)
                     sum.n = 0;
-                if (sum.n >= 16 && prof.addBulk(0, rec.data() + 2 * done, sum, wide.data(), wide.data() + room, 500 - 300))
+                pdh::VirtualNote note;
+                note.firstWindow = rec[0] / 30u * 30u;
+                note.skip = static_cast<uint32_t>(done);
+                note.tag = static_cast<uint32_t>(kept.empty() ? 0 : kept.size() - 1);
+                if (sum.n >= 16 && prof.addBulk(0, light == 4 ? nullptr : rec.data() + 2 * done, sum, wide.data(), wide.data() + room, 500 - 300, note))
                 {
                     done += sum.n;
                     ++g_bulkRuns;
@@ -511,6 +526,7 @@ int pdh_bench_filing_ex(unsigned rounds, int light, unsigned maxLoad, unsigned s
             mix(prof.ends[0].slots[k].total);
     }
     prof.setLightEnds(false);               // (back to ordered tables: what the host's window loop would find)
+    prof.materializeAllStarts();
     for (int k = 0; k < 3; ++k)
         for (const pdh::EndEntry & e : prof.ends[0].slots[k].entries)
         {

@@ -117,7 +117,12 @@ SUMMARY_FIELDS = ("n", "first_pos", "last_pos", "bin_base", "n_bins", "min_end_b
 
 class PdBlockSummaries(C.Structure):
     _fields_ = [("block_summaries", C.POINTER(C.c_uint32)), ("block_counts", C.POINTER(C.c_uint8)), ("starts_room", C.c_uint32),
-                ("ends_room", C.c_uint32)]
+                ("ends_room", C.c_uint32), ("record_index", C.POINTER(C.c_uint64))]
+
+
+class PdSummarizeOptions(C.Structure):
+    _fields_ = [("inner_offset", C.POINTER(C.c_int32)), ("starts_room", C.c_uint32), ("ends_room", C.c_uint32), ("lean", C.c_uint32),
+                ("keep_below", C.POINTER(C.c_uint32)), ("keep_from", C.POINTER(C.c_uint32))]
 
 
 def summarize_host(records, first, n, inner_offset, border_window, starts_room, ends_room):
@@ -136,14 +141,16 @@ def summarize_host(records, first, n, inner_offset, border_window, starts_room, 
     return dict(zip(SUMMARY_FIELDS, (int(v) for v in summary))), counts
 
 
-def parse_gpu(hip_lib, blobs, sample_first=None, device=0, inner_offsets=None, starts_room=0, ends_room=0, lean=False):
+def parse_gpu(hip_lib, blobs, sample_first=None, device=0, inner_offsets=None, starts_room=0, ends_room=0, lean=False, keep=None):
     """pd_inflater_run_parsed on gzip members (one sample unless `sample_first` says otherwise). Returns a dict: status[n],
     flags[n], counts[n, 3] (256-bp windows, 30-bp windows, records per block), profile_windows[.., 5], call_windows[.., 3],
     call_window_records[..], records[.., 2] (all blocks' rows in block order), bytes_copied. `inner_offsets` (one per member):
     pd_inflater_run_summarized instead, with `starts_room` / `ends_room` windows per block -> 'summaries' (a dict per block) and
     'block_counts' uint8[n, starts_room + ends_room] as well ('summarize_rc' != 0 if the call was refused: nothing else then).
     `lean`: the lean form -- 'profile_windows' holds rows {chrom, beginPos, first record, records, first position, last position},
-    'call_windows' / 'call_window_records' are empty."""
+    'call_windows' / 'call_window_records' are empty. `keep` = (keep_below[n], keep_from[n]): records come back for the blocks with a
+    record below / at or beyond only -> 'records' holds those blocks' records packed, 'record_index'[n] where each block's begin
+    (2**64 - 1: not copied back)."""
     data, offsets, out_offsets = pack_members(blobs)
     n = len(blobs)
     first = np.zeros(n, np.uint32) if sample_first is None else np.asarray(sample_first, np.uint32)
@@ -164,9 +171,12 @@ def parse_gpu(hip_lib, blobs, sample_first=None, device=0, inner_offsets=None, s
         if inner_offsets is not None:
             inner = np.ascontiguousarray(inner_offsets, dtype=np.int32)
             hip_lib.pd_inflater_run_summarized.restype = C.c_int
+            opt = PdSummarizeOptions(_ptr(inner, C.c_int32), starts_room, ends_room, 1 if lean else 0, None, None)
+            if keep is not None:
+                below, beyond = np.ascontiguousarray(keep[0], np.uint32), np.ascontiguousarray(keep[1], np.uint32)
+                opt.keep_below, opt.keep_from = _ptr(below, C.c_uint32), _ptr(beyond, C.c_uint32)
             rc = hip_lib.pd_inflater_run_summarized(C.c_void_p(inf), _ptr(offsets, C.c_uint64), C.c_uint32(n), _ptr(out_offsets, C.c_uint64),
-                                                    _ptr(first, C.c_uint32), _ptr(want, C.c_uint8), _ptr(inner, C.c_int32), C.c_uint32(starts_room),
-                                                    C.c_uint32(ends_room), C.c_uint32(1 if lean else 0), C.byref(out), C.byref(status),
+                                                    _ptr(first, C.c_uint32), _ptr(want, C.c_uint8), C.byref(opt), C.byref(out), C.byref(status),
                                                     C.byref(lengths), C.byref(pb), C.byref(sums), C.byref(ms))
             if rc != 0:
                 return dict(summarize_rc=rc)
@@ -188,10 +198,18 @@ def parse_gpu(hip_lib, blobs, sample_first=None, device=0, inner_offsets=None, s
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), (count * width,)).reshape(count, width).copy()
 
         n_cw = 0 if lean else int(wo[-1])
+        n_back = int(co[-1])
+        record_index = None
+        if inner_offsets is not None and keep is not None:
+            record_index = np.ctypeslib.as_array(sums.record_index, (n,)).copy()
+            kept = record_index != np.uint64(2**64 - 1)
+            n_back = int(np.diff(co)[kept].sum())
         res = dict(status=st, flags=fl[:, 3], counts=np.stack([np.diff(ro), np.diff(wo), np.diff(co)], axis=1),
                    profile_windows=rows(pb.profile_windows, int(ro[-1]), 6 if lean else 5), call_windows=rows(pb.call_windows, n_cw, 3),
-                   call_window_records=rows(pb.call_window_records, n_cw, 1)[:, 0], records=rows(pb.records, int(co[-1]), 2),
+                   call_window_records=rows(pb.call_window_records, n_cw, 1)[:, 0], records=rows(pb.records, n_back, 2),
                    bytes_copied=int(pb.bytes_copied))
+        if record_index is not None:
+            res["record_index"] = record_index
         if inner_offsets is not None:
             res["summarize_rc"] = 0
             words = np.ctypeslib.as_array(sums.block_summaries, (n * 10,)).reshape(n, 10).copy()

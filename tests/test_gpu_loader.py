@@ -96,6 +96,39 @@ def test_loader_variants_write_the_same_vcf(built, cohort_dir, tmp_path):
             assert "files filed in runs, 0 of them" in [l for l in r1.stderr.splitlines() if "[popdel timing] filing:" in l][0]
 
 
+def test_entries_the_device_kept_come_back_when_the_tables_need_them(built, cohort_dir, tmp_path):
+    """Round 6: the records in the middle of a round's stretch stay on the device -- the start slots hold them as virtual runs, the
+    end slots as deferred references, the window loop takes them from the loader's records there. When the tables do need the
+    entries (the host's window loop taking over; a slot recycled under references) they are read again from the profiles:
+    forced here -- every third sample's runs read back right after filing; the window loop handed back to the host at the
+    second, third and a later round (with pairs active on the device and a slot switch pending: what the switch does to the active
+    set is done to the pairs that come back, pd_walk_active_ex), also with small buffers so that slots are recycled while
+    references to them are alive -- against the default, and against the host-only configuration."""
+    from popdel_amd import synth
+    d = cohort_dir("s600", 600, synth.single_deletion)
+    for args, late in ((["-r", "chr20:1000000-2000000"], "4"), (["-r", "chr20:1003001-2000000", "-b", "60000"], "9")):
+        r, base = call(d, str(tmp_path / "base.vcf"), *args)
+        assert r.returncode == 0, r.stderr[-300:]
+        filed = [l for l in r.stderr.splitlines() if "[popdel timing] filing:" in l][0]
+        kept = int(filed.split("usable blocks); ")[1].split()[0])
+        assert kept > 3000000, filed                                   # (most entries never left the device)
+        r0, host = call(d, str(tmp_path / "host.vcf"), *args, env={"POPDEL_HOST_GUNZIP": "1", "POPDEL_HEAVY_TABLES": "1"})
+        assert r0.returncode == 0 and host == base
+        for env in ({"POPDEL_TEST_MATERIALIZE": "3"}, {"POPDEL_TEST_LEAVE_WALK_AT": "3"}, {"POPDEL_TEST_LEAVE_WALK_AT": late},
+                    {"POPDEL_TEST_LEAVE_WALK_AT": "2", "POPDEL_TEST_MATERIALIZE": "2"}, {"POPDEL_HOST_RECORDS": "1"}):
+            r1, other = call(d, str(tmp_path / "other.vcf"), *args, env=env)
+            assert r1.returncode == 0, (env, r1.stderr[-400:])
+            assert other == base, (args, env)
+            filed = [l for l in r1.stderr.splitlines() if "[popdel timing] filing:" in l][0]
+            back = int(filed.split("never left the device, ")[1].split()[0])
+            if "POPDEL_HOST_RECORDS" in env:
+                assert " 0 start entries never left the device" in filed, filed
+            else:
+                assert back > 100000, (env, filed)                     # (entries were read again from the profiles)
+            if "POPDEL_TEST_LEAVE_WALK_AT" in env:
+                assert "walked on the host" in r1.stderr and " 0 walked on the host" not in r1.stderr, r1.stderr[-600:]
+
+
 @pytest.mark.parametrize("region_size", [2000, 50000])
 def test_uneven_profiles_behave_as_on_the_host(built, tmp_path, region_size):
     """Profiles that differ where the prefetch has to be careful: index regions of 2,000 or 50,000 bp instead of 10,000 (the

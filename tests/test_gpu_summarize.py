@@ -138,6 +138,40 @@ def test_lean_arrays_are_the_full_ones_without_the_call_windows(built):
             assert np.array_equal(np.diff(np.concatenate([starts, [b - a]])), cr[fw: fw + nw]), k
 
 
+def test_records_come_back_for_the_blocks_at_the_ends_only(built):
+    """keep_below / keep_from: the records of a block are copied back only if one of them begins below / at or beyond the block's
+    limits; the kept blocks' records are packed in block order, record_index says where each begins, everything else -- lean
+    windows, summaries, the count of ALL records -- is unchanged."""
+    from popdel_amd import capi, inflate
+    hip = capi.load_hip()
+    blocks = inflate.profile_blocks(60, seed=33)              # regions of 10,000 bp from 1,000,000 on
+    blobs = [gzip.compress(b, 6, mtime=0) for b in blocks]
+    inner = np.full(60, 200, np.int32)
+    first = np.zeros(60, np.uint32)
+    first[30:] = 30                                            # two samples of 30 blocks
+    below = np.where(np.arange(60) < 30, 1000000 + 25000, 1300000 + 5000).astype(np.uint32)
+    beyond = np.where(np.arange(60) < 30, 1000000 + 281000, 1300000 + 300000).astype(np.uint32)
+    whole = inflate.parse_gpu(hip, blobs, sample_first=first, inner_offsets=inner, starts_room=345, ends_room=473, lean=True)
+    part = inflate.parse_gpu(hip, blobs, sample_first=first, inner_offsets=inner, starts_room=345, ends_room=473, lean=True, keep=(below, beyond))
+    assert part["summarize_rc"] == 0
+    for k in ("profile_windows", "counts", "flags"):
+        assert np.array_equal(part[k], whole[k]), k
+    assert part["summaries"] == whole["summaries"] and np.array_equal(part["block_counts"], whole["block_counts"])
+    at = np.concatenate([[0], np.cumsum(whole["counts"][:, 2])]).astype(np.int64)
+    idx = part["record_index"]
+    kept = [m for m in range(60) if idx[m] != np.uint64(2**64 - 1)]
+    spans = [(int(whole["records"][at[m], 0]), int(whole["records"][at[m + 1] - 1, 0])) for m in range(60)]
+    expect = [m for m in range(60) if spans[m][0] < below[m] or spans[m][1] >= beyond[m]]
+    assert kept == expect and 3 <= len(kept) <= 8, (kept, expect)
+    packed = 0
+    for m in kept:
+        n = int(at[m + 1] - at[m])
+        assert int(idx[m]) == packed
+        assert np.array_equal(part["records"][packed: packed + n], whole["records"][at[m]: at[m + 1]]), m
+        packed += n
+    assert packed == len(part["records"]) < len(whole["records"]) // 4
+
+
 def test_summaries_are_refused_without_room(built):
     from popdel_amd import capi, inflate
     hip = capi.load_hip()

@@ -59,6 +59,16 @@ def test_runs_filed_from_their_summaries_file_what_heavy_tables_file(filing, fla
         assert runs1.value == runs0.value
 
 
+@pytest.mark.parametrize("flavour", [0, 1, 3, 4])
+def test_virtual_start_runs_file_what_heavy_tables_file(filing, flavour):
+    """... and with the summarised runs' start entries not even copied (StartSlots::VirtualRun: the device keeps them, the table
+    knows their number and extremes): the same checksums round by round -- plans, cursors, loads -- and, after the entries have
+    been read back (ChromProfile::materializeStarts through the filer's refill), entry by entry."""
+    for cap in (25, 40, 100, 100000):
+        for seed in (1, 2, 3, 4, 5, 6):
+            assert filing(30, 4, cap, seed, flavour) == filing(30, 0, cap, seed, flavour), (flavour, cap, seed)
+
+
 def test_the_checksum_sees_the_cap(filing):
     # (the check is not blind: a different cap files different records in a burst)
     assert filing(30, 1, 25, 1, 1) != filing(30, 1, 100, 1, 1)
