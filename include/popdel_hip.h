@@ -330,11 +330,13 @@ typedef struct pd_inflater pd_inflater;     /* (a persistent device gunzip + par
  * records array the inflater's last pd_inflater_run_parsed() / _summarized() left in HBM -- the loader parsed them there, the host
  * filed them into its table in the same order. If given (inflater != NULL) and the inflater works on the context's GPU, the
  * library takes the entries from there instead of fetching the host's table over the link; rg_entries[rg] must still point to the
- * table (it is what every other case reads). The inflater must not run again before pd_walk_submit() returns. */
+ * table (it is what every other case reads) unless the host kept no table for them. The inflater must not run again before
+ * pd_walk_submit() returns; run_id lets the library notice if it has. */
 typedef struct pd_walk_source
 {
     pd_inflater *inflater;
     uint64_t     first_record;
+    uint64_t     run_id;        /* pd_inflater_run_id() when the chunk was parsed: the records are taken only if it still is the inflater's last */
 } pd_walk_source;
 
 typedef struct pd_walk
@@ -551,6 +553,8 @@ typedef struct pd_summarize_options
     uint32_t        lean;
     const uint32_t *keep_below, *keep_from;
 } pd_summarize_options;
+/* How many parsed chunks the inflater has run so far (the number of the one its device buffers hold; pd_walk_source::run_id). */
+uint64_t pd_inflater_run_id(pd_inflater *inflater);
 int pd_inflater_run_summarized(pd_inflater *inflater, const uint64_t *member_offsets, uint32_t n_members, const uint64_t *out_offsets,
                                const uint32_t *sample_first, const uint8_t *parse_member, const pd_summarize_options *options,
                                const uint8_t **out, const uint32_t **status, const uint64_t **out_lengths, pd_parsed_blocks *parsed,

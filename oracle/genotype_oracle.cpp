@@ -1122,6 +1122,7 @@ int pd_inflater_run(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *,
 int pd_ctx_set_shard_lanes(pd_ctx *, const pd_shard *, const pd_shard *, uint32_t) { return 1; }
 int pd_inflater_run_parsed(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *, const uint32_t *, const uint8_t *, const uint8_t **, const uint32_t **,
                            const uint64_t **, pd_parsed_blocks *, double *) { return 1; }
+uint64_t pd_inflater_run_id(pd_inflater *) { return 0; }
 int pd_inflater_run_summarized(pd_inflater *, const uint64_t *, uint32_t, const uint64_t *, const uint32_t *, const uint8_t *, const pd_summarize_options *,
                                const uint8_t **, const uint32_t **, const uint64_t **, pd_parsed_blocks *, pd_block_summaries *, double *) { return 1; }
 

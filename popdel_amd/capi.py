@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "pd_local_group_create", "pd_local_group_destroy", "pd_ctx_set_shard_local", "pd_log_table_view",
     "pd_ctx_keep_results_on_device", "pd_calls_merge", "pd_calls_fetch_columns", "pd_merged_free",
     "pd_walk_submit", "pd_walk_supported", "pd_walk_active", "pd_device_warmup", "pd_inflate_members", "pd_inflate_last_error",
-    "pd_inflater_create", "pd_inflater_destroy", "pd_inflater_input", "pd_inflater_run", "pd_inflater_run_parsed", "pd_inflater_run_summarized", "pd_walk_source_counts", "pd_walk_active_ex", "pd_ctx_set_shard_lanes",
+    "pd_inflater_create", "pd_inflater_destroy", "pd_inflater_input", "pd_inflater_run", "pd_inflater_run_parsed", "pd_inflater_run_summarized", "pd_walk_source_counts", "pd_walk_active_ex", "pd_inflater_run_id", "pd_ctx_set_shard_lanes",
     "pd_inflater_last_error", "pd_ctx_stage1_view", "pd_last_stage_timing", "pd_host_copy_gbs", "pd_host_regions_offer", "pd_walk_entry_counts",
 )
 RCCL_ID_BYTES = 128

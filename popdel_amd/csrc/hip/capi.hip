@@ -2858,10 +2858,11 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
                     const uint64_t n = c->hRgOffsets[r + 1] - c->hRgOffsets[r];
                     if (n == 0 || !wk->rg_sources[r].inflater)
                         continue;
-                    uint64_t have = 0;
+                    uint64_t have = 0, runId = 0;
                     int dev = -1;
-                    const uint2 * base = pd::inflaterDeviceRecords(wk->rg_sources[r].inflater, have, dev);
-                    if (!base || dev != c->device || wk->rg_sources[r].first_record > have || n > have - wk->rg_sources[r].first_record)
+                    const uint2 * base = pd::inflaterDeviceRecords(wk->rg_sources[r].inflater, have, dev, runId);
+                    if (!base || dev != c->device || runId != wk->rg_sources[r].run_id || wk->rg_sources[r].first_record > have ||
+                        n > have - wk->rg_sources[r].first_record)
                         continue;
                     c->hWalkDevSrc[r] = reinterpret_cast<uintptr_t>(base + wk->rg_sources[r].first_record);
                     fromDevice += n;
@@ -2871,7 +2872,7 @@ int pd_walk_submit(pd_ctx * c, const pd_walk * wk, uint64_t * ticket)
                 const uint64_t n = c->hRgOffsets[r + 1] - c->hRgOffsets[r];
                 if (n != 0 && !c->hWalkDevSrc[r] && !wk->rg_entries[r])
                     throw HipError{"a read group's entries were to be taken from an inflater's records on the device, which are not there (another GPU, "
-                                   "or POPDEL_HIP_WALK_SOURCES=0), and the host gave no table"};
+                                   "the inflater has run again, or POPDEL_HIP_WALK_SOURCES=0), and the host gave no table"};
                 c->hWalkSrc[r] = n != 0 && !c->hWalkDevSrc[r] && walkGatherWanted() ? deviceViewOfHost(wk->rg_entries[r], n * sizeof(uint2)) : 0u;
                 gathered += c->hWalkSrc[r] ? n : 0u;
             }

@@ -463,6 +463,7 @@ struct pd_inflater
     void *hOffsets = nullptr, *hFlags = nullptr, *hRaws = nullptr, *hWins = nullptr, *hWinCounts = nullptr, *hRecs = nullptr;
     size_t capHOffsets = 0, capHFlags = 0, capHRaws = 0, capHWins = 0, capHWinCounts = 0, capHRecs = 0;
     uint64_t nRecsLast = 0;             // records the last parsed chunk left in dRecs
+    uint64_t runId = 0;                 // parsed chunks run so far
     // records copied back for some blocks only (pd_summarize_options::keep_below / keep_from)
     void *dSpans = nullptr, *hSpans = nullptr, *dRanges = nullptr, *hRanges = nullptr, *dPacked = nullptr;
     size_t capDSpans = 0, capHSpans = 0, capDRanges = 0, capHRanges = 0, capDPacked = 0;
@@ -506,8 +507,9 @@ void growPinned(void *& p, size_t & cap, size_t want)
 }  // namespace
 
 namespace pd {
-const uint2 * inflaterDeviceRecords(pd_inflater * f, uint64_t & count, int & device)
+const uint2 * inflaterDeviceRecords(pd_inflater * f, uint64_t & count, int & device, uint64_t & runId)
 {
+    runId = f ? f->runId : 0;
     count = f ? f->nRecsLast : 0;
     device = f ? f->device : -1;
     return f ? static_cast<const uint2 *>(f->dRecs) : nullptr;
@@ -670,6 +672,7 @@ static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_
             const uint64_t * hRawOff = static_cast<const uint64_t *>(f->hOffsets), *hWinOff = hRawOff + n_members + 1, *hRecOff = hWinOff + n_members + 1;
             const uint64_t nRaws = hRawOff[n_members], nWins = hWinOff[n_members], nRecs = hRecOff[n_members];
             f->nRecsLast = nRecs;
+            ++f->runId;
             const size_t rawBytes = lean ? sizeof(LeanWindow) : sizeof(ParsedWindow);
             growDevice(f->dRaws, f->capRaws, std::max<uint64_t>(1, nRaws) * rawBytes);
             growDevice(f->dRecs, f->capRecs, std::max<uint64_t>(1, nRecs) * sizeof(uint2));
@@ -822,6 +825,7 @@ extern "C" int pd_inflater_run_summarized(pd_inflater * f, const uint64_t * memb
                        opt->inner_offset, opt->starts_room, opt->ends_room, summaries, opt->lean, opt->keep_below, opt->keep_from);
 }
 
+extern "C" uint64_t pd_inflater_run_id(pd_inflater * f) { return f ? f->runId : 0; }
 extern "C" const char * pd_inflate_last_error(void) { return g_inflateError.c_str(); }
 extern "C" const char * pd_inflater_last_error(pd_inflater * f) { return f ? f->error.c_str() : "pd_inflater_last_error: no inflater"; }
 

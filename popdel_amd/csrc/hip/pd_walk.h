@@ -59,7 +59,7 @@ void launchGatherHostEntries(const uint64_t * src, const uint64_t * rgOffsets, u
 // ... and from device memory (the records an inflater parsed, pd_walk_source): the same copy with a workgroup per read group
 void launchGatherDeviceEntries(const uint64_t * src, const uint64_t * rgOffsets, uint2 * entries, unsigned nRg, hipStream_t stream);
 // (inflate.hip) the records array the inflater's last parsed chunk left on the device: base, count, device
-const uint2 * inflaterDeviceRecords(::pd_inflater * inflater, uint64_t & count, int & device);
+const uint2 * inflaterDeviceRecords(::pd_inflater * inflater, uint64_t & count, int & device, uint64_t & runId);
 
 }  // namespace pd
 #endif

@@ -201,7 +201,7 @@ struct alignas(64) DecodedStream      // (neighbours in the pool are filled by d
     const uint8_t * blockCounts = nullptr;
     uint32_t startsRoom = 0, endsRoom = 0;
     pd_inflater * inflater = nullptr;          // the inflater whose device buffers hold the same records, recsV[0] at index recBase
-    uint64_t recBase = 0;
+    uint64_t recBase = 0, runId = 0;
     // (records copied back for the blocks at the two ends only: recsV is null, see recordsOf())
     const uint64_t * recIndex = nullptr;
     const PairRecord * recsPacked = nullptr;
@@ -308,7 +308,7 @@ public:
         const uint8_t * blockCounts = nullptr;
         uint32_t startsRoom = 0, endsRoom = 0;
         pd_inflater * inflater = nullptr;           // whose device buffers hold the records as well (recs[0] = record recBase there)
-        uint64_t recBase = 0;
+        uint64_t recBase = 0, runId = 0;
         const uint64_t * recIndex = nullptr;        // records copied back for some blocks only (recs is null then): recordsOf()
         const PairRecord * recsPacked = nullptr;
         const PairRecord * records(uint32_t first, uint32_t count) const { return recordsOf(recs, recsPacked, recIndex, blockRecs, nBlocks, first, count); }
@@ -392,6 +392,10 @@ public:
         for (size_t k = 0; k < items_.size(); ++k)
             slotOf_[items_[k].sample] = k;
         done_.assign(items_.empty() ? 0 : chunkOf(items_.size() - 1) + 1, 0);
+        // (a round of more chunks than inflaters runs an inflater twice: its records of the first time are gone when the round's
+        // segment is handed over -- such a round copies every record back and the window loop reads the host's tables)
+        roundFitsInflaters_ = done_.size() <= kInflaters;
+        gathered_ = false;
         releasedBelow_ = 0;
         stop_ = false;
         failed_ = false;
@@ -428,6 +432,12 @@ public:
             if (!d)
                 return false;
         return true;
+    }
+    // ... or at least gathered and handed to the threads that drive the device (the gathering thread is through)
+    bool allGathered()
+    {
+        std::lock_guard<std::mutex> lock(m_);
+        return gathered_ || failed_ || items_.empty();
     }
     // the sample's inflated bytes (waits for its chunk), or nullptr: inflate it yourself
     const Ready * wait(unsigned sample)
@@ -621,6 +631,7 @@ private:
         {
             std::lock_guard<std::mutex> lock(m_);
             gatherDone = true;
+            gathered_ = true;
         }
         cv_.notify_all();
         for (std::thread & t : device)
@@ -764,7 +775,7 @@ private:
         std::memset(&sums, 0, sizeof(sums));
         const bool haveSums = summariesWanted && parseOnDevice_;
         const bool lean = haveSums && leanWanted;
-        const bool partial = lean && edgesOnly;
+        const bool partial = lean && edgesOnly && roundFitsInflaters_;
         if (haveSums)
         {
             pd_summarize_options opt;
@@ -782,6 +793,7 @@ private:
         else if (pd_inflater_run_parsed(inf, j.inOff.data(), static_cast<uint32_t>(j.inOff.size() - 1), j.outOff.data(), j.sampleFirst.data(),
                                         j.parseMember.data(), &out, &status, &lengths, &pb, &ms) != 0)
             throw ProfileError("pd_inflater_run_parsed failed");
+        const uint64_t runId = pd_inflater_run_id(inf);
         const double t2 = PhaseClock::now();
         std::lock_guard<std::mutex> lock(m_);           // (the counters below; ready_[] of this chunk is read once done_ says so)
         for (size_t k = 0; k < n; ++k)
@@ -834,8 +846,11 @@ private:
                 else
                     r.recs = static_cast<const PairRecord *>(pb.records) + pb.record_offsets[m0];
                 r.nRecs = static_cast<size_t>(pb.record_offsets[m1] - pb.record_offsets[m0]);
-                r.inflater = inf;
+                // (the window loop may take the entries from these records only while the inflater's buffers hold this chunk: a round
+                // of more chunks than inflaters re-uses them before its segment is handed over)
+                r.inflater = roundFitsInflaters_ ? inf : nullptr;
                 r.recBase = pb.record_offsets[m0];
+                r.runId = runId;
                 if (haveSums)
                 {
                     r.blockRecs = pb.record_offsets + m0;
@@ -877,6 +892,8 @@ private:
     std::mutex m_;
     std::condition_variable cv_;
     std::vector<char> done_;            // per chunk
+    bool gathered_ = false;             // every chunk has been gathered (or the round given up)
+    bool roundFitsInflaters_ = true;    // the round has at most one chunk per inflater
     unsigned releasedBelow_ = 0;
     bool stop_ = false, failed_ = false;
 };
@@ -1652,7 +1669,11 @@ void CallRun::startLoaderAhead()
 {
     // (not before the running round's loader is through: started at once, the two loaders share the device and the round
     // that is waited for gets its blocks later -- 0.064 instead of 0.061 s per warmed round)
-    if (pendingGuess_.empty() || !gunzip_ || !gunzip_->allDone())
+    // (round 6, with the records staying on the device: the running round's loader need only have GATHERED its chunks -- its last
+    // gunzip launches and the next round's first then share the chip, and the kernel, a chain of dependent instructions per member,
+    // gets more out of it the more members are in flight; POPDEL_LOADER_OVERLAP=0 waits for the chunks to be through as before)
+    static const bool overlap = [] { const char * e = getenv("POPDEL_LOADER_OVERLAP"); return !(e && e[0] == '0'); }();
+    if (pendingGuess_.empty() || !gunzip_ || !(overlap ? gunzip_->allGathered() : gunzip_->allDone()))
         return;
     if (!handedOver(loaderJob_[pendingGuessSet_]))      // (a segment still points into that loader's records on the device: at the next call)
         return;
@@ -1782,6 +1803,7 @@ void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned
             out.endsRoom = pre->endsRoom;
             out.inflater = pre->inflater;
             out.recBase = pre->recBase;
+            out.runId = pre->runId;
             out.recIndex = pre->recIndex;
             out.recsPacked = pre->recsPacked;
             return;
@@ -1876,6 +1898,7 @@ void CallRun::decodeSample(unsigned i, const std::string & coordContig, unsigned
             out.endsRoom = pre->endsRoom;
             out.inflater = pre->inflater;
             out.recBase = pre->recBase;
+            out.runId = pre->runId;
             return;
         }
         ++hostDecodes_[1];
@@ -2521,7 +2544,7 @@ void CallRun::fileRun(unsigned sample, const DecodedStream & in, const ReplaySta
     // (the slot holds exactly this run: the device has the same entries in the loader's records)
     if (in.inflater && heldBefore == 0 && target.total == n)
     {
-        slotSource_[rg] = pd_walk_source{in.inflater, in.recBase + st.runFirst};
+        slotSource_[rg] = pd_walk_source{in.inflater, in.recBase + st.runFirst, in.runId};
         slotSourceCount_[rg] = static_cast<uint32_t>(n);
     }
     else
@@ -2939,7 +2962,7 @@ void CallRun::submitPlannedSegment(const WalkShape & shape, const std::vector<ui
     const size_t nRg = prof.starts.size();
     std::vector<uint32_t> counts(nRg), borders(nRg), idOffsets(nRg);
     std::vector<const pd_walk_entry *> tables(nRg);
-    std::vector<pd_walk_source> sources(nRg, pd_walk_source{nullptr, 0});
+    std::vector<pd_walk_source> sources(nRg, pd_walk_source{nullptr, 0, 0});
     bool anySource = false;
     static_assert(sizeof(StartEntry) == sizeof(pd_walk_entry), "the start tables are handed over as they are");
     const bool direct = backendReady_.load() && !getenv("POPDEL_COPY_HAND_OVER");
@@ -3544,7 +3567,7 @@ int CallRun::run()
     profile_->refill = [this](unsigned rg, const StartSlots::VirtualRun & run, StartEntry * dst) {
         readRunFromProfile(sampleOfRg_[rg], contigTable_[run.tag], run.jumpPos, run.firstWindow, run.skip, run.n, dst);
     };
-    slotSource_.assign(p_.readGroups.size(), pd_walk_source{nullptr, 0});
+    slotSource_.assign(p_.readGroups.size(), pd_walk_source{nullptr, 0, 0});
     slotSourceCount_.assign(p_.readGroups.size(), 0);
     bulkRoom_ = p_.windowBuffer / 30u + 512u;
     bulkFiling_ = deviceWalk_ && lightTables_ && !getenv("POPDEL_HOST_FILING");

@@ -23,16 +23,20 @@ inline size_t loaderEnvOr(const char * name, size_t dflt)
 // one of 200,000 takes 37), and with the staging copy of the walk gone the device's work on the blocks is what a warmed
 // round of `popdel call` waits for. Measured on 4,000 samples x 4 Mb, same box (first chunk : the others, seconds per
 // warmed round): 256 : 1024 (rounds 4-5: five chunks) 0.0604, 512 : 2048 0.0546, 1344 : 1344 (three) 0.0545, 1024 : 3072
-// 0.0574, 512 : 4096 0.0615, 2048 : 2048 (two) 0.0563. At most 4,096 items per chunk (its buffers: ~0.5 GB page-locked and
-// on the device); cohorts beyond 12,288 readers take more chunks, an inflater's buffers go round as before.
+// 0.0574, 512 : 4096 0.0615, 2048 : 2048 (two) 0.0563; round 6, same cohort, records staying on the device: three chunks 0.029,
+// two 0.035, one 0.046. Cohorts beyond 52,224 readers take more chunks, an inflater's buffers go round as before.
 // POPDEL_LOADER_CHUNK / POPDEL_LOADER_FIRST_CHUNK fix the sizes (measurements).
 inline size_t loaderChunkFor(size_t readers)
 {
     static const size_t fixed = loaderEnvOr("POPDEL_LOADER_CHUNK", 0);
     if (fixed)
         return fixed;
+    // (round 6: at most 17,408 items per chunk -- three chunks take the 50,000 profiles of BASELINE's largest cohort, so that a round
+    // runs each inflater once and the records it parsed are still on the device when the round's segment is handed over
+    // (pd_walk_source). With lean arrays and records copied back for the ends of a stretch only a chunk of that size is ~1 GB
+    // page-locked and ~5 GB on the device; rounds 4-5 capped at 4,096.)
     const size_t per = ((readers + kLoaderInflaters - 1) / kLoaderInflaters + 63) / 64 * 64;
-    return std::min<size_t>(4096, std::max<size_t>(256, per));
+    return std::min<size_t>(17408, std::max<size_t>(256, per));
 }
 inline size_t loaderFirstChunkFor(size_t readers)
 {

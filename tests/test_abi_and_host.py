@@ -110,23 +110,24 @@ def test_inflate_through_libdeflate_equals_zlib(built, tmp_path):
 
 
 def test_loader_chunks_and_the_replays_batch_limit(built):
-    """The device loader cuts a round's READERS into chunks (three equal ones up to 12,288 readers, 4,096 each beyond) and
+    """The device loader cuts a round's READERS into chunks (three equal ones up to 52,224 readers, 17,408 each beyond) and
     recycles an inflater's buffers once the replay has passed the chunk three before it; the replay releases a batch of SAMPLES as
     a whole. Whatever the numbers: a batch must never touch four consecutive chunks (it would wait for a chunk whose buffers it
     holds itself) -- the limit on its samples is two chunks' worth, so it touches at most three."""
     host = ctypes.CDLL(os.path.join(ROOT, "popdel_amd", "lib", "libpopdel_host.so"))
     host.pdh_loader_chunks.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
     out = (ctypes.c_uint64 * 3)()
-    for samples in (1, 40, 255, 256, 1000, 4000, 4033, 10000, 12288, 12289, 20000, 50000, 100000):
+    for samples in (1, 40, 255, 256, 1000, 4000, 4033, 10000, 12288, 12289, 20000, 50000, 52224, 52225, 100000, 200000):
         for readers in sorted({1, samples // 7 + 1, samples // 2 + 1, max(1, samples - 1), samples}):
             assert host.pdh_loader_chunks(readers, samples, out) == 0
             first, chunk, batch = out[0], out[1], out[2]
-            assert 256 <= chunk <= 4096 and first == chunk
+            assert 256 <= chunk <= 17408 and first == chunk
             n_chunks = 1 + max(0, -(-(readers - first) // chunk)) if readers > first else 1
-            if readers <= 12288:
-                assert n_chunks <= 3, (samples, readers, n_chunks)          # one per inflater: nothing is recycled
+            if readers <= 52224:
+                assert n_chunks <= 3, (samples, readers, n_chunks)          # one per inflater: nothing is recycled, and the records
+                #                                                             a round's segment takes from the device are still there
             # a batch holds at most `batch` readers: they lie in at most three consecutive chunks
-            assert batch <= 2 * 4096 and (n_chunks <= 3 or batch <= first + chunk), (samples, readers)
+            assert batch <= 2 * 17408 and (n_chunks <= 3 or batch <= first + chunk), (samples, readers)
 
 
 def test_parallel_passes_under_fire(built):
