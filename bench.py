@@ -1296,6 +1296,12 @@ def main():
                 if mc:
                     # CPU seconds of all threads per warmed round and the CPUs that kept busy: at the job's quota the round is CPU-bound
                     warmed.update(warmed_cpu_seconds_per_segment=float(mc.group(1)) / ws, warmed_cpus_busy=float(mc.group(1)) / wt)
+            # (round 6: how the round's records were filed -- from the device's block summaries, and how many start entries never
+            # crossed the link -- and where the window loop took its start entries from)
+            for key, mark in (("filing", "[popdel timing] filing: "), ("walk_entries", "[popdel timing] start entries of the window loop: ")):
+                lines = [l for l in r.stderr.splitlines() if mark in l]
+                if lines:
+                    warmed[key] = lines[-1][len(mark):]
             loader = [l for l in r.stderr.splitlines() if "[popdel timing] loader:" in l]
             if loader:
                 warmed["loader"] = loader[-1][len("[popdel timing] loader: "):]
