@@ -771,14 +771,12 @@ bool ChromProfile::addBulk(unsigned rg, const uint32_t * posDev, const RunSummar
     if (s.maxEndBin >= borderBin || s.minEndBin < base || s.maxEndBin - base >= slot.hist.size() || s.minEndBin < s.binBase ||
         s.maxEndBin - s.binBase >= s.nBins)
         return false;
-    if (slot.peak >= 0x8000u)                   // (no count of the slot may saturate: checked count by count below)
+    if (slot.peak >= 0x8000u)                   // (no count of the slot may saturate: every count of the run is below 0x7fff, checked below)
         return false;
-    for (unsigned b = s.minEndBin; b <= s.maxEndBin; ++b)
-        if (endCounts[b - s.binBase] >= 0x7fffu)
-            return false;
     // ---- the load behind every record, window by window: behind the last record that begins in window b the counting cursor
     // stands at max(where it stood, entries of the slot that end before b) -- the records of the run that end before b began
     // before b, so they are filed by then -- and the load is what it was, plus the records filed, minus the cursor's way
+    uint64_t belowAtEnd = 0;                    // entries that end before the window of the run's last record, once it is filed
     {
         const uint16_t * hist = slot.hist.data();
         uint64_t oldBelow = slot.curCum[0];     // entries already in the slot that end before window (base + at)
@@ -787,15 +785,17 @@ bool ChromProfile::addBulk(unsigned rg, const uint32_t * posDev, const RunSummar
         uint64_t filed = 0;
         const uint64_t dNext0 = en.dNext;
         const unsigned histBins = static_cast<unsigned>(slot.hist.size());
+        unsigned tooMany = 0;
         for (unsigned b = firstBin; b <= lastBin; ++b)
         {
             const unsigned rel = b - s.binBase;
             const unsigned t = b - base;        // (b >= base: tFirst >= curBin[0] >= 0 with firstBin > base, or firstBin <= base -> t clamps)
-            // old entries ending before b: advance the prefix to t
+            // old entries ending before b: advance the prefix to t (the slot has none from highBin on)
             const unsigned upTo = b > base ? std::min(t, histBins) : 0u;
-            for (; at < upTo; ++at)
-                if (at >= slot.lowBin && at < slot.highBin)
+            for (const unsigned stop = std::min(upTo, slot.highBin); at < stop; ++at)
+                if (at >= slot.lowBin)
                     oldBelow += hist[at];
+            at = std::max(at, upTo);
             if (startCounts[rel] != 0)
             {
                 filed += startCounts[rel];
@@ -804,10 +804,14 @@ bool ChromProfile::addBulk(unsigned rg, const uint32_t * posDev, const RunSummar
                 if (load0 + filed - (cursor - dNext0) >= cap)
                     return false;
             }
+            belowAtEnd = oldBelow + runBelow;
+            tooMany |= endCounts[rel];
             runBelow += endCounts[rel];
         }
-        if (filed != s.n)
-            return false;                       // (the counts do not add up to the records: not a summary of this run)
+        for (unsigned b = lastBin + 1; b <= s.maxEndBin; ++b)
+            tooMany |= endCounts[b - s.binBase];
+        if (filed != s.n || tooMany >= 0x4000u)
+            return false;                       // (the counts do not add up to the records, or one of them is beyond any sum of bytes: not a summary of this run)
     }
     // ---- file: the start entries in one copy, the end entries as counts and a reference
     StartSlots::Slot & sslot = st.slots[st.writeSlot];
@@ -852,8 +856,20 @@ bool ChromProfile::addBulk(unsigned rg, const uint32_t * posDev, const RunSummar
         slot.deferred.push_back(EndSlots::Deferred{slot.entries.size(), st.writeSlot, firstEntry, s.n, id, innerOffset});
         slot.total += s.n;
     }
+    // ... and the question behind the run's last record (EndSlots::countEndedFast(s.lastPos), whose everyday case this is by the
+    // checks above): the cursor over the counts goes to that record's window, where belowAtEnd entries lie before it
     unsigned load = load0 + s.n;
-    load -= en.countEndedFast(s.lastPos);
+    {
+        const unsigned tLast = lastBin > base ? lastBin - base : 0u;
+        slot.curBin[0] = tLast;
+        slot.curCum[0] = static_cast<unsigned>(belowAtEnd);
+        if (belowAtEnd > en.dNext)
+        {
+            const unsigned k = static_cast<unsigned>(belowAtEnd - en.dNext);
+            en.dNext += k;                      // (below the slot's entries: the record filed last is not over)
+            load -= k;
+        }
+    }
     activeLoad[rg] = load;
     return true;
 }
