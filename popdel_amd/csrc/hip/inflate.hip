@@ -260,50 +260,53 @@ __global__ __launch_bounds__(256) void packRecordsKernel(const uint2 * __restric
         to[i] = from[i];
 }
 
-// exclusive scans of the three counts over the blocks (offsets[k][0 .. n]); one workgroup
-__global__ __launch_bounds__(256) void parseScanKernel(const BlockCounts * __restrict__ counts, uint32_t n, uint64_t * __restrict__ rawOff,
-                                                       uint64_t * __restrict__ winOff, uint64_t * __restrict__ recOff)
+// exclusive scans of the three counts over the blocks (offsets[k][0 .. n]); one workgroup of 1,024: every thread adds up a
+// contiguous stretch of blocks, the stretches' sums are scanned in LDS, every thread writes its stretch's offsets (round 6: the
+// 256-wide form walked a chunk's 28,000 blocks in 110 rounds of three LDS scans, 0.31 ms per chunk)
+constexpr unsigned kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void parseScanKernel(const BlockCounts * __restrict__ counts, uint32_t n, uint64_t * __restrict__ rawOff,
+                                                                uint64_t * __restrict__ winOff, uint64_t * __restrict__ recOff)
 {
-    __shared__ uint64_t sh[3][256];
-    uint64_t carry[3] = {0, 0, 0};
-    for (uint32_t base = 0; base < n; base += 256u)
+    __shared__ uint64_t sh[3][kScanThreads];
+    const uint32_t per = (n + kScanThreads - 1u) / kScanThreads;
+    const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    uint64_t v[3] = {0, 0, 0};
+    for (uint32_t e = lo; e < hi; ++e)
     {
-        const uint32_t e = base + threadIdx.x;
-        uint64_t v[3] = {0, 0, 0};
-        if (e < n)
-        {
-            v[0] = counts[e].raws;
-            v[1] = counts[e].wins;
-            v[2] = counts[e].recs;
-        }
+        v[0] += counts[e].raws;
+        v[1] += counts[e].wins;
+        v[2] += counts[e].recs;
+    }
+    for (int k = 0; k < 3; ++k)
+        sh[k][threadIdx.x] = v[k];
+    __syncthreads();
+    for (unsigned o = 1; o < kScanThreads; o <<= 1)
+    {
+        uint64_t t[3];
         for (int k = 0; k < 3; ++k)
-            sh[k][threadIdx.x] = v[k];
+            t[k] = threadIdx.x >= o ? sh[k][threadIdx.x - o] : 0u;
         __syncthreads();
-        for (unsigned o = 1; o < 256u; o <<= 1)
-        {
-            uint64_t t[3];
-            for (int k = 0; k < 3; ++k)
-                t[k] = threadIdx.x >= o ? sh[k][threadIdx.x - o] : 0u;
-            __syncthreads();
-            for (int k = 0; k < 3; ++k)
-                sh[k][threadIdx.x] += t[k];
-            __syncthreads();
-        }
-        if (e < n)
-        {
-            rawOff[e] = carry[0] + sh[0][threadIdx.x] - v[0];
-            winOff[e] = carry[1] + sh[1][threadIdx.x] - v[1];
-            recOff[e] = carry[2] + sh[2][threadIdx.x] - v[2];
-        }
         for (int k = 0; k < 3; ++k)
-            carry[k] += sh[k][255];
+            sh[k][threadIdx.x] += t[k];
         __syncthreads();
     }
-    if (threadIdx.x == 0)
+    uint64_t at[3];
+    for (int k = 0; k < 3; ++k)
+        at[k] = sh[k][threadIdx.x] - v[k];          // (exclusive: what lies before this thread's stretch)
+    for (uint32_t e = lo; e < hi; ++e)
     {
-        rawOff[n] = carry[0];
-        winOff[n] = carry[1];
-        recOff[n] = carry[2];
+        rawOff[e] = at[0];
+        winOff[e] = at[1];
+        recOff[e] = at[2];
+        at[0] += counts[e].raws;
+        at[1] += counts[e].wins;
+        at[2] += counts[e].recs;
+    }
+    if (threadIdx.x == kScanThreads - 1u)
+    {
+        rawOff[n] = sh[0][kScanThreads - 1u];
+        winOff[n] = sh[1][kScanThreads - 1u];
+        recOff[n] = sh[2][kScanThreads - 1u];
     }
 }
 
@@ -661,7 +664,7 @@ static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_
                                static_cast<const uint64_t *>(f->dOutOff), static_cast<const uint64_t *>(f->dLen),
                                static_cast<const uint32_t *>(f->dStatus), static_cast<const uint8_t *>(f->dWanted), n_members,
                                static_cast<BlockCounts *>(f->dCounts), partial ? static_cast<uint2 *>(f->dSpans) : nullptr);
-            hipLaunchKernelGGL(parseScanKernel, dim3(1), dim3(256), 0, st, static_cast<const BlockCounts *>(f->dCounts), n_members, dRawOff, dWinOff, dRecOff);
+            hipLaunchKernelGGL(parseScanKernel, dim3(1), dim3(kScanThreads), 0, st, static_cast<const BlockCounts *>(f->dCounts), n_members, dRawOff, dWinOff, dRecOff);
             PD_INF_HIP(hipGetLastError());
             PD_INF_HIP(hipMemcpyAsync(f->hOffsets, f->dOffsets, 3 * (static_cast<size_t>(n_members) + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
             PD_INF_HIP(hipMemcpyAsync(f->hFlags, f->dCounts, static_cast<size_t>(n_members) * sizeof(BlockCounts), hipMemcpyDeviceToHost, st));
