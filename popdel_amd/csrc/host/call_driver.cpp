@@ -1164,7 +1164,7 @@ private:
     void startLoaderAhead();
     void createLoaders();
     unsigned deviceSegments_ = 0, hostSegments_ = 0;
-    void leaveDeviceWalk();
+    void leaveDeviceWalk(bool tablesAboutToGo = false);
     void submitPlannedSegment(const WalkShape & shape, const std::vector<uint8_t> & equalRun, const std::vector<uint8_t> & switches);
     // Planned segments go to the backend through a queue with a thread of its own behind it (collect + merge + write of the
     // previous segment, then the hand-over of the next one: the order of the sequential loop), beside the next rounds of
@@ -1591,6 +1591,7 @@ void CallRun::startGunzipPrefetch()
     {
         current = ahead >= 0 ? 1 - ahead : 0;
         waitForHandOver(loaderJob_[current]);       // (no segment may still point into that loader's records on the device)
+        gunzipSet_[current]->edgesOnly = edgesOnly_ && deviceWalk_;     // (with the window loop back on the host every record is wanted here)
         gunzipSet_[current]->start(items, roi.seqName);
         ++roundsOnDemand_;
     }
@@ -1678,6 +1679,7 @@ void CallRun::startLoaderAhead()
     if (!handedOver(loaderJob_[pendingGuessSet_]))      // (a segment still points into that loader's records on the device: at the next call)
         return;
     gunzipAhead_ = pendingGuessSet_;
+    gunzipSet_[gunzipAhead_]->edgesOnly = edgesOnly_ && deviceWalk_;
     gunzipSet_[gunzipAhead_]->start(std::move(pendingGuess_), pendingGuessContig_);
     pendingGuess_.clear();
 }
@@ -2883,6 +2885,38 @@ void CallRun::processSegment()
     clock_.walk += PhaseClock::now() - t0;
     std::vector<std::vector<PairInstance>> & log = prof.endSegmentLog();
     prof.noteSegmentWalked();
+    {
+        static const bool traceActive = getenv("POPDEL_ACTIVE_TRACE") != nullptr;
+        if (traceActive)
+        {
+            size_t left = 0, inst = 0;
+            for (const auto & a : prof.active)
+                left += a.size();
+            size_t carried = 0, openEnd = 0;
+            uint32_t minStart = 0xffffffffu, maxStart = 0;
+            for (const auto & v : log)
+            {
+                inst += v.size();
+                for (const PairInstance & pi : v)
+                {
+                    carried += pi.on == 0;
+                    openEnd += pi.off >= nWindows;
+                    minStart = std::min(minStart, pi.start);
+                    maxStart = std::max(maxStart, pi.start);
+                }
+            }
+            std::cerr << "[popdel active]   instances from window 0: " << carried << ", to the last window: " << openEnd << ", pair starts " << minStart << ".." << maxStart
+                      << "; position after the walk " << prof.currentPos << ", right border " << prof.currentRightBorder << "; start slots read "
+                      << prof.starts[0].readSlot << " write " << prof.starts[0].writeSlot << " sizes " << prof.starts[0].slots[0].total << " " << prof.starts[0].slots[1].total
+                      << " " << prof.starts[0].slots[2].total << " id offsets " << prof.starts[0].slots[0].idOffset << " " << prof.starts[0].slots[1].idOffset << " "
+                      << prof.starts[0].slots[2].idOffset << std::endl;
+            std::cerr << "[popdel active] segment walked on the host: " << windows_.current.contig << ":" << firstPos << ", " << nWindows << " windows, " << inst
+                      << " pair instances, " << left << " pairs active at its end; read groups' cursors: starts " << prof.starts[0].readIdx << "/"
+                      << prof.starts[0].slots[prof.starts[0].readSlot].total << " ends " << prof.ends[0].readIdx << "/"
+                      << prof.ends[0].slots[prof.ends[0].readSlot].total << " (end slots read " << prof.ends[0].readSlot << " write " << prof.ends[0].writeSlot
+                      << ", sizes " << prof.ends[0].slots[0].total << " " << prof.ends[0].slots[1].total << " " << prof.ends[0].slots[2].total << ")" << std::endl;
+        }
+    }
     if (havePlan)
         checkWalkAgainstPlan(planned, plannedRun, plannedSwitches, plannedCursors, firstPos, nWindows, log);
     if (observer_ && observer_->onSegment)
@@ -3213,13 +3247,16 @@ void CallRun::drainHandOver()
 
 // From the device's window loop back to the one here: the pairs the device holds as active become the tables' active
 // sets (the cursors have been kept where the walk would have left them all along).
-void CallRun::leaveDeviceWalk()
+void CallRun::leaveDeviceWalk(bool tablesAboutToGo)
 {
     ensureBackend();
     drainHandOver();
     ChromProfile & prof = *profile_;
-    prof.materializeAllStarts();        // (entries the device kept to itself: read again from the profiles)
-    prof.setLightEnds(false);           // the window loop comes back to the host: it walks ordered end tables
+    if (!tablesAboutToGo)
+    {
+        prof.materializeAllStarts();    // (entries the device kept to itself: read again from the profiles)
+        prof.setLightEnds(false);       // the window loop comes back to the host: it walks ordered end tables
+    }                                   // (else: the caller resets the tables and turns light mode off on the empty ones)
     for (size_t r = 0; r < ctxs_.size(); ++r)
     {
         uint64_t n = 0;
@@ -3304,28 +3341,41 @@ bool CallRun::finalizeRoi()
         return false;
     }
     flushPending();                             // records of the finished ROI carry the old contig id
+    // (the tables start afresh but pairs that are still active stay so -- the reference keeps them across the ROI change --: only
+    // with none left can the next ROI's first segment be planned in closed form. The pairs the device holds come back BEFORE the
+    // tables are reset -- as they stand after the last segment, which has been handed over by then -- and the entries it kept to
+    // itself are not read back: the tables are about to go.)
+    uint64_t left = 0;
+    if (deviceWalkOffered_ && deviceWalk_)
+    {
+        drainHandOver();
+        for (pd_ctx * c : ctxs_)
+        {
+            uint64_t n = 0;
+            if (pd_walk_active(c, &n, nullptr, nullptr, nullptr, nullptr, 0) != 0)
+                throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(c));
+            left += n;
+        }
+        if (left != 0)
+            leaveDeviceWalk(true);
+    }
     profile_->fullReset();
-    // (the tables start afresh but pairs that are still active stay so: only with none left can the next ROI's first
-    // segment be planned in closed form)
+    if (deviceWalkOffered_ && !deviceWalk_ && profile_->lightEnds())
+        profile_->setLightEnds(false);
     if (walkCheck_ && walkCheck_->activeTotal() == 0)
         profile_->setActiveKnownEmpty(true);
+    {
+        uint64_t kept = 0;
+        for (const auto & a : profile_->active)
+            kept += a.size();
+        if (timingWanted_)
+            std::cerr << "[popdel timing] region change: " << kept << " pairs stay active in the tables (" << left << " came back from the device)" << std::endl;
+    }
     if (deviceWalkOffered_)
     {
-        uint64_t left = 0;
-        if (deviceWalk_)
+        if (!deviceWalk_)
         {
-            for (pd_ctx * c : ctxs_)
-            {
-                uint64_t n = 0;
-                if (pd_walk_active(c, &n, nullptr, nullptr, nullptr, nullptr, 0) != 0)
-                    throw ProfileError(std::string("[PopDel] Genotyping backend failed: ") + pd_last_error(c));
-                left += n;
-            }
-            if (left != 0)
-                leaveDeviceWalk();          // (the reference keeps such pairs active across the ROI change: the tables take over)
-        }
-        else
-        {
+            left = 0;
             for (const auto & a : profile_->active)
                 left += a.size();
         }

@@ -9,7 +9,10 @@
 
 namespace pdh {
 
-constexpr size_t kLoaderInflaters = 3;
+#ifndef PDH_LOADER_INFLATERS
+#define PDH_LOADER_INFLATERS 3          // (measurements: -DPDH_LOADER_INFLATERS=n builds a binary with n inflaters per loader)
+#endif
+constexpr size_t kLoaderInflaters = PDH_LOADER_INFLATERS;
 
 inline size_t loaderEnvOr(const char * name, size_t dflt)
 {

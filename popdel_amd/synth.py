@@ -76,7 +76,9 @@ def sample_pairs(seed: int, region, lib: Library, deletions=()):
 
 def write_profile(path, rg_name, pos, dev, lib: Library, contigs=(("chr20", CHR20_LEN),), chrom=0, region_size=10000,
                   compressed=True):
-    """Write one single-read-group profile. ``pos``/``dev`` must be sorted by (pos, dev)."""
+    """Write one single-read-group profile. ``pos``/``dev`` must be sorted by (pos, dev). Data on SEVERAL contigs: ``chrom`` a list
+    of contig indices in increasing order, ``pos`` and ``dev`` lists of the same length (one pair of arrays per contig)."""
+    segments = list(zip(chrom, pos, dev)) if isinstance(chrom, (list, tuple)) else [(chrom, pos, dev)]
     hist_start, hist = lib.histogram()
     num_regions = sum(l // region_size + 1 for _, l in contigs)
     hdr = bytearray(b"POPDEL\x01")
@@ -91,38 +93,39 @@ def write_profile(path, rg_name, pos, dev, lib: Library, contigs=(("chr20", CHR2
     for name, length in contigs:
         hdr += struct.pack("<I", len(name) + 1) + name.encode() + b"\0" + struct.pack("<I", length)
 
-    first_slot = sum(l // region_size + 1 for _, l in contigs[:chrom])
     offsets = [0] * num_regions
     body = bytearray()
     base = len(hdr)
-    win = pos // 256
-    # boundaries of the 256-bp windows
-    cuts = np.flatnonzero(np.diff(win)) + 1
-    starts = np.concatenate(([0], cuts)) if len(pos) else np.array([], dtype=np.int64)
-    ends = np.concatenate((cuts, [len(pos)])) if len(pos) else np.array([], dtype=np.int64)
-    rec = np.empty(len(pos), dtype=_REC)
-    rec["off"] = (pos - win * 256).astype(np.uint8)
-    rec["dev"] = dev
-    raw = rec.tobytes()
-    cur_region, blk = None, bytearray()
+    for chrom, pos, dev in segments:
+        first_slot = sum(l // region_size + 1 for _, l in contigs[:chrom])
+        win = pos // 256
+        # boundaries of the 256-bp windows
+        cuts = np.flatnonzero(np.diff(win)) + 1
+        starts = np.concatenate(([0], cuts)) if len(pos) else np.array([], dtype=np.int64)
+        ends = np.concatenate((cuts, [len(pos)])) if len(pos) else np.array([], dtype=np.int64)
+        rec = np.empty(len(pos), dtype=_REC)
+        rec["off"] = (pos - win * 256).astype(np.uint8)
+        rec["dev"] = dev
+        raw = rec.tobytes()
+        cur_region, blk = None, bytearray()
 
-    def flush():
-        nonlocal blk
-        if cur_region is None:
-            return
-        offsets[first_slot + cur_region] = base + len(body)
-        body.extend(gzip.compress(bytes(blk), 6, mtime=0) if compressed else blk)
-        blk = bytearray()
+        def flush():
+            nonlocal blk
+            if cur_region is None:
+                return
+            offsets[first_slot + cur_region] = base + len(body)
+            body.extend(gzip.compress(bytes(blk), 6, mtime=0) if compressed else blk)
+            blk = bytearray()
 
-    for a, b in zip(starts.tolist(), ends.tolist()):
-        bp = int(win[a]) * 256
-        r = bp // region_size
-        if r != cur_region:
-            flush()
-            cur_region = r
-        blk += struct.pack("<III", chrom, bp, b - a)
-        blk += raw[a * 5:b * 5]
-    flush()
+        for a, b in zip(starts.tolist(), ends.tolist()):
+            bp = int(win[a]) * 256
+            r = bp // region_size
+            if r != cur_region:
+                flush()
+                cur_region = r
+            blk += struct.pack("<III", chrom, bp, b - a)
+            blk += raw[a * 5:b * 5]
+        flush()
     prev = base + len(body)
     for j in range(num_regions - 1, -1, -1):
         if offsets[j] == 0:

@@ -129,6 +129,52 @@ def test_entries_the_device_kept_come_back_when_the_tables_need_them(built, coho
                 assert "walked on the host" in r1.stderr and " 0 walked on the host" not in r1.stderr, r1.stderr[-600:]
 
 
+def two_contig_cohort(d, n):
+    """profiles with data on two contigs (chr19: 500,000-1,050,000 with a 900-bp deletion, chr20: 1,000,000-1,500,000 with one of
+    1,500 bp): what no other cohort of the suite has -- the loader crosses a contig border in the middle of a run. (The data of
+    the first contig ends in the middle of a slot for every sample: no pair is left active at the border. With pairs left --
+    samples that finish a round before the others are walked again by the reference's initializeActiveReads,
+    profile_structure_popdel_call.h:1120-1135, and never deactivated -- the reference carries ids into recycled tables, undefined
+    behaviour there, and the device's window loop hands over to the host's)"""
+    from popdel_amd import synth
+    contigs = (("chr19", 3000000), ("chr20", synth.CHR20_LEN))
+    paths = []
+    for k in range(n):
+        lib = synth.Library(hist_seed=100 + k)
+        p19, d19 = synth.sample_pairs(9000 + k, (500000, 1050000), lib, [synth.Deletion(800000, 900, [1, 2, 0][k % 3])])
+        p20, d20 = synth.sample_pairs(9100 + k, (1000000, 1500000), lib, [synth.Deletion(1250000, 1500, [2, 0, 1][k % 3])])
+        if k == 5:                          # (one sample's data on the second contig begins late and ends early)
+            keep = (p20 >= 1150000) & (p20 < 1420000)
+            p20, d20 = p20[keep], d20[keep]
+        path = os.path.join(d, "m%02d.profile" % k)
+        synth.write_profile(path, "M%02d" % k, [p19, p20], [d19, d20], lib, contigs=contigs, chrom=[0, 1])
+        paths.append(path)
+    with open(os.path.join(d, "profiles.txt"), "w") as fh:
+        fh.write("\n".join(paths) + "\n")
+
+
+def test_data_on_two_contigs(built, tmp_path):
+    """The loader across a contig border (the tables are reset, the virtual runs and deferred references of the contig before are
+    dropped, the loader that went ahead guessed the wrong contig): device loader with records staying on the device against the
+    host-only configuration and against the CPU driver (oracle kernels), whole genome, window-wise, regions on both contigs,
+    small buffers. Same bytes, and both planted deletions are called on their contigs."""
+    from conftest import ORACLE_CALL
+    d = str(tmp_path / "two")
+    os.makedirs(d)
+    two_contig_cohort(d, 40)
+    for args in ([], ["-n"], ["-r", "chr19:600000-1000000", "-r", "chr20:1100000-1400000", "-n"], ["-b", "50000"]):
+        r1, new = call(d, str(tmp_path / "new.vcf"), *args)
+        r0, old = call(d, str(tmp_path / "old.vcf"), *args, env={"POPDEL_HOST_GUNZIP": "1", "POPDEL_HEAVY_TABLES": "1"})
+        assert r0.returncode == 0 and r1.returncode == 0, (args, r0.stderr[-300:], [l for l in r1.stderr.splitlines() if "timing" not in l][-6:])
+        assert new == old, args
+        subprocess.check_call([ORACLE_CALL, os.path.join(d, "profiles.txt"), "-o", str(tmp_path / "cpu.vcf")] + args, stdout=subprocess.DEVNULL)
+        assert strip_date(open(str(tmp_path / "cpu.vcf")).read()) == new, args
+        where = [(l.split("\t")[0], int(l.split("\t")[1])) for l in new.splitlines() if not l.startswith("#")]
+        assert any(c == "chr19" and abs(p - 800000) < 400 for c, p in where) and any(c == "chr20" and abs(p - 1250000) < 400 for c, p in where), where[:5]
+        filed = [l for l in r1.stderr.splitlines() if "[popdel timing] filing:" in l][0]
+        assert int(filed.split("usable blocks); ")[1].split()[0]) > 500000, filed        # (entries stayed on the device on both contigs)
+
+
 @pytest.mark.parametrize("region_size", [2000, 50000])
 def test_uneven_profiles_behave_as_on_the_host(built, tmp_path, region_size):
     """Profiles that differ where the prefetch has to be careful: index regions of 2,000 or 50,000 bp instead of 10,000 (the

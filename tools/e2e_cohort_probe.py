@@ -29,14 +29,18 @@ def main():
         t0 = time.perf_counter()
         lst = synth.write_cohort(d, n, region=region, deletions=synth.single_deletion, workers=bench.usable_cores())
         t_write = time.perf_counter() - t0
-        product = os.path.join(ROOT, "popdel_amd", "lib", "popdel")
         for v in variants:
             env = dict(os.environ, POPDEL_TIMING="1")
             env.pop("POPDEL_HIP_LANES", None)
+            binary = "popdel"
             if v != "-":
                 for kv in v.split(","):
                     k, val = kv.split("=", 1)
-                    env[k] = val
+                    if k == "BINARY":           # (another build of the host side in popdel_amd/lib: measurements)
+                        binary = val
+                    else:
+                        env[k] = val
+            product = os.path.join(ROOT, "popdel_amd", "lib", binary)
             out = os.path.join(d, "out.vcf")
             q = time.perf_counter()
             r = subprocess.run([product, "call", lst, "-o", out, "-r", "chr20:%d-%d" % region], env=env, capture_output=True, text=True, timeout=900)
