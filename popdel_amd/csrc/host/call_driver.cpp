@@ -1655,11 +1655,16 @@ void CallRun::createLoaders()
         g->summariesWanted = deviceWalkOffered_ && !getenv("POPDEL_HEAVY_TABLES") && !getenv("POPDEL_HOST_FILING") && region != 0 &&
                              g->startsRoom + g->endsRoom <= 12000u;
         g->leanWanted = !getenv("POPDEL_FULL_PARSE");
-        // (... and the records of the blocks in the middle of a stretch stay on the device: one context on the loaders' GPU, whose
-        // window loop takes its entries from there; POPDEL_HOST_RECORDS=1 copies every record back as before)
+        // (... and the records of the blocks in the middle of a stretch stay on the device: every context of the run on the loaders'
+        // GPU -- one context, or several on one GPU --, whose window loops take their entries from there; with the contexts on
+        // several GPUs a sample's blocks may be parsed on another GPU than its context's, and every record is copied back;
+        // POPDEL_HOST_RECORDS=1 copies every record back as before)
         const char * src = getenv("POPDEL_HIP_WALK_SOURCES");
-        g->edgesOnly = g->summariesWanted && g->leanWanted && ctxs_.size() == 1 && gunzipDevices_.size() == 1 && !getenv("POPDEL_HOST_RECORDS") &&
-                       !getenv("POPDEL_COPY_HAND_OVER") && !(src && src[0] == '0');
+        bool oneGpu = true;
+        for (int dev : gunzipDevices_)
+            oneGpu = oneGpu && dev == gunzipDevices_[0];
+        g->edgesOnly = g->summariesWanted && g->leanWanted && oneGpu && !getenv("POPDEL_HOST_RECORDS") && !getenv("POPDEL_COPY_HAND_OVER") &&
+                       !(src && src[0] == '0');
         edgesOnly_ = g->edgesOnly;
     }
     const char * ahead = getenv("POPDEL_LOADER_AHEAD");
