@@ -210,3 +210,50 @@ def test_uneven_profiles_behave_as_on_the_host(built, tmp_path, region_size):
         assert line, r1.stderr[-400:]
         print("region size %d, %s: %s" % (region_size, " ".join(args), line[0].split("thread-seconds for it; ")[1]))
         print([l for l in r1.stderr.splitlines() if "[popdel timing] filing:" in l][0])
+
+
+def test_the_load_cap_bites_in_blocks_filed_from_summaries(built, tmp_path):
+    """Where ChromosomeProfile::add's maxLoad rule drops records (profile_structure_popdel_call.h:1084-1112) a block cannot be filed
+    from its counts: addBulk refuses it, the block's records are read again from the profile and filed one by one -- the same
+    records dropped as on the host. Samples with stretches of 150-400x coverage (the default cap of 100 active pairs bites
+    there), and caps of 12 / 25 / none from an -A file on samples without such stretches: device loader with records staying on
+    the device against host filing, the host-only configuration and the CPU driver; same bytes, and blocks were refused."""
+    import numpy as np
+    from conftest import ORACLE_CALL
+    from popdel_amd import synth
+    d = str(tmp_path / "bursts")
+    os.makedirs(d)
+    region = (1000000, 1500000)
+    paths = []
+    for k in range(40):
+        lib = synth.Library(hist_seed=500 + k)
+        dels = [synth.Deletion(1200000, 1100, [1, 2, 0][k % 3]), synth.Deletion(1380000, 700, [2, 1, 1][k % 3])]
+        pos, dev = synth.sample_pairs(8000 + k, region, lib, dels)
+        if k % 5 == 2:                      # pile-ups: 3-6 kb at 150-400x, one of them across an index-region border
+            for j, (at, length, cov) in enumerate(((1098500 + 40 * k, 3000, 150.0), (1301000, 6000, 400.0), (1449000 - 70 * k, 2500, 250.0))):
+                heavy = synth.Library(hist_seed=500 + k, coverage=cov)
+                p2, d2 = synth.sample_pairs(8500 + 3 * k + j, (at, at + length), heavy)
+                pos, dev = np.concatenate([pos, p2]), np.concatenate([dev, d2])
+            order = np.lexsort((dev, pos))
+            pos, dev = pos[order], dev[order]
+        p = os.path.join(d, "b%02d.profile" % k)
+        synth.write_profile(p, "B%02d" % k, pos, dev, lib)
+        paths.append(p)
+    with open(os.path.join(d, "profiles.txt"), "w") as fh:
+        fh.write("\n".join(paths) + "\n")
+    caps = os.path.join(d, "caps.txt")
+    with open(caps, "w") as fh:
+        fh.write("B00 12\nB01 25\nB03 0\nB07 0\nB10 18\n")
+    for args in (["-r", "chr20:1000000-1500000"], ["-r", "chr20:1000000-1500000", "-A", caps, "-n"], ["-r", "chr20:1003001-1500000", "-A", caps, "-b", "60000"]):
+        r1, new = call(d, str(tmp_path / "new.vcf"), *args)
+        assert r1.returncode == 0, r1.stderr[-400:]
+        filed = [l for l in r1.stderr.splitlines() if "[popdel timing] filing:" in l][0]
+        print(filed)
+        refused = int(filed.split(" refused by the tables")[0].split()[-1])
+        assert refused > 0 and int(filed.split("usable blocks); ")[1].split()[0]) > 200000, filed
+        for env in ({"POPDEL_HOST_FILING": "1"}, {"POPDEL_HOST_GUNZIP": "1", "POPDEL_HEAVY_TABLES": "1"}, {"POPDEL_TEST_LEAVE_WALK_AT": "3"}):
+            r0, old = call(d, str(tmp_path / "old.vcf"), *args, env=env)
+            assert r0.returncode == 0, (env, r0.stderr[-300:])
+            assert new == old and len(new.splitlines()) > 20, (args, env)
+        subprocess.check_call([ORACLE_CALL, os.path.join(d, "profiles.txt"), "-o", str(tmp_path / "cpu.vcf")] + args, stdout=subprocess.DEVNULL)
+        assert strip_date(open(str(tmp_path / "cpu.vcf")).read()) == new, args
