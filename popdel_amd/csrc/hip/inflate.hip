@@ -39,10 +39,6 @@ __global__ __launch_bounds__(L) void inflateMembersKernel(const uint8_t * __rest
                                                           uint64_t * __restrict__ outLen, unsigned nBatches)
 {
     __shared__ uint16_t tabs[pdinf::kTabWords * L];
-    __shared__ uint32_t crcTab[256];
-    for (unsigned i = threadIdx.x; i < 256u; i += L)
-        crcTab[i] = pdinf::crcTableEntry(i);
-    __syncthreads();
     pdinf::StridedTablesOf<L> t;
     t.base = tabs + threadIdx.x;
     __shared__ uint8_t lens[pdinf::kCodeLengths * L];
@@ -53,10 +49,44 @@ __global__ __launch_bounds__(L) void inflateMembersKernel(const uint8_t * __rest
         if (m >= n)
             continue;
         uint64_t got = 0, used = 0;
+        uint32_t crc = 0;
         const uint64_t a = inOff[m], b = outOff[m];
-        status[m] = pdinf::inflateGzipMember(data + a, inOff[m + 1] - a, out + b, outOff[m + 1] - b, &got, &used, t, crcTab);
-        outLen[m] = got;
+        status[m] = pdinf::inflateGzipMember(data + a, inOff[m + 1] - a, out + b, outOff[m + 1] - b, &got, &used, t, nullptr, &crc);
+        outLen[m] = got | (uint64_t)crc << 32;          // (the trailer's CRC rides along to crcMembersKernel, which takes it out again)
     }
+}
+
+// The CRC-32 of what the members inflated to, against their trailers (RFC 1952): a lane per member, eight bytes per load, every
+// lane of a wave busy -- in the symbol loop above, where eight lanes of a wave work, the same table look-ups cost eight times the
+// issue slots. Members the decoder refused keep their status.
+__global__ __launch_bounds__(256) void crcMembersKernel(const uint8_t * __restrict__ out, const uint64_t * __restrict__ outOff, uint32_t n,
+                                                        uint32_t * __restrict__ status, uint64_t * __restrict__ outLen)
+{
+    __shared__ uint32_t crcTab[256];
+    crcTab[threadIdx.x] = pdinf::crcTableEntry(threadIdx.x);
+    __syncthreads();
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    if (m >= n)
+        return;
+    const uint64_t packed = outLen[m];
+    const uint32_t len = (uint32_t)packed;
+    outLen[m] = len;
+    if (status[m] != pdinf::kOk)
+        return;
+    const uint8_t * p = out + outOff[m];
+    uint32_t c = 0xffffffffu, i = 0;
+    for (; i + 8u <= len; i += 8u)
+    {
+        uint64_t v;
+        __builtin_memcpy(&v, p + i, 8);
+#pragma unroll
+        for (unsigned k = 0; k < 8u; ++k, v >>= 8)
+            c = crcTab[(c ^ (uint32_t)v) & 0xffu] ^ (c >> 8);
+    }
+    for (; i < len; ++i)
+        c = crcTab[(c ^ p[i]) & 0xffu] ^ (c >> 8);
+    if ((c ^ 0xffffffffu) != (uint32_t)(packed >> 32))
+        status[m] = pdinf::kBadCrc;
 }
 
 // Members per wave (4 | 8 | 16 | 32) and the waves of that shape a CU holds (the runtime's occupancy figure: LDS and VGPRs).
@@ -101,6 +131,7 @@ unsigned launchInflate(unsigned nCu, hipStream_t st, const uint8_t * data, const
     case 16u: hipLaunchKernelGGL(inflateMembersKernel<16u>, dim3(groups), dim3(16u), 0, st, data, inOff, n, out, outOff, status, outLen, nBatches); break;
     default: hipLaunchKernelGGL(inflateMembersKernel<32u>, dim3(groups), dim3(32u), 0, st, data, inOff, n, out, outOff, status, outLen, nBatches); break;
     }
+    hipLaunchKernelGGL(crcMembersKernel, dim3((n + 255u) / 256u), dim3(256u), 0, st, out, outOff, n, status, outLen);
     return groups;
 }
 

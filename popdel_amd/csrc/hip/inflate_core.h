@@ -199,19 +199,21 @@ PD_INF_FN int buildCode(Tab & tab, unsigned from, unsigned n, unsigned countAt, 
 }
 
 // A canonical code as the symbol loop wants it: limit[len] = one past the last code of length len, left-aligned to 15 bits
-// (non-decreasing in len), in REGISTERS (every use below is unrolled); base[len] = index of the length's first symbol minus
-// its first code, in the table words at baseAt (biased by 0x8000). One symbol then costs a bit reversal, fifteen compares and
-// two dependent table reads instead of one table read per code bit.
+// (non-decreasing in len, at most 0x8000), in REGISTERS, two to a word: pair[j] holds limit[2j + 1] + 0x7fff in its low half and
+// limit[2j + 2] + 0x7fff in its high half (the sixteenth half: 0xffff). With the next fifteen bits v in both halves of a word,
+// pair[j] - v has bit 15 of a half set where v < limit (no borrow crosses the halves: limit + 0x7fff - v >= 0), so the length of
+// the code is 17 minus the number of such bits -- a subtraction, a mask and a bit count per two lengths instead of a compare, a
+// wait and a conditional add per length. base[len] = index of the length's first symbol minus its first code, in the table
+// words at baseAt (biased by 0x8000). One symbol then costs a bit reversal, these and two dependent table reads.
 struct FastCode
 {
-    uint32_t limit[kMaxBits + 1];
+    uint32_t pair[(kMaxBits + 1) / 2];
 };
 
 template <class Tab>
 PD_INF_FN void buildFast(Tab & tab, unsigned countAt, unsigned baseAt, FastCode & fc)
 {
-    uint32_t first = 0, index = 0;
-    fc.limit[0] = 0;
+    uint32_t first = 0, index = 0, low = 0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -220,10 +222,15 @@ PD_INF_FN void buildFast(Tab & tab, unsigned countAt, unsigned baseAt, FastCode 
         const uint32_t count = tab.w(countAt + len);
         tab.w(baseAt + len) = (uint16_t)(0x8000u + index - first);
         first += count;
-        fc.limit[len] = first << (kMaxBits - len);
+        const uint32_t biased = (first << (kMaxBits - len)) + 0x7fffu;
+        if (len & 1u)
+            low = biased;
+        else
+            fc.pair[len / 2u - 1u] = low | (biased << 16);
         index += count;
         first <<= 1;
     }
+    fc.pair[kMaxBits / 2u] = low | 0xffff0000u;
 }
 
 PD_INF_FN uint32_t reverse15(uint32_t v)
@@ -244,12 +251,14 @@ PD_INF_FN int decodeFast(BitReader & br, Tab & tab, const FastCode & fc, unsigne
 {
     br.refill();
     const uint32_t v = reverse15((uint32_t)br.buf & 0x7fffu);          // (bits beyond the input read as zeros)
-    unsigned len = 1;
+    const uint32_t both = v * 0x10001u;
+    unsigned below = 0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (unsigned k = 1; k <= kMaxBits; ++k)
-        len += v >= fc.limit[k] ? 1u : 0u;
+    for (unsigned j = 0; j < (kMaxBits + 1) / 2; ++j)
+        below += (unsigned)__builtin_popcount((fc.pair[j] - both) & 0x80008000u);
+    const unsigned len = 17u - below;
     if (len > kMaxBits)
         return -1;
     if (len > br.cnt)
@@ -267,92 +276,215 @@ struct Output
 {
     uint8_t * out;
     uint32_t  n, cap;
-    uint64_t  tail;        // the last eight bytes written, most recent in the low byte
-    uint32_t  crc;
-    const uint32_t * crcTable;
+    uint64_t  hist;        // the last eight bytes written as they lie in memory: the most recent one in the top byte
     PD_INF_FN void put(unsigned b)
     {
         out[n++] = (uint8_t)b;
-        tail = (tail << 8) | b;
-        crc = crcTable[(crc ^ b) & 0xffu] ^ (crc >> 8);
+        hist = (hist >> 8) | ((uint64_t)b << 56);
     }
 };
 
+// The input as the symbol loop reads it: the 32-bit word the bit cursor stands in and the one behind it, and the bits left in
+// the member. One symbol with its extra bits is at most 28 bits: ONE look at the next 32 bits serves a whole trip of the loop.
+// The word after these two is loaded at the beginning of EVERY trip and taken at its end if the cursor has crossed into the
+// second word by then (mostly it has not: the load is repeated, out of the cache) -- its latency passes behind the decoding,
+// and no register that waits for memory lives across the loop's back edge (the compiler would wait for it there, and for the
+// stores in front of it). Bits beyond the end of the input read as zeros; `left` tells when a symbol took bits that were not there.
+struct WordReader
+{
+    const uint8_t * in;
+    uint32_t end, at;      // bytes; at: where w0 was read from
+    uint32_t w0, w1, bo;
+    int32_t  left;         // bits of input not yet consumed
+    PD_INF_FN uint32_t word(uint32_t p) const
+    {
+        uint32_t v = 0;
+        if (p + 4u <= end)
+            __builtin_memcpy(&v, in + p, 4);
+        else
+            for (unsigned i = 0; i < 4u && p + i < end; ++i)
+                v |= (uint32_t)in[p + i] << (8u * i);
+        return v;
+    }
+    PD_INF_FN void start(const uint8_t * data, uint32_t to, uint32_t bitPos)
+    {
+        in = data;
+        end = to;
+        at = (bitPos >> 5) << 2;
+        bo = bitPos & 31u;
+        w0 = word(at);
+        w1 = word(at + 4u);
+        left = (int32_t)(8u * to - bitPos);
+    }
+    PD_INF_FN uint32_t upcoming() const { return word(at + 8u); }
+    PD_INF_FN uint32_t peek() const
+    {
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_alignbit(w1, w0, bo);
+#else
+        return (uint32_t)((((uint64_t)w1 << 32) | w0) >> bo);
+#endif
+    }
+    PD_INF_FN void consume(unsigned n, uint32_t next)      // n < 32; next: upcoming() of this position
+    {
+        bo += n;
+        left -= (int32_t)n;
+        if (bo >= 32u)
+        {
+            bo -= 32u;
+            w0 = w1;
+            w1 = next;
+            at += 4u;
+        }
+    }
+    PD_INF_FN uint32_t bitPos() const { return 8u * at + bo; }
+};
+
+PD_INF_FN uint32_t bitField(uint32_t v, unsigned from, unsigned n)      // n < 32, from < 32
+{
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(v, from, n);
+#else
+    return (v >> from) & ((1u << n) - 1u);
+#endif
+}
+
+// The symbols of one block. A trip of the loop decodes ONE symbol -- a literal / length symbol or, behind a length, the distance
+// symbol: which code the lane reads is a matter of its state, the instructions are the same, so that the lanes of a wave (each
+// with a member of its own, each somewhere else in it) walk through one instruction stream instead of taking turns on the
+// literal, the length and the distance path -- and emits what the trip BEFORE it produced, up to four bytes a time: a literal is
+// a copy of one byte out of a register, a match more than eight bytes back one of bytes loaded eight at a time -- the load goes
+// out at the beginning of the trip that emits the match, behind the bytes of the item before it, and has the symbol's decoding
+// to arrive --, a nearer match comes out of the last eight bytes written, which live in a register. (The CRC is not
+// taken here: a pass of its own over the output does that with every lane of a wave busy, crcMembersKernel / inflateGzipMember.)
 template <class Tab>
 PD_INF_FN uint32_t inflateCodes(BitReader & br, Output & o, Tab & tab)
 {
     FastCode lenCode, distCode;
     buildFast(tab, kTabLenCount, kTabLenBase, lenCode);
     buildFast(tab, kTabDistCount, kTabDistBase, distCode);
+    WordReader wr;
+    wr.start(br.in, br.end, 8u * (br.pos - (br.haveAhead ? 4u : 0u)) - br.cnt);
+    uint32_t rc = kOk, matchLen = 0;
+    bool distNext = false;
+    uint32_t itemBytes = 0, itemDist = 0, itemLiteral = 0;     // the item waiting to be emitted: itemDist = 0 for a literal
     for (;;)
     {
-        int sym = decodeFast(br, tab, lenCode, kTabLenBase, kTabLenSymbol);
-        if (sym < 0)
-            return sym == -2 ? kTruncated : kBadCode;
-        if (sym < 256)
+        // the loads of the trip: the input word that may be needed at its end, and the eight bytes at the source of a match more
+        // than eight bytes back that is waiting to be emitted. (On the device both go out unconditionally -- a lane without
+        // such a match reads the beginning of its output -- and through inline assembly, the wait for them placed by hand
+        // behind the decoding: the compiler would wait where the branches around conditional loads join, that is, at once.)
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+        uint32_t upcoming;
+        uint64_t itemChunk;
+        const bool inside = wr.at + 12u <= wr.end;
         {
-            if (o.n >= o.cap)
-                return kOutputFull;
-            o.put((unsigned)sym);
-            continue;
+            const uint8_t * wordAt = wr.in + (inside ? wr.at + 8u : 0u);
+            const uint8_t * chunkAt = o.out + (itemDist > 8u ? o.n - itemDist : 0u);
+            asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off"
+                         : "=&v"(upcoming), "=&v"(itemChunk) : "v"(wordAt), "v"(chunkAt) : "memory");
         }
-        if (sym == 256)
-            return kOk;
-        sym -= 257;
-        if (sym >= 29)
-            return kBadCode;
-        // length: 3..10 for symbols 0..7, then four symbols per extra-bit count, 258 for the last
-        unsigned len;
-        if (sym < 8)
-            len = 3u + (unsigned)sym;
-        else if (sym == 28)
-            len = 258u;
-        else
+#else
+        const uint32_t upcoming = wr.upcoming();
+        uint64_t itemChunk = 0;                                  // the eight bytes at the source of a match more than eight bytes back
+        if (itemDist > 8u)
+            __builtin_memcpy(&itemChunk, o.out + (o.n - itemDist), 8);
+#endif
+        const uint32_t window = wr.peek();
+        const uint32_t v = reverse15(window & 0x7fffu);                    // (bits beyond the input read as zeros)
+        const uint32_t both = v * 0x10001u;
+        unsigned below = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (unsigned j = 0; j < (kMaxBits + 1) / 2; ++j)
+            below += (unsigned)__builtin_popcount(((distNext ? distCode.pair[j] : lenCode.pair[j]) - both) & 0x80008000u);
+        const bool noCode = below < 2u;                                     // (17 - below > 15)
+        const unsigned len = noCode ? kMaxBits : 17u - below;
+        const uint32_t code = v >> (kMaxBits - len);
+        const uint32_t base = tab.w((distNext ? kTabDistBase : kTabLenBase) + len);
+        const uint32_t sym = tab.w((distNext ? kTabDistSymbol : kTabLenSymbol) + (noCode ? 0u : (code + base - 0x8000u) & 0xffffu));
+        // what the symbol is: a literal, the end of the block, a length (257 + x) or -- behind a length -- a distance (x). Lengths:
+        // 3..10 for x < 8, then four symbols per extra-bit count, 258 for x = 28; distances: 1..4 for x < 4, then two symbols per
+        // extra-bit count -- with q = 2 / 1: extra = max(x >> q, 1) - 1, value = first + (((x >> q ? 1 << q : 0) + (x mod 2^q)) << extra)
+        const bool literal = !distNext && sym < 256u;
+        const bool endOfBlock = !distNext && sym == 256u;
+        const uint32_t xRaw = distNext ? sym : sym - 257u;
+        const bool longest = !distNext && xRaw == 28u;
+        const uint32_t x = xRaw & 31u;
+        const unsigned q = distNext ? 1u : 2u;
+        const uint32_t group = x >> q;
+        const unsigned extra = literal || endOfBlock || longest ? 0u : (group > 1u ? group : 1u) - 1u;
+        const uint32_t value = longest ? 258u : (distNext ? 1u : 3u) + (((group != 0u ? 1u << q : 0u) + (x & ((1u << q) - 1u))) << extra) +
+                                                   bitField(window, len, extra);
+        const unsigned used = len + extra;
+        uint32_t fail = noCode || (!literal && !endOfBlock && xRaw >= (distNext ? 30u : 29u)) ? (uint32_t)kBadCode : 0u;
+        if (wr.left < (int32_t)used)
+            fail = kTruncated;
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(upcoming), "+v"(itemChunk) : : "memory");
+        if (!inside)
+            upcoming = wr.upcoming();                           // (the last words of the input, byte by byte)
+#endif
+        wr.consume(used, upcoming);
+        // the item of the trip before
         {
-            const unsigned ext = ((unsigned)sym >> 2) - 1u;
-            len = 3u + ((4u + ((unsigned)sym & 3u)) << ext) + br.bits(ext);
-        }
-        const int dsym = decodeFast(br, tab, distCode, kTabDistBase, kTabDistSymbol);
-        if (dsym < 0)
-            return dsym == -2 ? kTruncated : kBadCode;
-        if (dsym >= 30)
-            return kBadCode;
-        unsigned dist;
-        if (dsym < 4)
-            dist = 1u + (unsigned)dsym;
-        else
-        {
-            const unsigned ext = ((unsigned)dsym >> 1) - 1u;
-            dist = 1u + ((2u + ((unsigned)dsym & 1u)) << ext) + br.bits(ext);
-        }
-        if (br.shortInput)
-            return kTruncated;
-        if (dist > o.n)
-            return kBadDistance;
-        if (o.n + len > o.cap)
-            return kOutputFull;
-        if (dist <= 8u)
-        {
-            const unsigned sh = 8u * (dist - 1u);
-            for (unsigned i = 0; i < len; ++i)
-                o.put((unsigned)(o.tail >> sh) & 0xffu);
-        }
-        else
-        {
-            // more than eight bytes back: the eight bytes at the source are all there, one load serves up to eight of the
-            // match's bytes (70 % of a profile block's bytes come this way, four to a match)
-            unsigned left = len;
-            while (left != 0u)
+            const bool far = itemDist > 8u, nearBy = itemDist != 0u && !far;
+            unsigned avail = 8u;
+            while (itemBytes != 0u)
             {
-                uint64_t v;
-                __builtin_memcpy(&v, o.out + (o.n - dist), 8);
-                const unsigned take = left < 8u ? left : 8u;
-                for (unsigned i = 0; i < take; ++i, v >>= 8)
-                    o.put((unsigned)v & 0xffu);
-                left -= take;
+                unsigned k = itemBytes < 4u ? itemBytes : 4u;
+                uint32_t wd = itemLiteral;
+                if (far)
+                {
+                    if (avail == 0u)        // (a match of more than eight bytes: the next eight; the bytes at the source are all there)
+                    {
+                        __builtin_memcpy(&itemChunk, o.out + (o.n - itemDist), 8);
+                        avail = 8u;
+                    }
+                    wd = (uint32_t)itemChunk;
+                    itemChunk >>= 8u * k;
+                    avail -= k;
+                }
+                if (nearBy)
+                {
+                    k = k < itemDist ? k : itemDist;
+                    wd = (uint32_t)(o.hist >> (8u * (8u - itemDist)));
+                }
+                if (o.n + 4u <= o.cap)
+                    __builtin_memcpy(o.out + o.n, &wd, 4);          // (the bytes beyond k are written again by what follows)
+                else
+                    for (unsigned i = 0; i < k; ++i)
+                        o.out[o.n + i] = (uint8_t)(wd >> (8u * i));
+                o.hist = (o.hist >> (8u * k)) | ((uint64_t)wd << (64u - 8u * k));
+                o.n += k;
+                itemBytes -= k;
             }
         }
+        // ... and the one of this trip
+        const uint32_t bytes = literal ? 1u : distNext ? matchLen : 0u;
+        if (fail == 0u && distNext && value > o.n)
+            fail = kBadDistance;
+        if (fail == 0u && o.n + bytes > o.cap)
+            fail = kOutputFull;
+        if (fail != 0u || endOfBlock)
+        {
+            rc = fail;
+            break;
+        }
+        itemBytes = bytes;
+        itemDist = distNext ? value : 0u;
+        itemLiteral = sym;
+        if (!literal && !distNext)
+            matchLen = value;
+        distNext = !literal && !distNext;
     }
+    // the reader of the block headers goes on where the symbols ended
+    const uint32_t bitPos = wr.bitPos();
+    br.start(br.in, bitPos >> 3, br.end);
+    if ((bitPos & 7u) != 0u)
+        br.bits(bitPos & 7u);
+    return rc;
 }
 
 // The raw deflate stream behind a gzip header; on success the reader stands behind the final block.
@@ -468,7 +600,7 @@ PD_INF_FN uint32_t inflateStream(BitReader & br, Output & o, Tab & tab)
 // (also on failure: what had been produced), *used = bytes of input the member occupies (on success).
 template <class Tab>
 PD_INF_FN uint32_t inflateGzipMember(const uint8_t * in, uint64_t inLen, uint8_t * out, uint64_t outCap, uint64_t * outLen,
-                                     uint64_t * used, Tab & tab, const uint32_t * crcTable)
+                                     uint64_t * used, Tab & tab, const uint32_t * crcTable, uint32_t * crcOut = nullptr)
 {
     *outLen = 0;
     *used = 0;
@@ -503,9 +635,7 @@ PD_INF_FN uint32_t inflateGzipMember(const uint8_t * in, uint64_t inLen, uint8_t
     o.out = out;
     o.n = 0;
     o.cap = outCap > 0xffff0000ull ? 0xffff0000u : (uint32_t)outCap;
-    o.tail = 0;
-    o.crc = 0xffffffffu;
-    o.crcTable = crcTable;
+    o.hist = 0;
     const uint32_t rc = inflateStream(br, o, tab);
     *outLen = o.n;
     if (rc != kOk)
@@ -516,10 +646,18 @@ PD_INF_FN uint32_t inflateGzipMember(const uint8_t * in, uint64_t inLen, uint8_t
         return kTruncated;
     const uint32_t crc = (uint32_t)in[t] | ((uint32_t)in[t + 1] << 8) | ((uint32_t)in[t + 2] << 16) | ((uint32_t)in[t + 3] << 24);
     const uint32_t isize = (uint32_t)in[t + 4] | ((uint32_t)in[t + 5] << 8) | ((uint32_t)in[t + 6] << 16) | ((uint32_t)in[t + 7] << 24);
-    if (crc != (o.crc ^ 0xffffffffu))
-        return kBadCrc;
     if (isize != (uint32_t)o.n)
         return kBadLength;
+    if (crcOut != nullptr)
+        *crcOut = crc;                  // (the caller takes the CRC of the output: crcMembersKernel)
+    else
+    {
+        uint32_t c = 0xffffffffu;
+        for (uint32_t i = 0; i < o.n; ++i)
+            c = crcTable[(c ^ out[i]) & 0xffu] ^ (c >> 8);
+        if (crc != (c ^ 0xffffffffu))
+            return kBadCrc;
+    }
     *used = t + 8u;
     return kOk;
 }
