@@ -43,6 +43,11 @@ __global__ __launch_bounds__(L) void inflateMembersKernel(const uint8_t * __rest
     t.base = tabs + threadIdx.x;
     __shared__ uint8_t lens[pdinf::kCodeLengths * L];
     t.lengths = lens + threadIdx.x;
+    __shared__ uint32_t kinds[pdinf::kSymbolKinds];
+    for (unsigned i = threadIdx.x; i < pdinf::kSymbolKinds; i += L)
+        kinds[i] = pdinf::symbolKind(i);
+    t.kinds = kinds;
+    __syncthreads();
     for (unsigned batch = blockIdx.x; batch < nBatches; batch += gridDim.x)
     {
         const unsigned m = batch * L + threadIdx.x;
@@ -601,7 +606,7 @@ extern "C" uint8_t * pd_inflater_input(pd_inflater * f, uint64_t bytes)
     try
     {
         PD_INF_HIP(hipSetDevice(f->device));
-        growPinned(f->hIn, f->capHIn, bytes + 8);
+        growPinned(f->hIn, f->capHIn, bytes + pdinf::kInputSlack);
     }
     catch (const Fail & e)
     {
@@ -628,10 +633,10 @@ static int runInflater(pd_inflater * f, const uint64_t * member_offsets, uint32_
     {
         PD_INF_HIP(hipSetDevice(f->device));
         const uint64_t inBytes = member_offsets[n_members], outBytes = out_offsets[n_members];
-        if (inBytes + 8 > f->capHIn)
+        if (inBytes + pdinf::kInputSlack > f->capHIn)
             throw Fail{"the members were not gathered into pd_inflater_input()'s buffer"};
-        growDevice(f->dData, f->capData, inBytes + 8);
-        growDevice(f->dOut, f->capOut, outBytes + 8);      // (+ 8: the parser reads a record's five bytes with one eight-byte load, walkBlock())
+        growDevice(f->dData, f->capData, inBytes + pdinf::kInputSlack);
+        growDevice(f->dOut, f->capOut, outBytes + pdinf::kOutputSlack);      // (the gunzip kernel's match loads; the parser reads a record's five bytes with one eight-byte load, walkBlock())
         if (n_members + 1 > f->capMembers)
         {
             size_t a = 0, b = 0, c = 0, d = 0;
@@ -887,8 +892,8 @@ extern "C" int pd_inflate_members(int device, const uint8_t * data, const uint64
         PD_INF_HIP(hipStreamCreate(&st));
         for (hipEvent_t & e : ev)
             PD_INF_HIP(hipEventCreate(&e));
-        PD_INF_HIP(hipMalloc(&dData, inBytes + 8));
-        PD_INF_HIP(hipMalloc(&dOut, std::max<uint64_t>(outBytes, 1)));
+        PD_INF_HIP(hipMalloc(&dData, inBytes + pdinf::kInputSlack));
+        PD_INF_HIP(hipMalloc(&dOut, outBytes + pdinf::kOutputSlack));
         PD_INF_HIP(hipMalloc(&dInOff, (n_members + 1) * sizeof(uint64_t)));
         PD_INF_HIP(hipMalloc(&dOutOff, (n_members + 1) * sizeof(uint64_t)));
         PD_INF_HIP(hipMalloc(&dStatus, n_members * sizeof(uint32_t)));

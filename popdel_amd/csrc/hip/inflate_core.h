@@ -44,6 +44,30 @@ constexpr unsigned kMaxBits = 15, kLitLenCodes = 288, kDistCodes = 30, kCodeLeng
 constexpr unsigned kTabLenCount = 0, kTabLenSymbol = 16, kTabDistCount = 304, kTabDistSymbol = 320, kTabOffs = 350, kTabLenBase = 366,
                    kTabDistBase = 382, kTabWords = 398;
 
+// What a symbol stands for, in one word: bits 0-3 the number of extra bits behind it, bits 4-19 the value without them (the literal;
+// the length, 3..258; the distance, 1..24,577), bit 20: a literal, bit 21: the end of the block, bit 22: no symbol of the format
+// (286, 287; distances 30, 31). Entries 0..287: the literal / length symbols, 288..319: the distance symbols. Lengths: 3..10 for
+// x = symbol - 257 < 8, then four symbols per extra-bit count, 258 for x = 28; distances: 1..4 for x < 4, then two symbols per
+// extra-bit count -- with q = 2 / 1: extra = max(x >> q, 1) - 1, value = first + (((x >> q ? 1 << q : 0) + (x mod 2^q)) << extra).
+constexpr unsigned kSymbolKinds = 320;
+constexpr unsigned kInputSlack = 16, kOutputSlack = 16;      // bytes the device's loops may READ beyond the last member's input / output
+constexpr uint32_t kKindLiteral = 1u << 20, kKindEnd = 1u << 21, kKindNone = 1u << 22;
+PD_INF_FN uint32_t symbolKind(unsigned i)
+{
+    if (i < 256u)
+        return kKindLiteral | (i << 4);
+    if (i == 256u)
+        return kKindEnd;
+    const bool dist = i >= 288u;
+    const unsigned x = dist ? i - 288u : i - 257u, q = dist ? 1u : 2u;
+    if (x >= (dist ? 30u : 29u))
+        return kKindNone;
+    if (!dist && x == 28u)
+        return 258u << 4;
+    const unsigned group = x >> q, extra = (group > 1u ? group : 1u) - 1u;
+    return (((dist ? 1u : 3u) + (((group != 0u ? 1u << q : 0u) + (x & ((1u << q) - 1u))) << extra)) << 4) | extra;
+}
+
 // Plain-array tables (host; one decoder).
 struct FlatTables
 {
@@ -51,6 +75,7 @@ struct FlatTables
     uint8_t  length[kCodeLengths];
     PD_INF_FN uint16_t & w(unsigned i) { return word[i]; }
     PD_INF_FN uint8_t & len(unsigned i) { return length[i]; }
+    PD_INF_FN uint32_t kind(unsigned i) const { return symbolKind(i); }
 };
 
 // Tables of `Stride` decoders interleaved word by word (device: word i of lane l at base[i * Stride + l]; lanes that look at the same
@@ -60,8 +85,10 @@ struct StridedTablesOf
 {
     uint16_t * base;       // + lane
     uint8_t *  lengths;    // + lane
+    const uint32_t * kinds; // symbolKind() of 0 .. kSymbolKinds - 1, one table for the decoders of a workgroup
     PD_INF_FN uint16_t & w(unsigned i) { return base[i * Stride]; }
     PD_INF_FN uint8_t & len(unsigned i) { return lengths[i * Stride]; }
+    PD_INF_FN uint32_t kind(unsigned i) const { return kinds[i]; }
 };
 
 struct BitReader
@@ -276,12 +303,7 @@ struct Output
 {
     uint8_t * out;
     uint32_t  n, cap;
-    uint64_t  hist;        // the last eight bytes written as they lie in memory: the most recent one in the top byte
-    PD_INF_FN void put(unsigned b)
-    {
-        out[n++] = (uint8_t)b;
-        hist = (hist >> 8) | ((uint64_t)b << 56);
-    }
+    PD_INF_FN void put(unsigned b) { out[n++] = (uint8_t)b; }
 };
 
 // The input as the symbol loop reads it: the 32-bit word the bit cursor stands in and the one behind it, and the bits left in
@@ -299,11 +321,16 @@ struct WordReader
     PD_INF_FN uint32_t word(uint32_t p) const
     {
         uint32_t v = 0;
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+        __builtin_memcpy(&v, in + p, 4);        // (the device's input ends with sixteen bytes of slack, kInputSlack: what lies beyond a
+                                                //  member is never consumed -- `left` --, only looked at)
+#else
         if (p + 4u <= end)
             __builtin_memcpy(&v, in + p, 4);
         else
             for (unsigned i = 0; i < 4u && p + i < end; ++i)
                 v |= (uint32_t)in[p + i] << (8u * i);
+#endif
         return v;
     }
     PD_INF_FN void start(const uint8_t * data, uint32_t to, uint32_t bitPos)
@@ -353,10 +380,11 @@ PD_INF_FN uint32_t bitField(uint32_t v, unsigned from, unsigned n)      // n < 3
 // symbol: which code the lane reads is a matter of its state, the instructions are the same, so that the lanes of a wave (each
 // with a member of its own, each somewhere else in it) walk through one instruction stream instead of taking turns on the
 // literal, the length and the distance path -- and emits what the trip BEFORE it produced, up to four bytes a time: a literal is
-// a copy of one byte out of a register, a match more than eight bytes back one of bytes loaded eight at a time -- the load goes
-// out at the beginning of the trip that emits the match, behind the bytes of the item before it, and has the symbol's decoding
-// to arrive --, a nearer match comes out of the last eight bytes written, which live in a register. (The CRC is not
-// taken here: a pass of its own over the output does that with every lane of a wave busy, crcMembersKernel / inflateGzipMember.)
+// a copy of one byte out of a register, a match one of bytes loaded eight at a time (as many of them as the distance says are
+// there) -- the load goes out at the beginning of the trip that emits the match, behind the bytes of the item before it, and has
+// the symbol's decoding to arrive. A wave's time here is its instruction count (four waves a SIMD keep it issuing): what a symbol
+// stands for comes out of a table (symbolKind), every reason to stop is one branch. (The CRC is not taken here: a pass of
+// its own over the output does that with every lane of a wave busy, crcMembersKernel / inflateGzipMember.)
 template <class Tab>
 PD_INF_FN uint32_t inflateCodes(BitReader & br, Output & o, Tab & tab)
 {
@@ -365,33 +393,31 @@ PD_INF_FN uint32_t inflateCodes(BitReader & br, Output & o, Tab & tab)
     buildFast(tab, kTabDistCount, kTabDistBase, distCode);
     WordReader wr;
     wr.start(br.in, br.end, 8u * (br.pos - (br.haveAhead ? 4u : 0u)) - br.cnt);
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_s_waitcnt(0x0f70);     // (vmcnt(0) here: the compiler would wait for the first two words at the loop's head, trip after trip)
+#endif
     uint32_t rc = kOk, matchLen = 0;
     bool distNext = false;
     uint32_t itemBytes = 0, itemDist = 0, itemLiteral = 0;     // the item waiting to be emitted: itemDist = 0 for a literal
     for (;;)
     {
-        // the loads of the trip: the input word that may be needed at its end, and the eight bytes at the source of a match more
-        // than eight bytes back that is waiting to be emitted. (On the device both go out unconditionally -- a lane without
-        // such a match reads the beginning of its output -- and through inline assembly, the wait for them placed by hand
-        // behind the decoding: the compiler would wait where the branches around conditional loads join, that is, at once.)
-#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+        // the loads of the trip: the input word that may be needed at its end, and the eight bytes at the source of the match
+        // that is waiting to be emitted (a literal: the eight bytes at the cursor, not looked at). On the device through inline
+        // assembly, the wait for them placed by hand behind the decoding: no register that waits for memory lives across the
+        // loop's back edge or a branch's join, where the compiler would wait at once.
         uint32_t upcoming;
         uint64_t itemChunk;
-        const bool inside = wr.at + 12u <= wr.end;
-        {
-            const uint8_t * wordAt = wr.in + (inside ? wr.at + 8u : 0u);
-            const uint8_t * chunkAt = o.out + (itemDist > 8u ? o.n - itemDist : 0u);
-            asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off"
-                         : "=&v"(upcoming), "=&v"(itemChunk) : "v"(wordAt), "v"(chunkAt) : "memory");
-        }
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("global_load_dword %0, %2, off offset:8\n\tglobal_load_dwordx2 %1, %3, off"
+                     : "=&v"(upcoming), "=&v"(itemChunk) : "v"(wr.in + wr.at), "v"(o.out + (o.n - itemDist)) : "memory");
 #else
-        const uint32_t upcoming = wr.upcoming();
-        uint64_t itemChunk = 0;                                  // the eight bytes at the source of a match more than eight bytes back
-        if (itemDist > 8u)
-            __builtin_memcpy(&itemChunk, o.out + (o.n - itemDist), 8);
+        upcoming = wr.upcoming();
+        itemChunk = 0;
+        for (unsigned i = 0; i < 8u && i < itemDist; ++i)
+            itemChunk |= (uint64_t)o.out[o.n - itemDist + i] << (8u * i);
 #endif
         const uint32_t window = wr.peek();
-        const uint32_t v = reverse15(window & 0x7fffu);                    // (bits beyond the input read as zeros)
+        const uint32_t v = reverse15(window & 0x7fffu);                    // (what lies beyond the input is looked at, never consumed)
         const uint32_t both = v * 0x10001u;
         unsigned below = 0;
 #if defined(__HIPCC__)
@@ -403,81 +429,80 @@ PD_INF_FN uint32_t inflateCodes(BitReader & br, Output & o, Tab & tab)
         const unsigned len = noCode ? kMaxBits : 17u - below;
         const uint32_t code = v >> (kMaxBits - len);
         const uint32_t base = tab.w((distNext ? kTabDistBase : kTabLenBase) + len);
-        const uint32_t sym = tab.w((distNext ? kTabDistSymbol : kTabLenSymbol) + (noCode ? 0u : (code + base - 0x8000u) & 0xffffu));
-        // what the symbol is: a literal, the end of the block, a length (257 + x) or -- behind a length -- a distance (x). Lengths:
-        // 3..10 for x < 8, then four symbols per extra-bit count, 258 for x = 28; distances: 1..4 for x < 4, then two symbols per
-        // extra-bit count -- with q = 2 / 1: extra = max(x >> q, 1) - 1, value = first + (((x >> q ? 1 << q : 0) + (x mod 2^q)) << extra)
-        const bool literal = !distNext && sym < 256u;
-        const bool endOfBlock = !distNext && sym == 256u;
-        const uint32_t xRaw = distNext ? sym : sym - 257u;
-        const bool longest = !distNext && xRaw == 28u;
-        const uint32_t x = xRaw & 31u;
-        const unsigned q = distNext ? 1u : 2u;
-        const uint32_t group = x >> q;
-        const unsigned extra = literal || endOfBlock || longest ? 0u : (group > 1u ? group : 1u) - 1u;
-        const uint32_t value = longest ? 258u : (distNext ? 1u : 3u) + (((group != 0u ? 1u << q : 0u) + (x & ((1u << q) - 1u))) << extra) +
-                                                   bitField(window, len, extra);
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t index = (code + base - 0x8000u) & 0xffffu;           // (without a code: anything -- LDS reads out of range deliver zeros)
+#else
+        const uint32_t index = noCode ? 0u : (code + base - 0x8000u) & 0xffffu;
+#endif
+        const uint32_t sym = tab.w((distNext ? kTabDistSymbol : kTabLenSymbol) + index);
+        const uint32_t kind = tab.kind((distNext ? 288u : 0u) + sym);
+        const unsigned extra = kind & 15u;
+        const uint32_t value = ((kind >> 4) & 0xffffu) + bitField(window, len, extra);
+        const bool literal = (kind & kKindLiteral) != 0u, endOfBlock = (kind & kKindEnd) != 0u;
         const unsigned used = len + extra;
-        uint32_t fail = noCode || (!literal && !endOfBlock && xRaw >= (distNext ? 30u : 29u)) ? (uint32_t)kBadCode : 0u;
-        if (wr.left < (int32_t)used)
-            fail = kTruncated;
+        const bool truncated = wr.left < (int32_t)used;
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(upcoming), "+v"(itemChunk) : : "memory");
-        if (!inside)
-            upcoming = wr.upcoming();                           // (the last words of the input, byte by byte)
 #endif
         wr.consume(used, upcoming);
         // the item of the trip before
+        if (itemBytes != 0u)
         {
-            const bool far = itemDist > 8u, nearBy = itemDist != 0u && !far;
-            unsigned avail = 8u;
-            while (itemBytes != 0u)
+            uint64_t chunk = itemDist != 0u ? itemChunk : (uint64_t)itemLiteral;
+            unsigned avail = itemDist != 0u && itemDist < 8u ? itemDist : 8u;
+            const bool roomy = o.n + itemBytes + 4u <= o.cap;
+            for (;;)
             {
                 unsigned k = itemBytes < 4u ? itemBytes : 4u;
-                uint32_t wd = itemLiteral;
-                if (far)
+                k = k < avail ? k : avail;
+                const uint32_t wd = (uint32_t)chunk;
+                if (roomy)                                          // (the bytes beyond k are written again by what follows)
                 {
-                    if (avail == 0u)        // (a match of more than eight bytes: the next eight; the bytes at the source are all there)
-                    {
-                        __builtin_memcpy(&itemChunk, o.out + (o.n - itemDist), 8);
-                        avail = 8u;
-                    }
-                    wd = (uint32_t)itemChunk;
-                    itemChunk >>= 8u * k;
-                    avail -= k;
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("global_store_dword %0, %1, off" : : "v"(o.out + o.n), "v"(wd) : "memory");
+#else
+                    __builtin_memcpy(o.out + o.n, &wd, 4);
+#endif
                 }
-                if (nearBy)
-                {
-                    k = k < itemDist ? k : itemDist;
-                    wd = (uint32_t)(o.hist >> (8u * (8u - itemDist)));
-                }
-                if (o.n + 4u <= o.cap)
-                    __builtin_memcpy(o.out + o.n, &wd, 4);          // (the bytes beyond k are written again by what follows)
                 else
+                {
                     for (unsigned i = 0; i < k; ++i)
                         o.out[o.n + i] = (uint8_t)(wd >> (8u * i));
-                o.hist = (o.hist >> (8u * k)) | ((uint64_t)wd << (64u - 8u * k));
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+                    __builtin_amdgcn_s_waitcnt(0x0f70);             // (vmcnt(0): nothing of the compiler's own in flight at the loop's head)
+#endif
+                }
+                chunk >>= 8u * k;
+                avail -= k;
                 o.n += k;
                 itemBytes -= k;
+                if (itemBytes == 0u)
+                    break;
+                if (avail == 0u)            // (a match longer than its distance, or than eight bytes: what has been written since is there now)
+                {
+                    __builtin_memcpy(&chunk, o.out + (o.n - itemDist), 8);
+                    avail = itemDist < 8u ? itemDist : 8u;
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+                    __builtin_amdgcn_s_waitcnt(0x0f70);
+#endif
+                }
             }
         }
         // ... and the one of this trip
         const uint32_t bytes = literal ? 1u : distNext ? matchLen : 0u;
-        if (fail == 0u && distNext && value > o.n)
-            fail = kBadDistance;
-        if (fail == 0u && o.n + bytes > o.cap)
-            fail = kOutputFull;
-        if (fail != 0u || endOfBlock)
+        const bool noSymbol = noCode | ((kind & kKindNone) != 0u);
+        const bool tooFar = distNext & (value > o.n);
+        const bool full = o.n + bytes > o.cap;
+        if (noSymbol | truncated | endOfBlock | tooFar | full)
         {
-            rc = fail;
+            rc = noSymbol ? kBadCode : truncated ? kTruncated : endOfBlock ? kOk : tooFar ? kBadDistance : kOutputFull;
             break;
         }
         itemBytes = bytes;
         itemDist = distNext ? value : 0u;
         itemLiteral = sym;
-        if (!literal && !distNext)
-            matchLen = value;
-        distNext = !literal && !distNext;
+        matchLen = value;
+        distNext = !literal & !distNext;
     }
     // the reader of the block headers goes on where the symbols ended
     const uint32_t bitPos = wr.bitPos();
@@ -635,7 +660,6 @@ PD_INF_FN uint32_t inflateGzipMember(const uint8_t * in, uint64_t inLen, uint8_t
     o.out = out;
     o.n = 0;
     o.cap = outCap > 0xffff0000ull ? 0xffff0000u : (uint32_t)outCap;
-    o.hist = 0;
     const uint32_t rc = inflateStream(br, o, tab);
     *outLen = o.n;
     if (rc != kOk)
