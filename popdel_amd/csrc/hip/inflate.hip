@@ -31,7 +31,10 @@ namespace {
 // Measured on MI355X (tools/inflate_lanes_sweep.py, profiles/r05_j_inflate_lanes_sweep.md), 21,000 members (the chunk a decoder
 // thread of `popdel call` hands over at 4,000 samples) / 200,000 members (a 10,000-sample segment): 64 per wave 9.5 / 52.6 ms,
 // 32: 8.4 / 46.3, 16: 7.4 / 51.4, 8: 6.3 / 42.9, 4: 10.1 / 62.5 (too many waves for the chip to hold at once); with the
-// eight-byte loads of the far copies (inflate_core.h) and the code lengths in LDS, 8 per wave: 5.6 / 38.7 ms.
+// eight-byte loads of the far copies (inflate_core.h) and the code lengths in LDS, 8 per wave: 5.6 / 38.7 ms. Round 6: the symbol loop
+// rewritten so that the lanes of a wave share ONE instruction stream whatever their members hold (inflate_core.h, inflateCodes):
+// the union is no longer what a wave pays for, and more members per wave are fewer instructions per member -- 8 per wave 3.73 /
+// 25.4 ms, 16: 3.25 / 19.6, 32: - / 22.1, 4: - / 48.3.
 template <unsigned L>
 __global__ __launch_bounds__(L) void inflateMembersKernel(const uint8_t * __restrict__ data, const uint64_t * __restrict__ inOff,
                                                           uint32_t n, uint8_t * __restrict__ out,
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void crcMembersKernel(const uint8_t * __restri
 }
 
 // Members per wave (4 | 8 | 16 | 32) and the waves of that shape a CU holds (the runtime's occupancy figure: LDS and VGPRs).
-// Eight unless POPDEL_HIP_INFLATE_LANES says otherwise (measurements).
+// Sixteen unless POPDEL_HIP_INFLATE_LANES says otherwise (measurements).
 template <unsigned L>
 unsigned wavesPerCuOf()
 {
@@ -119,7 +122,7 @@ unsigned membersPerWave()
         const unsigned v = e ? (unsigned)std::atoi(e) : 0u;
         return (v == 4u || v == 8u || v == 16u || v == 32u) ? v : 0u;
     }();
-    return fixed ? fixed : 8u;
+    return fixed ? fixed : 16u;
 }
 
 // (returns the number of workgroups launched)
