@@ -23,8 +23,8 @@
 
 namespace {
 
-// Workgroups of ONE wave that holds L members (one per lane, lanes L..63 absent): the decoders' tables (398 16-bit words each)
-// and the code lengths of a dynamic block header (320 bytes each) take L x 1,116 bytes of LDS. Workgroups stride over the
+// Workgroups of ONE wave that holds L members (one per lane, lanes L..63 absent): the decoders' tables and the code lengths
+// of a dynamic block header take L x 582 bytes of LDS (inflate_core.h; L x 1,116 until round 6: twice the members in flight per CU). Workgroups stride over the
 // batches of L members. What a small L buys: a wave executes the UNION of its lanes' paths through the decoder (literal /
 // match / header / refill), so fewer members per wave is fewer instructions per wave, and the smaller table set lets more
 // waves share a SIMD -- a wave here is a chain of dependent instructions with nothing of its own to hide their latencies.
@@ -41,15 +41,19 @@ __global__ __launch_bounds__(L) void inflateMembersKernel(const uint8_t * __rest
                                                           const uint64_t * __restrict__ outOff, uint32_t * __restrict__ status,
                                                           uint64_t * __restrict__ outLen, unsigned nBatches)
 {
-    __shared__ uint16_t tabs[pdinf::kTabWords * L];
+    __shared__ uint8_t symbols[pdinf::kSymbols * L];
+    __shared__ uint32_t highs[pdinf::kHighWords * L];
+    __shared__ uint16_t metas[pdinf::kMeta * L];
+    __shared__ uint8_t lens[pdinf::kLengthBytes * L];
+    __shared__ uint16_t kinds[pdinf::kSymbolKinds];
     pdinf::StridedTablesOf<L> t;
-    t.base = tabs + threadIdx.x;
-    __shared__ uint8_t lens[pdinf::kCodeLengths * L];
+    t.symbols = symbols + threadIdx.x;
+    t.highs = highs + threadIdx.x;
+    t.metas = metas + threadIdx.x;
     t.lengths = lens + threadIdx.x;
-    __shared__ uint32_t kinds[pdinf::kSymbolKinds];
+    t.kinds = kinds;
     for (unsigned i = threadIdx.x; i < pdinf::kSymbolKinds; i += L)
         kinds[i] = pdinf::symbolKind(i);
-    t.kinds = kinds;
     __syncthreads();
     for (unsigned batch = blockIdx.x; batch < nBatches; batch += gridDim.x)
     {

@@ -1,9 +1,8 @@
 // DEFLATE (RFC 1951) decoder for ONE gzip member (RFC 1952), written so that one LANE can run it: no heap, no recursion,
-// canonical Huffman decoding from per-length counts and a symbol list (a few hundred 16-bit words of table per decoder
-// instead of the kilobytes a lookup-table decoder wants -- the decoders of a wave share its LDS; a table of the next nine
-// bits per code was built and measured slower on the device: the rare longer codes stall the lanes beside them), the last eight output
-// bytes in a register so that the short back-references the profiles are made of (the zero / ff bytes of the 32-bit
-// deviations, five bytes back) cost no memory round trip.
+// canonical Huffman decoding from per-length offsets and a symbol list (582 bytes of table per decoder instead of the
+// kilobytes a lookup-table decoder wants -- the decoders of a wave share its LDS, and how many of them a CU holds is how many
+// members are in flight; a table of the next nine bits per code was built and measured slower on the device: the rare longer
+// codes stall the lanes beside them).
 //
 // What it replaces: the gunzip of the per-index-region gzip members of a profile (reference: the writer ends a member per
 // 10,000-bp region, workflow_popdel.h:201-241; the reader jumps to one, insert_histogram_popdel.h:531-562, and inflates it
@@ -40,56 +39,90 @@ enum Status : uint32_t
 };
 
 constexpr unsigned kMaxBits = 15, kLitLenCodes = 288, kDistCodes = 30, kCodeLengths = 320;
-// 16-bit table words per decoder: lenCount[16] lenSymbol[288] distCount[16] distSymbol[30] offs[16] lenBase[16] distBase[16]
-constexpr unsigned kTabLenCount = 0, kTabLenSymbol = 16, kTabDistCount = 304, kTabDistSymbol = 320, kTabOffs = 350, kTabLenBase = 366,
-                   kTabDistBase = 382, kTabWords = 398;
+// A decoder's tables. The symbols of the two codes in canonical order, one byte each (kSymbols: the literal / length code's 288,
+// then the distance code's -- or the code-length code's -- 30) with the ninth bit of the literal / length symbols in a bit
+// map beside them (kHighWords x 32 bits: position p's bit is bit p % 32 of word p / 32; the distance symbols' word stays zero);
+// per code and code length one 16-bit word (kMeta: 0..15 the literal / length code, 16..31 the other): the number of symbols
+// of that length while they are counted, the place of the length's next symbol while they are listed -- so that afterwards it
+// is where the length's symbols END and the difference to the length before is their number --, and for the symbol loop
+// the index of the length's first symbol minus its first code (buildFast); the code lengths of a block header, four bits each.
+constexpr unsigned kSymbols = 318, kDistSymbolsAt = 288, kHighWords = 10, kMeta = 32, kLengthBytes = kCodeLengths / 2;
 
-// What a symbol stands for, in one word: bits 0-3 the number of extra bits behind it, bits 4-19 the value without them (the literal;
-// the length, 3..258; the distance, 1..24,577), bit 20: a literal, bit 21: the end of the block, bit 22: no symbol of the format
-// (286, 287; distances 30, 31). Entries 0..287: the literal / length symbols, 288..319: the distance symbols. Lengths: 3..10 for
-// x = symbol - 257 < 8, then four symbols per extra-bit count, 258 for x = 28; distances: 1..4 for x < 4, then two symbols per
-// extra-bit count -- with q = 2 / 1: extra = max(x >> q, 1) - 1, value = first + (((x >> q ? 1 << q : 0) + (x mod 2^q)) << extra).
+// What a symbol stands for, in sixteen bits: bits 0-3 the number of extra bits behind it, bits 4-11 a multiplier m -- the length
+// is 3 + (m << extra) + the extra bits, the distance 1 + (m << extra) + the extra bits --, bit 12: a literal, bit 13: the end of
+// the block, bit 14: no symbol of the format (286, 287; distances 30, 31). Entries 0..287: the literal / length symbols,
+// 288..319: the distance symbols. Lengths: 3..10 for x = symbol - 257 < 8 (m = x), then four symbols per extra-bit count
+// (m = 4 + x % 4), 258 for x = 28 (m = 255); distances: 1..4 for x < 4 (m = x), then two symbols per extra-bit count (m = 2 + x % 2).
 constexpr unsigned kSymbolKinds = 320;
 constexpr unsigned kInputSlack = 16, kOutputSlack = 16;      // bytes the device's loops may READ beyond the last member's input / output
-constexpr uint32_t kKindLiteral = 1u << 20, kKindEnd = 1u << 21, kKindNone = 1u << 22;
-PD_INF_FN uint32_t symbolKind(unsigned i)
+constexpr uint32_t kKindLiteral = 1u << 12, kKindEnd = 1u << 13, kKindNone = 1u << 14;
+PD_INF_FN uint16_t symbolKind(unsigned i)
 {
     if (i < 256u)
-        return kKindLiteral | (i << 4);
+        return (uint16_t)kKindLiteral;
     if (i == 256u)
-        return kKindEnd;
+        return (uint16_t)kKindEnd;
     const bool dist = i >= 288u;
-    const unsigned x = dist ? i - 288u : i - 257u, q = dist ? 1u : 2u;
+    const unsigned x = dist ? i - 288u : i - 257u;
     if (x >= (dist ? 30u : 29u))
-        return kKindNone;
+        return (uint16_t)kKindNone;
     if (!dist && x == 28u)
-        return 258u << 4;
-    const unsigned group = x >> q, extra = (group > 1u ? group : 1u) - 1u;
-    return (((dist ? 1u : 3u) + (((group != 0u ? 1u << q : 0u) + (x & ((1u << q) - 1u))) << extra)) << 4) | extra;
+        return (uint16_t)(255u << 4);
+    const unsigned q = dist ? 1u : 2u, group = x >> q;
+    if (group < 2u)
+        return (uint16_t)(x << 4);
+    return (uint16_t)((((1u << q) + (x & ((1u << q) - 1u))) << 4) | (group - 1u));
 }
 
 // Plain-array tables (host; one decoder).
 struct FlatTables
 {
-    uint16_t word[kTabWords];
-    uint8_t  length[kCodeLengths];
-    PD_INF_FN uint16_t & w(unsigned i) { return word[i]; }
-    PD_INF_FN uint8_t & len(unsigned i) { return length[i]; }
+    uint8_t  symbol[kSymbols];
+    uint32_t highBits[kHighWords];
+    uint16_t metaWord[kMeta];
+    uint8_t  lengths[kLengthBytes];
+    PD_INF_FN uint8_t & sym(unsigned i) { return symbol[i]; }
+    PD_INF_FN uint32_t & high(unsigned i) { return highBits[i]; }
+    PD_INF_FN uint16_t & meta(unsigned i) { return metaWord[i]; }
+    PD_INF_FN uint8_t & lenPair(unsigned i) { return lengths[i]; }
     PD_INF_FN uint32_t kind(unsigned i) const { return symbolKind(i); }
 };
 
-// Tables of `Stride` decoders interleaved word by word (device: word i of lane l at base[i * Stride + l]; lanes that look at the same
-// entry hit consecutive LDS banks), code lengths likewise in a global workspace.
+// Tables of `Stride` decoders interleaved element by element (device: element i of lane l at base[i * Stride + l]; lanes that look at
+// the same entry hit consecutive LDS banks).
 template <unsigned Stride>
 struct StridedTablesOf
 {
-    uint16_t * base;       // + lane
-    uint8_t *  lengths;    // + lane
-    const uint32_t * kinds; // symbolKind() of 0 .. kSymbolKinds - 1, one table for the decoders of a workgroup
-    PD_INF_FN uint16_t & w(unsigned i) { return base[i * Stride]; }
-    PD_INF_FN uint8_t & len(unsigned i) { return lengths[i * Stride]; }
+    uint8_t *  symbols;    // + lane, all of them
+    uint32_t * highs;
+    uint16_t * metas;
+    uint8_t *  lengths;
+    const uint16_t * kinds; // symbolKind() of 0 .. kSymbolKinds - 1, one table for the decoders of a workgroup
+    PD_INF_FN uint8_t & sym(unsigned i) { return symbols[i * Stride]; }
+    PD_INF_FN uint32_t & high(unsigned i) { return highs[i * Stride]; }
+    PD_INF_FN uint16_t & meta(unsigned i) { return metas[i * Stride]; }
+    PD_INF_FN uint8_t & lenPair(unsigned i) { return lengths[i * Stride]; }
     PD_INF_FN uint32_t kind(unsigned i) const { return kinds[i]; }
 };
+
+// (the code length of symbol i of a block header)
+template <class Tab>
+PD_INF_FN unsigned lengthOf(Tab & tab, unsigned i)
+{
+    return (tab.lenPair(i >> 1) >> (4u * (i & 1u))) & 15u;
+}
+template <class Tab>
+PD_INF_FN void setLength(Tab & tab, unsigned i, unsigned v)
+{
+    uint8_t & pair = tab.lenPair(i >> 1);
+    pair = (uint8_t)((i & 1u) ? (pair & 0x0fu) | (v << 4) : (pair & 0xf0u) | v);
+}
+// (symbol at position p of the lists: the literal / length code's from 0, the other code's from kDistSymbolsAt)
+template <class Tab>
+PD_INF_FN unsigned symbolAt(Tab & tab, unsigned p)
+{
+    return tab.sym(p) | (((tab.high(p >> 5) >> (p & 31u)) & 1u) << 8);
+}
 
 struct BitReader
 {
@@ -166,10 +199,10 @@ struct BitReader
     PD_INF_FN uint32_t bytePos() const { return pos - (haveAhead ? 4u : 0u) - (cnt >> 3); }
 };
 
-// One symbol of a canonical code (counts at countAt + 1 .. 15, symbols at symbolAt): -1 if the bits are no code of the set,
-// -2 if the input ends.
+// One symbol of a canonical code, bit by bit (the code-length code of a block header; `set`: 0 the literal / length slots, 1 the
+// other ones; the lists as buildCode leaves them): -1 if the bits are no code of the set, -2 if the input ends.
 template <class Tab>
-PD_INF_FN int decodeSymbol(BitReader & br, Tab & tab, unsigned countAt, unsigned symbolAt)
+PD_INF_FN int decodeSymbol(BitReader & br, Tab & tab, unsigned set)
 {
     br.refill();
     int code = 0, first = 0, index = 0;
@@ -183,9 +216,9 @@ PD_INF_FN int decodeSymbol(BitReader & br, Tab & tab, unsigned countAt, unsigned
         code |= (int)(br.buf & 1ull);
         br.buf >>= 1;
         --br.cnt;
-        const int count = tab.w(countAt + len);
+        const int count = (int)tab.meta(16u * set + len) - index;
         if (code - count < first)
-            return tab.w(symbolAt + (unsigned)(index + (code - first)));
+            return (int)symbolAt(tab, (set ? kDistSymbolsAt : 0u) + (unsigned)(index + (code - first)));
         index += count;
         first += count;
         first <<= 1;
@@ -194,33 +227,52 @@ PD_INF_FN int decodeSymbol(BitReader & br, Tab & tab, unsigned countAt, unsigned
     return -1;
 }
 
-// Builds counts and symbol list from code lengths tab.len(from .. from + n). Returns 0 for a complete set, > 0 for an
-// incomplete one (codes left over), < 0 for an over-subscribed one.
+// Lists the symbols of a code in canonical order from the code lengths of symbols from .. from + n (see the tables above).
+// Returns 0 for a complete set, > 0 for an incomplete one (codes left over), < 0 for an over-subscribed one; *zeros = symbols
+// without a code.
 template <class Tab>
-PD_INF_FN int buildCode(Tab & tab, unsigned from, unsigned n, unsigned countAt, unsigned symbolAt)
+PD_INF_FN int buildCode(Tab & tab, unsigned from, unsigned n, unsigned set, unsigned * zeros)
 {
+    const unsigned metaAt = 16u * set, listAt = set ? kDistSymbolsAt : 0u;
     for (unsigned len = 0; len <= kMaxBits; ++len)
-        tab.w(countAt + len) = 0;
+        tab.meta(metaAt + len) = 0;
     for (unsigned s = 0; s < n; ++s)
-        ++tab.w(countAt + tab.len(from + s));
-    if (tab.w(countAt) == n)
-        return 0;                       // no codes at all: complete, and decoding will fail
+        ++tab.meta(metaAt + lengthOf(tab, from + s));
+    *zeros = tab.meta(metaAt);
+    tab.meta(metaAt) = 0;
     int left = 1;
+    if (*zeros == n)
+        return 0;                       // no codes at all: complete, and decoding will fail
+    unsigned run = 0;
+    bool over = false;
     for (unsigned len = 1; len <= kMaxBits; ++len)
     {
+        const unsigned count = tab.meta(metaAt + len);
         left <<= 1;
-        left -= (int)tab.w(countAt + len);
-        if (left < 0)
-            return left;
+        left -= (int)count;
+        over = over || left < 0;
+        tab.meta(metaAt + len) = (uint16_t)run;
+        run += count;
     }
-    tab.w(kTabOffs + 1) = 0;
-    for (unsigned len = 1; len < kMaxBits; ++len)
-        tab.w(kTabOffs + len + 1) = (uint16_t)(tab.w(kTabOffs + len) + tab.w(countAt + len));
+    if (over)
+    {
+        for (unsigned len = 1; len <= kMaxBits; ++len)
+            tab.meta(metaAt + len) = 0;
+        return -1;
+    }
+    if (!set)
+        for (unsigned i = 0; i < kHighWords - 1u; ++i)
+            tab.high(i) = 0;
     for (unsigned s = 0; s < n; ++s)
     {
-        const unsigned l = tab.len(from + s);
+        const unsigned l = lengthOf(tab, from + s);
         if (l != 0u)
-            tab.w(symbolAt + tab.w(kTabOffs + l)++) = (uint16_t)s;
+        {
+            const unsigned at = listAt + tab.meta(metaAt + l)++;
+            tab.sym(at) = (uint8_t)s;
+            if (s >> 8)
+                tab.high(at >> 5) |= 1u << (at & 31u);
+        }
     }
     return left;
 }
@@ -230,15 +282,15 @@ PD_INF_FN int buildCode(Tab & tab, unsigned from, unsigned n, unsigned countAt, 
 // limit[2j + 2] + 0x7fff in its high half (the sixteenth half: 0xffff). With the next fifteen bits v in both halves of a word,
 // pair[j] - v has bit 15 of a half set where v < limit (no borrow crosses the halves: limit + 0x7fff - v >= 0), so the length of
 // the code is 17 minus the number of such bits -- a subtraction, a mask and a bit count per two lengths instead of a compare, a
-// wait and a conditional add per length. base[len] = index of the length's first symbol minus its first code, in the table
-// words at baseAt (biased by 0x8000). One symbol then costs a bit reversal, these and two dependent table reads.
+// wait and a conditional add per length. The meta word of a length becomes the index of the length's first symbol minus its
+// first code (biased by 0x8000). One symbol then costs a bit reversal, these and two dependent table reads.
 struct FastCode
 {
     uint32_t pair[(kMaxBits + 1) / 2];
 };
 
 template <class Tab>
-PD_INF_FN void buildFast(Tab & tab, unsigned countAt, unsigned baseAt, FastCode & fc)
+PD_INF_FN void buildFast(Tab & tab, unsigned set, FastCode & fc)
 {
     uint32_t first = 0, index = 0, low = 0;
 #if defined(__HIPCC__)
@@ -246,15 +298,15 @@ PD_INF_FN void buildFast(Tab & tab, unsigned countAt, unsigned baseAt, FastCode 
 #endif
     for (unsigned len = 1; len <= kMaxBits; ++len)
     {
-        const uint32_t count = tab.w(countAt + len);
-        tab.w(baseAt + len) = (uint16_t)(0x8000u + index - first);
+        const uint32_t end = tab.meta(16u * set + len), count = end - index;
+        tab.meta(16u * set + len) = (uint16_t)(0x8000u + index - first);
         first += count;
         const uint32_t biased = (first << (kMaxBits - len)) + 0x7fffu;
         if (len & 1u)
             low = biased;
         else
             fc.pair[len / 2u - 1u] = low | (biased << 16);
-        index += count;
+        index = end;
         first <<= 1;
     }
     fc.pair[kMaxBits / 2u] = low | 0xffff0000u;
@@ -270,33 +322,6 @@ PD_INF_FN uint32_t reverse15(uint32_t v)
         r |= ((v >> i) & 1u) << (14 - i);
     return r;
 #endif
-}
-
-// -1: the bits are no code of the set; -2: the input ends inside the code
-template <class Tab>
-PD_INF_FN int decodeFast(BitReader & br, Tab & tab, const FastCode & fc, unsigned baseAt, unsigned symbolAt)
-{
-    br.refill();
-    const uint32_t v = reverse15((uint32_t)br.buf & 0x7fffu);          // (bits beyond the input read as zeros)
-    const uint32_t both = v * 0x10001u;
-    unsigned below = 0;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (unsigned j = 0; j < (kMaxBits + 1) / 2; ++j)
-        below += (unsigned)__builtin_popcount((fc.pair[j] - both) & 0x80008000u);
-    const unsigned len = 17u - below;
-    if (len > kMaxBits)
-        return -1;
-    if (len > br.cnt)
-    {
-        br.shortInput = true;
-        return -2;
-    }
-    br.buf >>= len;
-    br.cnt -= len;
-    const uint32_t code = v >> (kMaxBits - len);
-    return tab.w(symbolAt + ((code + tab.w(baseAt + len) - 0x8000u) & 0xffffu));
 }
 
 struct Output
@@ -389,8 +414,8 @@ template <class Tab>
 PD_INF_FN uint32_t inflateCodes(BitReader & br, Output & o, Tab & tab)
 {
     FastCode lenCode, distCode;
-    buildFast(tab, kTabLenCount, kTabLenBase, lenCode);
-    buildFast(tab, kTabDistCount, kTabDistBase, distCode);
+    buildFast(tab, 0, lenCode);
+    buildFast(tab, 1, distCode);
     WordReader wr;
     wr.start(br.in, br.end, 8u * (br.pos - (br.haveAhead ? 4u : 0u)) - br.cnt);
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
@@ -428,16 +453,16 @@ PD_INF_FN uint32_t inflateCodes(BitReader & br, Output & o, Tab & tab)
         const bool noCode = below < 2u;                                     // (17 - below > 15)
         const unsigned len = noCode ? kMaxBits : 17u - below;
         const uint32_t code = v >> (kMaxBits - len);
-        const uint32_t base = tab.w((distNext ? kTabDistBase : kTabLenBase) + len);
+        const uint32_t base = tab.meta((distNext ? 16u : 0u) + len);
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
         const uint32_t index = (code + base - 0x8000u) & 0xffffu;           // (without a code: anything -- LDS reads out of range deliver zeros)
 #else
         const uint32_t index = noCode ? 0u : (code + base - 0x8000u) & 0xffffu;
 #endif
-        const uint32_t sym = tab.w((distNext ? kTabDistSymbol : kTabLenSymbol) + index);
+        const uint32_t sym = symbolAt(tab, (distNext ? kDistSymbolsAt : 0u) + index);
         const uint32_t kind = tab.kind((distNext ? 288u : 0u) + sym);
         const unsigned extra = kind & 15u;
-        const uint32_t value = ((kind >> 4) & 0xffffu) + bitField(window, len, extra);
+        const uint32_t value = (((kind >> 4) & 0xffu) << extra) + (distNext ? 1u : 3u) + bitField(window, len, extra);
         const bool literal = (kind & kKindLiteral) != 0u, endOfBlock = (kind & kKindEnd) != 0u;
         const unsigned used = len + extra;
         const bool truncated = wr.left < (int32_t)used;
@@ -545,13 +570,13 @@ PD_INF_FN uint32_t inflateStream(BitReader & br, Output & o, Tab & tab)
         }
         else if (type == 1u)
         {
-            for (unsigned s = 0; s < 144u; ++s) tab.len(s) = 8;
-            for (unsigned s = 144u; s < 256u; ++s) tab.len(s) = 9;
-            for (unsigned s = 256u; s < 280u; ++s) tab.len(s) = 7;
-            for (unsigned s = 280u; s < 288u; ++s) tab.len(s) = 8;
-            buildCode(tab, 0, 288, kTabLenCount, kTabLenSymbol);
-            for (unsigned s = 0; s < 30u; ++s) tab.len(288u + s) = 5;
-            buildCode(tab, 288, 30, kTabDistCount, kTabDistSymbol);
+            unsigned zeros;
+            for (unsigned s = 0; s < 288u; ++s)
+                setLength(tab, s, s < 144u ? 8u : s < 256u ? 9u : s < 280u ? 7u : 8u);
+            buildCode(tab, 0, 288, 0, &zeros);
+            for (unsigned s = 0; s < 30u; ++s)
+                setLength(tab, 288u + s, 5u);
+            buildCode(tab, 288, 30, 1, &zeros);
             const uint32_t rc = inflateCodes(br, o, tab);
             if (rc != kOk)
                 return rc;
@@ -564,23 +589,24 @@ PD_INF_FN uint32_t inflateStream(BitReader & br, Output & o, Tab & tab)
             if (nlen > 286u || ndist > 30u)
                 return kBadBlock;
             // the code-length code, built in the distance slots (free until the real tables are built)
+            unsigned zeros;
             for (unsigned i = 0; i < 19u; ++i)
-                tab.len(i) = 0;
+                setLength(tab, i, 0u);
             for (unsigned i = 0; i < ncode; ++i)
-                tab.len(order[i]) = (uint8_t)br.bits(3);
+                setLength(tab, order[i], br.bits(3));
             if (br.shortInput)
                 return kTruncated;
-            if (buildCode(tab, 0, 19, kTabDistCount, kTabDistSymbol) != 0)
+            if (buildCode(tab, 0, 19, 1, &zeros) != 0)
                 return kBadCode;        // the code-length code must be complete
             unsigned idx = 0;
             while (idx < nlen + ndist)
             {
-                const int sym = decodeSymbol(br, tab, kTabDistCount, kTabDistSymbol);
+                const int sym = decodeSymbol(br, tab, 1);
                 if (sym < 0)
                     return sym == -2 ? kTruncated : kBadCode;
                 if (sym < 16)
                 {
-                    tab.len(idx++) = (uint8_t)sym;
+                    setLength(tab, idx++, (unsigned)sym);
                     continue;
                 }
                 unsigned value = 0, rep;
@@ -588,7 +614,7 @@ PD_INF_FN uint32_t inflateStream(BitReader & br, Output & o, Tab & tab)
                 {
                     if (idx == 0u)
                         return kBadBlock;
-                    value = tab.len(idx - 1u);
+                    value = lengthOf(tab, idx - 1u);
                     rep = 3u + br.bits(2);
                 }
                 else if (sym == 17)
@@ -600,16 +626,17 @@ PD_INF_FN uint32_t inflateStream(BitReader & br, Output & o, Tab & tab)
                 if (idx + rep > nlen + ndist)
                     return kBadBlock;
                 while (rep--)
-                    tab.len(idx++) = (uint8_t)value;
+                    setLength(tab, idx++, value);
             }
-            if (tab.len(256) == 0)
+            if (lengthOf(tab, 256) == 0u)
                 return kBadCode;        // no end-of-block code
             // (the code lengths sit in one run: literal/length codes first, distance codes behind them)
-            int err = buildCode(tab, 0, nlen, kTabLenCount, kTabLenSymbol);
-            if (err != 0 && (err < 0 || nlen != (unsigned)tab.w(kTabLenCount) + tab.w(kTabLenCount + 1)))
+            // (the distance code goes first: its lengths lie behind the others and the list of the literal / length code does not touch them)
+            int err = buildCode(tab, nlen, ndist, 1, &zeros);
+            if (err != 0 && (err < 0 || ndist != zeros + tab.meta(16u + 1u)))
                 return kBadCode;        // incomplete sets are only allowed as a single one-bit code
-            err = buildCode(tab, nlen, ndist, kTabDistCount, kTabDistSymbol);
-            if (err != 0 && (err < 0 || ndist != (unsigned)tab.w(kTabDistCount) + tab.w(kTabDistCount + 1)))
+            err = buildCode(tab, 0, nlen, 0, &zeros);
+            if (err != 0 && (err < 0 || nlen != zeros + tab.meta(1u)))
                 return kBadCode;
             const uint32_t rc = inflateCodes(br, o, tab);
             if (rc != kOk)
@@ -660,6 +687,7 @@ PD_INF_FN uint32_t inflateGzipMember(const uint8_t * in, uint64_t inLen, uint8_t
     o.out = out;
     o.n = 0;
     o.cap = outCap > 0xffff0000ull ? 0xffff0000u : (uint32_t)outCap;
+    tab.high(kHighWords - 1u) = 0;          // (the distance symbols' ninth bits: never set)
     const uint32_t rc = inflateStream(br, o, tab);
     *outLen = o.n;
     if (rc != kOk)
