@@ -272,6 +272,14 @@ struct ReplayState
 // the chunk that used them last has been replayed. A sample whose index, members or inflated sizes look wrong in any way is
 // left to the host's own path (zlib's behaviour on damaged files is the specification there). CallRun keeps two of these:
 // one serves the running round, the other works ahead on a guess of the next (startGunzipPrefetch(), adopt()).
+// Loaders of `popdel call` (GunzipPrefetch): one runs the round that is being decoded, the other the round to come. A loader's
+// records on the device are what the segment of its round points into (pd_walk_source): the loader of round N + 1 cannot begin
+// before the segment of round N - 1 has been handed over. A THIRD set lifts that (built and measured, round 6: the next round's
+// loader then starts when the round begins) and buys nothing: what a round waits for is the device's side of its loader --
+// 260 MB in, 300 MB back, the kernels --, and two rounds' loaders on the link at once take as long as one after the other
+// (0.0258 / 0.0269 s per warmed round of 4,000 samples with three sets, 0.0232 / 0.0234 with two).
+constexpr size_t kLoaderSets = 2;
+
 class GunzipPrefetch
 {
 public:
@@ -350,12 +358,12 @@ public:
     GunzipPrefetch(const CallParams & p, const std::vector<int> & devices, size_t first) : p_(p)
     {
         {
-            // (each of the two loaders keeps its own descriptors: a third of the limit each, the rest is the process's own)
+            // (each of the loaders keeps its own descriptors: a share of the limit each, one share is the process's own)
             struct rlimit lim;
             size_t keep = 256;
             if (getrlimit(RLIMIT_NOFILE, &lim) == 0)           // (raised as far as the cohort needs when the run began: runPopdelCall)
                 keep = lim.rlim_cur == RLIM_INFINITY ? static_cast<size_t>(1) << 20
-                                                     : (static_cast<size_t>(lim.rlim_cur) > 1024 ? (static_cast<size_t>(lim.rlim_cur) - 1024) / 3 : 0);
+                                                     : (static_cast<size_t>(lim.rlim_cur) > 1024 ? (static_cast<size_t>(lim.rlim_cur) - 1024) / (kLoaderSets + 1) : 0);
             fds_.assign(std::min<size_t>(p.inputFiles.size(), keep), -1);
         }
         for (size_t k = 0; k < kInflaters; ++k)
@@ -509,6 +517,7 @@ public:
     uint64_t members = 0, compressedBytes = 0, inflatedBytes = 0, samplesServed = 0, samplesLeft = 0, samplesParsed = 0;
     bool parseOnDevice_ = true;         // POPDEL_HOST_PARSE=1: the device inflates, the host parses
     // the parsed blocks summarised for the tables as well (CallRun: runs filed from summaries), with this much room per block
+    std::function<void()> onGathered;   // called (from a loader thread) when every chunk of the round has been gathered
     bool summariesWanted = false;
     uint32_t startsRoom = 0, endsRoom = 0;
     bool leanWanted = false;            // ... and the 30-bp windows not written out (LeanRaw; POPDEL_FULL_PARSE=1 keeps them)
@@ -532,25 +541,54 @@ private:
         double seconds = 0;
     };
 
-    // Three threads per round: this one gathers chunk after chunk (index offsets, the members' bytes into an inflater's
-    // page-locked buffer); one per inflater runs its chunks on the device and publishes them -- the copies of one chunk
-    // overlap the kernel of the next. The buffers of an inflater go round when the chunk before last has been decoded.
+    // A thread per inflater and round: it gathers its chunks (index offsets, the members' bytes into the inflater's page-locked
+    // buffer), runs them on the device and publishes them -- the three gather at the same time (round 6; chunk after chunk from one
+    // thread until then: 3.7 + 3.7 + 5.3 ms of a 25-ms round in front of the last chunk's copies), the copies of one chunk
+    // overlap the kernels of another. The buffers of an inflater go round when the chunk before last has been decoded.
     void run()
     {
         const size_t nChunks = items_.empty() ? 0 : chunkOf(items_.size() - 1) + 1;
-        std::deque<std::unique_ptr<Prepared>> queue[kInflaters];
-        bool gatherDone = false;
+        size_t gatheredChunks = 0;
         auto deviceLoop = [&](size_t which) {
             for (size_t c = which; c < nChunks; c += kInflaters)
             {
-                std::unique_ptr<Prepared> job;
+                {
+                    std::lock_guard<std::mutex> lock(m_);
+                    if (stop_ || failed_)
+                        break;
+                }
+                std::unique_ptr<Prepared> job(new Prepared());
+                job->lo = chunkBegin(c);
+                job->hi = std::min(items_.size(), chunkBegin(c + 1));
+                bool prepared = false;
+                try
+                {
+                    if (gTrace.on)
+                        gTrace.mark("loader " + std::to_string(reinterpret_cast<uintptr_t>(this) % 997) + ": gathering chunk " + std::to_string(c));
+                    prepare(c, *job);
+                    if (gTrace.on)
+                        gTrace.mark("loader " + std::to_string(reinterpret_cast<uintptr_t>(this) % 997) + ": chunk " + std::to_string(c) + " gathered");
+                    prepared = true;
+                }
+                catch (...)
+                {
+                    std::lock_guard<std::mutex> lock(m_);
+                    failed_ = true;
+                    ok_ = false;
+                }
+                bool all = false;
+                {
+                    std::lock_guard<std::mutex> lock(m_);
+                    if (++gatheredChunks == nChunks || failed_)
+                        all = gathered_ = true;
+                }
+                cv_.notify_all();
+                if (all && onGathered)
+                    onGathered();
+                if (!prepared)
+                    break;
                 {
                     std::unique_lock<std::mutex> lock(m_);
-                    cv_.wait(lock, [&] { return !queue[which].empty() || gatherDone || stop_ || failed_; });
-                    if (queue[which].empty() || failed_)
-                        break;
-                    job = std::move(queue[which].front());
-                    queue[which].pop_front();
                     if (c >= kInflaters)
                     {
                         // the inflater's output still holds the chunk it ran last: wait until that chunk's last sample has been decoded
@@ -558,7 +596,7 @@ private:
                         const unsigned lastOfOld = items_[chunkBegin(c - kInflaters + 1) - 1].sample;
                         cv_.wait(lock, [&] { return releasedBelow_ > lastOfOld || stop_; });
                     }
-                    if (stop_)
+                    if (stop_ || failed_)
                         break;
                 }
                 try
@@ -589,55 +627,18 @@ private:
                 std::lock_guard<std::mutex> lock(m_);
                 for (size_t c = which; c < nChunks; c += kInflaters)
                     done_[c] = 1;
+                if (stop_ || failed_)
+                    gathered_ = true;
             }
             cv_.notify_all();
         };
         std::vector<std::thread> device;
-        for (size_t k = 0; k < kInflaters; ++k)
+        for (size_t k = 1; k < kInflaters; ++k)
             device.emplace_back(deviceLoop, k);
-        for (size_t c = 0; c < nChunks; ++c)
-        {
-            {
-                // the inflater's input buffer was read by chunk c - 2's copy: that chunk must be through
-                std::unique_lock<std::mutex> lock(m_);
-                cv_.wait(lock, [&] { return c < kInflaters || done_[c - kInflaters] || stop_ || failed_; });
-                if (stop_ || failed_)
-                    break;
-            }
-            std::unique_ptr<Prepared> job(new Prepared());
-            job->lo = chunkBegin(c);
-            job->hi = std::min(items_.size(), chunkBegin(c + 1));
-            try
-            {
-                if (gTrace.on)
-                    gTrace.mark("loader " + std::to_string(reinterpret_cast<uintptr_t>(this) % 997) + ": gathering chunk " + std::to_string(c));
-                prepare(c, *job);
-                if (gTrace.on)
-                    gTrace.mark("loader " + std::to_string(reinterpret_cast<uintptr_t>(this) % 997) + ": chunk " + std::to_string(c) + " gathered");
-            }
-            catch (...)
-            {
-                std::lock_guard<std::mutex> lock(m_);
-                failed_ = true;
-                ok_ = false;
-                break;
-            }
-            {
-                std::lock_guard<std::mutex> lock(m_);
-                queue[c % kInflaters].push_back(std::move(job));
-            }
-            cv_.notify_all();
-        }
-        {
-            std::lock_guard<std::mutex> lock(m_);
-            gatherDone = true;
-            gathered_ = true;
-        }
-        cv_.notify_all();
+        deviceLoop(0);
         for (std::thread & t : device)
             t.join();
     }
-
     void prepare(size_t c, Prepared & j)
     {
         pd_inflater * inf = inflater_[c % kInflaters];
@@ -950,8 +951,14 @@ public:
             std::lock_guard<std::mutex> guard(deviceNotesLock_);
             if (gunzipSet_[0])
             {
-                GunzipPrefetch & a = *gunzipSet_[0];
-                GunzipPrefetch & b = *gunzipSet_[1];
+                struct { uint64_t samplesServed = 0, samplesLeft = 0, samplesParsed = 0, members = 0, compressedBytes = 0, inflatedBytes = 0;
+                         double gatherSeconds = 0, runSeconds = 0, kernelMs = 0, waitSeconds = 0; } a, b;
+                for (auto & g : gunzipSet_)
+                {
+                    a.samplesServed += g->samplesServed; a.samplesLeft += g->samplesLeft; a.samplesParsed += g->samplesParsed;
+                    a.members += g->members; a.compressedBytes += g->compressedBytes; a.inflatedBytes += g->inflatedBytes;
+                    a.gatherSeconds += g->gatherSeconds; a.runSeconds += g->runSeconds; a.kernelMs += g->kernelMs; a.waitSeconds += g->waitSeconds;
+                }
                 std::cerr << "[popdel timing] loader: profile blocks inflated on the device for " << a.samplesServed + b.samplesServed << " sample rounds (" << a.samplesLeft + b.samplesLeft
                           << " left to the host), parsed there for " << a.samplesParsed + b.samplesParsed << "; " << a.members + b.members << " members, " << a.compressedBytes + b.compressedBytes << " -> " << a.inflatedBytes + b.inflatedBytes
                           << " bytes; gather " << a.gatherSeconds + b.gatherSeconds << " s, copies + kernel " << a.runSeconds + b.runSeconds << " s (kernel "
@@ -1077,11 +1084,27 @@ private:
     // before the segment that points into its records has been handed over (loaderJob_, startLoaderAhead()).
     std::vector<pd_walk_source> slotSource_;
     std::vector<uint32_t> slotSourceCount_;
-    uint64_t loaderJob_[2] = {0, 0};            // per loader: the newest hand-over job that points into its inflaters' records
+    uint64_t loaderJob_[kLoaderSets] = {};      // per loader: the newest hand-over job that points into its inflaters' records (under handOverLock_)
     bool handedOver(uint64_t seq)
     {
         std::lock_guard<std::mutex> lock(handOverLock_);
         return handOverFinished_ >= seq || handOverError_;
+    }
+    bool loaderHandedOver(int set)
+    {
+        std::lock_guard<std::mutex> lock(handOverLock_);
+        return handOverFinished_ >= loaderJob_[set] || handOverError_;
+    }
+    // Who starts the loader of the round to come: the main thread where it passes by (round begin, batch decoded, batch replayed)
+    // and -- round 6 -- the threads whose progress it waits for, the moment they are through: the running round's loader when it
+    // has gathered its chunks, the hand-over thread when a segment is on the device (startLoaderAheadFrom; they only TRY the
+    // lock: the main thread may be waiting for them while it holds it, and looks itself when it lets go).
+    std::recursive_mutex aheadLock_;
+    void startLoaderAheadFromOutside()
+    {
+        std::unique_lock<std::recursive_mutex> lock(aheadLock_, std::try_to_lock);
+        if (lock.owns_lock())
+            startLoaderAhead();
     }
     bool processSegmentCode(unsigned i, unsigned code);
     void processSegment();
@@ -1146,7 +1169,7 @@ private:
     bool deviceWalkOffered_ = false, deviceWalk_ = false, lightTables_ = false;
     // the round's profile blocks inflated on the device (GunzipPrefetch) once the backend is up; POPDEL_HOST_GUNZIP=1: never
     // two loaders: one serves the round that runs, the other works AHEAD on the round to come (startGunzipPrefetch())
-    std::unique_ptr<GunzipPrefetch> gunzipSet_[2];
+    std::unique_ptr<GunzipPrefetch> gunzipSet_[kLoaderSets];
     GunzipPrefetch * gunzip_ = nullptr;         // the running round's, if any
     int gunzipAhead_ = -1;                      // index of the loader that was started for the round to come
     bool loaderAhead_ = true;                   // POPDEL_LOADER_AHEAD=0: every round's blocks are fetched when the round starts
@@ -1520,13 +1543,17 @@ bool CallRun::firstWindowOnNextRoi(Coord & minCoord)
 // with the file or the region and whose slots will not be switched (checkAndSwitch() below: a switch ends a sample's turn).
 void CallRun::startGunzipPrefetch()
 {
+    std::lock_guard<std::recursive_mutex> aheadGuard(aheadLock_);
     gunzip_ = nullptr;
     pendingGuess_.clear();
     if (!backendReady_.load() && getenv("POPDEL_DEVICE_GUNZIP_WAIT") && deviceWalkOffered_)
         ensureBackend();            // (tests: short runs are over before the backend is up and would never take this path)
     if (!backendReady_.load() || !gunzipSet_[0])      // (the loaders are created by the backend's thread, before it says ready)
         return;
-    if (!gunzipSet_[0]->ok() || !gunzipSet_[1]->ok())
+    bool loadersFine = true;
+    for (auto & g : gunzipSet_)
+        loadersFine = loadersFine && g->ok();
+    if (!loadersFine)
     {
         // (a loader gave up: this and the rounds to come are inflated on the host)
         for (auto & g : gunzipSet_)
@@ -1589,8 +1616,13 @@ void CallRun::startGunzipPrefetch()
     }
     if (current < 0 && !items.empty())
     {
-        current = ahead >= 0 ? 1 - ahead : 0;
-        waitForHandOver(loaderJob_[current]);       // (no segment may still point into that loader's records on the device)
+        current = ahead >= 0 ? (ahead + 1) % static_cast<int>(kLoaderSets) : 0;
+        uint64_t lastJob = 0;
+        {
+            std::lock_guard<std::mutex> lock(handOverLock_);
+            lastJob = loaderJob_[current];
+        }
+        waitForHandOver(lastJob);                   // (no segment may still point into that loader's records on the device)
         gunzipSet_[current]->edgesOnly = edgesOnly_ && deviceWalk_;     // (with the window loop back on the host every record is wanted here)
         gunzipSet_[current]->start(items, roi.seqName);
         ++roundsOnDemand_;
@@ -1631,7 +1663,7 @@ void CallRun::startGunzipPrefetch()
     // startLoaderAhead(), called batch by batch)
     pendingGuess_ = std::move(guess);
     pendingGuessContig_ = roi.seqName;
-    pendingGuessSet_ = 1 - current;
+    pendingGuessSet_ = (current + 1) % static_cast<int>(kLoaderSets);
     guessedBegin_ = nextBegin;
     startLoaderAhead();
 }
@@ -1644,6 +1676,7 @@ void CallRun::createLoaders()
     for (auto & g : gunzipSet_)
     {
         g.reset(new GunzipPrefetch(p_, gunzipDevices_, first));
+        g->onGathered = [this] { startLoaderAheadFromOutside(); };
         first += GunzipPrefetch::kInflaters;
         // (the parsed blocks summarised for the tables: whenever the tables can make use of it -- light end tables, which go with
         // the device's window loop; a block spans one index region, its pairs end a little further on)
@@ -1679,9 +1712,10 @@ void CallRun::startLoaderAhead()
     // gunzip launches and the next round's first then share the chip, and the kernel, a chain of dependent instructions per member,
     // gets more out of it the more members are in flight; POPDEL_LOADER_OVERLAP=0 waits for the chunks to be through as before)
     static const bool overlap = [] { const char * e = getenv("POPDEL_LOADER_OVERLAP"); return !(e && e[0] == '0'); }();
+    std::lock_guard<std::recursive_mutex> aheadGuard(aheadLock_);
     if (pendingGuess_.empty() || !gunzip_ || !(overlap ? gunzip_->allGathered() : gunzip_->allDone()))
         return;
-    if (!handedOver(loaderJob_[pendingGuessSet_]))      // (a segment still points into that loader's records on the device: at the next call)
+    if (!loaderHandedOver(pendingGuessSet_))            // (a segment still points into that loader's records on the device: at the next call)
         return;
     gunzipAhead_ = pendingGuessSet_;
     gunzipSet_[gunzipAhead_]->edgesOnly = edgesOnly_ && deviceWalk_;
@@ -3077,7 +3111,9 @@ void CallRun::submitPlannedSegment(const WalkShape & shape, const std::vector<ui
         if (job->copy.empty())
             lastDirectJob_ = job->seq;
         if (!job->sources.empty() && gunzip_)
-            loaderJob_[gunzip_ == gunzipSet_[0].get() ? 0 : 1] = job->seq;
+            for (size_t k = 0; k < kLoaderSets; ++k)
+                if (gunzip_ == gunzipSet_[k].get())
+                    loaderJob_[k] = job->seq;
         handOverQueue_.push_back(job);
         handOverIdle_ = false;
         if (!handOverThread_.joinable())
@@ -3135,6 +3171,9 @@ void CallRun::handOverLoop()
             }
             last = handOverQueue_.empty();
         }
+        handOverDone_.notify_all();
+        if (!failed)
+            startLoaderAheadFromOutside();          // (the loader whose records this segment pointed into may go on to the round to come)
         if (last && !failed)
         {
             // nothing queued behind it: its results are collected and written right away (the end of the run, a change of
