@@ -520,7 +520,8 @@ PD_INF_FN uint32_t inflateCodes(BitReader & br, Output & o, Tab & tab)
         const bool full = o.n + bytes > o.cap;
         if (noSymbol | truncated | endOfBlock | tooFar | full)
         {
-            rc = noSymbol ? kBadCode : truncated ? kTruncated : endOfBlock ? kOk : tooFar ? kBadDistance : kOutputFull;
+            // (the end of the input first: what the device sees beyond it is not what the host sees, and must not decide)
+            rc = truncated ? kTruncated : noSymbol ? kBadCode : endOfBlock ? kOk : tooFar ? kBadDistance : kOutputFull;
             break;
         }
         itemBytes = bytes;
