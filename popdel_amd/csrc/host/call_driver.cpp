@@ -14,6 +14,7 @@
 #include <deque>
 #include <memory>
 #include <fcntl.h>
+#include <malloc.h>
 #include <sys/resource.h>
 #include <sys/syscall.h>
 #include <thread>
@@ -3870,6 +3871,17 @@ int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer, bool
     try
     {
         const double t0 = PhaseClock::now();
+#ifdef __GLIBC__
+        // (the rounds allocate and free the same large arrays over and over: kept in the heap instead of mapped, faulted in and
+        // unmapped every time -- 10,000 profiles x 2 Mb: 7.6 -> 6.0 of 17.9 CPU-seconds in the kernel, 0.082 -> 0.075 s per round
+        // over the run; the MALLOC_..._ environment variables still decide if they are set)
+        if (!getenv("MALLOC_MMAP_THRESHOLD_") && !getenv("MALLOC_TRIM_THRESHOLD_") && !getenv("MALLOC_TOP_PAD_"))
+        {
+            mallopt(M_MMAP_THRESHOLD, 1 << 30);
+            mallopt(M_TRIM_THRESHOLD, 0x7fffffff);
+            mallopt(M_TOP_PAD, 256 << 20);
+        }
+#endif
         if (const char * t = getenv("POPDEL_TIMING"))
         {
             gTrace.on = atoi(t) >= 2;
