@@ -906,6 +906,10 @@ public:
     CallRun(CallParams & p, SegmentObserver * obs) : p_(p), observer_(obs) {}
     ~CallRun()
     {
+        {
+            std::lock_guard<std::recursive_mutex> aheadGuard(aheadLock_);
+            aheadClosed_ = true;
+        }
         if (handOverThread_.joinable())
         {
             {
@@ -1101,10 +1105,11 @@ private:
     // has gathered its chunks, the hand-over thread when a segment is on the device (startLoaderAheadFrom; they only TRY the
     // lock: the main thread may be waiting for them while it holds it, and looks itself when it lets go).
     std::recursive_mutex aheadLock_;
+    bool aheadClosed_ = false;                  // the run is being taken down: nobody starts a loader any more
     void startLoaderAheadFromOutside()
     {
         std::unique_lock<std::recursive_mutex> lock(aheadLock_, std::try_to_lock);
-        if (lock.owns_lock())
+        if (lock.owns_lock() && !aheadClosed_)
             startLoaderAhead();
     }
     bool processSegmentCode(unsigned i, unsigned code);
