@@ -447,8 +447,10 @@ int pd_log_table_view(pd_ctx *ctx, uint32_t rg, double *value, double *log_value
  * (header, deflate stream, trailer); its output goes to out[out_offsets[m] .. out_offsets[m + 1]) -- the caller sizes that from
  * the ISIZE word that ends a member. status[m]: 0, or why the member was refused (1 not gzip/deflate, 2 truncated, 3 bad
  * block header, 4 bad code set, 5 distance before the start, 6 more output than room, 7 CRC-32 mismatch, 8 ISIZE mismatch --
- * the cases zlib's inflate refuses); out_lengths[m]: bytes produced. All pointers are host memory. The kernel is launched
- * `repeat` times (>= 1) and `timing` reports its mean duration next to the two copies. Returns 0, or non-zero with
+ * the cases zlib's inflate refuses; which of them a damaged member gets is not part of the contract beyond zero / non-zero and 6);
+ * out_lengths[m]: bytes produced. All pointers are host memory. Two kernels per launch since round 6 (no ABI change): the
+ * decoder, sixteen members per wave, and the CRC-32 of what it produced against the trailers. The kernels are launched
+ * `repeat` times (>= 1) and `timing` reports their mean duration next to the two copies. Returns 0, or non-zero with
  * pd_inflate_last_error() saying why (the message of the calling thread's last failed call). This one-shot form serves the
  * bench and the tests; `popdel call` inflates through the persistent pd_inflater objects below (call_driver.cpp,
  * GunzipPrefetch: a chunk of samples' members per call, three inflaters in turn). */
