@@ -781,33 +781,52 @@ bool ChromProfile::addBulk(unsigned rg, const uint32_t * posDev, const RunSummar
         const uint16_t * hist = slot.hist.data();
         uint64_t oldBelow = slot.curCum[0];     // entries already in the slot that end before window (base + at)
         unsigned at = slot.curBin[0];
-        uint64_t runBelow = 0;                  // records of the run that end before window b
-        uint64_t filed = 0;
         const uint64_t dNext0 = en.dNext;
         const unsigned histBins = static_cast<unsigned>(slot.hist.size());
-        unsigned tooMany = 0;
-        for (unsigned b = firstBin; b <= lastBin; ++b)
+        // (the prefix over the slot's own counts up to the run's first window: the slot has entries in [lowBin, highBin) only)
         {
-            const unsigned rel = b - s.binBase;
-            const unsigned t = b - base;        // (b >= base: tFirst >= curBin[0] >= 0 with firstBin > base, or firstBin <= base -> t clamps)
-            // old entries ending before b: advance the prefix to t (the slot has none from highBin on)
-            const unsigned upTo = b > base ? std::min(t, histBins) : 0u;
+            const unsigned upTo = firstBin > base ? std::min(firstBin - base, histBins) : 0u;
             for (const unsigned stop = std::min(upTo, slot.highBin); at < stop; ++at)
                 if (at >= slot.lowBin)
                     oldBelow += hist[at];
             at = std::max(at, upTo);
-            if (startCounts[rel] != 0)
-            {
-                filed += startCounts[rel];
-                const uint64_t below = oldBelow + runBelow;
-                const uint64_t cursor = std::max<uint64_t>(dNext0, below);
-                if (load0 + filed - (cursor - dNext0) >= cap)
-                    return false;
-            }
-            belowAtEnd = oldBelow + runBelow;
-            tooMany |= endCounts[rel];
-            runBelow += endCounts[rel];
         }
+        // From here on a window per trip, nothing to decide inside: window b's records are filed behind `filed` records of the
+        // run, `below` entries end before it -- the slot's (the prefix goes on by hist[t - 1], taken as zero outside the slot's
+        // range by cutting the loop there) and the run's --, the load behind them is load0 + filed - (max(below, dNext0) - dNext0).
+        // A window without records repeats the question of the window before it with a cursor further on: never a larger load.
+        // The largest load decides at the end (the rule bites rarely: nothing is gained by leaving early).
+        uint64_t runBelow = 0, filed = 0, worst = 0;
+        unsigned tooMany = 0;
+        const uint16_t * sc = startCounts + (firstBin - s.binBase), * ec = endCounts + (firstBin - s.binBase);
+        const unsigned nWin = lastBin - firstBin + 1u;
+        // windows whose predecessor lies inside the slot's counts: t - 1 = (firstBin + w) - base - 1 in [max(at', lowBin), highBin)
+        // with at' = where the prefix stands; w from wLo to wHi
+        const int64_t tFirstSigned = static_cast<int64_t>(firstBin) - static_cast<int64_t>(base);
+        auto clampW = [&](int64_t t) { return static_cast<unsigned>(std::min<int64_t>(std::max<int64_t>(t - tFirstSigned, 0), nWin)); };
+        // the prefix `oldBelow` holds hist[0 .. at); window w needs hist[0 .. min(t_w, histBins)) with t_w = tFirstSigned + w
+        const unsigned wLo = clampW(static_cast<int64_t>(std::max(at, slot.lowBin)) + 1), wHi = std::max(wLo, clampW(static_cast<int64_t>(std::min(slot.highBin, histBins)) + 1));
+        auto sweep = [&](unsigned w0, unsigned w1, bool inside) {
+            // (own[w] = hist[t_w - 1]; the pointer is formed only where such windows exist: w0 + tFirstSigned >= 1 there)
+            const uint16_t * own = inside && w0 < w1 ? hist + (tFirstSigned - 1 + static_cast<int64_t>(w0)) - w0 : nullptr;
+            for (unsigned w = w0; w < w1; ++w)
+            {
+                if (own)
+                    oldBelow += own[w];
+                filed += sc[w];
+                const uint64_t below = oldBelow + runBelow;
+                const uint64_t load = load0 + filed - (std::max(below, dNext0) - dNext0);
+                worst = std::max(worst, load);
+                tooMany |= ec[w];
+                runBelow += ec[w];
+            }
+        };
+        sweep(0, wLo, false);
+        sweep(wLo, wHi, true);
+        sweep(wHi, nWin, false);
+        belowAtEnd = oldBelow + runBelow - ec[nWin - 1u];
+        if (worst >= cap)
+            return false;
         for (unsigned b = lastBin + 1; b <= s.maxEndBin; ++b)
             tooMany |= endCounts[b - s.binBase];
         if (filed != s.n || tooMany >= 0x4000u)
@@ -828,20 +847,24 @@ bool ChromProfile::addBulk(unsigned rg, const uint32_t * posDev, const RunSummar
     else
         sslot.virtualRuns.push_back(StartSlots::VirtualRun{sslot.entries.size(), s.n, note.firstWindow, note.skip, note.jumpPos, note.tag});
     {
-        uint16_t * hist = slot.hist.data();
+        // (three plain loops: the counts added, and what of them lies in front of the two cursors)
         const unsigned cur0 = slot.curBin[0], cur1 = slot.curBin[1];
-        unsigned cum0 = 0, cum1 = 0, peak = slot.peak;
-        for (unsigned b = s.minEndBin; b <= s.maxEndBin; ++b)
+        const unsigned t0 = s.minEndBin - base, nEnd = s.maxEndBin - s.minEndBin + 1u;
+        uint16_t * __restrict__ own = slot.hist.data() + t0;
+        const uint16_t * __restrict__ add = endCounts + (s.minEndBin - s.binBase);
+        unsigned cum0 = 0, cum1 = 0;
+        uint16_t peak16 = 0;
+        for (unsigned k = 0; k < nEnd; ++k)
         {
-            const unsigned add = endCounts[b - s.binBase];
-            if (add == 0)
-                continue;
-            const unsigned t = b - base;
-            const unsigned count = (hist[t] = static_cast<uint16_t>(hist[t] + add));
-            peak = count > peak ? count : peak;
-            cum0 += t < cur0 ? add : 0u;
-            cum1 += t < cur1 ? add : 0u;
+            const uint16_t count = static_cast<uint16_t>(own[k] + add[k]);
+            own[k] = count;
+            peak16 = count > peak16 ? count : peak16;
         }
+        const unsigned peak = std::max<unsigned>(slot.peak, peak16);
+        for (unsigned k = 0, n0 = cur0 > t0 ? std::min(cur0 - t0, nEnd) : 0u; k < n0; ++k)
+            cum0 += add[k];
+        for (unsigned k = 0, n1 = cur1 > t0 ? std::min(cur1 - t0, nEnd) : 0u; k < n1; ++k)
+            cum1 += add[k];
         slot.peak = peak;
         slot.curCum[0] += cum0;
         slot.curCum[1] += cum1;
