@@ -336,7 +336,8 @@ struct Output
 // The word after these two is loaded at the beginning of EVERY trip and taken at its end if the cursor has crossed into the
 // second word by then (mostly it has not: the load is repeated, out of the cache) -- its latency passes behind the decoding,
 // and no register that waits for memory lives across the loop's back edge (the compiler would wait for it there, and for the
-// stores in front of it). Bits beyond the end of the input read as zeros; `left` tells when a symbol took bits that were not there.
+// stores in front of it). What lies beyond the end of the input may be looked at (zeros on the host, whatever follows on the
+// device) and is never consumed: `left` tells when a symbol took bits that were not there.
 struct WordReader
 {
     const uint8_t * in;
