@@ -168,10 +168,12 @@ def test_random_cohort(built, seed):
 # touched calls (LR by 8.9e-6); from the sweeps of seeds 1650-3149 (1,500 cohorts): 1997, 2741, 2875, 3025 one diverged call each and
 # 2954 four (neighbouring candidate lengths of one deletion); 2093 the largest LR difference seen (3.0e-2: same length and
 # position, the EM stops one iteration apart), 1916 the next of those sweeps (1.5e-5); 1829 the largest AF difference (1.03e-4);
-# 1658, 1760, 2519, 2584, 2699, 2945 calls with 54-69 % of their columns touched. What the shipped library does on them is pinned, call by call, in tests/golden/residual_<seed>.json
+# 1658, 1760, 2519, 2584, 2699, 2945 calls with 54-69 % of their columns touched; from round 6's sweep of seeds 3150-3749 on the
+# final build (profiles/r06_fuzz_sweeps.md): 3392 a diverged call, 3665 a call with 74 % of its columns touched (the largest share so
+# far), 3367 LR by 1.7e-5, 3666 AF by 7.5e-5. What the shipped library does on them is pinned, call by call, in tests/golden/residual_<seed>.json
 # (tools/make_residual_goldens.py; tests/residual.py says what a record holds and which invariants hold regardless).
 RESIDUAL_SEEDS = [132, 155, 483, 515, 533, 620, 632, 693, 887, 1003, 1070, 1112, 1145, 1328, 1424, 1435,
-                  1658, 1760, 1829, 1916, 1997, 2093, 2519, 2584, 2699, 2741, 2875, 2945, 2954, 3025]
+                  1658, 1760, 1829, 1916, 1997, 2093, 2519, 2584, 2699, 2741, 2875, 2945, 2954, 3025, 3367, 3392, 3665, 3666]
 
 
 @pytest.mark.parametrize("seed", RESIDUAL_SEEDS)
