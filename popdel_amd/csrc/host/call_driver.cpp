@@ -527,7 +527,7 @@ public:
     uint64_t members = 0, compressedBytes = 0, inflatedBytes = 0, samplesServed = 0, samplesLeft = 0, samplesParsed = 0;
     bool parseOnDevice_ = true;         // POPDEL_HOST_PARSE=1: the device inflates, the host parses
     // the parsed blocks summarised for the tables as well (CallRun: runs filed from summaries), with this much room per block
-    std::function<void()> onGathered;   // called (from a loader thread) when every chunk of the round has been gathered
+    std::function<void()> onProgress;   // called (from a loader thread) when every chunk of the round has been gathered, and when a chunk is through the device
     bool summariesWanted = false;
     uint32_t startsRoom = 0, endsRoom = 0;
     bool leanWanted = false;            // ... and the 30-bp windows not written out (LeanRaw; POPDEL_FULL_PARSE=1 keeps them)
@@ -593,8 +593,8 @@ private:
                         all = gathered_ = true;
                 }
                 cv_.notify_all();
-                if (all && onGathered)
-                    onGathered();
+                if (all && onProgress)
+                    onProgress();
                 if (!prepared)
                     break;
                 {
@@ -631,8 +631,8 @@ private:
                     done_[c] = 1;
                 }
                 cv_.notify_all();
-                if (onGathered)
-                    onGathered();               // (a chunk is through: the round to come may be waiting for just that)
+                if (onProgress)
+                    onProgress();               // (a chunk is through: the round to come may be waiting for just that)
             }
             {
                 // (whatever this thread leaves undone counts as done: the decoders then inflate those samples themselves)
@@ -1693,7 +1693,7 @@ void CallRun::createLoaders()
     for (auto & g : gunzipSet_)
     {
         g.reset(new GunzipPrefetch(p_, gunzipDevices_, first));
-        g->onGathered = [this] { startLoaderAheadFromOutside(); };
+        g->onProgress = [this] { startLoaderAheadFromOutside(); };
         first += GunzipPrefetch::kInflaters;
         // (the parsed blocks summarised for the tables: whenever the tables can make use of it -- light end tables, which go with
         // the device's window loop; a block spans one index region, its pairs end a little further on)
