@@ -286,6 +286,38 @@ int pdh_selftest_parallel(unsigned callers, unsigned rounds, unsigned n)
     return static_cast<int>(bad.load());
 }
 
+// What the gunzip core's symbol table says (pdinf::symbolKind: one formula for the lengths and one for the distances) against
+// RFC 1951's own tables, section 3.2.5, written out. Returns 0, or 1 + the first entry that differs.
+int pdh_selftest_symbol_kinds()
+{
+    static const uint16_t lengthBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t lengthExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t distBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145,
+                                          8193, 12289, 16385, 24577};
+    static const uint8_t distExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    for (unsigned i = 0; i < pdinf::kSymbolKinds; ++i)
+    {
+        const uint32_t k = pdinf::symbolKind(i);
+        const uint32_t extra = k & 15u, m = (k >> 4) & 0xffu, flags = k & (pdinf::kKindLiteral | pdinf::kKindEnd | pdinf::kKindNone);
+        bool fine;
+        if (i < 256u)
+            fine = flags == pdinf::kKindLiteral;
+        else if (i == 256u)
+            fine = flags == pdinf::kKindEnd;
+        else if (i < 286u)
+            fine = flags == 0u && extra == lengthExtra[i - 257u] && 3u + (m << extra) == lengthBase[i - 257u];
+        else if (i < 288u)
+            fine = flags == pdinf::kKindNone;
+        else if (i < 318u)
+            fine = flags == 0u && extra == distExtra[i - 288u] && 1u + (m << extra) == distBase[i - 288u];
+        else
+            fine = flags == pdinf::kKindNone;
+        if (!fine)
+            return 1 + static_cast<int>(i);
+    }
+    return 0;
+}
+
 // The device's gunzip (popdel_amd/csrc/hip/inflate_core.h, the source inflate.hip compiles for the GPU) run on the CPU, one
 // member after the other: tests compare it with zlib bit for bit, including damaged and truncated members (-m "not gpu").
 int pdh_inflate_members_core(const uint8_t * data, const uint64_t * offsets, uint32_t n, uint8_t * out, const uint64_t * outOffsets,

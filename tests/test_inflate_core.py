@@ -100,3 +100,12 @@ def test_truncated_and_damaged_members_are_refused_like_zlib(built):
 def test_library_exports_the_entry_point(built):
     lib = ctypes.CDLL(HIP_LIB)
     assert hasattr(lib, "pd_inflate_members") and hasattr(lib, "pd_inflate_last_error")
+
+
+def test_symbol_table_against_the_rfc(built):
+    """pdinf::symbolKind() -- what a literal / length or distance symbol stands for, from one formula each -- against the tables of
+    RFC 1951, 3.2.5, written out (length 3..258 with 0..5 extra bits, distance 1..24,577 with 0..13; 286, 287, 30 and 31: no symbols)."""
+    import os
+    from conftest import ROOT
+    host = ctypes.CDLL(os.path.join(ROOT, "popdel_amd", "lib", "libpopdel_host.so"))
+    assert host.pdh_selftest_symbol_kinds() == 0
