@@ -273,13 +273,12 @@ struct ReplayState
 // the chunk that used them last has been replayed. A sample whose index, members or inflated sizes look wrong in any way is
 // left to the host's own path (zlib's behaviour on damaged files is the specification there). CallRun keeps two of these:
 // one serves the running round, the other works ahead on a guess of the next (startGunzipPrefetch(), adopt()).
-// Loaders of `popdel call` (GunzipPrefetch): one runs the round that is being decoded, the other the round to come. A loader's
-// records on the device are what the segment of its round points into (pd_walk_source): the loader of round N + 1 cannot begin
-// before the segment of round N - 1 has been handed over. A THIRD set lifts that (built and measured, round 6: the next round's
-// loader then starts when the round begins) and buys nothing: what a round waits for is the device's side of its loader --
-// 260 MB in, 300 MB back, the kernels --, and two rounds' loaders on the link at once take as long as one after the other
-// (0.0258 / 0.0269 s per warmed round of 4,000 samples with three sets, 0.0232 / 0.0234 with two).
-constexpr size_t kLoaderSets = 2;
+// Loaders of `popdel call` (GunzipPrefetch): one runs the round that is being decoded, the others the rounds to come -- up to two of
+// them (CallRun::aheadDepth_): a loader takes a round's length and more from its first gather to its last chunk (5 + 15-18 ms at
+// 4,000 samples against 16 ms of decoding and replaying), so the loader of round N + 2 starts while round N runs. A loader's
+// records on the device are what the segment of its round points into (pd_walk_source): a set is free again when that segment
+// has been handed over -- hence three sets for two rounds ahead.
+constexpr size_t kLoaderSets = 3;
 
 class GunzipPrefetch
 {
@@ -1188,12 +1187,31 @@ private:
     // two loaders: one serves the round that runs, the other works AHEAD on the round to come (startGunzipPrefetch())
     std::unique_ptr<GunzipPrefetch> gunzipSet_[kLoaderSets];
     GunzipPrefetch * gunzip_ = nullptr;         // the running round's, if any
-    int gunzipAhead_ = -1;                      // index of the loader that was started for the round to come
     bool loaderAhead_ = true;                   // POPDEL_LOADER_AHEAD=0: every round's blocks are fetched when the round starts
-    int64_t guessedBegin_ = 0;
-    std::vector<GunzipPrefetch::Item> pendingGuess_;
-    std::string pendingGuessContig_;
-    int pendingGuessSet_ = 0;
+    size_t aheadDepth_ = 2;                     // rounds the loaders go ahead of the running one (POPDEL_LOADER_DEPTH=1: one, as until round 6)
+    // the rounds to come, in their order: loaders that have been started on a guess, and guesses that wait for a set and for the
+    // loader before them to have gathered (startLoaderAhead)
+    struct AheadLoader
+    {
+        int     set;
+        int64_t begin;
+    };
+    struct Guess
+    {
+        std::vector<GunzipPrefetch::Item> items;
+        std::string contig;
+        int64_t begin = 0;
+    };
+    std::deque<AheadLoader> aheadLoaders_;
+    std::deque<Guess> pendingGuesses_;
+    int lastSet_ = -1;                          // the set of the loader that was started last (the running round's or one ahead)
+    void dropAhead()                            // (a guess did not hold: what was extrapolated from it goes, too)
+    {
+        for (const AheadLoader & a : aheadLoaders_)
+            gunzipSet_[a.set]->finish();
+        aheadLoaders_.clear();
+        pendingGuesses_.clear();
+    }
     uint64_t roundsAhead_ = 0, roundsOnDemand_ = 0, roundsGuessedWrong_ = 0;
     std::vector<int> gunzipDevices_ = {0};
     size_t regionsOffered_ = 0;             // regions of the table pool the backend has been told of (hand-over thread)
@@ -1562,7 +1580,6 @@ void CallRun::startGunzipPrefetch()
 {
     std::lock_guard<std::recursive_mutex> aheadGuard(aheadLock_);
     gunzip_ = nullptr;
-    pendingGuess_.clear();
     if (!backendReady_.load() && getenv("POPDEL_DEVICE_GUNZIP_WAIT") && deviceWalkOffered_)
         ensureBackend();            // (tests: short runs are over before the backend is up and would never take this path)
     if (!backendReady_.load() || !gunzipSet_[0])      // (the loaders are created by the backend's thread, before it says ready)
@@ -1575,7 +1592,8 @@ void CallRun::startGunzipPrefetch()
         // (a loader gave up: this and the rounds to come are inflated on the host)
         for (auto & g : gunzipSet_)
             g->finish();
-        gunzipAhead_ = -1;
+        aheadLoaders_.clear();
+        pendingGuesses_.clear();
         return;
     }
     const Region & roi = p_.allRois[p_.nextRoi];
@@ -1608,32 +1626,37 @@ void CallRun::startGunzipPrefetch()
         }
     }
     // 1. this round: the loader that went ahead if its guess holds for (nearly) all readers, else a fresh one
-    const int ahead = gunzipAhead_;
-    gunzipAhead_ = -1;
     int current = -1;
     static const bool trace = getenv("POPDEL_LOADER_TRACE") != nullptr;
     if (trace)
         std::cerr << "[popdel loader] round begins at " << roi.seqName << ":" << roi.beginPos << " (region ends at " << roi.endPos << "), " << items.size()
-                  << " readers, farthest end " << farthest << (ahead >= 0 ? "; guessed begin " + std::to_string(guessedBegin_) : std::string()) << std::endl;
-    if (ahead >= 0)
+                  << " readers, farthest end " << farthest
+                  << (!aheadLoaders_.empty() ? "; guessed begin " + std::to_string(aheadLoaders_.front().begin) : std::string()) << std::endl;
+    if (!aheadLoaders_.empty())
     {
-        const size_t covered = items.empty() ? 0 : gunzipSet_[ahead]->adopt(items, roi.seqName);
+        const AheadLoader ahead = aheadLoaders_.front();
+        aheadLoaders_.pop_front();
+        const size_t covered = items.empty() ? 0 : gunzipSet_[ahead.set]->adopt(items, roi.seqName);
         if (trace)
             std::cerr << "[popdel loader] the guess covers " << covered << " of them" << std::endl;
         if (!items.empty() && covered * 10 >= items.size() * 9)
         {
-            current = ahead;
+            current = ahead.set;
             ++roundsAhead_;
         }
         else
         {
-            gunzipSet_[ahead]->finish();
+            gunzipSet_[ahead.set]->finish();
+            dropAhead();
             ++roundsGuessedWrong_;
         }
     }
+    else
+        pendingGuesses_.clear();                    // (a guess for THIS round that never got a loader)
     if (current < 0 && !items.empty())
     {
-        current = ahead >= 0 ? (ahead + 1) % static_cast<int>(kLoaderSets) : 0;
+        dropAhead();
+        current = (lastSet_ + 1) % static_cast<int>(kLoaderSets);
         uint64_t lastJob = 0;
         {
             std::lock_guard<std::mutex> lock(handOverLock_);
@@ -1642,46 +1665,53 @@ void CallRun::startGunzipPrefetch()
         waitForHandOver(lastJob);                   // (no segment may still point into that loader's records on the device)
         gunzipSet_[current]->edgesOnly = edgesOnly_ && deviceWalk_;     // (with the window loop back on the host every record is wanted here)
         gunzipSet_[current]->start(items, roi.seqName);
+        lastSet_ = current;
         ++roundsOnDemand_;
     }
     if (current >= 0)
         gunzip_ = gunzipSet_[current].get();
-    // 2. the round to come, guessed: everybody who still has data reads, from the border at which this round's readers stop
+    // 2. the rounds to come, guessed: everybody who still has data reads, from the border at which this round's readers stop
     //    (the next round begins at the first window at or beyond it: the same index region unless the border lies within a
-    //    window's length of the region's end) and one slot further. Its first chunks are inflated and parsed while this round is
-    //    decoded and replayed; the rest follows as that round releases the buffers. A wrong guess costs device time, never a
-    //    result (adopt()).
+    //    window's length of the region's end) and one slot further -- and the round after that one more slot on. Their chunks are
+    //    inflated and parsed while this round is decoded and replayed. A wrong guess costs device time, never a result (adopt()).
     if (!loaderAhead_ || current < 0 || farthest < 0 || nearestBorder <= roi.beginPos)
-        return;
-    const int64_t nextBegin = nearestBorder;
-    if (nextBegin >= roi.endPos)
-        return;
-    const int64_t step = nextBegin - roi.beginPos;
-    const int64_t nextEnd = std::min<int64_t>(std::min<int64_t>(farthest + step, static_cast<int64_t>(roi.endPos) + 256), 0x7fffffff);
-    std::vector<GunzipPrefetch::Item> guess;
-    for (unsigned i = 0; i < p_.sampleNum; ++i)
     {
-        if (finishedFiles_[i])
-            continue;
-        GunzipPrefetch::Item it;
-        it.sample = i;
-        it.parse = p_.rgs[i].size() == 1;
-        it.innerOffset = innerOffsetOf(i);
-        it.beginPos = static_cast<int32_t>(nextBegin);
-        it.firstRegion = static_cast<uint32_t>(nextBegin) / p_.indexRegionSizes[p_.representativeContigs ? 0 : i];
-        it.endPos = static_cast<int32_t>(nextEnd);
-        setKeepLimits(it, i);
-        if (it.endPos >= it.beginPos)
-            guess.push_back(it);
-    }
-    if (guess.empty())
+        dropAhead();
         return;
-    // (started once this round's loader has all its chunks through: the blocks this round still waits for go first --
-    // startLoaderAhead(), called batch by batch)
-    pendingGuess_ = std::move(guess);
-    pendingGuessContig_ = roi.seqName;
-    pendingGuessSet_ = (current + 1) % static_cast<int>(kLoaderSets);
-    guessedBegin_ = nextBegin;
+    }
+    // (a round is a slot long: the borders lie a window buffer apart -- this round may be shorter, a region begins where it begins)
+    const int64_t slotLen = profile_->starts[p_.rgs[items[0].sample][0]].numWindows;
+    for (size_t k = aheadLoaders_.size() + pendingGuesses_.size(); k < aheadDepth_; ++k)
+    {
+        // (round k + 1 from here)
+        const int64_t nextBegin = nearestBorder + static_cast<int64_t>(k) * slotLen;
+        if (nextBegin >= roi.endPos)
+            break;
+        const int64_t nextEnd = std::min<int64_t>(std::min<int64_t>(nextBegin + slotLen, static_cast<int64_t>(roi.endPos)) + 256, 0x7fffffff);
+        Guess g;
+        for (unsigned i = 0; i < p_.sampleNum; ++i)
+        {
+            if (finishedFiles_[i])
+                continue;
+            GunzipPrefetch::Item it;
+            it.sample = i;
+            it.parse = p_.rgs[i].size() == 1;
+            it.innerOffset = innerOffsetOf(i);
+            it.beginPos = static_cast<int32_t>(nextBegin);
+            it.firstRegion = static_cast<uint32_t>(nextBegin) / p_.indexRegionSizes[p_.representativeContigs ? 0 : i];
+            it.endPos = static_cast<int32_t>(nextEnd);
+            setKeepLimits(it, i);
+            if (it.endPos >= it.beginPos)
+                g.items.push_back(it);
+        }
+        if (g.items.empty())
+            break;
+        g.contig = roi.seqName;
+        g.begin = nextBegin;
+        pendingGuesses_.push_back(std::move(g));
+    }
+    // (started once the loader before it has gathered its chunks, and its set is free: startLoaderAhead(), called batch by batch
+    // and by whoever makes one of the two come true)
     startLoaderAhead();
 }
 
@@ -1719,6 +1749,8 @@ void CallRun::createLoaders()
     }
     const char * ahead = getenv("POPDEL_LOADER_AHEAD");
     loaderAhead_ = !(ahead && ahead[0] == '0');
+    if (const char * depth = getenv("POPDEL_LOADER_DEPTH"))
+        aheadDepth_ = std::min<size_t>(std::max(1, atoi(depth)), kLoaderSets - 1);
 }
 
 void CallRun::startLoaderAhead()
@@ -1735,14 +1767,28 @@ void CallRun::startLoaderAhead()
     // on the queues they share --, but the rounds after it are the shorter for it: 0.0255 / 0.0249 s per warmed round with n = 1,
     // 0.0272 / 0.0267 with 0, 0.0248 / 0.0241 without a limit, which stays the default)
     static const size_t outstandingAllowed = [] { const char * e = getenv("POPDEL_LOADER_OUTSTANDING"); return e ? static_cast<size_t>(atoi(e)) : ~static_cast<size_t>(0); }();
-    if (pendingGuess_.empty() || !gunzip_ || !(overlap ? gunzip_->allGathered() && gunzip_->outstanding() <= outstandingAllowed : gunzip_->allDone()))
-        return;
-    if (!loaderHandedOver(pendingGuessSet_))            // (a segment still points into that loader's records on the device: at the next call)
-        return;
-    gunzipAhead_ = pendingGuessSet_;
-    gunzipSet_[gunzipAhead_]->edgesOnly = edgesOnly_ && deviceWalk_;
-    gunzipSet_[gunzipAhead_]->start(std::move(pendingGuess_), pendingGuessContig_);
-    pendingGuess_.clear();
+    while (!pendingGuesses_.empty() && gunzip_)
+    {
+        // the loader before it: the one started last
+        GunzipPrefetch * before = lastSet_ >= 0 ? gunzipSet_[lastSet_].get() : nullptr;
+        if (before && !(overlap ? before->allGathered() && before->outstanding() <= outstandingAllowed : before->allDone()))
+            return;
+        // its set: the next in turn -- not the running round's, not one that is ahead, and no segment may point into its records any more
+        const int set = (lastSet_ + 1) % static_cast<int>(kLoaderSets);
+        if (gunzipSet_[set].get() == gunzip_)
+            return;
+        for (const AheadLoader & a : aheadLoaders_)
+            if (a.set == set)
+                return;
+        if (!loaderHandedOver(set))
+            return;
+        Guess g = std::move(pendingGuesses_.front());
+        pendingGuesses_.pop_front();
+        gunzipSet_[set]->edgesOnly = edgesOnly_ && deviceWalk_;
+        gunzipSet_[set]->start(std::move(g.items), g.contig);
+        aheadLoaders_.push_back(AheadLoader{set, g.begin});
+        lastSet_ = set;
+    }
 }
 
 bool CallRun::checkAndSwitch(const std::vector<unsigned> & rg, unsigned beginPos, unsigned * border)
@@ -3892,6 +3938,10 @@ int runPopdelCall(int argc, const char ** argv, SegmentObserver * observer, bool
     try
     {
         const double t0 = PhaseClock::now();
+        // (the loaders of up to three rounds work on the device at once, nine streams beside the contexts': with the runtime's four
+        // hardware queues their copies and kernels queue behind each other -- 0.0231 -> 0.0208 s per warmed round of 4,000 samples with
+        // sixteen; set before the runtime starts, and only if the caller has not decided)
+        setenv("GPU_MAX_HW_QUEUES", "16", 0);
 #ifdef __GLIBC__
         // (the rounds allocate and free the same large arrays over and over: kept in the heap instead of mapped, faulted in and
         // unmapped every time -- 10,000 profiles x 2 Mb: 7.6 -> 6.0 of 17.9 CPU-seconds in the kernel, 0.082 -> 0.075 s per round
