@@ -1205,6 +1205,8 @@ private:
     std::deque<AheadLoader> aheadLoaders_;
     std::deque<Guess> pendingGuesses_;
     int lastSet_ = -1;                          // the set of the loader that was started last (the running round's or one ahead)
+    bool thirdSetUsed_ = false;                 // two rounds of lead have been taken once: every set is warm
+    int setsInTurn() const { return thirdSetUsed_ ? static_cast<int>(kLoaderSets) : 2; }    // (the third set stays cold until it is wanted)
     void dropAhead()                            // (a guess did not hold: what was extrapolated from it goes, too)
     {
         for (const AheadLoader & a : aheadLoaders_)
@@ -1656,7 +1658,7 @@ void CallRun::startGunzipPrefetch()
     if (current < 0 && !items.empty())
     {
         dropAhead();
-        current = (lastSet_ + 1) % static_cast<int>(kLoaderSets);
+        current = (lastSet_ + 1) % setsInTurn();
         uint64_t lastJob = 0;
         {
             std::lock_guard<std::mutex> lock(handOverLock_);
@@ -1681,12 +1683,17 @@ void CallRun::startGunzipPrefetch()
     }
     // (a round is a slot long: the borders lie a window buffer apart -- this round may be shorter, a region begins where it begins)
     const int64_t slotLen = profile_->starts[p_.rgs[items[0].sample][0]].numWindows;
-    for (size_t k = aheadLoaders_.size() + pendingGuesses_.size(); k < aheadDepth_; ++k)
+    // (the second round of lead takes the third loader set, whose first use costs what every set's first use costs -- descriptors,
+    // page-locked and device buffers: about a round at 50,000 samples. On a region with only a few rounds to go that is not earned
+    // back -- 50,000 profiles x 1 Mb, five rounds: 8.2 s with one round of lead, 11.1 with two --, so: only with eight rounds ahead)
+    const size_t depth = thirdSetUsed_ || (static_cast<int64_t>(roi.endPos) - nearestBorder) / std::max<int64_t>(slotLen, 1) >= 8 ? aheadDepth_ : 1;
+    for (size_t k = aheadLoaders_.size() + pendingGuesses_.size(); k < depth; ++k)
     {
         // (round k + 1 from here)
         const int64_t nextBegin = nearestBorder + static_cast<int64_t>(k) * slotLen;
         if (nextBegin >= roi.endPos)
             break;
+        thirdSetUsed_ = thirdSetUsed_ || k >= 1;
         const int64_t nextEnd = std::min<int64_t>(std::min<int64_t>(nextBegin + slotLen, static_cast<int64_t>(roi.endPos)) + 256, 0x7fffffff);
         Guess g;
         for (unsigned i = 0; i < p_.sampleNum; ++i)
@@ -1774,7 +1781,7 @@ void CallRun::startLoaderAhead()
         if (before && !(overlap ? before->allGathered() && before->outstanding() <= outstandingAllowed : before->allDone()))
             return;
         // its set: the next in turn -- not the running round's, not one that is ahead, and no segment may point into its records any more
-        const int set = (lastSet_ + 1) % static_cast<int>(kLoaderSets);
+        const int set = (lastSet_ + 1) % setsInTurn();
         if (gunzipSet_[set].get() == gunzip_)
             return;
         for (const AheadLoader & a : aheadLoaders_)
