@@ -141,3 +141,25 @@ def test_device_loader_on_the_mixed_cohort(built, mixed_cohort, tmp_path, opts):
     assert new == old and new.count("\n") > 25
     line = [l for l in log.splitlines() if "loader: profile blocks inflated on the device" in l]
     assert line and int(line[0].split("for ")[1].split()[0]) >= 12, log[-400:]
+
+
+def test_option_files_mean_what_their_options_mean(built, mixed_cohort, tmp_path):
+    """Two checks of the option plumbing that need no second implementation: regions from a file (-R) against the same regions
+    given with -r, and a coverage file (-A) that gives every read group the value against -a with that value -- same bytes."""
+    from popdel_amd import synth
+    rois = os.path.join(mixed_cohort, "rois.txt")
+    a = run(POPDEL_BIN, mixed_cohort, str(tmp_path / "file.vcf"), ["-R", rois, "-n"])
+    b = run(POPDEL_BIN, mixed_cohort, str(tmp_path / "opts.vcf"), ["-r", "chr20:1050001-1150000", "-r", "chr20:1240001-1290000", "-n"])
+    assert a == b and a.count("\n") > 25
+    # every read group of the cohort at 15: the three-read-group samples by their read groups' names
+    names = []
+    for k in range(12):
+        names += ["M%02d_RG%d" % (k, j) for j in range(3)] if k in (3, 8) else ["M%02d" % k]
+    cov = str(tmp_path / "all15.txt")
+    with open(cov, "w") as fh:
+        fh.write("".join("%s 15\n" % n for n in names))
+    a = run(POPDEL_BIN, mixed_cohort, str(tmp_path / "covfile.vcf"), ["-r", "chr20:1000000-1400000", "-A", cov, "-n"])
+    b = run(POPDEL_BIN, mixed_cohort, str(tmp_path / "covopt.vcf"), ["-r", "chr20:1000000-1400000", "-a", "15", "-n"])
+    assert a == b and a.count("\n") > 25
+    c = run(POPDEL_BIN, mixed_cohort, str(tmp_path / "covdefault.vcf"), ["-r", "chr20:1000000-1400000", "-n"])
+    assert c != a                                   # (the value does something on this cohort)
