@@ -1116,11 +1116,11 @@ private:
     // lock: the main thread may be waiting for them while it holds it, and looks itself when it lets go).
     std::recursive_mutex aheadLock_;
     bool aheadClosed_ = false;                  // the run is being taken down: nobody starts a loader any more
-    void startLoaderAheadFromOutside()
+    void startLoaderAheadFromOutside(const GunzipPrefetch * caller = nullptr)
     {
         std::unique_lock<std::recursive_mutex> lock(aheadLock_, std::try_to_lock);
         if (lock.owns_lock() && !aheadClosed_)
-            startLoaderAhead();
+            startLoaderAhead(caller);
     }
     bool processSegmentCode(unsigned i, unsigned code);
     void processSegment();
@@ -1221,7 +1221,7 @@ private:
     // parsed blocks end before the point at which the round's reader stops
     mutable std::atomic<uint64_t> hostDecodes_[3] = {};     // ([2]: a window at an end of the round whose records had not been copied back)
     void startGunzipPrefetch();
-    void startLoaderAhead();
+    void startLoaderAhead(const GunzipPrefetch * caller = nullptr);    // caller: the loader whose thread asks (it cannot be started over from there)
     void createLoaders();
     unsigned deviceSegments_ = 0, hostSegments_ = 0;
     void leaveDeviceWalk(bool tablesAboutToGo = false);
@@ -1730,7 +1730,7 @@ void CallRun::createLoaders()
     for (auto & g : gunzipSet_)
     {
         g.reset(new GunzipPrefetch(p_, gunzipDevices_, first));
-        g->onProgress = [this] { startLoaderAheadFromOutside(); };
+        g->onProgress = [this, self = g.get()] { startLoaderAheadFromOutside(self); };
         first += GunzipPrefetch::kInflaters;
         // (the parsed blocks summarised for the tables: whenever the tables can make use of it -- light end tables, which go with
         // the device's window loop; a block spans one index region, its pairs end a little further on)
@@ -1760,7 +1760,7 @@ void CallRun::createLoaders()
         aheadDepth_ = std::min<size_t>(std::max(1, atoi(depth)), kLoaderSets - 1);
 }
 
-void CallRun::startLoaderAhead()
+void CallRun::startLoaderAhead(const GunzipPrefetch * caller)
 {
     // (not before the running round's loader is through: started at once, the two loaders share the device and the round
     // that is waited for gets its blocks later -- 0.064 instead of 0.061 s per warmed round)
@@ -1782,8 +1782,8 @@ void CallRun::startLoaderAhead()
             return;
         // its set: the next in turn -- not the running round's, not one that is ahead, and no segment may point into its records any more
         const int set = (lastSet_ + 1) % setsInTurn();
-        if (gunzipSet_[set].get() == gunzip_)
-            return;
+        if (gunzipSet_[set].get() == gunzip_ || gunzipSet_[set].get() == caller)
+            return;                                 // (caller: a thread of that very loader, late with its last report -- start() would join it)
         for (const AheadLoader & a : aheadLoaders_)
             if (a.set == set)
                 return;
